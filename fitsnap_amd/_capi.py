@@ -1,0 +1,249 @@
+"""ctypes binding of libfsnap_hip.so (C ABI: include/fsnap_hip.h).
+
+This is the ONLY way the Python host layer reaches the GPU.  There is no CPU fallback:
+if the library is missing it is built with hipcc; if that is impossible, or no gfx950
+device is present when a context is requested, a loud exception is raised.
+
+ctypes releases the GIL for the duration of each foreign call (reference threading model:
+single Python thread per rank).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int64, c_uint8, c_void_p
+
+import numpy as np
+
+from . import build as _build
+
+# status codes (include/fsnap_hip.h)
+OK = 0
+E_ARG, E_HIP, E_STATE, E_NOMEM = -1, -2, -3, -4
+NUM_NOT_SPD, NUM_SINGULAR, NUM_NONFINITE = 1, 2, 3
+SOLVE_CHOL, SOLVE_LSTSQ, SOLVE_RIDGE, SOLVE_RIDGE_INV = 0, 1, 2, 3
+
+_P_D = POINTER(c_double)
+_P_U8 = POINTER(c_uint8)
+
+# name -> (restype, argtypes); the "exports every declared symbol" test walks this table
+SIGNATURES = {
+    "fsnap_version": (c_int, []),
+    "fsnap_device_count": (c_int, [POINTER(c_int)]),
+    "fsnap_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "fsnap_ctx_destroy": (c_int, [c_void_p]),
+    "fsnap_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
+    "fsnap_set_option": (c_int, [c_void_p, c_char_p, c_int64]),
+    "fsnap_last_error": (c_char_p, [c_void_p]),
+    "fsnap_upload_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "fsnap_bind_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "fsnap_set_weights": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "fsnap_bind_weights": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "fsnap_normal_eq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fsnap_normal_eq_async": (c_int, [c_void_p, c_void_p]),
+    "fsnap_weight_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "fsnap_weight_rows_device": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "fsnap_predict": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fsnap_solve": (c_int, [c_int, c_double, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int), POINTER(c_double)]),
+    "fsnap_timing": (c_int, [c_void_p, _P_D, c_int]),
+    "fsnap_launch_info": (c_int, [c_void_p, POINTER(c_int64), c_int]),
+}
+
+_lib = None
+
+
+class FsnapError(RuntimeError):
+    """Runtime (HIP / state / argument) failure reported by libfsnap_hip."""
+
+
+def load_library(build_if_missing: bool = True):
+    """Load (building first if needed) libfsnap_hip.so and attach prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.lib_path()
+    if build_if_missing:
+        path = _build.build_library()
+    if not os.path.exists(path):
+        raise FsnapError(f"libfsnap_hip.so not found at {path}; run `python -m fitsnap_amd.build`")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = symbol missing = broken build
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(arr):
+    return None if arr is None else arr.ctypes.data_as(c_void_p)
+
+
+def _f64(x, name):
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError(f"{name} must be C-contiguous")
+    return a
+
+
+def raise_status(rc: int, msg: str):
+    """Map a non-zero status to the exception class the reference would raise
+    (np.linalg.LinAlgError / ValueError / MemoryError)."""
+    if rc == OK:
+        return
+    if rc in (NUM_NOT_SPD, NUM_SINGULAR):
+        raise np.linalg.LinAlgError(msg or ("matrix is not positive definite" if rc == NUM_NOT_SPD else "Singular matrix"))
+    if rc == NUM_NONFINITE:
+        raise ValueError(msg or "array must not contain infs or NaNs")
+    if rc == E_NOMEM:
+        raise MemoryError(msg or "device allocation failed")
+    if rc == E_ARG:
+        raise ValueError(msg or "bad argument")
+    raise FsnapError(f"libfsnap_hip status {rc}: {msg}")
+
+
+def device_count() -> int:
+    lib = load_library()
+    n = c_int(0)
+    rc = lib.fsnap_device_count(byref(n))
+    return n.value if rc == OK else 0
+
+
+def solve(kind: int, param: float, G: np.ndarray, c: np.ndarray):
+    """K x K back-solve on the host side of the library (no GPU needed).
+    Returns (beta, rank, rcond_estimate)."""
+    lib = load_library()
+    G = _f64(G, "G")
+    c = _f64(c, "c")
+    K = c.shape[0]
+    if G.shape != (K, K):
+        raise ValueError("G must be K x K")
+    beta = np.empty(K, dtype=np.float64)
+    rank = c_int(0)
+    rce = c_double(0.0)
+    rc = lib.fsnap_solve(int(kind), float(param), K, _ptr(G), _ptr(c), _ptr(beta), byref(rank), byref(rce))
+    raise_status(rc, "")
+    return beta, rank.value, rce.value
+
+
+class HipContext:
+    """One GPU's resident copy of (A, b, w, mask) and the kernels that run on it."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        self._h = c_void_p(None)
+        rc = self._lib.fsnap_ctx_create(int(device), byref(self._h))
+        if rc != OK:
+            msg = (self._lib.fsnap_last_error(None) or b"").decode()
+            raise FsnapError(f"cannot create a gfx950 context on device {device}: {msg} "
+                             "(the HIP path is mandatory; there is no CPU fallback)")
+        self.device = device
+        self.m = 0
+        self.K = 0
+        self._keep = []  # keep numpy buffers alive across async copies
+
+    # -- plumbing --------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != OK:
+            raise_status(rc, (self._lib.fsnap_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.fsnap_ctx_destroy(self._h)
+            self._h = c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, stream_handle):
+        self._check(self._lib.fsnap_ctx_set_stream(self._h, c_void_p(stream_handle or None)))
+
+    def set_option(self, key: str, value: int):
+        self._check(self._lib.fsnap_set_option(self._h, key.encode(), int(value)))
+
+    # -- rows / weights ----------------------------------------------------------------
+    def upload_rows(self, A: np.ndarray, b: np.ndarray):
+        A = np.asarray(A)
+        if A.dtype != np.float64 or A.ndim != 2:
+            A = np.ascontiguousarray(A, dtype=np.float64)
+            if A.ndim != 2:
+                raise ValueError("A must be 2-D")
+        if A.strides[1] != 8 or A.strides[0] % 8 or A.strides[0] < A.shape[1] * 8:
+            A = np.ascontiguousarray(A)
+        b = _f64(b, "b")
+        m, K = A.shape
+        if b.shape != (m,):
+            raise ValueError(f"b has shape {b.shape}, expected ({m},)")
+        lda = A.strides[0] // 8
+        self._check(self._lib.fsnap_upload_rows(self._h, _ptr(A), m, K, lda, _ptr(b)))
+        self.m, self.K = m, K
+
+    def bind_rows(self, dA_ptr: int, m: int, K: int, lda: int, db_ptr: int):
+        self._check(self._lib.fsnap_bind_rows(self._h, c_void_p(dA_ptr), m, K, lda, c_void_p(db_ptr)))
+        self.m, self.K = m, K
+
+    def set_weights(self, w: np.ndarray, mask=None):
+        w = _f64(w, "w")
+        if w.shape != (self.m,):
+            raise ValueError(f"w has shape {w.shape}, expected ({self.m},)")
+        mk = None
+        if mask is not None:
+            mk = np.ascontiguousarray(mask, dtype=np.uint8)
+            if mk.shape != (self.m,):
+                raise ValueError(f"mask has shape {mk.shape}, expected ({self.m},)")
+        self._check(self._lib.fsnap_set_weights(self._h, _ptr(w), _ptr(mk)))
+
+    def bind_weights(self, dw_ptr: int, dmask_ptr: int = 0):
+        self._check(self._lib.fsnap_bind_weights(self._h, c_void_p(dw_ptr), c_void_p(dmask_ptr or None)))
+
+    # -- hot path ----------------------------------------------------------------------
+    def normal_eq(self):
+        """Returns (G, c, scalars) on the host; scalars = [bw.bw, sum(bw), n_train]."""
+        K = self.K
+        G = np.empty((K, K))
+        c = np.empty(K)
+        s = np.empty(3)
+        self._check(self._lib.fsnap_normal_eq(self._h, _ptr(G), _ptr(c), _ptr(s)))
+        return G, c, s
+
+    def normal_eq_async(self, d_packed_ptr: int):
+        self._check(self._lib.fsnap_normal_eq_async(self._h, c_void_p(d_packed_ptr)))
+
+    def weight_rows(self):
+        aw = np.empty((self.m, self.K))
+        bw = np.empty(self.m)
+        self._check(self._lib.fsnap_weight_rows(self._h, _ptr(aw), self.K, _ptr(bw)))
+        return aw, bw
+
+    def weight_rows_device(self, d_aw_ptr: int, ldaw: int, d_bw_ptr: int):
+        self._check(self._lib.fsnap_weight_rows_device(self._h, c_void_p(d_aw_ptr), ldaw, c_void_p(d_bw_ptr)))
+
+    def predict(self, beta, want_preds=True, want_sse=False):
+        beta = _f64(beta, "beta")
+        if beta.shape != (self.K,):
+            raise ValueError(f"beta has shape {beta.shape}, expected ({self.K},)")
+        preds = np.empty(self.m) if want_preds else None
+        sse = c_double(0.0)
+        self._check(self._lib.fsnap_predict(self._h, _ptr(beta), _ptr(preds), byref(sse) if want_sse else None))
+        return preds, (sse.value if want_sse else None)
+
+    # -- measurement -------------------------------------------------------------------
+    def timing(self):
+        ms = (c_double * 8)()
+        self._check(self._lib.fsnap_timing(self._h, ms, 8))
+        return {"syrk_ms": ms[0], "reduce_ms": ms[1], "upload_ms": ms[2], "weight_ms": ms[3], "predict_ms": ms[4]}
+
+    def launch_info(self):
+        info = (c_int64 * 8)()
+        self._check(self._lib.fsnap_launch_info(self._h, info, 8))
+        return {"workgroups": info[0], "threads": info[1], "chunks_per_wave": info[2], "NB": info[3],
+                "split": info[4], "compute_units": info[5]}

@@ -1,0 +1,89 @@
+"""Build libfsnap_hip.so (gfx950 only) in-tree with hipcc.
+
+The library is the C-ABI boundary declared in include/fsnap_hip.h.  It is built
+explicitly (`hipcc --offload-arch=gfx950 -shared -fPIC`) into fitsnap_amd/_lib/ so that
+the artefact travels with the source tree to the GPU box; nothing is JIT-compiled into a
+user cache.  hipcc cross-compiles without a GPU.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "_lib")
+LIBNAME = "libfsnap_hip.so"
+SOURCES = ["fsnap_kernels.hip", "fsnap_capi.cpp", "fsnap_solve.cpp"]
+HEADERS = ["fsnap_kernels.h", os.path.join("..", "..", "include", "fsnap_hip.h")]
+ARCH = "gfx950"
+
+
+def lib_path() -> str:
+    return os.path.join(LIBDIR, LIBNAME)
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libfsnap_hip.so cannot be built")
+    return exe
+
+
+def _source_digest() -> str:
+    h = hashlib.sha256()
+    for name in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile the three translation units and link the shared library. Returns its path."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    out = lib_path()
+    stamp = out + ".sha256"
+    digest = _source_digest()
+    if not force and os.path.exists(out) and os.path.exists(stamp):
+        with open(stamp) as f:
+            if f.read().strip() == digest:
+                return out
+    hipcc = _hipcc()
+    objs = []
+    common = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(HERE, "..", "include")]
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc, *common]
+        if src.endswith(".cpp"):
+            cmd += ["-x", "hip"] if src == "fsnap_capi.cpp" else []
+        cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    for src, p in procs:
+        log, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{log}")
+        if verbose and log.strip():
+            print(log, file=sys.stderr)
+    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out, *objs, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    for obj in objs:
+        try:
+            os.remove(obj)
+        except OSError:
+            pass
+    with open(stamp, "w") as f:
+        f.write(digest + "\n")
+    return out
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

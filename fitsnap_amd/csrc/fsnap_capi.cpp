@@ -1,0 +1,507 @@
+// fsnap_capi.cpp — the C-ABI layer of libfsnap_hip.so (declared in include/fsnap_hip.h).
+// Owns the device-resident copy of the reference's shared arrays a / b / w
+// (fitsnap3lib/parallel_tools.py:352-389, calculator.py:287-289), the training mask
+// derived from fitsnap_dict['Testing'] (svd.py:35-40), launch geometry, HIP-event
+// timing, and error text.  All compute is in fsnap_kernels.hip; the K x K solve in
+// fsnap_solve.cpp.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/fsnap_hip.h"
+#include "fsnap_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error = "";
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    bool ensure(size_t n) {
+        if (n <= bytes && p) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        if (hipMalloc(&p, n) != hipSuccess) {
+            p = nullptr;
+            return false;
+        }
+        bytes = n;
+        return true;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+}  // namespace
+
+struct fsnap_ctx {
+    int device = 0;
+    int num_cu = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[10] = {};
+    std::string err;
+
+    // rows
+    const double* dA = nullptr;
+    const double* db = nullptr;
+    int64_t m = 0, K = 0, lda = 0;
+    DevBuf ownA, ownb;
+    // weights
+    const double* dw = nullptr;
+    const unsigned char* dmask = nullptr;
+    DevBuf ownw, ownmask, ones;
+    // workspaces
+    DevBuf part, cpart, spart, packed, beta, preds, sse, aw, bw;
+    // options
+    int opt_split = 0;        // 0 = auto
+    int opt_nt = 1;
+    int opt_nblocks = 0;      // 0 = auto
+    // timing flags
+    bool t_syrk = false, t_upload = false, t_weight = false, t_predict = false;
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        g_last_error = buf;
+        return code;
+    }
+    int hipfail(hipError_t e, const char* what) {
+        return fail(e == hipErrorOutOfMemory ? FSNAP_E_NOMEM : FSNAP_E_HIP, "%s: %s", what, hipGetErrorString(e));
+    }
+};
+
+namespace {
+
+#define FSNAP_HIP(call, what)                                \
+    do {                                                     \
+        hipError_t _e = (call);                              \
+        if (_e != hipSuccess) return ctx->hipfail(_e, what); \
+    } while (0)
+
+struct Geometry {
+    int nblocks, split, threads;
+    int64_t cpw;
+    int NB;
+};
+
+int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
+    const int K = (int)ctx->K;
+    const int64_t m = ctx->m;
+    g->NB = fsnap::syrk_num_blocks(K);
+    int split = ctx->opt_split ? ctx->opt_split : fsnap::syrk_default_split(K);
+    if (split == 2 && g->NB < 6) split = 1;
+    if (split == 1 && g->NB > 6) split = 2;
+    g->split = split;
+    g->threads = 256 * split;
+    const int64_t nchunks = (m + 3) / 4;
+    // workgroups resident per CU: waves per SIMD the register budget admits / split
+    int wg_per_cu = fsnap::syrk_waves_per_simd(K, split) / split;
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    int64_t nblocks = ctx->opt_nblocks > 0 ? ctx->opt_nblocks : (int64_t)ctx->num_cu * wg_per_cu;
+    // keep >= 8 chunks (32 rows) per row-wave so the pipeline prologue amortises
+    const int64_t max_blocks = (nchunks + 31) / 32;
+    if (nblocks > max_blocks) nblocks = max_blocks;
+    if (nblocks < 1) nblocks = 1;
+    int64_t cpw = (nchunks + nblocks * 4 - 1) / (nblocks * 4);
+    if (cpw < 1) cpw = 1;
+    // 32-bit buffer offsets: a row-wave's byte range must stay below 4 GiB
+    const int64_t max_cpw = ((int64_t)0xFFFFFF00 - 64) / (ctx->lda * 32);
+    if (max_cpw < 1) return ctx->fail(FSNAP_E_ARG, "leading dimension %lld too large", (long long)ctx->lda);
+    if (cpw > max_cpw) cpw = max_cpw;
+    nblocks = (nchunks + cpw * 4 - 1) / (cpw * 4);
+    if (nblocks < 1) nblocks = 1;
+    if (nblocks > 0x7FFFFFF) return ctx->fail(FSNAP_E_ARG, "too many workgroups");
+    g->nblocks = (int)nblocks;
+    g->cpw = cpw;
+    return FSNAP_OK;
+}
+
+int check_rows(fsnap_ctx* ctx) {
+    if (!ctx->dA || !ctx->db || ctx->m <= 0) return ctx->fail(FSNAP_E_STATE, "no rows: call fsnap_upload_rows/fsnap_bind_rows first");
+    return FSNAP_OK;
+}
+
+int check_weights(fsnap_ctx* ctx) {
+    if (!ctx->dw) return ctx->fail(FSNAP_E_STATE, "no weights: call fsnap_set_weights/fsnap_bind_weights first");
+    return FSNAP_OK;
+}
+
+int ensure_ones(fsnap_ctx* ctx) {
+    const size_t need = (size_t)ctx->m;
+    if (ctx->ones.p && ctx->ones.bytes >= need) return FSNAP_OK;
+    if (!ctx->ones.ensure(need)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(mask) failed");
+    FSNAP_HIP(hipMemsetAsync(ctx->ones.p, 1, need, ctx->stream), "hipMemsetAsync(mask)");
+    return FSNAP_OK;
+}
+
+int launch_normal_eq(fsnap_ctx* ctx, double* d_packed) {
+    int rc;
+    if ((rc = check_rows(ctx)) || (rc = check_weights(ctx))) return rc;
+    if (ctx->K > 128)
+        return ctx->fail(FSNAP_E_ARG, "K = %lld > 128 is not supported by the wave-triangle SYRK kernel yet", (long long)ctx->K);
+    Geometry g;
+    if ((rc = plan_geometry(ctx, &g))) return rc;
+    const unsigned char* mask = ctx->dmask;
+    if (!mask) {
+        if ((rc = ensure_ones(ctx))) return rc;
+        mask = (const unsigned char*)ctx->ones.p;
+    }
+    const int NT = g.NB * (g.NB + 1) / 2;
+    if (!ctx->part.ensure((size_t)g.nblocks * NT * 256 * sizeof(double)) ||
+        !ctx->cpart.ensure((size_t)g.nblocks * 4 * g.NB * 16 * sizeof(double)) ||
+        !ctx->spart.ensure((size_t)g.nblocks * 4 * 4 * sizeof(double)))
+        return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(partials) failed");
+    fsnap::SyrkArgs a;
+    a.A = ctx->dA;
+    a.lda = ctx->lda;
+    a.b = ctx->db;
+    a.w = ctx->dw;
+    a.mask = mask;
+    a.m = ctx->m;
+    a.K = (int)ctx->K;
+    a.nblocks = g.nblocks;
+    a.split = g.split;
+    a.chunks_per_wave = g.cpw;
+    a.nontemporal = ctx->opt_nt != 0;
+    a.part = (double*)ctx->part.p;
+    a.cpart = (double*)ctx->cpart.p;
+    a.spart = (double*)ctx->spart.p;
+    FSNAP_HIP(hipEventRecord(ctx->ev[0], ctx->stream), "hipEventRecord");
+    FSNAP_HIP(fsnap::launch_syrk(a, ctx->stream), "launch fsnap_syrk_wave");
+    FSNAP_HIP(hipEventRecord(ctx->ev[1], ctx->stream), "hipEventRecord");
+    FSNAP_HIP(fsnap::launch_reduce(a.part, a.cpart, a.spart, g.nblocks, a.K, d_packed, ctx->stream),
+              "launch fsnap_reduce_partials");
+    FSNAP_HIP(hipEventRecord(ctx->ev[2], ctx->stream), "hipEventRecord");
+    ctx->t_syrk = true;
+    return FSNAP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fsnap_version(void) { return 100; }
+
+int fsnap_device_count(int* count) {
+    if (!count) return FSNAP_E_ARG;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        g_last_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+        *count = 0;
+        return FSNAP_E_HIP;
+    }
+    *count = n;
+    return FSNAP_OK;
+}
+
+const char* fsnap_last_error(const fsnap_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int fsnap_ctx_create(int device, fsnap_ctx** out) {
+    if (!out) return FSNAP_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_last_error = std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return FSNAP_E_HIP;
+    }
+    if (device < 0 || device >= n) {
+        g_last_error = "device index out of range";
+        return FSNAP_E_ARG;
+    }
+    fsnap_ctx* ctx = new (std::nothrow) fsnap_ctx();
+    if (!ctx) return FSNAP_E_NOMEM;
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        g_last_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        delete ctx;
+        return FSNAP_E_HIP;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            g_last_error = std::string("libfsnap_hip is built for gfx950 (MI355X) only; device is ") + prop.gcnArchName;
+            delete ctx;
+            return FSNAP_E_HIP;
+        }
+    }
+    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_last_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+        delete ctx;
+        return FSNAP_E_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    for (auto& ev : ctx->ev) {
+        if ((e = hipEventCreate(&ev)) != hipSuccess) {
+            g_last_error = std::string("hipEventCreate: ") + hipGetErrorString(e);
+            fsnap_ctx_destroy(ctx);
+            return FSNAP_E_HIP;
+        }
+    }
+    *out = ctx;
+    return FSNAP_OK;
+}
+
+int fsnap_ctx_destroy(fsnap_ctx* ctx) {
+    if (!ctx) return FSNAP_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    DevBuf* bufs[] = {&ctx->ownA, &ctx->ownb, &ctx->ownw, &ctx->ownmask, &ctx->ones, &ctx->part, &ctx->cpart,
+                      &ctx->spart, &ctx->packed, &ctx->beta, &ctx->preds, &ctx->sse, &ctx->aw, &ctx->bw};
+    for (DevBuf* b : bufs) b->release();
+    for (auto& ev : ctx->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return FSNAP_OK;
+}
+
+int fsnap_ctx_set_stream(fsnap_ctx* ctx, void* hip_stream) {
+    if (!ctx) return FSNAP_E_ARG;
+    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return FSNAP_OK;
+}
+
+int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
+    if (!ctx || !key) return FSNAP_E_ARG;
+    if (!strcmp(key, "split")) {
+        if (value < 0 || value > 2) return ctx->fail(FSNAP_E_ARG, "split must be 0 (auto), 1 or 2");
+        ctx->opt_split = (int)value;
+    } else if (!strcmp(key, "nontemporal")) {
+        ctx->opt_nt = value != 0;
+    } else if (!strcmp(key, "nblocks")) {
+        if (value < 0 || value > (1 << 24)) return ctx->fail(FSNAP_E_ARG, "nblocks out of range");
+        ctx->opt_nblocks = (int)value;
+    } else {
+        return ctx->fail(FSNAP_E_ARG, "unknown option '%s'", key);
+    }
+    return FSNAP_OK;
+}
+
+int fsnap_upload_rows(fsnap_ctx* ctx, const double* A, int64_t m, int64_t K, int64_t lda, const double* b) {
+    if (!ctx) return FSNAP_E_ARG;
+    if (!A || !b || m <= 0 || K <= 0 || lda < K) return ctx->fail(FSNAP_E_ARG, "fsnap_upload_rows: bad argument");
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    // rows are stored densely (lda_dev = K) + 256 B of zeroed tail padding for the
+    // 16-byte over-read of the last row
+    const size_t abytes = (size_t)m * K * sizeof(double);
+    if (!ctx->ownA.ensure(abytes + 256) || !ctx->ownb.ensure((size_t)m * sizeof(double)))
+        return ctx->fail(FSNAP_E_NOMEM, "hipMalloc of %zu bytes for A failed", abytes);
+    FSNAP_HIP(hipEventRecord(ctx->ev[3], ctx->stream), "hipEventRecord");
+    FSNAP_HIP(hipMemsetAsync((char*)ctx->ownA.p + abytes, 0, 256, ctx->stream), "hipMemsetAsync");
+    if (lda == K) {
+        FSNAP_HIP(hipMemcpyAsync(ctx->ownA.p, A, abytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(A)");
+    } else {
+        FSNAP_HIP(hipMemcpy2DAsync(ctx->ownA.p, (size_t)K * 8, A, (size_t)lda * 8, (size_t)K * 8, (size_t)m,
+                                   hipMemcpyHostToDevice, ctx->stream),
+                  "hipMemcpy2D(A)");
+    }
+    FSNAP_HIP(hipMemcpyAsync(ctx->ownb.p, b, (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(b)");
+    FSNAP_HIP(hipEventRecord(ctx->ev[4], ctx->stream), "hipEventRecord");
+    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");  // host buffers may be reused now
+    ctx->t_upload = true;
+    ctx->dA = (const double*)ctx->ownA.p;
+    ctx->db = (const double*)ctx->ownb.p;
+    if (m != ctx->m) {  // weights / mask of a previous matrix no longer apply
+        ctx->dw = nullptr;
+        ctx->dmask = nullptr;
+        ctx->ones.release();
+    }
+    ctx->m = m;
+    ctx->K = K;
+    ctx->lda = K;
+    return FSNAP_OK;
+}
+
+int fsnap_bind_rows(fsnap_ctx* ctx, const double* dA, int64_t m, int64_t K, int64_t lda, const double* db) {
+    if (!ctx) return FSNAP_E_ARG;
+    if (!dA || !db || m <= 0 || K <= 0 || lda < K) return ctx->fail(FSNAP_E_ARG, "fsnap_bind_rows: bad argument");
+    if (m != ctx->m) {
+        ctx->dw = nullptr;
+        ctx->dmask = nullptr;
+        ctx->ones.release();
+    }
+    ctx->dA = dA;
+    ctx->db = db;
+    ctx->m = m;
+    ctx->K = K;
+    ctx->lda = lda;
+    return FSNAP_OK;
+}
+
+int fsnap_set_weights(fsnap_ctx* ctx, const double* w, const uint8_t* mask) {
+    if (!ctx) return FSNAP_E_ARG;
+    int rc;
+    if ((rc = check_rows(ctx))) return rc;
+    if (!w) return ctx->fail(FSNAP_E_ARG, "fsnap_set_weights: w is NULL");
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    const size_t m = (size_t)ctx->m;
+    if (!ctx->ownw.ensure(m * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(w) failed");
+    FSNAP_HIP(hipMemcpyAsync(ctx->ownw.p, w, m * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(w)");
+    ctx->dw = (const double*)ctx->ownw.p;
+    if (mask) {
+        if (!ctx->ownmask.ensure(m)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(mask) failed");
+        FSNAP_HIP(hipMemcpyAsync(ctx->ownmask.p, mask, m, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(mask)");
+        ctx->dmask = (const unsigned char*)ctx->ownmask.p;
+    } else {
+        ctx->dmask = nullptr;
+    }
+    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    return FSNAP_OK;
+}
+
+int fsnap_bind_weights(fsnap_ctx* ctx, const double* dw, const uint8_t* dmask) {
+    if (!ctx) return FSNAP_E_ARG;
+    int rc;
+    if ((rc = check_rows(ctx))) return rc;
+    if (!dw) return ctx->fail(FSNAP_E_ARG, "fsnap_bind_weights: dw is NULL");
+    ctx->dw = dw;
+    ctx->dmask = dmask;
+    return FSNAP_OK;
+}
+
+int fsnap_normal_eq_async(fsnap_ctx* ctx, double* d_packed) {
+    if (!ctx) return FSNAP_E_ARG;
+    if (!d_packed) return ctx->fail(FSNAP_E_ARG, "fsnap_normal_eq_async: d_packed is NULL");
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    return launch_normal_eq(ctx, d_packed);
+}
+
+int fsnap_normal_eq(fsnap_ctx* ctx, double* G, double* c, double* scalars) {
+    if (!ctx) return FSNAP_E_ARG;
+    int rc;
+    if ((rc = check_rows(ctx))) return rc;
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    const int64_t K = ctx->K;
+    if (!ctx->packed.ensure((size_t)FSNAP_PACKED_LEN(K) * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(packed) failed");
+    double* dp = (double*)ctx->packed.p;
+    if ((rc = launch_normal_eq(ctx, dp))) return rc;
+    if (G) FSNAP_HIP(hipMemcpyAsync(G, dp, (size_t)K * K * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(G)");
+    if (c) FSNAP_HIP(hipMemcpyAsync(c, dp + K * K, (size_t)K * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(c)");
+    if (scalars)
+        FSNAP_HIP(hipMemcpyAsync(scalars, dp + K * K + K, 3 * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(scalars)");
+    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    return FSNAP_OK;
+}
+
+int fsnap_weight_rows_device(fsnap_ctx* ctx, double* d_aw, int64_t ldaw, double* d_bw) {
+    if (!ctx) return FSNAP_E_ARG;
+    int rc;
+    if ((rc = check_rows(ctx)) || (rc = check_weights(ctx))) return rc;
+    if (!d_aw || !d_bw || ldaw < ctx->K) return ctx->fail(FSNAP_E_ARG, "fsnap_weight_rows: bad argument");
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    const unsigned char* mask = ctx->dmask;
+    if (!mask) {
+        if ((rc = ensure_ones(ctx))) return rc;
+        mask = (const unsigned char*)ctx->ones.p;
+    }
+    FSNAP_HIP(hipEventRecord(ctx->ev[5], ctx->stream), "hipEventRecord");
+    FSNAP_HIP(fsnap::launch_weight_rows(ctx->dA, ctx->lda, ctx->db, ctx->dw, mask, ctx->m, (int)ctx->K, d_aw, ldaw,
+                                        d_bw, ctx->stream),
+              "launch fsnap_weight_rows_k");
+    FSNAP_HIP(hipEventRecord(ctx->ev[6], ctx->stream), "hipEventRecord");
+    ctx->t_weight = true;
+    return FSNAP_OK;
+}
+
+int fsnap_weight_rows(fsnap_ctx* ctx, double* aw, int64_t ldaw, double* bw) {
+    if (!ctx) return FSNAP_E_ARG;
+    int rc;
+    if ((rc = check_rows(ctx))) return rc;
+    if (!aw || !bw || ldaw < ctx->K) return ctx->fail(FSNAP_E_ARG, "fsnap_weight_rows: bad argument");
+    const size_t m = (size_t)ctx->m, K = (size_t)ctx->K;
+    if (!ctx->aw.ensure(m * K * 8) || !ctx->bw.ensure(m * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(aw) failed");
+    if ((rc = fsnap_weight_rows_device(ctx, (double*)ctx->aw.p, (int64_t)K, (double*)ctx->bw.p))) return rc;
+    FSNAP_HIP(hipMemcpy2DAsync(aw, (size_t)ldaw * 8, ctx->aw.p, K * 8, K * 8, m, hipMemcpyDeviceToHost, ctx->stream),
+              "hipMemcpy2D(aw)");
+    FSNAP_HIP(hipMemcpyAsync(bw, ctx->bw.p, m * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(bw)");
+    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    return FSNAP_OK;
+}
+
+int fsnap_predict(fsnap_ctx* ctx, const double* beta, double* preds, double* sse) {
+    if (!ctx) return FSNAP_E_ARG;
+    int rc;
+    if ((rc = check_rows(ctx))) return rc;
+    if (!beta) return ctx->fail(FSNAP_E_ARG, "fsnap_predict: beta is NULL");
+    if (sse && (rc = check_weights(ctx))) return rc;
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    const size_t m = (size_t)ctx->m, K = (size_t)ctx->K;
+    const int nb = fsnap::gemv_num_blocks(ctx->m);
+    if (!ctx->beta.ensure(K * 8) || (preds && !ctx->preds.ensure(m * 8)) || (sse && !ctx->sse.ensure((size_t)nb * 8)))
+        return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(preds) failed");
+    const unsigned char* mask = ctx->dmask;
+    if (sse && !mask) {
+        if ((rc = ensure_ones(ctx))) return rc;
+        mask = (const unsigned char*)ctx->ones.p;
+    }
+    FSNAP_HIP(hipMemcpyAsync(ctx->beta.p, beta, K * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(beta)");
+    FSNAP_HIP(hipEventRecord(ctx->ev[7], ctx->stream), "hipEventRecord");
+    FSNAP_HIP(fsnap::launch_gemv_rows(ctx->dA, ctx->lda, (const double*)ctx->beta.p, ctx->m, (int)ctx->K,
+                                      preds ? (double*)ctx->preds.p : nullptr, ctx->db, ctx->dw, mask,
+                                      sse ? (double*)ctx->sse.p : nullptr, ctx->stream),
+              "launch fsnap_gemv_rows_k");
+    FSNAP_HIP(hipEventRecord(ctx->ev[8], ctx->stream), "hipEventRecord");
+    ctx->t_predict = true;
+    if (preds) FSNAP_HIP(hipMemcpyAsync(preds, ctx->preds.p, m * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(preds)");
+    if (sse) {
+        std::string tmp;
+        tmp.resize((size_t)nb * 8);
+        FSNAP_HIP(hipMemcpyAsync(&tmp[0], ctx->sse.p, (size_t)nb * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(sse)");
+        FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+        const double* ps = (const double*)tmp.data();
+        long double s = 0.0L;  // fixed-order host sum of the per-workgroup partials
+        for (int i = 0; i < nb; ++i) s += ps[i];
+        *sse = (double)s;
+    } else {
+        FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    }
+    return FSNAP_OK;
+}
+
+int fsnap_timing(fsnap_ctx* ctx, double* ms, int n) {
+    if (!ctx || !ms || n < 0 || n > 8) return FSNAP_E_ARG;
+    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float t = 0.f;
+    if (ctx->t_syrk) {
+        if (hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]) == hipSuccess) out[0] = t;
+        if (hipEventElapsedTime(&t, ctx->ev[1], ctx->ev[2]) == hipSuccess) out[1] = t;
+    }
+    if (ctx->t_upload && hipEventElapsedTime(&t, ctx->ev[3], ctx->ev[4]) == hipSuccess) out[2] = t;
+    if (ctx->t_weight && hipEventElapsedTime(&t, ctx->ev[5], ctx->ev[6]) == hipSuccess) out[3] = t;
+    if (ctx->t_predict && hipEventElapsedTime(&t, ctx->ev[7], ctx->ev[8]) == hipSuccess) out[4] = t;
+    for (int i = 0; i < n; ++i) ms[i] = out[i];
+    return FSNAP_OK;
+}
+
+int fsnap_launch_info(fsnap_ctx* ctx, int64_t* info, int n) {
+    if (!ctx || !info || n < 0 || n > 8) return FSNAP_E_ARG;
+    int rc;
+    if ((rc = check_rows(ctx))) return rc;
+    if (ctx->K > 128) return ctx->fail(FSNAP_E_ARG, "K > 128 not supported yet");
+    Geometry g;
+    if ((rc = plan_geometry(ctx, &g))) return rc;
+    int64_t out[8] = {g.nblocks, g.threads, g.cpw, g.NB, g.split, ctx->num_cu, 0, 0};
+    for (int i = 0; i < n; ++i) info[i] = out[i];
+    return FSNAP_OK;
+}
+
+}  // extern "C"

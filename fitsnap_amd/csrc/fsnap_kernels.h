@@ -1,0 +1,41 @@
+// fsnap_kernels.h — internal C++ interface between the gfx950 kernels
+// (fsnap_kernels.hip) and the C-ABI layer (fsnap_capi.cpp).  Not part of the public
+// boundary; the public boundary is include/fsnap_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fsnap {
+
+struct SyrkArgs {
+    const double* A;            // device, row-major m x K, leading dimension lda
+    int64_t lda;
+    const double* b;            // device, m
+    const double* w;            // device, m
+    const unsigned char* mask;  // device, m (1 = training row) or nullptr
+    int64_t m;
+    int K;                      // <= 128 for the wave-triangle kernel
+    int nblocks;                // workgroups (4 row-waves each)
+    int split;                  // sub-waves per row-wave sharing the tile triangle (1 or 2)
+    int64_t chunks_per_wave;    // 4-row chunks per wave
+    bool nontemporal;           // use nt loads for the A stream
+    double* part;               // [nblocks][NT][4][64]
+    double* cpart;              // [nblocks*4][NB][16]
+    double* spart;              // [nblocks*4][4]
+};
+
+int syrk_num_blocks(int K);
+int syrk_default_split(int K);
+int syrk_waves_per_simd(int K, int split);
+hipError_t launch_syrk(const SyrkArgs& a, hipStream_t st);
+hipError_t launch_reduce(const double* part, const double* cpart, const double* spart, int nblocks, int K,
+                         double* out, hipStream_t st);
+hipError_t launch_weight_rows(const double* A, int64_t lda, const double* b, const double* w,
+                              const unsigned char* mask, int64_t m, int K, double* aw, int64_t ldaw, double* bw,
+                              hipStream_t st);
+int gemv_num_blocks(int64_t m);
+hipError_t launch_gemv_rows(const double* A, int64_t lda, const double* beta, int64_t m, int K, double* preds,
+                            const double* b, const double* w, const unsigned char* mask, double* sse_part,
+                            hipStream_t st);
+
+}  // namespace fsnap

@@ -1,0 +1,607 @@
+// fsnap_kernels.hip — hand-written gfx950 (MI355X / CDNA4) kernels for the FitSNAP
+// linear-fit hot path.  No CUDA compatibility layer, no dual paths: this file only
+// builds for gfx950 (wave64, v_mfma_f64_16x16x4_f64).
+//
+// What the kernels replace in the reference (file:line into FitSNAP/FitSNAP):
+//   * fitsnap3lib/solvers/svd.py:35-46, ridge.py:28-39, ard.py:18-20
+//       training mask -> aw = w[:,None]*A[training], bw = w*b[training]
+//   * fitsnap3lib/solvers/svd.py:50-51, ridge.py:41-43, ard.py:22-24,
+//     fitsnap3lib/lib/ridge_solver/regressor.py:11-12,
+//     examples/library/transpose_trick/example.py:234-240
+//       G = aw.T @ aw ,  c = aw.T @ bw      (the "transpose trick")
+//   * fitsnap3lib/solvers/solver.py:377   preds = a @ fit
+//
+// Data layout in HBM: A is row-major fp64, m rows x K columns, leading dimension
+// lda (doubles, lda >= K); b, w are fp64[m]; mask is uint8[m] (1 = training row; the
+// C-ABI layer substitutes an all-ones buffer when the caller passes no mask).  The allocation that holds A is padded by >= 256 B so that
+// the vector loads of the last row may over-read (they are select-zeroed).
+//
+// Kernel 1 (fsnap_syrk_wave): fused mask x weight x [A|b]^T [A|b].
+//   One wave owns a contiguous range of 4-row chunks and the WHOLE upper block
+//   triangle of G in registers: NB = ceil(K/16) column blocks, NB(NB+1)/2 MFMA tiles
+//   of 16x16 fp64 (4 doubles = 8 VGPRs per lane per tile; 36 tiles = 288 registers at
+//   K = 128, which fits the unified 512-entry VGPR/AGPR file at one wave per SIMD).
+//   v_mfma_f64_16x16x4_f64 takes A[i = lane&15][k = lane>>4] and B[k = lane>>4][j =
+//   lane&15]: with k = row-in-chunk and i/j = column-in-block, the SAME register
+//   (w * a[row][col]) is the A operand of tile (p, .) and the B operand of tile (., p),
+//   so a chunk costs NB/2 coalesced 16-byte loads per lane, NB multiplies, and
+//   NB(NB+1)/2 MFMAs: no LDS staging, no transposes, A is read from HBM exactly once.
+//   16-byte loads give each lane two ADJACENT columns; they are assigned to two
+//   different column blocks (even / odd columns of a 32-column group).  The resulting
+//   column permutation is undone for free by the reduce kernel's scatter.
+//   c = (wA)^T (wb), b^T W^2 b, sum(wb) and the training-row count ride along on the
+//   VALU (NB + 3 fp64 FMAs per chunk).
+// Kernel 2 (fsnap_reduce_partials): deterministic fixed-order sum of the per-wave
+//   partial triangles, un-permutes columns, mirrors to the lower triangle and writes
+//   the packed statistics buffer [G (K*K) | c (K) | bTb, sum_bw, n_train].
+//   No floating-point atomics anywhere: results are run-to-run bit-identical for a
+//   given (m, K, grid).
+// Kernel 3 (fsnap_weight_rows): stand-alone wavefront row-weighting (HBM-bound),
+//   for callers that need aw / bw materialised.
+// Kernel 4 (fsnap_gemv_rows): preds = A @ beta (+ optional weighted SSE), HBM-bound.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fsnap_kernels.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+__host__ __device__ constexpr int tri_index(int p, int q, int NB) {
+    // index of upper-triangle tile (p <= q) in row-major packed order
+    return p * NB - (p * (p - 1)) / 2 + (q - p);
+}
+
+// column of A held by element e (0..15) of column block bq.
+// Blocks 2j, 2j+1 (pair j) interleave the even / odd columns of [32j, 32j+32);
+// if NB is odd the last block is a plain 16-column block.
+__host__ __device__ inline int col_of(int bq, int e, int NB) {
+    if ((NB & 1) && bq == NB - 1) return 16 * bq + e;
+    return 32 * (bq >> 1) + 2 * e + (bq & 1);
+}
+
+template <int NB>
+struct ChunkRegs {
+    double v[NB];   // w * a[row][col_of(bq, lane&15)]  (0 for masked / out-of-range)
+    double wb;      // w * b[row]
+    double cnt;     // 1.0 if the row is a training row (only lanes with (lane&15)==0 use it)
+};
+
+// Raw loads of one 4-row chunk.  All global reads of the SYRK kernel go through buffer
+// descriptors (V#) whose num_records ends at the end of the wave's row range: rows past
+// the range (or past m) read back as zero in hardware, so the tail needs no branches
+// and no address clamps, and the per-chunk address arithmetic is one scalar add
+// (soffset) on loop-invariant per-lane voffsets.  Buffer-load intrinsics also keep the
+// hand-written software pipeline intact: with plain pointer loads InstCombine folds
+// phi(load, load) into load(phi) and moves every prefetch to the top of the next
+// iteration, i.e. un-pipelines the loop.
+template <int NB>
+struct ChunkRaw {
+    u4 pr[NB / 2 > 0 ? NB / 2 : 1];
+    u2 tail;
+    u2 bv, wv;
+    unsigned char mk;
+};
+
+struct WaveBufs {
+    __amdgpu_buffer_rsrc_t A, b, w, mask;
+    unsigned voffA;   // per-lane byte offset inside a chunk: (kr*lda + 2e)*8
+    unsigned voffT;   // tail block: (kr*lda + 16*(NB-1) + e)*8
+    unsigned voffR;   // per-lane row offset kr*8 (b, w); mask uses kr
+    unsigned chunk_bytes;  // 4*lda*8
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    // dword3 0x00020000: raw buffer, 32-bit data format (gfx9-family encoding)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+template <int NB, bool NT>
+__device__ __forceinline__ void issue_chunk(ChunkRaw<NB>& r, const WaveBufs& wb, unsigned cl, int kr) {
+    // cl = chunk index local to the wave (wave-uniform)
+    const unsigned soff = cl * wb.chunk_bytes;
+    constexpr int AUX = NT ? 2 : 0;  // 2 = nt (streamed once)
+#pragma unroll
+    for (int j = 0; j < NB / 2; ++j) r.pr[j] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, wb.voffA + 256u * j, soff, AUX);
+    if (NB & 1) r.tail = __builtin_amdgcn_raw_buffer_load_b64(wb.A, wb.voffT, soff, AUX);
+    r.bv = __builtin_amdgcn_raw_buffer_load_b64(wb.b, wb.voffR, cl * 32u, 0);
+    r.wv = __builtin_amdgcn_raw_buffer_load_b64(wb.w, wb.voffR, cl * 32u, 0);
+    r.mk = __builtin_amdgcn_raw_buffer_load_b8(wb.mask, (unsigned)kr, cl * 4u, 0);
+}
+
+template <int NB, bool FULLK>
+__device__ __forceinline__ void finish_chunk(ChunkRegs<NB>& c, const ChunkRaw<NB>& r, int K, int e) {
+    const bool keep = (r.mk != 0);
+    const double wv = __builtin_bit_cast(double, r.wv);
+#pragma unroll
+    for (int j = 0; j < NB / 2; ++j) {
+        const d2 x = __builtin_bit_cast(d2, r.pr[j]);
+        double x0 = wv * x[0];
+        double x1 = wv * x[1];
+        bool k0 = keep, k1 = keep;
+        if (!FULLK) {
+            k0 = k0 && (32 * j + 2 * e < K);
+            k1 = k1 && (32 * j + 2 * e + 1 < K);
+        }
+        c.v[2 * j] = k0 ? x0 : 0.0;
+        c.v[2 * j + 1] = k1 ? x1 : 0.0;
+    }
+    if (NB & 1) {
+        double x = wv * __builtin_bit_cast(double, r.tail);
+        bool kt = keep;
+        if (!FULLK) kt = kt && (16 * (NB - 1) + e < K);
+        c.v[NB - 1] = kt ? x : 0.0;
+    }
+    c.wb = keep ? wv * __builtin_bit_cast(double, r.bv) : 0.0;
+    c.cnt = keep ? 1.0 : 0.0;
+}
+
+// One chunk of matrix work for sub-wave SUB of SPLIT: the tiles t of the packed upper
+// triangle with t % SPLIT == SUB (local accumulator index t / SPLIT).
+template <int NB, int SPLIT, int SUB>
+__device__ __forceinline__ void mfma_chunk(d4 (&acc)[(NB * (NB + 1) / 2 + SPLIT - 1) / SPLIT],
+                                           const ChunkRegs<NB>& c) {
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+#pragma unroll
+        for (int q = p; q < NB; ++q) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int t = tri_index(p, q, NB);
+            if (t % SPLIT == SUB) {
+                acc[t / SPLIT] = __builtin_amdgcn_mfma_f64_16x16x4f64(c.v[p], c.v[q], acc[t / SPLIT], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void valu_c_chunk(double (&cacc)[NB], const ChunkRegs<NB>& c) {
+#pragma unroll
+    for (int p = 0; p < NB; ++p) cacc[p] = __builtin_fma(c.v[p], c.wb, cacc[p]);
+}
+
+template <int NB>
+__device__ __forceinline__ void valu_s_chunk(double& bb, double& sbw, double& cnt, const ChunkRegs<NB>& c) {
+    bb = __builtin_fma(c.wb, c.wb, bb);
+    sbw += c.wb;
+    cnt += c.cnt;
+}
+
+__device__ __forceinline__ double xlane_sum_rows(double x) {
+    // sum over the four 16-lane row groups (lanes l, l^16, l^32, l^48)
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
+}
+
+// Whole life of one wave: stream its chunk range, keep its share of the triangle in
+// registers, write per-row-wave partials.  SUB == 0 additionally carries c / scalars.
+template <int NB, int SPLIT, int SUB, int DEPTH, bool FULLK, bool NT>
+__device__ __forceinline__ void syrk_wave_body(const double* __restrict__ A, int64_t lda,
+                                               const double* __restrict__ b, const double* __restrict__ w,
+                                               const unsigned char* __restrict__ mask, int64_t m, int K,
+                                               int64_t c0, int64_t c1, int64_t rowwave, double* lds,
+                                               double* __restrict__ part, double* __restrict__ cpart,
+                                               double* __restrict__ spart) {
+    constexpr int NTILE = NB * (NB + 1) / 2;
+    constexpr int NTW = (NTILE + SPLIT - 1) / SPLIT;
+    const int lane = threadIdx.x & 63;
+    const int e = lane & 15;
+    const int kr = lane >> 4;
+
+    d4 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+    double cacc[NB];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) cacc[p] = 0.0;
+    double bb = 0.0, sbw = 0.0, cnt = 0.0;
+
+    ChunkRaw<NB> r0, r1, r2;
+    ChunkRegs<NB> cr;
+
+    // buffer descriptors covering exactly this wave's rows [row0, row1)
+    const int64_t row0 = c0 << 2;
+    int64_t row1 = c1 << 2;
+    if (row1 > m) row1 = m;
+    const int64_t nrow = row1 > row0 ? row1 - row0 : 0;
+    WaveBufs wb;
+    // +16 B: the 16-byte column over-read of the last row (select-zeroed) stays in range
+    wb.A = make_rsrc(A + row0 * lda, (unsigned)(nrow * lda * 8 + (nrow ? 16 : 0)));
+    wb.b = make_rsrc(b + row0, (unsigned)(nrow * 8));
+    wb.w = make_rsrc(w + row0, (unsigned)(nrow * 8));
+    wb.mask = make_rsrc(mask + row0, (unsigned)nrow);
+    wb.voffA = (unsigned)((kr * lda + 2 * e) * 8);
+    wb.voffT = (unsigned)((kr * lda + 16 * (NB - 1) + e) * 8);
+    wb.voffR = (unsigned)(kr * 8);
+    wb.chunk_bytes = (unsigned)(lda * 32);
+    const unsigned ncl = (unsigned)(c1 > c0 ? c1 - c0 : 0);
+
+    // Software pipeline, DEPTH chunks in flight per wave.  The loop body is branch-free
+    // (one scheduling region: DEPTH x {weight, prefetch, MFMAs}); chunk slots past the
+    // wave's range read zeros through the bounds-checked descriptors, so a wave wastes
+    // at most DEPTH-1 chunks of matrix-pipe time.
+#define FSNAP_STAGE(R, OFF)                                                    \
+    finish_chunk<NB, FULLK>(cr, R, K, e);                                       \
+    issue_chunk<NB, NT>(R, wb, cl + (OFF) + DEPTH, kr);                         \
+    mfma_chunk<NB, SPLIT, SUB>(acc, cr);                                        \
+    if (SUB == 0) valu_c_chunk<NB>(cacc, cr);                                   \
+    if (SUB == SPLIT - 1) valu_s_chunk<NB>(bb, sbw, cnt, cr);
+    if (ncl > 0) {
+        issue_chunk<NB, NT>(r0, wb, 0, kr);
+        issue_chunk<NB, NT>(r1, wb, 1, kr);
+        if (DEPTH == 3) issue_chunk<NB, NT>(r2, wb, 2, kr);
+        for (unsigned cl = 0; cl < ncl; cl += DEPTH) {
+            FSNAP_STAGE(r0, 0)
+            FSNAP_STAGE(r1, 1)
+            if (DEPTH == 3) {
+                FSNAP_STAGE(r2, 2)
+            }
+        }
+    }
+#undef FSNAP_STAGE
+
+    // epilogue 1: fold the four row-waves of the workgroup through LDS (two rounds:
+    // {2,3} -> {0,1}, then 1 -> 0) so that only ONE partial triangle per workgroup goes
+    // to HBM.  Slot layout [slot][u][i][lane] doubles: conflict-free ds_write/read_b64.
+    // All waves of the workgroup execute the same three barriers (wave-uniform paths).
+    {
+        const int rw = (int)(rowwave & 3);
+        double* slot_hi = lds + (size_t)(((rw & 1) * SPLIT + SUB) * NTW) * 256;  // rounds use 2*SPLIT / SPLIT slots
+        if (rw >= 2) {
+#pragma unroll
+            for (int u = 0; u < NTW; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) slot_hi[(u * 4 + i) * 64 + lane] = acc[u][i];
+        }
+        __syncthreads();
+        if (rw < 2) {
+#pragma unroll
+            for (int u = 0; u < NTW; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[u][i] += slot_hi[(u * 4 + i) * 64 + lane];
+        }
+        __syncthreads();
+        double* slot_lo = lds + (size_t)(SUB * NTW) * 256;
+        if (rw == 1) {
+#pragma unroll
+            for (int u = 0; u < NTW; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) slot_lo[(u * 4 + i) * 64 + lane] = acc[u][i];
+        }
+        __syncthreads();
+        if (rw == 0) {
+            // epilogue 2: per-workgroup partial, coalesced 512-B stores
+            double* pw = part + (rowwave >> 2) * (int64_t)(NTILE * 256);
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) {
+                const int t = u * SPLIT + SUB;
+                if (t < NTILE) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        pw[(t * 4 + i) * 64 + lane] = acc[u][i] + slot_lo[(u * 4 + i) * 64 + lane];
+                }
+            }
+        }
+    }
+    if (SUB == 0) {
+        double* cw = cpart + rowwave * (int64_t)(NB * 16);
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            double s = xlane_sum_rows(cacc[p]);
+            if (kr == 0) cw[p * 16 + e] = s;
+        }
+    }
+    if (SUB == SPLIT - 1) {
+        // every lane of a 16-lane row group carries the same bb/sbw/cnt
+        double sb = xlane_sum_rows(bb), ss = xlane_sum_rows(sbw), sc = xlane_sum_rows(cnt);
+        if (lane == 0) {
+            double* sw = spart + rowwave * 4;
+            sw[0] = sb;
+            sw[1] = ss;
+            sw[2] = sc;
+            sw[3] = 0.0;
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------
+// Kernel 1: fused mask x weight x SYRK.
+// Workgroup = 4 row-waves x SPLIT sub-waves (256*SPLIT threads): row-wave g =
+// blockIdx.x*4 + (wave & 3) streams chunks [g*cpw, (g+1)*cpw) of 4 rows; its SPLIT
+// sub-waves (wave >> 2) read the same rows (second read is an L1/L2 hit) and own
+// disjoint halves of the block triangle, so that at K = 128 each wave holds 18 tiles
+// (144 accumulator registers) and two waves share each SIMD: one wave's loads and
+// weighting overlap the other's MFMAs.
+// Partial layout (doubles): part[workgroup][NT][4][64] (row-waves folded through LDS) |
+// cpart[rowwave][NB][16] | spart[rowwave][4]
+// ---------------------------------------------------------------------------------
+template <int NB, int SPLIT, int DEPTH, bool FULLK, bool NT>
+__global__ __launch_bounds__(256 * SPLIT, ((NB * (NB + 1) / 2 + SPLIT - 1) / SPLIT > 20) ? 1 : 2) void
+fsnap_syrk_wave(const double* __restrict__ A, int64_t lda, const double* __restrict__ b,
+                const double* __restrict__ w, const unsigned char* __restrict__ mask, int64_t m, int K,
+                int64_t chunks_per_wave, double* __restrict__ part, double* __restrict__ cpart,
+                double* __restrict__ spart) {
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t rowwave = (int64_t)blockIdx.x * 4 + (wv & 3);
+    const int sub = wv >> 2;
+    __shared__ double lds[2 * SPLIT * ((NB * (NB + 1) / 2 + SPLIT - 1) / SPLIT) * 256];
+    const int64_t nchunks = (m + 3) >> 2;
+    int64_t c0 = rowwave * chunks_per_wave;
+    int64_t c1 = c0 + chunks_per_wave;
+    if (c1 > nchunks) c1 = nchunks;
+    if (SPLIT == 1 || sub == 0) {
+        syrk_wave_body<NB, SPLIT, 0, DEPTH, FULLK, NT>(A, lda, b, w, mask, m, K, c0, c1, rowwave, lds, part, cpart, spart);
+    } else {
+        syrk_wave_body<NB, SPLIT, (SPLIT > 1 ? 1 : 0), DEPTH, FULLK, NT>(A, lda, b, w, mask, m, K, c0, c1, rowwave, lds,
+                                                                 part, cpart, spart);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 2: deterministic reduction of per-wave partials into the packed statistics
+// buffer  out = [G (K*K row-major) | c (K) | bTb, sum_bw, n_train].
+// One workgroup = 64 consecutive partial elements x 4 slices of the wave range;
+// thread (g = tid>>6, e = tid&63) sums waves g, g+4, g+8, ... then 4-way LDS combine.
+// Element space: [0, NT*256) triangle elements, then NB*16 c elements, then 4 scalars.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsnap_reduce_partials(const double* __restrict__ part,
+                                                             const double* __restrict__ cpart,
+                                                             const double* __restrict__ spart, int nblocks,
+                                                             int NB, int K, double* __restrict__ out) {
+    __shared__ double red[256];
+    const int NTILE = NB * (NB + 1) / 2;
+    const int nG = NTILE * 256, nC = NB * 16, nS = 4;
+    const int tid = threadIdx.x, g = tid >> 6, l = tid & 63;
+    const int idx = blockIdx.x * 64 + l;
+    double s = 0.0;
+    const double* src = nullptr;
+    int64_t stride = 0;
+    int nwaves = nblocks * 4;  // c / scalar partials are per row-wave, G partials per workgroup
+    if (idx < nG) {
+        src = part + idx;
+        stride = nG;
+        nwaves = nblocks;
+    } else if (idx < nG + nC) {
+        src = cpart + (idx - nG);
+        stride = nC;
+    } else if (idx < nG + nC + nS) {
+        src = spart + (idx - nG - nC);
+        stride = nS;
+    }
+    if (src) {
+        // fixed order: wave g, g+4, ...; unrolled by 4 for memory-level parallelism
+        int wv = g;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (; wv + 12 < nwaves; wv += 16) {
+            s0 += src[(int64_t)wv * stride];
+            s1 += src[(int64_t)(wv + 4) * stride];
+            s2 += src[(int64_t)(wv + 8) * stride];
+            s3 += src[(int64_t)(wv + 12) * stride];
+        }
+        for (; wv < nwaves; wv += 4) s0 += src[(int64_t)wv * stride];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (g == 0 && src) {
+        double tot = (red[l] + red[64 + l]) + (red[128 + l] + red[192 + l]);
+        if (idx < nG) {
+            int t = idx >> 8, rem = idx & 255, i = rem >> 6, ln = rem & 63;
+            // invert tri_index: find p with tri_index(p,p) <= t
+            int p = 0;
+            while (p + 1 < NB && tri_index(p + 1, p + 1, NB) <= t) ++p;
+            int q = p + (t - tri_index(p, p, NB));
+            int ep = (ln >> 4) + 4 * i, eq = ln & 15;
+            int r = col_of(p, ep, NB), c = col_of(q, eq, NB);
+            if (r < K && c < K) {
+                out[(int64_t)r * K + c] = tot;
+                if (p != q) out[(int64_t)c * K + r] = tot;
+            }
+        } else if (idx < nG + nC) {
+            int j = idx - nG;
+            int cidx = col_of(j >> 4, j & 15, NB);
+            if (cidx < K) out[(int64_t)K * K + cidx] = tot;
+        } else {
+            int j = idx - nG - nC;
+            if (j < 3) out[(int64_t)K * K + K + j] = tot;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 3: stand-alone wavefront row weighting (svd.py:46 / ridge.py:39).
+//   aw[i,:] = w[i]*A[i,:], bw[i] = w[i]*b[i] for every row; masked rows are written
+//   as zeros (row compaction is the host shim's business, see fsnap_weight_rows()).
+// One wave per row-slab, 16-byte vector accesses, grid-stride.  HBM-bound:
+// 16K + 24 bytes per row.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsnap_weight_rows_k(const double* __restrict__ A, int64_t lda,
+                                                           const double* __restrict__ b,
+                                                           const double* __restrict__ w,
+                                                           const unsigned char* __restrict__ mask, int64_t m,
+                                                           int K, double* __restrict__ aw, int64_t ldaw,
+                                                           double* __restrict__ bw) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * 4;
+    const bool vec2 = ((K & 1) == 0) && ((lda & 1) == 0) && ((ldaw & 1) == 0);
+    for (int64_t row = wave; row < m; row += nwave) {
+        const bool keep = mask ? (mask[row] != 0) : true;
+        const double wv = w[row];
+        const double* src = A + row * lda;
+        double* dst = aw + row * ldaw;
+        if (vec2) {
+            for (int c = 2 * lane; c < K; c += 128) {
+                d2u x = *reinterpret_cast<const d2u*>(src + c);
+                d2u y;
+                y[0] = keep ? wv * x[0] : 0.0;
+                y[1] = keep ? wv * x[1] : 0.0;
+                *reinterpret_cast<d2u*>(dst + c) = y;
+            }
+        } else {
+            for (int c = lane; c < K; c += 64) dst[c] = keep ? wv * src[c] : 0.0;
+        }
+        if (lane == 0) bw[row] = keep ? wv * b[row] : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 4: preds = A @ beta (solver.py:377) and, optionally, per-workgroup partial
+// sums of the weighted squared residual sum_i mask_i (w_i (b_i - preds_i))^2
+// (the SSE that sklearn's ARD loop recomputes each iteration, _bayes.py `rmse_`).
+// 16 lanes per row (4 rows per wave pass), beta staged once in LDS.  HBM-bound.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsnap_gemv_rows_k(const double* __restrict__ A, int64_t lda,
+                                                         const double* __restrict__ beta, int64_t m, int K,
+                                                         double* __restrict__ preds,
+                                                         const double* __restrict__ b,
+                                                         const double* __restrict__ w,
+                                                         const unsigned char* __restrict__ mask,
+                                                         double* __restrict__ sse_part) {
+    extern __shared__ __attribute__((aligned(16))) double sbeta[];
+    for (int c = threadIdx.x; c < K; c += 256) sbeta[c] = beta[c];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * 4;
+    double sse = 0.0;
+    for (int64_t r0 = wave * 4; r0 < m; r0 += nwave * 4) {
+        const int64_t row = r0 + kr;
+        double s = 0.0;
+        if (row < m) {
+            const double* src = A + row * lda;
+            for (int c = e; c < K; c += 16) s = __builtin_fma(src[c], sbeta[c], s);
+        }
+        // reduce over the 16 lanes of the row group
+        s += __shfl_xor(s, 8, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 1, 64);
+        if (row < m && e == 0) {
+            if (preds) preds[row] = s;
+            if (sse_part) {
+                const bool keep = mask ? (mask[row] != 0) : true;
+                if (keep) {
+                    double rr = w[row] * (b[row] - s);
+                    sse = __builtin_fma(rr, rr, sse);
+                }
+            }
+        }
+    }
+    if (sse_part) {
+        __shared__ double wsum[4];
+        sse += __shfl_xor(sse, 16, 64);
+        sse += __shfl_xor(sse, 32, 64);
+        if (lane == 0) wsum[threadIdx.x >> 6] = sse;
+        __syncthreads();
+        if (threadIdx.x == 0) sse_part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// host-side launchers (C++ linkage, used by fsnap_capi.cpp)
+// ---------------------------------------------------------------------------------
+namespace fsnap {
+
+int syrk_num_blocks(int K) { return (K + 15) / 16; }
+
+template <int NB, int SPLIT>
+static hipError_t launch_syrk_nb(const SyrkArgs& a, hipStream_t st) {
+    constexpr int DEPTH = (SPLIT == 2 && NB >= 7) ? 2 : 3;
+    dim3 grid((unsigned)a.nblocks), block(256 * SPLIT);
+    const bool fullk = (a.K == 16 * NB);
+#define FSNAP_LAUNCH(FK, NTL)                                                                              \
+    hipLaunchKernelGGL((fsnap_syrk_wave<NB, SPLIT, DEPTH, FK, NTL>), grid, block, 0, st, a.A, a.lda, a.b, a.w, a.mask, \
+                       a.m, a.K, a.chunks_per_wave, a.part, a.cpart, a.spart)
+    if (fullk) {
+        if (a.nontemporal) FSNAP_LAUNCH(true, true);
+        else FSNAP_LAUNCH(true, false);
+    } else {
+        if (a.nontemporal) FSNAP_LAUNCH(false, true);
+        else FSNAP_LAUNCH(false, false);
+    }
+#undef FSNAP_LAUNCH
+    return hipGetLastError();
+}
+
+int syrk_default_split(int K) { return syrk_num_blocks(K) >= 6 ? 2 : 1; }
+
+// waves per SIMD the register budget of the (NB, SPLIT) instantiation admits
+int syrk_waves_per_simd(int K, int split) {
+    const int NB = syrk_num_blocks(K);
+    const int ntw = (NB * (NB + 1) / 2 + split - 1) / split;
+    const int regs = 8 * ntw + 12 * NB + 40;  // accumulators + 3 raw chunks + weighted chunk + misc
+    int wps = 512 / regs;
+    if (wps < 1) wps = 1;
+    if (wps > 8) wps = 8;
+    return wps;
+}
+
+hipError_t launch_syrk(const SyrkArgs& a, hipStream_t st) {
+    const int nb = syrk_num_blocks(a.K);
+    if (a.split == 2) {
+        switch (nb) {
+            case 6: return launch_syrk_nb<6, 2>(a, st);
+            case 7: return launch_syrk_nb<7, 2>(a, st);
+            case 8: return launch_syrk_nb<8, 2>(a, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    if (a.split != 1) return hipErrorInvalidValue;
+    switch (nb) {
+        case 1: return launch_syrk_nb<1, 1>(a, st);
+        case 2: return launch_syrk_nb<2, 1>(a, st);
+        case 3: return launch_syrk_nb<3, 1>(a, st);
+        case 4: return launch_syrk_nb<4, 1>(a, st);
+        case 5: return launch_syrk_nb<5, 1>(a, st);
+        case 6: return launch_syrk_nb<6, 1>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_reduce(const double* part, const double* cpart, const double* spart, int nblocks, int K,
+                         double* out, hipStream_t st) {
+    const int NB = syrk_num_blocks(K);
+    const int nelem = NB * (NB + 1) / 2 * 256 + NB * 16 + 4;
+    dim3 grid((unsigned)((nelem + 63) / 64)), block(256);
+    hipLaunchKernelGGL(fsnap_reduce_partials, grid, block, 0, st, part, cpart, spart, nblocks, NB, K, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_weight_rows(const double* A, int64_t lda, const double* b, const double* w,
+                              const unsigned char* mask, int64_t m, int K, double* aw, int64_t ldaw,
+                              double* bw, hipStream_t st) {
+    int64_t nb = (m + 3) / 4;
+    if (nb > 256 * 8) nb = 256 * 8;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(fsnap_weight_rows_k, dim3((unsigned)nb), dim3(256), 0, st, A, lda, b, w, mask, m, K, aw,
+                       ldaw, bw);
+    return hipGetLastError();
+}
+
+int gemv_num_blocks(int64_t m) {
+    int64_t nb = (m + 15) / 16;
+    if (nb > 256 * 8) nb = 256 * 8;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+hipError_t launch_gemv_rows(const double* A, int64_t lda, const double* beta, int64_t m, int K, double* preds,
+                            const double* b, const double* w, const unsigned char* mask, double* sse_part,
+                            hipStream_t st) {
+    const int nb = gemv_num_blocks(m);
+    hipLaunchKernelGGL(fsnap_gemv_rows_k, dim3((unsigned)nb), dim3(256), (size_t)K * sizeof(double), st, A, lda,
+                       beta, m, K, preds, b, w, mask, sse_part);
+    return hipGetLastError();
+}
+
+}  // namespace fsnap

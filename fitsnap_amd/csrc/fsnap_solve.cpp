@@ -1,0 +1,324 @@
+// fsnap_solve.cpp — host-side K x K back-solve for the normal-equation statistics
+// produced on the GPU.  Self-contained C++ (no LAPACK dependency).
+//
+// Replaces, on the K x K statistics instead of the m x K matrix:
+//   * scipy.linalg.lstsq(aw, bw, 1.0e-13)              fitsnap3lib/solvers/svd.py:54
+//   * sklearn Ridge(alpha, fit_intercept=False).fit     fitsnap3lib/solvers/ridge.py:47-57
+//       (dense path = (X^T X + alpha I) coef = X^T y, Cholesky, SVD fallback)
+//   * inv(xtx + alpha I) @ xty                          fitsnap3lib/lib/ridge_solver/regressor.py:10-16
+//
+// Numerics: entries of G span > 30 decades on the golden Ta
+// matrices, so every factorisation works on the Jacobi-scaled matrix D^-1 G D^-1
+// (unit diagonal), which lowers the condition number from kappa(A_w)^2 to
+// kappa_equilibrated^2, followed by one step of iterative refinement with the
+// residual accumulated in long double.  Exactly-zero columns (e.g. SNAP columns
+// multiplied by blank2J = 0, lammps_snap.py:467-468) get beta = 0, which is what the
+// minimum-norm solution of lstsq gives them.  A numerically rank-deficient system
+// falls back to a cyclic-Jacobi eigendecomposition of G and a truncated pseudo-inverse
+// (minimum-norm solution, the gelsd semantics).
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "../../include/fsnap_hip.h"
+
+namespace {
+
+typedef std::vector<double> vec;
+
+// In-place lower Cholesky of the n x n row-major matrix a (only the lower triangle is
+// referenced/written).  Returns -1 on success or the index of the failing pivot.
+// *min_piv2 receives the smallest squared pivot (before sqrt) relative to the original
+// diagonal entry (1.0 for a Jacobi-scaled matrix).
+int chol_lower(double* a, int n, double* min_piv2) {
+    double mp = std::numeric_limits<double>::infinity();
+    for (int j = 0; j < n; ++j) {
+        double* aj = a + (size_t)j * n;
+        // row j against previous rows (row-oriented: contiguous inner loops)
+        for (int i = 0; i < j; ++i) {
+            const double* ai = a + (size_t)i * n;
+            double s = aj[i];
+            for (int k = 0; k < i; ++k) s -= aj[k] * ai[k];
+            aj[i] = s / ai[i];
+        }
+        double d = aj[j];
+        const double d0 = d;
+        for (int k = 0; k < j; ++k) d -= aj[k] * aj[k];
+        const double rel = (d0 != 0.0) ? d / d0 : d;
+        if (rel < mp) mp = rel;
+        if (!(d > 0.0) || !std::isfinite(d)) {
+            if (min_piv2) *min_piv2 = mp;
+            return j;
+        }
+        aj[j] = std::sqrt(d);
+    }
+    if (min_piv2) *min_piv2 = mp;
+    return -1;
+}
+
+void chol_solve(const double* l, int n, double* x) {
+    // forward L y = x
+    for (int i = 0; i < n; ++i) {
+        const double* li = l + (size_t)i * n;
+        double s = x[i];
+        for (int k = 0; k < i; ++k) s -= li[k] * x[k];
+        x[i] = s / li[i];
+    }
+    // backward L^T z = y
+    for (int i = n - 1; i >= 0; --i) {
+        double s = x[i];
+        for (int k = i + 1; k < n; ++k) s -= l[(size_t)k * n + i] * x[k];
+        x[i] = s / l[(size_t)i * n + i];
+    }
+}
+
+// LU with partial pivoting, solve a x = b (a destroyed).  Returns false if singular.
+bool lu_solve(double* a, int n, double* b) {
+    std::vector<int> piv(n);
+    for (int j = 0; j < n; ++j) {
+        int p = j;
+        double mx = std::fabs(a[(size_t)j * n + j]);
+        for (int i = j + 1; i < n; ++i) {
+            double v = std::fabs(a[(size_t)i * n + j]);
+            if (v > mx) {
+                mx = v;
+                p = i;
+            }
+        }
+        if (!(mx > 0.0) || !std::isfinite(mx)) return false;
+        if (p != j) {
+            for (int k = 0; k < n; ++k) std::swap(a[(size_t)j * n + k], a[(size_t)p * n + k]);
+            std::swap(b[j], b[p]);
+        }
+        const double inv = 1.0 / a[(size_t)j * n + j];
+        for (int i = j + 1; i < n; ++i) {
+            double f = a[(size_t)i * n + j] * inv;
+            if (f == 0.0) continue;
+            a[(size_t)i * n + j] = f;
+            for (int k = j + 1; k < n; ++k) a[(size_t)i * n + k] -= f * a[(size_t)j * n + k];
+            b[i] -= f * b[j];
+        }
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int k = i + 1; k < n; ++k) s -= a[(size_t)i * n + k] * b[k];
+        b[i] = s / a[(size_t)i * n + i];
+    }
+    return true;
+}
+
+// Cyclic Jacobi eigendecomposition of the symmetric n x n matrix a (row-major, full
+// storage, destroyed): on return eval[i] are the eigenvalues and the ROWS of v the
+// eigenvectors.  Jacobi is used because it resolves small eigenvalues of graded
+// matrices to high relative accuracy (Demmel & Veselic 1992), which is what the huge
+// dynamic range of G needs.
+void jacobi_eigh(double* a, int n, double* eval, double* v) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) v[(size_t)i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < n; ++i) {
+            diag += a[(size_t)i * n + i] * a[(size_t)i * n + i];
+            for (int j = i + 1; j < n; ++j) off += a[(size_t)i * n + j] * a[(size_t)i * n + j];
+        }
+        if (off == 0.0 || off <= 1e-34 * diag) break;
+        for (int p = 0; p < n - 1; ++p) {
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = a[(size_t)p * n + q];
+                if (apq == 0.0) continue;
+                const double app = a[(size_t)p * n + p], aqq = a[(size_t)q * n + q];
+                // skip if negligible relative to the geometric mean of the diagonals
+                if (std::fabs(apq) <= 1e-18 * std::sqrt(std::fabs(app) * std::fabs(aqq))) {
+                    a[(size_t)p * n + q] = a[(size_t)q * n + p] = 0.0;
+                    continue;
+                }
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+                // rotate rows/cols p,q of a (symmetric update, full storage)
+                for (int k = 0; k < n; ++k) {
+                    const double akp = a[(size_t)k * n + p], akq = a[(size_t)k * n + q];
+                    a[(size_t)k * n + p] = cs * akp - sn * akq;
+                    a[(size_t)k * n + q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = a[(size_t)p * n + k], aqk = a[(size_t)q * n + k];
+                    a[(size_t)p * n + k] = cs * apk - sn * aqk;
+                    a[(size_t)q * n + k] = sn * apk + cs * aqk;
+                }
+                a[(size_t)p * n + q] = a[(size_t)q * n + p] = 0.0;
+                // accumulate eigenvectors as rows of v
+                double* vp = v + (size_t)p * n;
+                double* vq = v + (size_t)q * n;
+                for (int k = 0; k < n; ++k) {
+                    const double x = vp[k], y = vq[k];
+                    vp[k] = cs * x - sn * y;
+                    vq[k] = sn * x + cs * y;
+                }
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i) eval[i] = a[(size_t)i * n + i];
+}
+
+// residual r = rhs - M x with long double accumulation (M symmetric n x n row-major)
+void residual_ld(const double* M, int n, const double* x, const double* rhs, double* r) {
+    for (int i = 0; i < n; ++i) {
+        long double s = rhs[i];
+        const double* mi = M + (size_t)i * n;
+        for (int k = 0; k < n; ++k) s -= (long double)mi[k] * (long double)x[k];
+        r[i] = (double)s;
+    }
+}
+
+struct Reduced {
+    int n;                  // active (non-zero) columns
+    std::vector<int> idx;   // active -> original column
+    vec M;                  // n x n active system (G + alpha I restricted)
+    vec rhs;                // n
+};
+
+bool all_finite(const double* p, size_t n) {
+    for (size_t i = 0; i < n; ++i)
+        if (!std::isfinite(p[i])) return false;
+    return true;
+}
+
+// Jacobi-scaled Cholesky solve with one refinement step.  Returns -1 ok, else failing
+// pivot.  min_piv2 = smallest relative squared pivot of the scaled matrix (a cheap
+// lower-bound style estimate of 1/cond).
+int scaled_chol_solve(const vec& M, const vec& rhs, int n, vec& x, double* min_piv2) {
+    vec d(n), S((size_t)n * n), y(n);
+    for (int i = 0; i < n; ++i) {
+        const double g = M[(size_t)i * n + i];
+        if (!(g > 0.0)) {
+            if (min_piv2) *min_piv2 = 0.0;
+            return i;
+        }
+        d[i] = 1.0 / std::sqrt(g);
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) S[(size_t)i * n + j] = M[(size_t)i * n + j] * d[i] * d[j];
+    vec L(S);
+    const int fail = chol_lower(L.data(), n, min_piv2);
+    if (fail >= 0) return fail;
+    for (int i = 0; i < n; ++i) y[i] = rhs[i] * d[i];
+    vec z(y);
+    chol_solve(L.data(), n, z.data());
+    // one step of iterative refinement on the scaled system, residual in long double
+    vec r(n);
+    residual_ld(S.data(), n, z.data(), y.data(), r.data());
+    chol_solve(L.data(), n, r.data());
+    for (int i = 0; i < n; ++i) z[i] += r[i];
+    x.resize(n);
+    for (int i = 0; i < n; ++i) x[i] = z[i] * d[i];
+    return -1;
+}
+
+// truncated pseudo-inverse solve via Jacobi eigendecomposition; returns rank
+int eig_pinv_solve(const vec& M, const vec& rhs, int n, double rel_cut, double shift, vec& x) {
+    vec a(M), ev(n), V((size_t)n * n);
+    jacobi_eigh(a.data(), n, ev.data(), V.data());
+    double lmax = 0.0;
+    for (int i = 0; i < n; ++i) lmax = std::fmax(lmax, std::fabs(ev[i]));
+    x.assign(n, 0.0);
+    int rank = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!(ev[i] > rel_cut * lmax)) continue;
+        ++rank;
+        const double* vi = V.data() + (size_t)i * n;
+        long double s = 0.0L;
+        for (int k = 0; k < n; ++k) s += (long double)vi[k] * rhs[k];
+        const double coef = (double)(s / (long double)(ev[i] + shift));
+        for (int k = 0; k < n; ++k) x[k] += coef * vi[k];
+    }
+    return rank;
+}
+
+}  // namespace
+
+extern "C" int fsnap_solve(int kind, double param, int64_t K64, const double* G, const double* c, double* beta,
+                           int* rank_out, double* rcond_est) {
+    if (!G || !c || !beta || K64 <= 0 || K64 > (1 << 20)) return FSNAP_E_ARG;
+    if (kind < FSNAP_SOLVE_CHOL || kind > FSNAP_SOLVE_RIDGE_INV) return FSNAP_E_ARG;
+    const int K = (int)K64;
+    if (!all_finite(G, (size_t)K * K) || !all_finite(c, K) || !std::isfinite(param)) return FSNAP_NUM_NONFINITE;
+    const double alpha = (kind == FSNAP_SOLVE_RIDGE || kind == FSNAP_SOLVE_RIDGE_INV) ? param : 0.0;
+    const double eps = std::numeric_limits<double>::epsilon();
+
+    // active columns: drop exactly-zero columns when there is no ridge shift
+    Reduced R;
+    R.idx.reserve(K);
+    for (int j = 0; j < K; ++j) {
+        const double gjj = G[(size_t)j * K + j] + alpha;
+        if (gjj == 0.0 && kind != FSNAP_SOLVE_CHOL && kind != FSNAP_SOLVE_RIDGE_INV) continue;  // beta_j = 0
+        R.idx.push_back(j);
+    }
+    const int n = R.n = (int)R.idx.size();
+    for (int j = 0; j < K; ++j) beta[j] = 0.0;
+    if (rank_out) *rank_out = 0;
+    if (rcond_est) *rcond_est = 0.0;
+    if (n == 0) return FSNAP_OK;
+    R.M.resize((size_t)n * n);
+    R.rhs.resize(n);
+    for (int i = 0; i < n; ++i) {
+        R.rhs[i] = c[R.idx[i]];
+        for (int j = 0; j < n; ++j) {
+            // symmetrise defensively (the GPU path already mirrors the triangle)
+            const double gij = 0.5 * (G[(size_t)R.idx[i] * K + R.idx[j]] + G[(size_t)R.idx[j] * K + R.idx[i]]);
+            R.M[(size_t)i * n + j] = gij + ((i == j) ? alpha : 0.0);
+        }
+    }
+
+    vec x;
+    double mp2 = 0.0;
+    const int fail = scaled_chol_solve(R.M, R.rhs, n, x, &mp2);
+    if (rcond_est) *rcond_est = mp2;
+    // a Jacobi-scaled SPD matrix with relative pivot below ~n*eps has lost all digits
+    const double piv_tol = 64.0 * n * eps;
+    const bool chol_ok = (fail < 0) && (mp2 > piv_tol);
+
+    if (chol_ok) {
+        for (int i = 0; i < n; ++i) beta[R.idx[i]] = x[i];
+        if (rank_out) *rank_out = n;
+        return all_finite(beta, K) ? FSNAP_OK : FSNAP_NUM_NONFINITE;
+    }
+
+    switch (kind) {
+        case FSNAP_SOLVE_CHOL:
+            return FSNAP_NUM_NOT_SPD;
+        case FSNAP_SOLVE_LSTSQ: {
+            // gelsd semantics: drop singular values sigma < rcond * sigma_max, i.e.
+            // eigenvalues of G below rcond^2 * lambda_max; eigenvalues of a computed G are
+            // not resolved below ~n*eps*lambda_max, so that is the floor of the cut.
+            double cut = param > 0 ? param * param : 0.0;
+            const double floor_cut = 4.0 * n * eps;
+            if (cut < floor_cut) cut = floor_cut;
+            const int rk = eig_pinv_solve(R.M, R.rhs, n, cut, 0.0, x);
+            for (int i = 0; i < n; ++i) beta[R.idx[i]] = x[i];
+            if (rank_out) *rank_out = rk;
+            return all_finite(beta, K) ? FSNAP_OK : FSNAP_NUM_NONFINITE;
+        }
+        case FSNAP_SOLVE_RIDGE: {
+            // sklearn falls back from Cholesky to an SVD solve (linear_model/_ridge.py,
+            // _ridge_regression: except LinAlgError -> solver = 'svd'); on the statistics
+            // that is the eigen form coef = V diag(1/(lambda + alpha)) V^T c over
+            // lambda > 1e-15-ish.  R.M already contains the alpha shift.
+            const int rk = eig_pinv_solve(R.M, R.rhs, n, 4.0 * n * eps, 0.0, x);
+            for (int i = 0; i < n; ++i) beta[R.idx[i]] = x[i];
+            if (rank_out) *rank_out = rk;
+            return all_finite(beta, K) ? FSNAP_OK : FSNAP_NUM_NONFINITE;
+        }
+        case FSNAP_SOLVE_RIDGE_INV: {
+            // np.linalg.inv semantics: LU with partial pivoting; singular -> LinAlgError
+            vec a(R.M), b(R.rhs);
+            if (!lu_solve(a.data(), n, b.data())) return FSNAP_NUM_SINGULAR;
+            for (int i = 0; i < n; ++i) beta[R.idx[i]] = b[i];
+            if (rank_out) *rank_out = n;
+            return all_finite(beta, K) ? FSNAP_OK : FSNAP_NUM_NONFINITE;
+        }
+    }
+    return FSNAP_E_ARG;
+}

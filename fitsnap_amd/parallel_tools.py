@@ -1,0 +1,408 @@
+"""MI355X-side counterpart of the reference's runtime / shared-memory layer for the
+linear-fit hot path (fitsnap3lib/parallel_tools.py:148-1077).
+
+Same public surface as the reference for the pieces the hot path touches —
+``ParallelTools(comm=None)``, ``create_shared_array(name, size1, size2=1, dtype='d', tm=0)``,
+``shared_arrays[name].array``, ``fitsnap_dict``, ``add_2_fitsnap``, ``DistributedList``,
+``SharedArray`` / ``StubsArray``, ``gather_fitsnap``, ``all_barrier``, ``single_print``,
+``rank_zero`` / ``sub_rank_zero``, ``single_timeit``, ``free`` — with a different engine
+underneath:
+
+* the reference shares ONE host copy of A between the MPI ranks of a node through an
+  MPI-3 shared-memory window (``Win.Allocate_shared``, parallel_tools.py:992-1009) and
+  solves on rank 0.  Here there is one process per GPU (``torch.distributed``, RCCL over
+  xGMI); every rank owns the rows of ITS configurations (the reference's per-proc row
+  partition, config i -> proc i % size, parallel_tools.py:612-651) in a rank-local
+  ``SharedArray`` whose rows are mirrored into that rank's HBM, and the ranks exchange
+  only the K x K statistics (one all-reduce, the analogue of
+  examples/library/transpose_trick/example.py:245-246);
+* ``comm=None`` is the reference's "stubs" mode: one process, no collectives.
+
+``comm`` may be ``None`` (stubs), the string ``"torch"`` / ``True`` (use the default
+``torch.distributed`` process group, which must already be initialised) or a
+``torch.distributed.ProcessGroup``.
+"""
+from __future__ import annotations
+
+from copy import deepcopy
+from time import time
+
+import numpy as np
+
+
+def _printf(*args, **kw):
+    kw.setdefault("flush", True)
+    print(*args, **kw)
+
+
+def _dummy_function(*args, **kwargs):
+    return
+
+
+class DistributedList:
+    """Fixed-length per-process list (fitsnap3lib/parallel_tools.py:892-941): slice
+    assignment must preserve the length so that the lists can be gathered at the end."""
+
+    def __init__(self, proc_length):
+        self._len = proc_length
+        self._list = list(" ") * self._len
+
+    def __getitem__(self, item):
+        return self._list.__getitem__(item)
+
+    def __len__(self):
+        return self._len
+
+    def __setitem__(self, key, value):
+        if isinstance(key, int):
+            assert len(value) == 1
+            assert key <= self.__len__()
+        elif isinstance(key, slice):
+            assert isinstance(value, list)
+            assert len(value) == len(range(*key.indices(self.__len__())))
+            assert key.stop <= self.__len__()
+        else:
+            raise NotImplementedError("Indexing type {} for Distributed list is not impelemented".format(type(key)))
+        self._list.__setitem__(key, value)
+
+    def __repr__(self):
+        return self._list.__repr__()
+
+    def get_list(self):
+        return deepcopy(self._list)
+
+
+class StubsArray:
+    """Plain ndarray holder (fitsnap3lib/parallel_tools.py:1047-1077).  Unlike the
+    reference (``np.ndarray(shape)`` = uninitialised memory, Appendix A of SURVEY.md) the
+    buffer is zero-initialised: an MPI shared window is zero pages too, and NaN garbage in
+    never-written rows would otherwise poison G."""
+
+    _ITEMSIZE = {"d": 8, "i": 4}
+
+    def __init__(self, size1, size2=1, dtype="d"):
+        if dtype not in self._ITEMSIZE:
+            raise TypeError("dtype {} has not been implemented yet".format(dtype))
+        self.array = None
+        self.sliced_array = None
+        self.energies_index = None
+        self.forces_index = None
+        self.strain_index = None
+        self._length = size1
+        self._width = size2
+        shape = (size1,) if size2 == 1 else (size1, size2)
+        self.array = np.zeros(shape, dtype="float64" if dtype == "d" else "int32")
+
+    def get_memory(self):
+        return self.array.nbytes
+
+    # length getters of the MPI variant (parallel_tools.py:1014-1028)
+    def get_storage_length(self):
+        return self._length
+
+    def get_scraped_length(self):
+        return self._length
+
+    def get_node_length(self):
+        return self._length
+
+    def get_total_length(self):
+        return self._length
+
+
+class _Window:
+    """Stand-in for the MPI window handle: ``shared_arrays[name].win.Free()``
+    (parallel_tools.py:338-350, 372-376) drops the host buffer and any HBM mirror."""
+
+    def __init__(self, owner):
+        self._owner = owner
+
+    def Free(self):  # noqa: N802 - reference spelling
+        self._owner._free()
+
+
+class SharedArray(StubsArray):
+    """Rank-local array whose rows are mirrored in this rank's HBM on demand
+    (reference: node-shared MPI window, parallel_tools.py:944-1044).
+
+    ``array`` is the host view the calculators fill (same attribute as the reference);
+    ``version`` must be bumped (``touch()``) by whoever writes into ``array`` after a fit
+    so that the resident device copy is refreshed; the solvers of this package call
+    ``device_rows`` which re-uploads when the version changed."""
+
+    def __init__(self, size1, size2=1, dtype="d", multinode=0, comms=None):
+        super().__init__(size1, size2, dtype)
+        self._comms = comms
+        self._nbytes = self.array.nbytes
+        self._scraped_length = self._length
+        self._total_length = self._length
+        self._node_length = self._length
+        self.win = _Window(self)
+        self.version = 0
+        if multinode and comms is not None:
+            self.multinode_lengths()
+
+    def touch(self):
+        self.version += 1
+
+    def get_memory(self):
+        return self._nbytes
+
+    def get_scraped_length(self):
+        return self._scraped_length
+
+    def get_node_length(self):
+        return self._node_length
+
+    def get_total_length(self):
+        return self._total_length
+
+    def multinode_lengths(self):
+        """Total row count over ranks (reference: ScaLAPACK bookkeeping,
+        parallel_tools.py:1030-1044).  Rows never move between ranks here."""
+        pt = self._comms
+        self._total_length = int(pt.allreduce_scalar(self._length))
+        self._node_length = self._length
+
+    def _free(self):
+        self.array = None
+        self.sliced_array = None
+        self._nbytes = 0
+
+
+class ParallelTools:
+    """See module docstring.  Attribute names follow fitsnap3lib/parallel_tools.py:157-200."""
+
+    def __init__(self, comm=None):
+        self.check_fitsnap_exist = True
+        self.create_shared_bool = True
+        self.double_size = 8
+        self._fp = None
+        self._lmp = None
+        self.logger = None
+        self._dist = None
+        self._group = None
+        self._hip = None
+        self._device_index = None
+        if comm is None or comm is False:
+            self.stubs = 1
+            self._comm = None
+            self._rank = 0
+            self._size = 1
+        else:
+            import torch.distributed as dist
+
+            if not dist.is_available() or not dist.is_initialized():
+                raise RuntimeError("ParallelTools(comm=...) needs an initialised torch.distributed process group")
+            self.stubs = 0
+            self._dist = dist
+            self._group = None if comm in (True, "torch") else comm
+            self._comm = comm
+            self._rank = dist.get_rank(self._group)
+            self._size = dist.get_world_size(self._group)
+        # one process per GPU: every rank is its own "node head" for its own rows
+        self._sub_rank = 0
+        self._sub_size = 1
+        self._sub_comm = None
+        self._sub_head_proc = self._rank
+        self._node_index = self._rank
+        self._number_of_nodes = self._size
+        self._seed = 0.0
+        self._set_seed()
+        self.shared_arrays = {}
+        self.fitsnap_dict = {}
+
+    # -- rank helpers (parallel_tools.py:245-336) ---------------------------------------
+    def get_rank(self):
+        return self._rank
+
+    def get_size(self):
+        return self._size
+
+    def get_subrank(self):
+        return self._sub_rank
+
+    def get_subsize(self):
+        return self._sub_size
+
+    def get_node(self):
+        return self._node_index
+
+    def get_number_of_nodes(self):
+        return self._number_of_nodes
+
+    def _set_seed(self):
+        seed = float(time()) if self._rank == 0 else 0.0
+        self._seed = self.bcast_object(seed)
+
+    def get_seed(self):
+        return self._seed
+
+    def single_print(self, *args, **kw):
+        if self._rank == 0:
+            _printf(*args, file=self._fp)
+
+    def sub_print(self, *args, **kw):
+        _printf("Node", self._node_index, ":", *args, file=self._fp)
+
+    def all_print(self, *args, **kw):
+        _printf("Rank", self._rank, ":", *args, file=self._fp)
+
+    def rank_zero(self, method):
+        if self._rank == 0:
+            def check_if_rank_zero(*args, **kw):
+                return method(*args, **kw)
+            return check_if_rank_zero
+        return _dummy_function
+
+    def sub_rank_zero(self, method):
+        if self._sub_rank == 0:
+            def check_if_rank_zero(*args, **kw):
+                return method(*args, **kw)
+            return check_if_rank_zero
+        return _dummy_function
+
+    def single_timeit(self, method):
+        """Wall-clock decorator, prints on rank 0 (parallel_tools.py:290-306)."""
+        def timed(*args, **kw):
+            ts = time()
+            result = method(*args, **kw)
+            te = time()
+            if "log_time" in kw:
+                kw["log_time"][kw.get("log_name", method.__name__.upper())] = int((te - ts) * 1000)
+            elif self._rank == 0:
+                _printf("'{0}' took {1:.2f} ms on rank {2}".format(method.__name__, (te - ts) * 1000, self._rank),
+                        file=self._fp)
+            return result
+        return timed
+
+    # -- collectives (reference: mpi4py) ---------------------------------
+    def all_barrier(self):
+        if not self.stubs:
+            self._dist.barrier(group=self._group)
+
+    def sub_barrier(self):
+        return
+
+    def bcast_object(self, obj, src=0):
+        if self.stubs:
+            return obj
+        box = [obj]
+        self._dist.broadcast_object_list(box, src=src, group=self._group)
+        return box[0]
+
+    def allreduce_scalar(self, value):
+        if self.stubs:
+            return value
+        import torch
+
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self._collective_device())
+        self._dist.all_reduce(t, group=self._group)
+        return float(t.item())
+
+    def _collective_device(self):
+        import torch
+
+        backend = self._dist.get_backend(self._group)
+        if backend == "nccl":
+            return torch.device("cuda", self.device_index())
+        return torch.device("cpu")
+
+    def allreduce_statistics(self, packed):
+        """Sum the packed K x K statistics [G | c | bTb, sum_bw, n_train] over ranks — the
+        one data-path collective of a fit (reference form:
+        examples/library/transpose_trick/example.py:245-246, two MPI Allreduce calls).
+        ``packed`` is a torch tensor (cuda: RCCL over xGMI; cpu: gloo in the CPU tests);
+        reduced in place and returned."""
+        if self.stubs or self._size == 1:
+            return packed
+        self._dist.all_reduce(packed, op=self._dist.ReduceOp.SUM, group=self._group)
+        return packed
+
+    def gather_fitsnap(self, name, allgather=None):
+        """All-gather a per-rank list held in ``fitsnap_dict`` (parallel_tools.py:426-441)."""
+        if name not in self.fitsnap_dict:
+            raise NameError("Dictionary element not yet in fitsnap_dictionary")
+        if self.stubs:
+            return
+        out = [None] * self._size
+        self._dist.all_gather_object(out, self.fitsnap_dict[name], group=self._group)
+        self.fitsnap_dict[name] = out
+
+    def get_ncpn(self, nconfigs):
+        """Number of configurations over all ranks (parallel_tools.py:562-577)."""
+        return int(self.allreduce_scalar(nconfigs)) if not self.stubs else nconfigs
+
+    # -- device -------------------------------------------------------------------------
+    def device_index(self):
+        """HIP device of this rank: LOCAL_RANK when launched by torchrun, else rank % #devices."""
+        if self._device_index is None:
+            import os
+
+            from . import _capi
+
+            n = max(_capi.device_count(), 1)
+            self._device_index = int(os.environ.get("LOCAL_RANK", self._rank)) % n
+        return self._device_index
+
+    def hip(self):
+        """This rank's ``HipContext`` (created on first use; raises loudly without a GPU)."""
+        if self._hip is None:
+            from . import _capi
+
+            self._hip = _capi.HipContext(self.device_index())
+        return self._hip
+
+    # -- shared arrays (parallel_tools.py:338-424) ----------------------------------------
+    def create_shared_array(self, name, size1, size2=1, dtype="d", tm=0):
+        if not isinstance(name, str):
+            raise TypeError("name must be a string")
+        if name in self.shared_arrays and hasattr(self.shared_arrays[name], "win"):
+            try:
+                self.shared_arrays[name].win.Free()
+            except Exception as e:  # pragma: no cover
+                self.single_print(f"Trouble deallocating shared array with name {name}: {e}.")
+        if self.stubs == 0 and self.create_shared_bool:
+            self.shared_arrays[name] = SharedArray(size1, size2=size2, dtype=dtype, multinode=tm, comms=self)
+        else:
+            self.shared_arrays[name] = SharedArray(size1, size2=size2, dtype=dtype)
+
+    def add_2_fitsnap(self, name, an_object):
+        if not isinstance(name, str):
+            raise TypeError("name must be a string")
+        if self.check_fitsnap_exist and name in self.fitsnap_dict:
+            self.fitsnap_dict.pop(name)
+        self.fitsnap_dict[name] = an_object
+
+    def free(self):
+        """Free all shared arrays (parallel_tools.py:338-350) and the HBM mirror."""
+        for name in list(self.shared_arrays):
+            try:
+                self.shared_arrays[name].win.Free()
+            except Exception:
+                pass
+        if self._hip is not None:
+            self._hip.close()
+            self._hip = None
+
+    def slice_array(self, name):
+        if name not in self.shared_arrays:
+            raise IndexError("{} not found in shared objects".format(name))
+        if name == "a":
+            raise NotImplementedError("Slice A using new_slice_a")
+        s = slice(self._sub_rank, None, self._sub_size)
+        self.shared_arrays[name].sliced_array = self.shared_arrays[name].array[s][:]
+
+    def split_by_node(self, obj):
+        """Round-robin split over ranks (parallel_tools.py:543-550): config i -> rank i % size."""
+        if isinstance(obj, list):
+            return obj[self._node_index::self._number_of_nodes]
+        if isinstance(obj, dict):
+            for key in obj:
+                obj[key] = obj[key][self._node_index::self._number_of_nodes]
+            return obj
+        return obj
+
+    def exception(self, err):
+        """Abort path (parallel_tools.py:840-860): no MPI.Abort here — re-raise."""
+        raise err

@@ -1,0 +1,100 @@
+"""ARD solver behind the reference's plugin API (fitsnap3lib/solvers/ard.py:9-49).
+
+The reference hands the weighted m x K matrix to scikit-learn's ``ARDRegression``; every
+iteration of that algorithm touches the data only through ``X_keep.T X_keep``,
+``X_keep.T y`` and the residual sum of squares (sklearn 1.7.2 linear_model/_bayes.py,
+``ARDRegression.fit`` / ``_update_sigma``).  Here the first two come once from the GPU
+statistics (G, c) and the third from the streaming GEMV+SSE kernel each iteration, so the
+loop below is a sufficient-statistics restatement of that algorithm with K x K host
+algebra.  The reference's own class cannot run on scikit-learn >= 1.5 (``n_iter=``,
+ard.py:40-45); parity is therefore pinned only against a direct ARDRegression call
+(tolerance 1e-3 relative, equal support — SURVEY.md 7.2)."""
+from __future__ import annotations
+
+import numpy as np
+from scipy.linalg import pinvh
+
+from .solver import Solver
+
+
+class ARD(Solver):
+
+    TOL = 1.0e-3        # ARDRegression default `tol`
+    MAX_ITER = 1000     # ard.py:40-45 (n_iter=1000)
+
+    def __init__(self, name, pt, config):
+        super().__init__(name, pt, config)
+        self.exact_sse = True   # recompute sum((y - X beta)^2) on the GPU each iteration (sklearn does)
+        self.n_iter_ = None
+        self.lambda_ = None
+        self.alpha_ = None
+
+    def perform_fit(self):
+        """ard.py:15-49 — no arguments: data comes from ``pt.shared_arrays``."""
+        pt = self.pt
+        G, c, s = self._fit_statistics(None, None, None, None, False)
+        bb, sbw, n = float(s[0]), float(s[1]), float(s[2])
+        var_bw = bb / n - (sbw / n) ** 2
+        if self.config.sections["EXTRAS"].apply_transpose:
+            raise NotImplementedError("ARD with EXTRAS.apply_transpose is not supported by the HIP path")
+        ap = 1.0 / var_bw
+        sec = self.config.sections["ARD"]
+        pt.single_print("inverse variance in training data: %f, logscale for threshold_lambda: %f" % (ap, np.log10(ap)))
+        pt.single_print("automated threshold_lambda will be 10**(%f + %1.3f)" % (sec.logcut, np.abs(np.log10(ap))))
+        if sec.directmethod:
+            hyper = dict(threshold_lambda=sec.threshold_lambda, alpha_1=sec.alphabig, alpha_2=sec.alphabig,
+                         lambda_1=sec.lambdasmall, lambda_2=sec.lambdasmall)
+        else:
+            hyper = dict(alpha_1=sec.scap * ap, alpha_2=sec.scap * ap, lambda_1=ap * sec.scai, lambda_2=ap * sec.scai,
+                         threshold_lambda=10 ** (int(np.abs(np.log10(ap))) + sec.logcut))
+        coef = self._ard_loop(G, c, bb, n, var_bw, **hyper)
+        if pt._rank == 0:
+            self.fit = coef
+
+    # sklearn 1.7.2 linear_model/_bayes.py ARDRegression.fit, on (G, c) instead of (X, y)
+    def _ard_loop(self, G, c, bb, n_samples, var_y, alpha_1, alpha_2, lambda_1, lambda_2, threshold_lambda):
+        K = len(c)
+        eps = np.finfo(np.float64).eps
+        coef_ = np.zeros(K)
+        keep = np.ones(K, dtype=bool)
+        alpha_ = 1.0 / (var_y + eps)
+        lambda_ = np.ones(K)
+        coef_old = None
+
+        def update_sigma(alpha_, lambda_, keep):
+            gram = G[np.ix_(keep, keep)]
+            return pinvh(lambda_[keep] * np.eye(gram.shape[0]) + alpha_ * gram)
+
+        def sse_of(coef_):
+            if self.exact_sse:
+                return self._device_sse(coef_)
+            return float(bb - 2.0 * coef_ @ c + coef_ @ G @ coef_)
+
+        it = 0
+        for it in range(self.MAX_ITER):
+            sigma_ = update_sigma(alpha_, lambda_, keep)
+            coef_[keep] = alpha_ * (sigma_ @ c[keep])
+            sse_ = sse_of(coef_)
+            gamma_ = 1.0 - lambda_[keep] * np.diag(sigma_)
+            lambda_[keep] = (gamma_ + 2.0 * lambda_1) / (coef_[keep] ** 2 + 2.0 * lambda_2)
+            alpha_ = (n_samples - gamma_.sum() + 2.0 * alpha_1) / (sse_ + 2.0 * alpha_2)
+            keep = lambda_ < threshold_lambda
+            coef_[~keep] = 0
+            if it > 0 and np.sum(np.abs(coef_old - coef_)) < self.TOL:
+                break
+            coef_old = np.copy(coef_)
+            if not keep.any():
+                break
+        self.n_iter_ = it + 1
+        if keep.any():
+            sigma_ = update_sigma(alpha_, lambda_, keep)
+            coef_[keep] = alpha_ * (sigma_ @ c[keep])
+        self.lambda_, self.alpha_ = lambda_, alpha_
+        return coef_
+
+    def _device_sse(self, coef_):
+        """sum over training rows of (w (b - A coef))^2 on every rank's rows, summed over ranks."""
+        pt = self.pt
+        ctx = pt.hip()
+        _, sse = ctx.predict(coef_, want_preds=False, want_sse=True)
+        return pt.allreduce_scalar(sse)

@@ -1,0 +1,46 @@
+"""RIDGE solver behind the reference's plugin API (fitsnap3lib/solvers/ridge.py:6-60,
+fitsnap3lib/lib/ridge_solver/regressor.py:4-21)."""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import _capi
+from .solver import Solver
+
+
+class RIDGE(Solver):
+    """``(aw.T aw + alpha I) beta = aw.T bw`` from the GPU statistics.
+
+    ``[RIDGE] local_solver = 0`` mirrors sklearn ``Ridge(alpha, fit_intercept=False)``
+    (ridge.py:47-53: Cholesky on the normal equations, eigen/SVD fallback);
+    ``local_solver = 1`` mirrors ``Local_Ridge`` (regressor.py:10-16: explicit inverse,
+    LinAlgError when singular).  With ``[EXTRAS] apply_transpose`` the reference feeds
+    X = aw.T aw, y = aw.T bw to the regressor (ridge.py:41-43), i.e. solves
+    (G G + alpha I) beta = G c; that K x K product is formed on the host."""
+
+    def __init__(self, name, pt, config):
+        super().__init__(name, pt, config)
+
+    def perform_fit(self, a=None, b=None, w=None, fs_dict=None, trainall=False):
+        """
+        Perform fit on a linear system. If no args are supplied, will use fitting data in `pt.shared_arrays`.
+
+        Args:
+            a (np.array): Optional "A" matrix.
+            b (np.array): Optional Truth array.
+            w (np.array): Optional Weight array (one entry per TRAINING row, as in the reference).
+            fs_dict (dict): Optional dictionary containing a `Testing` key of which A matrix rows should not be trained.
+            trainall (bool): Optional boolean declaring whether to train on all samples in the A matrix.
+
+        The fit is stored as a member `fs.solver.fit` (rank 0 only).
+        """
+        pt = self.pt
+        G, c, _ = self._fit_statistics(a, b, w, fs_dict, trainall)
+        if pt._rank == 0:
+            alval = self.config.sections["RIDGE"].alpha
+            local = bool(self.config.sections["RIDGE"].local_solver)
+            if "EXTRAS" in self.config.sections and self.config.sections["EXTRAS"].apply_transpose:
+                c = G.T @ c
+                G = G.T @ G
+            kind = _capi.SOLVE_RIDGE_INV if local else _capi.SOLVE_RIDGE
+            self.fit = self._solve(kind, alval, G, c)

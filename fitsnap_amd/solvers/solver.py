@@ -1,0 +1,298 @@
+"""Solver base class: the reference's plugin contract (fitsnap3lib/solvers/solver.py:19-48,
+137, 368-435) on top of the MI355X statistics engine.
+
+Contract kept from the reference
+  * ``__init__(name, pt, config, linear=True)``; attributes ``fit, errors, linear, cov,
+    fit_sam, configs, df, a, b, w, residuals, weighted, all_fits``;
+  * ``perform_fit(a=None, b=None, w=None, fs_dict=None, trainall=False)`` returns None and
+    sets ``self.fit`` (ndarray (K,), float64) ON RANK 0 ONLY; mask precedence
+    ``fs_dict`` > ``trainall`` > ``pt.fitsnap_dict['Testing']``; with no arrays the data
+    comes from ``pt.shared_arrays['a'|'b'|'w'].array``;
+  * explicit-array quirk of the reference (svd.py:46, ridge.py:39): ``w`` is multiplied
+    into ``a[training]`` WITHOUT being masked, so ``w`` must already have one entry per
+    training row (or be broadcastable); anything else raises numpy's broadcast ValueError;
+  * ``error_analysis(a=None, b=None, w=None, fs_dict=None)``, ``fit_gather()``.
+
+What is different underneath: A, b stay resident in HBM; mask x weight x A^T A runs as
+one fused fp64-MFMA kernel per GPU; with several ranks (one per GPU) every rank fits its
+OWN rows and the K x K statistics are summed with one RCCL all-reduce before rank 0
+solves.  There is no numpy fallback: without the HIP library / a gfx950 device
+``perform_fit`` raises.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import _capi
+
+
+class Solver:
+    """Base class for linear solvers (see module docstring)."""
+
+    def __init__(self, name, pt, config, linear=True):
+        self.config = config
+        self.pt = pt
+        self.name = name
+        self.configs = None
+        self.fit = None
+        self.all_fits = None
+        self.template_error = False
+        self.errors = []
+        self.weighted = "Unweighted"
+        self.residuals = None
+        self.a = None
+        self.b = None
+        self.w = None
+        self.df = None
+        self.linear = linear
+        self.cov = None
+        self.fit_sam = None
+        # engine state
+        self.keep_resident = False   # explicit-array mode: reuse the HBM copy of (a, b) across calls
+        self._resident_key = None
+        self.last_statistics = None  # (G, c, scalars) of the last fit, host ndarrays (after all-reduce)
+        self.last_rank = None
+        self._checks()
+
+    # ------------------------------------------------------------------------------
+    def perform_fit(self):
+        """Base class function for performing a fit."""
+        pass
+
+    def fit_gather(self):
+        pass
+
+    def _checks(self):
+        # fitsnap3lib/solvers/solver.py:106-107
+        calc = self.config.sections["CALCULATOR"]
+        assert not (calc.linear and calc.per_atom_energy and self.config.args.perform_fit), \
+            "Can only output per_atom_energy for non-linear fits (e.g., Pytorch) or with the '--nofit' flag. " \
+            "Either change to a non-linear fit, use the flag '--nofit', or set per_atom_energy = 0."
+
+    # ------------------------------------------------------------------------------
+    # mask / weights exactly as the reference resolves them
+    # ------------------------------------------------------------------------------
+    def _training_mask(self, a, fs_dict, trainall):
+        """svd.py:35-40 / ridge.py:28-33."""
+        if fs_dict is not None:
+            return ~np.asarray(fs_dict["Testing"], dtype=bool)
+        if trainall:
+            return np.ones(np.shape(a)[0], dtype=bool)
+        return ~np.asarray(self.pt.fitsnap_dict["Testing"], dtype=bool)
+
+    def _resolve_inputs(self, a, b, w, fs_dict, trainall):
+        """Returns (a, b, w_full, mask_u8, shared_mode)."""
+        pt = self.pt
+        training = self._training_mask(a, fs_dict, trainall)
+        if a is None and b is None and w is None:
+            sa, sb, sw = pt.shared_arrays["a"], pt.shared_arrays["b"], pt.shared_arrays["w"]
+            a, b, w_full = sa.array, sb.array, sw.array
+            if len(training) != a.shape[0]:
+                raise IndexError("boolean index did not match indexed array along axis 0; size of axis is "
+                                 f"{a.shape[0]} but size of corresponding boolean axis is {len(training)}")
+            return a, b, np.asarray(w_full, dtype=np.float64), training.astype(np.uint8), True
+        a = np.asarray(a)
+        b = np.asarray(b)
+        w = np.asarray(w, dtype=np.float64)
+        m = a.shape[0]
+        if len(training) != m:
+            raise IndexError("boolean index did not match indexed array along axis 0; size of axis is "
+                             f"{m} but size of corresponding boolean axis is {len(training)}")
+        ntrain = int(training.sum())
+        # reference: aw = w[:, None] * a[training]  (numpy broadcasting on the row axis)
+        if w.ndim == 0 or w.shape[0] == 1:
+            w_full = np.full(m, float(w.reshape(-1)[0]))
+        elif w.shape[0] == ntrain:
+            w_full = np.zeros(m)
+            w_full[training] = w
+        else:
+            raise ValueError(f"operands could not be broadcast together with shapes ({w.shape[0]},1) ({ntrain},{a.shape[1]}) ")
+        return a, b, w_full, training.astype(np.uint8), False
+
+    # ------------------------------------------------------------------------------
+    # the hot path
+    # ------------------------------------------------------------------------------
+    def _upload(self, a, b, shared_mode):
+        ctx = self.pt.hip()
+        if shared_mode:
+            sa, sb = self.pt.shared_arrays["a"], self.pt.shared_arrays["b"]
+            key = ("shared", id(sa), getattr(sa, "version", 0), id(sb), getattr(sb, "version", 0), a.shape)
+            # shared arrays are re-uploaded unless their owner kept the version (touch())
+            if self.keep_resident and key == self._resident_key:
+                return ctx
+        else:
+            key = ("explicit", a.__array_interface__["data"][0], a.shape, a.strides,
+                   b.__array_interface__["data"][0]) if isinstance(a, np.ndarray) and isinstance(b, np.ndarray) else None
+            if self.keep_resident and key is not None and key == self._resident_key:
+                return ctx
+        ctx.upload_rows(a, b)
+        self._resident_key = key
+        return ctx
+
+    def _local_statistics_async(self, a, b, w_full, mask, shared_mode, packed_ptr, stream_handle):
+        """Launch this rank's fused kernel into a DEVICE packed buffer (multi-GPU path)."""
+        ctx = self._upload(a, b, shared_mode)
+        ctx.set_weights(w_full, None if mask.all() else mask)
+        ctx.set_stream(stream_handle)
+        ctx.normal_eq_async(packed_ptr)
+
+    def _local_statistics(self, a, b, w_full, mask, shared_mode):
+        """This rank's (G, c, scalars) on the host (single-GPU path and CPU process groups)."""
+        ctx = self._upload(a, b, shared_mode)
+        ctx.set_weights(w_full, None if mask.all() else mask)
+        return ctx.normal_eq()
+
+    def _fit_statistics(self, a=None, b=None, w=None, fs_dict=None, trainall=False):
+        """mask x weight x normal equations on this rank's GPU, summed over ranks.
+
+        Returns (G, c, scalars) as host ndarrays on every rank (scalars = [bw.bw, sum(bw),
+        n_train]); also stored in ``self.last_statistics``."""
+        pt = self.pt
+        a, b, w_full, mask, shared_mode = self._resolve_inputs(a, b, w, fs_dict, trainall)
+        if a.ndim != 2:
+            raise ValueError("the A matrix must be 2-D")
+        K = a.shape[1]
+        n = K * K + K + 3
+        have_rows = a.shape[0] > 0
+        if pt.stubs or pt._size == 1:
+            G, c, s = self._local_statistics(a, b, w_full, mask, shared_mode) if have_rows else \
+                (np.zeros((K, K)), np.zeros(K), np.zeros(3))
+        else:
+            import torch
+
+            if pt._dist.get_backend(pt._group) == "nccl":
+                # statistics stay in HBM: kernel -> RCCL all-reduce on the same stream -> one D2H
+                dev = torch.device("cuda", pt.device_index())
+                packed = torch.zeros(n, dtype=torch.float64, device=dev)
+                if have_rows:
+                    self._local_statistics_async(a, b, w_full, mask, shared_mode, packed.data_ptr(),
+                                                 torch.cuda.current_stream(dev).cuda_stream)
+                pt.allreduce_statistics(packed)
+                host = packed.cpu().numpy()
+            else:
+                # CPU process group (gloo, used by the world_size-2 tests): reduce on the host
+                if have_rows:
+                    G, c, s = self._local_statistics(a, b, w_full, mask, shared_mode)
+                    host = np.concatenate([np.asarray(G).ravel(), c, s])
+                else:
+                    host = np.zeros(n)
+                packed = torch.from_numpy(np.ascontiguousarray(host))
+                pt.allreduce_statistics(packed)
+                host = packed.numpy()
+            G = host[:K * K].reshape(K, K).copy()
+            c = host[K * K:K * K + K].copy()
+            s = host[K * K + K:].copy()
+        self.last_statistics = (G, c, s)
+        return G, c, s
+
+    def _solve(self, kind, param, G, c):
+        beta, rank, _ = _capi.solve(kind, param, G, c)
+        self.last_rank = rank
+        return beta
+
+    # ------------------------------------------------------------------------------
+    # downstream of the fit (solver.py:108-133, 368-435)
+    # ------------------------------------------------------------------------------
+    def _offset(self):
+        """Insert a zero B0 per type when SNAP ``bzeroflag`` is set (solver.py:78-86)."""
+        num_types = self.config.sections["BISPECTRUM"].numtypes
+        if num_types > 1:
+            self.fit = self.fit.reshape(num_types, self.config.sections["BISPECTRUM"].ncoeff)
+            offsets = np.zeros((num_types, 1))
+            self.fit = np.concatenate([offsets, self.fit], axis=1)
+            self.fit = self.fit.reshape((-1, 1))
+        else:
+            self.fit = np.insert(self.fit, 0, 0)
+        if self.fit_sam is not None:
+            if num_types > 1:
+                offsets = np.zeros((num_types, 1))
+                nsam, ncf = self.fit_sam.shape
+                fit_sam = np.empty((nsam, ncf + num_types))
+                for isam, fit in enumerate(self.fit_sam.reshape(nsam, num_types, self.config.sections["BISPECTRUM"].ncoeff)):
+                    fit = np.concatenate([offsets, fit], axis=1)
+                    fit_sam[isam, :] = fit.reshape((-1,))
+                self.fit_sam = fit_sam + 0.0
+            else:
+                self.fit_sam = np.insert(self.fit_sam, 0, 0, axis=1)
+
+    @staticmethod
+    def _ncount_mae_rmse_rsq_unweighted_and_weighted(g):
+        """solver.py:108-133."""
+        from pandas import Series
+
+        res = g["truths"] - g["preds"]
+        mae = np.mean(abs(res))
+        ssr = np.square(res).sum()
+        nconfig = len(g["truths"])
+        mse = ssr / nconfig
+        rmse = np.sqrt(mse)
+        rsq = 1 - ssr / np.sum(np.square(g["truths"] - (g["truths"] / nconfig).sum()))
+        w_res = g["weights"] * (g["truths"] - g["preds"])
+        w_mae = np.mean(abs(w_res))
+        w_ssr = np.square(w_res).sum()
+        w_nconfig = np.count_nonzero(g["weights"])
+        w_mse = w_ssr / w_nconfig
+        w_rmse = np.sqrt(w_mse)
+        w_rsq = 1 - w_ssr / np.sum(np.square((g["weights"] * g["truths"]) - (g["weights"] * g["truths"] / w_nconfig).sum()))
+        return Series({"ncount": nconfig, "mae": mae, "rmse": rmse, "rsq": rsq, "w_ncount": w_nconfig,
+                       "w_mae": w_mae, "w_rmse": w_rmse, "w_rsq": w_rsq})
+
+    def predict_rows(self, a=None, b=None):
+        """``preds = a @ self.fit`` (solver.py:377) on the GPU (streaming GEMV kernel)."""
+        if a is None:
+            a, b = self.pt.shared_arrays["a"].array, self.pt.shared_arrays["b"].array
+            ctx = self._upload(a, b, True)
+        else:
+            a = np.asarray(a)
+            if b is None:
+                b = np.zeros(a.shape[0])
+            ctx = self._upload(a, np.asarray(b), False)
+        preds, _ = ctx.predict(np.asarray(self.fit, dtype=np.float64).reshape(-1))
+        return preds
+
+    def error_analysis(self, a=None, b=None, w=None, fs_dict=None):
+        """Linear part of the reference's error analysis (solver.py:368-435): per
+        (group, train/test, row type) weighted and unweighted count / MAE / RMSE / R^2,
+        then the bzeroflag offset.  Predictions come from the GPU GEMV kernel."""
+        from pandas import DataFrame, concat
+
+        self.errors = []
+        if self.pt._rank != 0:
+            return
+        if a is None and b is None and w is None and fs_dict is None:
+            a = self.pt.shared_arrays["a"].array
+            b = self.pt.shared_arrays["b"].array
+            w = self.pt.shared_arrays["w"].array
+            fs_dict = self.pt.fitsnap_dict
+            preds = self.predict_rows() if self.fit is not None else None
+        else:
+            preds = self.predict_rows(a, b) if self.fit is not None else None
+        self.df = DataFrame(a)
+        self.df["truths"] = np.asarray(b).tolist()
+        if preds is not None:
+            self.df["preds"] = preds
+        self.df["weights"] = np.asarray(w).tolist()
+        for key in fs_dict.keys():
+            if isinstance(fs_dict[key], list) and len(fs_dict[key]) == len(self.df.index):
+                self.df[key] = fs_dict[key]
+        if self.config.sections["EXTRAS"].dump_dataframe:
+            self.df.to_pickle(self.config.sections["EXTRAS"].dataframe_file)
+        if self.fit is not None and not self.config.sections["SOLVER"].true_multinode:
+            fn = self._ncount_mae_rmse_rsq_unweighted_and_weighted
+            cols = [["ncount", "mae", "rmse", "rsq"], ["w_ncount", "w_mae", "w_rmse", "w_rsq"]]
+            ren = {"w_ncount": "ncount", "w_mae": "mae", "w_rmse": "rmse", "w_rsq": "rsq"}
+            grouped = self.df.groupby(["Groups", "Testing", "Row_Type"])[["truths", "preds", "weights"]].apply(fn)
+            grouped = concat({"Unweighted": grouped[cols[0]], "weighted": grouped[cols[1]].rename(columns=ren)},
+                             names=["Weighting"]).reorder_levels(["Groups", "Weighting", "Testing", "Row_Type"]).sort_index()
+            allrows = self.df.groupby(["Testing", "Row_Type"])[["truths", "preds", "weights"]].apply(fn)
+            allrows = concat({"Unweighted": allrows[cols[0]], "weighted": allrows[cols[1]].rename(columns=ren)},
+                             names=["Weighting"]).reorder_levels(["Weighting", "Testing", "Row_Type"]).sort_index()
+            self.errors = concat([concat({"*ALL": allrows}, names=["Groups"]), grouped])
+            self.errors.ncount = self.errors.ncount.astype(int)
+            self.errors.index.rename(["Group", "Weighting", "Testing", "Subsystem"], inplace=True)
+            self.errors.index = self.errors.index.set_levels(
+                ["Testing" if e else "Training" for e in self.errors.index.levels[2]], level=2)
+        if self.fit is not None:
+            if (self.config.sections["CALCULATOR"].calculator == "LAMMPSSNAP"
+                    and "BISPECTRUM" in self.config.sections and self.config.sections["BISPECTRUM"].bzeroflag):
+                self._offset()

@@ -1,0 +1,51 @@
+"""SVD solver behind the reference's plugin API (fitsnap3lib/solvers/svd.py:13-54)."""
+from __future__ import annotations
+
+from sys import float_info as fi
+
+import numpy as np
+
+from .. import _capi
+from .solver import Solver
+
+
+class SVD(Solver):
+    """``perform_fit`` = reference semantics of ``lstsq(aw, bw, 1.0e-13)`` (svd.py:54),
+    computed from the GPU normal-equation statistics: Jacobi-scaled Cholesky with one
+    refinement step when the system is numerically full rank, truncated eigen
+    pseudo-inverse (minimum-norm, gelsd-like) otherwise.  Exactly-zero columns get a zero
+    coefficient, as lstsq's minimum-norm solution gives them."""
+
+    RCOND = 1.0e-13  # svd.py:54
+
+    def __init__(self, name, pt, config):
+        super().__init__(name, pt, config)
+
+    def perform_fit(self, a=None, b=None, w=None, fs_dict=None, trainall=False):
+        """
+        Perform fit on a linear system. If no args are supplied, will use fitting data in `pt.shared_arrays`.
+
+        Args:
+            a (np.array): Optional "A" matrix.
+            b (np.array): Optional Truth array.
+            w (np.array): Optional Weight array (one entry per TRAINING row, as in the reference).
+            fs_dict (dict): Optional dictionary containing a `Testing` key of which A matrix rows should not be trained.
+            trainall (bool): Optional boolean declaring whether to train on all samples in the A matrix.
+
+        The fit is stored as a member `fs.solver.fit` (rank 0 only).
+        """
+        pt = self.pt
+        # every rank contributes its rows' statistics; only rank 0 solves (svd.py:33)
+        G, c, _ = self._fit_statistics(a, b, w, fs_dict, trainall)
+        if pt._rank == 0:
+            rcond = self.RCOND
+            if "EXTRAS" in self.config.sections and self.config.sections["EXTRAS"].apply_transpose:
+                # svd.py:48-53: lstsq on (aw.T aw, aw.T bw) when cond(aw)^2 < 1/eps, i.e. the
+                # 1e-13 cut then applies to the singular values of G itself (= eigenvalues)
+                ev = np.linalg.eigvalsh(G)
+                cond2 = abs(ev[-1]) / max(abs(ev[0]), np.finfo(float).tiny)
+                if cond2 < 1 / fi.epsilon:
+                    rcond = np.sqrt(self.RCOND)
+                else:
+                    print("The Matrix is ill-conditioned for the transpose trick")
+            self.fit = self._solve(_capi.SOLVE_LSTSQ, rcond, G, c)

@@ -1,0 +1,151 @@
+/* fsnap_hip.h — C ABI of libfsnap_hip.so: the MI355X (gfx950) linear-fit hot path for
+ * FitSNAP, callable from the reference's Python over ctypes.
+ *
+ * Boundary rules: extern "C"; plain pointers and sizes only (no torch / numpy types);
+ * every function returns an int status — 0 = ok, negative = argument / runtime error
+ * (text via fsnap_last_error), positive = numerical failure (e.g. non-SPD normal
+ * matrix); no C++ exception ever crosses the boundary.  The caller owns every buffer it
+ * passes.  Matrices are row-major fp64; sizes are int64_t; the training mask is uint8_t
+ * with 1 = training row (the negation of the reference's fitsnap_dict['Testing']).
+ * A context is bound to ONE GPU (one process per GPU; multi-GPU is done by the host
+ * layer with one context per rank and an RCCL all-reduce of the packed statistics).
+ * Calls on one context must not be made concurrently from several threads; the ctypes
+ * shim releases the GIL for the duration of each call.
+ *
+ * Each entry point names the reference code it replaces (file:line in FitSNAP/FitSNAP
+ * at the surveyed revision).
+ */
+#ifndef FSNAP_HIP_H
+#define FSNAP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fsnap_ctx fsnap_ctx;
+
+/* status codes */
+#define FSNAP_OK 0
+#define FSNAP_E_ARG (-1)      /* bad argument (null pointer, size, unsupported K ...) */
+#define FSNAP_E_HIP (-2)      /* HIP runtime error; text in fsnap_last_error          */
+#define FSNAP_E_STATE (-3)    /* call order (no rows uploaded, no weights ...)        */
+#define FSNAP_E_NOMEM (-4)    /* device / host allocation failed -> MemoryError       */
+#define FSNAP_NUM_NOT_SPD 1   /* normal matrix not positive definite -> LinAlgError   */
+#define FSNAP_NUM_SINGULAR 2  /* exactly singular system -> LinAlgError               */
+#define FSNAP_NUM_NONFINITE 3 /* NaN/Inf in the statistics -> ValueError              */
+
+/* solve kinds for fsnap_solve */
+#define FSNAP_SOLVE_CHOL 0       /* G beta = c, SPD required                                        */
+#define FSNAP_SOLVE_LSTSQ 1      /* min-norm least squares, param = rcond  (svd.py:54 lstsq(aw,bw,1e-13)) */
+#define FSNAP_SOLVE_RIDGE 2      /* (G + alpha I) beta = c, param = alpha (ridge.py:47-57, sklearn Ridge) */
+#define FSNAP_SOLVE_RIDGE_INV 3  /* beta = inv(G + alpha I) c             (regressor.py:10-16 Local_Ridge) */
+
+/* packed statistics buffer: [ G (K*K row-major) | c (K) | bTb, sum(w*b), n_train ] */
+#define FSNAP_PACKED_LEN(K) ((int64_t)(K) * (K) + (K) + 3)
+
+/* ---- library / context ------------------------------------------------------------ */
+
+/* ABI version (major*100 + minor). */
+int fsnap_version(void);
+
+/* Number of visible HIP devices. */
+int fsnap_device_count(int* count);
+
+/* Create a context on HIP device `device` (own non-blocking stream, timing events).
+ * Replaces nothing in the reference: the reference's solvers are rank-0 numpy. */
+int fsnap_ctx_create(int device, fsnap_ctx** ctx);
+int fsnap_ctx_destroy(fsnap_ctx* ctx);
+
+/* Run all subsequent work of this context on the caller's hipStream_t (e.g.
+ * torch.cuda.current_stream().cuda_stream) so that RCCL collectives issued by the host
+ * layer order after the kernels without a host sync.  NULL restores the own stream. */
+int fsnap_ctx_set_stream(fsnap_ctx* ctx, void* hip_stream);
+
+/* Tuning knobs (all optional): "split" (1|2, sub-waves per row-wave), "nontemporal"
+ * (0|1), "nblocks" (workgroups of the SYRK kernel; 0 = auto), "refine" (0|1).
+ * Unknown key -> FSNAP_E_ARG. */
+int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value);
+
+/* Last error text of this context (or of the library when ctx is NULL).  Never NULL. */
+const char* fsnap_last_error(const fsnap_ctx* ctx);
+
+/* ---- rows: the A matrix and truth vector ----------------------------------------- */
+
+/* Copy the m x K row-major fp64 matrix A (leading dimension lda doubles) and b[m] from
+ * host memory into HBM; they stay resident for any number of re-weightings / fits.
+ * Device-side counterpart of pt.shared_arrays['a'|'b'].array
+ * (fitsnap3lib/parallel_tools.py:352-389, 944-1077; calculator.py:287-288). */
+int fsnap_upload_rows(fsnap_ctx* ctx, const double* A, int64_t m, int64_t K, int64_t lda, const double* b);
+
+/* Same, but A and b already live in device memory (not copied, not owned; the A
+ * allocation must be readable for 16 bytes past its last element). */
+int fsnap_bind_rows(fsnap_ctx* ctx, const double* dA, int64_t m, int64_t K, int64_t lda, const double* db);
+
+/* Row weights w[m] and training mask[m] (1 = train; NULL = all rows train) from host
+ * memory.  pt.shared_arrays['w'].array and `training = [not elem for elem in
+ * fitsnap_dict['Testing']]` (svd.py:35-44, ridge.py:28-37, ard.py:18-19). */
+int fsnap_set_weights(fsnap_ctx* ctx, const double* w, const uint8_t* mask);
+
+/* Same with device pointers (not copied, not owned). */
+int fsnap_bind_weights(fsnap_ctx* ctx, const double* dw, const uint8_t* dmask);
+
+/* ---- hot path --------------------------------------------------------------------- */
+
+/* Fused mask x weight x normal equations on the resident rows:
+ *   aw = w[:,None]*A[training]; bw = w*b[training]          (svd.py:44-46, ridge.py:37-39)
+ *   G = aw.T @ aw; c = aw.T @ bw                            (svd.py:50-51, ridge.py:42-43,
+ *                                                            regressor.py:11-12,
+ *                                                            transpose_trick/example.py:234-240)
+ * without materialising aw.  Outputs (host, any may be NULL): G[K*K], c[K],
+ * scalars[3] = { bw.bw, sum(bw), n_train }.  Synchronous. */
+int fsnap_normal_eq(fsnap_ctx* ctx, double* G, double* c, double* scalars);
+
+/* Asynchronous form: launches on the context's stream and leaves the packed statistics
+ * (FSNAP_PACKED_LEN(K) doubles) in DEVICE memory at d_packed — the buffer the host
+ * layer all-reduces with RCCL (the reference's comm.Allreduce of c and d,
+ * examples/library/transpose_trick/example.py:245-246). */
+int fsnap_normal_eq_async(fsnap_ctx* ctx, double* d_packed);
+
+/* Stand-alone wavefront row weighting: aw = w[:,None]*A, bw = w*b for ALL m rows
+ * (masked rows are written as zeros); host outputs, leading dimension ldaw.
+ * svd.py:46 / ridge.py:39 / solver.py:75 for callers that need aw, bw themselves. */
+int fsnap_weight_rows(fsnap_ctx* ctx, double* aw, int64_t ldaw, double* bw);
+
+/* Same with device outputs, asynchronous on the context's stream. */
+int fsnap_weight_rows_device(fsnap_ctx* ctx, double* d_aw, int64_t ldaw, double* d_bw);
+
+/* preds = A @ beta (solver.py:377) for all m rows; host in/out.  preds may be NULL.
+ * If sse is not NULL it receives sum over training rows of (w*(b - A beta))^2 using
+ * the current weights (sklearn ARDRegression's per-iteration `rmse_`). */
+int fsnap_predict(fsnap_ctx* ctx, const double* beta, double* preds, double* sse);
+
+/* ---- K x K solve (host side, no context needed) ----------------------------------- */
+
+/* Solve the K x K system given the statistics.  `kind` is one of FSNAP_SOLVE_*;
+ * `param` is rcond (LSTSQ) or alpha (RIDGE, RIDGE_INV), ignored for CHOL.
+ * beta[K] out; *rank (may be NULL) receives the numerical rank used; *rcond_est (may be
+ * NULL) an estimate of 1/cond of the (Jacobi-scaled) matrix that was factorised.
+ * Replaces scipy.linalg.lstsq (svd.py:54), sklearn Ridge's Cholesky solve
+ * (ridge.py:47-57) and np.linalg.inv (regressor.py:15). */
+int fsnap_solve(int kind, double param, int64_t K, const double* G, const double* c, double* beta, int* rank,
+                double* rcond_est);
+
+/* ---- measurement ------------------------------------------------------------------ */
+
+/* HIP-event timings of the last fsnap_normal_eq* call, milliseconds:
+ * ms[0] = SYRK kernel, ms[1] = partial reduction kernel, ms[2] = last H2D upload,
+ * ms[3] = last stand-alone weighting kernel, ms[4] = last predict kernel.
+ * Synchronises the context's stream.  n = number of entries of ms to fill (<= 8). */
+int fsnap_timing(fsnap_ctx* ctx, double* ms, int n);
+
+/* Launch geometry of the SYRK kernel for the current rows: info[0] = workgroups,
+ * info[1] = threads per workgroup, info[2] = 4-row chunks per row-wave, info[3] = NB
+ * (16-column blocks), info[4] = split, info[5] = compute units of the device. */
+int fsnap_launch_info(fsnap_ctx* ctx, int64_t* info, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSNAP_HIP_H */

@@ -1,0 +1,226 @@
+"""CPU oracle for the FitSNAP linear-fit hot path.  TEST INFRASTRUCTURE ONLY.
+
+This module restates, in plain numpy/scipy, the reference algorithm that the HIP path
+replaces.  It is the *checker*: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.  Nothing under ``fitsnap_amd/``
+imports it; the product path fails loudly when the HIP library is missing instead of
+falling back to this code.
+
+Pinning: every function below is checked in ``tests/test_oracle_golden.py`` against
+golden vectors produced by importing the *reference itself* in the build container
+(``tests/golden/make_golden.py`` -> ``tests/golden/ta_reference_fits.npz``) and against
+the reference's committed ``Ta_pot.snapcoeff`` / ``Ta_metrics.md``.  ARD is the one
+exception: the reference's ARD class does not run on scikit-learn >= 1.5
+(``n_iter=`` keyword, fitsnap3lib/solvers/ard.py:40-45) and no reference test pins its
+output, so ``ard_fit`` is **parity unpinned** beyond vectors captured from a direct
+scikit-learn call.
+
+Reference citations are file:line into FitSNAP/FitSNAP (/root/reference at build time).
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg
+
+
+# --------------------------------------------------------------------------------------
+# mask + weighting
+# --------------------------------------------------------------------------------------
+def training_mask(m, testing=None):
+    """fitsnap3lib/solvers/svd.py:35-40 (same in ridge.py:28-33, ard.py:18).
+
+    ``training = [not elem for elem in fs_dict['Testing']]``; ``trainall`` -> all True.
+    Returns a boolean ndarray (the reference builds a Python list and fancy-indexes).
+    """
+    if testing is None:
+        return np.ones(m, dtype=bool)
+    return ~np.asarray(testing, dtype=bool)
+
+
+def weight_rows(a, b, w, testing=None):
+    """fitsnap3lib/solvers/svd.py:44-46: ``aw, bw = w[:,None]*a[training], w*b[training]``."""
+    tr = training_mask(len(b), testing)
+    wt = np.asarray(w, dtype=np.float64)[tr]
+    aw = wt[:, np.newaxis] * np.asarray(a, dtype=np.float64)[tr]
+    bw = wt * np.asarray(b, dtype=np.float64)[tr]
+    return aw, bw
+
+
+def weight_rows_full(a, b, w, testing=None):
+    """All m rows, masked rows zeroed — the layout ``fsnap_weight_rows`` writes (the
+    reference compacts rows instead, svd.py:46; row order/zero rows do not change G, c)."""
+    tr = training_mask(len(b), testing)
+    wt = np.where(tr, np.asarray(w, dtype=np.float64), 0.0)
+    aw = np.where(tr[:, None], wt[:, None] * np.asarray(a, dtype=np.float64), 0.0)
+    bw = np.where(tr, wt * np.asarray(b, dtype=np.float64), 0.0)
+    return aw, bw
+
+
+# --------------------------------------------------------------------------------------
+# normal equations (the "transpose trick")
+# --------------------------------------------------------------------------------------
+def normal_eq(a, b, w, testing=None):
+    """G = aw.T @ aw, c = aw.T @ bw and the scalar statistics.
+
+    fitsnap3lib/solvers/svd.py:50-51, ridge.py:42-43, ard.py:23-24,
+    fitsnap3lib/lib/ridge_solver/regressor.py:11-12,
+    examples/library/transpose_trick/example.py:234-240 (per-configuration
+    ``c += aw.T@aw; d += aw.T@bw`` followed by Allreduce at :245-246).
+    Returns (G, c, scalars) with scalars = [bw.bw, sum(bw), n_train].
+    """
+    aw, bw = weight_rows(a, b, w, testing)
+    G = aw.T @ aw
+    c = aw.T @ bw
+    scal = np.array([bw @ bw, bw.sum(), float(len(bw))])
+    return G, c, scal
+
+
+# --------------------------------------------------------------------------------------
+# solvers
+# --------------------------------------------------------------------------------------
+def svd_fit(a, b, w, testing=None, apply_transpose=False):
+    """fitsnap3lib/solvers/svd.py:44-54.
+
+    ``lstsq(aw, bw, 1.0e-13)`` (LAPACK gelsd); with EXTRAS.apply_transpose the system is
+    replaced by (aw.T aw, aw.T bw) when ``cond(aw)**2 < 1/eps`` (svd.py:48-53).
+    """
+    aw, bw = weight_rows(a, b, w, testing)
+    if apply_transpose:
+        if np.linalg.cond(aw) ** 2 < 1 / np.finfo(float).eps:
+            bw = aw.T @ bw
+            aw = aw.T @ aw
+    fit, _res, _rank, _s = scipy.linalg.lstsq(aw, bw, 1.0e-13)
+    return fit
+
+
+def local_ridge(X, y, alpha):
+    """fitsnap3lib/lib/ridge_solver/regressor.py:10-16: ``inv(X.T X + alpha I) @ X.T y``."""
+    xty = np.matmul(X.T, y)
+    xtx = np.matmul(X.T, X)
+    normal = xtx + alpha * np.eye(xtx.shape[0])
+    return np.matmul(np.linalg.inv(normal), xty)
+
+
+def sklearn_ridge_dense(X, y, alpha):
+    """What ``sklearn.linear_model.Ridge(alpha, fit_intercept=False).fit(X, y)`` computes
+    for a dense X with n_samples > n_features (third-party: scikit-learn 1.7.2,
+    linear_model/_ridge.py ``_solve_cholesky``: ``A = X.T X; A.flat[::n+1] += alpha;
+    scipy.linalg.solve(A, X.T y, assume_a='pos')``), as used at
+    fitsnap3lib/solvers/ridge.py:47-57.  For n_samples <= n_features sklearn uses the
+    kernel form; the call sites here always have m >> K except with apply_transpose,
+    where X is K x K and both forms are the same linear system."""
+    n = X.shape[1]
+    if X.shape[0] > n:
+        A = X.T @ X
+        Xy = X.T @ y
+        A.flat[:: n + 1] += alpha
+        return scipy.linalg.solve(A, Xy, assume_a="pos", overwrite_a=True)
+    Kmat = X @ X.T
+    Kmat.flat[:: Kmat.shape[0] + 1] += alpha
+    dual = scipy.linalg.solve(Kmat, y, assume_a="pos", overwrite_a=True)
+    return X.T @ dual
+
+
+def ridge_fit(a, b, w, alpha=1.0e-8, local_solver=False, testing=None, apply_transpose=False):
+    """fitsnap3lib/solvers/ridge.py:37-59 (alpha default io/sections/solver_sections/ridge.py:13)."""
+    aw, bw = weight_rows(a, b, w, testing)
+    if apply_transpose:
+        bw = aw.T @ bw
+        aw = aw.T @ aw
+    if local_solver:
+        return local_ridge(aw, bw, alpha)
+    return sklearn_ridge_dense(aw, bw, alpha)
+
+
+def ard_hyper(bw, scap=1.0e-3, scai=1.0e-3, logcut=0.3):
+    """Hyper-parameters of the non-direct ARD method, fitsnap3lib/solvers/ard.py:26-43."""
+    ap = 1.0 / np.var(bw)
+    return dict(alpha_1=scap * ap, alpha_2=scap * ap, lambda_1=ap * scai, lambda_2=ap * scai,
+                threshold_lambda=10 ** (int(np.abs(np.log10(ap))) + logcut))
+
+
+def ard_fit(a, b, w, testing=None, directmethod=False, alphabig=1.0e-12, lambdasmall=1.0e-6,
+            threshold_lambda=100000, scap=1.0e-3, scai=1.0e-3, logcut=0.3, max_iter=1000):
+    """fitsnap3lib/solvers/ard.py:18-48 with ``n_iter`` spelled ``max_iter`` (PARITY
+    UNPINNED, see module docstring).  Third-party arithmetic: scikit-learn ARDRegression."""
+    from sklearn.linear_model import ARDRegression
+
+    aw, bw = weight_rows(a, b, w, testing)
+    if directmethod:
+        reg = ARDRegression(max_iter=max_iter, threshold_lambda=threshold_lambda, alpha_1=alphabig,
+                            alpha_2=alphabig, lambda_1=lambdasmall, lambda_2=lambdasmall, fit_intercept=False)
+    else:
+        reg = ARDRegression(max_iter=max_iter, fit_intercept=False, **ard_hyper(bw, scap, scai, logcut))
+    reg.fit(aw, bw)
+    return reg.coef_
+
+
+# --------------------------------------------------------------------------------------
+# downstream of the fit
+# --------------------------------------------------------------------------------------
+def predict(a, fit):
+    """fitsnap3lib/solvers/solver.py:377: ``preds = a @ fit``."""
+    return np.asarray(a) @ np.asarray(fit)
+
+
+def error_row(truths, preds, weights):
+    """fitsnap3lib/solvers/solver.py:108-133 (``_ncount_mae_rmse_rsq_unweighted_and_weighted``)."""
+    truths = np.asarray(truths, dtype=np.float64)
+    preds = np.asarray(preds, dtype=np.float64)
+    weights = np.asarray(weights, dtype=np.float64)
+    res = truths - preds
+    n = len(truths)
+    ssr = np.square(res).sum()
+    out = {"ncount": n, "mae": np.mean(np.abs(res)), "rmse": np.sqrt(ssr / n),
+           "rsq": 1 - ssr / np.sum(np.square(truths - (truths / n).sum()))}
+    w_res = weights * res
+    w_n = np.count_nonzero(weights)
+    w_ssr = np.square(w_res).sum()
+    out.update({"w_ncount": w_n, "w_mae": np.mean(np.abs(w_res)), "w_rmse": np.sqrt(w_ssr / w_n),
+                "w_rsq": 1 - w_ssr / np.sum(np.square(weights * truths - (weights * truths / w_n).sum()))})
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# synthetic workload of SURVEY.md 8(d) / BASELINE.md 2 (shared by bench.py and the tests)
+# --------------------------------------------------------------------------------------
+SYNTH_SEED = 20250926
+SYNTH_CHUNK = 65536
+
+
+def synth_chunk(chunk_index, rows, K, beta_star, scales):
+    """One <=64Ki-row chunk of the synthetic A/b/w: A = N(0,1)*s_j, b = A beta* + 1e-3 N(0,1),
+    w in {100, 1, 1e-8} with p = {0.03, 0.83, 0.14}."""
+    rng = np.random.default_rng([SYNTH_SEED, chunk_index])
+    A = rng.standard_normal((rows, K)) * scales
+    b = A @ beta_star + 1.0e-3 * rng.standard_normal(rows)
+    u = rng.random(rows)
+    w = np.where(u < 0.03, 100.0, np.where(u < 0.86, 1.0, 1.0e-8))
+    return A, b, w
+
+
+def synth_params(K):
+    scales = 10.0 ** (-4.0 * np.arange(K) / max(K - 1, 1))
+    beta_star = np.random.default_rng(1).standard_normal(K) / scales
+    return scales, beta_star
+
+
+def synth_problem(m, K, row_offset=0):
+    """Rows [row_offset, row_offset+m) of the synthetic problem (chunk-aligned offsets)."""
+    assert row_offset % SYNTH_CHUNK == 0
+    scales, beta_star = synth_params(K)
+    A = np.empty((m, K))
+    b = np.empty(m)
+    w = np.empty(m)
+    done = 0
+    ci = row_offset // SYNTH_CHUNK
+    while done < m:
+        rows = min(SYNTH_CHUNK, m - done)
+        A[done:done + rows], b[done:done + rows], w[done:done + rows] = synth_chunk(ci, rows, K, beta_star, scales)
+        done += rows
+        ci += 1
+    return A, b, w
+
+
+def synth_testing_mask(m, frac=0.1):
+    return np.random.default_rng(2).random(m) < frac

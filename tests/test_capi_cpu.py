@@ -1,0 +1,104 @@
+"""CPU: the C-ABI library loads, exports every symbol include/fsnap_hip.h declares, and its
+host-side K x K solve reproduces the reference's fits from oracle-computed statistics.
+No GPU compute is called here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from fitsnap_amd import _capi, build
+from oracle import fitsnap_oracle as orc
+
+from conftest import ROOT, maxrel
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "fsnap_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fsnap_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_builds_and_loads():
+    path = build.build_library()
+    assert os.path.exists(path)
+    lib = _capi.load_library()
+    assert lib.fsnap_version() >= 100
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = _capi.load_library()
+    declared = _declared_functions()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in fsnap_hip.h but not exported"
+        assert name in _capi.SIGNATURES, f"{name} has no ctypes prototype"
+    assert sorted(_capi.SIGNATURES) == declared
+
+
+def test_no_gpu_means_loud_failure():
+    if _capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_capi.FsnapError, match="no CPU fallback"):
+        _capi.HipContext(0)
+
+
+@pytest.mark.parametrize("kind,param,key,tol", [
+    (_capi.SOLVE_LSTSQ, 1e-13, "svd_all", 1e-6),
+    (_capi.SOLVE_CHOL, 0.0, "svd_all", 1e-6),
+    (_capi.SOLVE_RIDGE, 1e-8, "ridge_sklearn_1e-8_all", 1e-6),
+    (_capi.SOLVE_RIDGE_INV, 1e-8, "ridge_local_1e-8_all", 1e-6),
+    (_capi.SOLVE_RIDGE, 1e-4, "ridge_sklearn_1e-4_all", 1e-6),
+    (_capi.SOLVE_RIDGE_INV, 1e-4, "ridge_local_1e-4_all", 1e-6),
+])
+def test_solve_matches_reference_fits(ta, ta_fits, kind, param, key, tol):
+    A, b, w = ta
+    G, c, _ = orc.normal_eq(A, b, w)
+    beta, rank, _ = _capi.solve(kind, param, G, c)
+    assert rank == 31
+    assert maxrel(beta, ta_fits[key]) < tol          # north_star: 1e-6 relative
+    assert np.max(np.abs(beta - ta_fits[key])) < 1e-6  # reference's own bar (example_checker.py:62)
+
+
+def test_solve_zero_column_gets_zero_coefficient():
+    # lstsq's minimum-norm solution puts 0 on an identically-zero column (e.g. blank2J-masked
+    # SNAP columns, lammps_snap.py:467-468)
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((200, 6))
+    X[:, 2] = 0.0
+    y = rng.standard_normal(200)
+    ref = np.linalg.lstsq(X, y, rcond=1e-13)[0]
+    beta, rank, _ = _capi.solve(_capi.SOLVE_LSTSQ, 1e-13, X.T @ X, X.T @ y)
+    assert rank == 5 and beta[2] == 0.0
+    assert maxrel(beta[[0, 1, 3, 4, 5]], ref[[0, 1, 3, 4, 5]]) < 1e-10
+
+
+def test_solve_rank_deficient_is_minimum_norm():
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((300, 5))
+    X = np.hstack([X, X[:, :1] + X[:, 1:2]])          # exactly dependent column
+    y = rng.standard_normal(300)
+    ref, _, rk, _ = np.linalg.lstsq(X, y, rcond=1e-13)
+    beta, rank, _ = _capi.solve(_capi.SOLVE_LSTSQ, 1e-13, X.T @ X, X.T @ y)
+    assert rank == rk == 5
+    assert np.max(np.abs(beta - ref)) < 1e-8
+
+
+def test_solve_error_mapping():
+    G = np.array([[1.0, 2.0], [2.0, 1.0]])            # indefinite
+    with pytest.raises(np.linalg.LinAlgError):
+        _capi.solve(_capi.SOLVE_CHOL, 0.0, G, np.ones(2))
+    with pytest.raises(np.linalg.LinAlgError):
+        _capi.solve(_capi.SOLVE_RIDGE_INV, 0.0, np.zeros((2, 2)), np.ones(2))   # np.linalg.inv: Singular matrix
+    with pytest.raises(ValueError):
+        _capi.solve(_capi.SOLVE_RIDGE, 1e-8, np.array([[np.nan, 0.0], [0.0, 1.0]]), np.ones(2))
+    with pytest.raises(ValueError):
+        _capi.solve(_capi.SOLVE_RIDGE, 1e-8, np.eye(3), np.ones(2))
+
+
+def test_solve_k128_synthetic():
+    A, b, w = orc.synth_problem(20000, 128)
+    G, c, _ = orc.normal_eq(A, b, w)
+    beta, rank, _ = _capi.solve(_capi.SOLVE_RIDGE, 1e-8, G, c)
+    assert rank == 128
+    assert maxrel(beta, orc.ridge_fit(A, b, w, 1e-8)) < 1e-6

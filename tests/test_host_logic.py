@@ -1,0 +1,130 @@
+"""CPU: host-side mirror of the reference's plugin surface (config, factory, ParallelTools,
+mask/weight resolution) — no GPU."""
+import numpy as np
+import pytest
+
+from fitsnap_amd.config import Config, snap_ncoeff
+from fitsnap_amd.parallel_tools import DistributedList, ParallelTools, SharedArray
+from fitsnap_amd.solvers import solver_factory
+from fitsnap_amd.solvers.solver import Solver
+
+
+def make(solver="SVD", extra=None):
+    pt = ParallelTools()
+    d = {"SOLVER": {"solver": solver}}
+    d.update(extra or {})
+    cfg = Config(pt, d)
+    return pt, cfg, solver_factory.solver(solver, pt, cfg)
+
+
+def test_factory_discovers_by_class_name_case_insensitively():
+    # fitsnap3lib/solvers/solver_factory.py:18-34
+    for name, cls in (("svd", "SVD"), ("Ridge", "RIDGE"), ("ARD", "ARD")):
+        _, _, s = make(name)
+        assert type(s).__name__ == cls and isinstance(s, Solver) and s.linear and s.fit is None
+    with pytest.raises(IndexError, match="was not found in fitsnap solvers"):
+        solver_factory.search("nonesuch")
+
+
+def test_config_defaults_match_reference():
+    pt = ParallelTools()
+    cfg = Config(pt, {"SOLVER": {"solver": "RIDGE"}})
+    assert cfg.sections["RIDGE"].alpha == 1.0e-8 and cfg.sections["RIDGE"].local_solver is False
+    cfg = Config(pt, {"SOLVER": {"solver": "ARD"}})
+    a = cfg.sections["ARD"]
+    assert (a.scap, a.scai, a.logcut, a.directmethod, a.threshold_lambda) == (1e-3, 1e-3, 0.3, 0, 100000)
+    assert cfg.sections["EXTRAS"].apply_transpose is False
+    assert snap_ncoeff(6) == 30 and snap_ncoeff(8) == 55      # bispectrum.py:80-91
+
+
+def test_section_for_unselected_solver_raises_userwarning():
+    with pytest.raises(UserWarning):                              # sections.py:93-97
+        Config(ParallelTools(), {"SOLVER": {"solver": "SVD"}, "RIDGE": {"alpha": 1e-4}})
+    with pytest.raises(RuntimeError):
+        Config(ParallelTools(), {"SOLVER": {"solver": "RIDGE"}, "RIDGE": {"alfa": 1e-4}})
+
+
+def test_config_from_ini(tmp_path):
+    p = tmp_path / "in.in"
+    p.write_text("[SOLVER]\nsolver = RIDGE\n[RIDGE]\nalpha = 1.0E-4\nlocal_solver = 1\n"
+                 "[BISPECTRUM]\nnumTypes = 2\ntwojmax = 8\nbzeroflag = 1\ntype = W Be\n[EXTRAS]\ndump_descriptors = 1\n")
+    cfg = Config(ParallelTools(), str(p), ["--overwrite"])
+    assert cfg.sections["RIDGE"].alpha == 1e-4 and cfg.sections["RIDGE"].local_solver is True
+    assert cfg.sections["BISPECTRUM"].ncoeff == 55 and cfg.sections["BISPECTRUM"].numtypes == 2
+    assert cfg.sections["EXTRAS"].dump_a is True and cfg.args.overwrite
+
+
+def test_shared_array_contract():
+    # fitsnap3lib/parallel_tools.py:352-389, 944-1077
+    pt = ParallelTools()
+    assert pt.stubs == 1 and pt._rank == 0 and pt._size == 1
+    pt.create_shared_array("a", 10, 4)
+    pt.create_shared_array("b", 10)
+    pt.create_shared_array("n", 5, dtype="i")
+    a = pt.shared_arrays["a"]
+    assert isinstance(a, SharedArray) and a.array.shape == (10, 4) and a.array.flags["C_CONTIGUOUS"]
+    assert pt.shared_arrays["b"].array.shape == (10,) and pt.shared_arrays["n"].array.dtype == np.int32
+    assert a.get_memory() == 320 and a.sliced_array is None and a.energies_index is None
+    assert not a.array.any()
+    with pytest.raises(TypeError):
+        pt.create_shared_array(3, 10)
+    with pytest.raises(TypeError):
+        pt.create_shared_array("x", 10, dtype="f")
+    old = a
+    pt.create_shared_array("a", 6, 4)            # re-creating a name frees the old one first
+    assert old.array is None and pt.shared_arrays["a"].array.shape == (6, 4)
+    pt.free()
+    assert pt.shared_arrays["a"].array is None
+
+
+def test_distributed_list():
+    d = DistributedList(4)
+    d[0:2] = ["x", "y"]
+    assert d.get_list()[:2] == ["x", "y"] and len(d) == 4
+    with pytest.raises(AssertionError):
+        d[0:2] = ["only-one"]
+
+
+def test_mask_and_weight_resolution_follows_reference():
+    pt, cfg, s = make("SVD")
+    a, b = np.arange(12.0).reshape(6, 2), np.arange(6.0)
+    testing = [False, True, False, False, True, False]
+    # explicit arrays: w has one entry per TRAINING row (svd.py:46 multiplies unmasked w)
+    A, B, wf, mask, shared = s._resolve_inputs(a, b, np.array([1.0, 2, 3, 4]), {"Testing": testing}, False)
+    assert not shared and mask.tolist() == [1, 0, 1, 1, 0, 1] and wf.tolist() == [1, 0, 2, 3, 0, 4]
+    with pytest.raises(ValueError, match="could not be broadcast"):
+        s._resolve_inputs(a, b, np.ones(6), {"Testing": testing}, False)
+    # trainall
+    _, _, wf, mask, _ = s._resolve_inputs(a, b, np.ones(6), None, True)
+    assert mask.all() and wf.tolist() == [1] * 6
+    # fs_dict beats trainall; pt.fitsnap_dict is the last resort
+    _, _, _, mask, _ = s._resolve_inputs(a, b, np.ones(4), {"Testing": testing}, True)
+    assert mask.sum() == 4
+    pt.fitsnap_dict["Testing"] = testing
+    pt.create_shared_array("a", 6, 2)
+    pt.create_shared_array("b", 6)
+    pt.create_shared_array("w", 6)
+    pt.shared_arrays["w"].array[:] = 2.0
+    _, _, wf, mask, shared = s._resolve_inputs(None, None, None, None, False)
+    assert shared and mask.sum() == 4 and wf.tolist() == [2.0] * 6
+
+
+def test_perform_fit_without_gpu_raises_instead_of_falling_back():
+    from fitsnap_amd import _capi
+    if _capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    _, _, s = make("RIDGE")
+    with pytest.raises(_capi.FsnapError):
+        s.perform_fit(np.ones((8, 3)), np.ones(8), np.ones(8), trainall=True)
+    assert s.fit is None
+
+
+def test_offset_inserts_zero_b0():
+    # solver.py:78-86
+    pt = ParallelTools()
+    cfg = Config(pt, {"SOLVER": {"solver": "SVD"}, "BISPECTRUM": {"numTypes": 2, "twojmax": 2, "bzeroflag": 1, "type": "A B"}})
+    s = solver_factory.solver("SVD", pt, cfg)
+    n = cfg.sections["BISPECTRUM"].ncoeff
+    s.fit = np.arange(1.0, 2 * n + 1)
+    s._offset()
+    assert s.fit.shape == (2 * (n + 1), 1) and s.fit[0, 0] == 0 and s.fit[n + 1, 0] == 0
