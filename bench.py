@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json metric: training rows/sec through A^T A + solve on a synthetic
+10^6 x 128 fp64 A-matrix per GPU (configs[1]: RIDGE normal equations), 1/2/4/8 MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete fit of the resident rows: fused mask x weight x fp64-MFMA normal
+equations on every GPU, (N > 1) RCCL all-reduce of the packed K x K statistics, D2H of the
+statistics, K x K ridge solve -> beta on the host of rank 0.  A, b, w are resident in HBM
+before the timed region (the PCIe-inclusive rate is reported separately, never as `value`).
+Weak scaling: every rank owns 10^6 rows of its own (disjoint synthetic row blocks);
+value = N * rows_per_gpu * steps / max-over-ranks wall time.
+
+Rank 0 prints ONE JSON line (see the bench contract in the task statement) with two extra
+objects: `roofline` (fp64-MFMA roofline of the SYRK kernel, measured live with HIP events on
+the kernel's stream) and `cpu_baseline` (the oracle's restatement of the reference's numpy
+path timed on this box's host cores; N = 1 only; a reported baseline, not the target).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ROWS_PER_GPU = 1_000_000
+K = 128
+ALPHA = 1.0e-8                 # reference default, io/sections/solver_sections/ridge.py:13
+PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X vendor fp64 matrix peak
+RANK_ROW_STRIDE = 16 * 65536   # >= ROWS_PER_GPU, multiple of the generator's 64 Ki-row chunk
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default: BASELINE config)")
+    ap.add_argument("--cols", type=int, default=K)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--option", action="append", default=[], help="kernel option key=value (split, nontemporal, nblocks)")
+    return ap.parse_args()
+
+
+def cpu_baseline(A, b, w, beta_gpu):
+    """Reference algorithm (oracle restatement) on the host cores, bounded sample."""
+    from oracle import fitsnap_oracle as orc
+
+    m = len(b)
+    try:
+        from threadpoolctl import threadpool_info
+        pools = [(p.get("internal_api"), p.get("num_threads")) for p in threadpool_info()]
+        threads = max([p[1] for p in pools] + [1])
+    except Exception:
+        pools, threads = [], os.cpu_count() or 1
+    # RIDGE path of the reference (ridge.py:37-59): weighting + normal equations + Cholesky, all rows
+    t0 = time.perf_counter()
+    beta = orc.ridge_fit(A, b, w, ALPHA)
+    t_ridge = time.perf_counter() - t0
+    # SVD path (svd.py:44-54, lstsq/gelsd) on a quarter of the rows (bounded: ~3-5 s)
+    ms = min(m, 250_000)
+    t0 = time.perf_counter()
+    orc.svd_fit(A[:ms], b[:ms], w[:ms])
+    t_svd = time.perf_counter() - t0
+    rel = float(np.max(np.abs(beta_gpu - beta) / np.maximum(np.abs(beta), 1e-300)))
+    return {
+        "value": m / t_ridge, "unit": "rows/s", "cores": int(threads), "kind": "port",
+        "sample": f"oracle ridge_fit (weight + X^T X + Cholesky, reference ridge.py:37-59) on all {m} rows: "
+                  f"{t_ridge:.2f} s; oracle svd_fit (lstsq, svd.py:54) on {ms} rows: {t_svd:.2f} s",
+        "svd_lstsq_rows_per_s": ms / t_svd, "host_cpu_count": os.cpu_count(), "blas": pools,
+        "gpu_vs_oracle_max_rel_err": rel,
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from fitsnap_amd import _capi
+    from oracle import fitsnap_oracle as orc   # synthetic workload generator (shared with the tests)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a gfx950 GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    m, Kc = args.rows, args.cols
+    A, b, w = orc.synth_problem(m, Kc, row_offset=rank * RANK_ROW_STRIDE)
+
+    ctx = _capi.HipContext(local_rank)
+    for kv in args.option:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w)
+    upload_ms = ctx.timing()["upload_ms"]
+    info = ctx.launch_info()
+    n = Kc * Kc + Kc + 3
+    packed = torch.zeros(n, dtype=torch.float64, device=dev)
+    host = torch.zeros(n, dtype=torch.float64).pin_memory()
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)
+
+    def step():
+        ctx.normal_eq_async(packed.data_ptr())
+        if world > 1:
+            dist.all_reduce(packed)                       # RCCL over xGMI, same stream
+        host.copy_(packed, non_blocking=True)
+        stream.synchronize()
+        beta = None
+        if rank == 0:
+            h = host.numpy()
+            beta, _, _ = _capi.solve(_capi.SOLVE_RIDGE, ALPHA, h[:Kc * Kc].reshape(Kc, Kc), h[Kc * Kc:Kc * Kc + Kc])
+        return beta
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    syrk_ms, red_ms = [], []
+    t0 = time.perf_counter()
+    beta = None
+    for _ in range(args.steps):
+        beta = step()
+        t = ctx.timing()                                   # HIP events on the kernel's stream (already synced)
+        syrk_ms.append(t["syrk_ms"])
+        red_ms.append(t["reduce_ms"])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        kk = torch.tensor([float(np.mean(syrk_ms))], dtype=torch.float64, device=dev)
+        dist.all_reduce(kk, op=dist.ReduceOp.MAX)
+        syrk_avg_ms = float(kk.item())
+    else:
+        syrk_avg_ms = float(np.mean(syrk_ms))
+
+    if rank == 0:
+        total_rows = world * m
+        flops_per_launch = (Kc * Kc + 3 * Kc) * m          # K^2 + 3K flop/row x rows per launch
+        achieved = flops_per_launch / (syrk_avg_ms * 1e-3) / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile) and m == ROWS_PER_GPU and Kc == K:
+            try:
+                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "training rows/sec through A^T A + solve, 10^6 x 128 fp64 per GPU",
+            "value": total_rows * args.steps / elapsed,
+            "unit": "rows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"synthetic {m} x {Kc} fp64 A per GPU (SURVEY 8d generator), RIDGE alpha=1e-8 "
+                            "normal equations (BASELINE configs[1]), A/b/w resident in HBM",
+                "rows_per_gpu": m, "K": Kc, "solver": "RIDGE",
+                "parallelism": f"dp{world}: rows sharded by rank, one RCCL all-reduce of {n} doubles per fit",
+                "launch": info,
+            },
+            "roofline": {
+                "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+                "kernel": "fsnap_syrk_wave", "kernel_ms_avg": syrk_avg_ms, "reduce_kernel_ms_avg": float(np.mean(red_ms)),
+                "flops_per_launch": flops_per_launch, "algorithmic_bytes_per_launch": (8 * Kc + 16) * m,
+                "achieved_GBps_algorithmic": (8 * Kc + 16) * m / (syrk_avg_ms * 1e-3) / 1e9,
+            },
+            "h2d_upload_ms": upload_ms,
+            "h2d_inclusive_rows_per_s": m / ((upload_ms + elapsed / args.steps * 1e3) * 1e-3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(A, b, w, beta)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

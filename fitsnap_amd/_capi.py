@@ -33,6 +33,7 @@ SIGNATURES = {
     "fsnap_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
     "fsnap_ctx_destroy": (c_int, [c_void_p]),
     "fsnap_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
+    "fsnap_ctx_use_own_stream": (c_int, [c_void_p]),
     "fsnap_set_option": (c_int, [c_void_p, c_char_p, c_int64]),
     "fsnap_last_error": (c_char_p, [c_void_p]),
     "fsnap_upload_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
@@ -166,6 +167,9 @@ class HipContext:
 
     def set_stream(self, stream_handle):
         self._check(self._lib.fsnap_ctx_set_stream(self._h, c_void_p(stream_handle or None)))
+
+    def use_own_stream(self):
+        self._check(self._lib.fsnap_ctx_use_own_stream(self._h))
 
     def set_option(self, key: str, value: int):
         self._check(self._lib.fsnap_set_option(self._h, key.encode(), int(value)))

@@ -275,7 +275,14 @@ int fsnap_ctx_destroy(fsnap_ctx* ctx) {
 int fsnap_ctx_set_stream(fsnap_ctx* ctx, void* hip_stream) {
     if (!ctx) return FSNAP_E_ARG;
     FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;  // NULL = the HIP legacy default stream
+    return FSNAP_OK;
+}
+
+int fsnap_ctx_use_own_stream(fsnap_ctx* ctx) {
+    if (!ctx) return FSNAP_E_ARG;
+    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    ctx->stream = ctx->own_stream;
     return FSNAP_OK;
 }
 

@@ -60,8 +60,11 @@ int fsnap_ctx_destroy(fsnap_ctx* ctx);
 
 /* Run all subsequent work of this context on the caller's hipStream_t (e.g.
  * torch.cuda.current_stream().cuda_stream) so that RCCL collectives issued by the host
- * layer order after the kernels without a host sync.  NULL restores the own stream. */
+ * layer order after the kernels without a host sync.  NULL = the HIP default stream. */
 int fsnap_ctx_set_stream(fsnap_ctx* ctx, void* hip_stream);
+
+/* Go back to the context's own non-blocking stream. */
+int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
 
 /* Tuning knobs (all optional): "split" (1|2, sub-waves per row-wave), "nontemporal"
  * (0|1), "nblocks" (workgroups of the SYRK kernel; 0 = auto), "refine" (0|1).

@@ -1,0 +1,348 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C ABI, against the oracle and
+the reference-generated golden vectors.
+
+Tolerances: the statistics G, c are fp64 sums of the same products the oracle forms, in a
+different order -> compared relative to the natural scale sqrt(G_ii G_jj) at 1e-12;
+fitted coefficients must match the reference's SVD / RIDGE within 1e-6 relative
+(BASELINE.json north_star) and 1e-6 absolute (the reference's own test bar,
+tests/example_checker.py:62)."""
+import numpy as np
+import pytest
+
+from fitsnap_amd import _capi
+from fitsnap_amd.config import Config
+from fitsnap_amd.parallel_tools import ParallelTools
+from fitsnap_amd.solvers import solver_factory
+from oracle import fitsnap_oracle as orc
+
+from conftest import maxrel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _capi.HipContext(0)
+    yield c
+    c.close()
+
+
+def stats_close(G, c, s, Gr, cr, sr, tol=1e-12):
+    d = np.sqrt(np.maximum(np.diag(Gr), 1e-300))
+    assert np.max(np.abs(G - Gr) / (d[:, None] * d[None, :])) < tol
+    bscale = np.sqrt(max(sr[0], 1e-300))
+    assert np.max(np.abs(c - cr) / (d * bscale)) < tol
+    assert abs(s[0] - sr[0]) <= tol * max(abs(sr[0]), 1e-300) * 10
+    assert abs(s[1] - sr[1]) <= 1e-9 * max(np.sqrt(sr[0] * sr[2]), 1e-300)
+    assert s[2] == sr[2]
+    assert np.array_equal(G, G.T)
+
+
+def run_stats(ctx, A, b, w, testing=None):
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w, None if testing is None else (~np.asarray(testing, dtype=bool)).astype(np.uint8))
+    return ctx.normal_eq()
+
+
+# ---------------------------------------------------------------------------------------
+# statistics kernel
+# ---------------------------------------------------------------------------------------
+def test_ta_golden_statistics(ctx, ta, ta_fits):
+    A, b, w = ta
+    G, c, s = run_stats(ctx, A, b, w)
+    stats_close(G, c, s, *orc.normal_eq(A, b, w))
+    t = ta_fits["testing_mask"]
+    G, c, s = run_stats(ctx, A, b, w, t)
+    stats_close(G, c, s, *orc.normal_eq(A, b, w, t))
+
+
+@pytest.mark.parametrize("K", [1, 2, 15, 16, 17, 30, 31, 32, 33, 48, 55, 64, 79, 80, 96, 97, 110, 112, 113, 127, 128])
+def test_statistics_all_column_block_shapes(ctx, K):
+    # every NB (1..8), odd/even NB tails, K odd (unaligned 16-byte loads), both SPLIT paths
+    rng = np.random.default_rng(K)
+    m = 4099 + 7 * K                      # ragged: not a multiple of 4 or of the chunk pipeline
+    A = rng.standard_normal((m, K)) * (10.0 ** rng.uniform(-3, 3, size=K))
+    b = rng.standard_normal(m)
+    w = rng.choice([100.0, 1.0, 1e-8], size=m, p=[0.03, 0.83, 0.14])
+    t = rng.random(m) < 0.2
+    G, c, s = run_stats(ctx, A, b, w, t)
+    stats_close(G, c, s, *orc.normal_eq(A, b, w, t))
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 1023, 1025])
+def test_statistics_tiny_and_ragged_row_counts(ctx, m):
+    rng = np.random.default_rng(100 + m)
+    A = rng.standard_normal((m, 31))
+    b = rng.standard_normal(m)
+    w = rng.uniform(0.5, 2.0, m)
+    G, c, s = run_stats(ctx, A, b, w)
+    stats_close(G, c, s, *orc.normal_eq(A, b, w), tol=1e-11)
+
+
+@pytest.mark.parametrize("split", [1, 2])
+def test_split_variants_agree(ctx, split):
+    A, b, w = orc.synth_problem(20000, 96)           # NB = 6: both layouts exist
+    ctx.set_option("split", split)
+    try:
+        G, c, s = run_stats(ctx, A, b, w)
+        assert ctx.launch_info()["split"] == split
+    finally:
+        ctx.set_option("split", 0)
+    stats_close(G, c, s, *orc.normal_eq(A, b, w))
+
+
+def test_masked_rows_may_hold_garbage(ctx):
+    # test rows are excluded by fancy indexing in the reference (svd.py:44-46): NaN/Inf in
+    # them must not reach G
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((2000, 40))
+    b = rng.standard_normal(2000)
+    w = np.ones(2000)
+    t = np.zeros(2000, dtype=bool)
+    t[::7] = True
+    A2, b2 = A.copy(), b.copy()
+    A2[t] = np.nan
+    b2[t] = np.inf
+    G, c, s = run_stats(ctx, A2, b2, w, t)
+    stats_close(G, c, s, *orc.normal_eq(A, b, w, t))
+    assert np.isfinite(G).all()
+
+
+def test_all_rows_masked_and_zero_weights(ctx):
+    rng = np.random.default_rng(6)
+    A = rng.standard_normal((100, 20))
+    b = rng.standard_normal(100)
+    G, c, s = run_stats(ctx, A, b, np.ones(100), np.ones(100, dtype=bool))
+    assert not G.any() and not c.any() and s.tolist() == [0.0, 0.0, 0.0]
+    G, c, s = run_stats(ctx, A, b, np.zeros(100))
+    assert not G.any() and s[2] == 100
+
+
+def test_strided_rows_lda_greater_than_k(ctx):
+    rng = np.random.default_rng(7)
+    big = rng.standard_normal((3000, 80))
+    A = big[:, :50]                                 # row stride 80 doubles
+    b = rng.standard_normal(3000)
+    w = rng.uniform(0.1, 3, 3000)
+    G, c, s = run_stats(ctx, A, b, w)
+    stats_close(G, c, s, *orc.normal_eq(A, b, w))
+
+
+def test_reweighting_resident_rows(ctx, ta):
+    # GA use case (libmod_optimize.py:461-488): same A, b, new w per call, A stays in HBM
+    A, b, w = ta
+    ctx.upload_rows(A, b)
+    for seed in range(3):
+        w2 = w * np.random.default_rng(seed).uniform(0.5, 2.0, len(w))
+        ctx.set_weights(w2)
+        G, c, s = ctx.normal_eq()
+        stats_close(G, c, s, *orc.normal_eq(A, b, w2))
+
+
+def test_run_to_run_bit_identical(ctx, ta):
+    A, b, w = ta
+    G1, c1, s1 = run_stats(ctx, A, b, w)
+    G2, c2, s2 = run_stats(ctx, A, b, w)
+    assert np.array_equal(G1, G2) and np.array_equal(c1, c2) and np.array_equal(s1, s2)
+
+
+def test_k_above_128_is_refused_loudly(ctx):
+    A = np.ones((10, 129))
+    ctx.upload_rows(A, np.ones(10))
+    ctx.set_weights(np.ones(10))
+    with pytest.raises(ValueError, match="not supported"):
+        ctx.normal_eq()
+
+
+def test_call_order_errors(ctx):
+    c2 = _capi.HipContext(0)
+    try:
+        with pytest.raises(_capi.FsnapError, match="no rows"):
+            c2.normal_eq()
+    finally:
+        c2.close()
+
+
+# ---------------------------------------------------------------------------------------
+# stand-alone weighting kernel and GEMV
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K", [31, 128, 55])
+def test_weight_rows_bit_exact(ctx, K):
+    rng = np.random.default_rng(K)
+    m = 5001
+    A = rng.standard_normal((m, K))
+    b = rng.standard_normal(m)
+    w = rng.uniform(0.1, 10, m)
+    t = rng.random(m) < 0.3
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w, (~t).astype(np.uint8))
+    aw, bw = ctx.weight_rows()
+    awr, bwr = orc.weight_rows_full(A, b, w, t)
+    assert np.array_equal(aw, awr) and np.array_equal(bw, bwr)     # one IEEE multiply per element
+
+
+def test_predict_and_sse(ctx, ta, ta_fits):
+    A, b, w = ta
+    beta = ta_fits["svd_all"]
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w)
+    preds, sse = ctx.predict(beta, want_preds=True, want_sse=True)
+    ref = orc.predict(A, beta)
+    scale = np.abs(A) @ np.abs(beta)
+    assert np.max(np.abs(preds - ref) / scale) < 1e-14
+    aw, bw = orc.weight_rows(A, b, w)
+    assert sse == pytest.approx(np.sum((bw - aw @ beta) ** 2), rel=1e-10)
+
+
+# ---------------------------------------------------------------------------------------
+# solver classes through the plugin API vs the reference's own fits
+# ---------------------------------------------------------------------------------------
+def make_solver(name, extra=None):
+    pt = ParallelTools()
+    d = {"SOLVER": {"solver": name}}
+    d.update(extra or {})
+    cfg = Config(pt, d)
+    return pt, solver_factory.solver(name, pt, cfg)
+
+
+def check_fit(fit, ref):
+    assert fit.shape == ref.shape and fit.dtype == np.float64
+    assert maxrel(fit, ref) < 1e-6
+    assert np.max(np.abs(fit - ref)) < 1e-6
+
+
+def test_svd_solver_matches_reference(ta, ta_fits):
+    A, b, w = ta
+    t = ta_fits["testing_mask"]
+    pt, s = make_solver("SVD")
+    s.perform_fit(A, b, w, trainall=True)
+    check_fit(s.fit, ta_fits["svd_all"])
+    check_fit(s.fit, ta_fits["snapcoeff"])
+    s.perform_fit(A, b, w[~t], fs_dict={"Testing": t.tolist()})
+    check_fit(s.fit, ta_fits["svd_mask"])
+    pt.free()
+
+
+def test_svd_solver_shared_array_path(ta, ta_fits):
+    A, b, w = ta
+    t = ta_fits["testing_mask"]
+    pt, s = make_solver("SVD")
+    m, K = A.shape
+    pt.create_shared_array("a", m, K)
+    pt.create_shared_array("b", m)
+    pt.create_shared_array("w", m)
+    pt.shared_arrays["a"].array[:] = A
+    pt.shared_arrays["b"].array[:] = b
+    pt.shared_arrays["w"].array[:] = w
+    pt.fitsnap_dict["Testing"] = t.tolist()
+    s.perform_fit()
+    check_fit(s.fit, ta_fits["svd_mask_shared"])
+    pt.free()
+
+
+def test_svd_transpose_trick_flag(ta, ta_fits):
+    A, b, w = ta
+    pt, s = make_solver("SVD", {"EXTRAS": {"apply_transpose": 1}})
+    s.perform_fit(A, b, w, trainall=True)
+    check_fit(s.fit, ta_fits["svd_transpose_all"])
+    pt.free()
+
+
+@pytest.mark.parametrize("tag,alpha", [("1e-8", 1e-8), ("1e-4", 1e-4)])
+@pytest.mark.parametrize("local", [0, 1])
+def test_ridge_solver_matches_reference(ta, ta_fits, tag, alpha, local):
+    A, b, w = ta
+    t = ta_fits["testing_mask"]
+    pt, s = make_solver("RIDGE", {"RIDGE": {"alpha": alpha, "local_solver": local}})
+    kind = "local" if local else "sklearn"
+    s.perform_fit(A, b, w, trainall=True)
+    check_fit(s.fit, ta_fits[f"ridge_{kind}_{tag}_all"])
+    s.perform_fit(A, b, w[~t], fs_dict={"Testing": t.tolist()})
+    check_fit(s.fit, ta_fits[f"ridge_{kind}_{tag}_mask"])
+    pt.free()
+
+
+def test_second_golden_set(ta):
+    import os
+    from conftest import GOLDEN
+    A, b, w = ta
+    d = np.load(os.path.join(GOLDEN, "ta_xyz_delta.npz"))
+    pt, s = make_solver("SVD")
+    s.perform_fit(A + d["dA"], b + d["db"], w + d["dw"], trainall=True)
+    check_fit(s.fit, d["svd_all"])
+    pt.free()
+
+
+def test_ard_solver_support_and_values(ta, ta_fits):
+    # ARD parity is unpinned against the reference class: equal support and
+    # 1e-3 relative against the captured scikit-learn vector
+    A, b, w = ta
+    pt, s = make_solver("ARD")
+    m, K = A.shape
+    for name, arr in (("a", A), ("b", b), ("w", w)):
+        pt.create_shared_array(name, m, K if name == "a" else 1)
+        pt.shared_arrays[name].array[:] = arr
+    pt.fitsnap_dict["Testing"] = [False] * m
+    s.perform_fit()
+    ref = ta_fits["ard_all"]
+    assert np.array_equal(s.fit != 0, ref != 0)
+    nz = ref != 0
+    assert np.max(np.abs(s.fit[nz] - ref[nz]) / np.abs(ref[nz])) < 1e-3
+    pt.free()
+
+
+def test_error_analysis_all_rows(ta, ta_fits):
+    # '*ALL' rows of the committed Ta_metrics.md through Solver.error_analysis (GPU GEMV)
+    A, b, w = ta
+    pt, s = make_solver("SVD")
+    s.perform_fit(A, b, w, trainall=True)
+    m = len(b)
+    row_type = ["Energy"] * 363 + ["Force"] * 12672 + ["Stress"] * 2178
+    fs = {"Groups": ["g"] * m, "Testing": [False] * m, "Row_Type": row_type}
+    s.error_analysis(A, b, w, fs)
+    for wi, wt in enumerate(("Unweighted", "weighted")):
+        for ri, rt in enumerate(("Energy", "Force", "Stress")):
+            n, mae, rmse, rsq = ta_fits["metrics_all"][wi * 3 + ri]
+            row = s.errors.loc[("*ALL", wt, "Training", rt)]
+            assert row["ncount"] == n
+            assert row["mae"] == pytest.approx(mae, rel=6e-6)
+            assert row["rmse"] == pytest.approx(rmse, rel=6e-6)
+            assert row["rsq"] == pytest.approx(rsq, abs=6e-6)
+    pt.free()
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE.json full size (10^6 x 128): size-independent properties + fit vs the oracle
+# ---------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def big():
+    return orc.synth_problem(1_000_000, 128)
+
+
+def test_full_size_linearity_and_parity(ctx, big):
+    A, b, w = big
+    m = len(b)
+    G, c, s = run_stats(ctx, A, b, w)
+    # (1) additivity over a row split: stats(top) + stats(bottom) == stats(all)
+    h = 499_999
+    G1, c1, s1 = run_stats(ctx, A[:h], b[:h], w[:h])
+    G2, c2, s2 = run_stats(ctx, A[h:], b[h:], w[h:])
+    d = np.sqrt(np.diag(G))
+    assert np.max(np.abs(G1 + G2 - G) / (d[:, None] * d[None, :])) < 1e-12
+    assert s1[2] + s2[2] == s[2] == m
+    # (2) masking a row == zero weight on that row == deleting it
+    t = orc.synth_testing_mask(m)
+    Gm, cm, sm = run_stats(ctx, A, b, w, t)
+    Gz, cz, sz = run_stats(ctx, A, b, np.where(t, 0.0, w))
+    assert np.max(np.abs(Gm - Gz) / (d[:, None] * d[None, :])) < 1e-13 and sm[2] == (~t).sum()
+    # (3) weight scaling: stats(2w) == 4 stats(w) exactly (power-of-two scaling is exact in fp64)
+    G4, c4, s4 = run_stats(ctx, A, b, 2.0 * w)
+    assert np.array_equal(G4, 4.0 * G) and np.array_equal(c4, 4.0 * c)
+    # (4) against the oracle's BLAS
+    stats_close(G, c, s, *orc.normal_eq(A, b, w))
+    # (5) RIDGE fit through the plugin API vs the oracle's restatement of the reference
+    pt, sol = make_solver("RIDGE", {"RIDGE": {"alpha": 1e-8}})
+    sol.perform_fit(A, b, w, trainall=True)
+    ref = orc.ridge_fit(A, b, w, 1e-8)
+    assert maxrel(sol.fit, ref) < 1e-6
+    pt.free()
