@@ -188,7 +188,7 @@ def test_predict_and_sse(ctx, ta, ta_fits):
     ctx.set_weights(w)
     preds, sse = ctx.predict(beta, want_preds=True, want_sse=True)
     ref = orc.predict(A, beta)
-    scale = np.abs(A) @ np.abs(beta)
+    scale = np.maximum(np.abs(A) @ np.abs(beta), 1e-300)
     assert np.max(np.abs(preds - ref) / scale) < 1e-14
     aw, bw = orc.weight_rows(A, b, w)
     assert sse == pytest.approx(np.sum((bw - aw @ beta) ** 2), rel=1e-10)
