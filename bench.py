@@ -119,16 +119,25 @@ def main():
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
 
+    brk = {"launch": 0.0, "sync": 0.0, "solve": 0.0}
+
     def step():
+        t0 = time.perf_counter()
         ctx.normal_eq_async(packed.data_ptr())
         if world > 1:
             dist.all_reduce(packed)                       # RCCL over xGMI, same stream
         host.copy_(packed, non_blocking=True)
+        t1 = time.perf_counter()
         stream.synchronize()
+        t2 = time.perf_counter()
         beta = None
         if rank == 0:
             h = host.numpy()
             beta, _, _ = _capi.solve(_capi.SOLVE_RIDGE, ALPHA, h[:Kc * Kc].reshape(Kc, Kc), h[Kc * Kc:Kc * Kc + Kc])
+        t3 = time.perf_counter()
+        brk["launch"] += t1 - t0
+        brk["sync"] += t2 - t1
+        brk["solve"] += t3 - t2
         return beta
 
     def fence():
@@ -140,6 +149,8 @@ def main():
         step()
     fence()
     syrk_ms, red_ms = [], []
+    for k in brk:
+        brk[k] = 0.0
     t0 = time.perf_counter()
     beta = None
     for _ in range(args.steps):
@@ -197,6 +208,9 @@ def main():
                 "flops_per_launch": flops_per_launch, "algorithmic_bytes_per_launch": (8 * Kc + 16) * m,
                 "achieved_GBps_algorithmic": (8 * Kc + 16) * m / (syrk_avg_ms * 1e-3) / 1e9,
             },
+            "step_host_launch_ms_avg": brk["launch"] / args.steps * 1e3,
+            "step_wait_gpu_ms_avg": brk["sync"] / args.steps * 1e3,
+            "step_host_solve_ms_avg": brk["solve"] / args.steps * 1e3,
             "h2d_upload_ms": upload_ms,
             "h2d_inclusive_rows_per_s": m / ((upload_ms + elapsed / args.steps * 1e3) * 1e-3),
         }

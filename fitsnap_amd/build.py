@@ -58,8 +58,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
         cmd = [hipcc, *common]
-        if src.endswith(".cpp"):
-            cmd += ["-x", "hip"] if src == "fsnap_capi.cpp" else []
+        if src == "fsnap_capi.cpp":
+            cmd += ["-x", "hip"]
+        if src == "fsnap_solve.cpp":
+            cmd += ["-mavx2", "-mfma"]   # host-only K x K solve: vectorised dot products
         cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

@@ -347,29 +347,31 @@ fsnap_syrk_wave(const double* __restrict__ A, int64_t lda, const double* __restr
 }
 
 // ---------------------------------------------------------------------------------
-// Kernel 2: deterministic reduction of per-wave partials into the packed statistics
-// buffer  out = [G (K*K row-major) | c (K) | bTb, sum_bw, n_train].
-// One workgroup = 64 consecutive partial elements x 4 slices of the wave range;
-// thread (g = tid>>6, e = tid&63) sums waves g, g+4, g+8, ... then 4-way LDS combine.
-// Element space: [0, NT*256) triangle elements, then NB*16 c elements, then 4 scalars.
+// Kernel 2: deterministic reduction of the partials into the packed statistics buffer
+//   out = [G (K*K row-major) | c (K) | bTb, sum_bw, n_train].
+// One workgroup (1024 threads) = 64 consecutive partial elements x 16 slices of the
+// partial range: thread (g = tid>>6, l = tid&63) sums partials g, g+16, g+32, ... in a
+// fixed order with 8 independent loads in flight, then a fixed-order 16-way LDS
+// combine.  Element space: [0, NT*256) triangle elements (one partial per workgroup of
+// kernel 1), then NB*16 c elements and 4 scalars (one partial per row-wave).
+// The scatter undoes the even/odd column interleave and mirrors the upper triangle.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fsnap_reduce_partials(const double* __restrict__ part,
-                                                             const double* __restrict__ cpart,
-                                                             const double* __restrict__ spart, int nblocks,
-                                                             int NB, int K, double* __restrict__ out) {
-    __shared__ double red[256];
+__global__ __launch_bounds__(1024) void fsnap_reduce_partials(const double* __restrict__ part,
+                                                              const double* __restrict__ cpart,
+                                                              const double* __restrict__ spart, int nblocks,
+                                                              int NB, int K, double* __restrict__ out) {
+    __shared__ double red[1024];
     const int NTILE = NB * (NB + 1) / 2;
     const int nG = NTILE * 256, nC = NB * 16, nS = 4;
     const int tid = threadIdx.x, g = tid >> 6, l = tid & 63;
     const int idx = blockIdx.x * 64 + l;
-    double s = 0.0;
     const double* src = nullptr;
     int64_t stride = 0;
-    int nwaves = nblocks * 4;  // c / scalar partials are per row-wave, G partials per workgroup
+    int np = nblocks * 4;  // c / scalar partials are per row-wave, G partials per workgroup
     if (idx < nG) {
         src = part + idx;
         stride = nG;
-        nwaves = nblocks;
+        np = nblocks;
     } else if (idx < nG + nC) {
         src = cpart + (idx - nG);
         stride = nC;
@@ -377,23 +379,26 @@ __global__ __launch_bounds__(256) void fsnap_reduce_partials(const double* __res
         src = spart + (idx - nG - nC);
         stride = nS;
     }
+    double s = 0.0;
     if (src) {
-        // fixed order: wave g, g+4, ...; unrolled by 4 for memory-level parallelism
-        int wv = g;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        for (; wv + 12 < nwaves; wv += 16) {
-            s0 += src[(int64_t)wv * stride];
-            s1 += src[(int64_t)(wv + 4) * stride];
-            s2 += src[(int64_t)(wv + 8) * stride];
-            s3 += src[(int64_t)(wv + 12) * stride];
+        int p = g;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
+        for (; p + 112 < np; p += 128) {
+            const double x0 = src[(int64_t)p * stride], x1 = src[(int64_t)(p + 16) * stride];
+            const double x2 = src[(int64_t)(p + 32) * stride], x3 = src[(int64_t)(p + 48) * stride];
+            const double x4 = src[(int64_t)(p + 64) * stride], x5 = src[(int64_t)(p + 80) * stride];
+            const double x6 = src[(int64_t)(p + 96) * stride], x7 = src[(int64_t)(p + 112) * stride];
+            a0 += x0; a1 += x1; a2 += x2; a3 += x3; a4 += x4; a5 += x5; a6 += x6; a7 += x7;
         }
-        for (; wv < nwaves; wv += 4) s0 += src[(int64_t)wv * stride];
-        s = (s0 + s1) + (s2 + s3);
+        for (; p < np; p += 16) a0 += src[(int64_t)p * stride];
+        s = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
     }
     red[tid] = s;
     __syncthreads();
     if (g == 0 && src) {
-        double tot = (red[l] + red[64 + l]) + (red[128 + l] + red[192 + l]);
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += red[k * 64 + l];
         if (idx < nG) {
             int t = idx >> 8, rem = idx & 255, i = rem >> 6, ln = rem & 63;
             // invert tri_index: find p with tri_index(p,p) <= t
@@ -572,7 +577,7 @@ hipError_t launch_reduce(const double* part, const double* cpart, const double* 
                          double* out, hipStream_t st) {
     const int NB = syrk_num_blocks(K);
     const int nelem = NB * (NB + 1) / 2 * 256 + NB * 16 + 4;
-    dim3 grid((unsigned)((nelem + 63) / 64)), block(256);
+    dim3 grid((unsigned)((nelem + 63) / 64)), block(1024);
     hipLaunchKernelGGL(fsnap_reduce_partials, grid, block, 0, st, part, cpart, spart, nblocks, NB, K, out);
     return hipGetLastError();
 }

@@ -28,6 +28,29 @@ namespace {
 
 typedef std::vector<double> vec;
 
+// 4-wide fp64 vectors (AVX2 + FMA on the host; this file is compiled with -mavx2 -mfma)
+typedef double v4d __attribute__((vector_size(32)));
+typedef double v4du __attribute__((vector_size(32), aligned(8)));
+
+static inline v4d ld4(const double* p) { return *reinterpret_cast<const v4du*>(p); }
+static inline double hsum(v4d v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+
+// dot product with 4 independent vector accumulators (fixed association order)
+static inline double dotv(const double* x, const double* y, int n) {
+    v4d s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;
+    int k = 0;
+    for (; k + 16 <= n; k += 16) {
+        s0 += ld4(x + k) * ld4(y + k);
+        s1 += ld4(x + k + 4) * ld4(y + k + 4);
+        s2 += ld4(x + k + 8) * ld4(y + k + 8);
+        s3 += ld4(x + k + 12) * ld4(y + k + 12);
+    }
+    for (; k + 4 <= n; k += 4) s0 += ld4(x + k) * ld4(y + k);
+    double s = hsum((s0 + s1) + (s2 + s3));
+    for (; k < n; ++k) s += x[k] * y[k];
+    return s;
+}
+
 // In-place lower Cholesky of the n x n row-major matrix a (only the lower triangle is
 // referenced/written).  Returns -1 on success or the index of the failing pivot.
 // *min_piv2 receives the smallest squared pivot (before sqrt) relative to the original
@@ -36,16 +59,13 @@ int chol_lower(double* a, int n, double* min_piv2) {
     double mp = std::numeric_limits<double>::infinity();
     for (int j = 0; j < n; ++j) {
         double* aj = a + (size_t)j * n;
-        // row j against previous rows (row-oriented: contiguous inner loops)
+        // row j against previous rows (row-oriented: contiguous, vectorised dot products)
         for (int i = 0; i < j; ++i) {
             const double* ai = a + (size_t)i * n;
-            double s = aj[i];
-            for (int k = 0; k < i; ++k) s -= aj[k] * ai[k];
-            aj[i] = s / ai[i];
+            aj[i] = (aj[i] - dotv(aj, ai, i)) / ai[i];
         }
-        double d = aj[j];
-        const double d0 = d;
-        for (int k = 0; k < j; ++k) d -= aj[k] * aj[k];
+        const double d0 = aj[j];
+        const double d = d0 - dotv(aj, aj, j);
         const double rel = (d0 != 0.0) ? d / d0 : d;
         if (rel < mp) mp = rel;
         if (!(d > 0.0) || !std::isfinite(d)) {
@@ -58,19 +78,13 @@ int chol_lower(double* a, int n, double* min_piv2) {
     return -1;
 }
 
-void chol_solve(const double* l, int n, double* x) {
-    // forward L y = x
-    for (int i = 0; i < n; ++i) {
-        const double* li = l + (size_t)i * n;
-        double s = x[i];
-        for (int k = 0; k < i; ++k) s -= li[k] * x[k];
-        x[i] = s / li[i];
-    }
-    // backward L^T z = y
+// solve L L^T x = rhs in place; lt = transposed copy of l (rows of lt = columns of l) so
+// that both sweeps run over contiguous rows
+void chol_solve(const double* l, const double* lt, int n, double* x) {
+    for (int i = 0; i < n; ++i) x[i] = (x[i] - dotv(l + (size_t)i * n, x, i)) / l[(size_t)i * n + i];
     for (int i = n - 1; i >= 0; --i) {
-        double s = x[i];
-        for (int k = i + 1; k < n; ++k) s -= l[(size_t)k * n + i] * x[k];
-        x[i] = s / l[(size_t)i * n + i];
+        const double* r = lt + (size_t)i * n;
+        x[i] = (x[i] - dotv(r + i + 1, x + i + 1, n - 1 - i)) / r[i];
     }
 }
 
@@ -163,13 +177,43 @@ void jacobi_eigh(double* a, int n, double* eval, double* v) {
     for (int i = 0; i < n; ++i) eval[i] = a[(size_t)i * n + i];
 }
 
-// residual r = rhs - M x with long double accumulation (M symmetric n x n row-major)
-void residual_ld(const double* M, int n, const double* x, const double* rhs, double* r) {
+// residual r = rhs - M x, each row accumulated with the compensated dot product of
+// Ogita, Rump & Oishi (Dot2: TwoProduct via FMA + TwoSum), i.e. as if in twice the
+// working precision; 4 lanes wide.  M symmetric n x n row-major.
+void residual_dot2(const double* M, int n, const double* x, const double* rhs, double* r) {
     for (int i = 0; i < n; ++i) {
-        long double s = rhs[i];
         const double* mi = M + (size_t)i * n;
-        for (int k = 0; k < n; ++k) s -= (long double)mi[k] * (long double)x[k];
-        r[i] = (double)s;
+        v4d s = {0, 0, 0, 0}, c = {0, 0, 0, 0};
+        int k = 0;
+        for (; k + 4 <= n; k += 4) {
+            const v4d a = ld4(mi + k), b = ld4(x + k);
+            const v4d p = a * b;
+            v4d e;
+            for (int t = 0; t < 4; ++t) e[t] = __builtin_fma(a[t], b[t], -p[t]);
+            const v4d sn = s + p;
+            const v4d bp = sn - s;
+            const v4d err = (s - (sn - bp)) + (p - bp);
+            s = sn;
+            c += err + e;
+        }
+        double ss = 0.0, cc = 0.0;
+        for (int t = 0; t < 4; ++t) {  // fold lanes (TwoSum)
+            const double sn = ss + s[t];
+            const double bp = sn - ss;
+            cc += (ss - (sn - bp)) + (s[t] - bp) + c[t];
+            ss = sn;
+        }
+        for (; k < n; ++k) {
+            const double p = mi[k] * x[k];
+            const double e = __builtin_fma(mi[k], x[k], -p);
+            const double sn = ss + p;
+            const double bp = sn - ss;
+            cc += (ss - (sn - bp)) + (p - bp) + e;
+            ss = sn;
+        }
+        // rhs - (ss + cc)
+        const double t1 = rhs[i] - ss;
+        r[i] = t1 - cc;
     }
 }
 
@@ -204,13 +248,16 @@ int scaled_chol_solve(const vec& M, const vec& rhs, int n, vec& x, double* min_p
     vec L(S);
     const int fail = chol_lower(L.data(), n, min_piv2);
     if (fail >= 0) return fail;
+    vec LT((size_t)n * n);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) LT[(size_t)j * n + i] = L[(size_t)i * n + j];
     for (int i = 0; i < n; ++i) y[i] = rhs[i] * d[i];
     vec z(y);
-    chol_solve(L.data(), n, z.data());
-    // one step of iterative refinement on the scaled system, residual in long double
+    chol_solve(L.data(), LT.data(), n, z.data());
+    // one step of iterative refinement on the scaled system, residual in ~2x precision
     vec r(n);
-    residual_ld(S.data(), n, z.data(), y.data(), r.data());
-    chol_solve(L.data(), n, r.data());
+    residual_dot2(S.data(), n, z.data(), y.data(), r.data());
+    chol_solve(L.data(), LT.data(), n, r.data());
     for (int i = 0; i < n; ++i) z[i] += r[i];
     x.resize(n);
     for (int i = 0; i < n; ++i) x[i] = z[i] * d[i];
