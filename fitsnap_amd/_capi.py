@@ -250,4 +250,4 @@ class HipContext:
         info = (c_int64 * 8)()
         self._check(self._lib.fsnap_launch_info(self._h, info, 8))
         return {"workgroups": info[0], "threads": info[1], "chunks_per_wave": info[2], "NB": info[3],
-                "split": info[4], "compute_units": info[5]}
+                "split": info[4], "compute_units": info[5], "kernel_or_pairs": info[6], "nsplit": info[7]}

@@ -66,6 +66,9 @@ struct fsnap_ctx {
     int opt_split = 0;        // 0 = auto
     int opt_nt = 1;
     int opt_nblocks = 0;      // 0 = auto
+    int opt_tiled = 0;        // force the general-K tiled kernel also for K <= 128
+    int opt_kernel = 0;       // 0 auto | 1 wave-triangle (kernel 1) | 2 LDS-shared, 8 waves | 3 LDS-shared, 16 waves
+    int opt_nsplit = 0;       // row splits of the tiled kernel (0 = auto)
     // timing flags
     bool t_syrk = false, t_upload = false, t_weight = false, t_predict = false;
 
@@ -96,12 +99,37 @@ struct Geometry {
     int nblocks, split, threads;
     int64_t cpw;
     int NB;
+    int lds_waves;  // 0 = kernel 1 (wave-triangle); 8 / 16 = kernel 1L (LDS-shared) with that many waves
 };
 
 int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
     const int K = (int)ctx->K;
     const int64_t m = ctx->m;
     g->NB = fsnap::syrk_num_blocks(K);
+    g->lds_waves = 0;
+    const int64_t off_limit = (int64_t)0xFFF00000;  // 32-bit buffer offsets, 1 MiB of slack for prefetch overshoot
+    if (g->NB >= 6 && ctx->opt_kernel != 1) {
+        // kernel 1L: rows shared through LDS, whole triangle per workgroup
+        const int nw = (ctx->opt_kernel == 3) ? 16 : 8;
+        const int64_t nchunks = (m + 3) / 4;
+        int64_t nblocks = ctx->opt_nblocks > 0 ? ctx->opt_nblocks : (int64_t)ctx->num_cu * (nw == 8 ? 2 : 1);
+        const int64_t max_blocks = (nchunks + 4 * nw - 1) / (4 * nw);   // >= 4 stages per workgroup
+        if (nblocks > max_blocks) nblocks = max_blocks;
+        if (nblocks < 1) nblocks = 1;
+        int64_t cpg = (nchunks + nblocks - 1) / nblocks;
+        cpg = (cpg + nw - 1) / nw * nw;
+        const int64_t max_cpg = off_limit / (ctx->lda * 32) / nw * nw;
+        if (max_cpg < nw) return ctx->fail(FSNAP_E_ARG, "leading dimension %lld too large", (long long)ctx->lda);
+        if (cpg > max_cpg) cpg = max_cpg;
+        nblocks = (nchunks + cpg - 1) / cpg;
+        if (nblocks > 0x7FFFFFF) return ctx->fail(FSNAP_E_ARG, "too many workgroups");
+        g->nblocks = (int)nblocks;
+        g->cpw = cpg;
+        g->split = nw;
+        g->threads = 64 * nw;
+        g->lds_waves = nw;
+        return FSNAP_OK;
+    }
     int split = ctx->opt_split ? ctx->opt_split : fsnap::syrk_default_split(K);
     if (split == 2 && g->NB < 6) split = 1;
     if (split == 1 && g->NB > 6) split = 2;
@@ -119,7 +147,7 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
     int64_t cpw = (nchunks + nblocks * 4 - 1) / (nblocks * 4);
     if (cpw < 1) cpw = 1;
     // 32-bit buffer offsets: a row-wave's byte range must stay below 4 GiB
-    const int64_t max_cpw = ((int64_t)0xFFFFFF00 - 64) / (ctx->lda * 32);
+    const int64_t max_cpw = off_limit / (ctx->lda * 32);
     if (max_cpw < 1) return ctx->fail(FSNAP_E_ARG, "leading dimension %lld too large", (long long)ctx->lda);
     if (cpw > max_cpw) cpw = max_cpw;
     nblocks = (nchunks + cpw * 4 - 1) / (cpw * 4);
@@ -148,11 +176,85 @@ int ensure_ones(fsnap_ctx* ctx) {
     return FSNAP_OK;
 }
 
+struct TiledGeometry {
+    int NSB, npairs, nsplit;
+    int64_t cps;  // chunks per split
+};
+
+int plan_tiled(fsnap_ctx* ctx, TiledGeometry* g) {
+    const int64_t m = ctx->m, K = ctx->K;
+    if (K > 32768) return ctx->fail(FSNAP_E_ARG, "K = %lld too large", (long long)K);
+    g->NSB = (int)((K + 63) / 64);
+    g->npairs = g->NSB * (g->NSB + 1) / 2;
+    const int64_t nchunks = (m + 3) / 4;
+    // two workgroups (8 waves) per CU resident; aim at one full wave of workgroups
+    int64_t nsplit = ctx->opt_nsplit > 0 ? ctx->opt_nsplit : ((int64_t)ctx->num_cu * 2 + g->npairs - 1) / g->npairs;
+    // keep a split's rows resident in the Infinity Cache (256 MiB) while all pairs sweep them
+    const int64_t bytes = m * ctx->lda * 8;
+    const int64_t min_split_cache = (bytes + (96ll << 20) - 1) / (96ll << 20);
+    if (!ctx->opt_nsplit && nsplit < min_split_cache) nsplit = min_split_cache;
+    // >= 8 chunks per wave (4 waves per split)
+    const int64_t max_split = (nchunks + 31) / 32;
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    int64_t cps = (nchunks + nsplit - 1) / nsplit;
+    cps = (cps + 3) / 4 * 4;
+    // 32-bit buffer offsets per wave
+    const int64_t max_cpw = (int64_t)0xFFF00000 / (ctx->lda * 32);
+    if (max_cpw < 1) return ctx->fail(FSNAP_E_ARG, "leading dimension %lld too large", (long long)ctx->lda);
+    if (cps / 4 > max_cpw) cps = max_cpw * 4;
+    nsplit = (nchunks + cps - 1) / cps;
+    if ((int64_t)g->npairs * nsplit > 0x7FFFFFFF) return ctx->fail(FSNAP_E_ARG, "too many workgroups");
+    g->nsplit = (int)nsplit;
+    g->cps = cps;
+    return FSNAP_OK;
+}
+
+int launch_normal_eq_tiled(fsnap_ctx* ctx, double* d_packed) {
+    int rc;
+    TiledGeometry g;
+    if ((rc = plan_tiled(ctx, &g))) return rc;
+    const unsigned char* mask = ctx->dmask;
+    if (!mask) {
+        if ((rc = ensure_ones(ctx))) return rc;
+        mask = (const unsigned char*)ctx->ones.p;
+    }
+    if (!ctx->part.ensure((size_t)g.nsplit * g.npairs * 4096 * sizeof(double)) ||
+        !ctx->cpart.ensure((size_t)g.nsplit * g.NSB * 4 * 64 * sizeof(double)) ||
+        !ctx->spart.ensure((size_t)g.nsplit * 4 * 4 * sizeof(double)))
+        return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(partials) failed");
+    fsnap::TiledArgs a;
+    a.A = ctx->dA;
+    a.lda = ctx->lda;
+    a.b = ctx->db;
+    a.w = ctx->dw;
+    a.mask = mask;
+    a.m = ctx->m;
+    a.K = (int)ctx->K;
+    a.NSB = g.NSB;
+    a.npairs = g.npairs;
+    a.nsplit = g.nsplit;
+    a.chunks_per_split = g.cps;
+    a.nontemporal = false;  // rows are re-read by the other column pairs: keep them cached
+    a.part = (double*)ctx->part.p;
+    a.cpart = (double*)ctx->cpart.p;
+    a.spart = (double*)ctx->spart.p;
+    // waves of off-diagonal pairs never write their c / scalar slots: zero them once
+    FSNAP_HIP(hipMemsetAsync(a.cpart, 0, (size_t)g.nsplit * g.NSB * 4 * 64 * sizeof(double), ctx->stream), "hipMemsetAsync");
+    FSNAP_HIP(hipMemsetAsync(a.spart, 0, (size_t)g.nsplit * 4 * 4 * sizeof(double), ctx->stream), "hipMemsetAsync");
+    FSNAP_HIP(hipEventRecord(ctx->ev[0], ctx->stream), "hipEventRecord");
+    FSNAP_HIP(fsnap::launch_syrk_tiled(a, ctx->stream), "launch fsnap_syrk_tiled");
+    FSNAP_HIP(hipEventRecord(ctx->ev[1], ctx->stream), "hipEventRecord");
+    FSNAP_HIP(fsnap::launch_reduce_tiled(a, d_packed, ctx->stream), "launch fsnap_reduce_tiled");
+    FSNAP_HIP(hipEventRecord(ctx->ev[2], ctx->stream), "hipEventRecord");
+    ctx->t_syrk = true;
+    return FSNAP_OK;
+}
+
 int launch_normal_eq(fsnap_ctx* ctx, double* d_packed) {
     int rc;
     if ((rc = check_rows(ctx)) || (rc = check_weights(ctx))) return rc;
-    if (ctx->K > 128)
-        return ctx->fail(FSNAP_E_ARG, "K = %lld > 128 is not supported by the wave-triangle SYRK kernel yet", (long long)ctx->K);
+    if (ctx->K > 128 || ctx->opt_tiled) return launch_normal_eq_tiled(ctx, d_packed);
     Geometry g;
     if ((rc = plan_geometry(ctx, &g))) return rc;
     const unsigned char* mask = ctx->dmask;
@@ -161,9 +263,10 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed) {
         mask = (const unsigned char*)ctx->ones.p;
     }
     const int NT = g.NB * (g.NB + 1) / 2;
+    const int cs_per_block = g.lds_waves ? g.lds_waves : 4;
     if (!ctx->part.ensure((size_t)g.nblocks * NT * 256 * sizeof(double)) ||
-        !ctx->cpart.ensure((size_t)g.nblocks * 4 * g.NB * 16 * sizeof(double)) ||
-        !ctx->spart.ensure((size_t)g.nblocks * 4 * 4 * sizeof(double)))
+        !ctx->cpart.ensure((size_t)g.nblocks * cs_per_block * g.NB * 16 * sizeof(double)) ||
+        !ctx->spart.ensure((size_t)g.nblocks * cs_per_block * 4 * sizeof(double)))
         return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(partials) failed");
     fsnap::SyrkArgs a;
     a.A = ctx->dA;
@@ -181,9 +284,10 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed) {
     a.cpart = (double*)ctx->cpart.p;
     a.spart = (double*)ctx->spart.p;
     FSNAP_HIP(hipEventRecord(ctx->ev[0], ctx->stream), "hipEventRecord");
-    FSNAP_HIP(fsnap::launch_syrk(a, ctx->stream), "launch fsnap_syrk_wave");
+    if (g.lds_waves) FSNAP_HIP(fsnap::launch_syrk_lds(a, ctx->stream), "launch fsnap_syrk_lds");
+    else FSNAP_HIP(fsnap::launch_syrk(a, ctx->stream), "launch fsnap_syrk_wave");
     FSNAP_HIP(hipEventRecord(ctx->ev[1], ctx->stream), "hipEventRecord");
-    FSNAP_HIP(fsnap::launch_reduce(a.part, a.cpart, a.spart, g.nblocks, a.K, d_packed, ctx->stream),
+    FSNAP_HIP(fsnap::launch_reduce(a.part, a.cpart, a.spart, g.nblocks, cs_per_block, a.K, d_packed, ctx->stream),
               "launch fsnap_reduce_partials");
     FSNAP_HIP(hipEventRecord(ctx->ev[2], ctx->stream), "hipEventRecord");
     ctx->t_syrk = true;
@@ -293,6 +397,14 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
         ctx->opt_split = (int)value;
     } else if (!strcmp(key, "nontemporal")) {
         ctx->opt_nt = value != 0;
+    } else if (!strcmp(key, "kernel")) {
+        if (value < 0 || value > 3) return ctx->fail(FSNAP_E_ARG, "kernel must be 0 (auto), 1, 2 or 3");
+        ctx->opt_kernel = (int)value;
+    } else if (!strcmp(key, "tiled")) {
+        ctx->opt_tiled = value != 0;
+    } else if (!strcmp(key, "nsplit")) {
+        if (value < 0 || value > (1 << 24)) return ctx->fail(FSNAP_E_ARG, "nsplit out of range");
+        ctx->opt_nsplit = (int)value;
     } else if (!strcmp(key, "nblocks")) {
         if (value < 0 || value > (1 << 24)) return ctx->fail(FSNAP_E_ARG, "nblocks out of range");
         ctx->opt_nblocks = (int)value;
@@ -503,10 +615,27 @@ int fsnap_launch_info(fsnap_ctx* ctx, int64_t* info, int n) {
     if (!ctx || !info || n < 0 || n > 8) return FSNAP_E_ARG;
     int rc;
     if ((rc = check_rows(ctx))) return rc;
-    if (ctx->K > 128) return ctx->fail(FSNAP_E_ARG, "K > 128 not supported yet");
-    Geometry g;
-    if ((rc = plan_geometry(ctx, &g))) return rc;
-    int64_t out[8] = {g.nblocks, g.threads, g.cpw, g.NB, g.split, ctx->num_cu, 0, 0};
+    int64_t out[8] = {0, 0, 0, 0, 0, ctx->num_cu, 0, 0};
+    if (ctx->K > 128 || ctx->opt_tiled) {
+        TiledGeometry t;
+        if ((rc = plan_tiled(ctx, &t))) return rc;
+        out[0] = (int64_t)t.npairs * t.nsplit;
+        out[1] = 256;
+        out[2] = t.cps / 4;
+        out[3] = 4 * t.NSB;
+        out[4] = 0;  // 0 = tiled kernel
+        out[6] = t.npairs;
+        out[7] = t.nsplit;
+    } else {
+        Geometry g;
+        if ((rc = plan_geometry(ctx, &g))) return rc;
+        out[0] = g.nblocks;
+        out[1] = g.threads;
+        out[2] = g.cpw;
+        out[3] = g.NB;
+        out[4] = g.split;
+        out[6] = g.lds_waves ? 2 : 1;  // kernel id: 1 = wave-triangle, 2 = LDS-shared
+    }
     for (int i = 0; i < n; ++i) info[i] = out[i];
     return FSNAP_OK;
 }

@@ -24,12 +24,33 @@ struct SyrkArgs {
     double* spart;              // [nblocks*4][4]
 };
 
+struct TiledArgs {
+    const double* A;
+    int64_t lda;
+    const double* b;
+    const double* w;
+    const unsigned char* mask;
+    int64_t m;
+    int K;
+    int NSB;                    // 64-column superblocks
+    int npairs;                 // NSB*(NSB+1)/2
+    int nsplit;                 // row splits
+    int64_t chunks_per_split;   // 4-row chunks per split (each split = 4 waves)
+    bool nontemporal;
+    double* part;               // [nsplit*npairs][16][4][64]
+    double* cpart;              // [(nsplit*NSB)*4][4][16]
+    double* spart;              // [nsplit*4][4]
+};
+
 int syrk_num_blocks(int K);
 int syrk_default_split(int K);
 int syrk_waves_per_simd(int K, int split);
 hipError_t launch_syrk(const SyrkArgs& a, hipStream_t st);
-hipError_t launch_reduce(const double* part, const double* cpart, const double* spart, int nblocks, int K,
-                         double* out, hipStream_t st);
+hipError_t launch_syrk_lds(const SyrkArgs& a, hipStream_t st);
+hipError_t launch_reduce(const double* part, const double* cpart, const double* spart, int nblocks,
+                         int cs_per_block, int K, double* out, hipStream_t st);
+hipError_t launch_syrk_tiled(const TiledArgs& a, hipStream_t st);
+hipError_t launch_reduce_tiled(const TiledArgs& a, double* out, hipStream_t st);
 hipError_t launch_weight_rows(const double* A, int64_t lda, const double* b, const double* w,
                               const unsigned char* mask, int64_t m, int K, double* aw, int64_t ldaw, double* bw,
                               hipStream_t st);

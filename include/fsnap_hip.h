@@ -66,8 +66,10 @@ int fsnap_ctx_set_stream(fsnap_ctx* ctx, void* hip_stream);
 /* Go back to the context's own non-blocking stream. */
 int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
 
-/* Tuning knobs (all optional): "split" (1|2, sub-waves per row-wave), "nontemporal"
- * (0|1), "nblocks" (workgroups of the SYRK kernel; 0 = auto), "refine" (0|1).
+/* Tuning knobs (all optional; 0 = auto): "kernel" (1 wave-triangle, 2 LDS-shared with 8
+ * waves per workgroup, 3 with 16), "split" (1|2, sub-waves per row-wave of kernel 1),
+ * "nontemporal" (0|1), "nblocks" (workgroups of the SYRK kernel), "tiled" (1 = force the
+ * general-K tiled kernel also for K <= 128), "nsplit" (row splits of the tiled kernel).
  * Unknown key -> FSNAP_E_ARG. */
 int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value);
 
@@ -144,8 +146,11 @@ int fsnap_solve(int kind, double param, int64_t K, const double* G, const double
 int fsnap_timing(fsnap_ctx* ctx, double* ms, int n);
 
 /* Launch geometry of the SYRK kernel for the current rows: info[0] = workgroups,
- * info[1] = threads per workgroup, info[2] = 4-row chunks per row-wave, info[3] = NB
- * (16-column blocks), info[4] = split, info[5] = compute units of the device. */
+ * info[1] = threads per workgroup, info[2] = 4-row chunks per row-wave (kernel 1) / per
+ * workgroup (kernel 1L) / per wave (tiled), info[3] = NB (16-column blocks), info[4] =
+ * split (kernel 1) or waves per workgroup (kernel 1L), info[5] = compute units of the
+ * device, info[6] = kernel id (1 wave-triangle, 2 LDS-shared; tiled: superblock pairs),
+ * info[7] = row splits (tiled kernel). */
 int fsnap_launch_info(fsnap_ctx* ctx, int64_t* info, int n);
 
 #ifdef __cplusplus
