@@ -263,7 +263,7 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed) {
         mask = (const unsigned char*)ctx->ones.p;
     }
     const int NT = g.NB * (g.NB + 1) / 2;
-    const int cs_per_block = g.lds_waves ? g.lds_waves : 4;
+    const int cs_per_block = g.lds_waves ? 1 : 4;   // kernel 1L folds c / scalars per workgroup
     if (!ctx->part.ensure((size_t)g.nblocks * NT * 256 * sizeof(double)) ||
         !ctx->cpart.ensure((size_t)g.nblocks * cs_per_block * g.NB * 16 * sizeof(double)) ||
         !ctx->spart.ensure((size_t)g.nblocks * cs_per_block * 4 * sizeof(double)))

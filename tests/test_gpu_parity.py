@@ -82,12 +82,14 @@ def test_statistics_tiny_and_ragged_row_counts(ctx, m):
 @pytest.mark.parametrize("split", [1, 2])
 def test_split_variants_agree(ctx, split):
     A, b, w = orc.synth_problem(20000, 96)           # NB = 6: both layouts exist
+    ctx.set_option("kernel", 1)
     ctx.set_option("split", split)
     try:
         G, c, s = run_stats(ctx, A, b, w)
         assert ctx.launch_info()["split"] == split
     finally:
         ctx.set_option("split", 0)
+        ctx.set_option("kernel", 0)
     stats_close(G, c, s, *orc.normal_eq(A, b, w))
 
 
