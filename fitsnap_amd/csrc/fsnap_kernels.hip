@@ -349,9 +349,9 @@ fsnap_syrk_wave(const double* __restrict__ A, int64_t lda, const double* __restr
 // ---------------------------------------------------------------------------------
 // Kernel 2: deterministic reduction of the partials into the packed statistics buffer
 //   out = [G (K*K row-major) | c (K) | bTb, sum_bw, n_train].
-// One workgroup (1024 threads) = 64 consecutive partial elements x 16 slices of the
-// partial range: thread (g = tid>>6, l = tid&63) sums partials g, g+16, g+32, ... in a
-// fixed order with 8 independent loads in flight, then a fixed-order 16-way LDS
+// One workgroup (1024 threads) = 16 consecutive partial elements x 64 slices of the
+// partial range: thread (g = tid>>4, l = tid&15) sums partials g, g+64, g+128, ... in a
+// fixed order with 8 independent loads in flight, then a fixed-order 64-way LDS
 // combine.  Element space: [0, NT*256) triangle elements (one partial per workgroup of
 // kernel 1), then NB*16 c elements and 4 scalars (one partial per row-wave).
 // The scatter undoes the even/odd column interleave and mirrors the upper triangle.
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(1024) void fsnap_reduce_partials(const double* __re
     }
     red[tid] = s;
     __syncthreads();
-    // fixed-order 64-way combine: 4 threads per element do 16 each, then thread 0 of the 4
+    // fixed-order 64-way combine: 4 threads per element sum 16 slices each, then 4 -> 1
     if (tid < 64) {
         const int el = tid & 15, q = tid >> 4;
         double t4 = 0.0;
@@ -428,6 +428,474 @@ __global__ __launch_bounds__(1024) void fsnap_reduce_partials(const double* __re
             if (cidx < K) out[(int64_t)K * K + cidx] = tot;
         } else {
             int j = idx - nG - nC;
+            if (j < 3) out[(int64_t)K * K + K + j] = tot;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 1L: fused mask x weight x SYRK for 80 < K <= 128 with the weighted rows SHARED
+// through LDS (the production kernel for the BASELINE 10^6 x 128 shape).
+// A workgroup of NW waves owns a contiguous row range and the WHOLE block triangle; the
+// NT = NB(NB+1)/2 tiles are dealt to the waves in contiguous runs (at NB = 8, NW = 8:
+// waves 0-3 own 5 tiles, waves 4-7 own 4, so every SIMD carries 9).  Rows move in stages
+// of NW chunks (NW x 4 rows): wave v loads chunk v of the next stage from HBM (16-byte
+// buffer loads, each row read exactly ONCE per launch), applies mask and weight once,
+// accumulates c / scalars for that chunk on the VALU and writes the weighted values to
+// LDS in MFMA-fragment order ([chunk][block][lane], conflict-free ds_write/read_b64).
+// After one barrier per stage every wave reads, per chunk, only the operand blocks of
+// its own tiles and issues its MFMAs.  Versus kernel 1 with SPLIT = 2 this halves the
+// L2/HBM request traffic (measured: the duplicate `nt` reads of the two sub-waves MISS in
+// L2 and the chip fetched 2x the algorithmic bytes), and cuts the fp64 VALU work 8x.
+// LDS: 2 stages x NW chunks x NB blocks x 512 B (64 KiB at NB = 8, NW = 8), so two
+// workgroups share a CU.  Partials: part[wg][NT][4][64] | cpart[wg][NB][16] | spart[wg][4].
+// ---------------------------------------------------------------------------------
+namespace {
+
+// NTM = number of tiles THIS wave owns (compile-time: the kernel dispatches on the wave's
+// class so that the stage loop is one branch-free scheduling region).
+template <int NB, int NW, int NTM, bool FULLK, bool NT>
+__device__ __forceinline__ void syrk_lds_body(double* lds, const WaveBufs& wb, int K, unsigned nstage, int wv, int t0,
+                                              double* __restrict__ pw, double* __restrict__ cw,
+                                              double* __restrict__ sw) {
+    constexpr int NTILE = NB * (NB + 1) / 2;
+    constexpr int STAGE_DOUBLES = NW * NB * 64;
+    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
+
+    int tp[NTM], tq[NTM];
+#pragma unroll
+    for (int u = 0; u < NTM; ++u) {
+        int t = t0 + u;
+        if (t >= NTILE) t = NTILE - 1;
+        int p = 0;
+        while (p + 1 < NB && tri_index(p + 1, p + 1, NB) <= t) ++p;
+        tp[u] = p * 64;                                   // LDS offsets (doubles) of the operand blocks
+        tq[u] = (p + (t - tri_index(p, p, NB))) * 64;
+    }
+    d4 acc[NTM];
+#pragma unroll
+    for (int u = 0; u < NTM; ++u) acc[u] = d4{0.0, 0.0, 0.0, 0.0};
+    double cacc[NB];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) cacc[p] = 0.0;
+    double bb = 0.0, sbw = 0.0, cnt = 0.0;
+
+    ChunkRaw<NB> raw;
+    ChunkRegs<NB> cr;
+    // weight the raw chunk in `raw`, accumulate c / scalars, park it in LDS stage `buf`
+    auto park = [&](int buf) {
+        finish_chunk<NB, FULLK>(cr, raw, K, e);
+        valu_c_chunk<NB>(cacc, cr);
+        valu_s_chunk<NB>(bb, sbw, cnt, cr);
+        double* dst = lds + buf * STAGE_DOUBLES + (wv * NB) * 64 + lane;
+#pragma unroll
+        for (int bq = 0; bq < NB; ++bq) dst[bq * 64] = cr.v[bq];
+    };
+
+    if (nstage > 0) {
+        issue_chunk<NB, NT>(raw, wb, (unsigned)wv, kr);
+        park(0);
+        issue_chunk<NB, NT>(raw, wb, (unsigned)(NW + wv), kr);
+        __syncthreads();
+        for (unsigned s = 0; s < nstage; ++s) {
+            const double* src = lds + (s & 1) * STAGE_DOUBLES + lane;
+#pragma unroll
+            for (int c = 0; c < NW; ++c) {
+#pragma unroll
+                for (int u = 0; u < NTM; ++u) {
+                    const double va = src[c * NB * 64 + tp[u]];
+                    const double vb = src[c * NB * 64 + tq[u]];
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(va, vb, acc[u], 0, 0, 0);
+                }
+            }
+            // next stage: weight + park what was prefetched, then prefetch the stage after
+            park((s + 1) & 1);
+            issue_chunk<NB, NT>(raw, wb, (s + 2) * NW + wv, kr);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: tiles are disjoint across waves -> straight to the per-workgroup partial
+#pragma unroll
+    for (int u = 0; u < NTM; ++u) {
+        const int t = t0 + u;
+        if (t < NTILE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pw[(t * 4 + i) * 64 + lane] = acc[u][i];
+        }
+    }
+    // c / scalars: fold the NW per-wave partials through LDS in a fixed order -> one per workgroup
+    // (the stage buffers are free: every wave is past the last barrier of the stage loop)
+    constexpr int CS = NB * 16 + 4;
+    double* fold = lds + wv * CS;
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+        double sm = xlane_sum_rows(cacc[p]);
+        if (kr == 0) fold[p * 16 + e] = sm;
+    }
+    double sb = xlane_sum_rows(bb), ss = xlane_sum_rows(sbw), sc = xlane_sum_rows(cnt);
+    if (lane == 0) {
+        fold[NB * 16 + 0] = sb;
+        fold[NB * 16 + 1] = ss;
+        fold[NB * 16 + 2] = sc;
+        fold[NB * 16 + 3] = 0.0;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        for (int j = lane; j < CS; j += 64) {
+            double tot = 0.0;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) tot += lds[k * CS + j];
+            if (j < NB * 16) cw[j] = tot;
+            else sw[j - NB * 16] = tot;
+        }
+    }
+}
+
+}  // namespace
+
+template <int NB, int NW, bool FULLK, bool NT>
+__global__ __launch_bounds__(64 * NW, 4) void fsnap_syrk_lds(const double* __restrict__ A, int64_t lda,
+                                                             const double* __restrict__ b,
+                                                             const double* __restrict__ w,
+                                                             const unsigned char* __restrict__ mask, int64_t m, int K,
+                                                             int64_t chunks_per_wg, double* __restrict__ part,
+                                                             double* __restrict__ cpart, double* __restrict__ spart) {
+    constexpr int NTILE = NB * (NB + 1) / 2;
+    constexpr int NTW = (NTILE + NW - 1) / NW;        // tiles of a "big" wave
+    constexpr int BIG = NTILE - (NTW - 1) * NW;       // number of waves owning NTW tiles (the rest own NTW - 1)
+    __shared__ double lds[2 * NW * NB * 64];
+
+    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t wg = blockIdx.x;
+
+    // row range of this workgroup and the descriptors that bound it
+    const int64_t nchunks = (m + 3) >> 2;
+    int64_t c0 = wg * chunks_per_wg;
+    int64_t c1 = c0 + chunks_per_wg;
+    if (c1 > nchunks) c1 = nchunks;
+    if (c0 > c1) c0 = c1;
+    const int64_t row0 = c0 << 2;
+    int64_t row1 = c1 << 2;
+    if (row1 > m) row1 = m;
+    const int64_t nrow = row1 > row0 ? row1 - row0 : 0;
+    WaveBufs wb;
+    wb.A = make_rsrc(A + row0 * lda, (unsigned)(nrow * lda * 8 + (nrow ? 16 : 0)));
+    wb.b = make_rsrc(b + row0, (unsigned)(nrow * 8));
+    wb.w = make_rsrc(w + row0, (unsigned)(nrow * 8));
+    wb.mask = make_rsrc(mask + row0, (unsigned)nrow);
+    wb.voffA = (unsigned)((kr * lda + 2 * e) * 8);
+    wb.voffT = (unsigned)((kr * lda + 16 * (NB - 1) + e) * 8);
+    wb.voffR = (unsigned)(kr * 8);
+    wb.chunk_bytes = (unsigned)(lda * 32);
+    const unsigned ncl = (unsigned)(c1 - c0);
+    const unsigned nstage = (ncl + NW - 1) / NW;
+
+    double* pw = part + wg * (int64_t)(NTILE * 256);
+    double* cw = cpart + wg * (int64_t)(NB * 16);
+    double* sw = spart + wg * 4;
+    if (wv < BIG) {
+        syrk_lds_body<NB, NW, NTW, FULLK, NT>(lds, wb, K, nstage, wv, wv * NTW, pw, cw, sw);
+    } else {
+        syrk_lds_body<NB, NW, (NTW > 1 ? NTW - 1 : 1), FULLK, NT>(lds, wb, K, nstage, wv,
+                                                                  BIG * NTW + (wv - BIG) * (NTW - 1), pw, cw, sw);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 1T: general-K fused mask x weight x SYRK (K > 128: ACE / quadratic SNAP widths).
+// The column space is cut into superblocks of 64 columns (4 MFMA blocks, even/odd
+// interleaved in pairs like kernel 1).  A workgroup owns ONE superblock pair (I <= J) over
+// ONE row split; each of its 4 waves streams a quarter of the split's rows and keeps the
+// 4 x 4 tiles of G[I-block, J-block] (16 tiles, 128 accumulator registers; 10 tiles on
+// the diagonal I == J) in registers, so two workgroups share a CU.  Per 4-row chunk a
+// lane loads 4 + 4 doubles and feeds 16 MFMAs.  Pairs are the fast grid index: the
+// workgroups that run concurrently read the SAME rows (different column superblocks),
+// so every row is fetched from HBM once per split and re-read from L2 / Infinity Cache.
+// c and the scalars ride on the diagonal pairs / pair 0.
+// Partials: partT[split*npairs + pair][16][4][64] | cpartT[(split*NSB + I)*4 + wave][4][16]
+//           | spartT[split*4 + wave][4]
+// ---------------------------------------------------------------------------------
+namespace {
+
+template <bool NT>
+struct RawT {
+    u4 pi[2], pj[2];
+    u2 bv, wv;
+    unsigned char mk;
+};
+
+template <bool DIAG, bool NT>
+__device__ __forceinline__ void issue_chunk_t(RawT<NT>& r, const WaveBufs& wb, unsigned voffI, unsigned voffJ,
+                                              unsigned cl, int kr) {
+    const unsigned soff = cl * wb.chunk_bytes;
+    constexpr int AUX = NT ? 2 : 0;
+    r.pi[0] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, voffI, soff, AUX);
+    r.pi[1] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, voffI + 256u, soff, AUX);
+    if (!DIAG) {
+        r.pj[0] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, voffJ, soff, AUX);
+        r.pj[1] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, voffJ + 256u, soff, AUX);
+    }
+    r.bv = __builtin_amdgcn_raw_buffer_load_b64(wb.b, wb.voffR, cl * 32u, 0);
+    r.wv = __builtin_amdgcn_raw_buffer_load_b64(wb.w, wb.voffR, cl * 32u, 0);
+    r.mk = __builtin_amdgcn_raw_buffer_load_b8(wb.mask, (unsigned)kr, cl * 4u, 0);
+}
+
+__device__ __forceinline__ void weight4(double (&v)[4], const u4 (&p)[2], double wv, bool keep, int col0, int K, int e) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const d2 x = __builtin_bit_cast(d2, p[j]);
+        const bool k0 = keep && (col0 + 32 * j + 2 * e < K);
+        const bool k1 = keep && (col0 + 32 * j + 2 * e + 1 < K);
+        v[2 * j] = k0 ? wv * x[0] : 0.0;
+        v[2 * j + 1] = k1 ? wv * x[1] : 0.0;
+    }
+}
+
+template <bool DIAG, bool NT>
+__device__ __forceinline__ void syrk_tiled_body(const double* __restrict__ A, int64_t lda,
+                                                const double* __restrict__ b, const double* __restrict__ w,
+                                                const unsigned char* __restrict__ mask, int64_t m, int K, int I, int J,
+                                                int64_t c0, int64_t c1, int wv_in_wg, bool do_c, bool do_s,
+                                                double* lds, double* __restrict__ pw, double* __restrict__ cw,
+                                                double* __restrict__ sw) {
+    constexpr int NTW = 16;
+    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
+    d4 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+    double cacc[4] = {0.0, 0.0, 0.0, 0.0};
+    double bb = 0.0, sbw = 0.0, cnt = 0.0;
+
+    const int64_t row0 = c0 << 2;
+    int64_t row1 = c1 << 2;
+    if (row1 > m) row1 = m;
+    const int64_t nrow = row1 > row0 ? row1 - row0 : 0;
+    WaveBufs wb;
+    wb.A = make_rsrc(A + row0 * lda, (unsigned)(nrow * lda * 8 + (nrow ? 16 : 0)));
+    wb.b = make_rsrc(b + row0, (unsigned)(nrow * 8));
+    wb.w = make_rsrc(w + row0, (unsigned)(nrow * 8));
+    wb.mask = make_rsrc(mask + row0, (unsigned)nrow);
+    wb.voffA = 0;
+    wb.voffT = 0;
+    wb.voffR = (unsigned)(kr * 8);
+    wb.chunk_bytes = (unsigned)(lda * 32);
+    const unsigned voffI = (unsigned)((kr * lda + 64 * I + 2 * e) * 8);
+    const unsigned voffJ = (unsigned)((kr * lda + 64 * J + 2 * e) * 8);
+    const unsigned ncl = (unsigned)(c1 > c0 ? c1 - c0 : 0);
+
+    RawT<NT> r0, r1, r2;
+    double vI[4], vJ[4];
+
+#define FSNAP_STAGE_T(R, OFF)                                                                   \
+    {                                                                                           \
+        const bool keep = (R.mk != 0);                                                          \
+        const double wgt = __builtin_bit_cast(double, R.wv);                                    \
+        weight4(vI, R.pi, wgt, keep, 64 * I, K, e);                                             \
+        if (!DIAG) weight4(vJ, R.pj, wgt, keep, 64 * J, K, e);                                  \
+        const double wbv = keep ? wgt * __builtin_bit_cast(double, R.bv) : 0.0;                 \
+        const double one = keep ? 1.0 : 0.0;                                                    \
+        issue_chunk_t<DIAG, NT>(R, wb, voffI, voffJ, cl + (OFF) + 3, kr);                       \
+        _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                         \
+            _Pragma("unroll") for (int q = (DIAG ? p : 0); q < 4; ++q) {                        \
+                acc[p * 4 + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(vI[p], DIAG ? vI[q] : vJ[q], acc[p * 4 + q], 0, 0, 0); \
+            }                                                                                   \
+        }                                                                                       \
+        if (DIAG) {                                                                             \
+            if (do_c) {                                                                         \
+                _Pragma("unroll") for (int p = 0; p < 4; ++p) cacc[p] = __builtin_fma(vI[p], wbv, cacc[p]); \
+            }                                                                                   \
+            if (do_s) {                                                                         \
+                bb = __builtin_fma(wbv, wbv, bb);                                               \
+                sbw += wbv;                                                                     \
+                cnt += one;                                                                     \
+            }                                                                                   \
+        }                                                                                       \
+    }
+    if (ncl > 0) {
+        issue_chunk_t<DIAG, NT>(r0, wb, voffI, voffJ, 0, kr);
+        issue_chunk_t<DIAG, NT>(r1, wb, voffI, voffJ, 1, kr);
+        issue_chunk_t<DIAG, NT>(r2, wb, voffI, voffJ, 2, kr);
+        for (unsigned cl = 0; cl < ncl; cl += 3) {
+            FSNAP_STAGE_T(r0, 0)
+            FSNAP_STAGE_T(r1, 1)
+            FSNAP_STAGE_T(r2, 2)
+        }
+    }
+#undef FSNAP_STAGE_T
+
+    // fold the 4 waves through LDS ({2,3} -> {0,1}, 1 -> 0), then one partial per workgroup
+    {
+        const int rw = wv_in_wg;
+        double* slot_hi = lds + (size_t)((rw & 1) * NTW) * 256;
+        if (rw >= 2) {
+#pragma unroll
+            for (int u = 0; u < NTW; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) slot_hi[(u * 4 + i) * 64 + lane] = acc[u][i];
+        }
+        __syncthreads();
+        if (rw < 2) {
+#pragma unroll
+            for (int u = 0; u < NTW; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[u][i] += slot_hi[(u * 4 + i) * 64 + lane];
+        }
+        __syncthreads();
+        if (rw == 1) {
+#pragma unroll
+            for (int u = 0; u < NTW; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lds[(u * 4 + i) * 64 + lane] = acc[u][i];
+        }
+        __syncthreads();
+        if (rw == 0) {
+#pragma unroll
+            for (int u = 0; u < NTW; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pw[(u * 4 + i) * 64 + lane] = acc[u][i] + lds[(u * 4 + i) * 64 + lane];
+        }
+    }
+    if (DIAG && do_c) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            double s = xlane_sum_rows(cacc[p]);
+            if (kr == 0) cw[p * 16 + e] = s;
+        }
+    }
+    if (DIAG && do_s) {
+        double sb = xlane_sum_rows(bb), ss = xlane_sum_rows(sbw), sc = xlane_sum_rows(cnt);
+        if (lane == 0) {
+            sw[0] = sb;
+            sw[1] = ss;
+            sw[2] = sc;
+            sw[3] = 0.0;
+        }
+    }
+}
+
+}  // namespace
+
+template <bool NT>
+__global__ __launch_bounds__(256, 2) void fsnap_syrk_tiled(const double* __restrict__ A, int64_t lda,
+                                                           const double* __restrict__ b,
+                                                           const double* __restrict__ w,
+                                                           const unsigned char* __restrict__ mask, int64_t m, int K,
+                                                           int NSB, int npairs, int64_t chunks_per_split,
+                                                           double* __restrict__ part, double* __restrict__ cpart,
+                                                           double* __restrict__ spart) {
+    __shared__ double lds[2 * 16 * 256];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int pair = (int)(blockIdx.x % (unsigned)npairs);
+    const int split = (int)(blockIdx.x / (unsigned)npairs);
+    // decode pair -> (I, J), I <= J, row-major packed triangle over NSB superblocks
+    int I = 0, rem = pair;
+    while (rem >= NSB - I) {
+        rem -= NSB - I;
+        ++I;
+    }
+    const int J = I + rem;
+    const int64_t nchunks = (m + 3) >> 2;
+    const int64_t cpw = (chunks_per_split + 3) >> 2;
+    int64_t s0 = (int64_t)split * chunks_per_split;
+    int64_t s1 = s0 + chunks_per_split;
+    if (s1 > nchunks) s1 = nchunks;
+    int64_t c0 = s0 + (int64_t)wv * cpw;
+    int64_t c1 = c0 + cpw;
+    if (c1 > s1) c1 = s1;
+    if (c0 > s1) c0 = s1;
+    double* pw = part + ((int64_t)split * npairs + pair) * (16 * 256);
+    double* cw = cpart + (((int64_t)split * NSB + I) * 4 + wv) * 64;
+    double* sw = spart + ((int64_t)split * 4 + wv) * 4;
+    if (I == J) {
+        syrk_tiled_body<true, NT>(A, lda, b, w, mask, m, K, I, J, c0, c1, wv, true, pair == 0, lds, pw, cw, sw);
+    } else {
+        syrk_tiled_body<false, NT>(A, lda, b, w, mask, m, K, I, J, c0, c1, wv, false, false, lds, pw, cw, sw);
+    }
+}
+
+// Reduction of the tiled partials into the packed buffer (same output as kernel 2).
+// Element space: npairs*16*256 G elements (nsplit partials each), NSB*64 c elements and
+// 4 scalars (nsplit*4 partials each).  1024 threads = 64 elements x 16 partial slices.
+__global__ __launch_bounds__(1024) void fsnap_reduce_tiled(const double* __restrict__ part,
+                                                           const double* __restrict__ cpart,
+                                                           const double* __restrict__ spart, int nsplit, int NSB,
+                                                           int npairs, int K, double* __restrict__ out) {
+    __shared__ double red[1024];
+    const int64_t nG = (int64_t)npairs * 4096;
+    const int nC = NSB * 64, nS = 4;
+    const int tid = threadIdx.x, g = tid >> 6, l = tid & 63;
+    const int64_t idx = (int64_t)blockIdx.x * 64 + l;
+    const double* src = nullptr;
+    int64_t stride = 0;
+    int np = 0;
+    if (idx < nG) {
+        src = part + idx;
+        stride = nG;
+        np = nsplit;
+    } else if (idx < nG + nC) {
+        // c element j of superblock I: partial index ((split*NSB + I)*4 + wave)
+        const int j = (int)(idx - nG);
+        src = cpart + (int64_t)(j >> 6) * 256 + (j & 63);
+        stride = 0;  // handled below (two-level layout)
+        np = nsplit * 4;
+    } else if (idx < nG + nC + nS) {
+        src = spart + (idx - nG - nC);
+        stride = 4;
+        np = nsplit * 4;
+    }
+    double s = 0.0;
+    if (src) {
+        if (idx >= nG && idx < nG + nC) {
+            // partial q = split*4 + wave lives at cpart[((split*NSB + I)*4 + wave)*64 + e]
+            for (int q = g; q < np; q += 16) {
+                const int split = q >> 2, wave = q & 3;
+                s += src[((int64_t)split * NSB * 4 + wave) * 64];
+            }
+        } else {
+            int p = g;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            for (; p + 48 < np; p += 64) {
+                const double x0 = src[(int64_t)p * stride], x1 = src[(int64_t)(p + 16) * stride];
+                const double x2 = src[(int64_t)(p + 32) * stride], x3 = src[(int64_t)(p + 48) * stride];
+                a0 += x0; a1 += x1; a2 += x2; a3 += x3;
+            }
+            for (; p < np; p += 16) a0 += src[(int64_t)p * stride];
+            s = (a0 + a1) + (a2 + a3);
+        }
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (g == 0 && src) {
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += red[k * 64 + l];
+        if (idx < nG) {
+            const int pair = (int)(idx >> 12), rem = (int)(idx & 4095);
+            const int t = rem >> 8, i = (rem >> 6) & 3, ln = rem & 63;
+            int I = 0, pr = pair;
+            while (pr >= NSB - I) {
+                pr -= NSB - I;
+                ++I;
+            }
+            const int J = I + pr;
+            const int p = t >> 2, q = t & 3;
+            if (I == J && q < p) return;  // unused slots of a diagonal pair
+            const int ep = (ln >> 4) + 4 * i, eq = ln & 15;
+            const int r = 64 * I + 32 * (p >> 1) + 2 * ep + (p & 1);
+            const int c = 64 * J + 32 * (q >> 1) + 2 * eq + (q & 1);
+            if (r < K && c < K) {
+                out[(int64_t)r * K + c] = tot;
+                if (!(I == J && p == q)) out[(int64_t)c * K + r] = tot;
+            }
+        } else if (idx < nG + nC) {
+            const int j = (int)(idx - nG);
+            const int Ib = j >> 6, bq = (j >> 4) & 3, e = j & 15;
+            const int cidx = 64 * Ib + 32 * (bq >> 1) + 2 * e + (bq & 1);
+            if (cidx < K) out[(int64_t)K * K + cidx] = tot;
+        } else {
+            const int j = (int)(idx - nG - nC);
             if (j < 3) out[(int64_t)K * K + K + j] = tot;
         }
     }
