@@ -78,13 +78,26 @@ int chol_lower(double* a, int n, double* min_piv2) {
     return -1;
 }
 
-// solve L L^T x = rhs in place; lt = transposed copy of l (rows of lt = columns of l) so
-// that both sweeps run over contiguous rows
-void chol_solve(const double* l, const double* lt, int n, double* x) {
+// y -= alpha * x over n contiguous doubles
+static inline void axpy_neg(double* y, const double* x, double alpha, int n) {
+    const v4d av = {alpha, alpha, alpha, alpha};
+    int k = 0;
+    for (; k + 4 <= n; k += 4) {
+        v4d yv = ld4(y + k);
+        yv -= av * ld4(x + k);
+        *reinterpret_cast<v4du*>(y + k) = yv;
+    }
+    for (; k < n; ++k) y[k] -= alpha * x[k];
+}
+
+// solve L L^T x = rhs in place (l lower, row-major): forward sweep by dot products over
+// contiguous rows, backward sweep in axpy form over the same contiguous rows
+void chol_solve(const double* l, int n, double* x) {
     for (int i = 0; i < n; ++i) x[i] = (x[i] - dotv(l + (size_t)i * n, x, i)) / l[(size_t)i * n + i];
     for (int i = n - 1; i >= 0; --i) {
-        const double* r = lt + (size_t)i * n;
-        x[i] = (x[i] - dotv(r + i + 1, x + i + 1, n - 1 - i)) / r[i];
+        const double* r = l + (size_t)i * n;
+        x[i] /= r[i];
+        axpy_neg(x, r, x[i], i);
     }
 }
 
@@ -234,7 +247,9 @@ bool all_finite(const double* p, size_t n) {
 // pivot.  min_piv2 = smallest relative squared pivot of the scaled matrix (a cheap
 // lower-bound style estimate of 1/cond).
 int scaled_chol_solve(const vec& M, const vec& rhs, int n, vec& x, double* min_piv2) {
-    vec d(n), S((size_t)n * n), y(n);
+    vec d(n), y(n);
+    static thread_local vec S;   // scratch reused across calls (a fit loop calls this every step)
+    S.resize((size_t)n * n);
     for (int i = 0; i < n; ++i) {
         const double g = M[(size_t)i * n + i];
         if (!(g > 0.0)) {
@@ -245,19 +260,17 @@ int scaled_chol_solve(const vec& M, const vec& rhs, int n, vec& x, double* min_p
     }
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) S[(size_t)i * n + j] = M[(size_t)i * n + j] * d[i] * d[j];
-    vec L(S);
+    static thread_local vec L;
+    L = S;
     const int fail = chol_lower(L.data(), n, min_piv2);
     if (fail >= 0) return fail;
-    vec LT((size_t)n * n);
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j <= i; ++j) LT[(size_t)j * n + i] = L[(size_t)i * n + j];
     for (int i = 0; i < n; ++i) y[i] = rhs[i] * d[i];
     vec z(y);
-    chol_solve(L.data(), LT.data(), n, z.data());
+    chol_solve(L.data(), n, z.data());
     // one step of iterative refinement on the scaled system, residual in ~2x precision
     vec r(n);
     residual_dot2(S.data(), n, z.data(), y.data(), r.data());
-    chol_solve(L.data(), LT.data(), n, r.data());
+    chol_solve(L.data(), n, r.data());
     for (int i = 0; i < n; ++i) z[i] += r[i];
     x.resize(n);
     for (int i = 0; i < n; ++i) x[i] = z[i] * d[i];
@@ -296,7 +309,8 @@ extern "C" int fsnap_solve(int kind, double param, int64_t K64, const double* G,
     const double eps = std::numeric_limits<double>::epsilon();
 
     // active columns: drop exactly-zero columns when there is no ridge shift
-    Reduced R;
+    static thread_local Reduced R;
+    R.idx.clear();
     R.idx.reserve(K);
     for (int j = 0; j < K; ++j) {
         const double gjj = G[(size_t)j * K + j] + alpha;
