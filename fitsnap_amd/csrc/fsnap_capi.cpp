@@ -67,7 +67,7 @@ struct fsnap_ctx {
     int opt_nt = 1;
     int opt_nblocks = 0;      // 0 = auto
     int opt_tiled = 0;        // force the general-K tiled kernel also for K <= 128
-    int opt_kernel = 0;       // 0 auto | 1 wave-triangle (kernel 1) | 2 LDS-shared, 8 waves | 3 LDS-shared, 16 waves
+    int opt_kernel = 0;       // 0 auto | 1 wave-triangle (kernel 1) | 2 LDS-shared, static per-wave bodies | 3 LDS-shared, generic
     int opt_nsplit = 0;       // row splits of the tiled kernel (0 = auto)
     // timing flags
     bool t_syrk = false, t_upload = false, t_weight = false, t_predict = false;
@@ -110,9 +110,9 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
     const int64_t off_limit = (int64_t)0xFFF00000;  // 32-bit buffer offsets, 1 MiB of slack for prefetch overshoot
     if (g->NB >= 6 && ctx->opt_kernel != 1) {
         // kernel 1L: rows shared through LDS, whole triangle per workgroup
-        const int nw = (ctx->opt_kernel == 3) ? 16 : 8;
+        const int nw = 8;
         const int64_t nchunks = (m + 3) / 4;
-        int64_t nblocks = ctx->opt_nblocks > 0 ? ctx->opt_nblocks : (int64_t)ctx->num_cu * (nw == 8 ? 2 : 1);
+        int64_t nblocks = ctx->opt_nblocks > 0 ? ctx->opt_nblocks : (int64_t)ctx->num_cu * 2;
         const int64_t max_blocks = (nchunks + 4 * nw - 1) / (4 * nw);   // >= 4 stages per workgroup
         if (nblocks > max_blocks) nblocks = max_blocks;
         if (nblocks < 1) nblocks = 1;
@@ -125,7 +125,7 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
         if (nblocks > 0x7FFFFFF) return ctx->fail(FSNAP_E_ARG, "too many workgroups");
         g->nblocks = (int)nblocks;
         g->cpw = cpg;
-        g->split = nw;
+        g->split = (ctx->opt_kernel == 3) ? -nw : nw;   // -8 = generic tile-table variant (A/B)
         g->threads = 64 * nw;
         g->lds_waves = nw;
         return FSNAP_OK;

@@ -42,6 +42,9 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <utility>
+
 #include "fsnap_kernels.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -604,6 +607,181 @@ __global__ __launch_bounds__(64 * NW, 4) void fsnap_syrk_lds(const double* __res
 }
 
 // ---------------------------------------------------------------------------------
+// Kernel 1L, statically specialised per wave (the default): same algorithm as
+// fsnap_syrk_lds, but every wave runs a body instantiated for ITS tile list, so the
+// operand offsets are instruction immediates (no per-MFMA address VALU) and an A operand
+// shared by consecutive tiles of a row is read from LDS once (common-subexpression of the
+// identical ds_read).  Measured in-kernel (tools/mfma_f64_peak.hip): the matrix pipe issues
+// one fp64 MFMA per 64 cycles; two ds_read_b64 + wait per MFMA cost ~15 %, one fp64 VALU op
+// per MFMA ~7 % — hence fewer LDS reads and fewer VALU ops per MFMA.
+// ---------------------------------------------------------------------------------
+namespace {
+
+template <int NB>
+__host__ __device__ constexpr int tile_p_of(int t) {
+    int p = 0;
+    while (p + 1 < NB && tri_index(p + 1, p + 1, NB) <= t) ++p;
+    return p;
+}
+template <int NB>
+__host__ __device__ constexpr int tile_q_of(int t) {
+    return tile_p_of<NB>(t) + (t - tri_index(tile_p_of<NB>(t), tile_p_of<NB>(t), NB));
+}
+
+template <int NB, int NW>
+struct LdsPlan {
+    static constexpr int NTILE = NB * (NB + 1) / 2;
+    static constexpr int NTW = (NTILE + NW - 1) / NW;
+    static constexpr int BIG = NTILE - (NTW - 1) * NW;
+    static constexpr int ntm(int wv) { return wv < BIG ? NTW : NTW - 1; }
+    static constexpr int t0(int wv) { return wv < BIG ? wv * NTW : BIG * NTW + (wv - BIG) * (NTW - 1); }
+};
+
+template <int P, int Q>
+__device__ __forceinline__ void tile_mfma(d4& acc, const double* src) {
+    const double va = src[P * 64];
+    const double vb = src[Q * 64];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va, vb, acc, 0, 0, 0);
+}
+
+template <int NB, int T0, int NTM, int... U>
+__device__ __forceinline__ void chunk_tiles(d4 (&acc)[NTM], const double* src, std::integer_sequence<int, U...>) {
+    (tile_mfma<tile_p_of<NB>(T0 + U), tile_q_of<NB>(T0 + U)>(acc[U], src), ...);
+}
+
+template <int NB, int NW, int WV, bool FULLK, bool NT>
+__device__ __forceinline__ void syrk_lds_static_body(double* lds, const WaveBufs& wb, int K, unsigned nstage,
+                                                     double* __restrict__ pw, double* __restrict__ cw,
+                                                     double* __restrict__ sw) {
+    using Plan = LdsPlan<NB, NW>;
+    constexpr int NTILE = Plan::NTILE;
+    constexpr int NTM = Plan::ntm(WV) > 0 ? Plan::ntm(WV) : 1;
+    constexpr bool HAS_TILES = Plan::ntm(WV) > 0;
+    constexpr int T0 = Plan::t0(WV);
+    constexpr int STAGE_DOUBLES = NW * NB * 64;
+    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
+
+    d4 acc[NTM];
+#pragma unroll
+    for (int u = 0; u < NTM; ++u) acc[u] = d4{0.0, 0.0, 0.0, 0.0};
+    double cacc[NB];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) cacc[p] = 0.0;
+    double bb = 0.0, sbw = 0.0, cnt = 0.0;
+
+    ChunkRaw<NB> raw;
+    ChunkRegs<NB> cr;
+    auto park = [&](int buf) {
+        finish_chunk<NB, FULLK>(cr, raw, K, e);
+        valu_c_chunk<NB>(cacc, cr);
+        valu_s_chunk<NB>(bb, sbw, cnt, cr);
+        double* dst = lds + buf * STAGE_DOUBLES + (WV * NB) * 64 + lane;
+#pragma unroll
+        for (int bq = 0; bq < NB; ++bq) dst[bq * 64] = cr.v[bq];
+    };
+
+    if (nstage > 0) {
+        issue_chunk<NB, NT>(raw, wb, (unsigned)WV, kr);
+        park(0);
+        issue_chunk<NB, NT>(raw, wb, (unsigned)(NW + WV), kr);
+        __syncthreads();
+        for (unsigned s = 0; s < nstage; ++s) {
+            const double* src = lds + (s & 1) * STAGE_DOUBLES + lane;
+            if (HAS_TILES) {
+#pragma unroll
+                for (int c = 0; c < NW; ++c)
+                    chunk_tiles<NB, T0, NTM>(acc, src + c * NB * 64, std::make_integer_sequence<int, NTM>{});
+            }
+            park((s + 1) & 1);
+            issue_chunk<NB, NT>(raw, wb, (s + 2) * NW + WV, kr);
+            __syncthreads();
+        }
+    }
+
+    if (HAS_TILES) {
+#pragma unroll
+        for (int u = 0; u < NTM; ++u) {
+            const int t = T0 + u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pw[(t * 4 + i) * 64 + lane] = acc[u][i];
+        }
+    }
+    constexpr int CS = NB * 16 + 4;
+    double* fold = lds + WV * CS;
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+        double sm = xlane_sum_rows(cacc[p]);
+        if (kr == 0) fold[p * 16 + e] = sm;
+    }
+    double sb = xlane_sum_rows(bb), ss = xlane_sum_rows(sbw), sc = xlane_sum_rows(cnt);
+    if (lane == 0) {
+        fold[NB * 16 + 0] = sb;
+        fold[NB * 16 + 1] = ss;
+        fold[NB * 16 + 2] = sc;
+        fold[NB * 16 + 3] = 0.0;
+    }
+    __syncthreads();
+    if (WV == 0) {
+        for (int j = lane; j < CS; j += 64) {
+            double tot = 0.0;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) tot += lds[k * CS + j];
+            if (j < NB * 16) cw[j] = tot;
+            else sw[j - NB * 16] = tot;
+        }
+    }
+}
+
+template <int NB, int NW, bool FULLK, bool NT, int... W>
+__device__ __forceinline__ void syrk_lds_dispatch(int wv, double* lds, const WaveBufs& wb, int K, unsigned nstage,
+                                                  double* pw, double* cw, double* sw, std::integer_sequence<int, W...>) {
+    // every wave of the workgroup takes exactly one branch; all bodies execute the same barriers
+    ((wv == W ? (syrk_lds_static_body<NB, NW, W, FULLK, NT>(lds, wb, K, nstage, pw, cw, sw), 0) : 0), ...);
+}
+
+}  // namespace
+
+template <int NB, int NW, bool FULLK, bool NT>
+__global__ __launch_bounds__(64 * NW, 4) void fsnap_syrk_lds_static(const double* __restrict__ A, int64_t lda,
+                                                                    const double* __restrict__ b,
+                                                                    const double* __restrict__ w,
+                                                                    const unsigned char* __restrict__ mask, int64_t m,
+                                                                    int K, int64_t chunks_per_wg,
+                                                                    double* __restrict__ part,
+                                                                    double* __restrict__ cpart,
+                                                                    double* __restrict__ spart) {
+    constexpr int NTILE = NB * (NB + 1) / 2;
+    __shared__ double lds[2 * NW * NB * 64];
+    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t wg = blockIdx.x;
+    const int64_t nchunks = (m + 3) >> 2;
+    int64_t c0 = wg * chunks_per_wg;
+    int64_t c1 = c0 + chunks_per_wg;
+    if (c1 > nchunks) c1 = nchunks;
+    if (c0 > c1) c0 = c1;
+    const int64_t row0 = c0 << 2;
+    int64_t row1 = c1 << 2;
+    if (row1 > m) row1 = m;
+    const int64_t nrow = row1 > row0 ? row1 - row0 : 0;
+    WaveBufs wb;
+    wb.A = make_rsrc(A + row0 * lda, (unsigned)(nrow * lda * 8 + (nrow ? 16 : 0)));
+    wb.b = make_rsrc(b + row0, (unsigned)(nrow * 8));
+    wb.w = make_rsrc(w + row0, (unsigned)(nrow * 8));
+    wb.mask = make_rsrc(mask + row0, (unsigned)nrow);
+    wb.voffA = (unsigned)((kr * lda + 2 * e) * 8);
+    wb.voffT = (unsigned)((kr * lda + 16 * (NB - 1) + e) * 8);
+    wb.voffR = (unsigned)(kr * 8);
+    wb.chunk_bytes = (unsigned)(lda * 32);
+    const unsigned ncl = (unsigned)(c1 - c0);
+    const unsigned nstage = (ncl + NW - 1) / NW;
+    double* pw = part + wg * (int64_t)(NTILE * 256);
+    double* cw = cpart + wg * (int64_t)(NB * 16);
+    double* sw = spart + wg * 4;
+    syrk_lds_dispatch<NB, NW, FULLK, NT>(wv, lds, wb, K, nstage, pw, cw, sw, std::make_integer_sequence<int, NW>{});
+}
+
+// ---------------------------------------------------------------------------------
 // Kernel 1T: general-K fused mask x weight x SYRK (K > 128: ACE / quadratic SNAP widths).
 // The column space is cut into superblocks of 64 columns (4 MFMA blocks, even/odd
 // interleaved in pairs like kernel 1).  A workgroup owns ONE superblock pair (I <= J) over
@@ -1048,14 +1226,28 @@ static hipError_t launch_syrk_lds_nb(const SyrkArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-// a.split carries the waves per workgroup (8 or 16); a.chunks_per_wave = chunks per workgroup
+template <int NB, int NW>
+static hipError_t launch_syrk_lds_static_nb(const SyrkArgs& a, hipStream_t st) {
+    dim3 grid((unsigned)a.nblocks), block(64 * NW);
+    const bool fullk = (a.K == 16 * NB);
+    if (fullk)
+        hipLaunchKernelGGL((fsnap_syrk_lds_static<NB, NW, true, true>), grid, block, 0, st, a.A, a.lda, a.b, a.w, a.mask,
+                           a.m, a.K, a.chunks_per_wave, a.part, a.cpart, a.spart);
+    else
+        hipLaunchKernelGGL((fsnap_syrk_lds_static<NB, NW, false, true>), grid, block, 0, st, a.A, a.lda, a.b, a.w, a.mask,
+                           a.m, a.K, a.chunks_per_wave, a.part, a.cpart, a.spart);
+    return hipGetLastError();
+}
+
+// a.split = 8: statically specialised kernel 1L (default); a.split = -8: the generic
+// (run-time tile table) variant kept for A/B; a.chunks_per_wave = chunks per workgroup
 hipError_t launch_syrk_lds(const SyrkArgs& a, hipStream_t st) {
     const int nb = syrk_num_blocks(a.K);
-    if (a.split == 16) {
+    if (a.split == 8) {
         switch (nb) {
-            case 6: return launch_syrk_lds_nb<6, 16>(a, st);
-            case 7: return launch_syrk_lds_nb<7, 16>(a, st);
-            case 8: return launch_syrk_lds_nb<8, 16>(a, st);
+            case 6: return launch_syrk_lds_static_nb<6, 8>(a, st);
+            case 7: return launch_syrk_lds_static_nb<7, 8>(a, st);
+            case 8: return launch_syrk_lds_static_nb<8, 8>(a, st);
             default: return hipErrorInvalidValue;
         }
     }

@@ -66,8 +66,8 @@ int fsnap_ctx_set_stream(fsnap_ctx* ctx, void* hip_stream);
 /* Go back to the context's own non-blocking stream. */
 int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
 
-/* Tuning knobs (all optional; 0 = auto): "kernel" (1 wave-triangle, 2 LDS-shared with 8
- * waves per workgroup, 3 with 16), "split" (1|2, sub-waves per row-wave of kernel 1),
+/* Tuning knobs (all optional; 0 = auto): "kernel" (1 wave-triangle, 2 LDS-shared rows with
+ * per-wave specialised bodies, 3 LDS-shared generic variant), "split" (1|2, sub-waves per row-wave of kernel 1),
  * "nontemporal" (0|1), "nblocks" (workgroups of the SYRK kernel), "tiled" (1 = force the
  * general-K tiled kernel also for K <= 128), "nsplit" (row splits of the tiled kernel).
  * Unknown key -> FSNAP_E_ARG. */
