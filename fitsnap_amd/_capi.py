@@ -38,6 +38,10 @@ SIGNATURES = {
     "fsnap_last_error": (c_char_p, [c_void_p]),
     "fsnap_upload_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "fsnap_bind_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "fsnap_rows_alloc": (c_int, [c_void_p, c_int64, c_int64]),
+    "fsnap_assemble": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int]),
+    "fsnap_download_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "fsnap_set_weights": (c_int, [c_void_p, c_void_p, c_void_p]),
     "fsnap_bind_weights": (c_int, [c_void_p, c_void_p, c_void_p]),
     "fsnap_normal_eq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -194,6 +198,37 @@ class HipContext:
     def bind_rows(self, dA_ptr: int, m: int, K: int, lda: int, db_ptr: int):
         self._check(self._lib.fsnap_bind_rows(self._h, c_void_p(dA_ptr), m, K, lda, c_void_p(db_ptr)))
         self.m, self.K = m, K
+
+    def rows_alloc(self, m: int, K: int):
+        self._check(self._lib.fsnap_rows_alloc(self._h, int(m), int(K)))
+        self.m, self.K = int(m), int(K)
+
+    def assemble(self, raw, row0, src_row, kind, frac, d, truth, weight, fractions, blank2J, ntypes, ncoeff, offcol):
+        """Batch `_collect_lammps` transform into resident rows [row0, row0 + len(src_row))."""
+        raw = np.ascontiguousarray(raw, dtype=np.float64)
+        src_row = np.ascontiguousarray(src_row, dtype=np.int64)
+        kind = np.ascontiguousarray(kind, dtype=np.int32)
+        frac = np.ascontiguousarray(frac, dtype=np.int32)
+        d = np.ascontiguousarray(d, dtype=np.float64)
+        truth = np.ascontiguousarray(truth, dtype=np.float64)
+        weight = np.ascontiguousarray(weight, dtype=np.float64)
+        fractions = np.ascontiguousarray(fractions, dtype=np.float64).reshape(-1, ntypes)
+        blank2J = np.ascontiguousarray(blank2J, dtype=np.float64)
+        n = len(src_row)
+        if not (len(kind) == len(frac) == len(d) == len(truth) == len(weight) == n):
+            raise ValueError("plan arrays must have equal length")
+        self._check(self._lib.fsnap_assemble(
+            self._h, _ptr(raw), raw.shape[0], raw.shape[1], n, int(row0), _ptr(src_row), _ptr(kind), _ptr(frac), _ptr(d),
+            _ptr(truth), _ptr(weight), _ptr(fractions) if fractions.size else None, fractions.shape[0], _ptr(blank2J),
+            int(ntypes), int(ncoeff), int(offcol)))
+
+    def download_rows(self, want_a=True, want_b=True, want_w=True, out_a=None, out_b=None, out_w=None):
+        A = (out_a if out_a is not None else np.empty((self.m, self.K))) if want_a else None
+        b = (out_b if out_b is not None else np.empty(self.m)) if want_b else None
+        w = (out_w if out_w is not None else np.empty(self.m)) if want_w else None
+        lda = (A.strides[0] // 8) if A is not None else self.K
+        self._check(self._lib.fsnap_download_rows(self._h, _ptr(A), lda, _ptr(b), _ptr(w)))
+        return A, b, w
 
     def set_weights(self, w: np.ndarray, mask=None):
         w = _f64(w, "w")

@@ -1,0 +1,97 @@
+"""LAMMPS-backed calculator base (fitsnap3lib/calculators/lammps_base.py:10-307): the
+per-configuration driver ``process_configs`` / ``process_single`` and the zero-copy view of
+the LAMMPS compute array.  Building LAMMPS commands (box, atoms, computes) is LAMMPS'
+business and out of this repository's scope (OUT rows): ``_prepare_lammps``
+must be provided by whoever supplies the ``lammps`` object (tests inject a fake)."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from .calculator import Calculator
+
+
+def _extract_compute_np(lmp, name, compute_style, result_type, array_shape=None):
+    """Wrap a LAMMPS compute as an ndarray VIEW of LAMMPS' own memory, no copy
+    (lammps_base.py:280-307): style 0 global / type 2 array -> ``double**`` whose rows are
+    one contiguous row-major block."""
+    if array_shape is None:
+        return lmp.numpy.extract_compute(name, compute_style, result_type)
+    ptr = lmp.extract_compute(name, compute_style, result_type)
+    if result_type == 0:
+        return ptr
+    if result_type == 2:
+        ptr = ptr.contents
+    total_size = int(np.prod(array_shape))
+    buffer_ptr = ctypes.cast(ptr, ctypes.POINTER(ctypes.c_double * total_size))
+    array_np = np.frombuffer(buffer_ptr.contents, dtype=float)
+    array_np.shape = array_shape
+    return array_np
+
+
+class LammpsBase(Calculator):
+
+    def __init__(self, name, pt, config):
+        super().__init__(name, pt, config)
+        self._data = {}
+        self._i = 0
+        self._lmp = None
+        self._row_index = 0
+
+    # -- per-configuration driver (lammps_base.py:52-125) --------------------------------
+    def process_configs(self, data, i):
+        self._data = data
+        self._i = i
+        self._initialize_lammps()
+        try:
+            self._prepare_lammps()
+            self._run_lammps()
+            self._collect_lammps()
+        finally:
+            self._lmp = self.pt.close_lammps()
+
+    def process_single(self, data, i=0):
+        """(a, b, w) of ONE configuration without touching the shared arrays
+        (lammps_base.py:101-125) — the transpose-trick feed."""
+        self._data = data
+        self._i = i
+        self._initialize_lammps()
+        try:
+            self._prepare_lammps()
+            self._run_lammps()
+            a, b, w = self._collect_lammps_single()
+        finally:
+            self._lmp = self.pt.close_lammps()
+        return a, b, w
+
+    def _initialize_lammps(self, printlammps=0):
+        self._lmp = self.pt.initialize_lammps(getattr(self.config.args, "lammpslog", 0), printlammps)
+
+    def _prepare_lammps(self):
+        raise NotImplementedError("LAMMPS command generation is outside this repository's scope: "
+                                  "override _prepare_lammps (see INTEGRATION.md)")
+
+    def _run_lammps(self):
+        self._lmp.command("run 0")
+
+    def _collect_lammps(self):
+        raise NotImplementedError
+
+    def _collect_lammps_single(self):
+        raise NotImplementedError
+
+    # -- atom extraction (lammps_base.py:233-253) -----------------------------------------
+    def _extract_atom_ids(self, num_atoms):
+        try:
+            ids = self._lmp.numpy.extract_atom(name="id", nelem=num_atoms).ravel()
+        except Exception:
+            ids = self._lmp.numpy.extract_atom_iarray(name="id", nelem=num_atoms).ravel()
+        return ids
+
+    def _extract_atom_types(self, num_atoms):
+        try:
+            types = self._lmp.numpy.extract_atom(name="type", nelem=num_atoms).ravel()
+        except Exception:
+            types = self._lmp.numpy.extract_atom_iarray(name="type", nelem=num_atoms).ravel()
+        return types

@@ -66,6 +66,36 @@ def snap_ncoeff(twojmax: int) -> int:
     return n
 
 
+def snap_blank2j(numtypes, twojmax, quadratic, bzeroflag):
+    """0/1 column mask for per-type 2J_max (fitsnap3lib/io/sections/calculator_sections/
+    bispectrum.py:69-125): a bispectrum component of type t is kept iff all of its (j1, j2, j)
+    are <= twojmax[t]; quadratic terms iff all six indices are; with bzeroflag = 0 a 1 is
+    prepended per type (the offset column)."""
+    from itertools import combinations_with_replacement
+
+    import numpy as np
+
+    jmax = int(max(twojmax))
+    blank, nper = [], 0
+    for atype in range(numtypes):
+        lin = []
+        for j1 in range(jmax + 1):
+            for j2 in range(j1 + 1):
+                for j in range(abs(j1 - j2), min(jmax, j1 + j2) + 1, 2):
+                    if j >= j1:
+                        lin.append((j1, j2, j))
+        row = [1.0 if all(ind <= int(twojmax[atype]) for ind in t) else 0.0 for t in lin]
+        if quadratic:
+            for a, b in combinations_with_replacement(lin, r=2):
+                row.append(1.0 if all(ind <= int(twojmax[atype]) for ind in a + b) else 0.0)
+        nper = len(row)
+        blank.append(row)
+    blank = np.array(blank, dtype=np.float64).reshape(numtypes, nper)
+    if not bzeroflag:
+        blank = np.concatenate((np.ones((numtypes, 1)), blank), axis=1)
+    return blank.reshape(-1)
+
+
 class Config:
     def __init__(self, pt=None, input=None, arguments_lst=None):
         self.pt = pt
@@ -163,6 +193,7 @@ class Config:
             name="CALCULATOR", calculator=calc,
             energy=_get(ca, "energy", "True", "bool"), force=_get(ca, "force", "True", "bool"),
             stress=_get(ca, "stress", "True", "bool"), per_atom_energy=_get(ca, "per_atom_energy", "False", "bool"),
+            per_atom_scalar=_get(ca, "per_atom_scalar", "False", "bool"),
             nonlinear=_get(ca, "nonlinear", "False", "bool"))
         self.sections["CALCULATOR"].linear = not self.sections["CALCULATOR"].nonlinear
 
@@ -176,11 +207,34 @@ class Config:
             ncoeff = snap_ncoeff(max(twojmax))
             if quad:
                 ncoeff += ncoeff * (ncoeff + 1) // 2
+            bzero = _get(bi, "bzeroflag", "0", "bool")
+            types = _get(bi, "type", "H", "str").split()
+            chem = _get(bi, "chemflag", "0", "bool")
+            if chem:
+                raise NotImplementedError("chemflag (explicit multi-element SNAP) is not supported by this build")
             self.sections["BISPECTRUM"] = SimpleNamespace(
                 name="BISPECTRUM", numtypes=numtypes, twojmax=twojmax, ncoeff=ncoeff,
-                bzeroflag=_get(bi, "bzeroflag", "0", "bool"), quadraticflag=quad,
-                types=_get(bi, "type", "H", "str").split(),
+                bzeroflag=bzero, quadraticflag=quad, types=types,
+                type_mapping={t: i + 1 for i, t in enumerate(types)},      # bispectrum.py:29-37
+                bikflag=_get(bi, "bikflag", "0", "bool"), chemflag=chem,
+                wselfallflag=_get(bi, "wselfallflag", "0", "bool"),
+                blank2J=snap_blank2j(numtypes, twojmax, quad, bzero),
                 wj=[float(x) for x in _get(bi, "wj", "1.0", "str").split()],
                 radelem=[float(x) for x in _get(bi, "radelem", "0.5", "str").split()])
+        if "ACE" in raw:
+            ac = raw["ACE"]
+            numtypes = _get(ac, "numTypes", "1", "int")
+            types = _get(ac, "type", "H", "str").split()
+            ncoeff = _get(ac, "ncoeff", "0", "int")
+            if ncoeff <= 0:
+                raise NotImplementedError("[ACE] needs an explicit `ncoeff` (descriptors per type): ACE basis "
+                                          "generation (fitsnap3lib/lib/sym_ACE) is outside this repository's scope")
+            bzero = _get(ac, "bzeroflag", "0", "bool")
+            width = numtypes * (ncoeff + (0 if bzero else 1))
+            import numpy as _np
+            self.sections["ACE"] = SimpleNamespace(
+                name="ACE", numtypes=numtypes, ncoeff=ncoeff, bzeroflag=bzero, types=types,
+                type_mapping={t: i + 1 for i, t in enumerate(types)}, bikflag=_get(ac, "bikflag", "0", "bool"),
+                blank2J=_np.ones(width))
         mem = raw.get("MEMORY", {})
         self.sections["MEMORY"] = SimpleNamespace(name="MEMORY", override=_get(mem, "override", "0", "bool"))

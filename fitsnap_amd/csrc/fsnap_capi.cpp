@@ -62,6 +62,7 @@ struct fsnap_ctx {
     DevBuf ownw, ownmask, ones;
     // workspaces
     DevBuf part, cpart, spart, packed, beta, preds, sse, aw, bw;
+    DevBuf st_raw, st_plan, st_frac, st_blank;   // staging of fsnap_assemble
     // options
     int opt_split = 0;        // 0 = auto
     int opt_nt = 1;
@@ -367,7 +368,8 @@ int fsnap_ctx_destroy(fsnap_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->ownA, &ctx->ownb, &ctx->ownw, &ctx->ownmask, &ctx->ones, &ctx->part, &ctx->cpart,
-                      &ctx->spart, &ctx->packed, &ctx->beta, &ctx->preds, &ctx->sse, &ctx->aw, &ctx->bw};
+                      &ctx->spart, &ctx->packed, &ctx->beta, &ctx->preds, &ctx->sse, &ctx->aw, &ctx->bw,
+                      &ctx->st_raw, &ctx->st_plan, &ctx->st_frac, &ctx->st_blank};
     for (DevBuf* b : bufs) b->release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -462,6 +464,95 @@ int fsnap_bind_rows(fsnap_ctx* ctx, const double* dA, int64_t m, int64_t K, int6
     ctx->m = m;
     ctx->K = K;
     ctx->lda = lda;
+    return FSNAP_OK;
+}
+
+int fsnap_rows_alloc(fsnap_ctx* ctx, int64_t m, int64_t K) {
+    if (!ctx) return FSNAP_E_ARG;
+    if (m <= 0 || K <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_rows_alloc: bad argument");
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    const size_t abytes = (size_t)m * K * sizeof(double);
+    if (!ctx->ownA.ensure(abytes + 256) || !ctx->ownb.ensure((size_t)m * 8) || !ctx->ownw.ensure((size_t)m * 8))
+        return ctx->fail(FSNAP_E_NOMEM, "hipMalloc of %zu bytes for A failed", abytes);
+    FSNAP_HIP(hipMemsetAsync(ctx->ownA.p, 0, abytes + 256, ctx->stream), "hipMemsetAsync(A)");
+    FSNAP_HIP(hipMemsetAsync(ctx->ownb.p, 0, (size_t)m * 8, ctx->stream), "hipMemsetAsync(b)");
+    FSNAP_HIP(hipMemsetAsync(ctx->ownw.p, 0, (size_t)m * 8, ctx->stream), "hipMemsetAsync(w)");
+    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    ctx->dA = (const double*)ctx->ownA.p;
+    ctx->db = (const double*)ctx->ownb.p;
+    ctx->dw = (const double*)ctx->ownw.p;
+    ctx->dmask = nullptr;
+    ctx->ones.release();
+    ctx->m = m;
+    ctx->K = K;
+    ctx->lda = K;
+    return FSNAP_OK;
+}
+
+int fsnap_assemble(fsnap_ctx* ctx, const double* raw, int64_t raw_rows, int64_t raw_ld, int64_t nrows, int64_t row0,
+                   const int64_t* src_row, const int32_t* kind, const int32_t* frac, const double* d,
+                   const double* truth, const double* weight, const double* fractions, int64_t nfrac,
+                   const double* blank2J, int32_t ntypes, int32_t ncoeff, int32_t offcol) {
+    if (!ctx) return FSNAP_E_ARG;
+    int rc;
+    if ((rc = check_rows(ctx))) return rc;
+    if (ctx->dA != (const double*)ctx->ownA.p || ctx->dw != (const double*)ctx->ownw.p)
+        return ctx->fail(FSNAP_E_STATE, "fsnap_assemble needs rows allocated by fsnap_rows_alloc");
+    if (!raw || !src_row || !kind || !frac || !d || !truth || !weight || !blank2J || raw_rows <= 0 || nrows <= 0 ||
+        row0 < 0 || row0 + nrows > ctx->m || ntypes <= 0 || ncoeff <= 0 || (offcol != 0 && offcol != 1) ||
+        raw_ld < (int64_t)ntypes * ncoeff + 1 || (int64_t)ntypes * (ncoeff + offcol) != ctx->K || (nfrac > 0 && !fractions))
+        return ctx->fail(FSNAP_E_ARG, "fsnap_assemble: bad argument");
+    for (int64_t r = 0; r < nrows; ++r)
+        if (src_row[r] < 0 || src_row[r] >= raw_rows || kind[r] < 0 || kind[r] > 3 || frac[r] >= nfrac)
+            return ctx->fail(FSNAP_E_ARG, "fsnap_assemble: plan entry %lld out of range", (long long)r);
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    const size_t rawb = (size_t)raw_rows * raw_ld * 8;
+    // plan layout on the device: src_row (8n) | d (8n) | truth (8n) | weight (8n) | kind (4n) | frac (4n)
+    const size_t n = (size_t)nrows;
+    const size_t planb = n * 40;
+    const size_t fracb = (size_t)(nfrac > 0 ? nfrac : 1) * ntypes * 8;
+    if (!ctx->st_raw.ensure(rawb) || !ctx->st_plan.ensure(planb) || !ctx->st_frac.ensure(fracb) ||
+        !ctx->st_blank.ensure((size_t)ctx->K * 8))
+        return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(assembly staging) failed");
+    char* pl = (char*)ctx->st_plan.p;
+    hipStream_t st = ctx->stream;
+    FSNAP_HIP(hipMemcpyAsync(ctx->st_raw.p, raw, rawb, hipMemcpyHostToDevice, st), "hipMemcpy(raw)");
+    FSNAP_HIP(hipMemcpyAsync(pl, src_row, n * 8, hipMemcpyHostToDevice, st), "hipMemcpy(plan)");
+    FSNAP_HIP(hipMemcpyAsync(pl + n * 8, d, n * 8, hipMemcpyHostToDevice, st), "hipMemcpy(plan)");
+    FSNAP_HIP(hipMemcpyAsync(pl + n * 16, truth, n * 8, hipMemcpyHostToDevice, st), "hipMemcpy(plan)");
+    FSNAP_HIP(hipMemcpyAsync(pl + n * 24, weight, n * 8, hipMemcpyHostToDevice, st), "hipMemcpy(plan)");
+    FSNAP_HIP(hipMemcpyAsync(pl + n * 32, kind, n * 4, hipMemcpyHostToDevice, st), "hipMemcpy(plan)");
+    FSNAP_HIP(hipMemcpyAsync(pl + n * 36, frac, n * 4, hipMemcpyHostToDevice, st), "hipMemcpy(plan)");
+    if (nfrac > 0)
+        FSNAP_HIP(hipMemcpyAsync(ctx->st_frac.p, fractions, (size_t)nfrac * ntypes * 8, hipMemcpyHostToDevice, st),
+                  "hipMemcpy(fractions)");
+    FSNAP_HIP(hipMemcpyAsync(ctx->st_blank.p, blank2J, (size_t)ctx->K * 8, hipMemcpyHostToDevice, st), "hipMemcpy(blank2J)");
+    FSNAP_HIP(fsnap::launch_assemble((const double*)ctx->st_raw.p, raw_ld, nrows, (const int64_t*)pl,
+                                     (const int*)(pl + n * 32), (const int*)(pl + n * 36), (const double*)(pl + n * 8),
+                                     (const double*)(pl + n * 16), (const double*)(pl + n * 24),
+                                     (const double*)ctx->st_frac.p, (const double*)ctx->st_blank.p, ntypes, ncoeff,
+                                     offcol, (double*)ctx->ownA.p + row0 * ctx->lda, ctx->lda,
+                                     (double*)ctx->ownb.p + row0, (double*)ctx->ownw.p + row0, st),
+              "launch fsnap_assemble_k");
+    FSNAP_HIP(hipStreamSynchronize(st), "hipStreamSynchronize");   // host staging may be reused by the caller
+    return FSNAP_OK;
+}
+
+int fsnap_download_rows(fsnap_ctx* ctx, double* A, int64_t lda, double* b, double* w) {
+    if (!ctx) return FSNAP_E_ARG;
+    int rc;
+    if ((rc = check_rows(ctx))) return rc;
+    if (A && lda < ctx->K) return ctx->fail(FSNAP_E_ARG, "fsnap_download_rows: lda < K");
+    if (w && !ctx->dw) return ctx->fail(FSNAP_E_STATE, "no weights on the device");
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    const size_t m = (size_t)ctx->m, K = (size_t)ctx->K;
+    if (A)
+        FSNAP_HIP(hipMemcpy2DAsync(A, (size_t)lda * 8, ctx->dA, (size_t)ctx->lda * 8, K * 8, m, hipMemcpyDeviceToHost,
+                                   ctx->stream),
+                  "hipMemcpy2D(A)");
+    if (b) FSNAP_HIP(hipMemcpyAsync(b, ctx->db, m * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(b)");
+    if (w) FSNAP_HIP(hipMemcpyAsync(w, ctx->dw, m * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(w)");
+    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     return FSNAP_OK;
 }
 

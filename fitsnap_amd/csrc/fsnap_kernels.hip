@@ -1170,6 +1170,72 @@ __global__ __launch_bounds__(256) void fsnap_gemv_rows_k(const double* __restric
 }
 
 // ---------------------------------------------------------------------------------
+// Kernel 5: post-LAMMPS assembly — the `_collect_lammps` transform
+// (fitsnap3lib/calculators/lammps_snap.py:391-556, lammps_pace.py:369-509) for a batch of
+// configurations: raw `compute snap|pace` rows -> rows of A, b, w, written straight into the
+// resident HBM arrays.  One wave per output row, lanes stride the K output columns.
+//   raw      : row-major raw rows, leading dimension raw_ld = ncoeff*ntypes + 1; the last
+//              column (icolref) is the reference-potential contribution
+//   per output row r (SoA plan): src_row[r] raw row, kind[r], d[r], truth[r], weight[r],
+//              frac[r] (index of the per-type atom fractions of its configuration, or -1)
+//   kind 0 energy       : A = x / d              b = (truth - ref) / d   w = weight   (d = N)
+//   kind 1 force        : A = x                  b = truth - ref         w = weight
+//   kind 2 virial       : A = (1.6021765e6 x)/d  b = truth - ref         w = weight   (d = volume)
+//   kind 3 per-atom-energy rows after the first (bikflag): A = x / d, b = 0, w = 0
+//   column k -> type t = k / (ncoeff + off), j = k % (ncoeff + off); with off = 1
+//   (bzeroflag = 0) column j = 0 is the per-type offset column: atom fraction of type t on
+//   energy rows, 0 elsewhere; every column is multiplied by blank2J[k].
+// The arithmetic order is the reference's (divide, not multiply by a reciprocal), so
+// rows are bit-identical to the numpy path.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsnap_assemble_k(const double* __restrict__ raw, int64_t raw_ld,
+                                                        int64_t nrows, const int64_t* __restrict__ src_row,
+                                                        const int* __restrict__ kind, const int* __restrict__ frac,
+                                                        const double* __restrict__ dval,
+                                                        const double* __restrict__ truth,
+                                                        const double* __restrict__ weight,
+                                                        const double* __restrict__ fractions,
+                                                        const double* __restrict__ blank2J, int ntypes, int ncoeff,
+                                                        int off, double* __restrict__ A, int64_t lda,
+                                                        double* __restrict__ b, double* __restrict__ w) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * 4;
+    const int stride = ncoeff + off;
+    const int K = ntypes * stride;
+    const int icolref = ntypes * ncoeff;
+    for (int64_t r = wave; r < nrows; r += nwave) {
+        const double* src = raw + src_row[r] * raw_ld;
+        const int kd = kind[r];
+        const double d = dval[r];
+        const int fr = frac[r];
+        double* dst = A + r * lda;
+        for (int k = lane; k < K; k += 64) {
+            const int t = k / stride, j = k - t * stride;
+            double v;
+            if (off && j == 0) {
+                v = (kd == 0 && fr >= 0) ? fractions[(int64_t)fr * ntypes + t] : 0.0;
+            } else {
+                const double x = src[t * ncoeff + (j - off)];
+                v = (kd == 1) ? x : (kd == 2) ? (1.6021765e6 * x) / d : x / d;
+            }
+            dst[k] = v * blank2J[k];
+        }
+        if (lane == 0) {
+            const double ref = src[icolref];
+            double bv, wv = weight[r];
+            if (kd == 0) bv = (truth[r] - ref) / d;
+            else if (kd == 3) {
+                bv = 0.0;
+                wv = 0.0;
+            } else bv = truth[r] - ref;
+            b[r] = bv;
+            w[r] = wv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // host-side launchers (C++ linkage, used by fsnap_capi.cpp)
 // ---------------------------------------------------------------------------------
 namespace fsnap {
@@ -1317,6 +1383,18 @@ hipError_t launch_weight_rows(const double* A, int64_t lda, const double* b, con
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(fsnap_weight_rows_k, dim3((unsigned)nb), dim3(256), 0, st, A, lda, b, w, mask, m, K, aw,
                        ldaw, bw);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble(const double* raw, int64_t raw_ld, int64_t nrows, const int64_t* src_row, const int* kind,
+                           const int* frac, const double* dval, const double* truth, const double* weight,
+                           const double* fractions, const double* blank2J, int ntypes, int ncoeff, int off, double* A,
+                           int64_t lda, double* b, double* w, hipStream_t st) {
+    int64_t nb = (nrows + 3) / 4;
+    if (nb > 256 * 8) nb = 256 * 8;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(fsnap_assemble_k, dim3((unsigned)nb), dim3(256), 0, st, raw, raw_ld, nrows, src_row, kind, frac,
+                       dval, truth, weight, fractions, blank2J, ntypes, ncoeff, off, A, lda, b, w);
     return hipGetLastError();
 }
 

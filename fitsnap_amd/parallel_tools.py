@@ -139,11 +139,18 @@ class SharedArray(StubsArray):
         self._node_length = self._length
         self.win = _Window(self)
         self.version = 0
+        self.device_version = -1
         if multinode and comms is not None:
             self.multinode_lengths()
 
     def touch(self):
+        """The host view was written: any resident device copy is stale."""
         self.version += 1
+
+    def mark_device_current(self):
+        """The device rows and the host view hold the same data (after device-side assembly
+        + download): solvers may skip the upload."""
+        self.device_version = self.version
 
     def get_memory(self):
         return self._nbytes
@@ -402,6 +409,51 @@ class ParallelTools:
                 obj[key] = obj[key][self._node_index::self._number_of_nodes]
             return obj
         return obj
+
+    def new_slice_a(self, a_len=None):
+        """Row-offset table (parallel_tools.py:594-651).  One process per GPU: every rank owns
+        all rows of its own arrays, so the table is the trivial [0, a_len - 1]."""
+        if a_len is None:
+            a_len = len(self.shared_arrays["a"].array)
+        self.add_2_fitsnap("sub_a_size", int(a_len))
+        self.add_2_fitsnap("sub_a_indices", np.array([0, int(a_len) - 1]))
+
+    def get_ram(self):
+        """Total host RAM in bytes (parallel_tools.py:862-876 uses psutil)."""
+        try:
+            import psutil
+
+            return psutil.virtual_memory().total
+        except Exception:
+            return 0
+
+    # -- LAMMPS handles (parallel_tools.py:519-560): only opened when a `lammps` module exists --
+    def _lammps_class(self):
+        try:
+            from lammps import lammps
+        except Exception as e:
+            raise RuntimeError("the LAMMPS Python module is required to compute descriptors "
+                               "(this repository replaces the POST-LAMMPS path only)") from e
+        return lammps
+
+    def check_lammps(self, lammps_noexceptions=0):
+        lmp = self._lammps_class()(cmdargs=["-screen", "none", "-log", "none"])
+        if not (lmp.has_exceptions or lammps_noexceptions):
+            raise Exception("Fitting interrupted! LAMMPS not compiled with C++ exceptions handling enabled")
+        lmp.close()
+
+    def initialize_lammps(self, lammpslog=0, printlammps=0):
+        cmds = ["-screen", "none"]
+        if not lammpslog:
+            cmds += ["-log", "none"]
+        self._lmp = self._lammps_class()(cmdargs=cmds)
+        return self._lmp
+
+    def close_lammps(self):
+        if self._lmp is not None:
+            self._lmp.close()
+            self._lmp = None
+        return self._lmp
 
     def exception(self, err):
         """Abort path (parallel_tools.py:840-860): no MPI.Abort here — re-raise."""

@@ -117,6 +117,12 @@ class Solver:
         if shared_mode:
             sa, sb = self.pt.shared_arrays["a"], self.pt.shared_arrays["b"]
             key = ("shared", id(sa), getattr(sa, "version", 0), id(sb), getattr(sb, "version", 0), a.shape)
+            # rows assembled on the device (Calculator.flush_rows) are already resident
+            if (getattr(sa, "device_version", -1) == getattr(sa, "version", 0)
+                    and getattr(sb, "device_version", -1) == getattr(sb, "version", 0)
+                    and ctx.m == a.shape[0] and ctx.K == a.shape[1]):
+                self._resident_key = key
+                return ctx
             # shared arrays are re-uploaded unless their owner kept the version (touch())
             if self.keep_resident and key == self._resident_key:
                 return ctx

@@ -88,6 +88,36 @@ int fsnap_upload_rows(fsnap_ctx* ctx, const double* A, int64_t m, int64_t K, int
  * allocation must be readable for 16 bytes past its last element). */
 int fsnap_bind_rows(fsnap_ctx* ctx, const double* dA, int64_t m, int64_t K, int64_t lda, const double* db);
 
+/* Allocate resident, zero-filled A (m x K), b[m], w[m] in HBM without a host copy: the
+ * device-side counterpart of Calculator.create_a -> pt.create_shared_array('a'|'b'|'w')
+ * (fitsnap3lib/calculators/calculator.py:261-289), to be filled by fsnap_assemble. */
+int fsnap_rows_alloc(fsnap_ctx* ctx, int64_t m, int64_t K);
+
+/* Post-LAMMPS assembly of a batch of configurations straight into the resident rows
+ * [row0, row0 + nrows): the `_collect_lammps` transform
+ * (fitsnap3lib/calculators/lammps_snap.py:391-556, lammps_pace.py:369-509; single-config
+ * form lammps_snap.py:224-389) without the host copy of A.
+ *   raw[raw_rows * raw_ld]  the LAMMPS `compute snap|pace` global arrays of the batch, stacked
+ *                           (what _extract_compute_np views, lammps_base.py:280-307);
+ *                           raw_ld >= ncoeff*ntypes + 1, column ncoeff*ntypes = reference potential
+ *   per output row r: src_row[r] (row of raw), kind[r] (0 energy: A = x/d, b = (truth-ref)/d;
+ *     1 force: A = x, b = truth-ref; 2 virial: A = (1.6021765e6 x)/d, b = truth-ref;
+ *     3 extra per-atom energy row: A = x/d, b = 0, w = 0), d[r] (atoms or cell volume),
+ *     truth[r], weight[r], frac[r] (row of `fractions`, or -1)
+ *   fractions[nfrac * ntypes]  per-configuration atom-type fractions (offset column of energy rows)
+ *   blank2J[K]; offcol = 1 when bzeroflag = 0 (K = ntypes*(ncoeff+1)), else 0.
+ * All pointers are host memory; synchronous. */
+int fsnap_assemble(fsnap_ctx* ctx, const double* raw, int64_t raw_rows, int64_t raw_ld, int64_t nrows, int64_t row0,
+                   const int64_t* src_row, const int32_t* kind, const int32_t* frac, const double* d,
+                   const double* truth, const double* weight, const double* fractions, int64_t nfrac,
+                   const double* blank2J, int32_t ntypes, int32_t ncoeff, int32_t offcol);
+
+/* Copy the resident rows back to host arrays (any pointer may be NULL): fills the host
+ * view of pt.shared_arrays['a'|'b'|'w'] after device-side assembly, and serves
+ * Calculator.extras' Descriptors.npy / Truth-Ref.npy / Weights.npy dumps
+ * (calculator.py:329-348). */
+int fsnap_download_rows(fsnap_ctx* ctx, double* A, int64_t lda, double* b, double* w);
+
 /* Row weights w[m] and training mask[m] (1 = train; NULL = all rows train) from host
  * memory.  pt.shared_arrays['w'].array and `training = [not elem for elem in
  * fitsnap_dict['Testing']]` (svd.py:35-44, ridge.py:28-37, ard.py:18-19). */
