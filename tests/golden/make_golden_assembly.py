@@ -209,5 +209,44 @@ def main():
     print("wrote", os.path.join(HERE, "assembly_reference.npz"))
 
 
+
+
+def weighting_goldens():
+    """Scraper._weighting (scrape.py:323-353) run unbound on a stand-in `self`."""
+    import types as _t
+
+    sys.path.insert(0, REF)
+    if "lammps" not in sys.modules:
+        stub = types.ModuleType("lammps")
+        stub.lammps = FakeLammps
+        sys.modules["lammps"] = stub
+    from fitsnap3lib.scrapers.scrape import Scraper
+    rng = np.random.default_rng(77)
+    rows = []
+    for boltz in (0.0, 300.0):
+        for smart in (0, 1):
+            for force in (0, 1):
+                for stress in (0, 1):
+                    for test_bool in (0, 1):
+                        natoms = int(rng.integers(1, 40))
+                        grp = {"eweight": float(10 ** rng.uniform(-1, 2)), "fweight": float(10 ** rng.uniform(-2, 1)),
+                               "vweight": float(10 ** rng.uniform(-9, -6)), "training_size": int(rng.integers(0, 30)),
+                               "testing_size": int(rng.integers(1, 9))}
+                        energy = float(rng.normal(-5.0 * natoms, 0.5))
+                        me = _t.SimpleNamespace(
+                            config=_t.SimpleNamespace(sections={"GROUPS": _t.SimpleNamespace(boltz=boltz, smartweights=smart),
+                                                                "CALCULATOR": _t.SimpleNamespace(force=force, stress=stress)}),
+                            group_table={"g": dict(grp)}, data={"Group": "g", "Energy": energy, "test_bool": test_bool},
+                            kb=0.00008617333262145)
+                        Scraper._weighting(me, natoms)
+                        rows.append([boltz, smart, force, stress, test_bool, natoms, grp["eweight"], grp["fweight"],
+                                     grp["vweight"], grp["training_size"], grp["testing_size"], energy,
+                                     me.data["eweight"], me.data["fweight"], me.data["vweight"]])
+    np.save(os.path.join(HERE, "weighting_reference.npy"), np.array(rows, dtype=np.float64))
+    print("wrote weighting_reference.npy", len(rows), "cases")
+
+
+
 if __name__ == "__main__":
     main()
+    weighting_goldens()

@@ -92,3 +92,20 @@ def test_row_count_follows_create_a():
     calc.number_of_atoms = int(pt.shared_arrays["number_of_atoms"].array.sum())
     calc.number_of_files_per_node = len(data)
     assert calc.row_count() == len(g["b"])
+
+
+def test_weighting_matches_reference_bitwise():
+    # Scraper._weighting (scrape.py:323-353) — origin of the row weights; goldens produced by
+    # the reference function itself (tests/golden/make_golden_assembly.py: weighting_goldens)
+    import os
+    from fitsnap_amd.scrapers import apply_weighting
+    rows = np.load(os.path.join(os.path.dirname(__file__), "golden", "weighting_reference.npy"))
+    assert len(rows) == 32
+    for r in rows:
+        boltz, smart, force, stress, test_bool, natoms = float(r[0]), int(r[1]), int(r[2]), int(r[3]), int(r[4]), int(r[5])
+        # python floats, as the reference's group table holds them (np.float64 / 0 would give inf, not ZeroDivisionError)
+        grp = {"eweight": float(r[6]), "fweight": float(r[7]), "vweight": float(r[8]), "training_size": int(r[9]),
+               "testing_size": int(r[10])}
+        data = {"Energy": float(r[11]), "test_bool": test_bool}
+        apply_weighting(data, grp, natoms, boltz=boltz, smartweights=bool(smart), use_force=bool(force), use_stress=bool(stress))
+        assert (data["eweight"], data["fweight"], data["vweight"]) == (r[12], r[13], r[14])
