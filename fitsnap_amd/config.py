@@ -96,6 +96,28 @@ def snap_blank2j(numtypes, twojmax, quadratic, bzeroflag):
     return blank.reshape(-1)
 
 
+def snap_blist(numtypes, twojmax, quadratic):
+    """Names of the bispectrum components [i, j1, j2, j] per type (bispectrum.py:69-119), used
+    for the ``#  B[...]`` comments of the .snapcoeff file."""
+    from itertools import combinations_with_replacement
+
+    jmax = int(max(twojmax))
+    out = []
+    for _atype in range(numtypes):
+        lin, i = [], 0
+        for j1 in range(jmax + 1):
+            for j2 in range(j1 + 1):
+                for j in range(abs(j1 - j2), min(jmax, j1 + j2) + 1, 2):
+                    if j >= j1:
+                        i += 1
+                        lin.append([i, j1, j2, j])
+        per_type = list(lin)
+        if quadratic:
+            per_type += [[k, a, b] for k, (a, b) in enumerate(combinations_with_replacement(lin, r=2), start=len(lin))]
+        out += per_type
+    return out
+
+
 class Config:
     def __init__(self, pt=None, input=None, arguments_lst=None):
         self.pt = pt
@@ -219,6 +241,10 @@ class Config:
                 bikflag=_get(bi, "bikflag", "0", "bool"), chemflag=chem,
                 wselfallflag=_get(bi, "wselfallflag", "0", "bool"),
                 blank2J=snap_blank2j(numtypes, twojmax, quad, bzero),
+                blist=snap_blist(numtypes, twojmax, quad),
+                rcutfac=_get(bi, "rcutfac", "4.67637", "float"), rfac0=_get(bi, "rfac0", "0.99363", "float"),
+                rmin0=_get(bi, "rmin0", "0.0", "float"), bnormflag=_get(bi, "bnormflag", "0", "bool"),
+                switchinnerflag=_get(bi, "switchinnerflag", "0", "bool"),
                 wj=[float(x) for x in _get(bi, "wj", "1.0", "str").split()],
                 radelem=[float(x) for x in _get(bi, "radelem", "0.5", "str").split()])
         if "ACE" in raw:
@@ -236,5 +262,14 @@ class Config:
                 name="ACE", numtypes=numtypes, ncoeff=ncoeff, bzeroflag=bzero, types=types,
                 type_mapping={t: i + 1 for i, t in enumerate(types)}, bikflag=_get(ac, "bikflag", "0", "bool"),
                 blank2J=_np.ones(width))
+        if "REFERENCE" in raw:
+            rf = raw["REFERENCE"]
+            decl = ["pair_style " + _get(rf, "pair_style", "zero 10.0", "str")]      # reference.py:18-29
+            decl += ["pair_coeff " + v for k, v in rf.items() if k.lower().startswith("pair_coeff")]
+            self.sections["REFERENCE"] = SimpleNamespace(
+                name="REFERENCE", units=_get(rf, "units", "metal", "str").lower(),
+                atom_style=_get(rf, "atom_style", "atomic", "str").lower(), lmp_pairdecl=decl)
+        import hashlib
+        self.hash = hashlib.sha1(repr(sorted((k, sorted(v.items())) for k, v in raw.items())).encode()).hexdigest()[:30]
         mem = raw.get("MEMORY", {})
         self.sections["MEMORY"] = SimpleNamespace(name="MEMORY", override=_get(mem, "override", "0", "bool"))

@@ -211,6 +211,74 @@ def main():
 
 
 
+def pace_goldens():
+    """LammpsPace._collect_lammps (lammps_pace.py:369-509).  The reference's [ACE] section needs
+    sympy (absent here) only to GENERATE the basis; the collect step reads just numtypes /
+    ncoeff / bzeroflag / type_mapping / blank2J / bikflag, so those are injected."""
+    import types as _t
+
+    ParallelTools, Config, calculator_factory = import_reference()
+    from fitsnap3lib.calculators.lammps_pace import LammpsPace
+    out = {}
+    cases = {"pace_1type_bzero0_efs": (1, 7, 0, 1, 1, 1, [2, 3, 4], 31),
+             "pace_2type_bzero1_ef": (2, 5, 1, 1, 1, 0, [3, 2], 32),
+             "pace_1type_bzero0_efs_nan": (1, 4, 0, 1, 1, 1, [2, 2], 33)}
+    for name, (nt, nc, bzero, e, f, st, natoms, seed) in cases.items():
+        rng = np.random.default_rng(seed)
+        settings = snap_settings(nt, [2] * nt, bzero, e, f, st)
+        pt = ParallelTools()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            cfg = Config(pt, settings, arguments_lst=["--overwrite"])
+        elems = ["Ta", "W", "Be"][:nt]
+        width = nt * (nc + (0 if bzero else 1))
+        cfg.sections["ACE"] = _t.SimpleNamespace(numtypes=nt, ncoeff=nc, bzeroflag=bzero, bikflag=0,
+                                                 type_mapping={el: i + 1 for i, el in enumerate(elems)},
+                                                 blank2J=np.ones(width))
+        calc = LammpsPace.__new__(LammpsPace)
+        LammpsPace.__init__(calc, "LAMMPSPACE", pt, cfg)
+        calc._prepare_lammps = lambda: None
+        calc._run_lammps = lambda: None
+        data = make_configs(rng, natoms, elems)
+        raws, vols, types_l = [], [], []
+        for d in data:
+            n = d["NumAtoms"]
+            raw = rng.normal(0, 1, (1 + 3 * n + 6, nc * nt + 1))
+            if name.endswith("_nan") and not raws:
+                raw[2, 1] = np.nan
+                raw[4, 0] = np.inf
+            raws.append(np.ascontiguousarray(raw))
+            vols.append(float(rng.uniform(50, 500)))
+            types_l.append(np.array([cfg.sections["ACE"].type_mapping[a] for a in d["AtomTypes"]], dtype=np.int32))
+        calc.allocate_per_config(data)
+        for k, v in (("energy", e), ("force", f), ("stress", st), ("per_atom_energy", 0), ("per_atom_scalar", 0), ("nonlinear", 0)):
+            pt.add_2_fitsnap(k, v)
+        calc.create_a()
+        calc.shared_index = 0
+        calc.distributed_index = 0
+        for i, d in enumerate(data):
+            CURRENT.update(raw=raws[i].copy(), vol=vols[i], types=types_l[i], ids=1 + np.arange(d["NumAtoms"]), pos=d["Positions"])
+            calc.process_configs(d, i)
+        calc.collect_distributed_lists()
+        res = {"A": pt.shared_arrays["a"].array.copy(), "b": pt.shared_arrays["b"].array.copy(),
+               "w": pt.shared_arrays["w"].array.copy(), "Row_Type": np.array(pt.fitsnap_dict["Row_Type"]),
+               "Atom_I": np.array(pt.fitsnap_dict["Atom_I"]), "Testing": np.array(pt.fitsnap_dict["Testing"]),
+               "ntypes": nt, "ncoeff": nc, "bzeroflag": bzero, "efs": np.array([e, f, st]),
+               "raw_concat": np.concatenate([r.ravel() for r in raws]), "raw_rows": np.array([r.shape[0] for r in raws]),
+               "raw_cols": raws[0].shape[1], "vols": np.array(vols), "natoms": np.array(natoms),
+               "types_concat": np.concatenate(types_l), "energy": np.array([d["Energy"] for d in data]),
+               "forces_concat": np.concatenate([d["Forces"].ravel() for d in data]),
+               "stress": np.array([d["Stress"] for d in data]), "eweight": np.array([d["eweight"] for d in data]),
+               "fweight": np.array([d["fweight"] for d in data]), "vweight": np.array([d["vweight"] for d in data]),
+               "test_bool": np.array([d["test_bool"] for d in data]),
+               "atomtypes_concat": np.array([a for d in data for a in d["AtomTypes"]])}
+        print(f"{name:28s} A {res['A'].shape}")
+        for k, v in res.items():
+            out[f"{name}/{k}"] = v
+    out["cases"] = np.array(list(cases.keys()))
+    np.savez_compressed(os.path.join(HERE, "assembly_pace_reference.npz"), **out)
+
+
 def weighting_goldens():
     """Scraper._weighting (scrape.py:323-353) run unbound on a stand-in `self`."""
     import types as _t
@@ -250,3 +318,4 @@ def weighting_goldens():
 if __name__ == "__main__":
     main()
     weighting_goldens()
+    pace_goldens()

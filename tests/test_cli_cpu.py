@@ -1,0 +1,87 @@
+"""CPU: .snapcoeff writer and config-from-INI — byte-compatible with what the reference
+commits as its golden output (examples/Ta_Linear_JCP2014/20May21_Standard/Ta_pot.snapcoeff,
+kept as a data fixture in tests/golden/)."""
+import os
+
+import numpy as np
+
+from fitsnap_amd.config import Config
+from fitsnap_amd.io.outputs.snap import parse_snapcoeff, to_coeff_string, to_param_string
+from fitsnap_amd.parallel_tools import ParallelTools
+
+from conftest import GOLDEN
+
+TA_IN = """[BISPECTRUM]
+numTypes = 1
+twojmax = 6
+rcutfac = 4.67637
+rfac0 = 0.99363
+rmin0 = 0.0
+wj = 1.0
+radelem = 0.5
+type = Ta
+wselfallflag = 0
+chemflag = 0
+bzeroflag = 0
+quadraticflag = 0
+
+[CALCULATOR]
+calculator = LAMMPSSNAP
+energy = 1
+force = 1
+stress = 1
+
+[SOLVER]
+solver = SVD
+
+[OUTFILE]
+metrics = Ta_metrics.md
+potential = Ta_pot
+
+[REFERENCE]
+units = metal
+atom_style = atomic
+pair_style = hybrid/overlay zero 10.0 zbl 4.0 4.8
+pair_coeff1 = * * zero
+pair_coeff2 = * * zbl 73 73
+
+[EXTRAS]
+dump_descriptors = 1
+"""
+
+
+def test_snapcoeff_text_matches_reference_golden_file(tmp_path, ta_fits):
+    p = tmp_path / "Ta.in"
+    p.write_text(TA_IN)
+    cfg = Config(ParallelTools(), str(p), ["--overwrite"])
+    text = to_coeff_string(cfg, ta_fits["snapcoeff"])
+    ours = text.splitlines()
+    gold = open(os.path.join(GOLDEN, "Ta_pot.snapcoeff")).read().splitlines()
+    assert len(ours) == len(gold)
+    # line 0 carries a timestamp/hash; everything else must be byte-identical
+    assert ours[1:] == gold[1:]
+    out = tmp_path / "x.snapcoeff"
+    out.write_text(text)
+    assert np.array_equal(parse_snapcoeff(out), ta_fits["snapcoeff"])        # the reference checker's reader
+
+
+def test_snapparam_has_reference_keys(tmp_path):
+    p = tmp_path / "Ta.in"
+    p.write_text(TA_IN)
+    cfg = Config(ParallelTools(), str(p))
+    txt = to_param_string(cfg)
+    for line in ("rcutfac 4.67637", "twojmax 6", "rfac0 0.99363", "bzeroflag 0", "quadraticflag 0",
+                 "# pair_style hybrid/overlay zero 10.0 zbl 4.0 4.8", "# pair_coeff * * zbl 73 73"):
+        assert line in txt
+
+
+def test_multi_type_bzero_coefficients_layout():
+    # snap.py:164-168: with bzeroflag a 1.0 is inserted into blank2J for B0 of every type
+    cfg = Config(ParallelTools(), {"SOLVER": {"solver": "SVD"},
+                                   "BISPECTRUM": {"numTypes": 2, "twojmax": "2 2", "bzeroflag": 1, "type": "W Be",
+                                                  "wj": "1.0 0.9", "radelem": "0.5 0.4"}})
+    n = cfg.sections["BISPECTRUM"].ncoeff
+    coeffs = np.arange(1.0, 2 * (n + 1) + 1)
+    lines = to_coeff_string(cfg, coeffs).splitlines()
+    assert lines[2] == f"2 {n + 1}" and lines[3] == "W 0.5 1.0" and lines[3 + n + 2] == "Be 0.4 0.9"
+    assert float(lines[4].split()[0]) == 1.0 and "B[0]" in lines[4]

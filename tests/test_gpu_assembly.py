@@ -153,3 +153,65 @@ def test_nan_in_lammps_output_raises_like_reference():
     with pytest.raises(ValueError, match="Nan in computed data"):        # lammps_snap.py:426-428
         calc.process_configs(data[0], 0)
     pt.free()
+
+
+# ---------------------------------------------------------------------------------------
+# PACE (lammps_pace.py:369-509): goldens from the reference's LammpsPace with an injected
+# [ACE] section (tests/golden/make_golden_assembly.py: pace_goldens)
+# ---------------------------------------------------------------------------------------
+def _pace_cases():
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "assembly_pace_reference.npz"))
+    return {str(n): {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(str(n) + "/")} for n in z["cases"]}
+
+
+PACE = _pace_cases()
+
+
+@pytest.mark.parametrize("name", sorted(PACE))
+def test_pace_assembled_rows_match_reference_bitwise(name, capsys):
+    g = PACE[name]
+    fake_lammps.install()
+    nt, nc, bzero = int(g["ntypes"]), int(g["ncoeff"]), int(g["bzeroflag"])
+    e, f, st = (int(x) for x in g["efs"])
+    elems = ["Ta", "W", "Be"][:nt]
+    pt = ParallelTools()
+    cfg = Config(pt, {"SOLVER": {"solver": "SVD"},
+                      "CALCULATOR": {"calculator": "LAMMPSPACE", "energy": e, "force": f, "stress": st},
+                      "ACE": {"numTypes": nt, "ncoeff": nc, "bzeroflag": bzero, "type": " ".join(elems)}})
+    calc = calculator_factory.calculator("LAMMPSPACE", pt, cfg)
+    assert type(calc).__name__ == "LammpsPace" and calc.get_width() == g["A"].shape[1]
+    calc._prepare_lammps = lambda: None
+    calc._run_lammps = lambda: None
+    ncols = int(g["raw_cols"])
+    data, raws, ro, ao = [], [], 0, 0
+    for i, n in enumerate(g["natoms"]):
+        n = int(n)
+        nr = int(g["raw_rows"][i])
+        raws.append(g["raw_concat"][ro:ro + nr * ncols].reshape(nr, ncols).copy())
+        data.append(dict(Group="g", File=f"c{i}", NumAtoms=n, AtomTypes=[str(a) for a in g["atomtypes_concat"][ao:ao + n]],
+                         Positions=np.zeros((n, 3)), Energy=float(g["energy"][i]),
+                         Forces=g["forces_concat"][3 * ao:3 * (ao + n)].reshape(n, 3), Stress=g["stress"][i],
+                         eweight=float(g["eweight"][i]), fweight=float(g["fweight"][i]), vweight=float(g["vweight"][i]),
+                         test_bool=int(g["test_bool"][i])))
+        ro += nr * ncols
+        ao += n
+    calc.allocate_per_config(data)
+    calc.create_a()
+    calc.shared_index = 0
+    ao = 0
+    for i, d in enumerate(data):
+        n = d["NumAtoms"]
+        fake_lammps.CURRENT.update(raw=raws[i], vol=float(g["vols"][i]), types=g["types_concat"][ao:ao + n].astype(np.int32),
+                                   ids=1 + np.arange(n), pos=np.zeros((n, 3)))
+        calc.process_configs(d, i)
+        ao += n
+    calc.collect_distributed_lists()
+    assert np.array_equal(pt.shared_arrays["a"].array, g["A"])
+    assert np.array_equal(pt.shared_arrays["b"].array, g["b"])
+    assert np.array_equal(pt.shared_arrays["w"].array, g["w"])
+    assert pt.fitsnap_dict["Row_Type"] == [str(x) for x in g["Row_Type"]]
+    assert pt.fitsnap_dict["Atom_I"] == [int(x) for x in g["Atom_I"]]
+    if name.endswith("_nan"):
+        assert "applying np.nan_to_num()" in capsys.readouterr().out        # lammps_pace.py:399-403
+    pt.free()
