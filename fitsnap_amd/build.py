@@ -61,7 +61,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         if src == "fsnap_capi.cpp":
             cmd += ["-x", "hip"]
         if src == "fsnap_solve.cpp":
-            cmd += ["-mavx2", "-mfma"]   # host-only K x K solve: vectorised dot products
+            # host-only K x K solve: plain C++ (no device pass), AVX2+FMA baseline with AVX-512
+            # function clones resolved at load time
+            cmd = [hipcc, "-x", "c++", "-O3", "-std=c++17", "-fPIC", "-mavx2", "-mfma",
+                   "-I", os.path.join(HERE, "..", "include")]
         cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

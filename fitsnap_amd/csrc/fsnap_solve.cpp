@@ -28,15 +28,19 @@ namespace {
 
 typedef std::vector<double> vec;
 
+// the hot K x K loops are compiled twice (AVX-512 / AVX2+FMA) and resolved at load time
+#define FSNAP_CLONES __attribute__((target_clones("avx512f", "default")))
+#define FSNAP_INLINE static inline __attribute__((always_inline))
+
 // 4-wide fp64 vectors (AVX2 + FMA on the host; this file is compiled with -mavx2 -mfma)
 typedef double v4d __attribute__((vector_size(32)));
 typedef double v4du __attribute__((vector_size(32), aligned(8)));
 
-static inline v4d ld4(const double* p) { return *reinterpret_cast<const v4du*>(p); }
-static inline double hsum(v4d v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+FSNAP_INLINE v4d ld4(const double* p) { return *reinterpret_cast<const v4du*>(p); }
+FSNAP_INLINE double hsum(v4d v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 
 // dot product with 4 independent vector accumulators (fixed association order)
-static inline double dotv(const double* x, const double* y, int n) {
+FSNAP_INLINE double dotv(const double* x, const double* y, int n) {
     v4d s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;
     int k = 0;
     for (; k + 16 <= n; k += 16) {
@@ -51,53 +55,70 @@ static inline double dotv(const double* x, const double* y, int n) {
     return s;
 }
 
-// In-place lower Cholesky of the n x n row-major matrix a (only the lower triangle is
-// referenced/written).  Returns -1 on success or the index of the failing pivot.
-// *min_piv2 receives the smallest squared pivot (before sqrt) relative to the original
-// diagonal entry (1.0 for a Jacobi-scaled matrix).
-int chol_lower(double* a, int n, double* min_piv2) {
+// 8-wide vectors: one zmm op under the avx512f clone, two ymm ops under the default (AVX2) clone
+typedef double v8d __attribute__((vector_size(64)));
+typedef double v8du __attribute__((vector_size(64), aligned(8)));
+
+// y[0:n] -= alpha * x[0:n]
+FSNAP_INLINE void axpy_neg(double* y, const double* x, double alpha, int n) {
+    const v8d av = {alpha, alpha, alpha, alpha, alpha, alpha, alpha, alpha};
+    int k = 0;
+    for (; k + 16 <= n; k += 16) {
+        v8d y0 = *reinterpret_cast<const v8du*>(y + k), y1 = *reinterpret_cast<const v8du*>(y + k + 8);
+        y0 -= av * *reinterpret_cast<const v8du*>(x + k);
+        y1 -= av * *reinterpret_cast<const v8du*>(x + k + 8);
+        *reinterpret_cast<v8du*>(y + k) = y0;
+        *reinterpret_cast<v8du*>(y + k + 8) = y1;
+    }
+    for (; k + 8 <= n; k += 8) {
+        v8d yv = *reinterpret_cast<const v8du*>(y + k);
+        yv -= av * *reinterpret_cast<const v8du*>(x + k);
+        *reinterpret_cast<v8du*>(y + k) = yv;
+    }
+    for (; k < n; ++k) y[k] -= alpha * x[k];
+}
+
+// In-place Cholesky A = U^T U of the n x n row-major matrix a, UPPER triangle referenced and
+// overwritten with U (right-looking: every inner loop is a contiguous axpy on a row tail,
+// no horizontal sums).  Returns -1 on success or the index of the failing pivot.
+// *min_piv2 receives the smallest pivot (before sqrt); for the Jacobi-scaled (unit
+// diagonal) matrices this file factorises that is the pivot relative to the original
+// diagonal entry.
+FSNAP_CLONES int chol_upper(double* a, int n, double* min_piv2) {
     double mp = std::numeric_limits<double>::infinity();
     for (int j = 0; j < n; ++j) {
-        double* aj = a + (size_t)j * n;
-        // row j against previous rows (row-oriented: contiguous, vectorised dot products)
-        for (int i = 0; i < j; ++i) {
-            const double* ai = a + (size_t)i * n;
-            aj[i] = (aj[i] - dotv(aj, ai, i)) / ai[i];
-        }
-        const double d0 = aj[j];
-        const double d = d0 - dotv(aj, aj, j);
-        const double rel = (d0 != 0.0) ? d / d0 : d;
+        double* uj = a + (size_t)j * n;
+        const double d = uj[j];
+        const double rel = d;   // callers pass Jacobi-scaled matrices: original diagonal = 1
         if (rel < mp) mp = rel;
         if (!(d > 0.0) || !std::isfinite(d)) {
             if (min_piv2) *min_piv2 = mp;
             return j;
         }
-        aj[j] = std::sqrt(d);
+        const double r = std::sqrt(d), inv = 1.0 / r;
+        uj[j] = r;
+        for (int k = j + 1; k < n; ++k) uj[k] *= inv;
+        // trailing update: row i (i > j) tail [i, n) -= u[j][i] * u[j][i:n]
+        for (int i = j + 1; i < n; ++i) {
+            const double f = uj[i];
+            if (f != 0.0) axpy_neg(a + (size_t)i * n + i, uj + i, f, n - i);
+        }
     }
     if (min_piv2) *min_piv2 = mp;
     return -1;
 }
 
-// y -= alpha * x over n contiguous doubles
-static inline void axpy_neg(double* y, const double* x, double alpha, int n) {
-    const v4d av = {alpha, alpha, alpha, alpha};
-    int k = 0;
-    for (; k + 4 <= n; k += 4) {
-        v4d yv = ld4(y + k);
-        yv -= av * ld4(x + k);
-        *reinterpret_cast<v4du*>(y + k) = yv;
+// solve U^T U x = rhs in place (u upper, row-major): forward sweep in axpy form, backward
+// sweep by dot products — both over contiguous row tails
+FSNAP_CLONES void chol_solve(const double* u, int n, double* x) {
+    for (int k = 0; k < n; ++k) {
+        const double* r = u + (size_t)k * n;
+        x[k] /= r[k];
+        axpy_neg(x + k + 1, r + k + 1, x[k], n - 1 - k);
     }
-    for (; k < n; ++k) y[k] -= alpha * x[k];
-}
-
-// solve L L^T x = rhs in place (l lower, row-major): forward sweep by dot products over
-// contiguous rows, backward sweep in axpy form over the same contiguous rows
-void chol_solve(const double* l, int n, double* x) {
-    for (int i = 0; i < n; ++i) x[i] = (x[i] - dotv(l + (size_t)i * n, x, i)) / l[(size_t)i * n + i];
     for (int i = n - 1; i >= 0; --i) {
-        const double* r = l + (size_t)i * n;
-        x[i] /= r[i];
-        axpy_neg(x, r, x[i], i);
+        const double* r = u + (size_t)i * n;
+        x[i] = (x[i] - dotv(r + i + 1, x + i + 1, n - 1 - i)) / r[i];
     }
 }
 
@@ -262,7 +283,7 @@ int scaled_chol_solve(const vec& M, const vec& rhs, int n, vec& x, double* min_p
         for (int j = 0; j < n; ++j) S[(size_t)i * n + j] = M[(size_t)i * n + j] * d[i] * d[j];
     static thread_local vec L;
     L = S;
-    const int fail = chol_lower(L.data(), n, min_piv2);
+    const int fail = chol_upper(L.data(), n, min_piv2);
     if (fail >= 0) return fail;
     for (int i = 0; i < n; ++i) y[i] = rhs[i] * d[i];
     vec z(y);
@@ -307,6 +328,49 @@ extern "C" int fsnap_solve(int kind, double param, int64_t K64, const double* G,
     if (!all_finite(G, (size_t)K * K) || !all_finite(c, K) || !std::isfinite(param)) return FSNAP_NUM_NONFINITE;
     const double alpha = (kind == FSNAP_SOLVE_RIDGE || kind == FSNAP_SOLVE_RIDGE_INV) ? param : 0.0;
     const double eps = std::numeric_limits<double>::epsilon();
+
+    // ---- fast path (the common case of a fit loop): no zero column, well conditioned -----
+    // One contiguous pass over the UPPER triangle of G builds the Jacobi-scaled matrix (G is
+    // already exactly symmetric: the GPU reduction mirrors the triangle), checks finiteness
+    // on the fly, then Cholesky + two triangular sweeps.  Falls through to the general path
+    // when a diagonal entry is not positive, a pivot is small, or a value is not finite.
+    {
+        static thread_local vec U, dsc, z;
+        U.resize((size_t)K * K);
+        dsc.resize(K);
+        z.resize(K);
+        bool ok = true;
+        double chk = 0.0;
+        for (int i = 0; i < K && ok; ++i) {
+            const double g = G[(size_t)i * K + i] + alpha;
+            if (!(g > 0.0) || !std::isfinite(g)) ok = false;
+            else dsc[i] = 1.0 / std::sqrt(g);
+            chk += c[i] * 0.0;
+        }
+        if (ok) {
+            for (int i = 0; i < K; ++i) {
+                const double* gi = G + (size_t)i * K;
+                double* ui = U.data() + (size_t)i * K;
+                const double di = dsc[i];
+                for (int j = i; j < K; ++j) {
+                    ui[j] = gi[j] * di * dsc[j];
+                    chk += gi[j] * 0.0;       // NaN iff any entry is not finite
+                }
+                ui[i] = (gi[i] + alpha) * di * di;
+            }
+            double mp2 = 0.0;
+            if (chk == 0.0 && chol_upper(U.data(), K, &mp2) < 0 && mp2 > 1.0e-3) {
+                for (int i = 0; i < K; ++i) z[i] = c[i] * dsc[i];
+                chol_solve(U.data(), K, z.data());
+                for (int i = 0; i < K; ++i) beta[i] = z[i] * dsc[i];
+                if (all_finite(beta, K)) {
+                    if (rank_out) *rank_out = K;
+                    if (rcond_est) *rcond_est = mp2;
+                    return FSNAP_OK;
+                }
+            }
+        }
+    }
 
     // active columns: drop exactly-zero columns when there is no ridge shift
     static thread_local Reduced R;
