@@ -7,8 +7,8 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one complete fit of the resident rows: fused mask x weight x fp64-MFMA normal
-equations on every GPU, (N > 1) RCCL all-reduce of the packed K x K statistics, D2H of the
-statistics, K x K ridge solve -> beta on the host of rank 0.  A, b, w are resident in HBM
+equations on every GPU, (N > 1) RCCL all-reduce of the packed K x K statistics, K x K ridge
+solve on the GPU of rank 0 (single-workgroup Cholesky), D2H of beta -> beta on the host.  A, b, w are resident in HBM
 before the timed region (the PCIe-inclusive rate is reported separately, never as `value`).
 Weak scaling: every rank owns 10^6 rows of its own (disjoint synthetic row blocks);
 value = N * rows_per_gpu * steps / max-over-ranks wall time.
@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default: BASELINE config)")
     ap.add_argument("--cols", type=int, default=K)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-solve", action="store_true", help="D2H the statistics and solve on the host (A/B)")
     ap.add_argument("--option", action="append", default=[], help="kernel option key=value (split, nontemporal, nblocks)")
     return ap.parse_args()
 
@@ -126,14 +127,22 @@ def main():
         ctx.normal_eq_async(packed.data_ptr())
         if world > 1:
             dist.all_reduce(packed)                       # RCCL over xGMI, same stream
-        host.copy_(packed, non_blocking=True)
         t1 = time.perf_counter()
-        stream.synchronize()
-        t2 = time.perf_counter()
         beta = None
-        if rank == 0:
-            h = host.numpy()
-            beta, _, _ = _capi.solve(_capi.SOLVE_RIDGE, ALPHA, h[:Kc * Kc].reshape(Kc, Kc), h[Kc * Kc:Kc * Kc + Kc])
+        if args.host_solve:
+            host.copy_(packed, non_blocking=True)
+            stream.synchronize()
+            t2 = time.perf_counter()
+            if rank == 0:
+                h = host.numpy()
+                beta, _, _ = _capi.solve(_capi.SOLVE_RIDGE, ALPHA, h[:Kc * Kc].reshape(Kc, Kc), h[Kc * Kc:Kc * Kc + Kc])
+        else:
+            # K x K factorisation on the GPU (same stream); only beta crosses PCIe
+            t2 = t1
+            if rank == 0:
+                beta, _, _ = ctx.solve_device(_capi.SOLVE_RIDGE, ALPHA, Kc, packed.data_ptr())
+            else:
+                stream.synchronize()
         t3 = time.perf_counter()
         brk["launch"] += t1 - t0
         brk["sync"] += t2 - t1

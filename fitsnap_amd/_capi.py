@@ -46,10 +46,13 @@ SIGNATURES = {
     "fsnap_bind_weights": (c_int, [c_void_p, c_void_p, c_void_p]),
     "fsnap_normal_eq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fsnap_normal_eq_async": (c_int, [c_void_p, c_void_p]),
+    "fsnap_normal_eq_resident": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "fsnap_download_packed": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "fsnap_weight_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "fsnap_weight_rows_device": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "fsnap_predict": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fsnap_solve": (c_int, [c_int, c_double, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int), POINTER(c_double)]),
+    "fsnap_solve_device": (c_int, [c_void_p, c_int, c_double, c_int64, c_void_p, c_void_p, POINTER(c_int), POINTER(c_double)]),
     "fsnap_timing": (c_int, [c_void_p, _P_D, c_int]),
     "fsnap_launch_info": (c_int, [c_void_p, POINTER(c_int64), c_int]),
 }
@@ -257,6 +260,19 @@ class HipContext:
     def normal_eq_async(self, d_packed_ptr: int):
         self._check(self._lib.fsnap_normal_eq_async(self._h, c_void_p(d_packed_ptr)))
 
+    def normal_eq_resident(self) -> int:
+        """Statistics into the context-owned device buffer; returns its device address."""
+        ptr = c_void_p(None)
+        self._check(self._lib.fsnap_normal_eq_resident(self._h, byref(ptr)))
+        return ptr.value
+
+    def download_packed(self, d_packed_ptr: int, K: int):
+        G = np.empty((K, K))
+        c = np.empty(K)
+        s = np.empty(3)
+        self._check(self._lib.fsnap_download_packed(self._h, c_void_p(d_packed_ptr), K, _ptr(G), _ptr(c), _ptr(s)))
+        return G, c, s
+
     def weight_rows(self):
         aw = np.empty((self.m, self.K))
         bw = np.empty(self.m)
@@ -274,6 +290,17 @@ class HipContext:
         sse = c_double(0.0)
         self._check(self._lib.fsnap_predict(self._h, _ptr(beta), _ptr(preds), byref(sse) if want_sse else None))
         return preds, (sse.value if want_sse else None)
+
+    def solve_device(self, kind: int, param: float, K: int, d_packed_ptr: int):
+        """K x K solve from the packed statistics in HBM; returns (beta, rank, rcond_estimate)."""
+        beta = np.empty(K, dtype=np.float64)
+        rank = c_int(0)
+        rce = c_double(0.0)
+        rc = self._lib.fsnap_solve_device(self._h, int(kind), float(param), int(K), c_void_p(d_packed_ptr), _ptr(beta),
+                                          byref(rank), byref(rce))
+        if rc != OK:
+            raise_status(rc, (self._lib.fsnap_last_error(self._h) or b"").decode() if rc < 0 else "")
+        return beta, rank.value, rce.value
 
     # -- measurement -------------------------------------------------------------------
     def timing(self):

@@ -63,6 +63,7 @@ struct fsnap_ctx {
     // workspaces
     DevBuf part, cpart, spart, packed, beta, preds, sse, aw, bw;
     DevBuf st_raw, st_plan, st_frac, st_blank;   // staging of fsnap_assemble
+    DevBuf dsolve;                                // [beta | min pivot | status] of fsnap_solve_device
     // options
     int opt_split = 0;        // 0 = auto
     int opt_nt = 1;
@@ -369,7 +370,7 @@ int fsnap_ctx_destroy(fsnap_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->ownA, &ctx->ownb, &ctx->ownw, &ctx->ownmask, &ctx->ones, &ctx->part, &ctx->cpart,
                       &ctx->spart, &ctx->packed, &ctx->beta, &ctx->preds, &ctx->sse, &ctx->aw, &ctx->bw,
-                      &ctx->st_raw, &ctx->st_plan, &ctx->st_frac, &ctx->st_blank};
+                      &ctx->st_raw, &ctx->st_plan, &ctx->st_frac, &ctx->st_blank, &ctx->dsolve};
     for (DevBuf* b : bufs) b->release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -611,6 +612,30 @@ int fsnap_normal_eq(fsnap_ctx* ctx, double* G, double* c, double* scalars) {
     return FSNAP_OK;
 }
 
+int fsnap_normal_eq_resident(fsnap_ctx* ctx, double** d_packed) {
+    if (!ctx) return FSNAP_E_ARG;
+    if (!d_packed) return ctx->fail(FSNAP_E_ARG, "fsnap_normal_eq_resident: d_packed is NULL");
+    int rc;
+    if ((rc = check_rows(ctx))) return rc;
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    if (!ctx->packed.ensure((size_t)FSNAP_PACKED_LEN(ctx->K) * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(packed) failed");
+    if ((rc = launch_normal_eq(ctx, (double*)ctx->packed.p))) return rc;
+    *d_packed = (double*)ctx->packed.p;
+    return FSNAP_OK;
+}
+
+int fsnap_download_packed(fsnap_ctx* ctx, const double* d_packed, int64_t K, double* G, double* c, double* scalars) {
+    if (!ctx) return FSNAP_E_ARG;
+    if (!d_packed || K <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_download_packed: bad argument");
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    if (G) FSNAP_HIP(hipMemcpyAsync(G, d_packed, (size_t)K * K * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(G)");
+    if (c) FSNAP_HIP(hipMemcpyAsync(c, d_packed + K * K, (size_t)K * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(c)");
+    if (scalars)
+        FSNAP_HIP(hipMemcpyAsync(scalars, d_packed + K * K + K, 3 * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(s)");
+    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    return FSNAP_OK;
+}
+
 int fsnap_weight_rows_device(fsnap_ctx* ctx, double* d_aw, int64_t ldaw, double* d_bw) {
     if (!ctx) return FSNAP_E_ARG;
     int rc;
@@ -684,6 +709,44 @@ int fsnap_predict(fsnap_ctx* ctx, const double* beta, double* preds, double* sse
         FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     }
     return FSNAP_OK;
+}
+
+int fsnap_solve_device(fsnap_ctx* ctx, int kind, double param, int64_t K, const double* d_packed, double* beta,
+                       int* rank, double* rcond_est) {
+    if (!ctx) return FSNAP_E_ARG;
+    if (!d_packed || !beta || K <= 0 || kind < FSNAP_SOLVE_CHOL || kind > FSNAP_SOLVE_RIDGE_INV)
+        return ctx->fail(FSNAP_E_ARG, "fsnap_solve_device: bad argument");
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    const double alpha = (kind == FSNAP_SOLVE_RIDGE || kind == FSNAP_SOLVE_RIDGE_INV) ? param : 0.0;
+    if (K <= 128) {
+        if (!ctx->dsolve.ensure((size_t)(K + 2) * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(solve) failed");
+        double host[130];
+        FSNAP_HIP(fsnap::launch_chol_solve(d_packed, (int)K, alpha, (double*)ctx->dsolve.p, ctx->stream),
+                  "launch fsnap_chol_solve_k");
+        FSNAP_HIP(hipMemcpyAsync(host, ctx->dsolve.p, (size_t)(K + 2) * 8, hipMemcpyDeviceToHost, ctx->stream),
+                  "hipMemcpy(beta)");
+        FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+        // same acceptance rule as the host fast path: well-conditioned after Jacobi scaling
+        if (host[K + 1] == 0.0 && host[K] > 1.0e-3) {
+            bool fin = true;
+            for (int64_t i = 0; i < K; ++i) fin = fin && (host[i] - host[i] == 0.0);
+            if (fin) {
+                for (int64_t i = 0; i < K; ++i) beta[i] = host[i];
+                if (rank) *rank = (int)K;
+                if (rcond_est) *rcond_est = host[K];
+                return FSNAP_OK;
+            }
+        }
+    }
+    // general path: statistics to the host, full solver (rank-deficient / ill-conditioned / K > 128)
+    std::string tmp;
+    tmp.resize((size_t)(K * K + K) * 8);
+    FSNAP_HIP(hipMemcpyAsync(&tmp[0], d_packed, tmp.size(), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(G)");
+    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    const double* G = (const double*)tmp.data();
+    const int rc = fsnap_solve(kind, param, K, G, G + K * K, beta, rank, rcond_est);
+    if (rc) ctx->fail(rc, "fsnap_solve: numerical status %d", rc);
+    return rc;
 }
 
 int fsnap_timing(fsnap_ctx* ctx, double* ms, int n) {

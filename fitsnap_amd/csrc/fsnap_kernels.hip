@@ -1236,6 +1236,114 @@ __global__ __launch_bounds__(256) void fsnap_assemble_k(const double* __restrict
 }
 
 // ---------------------------------------------------------------------------------
+// Kernel 6: K x K solve on the device for K <= 128 (the latency path of a fit: avoids the
+// D2H of G and the host factorisation).  ONE workgroup; the Jacobi-scaled matrix
+// S = D (G + alpha I) D, D = diag(G + alpha I)^-1/2, lives in LDS (row stride K + 1 so
+// that row AND column accesses are bank-conflict free).  Right-looking upper Cholesky
+// S = U^T U with one barrier per column; forward / backward substitution by a single wave
+// with x in registers.  Same arithmetic as the host fast path (fsnap_solve.cpp): no
+// refinement; the host falls back to the full host solver when the kernel reports a small
+// pivot, a non-positive diagonal or a non-finite value.
+//   in : packed statistics [G (K*K) | c (K) | ...]
+//   out: [beta (K) | min relative pivot | status (0 ok, 1 = fall back)]
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsnap_chol_solve_k(const double* __restrict__ packed, int K, double alpha,
+                                                          double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int LD = K + 1;
+    double* U = sm;                 // K x LD
+    double* dsc = sm + (size_t)K * LD;
+    double* xs = dsc + K;
+    __shared__ int bad;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double* G = packed;
+    const double* c = packed + (size_t)K * K;
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    for (int i = tid; i < K; i += 256) {
+        const double g = G[(size_t)i * K + i] + alpha;
+        if (!(g > 0.0) || !(g < 1.0e300)) {
+            bad = 1;
+            dsc[i] = 0.0;
+        } else {
+            dsc[i] = 1.0 / sqrt(g);
+        }
+    }
+    __syncthreads();
+    double chk = 0.0;
+    for (int i = wv; i < K; i += 4) {
+        const double di = dsc[i];
+        for (int j = i + lane; j < K; j += 64) {
+            const double g = G[(size_t)i * K + j];
+            chk += g * 0.0;
+            U[i * LD + j] = ((i == j) ? g + alpha : g) * di * dsc[j];
+        }
+    }
+    for (int i = tid; i < K; i += 256) chk += c[i] * 0.0;
+    if (chk != 0.0) bad = 1;   // NaN: some entry was not finite
+    __syncthreads();
+    double minp = 1.0e300;
+    if (!bad) {
+        for (int j = 0; j < K; ++j) {
+            const double d = U[j * LD + j];
+            if (d < minp) minp = d;
+            if (!(d > 0.0)) {   // uniform: every thread reads the same value
+                minp = 0.0;
+                break;
+            }
+            const double inv = 1.0 / sqrt(d);
+            // trailing update with the UNSCALED row j (scaled on the fly): rows i > j
+            for (int i = j + 1 + wv; i < K; i += 4) {
+                const double f = U[j * LD + i] * inv;
+                for (int k = i + lane; k < K; k += 64) U[i * LD + k] -= f * (U[j * LD + k] * inv);
+            }
+            __syncthreads();
+            // row j gets its final (scaled) values; nobody reads it again before the solves
+            if (wv == 0) {
+                for (int k = j + lane; k < K; k += 64) U[j * LD + k] *= inv;
+            }
+        }
+    }
+    __syncthreads();
+    const bool fail = bad || !(minp > 0.0);
+    if (wv == 0) {
+        if (!fail) {
+            // forward: U^T y = D c   (axpy form over contiguous rows), x in registers
+            double x0 = (lane < K) ? c[lane] * dsc[lane] : 0.0;
+            double x1 = (lane + 64 < K) ? c[lane + 64] * dsc[lane + 64] : 0.0;
+            for (int k = 0; k < K; ++k) {
+                const double xk = (k < 64) ? __shfl(x0, k, 64) : __shfl(x1, k - 64, 64);
+                const double yk = xk / U[k * LD + k];
+                if (lane == (k & 63)) {
+                    if (k < 64) x0 = yk;
+                    else x1 = yk;
+                }
+                if (lane > k && lane < K) x0 -= U[k * LD + lane] * yk;
+                if (lane + 64 > k && lane + 64 < K) x1 -= U[k * LD + lane + 64] * yk;
+            }
+            // backward: U x = y   (column access; LD = K + 1 keeps it conflict free)
+            for (int i = K - 1; i >= 0; --i) {
+                const double xi0 = (i < 64) ? __shfl(x0, i, 64) : __shfl(x1, i - 64, 64);
+                const double xi = xi0 / U[i * LD + i];
+                if (lane == (i & 63)) {
+                    if (i < 64) x0 = xi;
+                    else x1 = xi;
+                }
+                if (lane < i) x0 -= U[lane * LD + i] * xi;
+                if (lane + 64 < i) x1 -= U[(lane + 64) * LD + i] * xi;
+            }
+            if (lane < K) out[lane] = x0 * dsc[lane];
+            if (lane + 64 < K) out[lane + 64] = x1 * dsc[lane + 64];
+        }
+        if (lane == 0) {
+            out[K] = minp;
+            out[K + 1] = fail ? 1.0 : 0.0;
+        }
+    }
+    (void)xs;
+}
+
+// ---------------------------------------------------------------------------------
 // host-side launchers (C++ linkage, used by fsnap_capi.cpp)
 // ---------------------------------------------------------------------------------
 namespace fsnap {
@@ -1395,6 +1503,19 @@ hipError_t launch_assemble(const double* raw, int64_t raw_ld, int64_t nrows, con
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(fsnap_assemble_k, dim3((unsigned)nb), dim3(256), 0, st, raw, raw_ld, nrows, src_row, kind, frac,
                        dval, truth, weight, fractions, blank2J, ntypes, ncoeff, off, A, lda, b, w);
+    return hipGetLastError();
+}
+
+hipError_t launch_chol_solve(const double* packed, int K, double alpha, double* out, hipStream_t st) {
+    const size_t lds = ((size_t)K * (K + 1) + 2 * (size_t)K) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)fsnap_chol_solve_k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024 - 64);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fsnap_chol_solve_k, dim3(1), dim3(256), lds, st, packed, K, alpha, out);
     return hipGetLastError();
 }
 

@@ -35,12 +35,14 @@ class RIDGE(Solver):
         The fit is stored as a member `fs.solver.fit` (rank 0 only).
         """
         pt = self.pt
-        G, c, _ = self._fit_statistics(a, b, w, fs_dict, trainall)
+        alval = self.config.sections["RIDGE"].alpha
+        local = bool(self.config.sections["RIDGE"].local_solver)
+        kind = _capi.SOLVE_RIDGE_INV if local else _capi.SOLVE_RIDGE
+        if "EXTRAS" in self.config.sections and self.config.sections["EXTRAS"].apply_transpose:
+            G, c, _ = self._fit_statistics(a, b, w, fs_dict, trainall)
+            if pt._rank == 0:
+                self.fit = self._solve(kind, alval, G.T @ G, G.T @ c)
+            return
+        fit = self._fit_and_solve(kind, alval, a, b, w, fs_dict, trainall)
         if pt._rank == 0:
-            alval = self.config.sections["RIDGE"].alpha
-            local = bool(self.config.sections["RIDGE"].local_solver)
-            if "EXTRAS" in self.config.sections and self.config.sections["EXTRAS"].apply_transpose:
-                c = G.T @ c
-                G = G.T @ G
-            kind = _capi.SOLVE_RIDGE_INV if local else _capi.SOLVE_RIDGE
-            self.fit = self._solve(kind, alval, G, c)
+            self.fit = fit

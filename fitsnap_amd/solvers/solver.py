@@ -50,7 +50,8 @@ class Solver:
         # engine state
         self.keep_resident = False   # explicit-array mode: reuse the HBM copy of (a, b) across calls
         self._resident_key = None
-        self.last_statistics = None  # (G, c, scalars) of the last fit, host ndarrays (after all-reduce)
+        self._stats_host = None      # (G, c, scalars) of the last fit, host ndarrays (after all-reduce)
+        self._stats_dev = None       # or (ctx, device address, K) while they are still in HBM only
         self.last_rank = None
         self._checks()
 
@@ -192,9 +193,50 @@ class Solver:
         return G, c, s
 
     def _solve(self, kind, param, G, c):
+        """Host K x K solve on statistics already on the host."""
         beta, rank, _ = _capi.solve(kind, param, G, c)
         self.last_rank = rank
         return beta
+
+    def _fit_and_solve(self, kind, param, a=None, b=None, w=None, fs_dict=None, trainall=False):
+        """The latency path of SVD / RIDGE in single-GPU mode: the statistics stay in HBM and
+        the K x K factorisation runs on the GPU (``fsnap_solve_device``; host fallback inside
+        the library for rank-deficient / ill-conditioned systems and K > 128); only beta
+        crosses PCIe.  ``last_statistics`` is then fetched lazily.  With several ranks the
+        all-reduced statistics are on the host already and rank 0 solves there."""
+        pt = self.pt
+        if not (pt.stubs or pt._size == 1):
+            G, c, _ = self._fit_statistics(a, b, w, fs_dict, trainall)
+            return self._solve(kind, param, G, c) if pt._rank == 0 else None
+        a, b, w_full, mask, shared_mode = self._resolve_inputs(a, b, w, fs_dict, trainall)
+        if a.ndim != 2:
+            raise ValueError("the A matrix must be 2-D")
+        K = a.shape[1]
+        if a.shape[0] == 0:
+            self._stats_host = (np.zeros((K, K)), np.zeros(K), np.zeros(3))
+            return self._solve(kind, param, *self._stats_host[:2])
+        ctx = self._upload(a, b, shared_mode)
+        ctx.set_weights(w_full, None if mask.all() else mask)
+        ptr = ctx.normal_eq_resident()
+        self._stats_host = None
+        self._stats_dev = (ctx, ptr, K)
+        beta, rank, _ = ctx.solve_device(kind, param, K, ptr)
+        self.last_rank = rank
+        return beta
+
+    @property
+    def last_statistics(self):
+        """(G, c, scalars) of the last fit as host ndarrays (downloaded on first access when the
+        fit kept them in HBM)."""
+        if self._stats_host is None and self._stats_dev is not None:
+            ctx, ptr, K = self._stats_dev
+            self._stats_host = ctx.download_packed(ptr, K)
+        return self._stats_host
+
+    @last_statistics.setter
+    def last_statistics(self, value):
+        self._stats_host = value
+        self._stats_dev = None
 
     # ------------------------------------------------------------------------------
     # downstream of the fit (solver.py:108-133, 368-435)

@@ -36,6 +36,11 @@ class SVD(Solver):
         """
         pt = self.pt
         # every rank contributes its rows' statistics; only rank 0 solves (svd.py:33)
+        if not ("EXTRAS" in self.config.sections and self.config.sections["EXTRAS"].apply_transpose):
+            fit = self._fit_and_solve(_capi.SOLVE_LSTSQ, self.RCOND, a, b, w, fs_dict, trainall)
+            if pt._rank == 0:
+                self.fit = fit
+            return
         G, c, _ = self._fit_statistics(a, b, w, fs_dict, trainall)
         if pt._rank == 0:
             rcond = self.RCOND

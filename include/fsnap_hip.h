@@ -143,6 +143,13 @@ int fsnap_normal_eq(fsnap_ctx* ctx, double* G, double* c, double* scalars);
  * examples/library/transpose_trick/example.py:245-246). */
 int fsnap_normal_eq_async(fsnap_ctx* ctx, double* d_packed);
 
+/* Same as fsnap_normal_eq_async into a context-owned device buffer whose address is
+ * returned in *d_packed (valid until the next call on this context); asynchronous. */
+int fsnap_normal_eq_resident(fsnap_ctx* ctx, double** d_packed);
+
+/* Copy packed statistics from device memory to host arrays (any may be NULL); synchronous. */
+int fsnap_download_packed(fsnap_ctx* ctx, const double* d_packed, int64_t K, double* G, double* c, double* scalars);
+
 /* Stand-alone wavefront row weighting: aw = w[:,None]*A, bw = w*b for ALL m rows
  * (masked rows are written as zeros); host outputs, leading dimension ldaw.
  * svd.py:46 / ridge.py:39 / solver.py:75 for callers that need aw, bw themselves. */
@@ -166,6 +173,14 @@ int fsnap_predict(fsnap_ctx* ctx, const double* beta, double* preds, double* sse
  * (ridge.py:47-57) and np.linalg.inv (regressor.py:15). */
 int fsnap_solve(int kind, double param, int64_t K, const double* G, const double* c, double* beta, int* rank,
                 double* rcond_est);
+
+/* Same solve, taking the packed statistics [G | c | ...] from DEVICE memory (the buffer
+ * fsnap_normal_eq_async / the all-reduce left in HBM).  For K <= 128 and a system that is
+ * well conditioned after Jacobi scaling the factorisation runs on the GPU (one workgroup,
+ * matrix in LDS) and only beta crosses PCIe; otherwise the statistics are copied to the
+ * host and fsnap_solve runs there.  Same status codes and semantics as fsnap_solve. */
+int fsnap_solve_device(fsnap_ctx* ctx, int kind, double param, int64_t K, const double* d_packed, double* beta,
+                       int* rank, double* rcond_est);
 
 /* ---- measurement ------------------------------------------------------------------ */
 

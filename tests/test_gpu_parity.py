@@ -405,3 +405,70 @@ def test_full_size_linearity_and_parity(ctx, big):
     ref = orc.ridge_fit(A, b, w, 1e-8)
     assert maxrel(sol.fit, ref) < 1e-6
     pt.free()
+
+
+# ---------------------------------------------------------------------------------------
+# K x K solve on the device (fsnap_solve_device) vs the host solver
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K", [1, 2, 5, 31, 63, 64, 65, 100, 127, 128])
+def test_device_solve_matches_host_solve(ctx, K):
+    A, b, w = orc.synth_problem(3000 + 11 * K, K)
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w)
+    ptr = ctx.normal_eq_resident()
+    G, c, s = ctx.download_packed(ptr, K)
+    for kind, param in ((_capi.SOLVE_RIDGE, 1e-8), (_capi.SOLVE_RIDGE, 1e-2), (_capi.SOLVE_CHOL, 0.0), (_capi.SOLVE_LSTSQ, 1e-13)):
+        bd, rank_d, _ = ctx.solve_device(kind, param, K, ptr)
+        bh, rank_h, _ = _capi.solve(kind, param, G, c)
+        assert rank_d == rank_h == K
+        assert maxrel(bd, bh) < 1e-9
+    ref = orc.ridge_fit(A, b, w, 1e-8)
+    bd, _, _ = ctx.solve_device(_capi.SOLVE_RIDGE, 1e-8, K, ptr)
+    assert maxrel(bd, ref) < 1e-6
+
+
+def test_device_solve_falls_back_for_hard_systems(ctx, ta, ta_fits):
+    import torch
+    A, b, w = ta
+    # ill-conditioned after scaling (min pivot 4e-5): host path with refinement, same answer as before
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w)
+    ptr = ctx.normal_eq_resident()
+    beta, rank, _ = ctx.solve_device(_capi.SOLVE_LSTSQ, 1e-13, 31, ptr)
+    assert rank == 31 and maxrel(beta, ta_fits["svd_all"]) < 1e-6
+    # zero column -> beta_j = 0 (lstsq minimum norm); indefinite -> LinAlgError; NaN -> ValueError
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(9)
+    X = rng.standard_normal((200, 6))
+    X[:, 2] = 0.0
+    y = rng.standard_normal(200)
+    pk = torch.tensor(np.concatenate([(X.T @ X).ravel(), X.T @ y, np.zeros(3)]), device=dev)
+    beta, rank, _ = ctx.solve_device(_capi.SOLVE_LSTSQ, 1e-13, 6, pk.data_ptr())
+    assert rank == 5 and beta[2] == 0.0
+    pk = torch.tensor(np.concatenate([np.array([[1.0, 2.0], [2.0, 1.0]]).ravel(), np.ones(2), np.zeros(3)]), device=dev)
+    with pytest.raises(np.linalg.LinAlgError):
+        ctx.solve_device(_capi.SOLVE_CHOL, 0.0, 2, pk.data_ptr())
+    pk = torch.tensor(np.concatenate([np.array([[np.nan, 0.0], [0.0, 1.0]]).ravel(), np.ones(2), np.zeros(3)]), device=dev)
+    with pytest.raises(ValueError):
+        ctx.solve_device(_capi.SOLVE_RIDGE, 1e-8, 2, pk.data_ptr())
+
+
+def test_collective_path_on_one_gpu(ta, ta_fits):
+    # torch.distributed/nccl (= RCCL) process group of ONE rank: exercises the multi-GPU code path
+    # (async kernel into a torch tensor on torch's stream -> all_reduce -> D2H -> rank-0 solve)
+    import torch.distributed as dist
+    A, b, w = ta
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29617", rank=0, world_size=1)
+    try:
+        pt = ParallelTools(comm="torch")
+        pt._size = 2          # force the collective branch; the group itself has one member
+        cfg = Config(pt, {"SOLVER": {"solver": "RIDGE"}, "RIDGE": {"alpha": 1e-8}})
+        s = solver_factory.solver("RIDGE", pt, cfg)
+        s.perform_fit(A, b, w, trainall=True)
+        check_fit(s.fit, ta_fits["ridge_sklearn_1e-8_all"])
+        G, c, sc = s.last_statistics
+        stats_close(G, c, sc, *orc.normal_eq(A, b, w))
+        pt.free()
+    finally:
+        dist.destroy_process_group()
