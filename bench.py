@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default: BASELINE config)")
     ap.add_argument("--cols", type=int, default=K)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--host-solve", action="store_true", help="D2H the statistics and solve on the host (A/B)")
+    ap.add_argument("--host-solve", action="store_true", help="D2H via torch + fsnap_solve on the host (A/B)")
     ap.add_argument("--option", action="append", default=[], help="kernel option key=value (split, nontemporal, nblocks)")
     return ap.parse_args()
 

@@ -71,6 +71,7 @@ struct fsnap_ctx {
     int opt_tiled = 0;        // force the general-K tiled kernel also for K <= 128
     int opt_kernel = 0;       // 0 auto | 1 wave-triangle (kernel 1) | 2 LDS-shared, static per-wave bodies | 3 LDS-shared, generic
     int opt_nsplit = 0;       // row splits of the tiled kernel (0 = auto)
+    int opt_device_solve = 0; // 1 = factorise K <= 128 systems on the GPU (fsnap_chol_solve_k)
     // timing flags
     bool t_syrk = false, t_upload = false, t_weight = false, t_predict = false;
 
@@ -403,6 +404,8 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
     } else if (!strcmp(key, "kernel")) {
         if (value < 0 || value > 3) return ctx->fail(FSNAP_E_ARG, "kernel must be 0 (auto), 1, 2 or 3");
         ctx->opt_kernel = (int)value;
+    } else if (!strcmp(key, "device_solve")) {
+        ctx->opt_device_solve = value != 0;
     } else if (!strcmp(key, "tiled")) {
         ctx->opt_tiled = value != 0;
     } else if (!strcmp(key, "nsplit")) {
@@ -718,7 +721,7 @@ int fsnap_solve_device(fsnap_ctx* ctx, int kind, double param, int64_t K, const 
         return ctx->fail(FSNAP_E_ARG, "fsnap_solve_device: bad argument");
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     const double alpha = (kind == FSNAP_SOLVE_RIDGE || kind == FSNAP_SOLVE_RIDGE_INV) ? param : 0.0;
-    if (K <= 128) {
+    if (K <= 128 && ctx->opt_device_solve) {
         if (!ctx->dsolve.ensure((size_t)(K + 2) * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(solve) failed");
         double host[130];
         FSNAP_HIP(fsnap::launch_chol_solve(d_packed, (int)K, alpha, (double*)ctx->dsolve.p, ctx->stream),

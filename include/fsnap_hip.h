@@ -69,7 +69,8 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
 /* Tuning knobs (all optional; 0 = auto): "kernel" (1 wave-triangle, 2 LDS-shared rows with
  * per-wave specialised bodies, 3 LDS-shared generic variant), "split" (1|2, sub-waves per row-wave of kernel 1),
  * "nontemporal" (0|1), "nblocks" (workgroups of the SYRK kernel), "tiled" (1 = force the
- * general-K tiled kernel also for K <= 128), "nsplit" (row splits of the tiled kernel).
+ * general-K tiled kernel also for K <= 128), "nsplit" (row splits of the tiled kernel),
+ * "device_solve" (1 = fsnap_solve_device factorises K <= 128 systems on the GPU).
  * Unknown key -> FSNAP_E_ARG. */
 int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value);
 
@@ -175,10 +176,10 @@ int fsnap_solve(int kind, double param, int64_t K, const double* G, const double
                 double* rcond_est);
 
 /* Same solve, taking the packed statistics [G | c | ...] from DEVICE memory (the buffer
- * fsnap_normal_eq_async / the all-reduce left in HBM).  For K <= 128 and a system that is
- * well conditioned after Jacobi scaling the factorisation runs on the GPU (one workgroup,
- * matrix in LDS) and only beta crosses PCIe; otherwise the statistics are copied to the
- * host and fsnap_solve runs there.  Same status codes and semantics as fsnap_solve. */
+ * fsnap_normal_eq_async / the all-reduce left in HBM).  By default the statistics are copied
+ * to the host and fsnap_solve runs there; with option "device_solve" = 1, K <= 128 and a
+ * system that is well conditioned after Jacobi scaling, the factorisation runs on the GPU
+ * (one workgroup, matrix in LDS) and only beta crosses PCIe.  Same status codes and semantics as fsnap_solve. */
 int fsnap_solve_device(fsnap_ctx* ctx, int kind, double param, int64_t K, const double* d_packed, double* beta,
                        int* rank, double* rcond_est);
 

@@ -417,19 +417,24 @@ def test_device_solve_matches_host_solve(ctx, K):
     ctx.set_weights(w)
     ptr = ctx.normal_eq_resident()
     G, c, s = ctx.download_packed(ptr, K)
-    for kind, param in ((_capi.SOLVE_RIDGE, 1e-8), (_capi.SOLVE_RIDGE, 1e-2), (_capi.SOLVE_CHOL, 0.0), (_capi.SOLVE_LSTSQ, 1e-13)):
-        bd, rank_d, _ = ctx.solve_device(kind, param, K, ptr)
-        bh, rank_h, _ = _capi.solve(kind, param, G, c)
-        assert rank_d == rank_h == K
-        assert maxrel(bd, bh) < 1e-9
-    ref = orc.ridge_fit(A, b, w, 1e-8)
-    bd, _, _ = ctx.solve_device(_capi.SOLVE_RIDGE, 1e-8, K, ptr)
-    assert maxrel(bd, ref) < 1e-6
+    ctx.set_option("device_solve", 1)
+    try:
+        for kind, param in ((_capi.SOLVE_RIDGE, 1e-8), (_capi.SOLVE_RIDGE, 1e-2), (_capi.SOLVE_CHOL, 0.0), (_capi.SOLVE_LSTSQ, 1e-13)):
+            bd, rank_d, _ = ctx.solve_device(kind, param, K, ptr)
+            bh, rank_h, _ = _capi.solve(kind, param, G, c)
+            assert rank_d == rank_h == K
+            assert maxrel(bd, bh) < 1e-9
+        ref = orc.ridge_fit(A, b, w, 1e-8)
+        bd, _, _ = ctx.solve_device(_capi.SOLVE_RIDGE, 1e-8, K, ptr)
+        assert maxrel(bd, ref) < 1e-6
+    finally:
+        ctx.set_option("device_solve", 0)
 
 
 def test_device_solve_falls_back_for_hard_systems(ctx, ta, ta_fits):
     import torch
     A, b, w = ta
+    ctx.set_option("device_solve", 1)
     # ill-conditioned after scaling (min pivot 4e-5): host path with refinement, same answer as before
     ctx.upload_rows(A, b)
     ctx.set_weights(w)
@@ -451,6 +456,7 @@ def test_device_solve_falls_back_for_hard_systems(ctx, ta, ta_fits):
     pk = torch.tensor(np.concatenate([np.array([[np.nan, 0.0], [0.0, 1.0]]).ravel(), np.ones(2), np.zeros(3)]), device=dev)
     with pytest.raises(ValueError):
         ctx.solve_device(_capi.SOLVE_RIDGE, 1e-8, 2, pk.data_ptr())
+    ctx.set_option("device_solve", 0)
 
 
 def test_collective_path_on_one_gpu(ta, ta_fits):
