@@ -64,6 +64,8 @@ struct fsnap_ctx {
     DevBuf part, cpart, spart, packed, beta, preds, sse, aw, bw;
     DevBuf st_raw, st_plan, st_frac, st_blank;   // staging of fsnap_assemble
     DevBuf dsolve;                                // [beta | min pivot | status] of fsnap_solve_device
+    double* pinned = nullptr;                     // page-locked host staging of the packed statistics
+    size_t pinned_bytes = 0;
     // options
     int opt_split = 0;        // 0 = auto
     int opt_nt = 1;
@@ -373,6 +375,7 @@ int fsnap_ctx_destroy(fsnap_ctx* ctx) {
                       &ctx->spart, &ctx->packed, &ctx->beta, &ctx->preds, &ctx->sse, &ctx->aw, &ctx->bw,
                       &ctx->st_raw, &ctx->st_plan, &ctx->st_frac, &ctx->st_blank, &ctx->dsolve};
     for (DevBuf* b : bufs) b->release();
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -741,12 +744,19 @@ int fsnap_solve_device(fsnap_ctx* ctx, int kind, double param, int64_t K, const 
             }
         }
     }
-    // general path: statistics to the host, full solver (rank-deficient / ill-conditioned / K > 128)
-    std::string tmp;
-    tmp.resize((size_t)(K * K + K) * 8);
-    FSNAP_HIP(hipMemcpyAsync(&tmp[0], d_packed, tmp.size(), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(G)");
+    // general path: statistics to the host (page-locked staging), full solver
+    const size_t need = (size_t)(K * K + K) * 8;
+    if (ctx->pinned_bytes < need) {
+        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+        if (hipHostMalloc((void**)&ctx->pinned, need, hipHostMallocDefault) != hipSuccess)
+            return ctx->fail(FSNAP_E_NOMEM, "hipHostMalloc(%zu) failed", need);
+        ctx->pinned_bytes = need;
+    }
+    FSNAP_HIP(hipMemcpyAsync(ctx->pinned, d_packed, need, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(G)");
     FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
-    const double* G = (const double*)tmp.data();
+    const double* G = ctx->pinned;
     const int rc = fsnap_solve(kind, param, K, G, G + K * K, beta, rank, rcond_est);
     if (rc) ctx->fail(rc, "fsnap_solve: numerical status %d", rc);
     return rc;

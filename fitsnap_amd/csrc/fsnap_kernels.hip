@@ -1237,30 +1237,35 @@ __global__ __launch_bounds__(256) void fsnap_assemble_k(const double* __restrict
 
 // ---------------------------------------------------------------------------------
 // Kernel 6: K x K solve on the device for K <= 128 (the latency path of a fit: avoids the
-// D2H of G and the host factorisation).  ONE workgroup; the Jacobi-scaled matrix
-// S = D (G + alpha I) D, D = diag(G + alpha I)^-1/2, lives in LDS (row stride K + 1 so
-// that row AND column accesses are bank-conflict free).  Right-looking upper Cholesky
-// S = U^T U with one barrier per column; forward / backward substitution by a single wave
-// with x in registers.  Same arithmetic as the host fast path (fsnap_solve.cpp): no
-// refinement; the host falls back to the full host solver when the kernel reports a small
-// pivot, a non-positive diagonal or a non-finite value.
+// D2H of G and the host factorisation).  ONE workgroup of 1024 threads; the Jacobi-scaled
+// matrix S = D (G + alpha I) D, D = diag(G + alpha I)^-1/2, is held IN REGISTERS in a 32 x 32
+// block-cyclic distribution (thread (ti, tk) owns S[ti + 32a][tk + 32b], a, b < 4), so the
+// right-looking upper Cholesky S = U^T U does no LDS read-modify-write: per column the owners
+// of the pivot row publish it (unscaled) through a double-buffered 1 KB LDS row, ONE barrier,
+// then every thread updates its 16 elements.  Finished rows of U are parked in LDS (row
+// stride K + 1: row and column access conflict-free) for the forward / backward sweeps,
+// which one wave runs with x in registers and pre-inverted diagonals.
+// Same arithmetic as the host fast path (fsnap_solve.cpp): no refinement; the host falls
+// back to the full host solver when the kernel reports a small pivot, a non-positive
+// diagonal or a non-finite value.
 //   in : packed statistics [G (K*K) | c (K) | ...]
 //   out: [beta (K) | min relative pivot | status (0 ok, 1 = fall back)]
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fsnap_chol_solve_k(const double* __restrict__ packed, int K, double alpha,
-                                                          double* __restrict__ out) {
+__global__ __launch_bounds__(1024) void fsnap_chol_solve_k(const double* __restrict__ packed, int K, double alpha,
+                                                           double* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int LD = K + 1;
-    double* U = sm;                 // K x LD
-    double* dsc = sm + (size_t)K * LD;
-    double* xs = dsc + K;
+    double* U = sm;                        // K x LD, final (scaled) rows of U
+    double* dsc = sm + (size_t)K * LD;     // K
+    double* rowbuf = dsc + K;              // 2 x 128, unscaled pivot rows
     __shared__ int bad;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ti = tid >> 5, tk = tid & 31;
     const double* G = packed;
     const double* c = packed + (size_t)K * K;
     if (tid == 0) bad = 0;
     __syncthreads();
-    for (int i = tid; i < K; i += 256) {
+    for (int i = tid; i < K; i += 1024) {
         const double g = G[(size_t)i * K + i] + alpha;
         if (!(g > 0.0) || !(g < 1.0e300)) {
             bad = 1;
@@ -1270,37 +1275,74 @@ __global__ __launch_bounds__(256) void fsnap_chol_solve_k(const double* __restri
         }
     }
     __syncthreads();
+    double e[4][4];
     double chk = 0.0;
-    for (int i = wv; i < K; i += 4) {
-        const double di = dsc[i];
-        for (int j = i + lane; j < K; j += 64) {
-            const double g = G[(size_t)i * K + j];
-            chk += g * 0.0;
-            U[i * LD + j] = ((i == j) ? g + alpha : g) * di * dsc[j];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int i = ti + 32 * a;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int k = tk + 32 * b;
+            double v = 0.0;
+            if (i < K && k < K && k >= i) {
+                const double g = G[(size_t)i * K + k];
+                chk += g * 0.0;
+                v = ((i == k) ? g + alpha : g) * dsc[i] * dsc[k];
+            }
+            e[a][b] = v;
         }
     }
-    for (int i = tid; i < K; i += 256) chk += c[i] * 0.0;
+    if (tid < K) chk += c[tid] * 0.0;
     if (chk != 0.0) bad = 1;   // NaN: some entry was not finite
     __syncthreads();
     double minp = 1.0e300;
     if (!bad) {
         for (int j = 0; j < K; ++j) {
-            const double d = U[j * LD + j];
+            double* rb = rowbuf + (j & 1) * 128;
+            const int aj = j >> 5;
+            if (ti == (j & 31)) {   // owners of row j publish it (unscaled)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (a == aj) {
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const int k = tk + 32 * b;
+                            if (k >= j && k < K) rb[k] = e[a][b];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            const double d = rb[j];
             if (d < minp) minp = d;
             if (!(d > 0.0)) {   // uniform: every thread reads the same value
                 minp = 0.0;
                 break;
             }
-            const double inv = 1.0 / sqrt(d);
-            // trailing update with the UNSCALED row j (scaled on the fly): rows i > j
-            for (int i = j + 1 + wv; i < K; i += 4) {
-                const double f = U[j * LD + i] * inv;
-                for (int k = i + lane; k < K; k += 64) U[i * LD + k] -= f * (U[j * LD + k] * inv);
+            const double r = sqrt(d), inv = 1.0 / r;
+            double fi[4], gk[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int i = ti + 32 * a;
+                fi[a] = (i > j && i < K) ? rb[i] * inv : 0.0;
             }
-            __syncthreads();
-            // row j gets its final (scaled) values; nobody reads it again before the solves
-            if (wv == 0) {
-                for (int k = j + lane; k < K; k += 64) U[j * LD + k] *= inv;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int k = tk + 32 * b;
+                gk[b] = (k > j && k < K) ? rb[k] * inv : 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) e[a][b] -= fi[a] * gk[b];   // rows i <= j get fi = 0
+            // park the final row j of U for the sweeps
+            if (ti == (j & 31)) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int k = tk + 32 * b;
+                    if (k > j && k < K) U[j * LD + k] = gk[b];
+                    if (k == j) U[j * LD + j] = r;
+                }
             }
         }
     }
@@ -1308,12 +1350,14 @@ __global__ __launch_bounds__(256) void fsnap_chol_solve_k(const double* __restri
     const bool fail = bad || !(minp > 0.0);
     if (wv == 0) {
         if (!fail) {
+            // pre-inverted diagonal
+            const double id0 = (lane < K) ? 1.0 / U[lane * LD + lane] : 0.0;
+            const double id1 = (lane + 64 < K) ? 1.0 / U[(lane + 64) * LD + lane + 64] : 0.0;
             // forward: U^T y = D c   (axpy form over contiguous rows), x in registers
             double x0 = (lane < K) ? c[lane] * dsc[lane] : 0.0;
             double x1 = (lane + 64 < K) ? c[lane + 64] * dsc[lane + 64] : 0.0;
             for (int k = 0; k < K; ++k) {
-                const double xk = (k < 64) ? __shfl(x0, k, 64) : __shfl(x1, k - 64, 64);
-                const double yk = xk / U[k * LD + k];
+                const double yk = (k < 64) ? __shfl(x0 * id0, k, 64) : __shfl(x1 * id1, k - 64, 64);
                 if (lane == (k & 63)) {
                     if (k < 64) x0 = yk;
                     else x1 = yk;
@@ -1323,8 +1367,7 @@ __global__ __launch_bounds__(256) void fsnap_chol_solve_k(const double* __restri
             }
             // backward: U x = y   (column access; LD = K + 1 keeps it conflict free)
             for (int i = K - 1; i >= 0; --i) {
-                const double xi0 = (i < 64) ? __shfl(x0, i, 64) : __shfl(x1, i - 64, 64);
-                const double xi = xi0 / U[i * LD + i];
+                const double xi = (i < 64) ? __shfl(x0 * id0, i, 64) : __shfl(x1 * id1, i - 64, 64);
                 if (lane == (i & 63)) {
                     if (i < 64) x0 = xi;
                     else x1 = xi;
@@ -1340,7 +1383,6 @@ __global__ __launch_bounds__(256) void fsnap_chol_solve_k(const double* __restri
             out[K + 1] = fail ? 1.0 : 0.0;
         }
     }
-    (void)xs;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1507,7 +1549,7 @@ hipError_t launch_assemble(const double* raw, int64_t raw_ld, int64_t nrows, con
 }
 
 hipError_t launch_chol_solve(const double* packed, int K, double alpha, double* out, hipStream_t st) {
-    const size_t lds = ((size_t)K * (K + 1) + 2 * (size_t)K) * sizeof(double);
+    const size_t lds = ((size_t)K * (K + 1) + (size_t)K + 256) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)fsnap_chol_solve_k, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1515,7 +1557,7 @@ hipError_t launch_chol_solve(const double* packed, int K, double alpha, double* 
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(fsnap_chol_solve_k, dim3(1), dim3(256), lds, st, packed, K, alpha, out);
+    hipLaunchKernelGGL(fsnap_chol_solve_k, dim3(1), dim3(1024), lds, st, packed, K, alpha, out);
     return hipGetLastError();
 }
 
