@@ -74,6 +74,7 @@ struct fsnap_ctx {
     int opt_kernel = 0;       // 0 auto | 1 wave-triangle (kernel 1) | 2 LDS-shared, static per-wave bodies | 3 LDS-shared, generic
     int opt_nsplit = 0;       // row splits of the tiled kernel (0 = auto)
     int opt_device_solve = 0; // 1 = factorise K <= 128 systems on the GPU (fsnap_chol_solve_k)
+    int opt_ablate = 0;       // timing-only ablation of kernel 1L (diagnostics; results are wrong)
     // timing flags
     bool t_syrk = false, t_upload = false, t_weight = false, t_predict = false;
 
@@ -285,6 +286,7 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed) {
     a.split = g.split;
     a.chunks_per_wave = g.cpw;
     a.nontemporal = ctx->opt_nt != 0;
+    a.ablate = ctx->opt_ablate;
     a.part = (double*)ctx->part.p;
     a.cpart = (double*)ctx->cpart.p;
     a.spart = (double*)ctx->spart.p;
@@ -407,6 +409,8 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
     } else if (!strcmp(key, "kernel")) {
         if (value < 0 || value > 3) return ctx->fail(FSNAP_E_ARG, "kernel must be 0 (auto), 1, 2 or 3");
         ctx->opt_kernel = (int)value;
+    } else if (!strcmp(key, "ablate")) {
+        ctx->opt_ablate = (int)value;
     } else if (!strcmp(key, "device_solve")) {
         ctx->opt_device_solve = value != 0;
     } else if (!strcmp(key, "tiled")) {

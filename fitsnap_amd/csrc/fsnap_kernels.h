@@ -19,6 +19,7 @@ struct SyrkArgs {
     int split;                  // sub-waves per row-wave sharing the tile triangle (1 or 2)
     int64_t chunks_per_wave;    // 4-row chunks per wave
     bool nontemporal;           // use nt loads for the A stream
+    int ablate = 0;             // timing-only diagnostic ablation of kernel 1L (0 = off)
     double* part;               // [nblocks][NT][4][64]
     double* cpart;              // [nblocks*4][NB][16]
     double* spart;              // [nblocks*4][4]

@@ -649,7 +649,7 @@ __device__ __forceinline__ void chunk_tiles(d4 (&acc)[NTM], const double* src, s
     (tile_mfma<tile_p_of<NB>(T0 + U), tile_q_of<NB>(T0 + U)>(acc[U], src), ...);
 }
 
-template <int NB, int NW, int WV, bool FULLK, bool NT>
+template <int NB, int NW, int WV, bool FULLK, bool NT, int ABL>
 __device__ __forceinline__ void syrk_lds_static_body(double* lds, const WaveBufs& wb, int K, unsigned nstage,
                                                      double* __restrict__ pw, double* __restrict__ cw,
                                                      double* __restrict__ sw) {
@@ -671,10 +671,22 @@ __device__ __forceinline__ void syrk_lds_static_body(double* lds, const WaveBufs
 
     ChunkRaw<NB> raw;
     ChunkRegs<NB> cr;
+    // ABL != 0: diagnostic ablations (wrong results, timing only; option "ablate"):
+    //   1 = no HBM loads in the stage loop, 2 = no weighting / c VALU work in park,
+    //   3 = no barriers in the stage loop, 4 = MFMA operands not re-read from LDS
     auto park = [&](int buf) {
-        finish_chunk<NB, FULLK>(cr, raw, K, e);
-        valu_c_chunk<NB>(cacc, cr);
-        valu_s_chunk<NB>(bb, sbw, cnt, cr);
+        if (ABL == 2) {
+#pragma unroll
+            for (int j = 0; j < NB / 2; ++j) {
+                const d2 x = __builtin_bit_cast(d2, raw.pr[j]);
+                cr.v[2 * j] = x[0];
+                cr.v[2 * j + 1] = x[1];
+            }
+        } else {
+            finish_chunk<NB, FULLK>(cr, raw, K, e);
+            valu_c_chunk<NB>(cacc, cr);
+            valu_s_chunk<NB>(bb, sbw, cnt, cr);
+        }
         double* dst = lds + buf * STAGE_DOUBLES + (WV * NB) * 64 + lane;
 #pragma unroll
         for (int bq = 0; bq < NB; ++bq) dst[bq * 64] = cr.v[bq];
@@ -686,15 +698,15 @@ __device__ __forceinline__ void syrk_lds_static_body(double* lds, const WaveBufs
         issue_chunk<NB, NT>(raw, wb, (unsigned)(NW + WV), kr);
         __syncthreads();
         for (unsigned s = 0; s < nstage; ++s) {
-            const double* src = lds + (s & 1) * STAGE_DOUBLES + lane;
+            const double* src = lds + ((ABL == 4) ? 0 : (s & 1)) * STAGE_DOUBLES + lane;
             if (HAS_TILES) {
 #pragma unroll
                 for (int c = 0; c < NW; ++c)
-                    chunk_tiles<NB, T0, NTM>(acc, src + c * NB * 64, std::make_integer_sequence<int, NTM>{});
+                    chunk_tiles<NB, T0, NTM>(acc, src + ((ABL == 4) ? 0 : c) * NB * 64, std::make_integer_sequence<int, NTM>{});
             }
             park((s + 1) & 1);
-            issue_chunk<NB, NT>(raw, wb, (s + 2) * NW + WV, kr);
-            __syncthreads();
+            if (ABL != 1) issue_chunk<NB, NT>(raw, wb, (s + 2) * NW + WV, kr);
+            if (ABL != 3) __syncthreads();
         }
     }
 
@@ -732,16 +744,16 @@ __device__ __forceinline__ void syrk_lds_static_body(double* lds, const WaveBufs
     }
 }
 
-template <int NB, int NW, bool FULLK, bool NT, int... W>
+template <int NB, int NW, bool FULLK, bool NT, int ABL, int... W>
 __device__ __forceinline__ void syrk_lds_dispatch(int wv, double* lds, const WaveBufs& wb, int K, unsigned nstage,
                                                   double* pw, double* cw, double* sw, std::integer_sequence<int, W...>) {
     // every wave of the workgroup takes exactly one branch; all bodies execute the same barriers
-    ((wv == W ? (syrk_lds_static_body<NB, NW, W, FULLK, NT>(lds, wb, K, nstage, pw, cw, sw), 0) : 0), ...);
+    ((wv == W ? (syrk_lds_static_body<NB, NW, W, FULLK, NT, ABL>(lds, wb, K, nstage, pw, cw, sw), 0) : 0), ...);
 }
 
 }  // namespace
 
-template <int NB, int NW, bool FULLK, bool NT>
+template <int NB, int NW, bool FULLK, bool NT, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, 4) void fsnap_syrk_lds_static(const double* __restrict__ A, int64_t lda,
                                                                     const double* __restrict__ b,
                                                                     const double* __restrict__ w,
@@ -778,7 +790,7 @@ __global__ __launch_bounds__(64 * NW, 4) void fsnap_syrk_lds_static(const double
     double* pw = part + wg * (int64_t)(NTILE * 256);
     double* cw = cpart + wg * (int64_t)(NB * 16);
     double* sw = spart + wg * 4;
-    syrk_lds_dispatch<NB, NW, FULLK, NT>(wv, lds, wb, K, nstage, pw, cw, sw, std::make_integer_sequence<int, NW>{});
+    syrk_lds_dispatch<NB, NW, FULLK, NT, ABL>(wv, lds, wb, K, nstage, pw, cw, sw, std::make_integer_sequence<int, NW>{});
 }
 
 // ---------------------------------------------------------------------------------
@@ -1446,6 +1458,19 @@ template <int NB, int NW>
 static hipError_t launch_syrk_lds_static_nb(const SyrkArgs& a, hipStream_t st) {
     dim3 grid((unsigned)a.nblocks), block(64 * NW);
     const bool fullk = (a.K == 16 * NB);
+#define FSNAP_ABL(N)                                                                                               \
+    hipLaunchKernelGGL((fsnap_syrk_lds_static<8, 8, true, true, N>), grid, block, 0, st, a.A, a.lda, a.b, a.w, a.mask, \
+                       a.m, a.K, a.chunks_per_wave, a.part, a.cpart, a.spart)
+    if (NB == 8 && NW == 8 && fullk && a.ablate) {   // timing-only diagnostic variants (option "ablate")
+        switch (a.ablate) {
+            case 1: FSNAP_ABL(1); break;
+            case 2: FSNAP_ABL(2); break;
+            case 3: FSNAP_ABL(3); break;
+            default: FSNAP_ABL(4); break;
+        }
+        return hipGetLastError();
+    }
+#undef FSNAP_ABL
     if (fullk)
         hipLaunchKernelGGL((fsnap_syrk_lds_static<NB, NW, true, true>), grid, block, 0, st, a.A, a.lda, a.b, a.w, a.mask,
                            a.m, a.K, a.chunks_per_wave, a.part, a.cpart, a.spart);
