@@ -76,7 +76,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{log}")
         if verbose and log.strip():
             print(log, file=sys.stderr)
-    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out, *objs, "-Wl,-rpath,/opt/rocm/lib"]
+    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out, *objs, "-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")

@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #include "../../include/fsnap_hip.h"
@@ -102,6 +103,91 @@ FSNAP_CLONES int chol_upper(double* a, int n, double* min_piv2) {
         for (int i = j + 1; i < n; ++i) {
             const double f = uj[i];
             if (f != 0.0) axpy_neg(a + (size_t)i * n + i, uj + i, f, n - i);
+        }
+    }
+    if (min_piv2) *min_piv2 = mp;
+    return -1;
+}
+
+// ---- blocked variant for large n --------------------------------------------------------
+// (the unblocked sweep streams the whole trailing matrix from L2/L3 once per column: 10 GB
+// at n = 1595).  Panels of NBK pivot rows are factorised with the unblocked recurrence
+// restricted to the panel's rows; every trailing row then receives the NBK rank-1 updates in
+// ONE pass, 32-column register chunks at a time; trailing rows are independent, so they are
+// dealt round-robin to a few host threads when the trailing matrix is large.
+constexpr int NBK = 64;
+
+// factorise pivot rows [jb, je) (unblocked, updates restricted to rows < je); -1 or failing row
+FSNAP_CLONES int chol_panel(double* a, int n, int jb, int je, double* mp) {
+    for (int j = jb; j < je; ++j) {
+        double* uj = a + (size_t)j * n;
+        const double d = uj[j];
+        if (d < *mp) *mp = d;
+        if (!(d > 0.0) || !std::isfinite(d)) return j;
+        const double r = std::sqrt(d), inv = 1.0 / r;
+        uj[j] = r;
+        for (int k = j + 1; k < n; ++k) uj[k] *= inv;
+        for (int i = j + 1; i < je; ++i) {
+            const double f = uj[i];
+            if (f != 0.0) axpy_neg(a + (size_t)i * n + i, uj + i, f, n - i);
+        }
+    }
+    return -1;
+}
+
+// rows i = i0, i0 + step, ... < n:  row_i[i:] -= sum_{k in [jb, je)} u[k][i] * u[k][i:]
+FSNAP_CLONES void chol_trailing_rows(double* a, int n, int jb, int je, int i0, int step) {
+    for (int i = i0; i < n; i += step) {
+        double* ri = a + (size_t)i * n;
+        int c = i;
+        for (; c + 32 <= n; c += 32) {
+            v8d y0 = *reinterpret_cast<const v8du*>(ri + c), y1 = *reinterpret_cast<const v8du*>(ri + c + 8);
+            v8d y2 = *reinterpret_cast<const v8du*>(ri + c + 16), y3 = *reinterpret_cast<const v8du*>(ri + c + 24);
+            for (int k = jb; k < je; ++k) {
+                const double* uk = a + (size_t)k * n;
+                const double f = uk[i];
+                const v8d fv = {f, f, f, f, f, f, f, f};
+                y0 -= fv * *reinterpret_cast<const v8du*>(uk + c);
+                y1 -= fv * *reinterpret_cast<const v8du*>(uk + c + 8);
+                y2 -= fv * *reinterpret_cast<const v8du*>(uk + c + 16);
+                y3 -= fv * *reinterpret_cast<const v8du*>(uk + c + 24);
+            }
+            *reinterpret_cast<v8du*>(ri + c) = y0;
+            *reinterpret_cast<v8du*>(ri + c + 8) = y1;
+            *reinterpret_cast<v8du*>(ri + c + 16) = y2;
+            *reinterpret_cast<v8du*>(ri + c + 24) = y3;
+        }
+        if (c < n) {
+            for (int k = jb; k < je; ++k) {
+                const double* uk = a + (size_t)k * n;
+                axpy_neg(ri + c, uk + c, uk[i], n - c);
+            }
+        }
+    }
+}
+
+int chol_upper_blocked(double* a, int n, double* min_piv2) {
+    double mp = std::numeric_limits<double>::infinity();
+    unsigned hw = std::thread::hardware_concurrency();
+    const int tmax = (int)(hw > 16 ? 16 : (hw < 1 ? 1 : hw));
+    for (int jb = 0; jb < n; jb += NBK) {
+        const int je = (jb + NBK < n) ? jb + NBK : n;
+        const int fail = chol_panel(a, n, jb, je, &mp);
+        if (fail >= 0) {
+            if (min_piv2) *min_piv2 = mp;
+            return fail;
+        }
+        const int rows = n - je;
+        int nt = rows / 256;                    // >= 256 trailing rows per thread (thread start-up ~50-100 us)
+        if (nt > tmax) nt = tmax;
+        if (nt <= 1) {
+            chol_trailing_rows(a, n, jb, je, je, 1);
+        } else {
+            std::vector<std::thread> th;
+            th.reserve(nt - 1);
+            for (int t = 1; t < nt; ++t) th.emplace_back(chol_trailing_rows, a, n, jb, je, je + t, nt);
+            chol_trailing_rows(a, n, jb, je, je, nt);
+            for (auto& x : th) x.join();
         }
     }
     if (min_piv2) *min_piv2 = mp;
@@ -283,7 +369,7 @@ int scaled_chol_solve(const vec& M, const vec& rhs, int n, vec& x, double* min_p
         for (int j = 0; j < n; ++j) S[(size_t)i * n + j] = M[(size_t)i * n + j] * d[i] * d[j];
     static thread_local vec L;
     L = S;
-    const int fail = chol_upper(L.data(), n, min_piv2);
+    const int fail = (n >= 192) ? chol_upper_blocked(L.data(), n, min_piv2) : chol_upper(L.data(), n, min_piv2);
     if (fail >= 0) return fail;
     for (int i = 0; i < n; ++i) y[i] = rhs[i] * d[i];
     vec z(y);
@@ -359,7 +445,8 @@ extern "C" int fsnap_solve(int kind, double param, int64_t K64, const double* G,
                 ui[i] = (gi[i] + alpha) * di * di;
             }
             double mp2 = 0.0;
-            if (chk == 0.0 && chol_upper(U.data(), K, &mp2) < 0 && mp2 > 1.0e-3) {
+            if (chk == 0.0 && (K >= 192 ? chol_upper_blocked(U.data(), K, &mp2) : chol_upper(U.data(), K, &mp2)) < 0 &&
+                mp2 > 1.0e-3) {
                 for (int i = 0; i < K; ++i) z[i] = c[i] * dsc[i];
                 chol_solve(U.data(), K, z.data());
                 for (int i = 0; i < K; ++i) beta[i] = z[i] * dsc[i];
