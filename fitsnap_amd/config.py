@@ -161,6 +161,7 @@ class Config:
             name="SOLVER", solver=solver,
             compute_testerrs=_get(sol, "compute_testerrs", "0", "bool"),
             detailed_errors=_get(sol, "detailed_errors", "0", "bool"),
+            nsam=_get(sol, "nsam", "0", "int"), cov_nugget=_get(sol, "cov_nugget", "0.0", "float"),
             true_multinode=1 if solver == "ScaLAPACK" else 0)
 
         def not_used(section):

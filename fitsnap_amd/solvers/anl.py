@@ -1,0 +1,46 @@
+"""ANL (analytical Bayesian linear fit) behind the reference's plugin API
+(fitsnap3lib/solvers/anl.py:7-68): posterior mean ``pinv(aw.T aw + nugget I) aw.T bw`` and
+covariance ``sigma_hat * pinv(...)`` — another consumer of the same GPU statistics (G, c)
+plus one streamed residual pass (``fsnap_predict``'s weighted SSE).  The K x K pseudo-inverse
+is host algebra, as in the reference."""
+from __future__ import annotations
+
+import numpy as np
+
+from .solver import Solver
+
+
+class ANL(Solver):
+
+    def __init__(self, name, pt, config):
+        super().__init__(name, pt, config)
+        self.save_files = True      # the reference writes covariance.npy / mean.npy into the cwd (anl.py:60-61)
+
+    def perform_fit(self, a=None, b=None, w=None, trainall=False):
+        pt, config = self.pt, self.config
+        if config.sections["EXTRAS"].apply_transpose:
+            raise NotImplementedError("ANL with EXTRAS.apply_transpose is not supported by the HIP path")
+        G, c, s = self._fit_statistics(a, b, w, None, trainall)
+        nbas = len(c)
+        npt = float(s[2])
+        cov_nugget = config.sections["SOLVER"].cov_nugget
+        invptp = np.linalg.pinv(G + cov_nugget * np.diag(np.ones((nbas,))))       # anl.py:39
+        invptp = invptp * 0.5 + invptp.T * 0.5                                     # anl.py:40
+        fit = np.dot(invptp, c)
+        # res = bw - aw @ fit; bp = res.res / 2  (anl.py:46-47): exact streamed residual on the GPU
+        ctx = pt.hip()
+        _, sse = ctx.predict(fit, want_preds=False, want_sse=True)
+        sse = pt.allreduce_scalar(sse) if not (pt.stubs or pt._size == 1) else sse
+        bp = sse / 2.0
+        ap = (npt - nbas) / 2.0
+        sigmahat = bp / (ap - 1.0)
+        if pt._rank != 0:
+            return
+        self.fit = fit
+        self.cov = sigmahat * invptp                                                # anl.py:53
+        if self.save_files:
+            np.save("covariance.npy", self.cov)
+            np.save("mean.npy", self.fit)
+        nsam = config.sections["SOLVER"].nsam
+        if nsam:
+            self.fit_sam = np.random.multivariate_normal(self.fit, self.cov, size=(nsam,))   # anl.py:63-65

@@ -3,6 +3,7 @@
 class name equals ``[SOLVER] solver`` case-insensitively; created with ``Solver.__new__``
 then ``__init__(name, pt, config)``; unknown name -> IndexError."""
 from .solver import Solver
+from .anl import ANL  # noqa: F401
 from .ard import ARD  # noqa: F401  (import = registration, as in the reference)
 from .ridge import RIDGE  # noqa: F401
 from .svd import SVD  # noqa: F401

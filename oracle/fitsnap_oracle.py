@@ -224,3 +224,16 @@ def synth_problem(m, K, row_offset=0):
 
 def synth_testing_mask(m, frac=0.1):
     return np.random.default_rng(2).random(m) < frac
+
+
+def anl_fit(a, b, w, testing=None, cov_nugget=0.0):
+    """fitsnap3lib/solvers/anl.py:39-53: posterior mean and covariance of the Bayesian linear fit."""
+    aw, bw = weight_rows(a, b, w, testing)
+    npt, nbas = aw.shape
+    invptp = np.linalg.pinv(np.dot(aw.T, aw) + cov_nugget * np.diag(np.ones((nbas,))))
+    invptp = invptp * 0.5 + invptp.T * 0.5
+    fit = np.dot(invptp, np.dot(aw.T, bw))
+    res = bw - np.dot(aw, fit)
+    bp = np.dot(res, res) / 2.0
+    ap = (npt - nbas) / 2.0
+    return fit, (bp / (ap - 1.0)) * invptp

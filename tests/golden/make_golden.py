@@ -129,6 +129,22 @@ def main():
         out[f"ridge_local_{tag}_mask"] = run("RIDGE", {"RIDGE": {"alpha": alpha, "local_solver": 1}}, use_mask=True)
     out["ridge_sklearn_1e-8_transpose_all"] = run("RIDGE", {"RIDGE": {"alpha": 1.0e-8, "local_solver": 0},
                                                              "EXTRAS": {"apply_transpose": 1}})
+    # ANL (anl.py): posterior mean + covariance; the class writes covariance.npy / mean.npy into the cwd
+    import tempfile
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        os.chdir(td)
+        try:
+            pt = ParallelTools()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                cfg = Config(pt, settings("ANL", {"SOLVER": {"nsam": 0, "cov_nugget": 1.0e-10}}), arguments_lst=["--overwrite"])
+            sanl = solver_factory.solver("ANL", pt, cfg)
+            sanl.perform_fit(A, b, w, trainall=True)
+            out["anl_fit"] = np.asarray(sanl.fit).copy()
+            out["anl_cov"] = np.asarray(sanl.cov).copy()
+        finally:
+            os.chdir(cwd)
     out["snapcoeff"] = parse_snapcoeff(os.path.join(TA, "Ta_pot.snapcoeff"))
     met = parse_metrics_all(os.path.join(TA, "Ta_metrics.md"))
     # order: (Unweighted|Weighted) x (Energy|Force|Stress) -> ncount, mae, rmse, rsq

@@ -478,3 +478,19 @@ def test_collective_path_on_one_gpu(ta, ta_fits):
         pt.free()
     finally:
         dist.destroy_process_group()
+
+
+def test_anl_solver_matches_reference(ta, ta_fits, tmp_path, monkeypatch):
+    # fitsnap3lib/solvers/anl.py: posterior mean and covariance from the same GPU statistics.
+    # The reference inverts the UNSCALED normal matrix with pinv (cond ~7e10): its own answer moves by
+    # ~4e-8 under a 1e-16 perturbation of G, so 1e-6 is the meaningful bar here too.
+    A, b, w = ta
+    monkeypatch.chdir(tmp_path)          # the class writes covariance.npy / mean.npy like the reference
+    pt, s = make_solver("ANL", {"SOLVER": {"solver": "ANL", "nsam": 0, "cov_nugget": 1.0e-10}})
+    s.perform_fit(A, b, w, trainall=True)
+    check_fit(s.fit, ta_fits["anl_fit"])
+    ref = ta_fits["anl_cov"]
+    dscale = np.sqrt(np.abs(np.diag(ref)))
+    assert np.max(np.abs(s.cov - ref) / (dscale[:, None] * dscale[None, :])) < 1e-5
+    assert (tmp_path / "covariance.npy").exists() and (tmp_path / "mean.npy").exists()
+    pt.free()

@@ -95,3 +95,9 @@ def test_synthetic_generator_is_deterministic():
     A2, b2, w2 = orc.synth_problem(1000, 16)
     assert np.array_equal(A1, A2) and np.array_equal(b1, b2) and np.array_equal(w1, w2)
     assert set(np.unique(w1)) <= {100.0, 1.0, 1e-8}
+
+
+def test_anl_matches_reference_class(ta, ta_fits):
+    A, b, w = ta
+    fit, cov = orc.anl_fit(A, b, w, cov_nugget=1.0e-10)
+    assert np.array_equal(fit, ta_fits["anl_fit"]) and np.array_equal(cov, ta_fits["anl_cov"])
