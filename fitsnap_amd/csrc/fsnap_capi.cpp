@@ -116,9 +116,9 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
     const int64_t off_limit = (int64_t)0xFFF00000;  // 32-bit buffer offsets, 1 MiB of slack for prefetch overshoot
     if (g->NB >= 6 && ctx->opt_kernel != 1) {
         // kernel 1L: rows shared through LDS, whole triangle per workgroup
-        const int nw = 8;
+        const int nw = (ctx->opt_kernel == 4 && g->NB == 8) ? 16 : 8;
         const int64_t nchunks = (m + 3) / 4;
-        int64_t nblocks = ctx->opt_nblocks > 0 ? ctx->opt_nblocks : (int64_t)ctx->num_cu * 2;
+        int64_t nblocks = ctx->opt_nblocks > 0 ? ctx->opt_nblocks : (int64_t)ctx->num_cu * (nw == 16 ? 1 : 2);
         const int64_t max_blocks = (nchunks + 4 * nw - 1) / (4 * nw);   // >= 4 stages per workgroup
         if (nblocks > max_blocks) nblocks = max_blocks;
         if (nblocks < 1) nblocks = 1;
@@ -407,7 +407,7 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
     } else if (!strcmp(key, "nontemporal")) {
         ctx->opt_nt = value != 0;
     } else if (!strcmp(key, "kernel")) {
-        if (value < 0 || value > 3) return ctx->fail(FSNAP_E_ARG, "kernel must be 0 (auto), 1, 2 or 3");
+        if (value < 0 || value > 4) return ctx->fail(FSNAP_E_ARG, "kernel must be 0 (auto), 1, 2, 3 or 4");
         ctx->opt_kernel = (int)value;
     } else if (!strcmp(key, "ablate")) {
         ctx->opt_ablate = (int)value;

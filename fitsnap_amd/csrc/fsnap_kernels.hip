@@ -649,6 +649,18 @@ __device__ __forceinline__ void chunk_tiles(d4 (&acc)[NTM], const double* src, s
     (tile_mfma<tile_p_of<NB>(T0 + U), tile_q_of<NB>(T0 + U)>(acc[U], src), ...);
 }
 
+// split form for operand prefetch: LDS reads of one chunk, then (later) its MFMAs
+template <int NB, int T0, int NTM, int... U>
+__device__ __forceinline__ void chunk_load(double (&va)[NTM], double (&vb)[NTM], const double* src,
+                                           std::integer_sequence<int, U...>) {
+    ((va[U] = src[tile_p_of<NB>(T0 + U) * 64], vb[U] = src[tile_q_of<NB>(T0 + U) * 64]), ...);
+}
+template <int NTM, int... U>
+__device__ __forceinline__ void chunk_mfma(d4 (&acc)[NTM], const double (&va)[NTM], const double (&vb)[NTM],
+                                           std::integer_sequence<int, U...>) {
+    ((acc[U] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[U], vb[U], acc[U], 0, 0, 0)), ...);
+}
+
 template <int NB, int NW, int WV, bool FULLK, bool NT, int ABL>
 __device__ __forceinline__ void syrk_lds_static_body(double* lds, const WaveBufs& wb, int K, unsigned nstage,
                                                      double* __restrict__ pw, double* __restrict__ cw,
@@ -700,9 +712,25 @@ __device__ __forceinline__ void syrk_lds_static_body(double* lds, const WaveBufs
         for (unsigned s = 0; s < nstage; ++s) {
             const double* src = lds + ((ABL == 4) ? 0 : (s & 1)) * STAGE_DOUBLES + lane;
             if (HAS_TILES) {
+                if (ABL == 5) {
+                    // operand prefetch: the LDS reads of chunk c + 1 are issued BEFORE the MFMAs of chunk c
+                    // (double-buffered operand registers; sched_barriers pin the order), so that the matrix
+                    // pipe never waits on lgkmcnt inside a stage
+                    constexpr auto seq = std::make_integer_sequence<int, NTM>{};
+                    double oa[2][NTM], ob[2][NTM];
+                    chunk_load<NB, T0, NTM>(oa[0], ob[0], src, seq);
 #pragma unroll
-                for (int c = 0; c < NW; ++c)
-                    chunk_tiles<NB, T0, NTM>(acc, src + ((ABL == 4) ? 0 : c) * NB * 64, std::make_integer_sequence<int, NTM>{});
+                    for (int c = 0; c < NW; ++c) {
+                        if (c + 1 < NW) chunk_load<NB, T0, NTM>(oa[(c + 1) & 1], ob[(c + 1) & 1], src + (c + 1) * NB * 64, seq);
+                        __builtin_amdgcn_sched_barrier(0);
+                        chunk_mfma<NTM>(acc, oa[c & 1], ob[c & 1], seq);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NW; ++c)
+                        chunk_tiles<NB, T0, NTM>(acc, src + ((ABL == 4) ? 0 : c) * NB * 64, std::make_integer_sequence<int, NTM>{});
+                }
             }
             park((s + 1) & 1);
             if (ABL != 1) issue_chunk<NB, NT>(raw, wb, (s + 2) * NW + WV, kr);
@@ -1461,6 +1489,11 @@ static hipError_t launch_syrk_lds_static_nb(const SyrkArgs& a, hipStream_t st) {
 #define FSNAP_ABL(N)                                                                                               \
     hipLaunchKernelGGL((fsnap_syrk_lds_static<8, 8, true, true, N>), grid, block, 0, st, a.A, a.lda, a.b, a.w, a.mask, \
                        a.m, a.K, a.chunks_per_wave, a.part, a.cpart, a.spart)
+    if (NB == 8 && fullk && a.ablate == 5) {        // operand-prefetch variant (correct results; A/B)
+        hipLaunchKernelGGL((fsnap_syrk_lds_static<8, NW, true, true, 5>), grid, block, 0, st, a.A, a.lda, a.b, a.w, a.mask,
+                           a.m, a.K, a.chunks_per_wave, a.part, a.cpart, a.spart);
+        return hipGetLastError();
+    }
     if (NB == 8 && NW == 8 && fullk && a.ablate) {   // timing-only diagnostic variants (option "ablate")
         switch (a.ablate) {
             case 1: FSNAP_ABL(1); break;
@@ -1484,6 +1517,10 @@ static hipError_t launch_syrk_lds_static_nb(const SyrkArgs& a, hipStream_t st) {
 // (run-time tile table) variant kept for A/B; a.chunks_per_wave = chunks per workgroup
 hipError_t launch_syrk_lds(const SyrkArgs& a, hipStream_t st) {
     const int nb = syrk_num_blocks(a.K);
+    if (a.split == 16) {   // one 16-wave workgroup per CU (A/B variant, NB = 8 only)
+        if (nb != 8) return hipErrorInvalidValue;
+        return launch_syrk_lds_static_nb<8, 16>(a, st);
+    }
     if (a.split == 8) {
         switch (nb) {
             case 6: return launch_syrk_lds_static_nb<6, 8>(a, st);

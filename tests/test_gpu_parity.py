@@ -494,3 +494,19 @@ def test_anl_solver_matches_reference(ta, ta_fits, tmp_path, monkeypatch):
     assert np.max(np.abs(s.cov - ref) / (dscale[:, None] * dscale[None, :])) < 1e-5
     assert (tmp_path / "covariance.npy").exists() and (tmp_path / "mean.npy").exists()
     pt.free()
+
+
+@pytest.mark.parametrize("opts", [{"kernel": 4}, {"ablate": 5}, {"kernel": 4, "ablate": 5}])
+def test_lds_kernel_ab_variants_are_correct(ctx, opts):
+    # A/B variants of kernel 1L at K = 128: 16-wave workgroups, operand prefetch (ablate = 5 is the
+    # only `ablate` value that keeps results correct)
+    A, b, w = orc.synth_problem(70001, 128)
+    t = orc.synth_testing_mask(len(b))
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    try:
+        G, c, s = run_stats(ctx, A, b, w, t)
+    finally:
+        for k in opts:
+            ctx.set_option(k, 0)
+    stats_close(G, c, s, *orc.normal_eq(A, b, w, t))
