@@ -145,6 +145,22 @@ def main():
             out["anl_cov"] = np.asarray(sanl.cov).copy()
         finally:
             os.chdir(cwd)
+    # error_analysis (solver.py:137-435) with synthetic group labels: per (group, weighting, train/test,
+    # row type) ncount / mae / rmse / rsq — the rows the committed Ta_metrics.md cannot pin offline
+    row_type = np.array(["Energy"] * 363 + ["Force"] * 12672 + ["Stress"] * 2178)
+    groups = np.array(["g%d" % g for g in np.random.default_rng(7).integers(0, 5, m)])
+    pt = ParallelTools()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cfg = Config(pt, settings("SVD"), arguments_lst=["--overwrite"])
+    sea = solver_factory.solver("SVD", pt, cfg)
+    fsd = {"Groups": groups.tolist(), "Testing": testing.tolist(), "Row_Type": row_type.tolist()}
+    sea.perform_fit(A, b, w[~testing], fs_dict=fsd)
+    sea.error_analysis(A, b, w, fsd)
+    err = sea.errors
+    out["ea_index"] = np.array(["|".join(str(x) for x in ix) for ix in err.index])
+    out["ea_values"] = err[["ncount", "mae", "rmse", "rsq"]].to_numpy(dtype=np.float64)
+    out["ea_groups"] = groups
     out["snapcoeff"] = parse_snapcoeff(os.path.join(TA, "Ta_pot.snapcoeff"))
     met = parse_metrics_all(os.path.join(TA, "Ta_metrics.md"))
     # order: (Unweighted|Weighted) x (Energy|Force|Stress) -> ncount, mae, rmse, rsq

@@ -510,3 +510,26 @@ def test_lds_kernel_ab_variants_are_correct(ctx, opts):
         for k in opts:
             ctx.set_option(k, 0)
     stats_close(G, c, s, *orc.normal_eq(A, b, w, t))
+
+
+def test_error_analysis_per_group_rows_match_reference(ta, ta_fits):
+    # Solver.error_analysis (solver.py:137-435) with group labels: every (group, weighting, train/test,
+    # row type) row vs the reference's own DataFrame (goldens: tests/golden/make_golden.py)
+    A, b, w = ta
+    t = ta_fits["testing_mask"]
+    m = len(b)
+    row_type = ["Energy"] * 363 + ["Force"] * 12672 + ["Stress"] * 2178
+    fsd = {"Groups": [str(g) for g in ta_fits["ea_groups"]], "Testing": t.tolist(), "Row_Type": row_type}
+    pt, s = make_solver("SVD")
+    s.perform_fit(A, b, w[~t], fs_dict=fsd)
+    s.error_analysis(A, b, w, fsd)
+    err = s.errors
+    idx = ["|".join(str(x) for x in ix) for ix in err.index]
+    assert idx == [str(x) for x in ta_fits["ea_index"]]
+    ours = err[["ncount", "mae", "rmse", "rsq"]].to_numpy(dtype=np.float64)
+    ref = ta_fits["ea_values"]
+    assert np.array_equal(ours[:, 0], ref[:, 0])
+    # mae / rmse to 1e-6 relative (coefficients agree to ~1e-7); rsq absolute
+    assert np.max(np.abs(ours[:, 1:3] - ref[:, 1:3]) / np.abs(ref[:, 1:3])) < 1e-6
+    assert np.nanmax(np.abs(ours[:, 3] - ref[:, 3])) < 1e-6
+    pt.free()
