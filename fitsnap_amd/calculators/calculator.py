@@ -120,6 +120,9 @@ class Calculator:
         """calculator.py:311-326; also the end of the per-configuration loop: flush the staged
         LAMMPS blocks through the assembly kernel and download the host view."""
         self.flush_rows()
+        if self.pt.stubs != 1:
+            # the arrays stay rank-local (one process per GPU): keep the lists that describe them
+            self.pt.local_lists = {k: v.get_list() for k, v in self.pt.fitsnap_dict.items() if isinstance(v, DistributedList)}
         for key in self.pt.fitsnap_dict.keys():
             if isinstance(self.pt.fitsnap_dict[key], DistributedList):
                 self.pt.gather_fitsnap(key)

@@ -218,6 +218,7 @@ class ParallelTools:
         self._set_seed()
         self.shared_arrays = {}
         self.fitsnap_dict = {}
+        self.local_lists = {}    # multi-rank: this rank's row-metadata lists after gather_fitsnap
 
     # -- rank helpers (parallel_tools.py:245-336) ---------------------------------------
     def get_rank(self):

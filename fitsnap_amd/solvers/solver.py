@@ -79,6 +79,11 @@ class Solver:
             return ~np.asarray(fs_dict["Testing"], dtype=bool)
         if trainall:
             return np.ones(np.shape(a)[0], dtype=bool)
+        # after Calculator.collect_distributed_lists the dictionary holds the lists of ALL ranks; the
+        # rows of this rank's arrays are described by the local copy kept in pt.local_lists
+        local = getattr(self.pt, "local_lists", None)
+        if local and "Testing" in local:
+            return ~np.asarray(local["Testing"], dtype=bool)
         return ~np.asarray(self.pt.fitsnap_dict["Testing"], dtype=bool)
 
     def _resolve_inputs(self, a, b, w, fs_dict, trainall):
@@ -305,24 +310,57 @@ class Solver:
         from pandas import DataFrame, concat
 
         self.errors = []
-        if self.pt._rank != 0:
-            return
-        if a is None and b is None and w is None and fs_dict is None:
-            a = self.pt.shared_arrays["a"].array
-            b = self.pt.shared_arrays["b"].array
-            w = self.pt.shared_arrays["w"].array
-            fs_dict = self.pt.fitsnap_dict
-            preds = self.predict_rows() if self.fit is not None else None
+        pt = self.pt
+        multi = not (pt.stubs or pt._size == 1)
+        shared = a is None and b is None and w is None and fs_dict is None
+        if multi:
+            # One process per GPU: every rank owns the rows of ITS configurations.  The fit lives on
+            # rank 0 (reference semantics); broadcast it, predict the local rows on every GPU, gather
+            # (truth, prediction, weight, row labels) on rank 0, which builds the table.  The
+            # reference sees all rows on rank 0 through the node-shared array instead.
+            self.fit = pt.bcast_object(self.fit, src=0)
+            if shared:
+                a = pt.shared_arrays["a"].array
+                b = pt.shared_arrays["b"].array
+                w = pt.shared_arrays["w"].array
+                local = pt.local_lists if getattr(pt, "local_lists", None) else pt.fitsnap_dict
+            else:
+                local = fs_dict
+            preds = (self.predict_rows() if shared else self.predict_rows(a, b)) if self.fit is not None else None
+            n = len(b)
+            piece = {"truths": np.asarray(b), "preds": preds, "weights": np.asarray(w),
+                     "lists": {k: v for k, v in local.items() if isinstance(v, list) and len(v) == n}}
+            parts = [None] * pt._size
+            pt._dist.all_gather_object(parts, piece, group=pt._group)
+            if pt._rank != 0:
+                self.fit = None
+                return
+            self.df = DataFrame({"truths": np.concatenate([q["truths"] for q in parts]).tolist()})
+            if self.fit is not None:
+                self.df["preds"] = np.concatenate([q["preds"] for q in parts])
+            self.df["weights"] = np.concatenate([q["weights"] for q in parts]).tolist()
+            for key in parts[0]["lists"]:
+                if all(key in q["lists"] for q in parts):
+                    self.df[key] = [x for q in parts for x in q["lists"][key]]
         else:
-            preds = self.predict_rows(a, b) if self.fit is not None else None
-        self.df = DataFrame(a)
-        self.df["truths"] = np.asarray(b).tolist()
-        if preds is not None:
-            self.df["preds"] = preds
-        self.df["weights"] = np.asarray(w).tolist()
-        for key in fs_dict.keys():
-            if isinstance(fs_dict[key], list) and len(fs_dict[key]) == len(self.df.index):
-                self.df[key] = fs_dict[key]
+            if pt._rank != 0:
+                return
+            if shared:
+                a = pt.shared_arrays["a"].array
+                b = pt.shared_arrays["b"].array
+                w = pt.shared_arrays["w"].array
+                fs_dict = pt.fitsnap_dict
+                preds = self.predict_rows() if self.fit is not None else None
+            else:
+                preds = self.predict_rows(a, b) if self.fit is not None else None
+            self.df = DataFrame(a)
+            self.df["truths"] = np.asarray(b).tolist()
+            if preds is not None:
+                self.df["preds"] = preds
+            self.df["weights"] = np.asarray(w).tolist()
+            for key in fs_dict.keys():
+                if isinstance(fs_dict[key], list) and len(fs_dict[key]) == len(self.df.index):
+                    self.df[key] = fs_dict[key]
         if self.config.sections["EXTRAS"].dump_dataframe:
             self.df.to_pickle(self.config.sections["EXTRAS"].dataframe_file)
         if self.fit is not None and not self.config.sections["SOLVER"].true_multinode:

@@ -56,8 +56,19 @@ def _worker(rank, world, port, outdir):
         pt.fitsnap_dict["Testing"] = testing[mine].tolist()
         s.perform_fit()
         G, c, sc = s.last_statistics
-        np.savez(os.path.join(outdir, f"rank{rank}.npz"), fit=s.fit if s.fit is not None else np.zeros(0),
-                 G=G, c=c, sc=sc)
+        fit = s.fit.copy() if s.fit is not None else np.zeros(0)
+        # error analysis over rank-sharded rows: local predictions + gather on rank 0
+        s.predict_rows = lambda a_=None, b_=None: pt.shared_arrays["a"].array @ s.fit
+        rt = np.array(["Energy"] * 363 + ["Force"] * 12672 + ["Stress"] * 2178)
+        pt.fitsnap_dict["Row_Type"] = rt[mine].tolist()
+        pt.fitsnap_dict["Groups"] = (np.arange(m) // 43 % 3).astype(str)[mine].tolist()
+        s.error_analysis()
+        ea = np.zeros((0, 4))
+        if rank == 0:
+            ea = s.errors[["ncount", "mae", "rmse", "rsq"]].to_numpy(dtype=np.float64)
+            with open(os.path.join(outdir, "ea_index.txt"), "w") as f:
+                f.write("\n".join("|".join(str(x) for x in ix) for ix in s.errors.index))
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), fit=fit, G=G, c=c, sc=sc, ea=ea)
         pt.all_barrier()
     finally:
         dist.destroy_process_group()
@@ -81,3 +92,23 @@ def test_two_rank_row_sharded_fit_matches_single_process(tmp_path, ta, ta_fits):
     assert r0["sc"][2] == sc[2]
     ref = ta_fits["ridge_sklearn_1e-8_mask"]
     assert np.max(np.abs(r0["fit"] - ref) / np.abs(ref)) < 1e-6
+    # gathered error table == single-process table built with pandas directly
+    import pandas as pd
+    m = len(b)
+    df = pd.DataFrame({"truths": b, "preds": A @ r0["fit"], "weights": w, "Testing": t,
+                       "Row_Type": ["Energy"] * 363 + ["Force"] * 12672 + ["Stress"] * 2178,
+                       "Groups": (np.arange(m) // 43 % 3).astype(str)})
+    idx = open(tmp_path / "ea_index.txt").read().split("\n")
+    assert r1["ea"].shape == (0, 4) and len(idx) == r0["ea"].shape[0] == 2 * (2 * 3 + 3 * 2 * 3)
+    for key, row in zip(idx, r0["ea"]):
+        g, wt, tt, rt = key.split("|")
+        sel = (df["Testing"] == (tt == "Testing")) & (df["Row_Type"] == rt)
+        if g != "*ALL":
+            sel &= df["Groups"] == g
+        sub = df[sel]
+        res = sub["truths"] - sub["preds"]
+        if wt == "Unweighted":
+            assert row[0] == len(sub) and row[1] == pytest.approx(np.mean(np.abs(res)), rel=1e-12)
+        else:
+            assert row[0] == np.count_nonzero(sub["weights"])
+            assert row[1] == pytest.approx(np.mean(np.abs(sub["weights"] * res)), rel=1e-12)
