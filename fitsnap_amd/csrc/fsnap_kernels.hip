@@ -16,29 +16,31 @@
 // C-ABI layer substitutes an all-ones buffer when the caller passes no mask).  The allocation that holds A is padded by >= 256 B so that
 // the vector loads of the last row may over-read (they are select-zeroed).
 //
-// Kernel 1 (fsnap_syrk_wave): fused mask x weight x [A|b]^T [A|b].
-//   One wave owns a contiguous range of 4-row chunks and the WHOLE upper block
-//   triangle of G in registers: NB = ceil(K/16) column blocks, NB(NB+1)/2 MFMA tiles
-//   of 16x16 fp64 (4 doubles = 8 VGPRs per lane per tile; 36 tiles = 288 registers at
-//   K = 128, which fits the unified 512-entry VGPR/AGPR file at one wave per SIMD).
-//   v_mfma_f64_16x16x4_f64 takes A[i = lane&15][k = lane>>4] and B[k = lane>>4][j =
-//   lane&15]: with k = row-in-chunk and i/j = column-in-block, the SAME register
-//   (w * a[row][col]) is the A operand of tile (p, .) and the B operand of tile (., p),
-//   so a chunk costs NB/2 coalesced 16-byte loads per lane, NB multiplies, and
-//   NB(NB+1)/2 MFMAs: no LDS staging, no transposes, A is read from HBM exactly once.
-//   16-byte loads give each lane two ADJACENT columns; they are assigned to two
-//   different column blocks (even / odd columns of a 32-column group).  The resulting
-//   column permutation is undone for free by the reduce kernel's scatter.
-//   c = (wA)^T (wb), b^T W^2 b, sum(wb) and the training-row count ride along on the
-//   VALU (NB + 3 fp64 FMAs per chunk).
-// Kernel 2 (fsnap_reduce_partials): deterministic fixed-order sum of the per-wave
-//   partial triangles, un-permutes columns, mirrors to the lower triangle and writes
-//   the packed statistics buffer [G (K*K) | c (K) | bTb, sum_bw, n_train].
-//   No floating-point atomics anywhere: results are run-to-run bit-identical for a
-//   given (m, K, grid).
-// Kernel 3 (fsnap_weight_rows): stand-alone wavefront row-weighting (HBM-bound),
-//   for callers that need aw / bw materialised.
-// Kernel 4 (fsnap_gemv_rows): preds = A @ beta (+ optional weighted SSE), HBM-bound.
+// Kernels (details at each definition):
+//   1   fsnap_syrk_wave        fused mask x weight x [A|b]^T [A|b], one wave = whole block
+//                              triangle in registers, no LDS (K <= 80; SPLIT = 2 variant for A/B)
+//   1L  fsnap_syrk_lds_static  same statistics for 80 < K <= 128 (the BASELINE shape): rows
+//                              read ONCE per workgroup, weighted once, shared through LDS in
+//                              MFMA-fragment order; per-wave specialised bodies (default).
+//       fsnap_syrk_lds         generic tile-table variant of 1L (A/B)
+//   1T  fsnap_syrk_tiled       general K > 128: 64-column superblock pairs x row splits
+//   2   fsnap_reduce_partials / fsnap_reduce_tiled   deterministic fixed-order reduction of the
+//                              per-workgroup partial triangles -> packed [G | c | scalars];
+//                              un-permutes the even/odd column interleave, mirrors the triangle
+//   3   fsnap_weight_rows_k    stand-alone wavefront row weighting (HBM-bound)
+//   4   fsnap_gemv_rows_k      preds = A @ beta (+ weighted SSE), HBM-bound
+//   5   fsnap_assemble_k       post-LAMMPS assembly (_collect_lammps transform) into HBM rows
+//   6   fsnap_chol_solve_k     K x K Cholesky solve on one workgroup (optional; host is faster)
+//
+// Common operand trick of kernels 1 / 1L / 1T: v_mfma_f64_16x16x4_f64 takes
+// A[i = lane&15][k = lane>>4] and B[k = lane>>4][j = lane&15]; with k = row inside a 4-row
+// chunk and i/j = column inside a 16-column block, the SAME register (w * a[row][col]) is
+// the A operand of tile (p, .) and the B operand of tile (., p): no transposes, A is read
+// from HBM once.  16-byte loads give a lane two ADJACENT columns; they go to two different
+// column blocks (even / odd columns of a 32-column group) and the column permutation is
+// undone for free by the reduction kernel's scatter.  c = (wA)^T (wb), b^T W^2 b, sum(wb)
+// and the training-row count ride along on the VALU.  No floating-point atomics anywhere:
+// results are run-to-run bit-identical for a given (m, K, grid).
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>

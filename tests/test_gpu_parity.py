@@ -533,3 +533,32 @@ def test_error_analysis_per_group_rows_match_reference(ta, ta_fits):
     assert np.max(np.abs(ours[:, 1:3] - ref[:, 1:3]) / np.abs(ref[:, 1:3])) < 1e-6
     assert np.nanmax(np.abs(ours[:, 3] - ref[:, 3])) < 1e-6
     pt.free()
+
+
+def test_randomised_shapes_masks_and_extreme_values(ctx):
+    # 40 random problems: ragged m, every K class, heavy masking, weights spanning 40 decades,
+    # denormal / huge descriptor magnitudes, negative zero, lda > K
+    rng = np.random.default_rng(20250926)
+    for it in range(40):
+        K = int(rng.choice([1, 3, 16, 30, 31, 55, 80, 81, 96, 110, 127, 128, 129, 200]))
+        m = int(rng.integers(1, 6000))
+        scale = 10.0 ** rng.uniform(-150, 100, size=K) if it % 4 == 0 else 10.0 ** rng.uniform(-3, 3, size=K)
+        big = rng.standard_normal((m, K + int(rng.integers(0, 9)))) if it % 3 == 0 else None
+        A = (big[:, :K] if big is not None else rng.standard_normal((m, K))) * scale
+        if it % 5 == 0:
+            A[rng.random((m, K)) < 0.3] = -0.0
+        b = rng.standard_normal(m) * 10.0 ** rng.uniform(-5, 5)
+        w = 10.0 ** rng.uniform(-20, 20, size=m) if it % 2 else rng.choice([0.0, 1.0, 467.0, 1e-9], size=m)
+        t = rng.random(m) < rng.choice([0.0, 0.1, 0.9, 1.0])
+        G, c, s = run_stats(ctx, A, b, w, t)
+        with np.errstate(over="ignore", invalid="ignore"):
+            Gr, cr, sr = orc.normal_eq(A, b, w, t)
+        fin = np.isfinite(Gr).all() and np.isfinite(cr).all() and np.isfinite(sr).all()
+        if not fin:          # overflow to inf in both implementations
+            assert not (np.isfinite(G).all() and np.isfinite(c).all() and np.isfinite(s).all())
+            continue
+        d = np.sqrt(np.maximum(np.diag(Gr), 1e-300))
+        ok = d > 1e-150      # products below the denormal range flush differently in different summation orders
+        if ok.any():
+            assert np.max(np.abs(G - Gr)[np.ix_(ok, ok)] / (d[ok][:, None] * d[ok][None, :])) < 1e-11, (it, m, K)
+        assert s[2] == sr[2], (it, m, K)
