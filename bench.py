@@ -179,6 +179,25 @@ def main():
     else:
         syrk_avg_ms = float(np.mean(syrk_ms))
 
+    # stand-alone row-weighting kernel (north_star: achieved HBM GB/s), measured outside the timed region
+    wk = None
+    if rank == 0 and world == 1:
+        try:
+            d_aw = torch.empty((m, Kc), dtype=torch.float64, device=dev)
+            d_bw = torch.empty(m, dtype=torch.float64, device=dev)
+            wms = []
+            for i in range(6):
+                ctx.weight_rows_device(d_aw.data_ptr(), Kc, d_bw.data_ptr())
+                wms.append(ctx.timing()["weight_ms"])
+            wms = float(np.mean(wms[1:]))
+            wbytes = (16 * Kc + 24) * m                      # read A, b, w; write aw, bw
+            wk = {"kernel": "fsnap_weight_rows_k", "bound": "hbm", "ms": wms, "achieved": wbytes / (wms * 1e-3) / 1e9,
+                  "peak": 8000.0, "unit": "GB/s", "frac": wbytes / (wms * 1e-3) / 1e9 / 8000.0,
+                  "algorithmic_bytes_per_launch": wbytes}
+            del d_aw, d_bw
+        except Exception as e:  # pragma: no cover
+            wk = {"error": str(e)}
+
     if rank == 0:
         total_rows = world * m
         flops_per_launch = (Kc * Kc + 3 * Kc) * m          # K^2 + 3K flop/row x rows per launch
@@ -220,6 +239,7 @@ def main():
             "step_host_launch_ms_avg": brk["launch"] / args.steps * 1e3,
             "step_wait_gpu_ms_avg": brk["sync"] / args.steps * 1e3,
             "step_host_solve_ms_avg": brk["solve"] / args.steps * 1e3,
+            "weighting_kernel": wk,
             "h2d_upload_ms": upload_ms,
             "h2d_inclusive_rows_per_s": m / ((upload_ms + elapsed / args.steps * 1e3) * 1e-3),
         }

@@ -111,7 +111,8 @@ FSNAP_CLONES int chol_upper(double* a, int n, double* min_piv2) {
 
 // ---- blocked variant for large n --------------------------------------------------------
 // (the unblocked sweep streams the whole trailing matrix from L2/L3 once per column: 10 GB
-// at n = 1595; at n = 128 a 16-row panel is ~25 % faster).  Panels of NBK pivot rows are factorised with the unblocked recurrence
+// at n = 1595: measured 92 ms unblocked vs 22 ms blocked + threads on the MI355X host; below
+// n ~ 768 the unblocked sweep is faster, 1.8 vs 4.0 ms at n = 480).  Panels of NBK pivot rows are factorised with the unblocked recurrence
 // restricted to the panel's rows; every trailing row then receives the NBK rank-1 updates in
 // ONE pass, 32-column register chunks at a time; trailing rows are independent, so they are
 // dealt round-robin to a few host threads when the trailing matrix is large.
@@ -368,7 +369,7 @@ int scaled_chol_solve(const vec& M, const vec& rhs, int n, vec& x, double* min_p
         for (int j = 0; j < n; ++j) S[(size_t)i * n + j] = M[(size_t)i * n + j] * d[i] * d[j];
     static thread_local vec L;
     L = S;
-    const int fail = (n >= 48) ? chol_upper_blocked(L.data(), n, min_piv2, n >= 192 ? 64 : 16) : chol_upper(L.data(), n, min_piv2);
+    const int fail = (n >= 768) ? chol_upper_blocked(L.data(), n, min_piv2, 64) : chol_upper(L.data(), n, min_piv2);
     if (fail >= 0) return fail;
     for (int i = 0; i < n; ++i) y[i] = rhs[i] * d[i];
     vec z(y);
@@ -444,7 +445,7 @@ extern "C" int fsnap_solve(int kind, double param, int64_t K64, const double* G,
                 ui[i] = (gi[i] + alpha) * di * di;
             }
             double mp2 = 0.0;
-            if (chk == 0.0 && (K >= 48 ? chol_upper_blocked(U.data(), K, &mp2, K >= 192 ? 64 : 16) : chol_upper(U.data(), K, &mp2)) < 0 &&
+            if (chk == 0.0 && (K >= 768 ? chol_upper_blocked(U.data(), K, &mp2, 64) : chol_upper(U.data(), K, &mp2)) < 0 &&
                 mp2 > 1.0e-3) {
                 for (int i = 0; i < K; ++i) z[i] = c[i] * dsc[i];
                 chol_solve(U.data(), K, z.data());
