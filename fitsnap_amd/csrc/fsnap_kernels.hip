@@ -1134,27 +1134,50 @@ __global__ __launch_bounds__(256) void fsnap_weight_rows_k(const double* __restr
                                                            const unsigned char* __restrict__ mask, int64_t m,
                                                            int K, double* __restrict__ aw, int64_t ldaw,
                                                            double* __restrict__ bw) {
+    // One wave handles 4 consecutive rows per iteration (4 independent 16-byte loads per lane in
+    // flight before the first store: memory-level parallelism for the HBM stream).
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwave = (int64_t)gridDim.x * 4;
     const bool vec2 = ((K & 1) == 0) && ((lda & 1) == 0) && ((ldaw & 1) == 0);
-    for (int64_t row = wave; row < m; row += nwave) {
-        const bool keep = mask ? (mask[row] != 0) : true;
-        const double wv = w[row];
-        const double* src = A + row * lda;
-        double* dst = aw + row * ldaw;
+    for (int64_t row0 = wave * 4; row0 < m; row0 += nwave * 4) {
+        double wv[4];
+        bool keep[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + r;
+            const bool in = row < m;
+            keep[r] = in && (mask[in ? row : 0] != 0);
+            wv[r] = in ? w[row] : 0.0;
+        }
         if (vec2) {
             for (int c = 2 * lane; c < K; c += 128) {
-                d2u x = *reinterpret_cast<const d2u*>(src + c);
-                d2u y;
-                y[0] = keep ? wv * x[0] : 0.0;
-                y[1] = keep ? wv * x[1] : 0.0;
-                *reinterpret_cast<d2u*>(dst + c) = y;
+                d2u x[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row0 + r < m) x[r] = __builtin_nontemporal_load(reinterpret_cast<const d2u*>(A + (row0 + r) * lda + c));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (row0 + r < m) {
+                        d2u y;
+                        y[0] = keep[r] ? wv[r] * x[r][0] : 0.0;
+                        y[1] = keep[r] ? wv[r] * x[r][1] : 0.0;
+                        __builtin_nontemporal_store(y, reinterpret_cast<d2u*>(aw + (row0 + r) * ldaw + c));
+                    }
+                }
             }
         } else {
-            for (int c = lane; c < K; c += 64) dst[c] = keep ? wv * src[c] : 0.0;
+            for (int c = lane; c < K; c += 64) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row0 + r < m) aw[(row0 + r) * ldaw + c] = keep[r] ? wv[r] * A[(row0 + r) * lda + c] : 0.0;
+            }
         }
-        if (lane == 0) bw[row] = keep ? wv * b[row] : 0.0;
+        if (lane < 4 && row0 + lane < m) {
+            const int64_t row = row0 + lane;
+            const bool kp = mask[row] != 0;
+            bw[row] = kp ? w[row] * b[row] : 0.0;
+        }
     }
 }
 
@@ -1592,7 +1615,7 @@ hipError_t launch_reduce_tiled(const TiledArgs& a, double* out, hipStream_t st) 
 hipError_t launch_weight_rows(const double* A, int64_t lda, const double* b, const double* w,
                               const unsigned char* mask, int64_t m, int K, double* aw, int64_t ldaw,
                               double* bw, hipStream_t st) {
-    int64_t nb = (m + 3) / 4;
+    int64_t nb = (m + 15) / 16;
     if (nb > 256 * 8) nb = 256 * 8;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(fsnap_weight_rows_k, dim3((unsigned)nb), dim3(256), 0, st, A, lda, b, w, mask, m, K, aw,
