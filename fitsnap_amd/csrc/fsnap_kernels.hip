@@ -1206,7 +1206,17 @@ __global__ __launch_bounds__(256) void fsnap_gemv_rows_k(const double* __restric
         double s = 0.0;
         if (row < m) {
             const double* src = A + row * lda;
-            for (int c = e; c < K; c += 16) s = __builtin_fma(src[c], sbeta[c], s);
+            if (((K | lda) & 1) == 0) {   // 16-byte loads: two adjacent columns per lane, two accumulators
+                double s1 = 0.0;
+                for (int c = 2 * e; c < K; c += 32) {
+                    const d2u x = __builtin_nontemporal_load(reinterpret_cast<const d2u*>(src + c));
+                    s = __builtin_fma(x[0], sbeta[c], s);
+                    s1 = __builtin_fma(x[1], sbeta[c + 1], s1);
+                }
+                s += s1;
+            } else {
+                for (int c = e; c < K; c += 16) s = __builtin_fma(src[c], sbeta[c], s);
+            }
         }
         // reduce over the 16 lanes of the row group
         s += __shfl_xor(s, 8, 64);
