@@ -51,6 +51,7 @@ SIGNATURES = {
     "fsnap_weight_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "fsnap_weight_rows_device": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "fsnap_predict": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fsnap_residual_rhs": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double)]),
     "fsnap_solve": (c_int, [c_int, c_double, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int), POINTER(c_double)]),
     "fsnap_solve_device": (c_int, [c_void_p, c_int, c_double, c_int64, c_void_p, c_void_p, POINTER(c_int), POINTER(c_double)]),
     "fsnap_timing": (c_int, [c_void_p, _P_D, c_int]),
@@ -290,6 +291,16 @@ class HipContext:
         sse = c_double(0.0)
         self._check(self._lib.fsnap_predict(self._h, _ptr(beta), _ptr(preds), byref(sse) if want_sse else None))
         return preds, (sse.value if want_sse else None)
+
+    def residual_rhs(self, beta, want_sse=False):
+        """s = (wA)^T (wb - wA beta) on the resident rows (refinement right-hand side)."""
+        beta = _f64(beta, "beta")
+        if beta.shape != (self.K,):
+            raise ValueError(f"beta has shape {beta.shape}, expected ({self.K},)")
+        s = np.empty(self.K)
+        sse = c_double(0.0)
+        self._check(self._lib.fsnap_residual_rhs(self._h, _ptr(beta), _ptr(s), byref(sse) if want_sse else None))
+        return s, (sse.value if want_sse else None)
 
     def solve_device(self, kind: int, param: float, K: int, d_packed_ptr: int):
         """K x K solve from the packed statistics in HBM; returns (beta, rank, rcond_estimate)."""

@@ -64,6 +64,7 @@ struct fsnap_ctx {
     DevBuf part, cpart, spart, packed, beta, preds, sse, aw, bw;
     DevBuf st_raw, st_plan, st_frac, st_blank;   // staging of fsnap_assemble
     DevBuf dsolve;                                // [beta | min pivot | status] of fsnap_solve_device
+    DevBuf du, dspart, dsvec;                     // refinement: row weights u, per-workgroup partials, s
     double* pinned = nullptr;                     // page-locked host staging of the packed statistics
     size_t pinned_bytes = 0;
     // options
@@ -375,7 +376,8 @@ int fsnap_ctx_destroy(fsnap_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->ownA, &ctx->ownb, &ctx->ownw, &ctx->ownmask, &ctx->ones, &ctx->part, &ctx->cpart,
                       &ctx->spart, &ctx->packed, &ctx->beta, &ctx->preds, &ctx->sse, &ctx->aw, &ctx->bw,
-                      &ctx->st_raw, &ctx->st_plan, &ctx->st_frac, &ctx->st_blank, &ctx->dsolve};
+                      &ctx->st_raw, &ctx->st_plan, &ctx->st_frac, &ctx->st_blank, &ctx->dsolve,
+                      &ctx->du, &ctx->dspart, &ctx->dsvec};
     for (DevBuf* b : bufs) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto& ev : ctx->ev)
@@ -701,7 +703,7 @@ int fsnap_predict(fsnap_ctx* ctx, const double* beta, double* preds, double* sse
     FSNAP_HIP(hipEventRecord(ctx->ev[7], ctx->stream), "hipEventRecord");
     FSNAP_HIP(fsnap::launch_gemv_rows(ctx->dA, ctx->lda, (const double*)ctx->beta.p, ctx->m, (int)ctx->K,
                                       preds ? (double*)ctx->preds.p : nullptr, ctx->db, ctx->dw, mask,
-                                      sse ? (double*)ctx->sse.p : nullptr, ctx->stream),
+                                      sse ? (double*)ctx->sse.p : nullptr, nullptr, ctx->stream),
               "launch fsnap_gemv_rows_k");
     FSNAP_HIP(hipEventRecord(ctx->ev[8], ctx->stream), "hipEventRecord");
     ctx->t_predict = true;
@@ -764,6 +766,45 @@ int fsnap_solve_device(fsnap_ctx* ctx, int kind, double param, int64_t K, const 
     const int rc = fsnap_solve(kind, param, K, G, G + K * K, beta, rank, rcond_est);
     if (rc) ctx->fail(rc, "fsnap_solve: numerical status %d", rc);
     return rc;
+}
+
+int fsnap_residual_rhs(fsnap_ctx* ctx, const double* beta, double* s, double* sse) {
+    if (!ctx) return FSNAP_E_ARG;
+    int rc;
+    if ((rc = check_rows(ctx)) || (rc = check_weights(ctx))) return rc;
+    if (!beta || !s) return ctx->fail(FSNAP_E_ARG, "fsnap_residual_rhs: NULL argument");
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    const size_t m = (size_t)ctx->m, K = (size_t)ctx->K;
+    const int nb = fsnap::gemv_num_blocks(ctx->m), nbt = fsnap::gemvT_num_blocks(ctx->m);
+    if (!ctx->beta.ensure(K * 8) || !ctx->du.ensure(m * 8) || !ctx->dspart.ensure((size_t)nbt * K * 8) ||
+        !ctx->dsvec.ensure(K * 8) || (sse && !ctx->sse.ensure((size_t)nb * 8)))
+        return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(refinement) failed");
+    const unsigned char* mask = ctx->dmask;
+    if (!mask) {
+        if ((rc = ensure_ones(ctx))) return rc;
+        mask = (const unsigned char*)ctx->ones.p;
+    }
+    FSNAP_HIP(hipMemcpyAsync(ctx->beta.p, beta, K * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(beta)");
+    FSNAP_HIP(fsnap::launch_gemv_rows(ctx->dA, ctx->lda, (const double*)ctx->beta.p, ctx->m, (int)ctx->K, nullptr, ctx->db,
+                                      ctx->dw, mask, sse ? (double*)ctx->sse.p : nullptr, (double*)ctx->du.p, ctx->stream),
+              "launch fsnap_gemv_rows_k");
+    FSNAP_HIP(fsnap::launch_gemvT_rows(ctx->dA, ctx->lda, (const double*)ctx->du.p, ctx->m, (int)ctx->K,
+                                       (double*)ctx->dspart.p, (double*)ctx->dsvec.p, ctx->stream),
+              "launch fsnap_gemvT_rows_k");
+    FSNAP_HIP(hipMemcpyAsync(s, ctx->dsvec.p, K * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(s)");
+    if (sse) {
+        std::string tmp;
+        tmp.resize((size_t)nb * 8);
+        FSNAP_HIP(hipMemcpyAsync(&tmp[0], ctx->sse.p, (size_t)nb * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(sse)");
+        FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+        const double* ps = (const double*)tmp.data();
+        long double acc = 0.0L;
+        for (int i = 0; i < nb; ++i) acc += ps[i];
+        *sse = (double)acc;
+    } else {
+        FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    }
+    return FSNAP_OK;
 }
 
 int fsnap_timing(fsnap_ctx* ctx, double* ms, int n) {

@@ -63,6 +63,9 @@ hipError_t launch_chol_solve(const double* packed, int K, double alpha, double* 
 int gemv_num_blocks(int64_t m);
 hipError_t launch_gemv_rows(const double* A, int64_t lda, const double* beta, int64_t m, int K, double* preds,
                             const double* b, const double* w, const unsigned char* mask, double* sse_part,
-                            hipStream_t st);
+                            double* uout, hipStream_t st);
+int gemvT_num_blocks(int64_t m);
+hipError_t launch_gemvT_rows(const double* A, int64_t lda, const double* u, int64_t m, int K, double* partial,
+                             double* out, hipStream_t st);
 
 }  // namespace fsnap

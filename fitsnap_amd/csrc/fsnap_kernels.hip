@@ -1193,7 +1193,10 @@ __global__ __launch_bounds__(256) void fsnap_gemv_rows_k(const double* __restric
                                                          const double* __restrict__ b,
                                                          const double* __restrict__ w,
                                                          const unsigned char* __restrict__ mask,
-                                                         double* __restrict__ sse_part) {
+                                                         double* __restrict__ sse_part,
+                                                         double* __restrict__ uout) {
+    // uout (optional): u_i = mask_i * w_i^2 * (b_i - a_i . beta), the row weights of the
+    // refinement right-hand side  s = (wA)^T (wb - wA beta) = A^T u   (kernel 7)
     extern __shared__ __attribute__((aligned(16))) double sbeta[];
     for (int c = threadIdx.x; c < K; c += 256) sbeta[c] = beta[c];
     __syncthreads();
@@ -1225,12 +1228,12 @@ __global__ __launch_bounds__(256) void fsnap_gemv_rows_k(const double* __restric
         s += __shfl_xor(s, 1, 64);
         if (row < m && e == 0) {
             if (preds) preds[row] = s;
-            if (sse_part) {
+            if (sse_part || uout) {
                 const bool keep = mask ? (mask[row] != 0) : true;
-                if (keep) {
-                    double rr = w[row] * (b[row] - s);
-                    sse = __builtin_fma(rr, rr, sse);
-                }
+                const double wr = w[row];
+                const double rr = keep ? wr * (b[row] - s) : 0.0;
+                if (sse_part) sse = __builtin_fma(rr, rr, sse);
+                if (uout) uout[row] = keep ? wr * rr : 0.0;
             }
         }
     }
@@ -1461,6 +1464,78 @@ __global__ __launch_bounds__(1024) void fsnap_chol_solve_k(const double* __restr
 }
 
 // ---------------------------------------------------------------------------------
+// Kernel 7: s = A^T u  (transposed streaming GEMV, HBM-bound) — with u from kernel 4 this is
+// the right-hand side of one step of iterative refinement of the least-squares solution
+// ("corrected semi-normal equations": G delta = (wA)^T (wb - wA beta), beta += delta), which
+// takes the error of the normal-equation solve from ~kappa^2 eps back to ~kappa eps — what
+// keeps the GPU path within 1e-6 of the reference's lstsq (svd.py:54) on ill-conditioned A.
+// Workgroup = row range; wave v takes rows v, v+4, ...; lane l owns columns 2l, 2l+1 (+128 j).
+// Per-workgroup partial vectors are written to spart2[wg][K] and summed in fixed order.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsnap_gemvT_rows_k(const double* __restrict__ A, int64_t lda,
+                                                          const double* __restrict__ u, int64_t m, int K,
+                                                          int64_t rows_per_wg, double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) double sacc[];   // 4 waves x Kpad
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int Kpad = (K + 1) & ~1;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+    int64_t r1 = r0 + rows_per_wg;
+    if (r1 > m) r1 = m;
+    const bool vec2 = ((K | lda) & 1) == 0;
+    for (int c0 = 0; c0 < K; c0 += 128) {
+        const int c = c0 + 2 * lane;
+        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+        if (c < K) {
+            int64_t row = r0 + wv;
+            for (; row + 4 < r1; row += 8) {   // two rows in flight per wave
+                const double u0 = u[row], u1 = u[row + 4];
+                double x0, x1, y0, y1;
+                if (vec2) {
+                    const d2u x = *reinterpret_cast<const d2u*>(A + row * lda + c);
+                    const d2u y = *reinterpret_cast<const d2u*>(A + (row + 4) * lda + c);
+                    x0 = x[0]; x1 = x[1]; y0 = y[0]; y1 = y[1];
+                } else {
+                    x0 = A[row * lda + c]; x1 = (c + 1 < K) ? A[row * lda + c + 1] : 0.0;
+                    y0 = A[(row + 4) * lda + c]; y1 = (c + 1 < K) ? A[(row + 4) * lda + c + 1] : 0.0;
+                }
+                a0 = __builtin_fma(x0, u0, a0);
+                a1 = __builtin_fma(x1, u0, a1);
+                b0 = __builtin_fma(y0, u1, b0);
+                b1 = __builtin_fma(y1, u1, b1);
+            }
+            for (; row < r1; row += 4) {
+                const double u0 = u[row];
+                const double x0 = A[row * lda + c];
+                const double x1 = (c + 1 < K) ? A[row * lda + c + 1] : 0.0;
+                a0 = __builtin_fma(x0, u0, a0);
+                a1 = __builtin_fma(x1, u0, a1);
+            }
+            sacc[wv * Kpad + c] = a0 + b0;
+            if (c + 1 < K) sacc[wv * Kpad + c + 1] = a1 + b1;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < K; c += 256)
+        partial[(int64_t)blockIdx.x * K + c] = (sacc[c] + sacc[Kpad + c]) + (sacc[2 * Kpad + c] + sacc[3 * Kpad + c]);
+}
+
+__global__ __launch_bounds__(256) void fsnap_colsum_partials_k(const double* __restrict__ partial, int nparts, int K,
+                                                               double* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= K) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int p = 0;
+    for (; p + 3 < nparts; p += 4) {
+        s0 += partial[(int64_t)p * K + c];
+        s1 += partial[(int64_t)(p + 1) * K + c];
+        s2 += partial[(int64_t)(p + 2) * K + c];
+        s3 += partial[(int64_t)(p + 3) * K + c];
+    }
+    for (; p < nparts; ++p) s0 += partial[(int64_t)p * K + c];
+    out[c] = (s0 + s1) + (s2 + s3);
+}
+
+// ---------------------------------------------------------------------------------
 // host-side launchers (C++ linkage, used by fsnap_capi.cpp)
 // ---------------------------------------------------------------------------------
 namespace fsnap {
@@ -1645,6 +1720,31 @@ hipError_t launch_assemble(const double* raw, int64_t raw_ld, int64_t nrows, con
     return hipGetLastError();
 }
 
+int gemvT_num_blocks(int64_t m) {
+    int64_t nb = (m + 63) / 64;
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+hipError_t launch_gemvT_rows(const double* A, int64_t lda, const double* u, int64_t m, int K, double* partial,
+                             double* out, hipStream_t st) {
+    const int nb = gemvT_num_blocks(m);
+    const int64_t rpw = (m + nb - 1) / nb;
+    const size_t lds = (size_t)4 * ((K + 1) & ~1) * sizeof(double);
+    if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)fsnap_gemvT_rows_k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024 - 256);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fsnap_gemvT_rows_k, dim3((unsigned)nb), dim3(256), lds, st, A, lda, u, m, K, rpw, partial);
+    hipLaunchKernelGGL(fsnap_colsum_partials_k, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, partial, nb, K, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_chol_solve(const double* packed, int K, double alpha, double* out, hipStream_t st) {
     const size_t lds = ((size_t)K * (K + 1) + (size_t)K + 256) * sizeof(double);
     static bool attr_set = false;
@@ -1667,10 +1767,10 @@ int gemv_num_blocks(int64_t m) {
 
 hipError_t launch_gemv_rows(const double* A, int64_t lda, const double* beta, int64_t m, int K, double* preds,
                             const double* b, const double* w, const unsigned char* mask, double* sse_part,
-                            hipStream_t st) {
+                            double* uout, hipStream_t st) {
     const int nb = gemv_num_blocks(m);
     hipLaunchKernelGGL(fsnap_gemv_rows_k, dim3((unsigned)nb), dim3(256), (size_t)K * sizeof(double), st, A, lda,
-                       beta, m, K, preds, b, w, mask, sse_part);
+                       beta, m, K, preds, b, w, mask, sse_part, uout);
     return hipGetLastError();
 }
 

@@ -44,5 +44,7 @@ class RIDGE(Solver):
                 self.fit = self._solve(kind, alval, G.T @ G, G.T @ c)
             return
         fit = self._fit_and_solve(kind, alval, a, b, w, fs_dict, trainall)
+        if self.refine_steps:        # off by default: the reference's ridge is itself a normal-equation solve
+            fit = self._refine(fit, kind, alval, self.refine_steps)
         if pt._rank == 0:
             self.fit = fit

@@ -20,6 +20,9 @@ class SVD(Solver):
 
     def __init__(self, name, pt, config):
         super().__init__(name, pt, config)
+        # lstsq works on A_w (error ~ kappa eps); the normal equations square kappa.  Two steps of
+        # refinement with the row-space residual close that gap (Solver._refine).
+        self.refine_steps = 2
 
     def perform_fit(self, a=None, b=None, w=None, fs_dict=None, trainall=False):
         """
@@ -38,6 +41,8 @@ class SVD(Solver):
         # every rank contributes its rows' statistics; only rank 0 solves (svd.py:33)
         if not ("EXTRAS" in self.config.sections and self.config.sections["EXTRAS"].apply_transpose):
             fit = self._fit_and_solve(_capi.SOLVE_LSTSQ, self.RCOND, a, b, w, fs_dict, trainall)
+            if self.refine_steps and (fit is None or self.last_rank == len(fit)):
+                fit = self._refine(fit, _capi.SOLVE_LSTSQ, self.RCOND, self.refine_steps)
             if pt._rank == 0:
                 self.fit = fit
             return

@@ -164,6 +164,14 @@ int fsnap_weight_rows_device(fsnap_ctx* ctx, double* d_aw, int64_t ldaw, double*
  * the current weights (sklearn ARDRegression's per-iteration `rmse_`). */
 int fsnap_predict(fsnap_ctx* ctx, const double* beta, double* preds, double* sse);
 
+/* Right-hand side of one step of iterative refinement of the least-squares solution:
+ *   s[K] = (wA)^T (wb - wA beta)   over the training rows, with the current weights / mask
+ * (two streaming passes over the resident A).  Solving G delta = s and setting beta += delta
+ * ("corrected semi-normal equations") brings the normal-equation error (~kappa^2 eps) back
+ * to ~kappa eps, i.e. to what the reference's lstsq on A_w delivers (svd.py:54).
+ * beta, s: host; *sse (optional) receives sum (w (b - A beta))^2. */
+int fsnap_residual_rhs(fsnap_ctx* ctx, const double* beta, double* s, double* sse);
+
 /* ---- K x K solve (host side, no context needed) ----------------------------------- */
 
 /* Solve the K x K system given the statistics.  `kind` is one of FSNAP_SOLVE_*;

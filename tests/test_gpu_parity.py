@@ -562,3 +562,65 @@ def test_randomised_shapes_masks_and_extreme_values(ctx):
         if ok.any():
             assert np.max(np.abs(G - Gr)[np.ix_(ok, ok)] / (d[ok][:, None] * d[ok][None, :])) < 1e-11, (it, m, K)
         assert s[2] == sr[2], (it, m, K)
+
+
+# ---------------------------------------------------------------------------------------
+# iterative refinement with the row-space residual (fsnap_residual_rhs)
+# ---------------------------------------------------------------------------------------
+def test_residual_rhs_matches_oracle(ctx, ta, ta_fits):
+    A, b, w = ta
+    t = ta_fits["testing_mask"]
+    beta = ta_fits["ridge_sklearn_1e-4_mask"]          # any vector that is not the LS solution
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w, (~t).astype(np.uint8))
+    s, sse = ctx.residual_rhs(beta, want_sse=True)
+    aw, bw = orc.weight_rows(A, b, w, t)
+    r = bw - aw @ beta
+    ref = aw.T @ r
+    scale = np.abs(aw).T @ np.abs(r)
+    assert np.max(np.abs(s - ref) / scale) < 1e-13
+    assert sse == pytest.approx(r @ r, rel=1e-12)
+
+
+@pytest.mark.parametrize("K", [40, 128, 200])
+def test_residual_rhs_general_k(ctx, K):
+    A, b, w = orc.synth_problem(5003, K)
+    beta = np.random.default_rng(K).standard_normal(K)
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w)
+    s, _ = ctx.residual_rhs(beta)
+    aw, bw = orc.weight_rows(A, b, w)
+    r = bw - aw @ beta
+    assert np.max(np.abs(s - aw.T @ r) / (np.abs(aw).T @ np.abs(r))) < 1e-13
+
+
+def test_refinement_recovers_lstsq_accuracy(ta, ta_fits):
+    # golden Ta set: plain normal equations 7e-8 from the reference SVD; refined: < 1e-10
+    A, b, w = ta
+    pt, s = make_solver("SVD")
+    s.refine_steps = 0
+    s.perform_fit(A, b, w, trainall=True)
+    plain = maxrel(s.fit, ta_fits["svd_all"])
+    s.refine_steps = 2
+    s.perform_fit(A, b, w, trainall=True)
+    refined = maxrel(s.fit, ta_fits["svd_all"])
+    assert plain < 1e-6 and refined < 1e-10 and refined < plain
+    pt.free()
+
+
+@pytest.mark.parametrize("kappa", [1e5, 1e6, 1e7])
+def test_refinement_on_ill_conditioned_problem(kappa):
+    # kappa(A) up to 1e7: kappa^2 eps ~ 1e-2 for the plain normal equations; lstsq (the reference,
+    # svd.py:54) is accurate to ~kappa eps.  Two refinement steps must land within 1e-6 of it.
+    rng = np.random.default_rng(int(np.log10(kappa)))
+    m, K = 20000, 40
+    U, _ = np.linalg.qr(rng.standard_normal((m, K)))
+    V, _ = np.linalg.qr(rng.standard_normal((K, K)))
+    X = (U * np.logspace(0, -np.log10(kappa), K)) @ V.T
+    y = X @ rng.standard_normal(K) + 1e-6 * rng.standard_normal(m)
+    w = np.ones(m)
+    ref = orc.svd_fit(X, y, w)
+    pt, s = make_solver("SVD")
+    s.perform_fit(X, y, w, trainall=True)
+    assert np.max(np.abs(s.fit - ref)) / np.max(np.abs(ref)) < 1e-6
+    pt.free()
