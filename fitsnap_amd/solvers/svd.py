@@ -41,7 +41,11 @@ class SVD(Solver):
         # every rank contributes its rows' statistics; only rank 0 solves (svd.py:33)
         if not ("EXTRAS" in self.config.sections and self.config.sections["EXTRAS"].apply_transpose):
             fit = self._fit_and_solve(_capi.SOLVE_LSTSQ, self.RCOND, a, b, w, fs_dict, trainall)
-            if self.refine_steps and (fit is None or self.last_rank == len(fit)):
+            # refine only a full-rank solve; rank 0 decides, every rank follows (collective)
+            do_refine = bool(self.refine_steps) and (pt._rank != 0 or self.last_rank == len(fit))
+            if not (pt.stubs or pt._size == 1):
+                do_refine = pt.bcast_object(do_refine if pt._rank == 0 else None, src=0)
+            if do_refine:
                 fit = self._refine(fit, _capi.SOLVE_LSTSQ, self.RCOND, self.refine_steps)
             if pt._rank == 0:
                 self.fit = fit
