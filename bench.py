@@ -164,7 +164,7 @@ def main():
     beta = None
     for _ in range(args.steps):
         beta = step()
-        t = ctx.timing()                                   # HIP events on the kernel's stream (already synced)
+        t = ctx.timing(2)                                  # HIP events on the kernel's stream (already synced)
         syrk_ms.append(t["syrk_ms"])
         red_ms.append(t["reduce_ms"])
     fence()

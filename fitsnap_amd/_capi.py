@@ -314,9 +314,10 @@ class HipContext:
         return beta, rank.value, rce.value
 
     # -- measurement -------------------------------------------------------------------
-    def timing(self):
+    def timing(self, n: int = 8):
+        """HIP-event timings (ms); ``n`` = how many leading entries to evaluate (2 = kernels of the last fit only)."""
         ms = (c_double * 8)()
-        self._check(self._lib.fsnap_timing(self._h, ms, 8))
+        self._check(self._lib.fsnap_timing(self._h, ms, int(n)))
         return {"syrk_ms": ms[0], "reduce_ms": ms[1], "upload_ms": ms[2], "weight_ms": ms[3], "predict_ms": ms[4]}
 
     def launch_info(self):

@@ -814,11 +814,11 @@ int fsnap_timing(fsnap_ctx* ctx, double* ms, int n) {
     float t = 0.f;
     if (ctx->t_syrk) {
         if (hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]) == hipSuccess) out[0] = t;
-        if (hipEventElapsedTime(&t, ctx->ev[1], ctx->ev[2]) == hipSuccess) out[1] = t;
+        if (n > 1 && hipEventElapsedTime(&t, ctx->ev[1], ctx->ev[2]) == hipSuccess) out[1] = t;
     }
-    if (ctx->t_upload && hipEventElapsedTime(&t, ctx->ev[3], ctx->ev[4]) == hipSuccess) out[2] = t;
-    if (ctx->t_weight && hipEventElapsedTime(&t, ctx->ev[5], ctx->ev[6]) == hipSuccess) out[3] = t;
-    if (ctx->t_predict && hipEventElapsedTime(&t, ctx->ev[7], ctx->ev[8]) == hipSuccess) out[4] = t;
+    if (n > 2 && ctx->t_upload && hipEventElapsedTime(&t, ctx->ev[3], ctx->ev[4]) == hipSuccess) out[2] = t;
+    if (n > 3 && ctx->t_weight && hipEventElapsedTime(&t, ctx->ev[5], ctx->ev[6]) == hipSuccess) out[3] = t;
+    if (n > 4 && ctx->t_predict && hipEventElapsedTime(&t, ctx->ev[7], ctx->ev[8]) == hipSuccess) out[4] = t;
     for (int i = 0; i < n; ++i) ms[i] = out[i];
     return FSNAP_OK;
 }
