@@ -209,6 +209,13 @@ def main():
                 traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        if info["split"] == 0:
+            kernel_name = "fsnap_syrk_tiled"
+        elif info["kernel_or_pairs"] == 2:
+            kernel_name = f"fsnap_syrk_lds_static<{info['NB']},{info['threads'] // 64}>" if dict(kv.split("=") for kv in args.option).get("kernel", "0") in ("0", "2", "4") \
+                else f"fsnap_syrk_lds<{info['NB']},{info['threads'] // 64}>"
+        else:
+            kernel_name = f"fsnap_syrk_wave<{info['NB']},{info['split']}>"
         out = {
             "metric": "training rows/sec through A^T A + solve, 10^6 x 128 fp64 per GPU",
             "value": total_rows * args.steps / elapsed,
@@ -232,7 +239,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
-                "kernel": "fsnap_syrk_wave", "kernel_ms_avg": syrk_avg_ms, "reduce_kernel_ms_avg": float(np.mean(red_ms)),
+                "kernel": kernel_name, "kernel_ms_avg": syrk_avg_ms, "reduce_kernel_ms_avg": float(np.mean(red_ms)),
                 "flops_per_launch": flops_per_launch, "algorithmic_bytes_per_launch": (8 * Kc + 16) * m,
                 "achieved_GBps_algorithmic": (8 * Kc + 16) * m / (syrk_avg_ms * 1e-3) / 1e9,
             },
