@@ -65,11 +65,36 @@ class FsnapError(RuntimeError):
     """Runtime (HIP / state / argument) failure reported by libfsnap_hip."""
 
 
+def _preload_torch_hip_runtime():
+    """Keep ONE HIP runtime in the process.  PyTorch-ROCm wheels bundle their own libamdhip64
+    (SONAME libamdhip64.so.7, requested by torch as plain ``libamdhip64.so``); if this library
+    pulled in /opt/rocm's copy first, a later ``import torch`` would map a second runtime and
+    its device enumeration fails ("No HIP GPUs are available").  Mapping torch's copy first
+    makes both resolve to the same file, in either import order."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library(build_if_missing: bool = True):
     """Load (building first if needed) libfsnap_hip.so and attach prototypes."""
     global _lib
     if _lib is not None:
         return _lib
+    _preload_torch_hip_runtime()
     path = _build.lib_path()
     if build_if_missing:
         path = _build.build_library()

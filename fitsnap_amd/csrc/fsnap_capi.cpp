@@ -74,6 +74,7 @@ struct fsnap_ctx {
     int opt_tiled = 0;        // force the general-K tiled kernel also for K <= 128
     int opt_kernel = 0;       // 0 auto | 1 wave-triangle (kernel 1) | 2 LDS-shared, static per-wave bodies | 3 LDS-shared, generic
     int opt_nsplit = 0;       // row splits of the tiled kernel (0 = auto)
+    int opt_xcd = 1;          // tiled kernel: contiguous work-item ranges per XCD
     int opt_device_solve = 0; // 1 = factorise K <= 128 systems on the GPU (fsnap_chol_solve_k)
     int opt_ablate = 0;       // timing-only ablation of kernel 1L (diagnostics; results are wrong)
     // timing flags
@@ -194,12 +195,33 @@ int plan_tiled(fsnap_ctx* ctx, TiledGeometry* g) {
     g->NSB = (int)((K + 63) / 64);
     g->npairs = g->NSB * (g->NSB + 1) / 2;
     const int64_t nchunks = (m + 3) / 4;
-    // two workgroups (8 waves) per CU resident; aim at one full wave of workgroups
-    int64_t nsplit = ctx->opt_nsplit > 0 ? ctx->opt_nsplit : ((int64_t)ctx->num_cu * 2 + g->npairs - 1) / g->npairs;
-    // keep a split's rows resident in the Infinity Cache (256 MiB) while all pairs sweep them
+    // Two workgroups (8 waves) per CU are resident.  Equal-sized work items run in rounds of
+    // `slots` workgroups (per XCD when items are dealt in contiguous ranges), so pick the
+    // smallest split count whose last round is (nearly) full: 36 pairs x 15 splits = 540 items
+    // on 512 slots would run a second, almost empty round.
     const int64_t bytes = m * ctx->lda * 8;
+    // keep a split's rows resident in the Infinity Cache (256 MiB) while all pairs sweep them
     const int64_t min_split_cache = (bytes + (96ll << 20) - 1) / (96ll << 20);
-    if (!ctx->opt_nsplit && nsplit < min_split_cache) nsplit = min_split_cache;
+    int64_t nsplit = ctx->opt_nsplit;
+    if (nsplit <= 0) {
+        const int64_t groups = ctx->opt_xcd ? 8 : 1;
+        const int64_t slots = (int64_t)ctx->num_cu * 2 / groups;
+        const int64_t n_hi = std::max<int64_t>(1, std::min<int64_t>(256, nchunks / 32));   // >= 8 chunks per wave
+        const int64_t n_lo = std::min<int64_t>(n_hi, std::max<int64_t>(1, min_split_cache));
+        double best = -1.0;
+        for (int64_t n = n_lo; n <= std::max(n_hi, n_lo); ++n) {
+            const int64_t per = (g->npairs * n + groups - 1) / groups;
+            const double util = (double)per / (double)(slots * ((per + slots - 1) / slots));
+            if (util > best + 1e-9) {
+                best = util;
+                nsplit = n;
+            }
+            if (util >= 0.93) {
+                nsplit = n;
+                break;
+            }
+        }
+    }
     // >= 8 chunks per wave (4 waves per split)
     const int64_t max_split = (nchunks + 31) / 32;
     if (nsplit > max_split) nsplit = max_split;
@@ -243,6 +265,7 @@ int launch_normal_eq_tiled(fsnap_ctx* ctx, double* d_packed) {
     a.nsplit = g.nsplit;
     a.chunks_per_split = g.cps;
     a.nontemporal = false;  // rows are re-read by the other column pairs: keep them cached
+    a.xcd_map = ctx->opt_xcd != 0;
     a.part = (double*)ctx->part.p;
     a.cpart = (double*)ctx->cpart.p;
     a.spart = (double*)ctx->spart.p;
@@ -417,6 +440,8 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
         ctx->opt_device_solve = value != 0;
     } else if (!strcmp(key, "tiled")) {
         ctx->opt_tiled = value != 0;
+    } else if (!strcmp(key, "xcd")) {
+        ctx->opt_xcd = value != 0;
     } else if (!strcmp(key, "nsplit")) {
         if (value < 0 || value > (1 << 24)) return ctx->fail(FSNAP_E_ARG, "nsplit out of range");
         ctx->opt_nsplit = (int)value;

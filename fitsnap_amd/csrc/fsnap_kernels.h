@@ -38,6 +38,7 @@ struct TiledArgs {
     int nsplit;                 // row splits
     int64_t chunks_per_split;   // 4-row chunks per split (each split = 4 waves)
     bool nontemporal;
+    bool xcd_map = true;        // contiguous (split, pair) ranges per XCD (L2 sharing of row slabs)
     double* part;               // [nsplit*npairs][16][4][64]
     double* cpart;              // [(nsplit*NSB)*4][4][16]
     double* spart;              // [nsplit*4][4]

@@ -783,6 +783,11 @@ __device__ __forceinline__ void syrk_lds_dispatch(int wv, double* lds, const Wav
 
 }  // namespace
 
+#ifdef FSNAP_TRACE
+// tools/syrk_trace.hip only: per-workgroup {start, end} (100 MHz wall clock), HW_ID, XCC_ID
+__device__ unsigned long long fsnap_trace_buf[4096 * 4];
+#endif
+
 template <int NB, int NW, bool FULLK, bool NT, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, 4) void fsnap_syrk_lds_static(const double* __restrict__ A, int64_t lda,
                                                                     const double* __restrict__ b,
@@ -794,6 +799,9 @@ __global__ __launch_bounds__(64 * NW, 4) void fsnap_syrk_lds_static(const double
                                                                     double* __restrict__ spart) {
     constexpr int NTILE = NB * (NB + 1) / 2;
     __shared__ double lds[2 * NW * NB * 64];
+#ifdef FSNAP_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+#endif
     const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t wg = blockIdx.x;
@@ -821,6 +829,14 @@ __global__ __launch_bounds__(64 * NW, 4) void fsnap_syrk_lds_static(const double
     double* cw = cpart + wg * (int64_t)(NB * 16);
     double* sw = spart + wg * 4;
     syrk_lds_dispatch<NB, NW, FULLK, NT, ABL>(wv, lds, wb, K, nstage, pw, cw, sw, std::make_integer_sequence<int, NW>{});
+#ifdef FSNAP_TRACE
+    if (threadIdx.x == 0 && wg < 4096) {
+        fsnap_trace_buf[wg * 4 + 0] = trace_t0;
+        fsnap_trace_buf[wg * 4 + 1] = wall_clock64();
+        fsnap_trace_buf[wg * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        fsnap_trace_buf[wg * 4 + 3] = __builtin_amdgcn_s_getreg((3 << 11) | 20);    // HW_REG_XCC_ID[3:0]
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------
@@ -1003,12 +1019,24 @@ __global__ __launch_bounds__(256, 2) void fsnap_syrk_tiled(const double* __restr
                                                            const double* __restrict__ w,
                                                            const unsigned char* __restrict__ mask, int64_t m, int K,
                                                            int NSB, int npairs, int64_t chunks_per_split,
+                                                           int nitems, int xcd_map,
                                                            double* __restrict__ part, double* __restrict__ cpart,
                                                            double* __restrict__ spart) {
     __shared__ double lds[2 * 16 * 256];
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int pair = (int)(blockIdx.x % (unsigned)npairs);
-    const int split = (int)(blockIdx.x / (unsigned)npairs);
+    // Work item = (split, pair), pair fastest.  Workgroups are dealt round-robin to the 8 XCDs
+    // (blockIdx % 8); with xcd_map every XCD gets a CONTIGUOUS range of items, so the
+    // workgroups that share an L2 sweep the same rows (different column pairs) together and a
+    // row slab is fetched from HBM once per XCD instead of once per pair.
+    unsigned item = blockIdx.x;
+    if (xcd_map) {
+        const unsigned per = ((unsigned)nitems + 7u) >> 3;
+        const unsigned slot = blockIdx.x >> 3;
+        item = (blockIdx.x & 7u) * per + slot;
+        if (slot >= per || item >= (unsigned)nitems) return;
+    }
+    const int pair = (int)(item % (unsigned)npairs);
+    const int split = (int)(item / (unsigned)npairs);
     // decode pair -> (I, J), I <= J, row-major packed triangle over NSB superblocks
     int I = 0, rem = pair;
     while (rem >= NSB - I) {
@@ -1679,13 +1707,14 @@ hipError_t launch_reduce(const double* part, const double* cpart, const double* 
 }
 
 hipError_t launch_syrk_tiled(const TiledArgs& a, hipStream_t st) {
-    dim3 grid((unsigned)((int64_t)a.npairs * a.nsplit)), block(256);
+    const int nitems = (int)((int64_t)a.npairs * a.nsplit);
+    dim3 grid((unsigned)(a.xcd_map ? 8 * ((nitems + 7) / 8) : nitems)), block(256);
     if (a.nontemporal)
         hipLaunchKernelGGL((fsnap_syrk_tiled<true>), grid, block, 0, st, a.A, a.lda, a.b, a.w, a.mask, a.m, a.K, a.NSB,
-                           a.npairs, a.chunks_per_split, a.part, a.cpart, a.spart);
+                           a.npairs, a.chunks_per_split, nitems, (int)a.xcd_map, a.part, a.cpart, a.spart);
     else
         hipLaunchKernelGGL((fsnap_syrk_tiled<false>), grid, block, 0, st, a.A, a.lda, a.b, a.w, a.mask, a.m, a.K, a.NSB,
-                           a.npairs, a.chunks_per_split, a.part, a.cpart, a.spart);
+                           a.npairs, a.chunks_per_split, nitems, (int)a.xcd_map, a.part, a.cpart, a.spart);
     return hipGetLastError();
 }
 

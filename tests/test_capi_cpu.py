@@ -102,3 +102,20 @@ def test_solve_k128_synthetic():
     beta, rank, _ = _capi.solve(_capi.SOLVE_RIDGE, 1e-8, G, c)
     assert rank == 128
     assert maxrel(beta, orc.ridge_fit(A, b, w, 1e-8)) < 1e-6
+
+
+def test_single_hip_runtime_whatever_the_import_order():
+    # libfsnap_hip.so first, torch second must not map a second libamdhip64 (torch's device
+    # enumeration fails with two runtimes in one process)
+    import subprocess
+    import sys
+    code = (
+        "import re, sys; sys.path.insert(0, %r)\n"
+        "from fitsnap_amd import _capi; _capi.load_library(build_if_missing=False)\n"
+        "import torch\n"
+        "maps = open('/proc/self/maps').read()\n"
+        "print(len(set(re.findall(r'\\S*libamdhip64\\S*', maps))))\n" % ROOT
+    )
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == "1"

@@ -1,0 +1,115 @@
+// tools/syrk_trace.hip — where and when do the workgroups of kernel 1L run?
+// Includes the product kernels with -DFSNAP_TRACE (per-workgroup start/end wall clock, HW_ID,
+// XCC_ID), launches fsnap_syrk_lds_static on a synthetic 10^6 x 128 problem with the same
+// geometry the C-ABI layer plans, and prints per-workgroup lifetimes grouped by compute unit.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DFSNAP_TRACE tools/syrk_trace.hip -o tools/syrk_trace
+#include "../fitsnap_amd/csrc/fsnap_kernels.hip"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <vector>
+
+#define CK(x)                                                                       \
+    do {                                                                            \
+        hipError_t e_ = (x);                                                        \
+        if (e_ != hipSuccess) {                                                     \
+            fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            exit(1);                                                                \
+        }                                                                           \
+    } while (0)
+
+__global__ void fill(double* p, size_t n, unsigned seed) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u + seed;
+        x ^= x >> 15;
+        x *= 2246822519u;
+        x ^= x >> 13;
+        p[i] = (double)(x & 0xffff) / 65536.0 - 0.5;
+    }
+}
+
+int main(int argc, char** argv) {
+    const int64_t m = argc > 1 ? atoll(argv[1]) : 1000000;
+    const int K = 128;
+    int nblocks = argc > 2 ? atoi(argv[2]) : 512;
+    const int verbose = argc > 3 ? atoi(argv[3]) : 0;
+    double *A, *b, *w, *part, *cpart, *spart;
+    unsigned char* mask;
+    CK(hipMalloc(&A, (size_t)m * K * 8 + 256));
+    CK(hipMalloc(&b, m * 8));
+    CK(hipMalloc(&w, m * 8));
+    CK(hipMalloc(&mask, m));
+    CK(hipMemset(mask, 1, m));
+    fill<<<2048, 256>>>(A, (size_t)m * K, 1u);
+    fill<<<256, 256>>>(b, m, 2u);
+    fill<<<256, 256>>>(w, m, 3u);
+    const int64_t nchunks = (m + 3) / 4;
+    int64_t cpwg = (nchunks + nblocks - 1) / nblocks;
+    cpwg = (cpwg + 7) / 8 * 8;
+    nblocks = (int)((nchunks + cpwg - 1) / cpwg);
+    CK(hipMalloc(&part, (size_t)nblocks * 36 * 256 * 8));
+    CK(hipMalloc(&cpart, (size_t)nblocks * 128 * 8));
+    CK(hipMalloc(&spart, (size_t)nblocks * 4 * 8));
+    fsnap::SyrkArgs a{};
+    a.A = A; a.lda = K; a.b = b; a.w = w; a.mask = mask; a.m = m; a.K = K;
+    a.nblocks = nblocks; a.split = 8; a.chunks_per_wave = cpwg; a.nontemporal = true;
+    a.part = part; a.cpart = cpart; a.spart = spart;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float ms = 0;
+    for (int it = 0; it < 6; ++it) {
+        CK(hipEventRecord(e0, 0));
+        CK(fsnap::launch_syrk_lds(a, 0));
+        CK(hipEventRecord(e1, 0));
+        CK(hipDeviceSynchronize());
+        CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    std::vector<unsigned long long> tr((size_t)nblocks * 4);
+    CK(hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(fsnap_trace_buf), tr.size() * 8));
+    unsigned long long tmin = ~0ull, tmax = 0;
+    for (int g = 0; g < nblocks; ++g) {
+        tmin = std::min(tmin, tr[g * 4]);
+        tmax = std::max(tmax, tr[g * 4 + 1]);
+    }
+    printf("m=%lld workgroups=%d chunks/wg=%lld kernel %.1f us (events), trace span %.1f us\n", (long long)m, nblocks,
+           (long long)cpwg, ms * 1e3, (tmax - tmin) * 0.01);
+    std::map<unsigned, std::vector<int>> bycu;
+    for (int g = 0; g < nblocks; ++g) {
+        const unsigned hw = (unsigned)tr[g * 4 + 2], xcc = (unsigned)tr[g * 4 + 3] & 15u;
+        const unsigned cu = (hw >> 8) & 15u, sh = (hw >> 12) & 1u, se = (hw >> 13) & 7u;
+        bycu[(xcc << 12) | (se << 8) | (sh << 4) | cu].push_back(g);
+    }
+    // lifetime statistics by dispatch layer (first / second workgroup on a compute unit)
+    double s0 = 0, s1 = 0, e0s = 0, e1s = 0, st1 = 0;
+    int n0 = 0, n1 = 0, nsolo = 0;
+    std::map<int, int> occupancy;
+    for (auto& kv : bycu) {
+        auto& v = kv.second;
+        std::sort(v.begin(), v.end(), [&](int x, int y) { return tr[x * 4] < tr[y * 4]; });
+        occupancy[(int)v.size()]++;
+        if (v.size() == 1) ++nsolo;
+        for (size_t i = 0; i < v.size(); ++i) {
+            const double ts = (tr[v[i] * 4] - tmin) * 0.01, te = (tr[v[i] * 4 + 1] - tmin) * 0.01;
+            if (i == 0) { s0 += te - ts; e0s += te; ++n0; }
+            else { s1 += te - ts; e1s += te; st1 += ts; ++n1; }
+            if (verbose) printf("  cu %05x wg %4d start %7.2f end %7.2f us\n", kv.first, v[i], ts, te);
+        }
+    }
+    printf("compute units used %zu; workgroups per CU histogram:", bycu.size());
+    for (auto& o : occupancy) printf(" %d:%d", o.first, o.second);
+    printf("\nfirst  workgroup on a CU: n=%d mean life %.1f us, mean end %.1f us\n", n0, s0 / n0, e0s / n0);
+    if (n1) printf("later  workgroups on a CU: n=%d mean life %.1f us, mean start %.1f us, mean end %.1f us\n", n1, s1 / n1,
+                   st1 / n1, e1s / n1);
+    // distribution of end times
+    std::vector<double> ends;
+    for (int g = 0; g < nblocks; ++g) ends.push_back((tr[g * 4 + 1] - tmin) * 0.01);
+    std::sort(ends.begin(), ends.end());
+    printf("end-time percentiles (us): p0 %.1f p10 %.1f p25 %.1f p50 %.1f p75 %.1f p90 %.1f p100 %.1f\n", ends[0],
+           ends[ends.size() / 10], ends[ends.size() / 4], ends[ends.size() / 2], ends[ends.size() * 3 / 4],
+           ends[ends.size() * 9 / 10], ends.back());
+    return 0;
+}
