@@ -211,6 +211,8 @@ def main():
                 traffic = None
         if info["split"] == 0:
             kernel_name = "fsnap_syrk_tiled"
+        elif info["kernel_or_pairs"] == 3:
+            kernel_name = f"fsnap_syrk_acc<{info['NB']}>"
         elif info["kernel_or_pairs"] == 2:
             kernel_name = f"fsnap_syrk_lds_static<{info['NB']},{info['threads'] // 64}>" if dict(kv.split("=") for kv in args.option).get("kernel", "0") in ("0", "2", "4") \
                 else f"fsnap_syrk_lds<{info['NB']},{info['threads'] // 64}>"

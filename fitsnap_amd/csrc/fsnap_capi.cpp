@@ -108,6 +108,7 @@ struct Geometry {
     int64_t cpw;
     int NB;
     int lds_waves;  // 0 = kernel 1 (wave-triangle); 8 / 16 = kernel 1L (LDS-shared) with that many waves
+    bool acc;       // kernel 1A: whole triangle in one wave (accumulation registers), one wave per SIMD
 };
 
 int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
@@ -116,11 +117,32 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
     g->NB = fsnap::syrk_num_blocks(K);
     g->lds_waves = 0;
     const int64_t off_limit = (int64_t)0xFFF00000;  // 32-bit buffer offsets, 1 MiB of slack for prefetch overshoot
+    g->acc = false;
+    if (g->NB >= 6 && (ctx->opt_kernel == 7 || ctx->opt_kernel == 0)) {
+        // kernel 1A: one 4-wave workgroup per CU, every wave streams its own rows and owns the whole triangle
+        const int64_t nchunks = (m + 3) / 4;
+        int64_t nblocks = ctx->opt_nblocks > 0 ? ctx->opt_nblocks : (int64_t)ctx->num_cu;
+        const int64_t max_blocks = (nchunks + 47) / 48;   // >= 12 chunks per row-wave
+        if (nblocks > max_blocks) nblocks = max_blocks;
+        if (nblocks < 1) nblocks = 1;
+        int64_t cpw = (nchunks + nblocks * 4 - 1) / (nblocks * 4);
+        const int64_t max_cpw = off_limit / (ctx->lda * 32);
+        if (max_cpw < 1) return ctx->fail(FSNAP_E_ARG, "leading dimension %lld too large", (long long)ctx->lda);
+        if (cpw > max_cpw) cpw = max_cpw;
+        nblocks = (nchunks + cpw * 4 - 1) / (cpw * 4);
+        if (nblocks > 0x7FFFFFF) return ctx->fail(FSNAP_E_ARG, "too many workgroups");
+        g->nblocks = (int)nblocks;
+        g->cpw = cpw;
+        g->split = 1;
+        g->threads = 256;
+        g->acc = true;
+        return FSNAP_OK;
+    }
     if (g->NB >= 6 && ctx->opt_kernel != 1) {
         // kernel 1L: rows shared through LDS, whole triangle per workgroup
-        const int nw = (ctx->opt_kernel == 4 && g->NB == 8) ? 16 : 8;
+        const int nw = (ctx->opt_kernel == 4 && g->NB == 8) ? 16 : (ctx->opt_kernel == 5 ? 4 : ctx->opt_kernel == 6 ? 2 : 8);
         const int64_t nchunks = (m + 3) / 4;
-        int64_t nblocks = ctx->opt_nblocks > 0 ? ctx->opt_nblocks : (int64_t)ctx->num_cu * (nw == 16 ? 1 : 2);
+        int64_t nblocks = ctx->opt_nblocks > 0 ? ctx->opt_nblocks : (int64_t)ctx->num_cu * (nw == 4 ? 3 : nw == 2 ? 4 : 16 / nw);
         const int64_t max_blocks = (nchunks + 4 * nw - 1) / (4 * nw);   // >= 4 stages per workgroup
         if (nblocks > max_blocks) nblocks = max_blocks;
         if (nblocks < 1) nblocks = 1;
@@ -315,7 +337,8 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed) {
     a.cpart = (double*)ctx->cpart.p;
     a.spart = (double*)ctx->spart.p;
     FSNAP_HIP(hipEventRecord(ctx->ev[0], ctx->stream), "hipEventRecord");
-    if (g.lds_waves) FSNAP_HIP(fsnap::launch_syrk_lds(a, ctx->stream), "launch fsnap_syrk_lds");
+    if (g.acc) FSNAP_HIP(fsnap::launch_syrk_acc(a, ctx->stream), "launch fsnap_syrk_acc");
+    else if (g.lds_waves) FSNAP_HIP(fsnap::launch_syrk_lds(a, ctx->stream), "launch fsnap_syrk_lds");
     else FSNAP_HIP(fsnap::launch_syrk(a, ctx->stream), "launch fsnap_syrk_wave");
     FSNAP_HIP(hipEventRecord(ctx->ev[1], ctx->stream), "hipEventRecord");
     FSNAP_HIP(fsnap::launch_reduce(a.part, a.cpart, a.spart, g.nblocks, cs_per_block, a.K, d_packed, ctx->stream),
@@ -432,7 +455,7 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
     } else if (!strcmp(key, "nontemporal")) {
         ctx->opt_nt = value != 0;
     } else if (!strcmp(key, "kernel")) {
-        if (value < 0 || value > 4) return ctx->fail(FSNAP_E_ARG, "kernel must be 0 (auto), 1, 2, 3 or 4");
+        if (value < 0 || value > 7) return ctx->fail(FSNAP_E_ARG, "kernel must be 0 (auto) or 1..7");
         ctx->opt_kernel = (int)value;
     } else if (!strcmp(key, "ablate")) {
         ctx->opt_ablate = (int)value;
@@ -871,7 +894,7 @@ int fsnap_launch_info(fsnap_ctx* ctx, int64_t* info, int n) {
         out[2] = g.cpw;
         out[3] = g.NB;
         out[4] = g.split;
-        out[6] = g.lds_waves ? 2 : 1;  // kernel id: 1 = wave-triangle, 2 = LDS-shared
+        out[6] = g.acc ? 3 : (g.lds_waves ? 2 : 1);  // kernel id: 1 = wave-triangle, 2 = LDS-shared, 3 = one-wave triangle (1A)
     }
     for (int i = 0; i < n; ++i) info[i] = out[i];
     return FSNAP_OK;

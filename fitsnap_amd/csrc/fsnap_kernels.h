@@ -49,6 +49,7 @@ int syrk_default_split(int K);
 int syrk_waves_per_simd(int K, int split);
 hipError_t launch_syrk(const SyrkArgs& a, hipStream_t st);
 hipError_t launch_syrk_lds(const SyrkArgs& a, hipStream_t st);
+hipError_t launch_syrk_acc(const SyrkArgs& a, hipStream_t st);
 hipError_t launch_reduce(const double* part, const double* cpart, const double* spart, int nblocks,
                          int cs_per_block, int K, double* out, hipStream_t st);
 hipError_t launch_syrk_tiled(const TiledArgs& a, hipStream_t st);

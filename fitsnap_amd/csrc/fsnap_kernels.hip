@@ -351,6 +351,268 @@ fsnap_syrk_wave(const double* __restrict__ A, int64_t lda, const double* __restr
     }
 }
 
+#ifdef FSNAP_TRACE
+// tools/syrk_trace.hip only: per-workgroup {start, end} (100 MHz wall clock), HW_ID, XCC_ID, and
+// per-wave shader-clock cycles spent in {MFMA phase, park + load issue, barrier} of the stage loop
+__device__ unsigned long long fsnap_trace_buf[4096 * 8];
+__device__ unsigned long long fsnap_trace_wave[4096 * 16 * 4];
+#define FSNAP_TRACE_CLK(v) const unsigned long long v = __builtin_readcyclecounter()
+#endif
+
+// ---------------------------------------------------------------------------------
+// Kernel 1A: fused mask x weight x SYRK with the WHOLE tile triangle resident in ONE wave
+// (80 < K <= 128).  One wave per SIMD (4-wave workgroups, one per CU): the wave streams its own
+// rows straight from HBM into MFMA-fragment registers (no LDS, no barrier in the loop, every
+// row fetched once) and keeps all NB(NB+1)/2 <= 36 accumulator tiles: tiles 0..31 in the 256
+// accumulation registers a[0:255], tiles 32..35 in VGPRs.  The compiler cannot allocate 288
+// accumulator registers across both files (it shuffles every tile through v_accvgpr moves),
+// so the MFMAs name their AGPR tiles explicitly in inline assembly; everything else (loads,
+// weighting, masks, c) is ordinary compiler-scheduled code placed BETWEEN the MFMA rows:
+// a wave issues in order, so VALU / VMEM instructions run in the shadow of the 64-cycle
+// MFMAs only if they sit between them.
+// Operand block p of the NEXT chunk overwrites V[p] right after row p of the CURRENT chunk
+// (tiles (p, p..NB-1)) has been issued -- block p is not read again in this chunk -- so one
+// operand set suffices and the loads run three chunks ahead.
+// tools/mfma_f64_peak.hip ("stream step 4"): this instruction mix sustains ~66 TF/s on
+// random data (one or two waves per SIMD), the LDS-shared kernel 1L ~50-54.
+// Partial layout = kernel 1: part[workgroup][NT][4][64] (4 row-waves folded through LDS) |
+// cpart[rowwave][NB][16] | spart[rowwave][4].
+// ---------------------------------------------------------------------------------
+namespace {
+
+template <int T>
+__device__ __forceinline__ void acc_mfma(double a, double b, d4 (&vt)[4]) {
+    if constexpr (T < 32) {
+        asm volatile("v_mfma_f64_16x16x4_f64 a[%2:%3], %0, %1, a[%2:%3]" : : "v"(a), "v"(b), "n"(8 * T), "n"(8 * T + 7));
+    } else {
+        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(vt[T - 32]) : "v"(a), "v"(b));
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void acc_zero_reg() {
+    asm volatile("v_accvgpr_write_b32 a[%0], 0" : : "n"(R));
+}
+template <int... R>
+__device__ __forceinline__ void acc_zero_all(std::integer_sequence<int, R...>) {
+    (acc_zero_reg<R>(), ...);
+}
+
+template <int T>
+__device__ __forceinline__ d4 acc_read(const d4 (&vt)[4]) {
+    if constexpr (T >= 32) {
+        return vt[T - 32];
+    } else {
+        unsigned r0, r1, r2, r3, r4, r5, r6, r7;
+        asm volatile(
+            "v_accvgpr_read_b32 %0, a[%8]\n\tv_accvgpr_read_b32 %1, a[%9]\n\t"
+            "v_accvgpr_read_b32 %2, a[%10]\n\tv_accvgpr_read_b32 %3, a[%11]\n\t"
+            "v_accvgpr_read_b32 %4, a[%12]\n\tv_accvgpr_read_b32 %5, a[%13]\n\t"
+            "v_accvgpr_read_b32 %6, a[%14]\n\tv_accvgpr_read_b32 %7, a[%15]"
+            : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3), "=v"(r4), "=v"(r5), "=v"(r6), "=v"(r7)
+            : "n"(8 * T), "n"(8 * T + 1), "n"(8 * T + 2), "n"(8 * T + 3), "n"(8 * T + 4), "n"(8 * T + 5), "n"(8 * T + 6),
+              "n"(8 * T + 7));
+        d4 x;
+        x[0] = __builtin_bit_cast(double, ((unsigned long long)r1 << 32) | r0);
+        x[1] = __builtin_bit_cast(double, ((unsigned long long)r3 << 32) | r2);
+        x[2] = __builtin_bit_cast(double, ((unsigned long long)r5 << 32) | r4);
+        x[3] = __builtin_bit_cast(double, ((unsigned long long)r7 << 32) | r6);
+        return x;
+    }
+}
+
+template <int TB, int N, int... U>
+__device__ __forceinline__ void acc_read_range(d4 (&tmp)[N], const d4 (&vt)[4], std::integer_sequence<int, U...>) {
+    ((tmp[U] = acc_read<TB + U>(vt)), ...);
+}
+
+// row p of the triangle: tiles (p, p..NB-1)
+template <int NB, int P, int... Q>
+__device__ __forceinline__ void acc_row(const double (&V)[NB], d4 (&vt)[4], std::integer_sequence<int, Q...>) {
+    (acc_mfma<tri_index(P, P + Q, NB)>(V[P], V[P + Q], vt), ...);
+}
+
+template <int NB, bool FULLK>
+__device__ __forceinline__ double raw_block(const ChunkRaw<NB>& r, int j, double wv, bool keep, int K, int e) {
+    double x;
+    bool kj = keep;
+    if ((NB & 1) && j == NB - 1) {
+        x = __builtin_bit_cast(double, r.tail);
+        if (!FULLK) kj = kj && (16 * (NB - 1) + e < K);
+    } else {
+        x = __builtin_bit_cast(d2, r.pr[j >> 1])[j & 1];
+        if (!FULLK) kj = kj && (32 * (j >> 1) + 2 * e + (j & 1) < K);
+    }
+    return kj ? wv * x : 0.0;
+}
+
+// One chunk: the MFMA rows of the chunk held in V, interleaved with the preparation of the next chunk
+// (raw registers RN) block by block; RF (consumed one step ago) is refilled three chunks ahead first.
+template <int NB, bool FULLK, bool NT, int... P>
+__device__ __forceinline__ void acc_step(double (&V)[NB], d4 (&vt)[4], ChunkRaw<NB>& RF, const ChunkRaw<NB>& RN,
+                                         const WaveBufs& wb, unsigned cl_fill, int K, int e, int kr, double (&cacc)[NB],
+                                         double& bb, double& sbw, double& cnt, std::integer_sequence<int, P...>) {
+    issue_chunk<NB, NT>(RF, wb, cl_fill, kr);
+    const bool keep = (RN.mk != 0);
+    const double wv = __builtin_bit_cast(double, RN.wv);
+    const double wbv = keep ? wv * __builtin_bit_cast(double, RN.bv) : 0.0;
+    bb = __builtin_fma(wbv, wbv, bb);
+    sbw += wbv;
+    cnt += keep ? 1.0 : 0.0;
+    ((acc_row<NB, P>(V, vt, std::make_integer_sequence<int, NB - P>{}),
+      V[P] = raw_block<NB, FULLK>(RN, P, wv, keep, K, e),
+      cacc[P] = __builtin_fma(V[P], wbv, cacc[P]),
+      __builtin_amdgcn_sched_barrier(0)),   // keep block P's VALU work between row P and row P + 1
+     ...);
+}
+
+}  // namespace
+
+template <int NB, bool FULLK, bool NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void
+fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restrict__ b, const double* __restrict__ w,
+               const unsigned char* __restrict__ mask, int64_t m, int K, int64_t chunks_per_wave,
+               double* __restrict__ part, double* __restrict__ cpart, double* __restrict__ spart) {
+    constexpr int NTILE = NB * (NB + 1) / 2;
+    constexpr int HALF = (NTILE + 1) / 2;
+    __shared__ double lds[2 * HALF * 256];
+#ifdef FSNAP_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+    const unsigned long long trace_c0 = __builtin_readcyclecounter();
+#endif
+    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
+    const int rw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t rowwave = (int64_t)blockIdx.x * 4 + rw;
+    const int64_t nchunks = (m + 3) >> 2;
+    int64_t c0 = rowwave * chunks_per_wave;
+    int64_t c1 = c0 + chunks_per_wave;
+    if (c1 > nchunks) c1 = nchunks;
+    if (c0 > c1) c0 = c1;
+    const int64_t row0 = c0 << 2;
+    int64_t row1 = c1 << 2;
+    if (row1 > m) row1 = m;
+    const int64_t nrow = row1 > row0 ? row1 - row0 : 0;
+    WaveBufs wb;
+    wb.A = make_rsrc(A + row0 * lda, (unsigned)(nrow * lda * 8 + (nrow ? 16 : 0)));
+    wb.b = make_rsrc(b + row0, (unsigned)(nrow * 8));
+    wb.w = make_rsrc(w + row0, (unsigned)(nrow * 8));
+    wb.mask = make_rsrc(mask + row0, (unsigned)nrow);
+    wb.voffA = (unsigned)((kr * lda + 2 * e) * 8);
+    wb.voffT = (unsigned)((kr * lda + 16 * (NB - 1) + e) * 8);
+    wb.voffR = (unsigned)(kr * 8);
+    wb.chunk_bytes = (unsigned)(lda * 32);
+    const unsigned ncl = (unsigned)(c1 - c0);
+
+    // the compiler must count a[0:255] as used (register allocation granule of the kernel descriptor): the
+    // clobber makes its resource analysis see the highest accumulation register
+    asm volatile("" : : : "a0", "a255");
+    acc_zero_all(std::make_integer_sequence<int, 256>{});
+    d4 vt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) vt[u] = d4{0.0, 0.0, 0.0, 0.0};
+    double cacc[NB], V[NB];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) cacc[p] = 0.0;
+    double bb = 0.0, sbw = 0.0, cnt = 0.0;
+
+    ChunkRaw<NB> r0, r1, r2;
+    constexpr auto rows = std::make_integer_sequence<int, NB>{};
+    if (ncl > 0) {
+        issue_chunk<NB, NT>(r0, wb, 0, kr);
+        issue_chunk<NB, NT>(r1, wb, 1, kr);
+        issue_chunk<NB, NT>(r2, wb, 2, kr);
+        {   // chunk 0 -> V
+            const bool keep = (r0.mk != 0);
+            const double wv = __builtin_bit_cast(double, r0.wv);
+            const double wbv = keep ? wv * __builtin_bit_cast(double, r0.bv) : 0.0;
+            bb = __builtin_fma(wbv, wbv, bb);
+            sbw += wbv;
+            cnt += keep ? 1.0 : 0.0;
+#pragma unroll
+            for (int p = 0; p < NB; ++p) {
+                V[p] = raw_block<NB, FULLK>(r0, p, wv, keep, K, e);
+                cacc[p] = __builtin_fma(V[p], wbv, cacc[p]);
+            }
+        }
+        // step cl: MFMAs of chunk cl (in V), V <- chunk cl+1, refill of the raw set freed one step ago with chunk
+        // cl+3.  Chunk slots past the wave's range read zeros through the bounds-checked descriptors.
+        for (unsigned cl = 0; cl < ncl; cl += 3) {
+            acc_step<NB, FULLK, NT>(V, vt, r0, r1, wb, cl + 3, K, e, kr, cacc, bb, sbw, cnt, rows);
+            acc_step<NB, FULLK, NT>(V, vt, r1, r2, wb, cl + 4, K, e, kr, cacc, bb, sbw, cnt, rows);
+            acc_step<NB, FULLK, NT>(V, vt, r2, r0, wb, cl + 5, K, e, kr, cacc, bb, sbw, cnt, rows);
+        }
+    }
+    // the last MFMAs (16 passes) must have left the pipe before their accumulators are read
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(vt[0]), "+v"(vt[1]), "+v"(vt[2]), "+v"(vt[3]));
+#ifdef FSNAP_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {   // loop only (the epilogue is timed by the kernel duration)
+        const int64_t wg = blockIdx.x;
+        fsnap_trace_buf[wg * 8 + 0] = trace_t0;
+        fsnap_trace_buf[wg * 8 + 1] = wall_clock64();
+        fsnap_trace_buf[wg * 8 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        fsnap_trace_buf[wg * 8 + 3] = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+        fsnap_trace_buf[wg * 8 + 4] = __builtin_readcyclecounter() - trace_c0;
+    }
+#endif
+
+    // epilogue: fold the four row-waves through LDS in two halves of the triangle
+    // ({2,3} -> {0,1}, then 1 -> 0 in place), one partial per workgroup
+    double* pw = part + (int64_t)blockIdx.x * (int64_t)(NTILE * 256);
+    auto fold_half = [&](auto half_tag) {
+        constexpr int H = decltype(half_tag)::value;
+        constexpr int TB = H * HALF;
+        constexpr int NT_H = (TB + HALF <= NTILE) ? HALF : (NTILE - TB);
+        double* slot = lds + (size_t)(rw & 1) * HALF * 256;
+        d4 tmp[NT_H];
+        acc_read_range<TB>(tmp, vt, std::make_integer_sequence<int, NT_H>{});
+        if (rw >= 2) {
+#pragma unroll
+            for (int u = 0; u < NT_H; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) slot[(u * 4 + i) * 64 + lane] = tmp[u][i];
+        }
+        __syncthreads();
+        if (rw < 2) {
+#pragma unroll
+            for (int u = 0; u < NT_H; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tmp[u][i] += slot[(u * 4 + i) * 64 + lane];
+        }
+        if (rw == 1) {
+#pragma unroll
+            for (int u = 0; u < NT_H; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) slot[(u * 4 + i) * 64 + lane] = tmp[u][i];
+        }
+        __syncthreads();
+        if (rw == 0) {
+            const double* s1 = lds + (size_t)HALF * 256;
+#pragma unroll
+            for (int u = 0; u < NT_H; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pw[((TB + u) * 4 + i) * 64 + lane] = tmp[u][i] + s1[(u * 4 + i) * 64 + lane];
+        }
+        __syncthreads();
+    };
+    fold_half(std::integral_constant<int, 0>{});
+    fold_half(std::integral_constant<int, 1>{});
+
+    double* cw = cpart + rowwave * (int64_t)(NB * 16);
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+        double sm = xlane_sum_rows(cacc[p]);
+        if (kr == 0) cw[p * 16 + e] = sm;
+    }
+    double sb = xlane_sum_rows(bb), ss = xlane_sum_rows(sbw), sc = xlane_sum_rows(cnt);
+    if (lane == 0) {
+        double* sw = spart + rowwave * 4;
+        sw[0] = sb;
+        sw[1] = ss;
+        sw[2] = sc;
+        sw[3] = 0.0;
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // Kernel 2: deterministic reduction of the partials into the packed statistics buffer
 //   out = [G (K*K row-major) | c (K) | bTb, sum_bw, n_train].
@@ -617,6 +879,7 @@ __global__ __launch_bounds__(64 * NW, 4) void fsnap_syrk_lds(const double* __res
 // one fp64 MFMA per 64 cycles; two ds_read_b64 + wait per MFMA cost ~15 %, one fp64 VALU op
 // per MFMA ~7 % — hence fewer LDS reads and fewer VALU ops per MFMA.
 // ---------------------------------------------------------------------------------
+
 namespace {
 
 template <int NB>
@@ -706,13 +969,89 @@ __device__ __forceinline__ void syrk_lds_static_body(double* lds, const WaveBufs
         for (int bq = 0; bq < NB; ++bq) dst[bq * 64] = cr.v[bq];
     };
 
+    // co-resident workgroups differ in blockIdx / (number of CUs); gridDim / 2 (or / 3) separates the layers
+    const unsigned prio_phase = (ABL == 8) ? (unsigned)(blockIdx.x >= (gridDim.x + 1) / 2) : 0u;
     if (nstage > 0) {
         issue_chunk<NB, NT>(raw, wb, (unsigned)WV, kr);
         park(0);
         issue_chunk<NB, NT>(raw, wb, (unsigned)(NW + WV), kr);
         __syncthreads();
+#if defined(FSNAP_TRACE) && FSNAP_TRACE >= 2
+        unsigned long long tr_mfma = 0, tr_park = 0, tr_bar = 0;
+#endif
         for (unsigned s = 0; s < nstage; ++s) {
+#if defined(FSNAP_TRACE) && FSNAP_TRACE >= 2
+            FSNAP_TRACE_CLK(tr0);
+#endif
             const double* src = lds + ((ABL == 4) ? 0 : (s & 1)) * STAGE_DOUBLES + lane;
+            // ABL == 6: the younger wave of each SIMD (WV >= NW/2; the SIMD serves its older wave
+            // first) parks the next stage's chunk BEFORE its MFMA phase, i.e. while the older wave
+            // owns the matrix pipe, instead of after it on the stage's critical path
+            constexpr bool EARLY = (ABL == 6) && (WV >= NW / 2);
+            if (EARLY) {
+                park((s + 1) & 1);
+                issue_chunk<NB, NT>(raw, wb, (s + 2) * NW + WV, kr);
+            }
+            // ABL 7 / 8: wave priorities.  The SIMD arbiter serves the highest s_setprio level first and
+            // only then the oldest wave; a wave in its MFMA phase outranks waves that are parking /
+            // issuing loads, so their VALU / LDS / VMEM instructions fill the 60 idle issue cycles
+            // between two MFMAs instead of delaying one.  ABL 8 additionally alternates, stage by
+            // stage, which of the co-resident workgroups wins ties (fair progress, no tail in which
+            // the younger workgroup runs alone).
+            if (ABL == 7) __builtin_amdgcn_s_setprio(2);
+            if (ABL == 8) {
+                if ((s ^ prio_phase) & 1u) __builtin_amdgcn_s_setprio(3);
+                else __builtin_amdgcn_s_setprio(2);
+            }
+            if (ABL == 9 || ABL == 10) {
+                // Interleaved park: the weighting / mask / c work of this wave's next chunk is cut into NB
+                // per-block pieces that are issued BETWEEN the MFMA groups of the stage (a wave issues in
+                // order: VALU / LDS-write instructions placed after the last MFMA of a stage run with the
+                // matrix pipe idle, placed between MFMAs they run in the shadow of the 64-cycle MFMA).
+                const bool keep = (raw.mk != 0);
+                const double wv = __builtin_bit_cast(double, raw.wv);
+                const double wbv = keep ? wv * __builtin_bit_cast(double, raw.bv) : 0.0;
+                double* dst = lds + ((s + 1) & 1) * STAGE_DOUBLES + (WV * NB) * 64 + lane;
+                // ABL == 10: additionally the LDS operands of chunk c + 1 are requested before the MFMAs of chunk c
+                constexpr auto seq = std::make_integer_sequence<int, NTM>{};
+                double oa[2][NTM], ob[2][NTM];
+                if (ABL == 10 && HAS_TILES) chunk_load<NB, T0, NTM>(oa[0], ob[0], src, seq);
+#pragma unroll
+                for (int c = 0; c < NW; ++c) {
+                    if (ABL == 10) {
+                        if (HAS_TILES) {
+                            if (c + 1 < NW) chunk_load<NB, T0, NTM>(oa[(c + 1) & 1], ob[(c + 1) & 1], src + (c + 1) * NB * 64, seq);
+                            chunk_mfma<NTM>(acc, oa[c & 1], ob[c & 1], seq);
+                        }
+                    } else if (HAS_TILES) {
+                        chunk_tiles<NB, T0, NTM>(acc, src + c * NB * 64, seq);
+                    }
+#pragma unroll
+                    for (int j = c * NB / NW; j < (c + 1) * NB / NW; ++j) {
+                        double x;
+                        bool kj = keep;
+                        if ((NB & 1) && j == NB - 1) {
+                            x = __builtin_bit_cast(double, raw.tail);
+                            if (!FULLK) kj = kj && (16 * (NB - 1) + e < K);
+                        } else {
+                            x = __builtin_bit_cast(d2, raw.pr[j >> 1])[j & 1];
+                            if (!FULLK) kj = kj && (32 * (j >> 1) + 2 * e + (j & 1) < K);
+                        }
+                        const double vj = kj ? wv * x : 0.0;
+                        cacc[j] = __builtin_fma(vj, wbv, cacc[j]);
+                        dst[j * 64] = vj;
+                    }
+                    if (c == NW - 1) {
+                        bb = __builtin_fma(wbv, wbv, bb);
+                        sbw += wbv;
+                        cnt += keep ? 1.0 : 0.0;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                issue_chunk<NB, NT>(raw, wb, (s + 2) * NW + WV, kr);
+                __syncthreads();
+                continue;
+            }
             if (HAS_TILES) {
                 if (ABL == 5) {
                     // operand prefetch: the LDS reads of chunk c + 1 are issued BEFORE the MFMAs of chunk c
@@ -734,10 +1073,34 @@ __device__ __forceinline__ void syrk_lds_static_body(double* lds, const WaveBufs
                         chunk_tiles<NB, T0, NTM>(acc, src + ((ABL == 4) ? 0 : c) * NB * 64, std::make_integer_sequence<int, NTM>{});
                 }
             }
-            park((s + 1) & 1);
-            if (ABL != 1) issue_chunk<NB, NT>(raw, wb, (s + 2) * NW + WV, kr);
+#if defined(FSNAP_TRACE) && FSNAP_TRACE >= 2
+            FSNAP_TRACE_CLK(tr1);
+#endif
+            if (ABL == 7 || ABL == 8) __builtin_amdgcn_s_setprio(0);
+            if (!EARLY) {
+                park((s + 1) & 1);
+                if (ABL != 1) issue_chunk<NB, NT>(raw, wb, (s + 2) * NW + WV, kr);
+            }
+#if defined(FSNAP_TRACE) && FSNAP_TRACE >= 2
+            FSNAP_TRACE_CLK(tr2);
+#endif
             if (ABL != 3) __syncthreads();
+#if defined(FSNAP_TRACE) && FSNAP_TRACE >= 2
+            FSNAP_TRACE_CLK(tr3);
+            tr_mfma += tr1 - tr0;
+            tr_park += tr2 - tr1;
+            tr_bar += tr3 - tr2;
+#endif
         }
+#if defined(FSNAP_TRACE) && FSNAP_TRACE >= 2
+        if (lane == 0 && blockIdx.x < 4096) {
+            unsigned long long* o = fsnap_trace_wave + ((size_t)blockIdx.x * 16 + WV) * 4;
+            o[0] = tr_mfma;
+            o[1] = tr_park;
+            o[2] = tr_bar;
+            o[3] = nstage;
+        }
+#endif
     }
 
     if (HAS_TILES) {
@@ -783,13 +1146,8 @@ __device__ __forceinline__ void syrk_lds_dispatch(int wv, double* lds, const Wav
 
 }  // namespace
 
-#ifdef FSNAP_TRACE
-// tools/syrk_trace.hip only: per-workgroup {start, end} (100 MHz wall clock), HW_ID, XCC_ID
-__device__ unsigned long long fsnap_trace_buf[4096 * 4];
-#endif
-
 template <int NB, int NW, bool FULLK, bool NT, int ABL = 0>
-__global__ __launch_bounds__(64 * NW, 4) void fsnap_syrk_lds_static(const double* __restrict__ A, int64_t lda,
+__global__ __launch_bounds__(64 * NW, (NW == 2 ? 2 : NW == 4 ? 3 : 4)) void fsnap_syrk_lds_static(const double* __restrict__ A, int64_t lda,
                                                                     const double* __restrict__ b,
                                                                     const double* __restrict__ w,
                                                                     const unsigned char* __restrict__ mask, int64_t m,
@@ -801,6 +1159,7 @@ __global__ __launch_bounds__(64 * NW, 4) void fsnap_syrk_lds_static(const double
     __shared__ double lds[2 * NW * NB * 64];
 #ifdef FSNAP_TRACE
     const unsigned long long trace_t0 = wall_clock64();
+    const unsigned long long trace_c0 = __builtin_readcyclecounter();
 #endif
     const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -831,10 +1190,11 @@ __global__ __launch_bounds__(64 * NW, 4) void fsnap_syrk_lds_static(const double
     syrk_lds_dispatch<NB, NW, FULLK, NT, ABL>(wv, lds, wb, K, nstage, pw, cw, sw, std::make_integer_sequence<int, NW>{});
 #ifdef FSNAP_TRACE
     if (threadIdx.x == 0 && wg < 4096) {
-        fsnap_trace_buf[wg * 4 + 0] = trace_t0;
-        fsnap_trace_buf[wg * 4 + 1] = wall_clock64();
-        fsnap_trace_buf[wg * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
-        fsnap_trace_buf[wg * 4 + 3] = __builtin_amdgcn_s_getreg((3 << 11) | 20);    // HW_REG_XCC_ID[3:0]
+        fsnap_trace_buf[wg * 8 + 0] = trace_t0;
+        fsnap_trace_buf[wg * 8 + 1] = wall_clock64();
+        fsnap_trace_buf[wg * 8 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        fsnap_trace_buf[wg * 8 + 3] = __builtin_amdgcn_s_getreg((3 << 11) | 20);    // HW_REG_XCC_ID[3:0]
+        fsnap_trace_buf[wg * 8 + 4] = __builtin_readcyclecounter() - trace_c0;      // shader-clock cycles of the workgroup's life
     }
 #endif
 }
@@ -1632,6 +1992,18 @@ static hipError_t launch_syrk_lds_static_nb(const SyrkArgs& a, hipStream_t st) {
                            a.m, a.K, a.chunks_per_wave, a.part, a.cpart, a.spart);
         return hipGetLastError();
     }
+#define FSNAP_VARIANT(N)                                                                                           \
+    if (NB == 8 && fullk && a.ablate == N) {                                                                       \
+        hipLaunchKernelGGL((fsnap_syrk_lds_static<8, NW, true, true, N>), grid, block, 0, st, a.A, a.lda, a.b, a.w, \
+                           a.mask, a.m, a.K, a.chunks_per_wave, a.part, a.cpart, a.spart);                         \
+        return hipGetLastError();                                                                                  \
+    }
+    FSNAP_VARIANT(6)   // early park (correct results; A/B)
+    FSNAP_VARIANT(7)   // wave priorities by phase
+    FSNAP_VARIANT(8)   // wave priorities by phase + alternating tie-break between co-resident workgroups
+    FSNAP_VARIANT(9)   // park work interleaved with the MFMA groups
+    FSNAP_VARIANT(10)  // ... plus LDS operand prefetch one chunk ahead
+#undef FSNAP_VARIANT
     if (NB == 8 && NW == 8 && fullk && a.ablate) {   // timing-only diagnostic variants (option "ablate")
         switch (a.ablate) {
             case 1: FSNAP_ABL(1); break;
@@ -1659,6 +2031,22 @@ hipError_t launch_syrk_lds(const SyrkArgs& a, hipStream_t st) {
         if (nb != 8) return hipErrorInvalidValue;
         return launch_syrk_lds_static_nb<8, 16>(a, st);
     }
+    if (a.split == 2) {    // 2-wave workgroups, 18 tiles per wave (two waves per SIMD)
+        switch (nb) {
+            case 6: return launch_syrk_lds_static_nb<6, 2>(a, st);
+            case 7: return launch_syrk_lds_static_nb<7, 2>(a, st);
+            case 8: return launch_syrk_lds_static_nb<8, 2>(a, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    if (a.split == 4) {    // four 4-wave workgroups per CU (one wave per SIMD each), 9 tiles per wave
+        switch (nb) {
+            case 6: return launch_syrk_lds_static_nb<6, 4>(a, st);
+            case 7: return launch_syrk_lds_static_nb<7, 4>(a, st);
+            case 8: return launch_syrk_lds_static_nb<8, 4>(a, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
     if (a.split == 8) {
         switch (nb) {
             case 6: return launch_syrk_lds_static_nb<6, 8>(a, st);
@@ -1671,6 +2059,34 @@ hipError_t launch_syrk_lds(const SyrkArgs& a, hipStream_t st) {
         case 6: return launch_syrk_lds_nb<6, 8>(a, st);
         case 7: return launch_syrk_lds_nb<7, 8>(a, st);
         case 8: return launch_syrk_lds_nb<8, 8>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int NB>
+static hipError_t launch_syrk_acc_nb(const SyrkArgs& a, hipStream_t st) {
+    dim3 grid((unsigned)a.nblocks), block(256);
+    const bool fullk = (a.K == 16 * NB);
+#define FSNAP_LAUNCH(FK, NTL)                                                                                       \
+    hipLaunchKernelGGL((fsnap_syrk_acc<NB, FK, NTL>), grid, block, 0, st, a.A, a.lda, a.b, a.w, a.mask, a.m, a.K, \
+                       a.chunks_per_wave, a.part, a.cpart, a.spart)
+    if (fullk) {
+        if (a.nontemporal) FSNAP_LAUNCH(true, true);
+        else FSNAP_LAUNCH(true, false);
+    } else {
+        if (a.nontemporal) FSNAP_LAUNCH(false, true);
+        else FSNAP_LAUNCH(false, false);
+    }
+#undef FSNAP_LAUNCH
+    return hipGetLastError();
+}
+
+// kernel 1A: a.nblocks workgroups of 4 row-waves, a.chunks_per_wave chunks per row-wave
+hipError_t launch_syrk_acc(const SyrkArgs& a, hipStream_t st) {
+    switch (syrk_num_blocks(a.K)) {
+        case 6: return launch_syrk_acc_nb<6>(a, st);
+        case 7: return launch_syrk_acc_nb<7>(a, st);
+        case 8: return launch_syrk_acc_nb<8>(a, st);
         default: return hipErrorInvalidValue;
     }
 }
