@@ -432,38 +432,123 @@ __device__ __forceinline__ void acc_row(const double (&V)[NB], d4 (&vt)[4], std:
     (acc_mfma<tri_index(P, P + Q, NB)>(V[P], V[P + Q], vt), ...);
 }
 
-template <int NB, bool FULLK>
-__device__ __forceinline__ double raw_block(const ChunkRaw<NB>& r, int j, double wv, bool keep, int K, int e) {
-    double x;
-    bool kj = keep;
-    if ((NB & 1) && j == NB - 1) {
-        x = __builtin_bit_cast(double, r.tail);
-        if (!FULLK) kj = kj && (16 * (NB - 1) + e < K);
-    } else {
-        x = __builtin_bit_cast(d2, r.pr[j >> 1])[j & 1];
-        if (!FULLK) kj = kj && (32 * (j >> 1) + 2 * e + (j & 1) < K);
+// Raw loads of kernel 1A.  The row mask is applied by the LOADS: a lane whose row is a test row (or lies past the
+// wave's range) uses an out-of-range buffer offset, so the hardware bounds check returns zeros for its A, b and w
+// values -- w = 0, b = 0 and a = 0 make every product of that row vanish without a single select instruction
+// (and garbage such as NaN / Inf in a masked row is never even fetched).  Every VALU instruction of this kernel
+// costs matrix-pipe time (fp64 MFMAs and VALU instructions serialise on the SIMD), hence: two offset selects per
+// chunk instead of two selects per value.
+template <int NB>
+struct RawM {
+    u4 pr[NB / 2 > 0 ? NB / 2 : 1];
+    u2 tail;
+    u2 bv, wv;
+};
+
+constexpr unsigned FSNAP_OOB_VOFF = 0xFFFFF000u;   // > any wave's buffer size (plan_geometry: < 0xFFF00010), no 32-bit wrap
+
+template <int NB, bool NT>
+__device__ __forceinline__ void issue_masked(RawM<NB>& r, const WaveBufs& wb, unsigned cl, unsigned mk) {
+    const unsigned soff = cl * wb.chunk_bytes;
+    constexpr int AUX = NT ? 2 : 0;
+    const bool keep = (mk != 0);
+    const unsigned va = keep ? wb.voffA : FSNAP_OOB_VOFF;
+    const unsigned vr = keep ? wb.voffR : FSNAP_OOB_VOFF;
+#pragma unroll
+    for (int j = 0; j < NB / 2; ++j) r.pr[j] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, va + 256u * j, soff, AUX);
+    if (NB & 1) {
+        const unsigned vtl = keep ? wb.voffT : FSNAP_OOB_VOFF;
+        r.tail = __builtin_amdgcn_raw_buffer_load_b64(wb.A, vtl, soff, AUX);
     }
-    return kj ? wv * x : 0.0;
+    r.bv = __builtin_amdgcn_raw_buffer_load_b64(wb.b, vr, cl * 32u, 0);
+    r.wv = __builtin_amdgcn_raw_buffer_load_b64(wb.w, vr, cl * 32u, 0);
 }
 
-// One chunk: the MFMA rows of the chunk held in V, interleaved with the preparation of the next chunk
-// (raw registers RN) block by block; RF (consumed one step ago) is refilled three chunks ahead first.
+// piece P of the refill of raw set r (one load instruction per MFMA slot: a block of back-to-back VMEM
+// instructions holds the in-order wave at the address path while the matrix pipe drains)
+template <int NB, bool NT, int P>
+__device__ __forceinline__ void issue_piece(RawM<NB>& r, const WaveBufs& wb, unsigned cl, unsigned va, unsigned vtl,
+                                            unsigned vr) {
+    constexpr int AUX = NT ? 2 : 0;
+    constexpr int NPR = NB / 2;
+    const unsigned soff = cl * wb.chunk_bytes;
+    if (P < NPR) r.pr[P] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, va + 256u * P, soff, AUX);
+    if ((NB & 1) && P == NPR) r.tail = __builtin_amdgcn_raw_buffer_load_b64(wb.A, vtl, soff, AUX);
+    constexpr int PB = NPR + (NB & 1);
+    if (P == PB) r.bv = __builtin_amdgcn_raw_buffer_load_b64(wb.b, vr, cl * 32u, 0);
+    if (P == PB + 1) r.wv = __builtin_amdgcn_raw_buffer_load_b64(wb.w, vr, cl * 32u, 0);
+    static_assert(NPR + (NB & 1) + 2 <= NB, "one load piece per MFMA slot");
+}
+
+// mask byte of the lane's row in chunk cl, normalised to 0 / 1 (rows past the range read 0)
+__device__ __forceinline__ unsigned load_mask(const WaveBufs& wb, unsigned cl, int kr) {
+    return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(wb.mask, (unsigned)kr, cl * 4u, 0);
+}
+
+// w * (raw value of block j); columns >= K (only possible in the last block / block pair when K is not a multiple
+// of 16) are zeroed by a select
+template <int NB, bool FULLK>
+__device__ __forceinline__ double weighted_block(const RawM<NB>& r, int j, double wv, int K, int e) {
+    if ((NB & 1) && j == NB - 1) {
+        const double x = wv * __builtin_bit_cast(double, r.tail);
+        if (FULLK) return x;
+        return (16 * (NB - 1) + e < K) ? x : 0.0;
+    }
+    const double x = wv * __builtin_bit_cast(d2, r.pr[j >> 1])[j & 1];
+    // K > 16 * (NB - 1): only the last even/odd block pair (NB even) can hold columns >= K
+    constexpr int last_pair = (NB & 1) ? -1 : NB / 2 - 1;
+    if (FULLK || (j >> 1) != last_pair) return x;
+    return (32 * (j >> 1) + 2 * e + (j & 1) < K) ? x : 0.0;
+}
+
+// Slot P of a step (between row P and row P + 1 of the MFMAs).  The pieces are independent of each other (a wave
+// issues in order: a dependent chain here would hold back row P + 1):
+//   V[P] <- w * raw block P        cacc[P-1] += V[P-1] * wbv        slots 1, 2: bb, sum_bw
+template <int NB, bool FULLK, bool NT, int P>
+__device__ __forceinline__ void acc_slot(double (&V)[NB], const RawM<NB>& RN, double wv, double wbv, double& wbp, int K,
+                                         int e, double (&cacc)[NB], double& bb, double& sbw, RawM<NB>& RF,
+                                         const WaveBufs& wb, unsigned cl_fill, unsigned va, unsigned vtl, unsigned vr) {
+#if !defined(FSNAP_ACC_ABL) || !(FSNAP_ACC_ABL & 1)
+    issue_piece<NB, NT, P>(RF, wb, cl_fill, va, vtl, vr);
+#endif
+    if (P == 0) cacc[NB - 1] = __builtin_fma(V[NB - 1], wbp, cacc[NB - 1]);   // previous chunk's last block
+    else cacc[P - 1] = __builtin_fma(V[P - 1], wbv, cacc[P - 1]);
+    V[P] = weighted_block<NB, FULLK>(RN, P, wv, K, e);
+    if (P == 1) bb = __builtin_fma(wbv, wbv, bb);
+    if (P == 2) sbw += wbv;
+    if (P == NB - 1) wbp = wbv;
+    __builtin_amdgcn_sched_barrier(0);   // keep the slot between row P and row P + 1
+}
+
+// One chunk: the MFMA rows of the chunk held in V, interleaved with the preparation of the next chunk (raw
+// registers RN) block by block.  First the raw set RF (consumed one step ago) is refilled three chunks ahead,
+// using the mask byte fetched during the previous step, and the mask of the following chunk is requested.
 template <int NB, bool FULLK, bool NT, int... P>
-__device__ __forceinline__ void acc_step(double (&V)[NB], d4 (&vt)[4], ChunkRaw<NB>& RF, const ChunkRaw<NB>& RN,
-                                         const WaveBufs& wb, unsigned cl_fill, int K, int e, int kr, double (&cacc)[NB],
-                                         double& bb, double& sbw, double& cnt, std::integer_sequence<int, P...>) {
-    issue_chunk<NB, NT>(RF, wb, cl_fill, kr);
-    const bool keep = (RN.mk != 0);
+__device__ __forceinline__ void acc_step(double (&V)[NB], d4 (&vt)[4], RawM<NB>& RF, const RawM<NB>& RN,
+                                         const WaveBufs& wb, unsigned cl_fill, unsigned& mk, unsigned& cnt, int K, int e,
+                                         int kr, double (&cacc)[NB], double& bb, double& sbw, double& wbp,
+                                         std::integer_sequence<int, P...>) {
+    const bool keep = (mk != 0);                    // mask bytes may be any non-zero value for "training row"
+    cnt += keep ? 1u : 0u;
+    const unsigned va = keep ? wb.voffA : FSNAP_OOB_VOFF;
+    const unsigned vr = keep ? wb.voffR : FSNAP_OOB_VOFF;
+    const unsigned vtl = (NB & 1) ? (keep ? wb.voffT : FSNAP_OOB_VOFF) : 0u;
+#if !defined(FSNAP_ACC_ABL) || !(FSNAP_ACC_ABL & 1)   // tools/syrk_trace.hip diagnostics: 1 = no loads, 2 = no VALU work
+    // the mask request goes out BEFORE this step's row loads: vmcnt retires in order, so the next step can wait for
+    // its mask byte without also draining the row loads issued here (they stay two steps ahead of their use)
+    mk = load_mask(wb, cl_fill + 1, kr);
+#endif
     const double wv = __builtin_bit_cast(double, RN.wv);
-    const double wbv = keep ? wv * __builtin_bit_cast(double, RN.bv) : 0.0;
-    bb = __builtin_fma(wbv, wbv, bb);
-    sbw += wbv;
-    cnt += keep ? 1.0 : 0.0;
+    const double wbv = wv * __builtin_bit_cast(double, RN.bv);
+    __builtin_amdgcn_sched_barrier(0);
+#if defined(FSNAP_ACC_ABL) && (FSNAP_ACC_ABL & 2)
+    (acc_row<NB, P>(V, vt, std::make_integer_sequence<int, NB - P>{}), ...);
+    (void)wbv;
+#else
     ((acc_row<NB, P>(V, vt, std::make_integer_sequence<int, NB - P>{}),
-      V[P] = raw_block<NB, FULLK>(RN, P, wv, keep, K, e),
-      cacc[P] = __builtin_fma(V[P], wbv, cacc[P]),
-      __builtin_amdgcn_sched_barrier(0)),   // keep block P's VALU work between row P and row P + 1
+      acc_slot<NB, FULLK, NT, P>(V, RN, wv, wbv, wbp, K, e, cacc, bb, sbw, RF, wb, cl_fill, va, vtl, vr)),
      ...);
+#endif
 }
 
 }  // namespace
@@ -475,7 +560,7 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
                double* __restrict__ part, double* __restrict__ cpart, double* __restrict__ spart) {
     constexpr int NTILE = NB * (NB + 1) / 2;
     constexpr int HALF = (NTILE + 1) / 2;
-    __shared__ double lds[2 * HALF * 256];
+    __shared__ double lds[4 * HALF * 256];
 #ifdef FSNAP_TRACE
     const unsigned long long trace_t0 = wall_clock64();
     const unsigned long long trace_c0 = __builtin_readcyclecounter();
@@ -513,34 +598,39 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
     double cacc[NB], V[NB];
 #pragma unroll
     for (int p = 0; p < NB; ++p) cacc[p] = 0.0;
-    double bb = 0.0, sbw = 0.0, cnt = 0.0;
+    double bb = 0.0, sbw = 0.0;
+    unsigned cnt = 0;
 
-    ChunkRaw<NB> r0, r1, r2;
+    RawM<NB> r0, r1, r2;
     constexpr auto rows = std::make_integer_sequence<int, NB>{};
     if (ncl > 0) {
-        issue_chunk<NB, NT>(r0, wb, 0, kr);
-        issue_chunk<NB, NT>(r1, wb, 1, kr);
-        issue_chunk<NB, NT>(r2, wb, 2, kr);
+        const unsigned m0 = load_mask(wb, 0, kr) ? 1u : 0u, m1 = load_mask(wb, 1, kr) ? 1u : 0u;
+        const unsigned m2 = load_mask(wb, 2, kr) ? 1u : 0u;
+        unsigned mk = load_mask(wb, 3, kr);
+        cnt = m0 + m1 + m2;
+        issue_masked<NB, NT>(r0, wb, 0, m0);
+        issue_masked<NB, NT>(r1, wb, 1, m1);
+        issue_masked<NB, NT>(r2, wb, 2, m2);
         {   // chunk 0 -> V
-            const bool keep = (r0.mk != 0);
             const double wv = __builtin_bit_cast(double, r0.wv);
-            const double wbv = keep ? wv * __builtin_bit_cast(double, r0.bv) : 0.0;
+            const double wbv = wv * __builtin_bit_cast(double, r0.bv);
             bb = __builtin_fma(wbv, wbv, bb);
             sbw += wbv;
-            cnt += keep ? 1.0 : 0.0;
 #pragma unroll
             for (int p = 0; p < NB; ++p) {
-                V[p] = raw_block<NB, FULLK>(r0, p, wv, keep, K, e);
+                V[p] = weighted_block<NB, FULLK>(r0, p, wv, K, e);
                 cacc[p] = __builtin_fma(V[p], wbv, cacc[p]);
             }
         }
         // step cl: MFMAs of chunk cl (in V), V <- chunk cl+1, refill of the raw set freed one step ago with chunk
         // cl+3.  Chunk slots past the wave's range read zeros through the bounds-checked descriptors.
+        double wbp = 0.0;   // chunk 0 is fully accounted for by the prologue
         for (unsigned cl = 0; cl < ncl; cl += 3) {
-            acc_step<NB, FULLK, NT>(V, vt, r0, r1, wb, cl + 3, K, e, kr, cacc, bb, sbw, cnt, rows);
-            acc_step<NB, FULLK, NT>(V, vt, r1, r2, wb, cl + 4, K, e, kr, cacc, bb, sbw, cnt, rows);
-            acc_step<NB, FULLK, NT>(V, vt, r2, r0, wb, cl + 5, K, e, kr, cacc, bb, sbw, cnt, rows);
+            acc_step<NB, FULLK, NT>(V, vt, r0, r1, wb, cl + 3, mk, cnt, K, e, kr, cacc, bb, sbw, wbp, rows);
+            acc_step<NB, FULLK, NT>(V, vt, r1, r2, wb, cl + 4, mk, cnt, K, e, kr, cacc, bb, sbw, wbp, rows);
+            acc_step<NB, FULLK, NT>(V, vt, r2, r0, wb, cl + 5, mk, cnt, K, e, kr, cacc, bb, sbw, wbp, rows);
         }
+        cacc[NB - 1] = __builtin_fma(V[NB - 1], wbp, cacc[NB - 1]);   // last prepared chunk (zeros past the range)
     }
     // the last MFMAs (16 passes) must have left the pipe before their accumulators are read
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(vt[0]), "+v"(vt[1]), "+v"(vt[2]), "+v"(vt[3]));
@@ -555,44 +645,34 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
     }
 #endif
 
-    // epilogue: fold the four row-waves through LDS in two halves of the triangle
-    // ({2,3} -> {0,1}, then 1 -> 0 in place), one partial per workgroup
+    // epilogue: fold the four row-waves through LDS in two halves of the triangle.  Every wave parks its tiles of
+    // the half (4 slots x HALF tiles x 2 KiB = 144 KiB at K = 128), then wave r sums a quarter of the tiles over the
+    // four slots in a fixed order and stores them: one partial triangle per workgroup, all four waves busy.
     double* pw = part + (int64_t)blockIdx.x * (int64_t)(NTILE * 256);
     auto fold_half = [&](auto half_tag) {
         constexpr int H = decltype(half_tag)::value;
         constexpr int TB = H * HALF;
         constexpr int NT_H = (TB + HALF <= NTILE) ? HALF : (NTILE - TB);
-        double* slot = lds + (size_t)(rw & 1) * HALF * 256;
-        d4 tmp[NT_H];
-        acc_read_range<TB>(tmp, vt, std::make_integer_sequence<int, NT_H>{});
-        if (rw >= 2) {
+        constexpr int Q = (NT_H + 3) / 4;
+        double* slot = lds + (size_t)rw * HALF * 256;
+        {
+            d4 tmp[NT_H];
+            acc_read_range<TB>(tmp, vt, std::make_integer_sequence<int, NT_H>{});
 #pragma unroll
             for (int u = 0; u < NT_H; ++u)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) slot[(u * 4 + i) * 64 + lane] = tmp[u][i];
         }
         __syncthreads();
-        if (rw < 2) {
+        for (int u = rw * Q; u < (rw + 1) * Q && u < NT_H; ++u) {
 #pragma unroll
-            for (int u = 0; u < NT_H; ++u)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) tmp[u][i] += slot[(u * 4 + i) * 64 + lane];
+            for (int i = 0; i < 4; ++i) {
+                const int o = (u * 4 + i) * 64 + lane;
+                const double s01 = lds[o] + lds[HALF * 256 + o];
+                pw[((TB + u) * 4 + i) * 64 + lane] = (s01 + lds[2 * HALF * 256 + o]) + lds[3 * HALF * 256 + o];
+            }
         }
-        if (rw == 1) {
-#pragma unroll
-            for (int u = 0; u < NT_H; ++u)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) slot[(u * 4 + i) * 64 + lane] = tmp[u][i];
-        }
-        __syncthreads();
-        if (rw == 0) {
-            const double* s1 = lds + (size_t)HALF * 256;
-#pragma unroll
-            for (int u = 0; u < NT_H; ++u)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pw[((TB + u) * 4 + i) * 64 + lane] = tmp[u][i] + s1[(u * 4 + i) * 64 + lane];
-        }
-        __syncthreads();
+        if (H == 0) __syncthreads();
     };
     fold_half(std::integral_constant<int, 0>{});
     fold_half(std::integral_constant<int, 1>{});
@@ -603,7 +683,7 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
         double sm = xlane_sum_rows(cacc[p]);
         if (kr == 0) cw[p * 16 + e] = sm;
     }
-    double sb = xlane_sum_rows(bb), ss = xlane_sum_rows(sbw), sc = xlane_sum_rows(cnt);
+    double sb = xlane_sum_rows(bb), ss = xlane_sum_rows(sbw), sc = xlane_sum_rows((double)cnt);
     if (lane == 0) {
         double* sw = spart + rowwave * 4;
         sw[0] = sb;
@@ -611,6 +691,9 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
         sw[2] = sc;
         sw[3] = 0.0;
     }
+#ifdef FSNAP_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 4096) fsnap_trace_buf[blockIdx.x * 8 + 5] = wall_clock64();   // after the epilogue
+#endif
 }
 
 // ---------------------------------------------------------------------------------

@@ -148,10 +148,11 @@ def test_run_to_run_bit_identical(ctx, ta):
     assert np.array_equal(G1, G2) and np.array_equal(c1, c2) and np.array_equal(s1, s2)
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3])
+@pytest.mark.parametrize("kernel", [1, 2, 3, 5, 6, 7])
 @pytest.mark.parametrize("K", [81, 96, 110, 112, 128])
 def test_kernel_variants_agree(ctx, kernel, K):
-    # kernel 1 = wave-triangle, 2 / 3 = LDS-shared rows with 8 / 16 waves per workgroup
+    # kernel 1 = wave-triangle (two sub-waves), 2 / 3 = LDS-shared rows (static / generic bodies), 5 / 6 = LDS-shared
+    # rows with 4- / 2-wave workgroups, 7 = whole triangle in one wave (accumulation registers; the default)
     rng = np.random.default_rng(1000 + K)
     m = 30011
     A = rng.standard_normal((m, K)) * (10.0 ** rng.uniform(-2, 2, size=K))
@@ -164,6 +165,34 @@ def test_kernel_variants_agree(ctx, kernel, K):
     finally:
         ctx.set_option("kernel", 0)
     stats_close(G, c, s, *orc.normal_eq(A, b, w, t))
+
+
+@pytest.mark.parametrize("m", [1, 3, 4, 13, 47, 48, 49, 191, 193, 1000, 12289])
+@pytest.mark.parametrize("K", [97, 128])
+def test_one_wave_triangle_kernel_tiny_and_ragged_row_counts(ctx, m, K):
+    # kernel 1A (default for 80 < K <= 128): row-waves without rows, partial 3-chunk pipeline groups, masked tails
+    rng = np.random.default_rng(7000 + 13 * m + K)
+    A = rng.standard_normal((m, K))
+    b = rng.standard_normal(m)
+    w = rng.uniform(0.5, 2.0, m)
+    t = rng.random(m) < 0.3
+    G, c, s = run_stats(ctx, A, b, w, t)
+    assert ctx.launch_info()["kernel_or_pairs"] == 3
+    stats_close(G, c, s, *orc.normal_eq(A, b, w, t), tol=1e-11)
+
+
+@pytest.mark.parametrize("xcd", [0, 1])
+def test_tiled_kernel_item_mapping_variants_agree(ctx, xcd):
+    rng = np.random.default_rng(31)
+    A = rng.standard_normal((20011, 300))
+    b = rng.standard_normal(20011)
+    w = rng.uniform(0.5, 2.0, 20011)
+    ctx.set_option("xcd", xcd)
+    try:
+        G, c, s = run_stats(ctx, A, b, w)
+    finally:
+        ctx.set_option("xcd", 1)
+    stats_close(G, c, s, *orc.normal_eq(A, b, w), tol=2e-12)
 
 
 @pytest.mark.parametrize("K,m", [(129, 5003), (142, 13035), (192, 4001), (200, 3000), (257, 2049), (480, 6000), (1595, 2500)])
@@ -496,10 +525,12 @@ def test_anl_solver_matches_reference(ta, ta_fits, tmp_path, monkeypatch):
     pt.free()
 
 
-@pytest.mark.parametrize("opts", [{"kernel": 4}, {"ablate": 5}, {"kernel": 4, "ablate": 5}])
+@pytest.mark.parametrize("opts", [{"kernel": 4}, {"kernel": 2, "ablate": 5}, {"kernel": 4, "ablate": 5}, {"kernel": 2, "ablate": 6},
+                                  {"kernel": 2, "ablate": 8}, {"kernel": 2, "ablate": 9}, {"kernel": 5, "ablate": 10},
+                                  {"kernel": 6, "ablate": 10}])
 def test_lds_kernel_ab_variants_are_correct(ctx, opts):
-    # A/B variants of kernel 1L at K = 128: 16-wave workgroups, operand prefetch (ablate = 5 is the
-    # only `ablate` value that keeps results correct)
+    # A/B variants of kernel 1L at K = 128: 16-wave workgroups, operand prefetch, early park, wave priorities,
+    # interleaved park (`ablate` 5..10 keep results correct; 1..4 are timing-only ablations)
     A, b, w = orc.synth_problem(70001, 128)
     t = orc.synth_testing_mask(len(b))
     for k, v in opts.items():

@@ -115,6 +115,15 @@ int main(int argc, char** argv) {
             wall += (double)(tr[g * 8 + 1] - tr[g * 8]) * 10e-9;
         }
         printf("shader clock while the workgroups ran: %.3f GHz (s_memtime cycles / 100 MHz wall clock)\n", cyc / wall / 1e9);
+        if (nw == 1) {
+            double ep = 0, last = 0;
+            for (int g = 0; g < nblocks; ++g) {
+                ep += (double)(tr[g * 8 + 5] - tr[g * 8 + 1]) * 0.01;
+                last = std::max(last, (double)(tr[g * 8 + 5] - tmin) * 0.01);
+            }
+            printf("kernel 1A epilogue (accumulator read-out, 4-wave fold, partial stores): mean %.2f us per workgroup, last one done at %.1f us\n",
+                   ep / nblocks, last);
+        }
     }
     printf("compute units used %zu; workgroups per CU histogram:", bycu.size());
     for (auto& o : occupancy) printf(" %d:%d", o.first, o.second);
