@@ -16,7 +16,11 @@
 // minimum-norm solution of lstsq gives them.  A numerically rank-deficient system
 // falls back to a cyclic-Jacobi eigendecomposition of G and a truncated pseudo-inverse
 // (minimum-norm solution, the gelsd semantics).
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <limits>
@@ -194,18 +198,91 @@ int chol_upper_blocked(double* a, int n, double* min_piv2, int NBK) {
     return -1;
 }
 
+// ---- register-blocked variant (all sizes >= 32) ----------------------------------------------
+// Panels of NBK pivot rows (unblocked recurrence inside the panel), then ONE pass over the
+// trailing matrix per panel: 32-column chunks OUTER (the panel's chunk, NBK x 32 doubles, stays
+// in L1), trailing rows INNER, four rows at a time in registers (16 accumulator vectors, 4 panel
+// vectors, 4 broadcasts: 16 FMAs per 4 panel loads).  Chunks are updated in full, i.e. a few
+// entries left of the diagonal (never read; the caller zeroes the lower triangle) are touched too.
+// chunks first_chunk, first_chunk + chunk_step, ... (column chunk index = c0 / 32): threads take disjoint chunks
+FSNAP_CLONES void chol_trailing_chunks(double* a, int n, int jb, int je, int first_chunk, int chunk_step) {
+    const int nk = je - jb;
+    for (int c0 = ((je >> 5) + first_chunk) << 5; c0 < n; c0 += 32 * chunk_step) {
+        const int cw = (n - c0 < 32) ? n - c0 : 32;
+        const int i_end = (c0 + 32 < n) ? c0 + 32 : n;    // rows with entries in this chunk: i < c0 + 32
+        int i = je;
+        if (cw == 32) {
+            for (; i + 4 <= i_end; i += 4) {
+                double* r0 = a + (size_t)i * n + c0;
+                double* r1 = r0 + n;
+                double* r2 = r1 + n;
+                double* r3 = r2 + n;
+                v8d y00 = *(const v8du*)(r0), y01 = *(const v8du*)(r0 + 8), y02 = *(const v8du*)(r0 + 16), y03 = *(const v8du*)(r0 + 24);
+                v8d y10 = *(const v8du*)(r1), y11 = *(const v8du*)(r1 + 8), y12 = *(const v8du*)(r1 + 16), y13 = *(const v8du*)(r1 + 24);
+                v8d y20 = *(const v8du*)(r2), y21 = *(const v8du*)(r2 + 8), y22 = *(const v8du*)(r2 + 16), y23 = *(const v8du*)(r2 + 24);
+                v8d y30 = *(const v8du*)(r3), y31 = *(const v8du*)(r3 + 8), y32 = *(const v8du*)(r3 + 16), y33 = *(const v8du*)(r3 + 24);
+                const double* uk = a + (size_t)jb * n;
+                for (int k = 0; k < nk; ++k, uk += n) {
+                    const v8d u0 = *(const v8du*)(uk + c0), u1 = *(const v8du*)(uk + c0 + 8);
+                    const v8d u2 = *(const v8du*)(uk + c0 + 16), u3 = *(const v8du*)(uk + c0 + 24);
+                    const double f0 = uk[i], f1 = uk[i + 1], f2 = uk[i + 2], f3 = uk[i + 3];
+                    const v8d b0 = {f0, f0, f0, f0, f0, f0, f0, f0}, b1 = {f1, f1, f1, f1, f1, f1, f1, f1};
+                    const v8d b2 = {f2, f2, f2, f2, f2, f2, f2, f2}, b3 = {f3, f3, f3, f3, f3, f3, f3, f3};
+                    y00 -= b0 * u0; y01 -= b0 * u1; y02 -= b0 * u2; y03 -= b0 * u3;
+                    y10 -= b1 * u0; y11 -= b1 * u1; y12 -= b1 * u2; y13 -= b1 * u3;
+                    y20 -= b2 * u0; y21 -= b2 * u1; y22 -= b2 * u2; y23 -= b2 * u3;
+                    y30 -= b3 * u0; y31 -= b3 * u1; y32 -= b3 * u2; y33 -= b3 * u3;
+                }
+                *(v8du*)(r0) = y00; *(v8du*)(r0 + 8) = y01; *(v8du*)(r0 + 16) = y02; *(v8du*)(r0 + 24) = y03;
+                *(v8du*)(r1) = y10; *(v8du*)(r1 + 8) = y11; *(v8du*)(r1 + 16) = y12; *(v8du*)(r1 + 24) = y13;
+                *(v8du*)(r2) = y20; *(v8du*)(r2 + 8) = y21; *(v8du*)(r2 + 16) = y22; *(v8du*)(r2 + 24) = y23;
+                *(v8du*)(r3) = y30; *(v8du*)(r3 + 8) = y31; *(v8du*)(r3 + 16) = y32; *(v8du*)(r3 + 24) = y33;
+            }
+        }
+        for (; i < i_end; ++i) {      // leftover rows / ragged last chunk
+            double* ri = a + (size_t)i * n + c0;
+            const double* uk = a + (size_t)jb * n;
+            for (int k = 0; k < nk; ++k, uk += n) axpy_neg(ri, uk + c0, uk[i], cw);
+        }
+    }
+}
+
+// rows i = i0, i0 + step, ... of the chunk columns: used by the threaded driver for large n
+int chol_upper_rb(double* a, int n, double* min_piv2, int NBK) {
+    double mp = std::numeric_limits<double>::infinity();
+    for (int jb = 0; jb < n; jb += NBK) {
+        const int je = (jb + NBK < n) ? jb + NBK : n;
+        const int fail = chol_panel(a, n, jb, je, &mp);
+        if (fail >= 0) {
+            if (min_piv2) *min_piv2 = mp;
+            return fail;
+        }
+        if (je < n) chol_trailing_chunks(a, n, jb, je, 0, 1);
+    }
+    if (min_piv2) *min_piv2 = mp;
+    return -1;
+}
+
 // solve U^T U x = rhs in place (u upper, row-major): forward sweep in axpy form, backward
 // sweep by dot products — both over contiguous row tails
-FSNAP_CLONES void chol_solve(const double* u, int n, double* x) {
+FSNAP_CLONES void chol_solve_inv(const double* u, int n, double* x, double* inv) {
+    // reciprocals of the diagonal first (independent, pipelined divisions): the two sweeps are dependency
+    // chains of n steps each and a division on the chain costs more than the rest of a step
+    for (int k = 0; k < n; ++k) inv[k] = 1.0 / u[(size_t)k * n + k];
     for (int k = 0; k < n; ++k) {
         const double* r = u + (size_t)k * n;
-        x[k] /= r[k];
+        x[k] *= inv[k];
         axpy_neg(x + k + 1, r + k + 1, x[k], n - 1 - k);
     }
     for (int i = n - 1; i >= 0; --i) {
         const double* r = u + (size_t)i * n;
-        x[i] = (x[i] - dotv(r + i + 1, x + i + 1, n - 1 - i)) / r[i];
+        x[i] = (x[i] - dotv(r + i + 1, x + i + 1, n - 1 - i)) * inv[i];
     }
+}
+void chol_solve(const double* u, int n, double* x) {
+    static thread_local vec inv;
+    inv.resize(n);
+    chol_solve_inv(u, n, x, inv.data());
 }
 
 // LU with partial pivoting, solve a x = b (a destroyed).  Returns false if singular.
@@ -345,9 +422,20 @@ struct Reduced {
 };
 
 bool all_finite(const double* p, size_t n) {
-    for (size_t i = 0; i < n; ++i)
-        if (!std::isfinite(p[i])) return false;
-    return true;
+    // x * 0 is 0 for finite x and NaN otherwise: four independent vector sums, no branches
+    const v8d zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    v8d s0 = zero, s1 = zero, s2 = zero, s3 = zero;
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        s0 += *(const v8du*)(p + i) * zero;
+        s1 += *(const v8du*)(p + i + 8) * zero;
+        s2 += *(const v8du*)(p + i + 16) * zero;
+        s3 += *(const v8du*)(p + i + 24) * zero;
+    }
+    const v8d s = (s0 + s1) + (s2 + s3);
+    double t = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    for (; i < n; ++i) t += p[i] * 0.0;
+    return t == 0.0;
 }
 
 // Jacobi-scaled Cholesky solve with one refinement step.  Returns -1 ok, else failing
@@ -404,16 +492,147 @@ int eig_pinv_solve(const vec& M, const vec& rhs, int n, double rel_cut, double s
     return rank;
 }
 
+// panel step split for the threaded driver: (1) the NBK x NBK diagonal block, columns [jb, je) only ...
+FSNAP_CLONES int chol_panel_diag(double* a, int n, int jb, int je, double* mp) {
+    for (int j = jb; j < je; ++j) {
+        double* uj = a + (size_t)j * n;
+        const double d = uj[j];
+        if (d < *mp) *mp = d;
+        if (!(d > 0.0) || !std::isfinite(d)) return j;
+        const double r = std::sqrt(d), inv = 1.0 / r;
+        uj[j] = r;
+        for (int k = j + 1; k < je; ++k) uj[k] *= inv;
+        for (int i = j + 1; i < je; ++i) {
+            const double f = uj[i];
+            double* ui = a + (size_t)i * n;
+            for (int k = i; k < je; ++k) ui[k] -= f * uj[k];
+        }
+    }
+    return -1;
+}
+// ... (2) the forward substitution of the panel's row tails, restricted to the caller's 32-column chunks
+FSNAP_CLONES void chol_panel_tails(double* a, int n, int jb, int je, int first_chunk, int chunk_step) {
+    for (int c0 = je + 32 * first_chunk; c0 < n; c0 += 32 * chunk_step) {
+        const int cw = (n - c0 < 32) ? n - c0 : 32;
+        for (int j = jb; j < je; ++j) {
+            double* uj = a + (size_t)j * n;
+            const double inv = 1.0 / uj[j];
+            for (int k = 0; k < cw; ++k) uj[c0 + k] *= inv;
+            for (int i = j + 1; i < je; ++i) axpy_neg(a + (size_t)i * n + c0, uj + c0, uj[i], cw);
+        }
+    }
+}
+
+// multi-threaded driver for large n: the threads live for the whole factorisation and meet at a spinning
+// barrier after every panel (thread 0 factorises the panel) and after every trailing sweep
+int chol_upper_rb_mt(double* a, int n, double* min_piv2, int NBK, int nt) {
+    struct Shared {
+        std::atomic<int> arrived{0};
+        std::atomic<int> phase{0};
+        std::atomic<int> fail{-1};
+        double mp = std::numeric_limits<double>::infinity();
+    } sh;
+    auto barrier = [&](int& local_phase) {
+        ++local_phase;
+        if (sh.arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == nt) {
+            sh.arrived.store(0, std::memory_order_relaxed);
+            sh.phase.store(local_phase, std::memory_order_release);
+        } else {
+            int spins = 0;
+            while (sh.phase.load(std::memory_order_acquire) != local_phase) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+                if (++spins > 4096) {          // oversubscribed host: let the thread we wait for run
+                    std::this_thread::yield();
+                    spins = 0;
+                }
+            }
+        }
+    };
+    auto body = [&](int t) {
+        int ph = 0;
+        for (int jb = 0; jb < n; jb += NBK) {
+            const int je = (jb + NBK < n) ? jb + NBK : n;
+            if (t == 0) {
+                const int f = chol_panel_diag(a, n, jb, je, &sh.mp);
+                if (f >= 0) sh.fail.store(f, std::memory_order_relaxed);
+            }
+            barrier(ph);
+            if (sh.fail.load(std::memory_order_relaxed) >= 0) return;
+            if (je < n) {
+                chol_panel_tails(a, n, jb, je, t, nt);
+                barrier(ph);            // the trailing update reads panel entries of other threads' chunks
+                chol_trailing_chunks(a, n, jb, je, t, nt);
+            }
+            barrier(ph);
+        }
+    };
+    std::vector<std::thread> th;
+    th.reserve(nt - 1);
+    for (int t = 1; t < nt; ++t) th.emplace_back(body, t);
+    body(0);
+    for (auto& x : th) x.join();
+    if (min_piv2) *min_piv2 = sh.mp;
+    return sh.fail.load();
+}
+
+// factorisation used by the fast path; FSNAP_CHOL_VARIANT (environment, tests / tuning only) forces a variant:
+// 0 = auto, 1 = unblocked, 2 = 64-row panels + threads, 3 = register-blocked chunks
+int fast_chol(double* u, int n, double* mp2) {
+    static const int forced = [] {
+        const char* e = std::getenv("FSNAP_CHOL_VARIANT");
+        return e ? std::atoi(e) : 0;
+    }();
+    static const int nbk_env = [] {
+        const char* e = std::getenv("FSNAP_CHOL_NBK");
+        return e ? std::atoi(e) : 0;
+    }();
+    if (forced == 1) return chol_upper(u, n, mp2);
+    if (forced == 2) return chol_upper_blocked(u, n, mp2, 64);
+    if (forced == 3 || n >= 48) {
+        const int nbk = nbk_env > 0 ? nbk_env : (n <= 256 ? 8 : 32);
+        static const int nt_env = [] {
+            const char* e = std::getenv("FSNAP_CHOL_THREADS");
+            return e ? std::atoi(e) : 0;
+        }();
+        // Host threads are opt-in (FSNAP_CHOL_THREADS): inside a CPU-quota'd container the spinning barriers of the
+        // threaded driver made the factorisation SLOWER on the MI355X boxes (K = 1595: 18 -> 23-41 ms, K = 480:
+        // 0.4 -> 2.3 ms with 4 threads); large systems are factorised on the GPU instead (fsnap_solve_device).
+        int nt = nt_env > 0 ? nt_env : 1;
+        if (nt > n / 160) nt = n / 160;          // >= 5 column chunks per thread
+        if (nt > 1) return chol_upper_rb_mt(u, n, mp2, nbk, nt);
+        return chol_upper_rb(u, n, mp2, nbk);
+    }
+    return chol_upper(u, n, mp2);
+}
+
+}  // namespace
+
+namespace {
+struct PhaseTimer {   // FSNAP_SOLVE_TIMING=1: print the phases of the fast path to stderr (tuning aid)
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    PhaseTimer() : on(std::getenv("FSNAP_SOLVE_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void lap(const char* what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[fsnap_solve] %-14s %9.1f us\n", what, std::chrono::duration<double, std::micro>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 }  // namespace
 
 extern "C" int fsnap_solve(int kind, double param, int64_t K64, const double* G, const double* c, double* beta,
                            int* rank_out, double* rcond_est) {
+    PhaseTimer timer;
     if (!G || !c || !beta || K64 <= 0 || K64 > (1 << 20)) return FSNAP_E_ARG;
     if (kind < FSNAP_SOLVE_CHOL || kind > FSNAP_SOLVE_RIDGE_INV) return FSNAP_E_ARG;
     const int K = (int)K64;
-    if (!all_finite(G, (size_t)K * K) || !all_finite(c, K) || !std::isfinite(param)) return FSNAP_NUM_NONFINITE;
+    if (!std::isfinite(param)) return FSNAP_NUM_NONFINITE;
     const double alpha = (kind == FSNAP_SOLVE_RIDGE || kind == FSNAP_SOLVE_RIDGE_INV) ? param : 0.0;
     const double eps = std::numeric_limits<double>::epsilon();
+    timer.lap("finite check");
 
     // ---- fast path (the common case of a fit loop): no zero column, well conditioned -----
     // One contiguous pass over the UPPER triangle of G builds the Jacobi-scaled matrix (G is
@@ -434,22 +653,43 @@ extern "C" int fsnap_solve(int kind, double param, int64_t K64, const double* G,
             chk += c[i] * 0.0;
         }
         if (ok) {
+            // rows are built in 8-wide vectors from the vector that holds the diagonal: the < 8 entries left of the
+            // diagonal receive (valid, unused) scaled values, everything further left is zeroed -- the blocked
+            // factorisation updates whole 32-column chunks.  The finiteness of everything read is folded into chkv.
+            const v8d zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            v8d chk0 = zero, chk1 = zero;
             for (int i = 0; i < K; ++i) {
                 const double* gi = G + (size_t)i * K;
                 double* ui = U.data() + (size_t)i * K;
                 const double di = dsc[i];
-                for (int j = i; j < K; ++j) {
+                const v8d dv = {di, di, di, di, di, di, di, di};
+                const int j0 = i & ~7;
+                int j = 0;
+                for (; j + 8 <= j0; j += 8) *(v8du*)(ui + j) = zero;
+                for (; j + 16 <= K; j += 16) {
+                    const v8d g0 = *(const v8du*)(gi + j), g1 = *(const v8du*)(gi + j + 8);
+                    chk0 += g0 * zero;
+                    chk1 += g1 * zero;
+                    *(v8du*)(ui + j) = g0 * dv * *(const v8du*)(dsc.data() + j);
+                    *(v8du*)(ui + j + 8) = g1 * dv * *(const v8du*)(dsc.data() + j + 8);
+                }
+                for (; j < K; ++j) {
                     ui[j] = gi[j] * di * dsc[j];
-                    chk += gi[j] * 0.0;       // NaN iff any entry is not finite
+                    chk += gi[j] * 0.0;
                 }
                 ui[i] = (gi[i] + alpha) * di * di;
             }
+            const v8d cs = chk0 + chk1;
+            chk += ((cs[0] + cs[1]) + (cs[2] + cs[3])) + ((cs[4] + cs[5]) + (cs[6] + cs[7]));
             double mp2 = 0.0;
-            if (chk == 0.0 && (K >= 768 ? chol_upper_blocked(U.data(), K, &mp2, 64) : chol_upper(U.data(), K, &mp2)) < 0 &&
-                mp2 > 1.0e-3) {
+            timer.lap("scale/build");
+            const bool fact_ok = (chk == 0.0) && fast_chol(U.data(), K, &mp2) < 0;
+            timer.lap("cholesky");
+            if (fact_ok && mp2 > 1.0e-3) {
                 for (int i = 0; i < K; ++i) z[i] = c[i] * dsc[i];
                 chol_solve(U.data(), K, z.data());
                 for (int i = 0; i < K; ++i) beta[i] = z[i] * dsc[i];
+                timer.lap("tri solves");
                 if (all_finite(beta, K)) {
                     if (rank_out) *rank_out = K;
                     if (rcond_est) *rcond_est = mp2;
@@ -459,6 +699,7 @@ extern "C" int fsnap_solve(int kind, double param, int64_t K64, const double* G,
         }
     }
 
+    if (!all_finite(G, (size_t)K * K) || !all_finite(c, K)) return FSNAP_NUM_NONFINITE;
     // active columns: drop exactly-zero columns when there is no ridge shift
     static thread_local Reduced R;
     R.idx.clear();
