@@ -70,7 +70,7 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * per-wave specialised bodies, 3 LDS-shared generic variant), "split" (1|2, sub-waves per row-wave of kernel 1),
  * "nontemporal" (0|1), "nblocks" (workgroups of the SYRK kernel), "tiled" (1 = force the
  * general-K tiled kernel also for K <= 128), "nsplit" (row splits of the tiled kernel), "xcd" (0|1: tiled kernel deals contiguous work-item ranges to each XCD),
- * "device_solve" (1 = fsnap_solve_device factorises K <= 128 systems on the GPU).
+ * "device_solve" (fsnap_solve_device: 0 = auto: K >= 768 is factorised on the GPU by the blocked kernels; 1 = every K on the GPU; 2 = never).
  * Unknown key -> FSNAP_E_ARG. */
 int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value);
 

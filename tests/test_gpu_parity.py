@@ -232,6 +232,59 @@ def test_ridge_fit_k142_ace_shape():
     pt.free()
 
 
+@pytest.mark.parametrize("K,m", [(257, 3001), (320, 4000), (480, 6000), (1000, 5000), (1595, 7000)])
+def test_large_k_device_cholesky_matches_host_solve(ctx, K, m):
+    # fsnap_solve_device factorises large systems on the GPU (blocked kernels 8a-8e); same answer as the host solver and
+    # as a dense numpy solve of the same statistics
+    rng = np.random.default_rng(4000 + K)
+    A = rng.standard_normal((m, K)) * (10.0 ** rng.uniform(-2, 2, size=K))
+    b = rng.standard_normal(m)
+    w = rng.uniform(0.5, 2.0, m)
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w)
+    ptr = ctx.normal_eq_resident()
+    G, c, _ = ctx.download_packed(ptr, K)
+    for kind, param in ((_capi.SOLVE_RIDGE, 1e-6), (_capi.SOLVE_LSTSQ, 1e-13), (_capi.SOLVE_CHOL, 0.0)):
+        ctx.set_option("device_solve", 1)          # force the GPU factorisation also below the automatic threshold
+        try:
+            beta_dev, rank, rcond = ctx.solve_device(kind, param, K, ptr)
+        finally:
+            ctx.set_option("device_solve", 0)
+        assert rank == K and rcond > 1e-3
+        ctx.set_option("device_solve", 2)
+        try:
+            beta_host, rank_h, _ = ctx.solve_device(kind, param, K, ptr)
+        finally:
+            ctx.set_option("device_solve", 0)
+        alpha = param if kind == _capi.SOLVE_RIDGE else 0.0
+        ref = np.linalg.solve(G + alpha * np.eye(K), c)
+        scale = np.max(np.abs(ref))
+        assert np.max(np.abs(beta_dev - beta_host)) / scale < 1e-9
+        assert np.max(np.abs(beta_dev - ref)) / scale < 1e-8
+
+
+def test_large_k_device_cholesky_falls_back_when_ill_conditioned(ctx):
+    # two identical columns: the scaled matrix is singular -> tiny / failed pivot on the GPU -> general host path
+    rng = np.random.default_rng(77)
+    K, m = 300, 2000
+    A = rng.standard_normal((m, K))
+    A[:, 299] = A[:, 7]
+    b = rng.standard_normal(m)
+    ctx.upload_rows(A, b)
+    ctx.set_weights(np.ones(m))
+    ptr = ctx.normal_eq_resident()
+    ctx.set_option("device_solve", 1)
+    try:
+        beta, rank, _ = ctx.solve_device(_capi.SOLVE_LSTSQ, 1e-13, K, ptr)
+        with pytest.raises(np.linalg.LinAlgError):
+            ctx.solve_device(_capi.SOLVE_CHOL, 0.0, K, ptr)
+    finally:
+        ctx.set_option("device_solve", 0)
+    assert rank == K - 1
+    ref = np.linalg.lstsq(A, b, rcond=1e-13)[0]
+    assert np.max(np.abs(A @ beta - A @ ref)) < 1e-8 * np.max(np.abs(b))
+
+
 def test_call_order_errors(ctx):
     c2 = _capi.HipContext(0)
     try:
