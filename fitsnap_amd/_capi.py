@@ -54,6 +54,8 @@ SIGNATURES = {
     "fsnap_residual_rhs": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double)]),
     "fsnap_solve": (c_int, [c_int, c_double, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int), POINTER(c_double)]),
     "fsnap_solve_device": (c_int, [c_void_p, c_int, c_double, c_int64, c_void_p, c_void_p, POINTER(c_int), POINTER(c_double)]),
+    "fsnap_solve_device_rhs": (c_int, [c_void_p, c_int, c_double, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int),
+                                        POINTER(c_double)]),
     "fsnap_timing": (c_int, [c_void_p, _P_D, c_int]),
     "fsnap_launch_info": (c_int, [c_void_p, POINTER(c_int64), c_int]),
 }
@@ -327,13 +329,21 @@ class HipContext:
         self._check(self._lib.fsnap_residual_rhs(self._h, _ptr(beta), _ptr(s), byref(sse) if want_sse else None))
         return s, (sse.value if want_sse else None)
 
-    def solve_device(self, kind: int, param: float, K: int, d_packed_ptr: int):
-        """K x K solve from the packed statistics in HBM; returns (beta, rank, rcond_estimate)."""
+    def solve_device(self, kind: int, param: float, K: int, d_packed_ptr: int, rhs=None):
+        """K x K solve from the packed statistics in HBM; returns (beta, rank, rcond_estimate).
+        ``rhs`` (host, K doubles) replaces the c part of the packed buffer as right-hand side."""
         beta = np.empty(K, dtype=np.float64)
         rank = c_int(0)
         rce = c_double(0.0)
-        rc = self._lib.fsnap_solve_device(self._h, int(kind), float(param), int(K), c_void_p(d_packed_ptr), _ptr(beta),
-                                          byref(rank), byref(rce))
+        if rhs is None:
+            rc = self._lib.fsnap_solve_device(self._h, int(kind), float(param), int(K), c_void_p(d_packed_ptr), _ptr(beta),
+                                              byref(rank), byref(rce))
+        else:
+            r = _f64(rhs, "rhs")
+            if r.shape != (K,):
+                raise ValueError("rhs must have K entries")
+            rc = self._lib.fsnap_solve_device_rhs(self._h, int(kind), float(param), int(K), c_void_p(d_packed_ptr), _ptr(r),
+                                                  _ptr(beta), byref(rank), byref(rce))
         if rc != OK:
             raise_status(rc, (self._lib.fsnap_last_error(self._h) or b"").decode() if rc < 0 else "")
         return beta, rank.value, rce.value

@@ -776,12 +776,17 @@ int fsnap_predict(fsnap_ctx* ctx, const double* beta, double* preds, double* sse
 
 int fsnap_solve_device(fsnap_ctx* ctx, int kind, double param, int64_t K, const double* d_packed, double* beta,
                        int* rank, double* rcond_est) {
+    return fsnap_solve_device_rhs(ctx, kind, param, K, d_packed, nullptr, beta, rank, rcond_est);
+}
+
+int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, const double* d_packed, const double* rhs,
+                           double* beta, int* rank, double* rcond_est) {
     if (!ctx) return FSNAP_E_ARG;
     if (!d_packed || !beta || K <= 0 || kind < FSNAP_SOLVE_CHOL || kind > FSNAP_SOLVE_RIDGE_INV)
         return ctx->fail(FSNAP_E_ARG, "fsnap_solve_device: bad argument");
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     const double alpha = (kind == FSNAP_SOLVE_RIDGE || kind == FSNAP_SOLVE_RIDGE_INV) ? param : 0.0;
-    if (K <= 128 && ctx->opt_device_solve == 1) {
+    if (K <= 128 && ctx->opt_device_solve == 1 && !rhs) {
         if (!ctx->dsolve.ensure((size_t)(K + 2) * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(solve) failed");
         double host[130];
         FSNAP_HIP(fsnap::launch_chol_solve(d_packed, (int)K, alpha, (double*)ctx->dsolve.p, ctx->stream),
@@ -823,8 +828,14 @@ int fsnap_solve_device(fsnap_ctx* ctx, int kind, double param, int64_t K, const 
                 return ctx->fail(FSNAP_E_NOMEM, "hipHostMalloc(%zu) failed", head * 8);
             ctx->pinned_bytes = head * 8;
         }
-        FSNAP_HIP(fsnap::launch_chol_large(d_packed, n, alpha, (double*)ctx->dchol.p, d_dsc, d_z, d_beta, d_status, d_minpiv,
-                                           ctx->stream),
+        const double* d_rhs = nullptr;
+        if (rhs) {
+            if (!ctx->dsvec.ensure((size_t)n * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(rhs) failed");
+            FSNAP_HIP(hipMemcpyAsync(ctx->dsvec.p, rhs, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(rhs)");
+            d_rhs = (const double*)ctx->dsvec.p;
+        }
+        FSNAP_HIP(fsnap::launch_chol_large(d_packed, d_rhs, n, alpha, (double*)ctx->dchol.p, d_dsc, d_z, d_beta, d_status,
+                                           d_minpiv, ctx->stream),
                   "launch device Cholesky");
         FSNAP_HIP(hipMemcpyAsync(ctx->pinned, dv, head * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(beta)");
         FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
@@ -861,7 +872,7 @@ int fsnap_solve_device(fsnap_ctx* ctx, int kind, double param, int64_t K, const 
     FSNAP_HIP(hipMemcpyAsync(ctx->pinned, d_packed, need, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(G)");
     FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     const double* G = ctx->pinned;
-    const int rc = fsnap_solve(kind, param, K, G, G + K * K, beta, rank, rcond_est);
+    const int rc = fsnap_solve(kind, param, K, G, rhs ? rhs : G + K * K, beta, rank, rcond_est);
     if (rc) ctx->fail(rc, "fsnap_solve: numerical status %d", rc);
     return rc;
 }

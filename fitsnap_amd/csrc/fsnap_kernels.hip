@@ -2028,7 +2028,8 @@ __global__ __launch_bounds__(256) void fsnap_colsum_partials_k(const double* __r
 // ---------------------------------------------------------------------------------
 constexpr int CHOL_NB = 64;
 
-__global__ __launch_bounds__(256) void fsnap_chol_prepare_d_k(const double* __restrict__ packed, int n, int np,
+__global__ __launch_bounds__(256) void fsnap_chol_prepare_d_k(const double* __restrict__ packed,
+                                                             const double* __restrict__ cvec, int n, int np,
                                                              double alpha, double* __restrict__ dsc,
                                                              double* __restrict__ z, int* __restrict__ status,
                                                              double* __restrict__ minpiv, int npanel) {
@@ -2041,7 +2042,7 @@ __global__ __launch_bounds__(256) void fsnap_chol_prepare_d_k(const double* __re
         return;
     }
     const double g = packed[(size_t)i * n + i] + alpha;
-    const double c = packed[(size_t)n * n + i];
+    const double c = cvec[i];
     const bool ok = (g > 0.0) && __builtin_isfinite(g) && __builtin_isfinite(c);
     const double d = ok ? 1.0 / sqrt(g) : 0.0;
     dsc[i] = d;
@@ -2508,12 +2509,13 @@ hipError_t launch_gemvT_rows(const double* A, int64_t lda, const double* u, int6
     return hipGetLastError();
 }
 
-hipError_t launch_chol_large(const double* packed, int n, double alpha, double* S, double* dsc, double* z, double* beta,
-                             int* status, double* minpiv, hipStream_t st) {
+hipError_t launch_chol_large(const double* packed, const double* cvec, int n, double alpha, double* S, double* dsc, double* z,
+                             double* beta, int* status, double* minpiv, hipStream_t st) {
+    if (!cvec) cvec = packed + (size_t)n * n;
     const int np = (n + CHOL_NB - 1) / CHOL_NB * CHOL_NB, npanel = np / CHOL_NB;
     hipError_t e = hipMemsetAsync(status, 0, sizeof(int), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fsnap_chol_prepare_d_k, dim3((np + 255) / 256), dim3(256), 0, st, packed, n, np, alpha, dsc, z, status,
+    hipLaunchKernelGGL(fsnap_chol_prepare_d_k, dim3((np + 255) / 256), dim3(256), 0, st, packed, cvec, n, np, alpha, dsc, z, status,
                        minpiv, npanel);
     hipLaunchKernelGGL(fsnap_chol_prepare_s_k, dim3((np + 255) / 256, np), dim3(256), 0, st, packed, n, np, alpha, dsc, S,
                        status);

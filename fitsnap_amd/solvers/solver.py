@@ -258,9 +258,15 @@ class Solver:
                 s = t.cpu().numpy()
             if pt._rank != 0:
                 continue
-            if G is None:
-                G = self.last_statistics[0]
-            delta, rank, _ = _capi.solve(kind, param, G, s - alpha * beta)
+            rhs = s - alpha * beta
+            if not multi and self._stats_dev is not None and self._stats_host is None:
+                # statistics still in HBM: solve there (large K: blocked Cholesky on the GPU, G never crosses PCIe)
+                dctx, dptr, dK = self._stats_dev
+                delta, rank, _ = dctx.solve_device(kind, param, dK, dptr, rhs=rhs)
+            else:
+                if G is None:
+                    G = self.last_statistics[0]
+                delta, rank, _ = _capi.solve(kind, param, G, rhs)
             if rank < len(beta):        # truncated (rank-deficient) solve: refinement is not meaningful
                 break
             beta = beta + delta

@@ -184,12 +184,18 @@ int fsnap_solve(int kind, double param, int64_t K, const double* G, const double
                 double* rcond_est);
 
 /* Same solve, taking the packed statistics [G | c | ...] from DEVICE memory (the buffer
- * fsnap_normal_eq_async / the all-reduce left in HBM).  By default the statistics are copied
- * to the host and fsnap_solve runs there; with option "device_solve" = 1, K <= 128 and a
- * system that is well conditioned after Jacobi scaling, the factorisation runs on the GPU
- * (one workgroup, matrix in LDS) and only beta crosses PCIe.  Same status codes and semantics as fsnap_solve. */
+ * fsnap_normal_eq_async / the all-reduce left in HBM).  Small systems are copied to the host
+ * (page-locked staging) and solved there (faster than any GPU factorisation of a 128-step recurrence); for
+ * K >= 768 (option "device_solve") a blocked Cholesky runs on the GPU and only beta crosses PCIe, provided the
+ * system is well conditioned after Jacobi scaling -- otherwise the general host path decides.  Same status codes and semantics as fsnap_solve. */
 int fsnap_solve_device(fsnap_ctx* ctx, int kind, double param, int64_t K, const double* d_packed, double* beta,
                        int* rank, double* rcond_est);
+
+/* Same as fsnap_solve_device with the right-hand side replaced by rhs (HOST, K doubles; NULL = the c part of the
+ * packed buffer): G delta = s of an iterative-refinement step (solver.py has no counterpart: the reference's
+ * lstsq works on the rows, see fsnap_residual_rhs) without bringing G to the host. */
+int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, const double* d_packed, const double* rhs,
+                           double* beta, int* rank, double* rcond_est);
 
 /* ---- measurement ------------------------------------------------------------------ */
 

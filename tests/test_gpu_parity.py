@@ -263,6 +263,41 @@ def test_large_k_device_cholesky_matches_host_solve(ctx, K, m):
         assert np.max(np.abs(beta_dev - ref)) / scale < 1e-8
 
 
+@pytest.mark.parametrize("K,m", [(96, 3000), (800, 4000)])
+def test_solve_device_with_replacement_rhs(ctx, K, m):
+    # fsnap_solve_device_rhs: G delta = s (refinement step) with G resident in HBM -- host path (K = 96) and
+    # blocked GPU factorisation (K = 800)
+    rng = np.random.default_rng(900 + K)
+    A = rng.standard_normal((m, K))
+    b = rng.standard_normal(m)
+    ctx.upload_rows(A, b)
+    ctx.set_weights(np.ones(m))
+    ptr = ctx.normal_eq_resident()
+    G, c, _ = ctx.download_packed(ptr, K)
+    rhs = rng.standard_normal(K)
+    x, rank, _ = ctx.solve_device(_capi.SOLVE_RIDGE, 1e-6, K, ptr, rhs=rhs)
+    ref = np.linalg.solve(G + 1e-6 * np.eye(K), rhs)
+    assert rank == K and np.max(np.abs(x - ref)) / np.max(np.abs(ref)) < 1e-9
+    x0, _, _ = ctx.solve_device(_capi.SOLVE_RIDGE, 1e-6, K, ptr)
+    assert np.max(np.abs(x0 - np.linalg.solve(G + 1e-6 * np.eye(K), c))) / np.max(np.abs(x0)) < 1e-9
+    with pytest.raises(ValueError):
+        ctx.solve_device(_capi.SOLVE_RIDGE, 1e-6, K, ptr, rhs=np.zeros(K + 1))
+
+
+def test_svd_fit_large_k_with_refinement_matches_lstsq():
+    # K = 800: statistics, blocked GPU Cholesky and the two refinement solves all stay in HBM
+    rng = np.random.default_rng(800)
+    m, K = 6000, 800
+    A = rng.standard_normal((m, K)) * (10.0 ** rng.uniform(-2, 2, size=K))
+    b = rng.standard_normal(m)
+    w = rng.uniform(0.5, 2.0, m)
+    pt, s = make_solver("SVD")
+    s.perform_fit(A, b, w, trainall=True)
+    ref = orc.svd_fit(A, b, w)
+    assert np.max(np.abs(s.fit - ref) / np.abs(ref)) < 1e-6
+    pt.free()
+
+
 def test_large_k_device_cholesky_falls_back_when_ill_conditioned(ctx):
     # two identical columns: the scaled matrix is singular -> tiny / failed pivot on the GPU -> general host path
     rng = np.random.default_rng(77)
