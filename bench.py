@@ -124,9 +124,13 @@ def main():
 
     def step():
         t0 = time.perf_counter()
-        ctx.normal_eq_async(packed.data_ptr())
-        if world > 1:
-            dist.all_reduce(packed)                       # RCCL over xGMI, same stream
+        if world == 1 and not args.host_solve:
+            ptr = ctx.normal_eq_resident()                # the Solver classes' single-GPU path (context-owned buffer)
+        else:
+            ptr = packed.data_ptr()
+            ctx.normal_eq_async(ptr)
+            if world > 1:
+                dist.all_reduce(packed)                   # RCCL over xGMI, same stream
         t1 = time.perf_counter()
         beta = None
         if args.host_solve:
@@ -137,10 +141,11 @@ def main():
                 h = host.numpy()
                 beta, _, _ = _capi.solve(_capi.SOLVE_RIDGE, ALPHA, h[:Kc * Kc].reshape(Kc, Kc), h[Kc * Kc:Kc * Kc + Kc])
         else:
-            # K x K factorisation on the GPU (same stream); only beta crosses PCIe
+            # fsnap_solve_device: statistics in HBM -> beta (K <= 128: host factorisation of the page-locked mirror the
+            # reduction kernel wrote, or of a D2H copy in the multi-GPU path; K >= 768: blocked Cholesky on the GPU)
             t2 = t1
             if rank == 0:
-                beta, _, _ = ctx.solve_device(_capi.SOLVE_RIDGE, ALPHA, Kc, packed.data_ptr())
+                beta, _, _ = ctx.solve_device(_capi.SOLVE_RIDGE, ALPHA, Kc, ptr)
             else:
                 stream.synchronize()
         t3 = time.perf_counter()

@@ -69,6 +69,10 @@ struct fsnap_ctx {
     DevBuf du, dspart, dsvec;                     // refinement: row weights u, per-workgroup partials, s
     double* pinned = nullptr;                     // page-locked host staging of the packed statistics
     size_t pinned_bytes = 0;
+    double* mirror = nullptr;                     // page-locked host mirror written by the reduction kernel itself
+    size_t mirror_bytes = 0;
+    const double* mirror_of = nullptr;            // device buffer the mirror currently reflects (nullptr = stale)
+    hipEvent_t mirror_ev = nullptr;               // recorded after the reduction that filled the mirror
     // options
     int opt_split = 0;        // 0 = auto
     int opt_nt = 1;
@@ -77,6 +81,7 @@ struct fsnap_ctx {
     int opt_kernel = 0;       // 0 auto | 1 wave-triangle (kernel 1) | 2 LDS-shared, static per-wave bodies | 3 LDS-shared, generic
     int opt_nsplit = 0;       // row splits of the tiled kernel (0 = auto)
     int opt_xcd = 1;          // tiled kernel: contiguous work-item ranges per XCD
+    int opt_mirror = 1;       // fsnap_normal_eq_resident: reduction writes a page-locked host mirror (K <= 128)
     int opt_device_solve = 0; // 0 = auto (K > 256 on the GPU, blocked), 1 = also K <= 128 (fsnap_chol_solve_k), 2 = never
     int opt_ablate = 0;       // timing-only ablation of kernel 1L (diagnostics; results are wrong)
     // timing flags
@@ -305,8 +310,9 @@ int launch_normal_eq_tiled(fsnap_ctx* ctx, double* d_packed) {
     return FSNAP_OK;
 }
 
-int launch_normal_eq(fsnap_ctx* ctx, double* d_packed) {
+int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false) {
     int rc;
+    ctx->mirror_of = nullptr;
     if ((rc = check_rows(ctx)) || (rc = check_weights(ctx))) return rc;
     if (ctx->K > 128 || ctx->opt_tiled) return launch_normal_eq_tiled(ctx, d_packed);
     Geometry g;
@@ -343,9 +349,30 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed) {
     else if (g.lds_waves) FSNAP_HIP(fsnap::launch_syrk_lds(a, ctx->stream), "launch fsnap_syrk_lds");
     else FSNAP_HIP(fsnap::launch_syrk(a, ctx->stream), "launch fsnap_syrk_wave");
     FSNAP_HIP(hipEventRecord(ctx->ev[1], ctx->stream), "hipEventRecord");
-    FSNAP_HIP(fsnap::launch_reduce(a.part, a.cpart, a.spart, g.nblocks, cs_per_block, a.K, d_packed, ctx->stream),
+    // K <= 128 and the context owns the output: the reduction also writes a page-locked host mirror, so the solve
+    // needs no D2H copy (the copy's launch latency was 12 us of a 440 us step)
+    double* mirror = nullptr;
+    if (want_mirror && ctx->opt_mirror) {
+        const size_t need = (size_t)FSNAP_PACKED_LEN(ctx->K) * 8;
+        if (ctx->mirror_bytes < need) {
+            if (ctx->mirror) (void)hipHostFree(ctx->mirror);
+            ctx->mirror = nullptr;
+            ctx->mirror_bytes = 0;
+            // coherent (fine-grained) host memory: the kernel's stores are visible to the host once the event has completed
+            if (hipHostMalloc((void**)&ctx->mirror, need, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
+                ctx->mirror_bytes = need;
+        }
+        if (ctx->mirror && !ctx->mirror_ev && hipEventCreateWithFlags(&ctx->mirror_ev, hipEventDisableTiming) != hipSuccess)
+            ctx->mirror_ev = nullptr;
+        if (ctx->mirror && ctx->mirror_ev) mirror = ctx->mirror;
+    }
+    FSNAP_HIP(fsnap::launch_reduce(a.part, a.cpart, a.spart, g.nblocks, cs_per_block, a.K, d_packed, mirror, ctx->stream),
               "launch fsnap_reduce_partials");
     FSNAP_HIP(hipEventRecord(ctx->ev[2], ctx->stream), "hipEventRecord");
+    if (mirror) {
+        FSNAP_HIP(hipEventRecord(ctx->mirror_ev, ctx->stream), "hipEventRecord");
+        ctx->mirror_of = d_packed;
+    }
     ctx->t_syrk = true;
     return FSNAP_OK;
 }
@@ -428,6 +455,8 @@ int fsnap_ctx_destroy(fsnap_ctx* ctx) {
                       &ctx->du, &ctx->dspart, &ctx->dsvec};
     for (DevBuf* b : bufs) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->mirror) (void)hipHostFree(ctx->mirror);
+    if (ctx->mirror_ev) (void)hipEventDestroy(ctx->mirror_ev);
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -466,6 +495,9 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
         ctx->opt_device_solve = (int)value;
     } else if (!strcmp(key, "tiled")) {
         ctx->opt_tiled = value != 0;
+    } else if (!strcmp(key, "mirror")) {
+        ctx->opt_mirror = value != 0;
+        ctx->mirror_of = nullptr;
     } else if (!strcmp(key, "xcd")) {
         ctx->opt_xcd = value != 0;
     } else if (!strcmp(key, "nsplit")) {
@@ -682,7 +714,7 @@ int fsnap_normal_eq_resident(fsnap_ctx* ctx, double** d_packed) {
     if ((rc = check_rows(ctx))) return rc;
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     if (!ctx->packed.ensure((size_t)FSNAP_PACKED_LEN(ctx->K) * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(packed) failed");
-    if ((rc = launch_normal_eq(ctx, (double*)ctx->packed.p))) return rc;
+    if ((rc = launch_normal_eq(ctx, (double*)ctx->packed.p, true))) return rc;
     *d_packed = (double*)ctx->packed.p;
     return FSNAP_OK;
 }
@@ -858,6 +890,19 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
             }
         }
         // ill-conditioned / indefinite / non-finite: the general host path decides
+    }
+    // statistics already mirrored in page-locked host memory by the reduction kernel: wait for it (polling the
+    // event: the blocking wait's wake-up latency is several microseconds) and solve
+    if (ctx->mirror_of == d_packed && ctx->mirror && K == ctx->K) {
+        while (true) {
+            const hipError_t q = hipEventQuery(ctx->mirror_ev);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return ctx->hipfail(q, "hipEventQuery");
+        }
+        const double* Gm = ctx->mirror;
+        const int rcm = fsnap_solve(kind, param, K, Gm, rhs ? rhs : Gm + K * K, beta, rank, rcond_est);
+        if (rcm) ctx->fail(rcm, "fsnap_solve: numerical status %d", rcm);
+        return rcm;
     }
     // general path: statistics to the host (page-locked staging), full solver
     const size_t need = (size_t)(K * K + K) * 8;

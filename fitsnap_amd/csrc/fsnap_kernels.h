@@ -50,8 +50,9 @@ int syrk_waves_per_simd(int K, int split);
 hipError_t launch_syrk(const SyrkArgs& a, hipStream_t st);
 hipError_t launch_syrk_lds(const SyrkArgs& a, hipStream_t st);
 hipError_t launch_syrk_acc(const SyrkArgs& a, hipStream_t st);
+// mirror: optional page-locked HOST buffer that receives the same packed statistics (zero-copy D2H)
 hipError_t launch_reduce(const double* part, const double* cpart, const double* spart, int nblocks,
-                         int cs_per_block, int K, double* out, hipStream_t st);
+                         int cs_per_block, int K, double* out, double* mirror, hipStream_t st);
 hipError_t launch_syrk_tiled(const TiledArgs& a, hipStream_t st);
 hipError_t launch_reduce_tiled(const TiledArgs& a, double* out, hipStream_t st);
 hipError_t launch_weight_rows(const double* A, int64_t lda, const double* b, const double* w,

@@ -710,7 +710,7 @@ __global__ __launch_bounds__(1024) void fsnap_reduce_partials(const double* __re
                                                               const double* __restrict__ cpart,
                                                               const double* __restrict__ spart, int nblocks,
                                                               int cs_per_block, int NB, int K,
-                                                              double* __restrict__ out) {
+                                                              double* __restrict__ out, double* __restrict__ mirror) {
     // One workgroup (1024 threads) = 16 consecutive elements (one 128-B line per partial)
     // x 64 slices of the partial range; ~585 workgroups at K = 128, every load in flight.
     __shared__ double red[1024];
@@ -771,14 +771,24 @@ __global__ __launch_bounds__(1024) void fsnap_reduce_partials(const double* __re
             if (r < K && c < K) {
                 out[(int64_t)r * K + c] = tot;
                 if (p != q) out[(int64_t)c * K + r] = tot;
+                if (mirror) {        // page-locked host copy written by the same kernel (no separate D2H copy)
+                    mirror[(int64_t)r * K + c] = tot;
+                    if (p != q) mirror[(int64_t)c * K + r] = tot;
+                }
             }
         } else if (idx < nG + nC) {
             int j = idx - nG;
             int cidx = col_of(j >> 4, j & 15, NB);
-            if (cidx < K) out[(int64_t)K * K + cidx] = tot;
+            if (cidx < K) {
+                out[(int64_t)K * K + cidx] = tot;
+                if (mirror) mirror[(int64_t)K * K + cidx] = tot;
+            }
         } else {
             int j = idx - nG - nC;
-            if (j < 3) out[(int64_t)K * K + K + j] = tot;
+            if (j < 3) {
+                out[(int64_t)K * K + K + j] = tot;
+                if (mirror) mirror[(int64_t)K * K + K + j] = tot;
+            }
         }
     }
 }
@@ -2433,11 +2443,11 @@ hipError_t launch_syrk(const SyrkArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_reduce(const double* part, const double* cpart, const double* spart, int nblocks,
-                         int cs_per_block, int K, double* out, hipStream_t st) {
+                         int cs_per_block, int K, double* out, double* mirror, hipStream_t st) {
     const int NB = syrk_num_blocks(K);
     const int nelem = NB * (NB + 1) / 2 * 256 + NB * 16 + 4;
     dim3 grid((unsigned)((nelem + 15) / 16)), block(1024);
-    hipLaunchKernelGGL(fsnap_reduce_partials, grid, block, 0, st, part, cpart, spart, nblocks, cs_per_block, NB, K, out);
+    hipLaunchKernelGGL(fsnap_reduce_partials, grid, block, 0, st, part, cpart, spart, nblocks, cs_per_block, NB, K, out, mirror);
     return hipGetLastError();
 }
 

@@ -69,7 +69,7 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
 /* Tuning knobs (all optional; 0 = auto): "kernel" (1 wave-triangle, 2 LDS-shared rows with
  * per-wave specialised bodies, 3 LDS-shared generic variant), "split" (1|2, sub-waves per row-wave of kernel 1),
  * "nontemporal" (0|1), "nblocks" (workgroups of the SYRK kernel), "tiled" (1 = force the
- * general-K tiled kernel also for K <= 128), "nsplit" (row splits of the tiled kernel), "xcd" (0|1: tiled kernel deals contiguous work-item ranges to each XCD),
+ * general-K tiled kernel also for K <= 128), "nsplit" (row splits of the tiled kernel), "mirror" (0|1, see fsnap_normal_eq_resident), "xcd" (0|1: tiled kernel deals contiguous work-item ranges to each XCD),
  * "device_solve" (fsnap_solve_device: 0 = auto: K >= 768 is factorised on the GPU by the blocked kernels; 1 = every K on the GPU; 2 = never).
  * Unknown key -> FSNAP_E_ARG. */
 int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value);
@@ -145,7 +145,11 @@ int fsnap_normal_eq(fsnap_ctx* ctx, double* G, double* c, double* scalars);
 int fsnap_normal_eq_async(fsnap_ctx* ctx, double* d_packed);
 
 /* Same as fsnap_normal_eq_async into a context-owned device buffer whose address is
- * returned in *d_packed (valid until the next call on this context); asynchronous. */
+ * returned in *d_packed (valid until the next call on this context); asynchronous.
+ * For K <= 128 the reduction kernel also writes the statistics into a page-locked host mirror
+ * (option "mirror", default 1), which fsnap_solve_device uses instead of a D2H copy when it is
+ * handed this same pointer: read-only for the caller -- to modify the buffer (e.g. all-reduce it)
+ * use fsnap_normal_eq_async with a buffer of your own. */
 int fsnap_normal_eq_resident(fsnap_ctx* ctx, double** d_packed);
 
 /* Copy packed statistics from device memory to host arrays (any may be NULL); synchronous. */
