@@ -53,6 +53,7 @@ class Solver:
         self._resident_key = None
         self._stats_host = None      # (G, c, scalars) of the last fit, host ndarrays (after all-reduce)
         self._stats_dev = None       # or (ctx, device address, K) while they are still in HBM only
+        self._stats_keepalive = None  # torch tensor that owns that device address (multi-GPU path)
         self.last_rank = None
         self._checks()
 
@@ -155,6 +156,24 @@ class Solver:
         ctx.set_weights(w_full, None if mask.all() else mask)
         return ctx.normal_eq()
 
+    def _allreduced_packed_device(self, a=None, b=None, w=None, fs_dict=None, trainall=False):
+        """Multi-GPU (nccl = RCCL) path: this rank's fused kernel into a device tensor, all-reduced in place on the
+        same stream.  Returns (packed torch tensor [G | c | scalars] on this rank's GPU, K)."""
+        import torch
+
+        pt = self.pt
+        a, b, w_full, mask, shared_mode = self._resolve_inputs(a, b, w, fs_dict, trainall)
+        if a.ndim != 2:
+            raise ValueError("the A matrix must be 2-D")
+        K = a.shape[1]
+        dev = torch.device("cuda", pt.device_index())
+        packed = torch.zeros(K * K + K + 3, dtype=torch.float64, device=dev)
+        if a.shape[0] > 0:
+            self._local_statistics_async(a, b, w_full, mask, shared_mode, packed.data_ptr(),
+                                         torch.cuda.current_stream(dev).cuda_stream)
+        pt.allreduce_statistics(packed)
+        return packed, K
+
     def _fit_statistics(self, a=None, b=None, w=None, fs_dict=None, trainall=False):
         """mask x weight x normal equations on this rank's GPU, summed over ranks.
 
@@ -212,6 +231,19 @@ class Solver:
         all-reduced statistics are on the host already and rank 0 solves there."""
         pt = self.pt
         if not (pt.stubs or pt._size == 1):
+            if pt._dist.get_backend(pt._group) == "nccl":
+                # kernel -> RCCL all-reduce on the same stream -> rank 0 solves straight from HBM
+                # (fsnap_solve_device: large K is factorised on the GPU, G is downloaded only on demand)
+                packed, K = self._allreduced_packed_device(a, b, w, fs_dict, trainall)
+                self._stats_host = None
+                self._stats_keepalive = packed
+                ctx = pt.hip()
+                self._stats_dev = (ctx, packed.data_ptr(), K)
+                if pt._rank != 0:
+                    return None
+                beta, rank, _ = ctx.solve_device(kind, param, K, packed.data_ptr())
+                self.last_rank = rank
+                return beta
             G, c, _ = self._fit_statistics(a, b, w, fs_dict, trainall)
             return self._solve(kind, param, G, c) if pt._rank == 0 else None
         a, b, w_full, mask, shared_mode = self._resolve_inputs(a, b, w, fs_dict, trainall)
@@ -259,7 +291,7 @@ class Solver:
             if pt._rank != 0:
                 continue
             rhs = s - alpha * beta
-            if not multi and self._stats_dev is not None and self._stats_host is None:
+            if self._stats_dev is not None and self._stats_host is None:
                 # statistics still in HBM: solve there (large K: blocked Cholesky on the GPU, G never crosses PCIe)
                 dctx, dptr, dK = self._stats_dev
                 delta, rank, _ = dctx.solve_device(kind, param, dK, dptr, rhs=rhs)
