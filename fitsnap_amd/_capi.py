@@ -53,6 +53,7 @@ SIGNATURES = {
     "fsnap_predict": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fsnap_residual_rhs": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double)]),
     "fsnap_solve": (c_int, [c_int, c_double, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int), POINTER(c_double)]),
+    "fsnap_error_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "fsnap_solve_device": (c_int, [c_void_p, c_int, c_double, c_int64, c_void_p, c_void_p, POINTER(c_int), POINTER(c_double)]),
     "fsnap_solve_device_rhs": (c_int, [c_void_p, c_int, c_double, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int),
                                         POINTER(c_double)]),
@@ -328,6 +329,19 @@ class HipContext:
         sse = c_double(0.0)
         self._check(self._lib.fsnap_residual_rhs(self._h, _ptr(beta), _ptr(s), byref(sse) if want_sse else None))
         return s, (sse.value if want_sse else None)
+
+    def error_stats(self, beta, cat, ncat: int):
+        """Per-category sums of ``Solver.error_analysis`` for the resident rows (see fsnap_error_stats):
+        returns an (ncat, 10) array."""
+        beta = _f64(beta, "beta").reshape(-1)
+        if beta.shape[0] != self.K:
+            raise ValueError("beta must have K entries")
+        cat = np.ascontiguousarray(cat, dtype=np.int32)
+        if cat.shape != (self.m,):
+            raise ValueError("cat must have one entry per row")
+        stats = np.empty((int(ncat), 10), dtype=np.float64)
+        self._check(self._lib.fsnap_error_stats(self._h, _ptr(beta), _ptr(cat), int(ncat), _ptr(stats)))
+        return stats
 
     def solve_device(self, kind: int, param: float, K: int, d_packed_ptr: int, rhs=None):
         """K x K solve from the packed statistics in HBM; returns (beta, rank, rcond_estimate).

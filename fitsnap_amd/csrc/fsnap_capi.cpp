@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/fsnap_hip.h"
 #include "fsnap_kernels.h"
@@ -66,6 +67,7 @@ struct fsnap_ctx {
     DevBuf st_raw, st_plan, st_frac, st_blank;   // staging of fsnap_assemble
     DevBuf dsolve;                                // [beta | min pivot | status] of fsnap_solve_device
     DevBuf dchol;                                 // padded work matrix of the blocked device Cholesky
+    DevBuf dcat, dstat;                           // fsnap_error_stats: row categories, partial tables + means
     DevBuf du, dspart, dsvec;                     // refinement: row weights u, per-workgroup partials, s
     double* pinned = nullptr;                     // page-locked host staging of the packed statistics
     size_t pinned_bytes = 0;
@@ -451,7 +453,7 @@ int fsnap_ctx_destroy(fsnap_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->ownA, &ctx->ownb, &ctx->ownw, &ctx->ownmask, &ctx->ones, &ctx->part, &ctx->cpart,
                       &ctx->spart, &ctx->packed, &ctx->beta, &ctx->preds, &ctx->sse, &ctx->aw, &ctx->bw,
-                      &ctx->st_raw, &ctx->st_plan, &ctx->st_frac, &ctx->st_blank, &ctx->dsolve, &ctx->dchol,
+                      &ctx->st_raw, &ctx->st_plan, &ctx->st_frac, &ctx->st_blank, &ctx->dsolve, &ctx->dchol, &ctx->dcat, &ctx->dstat,
                       &ctx->du, &ctx->dspart, &ctx->dsvec};
     for (DevBuf* b : bufs) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -802,6 +804,61 @@ int fsnap_predict(fsnap_ctx* ctx, const double* beta, double* preds, double* sse
         *sse = (double)s;
     } else {
         FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    }
+    return FSNAP_OK;
+}
+
+int fsnap_error_stats(fsnap_ctx* ctx, const double* beta, const int32_t* cat, int ncat, double* stats) {
+    if (!ctx) return FSNAP_E_ARG;
+    int rc;
+    if ((rc = check_rows(ctx)) || (rc = check_weights(ctx))) return rc;
+    if (!beta || !cat || !stats || ncat <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_error_stats: bad argument");
+    if (ncat > 3000) return ctx->fail(FSNAP_E_ARG, "fsnap_error_stats: more than 3000 categories");   // LDS table
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    const size_t m = (size_t)ctx->m, K = (size_t)ctx->K;
+    const int nb = fsnap::error_stats_num_blocks(ctx->m);
+    if (!ctx->beta.ensure(K * 8) || !ctx->preds.ensure(m * 8) || !ctx->dcat.ensure(m * 4) ||
+        !ctx->dstat.ensure(((size_t)nb * ncat * 6 + (size_t)ncat * 2) * 8))
+        return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(error statistics) failed");
+    double* d_partial = (double*)ctx->dstat.p;
+    double* d_means = d_partial + (size_t)nb * ncat * 6;
+    FSNAP_HIP(hipMemcpyAsync(ctx->beta.p, beta, K * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(beta)");
+    FSNAP_HIP(hipMemcpyAsync(ctx->dcat.p, cat, m * 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(categories)");
+    FSNAP_HIP(fsnap::launch_gemv_rows(ctx->dA, ctx->lda, (const double*)ctx->beta.p, ctx->m, (int)ctx->K, (double*)ctx->preds.p,
+                                      ctx->db, ctx->dw, nullptr, nullptr, nullptr, ctx->stream),
+              "launch fsnap_gemv_rows_k");
+    std::vector<double> h((size_t)nb * ncat * 6), means((size_t)ncat * 2);
+    // pass 0: counts and sums -> category means
+    FSNAP_HIP(fsnap::launch_error_stats(ctx->db, (const double*)ctx->preds.p, ctx->dw, (const int*)ctx->dcat.p, ctx->m, ncat, 0,
+                                        nullptr, d_partial, ctx->stream),
+              "launch fsnap_error_stats_k");
+    FSNAP_HIP(hipMemcpyAsync(h.data(), d_partial, (size_t)nb * ncat * 4 * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(stats)");
+    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    for (int c = 0; c < ncat; ++c) {
+        long double a0 = 0, a1 = 0, a2 = 0, a3 = 0;   // fixed-order sum of the per-workgroup tables
+        for (int g = 0; g < nb; ++g) {
+            const double* e = h.data() + ((size_t)g * ncat + c) * 4;
+            a0 += e[0]; a1 += e[1]; a2 += e[2]; a3 += e[3];
+        }
+        double* o = stats + (size_t)c * 10;
+        o[0] = (double)a0; o[1] = (double)a1; o[2] = (double)a2; o[3] = (double)a3;
+        means[2 * c] = a0 > 0 ? (double)(a2 / a0) : 0.0;            // (truths / n).sum()
+        means[2 * c + 1] = a1 > 0 ? (double)(a3 / a1) : 0.0;        // (w * truths / n_w).sum()
+    }
+    FSNAP_HIP(hipMemcpyAsync(d_means, means.data(), (size_t)ncat * 2 * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(means)");
+    FSNAP_HIP(fsnap::launch_error_stats(ctx->db, (const double*)ctx->preds.p, ctx->dw, (const int*)ctx->dcat.p, ctx->m, ncat, 1,
+                                        d_means, d_partial, ctx->stream),
+              "launch fsnap_error_stats_k");
+    FSNAP_HIP(hipMemcpyAsync(h.data(), d_partial, (size_t)nb * ncat * 6 * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(stats)");
+    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    for (int c = 0; c < ncat; ++c) {
+        long double a[6] = {0, 0, 0, 0, 0, 0};
+        for (int g = 0; g < nb; ++g) {
+            const double* e = h.data() + ((size_t)g * ncat + c) * 6;
+            for (int k = 0; k < 6; ++k) a[k] += e[k];
+        }
+        double* o = stats + (size_t)c * 10;
+        for (int k = 0; k < 6; ++k) o[4 + k] = (double)a[k];
     }
     return FSNAP_OK;
 }

@@ -2255,6 +2255,52 @@ __global__ __launch_bounds__(1024) void fsnap_chol_sweeps_k(const double* __rest
     for (int i = tid; i < n; i += 1024) beta[i] = z[i] * dsc[i];
 }
 
+// ---------------------------------------------------------------------------------
+// Kernel 9: grouped error statistics of Solver.error_analysis (solver.py:108-133, 391-429).
+// Every row carries a category id (group x train/test x row type, built by the host shim); per category the
+// reference needs  n, count_nonzero(w), mean|r|, sum r^2, sum (t - mean t)^2  and the same for w r, w t
+// (r = truth - prediction).  The centred sums need the category means first, hence two passes:
+//   pass 0:  [n, n_w, sum t, sum w t]                       (4 values per category)
+//   pass 1:  [sum|r|, sum r^2, sum (t - mean)^2, sum|w r|, sum (w r)^2, sum (w t - wmean)^2]   (6 values)
+// A workgroup accumulates its rows into an LDS table (ds_add_f64) and writes one partial table; the host sums the
+// partial tables in a fixed order.  HBM-bound: 8 (t) + 8 (w) + 8 (pred) + 4 (cat) bytes per row and pass.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsnap_error_stats_k(const double* __restrict__ truth,
+                                                          const double* __restrict__ pred,
+                                                          const double* __restrict__ wgt, const int* __restrict__ cat,
+                                                          int64_t m, int ncat, int pass,
+                                                          const double* __restrict__ means /* [ncat][2] */,
+                                                          double* __restrict__ partial /* [grid][ncat][nv] */) {
+    extern __shared__ double tab[];
+    const int nv = pass == 0 ? 4 : 6;
+    for (int i = threadIdx.x; i < ncat * nv; i += 256) tab[i] = 0.0;
+    __syncthreads();
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < m; row += (int64_t)gridDim.x * 256) {
+        const int c = cat[row];
+        if (c < 0 || c >= ncat) continue;
+        const double t = truth[row], w = wgt[row];
+        double* e = tab + (size_t)c * nv;
+        if (pass == 0) {
+            atomicAdd(e + 0, 1.0);
+            atomicAdd(e + 1, w != 0.0 ? 1.0 : 0.0);
+            atomicAdd(e + 2, t);
+            atomicAdd(e + 3, w * t);
+        } else {
+            const double r = t - pred[row], wr = w * r;
+            const double dt = t - means[2 * c], dwt = w * t - means[2 * c + 1];
+            atomicAdd(e + 0, fabs(r));
+            atomicAdd(e + 1, r * r);
+            atomicAdd(e + 2, dt * dt);
+            atomicAdd(e + 3, fabs(wr));
+            atomicAdd(e + 4, wr * wr);
+            atomicAdd(e + 5, dwt * dwt);
+        }
+    }
+    __syncthreads();
+    double* out = partial + (size_t)blockIdx.x * ncat * nv;
+    for (int i = threadIdx.x; i < ncat * nv; i += 256) out[i] = tab[i];
+}
+
 namespace fsnap {
 
 int syrk_num_blocks(int K) { return (K + 15) / 16; }
@@ -2516,6 +2562,29 @@ hipError_t launch_gemvT_rows(const double* A, int64_t lda, const double* u, int6
     }
     hipLaunchKernelGGL(fsnap_gemvT_rows_k, dim3((unsigned)nb), dim3(256), lds, st, A, lda, u, m, K, rpw, partial);
     hipLaunchKernelGGL(fsnap_colsum_partials_k, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, partial, nb, K, out);
+    return hipGetLastError();
+}
+
+int error_stats_num_blocks(int64_t m) {
+    int64_t nb = (m + 256 * 16 - 1) / (256 * 16);
+    if (nb > 512) nb = 512;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+hipError_t launch_error_stats(const double* truth, const double* pred, const double* wgt, const int* cat, int64_t m, int ncat,
+                              int pass, const double* means, double* partial, hipStream_t st) {
+    const int nv = pass == 0 ? 4 : 6;
+    const size_t lds = (size_t)ncat * nv * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)fsnap_error_stats_k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024 - 64);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fsnap_error_stats_k, dim3((unsigned)error_stats_num_blocks(m)), dim3(256), lds, st, truth, pred, wgt, cat,
+                       m, ncat, pass, means, partial);
     return hipGetLastError();
 }
 

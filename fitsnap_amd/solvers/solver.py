@@ -54,6 +54,7 @@ class Solver:
         self._stats_host = None      # (G, c, scalars) of the last fit, host ndarrays (after all-reduce)
         self._stats_dev = None       # or (ctx, device address, K) while they are still in HBM only
         self._stats_keepalive = None  # torch tensor that owns that device address (multi-GPU path)
+        self.device_error_stats = True  # error_analysis: grouped reductions on the GPU (False = pandas groupby)
         self.last_rank = None
         self._checks()
 
@@ -367,6 +368,49 @@ class Solver:
         return Series({"ncount": nconfig, "mae": mae, "rmse": rmse, "rsq": rsq, "w_ncount": w_nconfig,
                        "w_mae": w_mae, "w_rmse": w_rmse, "w_rsq": w_rsq})
 
+    @staticmethod
+    def _metrics_from_sums(n, nw, st, swt, sar, srr, sct, sawr, swrr, scwt):
+        """The eight numbers of solver.py:119-133 from the ten sums of fsnap_error_stats (arrays, one entry per
+        group).  Same quirks: w_mae divides by ALL rows, w_rmse by the rows with non-zero weight."""
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return {"ncount": n, "mae": sar / n, "rmse": np.sqrt(srr / n), "rsq": 1 - srr / sct,
+                    "w_ncount": nw, "w_mae": sawr / n, "w_rmse": np.sqrt(swrr / nw), "w_rsq": 1 - swrr / scwt}
+
+    def _device_error_tables(self, a, b, w, shared):
+        """(per-group table, *ALL table) of solver.py:391-405, built from fsnap_error_stats."""
+        from pandas import DataFrame, MultiIndex
+
+        ctx = self.pt.hip()                                 # predict_rows() has just made these rows resident
+        if ctx.m != len(self.df.index):
+            ctx = self._upload(a, np.asarray(b), shared)
+        ctx.set_weights(np.asarray(w, dtype=np.float64))
+        gb = self.df.groupby(["Groups", "Testing", "Row_Type"], sort=True)
+        cat = gb.ngroup().to_numpy(dtype=np.int32)
+        keys = list(gb.size().index)                       # sorted group keys, position = category id
+        st = ctx.error_stats(np.asarray(self.fit, dtype=np.float64).reshape(-1), cat, len(keys))
+        n, nw, s_t, s_wt = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
+        grouped = DataFrame(self._metrics_from_sums(n, nw, s_t, s_wt, st[:, 4], st[:, 5], st[:, 6], st[:, 7], st[:, 8], st[:, 9]),
+                            index=MultiIndex.from_tuples(keys, names=["Groups", "Testing", "Row_Type"]))
+        # *ALL rows: merge the groups of one (Testing, Row_Type); centred sums are re-centred on the pooled mean:
+        # sum (x - M)^2 = sum_c [ S_c + 2 (mu_c - M) (sum x_c - n_c mu_c) + n_c (mu_c - M)^2 ]
+        sub = sorted({(k[1], k[2]) for k in keys})
+        rows = {name: [] for name in ("ncount", "mae", "rmse", "rsq", "w_ncount", "w_mae", "w_rmse", "w_rsq")}
+        for tk in sub:
+            idx = np.array([i for i, k in enumerate(keys) if (k[1], k[2]) == tk])
+            N, NW = n[idx].sum(), nw[idx].sum()
+            with np.errstate(divide="ignore", invalid="ignore"):
+                mu_c, M = s_t[idx] / n[idx], s_t[idx].sum() / N
+                wmu_c = np.where(nw[idx] > 0, s_wt[idx] / np.where(nw[idx] > 0, nw[idx], 1), 0.0)
+                WM = s_wt[idx].sum() / NW
+            sct = np.sum(st[idx, 6] + 2 * (mu_c - M) * (s_t[idx] - n[idx] * mu_c) + n[idx] * (mu_c - M) ** 2)
+            scwt = np.sum(st[idx, 9] + 2 * (wmu_c - WM) * (s_wt[idx] - n[idx] * wmu_c) + n[idx] * (wmu_c - WM) ** 2)
+            mets = self._metrics_from_sums(N, NW, s_t[idx].sum(), s_wt[idx].sum(), st[idx, 4].sum(), st[idx, 5].sum(), sct,
+                                           st[idx, 7].sum(), st[idx, 8].sum(), scwt)
+            for name in rows:
+                rows[name].append(mets[name])
+        allrows = DataFrame(rows, index=MultiIndex.from_tuples(sub, names=["Testing", "Row_Type"]))
+        return grouped, allrows
+
     def predict_rows(self, a=None, b=None):
         """``preds = a @ self.fit`` (solver.py:377) on the GPU (streaming GEMV kernel)."""
         if a is None:
@@ -444,10 +488,17 @@ class Solver:
             fn = self._ncount_mae_rmse_rsq_unweighted_and_weighted
             cols = [["ncount", "mae", "rmse", "rsq"], ["w_ncount", "w_mae", "w_rmse", "w_rsq"]]
             ren = {"w_ncount": "ncount", "w_mae": "mae", "w_rmse": "rmse", "w_rsq": "rsq"}
-            grouped = self.df.groupby(["Groups", "Testing", "Row_Type"])[["truths", "preds", "weights"]].apply(fn)
+            if not multi and self.device_error_stats:
+                # single GPU: the rows are resident -- predictions and the grouped reductions run on the GPU
+                # (fsnap_error_stats); only the (groups x 10) table of sums comes back
+                grouped, allrows = self._device_error_tables(a, b, w, shared)
+            else:
+                grouped = self.df.groupby(["Groups", "Testing", "Row_Type"])[["truths", "preds", "weights"]].apply(fn)
+                allrows = None
             grouped = concat({"Unweighted": grouped[cols[0]], "weighted": grouped[cols[1]].rename(columns=ren)},
                              names=["Weighting"]).reorder_levels(["Groups", "Weighting", "Testing", "Row_Type"]).sort_index()
-            allrows = self.df.groupby(["Testing", "Row_Type"])[["truths", "preds", "weights"]].apply(fn)
+            if allrows is None:
+                allrows = self.df.groupby(["Testing", "Row_Type"])[["truths", "preds", "weights"]].apply(fn)
             allrows = concat({"Unweighted": allrows[cols[0]], "weighted": allrows[cols[1]].rename(columns=ren)},
                              names=["Weighting"]).reorder_levels(["Weighting", "Testing", "Row_Type"]).sort_index()
             self.errors = concat([concat({"*ALL": allrows}, names=["Groups"]), grouped])

@@ -201,6 +201,15 @@ int fsnap_solve_device(fsnap_ctx* ctx, int kind, double param, int64_t K, const 
 int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, const double* d_packed, const double* rhs,
                            double* beta, int* rank, double* rcond_est);
 
+/* Grouped error statistics of Solver.error_analysis (solver.py:108-133: the function applied to every
+ * (Groups, Testing, Row_Type) group of the DataFrame, solver.py:391-405) for the resident rows and weights:
+ * cat[m] (host) = category id of each row in [0, ncat) (negative = skip), beta = coefficients.
+ * stats[ncat][10] (host) = n, count_nonzero(w), sum t, sum w t, sum|r|, sum r^2, sum (t - mean t)^2,
+ * sum|w r|, sum (w r)^2, sum (w t - sum(w t)/n_w)^2 with r = t - a.beta; mae = sum|r| / n,
+ * rmse = sqrt(sum r^2 / n), rsq = 1 - sum r^2 / sum (t - mean)^2 (weighted: w_mae = sum|w r| / n,
+ * w_rmse = sqrt(sum (w r)^2 / n_w), ...).  Predictions (GEMV) and both reduction passes run on the GPU. */
+int fsnap_error_stats(fsnap_ctx* ctx, const double* beta, const int32_t* cat, int ncat, double* stats);
+
 /* ---- measurement ------------------------------------------------------------------ */
 
 /* HIP-event timings of the last fsnap_normal_eq* call, milliseconds:

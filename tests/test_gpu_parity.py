@@ -743,3 +743,46 @@ def test_refinement_on_ill_conditioned_problem(kappa):
     s.perform_fit(X, y, w, trainall=True)
     assert np.max(np.abs(s.fit - ref)) / np.max(np.abs(ref)) < 1e-6
     pt.free()
+
+
+def test_error_stats_kernel_matches_numpy(ctx):
+    # fsnap_error_stats: the ten per-category sums vs a direct numpy evaluation (two-pass centred sums)
+    rng = np.random.default_rng(321)
+    m, K, ncat = 50021, 40, 37
+    A = rng.standard_normal((m, K))
+    b = rng.standard_normal(m) * 50 + 1000.0          # large mean: the centred sums must not cancel
+    w = rng.choice([0.0, 1.0, 1e-3, 250.0], size=m)
+    beta = rng.standard_normal(K)
+    cat = rng.integers(-1, ncat, size=m).astype(np.int32)   # -1 = row not in any category
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w)
+    st = ctx.error_stats(beta, cat, ncat)
+    r = b - A @ beta
+    for c in range(ncat):
+        sel = cat == c
+        t, ww, rr = b[sel], w[sel], r[sel]
+        n, nw = sel.sum(), np.count_nonzero(ww)
+        ref = [n, nw, t.sum(), (ww * t).sum(), np.abs(rr).sum(), (rr ** 2).sum(), ((t - t.sum() / n) ** 2).sum(),
+               np.abs(ww * rr).sum(), ((ww * rr) ** 2).sum(), ((ww * t - (ww * t).sum() / max(nw, 1)) ** 2).sum()]
+        assert st[c, 0] == n and st[c, 1] == nw
+        assert np.allclose(st[c, 2:], ref[2:], rtol=1e-11, atol=0)
+
+
+def test_error_analysis_device_and_pandas_paths_agree(ta, ta_fits):
+    A, b, w = ta
+    t = ta_fits["testing_mask"]
+    row_type = ["Energy"] * 363 + ["Force"] * 12672 + ["Stress"] * 2178
+    fsd = {"Groups": [str(g) for g in ta_fits["ea_groups"]], "Testing": t.tolist(), "Row_Type": row_type}
+    tables = []
+    for device in (True, False):
+        pt, s = make_solver("SVD")
+        s.device_error_stats = device
+        s.perform_fit(A, b, w[~t], fs_dict=fsd)
+        s.error_analysis(A, b, w, fsd)
+        tables.append(s.errors)
+        pt.free()
+    assert list(tables[0].index) == list(tables[1].index)
+    x = tables[0][["ncount", "mae", "rmse", "rsq"]].to_numpy(dtype=np.float64)
+    y = tables[1][["ncount", "mae", "rmse", "rsq"]].to_numpy(dtype=np.float64)
+    ok = np.isclose(x, y, rtol=1e-9, atol=1e-300) | (np.isnan(x) & np.isnan(y)) | (np.isinf(x) & np.isinf(y))
+    assert ok.all()
