@@ -601,16 +601,32 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
     double bb = 0.0, sbw = 0.0;
     unsigned cnt = 0;
 
+    // FSNAP_ACC_DEPTH raw sets in flight (3 by default; 4 = one more chunk of prefetch, tools/syrk_trace.hip A/B)
+#ifndef FSNAP_ACC_DEPTH
+#define FSNAP_ACC_DEPTH 3
+#endif
     RawM<NB> r0, r1, r2;
+#if FSNAP_ACC_DEPTH == 4
+    RawM<NB> r3;
+#endif
     constexpr auto rows = std::make_integer_sequence<int, NB>{};
     if (ncl > 0) {
         const unsigned m0 = load_mask(wb, 0, kr) ? 1u : 0u, m1 = load_mask(wb, 1, kr) ? 1u : 0u;
         const unsigned m2 = load_mask(wb, 2, kr) ? 1u : 0u;
+#if FSNAP_ACC_DEPTH == 4
+        const unsigned m3 = load_mask(wb, 3, kr) ? 1u : 0u;
+        unsigned mk = load_mask(wb, 4, kr);
+        cnt = m0 + m1 + m2 + m3;
+#else
         unsigned mk = load_mask(wb, 3, kr);
         cnt = m0 + m1 + m2;
+#endif
         issue_masked<NB, NT>(r0, wb, 0, m0);
         issue_masked<NB, NT>(r1, wb, 1, m1);
         issue_masked<NB, NT>(r2, wb, 2, m2);
+#if FSNAP_ACC_DEPTH == 4
+        issue_masked<NB, NT>(r3, wb, 3, m3);
+#endif
         {   // chunk 0 -> V
             const double wv = __builtin_bit_cast(double, r0.wv);
             const double wbv = wv * __builtin_bit_cast(double, r0.bv);
@@ -623,13 +639,22 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
             }
         }
         // step cl: MFMAs of chunk cl (in V), V <- chunk cl+1, refill of the raw set freed one step ago with chunk
-        // cl+3.  Chunk slots past the wave's range read zeros through the bounds-checked descriptors.
+        // cl+DEPTH.  Chunk slots past the wave's range read zeros through the bounds-checked descriptors.
         double wbp = 0.0;   // chunk 0 is fully accounted for by the prologue
+#if FSNAP_ACC_DEPTH == 4
+        for (unsigned cl = 0; cl < ncl; cl += 4) {
+            acc_step<NB, FULLK, NT>(V, vt, r0, r1, wb, cl + 4, mk, cnt, K, e, kr, cacc, bb, sbw, wbp, rows);
+            acc_step<NB, FULLK, NT>(V, vt, r1, r2, wb, cl + 5, mk, cnt, K, e, kr, cacc, bb, sbw, wbp, rows);
+            acc_step<NB, FULLK, NT>(V, vt, r2, r3, wb, cl + 6, mk, cnt, K, e, kr, cacc, bb, sbw, wbp, rows);
+            acc_step<NB, FULLK, NT>(V, vt, r3, r0, wb, cl + 7, mk, cnt, K, e, kr, cacc, bb, sbw, wbp, rows);
+        }
+#else
         for (unsigned cl = 0; cl < ncl; cl += 3) {
             acc_step<NB, FULLK, NT>(V, vt, r0, r1, wb, cl + 3, mk, cnt, K, e, kr, cacc, bb, sbw, wbp, rows);
             acc_step<NB, FULLK, NT>(V, vt, r1, r2, wb, cl + 4, mk, cnt, K, e, kr, cacc, bb, sbw, wbp, rows);
             acc_step<NB, FULLK, NT>(V, vt, r2, r0, wb, cl + 5, mk, cnt, K, e, kr, cacc, bb, sbw, wbp, rows);
         }
+#endif
         cacc[NB - 1] = __builtin_fma(V[NB - 1], wbp, cacc[NB - 1]);   // last prepared chunk (zeros past the range)
     }
     // the last MFMAs (16 passes) must have left the pipe before their accumulators are read
