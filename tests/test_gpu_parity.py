@@ -786,3 +786,42 @@ def test_error_analysis_device_and_pandas_paths_agree(ta, ta_fits):
     y = tables[1][["ncount", "mae", "rmse", "rsq"]].to_numpy(dtype=np.float64)
     ok = np.isclose(x, y, rtol=1e-9, atol=1e-300) | (np.isnan(x) & np.isnan(y)) | (np.isinf(x) & np.isinf(y))
     assert ok.all()
+
+
+@pytest.mark.parametrize("K", [100, 128])
+def test_one_wave_triangle_kernel_masked_rows_may_hold_garbage(ctx, K):
+    # kernel 1A applies the row mask through out-of-range load offsets: NaN / Inf in A, b AND w of test rows must not
+    # reach the statistics (the reference drops those rows by fancy indexing, svd.py:44-46)
+    rng = np.random.default_rng(50 + K)
+    m = 20003
+    A = rng.standard_normal((m, K))
+    b = rng.standard_normal(m)
+    w = rng.uniform(0.5, 2.0, m)
+    t = rng.random(m) < 0.25
+    A2, b2, w2 = A.copy(), b.copy(), w.copy()
+    A2[t] = np.nan
+    b2[t] = np.inf
+    w2[t] = -np.inf
+    G, c, s = run_stats(ctx, A2, b2, w2, t)
+    assert ctx.launch_info()["kernel_or_pairs"] == 3
+    stats_close(G, c, s, *orc.normal_eq(A, b, w, t))
+    assert np.isfinite(G).all() and np.isfinite(c).all() and np.isfinite(s).all()
+
+
+def test_one_wave_triangle_kernel_strided_rows(ctx):
+    # rows bound in place (fsnap_bind_rows): odd leading dimension, first column at a 24-byte offset -> rows are only
+    # 8-byte aligned and the 16-byte buffer loads straddle them
+    import torch
+    rng = np.random.default_rng(8)
+    big = rng.standard_normal((9001, 131))
+    A = np.ascontiguousarray(big[:, 3:103])         # K = 100 view of the 131-wide rows
+    b = rng.standard_normal(9001)
+    w = rng.uniform(0.1, 3, 9001)
+    dev = torch.device("cuda", 0)
+    dbig = torch.from_numpy(big).to(dev)
+    db = torch.from_numpy(b).to(dev)
+    ctx.bind_rows(dbig.data_ptr() + 3 * 8, 9001, 100, 131, db.data_ptr())
+    ctx.set_weights(w)
+    G, c, s = ctx.normal_eq()
+    assert ctx.launch_info()["kernel_or_pairs"] == 3
+    stats_close(G, c, s, *orc.normal_eq(A, b, w))
