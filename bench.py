@@ -8,8 +8,17 @@
 
 One "step" = one complete fit of the resident rows: fused mask x weight x fp64-MFMA normal
 equations on every GPU, (N > 1) RCCL all-reduce of the packed K x K statistics, K x K ridge
-solve on the GPU of rank 0 (single-workgroup Cholesky), D2H of beta -> beta on the host.  A, b, w are resident in HBM
-before the timed region (the PCIe-inclusive rate is reported separately, never as `value`).
+solve by rank 0 through fsnap_solve_device (K = 128: Jacobi-scaled Cholesky on the host from the
+page-locked mirror the reduction kernel wrote; K >= 768: blocked Cholesky on the GPU) -> beta on
+the host.  A, b, w are resident in HBM before the timed region (the PCIe-inclusive rate is
+reported separately, never as `value`).
+
+Steady state: an MI355X that has been idle needs ~35 ms of sustained load before its clocks
+settle (scripts/ramptest.py: SYRK kernel 1.2 ms on the very first steps, 0.35 ms after 10 ms,
+0.293 ms from ~35 ms on).  Before the W warm-up steps the benchmark therefore runs `--preheat`
+(default 300) additional UNTIMED steps of the same workload -- a fixed count, so that every rank
+of a multi-GPU run executes the same number of collectives.  The timed region is still exactly
+K steps between barrier + synchronize.
 Weak scaling: every rank owns 10^6 rows of its own (disjoint synthetic row blocks);
 value = N * rows_per_gpu * steps / max-over-ranks wall time.
 
@@ -43,6 +52,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--preheat", type=int, default=300,
+                    help="untimed steps before the warm-up, to bring the GPU to its steady clock (0 = none)")
     ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default: BASELINE config)")
     ap.add_argument("--cols", type=int, default=K)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -159,6 +170,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(max(0, args.preheat)):
+        step()
     for _ in range(args.warmup):
         step()
     fence()
@@ -230,6 +243,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "preheat_steps": max(0, args.preheat),
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",

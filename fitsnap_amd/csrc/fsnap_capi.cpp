@@ -913,7 +913,7 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
             if (ctx->pinned) (void)hipHostFree(ctx->pinned);
             ctx->pinned = nullptr;
             ctx->pinned_bytes = 0;
-            if (hipHostMalloc((void**)&ctx->pinned, head * 8, hipHostMallocDefault) != hipSuccess)
+            if (hipHostMalloc((void**)&ctx->pinned, head * 8, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess)
                 return ctx->fail(FSNAP_E_NOMEM, "hipHostMalloc(%zu) failed", head * 8);
             ctx->pinned_bytes = head * 8;
         }
@@ -967,12 +967,28 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
         ctx->pinned = nullptr;
         ctx->pinned_bytes = 0;
-        if (hipHostMalloc((void**)&ctx->pinned, need, hipHostMallocDefault) != hipSuccess)
+        if (hipHostMalloc((void**)&ctx->pinned, need, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess)
             return ctx->fail(FSNAP_E_NOMEM, "hipHostMalloc(%zu) failed", need);
         ctx->pinned_bytes = need;
     }
-    FSNAP_HIP(hipMemcpyAsync(ctx->pinned, d_packed, need, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(G)");
-    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    if (need <= (1u << 20) && ctx->opt_mirror) {
+        // small statistics (e.g. the all-reduced buffer of the multi-GPU path): copy kernel into the page-locked
+        // staging + event poll instead of the copy engine + blocking wait
+        if (!ctx->mirror_ev && hipEventCreateWithFlags(&ctx->mirror_ev, hipEventDisableTiming) != hipSuccess)
+            ctx->mirror_ev = nullptr;
+    }
+    if (need <= (1u << 20) && ctx->opt_mirror && ctx->mirror_ev) {
+        FSNAP_HIP(fsnap::launch_copy_to_host(d_packed, ctx->pinned, (int64_t)(need / 8), ctx->stream), "launch fsnap_copy_to_host_k");
+        FSNAP_HIP(hipEventRecord(ctx->mirror_ev, ctx->stream), "hipEventRecord");
+        while (true) {
+            const hipError_t q = hipEventQuery(ctx->mirror_ev);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return ctx->hipfail(q, "hipEventQuery");
+        }
+    } else {
+        FSNAP_HIP(hipMemcpyAsync(ctx->pinned, d_packed, need, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(G)");
+        FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    }
     const double* G = ctx->pinned;
     const int rc = fsnap_solve(kind, param, K, G, rhs ? rhs : G + K * K, beta, rank, rcond_est);
     if (rc) ctx->fail(rc, "fsnap_solve: numerical status %d", rc);
