@@ -53,6 +53,7 @@ SIGNATURES = {
     "fsnap_predict": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fsnap_residual_rhs": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double)]),
     "fsnap_solve": (c_int, [c_int, c_double, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int), POINTER(c_double)]),
+    "fsnap_normal_eq_accumulate": (c_int, [c_void_p, c_void_p]),
     "fsnap_error_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "fsnap_solve_device": (c_int, [c_void_p, c_int, c_double, c_int64, c_void_p, c_void_p, POINTER(c_int), POINTER(c_double)]),
     "fsnap_solve_device_rhs": (c_int, [c_void_p, c_int, c_double, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int),
@@ -329,6 +330,10 @@ class HipContext:
         sse = c_double(0.0)
         self._check(self._lib.fsnap_residual_rhs(self._h, _ptr(beta), _ptr(s), byref(sse) if want_sse else None))
         return s, (sse.value if want_sse else None)
+
+    def normal_eq_accumulate(self, d_packed_ptr: int):
+        """d_packed (device) += statistics of the resident rows (streaming / transpose-trick accumulation)."""
+        self._check(self._lib.fsnap_normal_eq_accumulate(self._h, c_void_p(d_packed_ptr)))
 
     def error_stats(self, beta, cat, ncat: int):
         """Per-category sums of ``Solver.error_analysis`` for the resident rows (see fsnap_error_stats):

@@ -270,7 +270,7 @@ int plan_tiled(fsnap_ctx* ctx, TiledGeometry* g) {
     return FSNAP_OK;
 }
 
-int launch_normal_eq_tiled(fsnap_ctx* ctx, double* d_packed) {
+int launch_normal_eq_tiled(fsnap_ctx* ctx, double* d_packed, bool accumulate) {
     int rc;
     TiledGeometry g;
     if ((rc = plan_tiled(ctx, &g))) return rc;
@@ -306,17 +306,17 @@ int launch_normal_eq_tiled(fsnap_ctx* ctx, double* d_packed) {
     FSNAP_HIP(hipEventRecord(ctx->ev[0], ctx->stream), "hipEventRecord");
     FSNAP_HIP(fsnap::launch_syrk_tiled(a, ctx->stream), "launch fsnap_syrk_tiled");
     FSNAP_HIP(hipEventRecord(ctx->ev[1], ctx->stream), "hipEventRecord");
-    FSNAP_HIP(fsnap::launch_reduce_tiled(a, d_packed, ctx->stream), "launch fsnap_reduce_tiled");
+    FSNAP_HIP(fsnap::launch_reduce_tiled(a, d_packed, accumulate, ctx->stream), "launch fsnap_reduce_tiled");
     FSNAP_HIP(hipEventRecord(ctx->ev[2], ctx->stream), "hipEventRecord");
     ctx->t_syrk = true;
     return FSNAP_OK;
 }
 
-int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false) {
+int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false, bool accumulate = false) {
     int rc;
     ctx->mirror_of = nullptr;
     if ((rc = check_rows(ctx)) || (rc = check_weights(ctx))) return rc;
-    if (ctx->K > 128 || ctx->opt_tiled) return launch_normal_eq_tiled(ctx, d_packed);
+    if (ctx->K > 128 || ctx->opt_tiled) return launch_normal_eq_tiled(ctx, d_packed, accumulate);
     Geometry g;
     if ((rc = plan_geometry(ctx, &g))) return rc;
     const unsigned char* mask = ctx->dmask;
@@ -368,7 +368,8 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false)
             ctx->mirror_ev = nullptr;
         if (ctx->mirror && ctx->mirror_ev) mirror = ctx->mirror;
     }
-    FSNAP_HIP(fsnap::launch_reduce(a.part, a.cpart, a.spart, g.nblocks, cs_per_block, a.K, d_packed, mirror, ctx->stream),
+    FSNAP_HIP(fsnap::launch_reduce(a.part, a.cpart, a.spart, g.nblocks, cs_per_block, a.K, d_packed, mirror, accumulate,
+                                   ctx->stream),
               "launch fsnap_reduce_partials");
     FSNAP_HIP(hipEventRecord(ctx->ev[2], ctx->stream), "hipEventRecord");
     if (mirror) {
@@ -707,6 +708,15 @@ int fsnap_normal_eq(fsnap_ctx* ctx, double* G, double* c, double* scalars) {
         FSNAP_HIP(hipMemcpyAsync(scalars, dp + K * K + K, 3 * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(scalars)");
     FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     return FSNAP_OK;
+}
+
+int fsnap_normal_eq_accumulate(fsnap_ctx* ctx, double* d_packed) {
+    if (!ctx) return FSNAP_E_ARG;
+    if (!d_packed) return ctx->fail(FSNAP_E_ARG, "fsnap_normal_eq_accumulate: d_packed is NULL");
+    int rc;
+    if ((rc = check_rows(ctx))) return rc;
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    return launch_normal_eq(ctx, d_packed, false, true);
 }
 
 int fsnap_normal_eq_resident(fsnap_ctx* ctx, double** d_packed) {

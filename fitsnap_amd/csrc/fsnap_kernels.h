@@ -51,10 +51,11 @@ hipError_t launch_syrk(const SyrkArgs& a, hipStream_t st);
 hipError_t launch_syrk_lds(const SyrkArgs& a, hipStream_t st);
 hipError_t launch_syrk_acc(const SyrkArgs& a, hipStream_t st);
 // mirror: optional page-locked HOST buffer that receives the same packed statistics (zero-copy D2H)
+// accumulate: out += statistics instead of out = statistics
 hipError_t launch_reduce(const double* part, const double* cpart, const double* spart, int nblocks,
-                         int cs_per_block, int K, double* out, double* mirror, hipStream_t st);
+                         int cs_per_block, int K, double* out, double* mirror, bool accumulate, hipStream_t st);
 hipError_t launch_syrk_tiled(const TiledArgs& a, hipStream_t st);
-hipError_t launch_reduce_tiled(const TiledArgs& a, double* out, hipStream_t st);
+hipError_t launch_reduce_tiled(const TiledArgs& a, double* out, bool accumulate, hipStream_t st);
 hipError_t launch_weight_rows(const double* A, int64_t lda, const double* b, const double* w,
                               const unsigned char* mask, int64_t m, int K, double* aw, int64_t ldaw, double* bw,
                               hipStream_t st);

@@ -735,7 +735,8 @@ __global__ __launch_bounds__(1024) void fsnap_reduce_partials(const double* __re
                                                               const double* __restrict__ cpart,
                                                               const double* __restrict__ spart, int nblocks,
                                                               int cs_per_block, int NB, int K,
-                                                              double* __restrict__ out, double* __restrict__ mirror) {
+                                                              double* __restrict__ out, double* __restrict__ mirror,
+                                                              int accumulate) {
     // One workgroup (1024 threads) = 16 consecutive elements (one 128-B line per partial)
     // x 64 slices of the partial range; ~585 workgroups at K = 128, every load in flight.
     __shared__ double red[1024];
@@ -794,25 +795,30 @@ __global__ __launch_bounds__(1024) void fsnap_reduce_partials(const double* __re
             int ep = (ln >> 4) + 4 * i, eq = ln & 15;
             int r = col_of(p, ep, NB), c = col_of(q, eq, NB);
             if (r < K && c < K) {
-                out[(int64_t)r * K + c] = tot;
-                if (p != q) out[(int64_t)c * K + r] = tot;
+                // accumulate: out += statistics of these rows (streaming per-batch accumulation, the reference's
+                // `c += cm; d += dm`, transpose_trick/example.py:236-237); (r, c) and (c, r) hold equal values
+                const double val = accumulate ? out[(int64_t)r * K + c] + tot : tot;
+                out[(int64_t)r * K + c] = val;
+                if (p != q) out[(int64_t)c * K + r] = val;
                 if (mirror) {        // page-locked host copy written by the same kernel (no separate D2H copy)
-                    mirror[(int64_t)r * K + c] = tot;
-                    if (p != q) mirror[(int64_t)c * K + r] = tot;
+                    mirror[(int64_t)r * K + c] = val;
+                    if (p != q) mirror[(int64_t)c * K + r] = val;
                 }
             }
         } else if (idx < nG + nC) {
             int j = idx - nG;
             int cidx = col_of(j >> 4, j & 15, NB);
             if (cidx < K) {
-                out[(int64_t)K * K + cidx] = tot;
-                if (mirror) mirror[(int64_t)K * K + cidx] = tot;
+                const double val = accumulate ? out[(int64_t)K * K + cidx] + tot : tot;
+                out[(int64_t)K * K + cidx] = val;
+                if (mirror) mirror[(int64_t)K * K + cidx] = val;
             }
         } else {
             int j = idx - nG - nC;
             if (j < 3) {
-                out[(int64_t)K * K + K + j] = tot;
-                if (mirror) mirror[(int64_t)K * K + K + j] = tot;
+                const double val = accumulate ? out[(int64_t)K * K + K + j] + tot : tot;
+                out[(int64_t)K * K + K + j] = val;
+                if (mirror) mirror[(int64_t)K * K + K + j] = val;
             }
         }
     }
@@ -1547,7 +1553,7 @@ __global__ __launch_bounds__(256, 2) void fsnap_syrk_tiled(const double* __restr
 __global__ __launch_bounds__(1024) void fsnap_reduce_tiled(const double* __restrict__ part,
                                                            const double* __restrict__ cpart,
                                                            const double* __restrict__ spart, int nsplit, int NSB,
-                                                           int npairs, int K, double* __restrict__ out) {
+                                                           int npairs, int K, double* __restrict__ out, int accumulate) {
     __shared__ double red[1024];
     const int64_t nG = (int64_t)npairs * 4096;
     const int nC = NSB * 64, nS = 4;
@@ -1612,17 +1618,18 @@ __global__ __launch_bounds__(1024) void fsnap_reduce_tiled(const double* __restr
             const int r = 64 * I + 32 * (p >> 1) + 2 * ep + (p & 1);
             const int c = 64 * J + 32 * (q >> 1) + 2 * eq + (q & 1);
             if (r < K && c < K) {
-                out[(int64_t)r * K + c] = tot;
-                if (!(I == J && p == q)) out[(int64_t)c * K + r] = tot;
+                const double val = accumulate ? out[(int64_t)r * K + c] + tot : tot;
+                out[(int64_t)r * K + c] = val;
+                if (!(I == J && p == q)) out[(int64_t)c * K + r] = val;
             }
         } else if (idx < nG + nC) {
             const int j = (int)(idx - nG);
             const int Ib = j >> 6, bq = (j >> 4) & 3, e = j & 15;
             const int cidx = 64 * Ib + 32 * (bq >> 1) + 2 * e + (bq & 1);
-            if (cidx < K) out[(int64_t)K * K + cidx] = tot;
+            if (cidx < K) out[(int64_t)K * K + cidx] = accumulate ? out[(int64_t)K * K + cidx] + tot : tot;
         } else {
             const int j = (int)(idx - nG - nC);
-            if (j < 3) out[(int64_t)K * K + K + j] = tot;
+            if (j < 3) out[(int64_t)K * K + K + j] = accumulate ? out[(int64_t)K * K + K + j] + tot : tot;
         }
     }
 }
@@ -2520,11 +2527,12 @@ hipError_t launch_syrk(const SyrkArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_reduce(const double* part, const double* cpart, const double* spart, int nblocks,
-                         int cs_per_block, int K, double* out, double* mirror, hipStream_t st) {
+                         int cs_per_block, int K, double* out, double* mirror, bool accumulate, hipStream_t st) {
     const int NB = syrk_num_blocks(K);
     const int nelem = NB * (NB + 1) / 2 * 256 + NB * 16 + 4;
     dim3 grid((unsigned)((nelem + 15) / 16)), block(1024);
-    hipLaunchKernelGGL(fsnap_reduce_partials, grid, block, 0, st, part, cpart, spart, nblocks, cs_per_block, NB, K, out, mirror);
+    hipLaunchKernelGGL(fsnap_reduce_partials, grid, block, 0, st, part, cpart, spart, nblocks, cs_per_block, NB, K, out, mirror,
+                       accumulate ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -2540,11 +2548,11 @@ hipError_t launch_syrk_tiled(const TiledArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_reduce_tiled(const TiledArgs& a, double* out, hipStream_t st) {
+hipError_t launch_reduce_tiled(const TiledArgs& a, double* out, bool accumulate, hipStream_t st) {
     const int64_t nelem = (int64_t)a.npairs * 4096 + a.NSB * 64 + 4;
     dim3 grid((unsigned)((nelem + 63) / 64)), block(1024);
     hipLaunchKernelGGL(fsnap_reduce_tiled, grid, block, 0, st, a.part, a.cpart, a.spart, a.nsplit, a.NSB, a.npairs, a.K,
-                       out);
+                       out, accumulate ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -144,6 +144,12 @@ int fsnap_normal_eq(fsnap_ctx* ctx, double* G, double* c, double* scalars);
  * examples/library/transpose_trick/example.py:245-246). */
 int fsnap_normal_eq_async(fsnap_ctx* ctx, double* d_packed);
 
+/* Streaming form: d_packed (device, FSNAP_PACKED_LEN(K) doubles, zeroed by the caller before the first batch)
+ * += statistics of the resident rows.  The reference's per-configuration accumulation `c += cm; d += dm`
+ * (examples/library/transpose_trick/example.py:230-237): batches of rows are uploaded (or assembled), accumulated
+ * and dropped, so A never has to be resident as a whole.  Asynchronous. */
+int fsnap_normal_eq_accumulate(fsnap_ctx* ctx, double* d_packed);
+
 /* Same as fsnap_normal_eq_async into a context-owned device buffer whose address is
  * returned in *d_packed (valid until the next call on this context); asynchronous.
  * For K <= 128 the reduction kernel also writes the statistics into a page-locked host mirror

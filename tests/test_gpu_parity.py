@@ -825,3 +825,28 @@ def test_one_wave_triangle_kernel_strided_rows(ctx):
     G, c, s = ctx.normal_eq()
     assert ctx.launch_info()["kernel_or_pairs"] == 3
     stats_close(G, c, s, *orc.normal_eq(A, b, w))
+
+
+@pytest.mark.parametrize("K", [31, 128, 200])
+def test_streaming_accumulation_matches_one_shot(ctx, K):
+    # fsnap_normal_eq_accumulate: per-batch `c += cm; d += dm` (transpose_trick/example.py:230-237) on the device;
+    # covers the wave-triangle (31), one-wave-triangle (128) and tiled (200) kernels' reductions
+    import torch
+    rng = np.random.default_rng(600 + K)
+    m = 9001
+    A = rng.standard_normal((m, K))
+    b = rng.standard_normal(m)
+    w = rng.uniform(0.5, 2.0, m)
+    t = rng.random(m) < 0.2
+    dev = torch.device("cuda", 0)
+    total = torch.zeros(K * K + K + 3, dtype=torch.float64, device=dev)
+    for lo in range(0, m, 2500):
+        hi = min(lo + 2500, m)
+        ctx.upload_rows(A[lo:hi], b[lo:hi])
+        ctx.set_weights(w[lo:hi], (~t[lo:hi]).astype(np.uint8))
+        ctx.normal_eq_accumulate(total.data_ptr())
+    G, c, s = ctx.download_packed(total.data_ptr(), K)
+    stats_close(G, c, s, *orc.normal_eq(A, b, w, t), tol=2e-12)
+    beta, rank, _ = ctx.solve_device(_capi.SOLVE_RIDGE, 1e-6, K, total.data_ptr())
+    ref = np.linalg.solve(G + 1e-6 * np.eye(K), c)
+    assert rank == K and np.max(np.abs(beta - ref)) / np.max(np.abs(ref)) < 1e-9
