@@ -128,8 +128,15 @@ def main():
     n = Kc * Kc + Kc + 3
     packed = torch.zeros(n, dtype=torch.float64, device=dev)
     host = torch.zeros(n, dtype=torch.float64).pin_memory()
-    stream = torch.cuda.current_stream(dev)
-    ctx.set_stream(stream.cuda_stream)
+    if world > 1:
+        # kernels and the RCCL all-reduce share ONE non-default stream (the legacy default stream synchronises
+        # implicitly with every other stream and costs several microseconds per launch)
+        stream = torch.cuda.Stream(dev)
+        torch.cuda.set_stream(stream)
+        ctx.set_stream(stream.cuda_stream)
+        torch.cuda.synchronize()                        # buffers above were created on the default stream
+    else:
+        stream = None                                   # single GPU: the context's own non-blocking stream
 
     brk = {"launch": 0.0, "sync": 0.0, "solve": 0.0}
 
@@ -145,8 +152,10 @@ def main():
         t1 = time.perf_counter()
         beta = None
         if args.host_solve:
+            if stream is None:
+                ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
             host.copy_(packed, non_blocking=True)
-            stream.synchronize()
+            torch.cuda.current_stream(dev).synchronize()
             t2 = time.perf_counter()
             if rank == 0:
                 h = host.numpy()
@@ -158,7 +167,7 @@ def main():
             if rank == 0:
                 beta, _, _ = ctx.solve_device(_capi.SOLVE_RIDGE, ALPHA, Kc, ptr)
             else:
-                stream.synchronize()
+                torch.cuda.current_stream(dev).synchronize()
         t3 = time.perf_counter()
         brk["launch"] += t1 - t0
         brk["sync"] += t2 - t1
@@ -182,11 +191,12 @@ def main():
     beta = None
     for _ in range(args.steps):
         beta = step()
-        t = ctx.timing(2)                                  # HIP events on the kernel's stream (already synced)
-        syrk_ms.append(t["syrk_ms"])
-        red_ms.append(t["reduce_ms"])
     fence()
     elapsed = time.perf_counter() - t0
+    # kernel times of the timed steps: HIP events recorded on the kernel's stream around every launch, read now
+    nh = min(args.steps, 256)
+    syrk_hist, red_hist = ctx.timing_history(nh)
+    syrk_ms, red_ms = list(syrk_hist), list(red_hist)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

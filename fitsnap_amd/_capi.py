@@ -59,6 +59,7 @@ SIGNATURES = {
     "fsnap_solve_device_rhs": (c_int, [c_void_p, c_int, c_double, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int),
                                         POINTER(c_double)]),
     "fsnap_timing": (c_int, [c_void_p, _P_D, c_int]),
+    "fsnap_timing_history": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
     "fsnap_launch_info": (c_int, [c_void_p, POINTER(c_int64), c_int]),
 }
 
@@ -373,6 +374,13 @@ class HipContext:
         ms = (c_double * 8)()
         self._check(self._lib.fsnap_timing(self._h, ms, int(n)))
         return {"syrk_ms": ms[0], "reduce_ms": ms[1], "upload_ms": ms[2], "weight_ms": ms[3], "predict_ms": ms[4]}
+
+    def timing_history(self, n: int):
+        """(syrk_ms, reduce_ms) arrays of the last ``n`` fits (oldest first), read from HIP events after the fact."""
+        a = np.empty(int(n))
+        b = np.empty(int(n))
+        self._check(self._lib.fsnap_timing_history(self._h, _ptr(a), _ptr(b), int(n)))
+        return a, b
 
     def launch_info(self):
         info = (c_int64 * 8)()

@@ -17,6 +17,10 @@
 #include "../../include/fsnap_hip.h"
 #include "fsnap_kernels.h"
 
+// fsnap_solve with a contiguous copy of diag(G) (fsnap_solve.cpp; not part of the public ABI)
+extern "C" int fsnap_solve_diag(int kind, double param, int64_t K, const double* G, const double* c, const double* diag,
+                                double* beta, int* rank, double* rcond_est);
+
 namespace {
 
 thread_local std::string g_last_error = "";
@@ -51,6 +55,9 @@ struct fsnap_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev[10] = {};
+    static constexpr int RING = 256;              // event triples of the last RING fits (fsnap_timing_history)
+    hipEvent_t ring[RING][3] = {};
+    int64_t nfit = 0;                             // fits launched so far
     std::string err;
 
     // rows
@@ -220,6 +227,17 @@ struct TiledGeometry {
     int64_t cps;  // chunks per split
 };
 
+// event triple {before SYRK, after SYRK, after reduction} of the fit being launched: a ring, so that the kernel times
+// of many consecutive fits can be read AFTER a timed loop instead of synchronising inside it
+int fit_events(fsnap_ctx* ctx, hipEvent_t** slot) {
+    hipEvent_t* sl = ctx->ring[ctx->nfit % fsnap_ctx::RING];
+    for (int i = 0; i < 3; ++i)
+        if (!sl[i]) FSNAP_HIP(hipEventCreate(&sl[i]), "hipEventCreate");
+    ++ctx->nfit;
+    *slot = sl;
+    return FSNAP_OK;
+}
+
 int plan_tiled(fsnap_ctx* ctx, TiledGeometry* g) {
     const int64_t m = ctx->m, K = ctx->K;
     if (K > 32768) return ctx->fail(FSNAP_E_ARG, "K = %lld too large", (long long)K);
@@ -303,11 +321,13 @@ int launch_normal_eq_tiled(fsnap_ctx* ctx, double* d_packed, bool accumulate) {
     // waves of off-diagonal pairs never write their c / scalar slots: zero them once
     FSNAP_HIP(hipMemsetAsync(a.cpart, 0, (size_t)g.nsplit * g.NSB * 4 * 64 * sizeof(double), ctx->stream), "hipMemsetAsync");
     FSNAP_HIP(hipMemsetAsync(a.spart, 0, (size_t)g.nsplit * 4 * 4 * sizeof(double), ctx->stream), "hipMemsetAsync");
-    FSNAP_HIP(hipEventRecord(ctx->ev[0], ctx->stream), "hipEventRecord");
+    hipEvent_t* evs;
+    if ((rc = fit_events(ctx, &evs))) return rc;
+    FSNAP_HIP(hipEventRecord(evs[0], ctx->stream), "hipEventRecord");
     FSNAP_HIP(fsnap::launch_syrk_tiled(a, ctx->stream), "launch fsnap_syrk_tiled");
-    FSNAP_HIP(hipEventRecord(ctx->ev[1], ctx->stream), "hipEventRecord");
+    FSNAP_HIP(hipEventRecord(evs[1], ctx->stream), "hipEventRecord");
     FSNAP_HIP(fsnap::launch_reduce_tiled(a, d_packed, accumulate, ctx->stream), "launch fsnap_reduce_tiled");
-    FSNAP_HIP(hipEventRecord(ctx->ev[2], ctx->stream), "hipEventRecord");
+    FSNAP_HIP(hipEventRecord(evs[2], ctx->stream), "hipEventRecord");
     ctx->t_syrk = true;
     return FSNAP_OK;
 }
@@ -346,16 +366,18 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
     a.part = (double*)ctx->part.p;
     a.cpart = (double*)ctx->cpart.p;
     a.spart = (double*)ctx->spart.p;
-    FSNAP_HIP(hipEventRecord(ctx->ev[0], ctx->stream), "hipEventRecord");
+    hipEvent_t* evs;
+    if ((rc = fit_events(ctx, &evs))) return rc;
+    FSNAP_HIP(hipEventRecord(evs[0], ctx->stream), "hipEventRecord");
     if (g.acc) FSNAP_HIP(fsnap::launch_syrk_acc(a, ctx->stream), "launch fsnap_syrk_acc");
     else if (g.lds_waves) FSNAP_HIP(fsnap::launch_syrk_lds(a, ctx->stream), "launch fsnap_syrk_lds");
     else FSNAP_HIP(fsnap::launch_syrk(a, ctx->stream), "launch fsnap_syrk_wave");
-    FSNAP_HIP(hipEventRecord(ctx->ev[1], ctx->stream), "hipEventRecord");
+    FSNAP_HIP(hipEventRecord(evs[1], ctx->stream), "hipEventRecord");
     // K <= 128 and the context owns the output: the reduction also writes a page-locked host mirror, so the solve
     // needs no D2H copy (the copy's launch latency was 12 us of a 440 us step)
     double* mirror = nullptr;
     if (want_mirror && ctx->opt_mirror) {
-        const size_t need = (size_t)FSNAP_PACKED_LEN(ctx->K) * 8;
+        const size_t need = ((size_t)FSNAP_PACKED_LEN(ctx->K) + (size_t)ctx->K) * 8;   // + compact diagonal
         if (ctx->mirror_bytes < need) {
             if (ctx->mirror) (void)hipHostFree(ctx->mirror);
             ctx->mirror = nullptr;
@@ -371,7 +393,7 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
     FSNAP_HIP(fsnap::launch_reduce(a.part, a.cpart, a.spart, g.nblocks, cs_per_block, a.K, d_packed, mirror, accumulate,
                                    ctx->stream),
               "launch fsnap_reduce_partials");
-    FSNAP_HIP(hipEventRecord(ctx->ev[2], ctx->stream), "hipEventRecord");
+    FSNAP_HIP(hipEventRecord(evs[2], ctx->stream), "hipEventRecord");
     if (mirror) {
         FSNAP_HIP(hipEventRecord(ctx->mirror_ev, ctx->stream), "hipEventRecord");
         ctx->mirror_of = d_packed;
@@ -462,6 +484,9 @@ int fsnap_ctx_destroy(fsnap_ctx* ctx) {
     if (ctx->mirror_ev) (void)hipEventDestroy(ctx->mirror_ev);
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto& sl : ctx->ring)
+        for (auto& ev : sl)
+            if (ev) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return FSNAP_OK;
@@ -967,7 +992,7 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
             if (q != hipErrorNotReady) return ctx->hipfail(q, "hipEventQuery");
         }
         const double* Gm = ctx->mirror;
-        const int rcm = fsnap_solve(kind, param, K, Gm, rhs ? rhs : Gm + K * K, beta, rank, rcond_est);
+        const int rcm = fsnap_solve_diag(kind, param, K, Gm, rhs ? rhs : Gm + K * K, Gm + K * K + K + 3, beta, rank, rcond_est);
         if (rcm) ctx->fail(rcm, "fsnap_solve: numerical status %d", rcm);
         return rcm;
     }
@@ -1049,14 +1074,33 @@ int fsnap_timing(fsnap_ctx* ctx, double* ms, int n) {
     FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float t = 0.f;
-    if (ctx->t_syrk) {
-        if (hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]) == hipSuccess) out[0] = t;
-        if (n > 1 && hipEventElapsedTime(&t, ctx->ev[1], ctx->ev[2]) == hipSuccess) out[1] = t;
+    if (ctx->t_syrk && ctx->nfit > 0) {
+        hipEvent_t* sl = ctx->ring[(ctx->nfit - 1) % fsnap_ctx::RING];
+        if (hipEventElapsedTime(&t, sl[0], sl[1]) == hipSuccess) out[0] = t;
+        if (n > 1 && hipEventElapsedTime(&t, sl[1], sl[2]) == hipSuccess) out[1] = t;
     }
     if (n > 2 && ctx->t_upload && hipEventElapsedTime(&t, ctx->ev[3], ctx->ev[4]) == hipSuccess) out[2] = t;
     if (n > 3 && ctx->t_weight && hipEventElapsedTime(&t, ctx->ev[5], ctx->ev[6]) == hipSuccess) out[3] = t;
     if (n > 4 && ctx->t_predict && hipEventElapsedTime(&t, ctx->ev[7], ctx->ev[8]) == hipSuccess) out[4] = t;
     for (int i = 0; i < n; ++i) ms[i] = out[i];
+    return FSNAP_OK;
+}
+
+int fsnap_timing_history(fsnap_ctx* ctx, double* syrk_ms, double* reduce_ms, int n) {
+    if (!ctx || !syrk_ms || n < 0) return FSNAP_E_ARG;
+    if (n > fsnap_ctx::RING || n > ctx->nfit) return ctx->fail(FSNAP_E_ARG, "fsnap_timing_history: only the last %d fits are kept",
+                                                             (int)(ctx->nfit < fsnap_ctx::RING ? ctx->nfit : fsnap_ctx::RING));
+    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    for (int i = 0; i < n; ++i) {
+        hipEvent_t* sl = ctx->ring[(ctx->nfit - n + i) % fsnap_ctx::RING];
+        float t = 0.f;
+        FSNAP_HIP(hipEventElapsedTime(&t, sl[0], sl[1]), "hipEventElapsedTime");
+        syrk_ms[i] = t;
+        if (reduce_ms) {
+            FSNAP_HIP(hipEventElapsedTime(&t, sl[1], sl[2]), "hipEventElapsedTime");
+            reduce_ms[i] = t;
+        }
+    }
     return FSNAP_OK;
 }
 

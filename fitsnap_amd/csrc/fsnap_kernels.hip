@@ -803,6 +803,9 @@ __global__ __launch_bounds__(1024) void fsnap_reduce_partials(const double* __re
                 if (mirror) {        // page-locked host copy written by the same kernel (no separate D2H copy)
                     mirror[(int64_t)r * K + c] = val;
                     if (p != q) mirror[(int64_t)c * K + r] = val;
+                    // compact copy of the diagonal behind the packed statistics: the host's scaling pass needs it
+                    // first, and 128 entries with a 1 KiB stride are 128 cold cache lines
+                    if (r == c) mirror[(int64_t)K * K + K + 3 + r] = val;
                 }
             }
         } else if (idx < nG + nC) {

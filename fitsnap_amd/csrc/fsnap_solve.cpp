@@ -623,8 +623,19 @@ struct PhaseTimer {   // FSNAP_SOLVE_TIMING=1: print the phases of the fast path
 };
 }  // namespace
 
+extern "C" int fsnap_solve_diag(int kind, double param, int64_t K64, const double* G, const double* c, const double* diag,
+                                double* beta, int* rank_out, double* rcond_est);
+
 extern "C" int fsnap_solve(int kind, double param, int64_t K64, const double* G, const double* c, double* beta,
                            int* rank_out, double* rcond_est) {
+    return fsnap_solve_diag(kind, param, K64, G, c, nullptr, beta, rank_out, rcond_est);
+}
+
+// diag (optional): contiguous copy of diag(G) -- the device reduction writes one next to its host mirror so that
+// the scaling pass does not start with K cold cache lines
+extern "C" __attribute__((visibility("hidden"))) int fsnap_solve_diag(int kind, double param, int64_t K64, const double* G,
+                                                                      const double* c, const double* diag, double* beta,
+                                                                      int* rank_out, double* rcond_est) {
     PhaseTimer timer;
     if (!G || !c || !beta || K64 <= 0 || K64 > (1 << 20)) return FSNAP_E_ARG;
     if (kind < FSNAP_SOLVE_CHOL || kind > FSNAP_SOLVE_RIDGE_INV) return FSNAP_E_ARG;
@@ -647,11 +658,12 @@ extern "C" int fsnap_solve(int kind, double param, int64_t K64, const double* G,
         bool ok = true;
         double chk = 0.0;
         for (int i = 0; i < K && ok; ++i) {
-            const double g = G[(size_t)i * K + i] + alpha;
+            const double g = (diag ? diag[i] : G[(size_t)i * K + i]) + alpha;
             if (!(g > 0.0) || !std::isfinite(g)) ok = false;
             else dsc[i] = 1.0 / std::sqrt(g);
             chk += c[i] * 0.0;
         }
+        timer.lap("diag scale");
         if (ok) {
             // rows are built in 8-wide vectors from the vector that holds the diagonal: the < 8 entries left of the
             // diagonal receive (valid, unused) scaled values, everything further left is zeroed -- the blocked
@@ -664,6 +676,10 @@ extern "C" int fsnap_solve(int kind, double param, int64_t K64, const double* G,
                 const double di = dsc[i];
                 const v8d dv = {di, di, di, di, di, di, di, di};
                 const int j0 = i & ~7;
+                if (i + 2 < K) {     // the statistics were just written by the device: fetch the row after next early
+                    const double* gn = G + (size_t)(i + 2) * K;
+                    for (int jp = (i + 2) & ~7; jp < K; jp += 8) __builtin_prefetch(gn + jp, 0, 0);
+                }
                 int j = 0;
                 for (; j + 8 <= j0; j += 8) *(v8du*)(ui + j) = zero;
                 for (; j + 16 <= K; j += 16) {

@@ -224,6 +224,11 @@ int fsnap_error_stats(fsnap_ctx* ctx, const double* beta, const int32_t* cat, in
  * Synchronises the context's stream.  n = number of entries of ms to fill (<= 8). */
 int fsnap_timing(fsnap_ctx* ctx, double* ms, int n);
 
+/* Kernel times (ms) of the last n fits launched on this context, oldest first (n <= 256): syrk_ms[i] = SYRK kernel,
+ * reduce_ms[i] (may be NULL) = partial reduction.  HIP events on the kernels' stream, read after the fact, so a
+ * timed loop does not have to synchronise for its measurements.  Synchronises the context's stream. */
+int fsnap_timing_history(fsnap_ctx* ctx, double* syrk_ms, double* reduce_ms, int n);
+
 /* Launch geometry of the SYRK kernel for the current rows: info[0] = workgroups,
  * info[1] = threads per workgroup, info[2] = 4-row chunks per row-wave (kernel 1) / per
  * workgroup (kernel 1L) / per wave (tiled), info[3] = NB (16-column blocks), info[4] =
