@@ -2,7 +2,7 @@
 """bench.py — BASELINE.json metric: training rows/sec through A^T A + solve on a synthetic
 10^6 x 128 fp64 A-matrix per GPU (configs[1]: RIDGE normal equations), 1/2/4/8 MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -50,8 +50,8 @@ RANK_ROW_STRIDE = 16 * 65536   # >= ROWS_PER_GPU, multiple of the generator's 64
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--preheat", type=int, default=300,
                     help="untimed steps before the warm-up, to bring the GPU to its steady clock (0 = none)")
     ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default: BASELINE config)")
@@ -143,7 +143,11 @@ def main():
     def step():
         t0 = time.perf_counter()
         if world == 1 and not args.host_solve:
-            ptr = ctx.normal_eq_resident()                # the Solver classes' single-GPU path (context-owned buffer)
+            # the Solver classes' single-GPU path: statistics into a context-owned buffer + solve, one library call
+            beta, _, _, _ = ctx.fit_resident(_capi.SOLVE_RIDGE, ALPHA)
+            t1 = time.perf_counter()
+            brk["launch"] += t1 - t0
+            return beta
         else:
             ptr = packed.data_ptr()
             ctx.normal_eq_async(ptr)

@@ -56,6 +56,7 @@ SIGNATURES = {
     "fsnap_normal_eq_accumulate": (c_int, [c_void_p, c_void_p]),
     "fsnap_error_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "fsnap_solve_device": (c_int, [c_void_p, c_int, c_double, c_int64, c_void_p, c_void_p, POINTER(c_int), POINTER(c_double)]),
+    "fsnap_fit_resident": (c_int, [c_void_p, c_int, c_double, c_void_p, POINTER(c_int), POINTER(c_double), POINTER(c_void_p)]),
     "fsnap_solve_device_rhs": (c_int, [c_void_p, c_int, c_double, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int),
                                         POINTER(c_double)]),
     "fsnap_timing": (c_int, [c_void_p, _P_D, c_int]),
@@ -348,6 +349,18 @@ class HipContext:
         stats = np.empty((int(ncat), 10), dtype=np.float64)
         self._check(self._lib.fsnap_error_stats(self._h, _ptr(beta), _ptr(cat), int(ncat), _ptr(stats)))
         return stats
+
+    def fit_resident(self, kind: int, param: float):
+        """Statistics + K x K solve of the resident rows in one library call; returns
+        (beta, rank, rcond_estimate, device address of the packed statistics)."""
+        beta = np.empty(self.K, dtype=np.float64)
+        rank = c_int(0)
+        rce = c_double(0.0)
+        ptr = c_void_p()
+        rc = self._lib.fsnap_fit_resident(self._h, int(kind), float(param), _ptr(beta), byref(rank), byref(rce), byref(ptr))
+        if rc != OK:
+            raise_status(rc, (self._lib.fsnap_last_error(self._h) or b"").decode() if rc < 0 else "")
+        return beta, rank.value, rce.value, ptr.value
 
     def solve_device(self, kind: int, param: float, K: int, d_packed_ptr: int, rhs=None):
         """K x K solve from the packed statistics in HBM; returns (beta, rank, rcond_estimate).

@@ -1030,6 +1030,16 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
     return rc;
 }
 
+int fsnap_fit_resident(fsnap_ctx* ctx, int kind, double param, double* beta, int* rank, double* rcond_est,
+                       double** d_packed) {
+    if (!ctx) return FSNAP_E_ARG;
+    double* dp = nullptr;
+    int rc = fsnap_normal_eq_resident(ctx, &dp);
+    if (rc) return rc;
+    if (d_packed) *d_packed = dp;
+    return fsnap_solve_device_rhs(ctx, kind, param, ctx->K, dp, nullptr, beta, rank, rcond_est);
+}
+
 int fsnap_residual_rhs(fsnap_ctx* ctx, const double* beta, double* s, double* sse) {
     if (!ctx) return FSNAP_E_ARG;
     int rc;

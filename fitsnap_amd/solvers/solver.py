@@ -256,10 +256,10 @@ class Solver:
             return self._solve(kind, param, *self._stats_host[:2])
         ctx = self._upload(a, b, shared_mode)
         ctx.set_weights(w_full, None if mask.all() else mask)
-        ptr = ctx.normal_eq_resident()
         self._stats_host = None
+        self._stats_dev = None
+        beta, rank, _, ptr = ctx.fit_resident(kind, param)      # kernel + reduction + K x K solve, one library call
         self._stats_dev = (ctx, ptr, K)
-        beta, rank, _ = ctx.solve_device(kind, param, K, ptr)
         self.last_rank = rank
         return beta
 

@@ -201,6 +201,12 @@ int fsnap_solve(int kind, double param, int64_t K, const double* G, const double
 int fsnap_solve_device(fsnap_ctx* ctx, int kind, double param, int64_t K, const double* d_packed, double* beta,
                        int* rank, double* rcond_est);
 
+/* One call per fit on resident rows: fsnap_normal_eq_resident followed by fsnap_solve_device on its buffer
+ * (the whole of SVD / RIDGE.perform_fit, svd.py:44-54 / ridge.py:37-59, for rows and weights already on the
+ * device).  *d_packed (may be NULL) receives the address of the statistics, as fsnap_normal_eq_resident does. */
+int fsnap_fit_resident(fsnap_ctx* ctx, int kind, double param, double* beta, int* rank, double* rcond_est,
+                       double** d_packed);
+
 /* Same as fsnap_solve_device with the right-hand side replaced by rhs (HOST, K doubles; NULL = the c part of the
  * packed buffer): G delta = s of an iterative-refinement step (solver.py has no counterpart: the reference's
  * lstsq works on the rows, see fsnap_residual_rhs) without bringing G to the host. */
