@@ -119,3 +119,31 @@ def test_single_hip_runtime_whatever_the_import_order():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert out.stdout.strip() == "1"
+
+
+@pytest.mark.parametrize("env", [{"FSNAP_CHOL_VARIANT": "1"}, {"FSNAP_CHOL_VARIANT": "2"}, {"FSNAP_CHOL_VARIANT": "3", "FSNAP_CHOL_NBK": "8"},
+                                 {"FSNAP_CHOL_VARIANT": "3", "FSNAP_CHOL_NBK": "32", "FSNAP_CHOL_THREADS": "3"}])
+def test_host_cholesky_variants_agree(env):
+    # unblocked / 64-row panels + threads / register-blocked chunks (single- and multi-threaded): same solution for
+    # sizes around the 32-column chunk and panel boundaries
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from fitsnap_amd import _capi\n"
+        "worst = 0.0\n"
+        "for K in (5, 31, 32, 33, 63, 64, 65, 100, 128, 129, 200, 511, 700):\n"
+        "    rng = np.random.default_rng(K)\n"
+        "    X = rng.standard_normal((3 * K + 7, K)) * (10.0 ** rng.uniform(-3, 3, size=K))\n"
+        "    G = X.T @ X; c = X.T @ rng.standard_normal(3 * K + 7)\n"
+        "    beta, rank, rc = _capi.solve(_capi.SOLVE_RIDGE, 0.0, G, c)\n"
+        "    d = np.sqrt(np.diag(G)); ref = np.linalg.solve(G / d[:, None] / d[None, :], c / d) / d\n"
+        "    assert rank == K\n"
+        "    worst = max(worst, float(np.max(np.abs(beta - ref) / np.max(np.abs(ref)))))\n"
+        "print(worst)\n" % ROOT
+    )
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=e)
+    assert out.returncode == 0, out.stderr
+    assert float(out.stdout.strip()) < 1e-9
