@@ -17,8 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "_lib")
 LIBNAME = "libfsnap_hip.so"
-SOURCES = ["fsnap_kernels.hip", "fsnap_capi.cpp", "fsnap_solve.cpp"]
-HEADERS = ["fsnap_kernels.h", os.path.join("..", "..", "include", "fsnap_hip.h")]
+SOURCES = ["fsnap_syrk.hip", "fsnap_rows.hip", "fsnap_chol.hip", "fsnap_capi.cpp", "fsnap_solve.cpp"]
+HEADERS = ["fsnap_kernels.h", "fsnap_device_common.h", os.path.join("..", "..", "include", "fsnap_hip.h")]
 ARCH = "gfx950"
 
 
@@ -42,7 +42,7 @@ def _source_digest() -> str:
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile the three translation units and link the shared library. Returns its path."""
+    """Compile the translation units (in parallel) and link the shared library. Returns its path."""
     os.makedirs(LIBDIR, exist_ok=True)
     out = lib_path()
     stamp = out + ".sha256"

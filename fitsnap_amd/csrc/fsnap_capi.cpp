@@ -2,7 +2,7 @@
 // Owns the device-resident copy of the reference's shared arrays a / b / w
 // (fitsnap3lib/parallel_tools.py:352-389, calculator.py:287-289), the training mask
 // derived from fitsnap_dict['Testing'] (svd.py:35-40), launch geometry, HIP-event
-// timing, and error text.  All compute is in fsnap_kernels.hip; the K x K solve in
+// timing, and error text.  All compute is in fsnap_syrk.hip / fsnap_rows.hip / fsnap_chol.hip; the host K x K solve in
 // fsnap_solve.cpp.
 #include <hip/hip_runtime.h>
 

@@ -1,5 +1,5 @@
 // fsnap_kernels.h — internal C++ interface between the gfx950 kernels
-// (fsnap_kernels.hip) and the C-ABI layer (fsnap_capi.cpp).  Not part of the public
+// (fsnap_syrk.hip, fsnap_rows.hip, fsnap_chol.hip) and the C-ABI layer (fsnap_capi.cpp).  Not part of the public
 // boundary; the public boundary is include/fsnap_hip.h.
 #pragma once
 #include <hip/hip_runtime.h>

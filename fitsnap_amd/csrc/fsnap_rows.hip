@@ -1,0 +1,426 @@
+// fsnap_rows.hip — HBM-bound row-streaming kernels of the FitSNAP linear-fit path (gfx950 only):
+//   3   fsnap_weight_rows_k    stand-alone wavefront row weighting            (svd.py:46 / ridge.py:39)
+//   4   fsnap_gemv_rows_k      preds = A @ beta (+ weighted SSE, refinement u) (solver.py:377)
+//   5   fsnap_assemble_k       post-LAMMPS assembly (_collect_lammps)         (lammps_snap.py:391-556)
+//   7   fsnap_gemvT_rows_k     s = A^T u (right-hand side of a refinement step)
+//   9   fsnap_error_stats_k    grouped error statistics of error_analysis     (solver.py:108-133)
+//   10  fsnap_copy_to_host_k   small device -> page-locked host copy
+// Every kernel here moves each byte once; the roofline is HBM bandwidth.
+#include "fsnap_device_common.h"
+#include "fsnap_kernels.h"
+
+// ---------------------------------------------------------------------------------
+// Kernel 3: stand-alone wavefront row weighting (svd.py:46 / ridge.py:39).
+//   aw[i,:] = w[i]*A[i,:], bw[i] = w[i]*b[i] for every row; masked rows are written
+//   as zeros (row compaction is the host shim's business, see fsnap_weight_rows()).
+// One wave per row-slab, 16-byte vector accesses, grid-stride.  HBM-bound:
+// 16K + 24 bytes per row.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsnap_weight_rows_k(const double* __restrict__ A, int64_t lda,
+                                                           const double* __restrict__ b,
+                                                           const double* __restrict__ w,
+                                                           const unsigned char* __restrict__ mask, int64_t m,
+                                                           int K, double* __restrict__ aw, int64_t ldaw,
+                                                           double* __restrict__ bw) {
+    // One wave handles 4 consecutive rows per iteration (4 independent 16-byte loads per lane in
+    // flight before the first store: memory-level parallelism for the HBM stream).
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * 4;
+    const bool vec2 = ((K & 1) == 0) && ((lda & 1) == 0) && ((ldaw & 1) == 0);
+    for (int64_t row0 = wave * 4; row0 < m; row0 += nwave * 4) {
+        double wv[4];
+        bool keep[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + r;
+            const bool in = row < m;
+            keep[r] = in && (mask[in ? row : 0] != 0);
+            wv[r] = in ? w[row] : 0.0;
+        }
+        if (vec2) {
+            for (int c = 2 * lane; c < K; c += 128) {
+                d2u x[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row0 + r < m) x[r] = __builtin_nontemporal_load(reinterpret_cast<const d2u*>(A + (row0 + r) * lda + c));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (row0 + r < m) {
+                        d2u y;
+                        y[0] = keep[r] ? wv[r] * x[r][0] : 0.0;
+                        y[1] = keep[r] ? wv[r] * x[r][1] : 0.0;
+                        __builtin_nontemporal_store(y, reinterpret_cast<d2u*>(aw + (row0 + r) * ldaw + c));
+                    }
+                }
+            }
+        } else {
+            for (int c = lane; c < K; c += 64) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row0 + r < m) aw[(row0 + r) * ldaw + c] = keep[r] ? wv[r] * A[(row0 + r) * lda + c] : 0.0;
+            }
+        }
+        if (lane < 4 && row0 + lane < m) {
+            const int64_t row = row0 + lane;
+            const bool kp = mask[row] != 0;
+            bw[row] = kp ? w[row] * b[row] : 0.0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 4: preds = A @ beta (solver.py:377) and, optionally, per-workgroup partial
+// sums of the weighted squared residual sum_i mask_i (w_i (b_i - preds_i))^2
+// (the SSE that sklearn's ARD loop recomputes each iteration, _bayes.py `rmse_`).
+// 16 lanes per row (4 rows per wave pass), beta staged once in LDS.  HBM-bound.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsnap_gemv_rows_k(const double* __restrict__ A, int64_t lda,
+                                                         const double* __restrict__ beta, int64_t m, int K,
+                                                         double* __restrict__ preds,
+                                                         const double* __restrict__ b,
+                                                         const double* __restrict__ w,
+                                                         const unsigned char* __restrict__ mask,
+                                                         double* __restrict__ sse_part,
+                                                         double* __restrict__ uout) {
+    // uout (optional): u_i = mask_i * w_i^2 * (b_i - a_i . beta), the row weights of the
+    // refinement right-hand side  s = (wA)^T (wb - wA beta) = A^T u   (kernel 7)
+    extern __shared__ __attribute__((aligned(16))) double sbeta[];
+    for (int c = threadIdx.x; c < K; c += 256) sbeta[c] = beta[c];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * 4;
+    double sse = 0.0;
+    for (int64_t r0 = wave * 4; r0 < m; r0 += nwave * 4) {
+        const int64_t row = r0 + kr;
+        double s = 0.0;
+        if (row < m) {
+            const double* src = A + row * lda;
+            if (((K | lda) & 1) == 0) {   // 16-byte loads: two adjacent columns per lane, two accumulators
+                double s1 = 0.0;
+                for (int c = 2 * e; c < K; c += 32) {
+                    const d2u x = __builtin_nontemporal_load(reinterpret_cast<const d2u*>(src + c));
+                    s = __builtin_fma(x[0], sbeta[c], s);
+                    s1 = __builtin_fma(x[1], sbeta[c + 1], s1);
+                }
+                s += s1;
+            } else {
+                for (int c = e; c < K; c += 16) s = __builtin_fma(src[c], sbeta[c], s);
+            }
+        }
+        // reduce over the 16 lanes of the row group
+        s += __shfl_xor(s, 8, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 1, 64);
+        if (row < m && e == 0) {
+            if (preds) preds[row] = s;
+            if (sse_part || uout) {
+                const bool keep = mask ? (mask[row] != 0) : true;
+                const double wr = w[row];
+                const double rr = keep ? wr * (b[row] - s) : 0.0;
+                if (sse_part) sse = __builtin_fma(rr, rr, sse);
+                if (uout) uout[row] = keep ? wr * rr : 0.0;
+            }
+        }
+    }
+    if (sse_part) {
+        __shared__ double wsum[4];
+        sse += __shfl_xor(sse, 16, 64);
+        sse += __shfl_xor(sse, 32, 64);
+        if (lane == 0) wsum[threadIdx.x >> 6] = sse;
+        __syncthreads();
+        if (threadIdx.x == 0) sse_part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 5: post-LAMMPS assembly — the `_collect_lammps` transform
+// (fitsnap3lib/calculators/lammps_snap.py:391-556, lammps_pace.py:369-509) for a batch of
+// configurations: raw `compute snap|pace` rows -> rows of A, b, w, written straight into the
+// resident HBM arrays.  One wave per output row, lanes stride the K output columns.
+//   raw      : row-major raw rows, leading dimension raw_ld = ncoeff*ntypes + 1; the last
+//              column (icolref) is the reference-potential contribution
+//   per output row r (SoA plan): src_row[r] raw row, kind[r], d[r], truth[r], weight[r],
+//              frac[r] (index of the per-type atom fractions of its configuration, or -1)
+//   kind 0 energy       : A = x / d              b = (truth - ref) / d   w = weight   (d = N)
+//   kind 1 force        : A = x                  b = truth - ref         w = weight
+//   kind 2 virial       : A = (1.6021765e6 x)/d  b = truth - ref         w = weight   (d = volume)
+//   kind 3 per-atom-energy rows after the first (bikflag): A = x / d, b = 0, w = 0
+//   column k -> type t = k / (ncoeff + off), j = k % (ncoeff + off); with off = 1
+//   (bzeroflag = 0) column j = 0 is the per-type offset column: atom fraction of type t on
+//   energy rows, 0 elsewhere; every column is multiplied by blank2J[k].
+// The arithmetic order is the reference's (divide, not multiply by a reciprocal), so
+// rows are bit-identical to the numpy path.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsnap_assemble_k(const double* __restrict__ raw, int64_t raw_ld,
+                                                        int64_t nrows, const int64_t* __restrict__ src_row,
+                                                        const int* __restrict__ kind, const int* __restrict__ frac,
+                                                        const double* __restrict__ dval,
+                                                        const double* __restrict__ truth,
+                                                        const double* __restrict__ weight,
+                                                        const double* __restrict__ fractions,
+                                                        const double* __restrict__ blank2J, int ntypes, int ncoeff,
+                                                        int off, double* __restrict__ A, int64_t lda,
+                                                        double* __restrict__ b, double* __restrict__ w) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * 4;
+    const int stride = ncoeff + off;
+    const int K = ntypes * stride;
+    const int icolref = ntypes * ncoeff;
+    for (int64_t r = wave; r < nrows; r += nwave) {
+        const double* src = raw + src_row[r] * raw_ld;
+        const int kd = kind[r];
+        const double d = dval[r];
+        const int fr = frac[r];
+        double* dst = A + r * lda;
+        for (int k = lane; k < K; k += 64) {
+            const int t = k / stride, j = k - t * stride;
+            double v;
+            if (off && j == 0) {
+                v = (kd == 0 && fr >= 0) ? fractions[(int64_t)fr * ntypes + t] : 0.0;
+            } else {
+                const double x = src[t * ncoeff + (j - off)];
+                v = (kd == 1) ? x : (kd == 2) ? (1.6021765e6 * x) / d : x / d;
+            }
+            dst[k] = v * blank2J[k];
+        }
+        if (lane == 0) {
+            const double ref = src[icolref];
+            double bv, wv = weight[r];
+            if (kd == 0) bv = (truth[r] - ref) / d;
+            else if (kd == 3) {
+                bv = 0.0;
+                wv = 0.0;
+            } else bv = truth[r] - ref;
+            b[r] = bv;
+            w[r] = wv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 7: s = A^T u  (transposed streaming GEMV, HBM-bound) — with u from kernel 4 this is
+// the right-hand side of one step of iterative refinement of the least-squares solution
+// ("corrected semi-normal equations": G delta = (wA)^T (wb - wA beta), beta += delta), which
+// takes the error of the normal-equation solve from ~kappa^2 eps back to ~kappa eps — what
+// keeps the GPU path within 1e-6 of the reference's lstsq (svd.py:54) on ill-conditioned A.
+// Workgroup = row range; wave v takes rows v, v+4, ...; lane l owns columns 2l, 2l+1 (+128 j).
+// Per-workgroup partial vectors are written to spart2[wg][K] and summed in fixed order.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsnap_gemvT_rows_k(const double* __restrict__ A, int64_t lda,
+                                                          const double* __restrict__ u, int64_t m, int K,
+                                                          int64_t rows_per_wg, double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) double sacc[];   // 4 waves x Kpad
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int Kpad = (K + 1) & ~1;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+    int64_t r1 = r0 + rows_per_wg;
+    if (r1 > m) r1 = m;
+    const bool vec2 = ((K | lda) & 1) == 0;
+    for (int c0 = 0; c0 < K; c0 += 128) {
+        const int c = c0 + 2 * lane;
+        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+        if (c < K) {
+            int64_t row = r0 + wv;
+            for (; row + 4 < r1; row += 8) {   // two rows in flight per wave
+                const double u0 = u[row], u1 = u[row + 4];
+                double x0, x1, y0, y1;
+                if (vec2) {
+                    const d2u x = *reinterpret_cast<const d2u*>(A + row * lda + c);
+                    const d2u y = *reinterpret_cast<const d2u*>(A + (row + 4) * lda + c);
+                    x0 = x[0]; x1 = x[1]; y0 = y[0]; y1 = y[1];
+                } else {
+                    x0 = A[row * lda + c]; x1 = (c + 1 < K) ? A[row * lda + c + 1] : 0.0;
+                    y0 = A[(row + 4) * lda + c]; y1 = (c + 1 < K) ? A[(row + 4) * lda + c + 1] : 0.0;
+                }
+                a0 = __builtin_fma(x0, u0, a0);
+                a1 = __builtin_fma(x1, u0, a1);
+                b0 = __builtin_fma(y0, u1, b0);
+                b1 = __builtin_fma(y1, u1, b1);
+            }
+            for (; row < r1; row += 4) {
+                const double u0 = u[row];
+                const double x0 = A[row * lda + c];
+                const double x1 = (c + 1 < K) ? A[row * lda + c + 1] : 0.0;
+                a0 = __builtin_fma(x0, u0, a0);
+                a1 = __builtin_fma(x1, u0, a1);
+            }
+            sacc[wv * Kpad + c] = a0 + b0;
+            if (c + 1 < K) sacc[wv * Kpad + c + 1] = a1 + b1;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < K; c += 256)
+        partial[(int64_t)blockIdx.x * K + c] = (sacc[c] + sacc[Kpad + c]) + (sacc[2 * Kpad + c] + sacc[3 * Kpad + c]);
+}
+
+__global__ __launch_bounds__(256) void fsnap_colsum_partials_k(const double* __restrict__ partial, int nparts, int K,
+                                                               double* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= K) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int p = 0;
+    for (; p + 3 < nparts; p += 4) {
+        s0 += partial[(int64_t)p * K + c];
+        s1 += partial[(int64_t)(p + 1) * K + c];
+        s2 += partial[(int64_t)(p + 2) * K + c];
+        s3 += partial[(int64_t)(p + 3) * K + c];
+    }
+    for (; p < nparts; ++p) s0 += partial[(int64_t)p * K + c];
+    out[c] = (s0 + s1) + (s2 + s3);
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 9: grouped error statistics of Solver.error_analysis (solver.py:108-133, 391-429).
+// Every row carries a category id (group x train/test x row type, built by the host shim); per category the
+// reference needs  n, count_nonzero(w), mean|r|, sum r^2, sum (t - mean t)^2  and the same for w r, w t
+// (r = truth - prediction).  The centred sums need the category means first, hence two passes:
+//   pass 0:  [n, n_w, sum t, sum w t]                       (4 values per category)
+//   pass 1:  [sum|r|, sum r^2, sum (t - mean)^2, sum|w r|, sum (w r)^2, sum (w t - wmean)^2]   (6 values)
+// A workgroup accumulates its rows into an LDS table (ds_add_f64) and writes one partial table; the host sums the
+// partial tables in a fixed order.  HBM-bound: 8 (t) + 8 (w) + 8 (pred) + 4 (cat) bytes per row and pass.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsnap_error_stats_k(const double* __restrict__ truth,
+                                                          const double* __restrict__ pred,
+                                                          const double* __restrict__ wgt, const int* __restrict__ cat,
+                                                          int64_t m, int ncat, int pass,
+                                                          const double* __restrict__ means /* [ncat][2] */,
+                                                          double* __restrict__ partial /* [grid][ncat][nv] */) {
+    extern __shared__ double tab[];
+    const int nv = pass == 0 ? 4 : 6;
+    for (int i = threadIdx.x; i < ncat * nv; i += 256) tab[i] = 0.0;
+    __syncthreads();
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < m; row += (int64_t)gridDim.x * 256) {
+        const int c = cat[row];
+        if (c < 0 || c >= ncat) continue;
+        const double t = truth[row], w = wgt[row];
+        double* e = tab + (size_t)c * nv;
+        if (pass == 0) {
+            atomicAdd(e + 0, 1.0);
+            atomicAdd(e + 1, w != 0.0 ? 1.0 : 0.0);
+            atomicAdd(e + 2, t);
+            atomicAdd(e + 3, w * t);
+        } else {
+            const double r = t - pred[row], wr = w * r;
+            const double dt = t - means[2 * c], dwt = w * t - means[2 * c + 1];
+            atomicAdd(e + 0, fabs(r));
+            atomicAdd(e + 1, r * r);
+            atomicAdd(e + 2, dt * dt);
+            atomicAdd(e + 3, fabs(wr));
+            atomicAdd(e + 4, wr * wr);
+            atomicAdd(e + 5, dwt * dwt);
+        }
+    }
+    __syncthreads();
+    double* out = partial + (size_t)blockIdx.x * ncat * nv;
+    for (int i = threadIdx.x; i < ncat * nv; i += 256) out[i] = tab[i];
+}
+
+// Kernel 10: small device -> page-locked host copy done by a kernel (the copy engine's start-up latency, ~12 us on
+// these boxes, is several times the transfer time of the 132 KB statistics)
+__global__ __launch_bounds__(256) void fsnap_copy_to_host_k(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+// ---------------------------------------------------------------------------------
+// host-side launchers (C++ linkage, used by fsnap_capi.cpp)
+// ---------------------------------------------------------------------------------
+namespace fsnap {
+
+hipError_t launch_weight_rows(const double* A, int64_t lda, const double* b, const double* w,
+                              const unsigned char* mask, int64_t m, int K, double* aw, int64_t ldaw,
+                              double* bw, hipStream_t st) {
+    int64_t nb = (m + 15) / 16;
+    if (nb > 256 * 8) nb = 256 * 8;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(fsnap_weight_rows_k, dim3((unsigned)nb), dim3(256), 0, st, A, lda, b, w, mask, m, K, aw,
+                       ldaw, bw);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble(const double* raw, int64_t raw_ld, int64_t nrows, const int64_t* src_row, const int* kind,
+                           const int* frac, const double* dval, const double* truth, const double* weight,
+                           const double* fractions, const double* blank2J, int ntypes, int ncoeff, int off, double* A,
+                           int64_t lda, double* b, double* w, hipStream_t st) {
+    int64_t nb = (nrows + 3) / 4;
+    if (nb > 256 * 8) nb = 256 * 8;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(fsnap_assemble_k, dim3((unsigned)nb), dim3(256), 0, st, raw, raw_ld, nrows, src_row, kind, frac,
+                       dval, truth, weight, fractions, blank2J, ntypes, ncoeff, off, A, lda, b, w);
+    return hipGetLastError();
+}
+
+int gemvT_num_blocks(int64_t m) {
+    int64_t nb = (m + 63) / 64;
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+hipError_t launch_gemvT_rows(const double* A, int64_t lda, const double* u, int64_t m, int K, double* partial,
+                             double* out, hipStream_t st) {
+    const int nb = gemvT_num_blocks(m);
+    const int64_t rpw = (m + nb - 1) / nb;
+    const size_t lds = (size_t)4 * ((K + 1) & ~1) * sizeof(double);
+    if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)fsnap_gemvT_rows_k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024 - 256);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fsnap_gemvT_rows_k, dim3((unsigned)nb), dim3(256), lds, st, A, lda, u, m, K, rpw, partial);
+    hipLaunchKernelGGL(fsnap_colsum_partials_k, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, partial, nb, K, out);
+    return hipGetLastError();
+}
+
+int error_stats_num_blocks(int64_t m) {
+    int64_t nb = (m + 256 * 16 - 1) / (256 * 16);
+    if (nb > 512) nb = 512;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+hipError_t launch_error_stats(const double* truth, const double* pred, const double* wgt, const int* cat, int64_t m, int ncat,
+                              int pass, const double* means, double* partial, hipStream_t st) {
+    const int nv = pass == 0 ? 4 : 6;
+    const size_t lds = (size_t)ncat * nv * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)fsnap_error_stats_k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024 - 64);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fsnap_error_stats_k, dim3((unsigned)error_stats_num_blocks(m)), dim3(256), lds, st, truth, pred, wgt, cat,
+                       m, ncat, pass, means, partial);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_to_host(const double* src, double* dst_pinned, int64_t n, hipStream_t st) {
+    int64_t nb = (n + 255) / 256;
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(fsnap_copy_to_host_k, dim3((unsigned)nb), dim3(256), 0, st, src, dst_pinned, n);
+    return hipGetLastError();
+}
+
+int gemv_num_blocks(int64_t m) {
+    int64_t nb = (m + 15) / 16;
+    if (nb > 256 * 8) nb = 256 * 8;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+hipError_t launch_gemv_rows(const double* A, int64_t lda, const double* beta, int64_t m, int K, double* preds,
+                            const double* b, const double* w, const unsigned char* mask, double* sse_part,
+                            double* uout, hipStream_t st) {
+    const int nb = gemv_num_blocks(m);
+    hipLaunchKernelGGL(fsnap_gemv_rows_k, dim3((unsigned)nb), dim3(256), (size_t)K * sizeof(double), st, A, lda,
+                       beta, m, K, preds, b, w, mask, sse_part, uout);
+    return hipGetLastError();
+}
+
+}  // namespace fsnap

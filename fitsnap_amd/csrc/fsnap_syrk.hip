@@ -1,5 +1,6 @@
-// fsnap_kernels.hip — hand-written gfx950 (MI355X / CDNA4) kernels for the FitSNAP
-// linear-fit hot path.  No CUDA compatibility layer, no dual paths: this file only
+// fsnap_syrk.hip — hand-written gfx950 (MI355X / CDNA4) kernels of the FitSNAP linear-fit hot path: the fused
+// mask x weight x normal-equation (SYRK) kernels and the reduction of their partials.  The HBM-bound row kernels
+// (weighting, GEMV, assembly, error statistics) are in fsnap_rows.hip, the device Cholesky solves in fsnap_chol.hip.  No CUDA compatibility layer, no dual paths: this file only
 // builds for gfx950 (wave64, v_mfma_f64_16x16x4_f64).
 //
 // What the kernels replace in the reference (file:line into FitSNAP/FitSNAP):
@@ -42,18 +43,10 @@
 // and the training-row count ride along on the VALU.  No floating-point atomics anywhere:
 // results are run-to-run bit-identical for a given (m, K, grid).
 
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
 #include <utility>
 
+#include "fsnap_device_common.h"
 #include "fsnap_kernels.h"
-
-typedef double d4 __attribute__((ext_vector_type(4)));
-typedef double d2 __attribute__((ext_vector_type(2)));
-typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
-typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -1638,710 +1631,8 @@ __global__ __launch_bounds__(1024) void fsnap_reduce_tiled(const double* __restr
 }
 
 // ---------------------------------------------------------------------------------
-// Kernel 3: stand-alone wavefront row weighting (svd.py:46 / ridge.py:39).
-//   aw[i,:] = w[i]*A[i,:], bw[i] = w[i]*b[i] for every row; masked rows are written
-//   as zeros (row compaction is the host shim's business, see fsnap_weight_rows()).
-// One wave per row-slab, 16-byte vector accesses, grid-stride.  HBM-bound:
-// 16K + 24 bytes per row.
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fsnap_weight_rows_k(const double* __restrict__ A, int64_t lda,
-                                                           const double* __restrict__ b,
-                                                           const double* __restrict__ w,
-                                                           const unsigned char* __restrict__ mask, int64_t m,
-                                                           int K, double* __restrict__ aw, int64_t ldaw,
-                                                           double* __restrict__ bw) {
-    // One wave handles 4 consecutive rows per iteration (4 independent 16-byte loads per lane in
-    // flight before the first store: memory-level parallelism for the HBM stream).
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nwave = (int64_t)gridDim.x * 4;
-    const bool vec2 = ((K & 1) == 0) && ((lda & 1) == 0) && ((ldaw & 1) == 0);
-    for (int64_t row0 = wave * 4; row0 < m; row0 += nwave * 4) {
-        double wv[4];
-        bool keep[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t row = row0 + r;
-            const bool in = row < m;
-            keep[r] = in && (mask[in ? row : 0] != 0);
-            wv[r] = in ? w[row] : 0.0;
-        }
-        if (vec2) {
-            for (int c = 2 * lane; c < K; c += 128) {
-                d2u x[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (row0 + r < m) x[r] = __builtin_nontemporal_load(reinterpret_cast<const d2u*>(A + (row0 + r) * lda + c));
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (row0 + r < m) {
-                        d2u y;
-                        y[0] = keep[r] ? wv[r] * x[r][0] : 0.0;
-                        y[1] = keep[r] ? wv[r] * x[r][1] : 0.0;
-                        __builtin_nontemporal_store(y, reinterpret_cast<d2u*>(aw + (row0 + r) * ldaw + c));
-                    }
-                }
-            }
-        } else {
-            for (int c = lane; c < K; c += 64) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (row0 + r < m) aw[(row0 + r) * ldaw + c] = keep[r] ? wv[r] * A[(row0 + r) * lda + c] : 0.0;
-            }
-        }
-        if (lane < 4 && row0 + lane < m) {
-            const int64_t row = row0 + lane;
-            const bool kp = mask[row] != 0;
-            bw[row] = kp ? w[row] * b[row] : 0.0;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// Kernel 4: preds = A @ beta (solver.py:377) and, optionally, per-workgroup partial
-// sums of the weighted squared residual sum_i mask_i (w_i (b_i - preds_i))^2
-// (the SSE that sklearn's ARD loop recomputes each iteration, _bayes.py `rmse_`).
-// 16 lanes per row (4 rows per wave pass), beta staged once in LDS.  HBM-bound.
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fsnap_gemv_rows_k(const double* __restrict__ A, int64_t lda,
-                                                         const double* __restrict__ beta, int64_t m, int K,
-                                                         double* __restrict__ preds,
-                                                         const double* __restrict__ b,
-                                                         const double* __restrict__ w,
-                                                         const unsigned char* __restrict__ mask,
-                                                         double* __restrict__ sse_part,
-                                                         double* __restrict__ uout) {
-    // uout (optional): u_i = mask_i * w_i^2 * (b_i - a_i . beta), the row weights of the
-    // refinement right-hand side  s = (wA)^T (wb - wA beta) = A^T u   (kernel 7)
-    extern __shared__ __attribute__((aligned(16))) double sbeta[];
-    for (int c = threadIdx.x; c < K; c += 256) sbeta[c] = beta[c];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nwave = (int64_t)gridDim.x * 4;
-    double sse = 0.0;
-    for (int64_t r0 = wave * 4; r0 < m; r0 += nwave * 4) {
-        const int64_t row = r0 + kr;
-        double s = 0.0;
-        if (row < m) {
-            const double* src = A + row * lda;
-            if (((K | lda) & 1) == 0) {   // 16-byte loads: two adjacent columns per lane, two accumulators
-                double s1 = 0.0;
-                for (int c = 2 * e; c < K; c += 32) {
-                    const d2u x = __builtin_nontemporal_load(reinterpret_cast<const d2u*>(src + c));
-                    s = __builtin_fma(x[0], sbeta[c], s);
-                    s1 = __builtin_fma(x[1], sbeta[c + 1], s1);
-                }
-                s += s1;
-            } else {
-                for (int c = e; c < K; c += 16) s = __builtin_fma(src[c], sbeta[c], s);
-            }
-        }
-        // reduce over the 16 lanes of the row group
-        s += __shfl_xor(s, 8, 64);
-        s += __shfl_xor(s, 4, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 1, 64);
-        if (row < m && e == 0) {
-            if (preds) preds[row] = s;
-            if (sse_part || uout) {
-                const bool keep = mask ? (mask[row] != 0) : true;
-                const double wr = w[row];
-                const double rr = keep ? wr * (b[row] - s) : 0.0;
-                if (sse_part) sse = __builtin_fma(rr, rr, sse);
-                if (uout) uout[row] = keep ? wr * rr : 0.0;
-            }
-        }
-    }
-    if (sse_part) {
-        __shared__ double wsum[4];
-        sse += __shfl_xor(sse, 16, 64);
-        sse += __shfl_xor(sse, 32, 64);
-        if (lane == 0) wsum[threadIdx.x >> 6] = sse;
-        __syncthreads();
-        if (threadIdx.x == 0) sse_part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// Kernel 5: post-LAMMPS assembly — the `_collect_lammps` transform
-// (fitsnap3lib/calculators/lammps_snap.py:391-556, lammps_pace.py:369-509) for a batch of
-// configurations: raw `compute snap|pace` rows -> rows of A, b, w, written straight into the
-// resident HBM arrays.  One wave per output row, lanes stride the K output columns.
-//   raw      : row-major raw rows, leading dimension raw_ld = ncoeff*ntypes + 1; the last
-//              column (icolref) is the reference-potential contribution
-//   per output row r (SoA plan): src_row[r] raw row, kind[r], d[r], truth[r], weight[r],
-//              frac[r] (index of the per-type atom fractions of its configuration, or -1)
-//   kind 0 energy       : A = x / d              b = (truth - ref) / d   w = weight   (d = N)
-//   kind 1 force        : A = x                  b = truth - ref         w = weight
-//   kind 2 virial       : A = (1.6021765e6 x)/d  b = truth - ref         w = weight   (d = volume)
-//   kind 3 per-atom-energy rows after the first (bikflag): A = x / d, b = 0, w = 0
-//   column k -> type t = k / (ncoeff + off), j = k % (ncoeff + off); with off = 1
-//   (bzeroflag = 0) column j = 0 is the per-type offset column: atom fraction of type t on
-//   energy rows, 0 elsewhere; every column is multiplied by blank2J[k].
-// The arithmetic order is the reference's (divide, not multiply by a reciprocal), so
-// rows are bit-identical to the numpy path.
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fsnap_assemble_k(const double* __restrict__ raw, int64_t raw_ld,
-                                                        int64_t nrows, const int64_t* __restrict__ src_row,
-                                                        const int* __restrict__ kind, const int* __restrict__ frac,
-                                                        const double* __restrict__ dval,
-                                                        const double* __restrict__ truth,
-                                                        const double* __restrict__ weight,
-                                                        const double* __restrict__ fractions,
-                                                        const double* __restrict__ blank2J, int ntypes, int ncoeff,
-                                                        int off, double* __restrict__ A, int64_t lda,
-                                                        double* __restrict__ b, double* __restrict__ w) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nwave = (int64_t)gridDim.x * 4;
-    const int stride = ncoeff + off;
-    const int K = ntypes * stride;
-    const int icolref = ntypes * ncoeff;
-    for (int64_t r = wave; r < nrows; r += nwave) {
-        const double* src = raw + src_row[r] * raw_ld;
-        const int kd = kind[r];
-        const double d = dval[r];
-        const int fr = frac[r];
-        double* dst = A + r * lda;
-        for (int k = lane; k < K; k += 64) {
-            const int t = k / stride, j = k - t * stride;
-            double v;
-            if (off && j == 0) {
-                v = (kd == 0 && fr >= 0) ? fractions[(int64_t)fr * ntypes + t] : 0.0;
-            } else {
-                const double x = src[t * ncoeff + (j - off)];
-                v = (kd == 1) ? x : (kd == 2) ? (1.6021765e6 * x) / d : x / d;
-            }
-            dst[k] = v * blank2J[k];
-        }
-        if (lane == 0) {
-            const double ref = src[icolref];
-            double bv, wv = weight[r];
-            if (kd == 0) bv = (truth[r] - ref) / d;
-            else if (kd == 3) {
-                bv = 0.0;
-                wv = 0.0;
-            } else bv = truth[r] - ref;
-            b[r] = bv;
-            w[r] = wv;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// Kernel 6: K x K solve on the device for K <= 128 (the latency path of a fit: avoids the
-// D2H of G and the host factorisation).  ONE workgroup of 1024 threads; the Jacobi-scaled
-// matrix S = D (G + alpha I) D, D = diag(G + alpha I)^-1/2, is held IN REGISTERS in a 32 x 32
-// block-cyclic distribution (thread (ti, tk) owns S[ti + 32a][tk + 32b], a, b < 4), so the
-// right-looking upper Cholesky S = U^T U does no LDS read-modify-write: per column the owners
-// of the pivot row publish it (unscaled) through a double-buffered 1 KB LDS row, ONE barrier,
-// then every thread updates its 16 elements.  Finished rows of U are parked in LDS (row
-// stride K + 1: row and column access conflict-free) for the forward / backward sweeps,
-// which one wave runs with x in registers and pre-inverted diagonals.
-// Same arithmetic as the host fast path (fsnap_solve.cpp): no refinement; the host falls
-// back to the full host solver when the kernel reports a small pivot, a non-positive
-// diagonal or a non-finite value.
-//   in : packed statistics [G (K*K) | c (K) | ...]
-//   out: [beta (K) | min relative pivot | status (0 ok, 1 = fall back)]
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void fsnap_chol_solve_k(const double* __restrict__ packed, int K, double alpha,
-                                                           double* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int LD = K + 1;
-    double* U = sm;                        // K x LD, final (scaled) rows of U
-    double* dsc = sm + (size_t)K * LD;     // K
-    double* rowbuf = dsc + K;              // 2 x 128, unscaled pivot rows
-    __shared__ int bad;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int ti = tid >> 5, tk = tid & 31;
-    const double* G = packed;
-    const double* c = packed + (size_t)K * K;
-    if (tid == 0) bad = 0;
-    __syncthreads();
-    for (int i = tid; i < K; i += 1024) {
-        const double g = G[(size_t)i * K + i] + alpha;
-        if (!(g > 0.0) || !(g < 1.0e300)) {
-            bad = 1;
-            dsc[i] = 0.0;
-        } else {
-            dsc[i] = 1.0 / sqrt(g);
-        }
-    }
-    __syncthreads();
-    double e[4][4];
-    double chk = 0.0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int i = ti + 32 * a;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int k = tk + 32 * b;
-            double v = 0.0;
-            if (i < K && k < K && k >= i) {
-                const double g = G[(size_t)i * K + k];
-                chk += g * 0.0;
-                v = ((i == k) ? g + alpha : g) * dsc[i] * dsc[k];
-            }
-            e[a][b] = v;
-        }
-    }
-    if (tid < K) chk += c[tid] * 0.0;
-    if (chk != 0.0) bad = 1;   // NaN: some entry was not finite
-    __syncthreads();
-    double minp = 1.0e300;
-    if (!bad) {
-        for (int j = 0; j < K; ++j) {
-            double* rb = rowbuf + (j & 1) * 128;
-            const int aj = j >> 5;
-            if (ti == (j & 31)) {   // owners of row j publish it (unscaled)
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    if (a == aj) {
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            const int k = tk + 32 * b;
-                            if (k >= j && k < K) rb[k] = e[a][b];
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            const double d = rb[j];
-            if (d < minp) minp = d;
-            if (!(d > 0.0)) {   // uniform: every thread reads the same value
-                minp = 0.0;
-                break;
-            }
-            const double r = sqrt(d), inv = 1.0 / r;
-            double fi[4], gk[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int i = ti + 32 * a;
-                fi[a] = (i > j && i < K) ? rb[i] * inv : 0.0;
-            }
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int k = tk + 32 * b;
-                gk[b] = (k > j && k < K) ? rb[k] * inv : 0.0;
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) e[a][b] -= fi[a] * gk[b];   // rows i <= j get fi = 0
-            // park the final row j of U for the sweeps
-            if (ti == (j & 31)) {
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int k = tk + 32 * b;
-                    if (k > j && k < K) U[j * LD + k] = gk[b];
-                    if (k == j) U[j * LD + j] = r;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const bool fail = bad || !(minp > 0.0);
-    if (wv == 0) {
-        if (!fail) {
-            // pre-inverted diagonal
-            const double id0 = (lane < K) ? 1.0 / U[lane * LD + lane] : 0.0;
-            const double id1 = (lane + 64 < K) ? 1.0 / U[(lane + 64) * LD + lane + 64] : 0.0;
-            // forward: U^T y = D c   (axpy form over contiguous rows), x in registers
-            double x0 = (lane < K) ? c[lane] * dsc[lane] : 0.0;
-            double x1 = (lane + 64 < K) ? c[lane + 64] * dsc[lane + 64] : 0.0;
-            for (int k = 0; k < K; ++k) {
-                const double yk = (k < 64) ? __shfl(x0 * id0, k, 64) : __shfl(x1 * id1, k - 64, 64);
-                if (lane == (k & 63)) {
-                    if (k < 64) x0 = yk;
-                    else x1 = yk;
-                }
-                if (lane > k && lane < K) x0 -= U[k * LD + lane] * yk;
-                if (lane + 64 > k && lane + 64 < K) x1 -= U[k * LD + lane + 64] * yk;
-            }
-            // backward: U x = y   (column access; LD = K + 1 keeps it conflict free)
-            for (int i = K - 1; i >= 0; --i) {
-                const double xi = (i < 64) ? __shfl(x0 * id0, i, 64) : __shfl(x1 * id1, i - 64, 64);
-                if (lane == (i & 63)) {
-                    if (i < 64) x0 = xi;
-                    else x1 = xi;
-                }
-                if (lane < i) x0 -= U[lane * LD + i] * xi;
-                if (lane + 64 < i) x1 -= U[(lane + 64) * LD + i] * xi;
-            }
-            if (lane < K) out[lane] = x0 * dsc[lane];
-            if (lane + 64 < K) out[lane + 64] = x1 * dsc[lane + 64];
-        }
-        if (lane == 0) {
-            out[K] = minp;
-            out[K + 1] = fail ? 1.0 : 0.0;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// Kernel 7: s = A^T u  (transposed streaming GEMV, HBM-bound) — with u from kernel 4 this is
-// the right-hand side of one step of iterative refinement of the least-squares solution
-// ("corrected semi-normal equations": G delta = (wA)^T (wb - wA beta), beta += delta), which
-// takes the error of the normal-equation solve from ~kappa^2 eps back to ~kappa eps — what
-// keeps the GPU path within 1e-6 of the reference's lstsq (svd.py:54) on ill-conditioned A.
-// Workgroup = row range; wave v takes rows v, v+4, ...; lane l owns columns 2l, 2l+1 (+128 j).
-// Per-workgroup partial vectors are written to spart2[wg][K] and summed in fixed order.
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fsnap_gemvT_rows_k(const double* __restrict__ A, int64_t lda,
-                                                          const double* __restrict__ u, int64_t m, int K,
-                                                          int64_t rows_per_wg, double* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) double sacc[];   // 4 waves x Kpad
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int Kpad = (K + 1) & ~1;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
-    int64_t r1 = r0 + rows_per_wg;
-    if (r1 > m) r1 = m;
-    const bool vec2 = ((K | lda) & 1) == 0;
-    for (int c0 = 0; c0 < K; c0 += 128) {
-        const int c = c0 + 2 * lane;
-        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-        if (c < K) {
-            int64_t row = r0 + wv;
-            for (; row + 4 < r1; row += 8) {   // two rows in flight per wave
-                const double u0 = u[row], u1 = u[row + 4];
-                double x0, x1, y0, y1;
-                if (vec2) {
-                    const d2u x = *reinterpret_cast<const d2u*>(A + row * lda + c);
-                    const d2u y = *reinterpret_cast<const d2u*>(A + (row + 4) * lda + c);
-                    x0 = x[0]; x1 = x[1]; y0 = y[0]; y1 = y[1];
-                } else {
-                    x0 = A[row * lda + c]; x1 = (c + 1 < K) ? A[row * lda + c + 1] : 0.0;
-                    y0 = A[(row + 4) * lda + c]; y1 = (c + 1 < K) ? A[(row + 4) * lda + c + 1] : 0.0;
-                }
-                a0 = __builtin_fma(x0, u0, a0);
-                a1 = __builtin_fma(x1, u0, a1);
-                b0 = __builtin_fma(y0, u1, b0);
-                b1 = __builtin_fma(y1, u1, b1);
-            }
-            for (; row < r1; row += 4) {
-                const double u0 = u[row];
-                const double x0 = A[row * lda + c];
-                const double x1 = (c + 1 < K) ? A[row * lda + c + 1] : 0.0;
-                a0 = __builtin_fma(x0, u0, a0);
-                a1 = __builtin_fma(x1, u0, a1);
-            }
-            sacc[wv * Kpad + c] = a0 + b0;
-            if (c + 1 < K) sacc[wv * Kpad + c + 1] = a1 + b1;
-        }
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < K; c += 256)
-        partial[(int64_t)blockIdx.x * K + c] = (sacc[c] + sacc[Kpad + c]) + (sacc[2 * Kpad + c] + sacc[3 * Kpad + c]);
-}
-
-__global__ __launch_bounds__(256) void fsnap_colsum_partials_k(const double* __restrict__ partial, int nparts, int K,
-                                                               double* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= K) return;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int p = 0;
-    for (; p + 3 < nparts; p += 4) {
-        s0 += partial[(int64_t)p * K + c];
-        s1 += partial[(int64_t)(p + 1) * K + c];
-        s2 += partial[(int64_t)(p + 2) * K + c];
-        s3 += partial[(int64_t)(p + 3) * K + c];
-    }
-    for (; p < nparts; ++p) s0 += partial[(int64_t)p * K + c];
-    out[c] = (s0 + s1) + (s2 + s3);
-}
-
-// ---------------------------------------------------------------------------------
 // host-side launchers (C++ linkage, used by fsnap_capi.cpp)
 // ---------------------------------------------------------------------------------
-// ---------------------------------------------------------------------------------
-// Kernels 8a-8e: blocked Cholesky solve of the K x K statistics on the GPU for LARGE K (ACE / quadratic-SNAP
-// widths; the host factorisation takes 20-40 ms at K = 1595, this path ~1 ms).  Same algorithm as the host fast
-// path (fsnap_solve.cpp): Jacobi scaling S = D (G + alpha I) D with D = diag(G + alpha I)^-1/2, S = U^T U,
-// two triangular sweeps, beta = D x; accepted by the caller only if every pivot of the scaled matrix stays
-// above 1e-3 (otherwise the general host path runs).
-// The work matrix is padded to a multiple of 64 with an identity block, so no kernel has edge cases:
-//   8a prepare   d, z = D c, status; S (upper and lower) into the padded work matrix
-//   per 64-row panel [jb, je):
-//   8b diag      one workgroup factorises the 64 x 64 diagonal block in LDS (64-step recurrence)
-//   8c tails     one thread per trailing column: forward substitution U12 = U11^-T S12
-//   8d update    S22 -= U12^T U12 on the matrix pipe: one wave per 32 x 32 block pair (2 x 2 MFMA tiles),
-//                k = 64 rows in 16 MFMA steps -- a 64-row SYRK, the same operand trick as kernel 1
-//   8e sweeps    one workgroup: blocked forward / backward substitution and the un-scaling
-// status[0]: bit 0 = non-positive / non-finite diagonal of G + alpha I, bit 1 = failed pivot;
-// minpiv[p] = smallest pivot of panel p.
-// ---------------------------------------------------------------------------------
-constexpr int CHOL_NB = 64;
-
-__global__ __launch_bounds__(256) void fsnap_chol_prepare_d_k(const double* __restrict__ packed,
-                                                             const double* __restrict__ cvec, int n, int np,
-                                                             double alpha, double* __restrict__ dsc,
-                                                             double* __restrict__ z, int* __restrict__ status,
-                                                             double* __restrict__ minpiv, int npanel) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < npanel) minpiv[i] = 1.0e300;
-    if (i >= np) return;
-    if (i >= n) {
-        dsc[i] = 1.0;
-        z[i] = 0.0;
-        return;
-    }
-    const double g = packed[(size_t)i * n + i] + alpha;
-    const double c = cvec[i];
-    const bool ok = (g > 0.0) && __builtin_isfinite(g) && __builtin_isfinite(c);
-    const double d = ok ? 1.0 / sqrt(g) : 0.0;
-    dsc[i] = d;
-    z[i] = ok ? c * d : 0.0;
-    if (!ok) atomicOr(status, 1);
-}
-
-__global__ __launch_bounds__(256) void fsnap_chol_prepare_s_k(const double* __restrict__ packed, int n, int np,
-                                                             double alpha, const double* __restrict__ dsc,
-                                                             double* __restrict__ S, int* __restrict__ status) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int i = blockIdx.y;
-    if (j >= np) return;
-    double v;
-    if (i < n && j < n) {
-        const double g = packed[(size_t)i * n + j] + ((i == j) ? alpha : 0.0);
-        v = g * dsc[i] * dsc[j];
-        // (not `v - v == 0`: with fp contraction that becomes fma(g d_i, d_j, -v), the rounding error of the product)
-        if (!__builtin_isfinite(v)) atomicOr(status, 1);
-    } else {
-        v = (i == j) ? 1.0 : 0.0;
-    }
-    S[(size_t)i * np + j] = v;
-}
-
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
-// 8b: ONE wave, lane c holds column c of the 64 x 64 block in 64 registers; the recurrence is fully unrolled, the
-// pivot row entry B[j][i] reaches all lanes through v_readlane (scalar broadcast): no LDS, no barrier.  Entries
-// below the diagonal are updated along (never read, not written back).  (Measured 58 us per block; an LDS version
-// with 256 threads took 95 us, one with 4 x 4 register sub-blocks and two barriers per step 168 us: these
-// single-workgroup kernels run while the chip is almost idle, at whatever clock it then holds.)
-__global__ __launch_bounds__(64) void fsnap_chol_diag_k(double* __restrict__ S, int np, int jb, int* __restrict__ status,
-                                                       double* __restrict__ minpiv) {
-    const int c = threadIdx.x;
-    double col[CHOL_NB];
-#pragma unroll
-    for (int r = 0; r < CHOL_NB; ++r) col[r] = S[(size_t)(jb + r) * np + jb + c];
-    double pmin = 1.0e300;
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < CHOL_NB; ++j) {
-        const double d = readlane_f64(col[j], j);          // pivot (the same value in every lane)
-        bad = bad || !(d > 0.0) || !__builtin_isfinite(d);
-        pmin = d < pmin ? d : pmin;
-        const double r = sqrt(d), inv = 1.0 / r;
-        col[j] = (c == j) ? r : col[j] * inv;
-#pragma unroll
-        for (int i = j + 1; i < CHOL_NB; ++i) {
-            const double f = readlane_f64(col[j], i);      // B[j][i]
-            col[i] = __builtin_fma(-f, col[j], col[i]);    // B[i][c] -= B[j][i] * B[j][c]
-        }
-    }
-    if (bad) {
-        if (c == 0) atomicOr(status, 2);
-        return;
-    }
-#pragma unroll
-    for (int r = 0; r < CHOL_NB; ++r)
-        if (c >= r) S[(size_t)(jb + r) * np + jb + c] = col[r];
-    if (c == 0) minpiv[jb / CHOL_NB] = pmin;
-}
-
-// 8c: one thread per trailing column, forward substitution over the 64 panel rows with U11 in LDS (uniform reads)
-__global__ __launch_bounds__(256) void fsnap_chol_tails_k(double* __restrict__ S, int np, int jb,
-                                                         const int* __restrict__ status) {
-    __shared__ double U11[CHOL_NB][CHOL_NB + 1];
-    __shared__ double rinv[CHOL_NB];
-    if (*status) return;
-    const int tid = threadIdx.x;
-    for (int t = tid; t < CHOL_NB * CHOL_NB; t += 256) {
-        const int i = t >> 6, k = t & 63;
-        U11[i][k] = S[(size_t)(jb + i) * np + jb + k];
-    }
-    __syncthreads();
-    if (tid < CHOL_NB) rinv[tid] = 1.0 / U11[tid][tid];
-    __syncthreads();
-    const int c = jb + CHOL_NB + blockIdx.x * 256 + tid;
-    if (c >= np) return;
-    double x[CHOL_NB];
-#pragma unroll
-    for (int k = 0; k < CHOL_NB; ++k) x[k] = S[(size_t)(jb + k) * np + c];
-#pragma unroll
-    for (int k = 0; k < CHOL_NB; ++k) {
-        double v = x[k];
-#pragma unroll
-        for (int p = 0; p < k; ++p) v -= U11[p][k] * x[p];
-        x[k] = v * rinv[k];
-    }
-#pragma unroll
-    for (int k = 0; k < CHOL_NB; ++k) S[(size_t)(jb + k) * np + c] = x[k];
-}
-
-__global__ __launch_bounds__(256) void fsnap_chol_update_k(double* __restrict__ S, int np, int jb, int nblk,
-                                                          const int* __restrict__ status) {
-    if (*status) return;
-    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
-    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pair >= nblk * (nblk + 1) / 2) return;
-    // pair -> (I, J), I <= J, row-major packed triangle over nblk 32-column blocks
-    int I = 0, rem = pair;
-    while (rem >= nblk - I) {
-        rem -= nblk - I;
-        ++I;
-    }
-    const int J = I + rem;
-    const int je = jb + CHOL_NB;
-    const int cI = je + 32 * I, cJ = je + 32 * J;
-    d4 a00 = {0, 0, 0, 0}, a01 = a00, a10 = a00, a11 = a00;
-    const double* base = S + (size_t)(jb + kr) * np;
-#pragma unroll 4
-    for (int s4 = 0; s4 < CHOL_NB / 4; ++s4) {
-        const double* r = base + (size_t)(4 * s4) * np;
-        const double x0 = r[cI + e], x1 = r[cI + 16 + e];
-        const double y0 = r[cJ + e], y1 = r[cJ + 16 + e];
-        a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y0, a00, 0, 0, 0);
-        a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y1, a01, 0, 0, 0);
-        a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y0, a10, 0, 0, 0);
-        a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y1, a11, 0, 0, 0);
-    }
-    // D tile layout: element (row = kr + 4 r, col = e)
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-        const int row = kr + 4 * r4;
-        double* p0 = S + (size_t)(cI + row) * np;
-        double* p1 = S + (size_t)(cI + 16 + row) * np;
-        p0[cJ + e] -= a00[r4];
-        p0[cJ + 16 + e] -= a01[r4];
-        p1[cJ + e] -= a10[r4];
-        p1[cJ + 16 + e] -= a11[r4];
-    }
-}
-
-__global__ __launch_bounds__(1024) void fsnap_chol_sweeps_k(const double* __restrict__ S, int np, int n,
-                                                           double* __restrict__ z, const double* __restrict__ dsc,
-                                                           double* __restrict__ beta, const int* __restrict__ status) {
-    // z (length np, global) is solved in place: forward U^T y = z, backward U x = y; beta = D x
-    __shared__ double U11[CHOL_NB][CHOL_NB + 1];
-    __shared__ double xb[CHOL_NB];
-    __shared__ double red[1024];
-    if (*status) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int npanel = np / CHOL_NB;
-    for (int pb = 0; pb < npanel; ++pb) {
-        const int jb = pb * CHOL_NB, je = jb + CHOL_NB;
-        for (int t = tid; t < CHOL_NB * CHOL_NB; t += 1024) U11[t >> 6][t & 63] = S[(size_t)(jb + (t >> 6)) * np + jb + (t & 63)];
-        __syncthreads();
-        if (wv == 0) {      // 64 x 64 lower-triangular solve (U11^T y = z_b) inside one wave
-            double v = z[jb + lane];
-            const double rdiag = 1.0 / U11[lane][lane];
-            for (int k = 0; k < CHOL_NB; ++k) {
-                const double yk = readlane_f64(v, k) * readlane_f64(rdiag, k);
-                if (lane == k) v = yk;
-                else if (lane > k) v -= U11[k][lane] * yk;
-            }
-            xb[lane] = v;
-            z[jb + lane] = v;
-        }
-        __syncthreads();
-        for (int c = je + tid; c < np; c += 1024) {
-            double acc = z[c];
-#pragma unroll 8
-            for (int k = 0; k < CHOL_NB; ++k) acc -= S[(size_t)(jb + k) * np + c] * xb[k];
-            z[c] = acc;
-        }
-        __syncthreads();
-    }
-    for (int pb = npanel - 1; pb >= 0; --pb) {
-        const int jb = pb * CHOL_NB, je = jb + CHOL_NB;
-        for (int t = tid; t < CHOL_NB * CHOL_NB; t += 1024) U11[t >> 6][t & 63] = S[(size_t)(jb + (t >> 6)) * np + jb + (t & 63)];
-        // row k of the panel: z_k -= sum_{c >= je} U[k][c] x_c, 16 threads per row
-        {
-            const int k = tid >> 4, q = tid & 15;
-            double acc = 0.0;
-            const double* r = S + (size_t)(jb + k) * np;
-            for (int c = je + q; c < np; c += 16) acc += r[c] * z[c];
-            red[tid] = acc;
-        }
-        __syncthreads();
-        if (wv == 0) {
-            double v = z[jb + lane];
-            double sub = 0.0;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) sub += red[lane * 16 + q];
-            v -= sub;
-            const double rdiag = 1.0 / U11[lane][lane];
-            for (int k = CHOL_NB - 1; k >= 0; --k) {
-                const double xk = readlane_f64(v, k) * readlane_f64(rdiag, k);
-                if (lane == k) v = xk;
-                else if (lane < k) v -= U11[lane][k] * xk;
-            }
-            z[jb + lane] = v;
-        }
-        __syncthreads();
-    }
-    for (int i = tid; i < n; i += 1024) beta[i] = z[i] * dsc[i];
-}
-
-// ---------------------------------------------------------------------------------
-// Kernel 9: grouped error statistics of Solver.error_analysis (solver.py:108-133, 391-429).
-// Every row carries a category id (group x train/test x row type, built by the host shim); per category the
-// reference needs  n, count_nonzero(w), mean|r|, sum r^2, sum (t - mean t)^2  and the same for w r, w t
-// (r = truth - prediction).  The centred sums need the category means first, hence two passes:
-//   pass 0:  [n, n_w, sum t, sum w t]                       (4 values per category)
-//   pass 1:  [sum|r|, sum r^2, sum (t - mean)^2, sum|w r|, sum (w r)^2, sum (w t - wmean)^2]   (6 values)
-// A workgroup accumulates its rows into an LDS table (ds_add_f64) and writes one partial table; the host sums the
-// partial tables in a fixed order.  HBM-bound: 8 (t) + 8 (w) + 8 (pred) + 4 (cat) bytes per row and pass.
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fsnap_error_stats_k(const double* __restrict__ truth,
-                                                          const double* __restrict__ pred,
-                                                          const double* __restrict__ wgt, const int* __restrict__ cat,
-                                                          int64_t m, int ncat, int pass,
-                                                          const double* __restrict__ means /* [ncat][2] */,
-                                                          double* __restrict__ partial /* [grid][ncat][nv] */) {
-    extern __shared__ double tab[];
-    const int nv = pass == 0 ? 4 : 6;
-    for (int i = threadIdx.x; i < ncat * nv; i += 256) tab[i] = 0.0;
-    __syncthreads();
-    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < m; row += (int64_t)gridDim.x * 256) {
-        const int c = cat[row];
-        if (c < 0 || c >= ncat) continue;
-        const double t = truth[row], w = wgt[row];
-        double* e = tab + (size_t)c * nv;
-        if (pass == 0) {
-            atomicAdd(e + 0, 1.0);
-            atomicAdd(e + 1, w != 0.0 ? 1.0 : 0.0);
-            atomicAdd(e + 2, t);
-            atomicAdd(e + 3, w * t);
-        } else {
-            const double r = t - pred[row], wr = w * r;
-            const double dt = t - means[2 * c], dwt = w * t - means[2 * c + 1];
-            atomicAdd(e + 0, fabs(r));
-            atomicAdd(e + 1, r * r);
-            atomicAdd(e + 2, dt * dt);
-            atomicAdd(e + 3, fabs(wr));
-            atomicAdd(e + 4, wr * wr);
-            atomicAdd(e + 5, dwt * dwt);
-        }
-    }
-    __syncthreads();
-    double* out = partial + (size_t)blockIdx.x * ncat * nv;
-    for (int i = threadIdx.x; i < ncat * nv; i += 256) out[i] = tab[i];
-}
-
-// Kernel 10: small device -> page-locked host copy done by a kernel (the copy engine's start-up latency, ~12 us on
-// these boxes, is several times the transfer time of the 132 KB statistics)
-__global__ __launch_bounds__(256) void fsnap_copy_to_host_k(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
-}
-
 namespace fsnap {
 
 int syrk_num_blocks(int K) { return (K + 15) / 16; }
@@ -2556,137 +1847,6 @@ hipError_t launch_reduce_tiled(const TiledArgs& a, double* out, bool accumulate,
     dim3 grid((unsigned)((nelem + 63) / 64)), block(1024);
     hipLaunchKernelGGL(fsnap_reduce_tiled, grid, block, 0, st, a.part, a.cpart, a.spart, a.nsplit, a.NSB, a.npairs, a.K,
                        out, accumulate ? 1 : 0);
-    return hipGetLastError();
-}
-
-hipError_t launch_weight_rows(const double* A, int64_t lda, const double* b, const double* w,
-                              const unsigned char* mask, int64_t m, int K, double* aw, int64_t ldaw,
-                              double* bw, hipStream_t st) {
-    int64_t nb = (m + 15) / 16;
-    if (nb > 256 * 8) nb = 256 * 8;
-    if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(fsnap_weight_rows_k, dim3((unsigned)nb), dim3(256), 0, st, A, lda, b, w, mask, m, K, aw,
-                       ldaw, bw);
-    return hipGetLastError();
-}
-
-hipError_t launch_assemble(const double* raw, int64_t raw_ld, int64_t nrows, const int64_t* src_row, const int* kind,
-                           const int* frac, const double* dval, const double* truth, const double* weight,
-                           const double* fractions, const double* blank2J, int ntypes, int ncoeff, int off, double* A,
-                           int64_t lda, double* b, double* w, hipStream_t st) {
-    int64_t nb = (nrows + 3) / 4;
-    if (nb > 256 * 8) nb = 256 * 8;
-    if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(fsnap_assemble_k, dim3((unsigned)nb), dim3(256), 0, st, raw, raw_ld, nrows, src_row, kind, frac,
-                       dval, truth, weight, fractions, blank2J, ntypes, ncoeff, off, A, lda, b, w);
-    return hipGetLastError();
-}
-
-int gemvT_num_blocks(int64_t m) {
-    int64_t nb = (m + 63) / 64;
-    if (nb > 2048) nb = 2048;
-    if (nb < 1) nb = 1;
-    return (int)nb;
-}
-
-hipError_t launch_gemvT_rows(const double* A, int64_t lda, const double* u, int64_t m, int K, double* partial,
-                             double* out, hipStream_t st) {
-    const int nb = gemvT_num_blocks(m);
-    const int64_t rpw = (m + nb - 1) / nb;
-    const size_t lds = (size_t)4 * ((K + 1) & ~1) * sizeof(double);
-    if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)fsnap_gemvT_rows_k, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024 - 256);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(fsnap_gemvT_rows_k, dim3((unsigned)nb), dim3(256), lds, st, A, lda, u, m, K, rpw, partial);
-    hipLaunchKernelGGL(fsnap_colsum_partials_k, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, partial, nb, K, out);
-    return hipGetLastError();
-}
-
-int error_stats_num_blocks(int64_t m) {
-    int64_t nb = (m + 256 * 16 - 1) / (256 * 16);
-    if (nb > 512) nb = 512;
-    if (nb < 1) nb = 1;
-    return (int)nb;
-}
-
-hipError_t launch_error_stats(const double* truth, const double* pred, const double* wgt, const int* cat, int64_t m, int ncat,
-                              int pass, const double* means, double* partial, hipStream_t st) {
-    const int nv = pass == 0 ? 4 : 6;
-    const size_t lds = (size_t)ncat * nv * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)fsnap_error_stats_k, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024 - 64);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(fsnap_error_stats_k, dim3((unsigned)error_stats_num_blocks(m)), dim3(256), lds, st, truth, pred, wgt, cat,
-                       m, ncat, pass, means, partial);
-    return hipGetLastError();
-}
-
-hipError_t launch_copy_to_host(const double* src, double* dst_pinned, int64_t n, hipStream_t st) {
-    int64_t nb = (n + 255) / 256;
-    if (nb > 256) nb = 256;
-    hipLaunchKernelGGL(fsnap_copy_to_host_k, dim3((unsigned)nb), dim3(256), 0, st, src, dst_pinned, n);
-    return hipGetLastError();
-}
-
-hipError_t launch_chol_large(const double* packed, const double* cvec, int n, double alpha, double* S, double* dsc, double* z,
-                             double* beta, int* status, double* minpiv, hipStream_t st) {
-    if (!cvec) cvec = packed + (size_t)n * n;
-    const int np = (n + CHOL_NB - 1) / CHOL_NB * CHOL_NB, npanel = np / CHOL_NB;
-    hipError_t e = hipMemsetAsync(status, 0, sizeof(int), st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fsnap_chol_prepare_d_k, dim3((np + 255) / 256), dim3(256), 0, st, packed, cvec, n, np, alpha, dsc, z, status,
-                       minpiv, npanel);
-    hipLaunchKernelGGL(fsnap_chol_prepare_s_k, dim3((np + 255) / 256, np), dim3(256), 0, st, packed, n, np, alpha, dsc, S,
-                       status);
-    for (int pb = 0; pb < npanel; ++pb) {
-        const int jb = pb * CHOL_NB;
-        hipLaunchKernelGGL(fsnap_chol_diag_k, dim3(1), dim3(64), 0, st, S, np, jb, status, minpiv);
-        const int ntail = np - jb - CHOL_NB;
-        if (ntail > 0) {
-            hipLaunchKernelGGL(fsnap_chol_tails_k, dim3((ntail + 255) / 256), dim3(256), 0, st, S, np, jb, status);
-            const int nblk = ntail / 32, npair = nblk * (nblk + 1) / 2;
-            hipLaunchKernelGGL(fsnap_chol_update_k, dim3((npair + 3) / 4), dim3(256), 0, st, S, np, jb, nblk, status);
-        }
-    }
-    hipLaunchKernelGGL(fsnap_chol_sweeps_k, dim3(1), dim3(1024), 0, st, S, np, n, z, dsc, beta, status);
-    return hipGetLastError();
-}
-
-hipError_t launch_chol_solve(const double* packed, int K, double alpha, double* out, hipStream_t st) {
-    const size_t lds = ((size_t)K * (K + 1) + (size_t)K + 256) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)fsnap_chol_solve_k, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024 - 64);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(fsnap_chol_solve_k, dim3(1), dim3(1024), lds, st, packed, K, alpha, out);
-    return hipGetLastError();
-}
-
-int gemv_num_blocks(int64_t m) {
-    int64_t nb = (m + 15) / 16;
-    if (nb > 256 * 8) nb = 256 * 8;
-    if (nb < 1) nb = 1;
-    return (int)nb;
-}
-
-hipError_t launch_gemv_rows(const double* A, int64_t lda, const double* beta, int64_t m, int K, double* preds,
-                            const double* b, const double* w, const unsigned char* mask, double* sse_part,
-                            double* uout, hipStream_t st) {
-    const int nb = gemv_num_blocks(m);
-    hipLaunchKernelGGL(fsnap_gemv_rows_k, dim3((unsigned)nb), dim3(256), (size_t)K * sizeof(double), st, A, lda,
-                       beta, m, K, preds, b, w, mask, sse_part, uout);
     return hipGetLastError();
 }
 

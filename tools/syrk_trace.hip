@@ -5,7 +5,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DFSNAP_TRACE=1 tools/syrk_trace.hip -o tools/syrk_trace
 //   (-DFSNAP_TRACE=2 adds per-wave phase clocks inside the stage loop; they perturb the kernel by ~20 %)
 //   usage: syrk_trace [rows] [workgroups] [verbose] [waves per workgroup: 8|4|16] [variant]
-#include "../fitsnap_amd/csrc/fsnap_kernels.hip"
+#include "../fitsnap_amd/csrc/fsnap_syrk.hip"
 
 #include <algorithm>
 #include <cstdio>
