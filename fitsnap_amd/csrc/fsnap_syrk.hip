@@ -20,18 +20,16 @@
 // Kernels (details at each definition):
 //   1   fsnap_syrk_wave        fused mask x weight x [A|b]^T [A|b], one wave = whole block
 //                              triangle in registers, no LDS (K <= 80; SPLIT = 2 variant for A/B)
-//   1L  fsnap_syrk_lds_static  same statistics for 80 < K <= 128 (the BASELINE shape): rows
-//                              read ONCE per workgroup, weighted once, shared through LDS in
-//                              MFMA-fragment order; per-wave specialised bodies (default).
+//   1L  fsnap_syrk_lds_static  same statistics for 80 < K <= 128: rows read ONCE per workgroup, weighted once,
+//                              shared through LDS in MFMA-fragment order; per-wave specialised bodies
+//                              (the default before kernel 1A; option kernel = 2).
 //       fsnap_syrk_lds         generic tile-table variant of 1L (A/B)
 //   1T  fsnap_syrk_tiled       general K > 128: 64-column superblock pairs x row splits
 //   2   fsnap_reduce_partials / fsnap_reduce_tiled   deterministic fixed-order reduction of the
 //                              per-workgroup partial triangles -> packed [G | c | scalars];
 //                              un-permutes the even/odd column interleave, mirrors the triangle
-//   3   fsnap_weight_rows_k    stand-alone wavefront row weighting (HBM-bound)
-//   4   fsnap_gemv_rows_k      preds = A @ beta (+ weighted SSE), HBM-bound
-//   5   fsnap_assemble_k       post-LAMMPS assembly (_collect_lammps transform) into HBM rows
-//   6   fsnap_chol_solve_k     K x K Cholesky solve on one workgroup (optional; host is faster)
+//   1A  fsnap_syrk_acc         80 < K <= 128, DEFAULT: one wave per SIMD owns the whole tile triangle (32 tiles in
+//                              the accumulation registers, named in inline assembly), streams its own rows, no LDS
 //
 // Common operand trick of kernels 1 / 1L / 1T: v_mfma_f64_16x16x4_f64 takes
 // A[i = lane&15][k = lane>>4] and B[k = lane>>4][j = lane&15]; with k = row inside a 4-row

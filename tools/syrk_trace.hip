@@ -70,7 +70,8 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     float ms = 0;
-    for (int it = 0; it < 6; ++it) {
+    // ~200 launches first: an idle MI355X needs ~35 ms of load to reach its steady clock (scripts/ramptest.py)
+    for (int it = 0; it < 200; ++it) {
         CK(hipEventRecord(e0, 0));
         if (nw == 1) CK(fsnap::launch_syrk_acc(a, 0));
         else CK(fsnap::launch_syrk_lds(a, 0));
