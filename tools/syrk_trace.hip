@@ -8,6 +8,7 @@
 #include "../fitsnap_amd/csrc/fsnap_syrk.hip"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -40,6 +41,7 @@ int main(int argc, char** argv) {
     const int verbose = argc > 3 ? atoi(argv[3]) : 0;
     const int nw = argc > 4 ? atoi(argv[4]) : 8;        // waves per workgroup (8 default, 4, 16)
     const int ablate = argc > 5 ? atoi(argv[5]) : 0;    // kernel variant (option "ablate")
+    const int gap_us = argc > 6 ? atoi(argv[6]) : 0;    // idle time between launches
     double *A, *b, *w, *part, *cpart, *spart;
     unsigned char* mask;
     CK(hipMalloc(&A, (size_t)m * K * 8 + 256));
@@ -78,6 +80,10 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e1, 0));
         CK(hipDeviceSynchronize());
         CK(hipEventElapsedTime(&ms, e0, e1));
+        if (gap_us > 0) {      // idle gap between launches (a fit loop's host solve), busy-waited
+            const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(gap_us);
+            while (std::chrono::steady_clock::now() < t_end) {}
+        }
     }
     std::vector<unsigned long long> tr((size_t)nblocks * 8);
     CK(hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(fsnap_trace_buf), tr.size() * 8));
@@ -86,7 +92,7 @@ int main(int argc, char** argv) {
         tmin = std::min(tmin, tr[g * 8]);
         tmax = std::max(tmax, tr[g * 8 + 1]);
     }
-    printf("nw=%d variant=%d ", nw, ablate);
+    printf("nw=%d variant=%d gap=%dus ", nw, ablate, gap_us);
     printf("m=%lld workgroups=%d chunks/wg=%lld kernel %.1f us (events), trace span %.1f us\n", (long long)m, nblocks,
            (long long)cpwg, ms * 1e3, (tmax - tmin) * 0.01);
     std::map<unsigned, std::vector<int>> bycu;
