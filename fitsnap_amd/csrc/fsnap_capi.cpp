@@ -1006,24 +1006,8 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
             return ctx->fail(FSNAP_E_NOMEM, "hipHostMalloc(%zu) failed", need);
         ctx->pinned_bytes = need;
     }
-    if (need <= (1u << 20) && ctx->opt_mirror) {
-        // small statistics (e.g. the all-reduced buffer of the multi-GPU path): copy kernel into the page-locked
-        // staging + event poll instead of the copy engine + blocking wait
-        if (!ctx->mirror_ev && hipEventCreateWithFlags(&ctx->mirror_ev, hipEventDisableTiming) != hipSuccess)
-            ctx->mirror_ev = nullptr;
-    }
-    if (need <= (1u << 20) && ctx->opt_mirror && ctx->mirror_ev) {
-        FSNAP_HIP(fsnap::launch_copy_to_host(d_packed, ctx->pinned, (int64_t)(need / 8), ctx->stream), "launch fsnap_copy_to_host_k");
-        FSNAP_HIP(hipEventRecord(ctx->mirror_ev, ctx->stream), "hipEventRecord");
-        while (true) {
-            const hipError_t q = hipEventQuery(ctx->mirror_ev);
-            if (q == hipSuccess) break;
-            if (q != hipErrorNotReady) return ctx->hipfail(q, "hipEventQuery");
-        }
-    } else {
-        FSNAP_HIP(hipMemcpyAsync(ctx->pinned, d_packed, need, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(G)");
-        FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
-    }
+    FSNAP_HIP(hipMemcpyAsync(ctx->pinned, d_packed, need, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(G)");
+    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     const double* G = ctx->pinned;
     const int rc = fsnap_solve(kind, param, K, G, rhs ? rhs : G + K * K, beta, rank, rcond_est);
     if (rc) ctx->fail(rc, "fsnap_solve: numerical status %d", rc);

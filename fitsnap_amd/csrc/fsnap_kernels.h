@@ -74,7 +74,6 @@ hipError_t launch_gemv_rows(const double* A, int64_t lda, const double* beta, in
                             const double* b, const double* w, const unsigned char* mask, double* sse_part,
                             double* uout, hipStream_t st);
 int gemvT_num_blocks(int64_t m);
-hipError_t launch_copy_to_host(const double* src, double* dst_pinned, int64_t n, hipStream_t st);
 int error_stats_num_blocks(int64_t m);
 // pass 0: partial[grid][ncat][4] = n, n_w, sum t, sum w t; pass 1: partial[grid][ncat][6] (see kernel 9)
 hipError_t launch_error_stats(const double* truth, const double* pred, const double* wgt, const int* cat, int64_t m, int ncat,

@@ -4,7 +4,6 @@
 //   5   fsnap_assemble_k       post-LAMMPS assembly (_collect_lammps)         (lammps_snap.py:391-556)
 //   7   fsnap_gemvT_rows_k     s = A^T u (right-hand side of a refinement step)
 //   9   fsnap_error_stats_k    grouped error statistics of error_analysis     (solver.py:108-133)
-//   10  fsnap_copy_to_host_k   small device -> page-locked host copy
 // Every kernel here moves each byte once; the roofline is HBM bandwidth.
 #include "fsnap_device_common.h"
 #include "fsnap_kernels.h"
@@ -319,11 +318,6 @@ __global__ __launch_bounds__(256) void fsnap_error_stats_k(const double* __restr
     for (int i = threadIdx.x; i < ncat * nv; i += 256) out[i] = tab[i];
 }
 
-// Kernel 10: small device -> page-locked host copy done by a kernel (the copy engine's start-up latency, ~12 us on
-// these boxes, is several times the transfer time of the 132 KB statistics)
-__global__ __launch_bounds__(256) void fsnap_copy_to_host_k(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
-}
 // ---------------------------------------------------------------------------------
 // host-side launchers (C++ linkage, used by fsnap_capi.cpp)
 // ---------------------------------------------------------------------------------
@@ -397,13 +391,6 @@ hipError_t launch_error_stats(const double* truth, const double* pred, const dou
     }
     hipLaunchKernelGGL(fsnap_error_stats_k, dim3((unsigned)error_stats_num_blocks(m)), dim3(256), lds, st, truth, pred, wgt, cat,
                        m, ncat, pass, means, partial);
-    return hipGetLastError();
-}
-
-hipError_t launch_copy_to_host(const double* src, double* dst_pinned, int64_t n, hipStream_t st) {
-    int64_t nb = (n + 255) / 256;
-    if (nb > 256) nb = 256;
-    hipLaunchKernelGGL(fsnap_copy_to_host_k, dim3((unsigned)nb), dim3(256), 0, st, src, dst_pinned, n);
     return hipGetLastError();
 }
 
