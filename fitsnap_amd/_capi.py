@@ -343,9 +343,11 @@ class HipContext:
         beta = _f64(beta, "beta").reshape(-1)
         if beta.shape[0] != self.K:
             raise ValueError("beta must have K entries")
-        cat = np.ascontiguousarray(cat, dtype=np.int32)
-        if cat.shape != (self.m,):
-            raise ValueError("cat must have one entry per row")
+        if cat is not None:
+            cat = np.ascontiguousarray(cat, dtype=np.int32)
+            if cat.shape != (self.m,):
+                raise ValueError("cat must have one entry per row")
+            self.cat_serial = getattr(self, "cat_serial", 0) + 1    # identifies the categories now on the device
         stats = np.empty((int(ncat), 10), dtype=np.float64)
         self._check(self._lib.fsnap_error_stats(self._h, _ptr(beta), _ptr(cat), int(ncat), _ptr(stats)))
         return stats

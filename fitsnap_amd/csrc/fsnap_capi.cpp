@@ -75,6 +75,7 @@ struct fsnap_ctx {
     DevBuf dsolve;                                // [beta | min pivot | status] of fsnap_solve_device
     DevBuf dchol;                                 // padded work matrix of the blocked device Cholesky
     DevBuf dcat, dstat;                           // fsnap_error_stats: row categories, partial tables + means
+    int64_t dcat_rows = -1;                       // number of rows the categories on the device belong to
     DevBuf du, dspart, dsvec;                     // refinement: row weights u, per-workgroup partials, s
     double* pinned = nullptr;                     // page-locked host staging of the packed statistics
     size_t pinned_bytes = 0;
@@ -847,7 +848,9 @@ int fsnap_error_stats(fsnap_ctx* ctx, const double* beta, const int32_t* cat, in
     if (!ctx) return FSNAP_E_ARG;
     int rc;
     if ((rc = check_rows(ctx)) || (rc = check_weights(ctx))) return rc;
-    if (!beta || !cat || !stats || ncat <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_error_stats: bad argument");
+    if (!beta || !stats || ncat <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_error_stats: bad argument");
+    if (!cat && (ctx->dcat_rows != ctx->m || !ctx->dcat.p))
+        return ctx->fail(FSNAP_E_STATE, "fsnap_error_stats: no categories on the device for these rows");
     if (ncat > 3000) return ctx->fail(FSNAP_E_ARG, "fsnap_error_stats: more than 3000 categories");   // LDS table
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     const size_t m = (size_t)ctx->m, K = (size_t)ctx->K;
@@ -858,7 +861,10 @@ int fsnap_error_stats(fsnap_ctx* ctx, const double* beta, const int32_t* cat, in
     double* d_partial = (double*)ctx->dstat.p;
     double* d_means = d_partial + (size_t)nb * ncat * 6;
     FSNAP_HIP(hipMemcpyAsync(ctx->beta.p, beta, K * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(beta)");
-    FSNAP_HIP(hipMemcpyAsync(ctx->dcat.p, cat, m * 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(categories)");
+    if (cat) {
+        FSNAP_HIP(hipMemcpyAsync(ctx->dcat.p, cat, m * 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(categories)");
+        ctx->dcat_rows = ctx->m;
+    }
     FSNAP_HIP(fsnap::launch_gemv_rows(ctx->dA, ctx->lda, (const double*)ctx->beta.p, ctx->m, (int)ctx->K, (double*)ctx->preds.p,
                                       ctx->db, ctx->dw, nullptr, nullptr, nullptr, ctx->stream),
               "launch fsnap_gemv_rows_k");

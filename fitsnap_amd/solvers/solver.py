@@ -43,7 +43,11 @@ class Solver:
         self.a = None
         self.b = None
         self.w = None
-        self.df = None
+        self._df = None              # error_analysis DataFrame, built on first access (see the df property)
+        self._df_parts = None
+        self._cat_cache = None       # (key, category ids, group keys) of the last error_analysis row labelling
+        self._cat_ctx = None         # context that holds those category ids on the device
+        self._mask_cache = None      # (key, training mask) of the last fs_dict['Testing'] list (keep_resident only)
         self.linear = linear
         self.cov = None
         self.fit_sam = None
@@ -79,7 +83,16 @@ class Solver:
     def _training_mask(self, a, fs_dict, trainall):
         """svd.py:35-40 / ridge.py:28-33."""
         if fs_dict is not None:
-            return ~np.asarray(fs_dict["Testing"], dtype=bool)
+            lst = fs_dict["Testing"]
+            if self.keep_resident and isinstance(lst, list):
+                # re-weighting loops pass the same (large) Python list every time: convert it once
+                key = (id(lst), len(lst))
+                if self._mask_cache is not None and self._mask_cache[0] == key:
+                    return self._mask_cache[1]
+                mask = ~np.asarray(lst, dtype=bool)
+                self._mask_cache = (key, mask)
+                return mask
+            return ~np.asarray(lst, dtype=bool)
         if trainall:
             return np.ones(np.shape(a)[0], dtype=bool)
         # after Calculator.collect_distributed_lists the dictionary holds the lists of ALL ranks; the
@@ -376,18 +389,21 @@ class Solver:
             return {"ncount": n, "mae": sar / n, "rmse": np.sqrt(srr / n), "rsq": 1 - srr / sct,
                     "w_ncount": nw, "w_mae": sawr / n, "w_rmse": np.sqrt(swrr / nw), "w_rsq": 1 - swrr / scwt}
 
-    def _device_error_tables(self, a, b, w, shared):
+    def _device_error_tables(self, a, b, w, shared, fs_dict):
         """(per-group table, *ALL table) of solver.py:391-405, built from fsnap_error_stats."""
         from pandas import DataFrame, MultiIndex
 
-        ctx = self.pt.hip()                                 # predict_rows() has just made these rows resident
-        if ctx.m != len(self.df.index):
-            ctx = self._upload(a, np.asarray(b), shared)
+        ctx = self._upload(a, np.asarray(b), shared)        # no copy when these rows are already resident
         ctx.set_weights(np.asarray(w, dtype=np.float64))
-        gb = self.df.groupby(["Groups", "Testing", "Row_Type"], sort=True)
-        cat = gb.ngroup().to_numpy(dtype=np.int32)
-        keys = list(gb.size().index)                       # sorted group keys, position = category id
-        st = ctx.error_stats(np.asarray(self.fit, dtype=np.float64).reshape(-1), cat, len(keys))
+        cat, keys, fresh = self._row_categories(fs_dict, np.shape(a)[0])   # sorted group keys, position = category id
+        beta = np.asarray(self.fit, dtype=np.float64).reshape(-1)
+        # the category ids stay on the device between calls; (context, serial) tells whether they are still OURS
+        mine = (not fresh) and self._cat_ctx is not None and self._cat_ctx == (id(ctx), getattr(ctx, "cat_serial", -1))
+        try:
+            st = ctx.error_stats(beta, None if mine else cat, len(keys))
+        except _capi.FsnapError:
+            st = ctx.error_stats(beta, cat, len(keys))       # rows were replaced meanwhile: send the ids again
+        self._cat_ctx = (id(ctx), getattr(ctx, "cat_serial", -1))
         n, nw, s_t, s_wt = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
         grouped = DataFrame(self._metrics_from_sums(n, nw, s_t, s_wt, st[:, 4], st[:, 5], st[:, 6], st[:, 7], st[:, 8], st[:, 9]),
                             index=MultiIndex.from_tuples(keys, names=["Groups", "Testing", "Row_Type"]))
@@ -410,6 +426,49 @@ class Solver:
                 rows[name].append(mets[name])
         allrows = DataFrame(rows, index=MultiIndex.from_tuples(sub, names=["Testing", "Row_Type"]))
         return grouped, allrows
+
+    @property
+    def df(self):
+        """The reference's per-row DataFrame (descriptor columns, truths, preds, weights, row labels; solver.py:376-389).
+        Built on first access: a fit loop that only reads ``errors`` (the GA of examples/library/genetic_algorithm) never
+        pays for it."""
+        if self._df is None and self._df_parts is not None:
+            from pandas import DataFrame
+
+            a, b, w, fs_dict, shared = self._df_parts
+            df = DataFrame(a)
+            df["truths"] = np.asarray(b).tolist()
+            if self.fit is not None:
+                fit = np.asarray(self.fit, dtype=np.float64).reshape(-1)
+                if fit.shape[0] == np.shape(a)[1]:
+                    df["preds"] = self.predict_rows() if shared else self.predict_rows(a, b)
+            df["weights"] = np.asarray(w).tolist()
+            for key in fs_dict.keys():
+                if isinstance(fs_dict[key], list) and len(fs_dict[key]) == len(df.index):
+                    df[key] = fs_dict[key]
+            self._df = df
+        return self._df
+
+    @df.setter
+    def df(self, value):
+        self._df = value
+        self._df_parts = None
+
+    def _row_categories(self, fs_dict, m):
+        """Category id of every row = index of its (Groups, Testing, Row_Type) key in sorted order (the order of the
+        reference's groupby).  Cached while the caller keeps passing the same label lists (re-weighting loops)."""
+        from pandas import DataFrame
+
+        lists = (fs_dict["Groups"], fs_dict["Testing"], fs_dict["Row_Type"])
+        key = (id(lists[0]), id(lists[1]), id(lists[2]), m)
+        if self._cat_cache is not None and self._cat_cache[0] == key:
+            return self._cat_cache[1], self._cat_cache[2], False
+        gb = DataFrame({"Groups": lists[0], "Testing": lists[1], "Row_Type": lists[2]}).groupby(
+            ["Groups", "Testing", "Row_Type"], sort=True)
+        cat = gb.ngroup().to_numpy(dtype=np.int32)
+        keys = list(gb.size().index)
+        self._cat_cache = (key, cat, keys)
+        return cat, keys, True
 
     def predict_rows(self, a=None, b=None):
         """``preds = a @ self.fit`` (solver.py:377) on the GPU (streaming GEMV kernel)."""
@@ -471,17 +530,8 @@ class Solver:
                 b = pt.shared_arrays["b"].array
                 w = pt.shared_arrays["w"].array
                 fs_dict = pt.fitsnap_dict
-                preds = self.predict_rows() if self.fit is not None else None
-            else:
-                preds = self.predict_rows(a, b) if self.fit is not None else None
-            self.df = DataFrame(a)
-            self.df["truths"] = np.asarray(b).tolist()
-            if preds is not None:
-                self.df["preds"] = preds
-            self.df["weights"] = np.asarray(w).tolist()
-            for key in fs_dict.keys():
-                if isinstance(fs_dict[key], list) and len(fs_dict[key]) == len(self.df.index):
-                    self.df[key] = fs_dict[key]
+            self._df = None
+            self._df_parts = (a, b, w, fs_dict, shared)      # the DataFrame itself is built on first access
         if self.config.sections["EXTRAS"].dump_dataframe:
             self.df.to_pickle(self.config.sections["EXTRAS"].dataframe_file)
         if self.fit is not None and not self.config.sections["SOLVER"].true_multinode:
@@ -491,7 +541,7 @@ class Solver:
             if not multi and self.device_error_stats:
                 # single GPU: the rows are resident -- predictions and the grouped reductions run on the GPU
                 # (fsnap_error_stats); only the (groups x 10) table of sums comes back
-                grouped, allrows = self._device_error_tables(a, b, w, shared)
+                grouped, allrows = self._device_error_tables(a, b, w, shared, fs_dict)
             else:
                 grouped = self.df.groupby(["Groups", "Testing", "Row_Type"])[["truths", "preds", "weights"]].apply(fn)
                 allrows = None

@@ -215,7 +215,8 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
 
 /* Grouped error statistics of Solver.error_analysis (solver.py:108-133: the function applied to every
  * (Groups, Testing, Row_Type) group of the DataFrame, solver.py:391-405) for the resident rows and weights:
- * cat[m] (host) = category id of each row in [0, ncat) (negative = skip), beta = coefficients.
+ * cat[m] (host) = category id of each row in [0, ncat) (negative = skip; NULL = the categories of the previous call
+ * are still valid: re-weighting loops re-use them), beta = coefficients.
  * stats[ncat][10] (host) = n, count_nonzero(w), sum t, sum w t, sum|r|, sum r^2, sum (t - mean t)^2,
  * sum|w r|, sum (w r)^2, sum (w t - sum(w t)/n_w)^2 with r = t - a.beta; mae = sum|r| / n,
  * rmse = sqrt(sum r^2 / n), rsq = 1 - sum r^2 / sum (t - mean)^2 (weighted: w_mae = sum|w r| / n,

@@ -1,0 +1,36 @@
+"""Cost of one candidate of a re-weighting (GA) loop: perform_fit + error_analysis on resident rows
+(examples/library/genetic_algorithm/libmod_optimize.py:461-488 in the reference)."""
+import sys, time, numpy as np
+sys.path.insert(0, ".")
+from fitsnap_amd.config import Config
+from fitsnap_amd.parallel_tools import ParallelTools
+from fitsnap_amd.solvers import solver_factory
+from oracle import fitsnap_oracle as orc
+
+for m, K, ngroups in ((15213, 31, 12), (1000000, 128, 40)):
+    A, b, w = orc.synth_problem(m, K)
+    rng = np.random.default_rng(3)
+    groups = [f"g{g:02d}" for g in np.sort(rng.integers(0, ngroups, size=m))]
+    testing = (rng.random(m) < 0.1).tolist()
+    row_type = [("Energy", "Force", "Stress")[i % 3] for i in range(m)]
+    fsd = {"Groups": groups, "Testing": testing, "Row_Type": row_type}
+    t = np.asarray(testing)
+    pt = ParallelTools()
+    cfg = Config(pt, {"SOLVER": {"solver": "RIDGE"}, "RIDGE": {"alpha": 1e-8}})
+    s = solver_factory.solver("RIDGE", pt, cfg)
+    s.keep_resident = True
+    times = []
+    for it in range(8):
+        w_it = w * rng.uniform(0.5, 2.0)                       # a new candidate's weights
+        t0 = time.perf_counter()
+        s.fit = None
+        s.perform_fit(A, b, w_it[~t], fs_dict=fsd)
+        t1 = time.perf_counter()
+        s.error_analysis(A, b, w_it, fsd)
+        rmse = s.errors.iloc[:, 2].to_numpy()[:3]
+        t2 = time.perf_counter()
+        times.append((t1 - t0, t2 - t1))
+    tt = np.array(times[2:])
+    print(f"{m} x {K}, {ngroups} groups: perform_fit {tt[:,0].mean()*1e3:.2f} ms, error_analysis {tt[:,1].mean()*1e3:.2f} ms per candidate "
+          f"(first call: {times[0][0]*1e3:.1f} + {times[0][1]*1e3:.1f} ms); rmse {rmse}")
+    pt.free()

@@ -850,3 +850,28 @@ def test_streaming_accumulation_matches_one_shot(ctx, K):
     beta, rank, _ = ctx.solve_device(_capi.SOLVE_RIDGE, 1e-6, K, total.data_ptr())
     ref = np.linalg.solve(G + 1e-6 * np.eye(K), c)
     assert rank == K and np.max(np.abs(beta - ref)) / np.max(np.abs(ref)) < 1e-9
+
+
+def test_reweighting_loop_error_analysis_reuses_labels_and_builds_df_lazily(ta, ta_fits):
+    # GA-style loop (libmod_optimize.py:461-488): same rows and label lists, new weights per candidate.  The row
+    # categories are converted / uploaded once, the DataFrame is only built when somebody reads it.
+    A, b, w = ta
+    t = ta_fits["testing_mask"]
+    row_type = ["Energy"] * 363 + ["Force"] * 12672 + ["Stress"] * 2178
+    fsd = {"Groups": [str(g) for g in ta_fits["ea_groups"]], "Testing": t.tolist(), "Row_Type": row_type}
+    pt, s = make_solver("SVD")
+    s.keep_resident = True
+    tables = []
+    for scale in (1.0, 3.0, 1.0):
+        s.fit = None
+        s.perform_fit(A, b, (w * scale)[~t], fs_dict=fsd)
+        s.error_analysis(A, b, w * scale, fsd)
+        assert s._df is None                                    # not built by error_analysis itself
+        tables.append(s.errors[["ncount", "mae", "rmse", "rsq"]].to_numpy(dtype=np.float64))
+    # unweighted rows are scale invariant, weighted MAE / RMSE scale with the weights; first and third candidate agree
+    assert np.allclose(tables[0], tables[2], rtol=1e-10, atol=1e-300, equal_nan=True)
+    assert not np.allclose(tables[0], tables[1], rtol=1e-3, atol=1e-300, equal_nan=True)
+    df = s.df
+    assert len(df.index) == len(b) and {"truths", "preds", "weights", "Groups", "Testing", "Row_Type"} <= set(df.columns)
+    assert np.allclose(df["preds"].to_numpy(), A @ s.fit[:A.shape[1]] if len(s.fit) == A.shape[1] else df["preds"].to_numpy())
+    pt.free()
