@@ -75,6 +75,8 @@ struct fsnap_ctx {
     DevBuf dsolve;                                // [beta | min pivot | status] of fsnap_solve_device
     DevBuf dchol;                                 // padded work matrix of the blocked device Cholesky
     DevBuf dcat, dstat;                           // fsnap_error_stats: row categories, partial tables + means
+    DevBuf wpack, wpack_spart;                    // kernel 1A: packed (w_eff, w_eff b) per row + partial b-only scalars
+    bool wpack_valid = false;                     // false after anything that can change b, w or the mask
     int64_t dcat_rows = -1;                       // number of rows the categories on the device belong to
     DevBuf du, dspart, dsvec;                     // refinement: row weights u, per-workgroup partials, s
     double* pinned = nullptr;                     // page-locked host staging of the packed statistics
@@ -367,6 +369,26 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
     a.part = (double*)ctx->part.p;
     a.cpart = (double*)ctx->cpart.p;
     a.spart = (double*)ctx->spart.p;
+    int ns = -1;                      // scalar partials: from the SYRK kernel, or (kernel 1A) from the weight packing
+    const double* spart_src = a.spart;
+    if (g.acc) {
+        // kernel 1A reads (w_eff, w_eff b) per row; packed once per (b, w, mask) -- every time if any of them lives
+        // in memory the caller owns (fsnap_bind_rows / fsnap_bind_weights: it may have changed without notice)
+        const int npk = fsnap::pack_weights_num_blocks(ctx->m);
+        if (!ctx->wpack.ensure((size_t)ctx->m * 16 + 64) || !ctx->wpack_spart.ensure((size_t)npk * 4 * 8))
+            return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(packed weights) failed");
+        const bool caller_owned = ctx->db != (const double*)ctx->ownb.p || ctx->dw != (const double*)ctx->ownw.p ||
+                                  (ctx->dmask && ctx->dmask != (const unsigned char*)ctx->ownmask.p);
+        if (!ctx->wpack_valid || caller_owned) {
+            FSNAP_HIP(fsnap::launch_pack_weights(ctx->db, ctx->dw, ctx->dmask, ctx->m, (double*)ctx->wpack.p,
+                                                 (double*)ctx->wpack_spart.p, ctx->stream),
+                      "launch fsnap_pack_weights_k");
+            ctx->wpack_valid = true;
+        }
+        a.wpack = (const double*)ctx->wpack.p;
+        spart_src = (const double*)ctx->wpack_spart.p;
+        ns = npk;
+    }
     hipEvent_t* evs;
     if ((rc = fit_events(ctx, &evs))) return rc;
     FSNAP_HIP(hipEventRecord(evs[0], ctx->stream), "hipEventRecord");
@@ -391,7 +413,7 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
             ctx->mirror_ev = nullptr;
         if (ctx->mirror && ctx->mirror_ev) mirror = ctx->mirror;
     }
-    FSNAP_HIP(fsnap::launch_reduce(a.part, a.cpart, a.spart, g.nblocks, cs_per_block, a.K, d_packed, mirror, accumulate,
+    FSNAP_HIP(fsnap::launch_reduce(a.part, a.cpart, spart_src, g.nblocks, cs_per_block, ns, a.K, d_packed, mirror, accumulate,
                                    ctx->stream),
               "launch fsnap_reduce_partials");
     FSNAP_HIP(hipEventRecord(evs[2], ctx->stream), "hipEventRecord");
@@ -477,7 +499,7 @@ int fsnap_ctx_destroy(fsnap_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->ownA, &ctx->ownb, &ctx->ownw, &ctx->ownmask, &ctx->ones, &ctx->part, &ctx->cpart,
                       &ctx->spart, &ctx->packed, &ctx->beta, &ctx->preds, &ctx->sse, &ctx->aw, &ctx->bw,
-                      &ctx->st_raw, &ctx->st_plan, &ctx->st_frac, &ctx->st_blank, &ctx->dsolve, &ctx->dchol, &ctx->dcat, &ctx->dstat,
+                      &ctx->st_raw, &ctx->st_plan, &ctx->st_frac, &ctx->st_blank, &ctx->dsolve, &ctx->dchol, &ctx->dcat, &ctx->dstat, &ctx->wpack, &ctx->wpack_spart,
                       &ctx->du, &ctx->dspart, &ctx->dsvec};
     for (DevBuf* b : bufs) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -565,6 +587,7 @@ int fsnap_upload_rows(fsnap_ctx* ctx, const double* A, int64_t m, int64_t K, int
     ctx->t_upload = true;
     ctx->dA = (const double*)ctx->ownA.p;
     ctx->db = (const double*)ctx->ownb.p;
+    ctx->wpack_valid = false;
     if (m != ctx->m) {  // weights / mask of a previous matrix no longer apply
         ctx->dw = nullptr;
         ctx->dmask = nullptr;
@@ -586,6 +609,7 @@ int fsnap_bind_rows(fsnap_ctx* ctx, const double* dA, int64_t m, int64_t K, int6
     }
     ctx->dA = dA;
     ctx->db = db;
+    ctx->wpack_valid = false;
     ctx->m = m;
     ctx->K = K;
     ctx->lda = lda;
@@ -605,6 +629,7 @@ int fsnap_rows_alloc(fsnap_ctx* ctx, int64_t m, int64_t K) {
     FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     ctx->dA = (const double*)ctx->ownA.p;
     ctx->db = (const double*)ctx->ownb.p;
+    ctx->wpack_valid = false;
     ctx->dw = (const double*)ctx->ownw.p;
     ctx->dmask = nullptr;
     ctx->ones.release();
@@ -652,6 +677,7 @@ int fsnap_assemble(fsnap_ctx* ctx, const double* raw, int64_t raw_rows, int64_t 
         FSNAP_HIP(hipMemcpyAsync(ctx->st_frac.p, fractions, (size_t)nfrac * ntypes * 8, hipMemcpyHostToDevice, st),
                   "hipMemcpy(fractions)");
     FSNAP_HIP(hipMemcpyAsync(ctx->st_blank.p, blank2J, (size_t)ctx->K * 8, hipMemcpyHostToDevice, st), "hipMemcpy(blank2J)");
+    ctx->wpack_valid = false;      // the kernel below writes b and w of these rows
     FSNAP_HIP(fsnap::launch_assemble((const double*)ctx->st_raw.p, raw_ld, nrows, (const int64_t*)pl,
                                      (const int*)(pl + n * 32), (const int*)(pl + n * 36), (const double*)(pl + n * 8),
                                      (const double*)(pl + n * 16), (const double*)(pl + n * 24),
@@ -691,6 +717,7 @@ int fsnap_set_weights(fsnap_ctx* ctx, const double* w, const uint8_t* mask) {
     if (!ctx->ownw.ensure(m * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(w) failed");
     FSNAP_HIP(hipMemcpyAsync(ctx->ownw.p, w, m * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(w)");
     ctx->dw = (const double*)ctx->ownw.p;
+    ctx->wpack_valid = false;
     if (mask) {
         if (!ctx->ownmask.ensure(m)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(mask) failed");
         FSNAP_HIP(hipMemcpyAsync(ctx->ownmask.p, mask, m, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(mask)");
@@ -709,6 +736,7 @@ int fsnap_bind_weights(fsnap_ctx* ctx, const double* dw, const uint8_t* dmask) {
     if (!dw) return ctx->fail(FSNAP_E_ARG, "fsnap_bind_weights: dw is NULL");
     ctx->dw = dw;
     ctx->dmask = dmask;
+    ctx->wpack_valid = false;
     return FSNAP_OK;
 }
 

@@ -23,6 +23,7 @@ struct SyrkArgs {
     double* part;               // [nblocks][NT][4][64]
     double* cpart;              // [nblocks*4][NB][16]
     double* spart;              // [nblocks*4][4]
+    const double* wpack = nullptr;  // kernel 1A: packed (w_eff, w_eff * b) per row (launch_pack_weights)
 };
 
 struct TiledArgs {
@@ -52,8 +53,13 @@ hipError_t launch_syrk_lds(const SyrkArgs& a, hipStream_t st);
 hipError_t launch_syrk_acc(const SyrkArgs& a, hipStream_t st);
 // mirror: optional page-locked HOST buffer that receives the same packed statistics (zero-copy D2H)
 // accumulate: out += statistics instead of out = statistics
+// ns: number of scalar partials in spart (< 0: nblocks * cs_per_block, like the c partials)
 hipError_t launch_reduce(const double* part, const double* cpart, const double* spart, int nblocks,
-                         int cs_per_block, int K, double* out, double* mirror, bool accumulate, hipStream_t st);
+                         int cs_per_block, int ns, int K, double* out, double* mirror, bool accumulate, hipStream_t st);
+int pack_weights_num_blocks(int64_t m);
+// wpack[m][2] = (w_eff, w_eff * b); spart[pack_weights_num_blocks(m)][4] = partial b^T W^2 b, sum(w b), n_train, 0
+hipError_t launch_pack_weights(const double* b, const double* w, const unsigned char* mask, int64_t m, double* wpack,
+                               double* spart, hipStream_t st);
 hipError_t launch_syrk_tiled(const TiledArgs& a, hipStream_t st);
 hipError_t launch_reduce_tiled(const TiledArgs& a, double* out, bool accumulate, hipStream_t st);
 hipError_t launch_weight_rows(const double* A, int64_t lda, const double* b, const double* w,

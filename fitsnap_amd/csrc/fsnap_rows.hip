@@ -4,6 +4,7 @@
 //   5   fsnap_assemble_k       post-LAMMPS assembly (_collect_lammps)         (lammps_snap.py:391-556)
 //   7   fsnap_gemvT_rows_k     s = A^T u (right-hand side of a refinement step)
 //   9   fsnap_error_stats_k    grouped error statistics of error_analysis     (solver.py:108-133)
+//   11  fsnap_pack_weights_k   (w_eff, w_eff b) per row + the b-only statistics, once per (b, w, mask)
 // Every kernel here moves each byte once; the roofline is HBM bandwidth.
 #include "fsnap_device_common.h"
 #include "fsnap_kernels.h"
@@ -319,6 +320,50 @@ __global__ __launch_bounds__(256) void fsnap_error_stats_k(const double* __restr
 }
 
 // ---------------------------------------------------------------------------------
+// Kernel 11: per-row weights of the SYRK kernel 1A, packed once per (b, w, mask):
+//   wpack[row] = (w_eff, wb_eff),  w_eff = keep ? w : 0,  wb_eff = keep ? w * b : 0     (svd.py:44-46: w[training], w * b)
+// and the statistics that do not involve A:  b^T W^2 b = sum wb_eff^2,  sum wb_eff,  n_train = sum keep
+// (per-workgroup partials, summed in fixed order by the reduction kernel).  HBM-bound, 33 B per row.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsnap_pack_weights_k(const double* __restrict__ b, const double* __restrict__ w,
+                                                           const unsigned char* __restrict__ mask, int64_t m,
+                                                           double* __restrict__ wpack, double* __restrict__ spart) {
+    __shared__ double red[3][256];
+    double bb = 0.0, sb = 0.0, cnt = 0.0;
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < m; row += (int64_t)gridDim.x * 256) {
+        const bool keep = mask ? (mask[row] != 0) : true;
+        const double wv = keep ? w[row] : 0.0;
+        const double wb = keep ? wv * b[row] : 0.0;
+        d2u o;
+        o[0] = wv;
+        o[1] = wb;
+        *reinterpret_cast<d2u*>(wpack + 2 * row) = o;
+        bb = __builtin_fma(wb, wb, bb);
+        sb += wb;
+        cnt += keep ? 1.0 : 0.0;
+    }
+    red[0][threadIdx.x] = bb;
+    red[1][threadIdx.x] = sb;
+    red[2][threadIdx.x] = cnt;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {        // fixed-order tree: deterministic
+        if ((int)threadIdx.x < s) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + s];
+            red[1][threadIdx.x] += red[1][threadIdx.x + s];
+            red[2][threadIdx.x] += red[2][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double* o = spart + (size_t)blockIdx.x * 4;
+        o[0] = red[0][0];
+        o[1] = red[1][0];
+        o[2] = red[2][0];
+        o[3] = 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // host-side launchers (C++ linkage, used by fsnap_capi.cpp)
 // ---------------------------------------------------------------------------------
 namespace fsnap {
@@ -368,6 +413,20 @@ hipError_t launch_gemvT_rows(const double* A, int64_t lda, const double* u, int6
     }
     hipLaunchKernelGGL(fsnap_gemvT_rows_k, dim3((unsigned)nb), dim3(256), lds, st, A, lda, u, m, K, rpw, partial);
     hipLaunchKernelGGL(fsnap_colsum_partials_k, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, partial, nb, K, out);
+    return hipGetLastError();
+}
+
+int pack_weights_num_blocks(int64_t m) {
+    int64_t nb = (m + 2047) / 2048;
+    if (nb > 512) nb = 512;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+hipError_t launch_pack_weights(const double* b, const double* w, const unsigned char* mask, int64_t m, double* wpack,
+                               double* spart, hipStream_t st) {
+    hipLaunchKernelGGL(fsnap_pack_weights_k, dim3((unsigned)pack_weights_num_blocks(m)), dim3(256), 0, st, b, w, mask, m,
+                       wpack, spart);
     return hipGetLastError();
 }
 

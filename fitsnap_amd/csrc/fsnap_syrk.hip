@@ -423,57 +423,64 @@ __device__ __forceinline__ void acc_row(const double (&V)[NB], d4 (&vt)[4], std:
     (acc_mfma<tri_index(P, P + Q, NB)>(V[P], V[P + Q], vt), ...);
 }
 
-// Raw loads of kernel 1A.  The row mask is applied by the LOADS: a lane whose row is a test row (or lies past the
-// wave's range) uses an out-of-range buffer offset, so the hardware bounds check returns zeros for its A, b and w
-// values -- w = 0, b = 0 and a = 0 make every product of that row vanish without a single select instruction
-// (and garbage such as NaN / Inf in a masked row is never even fetched).  Every VALU instruction of this kernel
-// costs matrix-pipe time (fp64 MFMAs and VALU instructions serialise on the SIMD), hence: two offset selects per
-// chunk instead of two selects per value.
+// Raw loads of kernel 1A.  Per row the kernel needs three numbers that do not depend on A: keep (training row?),
+// w and w*b.  They are packed once per (b, w, mask) by fsnap_pack_weights_k into wpack[row] = (w_eff, wb_eff) with
+// w_eff = keep ? w : 0, wb_eff = keep ? w*b : 0 (16 bytes, ONE load per chunk instead of three), together with the
+// scalars b^T W^2 b, sum(w b), n_train, which therefore leave this kernel altogether.
+// The row mask is applied by the LOADS: a lane whose row has w_eff == 0 (test row, zero-weight row, or a row past
+// the wave's range, whose packed entry reads back as zero) uses an out-of-range buffer offset for its A values, so
+// the hardware bounds check returns zeros -- a = 0 and w_eff = 0 make every product of that row vanish without a
+// select instruction, and garbage (NaN / Inf) in such a row is never even fetched.  Every VALU / VMEM instruction of
+// this kernel costs matrix-pipe time (fp64 MFMAs and VALU instructions serialise on the SIMD): per 4-row chunk
+// 8 multiplies, 8 FMAs (c), 1 compare, 1-2 offset selects and 5 loads remain.
 template <int NB>
 struct RawM {
     u4 pr[NB / 2 > 0 ? NB / 2 : 1];
     u2 tail;
-    u2 bv, wv;
+    u4 wp;      // (w_eff, wb_eff) of the lane's row
 };
 
 constexpr unsigned FSNAP_OOB_VOFF = 0xFFFFF000u;   // > any wave's buffer size (plan_geometry: < 0xFFF00010), no 32-bit wrap
 
+struct WaveBufsP {
+    __amdgpu_buffer_rsrc_t A, wp;
+    unsigned voffA;        // per-lane byte offset inside a chunk: (kr*lda + 2e)*8
+    unsigned voffT;        // tail block: (kr*lda + 16*(NB-1) + e)*8
+    unsigned voffP;        // kr * 16 (packed weights)
+    unsigned chunk_bytes;  // 4*lda*8
+};
+
+__device__ __forceinline__ u4 load_pack(const WaveBufsP& wb, unsigned cl) {
+    return __builtin_amdgcn_raw_buffer_load_b128(wb.wp, wb.voffP, cl * 64u, 0);
+}
+__device__ __forceinline__ bool pack_keep(const u4& wp) {
+    return ((wp[0] | (wp[1] & 0x7FFFFFFFu)) != 0u);      // w_eff != +-0 (integer test: no fp64 VALU)
+}
+
 template <int NB, bool NT>
-__device__ __forceinline__ void issue_masked(RawM<NB>& r, const WaveBufs& wb, unsigned cl, unsigned mk) {
+__device__ __forceinline__ void issue_rows(RawM<NB>& r, const WaveBufsP& wb, unsigned cl) {
     const unsigned soff = cl * wb.chunk_bytes;
     constexpr int AUX = NT ? 2 : 0;
-    const bool keep = (mk != 0);
+    const bool keep = pack_keep(r.wp);
     const unsigned va = keep ? wb.voffA : FSNAP_OOB_VOFF;
-    const unsigned vr = keep ? wb.voffR : FSNAP_OOB_VOFF;
 #pragma unroll
     for (int j = 0; j < NB / 2; ++j) r.pr[j] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, va + 256u * j, soff, AUX);
     if (NB & 1) {
         const unsigned vtl = keep ? wb.voffT : FSNAP_OOB_VOFF;
         r.tail = __builtin_amdgcn_raw_buffer_load_b64(wb.A, vtl, soff, AUX);
     }
-    r.bv = __builtin_amdgcn_raw_buffer_load_b64(wb.b, vr, cl * 32u, 0);
-    r.wv = __builtin_amdgcn_raw_buffer_load_b64(wb.w, vr, cl * 32u, 0);
 }
 
 // piece P of the refill of raw set r (one load instruction per MFMA slot: a block of back-to-back VMEM
 // instructions holds the in-order wave at the address path while the matrix pipe drains)
 template <int NB, bool NT, int P>
-__device__ __forceinline__ void issue_piece(RawM<NB>& r, const WaveBufs& wb, unsigned cl, unsigned va, unsigned vtl,
-                                            unsigned vr) {
+__device__ __forceinline__ void issue_piece(RawM<NB>& r, const WaveBufsP& wb, unsigned cl, unsigned va, unsigned vtl) {
     constexpr int AUX = NT ? 2 : 0;
     constexpr int NPR = NB / 2;
     const unsigned soff = cl * wb.chunk_bytes;
     if (P < NPR) r.pr[P] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, va + 256u * P, soff, AUX);
     if ((NB & 1) && P == NPR) r.tail = __builtin_amdgcn_raw_buffer_load_b64(wb.A, vtl, soff, AUX);
-    constexpr int PB = NPR + (NB & 1);
-    if (P == PB) r.bv = __builtin_amdgcn_raw_buffer_load_b64(wb.b, vr, cl * 32u, 0);
-    if (P == PB + 1) r.wv = __builtin_amdgcn_raw_buffer_load_b64(wb.w, vr, cl * 32u, 0);
-    static_assert(NPR + (NB & 1) + 2 <= NB, "one load piece per MFMA slot");
-}
-
-// mask byte of the lane's row in chunk cl, normalised to 0 / 1 (rows past the range read 0)
-__device__ __forceinline__ unsigned load_mask(const WaveBufs& wb, unsigned cl, int kr) {
-    return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(wb.mask, (unsigned)kr, cl * 4u, 0);
+    static_assert(NPR + (NB & 1) <= NB, "one load piece per MFMA slot");
 }
 
 // w * (raw value of block j); columns >= K (only possible in the last block / block pair when K is not a multiple
@@ -494,50 +501,45 @@ __device__ __forceinline__ double weighted_block(const RawM<NB>& r, int j, doubl
 
 // Slot P of a step (between row P and row P + 1 of the MFMAs).  The pieces are independent of each other (a wave
 // issues in order: a dependent chain here would hold back row P + 1):
-//   V[P] <- w * raw block P        cacc[P-1] += V[P-1] * wbv        slots 1, 2: bb, sum_bw
+//   V[P] <- w * raw block P        cacc[P-1] += V[P-1] * wbv        one load of the refill
 template <int NB, bool FULLK, bool NT, int P>
 __device__ __forceinline__ void acc_slot(double (&V)[NB], const RawM<NB>& RN, double wv, double wbv, double& wbp, int K,
-                                         int e, double (&cacc)[NB], double& bb, double& sbw, RawM<NB>& RF,
-                                         const WaveBufs& wb, unsigned cl_fill, unsigned va, unsigned vtl, unsigned vr) {
+                                         int e, double (&cacc)[NB], RawM<NB>& RF, const WaveBufsP& wb, unsigned cl_fill,
+                                         unsigned va, unsigned vtl) {
 #if !defined(FSNAP_ACC_ABL) || !(FSNAP_ACC_ABL & 1)
-    issue_piece<NB, NT, P>(RF, wb, cl_fill, va, vtl, vr);
+    issue_piece<NB, NT, P>(RF, wb, cl_fill, va, vtl);
 #endif
     if (P == 0) cacc[NB - 1] = __builtin_fma(V[NB - 1], wbp, cacc[NB - 1]);   // previous chunk's last block
     else cacc[P - 1] = __builtin_fma(V[P - 1], wbv, cacc[P - 1]);
     V[P] = weighted_block<NB, FULLK>(RN, P, wv, K, e);
-    if (P == 1) bb = __builtin_fma(wbv, wbv, bb);
-    if (P == 2) sbw += wbv;
     if (P == NB - 1) wbp = wbv;
     __builtin_amdgcn_sched_barrier(0);   // keep the slot between row P and row P + 1
 }
 
-// One chunk: the MFMA rows of the chunk held in V, interleaved with the preparation of the next chunk (raw
-// registers RN) block by block.  First the raw set RF (consumed one step ago) is refilled three chunks ahead,
-// using the mask byte fetched during the previous step, and the mask of the following chunk is requested.
+// One chunk (step c): the MFMA rows of chunk c held in V, interleaved with the preparation of chunk c + 1 (raw set
+// RN) block by block.  RN's packed weights are read first and its slot is refilled with those of chunk c + 4 (same
+// raw set, three steps on); RF (consumed one step ago, packed weights of chunk c + 3 loaded one step ago) gets the
+// rows of chunk c + 3.  The packed load goes out BEFORE the row loads: vmcnt retires in order, so the next step can
+// wait for it without also draining the row loads issued here.
 template <int NB, bool FULLK, bool NT, int... P>
-__device__ __forceinline__ void acc_step(double (&V)[NB], d4 (&vt)[4], RawM<NB>& RF, const RawM<NB>& RN,
-                                         const WaveBufs& wb, unsigned cl_fill, unsigned& mk, unsigned& cnt, int K, int e,
-                                         int kr, double (&cacc)[NB], double& bb, double& sbw, double& wbp,
+__device__ __forceinline__ void acc_step(double (&V)[NB], d4 (&vt)[4], RawM<NB>& RF, RawM<NB>& RN, const WaveBufsP& wb,
+                                         unsigned cl_fill, int K, int e, double (&cacc)[NB], double& wbp,
                                          std::integer_sequence<int, P...>) {
-    const bool keep = (mk != 0);                    // mask bytes may be any non-zero value for "training row"
-    cnt += keep ? 1u : 0u;
+    const d2 wpn = __builtin_bit_cast(d2, RN.wp);
+    const double wv = wpn[0], wbv = wpn[1];
+    const bool keep = pack_keep(RF.wp);
     const unsigned va = keep ? wb.voffA : FSNAP_OOB_VOFF;
-    const unsigned vr = keep ? wb.voffR : FSNAP_OOB_VOFF;
     const unsigned vtl = (NB & 1) ? (keep ? wb.voffT : FSNAP_OOB_VOFF) : 0u;
 #if !defined(FSNAP_ACC_ABL) || !(FSNAP_ACC_ABL & 1)   // tools/syrk_trace.hip diagnostics: 1 = no loads, 2 = no VALU work
-    // the mask request goes out BEFORE this step's row loads: vmcnt retires in order, so the next step can wait for
-    // its mask byte without also draining the row loads issued here (they stay two steps ahead of their use)
-    mk = load_mask(wb, cl_fill + 1, kr);
+    RN.wp = load_pack(wb, cl_fill + 1);
 #endif
-    const double wv = __builtin_bit_cast(double, RN.wv);
-    const double wbv = wv * __builtin_bit_cast(double, RN.bv);
     __builtin_amdgcn_sched_barrier(0);
 #if defined(FSNAP_ACC_ABL) && (FSNAP_ACC_ABL & 2)
     (acc_row<NB, P>(V, vt, std::make_integer_sequence<int, NB - P>{}), ...);
     (void)wbv;
 #else
     ((acc_row<NB, P>(V, vt, std::make_integer_sequence<int, NB - P>{}),
-      acc_slot<NB, FULLK, NT, P>(V, RN, wv, wbv, wbp, K, e, cacc, bb, sbw, RF, wb, cl_fill, va, vtl, vr)),
+      acc_slot<NB, FULLK, NT, P>(V, RN, wv, wbv, wbp, K, e, cacc, RF, wb, cl_fill, va, vtl)),
      ...);
 #endif
 }
@@ -546,9 +548,9 @@ __device__ __forceinline__ void acc_step(double (&V)[NB], d4 (&vt)[4], RawM<NB>&
 
 template <int NB, bool FULLK, bool NT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void
-fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restrict__ b, const double* __restrict__ w,
-               const unsigned char* __restrict__ mask, int64_t m, int K, int64_t chunks_per_wave,
-               double* __restrict__ part, double* __restrict__ cpart, double* __restrict__ spart) {
+fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restrict__ wpack, int64_t m, int K,
+               int64_t chunks_per_wave, double* __restrict__ part, double* __restrict__ cpart) {
+
     constexpr int NTILE = NB * (NB + 1) / 2;
     constexpr int HALF = (NTILE + 1) / 2;
     __shared__ double lds[4 * HALF * 256];
@@ -568,14 +570,12 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
     int64_t row1 = c1 << 2;
     if (row1 > m) row1 = m;
     const int64_t nrow = row1 > row0 ? row1 - row0 : 0;
-    WaveBufs wb;
+    WaveBufsP wb;
     wb.A = make_rsrc(A + row0 * lda, (unsigned)(nrow * lda * 8 + (nrow ? 16 : 0)));
-    wb.b = make_rsrc(b + row0, (unsigned)(nrow * 8));
-    wb.w = make_rsrc(w + row0, (unsigned)(nrow * 8));
-    wb.mask = make_rsrc(mask + row0, (unsigned)nrow);
+    wb.wp = make_rsrc(wpack + 2 * row0, (unsigned)(nrow * 16));
     wb.voffA = (unsigned)((kr * lda + 2 * e) * 8);
     wb.voffT = (unsigned)((kr * lda + 16 * (NB - 1) + e) * 8);
-    wb.voffR = (unsigned)(kr * 8);
+    wb.voffP = (unsigned)(kr * 16);
     wb.chunk_bytes = (unsigned)(lda * 32);
     const unsigned ncl = (unsigned)(c1 - c0);
 
@@ -589,63 +589,34 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
     double cacc[NB], V[NB];
 #pragma unroll
     for (int p = 0; p < NB; ++p) cacc[p] = 0.0;
-    double bb = 0.0, sbw = 0.0;
-    unsigned cnt = 0;
-
-    // FSNAP_ACC_DEPTH raw sets in flight (3 by default; 4 = one more chunk of prefetch, tools/syrk_trace.hip A/B)
-#ifndef FSNAP_ACC_DEPTH
-#define FSNAP_ACC_DEPTH 3
-#endif
+    // FSNAP_ACC_DEPTH raw sets in flight (3)
     RawM<NB> r0, r1, r2;
-#if FSNAP_ACC_DEPTH == 4
-    RawM<NB> r3;
-#endif
     constexpr auto rows = std::make_integer_sequence<int, NB>{};
     if (ncl > 0) {
-        const unsigned m0 = load_mask(wb, 0, kr) ? 1u : 0u, m1 = load_mask(wb, 1, kr) ? 1u : 0u;
-        const unsigned m2 = load_mask(wb, 2, kr) ? 1u : 0u;
-#if FSNAP_ACC_DEPTH == 4
-        const unsigned m3 = load_mask(wb, 3, kr) ? 1u : 0u;
-        unsigned mk = load_mask(wb, 4, kr);
-        cnt = m0 + m1 + m2 + m3;
-#else
-        unsigned mk = load_mask(wb, 3, kr);
-        cnt = m0 + m1 + m2;
-#endif
-        issue_masked<NB, NT>(r0, wb, 0, m0);
-        issue_masked<NB, NT>(r1, wb, 1, m1);
-        issue_masked<NB, NT>(r2, wb, 2, m2);
-#if FSNAP_ACC_DEPTH == 4
-        issue_masked<NB, NT>(r3, wb, 3, m3);
-#endif
+        r0.wp = load_pack(wb, 0);
+        r1.wp = load_pack(wb, 1);
+        r2.wp = load_pack(wb, 2);
+        issue_rows<NB, NT>(r0, wb, 0);
+        issue_rows<NB, NT>(r1, wb, 1);
+        issue_rows<NB, NT>(r2, wb, 2);
         {   // chunk 0 -> V
-            const double wv = __builtin_bit_cast(double, r0.wv);
-            const double wbv = wv * __builtin_bit_cast(double, r0.bv);
-            bb = __builtin_fma(wbv, wbv, bb);
-            sbw += wbv;
+            const d2 wp0 = __builtin_bit_cast(d2, r0.wp);
+            const double wv = wp0[0], wbv = wp0[1];
 #pragma unroll
             for (int p = 0; p < NB; ++p) {
                 V[p] = weighted_block<NB, FULLK>(r0, p, wv, K, e);
                 cacc[p] = __builtin_fma(V[p], wbv, cacc[p]);
             }
         }
-        // step cl: MFMAs of chunk cl (in V), V <- chunk cl+1, refill of the raw set freed one step ago with chunk
-        // cl+DEPTH.  Chunk slots past the wave's range read zeros through the bounds-checked descriptors.
+        r0.wp = load_pack(wb, 3);
+        // step cl: MFMAs of chunk cl (in V), V <- chunk cl+1, rows of chunk cl+3 into the raw set freed one step ago,
+        // packed weights of chunk cl+4.  Chunk slots past the wave's range read zeros (bounds-checked descriptors).
         double wbp = 0.0;   // chunk 0 is fully accounted for by the prologue
-#if FSNAP_ACC_DEPTH == 4
-        for (unsigned cl = 0; cl < ncl; cl += 4) {
-            acc_step<NB, FULLK, NT>(V, vt, r0, r1, wb, cl + 4, mk, cnt, K, e, kr, cacc, bb, sbw, wbp, rows);
-            acc_step<NB, FULLK, NT>(V, vt, r1, r2, wb, cl + 5, mk, cnt, K, e, kr, cacc, bb, sbw, wbp, rows);
-            acc_step<NB, FULLK, NT>(V, vt, r2, r3, wb, cl + 6, mk, cnt, K, e, kr, cacc, bb, sbw, wbp, rows);
-            acc_step<NB, FULLK, NT>(V, vt, r3, r0, wb, cl + 7, mk, cnt, K, e, kr, cacc, bb, sbw, wbp, rows);
-        }
-#else
         for (unsigned cl = 0; cl < ncl; cl += 3) {
-            acc_step<NB, FULLK, NT>(V, vt, r0, r1, wb, cl + 3, mk, cnt, K, e, kr, cacc, bb, sbw, wbp, rows);
-            acc_step<NB, FULLK, NT>(V, vt, r1, r2, wb, cl + 4, mk, cnt, K, e, kr, cacc, bb, sbw, wbp, rows);
-            acc_step<NB, FULLK, NT>(V, vt, r2, r0, wb, cl + 5, mk, cnt, K, e, kr, cacc, bb, sbw, wbp, rows);
+            acc_step<NB, FULLK, NT>(V, vt, r0, r1, wb, cl + 3, K, e, cacc, wbp, rows);
+            acc_step<NB, FULLK, NT>(V, vt, r1, r2, wb, cl + 4, K, e, cacc, wbp, rows);
+            acc_step<NB, FULLK, NT>(V, vt, r2, r0, wb, cl + 5, K, e, cacc, wbp, rows);
         }
-#endif
         cacc[NB - 1] = __builtin_fma(V[NB - 1], wbp, cacc[NB - 1]);   // last prepared chunk (zeros past the range)
     }
     // the last MFMAs (16 passes) must have left the pipe before their accumulators are read
@@ -699,14 +670,6 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
         double sm = xlane_sum_rows(cacc[p]);
         if (kr == 0) cw[p * 16 + e] = sm;
     }
-    double sb = xlane_sum_rows(bb), ss = xlane_sum_rows(sbw), sc = xlane_sum_rows((double)cnt);
-    if (lane == 0) {
-        double* sw = spart + rowwave * 4;
-        sw[0] = sb;
-        sw[1] = ss;
-        sw[2] = sc;
-        sw[3] = 0.0;
-    }
 #ifdef FSNAP_TRACE
     if (threadIdx.x == 0 && blockIdx.x < 4096) fsnap_trace_buf[blockIdx.x * 8 + 5] = wall_clock64();   // after the epilogue
 #endif
@@ -725,7 +688,7 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
 __global__ __launch_bounds__(1024) void fsnap_reduce_partials(const double* __restrict__ part,
                                                               const double* __restrict__ cpart,
                                                               const double* __restrict__ spart, int nblocks,
-                                                              int cs_per_block, int NB, int K,
+                                                              int cs_per_block, int ns, int NB, int K,
                                                               double* __restrict__ out, double* __restrict__ mirror,
                                                               int accumulate) {
     // One workgroup (1024 threads) = 16 consecutive elements (one 128-B line per partial)
@@ -749,6 +712,7 @@ __global__ __launch_bounds__(1024) void fsnap_reduce_partials(const double* __re
     } else if (idx < nG + nC + nS) {
         src = spart + (idx - nG - nC);
         stride = nS;
+        if (ns >= 0) np = ns;     // scalar partials come from elsewhere (fsnap_pack_weights_k)
     }
     double s = 0.0;
     if (src) {
@@ -1772,9 +1736,10 @@ template <int NB>
 static hipError_t launch_syrk_acc_nb(const SyrkArgs& a, hipStream_t st) {
     dim3 grid((unsigned)a.nblocks), block(256);
     const bool fullk = (a.K == 16 * NB);
+    if (!a.wpack) return hipErrorInvalidValue;
 #define FSNAP_LAUNCH(FK, NTL)                                                                                       \
-    hipLaunchKernelGGL((fsnap_syrk_acc<NB, FK, NTL>), grid, block, 0, st, a.A, a.lda, a.b, a.w, a.mask, a.m, a.K, \
-                       a.chunks_per_wave, a.part, a.cpart, a.spart)
+    hipLaunchKernelGGL((fsnap_syrk_acc<NB, FK, NTL>), grid, block, 0, st, a.A, a.lda, a.wpack, a.m, a.K,            \
+                       a.chunks_per_wave, a.part, a.cpart)
     if (fullk) {
         if (a.nontemporal) FSNAP_LAUNCH(true, true);
         else FSNAP_LAUNCH(true, false);
@@ -1819,11 +1784,11 @@ hipError_t launch_syrk(const SyrkArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_reduce(const double* part, const double* cpart, const double* spart, int nblocks,
-                         int cs_per_block, int K, double* out, double* mirror, bool accumulate, hipStream_t st) {
+                         int cs_per_block, int ns, int K, double* out, double* mirror, bool accumulate, hipStream_t st) {
     const int NB = syrk_num_blocks(K);
     const int nelem = NB * (NB + 1) / 2 * 256 + NB * 16 + 4;
     dim3 grid((unsigned)((nelem + 15) / 16)), block(1024);
-    hipLaunchKernelGGL(fsnap_reduce_partials, grid, block, 0, st, part, cpart, spart, nblocks, cs_per_block, NB, K, out, mirror,
+    hipLaunchKernelGGL(fsnap_reduce_partials, grid, block, 0, st, part, cpart, spart, nblocks, cs_per_block, ns, NB, K, out, mirror,
                        accumulate ? 1 : 0);
     return hipGetLastError();
 }

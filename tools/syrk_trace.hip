@@ -6,6 +6,7 @@
 //   (-DFSNAP_TRACE=2 adds per-wave phase clocks inside the stage loop; they perturb the kernel by ~20 %)
 //   usage: syrk_trace [rows] [workgroups] [verbose] [waves per workgroup: 8|4|16] [variant]
 #include "../fitsnap_amd/csrc/fsnap_syrk.hip"
+#include "../fitsnap_amd/csrc/fsnap_rows.hip"
 
 #include <algorithm>
 #include <chrono>
@@ -68,6 +69,11 @@ int main(int argc, char** argv) {
     a.A = A; a.lda = K; a.b = b; a.w = w; a.mask = mask; a.m = m; a.K = K;
     a.nblocks = nblocks; a.split = nw; a.chunks_per_wave = cpwg; a.nontemporal = true; a.ablate = ablate;
     a.part = part; a.cpart = cpart; a.spart = spart;
+    double *wpack, *wpack_spart;                      // kernel 1A: packed (w_eff, w_eff b) per row
+    CK(hipMalloc(&wpack, (size_t)m * 16 + 64));
+    CK(hipMalloc(&wpack_spart, (size_t)fsnap::pack_weights_num_blocks(m) * 32));
+    CK(fsnap::launch_pack_weights(b, w, mask, m, wpack, wpack_spart, 0));
+    a.wpack = wpack;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
