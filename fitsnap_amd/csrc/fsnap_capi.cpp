@@ -94,7 +94,7 @@ struct fsnap_ctx {
     int opt_nsplit = 0;       // row splits of the tiled kernel (0 = auto)
     int opt_xcd = 1;          // tiled kernel: contiguous work-item ranges per XCD
     int opt_mirror = 1;       // fsnap_normal_eq_resident: reduction writes a page-locked host mirror (K <= 128)
-    int opt_device_solve = 0; // 0 = auto (K > 256 on the GPU, blocked), 1 = also K <= 128 (fsnap_chol_solve_k), 2 = never
+    int opt_device_solve = 0; // 0 = auto (K >= 384 on the GPU, blocked), 1 = every K (K <= 128: fsnap_chol_solve_k), 2 = never
     int opt_ablate = 0;       // timing-only ablation of kernel 1L (diagnostics; results are wrong)
     // timing flags
     bool t_syrk = false, t_upload = false, t_weight = false, t_predict = false;
@@ -965,12 +965,12 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
         }
     }
     // large systems: blocked Cholesky on the GPU (kernels 8a-8e); option device_solve = 2 disables it
-    // (K = 1595: ~3.7 ms against 17-22 ms for the host factorisation; below ~768 columns the host is faster: the
-    // panel kernels are latency-bound single-workgroup launches)
-    if ((K >= 768 || (K > 128 && ctx->opt_device_solve == 1)) && ctx->opt_device_solve != 2) {
+    // (measured, scripts/chol_large_test.py: K = 384: 0.30 ms against 0.33 ms for the host factorisation, 768: 0.63 / 2.6,
+    // 1595: 1.5 / 17.5; below ~384 columns the host is faster: the panel kernels are latency-bound launches)
+    if ((K >= 384 || (K > 128 && ctx->opt_device_solve == 1)) && ctx->opt_device_solve != 2) {
         const int n = (int)K, np = (n + 63) / 64 * 64, npanel = np / 64;
         const size_t head = (size_t)n + npanel + 1;            // [beta | min pivots | status]
-        if (!ctx->dchol.ensure((size_t)np * np * 8) || !ctx->dsolve.ensure((head + 2 * (size_t)np) * 8))
+        if (!ctx->dchol.ensure(fsnap::chol_large_work_doubles(n) * 8) || !ctx->dsolve.ensure((head + 2 * (size_t)np) * 8))
             return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(device Cholesky) failed");
         double* dv = (double*)ctx->dsolve.p;
         double* d_beta = dv;

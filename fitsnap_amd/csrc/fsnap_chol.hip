@@ -157,22 +157,30 @@ __global__ __launch_bounds__(1024) void fsnap_chol_solve_k(const double* __restr
 
 // ---------------------------------------------------------------------------------
 // Kernels 8a-8e: blocked Cholesky solve of the K x K statistics on the GPU for LARGE K (ACE / quadratic-SNAP
-// widths; the host factorisation takes 20-40 ms at K = 1595, this path ~1 ms).  Same algorithm as the host fast
-// path (fsnap_solve.cpp): Jacobi scaling S = D (G + alpha I) D with D = diag(G + alpha I)^-1/2, S = U^T U,
+// widths; the host factorisation takes 17-22 ms at K = 1595).  Same algorithm as the host fast path
+// (fsnap_solve.cpp): Jacobi scaling S = D (G + alpha I) D with D = diag(G + alpha I)^-1/2, S = U^T U,
 // two triangular sweeps, beta = D x; accepted by the caller only if every pivot of the scaled matrix stays
 // above 1e-3 (otherwise the general host path runs).
-// The work matrix is padded to a multiple of 64 with an identity block, so no kernel has edge cases:
-//   8a prepare   d, z = D c, status; S (upper and lower) into the padded work matrix
+// The work matrix is padded to a multiple of 64 with an identity block, so no kernel has edge cases, and carries
+// an extra 32-column strip whose first column is the scaled right-hand side z = D c: the factorisation transforms
+// it along with the trailing columns, which IS the forward sweep U^T y = z.
+//   8a prepare   d, z = D c, status; S (upper and lower) and the strip into the padded work matrix (row stride np + 32)
 //   per 64-row panel [jb, je):
-//   8b diag      one workgroup factorises the 64 x 64 diagonal block in LDS (64-step recurrence)
-//   8c tails     one thread per trailing column: forward substitution U12 = U11^-T S12
+//   8b diag      ONE wave factorises the 64 x 64 diagonal block in registers and inverts its four 16 x 16
+//                diagonal sub-blocks (Y_b = U_bb^-1)
+//   8c tails     U12 = U11^-T S12 as a blocked substitution ON THE MATRIX PIPE: one wave per 16-column strip,
+//                four stages X_b = Y_b^T (S_b - sum_{b'<b} L_bb' X_b'), 40 MFMAs; an accumulator tile in the D layout
+//                (row 4r + k, column e) is exactly the B operand of k-step r, so the stages chain in registers
 //   8d update    S22 -= U12^T U12 on the matrix pipe: one wave per 32 x 32 block pair (2 x 2 MFMA tiles),
-//                k = 64 rows in 16 MFMA steps -- a 64-row SYRK, the same operand trick as kernel 1
-//   8e sweeps    one workgroup: blocked forward / backward substitution and the un-scaling
+//                k = 64 rows in 16 MFMA steps -- a 64-row SYRK, the same operand trick as kernel 1; the strip is one
+//                more block column
+//   8e backsolve one workgroup: U x = y panel by panel from the bottom (64 x 64 triangular solve inside one wave,
+//                then y_r -= U[r, panel] x_panel for all rows above, one thread per row), beta = D x
 // status[0]: bit 0 = non-positive / non-finite diagonal of G + alpha I, bit 1 = failed pivot;
 // minpiv[p] = smallest pivot of panel p.
 // ---------------------------------------------------------------------------------
 constexpr int CHOL_NB = 64;
+constexpr int CHOL_XS = 32;   // width of the right-hand-side strip (one block column of kernel 8d)
 
 __global__ __launch_bounds__(256) void fsnap_chol_prepare_d_k(const double* __restrict__ packed,
                                                              const double* __restrict__ cvec, int n, int np,
@@ -198,12 +206,16 @@ __global__ __launch_bounds__(256) void fsnap_chol_prepare_d_k(const double* __re
 
 __global__ __launch_bounds__(256) void fsnap_chol_prepare_s_k(const double* __restrict__ packed, int n, int np,
                                                              double alpha, const double* __restrict__ dsc,
-                                                             double* __restrict__ S, int* __restrict__ status) {
+                                                             const double* __restrict__ z, double* __restrict__ S,
+                                                             int* __restrict__ status) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int i = blockIdx.y;
-    if (j >= np) return;
+    const int ld = np + CHOL_XS;
+    if (j >= ld) return;
     double v;
-    if (i < n && j < n) {
+    if (j >= np) {
+        v = (j == np) ? z[i] : 0.0;
+    } else if (i < n && j < n) {
         const double g = packed[(size_t)i * n + j] + ((i == j) ? alpha : 0.0);
         v = g * dsc[i] * dsc[j];
         // (not `v - v == 0`: with fp contraction that becomes fma(g d_i, d_j, -v), the rounding error of the product)
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(256) void fsnap_chol_prepare_s_k(const double* __re
     } else {
         v = (i == j) ? 1.0 : 0.0;
     }
-    S[(size_t)i * np + j] = v;
+    S[(size_t)i * ld + j] = v;
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
@@ -220,30 +232,54 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+// 1/sqrt(d) to full precision: v_rsq_f64 + three Newton steps (the IEEE sqrt + divide pair the compiler emits for
+// sqrt(d), 1.0 / r is a ~60-instruction dependent chain, and this sits on the critical path of every column)
+__device__ __forceinline__ double rsqrt_newton(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const double e = __builtin_fma(-h * y, y, 0.5);
+        y = __builtin_fma(y, e, y);
+    }
+    return y;
+}
+
 // 8b: ONE wave, lane c holds column c of the 64 x 64 block in 64 registers; the recurrence is fully unrolled, the
-// pivot row entry B[j][i] reaches all lanes through v_readlane (scalar broadcast): no LDS, no barrier.  Entries
-// below the diagonal are updated along (never read, not written back).  (Measured 58 us per block; an LDS version
-// with 256 threads took 95 us, one with 4 x 4 register sub-blocks and two barriers per step 168 us: these
-// single-workgroup kernels run while the chip is almost idle, at whatever clock it then holds.)
-__global__ __launch_bounds__(64) void fsnap_chol_diag_k(double* __restrict__ S, int np, int jb, int* __restrict__ status,
-                                                       double* __restrict__ minpiv) {
+// pivot-row entry U[j][i] reaches all lanes through v_readlane (scalar broadcast): no LDS, no barrier.  Entries
+// below the diagonal are updated along (never read, not written back).  The readlane of the next multiplier is
+// issued before the FMA of the current one and a scheduling barrier closes every (readlane, readlane, fma) group:
+// left alone, the scheduler hoists all 63 broadcasts of a step, runs out of scalar registers and spills them
+// through v_writelane (7 k readlanes, 3 k writelanes and 3.5 k s_nops in the first version of this kernel).
+// Afterwards the four 16 x 16 diagonal sub-blocks are inverted (lane 16 b + cc: column cc of Y_b = U_bb^-1 by
+// back substitution, multipliers from LDS) for the blocked substitution of kernel 8c.
+__global__ __launch_bounds__(64) void fsnap_chol_diag_k(double* __restrict__ S, int ld, int jb, double* __restrict__ Y,
+                                                       int* __restrict__ status, double* __restrict__ minpiv) {
+    __shared__ __attribute__((aligned(16))) double UbT[4][16][16];   // UbT[b][k][r] = U_bb[r][k]
+    __shared__ double rinvL[CHOL_NB];
     const int c = threadIdx.x;
     double col[CHOL_NB];
 #pragma unroll
-    for (int r = 0; r < CHOL_NB; ++r) col[r] = S[(size_t)(jb + r) * np + jb + c];
-    double pmin = 1.0e300;
+    for (int r = 0; r < CHOL_NB; ++r) col[r] = S[(size_t)(jb + r) * ld + jb + c];
+    double pmin = 1.0e300, myinv = 0.0;
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < CHOL_NB; ++j) {
         const double d = readlane_f64(col[j], j);          // pivot (the same value in every lane)
         bad = bad || !(d > 0.0) || !__builtin_isfinite(d);
         pmin = d < pmin ? d : pmin;
-        const double r = sqrt(d), inv = 1.0 / r;
+        const double inv = rsqrt_newton(d), r = d * inv;
         col[j] = (c == j) ? r : col[j] * inv;
+        myinv = (c == j) ? inv : myinv;
+        if (j + 1 < CHOL_NB) {
+            double f = readlane_f64(col[j], j + 1);
 #pragma unroll
-        for (int i = j + 1; i < CHOL_NB; ++i) {
-            const double f = readlane_f64(col[j], i);      // B[j][i]
-            col[i] = __builtin_fma(-f, col[j], col[i]);    // B[i][c] -= B[j][i] * B[j][c]
+            for (int i = j + 1; i < CHOL_NB; ++i) {
+                const double fn = (i + 1 < CHOL_NB) ? readlane_f64(col[j], i + 1) : 0.0;
+                col[i] = __builtin_fma(-f, col[j], col[i]);    // B[i][c] -= U[j][i] * U[j][c]
+                __builtin_amdgcn_sched_barrier(0);
+                f = fn;
+            }
         }
     }
     if (bad) {
@@ -252,60 +288,96 @@ __global__ __launch_bounds__(64) void fsnap_chol_diag_k(double* __restrict__ S, 
     }
 #pragma unroll
     for (int r = 0; r < CHOL_NB; ++r)
-        if (c >= r) S[(size_t)(jb + r) * np + jb + c] = col[r];
+        if (c >= r) S[(size_t)(jb + r) * ld + jb + c] = col[r];
     if (c == 0) minpiv[jb / CHOL_NB] = pmin;
+    // diagonal sub-blocks to LDS (transposed), reciprocal diagonal
+    const int b = c >> 4, cc = c & 15;
+#pragma unroll
+    for (int r = 0; r < CHOL_NB; ++r)
+        if ((r >> 4) == b) UbT[b][cc][r & 15] = col[r];
+    rinvL[c] = myinv;
+    __syncthreads();
+    double y[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) y[r] = 0.0;
+#pragma unroll
+    for (int k = 15; k >= 0; --k) {
+        const double yk = ((k == cc) ? 1.0 : y[k]) * rinvL[16 * b + k];
+        y[k] = yk;
+#pragma unroll
+        for (int r = 0; r < k; ++r) y[r] = __builtin_fma(-UbT[b][k][r], yk, y[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Y[(b * 16 + r) * 16 + cc] = y[r];
 }
 
-// 8c: one thread per trailing column, forward substitution over the 64 panel rows with U11 in LDS (uniform reads)
-__global__ __launch_bounds__(256) void fsnap_chol_tails_k(double* __restrict__ S, int np, int jb,
-                                                         const int* __restrict__ status) {
-    __shared__ double U11[CHOL_NB][CHOL_NB + 1];
-    __shared__ double rinv[CHOL_NB];
+// 8c: blocked forward substitution on the matrix pipe.  One wave per 16-column strip of the columns right of the
+// panel (trailing columns + the right-hand-side strip).
+__global__ __launch_bounds__(256) void fsnap_chol_tails_k(double* __restrict__ S, int ld, int jb, int nstrip,
+                                                         const double* __restrict__ Y, const int* __restrict__ status) {
     if (*status) return;
-    const int tid = threadIdx.x;
-    for (int t = tid; t < CHOL_NB * CHOL_NB; t += 256) {
-        const int i = t >> 6, k = t & 63;
-        U11[i][k] = S[(size_t)(jb + i) * np + jb + k];
+    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
+    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (strip >= nstrip) return;
+    const int c0 = jb + CHOL_NB + 16 * strip;
+    double* base = S + (size_t)(jb + kr) * ld;     // row jb + kr
+    d4 X[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) X[b][s] = base[(size_t)(16 * b + 4 * s) * ld + c0 + e];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        d4 acc = X[b];
+#pragma unroll
+        for (int bp = 0; bp < b; ++bp)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double a = -base[(size_t)(16 * bp + 4 * s) * ld + jb + 16 * b + e];   // -L[16b+e][16bp+4s+kr]
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[bp][s], acc, 0, 0, 0);
+            }
+        d4 xb = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double t = Y[(b * 16 + 4 * s + kr) * 16 + e];   // (Y_b^T)[e][4s+kr]
+            xb = __builtin_amdgcn_mfma_f64_16x16x4f64(t, acc[s], xb, 0, 0, 0);
+        }
+        X[b] = xb;
     }
-    __syncthreads();
-    if (tid < CHOL_NB) rinv[tid] = 1.0 / U11[tid][tid];
-    __syncthreads();
-    const int c = jb + CHOL_NB + blockIdx.x * 256 + tid;
-    if (c >= np) return;
-    double x[CHOL_NB];
 #pragma unroll
-    for (int k = 0; k < CHOL_NB; ++k) x[k] = S[(size_t)(jb + k) * np + c];
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
-    for (int k = 0; k < CHOL_NB; ++k) {
-        double v = x[k];
-#pragma unroll
-        for (int p = 0; p < k; ++p) v -= U11[p][k] * x[p];
-        x[k] = v * rinv[k];
-    }
-#pragma unroll
-    for (int k = 0; k < CHOL_NB; ++k) S[(size_t)(jb + k) * np + c] = x[k];
+        for (int r = 0; r < 4; ++r) base[(size_t)(16 * b + 4 * r) * ld + c0 + e] = X[b][r];
 }
 
-__global__ __launch_bounds__(256) void fsnap_chol_update_k(double* __restrict__ S, int np, int jb, int nblk,
+__global__ __launch_bounds__(256) void fsnap_chol_update_k(double* __restrict__ S, int ld, int jb, int nblk,
                                                           const int* __restrict__ status) {
     if (*status) return;
     const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
     const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pair >= nblk * (nblk + 1) / 2) return;
-    // pair -> (I, J), I <= J, row-major packed triangle over nblk 32-column blocks
-    int I = 0, rem = pair;
-    while (rem >= nblk - I) {
-        rem -= nblk - I;
-        ++I;
+    const int ntri = nblk * (nblk + 1) / 2;
+    if (pair >= ntri + nblk) return;
+    // pair -> (I, J), I <= J, row-major packed triangle over nblk 32-column blocks; then (I, strip) for every I
+    int I, J;
+    if (pair < ntri) {
+        I = 0;
+        int rem = pair;
+        while (rem >= nblk - I) {
+            rem -= nblk - I;
+            ++I;
+        }
+        J = I + rem;
+    } else {
+        I = pair - ntri;
+        J = nblk;          // je + 32 nblk = np: the right-hand-side strip
     }
-    const int J = I + rem;
     const int je = jb + CHOL_NB;
     const int cI = je + 32 * I, cJ = je + 32 * J;
     d4 a00 = {0, 0, 0, 0}, a01 = a00, a10 = a00, a11 = a00;
-    const double* base = S + (size_t)(jb + kr) * np;
+    const double* base = S + (size_t)(jb + kr) * ld;
 #pragma unroll 4
     for (int s4 = 0; s4 < CHOL_NB / 4; ++s4) {
-        const double* r = base + (size_t)(4 * s4) * np;
+        const double* r = base + (size_t)(4 * s4) * ld;
         const double x0 = r[cI + e], x1 = r[cI + 16 + e];
         const double y0 = r[cJ + e], y1 = r[cJ + 16 + e];
         a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y0, a00, 0, 0, 0);
@@ -317,8 +389,8 @@ __global__ __launch_bounds__(256) void fsnap_chol_update_k(double* __restrict__ 
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
         const int row = kr + 4 * r4;
-        double* p0 = S + (size_t)(cI + row) * np;
-        double* p1 = S + (size_t)(cI + 16 + row) * np;
+        double* p0 = S + (size_t)(cI + row) * ld;
+        double* p1 = S + (size_t)(cI + 16 + row) * ld;
         p0[cJ + e] -= a00[r4];
         p0[cJ + 16 + e] -= a01[r4];
         p1[cJ + e] -= a10[r4];
@@ -326,96 +398,89 @@ __global__ __launch_bounds__(256) void fsnap_chol_update_k(double* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(1024) void fsnap_chol_sweeps_k(const double* __restrict__ S, int np, int n,
-                                                           double* __restrict__ z, const double* __restrict__ dsc,
-                                                           double* __restrict__ beta, const int* __restrict__ status) {
-    // z (length np, global) is solved in place: forward U^T y = z, backward U x = y; beta = D x
+// 8e: the strip's first column now holds y = U^-T z; solve U x = y from the last panel upwards.  zv = working copy.
+__global__ __launch_bounds__(1024) void fsnap_chol_backsolve_k(const double* __restrict__ S, int ld, int np, int n,
+                                                              double* __restrict__ zv, const double* __restrict__ dsc,
+                                                              double* __restrict__ beta, const int* __restrict__ status) {
     __shared__ double U11[CHOL_NB][CHOL_NB + 1];
-    __shared__ double xb[CHOL_NB];
-    __shared__ double red[1024];
+    __shared__ __attribute__((aligned(16))) double xb[CHOL_NB];
     if (*status) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int npanel = np / CHOL_NB;
-    for (int pb = 0; pb < npanel; ++pb) {
-        const int jb = pb * CHOL_NB, je = jb + CHOL_NB;
-        for (int t = tid; t < CHOL_NB * CHOL_NB; t += 1024) U11[t >> 6][t & 63] = S[(size_t)(jb + (t >> 6)) * np + jb + (t & 63)];
-        __syncthreads();
-        if (wv == 0) {      // 64 x 64 lower-triangular solve (U11^T y = z_b) inside one wave
-            double v = z[jb + lane];
-            const double rdiag = 1.0 / U11[lane][lane];
-            for (int k = 0; k < CHOL_NB; ++k) {
-                const double yk = readlane_f64(v, k) * readlane_f64(rdiag, k);
-                if (lane == k) v = yk;
-                else if (lane > k) v -= U11[k][lane] * yk;
-            }
-            xb[lane] = v;
-            z[jb + lane] = v;
-        }
-        __syncthreads();
-        for (int c = je + tid; c < np; c += 1024) {
-            double acc = z[c];
-#pragma unroll 8
-            for (int k = 0; k < CHOL_NB; ++k) acc -= S[(size_t)(jb + k) * np + c] * xb[k];
-            z[c] = acc;
-        }
-        __syncthreads();
-    }
+    for (int i = tid; i < np; i += 1024) zv[i] = S[(size_t)i * ld + np];
+    __syncthreads();
     for (int pb = npanel - 1; pb >= 0; --pb) {
-        const int jb = pb * CHOL_NB, je = jb + CHOL_NB;
-        for (int t = tid; t < CHOL_NB * CHOL_NB; t += 1024) U11[t >> 6][t & 63] = S[(size_t)(jb + (t >> 6)) * np + jb + (t & 63)];
-        // row k of the panel: z_k -= sum_{c >= je} U[k][c] x_c, 16 threads per row
-        {
-            const int k = tid >> 4, q = tid & 15;
-            double acc = 0.0;
-            const double* r = S + (size_t)(jb + k) * np;
-            for (int c = je + q; c < np; c += 16) acc += r[c] * z[c];
-            red[tid] = acc;
-        }
+        const int jb = pb * CHOL_NB;
+        for (int t = tid; t < CHOL_NB * CHOL_NB; t += 1024) U11[t >> 6][t & 63] = S[(size_t)(jb + (t >> 6)) * ld + jb + (t & 63)];
         __syncthreads();
-        if (wv == 0) {
-            double v = z[jb + lane];
-            double sub = 0.0;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) sub += red[lane * 16 + q];
-            v -= sub;
+        if (wv == 0) {      // 64 x 64 upper-triangular solve inside one wave
+            double v = zv[jb + lane];
             const double rdiag = 1.0 / U11[lane][lane];
             for (int k = CHOL_NB - 1; k >= 0; --k) {
                 const double xk = readlane_f64(v, k) * readlane_f64(rdiag, k);
                 if (lane == k) v = xk;
                 else if (lane < k) v -= U11[lane][k] * xk;
             }
-            z[jb + lane] = v;
+            xb[lane] = v;
+            zv[jb + lane] = v;
+        }
+        __syncthreads();
+        // rows above the panel: y_r -= U[r, jb : jb + 64] x_panel (64 contiguous doubles per row)
+        for (int r = tid; r < jb; r += 1024) {
+            const d2* u = reinterpret_cast<const d2*>(S + (size_t)r * ld + jb);   // 16-byte aligned: ld, jb multiples of 32
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {          // 16 x 16-byte loads in flight (128-register budget of 1024 threads)
+                d2 uv[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) uv[q] = u[16 * h + q];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    a0 = __builtin_fma(uv[q][0], xb[32 * h + 2 * q], a0);
+                    a1 = __builtin_fma(uv[q][1], xb[32 * h + 2 * q + 1], a1);
+                }
+            }
+            zv[r] -= a0 + a1;
         }
         __syncthreads();
     }
-    for (int i = tid; i < n; i += 1024) beta[i] = z[i] * dsc[i];
+    for (int i = tid; i < n; i += 1024) beta[i] = zv[i] * dsc[i];
 }
 // ---------------------------------------------------------------------------------
 // host-side launchers (C++ linkage, used by fsnap_capi.cpp)
 // ---------------------------------------------------------------------------------
 namespace fsnap {
 
-hipError_t launch_chol_large(const double* packed, const double* cvec, int n, double alpha, double* S, double* dsc, double* z,
+size_t chol_large_work_doubles(int n) {
+    const size_t np = (size_t)(n + CHOL_NB - 1) / CHOL_NB * CHOL_NB;
+    return np * (np + CHOL_XS) + (np / CHOL_NB) * 1024;     // work matrix + strip, Y blocks of every panel
+}
+
+hipError_t launch_chol_large(const double* packed, const double* cvec, int n, double alpha, double* work, double* dsc, double* z,
                              double* beta, int* status, double* minpiv, hipStream_t st) {
     if (!cvec) cvec = packed + (size_t)n * n;
-    const int np = (n + CHOL_NB - 1) / CHOL_NB * CHOL_NB, npanel = np / CHOL_NB;
+    const int np = (n + CHOL_NB - 1) / CHOL_NB * CHOL_NB, npanel = np / CHOL_NB, ld = np + CHOL_XS;
+    double* S = work;
+    double* Yall = work + (size_t)np * ld;
     hipError_t e = hipMemsetAsync(status, 0, sizeof(int), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fsnap_chol_prepare_d_k, dim3((np + 255) / 256), dim3(256), 0, st, packed, cvec, n, np, alpha, dsc, z, status,
                        minpiv, npanel);
-    hipLaunchKernelGGL(fsnap_chol_prepare_s_k, dim3((np + 255) / 256, np), dim3(256), 0, st, packed, n, np, alpha, dsc, S,
+    hipLaunchKernelGGL(fsnap_chol_prepare_s_k, dim3((ld + 255) / 256, np), dim3(256), 0, st, packed, n, np, alpha, dsc, z, S,
                        status);
     for (int pb = 0; pb < npanel; ++pb) {
         const int jb = pb * CHOL_NB;
-        hipLaunchKernelGGL(fsnap_chol_diag_k, dim3(1), dim3(64), 0, st, S, np, jb, status, minpiv);
+        double* Y = Yall + (size_t)pb * 1024;
+        hipLaunchKernelGGL(fsnap_chol_diag_k, dim3(1), dim3(64), 0, st, S, ld, jb, Y, status, minpiv);
         const int ntail = np - jb - CHOL_NB;
+        const int nstrip = (ntail + CHOL_XS) / 16;
+        hipLaunchKernelGGL(fsnap_chol_tails_k, dim3((nstrip + 3) / 4), dim3(256), 0, st, S, ld, jb, nstrip, Y, status);
         if (ntail > 0) {
-            hipLaunchKernelGGL(fsnap_chol_tails_k, dim3((ntail + 255) / 256), dim3(256), 0, st, S, np, jb, status);
-            const int nblk = ntail / 32, npair = nblk * (nblk + 1) / 2;
-            hipLaunchKernelGGL(fsnap_chol_update_k, dim3((npair + 3) / 4), dim3(256), 0, st, S, np, jb, nblk, status);
+            const int nblk = ntail / 32, npair = nblk * (nblk + 1) / 2 + nblk;
+            hipLaunchKernelGGL(fsnap_chol_update_k, dim3((npair + 3) / 4), dim3(256), 0, st, S, ld, jb, nblk, status);
         }
     }
-    hipLaunchKernelGGL(fsnap_chol_sweeps_k, dim3(1), dim3(1024), 0, st, S, np, n, z, dsc, beta, status);
+    hipLaunchKernelGGL(fsnap_chol_backsolve_k, dim3(1), dim3(1024), 0, st, S, ld, np, n, z, dsc, beta, status);
     return hipGetLastError();
 }
 

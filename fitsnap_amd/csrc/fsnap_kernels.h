@@ -70,10 +70,11 @@ hipError_t launch_assemble(const double* raw, int64_t raw_ld, int64_t nrows, con
                            const double* fractions, const double* blank2J, int ntypes, int ncoeff, int off, double* A,
                            int64_t lda, double* b, double* w, hipStream_t st);
 hipError_t launch_chol_solve(const double* packed, int K, double alpha, double* out, hipStream_t st);
-// blocked Cholesky solve for large K: S (np x np, np = K rounded up to 64), dsc, z (np), beta (K), status (1 int),
-// minpiv (np / 64) are device scratch / outputs
+// blocked Cholesky solve for large K: work (chol_large_work_doubles(K) doubles), dsc, z (np = K rounded up to 64),
+// beta (K), status (1 int), minpiv (np / 64) are device scratch / outputs
 // cvec: device right-hand side (NULL = the c part of packed)
-hipError_t launch_chol_large(const double* packed, const double* cvec, int n, double alpha, double* S, double* dsc, double* z,
+size_t chol_large_work_doubles(int n);
+hipError_t launch_chol_large(const double* packed, const double* cvec, int n, double alpha, double* work, double* dsc, double* z,
                              double* beta, int* status, double* minpiv, hipStream_t st);
 int gemv_num_blocks(int64_t m);
 hipError_t launch_gemv_rows(const double* A, int64_t lda, const double* beta, int64_t m, int K, double* preds,

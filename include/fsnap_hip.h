@@ -70,7 +70,7 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * per-wave specialised bodies, 3 LDS-shared generic variant), "split" (1|2, sub-waves per row-wave of kernel 1),
  * "nontemporal" (0|1), "nblocks" (workgroups of the SYRK kernel), "tiled" (1 = force the
  * general-K tiled kernel also for K <= 128), "nsplit" (row splits of the tiled kernel), "mirror" (0|1, see fsnap_normal_eq_resident), "xcd" (0|1: tiled kernel deals contiguous work-item ranges to each XCD),
- * "device_solve" (fsnap_solve_device: 0 = auto: K >= 768 is factorised on the GPU by the blocked kernels; 1 = every K on the GPU; 2 = never).
+ * "device_solve" (fsnap_solve_device: 0 = auto: K >= 384 is factorised on the GPU by the blocked kernels; 1 = every K on the GPU; 2 = never).
  * Unknown key -> FSNAP_E_ARG. */
 int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value);
 
@@ -196,7 +196,7 @@ int fsnap_solve(int kind, double param, int64_t K, const double* G, const double
 /* Same solve, taking the packed statistics [G | c | ...] from DEVICE memory (the buffer
  * fsnap_normal_eq_async / the all-reduce left in HBM).  Small systems are copied to the host
  * (page-locked staging) and solved there (faster than any GPU factorisation of a 128-step recurrence); for
- * K >= 768 (option "device_solve") a blocked Cholesky runs on the GPU and only beta crosses PCIe, provided the
+ * K >= 384 (option "device_solve") a blocked Cholesky runs on the GPU and only beta crosses PCIe, provided the
  * system is well conditioned after Jacobi scaling -- otherwise the general host path decides.  Same status codes and semantics as fsnap_solve. */
 int fsnap_solve_device(fsnap_ctx* ctx, int kind, double param, int64_t K, const double* d_packed, double* beta,
                        int* rank, double* rcond_est);
