@@ -373,61 +373,128 @@ __global__ __launch_bounds__(256) void fsnap_chol_update_k(double* __restrict__ 
     }
     const int je = jb + CHOL_NB;
     const int cI = je + 32 * I, cJ = je + 32 * J;
-    d4 a00 = {0, 0, 0, 0}, a01 = a00, a10 = a00, a11 = a00;
     const double* base = S + (size_t)(jb + kr) * ld;
-#pragma unroll 4
+    // every load of this wave is independent: issue the 64 operand values and the 16 values of the target tiles
+    // together (one memory round trip; with a partially unrolled loop the wave paid four, plus one for the
+    // read-modify-write at the end)
+    double x0[16], x1[16], y0[16], y1[16];
+#pragma unroll
     for (int s4 = 0; s4 < CHOL_NB / 4; ++s4) {
         const double* r = base + (size_t)(4 * s4) * ld;
-        const double x0 = r[cI + e], x1 = r[cI + 16 + e];
-        const double y0 = r[cJ + e], y1 = r[cJ + 16 + e];
-        a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y0, a00, 0, 0, 0);
-        a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y1, a01, 0, 0, 0);
-        a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y0, a10, 0, 0, 0);
-        a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y1, a11, 0, 0, 0);
+        x0[s4] = r[cI + e];
+        x1[s4] = r[cI + 16 + e];
+        y0[s4] = r[cJ + e];
+        y1[s4] = r[cJ + 16 + e];
     }
+    d4 a00, a01, a10, a11;
     // D tile layout: element (row = kr + 4 r, col = e)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int row = kr + 4 * r4;
+        const double* p0 = S + (size_t)(cI + row) * ld;
+        const double* p1 = S + (size_t)(cI + 16 + row) * ld;
+        a00[r4] = p0[cJ + e];
+        a01[r4] = p0[cJ + 16 + e];
+        a10[r4] = p1[cJ + e];
+        a11[r4] = p1[cJ + 16 + e];
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < CHOL_NB / 4; ++s4) {      // C - U12^T U12: the A operand is negated
+        a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x0[s4], y0[s4], a00, 0, 0, 0);
+        a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x0[s4], y1[s4], a01, 0, 0, 0);
+        a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[s4], y0[s4], a10, 0, 0, 0);
+        a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[s4], y1[s4], a11, 0, 0, 0);
+    }
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
         const int row = kr + 4 * r4;
         double* p0 = S + (size_t)(cI + row) * ld;
         double* p1 = S + (size_t)(cI + 16 + row) * ld;
-        p0[cJ + e] -= a00[r4];
-        p0[cJ + 16 + e] -= a01[r4];
-        p1[cJ + e] -= a10[r4];
-        p1[cJ + 16 + e] -= a11[r4];
+        p0[cJ + e] = a00[r4];
+        p0[cJ + 16 + e] = a01[r4];
+        p1[cJ + e] = a10[r4];
+        p1[cJ + 16 + e] = a11[r4];
     }
 }
 
-// 8e: the strip's first column now holds y = U^-T z; solve U x = y from the last panel upwards.  zv = working copy.
+// 8e: the strip's first column now holds y = U^-T z; solve U x = y from the last panel upwards.  Per panel: wave 0
+// solves the 64 x 64 triangular system as a blocked substitution with the inverted 16 x 16 diagonal blocks of
+// kernel 8b (7 small matrix-vector products, multipliers broadcast with v_readlane; the 64-step scalar recurrence
+// took ~5 us per panel), then every thread takes rows above the panel: y_r -= U[r, panel] x_panel (64 contiguous
+// doubles per row).  The next panel's diagonal block and inverses are fetched into registers while that runs.
+// Dynamic LDS: two buffers of [U11 64 x 65 | Y 4 x 16 x 17] + x_panel (64) + y of the next panel (64).
+constexpr int CHOL_BS_BUF = CHOL_NB * (CHOL_NB + 1) + 4 * 16 * 17;
+constexpr size_t CHOL_BS_LDS = (size_t)(2 * CHOL_BS_BUF + 2 * CHOL_NB) * sizeof(double);
+
 __global__ __launch_bounds__(1024) void fsnap_chol_backsolve_k(const double* __restrict__ S, int ld, int np, int n,
-                                                              double* __restrict__ zv, const double* __restrict__ dsc,
-                                                              double* __restrict__ beta, const int* __restrict__ status) {
-    __shared__ double U11[CHOL_NB][CHOL_NB + 1];
-    __shared__ __attribute__((aligned(16))) double xb[CHOL_NB];
+                                                              const double* __restrict__ Yall, double* __restrict__ zv,
+                                                              const double* __restrict__ dsc, double* __restrict__ beta,
+                                                              const int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double bs_lds[];
     if (*status) return;
+    double* xb = bs_lds + 2 * CHOL_BS_BUF;     // x of the current panel
+    double* ynext = xb + CHOL_NB;              // finished y of the next panel (rows jb - 64 .. jb - 1)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int npanel = np / CHOL_NB;
     for (int i = tid; i < np; i += 1024) zv[i] = S[(size_t)i * ld + np];
+    if (tid < CHOL_NB) ynext[tid] = S[(size_t)(np - CHOL_NB + tid) * ld + np];
+    // thread t stages U11 elements t, t + 1024, ... and Y element t of a panel
+    double pu[4], py;
+    auto fetch = [&](int pb) {
+        const int jb = pb * CHOL_NB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = tid + 1024 * q;
+            pu[q] = S[(size_t)(jb + (t >> 6)) * ld + jb + (t & 63)];
+        }
+        py = Yall[(size_t)pb * 1024 + tid];
+    };
+    auto park = [&](int buf) {
+        double* U11 = bs_lds + buf * CHOL_BS_BUF;
+        double* Ysm = U11 + CHOL_NB * (CHOL_NB + 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = tid + 1024 * q;
+            U11[(t >> 6) * (CHOL_NB + 1) + (t & 63)] = pu[q];
+        }
+        Ysm[(tid >> 4) * 17 + (tid & 15)] = py;      // (block, row) = tid >> 4, column = tid & 15
+    };
+    fetch(npanel - 1);
+    park(0);
     __syncthreads();
     for (int pb = npanel - 1; pb >= 0; --pb) {
         const int jb = pb * CHOL_NB;
-        for (int t = tid; t < CHOL_NB * CHOL_NB; t += 1024) U11[t >> 6][t & 63] = S[(size_t)(jb + (t >> 6)) * ld + jb + (t & 63)];
-        __syncthreads();
-        if (wv == 0) {      // 64 x 64 upper-triangular solve inside one wave
-            double v = zv[jb + lane];
-            const double rdiag = 1.0 / U11[lane][lane];
-            for (int k = CHOL_NB - 1; k >= 0; --k) {
-                const double xk = readlane_f64(v, k) * readlane_f64(rdiag, k);
-                if (lane == k) v = xk;
-                else if (lane < k) v -= U11[lane][k] * xk;
+        const int cur = (npanel - 1 - pb) & 1;
+        const double* U11 = bs_lds + cur * CHOL_BS_BUF;
+        const double* Ysm = U11 + CHOL_NB * (CHOL_NB + 1);
+        if (pb > 0) fetch(pb - 1);
+        if (wv == 0) {
+            double v = ynext[lane];
+            const int blk = lane >> 4, i = lane & 15;
+#pragma unroll
+            for (int b = 3; b >= 0; --b) {
+                // x_b = Y_b v_b (lanes of block b)
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc = __builtin_fma(Ysm[(b * 16 + i) * 17 + k], readlane_f64(v, 16 * b + k), acc);
+                if (blk == b) v = acc;
+                // v_b' -= U_b'b x_b for the blocks above (rows < 16 b)
+                if (b > 0) {
+                    double sub = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        sub = __builtin_fma(U11[lane * (CHOL_NB + 1) + 16 * b + k], readlane_f64(v, 16 * b + k), sub);
+                    if (blk < b) v -= sub;
+                }
             }
             xb[lane] = v;
             zv[jb + lane] = v;
         }
         __syncthreads();
-        // rows above the panel: y_r -= U[r, jb : jb + 64] x_panel (64 contiguous doubles per row)
+        // rows above the panel: y_r -= U[r, jb : jb + 64] x_panel
         for (int r = tid; r < jb; r += 1024) {
             const d2* u = reinterpret_cast<const d2*>(S + (size_t)r * ld + jb);   // 16-byte aligned: ld, jb multiples of 32
+            const double z0 = zv[r];
             double a0 = 0.0, a1 = 0.0;
 #pragma unroll 1
             for (int h = 0; h < 2; ++h) {          // 16 x 16-byte loads in flight (128-register budget of 1024 threads)
@@ -440,8 +507,11 @@ __global__ __launch_bounds__(1024) void fsnap_chol_backsolve_k(const double* __r
                     a1 = __builtin_fma(uv[q][1], xb[32 * h + 2 * q + 1], a1);
                 }
             }
-            zv[r] -= a0 + a1;
+            const double zn = z0 - (a0 + a1);
+            zv[r] = zn;
+            if (r >= jb - CHOL_NB) ynext[r - (jb - CHOL_NB)] = zn;
         }
+        if (pb > 0) park(cur ^ 1);
         __syncthreads();
     }
     for (int i = tid; i < n; i += 1024) beta[i] = zv[i] * dsc[i];
@@ -480,7 +550,13 @@ hipError_t launch_chol_large(const double* packed, const double* cvec, int n, do
             hipLaunchKernelGGL(fsnap_chol_update_k, dim3((npair + 3) / 4), dim3(256), 0, st, S, ld, jb, nblk, status);
         }
     }
-    hipLaunchKernelGGL(fsnap_chol_backsolve_k, dim3(1), dim3(1024), 0, st, S, ld, np, n, z, dsc, beta, status);
+    static bool bs_attr_set = false;
+    if (!bs_attr_set) {
+        e = hipFuncSetAttribute((const void*)fsnap_chol_backsolve_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHOL_BS_LDS);
+        if (e != hipSuccess) return e;
+        bs_attr_set = true;
+    }
+    hipLaunchKernelGGL(fsnap_chol_backsolve_k, dim3(1), dim3(1024), CHOL_BS_LDS, st, S, ld, np, n, Yall, z, dsc, beta, status);
     return hipGetLastError();
 }
 
