@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <queue>
 #include <string>
 #include <vector>
 
@@ -96,6 +97,11 @@ struct fsnap_ctx {
     int opt_mirror = 1;       // fsnap_normal_eq_resident: reduction writes a page-locked host mirror (K <= 128)
     int opt_device_solve = 0; // 0 = auto (K >= 384 on the GPU, blocked), 1 = every K (K <= 128: fsnap_chol_solve_k), 2 = never
     int opt_ablate = 0;       // timing-only ablation of kernel 1L (diagnostics; results are wrong)
+    // cached launch plan of the tiled kernel (plan_tiled)
+    bool tplan_valid = false;
+    int64_t tplan_key[5] = {0, 0, 0, 0, 0};
+    int tplan[3] = {0, 0, 0};
+    int64_t tplan_cps = 0;
     // timing flags
     bool t_syrk = false, t_upload = false, t_weight = false, t_predict = false;
 
@@ -241,36 +247,73 @@ int fit_events(fsnap_ctx* ctx, hipEvent_t** slot) {
     return FSNAP_OK;
 }
 
+// Row splits of the tiled kernel.  Work items (split, superblock pair) are NOT equal: an off-diagonal pair runs 16
+// MFMAs per chunk, a diagonal pair 10, pairs with the (half-empty) last superblock 8 / 3, and two workgroups per CU
+// are resident -- with one or two rounds of items the short ones leave their slots idle (367 900 x 480: 27 splits
+// 1.84 ms, 57 splits 1.60 ms).  So the split count comes from a small model: greedy list scheduling of one XCD's
+// item range on its slots (the hardware dispatches the next workgroup when a slot frees up) + the reduction of the
+// partial triangles; it reproduces the measured kernel times within ~5 %.  The result is cached per shape.
+double tiled_makespan_units(const std::vector<int>& tiles, int64_t n, int64_t chunks_per_wave, int64_t groups, int64_t slots) {
+    const int64_t npairs = (int64_t)tiles.size();
+    const int64_t nitems = npairs * n;
+    const int64_t per = (nitems + groups - 1) / groups;
+    std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
+    for (int64_t i = 0; i < slots; ++i) free_at.push(0.0);
+    const double ovh = 128.0;      // prologue + 4-wave fold + 32 KiB partial store, in units of one chunk of one tile
+    double makespan = 0.0;
+    for (int64_t it = 0; it < per && it < nitems; ++it) {
+        const double t0 = free_at.top();
+        free_at.pop();
+        const double t1 = t0 + ovh + (double)chunks_per_wave * tiles[(size_t)(it % npairs)];
+        free_at.push(t1);
+        if (t1 > makespan) makespan = t1;
+    }
+    return makespan;
+}
+
 int plan_tiled(fsnap_ctx* ctx, TiledGeometry* g) {
     const int64_t m = ctx->m, K = ctx->K;
     if (K > 32768) return ctx->fail(FSNAP_E_ARG, "K = %lld too large", (long long)K);
+    if (ctx->tplan_valid && ctx->tplan_key[0] == m && ctx->tplan_key[1] == K && ctx->tplan_key[2] == ctx->lda &&
+        ctx->tplan_key[3] == ctx->opt_nsplit && ctx->tplan_key[4] == ctx->opt_xcd) {
+        g->NSB = ctx->tplan[0];
+        g->npairs = ctx->tplan[1];
+        g->nsplit = ctx->tplan[2];
+        g->cps = ctx->tplan_cps;
+        return FSNAP_OK;
+    }
     g->NSB = (int)((K + 63) / 64);
     g->npairs = g->NSB * (g->NSB + 1) / 2;
     const int64_t nchunks = (m + 3) / 4;
-    // Two workgroups (8 waves) per CU are resident.  Equal-sized work items run in rounds of
-    // `slots` workgroups (per XCD when items are dealt in contiguous ranges), so pick the
-    // smallest split count whose last round is (nearly) full: 36 pairs x 15 splits = 540 items
-    // on 512 slots would run a second, almost empty round.
     const int64_t bytes = m * ctx->lda * 8;
     // keep a split's rows resident in the Infinity Cache (256 MiB) while all pairs sweep them
     const int64_t min_split_cache = (bytes + (96ll << 20) - 1) / (96ll << 20);
     int64_t nsplit = ctx->opt_nsplit;
     if (nsplit <= 0) {
         const int64_t groups = ctx->opt_xcd ? 8 : 1;
-        const int64_t slots = (int64_t)ctx->num_cu * 2 / groups;
-        const int64_t n_hi = std::max<int64_t>(1, std::min<int64_t>(256, nchunks / 32));   // >= 8 chunks per wave
-        const int64_t n_lo = std::min<int64_t>(n_hi, std::max<int64_t>(1, min_split_cache));
-        double best = -1.0;
-        for (int64_t n = n_lo; n <= std::max(n_hi, n_lo); ++n) {
-            const int64_t per = (g->npairs * n + groups - 1) / groups;
-            const double util = (double)per / (double)(slots * ((per + slots - 1) / slots));
-            if (util > best + 1e-9) {
-                best = util;
-                nsplit = n;
+        const int64_t slots = (int64_t)ctx->num_cu * 2 / groups;     // two workgroups (8 waves) per CU are resident
+        const int tail = (int)(K & 63);
+        const bool half = tail != 0 && tail <= 32;                   // last superblock: second 32-column group empty
+        std::vector<int> tiles;
+        tiles.reserve((size_t)g->npairs);
+        for (int I = 0; I < g->NSB; ++I)
+            for (int J = I; J < g->NSB; ++J) {
+                const bool last = half && J == g->NSB - 1;
+                tiles.push_back(I == J ? (last ? 3 : 10) : (last ? 8 : 16));
             }
-            if (util >= 0.93) {
+        const int64_t part_bytes = (int64_t)g->npairs * 32768;                        // partial triangles of one split
+        int64_t n_hi = std::max<int64_t>(1, std::min<int64_t>(1024, nchunks / 128));  // >= 32 chunks per wave
+        n_hi = std::min(n_hi, std::max<int64_t>(1, (256ll << 20) / part_bytes));      // <= 256 MiB of partials
+        const int64_t n_lo = std::min(n_hi, std::max<int64_t>(1, min_split_cache));
+        double best = 1.0e300;
+        for (int64_t n = n_lo; n <= n_hi; ++n) {
+            const int64_t cps = (nchunks + n - 1) / n;
+            const int64_t cpw = (cps + 3) / 4;
+            const double cost = 66.0e-9 * tiled_makespan_units(tiles, n, cpw, groups, slots) +   // 64-cycle MFMAs, two waves per SIMD, ~80 % issue
+                                (double)n * (double)part_bytes / 3.0e12;
+            if (cost < best) {
+                best = cost;
                 nsplit = n;
-                break;
             }
         }
     }
@@ -288,6 +331,34 @@ int plan_tiled(fsnap_ctx* ctx, TiledGeometry* g) {
     if ((int64_t)g->npairs * nsplit > 0x7FFFFFFF) return ctx->fail(FSNAP_E_ARG, "too many workgroups");
     g->nsplit = (int)nsplit;
     g->cps = cps;
+    ctx->tplan_key[0] = m;
+    ctx->tplan_key[1] = K;
+    ctx->tplan_key[2] = ctx->lda;
+    ctx->tplan_key[3] = ctx->opt_nsplit;
+    ctx->tplan_key[4] = ctx->opt_xcd;
+    ctx->tplan[0] = g->NSB;
+    ctx->tplan[1] = g->npairs;
+    ctx->tplan[2] = g->nsplit;
+    ctx->tplan_cps = g->cps;
+    ctx->tplan_valid = true;
+    return FSNAP_OK;
+}
+
+// (w_eff, w_eff b) per row for kernels 1A / 1T, packed once per (b, w, mask) -- every time if any of them lives in
+// memory the caller owns (fsnap_bind_rows / fsnap_bind_weights: it may have changed without notice).  *npk = number
+// of partial b-only scalars in ctx->wpack_spart.
+int ensure_wpack(fsnap_ctx* ctx, int* npk) {
+    *npk = fsnap::pack_weights_num_blocks(ctx->m);
+    if (!ctx->wpack.ensure((size_t)ctx->m * 16 + 64) || !ctx->wpack_spart.ensure((size_t)*npk * 4 * 8))
+        return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(packed weights) failed");
+    const bool caller_owned = ctx->db != (const double*)ctx->ownb.p || ctx->dw != (const double*)ctx->ownw.p ||
+                              (ctx->dmask && ctx->dmask != (const unsigned char*)ctx->ownmask.p);
+    if (!ctx->wpack_valid || caller_owned) {
+        FSNAP_HIP(fsnap::launch_pack_weights(ctx->db, ctx->dw, ctx->dmask, ctx->m, (double*)ctx->wpack.p,
+                                             (double*)ctx->wpack_spart.p, ctx->stream),
+                  "launch fsnap_pack_weights_k");
+        ctx->wpack_valid = true;
+    }
     return FSNAP_OK;
 }
 
@@ -295,21 +366,15 @@ int launch_normal_eq_tiled(fsnap_ctx* ctx, double* d_packed, bool accumulate) {
     int rc;
     TiledGeometry g;
     if ((rc = plan_tiled(ctx, &g))) return rc;
-    const unsigned char* mask = ctx->dmask;
-    if (!mask) {
-        if ((rc = ensure_ones(ctx))) return rc;
-        mask = (const unsigned char*)ctx->ones.p;
-    }
+    int npk = 0;
+    if ((rc = ensure_wpack(ctx, &npk))) return rc;
     if (!ctx->part.ensure((size_t)g.nsplit * g.npairs * 4096 * sizeof(double)) ||
-        !ctx->cpart.ensure((size_t)g.nsplit * g.NSB * 4 * 64 * sizeof(double)) ||
-        !ctx->spart.ensure((size_t)g.nsplit * 4 * 4 * sizeof(double)))
+        !ctx->cpart.ensure((size_t)g.nsplit * g.NSB * 4 * 64 * sizeof(double)))
         return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(partials) failed");
     fsnap::TiledArgs a;
     a.A = ctx->dA;
     a.lda = ctx->lda;
-    a.b = ctx->db;
-    a.w = ctx->dw;
-    a.mask = mask;
+    a.wpack = (const double*)ctx->wpack.p;
     a.m = ctx->m;
     a.K = (int)ctx->K;
     a.NSB = g.NSB;
@@ -320,10 +385,10 @@ int launch_normal_eq_tiled(fsnap_ctx* ctx, double* d_packed, bool accumulate) {
     a.xcd_map = ctx->opt_xcd != 0;
     a.part = (double*)ctx->part.p;
     a.cpart = (double*)ctx->cpart.p;
-    a.spart = (double*)ctx->spart.p;
-    // waves of off-diagonal pairs never write their c / scalar slots: zero them once
+    a.spart = (const double*)ctx->wpack_spart.p;
+    a.ns = npk;
+    // waves of off-diagonal pairs never write their c slots: zero them once
     FSNAP_HIP(hipMemsetAsync(a.cpart, 0, (size_t)g.nsplit * g.NSB * 4 * 64 * sizeof(double), ctx->stream), "hipMemsetAsync");
-    FSNAP_HIP(hipMemsetAsync(a.spart, 0, (size_t)g.nsplit * 4 * 4 * sizeof(double), ctx->stream), "hipMemsetAsync");
     hipEvent_t* evs;
     if ((rc = fit_events(ctx, &evs))) return rc;
     FSNAP_HIP(hipEventRecord(evs[0], ctx->stream), "hipEventRecord");
@@ -372,19 +437,8 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
     int ns = -1;                      // scalar partials: from the SYRK kernel, or (kernel 1A) from the weight packing
     const double* spart_src = a.spart;
     if (g.acc) {
-        // kernel 1A reads (w_eff, w_eff b) per row; packed once per (b, w, mask) -- every time if any of them lives
-        // in memory the caller owns (fsnap_bind_rows / fsnap_bind_weights: it may have changed without notice)
-        const int npk = fsnap::pack_weights_num_blocks(ctx->m);
-        if (!ctx->wpack.ensure((size_t)ctx->m * 16 + 64) || !ctx->wpack_spart.ensure((size_t)npk * 4 * 8))
-            return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(packed weights) failed");
-        const bool caller_owned = ctx->db != (const double*)ctx->ownb.p || ctx->dw != (const double*)ctx->ownw.p ||
-                                  (ctx->dmask && ctx->dmask != (const unsigned char*)ctx->ownmask.p);
-        if (!ctx->wpack_valid || caller_owned) {
-            FSNAP_HIP(fsnap::launch_pack_weights(ctx->db, ctx->dw, ctx->dmask, ctx->m, (double*)ctx->wpack.p,
-                                                 (double*)ctx->wpack_spart.p, ctx->stream),
-                      "launch fsnap_pack_weights_k");
-            ctx->wpack_valid = true;
-        }
+        int npk = 0;
+        if ((rc = ensure_wpack(ctx, &npk))) return rc;
         a.wpack = (const double*)ctx->wpack.p;
         spart_src = (const double*)ctx->wpack_spart.p;
         ns = npk;

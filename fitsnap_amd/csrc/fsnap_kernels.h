@@ -29,9 +29,7 @@ struct SyrkArgs {
 struct TiledArgs {
     const double* A;
     int64_t lda;
-    const double* b;
-    const double* w;
-    const unsigned char* mask;
+    const double* wpack;        // (w_eff, w_eff b) per row (fsnap_pack_weights_k)
     int64_t m;
     int K;
     int NSB;                    // 64-column superblocks
@@ -42,7 +40,8 @@ struct TiledArgs {
     bool xcd_map = true;        // contiguous (split, pair) ranges per XCD (L2 sharing of row slabs)
     double* part;               // [nsplit*npairs][16][4][64]
     double* cpart;              // [(nsplit*NSB)*4][4][16]
-    double* spart;              // [nsplit*4][4]
+    const double* spart;        // [ns][4]: partial b-only scalars of fsnap_pack_weights_k
+    int ns;
 };
 
 int syrk_num_blocks(int K);

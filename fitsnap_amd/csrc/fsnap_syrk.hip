@@ -1291,117 +1291,152 @@ __global__ __launch_bounds__(64 * NW, (NW == 2 ? 2 : NW == 4 ? 3 : 4)) void fsna
 // lane loads 4 + 4 doubles and feeds 16 MFMAs.  Pairs are the fast grid index: the
 // workgroups that run concurrently read the SAME rows (different column superblocks),
 // so every row is fetched from HBM once per split and re-read from L2 / Infinity Cache.
-// c and the scalars ride on the diagonal pairs / pair 0.
+// (A 2 x 2 arrangement -- the four waves of a workgroup on the four superblock pairs of a 128-column block pair
+// over the same rows, every slice requested by two waves -- was measured 15-25 % slower: idle waves on diagonal and
+// edge blocks, and no gain from the shared requests: the kernel is not bound by L2 traffic.)
+// c rides on the diagonal pairs; the b-only scalars come from fsnap_pack_weights_k.
 // Partials: partT[split*npairs + pair][16][4][64] | cpartT[(split*NSB + I)*4 + wave][4][16]
-//           | spartT[split*4 + wave][4]
 // ---------------------------------------------------------------------------------
 namespace {
 
-template <bool NT>
+// Raw loads of the tiled kernel: like kernel 1A it reads ONE packed pair (w_eff, w_eff b) per row
+// (fsnap_pack_weights_k) instead of mask, b and w, and applies the row mask through the loads (rows with
+// w_eff == 0 get an out-of-range buffer offset: zeros come back, the row is never fetched).
 struct RawT {
     u4 pi[2], pj[2];
-    u2 bv, wv;
-    unsigned char mk;
+    u4 wp;
 };
 
-template <bool DIAG, bool NT>
-__device__ __forceinline__ void issue_chunk_t(RawT<NT>& r, const WaveBufs& wb, unsigned voffI, unsigned voffJ,
-                                              unsigned cl, int kr) {
+struct WaveBufsT {
+    __amdgpu_buffer_rsrc_t A, wp;
+    unsigned voffP;        // kr * 16 (packed weights)
+    unsigned chunk_bytes;  // 4*lda*8
+};
+
+__device__ __forceinline__ u4 load_pack_t(const WaveBufsT& wb, unsigned cl) {
+    return __builtin_amdgcn_raw_buffer_load_b128(wb.wp, wb.voffP, cl * 64u, 0);
+}
+
+template <bool DIAG, int EDGE, bool NT>
+__device__ __forceinline__ void issue_rows_t(RawT& r, const WaveBufsT& wb, unsigned voffI, unsigned voffJ, unsigned cl) {
     const unsigned soff = cl * wb.chunk_bytes;
     constexpr int AUX = NT ? 2 : 0;
-    r.pi[0] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, voffI, soff, AUX);
-    r.pi[1] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, voffI + 256u, soff, AUX);
+    const bool keep = pack_keep(r.wp);
+    const unsigned vi = keep ? voffI : FSNAP_OOB_VOFF;
+    r.pi[0] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, vi, soff, AUX);
+    if (!(DIAG && EDGE == 2)) r.pi[1] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, vi + 256u, soff, AUX);
     if (!DIAG) {
-        r.pj[0] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, voffJ, soff, AUX);
-        r.pj[1] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, voffJ + 256u, soff, AUX);
+        const unsigned vj = keep ? voffJ : FSNAP_OOB_VOFF;
+        r.pj[0] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, vj, soff, AUX);
+        if (EDGE != 2) r.pj[1] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, vj + 256u, soff, AUX);
     }
-    r.bv = __builtin_amdgcn_raw_buffer_load_b64(wb.b, wb.voffR, cl * 32u, 0);
-    r.wv = __builtin_amdgcn_raw_buffer_load_b64(wb.w, wb.voffR, cl * 32u, 0);
-    r.mk = __builtin_amdgcn_raw_buffer_load_b8(wb.mask, (unsigned)kr, cl * 4u, 0);
 }
 
-__device__ __forceinline__ void weight4(double (&v)[4], const u4 (&p)[2], double wv, bool keep, int col0, int K, int e) {
+// MFMA operands of one chunk.  Diagonal pair (I == J): the same registers w a serve both sides.  Off-diagonal
+// pair: the weight goes on ONE side, (w^2 a_I) x a_J -- the J side is used as loaded (no VALU instruction at all;
+// fp64 MFMAs and VALU instructions serialise on the SIMD, the first version of this kernel spent ~40 VALU
+// instructions per 16 MFMAs on per-value weighting and masking and stopped at 57-68 % of the matrix peak).
+// Columns >= K exist only in the last superblock (EDGE): they are zeroed by selects there and nowhere else.
+template <bool DIAG, int EDGE>
+__device__ __forceinline__ void prep_t(double (&vI)[4], double (&vJ)[4], const RawT& r, double wv, int colI0, int colJ0,
+                                       int K, int e) {
+    // EDGE: 0 = every column of both superblocks is < K; 4 = the J superblock (= the I superblock on a diagonal
+    // pair) is the last one and columns >= K are zeroed by selects; 2 = as 4, and its second 32-column group holds
+    // no column < K at all: blocks 2, 3 are neither loaded nor multiplied
+    const double f = DIAG ? wv : wv * wv;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const d2 x = __builtin_bit_cast(d2, p[j]);
-        const bool k0 = keep && (col0 + 32 * j + 2 * e < K);
-        const bool k1 = keep && (col0 + 32 * j + 2 * e + 1 < K);
-        v[2 * j] = k0 ? wv * x[0] : 0.0;
-        v[2 * j + 1] = k1 ? wv * x[1] : 0.0;
+        if (!(DIAG && EDGE == 2 && j == 1)) {
+            const d2 x = __builtin_bit_cast(d2, r.pi[j]);
+            vI[2 * j] = f * x[0];
+            vI[2 * j + 1] = f * x[1];
+            if (DIAG && EDGE) {
+                if (!(colI0 + 32 * j + 2 * e < K)) vI[2 * j] = 0.0;
+                if (!(colI0 + 32 * j + 2 * e + 1 < K)) vI[2 * j + 1] = 0.0;
+            }
+        }
+        if (!DIAG && !(EDGE == 2 && j == 1)) {
+            const d2 y = __builtin_bit_cast(d2, r.pj[j]);
+            vJ[2 * j] = y[0];
+            vJ[2 * j + 1] = y[1];
+            if (EDGE) {
+                if (!(colJ0 + 32 * j + 2 * e < K)) vJ[2 * j] = 0.0;
+                if (!(colJ0 + 32 * j + 2 * e + 1 < K)) vJ[2 * j + 1] = 0.0;
+            }
+        }
     }
 }
 
-template <bool DIAG, bool NT>
+template <bool DIAG, int EDGE, bool NT>
 __device__ __forceinline__ void syrk_tiled_body(const double* __restrict__ A, int64_t lda,
-                                                const double* __restrict__ b, const double* __restrict__ w,
-                                                const unsigned char* __restrict__ mask, int64_t m, int K, int I, int J,
-                                                int64_t c0, int64_t c1, int wv_in_wg, bool do_c, bool do_s,
-                                                double* lds, double* __restrict__ pw, double* __restrict__ cw,
-                                                double* __restrict__ sw) {
+                                                const double* __restrict__ wpack, int64_t m, int K, int I, int J,
+                                                int64_t c0, int64_t c1, int wv_in_wg, double* lds,
+                                                double* __restrict__ pw, double* __restrict__ cw) {
     constexpr int NTW = 16;
     const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
     d4 acc[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
     double cacc[4] = {0.0, 0.0, 0.0, 0.0};
-    double bb = 0.0, sbw = 0.0, cnt = 0.0;
 
     const int64_t row0 = c0 << 2;
     int64_t row1 = c1 << 2;
     if (row1 > m) row1 = m;
     const int64_t nrow = row1 > row0 ? row1 - row0 : 0;
-    WaveBufs wb;
+    WaveBufsT wb;
     wb.A = make_rsrc(A + row0 * lda, (unsigned)(nrow * lda * 8 + (nrow ? 16 : 0)));
-    wb.b = make_rsrc(b + row0, (unsigned)(nrow * 8));
-    wb.w = make_rsrc(w + row0, (unsigned)(nrow * 8));
-    wb.mask = make_rsrc(mask + row0, (unsigned)nrow);
-    wb.voffA = 0;
-    wb.voffT = 0;
-    wb.voffR = (unsigned)(kr * 8);
+    wb.wp = make_rsrc(wpack + 2 * row0, (unsigned)(nrow * 16));
+    wb.voffP = (unsigned)(kr * 16);
     wb.chunk_bytes = (unsigned)(lda * 32);
     const unsigned voffI = (unsigned)((kr * lda + 64 * I + 2 * e) * 8);
     const unsigned voffJ = (unsigned)((kr * lda + 64 * J + 2 * e) * 8);
     const unsigned ncl = (unsigned)(c1 > c0 ? c1 - c0 : 0);
 
-    RawT<NT> r0, r1, r2;
-    double vI[4], vJ[4];
+    RawT r0, r1, r2;
+    double vI[4] = {0.0, 0.0, 0.0, 0.0}, vJ[4] = {0.0, 0.0, 0.0, 0.0};
+    double wbcur = 0.0;
+    constexpr int QMAX = (EDGE == 2) ? 2 : 4;              // 16-column blocks of the J side that hold columns < K
+    constexpr int PMAX = (DIAG && EDGE == 2) ? 2 : 4;
 
-#define FSNAP_STAGE_T(R, OFF)                                                                   \
+    // step c: MFMAs of chunk c (operands prepared one step ago), operands of chunk c + 1 from raw set RN, rows of
+    // chunk c + 3 into the raw set RF consumed one step ago (its packed weights arrived during the last step),
+    // packed weights of chunk c + 4 into RN.  The packed load goes out before the row loads (in-order vmcnt).
+#define FSNAP_STEP_T(RF, RN, CLF)                                                               \
     {                                                                                           \
-        const bool keep = (R.mk != 0);                                                          \
-        const double wgt = __builtin_bit_cast(double, R.wv);                                    \
-        weight4(vI, R.pi, wgt, keep, 64 * I, K, e);                                             \
-        if (!DIAG) weight4(vJ, R.pj, wgt, keep, 64 * J, K, e);                                  \
-        const double wbv = keep ? wgt * __builtin_bit_cast(double, R.bv) : 0.0;                 \
-        const double one = keep ? 1.0 : 0.0;                                                    \
-        issue_chunk_t<DIAG, NT>(R, wb, voffI, voffJ, cl + (OFF) + 3, kr);                       \
-        _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                         \
-            _Pragma("unroll") for (int q = (DIAG ? p : 0); q < 4; ++q) {                        \
+        const d2 wpn = __builtin_bit_cast(d2, RN.wp);                                           \
+        RN.wp = load_pack_t(wb, (CLF) + 1);                                                     \
+        issue_rows_t<DIAG, EDGE, NT>(RF, wb, voffI, voffJ, (CLF));                                    \
+        _Pragma("unroll") for (int p = 0; p < PMAX; ++p) {                                      \
+            _Pragma("unroll") for (int q = (DIAG ? p : 0); q < QMAX; ++q) {                     \
                 acc[p * 4 + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(vI[p], DIAG ? vI[q] : vJ[q], acc[p * 4 + q], 0, 0, 0); \
             }                                                                                   \
         }                                                                                       \
         if (DIAG) {                                                                             \
-            if (do_c) {                                                                         \
-                _Pragma("unroll") for (int p = 0; p < 4; ++p) cacc[p] = __builtin_fma(vI[p], wbv, cacc[p]); \
-            }                                                                                   \
-            if (do_s) {                                                                         \
-                bb = __builtin_fma(wbv, wbv, bb);                                               \
-                sbw += wbv;                                                                     \
-                cnt += one;                                                                     \
-            }                                                                                   \
+            _Pragma("unroll") for (int p = 0; p < PMAX; ++p) cacc[p] = __builtin_fma(vI[p], wbcur, cacc[p]); \
         }                                                                                       \
+        prep_t<DIAG, EDGE>(vI, vJ, RN, wpn[0], 64 * I, 64 * J, K, e);                           \
+        wbcur = wpn[1];                                                                         \
     }
     if (ncl > 0) {
-        issue_chunk_t<DIAG, NT>(r0, wb, voffI, voffJ, 0, kr);
-        issue_chunk_t<DIAG, NT>(r1, wb, voffI, voffJ, 1, kr);
-        issue_chunk_t<DIAG, NT>(r2, wb, voffI, voffJ, 2, kr);
+        r0.wp = load_pack_t(wb, 0);
+        r1.wp = load_pack_t(wb, 1);
+        r2.wp = load_pack_t(wb, 2);
+        issue_rows_t<DIAG, EDGE, NT>(r0, wb, voffI, voffJ, 0);
+        issue_rows_t<DIAG, EDGE, NT>(r1, wb, voffI, voffJ, 1);
+        issue_rows_t<DIAG, EDGE, NT>(r2, wb, voffI, voffJ, 2);
+        {
+            const d2 wp0 = __builtin_bit_cast(d2, r0.wp);
+            prep_t<DIAG, EDGE>(vI, vJ, r0, wp0[0], 64 * I, 64 * J, K, e);
+            wbcur = wp0[1];
+        }
+        r0.wp = load_pack_t(wb, 3);
         for (unsigned cl = 0; cl < ncl; cl += 3) {
-            FSNAP_STAGE_T(r0, 0)
-            FSNAP_STAGE_T(r1, 1)
-            FSNAP_STAGE_T(r2, 2)
+            FSNAP_STEP_T(r0, r1, cl + 3)
+            FSNAP_STEP_T(r1, r2, cl + 4)
+            FSNAP_STEP_T(r2, r0, cl + 5)
         }
     }
-#undef FSNAP_STAGE_T
+#undef FSNAP_STEP_T
 
     // fold the 4 waves through LDS ({2,3} -> {0,1}, 1 -> 0), then one partial per workgroup
     {
@@ -1435,20 +1470,11 @@ __device__ __forceinline__ void syrk_tiled_body(const double* __restrict__ A, in
                 for (int i = 0; i < 4; ++i) pw[(u * 4 + i) * 64 + lane] = acc[u][i] + lds[(u * 4 + i) * 64 + lane];
         }
     }
-    if (DIAG && do_c) {
+    if (DIAG) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             double s = xlane_sum_rows(cacc[p]);
             if (kr == 0) cw[p * 16 + e] = s;
-        }
-    }
-    if (DIAG && do_s) {
-        double sb = xlane_sum_rows(bb), ss = xlane_sum_rows(sbw), sc = xlane_sum_rows(cnt);
-        if (lane == 0) {
-            sw[0] = sb;
-            sw[1] = ss;
-            sw[2] = sc;
-            sw[3] = 0.0;
         }
     }
 }
@@ -1457,13 +1483,10 @@ __device__ __forceinline__ void syrk_tiled_body(const double* __restrict__ A, in
 
 template <bool NT>
 __global__ __launch_bounds__(256, 2) void fsnap_syrk_tiled(const double* __restrict__ A, int64_t lda,
-                                                           const double* __restrict__ b,
-                                                           const double* __restrict__ w,
-                                                           const unsigned char* __restrict__ mask, int64_t m, int K,
+                                                           const double* __restrict__ wpack, int64_t m, int K,
                                                            int NSB, int npairs, int64_t chunks_per_split,
                                                            int nitems, int xcd_map,
-                                                           double* __restrict__ part, double* __restrict__ cpart,
-                                                           double* __restrict__ spart) {
+                                                           double* __restrict__ part, double* __restrict__ cpart) {
     __shared__ double lds[2 * 16 * 256];
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // Work item = (split, pair), pair fastest.  Workgroups are dealt round-robin to the 8 XCDs
@@ -1497,11 +1520,18 @@ __global__ __launch_bounds__(256, 2) void fsnap_syrk_tiled(const double* __restr
     if (c0 > s1) c0 = s1;
     double* pw = part + ((int64_t)split * npairs + pair) * (16 * 256);
     double* cw = cpart + (((int64_t)split * NSB + I) * 4 + wv) * 64;
-    double* sw = spart + ((int64_t)split * 4 + wv) * 4;
+    // columns >= K live in the last superblock only: 4 = all of its 16-column blocks hold columns < K,
+    // 2 = only the first 32-column group does (blocks 2, 3 are empty: their tiles are skipped), 0 = no edge
+    const int tail = K & 63;
+    const int edge = (J == NSB - 1 && tail != 0) ? (tail <= 32 ? 2 : 4) : 0;
     if (I == J) {
-        syrk_tiled_body<true, NT>(A, lda, b, w, mask, m, K, I, J, c0, c1, wv, true, pair == 0, lds, pw, cw, sw);
+        if (edge == 2) syrk_tiled_body<true, 2, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+        else if (edge == 4) syrk_tiled_body<true, 4, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+        else syrk_tiled_body<true, 0, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
     } else {
-        syrk_tiled_body<false, NT>(A, lda, b, w, mask, m, K, I, J, c0, c1, wv, false, false, lds, pw, cw, sw);
+        if (edge == 2) syrk_tiled_body<false, 2, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+        else if (edge == 4) syrk_tiled_body<false, 4, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+        else syrk_tiled_body<false, 0, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
     }
 }
 
@@ -1510,7 +1540,7 @@ __global__ __launch_bounds__(256, 2) void fsnap_syrk_tiled(const double* __restr
 // 4 scalars (nsplit*4 partials each).  1024 threads = 64 elements x 16 partial slices.
 __global__ __launch_bounds__(1024) void fsnap_reduce_tiled(const double* __restrict__ part,
                                                            const double* __restrict__ cpart,
-                                                           const double* __restrict__ spart, int nsplit, int NSB,
+                                                           const double* __restrict__ spart, int ns, int nsplit, int NSB,
                                                            int npairs, int K, double* __restrict__ out, int accumulate) {
     __shared__ double red[1024];
     const int64_t nG = (int64_t)npairs * 4096;
@@ -1531,9 +1561,9 @@ __global__ __launch_bounds__(1024) void fsnap_reduce_tiled(const double* __restr
         stride = 0;  // handled below (two-level layout)
         np = nsplit * 4;
     } else if (idx < nG + nC + nS) {
-        src = spart + (idx - nG - nC);
+        src = spart + (idx - nG - nC);      // per-workgroup partials of fsnap_pack_weights_k
         stride = 4;
-        np = nsplit * 4;
+        np = ns;
     }
     double s = 0.0;
     if (src) {
@@ -1797,18 +1827,18 @@ hipError_t launch_syrk_tiled(const TiledArgs& a, hipStream_t st) {
     const int nitems = (int)((int64_t)a.npairs * a.nsplit);
     dim3 grid((unsigned)(a.xcd_map ? 8 * ((nitems + 7) / 8) : nitems)), block(256);
     if (a.nontemporal)
-        hipLaunchKernelGGL((fsnap_syrk_tiled<true>), grid, block, 0, st, a.A, a.lda, a.b, a.w, a.mask, a.m, a.K, a.NSB,
-                           a.npairs, a.chunks_per_split, nitems, (int)a.xcd_map, a.part, a.cpart, a.spart);
+        hipLaunchKernelGGL((fsnap_syrk_tiled<true>), grid, block, 0, st, a.A, a.lda, a.wpack, a.m, a.K, a.NSB,
+                           a.npairs, a.chunks_per_split, nitems, (int)a.xcd_map, a.part, a.cpart);
     else
-        hipLaunchKernelGGL((fsnap_syrk_tiled<false>), grid, block, 0, st, a.A, a.lda, a.b, a.w, a.mask, a.m, a.K, a.NSB,
-                           a.npairs, a.chunks_per_split, nitems, (int)a.xcd_map, a.part, a.cpart, a.spart);
+        hipLaunchKernelGGL((fsnap_syrk_tiled<false>), grid, block, 0, st, a.A, a.lda, a.wpack, a.m, a.K, a.NSB,
+                           a.npairs, a.chunks_per_split, nitems, (int)a.xcd_map, a.part, a.cpart);
     return hipGetLastError();
 }
 
 hipError_t launch_reduce_tiled(const TiledArgs& a, double* out, bool accumulate, hipStream_t st) {
     const int64_t nelem = (int64_t)a.npairs * 4096 + a.NSB * 64 + 4;
     dim3 grid((unsigned)((nelem + 63) / 64)), block(1024);
-    hipLaunchKernelGGL(fsnap_reduce_tiled, grid, block, 0, st, a.part, a.cpart, a.spart, a.nsplit, a.NSB, a.npairs, a.K,
+    hipLaunchKernelGGL(fsnap_reduce_tiled, grid, block, 0, st, a.part, a.cpart, a.spart, a.ns, a.nsplit, a.NSB, a.npairs, a.K,
                        out, accumulate ? 1 : 0);
     return hipGetLastError();
 }

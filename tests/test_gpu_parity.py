@@ -208,6 +208,27 @@ def test_general_k_tiled_kernel(ctx, K, m):
     stats_close(G, c, s, *orc.normal_eq(A, b, w, t), tol=2e-12)
 
 
+@pytest.mark.parametrize("K", [142, 300, 448])
+def test_tiled_kernel_masked_rows_may_hold_garbage(ctx, K):
+    # the tiled kernel reads packed (w_eff, w_eff b) pairs and masks rows through out-of-range load offsets: NaN / Inf
+    # in A, b and w of test rows must not reach the statistics; K = 142 / 300 / 448: last superblock half empty
+    # (its empty blocks are skipped) / partly filled (selects) / full
+    rng = np.random.default_rng(70 + K)
+    m = 9001
+    A = rng.standard_normal((m, K))
+    b = rng.standard_normal(m)
+    w = rng.uniform(0.5, 2.0, m)
+    t = rng.random(m) < 0.25
+    A2, b2, w2 = A.copy(), b.copy(), w.copy()
+    A2[t] = np.nan
+    b2[t] = np.inf
+    w2[t] = -np.inf
+    G, c, s = run_stats(ctx, A2, b2, w2, t)
+    assert ctx.launch_info()["split"] == 0
+    stats_close(G, c, s, *orc.normal_eq(A, b, w, t), tol=2e-12)
+    assert np.isfinite(G).all() and np.isfinite(c).all() and np.isfinite(s).all()
+
+
 @pytest.mark.parametrize("K", [31, 64, 100, 128])
 def test_tiled_kernel_forced_on_small_k(ctx, K):
     A, b, w = orc.synth_problem(9001, K)
