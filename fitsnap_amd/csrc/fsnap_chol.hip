@@ -245,70 +245,137 @@ __device__ __forceinline__ double rsqrt_newton(double d) {
     return y;
 }
 
-// 8b: ONE wave, lane c holds column c of the 64 x 64 block in 64 registers; the recurrence is fully unrolled, the
-// pivot-row entry U[j][i] reaches all lanes through v_readlane (scalar broadcast): no LDS, no barrier.  Entries
-// below the diagonal are updated along (never read, not written back).  The readlane of the next multiplier is
-// issued before the FMA of the current one and a scheduling barrier closes every (readlane, readlane, fma) group:
-// left alone, the scheduler hoists all 63 broadcasts of a step, runs out of scalar registers and spills them
-// through v_writelane (7 k readlanes, 3 k writelanes and 3.5 k s_nops in the first version of this kernel).
-// Afterwards the four 16 x 16 diagonal sub-blocks are inverted (lane 16 b + cc: column cc of Y_b = U_bb^-1 by
-// back substitution, multipliers from LDS) for the blocked substitution of kernel 8c.
-__global__ __launch_bounds__(64) void fsnap_chol_diag_k(double* __restrict__ S, int ld, int jb, double* __restrict__ Y,
-                                                       int* __restrict__ status, double* __restrict__ minpiv) {
-    __shared__ __attribute__((aligned(16))) double UbT[4][16][16];   // UbT[b][k][r] = U_bb[r][k]
-    __shared__ double rinvL[CHOL_NB];
-    const int c = threadIdx.x;
-    double col[CHOL_NB];
+// 8b: ONE wave factorises the 64 x 64 diagonal block as a 4 x 4 grid of 16 x 16 blocks held in registers in the
+// MFMA accumulator layout (lane (k, e): rows 4r + k, column e of a block).  Per block step a:
+//   * the diagonal block goes through LDS into a column-per-lane layout and is factorised by the 16-step
+//     recurrence (pivot row entries broadcast with v_readlane; v_rsq_f64 + Newton instead of IEEE sqrt / divide),
+//     then inverted by back substitution in the same layout (Y_a = U_aa^-1, needed by kernels 8c and 8e);
+//   * U_ab = Y_a^T S_ab for the blocks right of it and S_bc -= U_ab^T U_ac for the blocks below: MFMAs whose operands
+//     are the accumulator registers themselves (the layout of a D tile is the layout of the B operand of k-step r
+//     and, transposed, of the A operand).
+// The scalar recurrence over all 64 columns (2016 broadcast + FMA groups, 9.7 k instructions, 22 us per block) was
+// half of the whole device solve; here 4 x 120 groups remain and the rest is 64 MFMAs.
+// The next multiplier is read before the FMA of the current one and a scheduling barrier closes every (readlane,
+// readlane, fma) group: left alone, the scheduler hoists all broadcasts of a step, runs out of scalar registers and
+// spills them through v_writelane.
+template <int a>
+__device__ __forceinline__ void chol_diag_step(d4 (&B)[4][4], double (*T)[17], double (*UT)[16], double* __restrict__ S,
+                                               int ld, int jb, double* __restrict__ Y, int e, int kr, double& pmin,
+                                               double& psum) {
+    // diagonal block -> column e in every lane (the four lane groups hold identical copies)
+    __syncthreads();
 #pragma unroll
-    for (int r = 0; r < CHOL_NB; ++r) col[r] = S[(size_t)(jb + r) * ld + jb + c];
-    double pmin = 1.0e300, myinv = 0.0;
-    bool bad = false;
+    for (int r = 0; r < 4; ++r) T[4 * r + kr][e] = B[a][a][r];
+    __syncthreads();
+    double col[16], rinv[16];
 #pragma unroll
-    for (int j = 0; j < CHOL_NB; ++j) {
+    for (int r = 0; r < 16; ++r) col[r] = T[r][e];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
         const double d = readlane_f64(col[j], j);          // pivot (the same value in every lane)
-        bad = bad || !(d > 0.0) || !__builtin_isfinite(d);
-        pmin = d < pmin ? d : pmin;
-        const double inv = rsqrt_newton(d), r = d * inv;
-        col[j] = (c == j) ? r : col[j] * inv;
-        myinv = (c == j) ? inv : myinv;
-        if (j + 1 < CHOL_NB) {
+        pmin = d < pmin ? d : pmin;                        // (a NaN pivot is caught by the sum)
+        psum += d;
+        const double inv = rsqrt_newton(d);
+        rinv[j] = inv;
+        col[j] = (e == j) ? d * inv : col[j] * inv;
+        if (j + 1 < 16) {
             double f = readlane_f64(col[j], j + 1);
 #pragma unroll
-            for (int i = j + 1; i < CHOL_NB; ++i) {
-                const double fn = (i + 1 < CHOL_NB) ? readlane_f64(col[j], i + 1) : 0.0;
-                col[i] = __builtin_fma(-f, col[j], col[i]);    // B[i][c] -= U[j][i] * U[j][c]
+            for (int i = j + 1; i < 16; ++i) {
+                const double fn = (i + 1 < 16) ? readlane_f64(col[j], i + 1) : 0.0;
+                col[i] = __builtin_fma(-f, col[j], col[i]);    // S[i][e] -= U[j][i] * U[j][e]
                 __builtin_amdgcn_sched_barrier(0);
                 f = fn;
             }
         }
     }
-    if (bad) {
-        if (c == 0) atomicOr(status, 2);
-        return;
+    if (kr == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (e >= r) S[(size_t)(jb + 16 * a + r) * ld + jb + 16 * a + e] = col[r];
+            UT[e][r] = col[r];                              // UT[k][r] = U[r][k]: the multipliers of step k, contiguous
+        }
     }
-#pragma unroll
-    for (int r = 0; r < CHOL_NB; ++r)
-        if (c >= r) S[(size_t)(jb + r) * ld + jb + c] = col[r];
-    if (c == 0) minpiv[jb / CHOL_NB] = pmin;
-    // diagonal sub-blocks to LDS (transposed), reciprocal diagonal
-    const int b = c >> 4, cc = c & 15;
-#pragma unroll
-    for (int r = 0; r < CHOL_NB; ++r)
-        if ((r >> 4) == b) UbT[b][cc][r & 15] = col[r];
-    rinvL[c] = myinv;
     __syncthreads();
-    double y[16];
+    // Y_a = U_aa^-1: lane e solves U y = e_e by back substitution.  The multipliers U[0..k-1][k] of step k are the
+    // same for every lane and do not depend on y: they are read from LDS one step ahead.
+    double y[16], mcur[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) y[r] = 0.0;
 #pragma unroll
+    for (int r = 0; r < 15; ++r) mcur[r] = UT[15][r];
+#pragma unroll
     for (int k = 15; k >= 0; --k) {
-        const double yk = ((k == cc) ? 1.0 : y[k]) * rinvL[16 * b + k];
+        double mnext[16];
+#pragma unroll
+        for (int r = 0; r + 1 < k; ++r) mnext[r] = UT[k - 1][r];
+        const double yk = ((k == e) ? 1.0 : y[k]) * rinv[k];
         y[k] = yk;
 #pragma unroll
-        for (int r = 0; r < k; ++r) y[r] = __builtin_fma(-UbT[b][k][r], yk, y[r]);
+        for (int r = 0; r < k; ++r) y[r] = __builtin_fma(-mcur[r], yk, y[r]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r + 1 < k; ++r) mcur[r] = mnext[r];
+    }
+    if (kr == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Y[(a * 16 + r) * 16 + e] = y[r];
+    }
+    if constexpr (a < 3) {
+        // A operand of the substitution: (Y_a^T)[e][4 s + kr] = Y_a[4 s + kr][e], through LDS
+        if (kr == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[r][e] = y[r];
+        }
+        __syncthreads();
+        double yt[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) yt[s] = T[4 * s + kr][e];
+#pragma unroll
+        for (int b = a + 1; b < 4; ++b) {
+            d4 u = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) u = __builtin_amdgcn_mfma_f64_16x16x4f64(yt[s], B[a][b][s], u, 0, 0, 0);
+            B[a][b] = u;
+        }
+#pragma unroll
+        for (int b = a + 1; b < 4; ++b)
+#pragma unroll
+            for (int c = b; c < 4; ++c)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    B[b][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(-B[a][b][s], B[a][c][s], B[b][c], 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(64) void fsnap_chol_diag_k(double* __restrict__ S, int ld, int jb, double* __restrict__ Y,
+                                                       int* __restrict__ status, double* __restrict__ minpiv) {
+    __shared__ double T[16][17];
+    __shared__ __attribute__((aligned(16))) double UT[16][16];
+    const int lane = threadIdx.x, e = lane & 15, kr = lane >> 4;
+    d4 B[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) B[a][b][r] = S[(size_t)(jb + 16 * a + 4 * r + kr) * ld + jb + 16 * b + e];
+    double pmin = 1.0e300, psum = 0.0;
+    chol_diag_step<0>(B, T, UT, S, ld, jb, Y, e, kr, pmin, psum);
+    chol_diag_step<1>(B, T, UT, S, ld, jb, Y, e, kr, pmin, psum);
+    chol_diag_step<2>(B, T, UT, S, ld, jb, Y, e, kr, pmin, psum);
+    chol_diag_step<3>(B, T, UT, S, ld, jb, Y, e, kr, pmin, psum);
+    if (!(pmin > 0.0) || !__builtin_isfinite(psum)) {      // non-positive, NaN or infinite pivot
+        if (lane == 0) atomicOr(status, 2);
+        return;
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Y[(b * 16 + r) * 16 + cc] = y[r];
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a + 1; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(size_t)(jb + 16 * a + 4 * r + kr) * ld + jb + 16 * b + e] = B[a][b][r];
+    if (lane == 0) minpiv[jb / CHOL_NB] = pmin;
 }
 
 // 8c: blocked forward substitution on the matrix pipe.  One wave per 16-column strip of the columns right of the
