@@ -243,6 +243,8 @@ def main():
                 traffic = None
         if info["split"] == 0:
             kernel_name = "fsnap_syrk_tiled"
+        elif info["kernel_or_pairs"] == 4:
+            kernel_name = f"fsnap_syrk_wave_p<{info['NB']}>"
         elif info["kernel_or_pairs"] == 3:
             kernel_name = f"fsnap_syrk_acc<{info['NB']}>"
         elif info["kernel_or_pairs"] == 2:

@@ -134,6 +134,7 @@ struct Geometry {
     int NB;
     int lds_waves;  // 0 = kernel 1 (wave-triangle); 8 / 16 = kernel 1L (LDS-shared) with that many waves
     bool acc;       // kernel 1A: whole triangle in one wave (accumulation registers), one wave per SIMD
+    bool packed;    // kernel 1P: kernel 1 on packed weights (K <= 80)
 };
 
 int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
@@ -143,6 +144,7 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
     g->lds_waves = 0;
     const int64_t off_limit = (int64_t)0xFFF00000;  // 32-bit buffer offsets, 1 MiB of slack for prefetch overshoot
     g->acc = false;
+    g->packed = false;
     if (g->NB >= 6 && (ctx->opt_kernel == 7 || ctx->opt_kernel == 0)) {
         // kernel 1A: one 4-wave workgroup per CU, every wave streams its own rows and owns the whole triangle
         const int64_t nchunks = (m + 3) / 4;
@@ -187,6 +189,10 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
     }
     int split = ctx->opt_split ? ctx->opt_split : fsnap::syrk_default_split(K);
     if (split == 2 && g->NB < 6) split = 1;
+    if (g->NB < 6 && ctx->opt_kernel == 0) {
+        g->packed = true;   // kernel 1P (option kernel = 1 keeps kernel 1 with separate mask / b / w loads for A/B)
+        split = 1;
+    }
     if (split == 1 && g->NB > 6) split = 2;
     g->split = split;
     g->threads = 256 * split;
@@ -436,7 +442,7 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
     a.spart = (double*)ctx->spart.p;
     int ns = -1;                      // scalar partials: from the SYRK kernel, or (kernel 1A) from the weight packing
     const double* spart_src = a.spart;
-    if (g.acc) {
+    if (g.acc || g.packed) {
         int npk = 0;
         if ((rc = ensure_wpack(ctx, &npk))) return rc;
         a.wpack = (const double*)ctx->wpack.p;
@@ -447,6 +453,7 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
     if ((rc = fit_events(ctx, &evs))) return rc;
     FSNAP_HIP(hipEventRecord(evs[0], ctx->stream), "hipEventRecord");
     if (g.acc) FSNAP_HIP(fsnap::launch_syrk_acc(a, ctx->stream), "launch fsnap_syrk_acc");
+    else if (g.packed) FSNAP_HIP(fsnap::launch_syrk_wave_p(a, ctx->stream), "launch fsnap_syrk_wave_p");
     else if (g.lds_waves) FSNAP_HIP(fsnap::launch_syrk_lds(a, ctx->stream), "launch fsnap_syrk_lds");
     else FSNAP_HIP(fsnap::launch_syrk(a, ctx->stream), "launch fsnap_syrk_wave");
     FSNAP_HIP(hipEventRecord(evs[1], ctx->stream), "hipEventRecord");
@@ -1209,7 +1216,7 @@ int fsnap_launch_info(fsnap_ctx* ctx, int64_t* info, int n) {
         out[2] = g.cpw;
         out[3] = g.NB;
         out[4] = g.split;
-        out[6] = g.acc ? 3 : (g.lds_waves ? 2 : 1);  // kernel id: 1 = wave-triangle, 2 = LDS-shared, 3 = one-wave triangle (1A)
+        out[6] = g.acc ? 3 : (g.packed ? 4 : (g.lds_waves ? 2 : 1));  // kernel id: 1 = wave-triangle, 2 = LDS-shared, 3 = one-wave triangle (1A), 4 = wave-triangle on packed weights (1P)
     }
     for (int i = 0; i < n; ++i) info[i] = out[i];
     return FSNAP_OK;

@@ -48,6 +48,7 @@ int syrk_num_blocks(int K);
 int syrk_default_split(int K);
 int syrk_waves_per_simd(int K, int split);
 hipError_t launch_syrk(const SyrkArgs& a, hipStream_t st);
+hipError_t launch_syrk_wave_p(const SyrkArgs& a, hipStream_t st);   // K <= 80, packed weights (a.wpack)
 hipError_t launch_syrk_lds(const SyrkArgs& a, hipStream_t st);
 hipError_t launch_syrk_acc(const SyrkArgs& a, hipStream_t st);
 // mirror: optional page-locked HOST buffer that receives the same packed statistics (zero-copy D2H)

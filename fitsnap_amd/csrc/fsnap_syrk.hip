@@ -24,6 +24,7 @@
 //                              shared through LDS in MFMA-fragment order; per-wave specialised bodies
 //                              (the default before kernel 1A; option kernel = 2).
 //       fsnap_syrk_lds         generic tile-table variant of 1L (A/B)
+//   1P  fsnap_syrk_wave_p      K <= 80 (default): kernel 1 on packed weights, rows masked by the loads
 //   1T  fsnap_syrk_tiled       general K > 128: 64-column superblock pairs x row splits
 //   2   fsnap_reduce_partials / fsnap_reduce_tiled   deterministic fixed-order reduction of the
 //                              per-workgroup partial triangles -> packed [G | c | scalars];
@@ -673,6 +674,134 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
 #ifdef FSNAP_TRACE
     if (threadIdx.x == 0 && blockIdx.x < 4096) fsnap_trace_buf[blockIdx.x * 8 + 5] = wall_clock64();   // after the epilogue
 #endif
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 1P: kernel 1 (one wave = whole triangle in compiler-allocated registers, K <= 80: at most 15 tiles) on the
+// packed weights of kernel 1A: one 16-byte (w_eff, w_eff b) pair per row instead of mask, b and w, the row mask
+// applied by the loads (out-of-range offset for rows with w_eff == 0), the b-only scalars from the packing kernel.
+// These shapes are HBM-bound or co-bound (K = 64: the MFMAs of a 2 KiB chunk take as long as its bytes at ~8 TB/s),
+// and every VALU instruction still costs matrix-pipe time: ~14 instead of ~35 per chunk at K = 64.  Several waves
+// per SIMD (compiler-scheduled code, no hand placement): the waves cover each other's load latency.
+// Partial layout = kernel 1 / 1A: part[workgroup][NT][4][64] | cpart[rowwave][NB][16].
+// ---------------------------------------------------------------------------------
+template <int NB, bool FULLK, bool NT>
+__global__ __launch_bounds__(256, 2) void fsnap_syrk_wave_p(const double* __restrict__ A, int64_t lda,
+                                                            const double* __restrict__ wpack, int64_t m, int K,
+                                                            int64_t chunks_per_wave, double* __restrict__ part,
+                                                            double* __restrict__ cpart) {
+    constexpr int NTILE = NB * (NB + 1) / 2;
+    __shared__ double lds[2 * NTILE * 256];
+    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
+    const int rw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t rowwave = (int64_t)blockIdx.x * 4 + rw;
+    const int64_t nchunks = (m + 3) >> 2;
+    int64_t c0 = rowwave * chunks_per_wave;
+    int64_t c1 = c0 + chunks_per_wave;
+    if (c1 > nchunks) c1 = nchunks;
+    if (c0 > c1) c0 = c1;
+    const int64_t row0 = c0 << 2;
+    int64_t row1 = c1 << 2;
+    if (row1 > m) row1 = m;
+    const int64_t nrow = row1 > row0 ? row1 - row0 : 0;
+    WaveBufsP wb;
+    wb.A = make_rsrc(A + row0 * lda, (unsigned)(nrow * lda * 8 + (nrow ? 16 : 0)));
+    wb.wp = make_rsrc(wpack + 2 * row0, (unsigned)(nrow * 16));
+    wb.voffA = (unsigned)((kr * lda + 2 * e) * 8);
+    wb.voffT = (unsigned)((kr * lda + 16 * (NB - 1) + e) * 8);
+    wb.voffP = (unsigned)(kr * 16);
+    wb.chunk_bytes = (unsigned)(lda * 32);
+    const unsigned ncl = (unsigned)(c1 - c0);
+
+    d4 acc[NTILE];
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+    double cacc[NB], V[NB];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+        cacc[p] = 0.0;
+        V[p] = 0.0;
+    }
+    double wbcur = 0.0;
+    RawM<NB> r0, r1, r2;
+    // step c: MFMAs of chunk c (operands V prepared one step ago), V <- chunk c + 1 (raw set RN), rows of chunk c + 3
+    // into the raw set RF consumed one step ago (its packed weights arrived during the last step), packed weights of
+    // chunk c + 4 into RN.  Chunk slots past the wave's range read zeros (bounds-checked descriptors).
+#define FSNAP_STEP_P(RF, RN, CLF)                                                                \
+    {                                                                                            \
+        const d2 wpn = __builtin_bit_cast(d2, RN.wp);                                            \
+        RN.wp = load_pack(wb, (CLF) + 1);                                                        \
+        issue_rows<NB, NT>(RF, wb, (CLF));                                                       \
+        _Pragma("unroll") for (int p = 0; p < NB; ++p) {                                         \
+            _Pragma("unroll") for (int q = p; q < NB; ++q) {                                     \
+                acc[tri_index(p, q, NB)] =                                                       \
+                    __builtin_amdgcn_mfma_f64_16x16x4f64(V[p], V[q], acc[tri_index(p, q, NB)], 0, 0, 0); \
+            }                                                                                    \
+        }                                                                                        \
+        _Pragma("unroll") for (int p = 0; p < NB; ++p) cacc[p] = __builtin_fma(V[p], wbcur, cacc[p]); \
+        _Pragma("unroll") for (int p = 0; p < NB; ++p) V[p] = weighted_block<NB, FULLK>(RN, p, wpn[0], K, e); \
+        wbcur = wpn[1];                                                                          \
+    }
+    if (ncl > 0) {
+        r0.wp = load_pack(wb, 0);
+        r1.wp = load_pack(wb, 1);
+        r2.wp = load_pack(wb, 2);
+        issue_rows<NB, NT>(r0, wb, 0);
+        issue_rows<NB, NT>(r1, wb, 1);
+        issue_rows<NB, NT>(r2, wb, 2);
+        {
+            const d2 wp0 = __builtin_bit_cast(d2, r0.wp);
+#pragma unroll
+            for (int p = 0; p < NB; ++p) V[p] = weighted_block<NB, FULLK>(r0, p, wp0[0], K, e);
+            wbcur = wp0[1];
+        }
+        r0.wp = load_pack(wb, 3);
+        for (unsigned cl = 0; cl < ncl; cl += 3) {
+            FSNAP_STEP_P(r0, r1, cl + 3)
+            FSNAP_STEP_P(r1, r2, cl + 4)
+            FSNAP_STEP_P(r2, r0, cl + 5)
+        }
+    }
+#undef FSNAP_STEP_P
+
+    // fold the four row-waves through LDS ({2,3} -> {0,1}, then 1 -> 0): one partial triangle per workgroup
+    {
+        double* slot_hi = lds + (size_t)((rw & 1) * NTILE) * 256;
+        if (rw >= 2) {
+#pragma unroll
+            for (int u = 0; u < NTILE; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) slot_hi[(u * 4 + i) * 64 + lane] = acc[u][i];
+        }
+        __syncthreads();
+        if (rw < 2) {
+#pragma unroll
+            for (int u = 0; u < NTILE; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[u][i] += slot_hi[(u * 4 + i) * 64 + lane];
+        }
+        __syncthreads();
+        if (rw == 1) {
+#pragma unroll
+            for (int u = 0; u < NTILE; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lds[(u * 4 + i) * 64 + lane] = acc[u][i];
+        }
+        __syncthreads();
+        if (rw == 0) {
+            double* pw = part + (int64_t)blockIdx.x * (int64_t)(NTILE * 256);
+#pragma unroll
+            for (int u = 0; u < NTILE; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pw[(u * 4 + i) * 64 + lane] = acc[u][i] + lds[(u * 4 + i) * 64 + lane];
+        }
+    }
+    double* cw = cpart + rowwave * (int64_t)(NB * 16);
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+        double sm = xlane_sum_rows(cacc[p]);
+        if (kr == 0) cw[p * 16 + e] = sm;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -1779,6 +1908,37 @@ static hipError_t launch_syrk_acc_nb(const SyrkArgs& a, hipStream_t st) {
     }
 #undef FSNAP_LAUNCH
     return hipGetLastError();
+}
+
+template <int NB>
+static hipError_t launch_syrk_wave_p_nb(const SyrkArgs& a, hipStream_t st) {
+    dim3 grid((unsigned)a.nblocks), block(256);
+    const bool fullk = (a.K == 16 * NB);
+    if (!a.wpack) return hipErrorInvalidValue;
+#define FSNAP_LAUNCH(FK, NTL)                                                                                       \
+    hipLaunchKernelGGL((fsnap_syrk_wave_p<NB, FK, NTL>), grid, block, 0, st, a.A, a.lda, a.wpack, a.m, a.K,         \
+                       a.chunks_per_wave, a.part, a.cpart)
+    if (fullk) {
+        if (a.nontemporal) FSNAP_LAUNCH(true, true);
+        else FSNAP_LAUNCH(true, false);
+    } else {
+        if (a.nontemporal) FSNAP_LAUNCH(false, true);
+        else FSNAP_LAUNCH(false, false);
+    }
+#undef FSNAP_LAUNCH
+    return hipGetLastError();
+}
+
+// kernel 1P (K <= 80): a.nblocks workgroups of 4 row-waves, a.chunks_per_wave chunks per row-wave
+hipError_t launch_syrk_wave_p(const SyrkArgs& a, hipStream_t st) {
+    switch (syrk_num_blocks(a.K)) {
+        case 1: return launch_syrk_wave_p_nb<1>(a, st);
+        case 2: return launch_syrk_wave_p_nb<2>(a, st);
+        case 3: return launch_syrk_wave_p_nb<3>(a, st);
+        case 4: return launch_syrk_wave_p_nb<4>(a, st);
+        case 5: return launch_syrk_wave_p_nb<5>(a, st);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 // kernel 1A: a.nblocks workgroups of 4 row-waves, a.chunks_per_wave chunks per row-wave
