@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--cols", type=int, default=K)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-solve", action="store_true", help="D2H via torch + fsnap_solve on the host (A/B)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="diagnostics: run the multi-GPU step (dedicated stream, RCCL all-reduce, solve from HBM) in a "
+                         "process group of ONE rank, to measure its fixed overhead against the single-GPU step")
     ap.add_argument("--option", action="append", default=[], help="kernel option key=value (split, nontemporal, nblocks)")
     return ap.parse_args()
 
@@ -94,6 +97,11 @@ def cpu_baseline(A, b, w, beta_gpu):
 
 def main():
     args = parse()
+    # exactly ONE line on stdout: libraries underneath (RCCL prints a version banner through C stdio, which surfaces
+    # at exit, after everything Python printed) get stderr as their fd 1; the JSON line goes to the real stdout
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -110,9 +118,11 @@ def main():
         raise SystemExit("bench.py needs a gfx950 GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     m, Kc = args.rows, args.cols
     A, b, w = orc.synth_problem(m, Kc, row_offset=rank * RANK_ROW_STRIDE)
@@ -128,7 +138,7 @@ def main():
     n = Kc * Kc + Kc + 3
     packed = torch.zeros(n, dtype=torch.float64, device=dev)
     host = torch.zeros(n, dtype=torch.float64).pin_memory()
-    if world > 1:
+    if multi:
         # kernels and the RCCL all-reduce share ONE non-default stream (the legacy default stream synchronises
         # implicitly with every other stream and costs several microseconds per launch)
         stream = torch.cuda.Stream(dev)
@@ -142,7 +152,7 @@ def main():
 
     def step():
         t0 = time.perf_counter()
-        if world == 1 and not args.host_solve:
+        if not multi and not args.host_solve:
             # the Solver classes' single-GPU path: statistics into a context-owned buffer + solve, one library call
             beta, _, _, _ = ctx.fit_resident(_capi.SOLVE_RIDGE, ALPHA)
             t1 = time.perf_counter()
@@ -151,7 +161,7 @@ def main():
         else:
             ptr = packed.data_ptr()
             ctx.normal_eq_async(ptr)
-            if world > 1:
+            if multi:
                 dist.all_reduce(packed)                   # RCCL over xGMI, same stream
         t1 = time.perf_counter()
         beta = None
@@ -179,7 +189,7 @@ def main():
         return beta
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -201,7 +211,7 @@ def main():
     nh = min(args.steps, 256)
     syrk_hist, red_hist = ctx.timing_history(nh)
     syrk_ms, red_ms = list(syrk_hist), list(red_hist)
-    if world > 1:
+    if multi:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -289,9 +299,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(A, b, w, beta)
-        print(json.dumps(out), flush=True)
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     ctx.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
