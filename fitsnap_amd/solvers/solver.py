@@ -47,6 +47,8 @@ class Solver:
         self._df_parts = None
         self._cat_cache = None       # (key, category ids, group keys) of the last error_analysis row labelling
         self._cat_ctx = None         # context that holds those category ids on the device
+        self._err_layout = None      # (group keys, index, source rows, weighting flags) of the last errors table
+        self._all_idx = None         # (group keys, [(sub key, member indices)]) of the last *ALL merge
         self._mask_cache = None      # (key, training mask) of the last fs_dict['Testing'] list (keep_resident only)
         self.linear = linear
         self.cov = None
@@ -120,16 +122,27 @@ class Solver:
         if len(training) != m:
             raise IndexError("boolean index did not match indexed array along axis 0; size of axis is "
                              f"{m} but size of corresponding boolean axis is {len(training)}")
-        ntrain = int(training.sum())
+        # a cached mask (re-weighting loop) carries its row indices and uint8 form along
+        aux = self._mask_cache[2] if (self._mask_cache is not None and len(self._mask_cache) > 2
+                                      and self._mask_cache[1] is training) else None
+        if aux is None:
+            aux = (np.flatnonzero(training), training.astype(np.uint8))
+            if self._mask_cache is not None and self._mask_cache[1] is training:
+                self._mask_cache = (self._mask_cache[0], training, aux)
+        idx, mask_u8 = aux
+        ntrain = idx.shape[0]
         # reference: aw = w[:, None] * a[training]  (numpy broadcasting on the row axis)
         if w.ndim == 0 or w.shape[0] == 1:
             w_full = np.full(m, float(w.reshape(-1)[0]))
         elif w.shape[0] == ntrain:
-            w_full = np.zeros(m)
-            w_full[training] = w
+            if ntrain == m:
+                w_full = w
+            else:
+                w_full = np.zeros(m)
+                w_full[idx] = w
         else:
             raise ValueError(f"operands could not be broadcast together with shapes ({w.shape[0]},1) ({ntrain},{a.shape[1]}) ")
-        return a, b, w_full, training.astype(np.uint8), False
+        return a, b, w_full, mask_u8, False
 
     # ------------------------------------------------------------------------------
     # the hot path
@@ -409,10 +422,12 @@ class Solver:
                             index=MultiIndex.from_tuples(keys, names=["Groups", "Testing", "Row_Type"]))
         # *ALL rows: merge the groups of one (Testing, Row_Type); centred sums are re-centred on the pooled mean:
         # sum (x - M)^2 = sum_c [ S_c + 2 (mu_c - M) (sum x_c - n_c mu_c) + n_c (mu_c - M)^2 ]
-        sub = sorted({(k[1], k[2]) for k in keys})
+        if self._all_idx is None or self._all_idx[0] is not keys:
+            subs = sorted({(k[1], k[2]) for k in keys})
+            self._all_idx = (keys, [(tk, np.array([i for i, k in enumerate(keys) if (k[1], k[2]) == tk])) for tk in subs])
+        sub = [tk for tk, _ in self._all_idx[1]]
         rows = {name: [] for name in ("ncount", "mae", "rmse", "rsq", "w_ncount", "w_mae", "w_rmse", "w_rsq")}
-        for tk in sub:
-            idx = np.array([i for i, k in enumerate(keys) if (k[1], k[2]) == tk])
+        for tk, idx in self._all_idx[1]:
             N, NW = n[idx].sum(), nw[idx].sum()
             with np.errstate(divide="ignore", invalid="ignore"):
                 mu_c, M = s_t[idx] / n[idx], s_t[idx].sum() / N
@@ -470,6 +485,51 @@ class Solver:
         self._cat_cache = (key, cat, keys)
         return cat, keys, True
 
+    def _assemble_errors(self, grouped, allrows, layout_key=None):
+        """The reference's errors table (solver.py:391-429) from the per-group and *ALL metric tables (8 columns each:
+        unweighted and weighted ncount / mae / rmse / rsq).  The pandas reshaping (two concats, level reordering,
+        sorting, relabelling) costs ~3 ms and depends only on the group keys: with ``layout_key`` (the key list of a
+        re-weighting loop, compared by identity) the row order is derived once -- by pushing row tags through the very
+        same pandas pipeline -- and later tables are filled by one numpy gather."""
+        from pandas import DataFrame, concat
+
+        names = ["ncount", "mae", "rmse", "rsq"]
+        cols = [names, ["w_ncount", "w_mae", "w_rmse", "w_rsq"]]
+        ren = dict(zip(cols[1], names))
+
+        def pipeline(g, a):
+            g = concat({"Unweighted": g[cols[0]], "weighted": g[cols[1]].rename(columns=ren)},
+                       names=["Weighting"]).reorder_levels(["Groups", "Weighting", "Testing", "Row_Type"]).sort_index()
+            a = concat({"Unweighted": a[cols[0]], "weighted": a[cols[1]].rename(columns=ren)},
+                       names=["Weighting"]).reorder_levels(["Weighting", "Testing", "Row_Type"]).sort_index()
+            e = concat([concat({"*ALL": a}, names=["Groups"]), g])
+            e.index.rename(["Group", "Weighting", "Testing", "Subsystem"], inplace=True)
+            e.index = e.index.set_levels(["Testing" if t else "Training" for t in e.index.levels[2]], level=2)
+            return e
+
+        if layout_key is not None:
+            lay = self._err_layout
+            if lay is None or lay[0] is not layout_key or lay[4] != (len(allrows), len(grouped)):
+                # tags: source row (the *ALL rows first) in the unweighted columns, -(source row) - 1 in the weighted ones
+                na, ng = len(allrows), len(grouped)
+                ta = DataFrame({c: (np.arange(na) if c in names else -np.arange(na) - 1) for c in cols[0] + cols[1]},
+                               index=allrows.index, dtype=np.int64)
+                tg = DataFrame({c: (np.arange(ng) + na if c in names else -(np.arange(ng) + na) - 1) for c in cols[0] + cols[1]},
+                               index=grouped.index, dtype=np.int64)
+                tagged = pipeline(tg, ta)
+                tag = tagged["ncount"].to_numpy()
+                weighted = tag < 0
+                src = np.where(weighted, -tag - 1, tag)
+                lay = self._err_layout = (layout_key, tagged.index, src, weighted, (na, ng))
+            vals = np.vstack([allrows[cols[0] + cols[1]].to_numpy(dtype=np.float64),
+                              grouped[cols[0] + cols[1]].to_numpy(dtype=np.float64)])[lay[2]]
+            out = np.where(lay[3][:, None], vals[:, 4:], vals[:, :4])
+            errors = DataFrame(out, index=lay[1], columns=names)
+        else:
+            errors = pipeline(grouped, allrows)
+        errors.ncount = errors.ncount.astype(int)
+        return errors
+
     def predict_rows(self, a=None, b=None):
         """``preds = a @ self.fit`` (solver.py:377) on the GPU (streaming GEMV kernel)."""
         if a is None:
@@ -487,7 +547,7 @@ class Solver:
         """Linear part of the reference's error analysis (solver.py:368-435): per
         (group, train/test, row type) weighted and unweighted count / MAE / RMSE / R^2,
         then the bzeroflag offset.  Predictions come from the GPU GEMV kernel."""
-        from pandas import DataFrame, concat
+        from pandas import DataFrame
 
         self.errors = []
         pt = self.pt
@@ -536,8 +596,6 @@ class Solver:
             self.df.to_pickle(self.config.sections["EXTRAS"].dataframe_file)
         if self.fit is not None and not self.config.sections["SOLVER"].true_multinode:
             fn = self._ncount_mae_rmse_rsq_unweighted_and_weighted
-            cols = [["ncount", "mae", "rmse", "rsq"], ["w_ncount", "w_mae", "w_rmse", "w_rsq"]]
-            ren = {"w_ncount": "ncount", "w_mae": "mae", "w_rmse": "rmse", "w_rsq": "rsq"}
             if not multi and self.device_error_stats:
                 # single GPU: the rows are resident -- predictions and the grouped reductions run on the GPU
                 # (fsnap_error_stats); only the (groups x 10) table of sums comes back
@@ -545,17 +603,10 @@ class Solver:
             else:
                 grouped = self.df.groupby(["Groups", "Testing", "Row_Type"])[["truths", "preds", "weights"]].apply(fn)
                 allrows = None
-            grouped = concat({"Unweighted": grouped[cols[0]], "weighted": grouped[cols[1]].rename(columns=ren)},
-                             names=["Weighting"]).reorder_levels(["Groups", "Weighting", "Testing", "Row_Type"]).sort_index()
             if allrows is None:
                 allrows = self.df.groupby(["Testing", "Row_Type"])[["truths", "preds", "weights"]].apply(fn)
-            allrows = concat({"Unweighted": allrows[cols[0]], "weighted": allrows[cols[1]].rename(columns=ren)},
-                             names=["Weighting"]).reorder_levels(["Weighting", "Testing", "Row_Type"]).sort_index()
-            self.errors = concat([concat({"*ALL": allrows}, names=["Groups"]), grouped])
-            self.errors.ncount = self.errors.ncount.astype(int)
-            self.errors.index.rename(["Group", "Weighting", "Testing", "Subsystem"], inplace=True)
-            self.errors.index = self.errors.index.set_levels(
-                ["Testing" if e else "Training" for e in self.errors.index.levels[2]], level=2)
+            layout_key = self._cat_cache[2] if (not multi and self.device_error_stats and self._cat_cache is not None) else None
+            self.errors = self._assemble_errors(grouped, allrows, layout_key)
         if self.fit is not None:
             if (self.config.sections["CALCULATOR"].calculator == "LAMMPSSNAP"
                     and "BISPECTRUM" in self.config.sections and self.config.sections["BISPECTRUM"].bzeroflag):

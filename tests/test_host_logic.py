@@ -128,3 +128,40 @@ def test_offset_inserts_zero_b0():
     s.fit = np.arange(1.0, 2 * n + 1)
     s._offset()
     assert s.fit.shape == (2 * (n + 1), 1) and s.fit[0, 0] == 0 and s.fit[n + 1, 0] == 0
+
+
+def test_cached_errors_table_layout_equals_the_pandas_pipeline():
+    # Solver._assemble_errors: in a re-weighting loop the row order of the errors table (solver.py:391-429) is derived
+    # once per key list and later tables are filled by a numpy gather -- same table as the full pandas reshaping
+    from pandas import DataFrame, MultiIndex
+    from pandas.testing import assert_frame_equal
+
+    pt, cfg, s = make("RIDGE")
+    rng = np.random.default_rng(12)
+    keys = sorted({(f"g{g}", bool(t), rt) for g in range(7) for t in (False, True) for rt in ("Energy", "Force", "Stress")
+                   if rng.random() < 0.8})
+    sub = sorted({(k[1], k[2]) for k in keys})
+    cols = ["ncount", "mae", "rmse", "rsq", "w_ncount", "w_mae", "w_rmse", "w_rsq"]
+
+    def tables():
+        g = DataFrame(rng.random((len(keys), 8)) * 10, columns=cols,
+                      index=MultiIndex.from_tuples(keys, names=["Groups", "Testing", "Row_Type"]))
+        a = DataFrame(rng.random((len(sub), 8)) * 10, columns=cols,
+                      index=MultiIndex.from_tuples(sub, names=["Testing", "Row_Type"]))
+        for t in (g, a):
+            t["ncount"] = np.floor(t["ncount"] * 10)
+            t["w_ncount"] = np.floor(t["w_ncount"] * 10)
+        return g, a
+
+    for _ in range(3):                                     # first pass derives the layout, the others reuse it
+        g, a = tables()
+        slow = s._assemble_errors(g, a, None)
+        fast = s._assemble_errors(g, a, keys)
+        assert_frame_equal(slow, fast)
+    assert list(fast.index.names) == ["Group", "Weighting", "Testing", "Subsystem"]
+    assert fast.index[0][0] == "*ALL" and set(fast.index.get_level_values(2)) <= {"Training", "Testing"}
+    # a different key list (by identity) rebuilds the layout
+    keys2 = list(keys[:-1])
+    g2 = g.iloc[:-1]
+    assert_frame_equal(s._assemble_errors(g2, a, None), s._assemble_errors(g2, a, keys2))
+    pt.free()
