@@ -94,6 +94,7 @@ struct fsnap_ctx {
     int opt_kernel = 0;       // 0 auto | 1 wave-triangle (kernel 1) | 2 LDS-shared, static per-wave bodies | 3 LDS-shared, generic
     int opt_nsplit = 0;       // row splits of the tiled kernel (0 = auto)
     int opt_xcd = 1;          // tiled kernel: contiguous work-item ranges per XCD
+    int opt_tiled2 = 0;       // K > 128: 1 = kernel 1T2 (one wave per SIMD, 32-tile items; measured no faster), 0 = kernel 1T
     int opt_mirror = 1;       // fsnap_normal_eq_resident: reduction writes a page-locked host mirror (K <= 128)
     int opt_device_solve = 0; // 0 = auto (K >= 384 on the GPU, blocked), 1 = every K (K <= 128: fsnap_chol_solve_k), 2 = never
     int opt_ablate = 0;       // timing-only ablation of kernel 1L (diagnostics; results are wrong)
@@ -102,6 +103,8 @@ struct fsnap_ctx {
     int64_t tplan_key[5] = {0, 0, 0, 0, 0};
     int tplan[3] = {0, 0, 0};
     int64_t tplan_cps = 0;
+    int tplan_items = 0;                          // kernel 1T2: work items per split (table in titems)
+    DevBuf titems;
     // timing flags
     bool t_syrk = false, t_upload = false, t_weight = false, t_predict = false;
 
@@ -239,6 +242,7 @@ int ensure_ones(fsnap_ctx* ctx) {
 
 struct TiledGeometry {
     int NSB, npairs, nsplit;
+    int items_per_split = 0;   // kernel 1T2 (0 = kernel 1T)
     int64_t cps;  // chunks per split
 };
 
@@ -259,17 +263,18 @@ int fit_events(fsnap_ctx* ctx, hipEvent_t** slot) {
 // 1.84 ms, 57 splits 1.60 ms).  So the split count comes from a small model: greedy list scheduling of one XCD's
 // item range on its slots (the hardware dispatches the next workgroup when a slot frees up) + the reduction of the
 // partial triangles; it reproduces the measured kernel times within ~5 %.  The result is cached per shape.
-double tiled_makespan_units(const std::vector<int>& tiles, int64_t n, int64_t chunks_per_wave, int64_t groups, int64_t slots) {
+double tiled_makespan_units(const std::vector<int>& tiles, int64_t n, int64_t chunks_per_wave, int64_t groups, int64_t slots,
+                            double ovh) {
     const int64_t npairs = (int64_t)tiles.size();
     const int64_t nitems = npairs * n;
     const int64_t per = (nitems + groups - 1) / groups;
     std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
     for (int64_t i = 0; i < slots; ++i) free_at.push(0.0);
-    const double ovh = 128.0;      // prologue + 4-wave fold + 32 KiB partial store, in units of one chunk of one tile
     double makespan = 0.0;
     for (int64_t it = 0; it < per && it < nitems; ++it) {
         const double t0 = free_at.top();
         free_at.pop();
+        // ovh: prologue + 4-wave fold + partial store, in units of one chunk of one tile
         const double t1 = t0 + ovh + (double)chunks_per_wave * tiles[(size_t)(it % npairs)];
         free_at.push(t1);
         if (t1 > makespan) makespan = t1;
@@ -281,11 +286,12 @@ int plan_tiled(fsnap_ctx* ctx, TiledGeometry* g) {
     const int64_t m = ctx->m, K = ctx->K;
     if (K > 32768) return ctx->fail(FSNAP_E_ARG, "K = %lld too large", (long long)K);
     if (ctx->tplan_valid && ctx->tplan_key[0] == m && ctx->tplan_key[1] == K && ctx->tplan_key[2] == ctx->lda &&
-        ctx->tplan_key[3] == ctx->opt_nsplit && ctx->tplan_key[4] == ctx->opt_xcd) {
+        ctx->tplan_key[3] == ctx->opt_nsplit && ctx->tplan_key[4] == ctx->opt_xcd + 2 * ctx->opt_tiled2) {
         g->NSB = ctx->tplan[0];
         g->npairs = ctx->tplan[1];
         g->nsplit = ctx->tplan[2];
         g->cps = ctx->tplan_cps;
+        g->items_per_split = ctx->tplan_items;
         return FSNAP_OK;
     }
     g->NSB = (int)((K + 63) / 64);
@@ -294,19 +300,45 @@ int plan_tiled(fsnap_ctx* ctx, TiledGeometry* g) {
     const int64_t bytes = m * ctx->lda * 8;
     // keep a split's rows resident in the Infinity Cache (256 MiB) while all pairs sweep them
     const int64_t min_split_cache = (bytes + (96ll << 20) - 1) / (96ll << 20);
-    int64_t nsplit = ctx->opt_nsplit;
-    if (nsplit <= 0) {
-        const int64_t groups = ctx->opt_xcd ? 8 : 1;
-        const int64_t slots = (int64_t)ctx->num_cu * 2 / groups;     // two workgroups (8 waves) per CU are resident
-        const int tail = (int)(K & 63);
-        const bool half = tail != 0 && tail <= 32;                   // last superblock: second 32-column group empty
-        std::vector<int> tiles;
-        tiles.reserve((size_t)g->npairs);
+    // work items of one split and their cost in MFMA tiles per chunk
+    const int tail = (int)(K & 63);
+    const bool half = tail != 0 && tail <= 32;                   // last superblock: second 32-column group empty
+    const bool t2 = ctx->opt_tiled2 != 0 && g->NSB >= 3;
+    std::vector<int> tiles, table;
+    if (t2) {
+        // kernel 1T2: superblock I against consecutive pairs (J, J + 1) right of it (32 tiles, heaviest first), then
+        // the lone last column of the rows with an odd count (16 tiles), then the diagonal (10 tiles)
+        auto tri = [&](int I, int J) { return I * g->NSB - (I * (I - 1)) / 2 + (J - I); };
+        for (int I = 0; I < g->NSB; ++I)
+            for (int J = I + 1; J + 1 < g->NSB; J += 2) {
+                table.insert(table.end(), {0, I, J, tri(I, J)});
+                tiles.push_back((half && J + 1 == g->NSB - 1) ? 24 : 32);
+            }
+        for (int I = 0; I < g->NSB; ++I)
+            if ((g->NSB - 1 - I) & 1) {
+                table.insert(table.end(), {1, I, g->NSB - 1, tri(I, g->NSB - 1)});
+                tiles.push_back(half ? 8 : 16);
+            }
+        for (int I = 0; I < g->NSB; ++I) {
+            table.insert(table.end(), {1, I, I, tri(I, I)});
+            tiles.push_back((half && I == g->NSB - 1) ? 3 : 10);
+        }
+        g->items_per_split = (int)tiles.size();
+    } else {
         for (int I = 0; I < g->NSB; ++I)
             for (int J = I; J < g->NSB; ++J) {
                 const bool last = half && J == g->NSB - 1;
                 tiles.push_back(I == J ? (last ? 3 : 10) : (last ? 8 : 16));
             }
+        g->items_per_split = 0;
+    }
+    int64_t nsplit = ctx->opt_nsplit;
+    if (nsplit <= 0) {
+        const int64_t groups = ctx->opt_xcd ? 8 : 1;
+        // kernel 1T: two workgroups (8 waves) per CU share the matrix pipe, 66 ns per tile and chunk at ~80 % issue;
+        // kernel 1T2: one workgroup per CU, ~30 ns
+        const int64_t slots = (int64_t)ctx->num_cu * (t2 ? 1 : 2) / groups;
+        const double unit = t2 ? 30.0e-9 : 66.0e-9, ovh = t2 ? 250.0 : 128.0;
         const int64_t part_bytes = (int64_t)g->npairs * 32768;                        // partial triangles of one split
         int64_t n_hi = std::max<int64_t>(1, std::min<int64_t>(1024, nchunks / 128));  // >= 32 chunks per wave
         n_hi = std::min(n_hi, std::max<int64_t>(1, (256ll << 20) / part_bytes));      // <= 256 MiB of partials
@@ -315,8 +347,7 @@ int plan_tiled(fsnap_ctx* ctx, TiledGeometry* g) {
         for (int64_t n = n_lo; n <= n_hi; ++n) {
             const int64_t cps = (nchunks + n - 1) / n;
             const int64_t cpw = (cps + 3) / 4;
-            const double cost = 66.0e-9 * tiled_makespan_units(tiles, n, cpw, groups, slots) +   // 64-cycle MFMAs, two waves per SIMD, ~80 % issue
-                                (double)n * (double)part_bytes / 3.0e12;
+            const double cost = unit * tiled_makespan_units(tiles, n, cpw, groups, slots, ovh) + (double)n * (double)part_bytes / 3.0e12;
             if (cost < best) {
                 best = cost;
                 nsplit = n;
@@ -337,11 +368,17 @@ int plan_tiled(fsnap_ctx* ctx, TiledGeometry* g) {
     if ((int64_t)g->npairs * nsplit > 0x7FFFFFFF) return ctx->fail(FSNAP_E_ARG, "too many workgroups");
     g->nsplit = (int)nsplit;
     g->cps = cps;
+    if (t2) {
+        if (!ctx->titems.ensure(table.size() * sizeof(int))) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(work items) failed");
+        FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");      // a launch may still read the old table
+        FSNAP_HIP(hipMemcpy(ctx->titems.p, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy(work items)");
+    }
+    ctx->tplan_items = g->items_per_split;
     ctx->tplan_key[0] = m;
     ctx->tplan_key[1] = K;
     ctx->tplan_key[2] = ctx->lda;
     ctx->tplan_key[3] = ctx->opt_nsplit;
-    ctx->tplan_key[4] = ctx->opt_xcd;
+    ctx->tplan_key[4] = ctx->opt_xcd + 2 * ctx->opt_tiled2;
     ctx->tplan[0] = g->NSB;
     ctx->tplan[1] = g->npairs;
     ctx->tplan[2] = g->nsplit;
@@ -398,7 +435,13 @@ int launch_normal_eq_tiled(fsnap_ctx* ctx, double* d_packed, bool accumulate) {
     hipEvent_t* evs;
     if ((rc = fit_events(ctx, &evs))) return rc;
     FSNAP_HIP(hipEventRecord(evs[0], ctx->stream), "hipEventRecord");
-    FSNAP_HIP(fsnap::launch_syrk_tiled(a, ctx->stream), "launch fsnap_syrk_tiled");
+    if (g.items_per_split > 0) {
+        a.items = (const int*)ctx->titems.p;
+        a.items_per_split = g.items_per_split;
+        FSNAP_HIP(fsnap::launch_syrk_tiled2(a, ctx->stream), "launch fsnap_syrk_tiled2");
+    } else {
+        FSNAP_HIP(fsnap::launch_syrk_tiled(a, ctx->stream), "launch fsnap_syrk_tiled");
+    }
     FSNAP_HIP(hipEventRecord(evs[1], ctx->stream), "hipEventRecord");
     FSNAP_HIP(fsnap::launch_reduce_tiled(a, d_packed, accumulate, ctx->stream), "launch fsnap_reduce_tiled");
     FSNAP_HIP(hipEventRecord(evs[2], ctx->stream), "hipEventRecord");
@@ -561,7 +604,7 @@ int fsnap_ctx_destroy(fsnap_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->ownA, &ctx->ownb, &ctx->ownw, &ctx->ownmask, &ctx->ones, &ctx->part, &ctx->cpart,
                       &ctx->spart, &ctx->packed, &ctx->beta, &ctx->preds, &ctx->sse, &ctx->aw, &ctx->bw,
                       &ctx->st_raw, &ctx->st_plan, &ctx->st_frac, &ctx->st_blank, &ctx->dsolve, &ctx->dchol, &ctx->dcat, &ctx->dstat, &ctx->wpack, &ctx->wpack_spart,
-                      &ctx->du, &ctx->dspart, &ctx->dsvec};
+                      &ctx->du, &ctx->dspart, &ctx->dsvec, &ctx->titems};
     for (DevBuf* b : bufs) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->mirror) (void)hipHostFree(ctx->mirror);
@@ -612,6 +655,8 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
         ctx->mirror_of = nullptr;
     } else if (!strcmp(key, "xcd")) {
         ctx->opt_xcd = value != 0;
+    } else if (!strcmp(key, "tiled2")) {
+        ctx->opt_tiled2 = value != 0;
     } else if (!strcmp(key, "nsplit")) {
         if (value < 0 || value > (1 << 24)) return ctx->fail(FSNAP_E_ARG, "nsplit out of range");
         ctx->opt_nsplit = (int)value;
@@ -1201,7 +1246,7 @@ int fsnap_launch_info(fsnap_ctx* ctx, int64_t* info, int n) {
     if (ctx->K > 128 || ctx->opt_tiled) {
         TiledGeometry t;
         if ((rc = plan_tiled(ctx, &t))) return rc;
-        out[0] = (int64_t)t.npairs * t.nsplit;
+        out[0] = (int64_t)(t.items_per_split > 0 ? t.items_per_split : t.npairs) * t.nsplit;
         out[1] = 256;
         out[2] = t.cps / 4;
         out[3] = 4 * t.NSB;

@@ -42,6 +42,8 @@ struct TiledArgs {
     double* cpart;              // [(nsplit*NSB)*4][4][16]
     const double* spart;        // [ns][4]: partial b-only scalars of fsnap_pack_weights_k
     int ns;
+    const int* items = nullptr; // kernel 1T2: device table [items_per_split][4] = {type, I, J, pair index}
+    int items_per_split = 0;
 };
 
 int syrk_num_blocks(int K);
@@ -61,6 +63,7 @@ int pack_weights_num_blocks(int64_t m);
 hipError_t launch_pack_weights(const double* b, const double* w, const unsigned char* mask, int64_t m, double* wpack,
                                double* spart, hipStream_t st);
 hipError_t launch_syrk_tiled(const TiledArgs& a, hipStream_t st);
+hipError_t launch_syrk_tiled2(const TiledArgs& a, hipStream_t st);
 hipError_t launch_reduce_tiled(const TiledArgs& a, double* out, bool accumulate, hipStream_t st);
 hipError_t launch_weight_rows(const double* A, int64_t lda, const double* b, const double* w,
                               const unsigned char* mask, int64_t m, int K, double* aw, int64_t ldaw, double* bw,

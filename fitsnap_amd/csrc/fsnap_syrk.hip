@@ -25,7 +25,8 @@
 //                              (the default before kernel 1A; option kernel = 2).
 //       fsnap_syrk_lds         generic tile-table variant of 1L (A/B)
 //   1P  fsnap_syrk_wave_p      K <= 80 (default): kernel 1 on packed weights, rows masked by the loads
-//   1T  fsnap_syrk_tiled       general K > 128: 64-column superblock pairs x row splits
+//   1T  fsnap_syrk_tiled       general K > 128 (default): 64-column superblock pairs x row splits
+//   1T2 fsnap_syrk_tiled2      general K > 128 (option tiled2 = 1): one wave per SIMD, 64 x 128-column items, 32 AGPR tiles
 //   2   fsnap_reduce_partials / fsnap_reduce_tiled   deterministic fixed-order reduction of the
 //                              per-workgroup partial triangles -> packed [G | c | scalars];
 //                              un-permutes the even/odd column interleave, mirrors the triangle
@@ -1445,6 +1446,23 @@ struct WaveBufsT {
 __device__ __forceinline__ u4 load_pack_t(const WaveBufsT& wb, unsigned cl) {
     return __builtin_amdgcn_raw_buffer_load_b128(wb.wp, wb.voffP, cl * 64u, 0);
 }
+// w_eff only (off-diagonal items never use w_eff b): the unused half of a 16-byte load would be a dead register pair
+// that the allocator reuses at once -- and every such reuse waits for the load (write-after-write, vmcnt(0))
+__device__ __forceinline__ u2 load_pack_w(const WaveBufsT& wb, unsigned cl) {
+    return __builtin_amdgcn_raw_buffer_load_b64(wb.wp, wb.voffP, cl * 64u, 0);
+}
+__device__ __forceinline__ bool pack_keep_w(const u2& wp) { return ((wp[0] | (wp[1] & 0x7FFFFFFFu)) != 0u); }
+// kernel 1T: diagonal pairs need (w_eff, w_eff b), off-diagonal pairs w_eff only
+template <bool DIAG>
+__device__ __forceinline__ void load_pack_d(u4& dst, const WaveBufsT& wb, unsigned cl) {
+    if (DIAG) {
+        dst = load_pack_t(wb, cl);
+    } else {
+        const u2 t = load_pack_w(wb, cl);
+        dst[0] = t[0];
+        dst[1] = t[1];
+    }
+}
 
 template <bool DIAG, int EDGE, bool NT>
 __device__ __forceinline__ void issue_rows_t(RawT& r, const WaveBufsT& wb, unsigned voffI, unsigned voffJ, unsigned cl) {
@@ -1533,7 +1551,7 @@ __device__ __forceinline__ void syrk_tiled_body(const double* __restrict__ A, in
 #define FSNAP_STEP_T(RF, RN, CLF)                                                               \
     {                                                                                           \
         const d2 wpn = __builtin_bit_cast(d2, RN.wp);                                           \
-        RN.wp = load_pack_t(wb, (CLF) + 1);                                                     \
+        load_pack_d<DIAG>(RN.wp, wb, (CLF) + 1);                                                \
         issue_rows_t<DIAG, EDGE, NT>(RF, wb, voffI, voffJ, (CLF));                                    \
         _Pragma("unroll") for (int p = 0; p < PMAX; ++p) {                                      \
             _Pragma("unroll") for (int q = (DIAG ? p : 0); q < QMAX; ++q) {                     \
@@ -1547,9 +1565,9 @@ __device__ __forceinline__ void syrk_tiled_body(const double* __restrict__ A, in
         wbcur = wpn[1];                                                                         \
     }
     if (ncl > 0) {
-        r0.wp = load_pack_t(wb, 0);
-        r1.wp = load_pack_t(wb, 1);
-        r2.wp = load_pack_t(wb, 2);
+        load_pack_d<DIAG>(r0.wp, wb, 0);
+        load_pack_d<DIAG>(r1.wp, wb, 1);
+        load_pack_d<DIAG>(r2.wp, wb, 2);
         issue_rows_t<DIAG, EDGE, NT>(r0, wb, voffI, voffJ, 0);
         issue_rows_t<DIAG, EDGE, NT>(r1, wb, voffI, voffJ, 1);
         issue_rows_t<DIAG, EDGE, NT>(r2, wb, voffI, voffJ, 2);
@@ -1558,7 +1576,7 @@ __device__ __forceinline__ void syrk_tiled_body(const double* __restrict__ A, in
             prep_t<DIAG, EDGE>(vI, vJ, r0, wp0[0], 64 * I, 64 * J, K, e);
             wbcur = wp0[1];
         }
-        r0.wp = load_pack_t(wb, 3);
+        load_pack_d<DIAG>(r0.wp, wb, 3);
         for (unsigned cl = 0; cl < ncl; cl += 3) {
             FSNAP_STEP_T(r0, r1, cl + 3)
             FSNAP_STEP_T(r1, r2, cl + 4)
@@ -1661,6 +1679,229 @@ __global__ __launch_bounds__(256, 2) void fsnap_syrk_tiled(const double* __restr
         if (edge == 2) syrk_tiled_body<false, 2, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
         else if (edge == 4) syrk_tiled_body<false, 4, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
         else syrk_tiled_body<false, 0, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 1T2: the tiled kernel with kernel 1A's register plan.  One wave per SIMD (one 4-wave workgroup per CU);
+// an off-diagonal work item is a 64-column superblock I against a PAIR of superblocks (J0, J0 + 1) right of it:
+// 32 tiles in the 256 accumulation registers a[0:255], named by the MFMAs in inline assembly like kernel 1A.
+// Per 4-row chunk a lane loads 4 + 8 doubles and feeds 32 MFMAs (the 16-tile items of kernel 1T: 4 + 4 for 16);
+// the J side goes from the load registers straight into the MFMAs, the I side is multiplied by w^2 one step ahead,
+// block by block, right after the MFMA row that last used the old value.  Four raw sets: rows three chunks ahead.
+// The pairs this shape cannot cover -- the diagonal (I, I), its right neighbour (I, I + 1) for even I, and the lone
+// last column when the number of superblocks is odd -- are work items of the same kernel and run kernel 1T's
+// 16-tile body.  Items come from a table built by the host (heavy items first).
+// Measured (15 213 x 1 595, PMC): matrix pipe busy 75.7 % of the kernel (kernel 1T: 78 %), L2 hit rate 76 % (69 %),
+// HBM-side fetch 0.99 GB (1.82 GB) per launch, kernel time 0.72 ms (0.69 ms): no faster, and slower for few superblocks
+// (K = 256: 0.36 vs 0.25 ms) -- kept as an option for A/B, kernel 1T stays the default.
+// Partials: as kernel 1T (one 16-tile block per 64-column superblock pair and split).
+// ---------------------------------------------------------------------------------
+namespace {
+
+struct RawT2 {
+    u4 pi[2], pj[4];
+    u2 wp;      // w_eff of the lane's row
+};
+
+template <int EDGE, bool NT>
+__device__ __forceinline__ void issue_rows_t2(RawT2& r, const WaveBufsT& wb, unsigned voffI, unsigned voffJ, unsigned cl) {
+    const unsigned soff = cl * wb.chunk_bytes;
+    constexpr int AUX = NT ? 2 : 0;
+    const bool keep = pack_keep_w(r.wp);
+    const unsigned vi = keep ? voffI : FSNAP_OOB_VOFF;
+    const unsigned vj = keep ? voffJ : FSNAP_OOB_VOFF;
+    r.pi[0] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, vi, soff, AUX);
+    r.pi[1] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, vi + 256u, soff, AUX);
+    r.pj[0] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, vj, soff, AUX);
+    r.pj[1] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, vj + 256u, soff, AUX);
+    r.pj[2] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, vj + 512u, soff, AUX);
+    if (EDGE != 2) r.pj[3] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, vj + 768u, soff, AUX);
+}
+
+// B operand block q (0..7) of the 128-column J range: the loaded value itself; with EDGE the second superblock is
+// the last one of the matrix and its columns >= K are zeroed by selects (EDGE == 2: its blocks 6, 7 are empty)
+template <int EDGE>
+__device__ __forceinline__ double vj_block_t2(const RawT2& r, int q, int colJ0, int K, int e) {
+    if (EDGE == 2 && q >= 6) return 0.0;
+    const double x = __builtin_bit_cast(d2, r.pj[q >> 1])[q & 1];
+    if (EDGE != 0 && q >= 4) return (colJ0 + 32 * (q >> 1) + 2 * e + (q & 1) < K) ? x : 0.0;
+    return x;
+}
+
+template <int T, bool SKIP>
+__device__ __forceinline__ void t2_mfma(double a, double b, d4 (&vt)[4]) {
+    if constexpr (!SKIP) acc_mfma<T>(a, b, vt);
+}
+
+template <int P, int EDGE, int... Q>
+__device__ __forceinline__ void t2_row(double vi, const double (&vj)[8], d4 (&vt)[4], std::integer_sequence<int, Q...>) {
+    (t2_mfma<P * 8 + Q, (EDGE == 2 && Q >= 6)>(vi, vj[Q], vt), ...);
+}
+
+// step c: MFMAs of chunk c (A operands VI prepared one step ago, B operands = raw set RC), VI <- w^2 x rows of chunk
+// c + 1 (raw set RN) block by block behind the MFMA rows, rows of chunk c + 3 into the raw set RF consumed one step
+// ago (its packed weights were loaded two steps ago), packed weights of chunk c + 5 into RN's slot.
+template <int EDGE, bool NT>
+__device__ __forceinline__ void t2_step(double (&VI)[4], d4 (&vt)[4], const RawT2& RC, RawT2& RN, RawT2& RF,
+                                        const WaveBufsT& wb, unsigned voffI, unsigned voffJ, unsigned clf, int colJ0,
+                                        int K, int e) {
+    const double wn = __builtin_bit_cast(double, RN.wp);
+    const double w2 = wn * wn;
+    double vj[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) vj[q] = vj_block_t2<EDGE>(RC, q, colJ0, K, e);
+    RN.wp = load_pack_w(wb, clf + 2);       // packed weights TWO steps ahead of the rows they gate (chunk c + 5, used by
+    __builtin_amdgcn_sched_barrier(0);      // the refill in step c + 2) and BEFORE this step's row loads: vmcnt retires
+                                            // in order, the wait for them must not drain the rows issued meanwhile
+    issue_rows_t2<EDGE, NT>(RF, wb, voffI, voffJ, clf);
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr auto cols = std::make_integer_sequence<int, 8>{};
+    t2_row<0, EDGE>(VI[0], vj, vt, cols);
+    VI[0] = w2 * __builtin_bit_cast(d2, RN.pi[0])[0];
+    __builtin_amdgcn_sched_barrier(0);
+    t2_row<1, EDGE>(VI[1], vj, vt, cols);
+    VI[1] = w2 * __builtin_bit_cast(d2, RN.pi[0])[1];
+    __builtin_amdgcn_sched_barrier(0);
+    t2_row<2, EDGE>(VI[2], vj, vt, cols);
+    VI[2] = w2 * __builtin_bit_cast(d2, RN.pi[1])[0];
+    __builtin_amdgcn_sched_barrier(0);
+    t2_row<3, EDGE>(VI[3], vj, vt, cols);
+    VI[3] = w2 * __builtin_bit_cast(d2, RN.pi[1])[1];
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int EDGE, bool NT>
+__device__ __forceinline__ void syrk_tiled2_body(const double* __restrict__ A, int64_t lda,
+                                                 const double* __restrict__ wpack, int64_t m, int K, int I, int J0,
+                                                 int64_t c0, int64_t c1, int rw, double* lds,
+                                                 double* __restrict__ pw0, double* __restrict__ pw1) {
+    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
+    const int64_t row0 = c0 << 2;
+    int64_t row1 = c1 << 2;
+    if (row1 > m) row1 = m;
+    const int64_t nrow = row1 > row0 ? row1 - row0 : 0;
+    WaveBufsT wb;
+    wb.A = make_rsrc(A + row0 * lda, (unsigned)(nrow * lda * 8 + (nrow ? 16 : 0)));
+    wb.wp = make_rsrc(wpack + 2 * row0, (unsigned)(nrow * 16));
+    wb.voffP = (unsigned)(kr * 16);
+    wb.chunk_bytes = (unsigned)(lda * 32);
+    const unsigned voffI = (unsigned)((kr * lda + 64 * I + 2 * e) * 8);
+    const unsigned voffJ = (unsigned)((kr * lda + 64 * J0 + 2 * e) * 8);
+    const unsigned ncl = (unsigned)(c1 > c0 ? c1 - c0 : 0);
+
+    acc_zero_all(std::make_integer_sequence<int, 256>{});
+    d4 vt[4];      // unused (every tile lives in an accumulation register); acc_mfma's signature
+#pragma unroll
+    for (int u = 0; u < 4; ++u) vt[u] = d4{0.0, 0.0, 0.0, 0.0};
+    double VI[4] = {0.0, 0.0, 0.0, 0.0};
+    RawT2 s0, s1, s2, s3;
+    if (ncl > 0) {
+        s0.wp = load_pack_w(wb, 0);
+        s1.wp = load_pack_w(wb, 1);
+        s2.wp = load_pack_w(wb, 2);
+        s3.wp = load_pack_w(wb, 3);
+        issue_rows_t2<EDGE, NT>(s0, wb, voffI, voffJ, 0);
+        issue_rows_t2<EDGE, NT>(s1, wb, voffI, voffJ, 1);
+        issue_rows_t2<EDGE, NT>(s2, wb, voffI, voffJ, 2);
+        {
+            const double w0 = __builtin_bit_cast(double, s0.wp);
+            const double w2 = w0 * w0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) VI[p] = w2 * __builtin_bit_cast(d2, s0.pi[p >> 1])[p & 1];
+        }
+        s0.wp = load_pack_w(wb, 4);
+        for (unsigned cl = 0; cl < ncl; cl += 4) {
+            t2_step<EDGE, NT>(VI, vt, s0, s1, s3, wb, voffI, voffJ, cl + 3, 64 * J0, K, e);
+            t2_step<EDGE, NT>(VI, vt, s1, s2, s0, wb, voffI, voffJ, cl + 4, 64 * J0, K, e);
+            t2_step<EDGE, NT>(VI, vt, s2, s3, s1, wb, voffI, voffJ, cl + 5, 64 * J0, K, e);
+            t2_step<EDGE, NT>(VI, vt, s3, s0, s2, wb, voffI, voffJ, cl + 6, 64 * J0, K, e);
+        }
+    }
+    // the last MFMAs (16 passes) must have left the pipe before their accumulators are read
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(vt[0]));
+    // fold the four row-waves through LDS in two halves of 16 tiles (4 slots x 16 tiles x 2 KiB = 128 KiB); wave r
+    // then sums a quarter of the tiles over the four slots in a fixed order and stores them
+    auto fold_half = [&](auto half_tag) {
+        constexpr int H = decltype(half_tag)::value;
+        double* slot = lds + (size_t)rw * 16 * 256;
+        {
+            d4 tmp[16];
+            acc_read_range<16 * H>(tmp, vt, std::make_integer_sequence<int, 16>{});
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) slot[(u * 4 + i) * 64 + lane] = tmp[u][i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int uu = 0; uu < 4; ++uu) {
+            const int u = rw * 4 + uu;                 // tile 16 H + u = (p, q) with p = 2 H + (u >> 3), q = u & 7
+            const int p = 2 * H + (u >> 3), q = u & 7;
+            double* dst = ((q < 4) ? pw0 : pw1) + (size_t)(p * 4 + (q & 3)) * 256;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int o = (u * 4 + i) * 64 + lane;
+                const double s01 = lds[o] + lds[16 * 256 + o];
+                dst[i * 64 + lane] = (s01 + lds[2 * 16 * 256 + o]) + lds[3 * 16 * 256 + o];
+            }
+        }
+        if (H == 0) __syncthreads();
+    };
+    fold_half(std::integral_constant<int, 0>{});
+    fold_half(std::integral_constant<int, 1>{});
+}
+
+}  // namespace
+
+template <bool NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void
+fsnap_syrk_tiled2(const double* __restrict__ A, int64_t lda, const double* __restrict__ wpack, int64_t m, int K, int NSB,
+                  int npairs, const int* __restrict__ items, int items_per_split, int64_t chunks_per_split, int nitems,
+                  int xcd_map, double* __restrict__ part, double* __restrict__ cpart) {
+    __shared__ double lds[4 * 16 * 256];
+    // the compiler must count a[0:255] as used (see kernel 1A)
+    asm volatile("" : : : "a0", "a255");
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned item = blockIdx.x;
+    if (xcd_map) {
+        const unsigned per = ((unsigned)nitems + 7u) >> 3;
+        const unsigned slot = blockIdx.x >> 3;
+        item = (blockIdx.x & 7u) * per + slot;
+        if (slot >= per || item >= (unsigned)nitems) return;
+    }
+    const int local = (int)(item % (unsigned)items_per_split);
+    const int split = (int)(item / (unsigned)items_per_split);
+    const int type = items[4 * local], I = items[4 * local + 1], J = items[4 * local + 2], pair = items[4 * local + 3];
+    const int64_t nchunks = (m + 3) >> 2;
+    const int64_t cpw = (chunks_per_split + 3) >> 2;
+    int64_t s0 = (int64_t)split * chunks_per_split;
+    int64_t s1 = s0 + chunks_per_split;
+    if (s1 > nchunks) s1 = nchunks;
+    int64_t c0 = s0 + (int64_t)wv * cpw;
+    int64_t c1 = c0 + cpw;
+    if (c1 > s1) c1 = s1;
+    if (c0 > s1) c0 = s1;
+    double* pw = part + ((int64_t)split * npairs + pair) * (16 * 256);
+    const int tail = K & 63;
+    if (type == 0) {
+        // superblock I against the superblock pair (J, J + 1), both right of I; J + 1 may be the last superblock
+        const int edge = (J + 1 == NSB - 1 && tail != 0) ? (tail <= 32 ? 2 : 4) : 0;
+        if (edge == 2) syrk_tiled2_body<2, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, pw + 16 * 256);
+        else if (edge == 4) syrk_tiled2_body<4, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, pw + 16 * 256);
+        else syrk_tiled2_body<0, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, pw + 16 * 256);
+    } else {
+        double* cw = cpart + (((int64_t)split * NSB + I) * 4 + wv) * 64;
+        const int edge = (J == NSB - 1 && tail != 0) ? (tail <= 32 ? 2 : 4) : 0;
+        if (I == J) {
+            if (edge == 2) syrk_tiled_body<true, 2, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+            else if (edge == 4) syrk_tiled_body<true, 4, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+            else syrk_tiled_body<true, 0, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+        } else {
+            if (edge == 2) syrk_tiled_body<false, 2, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+            else if (edge == 4) syrk_tiled_body<false, 4, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+            else syrk_tiled_body<false, 0, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+        }
     }
 }
 
@@ -1992,6 +2233,19 @@ hipError_t launch_syrk_tiled(const TiledArgs& a, hipStream_t st) {
     else
         hipLaunchKernelGGL((fsnap_syrk_tiled<false>), grid, block, 0, st, a.A, a.lda, a.wpack, a.m, a.K, a.NSB,
                            a.npairs, a.chunks_per_split, nitems, (int)a.xcd_map, a.part, a.cpart);
+    return hipGetLastError();
+}
+
+hipError_t launch_syrk_tiled2(const TiledArgs& a, hipStream_t st) {
+    const int nitems = (int)((int64_t)a.items_per_split * a.nsplit);
+    dim3 grid((unsigned)(a.xcd_map ? 8 * ((nitems + 7) / 8) : nitems)), block(256);
+    if (!a.items) return hipErrorInvalidValue;
+    if (a.nontemporal)
+        hipLaunchKernelGGL((fsnap_syrk_tiled2<true>), grid, block, 0, st, a.A, a.lda, a.wpack, a.m, a.K, a.NSB, a.npairs,
+                           a.items, a.items_per_split, a.chunks_per_split, nitems, (int)a.xcd_map, a.part, a.cpart);
+    else
+        hipLaunchKernelGGL((fsnap_syrk_tiled2<false>), grid, block, 0, st, a.A, a.lda, a.wpack, a.m, a.K, a.NSB, a.npairs,
+                           a.items, a.items_per_split, a.chunks_per_split, nitems, (int)a.xcd_map, a.part, a.cpart);
     return hipGetLastError();
 }
 

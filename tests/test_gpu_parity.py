@@ -195,16 +195,24 @@ def test_tiled_kernel_item_mapping_variants_agree(ctx, xcd):
     stats_close(G, c, s, *orc.normal_eq(A, b, w), tol=2e-12)
 
 
-@pytest.mark.parametrize("K,m", [(129, 5003), (142, 13035), (192, 4001), (200, 3000), (257, 2049), (480, 6000), (1595, 2500)])
-def test_general_k_tiled_kernel(ctx, K, m):
-    # K > 128: ACE (142), EME (480) and quadratic SNAP (1595) widths -> tiled kernel
+@pytest.mark.parametrize("tiled2", [1, 0])
+@pytest.mark.parametrize("K,m", [(129, 5003), (142, 13035), (192, 4001), (200, 3000), (257, 2049), (300, 4100), (448, 3000),
+                                 (480, 6000), (1000, 3000), (1595, 2500)])
+def test_general_k_tiled_kernel(ctx, K, m, tiled2):
+    # K > 128: ACE (142), EME (480) and quadratic SNAP (1595) widths -> tiled kernels: 1T2 (one wave per SIMD, superblock
+    # against superblock PAIRS, 32 AGPR tiles; even / odd superblock counts, full / partly filled / half-empty last
+    # superblock) and its predecessor 1T (option tiled2 = 0)
     rng = np.random.default_rng(2000 + K)
     A = rng.standard_normal((m, K)) * (10.0 ** rng.uniform(-2, 2, size=K))
     b = rng.standard_normal(m)
     w = rng.choice([100.0, 1.0, 1e-8], size=m, p=[0.03, 0.83, 0.14])
     t = rng.random(m) < 0.1
-    G, c, s = run_stats(ctx, A, b, w, t)
-    assert ctx.launch_info()["split"] == 0
+    ctx.set_option("tiled2", tiled2)
+    try:
+        G, c, s = run_stats(ctx, A, b, w, t)
+        assert ctx.launch_info()["split"] == 0
+    finally:
+        ctx.set_option("tiled2", 0)
     stats_close(G, c, s, *orc.normal_eq(A, b, w, t), tol=2e-12)
 
 
