@@ -519,21 +519,22 @@ __device__ __forceinline__ void acc_slot(double (&V)[NB], const RawM<NB>& RN, do
 }
 
 // One chunk (step c): the MFMA rows of chunk c held in V, interleaved with the preparation of chunk c + 1 (raw set
-// RN) block by block.  RN's packed weights are read first and its slot is refilled with those of chunk c + 4 (same
-// raw set, three steps on); RF (consumed one step ago, packed weights of chunk c + 3 loaded one step ago) gets the
-// rows of chunk c + 3.  The packed load goes out BEFORE the row loads: vmcnt retires in order, so the next step can
-// wait for it without also draining the row loads issued here.
+// RN, packed weights PW) block by block.  RF (consumed one step ago) gets the rows of chunk c + 3, gated by the
+// packed weights PKEEP of that chunk, which were loaded TWO steps ago: the packed pairs stream from HBM like the
+// rows, and a wave that needs one only a step (~1 us) after issuing its load stalls on it (the packs live in a ring of
+// six registers of their own, PLOAD is the slot for chunk c + 5).  The packed load goes out BEFORE the row loads:
+// vmcnt retires in order, so a later wait for it does not drain the row loads issued here.
 template <int NB, bool FULLK, bool NT, int... P>
-__device__ __forceinline__ void acc_step(double (&V)[NB], d4 (&vt)[4], RawM<NB>& RF, RawM<NB>& RN, const WaveBufsP& wb,
-                                         unsigned cl_fill, int K, int e, double (&cacc)[NB], double& wbp,
-                                         std::integer_sequence<int, P...>) {
-    const d2 wpn = __builtin_bit_cast(d2, RN.wp);
+__device__ __forceinline__ void acc_step(double (&V)[NB], d4 (&vt)[4], RawM<NB>& RF, const RawM<NB>& RN, const WaveBufsP& wb,
+                                         unsigned cl_fill, int K, int e, double (&cacc)[NB], double& wbp, const u4& PW,
+                                         const u4& PKEEP, u4& PLOAD, std::integer_sequence<int, P...>) {
+    const d2 wpn = __builtin_bit_cast(d2, PW);
     const double wv = wpn[0], wbv = wpn[1];
-    const bool keep = pack_keep(RF.wp);
+    const bool keep = pack_keep(PKEEP);
     const unsigned va = keep ? wb.voffA : FSNAP_OOB_VOFF;
     const unsigned vtl = (NB & 1) ? (keep ? wb.voffT : FSNAP_OOB_VOFF) : 0u;
 #if !defined(FSNAP_ACC_ABL) || !(FSNAP_ACC_ABL & 1)   // tools/syrk_trace.hip diagnostics: 1 = no loads, 2 = no VALU work
-    RN.wp = load_pack(wb, cl_fill + 1);
+    PLOAD = load_pack(wb, cl_fill + 2);
 #endif
     __builtin_amdgcn_sched_barrier(0);
 #if defined(FSNAP_ACC_ABL) && (FSNAP_ACC_ABL & 2)
@@ -610,14 +611,20 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
                 cacc[p] = __builtin_fma(V[p], wbv, cacc[p]);
             }
         }
-        r0.wp = load_pack(wb, 3);
+        // ring of packed weights: slot (c mod 6) holds the pair of chunk c; steps use c + 1 (weights), c + 3 (row
+        // mask of the refill) and load c + 5
+        u4 pk0 = r0.wp, pk1 = r1.wp, pk2 = r2.wp, pk3 = load_pack(wb, 3), pk4 = load_pack(wb, 4), pk5 = {0u, 0u, 0u, 0u};
+        (void)pk0;
         // step cl: MFMAs of chunk cl (in V), V <- chunk cl+1, rows of chunk cl+3 into the raw set freed one step ago,
-        // packed weights of chunk cl+4.  Chunk slots past the wave's range read zeros (bounds-checked descriptors).
+        // packed weights of chunk cl+5.  Chunk slots past the wave's range read zeros (bounds-checked descriptors).
         double wbp = 0.0;   // chunk 0 is fully accounted for by the prologue
-        for (unsigned cl = 0; cl < ncl; cl += 3) {
-            acc_step<NB, FULLK, NT>(V, vt, r0, r1, wb, cl + 3, K, e, cacc, wbp, rows);
-            acc_step<NB, FULLK, NT>(V, vt, r1, r2, wb, cl + 4, K, e, cacc, wbp, rows);
-            acc_step<NB, FULLK, NT>(V, vt, r2, r0, wb, cl + 5, K, e, cacc, wbp, rows);
+        for (unsigned cl = 0; cl < ncl; cl += 6) {
+            acc_step<NB, FULLK, NT>(V, vt, r0, r1, wb, cl + 3, K, e, cacc, wbp, pk1, pk3, pk5, rows);
+            acc_step<NB, FULLK, NT>(V, vt, r1, r2, wb, cl + 4, K, e, cacc, wbp, pk2, pk4, pk0, rows);
+            acc_step<NB, FULLK, NT>(V, vt, r2, r0, wb, cl + 5, K, e, cacc, wbp, pk3, pk5, pk1, rows);
+            acc_step<NB, FULLK, NT>(V, vt, r0, r1, wb, cl + 6, K, e, cacc, wbp, pk4, pk0, pk2, rows);
+            acc_step<NB, FULLK, NT>(V, vt, r1, r2, wb, cl + 7, K, e, cacc, wbp, pk5, pk1, pk3, rows);
+            acc_step<NB, FULLK, NT>(V, vt, r2, r0, wb, cl + 8, K, e, cacc, wbp, pk0, pk2, pk4, rows);
         }
         cacc[NB - 1] = __builtin_fma(V[NB - 1], wbp, cacc[NB - 1]);   // last prepared chunk (zeros past the range)
     }
