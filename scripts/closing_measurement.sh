@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round-1 closing measurement with kernel 1A as default: tests, bench, rocprofv3 stats, PMC passes, microbenchmarks.
+# Closing measurement of a round: tests, smoke, default bench, rocprofv3 stats, PMC passes, micro-benchmarks,
+# large-K shapes (tiled kernel + device Cholesky).
 set +e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
@@ -24,4 +25,20 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GR
   echo "pmc pass $i rc=$?"
 done
 python $R/scripts/pmc_summary.py $O/pmc_final fsnap_syrk > $O/final_pmc.md; cat $O/final_pmc.md
+echo "== large-K shapes"
+cd $R
+timeout 200 python scripts/chol_large_test.py 2>&1 | grep "K=" > $O/chol_large_k_sweep.txt; cat $O/chol_large_k_sweep.txt
+timeout 200 python bench.py --no-cpu-baseline --rows 15213 --cols 1595 --steps 20 --warmup 3 --preheat 100 > $O/bench_15213x1595.json 2>> $O/final_bench.err
+timeout 200 python bench.py --no-cpu-baseline --rows 367900 --cols 480 --steps 20 --warmup 3 --preheat 100 > $O/bench_367900x480.json 2>> $O/final_bench.err
+timeout 200 python bench.py --no-cpu-baseline --rows 1772880 --cols 110 --steps 30 --warmup 3 --preheat 150 > $O/bench_1772880x110.json 2>> $O/final_bench.err
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_k1595 -o k1595 -- python $R/bench.py --no-cpu-baseline --rows 15213 --cols 1595 --steps 20 --warmup 3 --preheat 50 > /dev/null 2>> $O/final_rocprof.log
+cp $(find $O/prof_k1595 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_15213x1595.csv
+cd $R
+python - <<'PY'
+import json
+for f in ("bench_15213x1595", "bench_367900x480", "bench_1772880x110"):
+    d = json.load(open(f"gpurun_out/{f}.json"))
+    print(f, "step ms %.3f kernel ms %.4f frac %.3f" % (d["ms_per_step"], d["roofline"]["kernel_ms_avg"], d["roofline"]["frac"]))
+PY
 find $O -name "*.csv" -size +8M -delete
