@@ -325,11 +325,9 @@ int plan_tiled(fsnap_ctx* ctx, TiledGeometry* g) {
         }
         g->items_per_split = (int)tiles.size();
     } else {
-        for (int I = 0; I < g->NSB; ++I)
-            for (int J = I; J < g->NSB; ++J) {
-                const bool last = half && J == g->NSB - 1;
-                tiles.push_back(I == J ? (last ? 3 : 10) : (last ? 8 : 16));
-            }
+        for (int I = 0; I < g->NSB; ++I)                 // kernel 1T's item order: off-diagonal pairs, then the diagonal
+            for (int J = I + 1; J < g->NSB; ++J) tiles.push_back((half && J == g->NSB - 1) ? 8 : 16);
+        for (int I = 0; I < g->NSB; ++I) tiles.push_back((half && I == g->NSB - 1) ? 3 : 10);
         g->items_per_split = 0;
     }
     int64_t nsplit = ctx->opt_nsplit;

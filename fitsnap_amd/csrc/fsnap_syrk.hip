@@ -1654,15 +1654,26 @@ __global__ __launch_bounds__(256, 2) void fsnap_syrk_tiled(const double* __restr
         item = (blockIdx.x & 7u) * per + slot;
         if (slot >= per || item >= (unsigned)nitems) return;
     }
-    const int pair = (int)(item % (unsigned)npairs);
+    const int id = (int)(item % (unsigned)npairs);
     const int split = (int)(item / (unsigned)npairs);
-    // decode pair -> (I, J), I <= J, row-major packed triangle over NSB superblocks
-    int I = 0, rem = pair;
-    while (rem >= NSB - I) {
-        rem -= NSB - I;
-        ++I;
+    // Items of a split: first the off-diagonal pairs (row-major strict upper triangle, 16 tiles each), then the
+    // diagonal pairs (10 tiles): workgroups that run side by side then cost the same and sweep the split's rows in
+    // step (a short item in their midst finishes early and its successor starts over at the first row, out of phase
+    // with the rows its neighbours keep in L2).
+    const int noff = npairs - NSB;
+    int I, J;
+    if (id < noff) {
+        I = 0;
+        int rem = id;
+        while (rem >= NSB - 1 - I) {
+            rem -= NSB - 1 - I;
+            ++I;
+        }
+        J = I + 1 + rem;
+    } else {
+        I = J = id - noff;
     }
-    const int J = I + rem;
+    const int pair = I * NSB - (I * (I - 1)) / 2 + (J - I);      // slot in the packed upper triangle (partials)
     const int64_t nchunks = (m + 3) >> 2;
     const int64_t cpw = (chunks_per_split + 3) >> 2;
     int64_t s0 = (int64_t)split * chunks_per_split;
