@@ -163,6 +163,8 @@ def main():
             ctx.normal_eq_async(ptr)
             if multi:
                 dist.all_reduce(packed)                   # RCCL over xGMI, same stream
+                if rank == 0 and not args.host_solve:
+                    ctx.mirror_packed(ptr, Kc)            # reduced statistics -> page-locked mirror (no D2H copy)
         t1 = time.perf_counter()
         beta = None
         if args.host_solve:

@@ -48,6 +48,7 @@ SIGNATURES = {
     "fsnap_normal_eq_async": (c_int, [c_void_p, c_void_p]),
     "fsnap_normal_eq_resident": (c_int, [c_void_p, POINTER(c_void_p)]),
     "fsnap_download_packed": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "fsnap_mirror_packed": (c_int, [c_void_p, c_void_p, c_int64]),
     "fsnap_weight_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "fsnap_weight_rows_device": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "fsnap_predict": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -297,6 +298,11 @@ class HipContext:
         ptr = c_void_p(None)
         self._check(self._lib.fsnap_normal_eq_resident(self._h, byref(ptr)))
         return ptr.value
+
+    def mirror_packed(self, d_packed_ptr: int, K: int):
+        """Statistics in HBM (e.g. just all-reduced) -> page-locked host mirror, asynchronously; the next
+        solve_device on the same pointer then needs no D2H copy."""
+        self._check(self._lib.fsnap_mirror_packed(self._h, c_void_p(d_packed_ptr), int(K)))
 
     def download_packed(self, d_packed_ptr: int, K: int):
         G = np.empty((K, K))

@@ -85,6 +85,7 @@ struct fsnap_ctx {
     double* mirror = nullptr;                     // page-locked host mirror written by the reduction kernel itself
     size_t mirror_bytes = 0;
     const double* mirror_of = nullptr;            // device buffer the mirror currently reflects (nullptr = stale)
+    int64_t mirror_K = 0;                         // order of the system in the mirror
     hipEvent_t mirror_ev = nullptr;               // recorded after the reduction that filled the mirror
     // options
     int opt_split = 0;        // 0 = auto
@@ -522,6 +523,7 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
     if (mirror) {
         FSNAP_HIP(hipEventRecord(ctx->mirror_ev, ctx->stream), "hipEventRecord");
         ctx->mirror_of = d_packed;
+        ctx->mirror_K = ctx->K;
     }
     ctx->t_syrk = true;
     return FSNAP_OK;
@@ -889,6 +891,32 @@ int fsnap_normal_eq_resident(fsnap_ctx* ctx, double** d_packed) {
     return FSNAP_OK;
 }
 
+int fsnap_mirror_packed(fsnap_ctx* ctx, const double* d_packed, int64_t K) {
+    if (!ctx) return FSNAP_E_ARG;
+    if (!d_packed || K <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_mirror_packed: bad argument");
+    ctx->mirror_of = nullptr;
+    if (K >= 384 || !ctx->opt_mirror) return FSNAP_OK;     // large systems are factorised on the GPU: nothing to mirror
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    const size_t need = ((size_t)FSNAP_PACKED_LEN(K) + (size_t)K) * 8;
+    if (ctx->mirror_bytes < need) {
+        if (ctx->mirror) (void)hipHostFree(ctx->mirror);
+        ctx->mirror = nullptr;
+        ctx->mirror_bytes = 0;
+        if (hipHostMalloc((void**)&ctx->mirror, need, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess)
+            return FSNAP_OK;                                 // no mirror: fsnap_solve_device copies instead
+        ctx->mirror_bytes = need;
+    }
+    if (!ctx->mirror_ev && hipEventCreateWithFlags(&ctx->mirror_ev, hipEventDisableTiming) != hipSuccess) {
+        ctx->mirror_ev = nullptr;
+        return FSNAP_OK;
+    }
+    FSNAP_HIP(fsnap::launch_mirror_copy(d_packed, (int)K, ctx->mirror, ctx->stream), "launch fsnap_mirror_copy_k");
+    FSNAP_HIP(hipEventRecord(ctx->mirror_ev, ctx->stream), "hipEventRecord");
+    ctx->mirror_of = d_packed;
+    ctx->mirror_K = K;
+    return FSNAP_OK;
+}
+
 int fsnap_download_packed(fsnap_ctx* ctx, const double* d_packed, int64_t K, double* G, double* c, double* scalars) {
     if (!ctx) return FSNAP_E_ARG;
     if (!d_packed || K <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_download_packed: bad argument");
@@ -1123,7 +1151,7 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
     }
     // statistics already mirrored in page-locked host memory by the reduction kernel: wait for it (polling the
     // event: the blocking wait's wake-up latency is several microseconds) and solve
-    if (ctx->mirror_of == d_packed && ctx->mirror && K == ctx->K) {
+    if (ctx->mirror_of == d_packed && ctx->mirror && K == ctx->mirror_K) {
         while (true) {
             const hipError_t q = hipEventQuery(ctx->mirror_ev);
             if (q == hipSuccess) break;

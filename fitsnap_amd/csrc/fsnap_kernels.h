@@ -72,6 +72,7 @@ hipError_t launch_assemble(const double* raw, int64_t raw_ld, int64_t nrows, con
                            const int* frac, const double* dval, const double* truth, const double* weight,
                            const double* fractions, const double* blank2J, int ntypes, int ncoeff, int off, double* A,
                            int64_t lda, double* b, double* w, hipStream_t st);
+hipError_t launch_mirror_copy(const double* src, int K, double* mirror, hipStream_t st);
 hipError_t launch_chol_solve(const double* packed, int K, double alpha, double* out, hipStream_t st);
 // blocked Cholesky solve for large K: work (chol_large_work_doubles(K) doubles), dsc, z (np = K rounded up to 64),
 // beta (K), status (1 int), minpiv (np / 64) are device scratch / outputs

@@ -5,6 +5,7 @@
 //   7   fsnap_gemvT_rows_k     s = A^T u (right-hand side of a refinement step)
 //   9   fsnap_error_stats_k    grouped error statistics of error_analysis     (solver.py:108-133)
 //   11  fsnap_pack_weights_k   (w_eff, w_eff b) per row + the b-only statistics, once per (b, w, mask)
+//   12  fsnap_mirror_copy_k    packed statistics + diag(G) into the page-locked host mirror (multi-GPU path)
 // Every kernel here moves each byte once; the roofline is HBM bandwidth.
 #include "fsnap_device_common.h"
 #include "fsnap_kernels.h"
@@ -366,6 +367,19 @@ __global__ __launch_bounds__(256) void fsnap_pack_weights_k(const double* __rest
 // ---------------------------------------------------------------------------------
 // host-side launchers (C++ linkage, used by fsnap_capi.cpp)
 // ---------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------
+// Kernel 12: packed statistics [G | c | scalars] + a compact copy of diag(G) from HBM into page-locked, coherent host
+// memory (the "mirror" of fsnap_solve_device).  The single-GPU reduction kernel writes its mirror itself; this one
+// serves statistics that were changed afterwards -- the all-reduced buffer of the multi-GPU path -- and replaces a
+// D2H copy (SDMA launch latency + a blocking stream wait) by a 3 us kernel and an event the host polls.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsnap_mirror_copy_k(const double* __restrict__ src, int K, double* __restrict__ mirror) {
+    const int n = K * K + K + 3;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) mirror[i] = src[i];
+    else if (i < n + K) mirror[i] = src[(size_t)(i - n) * K + (i - n)];
+}
+
 namespace fsnap {
 
 hipError_t launch_weight_rows(const double* A, int64_t lda, const double* b, const double* w,
@@ -468,6 +482,12 @@ hipError_t launch_gemv_rows(const double* A, int64_t lda, const double* beta, in
     const int nb = gemv_num_blocks(m);
     hipLaunchKernelGGL(fsnap_gemv_rows_k, dim3((unsigned)nb), dim3(256), (size_t)K * sizeof(double), st, A, lda,
                        beta, m, K, preds, b, w, mask, sse_part, uout);
+    return hipGetLastError();
+}
+
+hipError_t launch_mirror_copy(const double* src, int K, double* mirror, hipStream_t st) {
+    const int n = K * K + 2 * K + 3;
+    hipLaunchKernelGGL(fsnap_mirror_copy_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, K, mirror);
     return hipGetLastError();
 }
 

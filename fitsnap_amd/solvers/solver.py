@@ -268,6 +268,7 @@ class Solver:
                 self._stats_dev = (ctx, packed.data_ptr(), K)
                 if pt._rank != 0:
                     return None
+                ctx.mirror_packed(packed.data_ptr(), K)       # K < 384: page-locked mirror instead of a D2H copy
                 beta, rank, _ = ctx.solve_device(kind, param, K, packed.data_ptr())
                 self.last_rank = rank
                 return beta

@@ -158,6 +158,13 @@ int fsnap_normal_eq_accumulate(fsnap_ctx* ctx, double* d_packed);
  * use fsnap_normal_eq_async with a buffer of your own. */
 int fsnap_normal_eq_resident(fsnap_ctx* ctx, double** d_packed);
 
+/* Mirror packed statistics that live in device memory (e.g. the buffer a RCCL all-reduce just summed over the ranks,
+ * the reference's comm.Allreduce(c), comm.Allreduce(d) in examples/library/transpose_trick/example.py:245-246) into
+ * the context's page-locked host mirror; asynchronous (a small copy kernel + an event on the context's stream).  A
+ * following fsnap_solve_device on the same pointer then needs no D2H copy.  No-op for K >= 384 (those are factorised
+ * on the GPU).  The caller must not modify the buffer between this call and the solve. */
+int fsnap_mirror_packed(fsnap_ctx* ctx, const double* d_packed, int64_t K);
+
 /* Copy packed statistics from device memory to host arrays (any may be NULL); synchronous. */
 int fsnap_download_packed(fsnap_ctx* ctx, const double* d_packed, int64_t K, double* G, double* c, double* scalars);
 

@@ -292,6 +292,39 @@ def test_large_k_device_cholesky_matches_host_solve(ctx, K, m):
         assert np.max(np.abs(beta_dev - ref)) / scale < 1e-8
 
 
+@pytest.mark.parametrize("K", [40, 128, 200])
+def test_mirror_packed_serves_statistics_modified_in_hbm(ctx, K):
+    # fsnap_mirror_packed: the multi-GPU path all-reduces the packed statistics in place; the page-locked host mirror
+    # must then reflect the REDUCED buffer.  Here the "all-reduce" is a doubling on the same stream.
+    import torch
+
+    rng = np.random.default_rng(300 + K)
+    m = 5000
+    A = rng.standard_normal((m, K))
+    b = rng.standard_normal(m)
+    ctx.upload_rows(A, b)
+    ctx.set_weights(np.ones(m))
+    dev = torch.device("cuda", 0)
+    packed = torch.zeros(K * K + K + 3, dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream(dev)
+    ctx.set_stream(st.cuda_stream)
+    try:
+        ctx.normal_eq_async(packed.data_ptr())
+        packed.mul_(2.0)                                  # stands in for the sum over two identical ranks
+        ctx.mirror_packed(packed.data_ptr(), K)
+        beta, rank, _ = ctx.solve_device(_capi.SOLVE_RIDGE, 0.5, K, packed.data_ptr())
+        G, c, _ = orc.normal_eq(A, b, np.ones(m))
+        ref = np.linalg.solve(2 * G + 0.5 * np.eye(K), 2 * c)
+        assert rank == K and np.max(np.abs(beta - ref)) / np.max(np.abs(ref)) < 1e-9
+        # a new kernel launch invalidates the mirror: the solve reads the fresh (undoubled) statistics
+        ctx.normal_eq_async(packed.data_ptr())
+        beta1, _, _ = ctx.solve_device(_capi.SOLVE_RIDGE, 0.5, K, packed.data_ptr())
+        ref1 = np.linalg.solve(G + 0.5 * np.eye(K), c)
+        assert np.max(np.abs(beta1 - ref1)) / np.max(np.abs(ref1)) < 1e-9
+    finally:
+        ctx.use_own_stream()
+
+
 @pytest.mark.parametrize("K,m", [(96, 3000), (800, 4000)])
 def test_solve_device_with_replacement_rhs(ctx, K, m):
     # fsnap_solve_device_rhs: G delta = s (refinement step) with G resident in HBM -- host path (K = 96) and
