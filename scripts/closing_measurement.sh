@@ -10,6 +10,9 @@ export TMPDIR=/tmp
 echo "== pytest gpu"; timeout 1500 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; echo "rc=$?"; tail -3 $O/pytest_gpu.log
 echo "== smoke"; timeout 600 python __graft_entry__.py --smoke 2>&1 | tail -2
 echo "== bench default"; timeout 900 python bench.py > $O/final_bench.json 2> $O/final_bench.err; echo "rc=$?"; cat $O/final_bench.json
+# K sweep of the device Cholesky BEFORE the profiler passes (their post-processing competes for the host cores that
+# issue its ~100 launches per solve)
+timeout 200 python scripts/chol_large_test.py 2>&1 | grep "K=" > $O/chol_large_k_sweep.txt; cat $O/chol_large_k_sweep.txt
 tools/mfma_f64_peak > $O/microbench_mfma_f64_peak.txt 2>&1
 { for c in "256 0 1 0" "512 0 8 0" "768 0 4 0" "1024 0 2 0"; do timeout 60 tools/syrk_trace 1000000 $c; echo; done; } > $O/microbench_syrk_trace.txt 2>&1
 cd /tmp
@@ -27,7 +30,6 @@ done
 python $R/scripts/pmc_summary.py $O/pmc_final fsnap_syrk > $O/final_pmc.md; cat $O/final_pmc.md
 echo "== large-K shapes"
 cd $R
-timeout 200 python scripts/chol_large_test.py 2>&1 | grep "K=" > $O/chol_large_k_sweep.txt; cat $O/chol_large_k_sweep.txt
 timeout 200 python bench.py --no-cpu-baseline --rows 15213 --cols 1595 --steps 20 --warmup 3 --preheat 100 > $O/bench_15213x1595.json 2>> $O/final_bench.err
 timeout 200 python bench.py --no-cpu-baseline --rows 367900 --cols 480 --steps 20 --warmup 3 --preheat 100 > $O/bench_367900x480.json 2>> $O/final_bench.err
 timeout 200 python bench.py --no-cpu-baseline --rows 1772880 --cols 110 --steps 30 --warmup 3 --preheat 150 > $O/bench_1772880x110.json 2>> $O/final_bench.err
