@@ -403,10 +403,42 @@ class Solver:
             return {"ncount": n, "mae": sar / n, "rmse": np.sqrt(srr / n), "rsq": 1 - srr / sct,
                     "w_ncount": nw, "w_mae": sawr / n, "w_rmse": np.sqrt(swrr / nw), "w_rsq": 1 - swrr / scwt}
 
-    def _device_error_tables(self, a, b, w, shared, fs_dict):
-        """(per-group table, *ALL table) of solver.py:391-405, built from fsnap_error_stats."""
+    @staticmethod
+    def _pool_sums(rows):
+        """Pools the ten sums of fsnap_error_stats of several disjoint row sets (rows: (k, 10) array) into those of
+        their union.  Counts and plain sums add; the centred sums are re-centred on the pooled mean:
+        sum (x - M)^2 = sum_c [ S_c + 2 (mu_c - M) (sum x_c - n_c mu_c) + n_c (mu_c - M)^2 ]."""
+        rows = np.asarray(rows, dtype=np.float64).reshape(-1, 10)
+        n, nw, s_t, s_wt = rows[:, 0], rows[:, 1], rows[:, 2], rows[:, 3]
+        N, NW = n.sum(), nw.sum()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mu_c, M = s_t / n, s_t.sum() / N
+            wmu_c = np.where(nw > 0, s_wt / np.where(nw > 0, nw, 1), 0.0)
+            WM = s_wt.sum() / NW
+        sct = np.sum(rows[:, 6] + 2 * (mu_c - M) * (s_t - n * mu_c) + n * (mu_c - M) ** 2)
+        scwt = np.sum(rows[:, 9] + 2 * (wmu_c - WM) * (s_wt - n * wmu_c) + n * (wmu_c - WM) ** 2)
+        return np.array([N, NW, s_t.sum(), s_wt.sum(), rows[:, 4].sum(), rows[:, 5].sum(), sct, rows[:, 7].sum(),
+                         rows[:, 8].sum(), scwt])
+
+    def _tables_from_sums(self, keys, st):
+        """(per-group table, *ALL table) of solver.py:391-405 from the (len(keys), 10) array of sums."""
         from pandas import DataFrame, MultiIndex
 
+        st = np.asarray(st, dtype=np.float64).reshape(len(keys), 10)
+        grouped = DataFrame(self._metrics_from_sums(*(st[:, k] for k in range(10))),
+                            index=MultiIndex.from_tuples(keys, names=["Groups", "Testing", "Row_Type"]))
+        # *ALL rows: pool the groups of one (Testing, Row_Type)
+        if self._all_idx is None or self._all_idx[0] is not keys:
+            subs = sorted({(k[1], k[2]) for k in keys})
+            self._all_idx = (keys, [(tk, np.array([i for i, k in enumerate(keys) if (k[1], k[2]) == tk])) for tk in subs])
+        sub = [tk for tk, _ in self._all_idx[1]]
+        pooled = np.array([self._pool_sums(st[idx]) for _, idx in self._all_idx[1]]).reshape(len(sub), 10)
+        allrows = DataFrame(self._metrics_from_sums(*(pooled[:, k] for k in range(10))),
+                            index=MultiIndex.from_tuples(sub, names=["Testing", "Row_Type"]))
+        return grouped, allrows
+
+    def _device_error_sums(self, a, b, w, shared, fs_dict):
+        """(sorted group keys, (len(keys), 10) sums) of the rows of THIS rank from fsnap_error_stats."""
         ctx = self._upload(a, np.asarray(b), shared)        # no copy when these rows are already resident
         ctx.set_weights(np.asarray(w, dtype=np.float64))
         cat, keys, fresh = self._row_categories(fs_dict, np.shape(a)[0])   # sorted group keys, position = category id
@@ -418,30 +450,25 @@ class Solver:
         except _capi.FsnapError:
             st = ctx.error_stats(beta, cat, len(keys))       # rows were replaced meanwhile: send the ids again
         self._cat_ctx = (id(ctx), getattr(ctx, "cat_serial", -1))
-        n, nw, s_t, s_wt = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
-        grouped = DataFrame(self._metrics_from_sums(n, nw, s_t, s_wt, st[:, 4], st[:, 5], st[:, 6], st[:, 7], st[:, 8], st[:, 9]),
-                            index=MultiIndex.from_tuples(keys, names=["Groups", "Testing", "Row_Type"]))
-        # *ALL rows: merge the groups of one (Testing, Row_Type); centred sums are re-centred on the pooled mean:
-        # sum (x - M)^2 = sum_c [ S_c + 2 (mu_c - M) (sum x_c - n_c mu_c) + n_c (mu_c - M)^2 ]
-        if self._all_idx is None or self._all_idx[0] is not keys:
-            subs = sorted({(k[1], k[2]) for k in keys})
-            self._all_idx = (keys, [(tk, np.array([i for i, k in enumerate(keys) if (k[1], k[2]) == tk])) for tk in subs])
-        sub = [tk for tk, _ in self._all_idx[1]]
-        rows = {name: [] for name in ("ncount", "mae", "rmse", "rsq", "w_ncount", "w_mae", "w_rmse", "w_rsq")}
-        for tk, idx in self._all_idx[1]:
-            N, NW = n[idx].sum(), nw[idx].sum()
-            with np.errstate(divide="ignore", invalid="ignore"):
-                mu_c, M = s_t[idx] / n[idx], s_t[idx].sum() / N
-                wmu_c = np.where(nw[idx] > 0, s_wt[idx] / np.where(nw[idx] > 0, nw[idx], 1), 0.0)
-                WM = s_wt[idx].sum() / NW
-            sct = np.sum(st[idx, 6] + 2 * (mu_c - M) * (s_t[idx] - n[idx] * mu_c) + n[idx] * (mu_c - M) ** 2)
-            scwt = np.sum(st[idx, 9] + 2 * (wmu_c - WM) * (s_wt[idx] - n[idx] * wmu_c) + n[idx] * (wmu_c - WM) ** 2)
-            mets = self._metrics_from_sums(N, NW, s_t[idx].sum(), s_wt[idx].sum(), st[idx, 4].sum(), st[idx, 5].sum(), sct,
-                                           st[idx, 7].sum(), st[idx, 8].sum(), scwt)
-            for name in rows:
-                rows[name].append(mets[name])
-        allrows = DataFrame(rows, index=MultiIndex.from_tuples(sub, names=["Testing", "Row_Type"]))
-        return grouped, allrows
+        return keys, st
+
+    def _device_error_tables(self, a, b, w, shared, fs_dict):
+        """(per-group table, *ALL table) of solver.py:391-405, built from fsnap_error_stats."""
+        keys, st = self._device_error_sums(a, b, w, shared, fs_dict)
+        return self._tables_from_sums(keys, st)
+
+    def _merge_rank_sums(self, parts):
+        """Multi-GPU error analysis: every rank reduced ITS rows to (keys, sums); the union over the ranks is the
+        table of all rows (a group may live on several ranks: its sums are pooled).  parts: [(keys, st), ...]."""
+        allkeys = sorted({k for keys, _ in parts for k in keys})
+        pos = {k: i for i, k in enumerate(allkeys)}
+        buckets = [[] for _ in allkeys]
+        for keys, st in parts:
+            st = np.asarray(st, dtype=np.float64).reshape(len(keys), 10)
+            for k, row in zip(keys, st):
+                buckets[pos[k]].append(row)
+        merged = np.array([self._pool_sums(np.array(rows)) for rows in buckets]).reshape(len(allkeys), 10)
+        return allkeys, merged
 
     @property
     def df(self):
@@ -567,6 +594,27 @@ class Solver:
                 local = pt.local_lists if getattr(pt, "local_lists", None) else pt.fitsnap_dict
             else:
                 local = fs_dict
+            # RCCL job with the rows resident on every rank's GPU: each rank reduces ITS rows to the (groups x 10)
+            # table of sums (fsnap_error_stats), only those tables travel, rank 0 pools them -- no per-row gather
+            # (the reference sees all rows on rank 0 through the node-shared array; SURVEY 8e: "reduce per-group
+            # error sums").  The per-row DataFrame is not built in this mode (EXTRAS dump_dataframe takes the gather).
+            if (self.device_error_stats and self.fit is not None and not self.config.sections["EXTRAS"].dump_dataframe
+                    and not self.config.sections["SOLVER"].true_multinode and pt._dist.get_backend(pt._group) == "nccl"):
+                part = self._device_error_sums(a, b, w, shared, local) if len(b) > 0 else ([], np.zeros((0, 10)))
+                parts = [None] * pt._size
+                pt._dist.all_gather_object(parts, part, group=pt._group)
+                if pt._rank != 0:
+                    self.fit = None
+                    return
+                self._df = None
+                self._df_parts = None
+                gkeys, gst = self._merge_rank_sums([q for q in parts if q is not None])
+                grouped, allrows = self._tables_from_sums(gkeys, gst)
+                self.errors = self._assemble_errors(grouped, allrows, None)
+                if (self.config.sections["CALCULATOR"].calculator == "LAMMPSSNAP"
+                        and "BISPECTRUM" in self.config.sections and self.config.sections["BISPECTRUM"].bzeroflag):
+                    self._offset()
+                return
             preds = (self.predict_rows() if shared else self.predict_rows(a, b)) if self.fit is not None else None
             n = len(b)
             piece = {"truths": np.asarray(b), "preds": preds, "weights": np.asarray(w),

@@ -654,7 +654,22 @@ def test_collective_path_on_one_gpu(ta, ta_fits):
         check_fit(s.fit, ta_fits["ridge_sklearn_1e-8_all"])
         G, c, sc = s.last_statistics
         stats_close(G, c, sc, *orc.normal_eq(A, b, w))
+        # error analysis through the collective branch: every rank reduces its rows to per-group sums on its GPU,
+        # the small tables are gathered and pooled on rank 0 -- same table as the single-process evaluation
+        m = len(b)
+        fsd = {"Groups": [f"g{(i // 43) % 5}" for i in range(m)], "Testing": [bool((i // 43) % 7 == 0) for i in range(m)],
+               "Row_Type": ["Energy"] * 363 + ["Force"] * 12672 + ["Stress"] * 2178}
+        fit = s.fit.copy()
+        s.error_analysis(A, b, w, fsd)
+        multi_errors = s.errors.copy()
         pt.free()
+        pt1, s1 = make_solver("RIDGE", {"RIDGE": {"alpha": 1e-8}})
+        s1.fit = fit
+        s1.device_error_stats = False                      # the reference's pandas evaluation of the GPU predictions
+        s1.error_analysis(A, b, w, fsd)
+        from pandas.testing import assert_frame_equal
+        assert_frame_equal(multi_errors, s1.errors, check_exact=False, rtol=1e-9, atol=1e-12)
+        pt1.free()
     finally:
         dist.destroy_process_group()
 

@@ -165,3 +165,55 @@ def test_cached_errors_table_layout_equals_the_pandas_pipeline():
     g2 = g.iloc[:-1]
     assert_frame_equal(s._assemble_errors(g2, a, None), s._assemble_errors(g2, a, keys2))
     pt.free()
+
+
+def _error_sums_numpy(t, p, w, cat, ncat):
+    """numpy statement of fsnap_error_stats (include/fsnap_hip.h): ten sums per category."""
+    out = np.zeros((ncat, 10))
+    for c in range(ncat):
+        s = cat == c
+        tt, rr, ww = t[s], t[s] - p[s], w[s]
+        n, nw = s.sum(), np.count_nonzero(ww)
+        mu = tt.mean() if n else 0.0
+        wmu = (ww * tt).sum() / nw if nw else 0.0
+        out[c] = [n, nw, tt.sum(), (ww * tt).sum(), np.abs(rr).sum(), (rr ** 2).sum(), ((tt - mu) ** 2).sum(),
+                  np.abs(ww * rr).sum(), ((ww * rr) ** 2).sum(), ((ww * tt - wmu) ** 2).sum()]
+    return out
+
+
+def test_rank_sums_pool_to_the_single_process_error_table():
+    # multi-GPU error analysis: every rank reduces its rows to (keys, sums); pooling them (groups may be split over
+    # ranks, ranks may miss groups) must give the table of all rows -- checked against the reference's own formulas
+    # (solver.py:108-133) applied to the whole DataFrame
+    import pandas as pd
+    from pandas.testing import assert_frame_equal
+
+    pt, cfg, s = make("RIDGE")
+    rng = np.random.default_rng(5)
+    m = 4000
+    truth = rng.standard_normal(m) * 3 + 1
+    pred = truth + 0.1 * rng.standard_normal(m)
+    w = rng.choice([0.0, 1.0, 25.0, 1e-3], size=m)
+    groups = rng.choice(["A", "B", "C", "D"], size=m)
+    testing = rng.random(m) < 0.2
+    rtype = rng.choice(["Energy", "Force", "Stress"], size=m)
+    owner = rng.integers(0, 3, size=m)
+    owner[groups == "D"] = 2                                   # a group that lives on one rank only
+    parts = []
+    for r in range(3):
+        sel = owner == r
+        df = pd.DataFrame({"Groups": groups[sel], "Testing": testing[sel], "Row_Type": rtype[sel]})
+        gb = df.groupby(["Groups", "Testing", "Row_Type"], sort=True)
+        keys = list(gb.size().index)
+        cat = gb.ngroup().to_numpy()
+        parts.append((keys, _error_sums_numpy(truth[sel], pred[sel], w[sel], cat, len(keys))))
+    gkeys, gst = s._merge_rank_sums(parts)
+    grouped, allrows = s._tables_from_sums(gkeys, gst)
+    got = s._assemble_errors(grouped, allrows, None)
+    full = pd.DataFrame({"truths": truth, "preds": pred, "weights": w, "Groups": groups, "Testing": testing, "Row_Type": rtype})
+    fn = s._ncount_mae_rmse_rsq_unweighted_and_weighted
+    g_ref = full.groupby(["Groups", "Testing", "Row_Type"])[["truths", "preds", "weights"]].apply(fn)
+    a_ref = full.groupby(["Testing", "Row_Type"])[["truths", "preds", "weights"]].apply(fn)
+    want = s._assemble_errors(g_ref, a_ref, None)
+    assert_frame_equal(got, want, check_exact=False, rtol=1e-10, atol=1e-12)
+    pt.free()
