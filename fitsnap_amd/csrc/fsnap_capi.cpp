@@ -80,7 +80,9 @@ struct fsnap_ctx {
     bool wpack_valid = false;                     // false after anything that can change b, w or the mask
     int64_t dcat_rows = -1;                       // number of rows the categories on the device belong to
     DevBuf du, dspart, dsvec;                     // refinement: row weights u, per-workgroup partials, s
-    double* pinned = nullptr;                     // page-locked host staging of the packed statistics
+    double* pinned = nullptr;                     // page-locked host staging of the packed statistics: plain (coarse-grained)
+                                                  // pinned memory, the target of DMA copies only -- copies into COHERENT
+                                                  // host memory were bimodal (2 MB in 0.05 or in 8 ms)
     size_t pinned_bytes = 0;
     double* mirror = nullptr;                     // page-locked host mirror written by the reduction kernel itself
     size_t mirror_bytes = 0;
@@ -1114,7 +1116,7 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
             if (ctx->pinned) (void)hipHostFree(ctx->pinned);
             ctx->pinned = nullptr;
             ctx->pinned_bytes = 0;
-            if (hipHostMalloc((void**)&ctx->pinned, head * 8, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess)
+            if (hipHostMalloc((void**)&ctx->pinned, head * 8, hipHostMallocDefault) != hipSuccess)
                 return ctx->fail(FSNAP_E_NOMEM, "hipHostMalloc(%zu) failed", head * 8);
             ctx->pinned_bytes = head * 8;
         }
@@ -1168,7 +1170,7 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
         ctx->pinned = nullptr;
         ctx->pinned_bytes = 0;
-        if (hipHostMalloc((void**)&ctx->pinned, need, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess)
+        if (hipHostMalloc((void**)&ctx->pinned, need, hipHostMallocDefault) != hipSuccess)
             return ctx->fail(FSNAP_E_NOMEM, "hipHostMalloc(%zu) failed", need);
         ctx->pinned_bytes = need;
     }

@@ -654,7 +654,10 @@ extern "C" __attribute__((visibility("hidden"))) int fsnap_solve_diag(int kind, 
         // The register-blocked factorisation works on 32-column chunks; a partial last chunk runs a much slower
         // remainder path (K = 184: 0.30 ms, K = 192: 0.12 ms).  So the scaled matrix is padded to a multiple of 32 with
         // an identity block (pivots 1, solution components 0): Kp = leading dimension and order of the padded system.
-        const int Kp = (K >= 48 && (K & 31) != 0) ? ((K + 31) & ~31) : K;
+        int Kp = (K >= 48 && (K & 31) != 0) ? ((K + 31) & ~31) : K;
+        // a row stride that is a multiple of 1 KiB maps the rows of a column onto a few cache sets: on the MI355X
+        // hosts K = 512 took 0.9 or 8.9 ms depending on the physical pages of the run -- one more chunk of padding
+        if (Kp >= 384 && (Kp & 127) == 0) Kp += 32;
         static thread_local vec U, dsc, z;
         U.resize((size_t)Kp * Kp);
         dsc.resize(Kp);
