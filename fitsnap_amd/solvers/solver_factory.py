@@ -1,26 +1,17 @@
-"""Solver factory: same discovery rule as the reference
-(fitsnap3lib/solvers/solver_factory.py:18-34): any imported subclass of ``Solver`` whose
-class name equals ``[SOLVER] solver`` case-insensitively; created with ``Solver.__new__``
-then ``__init__(name, pt, config)``; unknown name -> IndexError."""
+"""Solver factory with the reference's discovery rule (fitsnap3lib/solvers/solver_factory.py:18-34): any imported
+direct subclass of ``Solver`` whose class name equals ``[SOLVER] solver`` case-insensitively; unknown name ->
+IndexError.  The imports below are the registration."""
+from .._discovery import find_plugin
 from .solver import Solver
-from .anl import ANL  # noqa: F401
-from .ard import ARD  # noqa: F401  (import = registration, as in the reference)
-from .ridge import RIDGE  # noqa: F401
-from .svd import SVD  # noqa: F401
+from . import anl, ard, ridge, svd  # noqa: F401  (ANL, ARD, RIDGE, SVD)
+
+
+def search(solver_name):
+    return find_plugin(Solver, solver_name, 1, "solvers")
 
 
 def solver(solver_name, pt, cfg):
     """Solver Factory"""
-    instance = search(solver_name)
-    instance.__init__(solver_name, pt, cfg)
-    return instance
-
-
-def search(solver_name):
-    instance = None
-    for cls in Solver.__subclasses__():
-        if cls.__name__.lower() == solver_name.lower():
-            instance = Solver.__new__(cls)
-    if instance is None:
-        raise IndexError("{} was not found in fitsnap solvers".format(solver_name))
-    return instance
+    obj = search(solver_name)
+    obj.__init__(solver_name, pt, cfg)
+    return obj
