@@ -25,18 +25,13 @@ class SVD(Solver):
         self.refine_steps = 2
 
     def perform_fit(self, a=None, b=None, w=None, fs_dict=None, trainall=False):
-        """
-        Perform fit on a linear system. If no args are supplied, will use fitting data in `pt.shared_arrays`.
+        """Weighted least-squares fit; same call contract as the reference (svd.py:18-54).
 
-        Args:
-            a (np.array): Optional "A" matrix.
-            b (np.array): Optional Truth array.
-            w (np.array): Optional Weight array (one entry per TRAINING row, as in the reference).
-            fs_dict (dict): Optional dictionary containing a `Testing` key of which A matrix rows should not be trained.
-            trainall (bool): Optional boolean declaring whether to train on all samples in the A matrix.
-
-        The fit is stored as a member `fs.solver.fit` (rank 0 only).
-        """
+        With no arguments the rows come from ``pt.shared_arrays['a' | 'b' | 'w']`` and the training mask from
+        ``pt.fitsnap_dict['Testing']``.  Otherwise ``a`` (m x K), ``b`` (m) and ``w`` are used, where ``w`` holds one
+        weight per TRAINING row; the rows to leave out are taken from ``fs_dict['Testing']`` if a dictionary is
+        given, and nothing is left out if ``trainall`` is set (precedence: fs_dict, trainall, pt.fitsnap_dict).
+        Collective in a multi-rank job; the coefficients end up in ``self.fit`` on rank 0 only."""
         pt = self.pt
         # every rank contributes its rows' statistics; only rank 0 solves (svd.py:33)
         if not ("EXTRAS" in self.config.sections and self.config.sections["EXTRAS"].apply_transpose):
