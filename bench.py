@@ -106,7 +106,7 @@ def main():
     import torch.distributed as dist
 
     from fitsnap_amd import _capi
-    from oracle import fitsnap_oracle as orc   # synthetic workload generator (shared with the tests)
+    from fitsnap_amd.synthetic import synth_problem   # input data; oracle/ is imported by the cpu_baseline leg only
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -125,7 +125,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     m, Kc = args.rows, args.cols
-    A, b, w = orc.synth_problem(m, Kc, row_offset=rank * RANK_ROW_STRIDE)
+    A, b, w = synth_problem(m, Kc, row_offset=rank * RANK_ROW_STRIDE)
 
     ctx = _capi.HipContext(local_rank)
     for kv in args.option:

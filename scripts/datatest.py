@@ -2,7 +2,7 @@
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
 from fitsnap_amd import _capi
-from oracle import fitsnap_oracle as orc
+from fitsnap_amd import synthetic as orc  # input data only
 m, K = 1000000, 128
 dev = torch.device("cuda", 0)
 ctx = _capi.HipContext(0)

@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 from fitsnap_amd.config import Config
 from fitsnap_amd.parallel_tools import ParallelTools
 from fitsnap_amd.solvers import solver_factory
-from oracle import fitsnap_oracle as orc
+from fitsnap_amd import synthetic as orc  # input data only
 
 for m, K, ngroups in ((15213, 31, 12), (1000000, 128, 40)):
     A, b, w = orc.synth_problem(m, K)

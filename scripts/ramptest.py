@@ -2,7 +2,7 @@
 import sys, time, numpy as np, torch
 sys.path.insert(0, ".")
 from fitsnap_amd import _capi
-from oracle import fitsnap_oracle as orc
+from fitsnap_amd import synthetic as orc  # input data only
 A, b, w = orc.synth_problem(1000000, 128)
 ctx = _capi.HipContext(0); ctx.upload_rows(A, b); ctx.set_weights(w)
 torch.cuda.synchronize()
