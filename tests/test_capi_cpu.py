@@ -147,3 +147,20 @@ def test_host_cholesky_variants_agree(env):
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=e)
     assert out.returncode == 0, out.stderr
     assert float(out.stdout.strip()) < 1e-9
+
+
+@pytest.mark.parametrize("K", [1, 7, 31, 47, 48, 49, 63, 96, 110, 127, 128, 129, 142, 184, 200, 255, 256, 300, 383, 384, 400, 512, 520])
+def test_host_solve_padding_is_transparent(K):
+    # fsnap_solve pads the Jacobi-scaled matrix to a multiple of 32 columns (and past row strides that are multiples of
+    # 1 KiB) with an identity block: every K must give the dense solution, for every kind of solve
+    rng = np.random.default_rng(9000 + K)
+    A = rng.standard_normal((3 * K + 5, K)) * (10.0 ** rng.uniform(-3, 3, K))
+    G = A.T @ A
+    c = A.T @ rng.standard_normal(3 * K + 5)
+    for kind, param, alpha in ((_capi.SOLVE_RIDGE, 1e-8, 1e-8), (_capi.SOLVE_LSTSQ, 1e-13, 0.0), (_capi.SOLVE_CHOL, 0.0, 0.0),
+                               (_capi.SOLVE_RIDGE_INV, 1e-6, 1e-6)):
+        beta, rank, rcond = _capi.solve(kind, param, G, c)
+        d = 1.0 / np.sqrt(np.diag(G) + alpha)                      # reference: dense solve of the equilibrated system
+        ref = d * np.linalg.solve((G + alpha * np.eye(K)) * d[:, None] * d[None, :], c * d)
+        assert rank == K
+        assert np.linalg.norm(beta - ref) / np.linalg.norm(ref) < 1e-8, (K, kind)
