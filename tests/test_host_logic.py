@@ -217,3 +217,27 @@ def test_rank_sums_pool_to_the_single_process_error_table():
     want = s._assemble_errors(g_ref, a_ref, None)
     assert_frame_equal(got, want, check_exact=False, rtol=1e-10, atol=1e-12)
     pt.free()
+
+
+def test_pooling_error_sums_is_independent_of_the_partition():
+    # the ten sums of a row set pooled from ANY partition of it must agree (that is what makes the multi-GPU error
+    # table independent of how the configurations were dealt to the ranks)
+    pt, cfg, s = make("RIDGE")
+    rng = np.random.default_rng(77)
+    n = 3000
+    t = rng.standard_normal(n) * 5 - 2
+    p = t + rng.standard_normal(n) * 0.3
+    w = rng.choice([0.0, 0.5, 3.0, 40.0], size=n)
+    whole = _error_sums_numpy(t, p, w, np.zeros(n, dtype=int), 1)[0]
+    for parts in (2, 3, 7, 50):
+        owner = rng.integers(0, parts, size=n)
+        rows = np.array([_error_sums_numpy(t[owner == r], p[owner == r], w[owner == r], np.zeros((owner == r).sum(), dtype=int), 1)[0]
+                         for r in range(parts) if (owner == r).any()])
+        pooled = s._pool_sums(rows)
+        assert np.allclose(pooled, whole, rtol=1e-11, atol=1e-9), parts
+        # pooling in two stages gives the same again
+        half = len(rows) // 2
+        if half:
+            two = s._pool_sums(np.array([s._pool_sums(rows[:half]), s._pool_sums(rows[half:])]))
+            assert np.allclose(two, whole, rtol=1e-11, atol=1e-9)
+    pt.free()
