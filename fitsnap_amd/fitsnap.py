@@ -30,6 +30,10 @@ class FitSnap:
             from .io.outputs.snap import Snap
 
             self.output = Snap("SNAP", self.pt, self.config)
+        elif self.config.sections["CALCULATOR"].calculator.upper() == "LAMMPSPACE" and "ACE" in self.config.sections:
+            from .io.outputs.pace import Pace
+
+            self.output = Pace("PACE", self.pt, self.config)
         self.data = []
         self.fit = None
 

@@ -1,0 +1,55 @@
+"""ACE potential writer: ``<potential>.acecoeff`` in the reference's text layout
+(fitsnap3lib/io/outputs/pace.py:187-208), so that the reference's own checker (tests/example_checker.py:94-103:
+``ndescs = int(lines[2].split()[-1]); float(lines[4 + i].split()[0])``) reads our file.
+
+The basis-function labels after ``#  B`` come from the ACE basis enumeration of the reference
+(fitsnap3lib/lib/sym_ACE), which is outside this repository's scope: without them the functions are numbered.  For the
+same reason the ``.yace`` potential file, which needs the coupling coefficients of that basis, is not written here."""
+from __future__ import annotations
+
+from datetime import datetime
+
+import numpy as np
+
+from .snap import Snap
+
+
+def to_acecoeff_string(config, coeffs, names=None):
+    ace = config.sections["ACE"]
+    numtypes = ace.numtypes
+    table = np.asarray(coeffs, dtype=np.float64).reshape((numtypes, -1))
+    scale = np.asarray(ace.blank2J, dtype=np.float64).reshape((numtypes, -1))
+    table = table * scale
+    per_type = table.shape[1]
+    if names is None:
+        names = getattr(ace, "blist", None)
+        if names is not None and not ace.bzeroflag:
+            names = [[0]] + list(names)
+    if names is None:
+        names = [[i] for i in range(per_type)]
+    lines = [f"# FitSNAP generated on {datetime.now()} with Hash: {getattr(config, 'hash', '')}", "",
+             "{} {}".format(len(ace.types), per_type)]
+    for element, row in zip(ace.types, table):
+        lines.append(str(element))
+        lines.extend(f" {value:<30.18} #  B{label} " for value, label in zip(row, names))
+    lines.extend(["", "# End of potential"])
+    return "\n".join(lines)
+
+
+def parse_acecoeff(path):
+    """The reference test-suite's reader (tests/example_checker.py:94-103), restated."""
+    with open(path) as f:
+        lines = f.readlines()
+    count = int(lines[2].split()[-1])
+    return np.array([float(lines[4 + i].split()[0]) for i in range(count)])
+
+
+class Pace(Snap):
+    """[CALCULATOR] calculator = LAMMPSPACE output plugin (pace.py:17-64): coefficients + the metrics table."""
+
+    def write_lammps(self, coeffs):
+        if self.config.sections["CALCULATOR"].calculator.upper() != "LAMMPSPACE":
+            raise TypeError("PACE output style must be paired with LAMMPSPACE calculator")
+        name = self.config.sections["OUTFILE"].potential_name
+        with open(f"{name}.acecoeff", "w") as f:
+            f.write(to_acecoeff_string(self.config, coeffs))

@@ -85,3 +85,55 @@ def test_multi_type_bzero_coefficients_layout():
     lines = to_coeff_string(cfg, coeffs).splitlines()
     assert lines[2] == f"2 {n + 1}" and lines[3] == "W 0.5 1.0" and lines[3 + n + 2] == "Be 0.4 0.9"
     assert float(lines[4].split()[0]) == 1.0 and "B[0]" in lines[4]
+
+
+ACE_IN = """[ACE]
+numTypes = 1
+type = Ta
+ncoeff = 141
+bzeroflag = 0
+
+[CALCULATOR]
+calculator = LAMMPSPACE
+energy = 1
+force = 1
+stress = 0
+
+[SOLVER]
+solver = RIDGE
+
+[RIDGE]
+alpha = 1.0e-4
+local_solver = 1
+
+[OUTFILE]
+metrics = Ta_metrics.md
+potential = Ta_pot
+"""
+
+
+def test_acecoeff_text_is_readable_by_the_reference_checker(tmp_path):
+    # fitsnap3lib/io/outputs/pace.py:187-208 layout; the reference's tests read it with
+    # example_checker._pace_parser (ndescs = int(lines[2].split()[-1]); float(lines[4 + i].split()[0]))
+    from fitsnap_amd.io.outputs.pace import Pace, parse_acecoeff, to_acecoeff_string
+
+    ini = tmp_path / "ace.in"
+    ini.write_text(ACE_IN)
+    pt = ParallelTools()
+    cfg = Config(pt, str(ini), arguments_lst=["--overwrite"])
+    coeffs = np.random.default_rng(3).standard_normal(142) * 10.0 ** np.random.default_rng(4).uniform(-6, 2, 142)
+    text = to_acecoeff_string(cfg, coeffs)
+    lines = text.split("\n")
+    assert lines[0].startswith("# FitSNAP generated on ") and lines[1] == "" and lines[2] == "1 142" and lines[3] == "Ta"
+    assert lines[-1] == "# End of potential" and len(lines) == 4 + 142 + 2
+    # same number formatting as the reference's f" {bval:<30.18} #  B{bname} "
+    assert lines[4] == f" {coeffs[0]:<30.18} #  B[0] "
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        Pace("PACE", pt, cfg).write_lammps(coeffs)
+        back = parse_acecoeff("Ta_pot.acecoeff")
+    finally:
+        os.chdir(cwd)
+    assert back.shape == (142,) and np.array_equal(back, np.array([float(f"{c:.18}") for c in coeffs]))
+    pt.free()
