@@ -233,16 +233,29 @@ class Config:
             bzero = _get(bi, "bzeroflag", "0", "bool")
             types = _get(bi, "type", "H", "str").split()
             chem = _get(bi, "chemflag", "0", "bool")
+            blank2j = snap_blank2j(numtypes, twojmax, quad, bzero)
+            blist = snap_blist(numtypes, twojmax, quad)
             if chem:
-                raise NotImplementedError("chemflag (explicit multi-element SNAP) is not supported by this build")
+                # explicit multi-element (EME) model, bispectrum.py:104-110, 127-134: every component exists once per
+                # ordered element triple -> numTypes^3 times the descriptors per type; LAMMPS gets "N e0 e1 ..."
+                if quad:
+                    raise ValueError("Quadratic chemsnap not impelemented.")
+                if min(twojmax) != max(twojmax):
+                    raise RuntimeError("Still working on the capability to do mixed 2J values per-element and explicit "
+                                       "multi-element descriptors \n Aborting...!")
+                blist = blist * numtypes ** 3
+                ncoeff = len(blist) // numtypes
+                import numpy as _np
+                blank2j = _np.ones(numtypes * (ncoeff + (0 if bzero else 1)))
+                chem = " ".join([str(numtypes)] + [str(i) for i in range(len(types))])
             self.sections["BISPECTRUM"] = SimpleNamespace(
                 name="BISPECTRUM", numtypes=numtypes, twojmax=twojmax, ncoeff=ncoeff,
                 bzeroflag=bzero, quadraticflag=quad, types=types,
                 type_mapping={t: i + 1 for i, t in enumerate(types)},      # bispectrum.py:29-37
                 bikflag=_get(bi, "bikflag", "0", "bool"), chemflag=chem,
                 wselfallflag=_get(bi, "wselfallflag", "0", "bool"),
-                blank2J=snap_blank2j(numtypes, twojmax, quad, bzero),
-                blist=snap_blist(numtypes, twojmax, quad),
+                blank2J=blank2j,
+                blist=blist,
                 rcutfac=_get(bi, "rcutfac", "4.67637", "float"), rfac0=_get(bi, "rfac0", "0.99363", "float"),
                 rmin0=_get(bi, "rmin0", "0.0", "float"), bnormflag=_get(bi, "bnormflag", "0", "bool"),
                 switchinnerflag=_get(bi, "switchinnerflag", "0", "bool"),

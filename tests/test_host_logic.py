@@ -241,3 +241,26 @@ def test_pooling_error_sums_is_independent_of_the_partition():
             two = s._pool_sums(np.array([s._pool_sums(rows[:half]), s._pool_sums(rows[half:])]))
             assert np.allclose(two, whole, rtol=1e-11, atol=1e-9)
     pt.free()
+
+
+def test_chemflag_descriptor_count_matches_reference(tmp_path):
+    # explicit multi-element SNAP (bispectrum.py:104-110, 127-134): numTypes^3 x the per-type descriptors;
+    # InP_JPCA2020: 2 types, 2J = 6 -> 30 * 8 = 240 per type, A matrix 480 wide with bzeroflag = 1
+    ini = tmp_path / "eme.in"
+    body = ("[BISPECTRUM]\nnumTypes = 2\ntwojmax = 6 6\ntype = In P\nwj = 1.0 0.5\nradelem = 0.5 0.4\nchemflag = 1\n"
+            "bzeroflag = {bz}\n\n[CALCULATOR]\ncalculator = LAMMPSSNAP\n\n[SOLVER]\nsolver = SVD\n")
+    pt = ParallelTools()
+    ini.write_text(body.format(bz=1))
+    bis = Config(pt, str(ini), arguments_lst=["--overwrite"]).sections["BISPECTRUM"]
+    assert bis.ncoeff == 240 and len(bis.blist) == 480 and bis.blank2J.shape == (480,) and bis.blank2J.all()
+    assert bis.chemflag == "2 0 1" and bis.blist[0] == [1, 0, 0, 0] and bis.blist[30] == bis.blist[0]
+    ini.write_text(body.format(bz=0))
+    bis = Config(pt, str(ini), arguments_lst=["--overwrite"]).sections["BISPECTRUM"]
+    assert bis.ncoeff == 240 and bis.blank2J.shape == (482,)
+    ini.write_text(body.format(bz=0).replace("twojmax = 6 6", "twojmax = 6 4"))
+    with pytest.raises(RuntimeError):
+        Config(pt, str(ini), arguments_lst=["--overwrite"])
+    ini.write_text(body.format(bz=0) .replace("chemflag = 1", "chemflag = 1\nquadraticflag = 1"))
+    with pytest.raises(ValueError):
+        Config(pt, str(ini), arguments_lst=["--overwrite"])
+    pt.free()
