@@ -1923,18 +1923,56 @@ fsnap_syrk_tiled2(const double* __restrict__ A, int64_t lda, const double* __res
     }
 }
 
+// G element idx of the tiled partial layout (pair, tile, register, lane) -> its place(s) in the packed buffer
+__device__ __forceinline__ void reduce_tiled_store_g(int64_t idx, double tot, int NSB, int K, double* __restrict__ out,
+                                                     int accumulate) {
+    const int pair = (int)(idx >> 12), rem = (int)(idx & 4095);
+    const int t = rem >> 8, i = (rem >> 6) & 3, ln = rem & 63;
+    int I = 0, pr = pair;
+    while (pr >= NSB - I) {
+        pr -= NSB - I;
+        ++I;
+    }
+    const int J = I + pr;
+    const int p = t >> 2, q = t & 3;
+    if (I == J && q < p) return;  // unused slots of a diagonal pair
+    const int ep = (ln >> 4) + 4 * i, eq = ln & 15;
+    const int r = 64 * I + 32 * (p >> 1) + 2 * ep + (p & 1);
+    const int c = 64 * J + 32 * (q >> 1) + 2 * eq + (q & 1);
+    if (r < K && c < K) {
+        const double val = accumulate ? out[(int64_t)r * K + c] + tot : tot;
+        out[(int64_t)r * K + c] = val;
+        if (!(I == J && p == q)) out[(int64_t)c * K + r] = val;
+    }
+}
+
+// Few row splits (<= 16, the usual case for wide matrices): one thread per G element sums its partials in order --
+// the same order and therefore the same bits as the sliced kernel below, which for <= 16 partials keeps 15 of its 16
+// slices idle (K = 1595, 3 splits: 55 us for 52 MB).  c and the scalars stay with the sliced kernel (idx0 = nG).
+__global__ __launch_bounds__(256) void fsnap_reduce_tiled_small(const double* __restrict__ part, int nsplit, int NSB,
+                                                                int npairs, int K, double* __restrict__ out,
+                                                                int accumulate) {
+    const int64_t nG = (int64_t)npairs * 4096;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nG) return;
+    double tot = 0.0;
+    for (int p = 0; p < nsplit; ++p) tot += part[(int64_t)p * nG + idx];
+    reduce_tiled_store_g(idx, tot, NSB, K, out, accumulate);
+}
+
 // Reduction of the tiled partials into the packed buffer (same output as kernel 2).
 // Element space: npairs*16*256 G elements (nsplit partials each), NSB*64 c elements and
 // 4 scalars (nsplit*4 partials each).  1024 threads = 64 elements x 16 partial slices.
 __global__ __launch_bounds__(1024) void fsnap_reduce_tiled(const double* __restrict__ part,
                                                            const double* __restrict__ cpart,
                                                            const double* __restrict__ spart, int ns, int nsplit, int NSB,
-                                                           int npairs, int K, double* __restrict__ out, int accumulate) {
+                                                           int npairs, int K, double* __restrict__ out, int accumulate,
+                                                           int64_t idx0) {
     __shared__ double red[1024];
     const int64_t nG = (int64_t)npairs * 4096;
     const int nC = NSB * 64, nS = 4;
     const int tid = threadIdx.x, g = tid >> 6, l = tid & 63;
-    const int64_t idx = (int64_t)blockIdx.x * 64 + l;
+    const int64_t idx = idx0 + (int64_t)blockIdx.x * 64 + l;      // idx0: first element of this launch
     const double* src = nullptr;
     int64_t stride = 0;
     int np = 0;
@@ -1980,24 +2018,7 @@ __global__ __launch_bounds__(1024) void fsnap_reduce_tiled(const double* __restr
 #pragma unroll
         for (int k = 0; k < 16; ++k) tot += red[k * 64 + l];
         if (idx < nG) {
-            const int pair = (int)(idx >> 12), rem = (int)(idx & 4095);
-            const int t = rem >> 8, i = (rem >> 6) & 3, ln = rem & 63;
-            int I = 0, pr = pair;
-            while (pr >= NSB - I) {
-                pr -= NSB - I;
-                ++I;
-            }
-            const int J = I + pr;
-            const int p = t >> 2, q = t & 3;
-            if (I == J && q < p) return;  // unused slots of a diagonal pair
-            const int ep = (ln >> 4) + 4 * i, eq = ln & 15;
-            const int r = 64 * I + 32 * (p >> 1) + 2 * ep + (p & 1);
-            const int c = 64 * J + 32 * (q >> 1) + 2 * eq + (q & 1);
-            if (r < K && c < K) {
-                const double val = accumulate ? out[(int64_t)r * K + c] + tot : tot;
-                out[(int64_t)r * K + c] = val;
-                if (!(I == J && p == q)) out[(int64_t)c * K + r] = val;
-            }
+            reduce_tiled_store_g(idx, tot, NSB, K, out, accumulate);
         } else if (idx < nG + nC) {
             const int j = (int)(idx - nG);
             const int Ib = j >> 6, bq = (j >> 4) & 3, e = j & 15;
@@ -2268,10 +2289,18 @@ hipError_t launch_syrk_tiled2(const TiledArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_reduce_tiled(const TiledArgs& a, double* out, bool accumulate, hipStream_t st) {
-    const int64_t nelem = (int64_t)a.npairs * 4096 + a.NSB * 64 + 4;
+    const int64_t nG = (int64_t)a.npairs * 4096, nrest = a.NSB * 64 + 4;
+    if (a.nsplit <= 16) {
+        hipLaunchKernelGGL(fsnap_reduce_tiled_small, dim3((unsigned)((nG + 255) / 256)), dim3(256), 0, st, a.part, a.nsplit, a.NSB,
+                           a.npairs, a.K, out, accumulate ? 1 : 0);
+        hipLaunchKernelGGL(fsnap_reduce_tiled, dim3((unsigned)((nrest + 63) / 64)), dim3(1024), 0, st, a.part, a.cpart, a.spart, a.ns,
+                           a.nsplit, a.NSB, a.npairs, a.K, out, accumulate ? 1 : 0, nG);
+        return hipGetLastError();
+    }
+    const int64_t nelem = nG + nrest;
     dim3 grid((unsigned)((nelem + 63) / 64)), block(1024);
     hipLaunchKernelGGL(fsnap_reduce_tiled, grid, block, 0, st, a.part, a.cpart, a.spart, a.ns, a.nsplit, a.NSB, a.npairs, a.K,
-                       out, accumulate ? 1 : 0);
+                       out, accumulate ? 1 : 0, (int64_t)0);
     return hipGetLastError();
 }
 
