@@ -22,7 +22,6 @@ A section that belongs to an un-selected solver raises UserWarning like the refe
 from __future__ import annotations
 
 import configparser
-import warnings
 from types import SimpleNamespace
 
 _BOOL_TRUE = {"1", "true", "yes", "on"}

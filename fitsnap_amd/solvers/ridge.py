@@ -2,8 +2,6 @@
 fitsnap3lib/lib/ridge_solver/regressor.py:4-21)."""
 from __future__ import annotations
 
-import numpy as np
-
 from .. import _capi
 from .solver import Solver
 
