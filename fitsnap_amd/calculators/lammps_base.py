@@ -13,21 +13,22 @@ from .calculator import Calculator
 
 
 def _extract_compute_np(lmp, name, compute_style, result_type, array_shape=None):
-    """Wrap a LAMMPS compute as an ndarray VIEW of LAMMPS' own memory, no copy
-    (lammps_base.py:280-307): style 0 global / type 2 array -> ``double**`` whose rows are
-    one contiguous row-major block."""
+    """ndarray VIEW (no copy) of a LAMMPS compute; same call contract as the reference helper
+    (lammps_base.py:280-307).  Without ``array_shape`` LAMMPS' own numpy wrapper decides the shape; with it the
+    raw pointer is wrapped: a scalar (type 0) is returned as is, a vector (type 1) is a ``double*``, an array
+    (type 2) a ``double**`` whose first row pointer addresses ONE contiguous row-major block -- the layout
+    ``fsnap_assemble`` consumes."""
     if array_shape is None:
         return lmp.numpy.extract_compute(name, compute_style, result_type)
-    ptr = lmp.extract_compute(name, compute_style, result_type)
+    handle = lmp.extract_compute(name, compute_style, result_type)
     if result_type == 0:
-        return ptr
-    if result_type == 2:
-        ptr = ptr.contents
-    total_size = int(np.prod(array_shape))
-    buffer_ptr = ctypes.cast(ptr, ctypes.POINTER(ctypes.c_double * total_size))
-    array_np = np.frombuffer(buffer_ptr.contents, dtype=float)
-    array_np.shape = array_shape
-    return array_np
+        return handle
+    first = handle.contents if result_type == 2 else handle
+    shape = tuple(int(n) for n in np.atleast_1d(array_shape))
+    count = int(np.prod(shape))
+    address = ctypes.addressof(first.contents) if hasattr(first, "contents") else ctypes.cast(first, ctypes.c_void_p).value
+    block = (ctypes.c_double * count).from_address(address)
+    return np.ctypeslib.as_array(block).reshape(shape)
 
 
 class LammpsBase(Calculator):

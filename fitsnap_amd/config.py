@@ -221,6 +221,9 @@ class Config:
 
         if "BISPECTRUM" in raw:
             bi = raw["BISPECTRUM"]
+            _check_keys("BISPECTRUM", bi, ["numTypes", "twojmax", "rcutfac", "rfac0", "rmin0", "wj", "radelem", "type",
+                                           "wselfallflag", "chemflag", "bzeroflag", "quadraticflag", "bnormflag", "bikflag",
+                                           "switchinnerflag", "switchflag", "sinner", "dinner", "dgradflag"])
             numtypes = _get(bi, "numTypes", "1", "int")
             twojmax = [int(x) for x in _get(bi, "twojmax", "6", "str").split()]
             if len(twojmax) == 1:
@@ -247,6 +250,15 @@ class Config:
                 import numpy as _np
                 blank2j = _np.ones(numtypes * (ncoeff + (0 if bzero else 1)))
                 chem = " ".join([str(numtypes)] + [str(i) for i in range(len(types))])
+            # inner cutoff switching (bispectrum.py:55-63): one sinner / dinner value per type, kept as the strings
+            # that go into the .snapparam file
+            inner = _get(bi, "switchinnerflag", "0", "bool")
+            sinner = dinner = None
+            if inner:
+                sinner = _get(bi, "sinner", " ".join(["0.9"] * numtypes), "str")
+                dinner = _get(bi, "dinner", " ".join(["0.1"] * numtypes), "str")
+                if len(sinner.split()) != numtypes or len(dinner.split()) != numtypes:
+                    raise ValueError("Number of sinner/dinner args must be number of types.")
             self.sections["BISPECTRUM"] = SimpleNamespace(
                 name="BISPECTRUM", numtypes=numtypes, twojmax=twojmax, ncoeff=ncoeff,
                 bzeroflag=bzero, quadraticflag=quad, types=types,
@@ -257,7 +269,7 @@ class Config:
                 blist=blist,
                 rcutfac=_get(bi, "rcutfac", "4.67637", "float"), rfac0=_get(bi, "rfac0", "0.99363", "float"),
                 rmin0=_get(bi, "rmin0", "0.0", "float"), bnormflag=_get(bi, "bnormflag", "0", "bool"),
-                switchinnerflag=_get(bi, "switchinnerflag", "0", "bool"),
+                switchinnerflag=inner, sinner=sinner, dinner=dinner,
                 wj=[float(x) for x in _get(bi, "wj", "1.0", "str").split()],
                 radelem=[float(x) for x in _get(bi, "radelem", "0.5", "str").split()])
         if "ACE" in raw:

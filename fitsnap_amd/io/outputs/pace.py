@@ -11,7 +11,7 @@ from datetime import datetime
 
 import numpy as np
 
-from .snap import Snap
+from .snap import Snap, potential_mod_text
 
 
 def to_acecoeff_string(config, coeffs, names=None):
@@ -37,27 +37,11 @@ def to_acecoeff_string(config, coeffs, names=None):
 
 
 def to_potential_mod_string(config):
-    """LAMMPS include file ``<potential>.mod`` naming the pair style (pace.py:211-246): ``pace product`` alone, or
-    appended to the non-zero parts of a hybrid reference potential (its ``zero <cutoff>`` entry and the pair_coeff
-    lines of the zero style are dropped); the ACE pair_coeff line lists the element names."""
-    ref = config.sections.get("REFERENCE")
-    declared = list(ref.lmp_pairdecl) if ref is not None else ["pair_style zero 10.0"]
-    style = declared[0]
+    """``<potential>.mod`` of an ACE fit (pace.py:211-246): style ``pace product``, the pair_coeff line names the
+    ``.yace`` file and the elements."""
     stem = config.sections["OUTFILE"].potential_name.split("/")[-1]
     elements = "".join(f" {t}" for t in config.sections["ACE"].types)
-    text = "# This file was generated by FitSNAP.\n" + f"# Hash: {getattr(config, 'hash', '')}\n\n"
-    if "hybrid" in style:
-        words = style.split()
-        if "zero" in words:
-            at = words.index("zero")
-            del words[at:at + 2]                    # the style name and its cutoff
-        text += " ".join(words) + " pace product\n"
-        text += "".join(f"{line}\n" for line in declared[1:] if "zero" not in line)
-        text += f"pair_coeff * * pace {stem}.yace" + elements
-    else:
-        text += "pair_style pace product\n"
-        text += f"pair_coeff * * {stem}.yace" + elements
-    return text
+    return potential_mod_text(config, "pace product", f"{stem}.yace" + elements)
 
 
 def parse_acecoeff(path):

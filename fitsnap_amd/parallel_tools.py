@@ -24,8 +24,9 @@ underneath:
 """
 from __future__ import annotations
 
+import functools
 from copy import deepcopy
-from time import time
+from time import perf_counter, time
 
 import numpy as np
 
@@ -40,36 +41,42 @@ def _dummy_function(*args, **kwargs):
 
 
 class DistributedList:
-    """Fixed-length per-process list (fitsnap3lib/parallel_tools.py:892-941): slice
-    assignment must preserve the length so that the lists can be gathered at the end."""
+    """This rank's fixed-length share of a row-metadata list (reference type:
+    fitsnap3lib/parallel_tools.py:892-941).  The calculators fill it slice by slice while the rows are assembled;
+    its length never changes, so that the shares of all ranks concatenate into one list with one entry per row
+    (``gather_fitsnap``).  Single positions take a one-element sequence, slices a list of exactly the slice's
+    length; anything that would change the length is refused with an AssertionError, an unsupported index type
+    with NotImplementedError, as in the reference."""
+
+    __slots__ = ("_items",)
 
     def __init__(self, proc_length):
-        self._len = proc_length
-        self._list = list(" ") * self._len
-
-    def __getitem__(self, item):
-        return self._list.__getitem__(item)
+        self._items = [" "] * int(proc_length)
 
     def __len__(self):
-        return self._len
+        return len(self._items)
+
+    def __getitem__(self, item):
+        return self._items[item]
 
     def __setitem__(self, key, value):
-        if isinstance(key, int):
-            assert len(value) == 1
-            assert key <= self.__len__()
-        elif isinstance(key, slice):
-            assert isinstance(value, list)
-            assert len(value) == len(range(*key.indices(self.__len__())))
-            assert key.stop <= self.__len__()
+        size = len(self._items)
+        if isinstance(key, slice):
+            assert isinstance(value, list), "slice assignment needs a list"
+            assert key.stop is not None and key.stop <= size, "slice runs past the end of the list"
+            assert len(value) == len(range(*key.indices(size))), "slice assignment must keep the length"
+        elif isinstance(key, int):
+            assert key <= size and len(value) == 1, "single positions take a one-element sequence"
         else:
-            raise NotImplementedError("Indexing type {} for Distributed list is not impelemented".format(type(key)))
-        self._list.__setitem__(key, value)
+            raise NotImplementedError(f"DistributedList cannot be indexed with {type(key)}")
+        self._items[key] = value
 
     def __repr__(self):
-        return self._list.__repr__()
+        return repr(self._items)
 
     def get_list(self):
-        return deepcopy(self._list)
+        """Independent copy of the entries."""
+        return deepcopy(self._items)
 
 
 class StubsArray:
@@ -256,32 +263,31 @@ class ParallelTools:
     def all_print(self, *args, **kw):
         _printf("Rank", self._rank, ":", *args, file=self._fp)
 
+    def _only_if(self, active, method):
+        return method if active else _dummy_function
+
     def rank_zero(self, method):
-        if self._rank == 0:
-            def check_if_rank_zero(*args, **kw):
-                return method(*args, **kw)
-            return check_if_rank_zero
-        return _dummy_function
+        """Decorator: the call happens on rank 0 and is a no-op returning None elsewhere (parallel_tools.py:322-328)."""
+        return self._only_if(self._rank == 0, method)
 
     def sub_rank_zero(self, method):
-        if self._sub_rank == 0:
-            def check_if_rank_zero(*args, **kw):
-                return method(*args, **kw)
-            return check_if_rank_zero
-        return _dummy_function
+        """Same for the head of a node (parallel_tools.py:330-336); every rank is the head of its own GPU here."""
+        return self._only_if(self._sub_rank == 0, method)
 
     def single_timeit(self, method):
-        """Wall-clock decorator, prints on rank 0 (parallel_tools.py:290-306)."""
+        """Decorator: wall-clock time of a call in ms, stored under ``log_time[log_name]`` when the caller passes
+        those keywords, else printed by rank 0 (parallel_tools.py:290-306)."""
+        @functools.wraps(method)
         def timed(*args, **kw):
-            ts = time()
-            result = method(*args, **kw)
-            te = time()
-            if "log_time" in kw:
-                kw["log_time"][kw.get("log_name", method.__name__.upper())] = int((te - ts) * 1000)
-            elif self._rank == 0:
-                _printf("'{0}' took {1:.2f} ms on rank {2}".format(method.__name__, (te - ts) * 1000, self._rank),
-                        file=self._fp)
-            return result
+            start = perf_counter()
+            try:
+                return method(*args, **kw)
+            finally:
+                ms = (perf_counter() - start) * 1e3
+                if "log_time" in kw:
+                    kw["log_time"][kw.get("log_name", method.__name__.upper())] = int(ms)
+                else:
+                    self.single_print(f"'{method.__name__}' took {ms:.2f} ms on rank {self._rank}")
         return timed
 
     # -- collectives (reference: mpi4py, SURVEY.md 2.1) ---------------------------------

@@ -29,6 +29,8 @@ from .. import _capi
 class Solver:
     """Base class for linear solvers (see module docstring)."""
 
+    MAX_DEVICE_CATEGORIES = 3000     # (group, train/test, row type) categories fsnap_error_stats_k keeps in LDS
+
     def __init__(self, name, pt, config, linear=True):
         self.config = config
         self.pt = pt
@@ -45,11 +47,11 @@ class Solver:
         self.w = None
         self._df = None              # error_analysis DataFrame, built on first access (see the df property)
         self._df_parts = None
-        self._cat_cache = None       # (key, category ids, group keys) of the last error_analysis row labelling
+        self._cat_cache = None       # (label lists, probes, m, category ids, group keys) of the last error_analysis
         self._cat_ctx = None         # context that holds those category ids on the device
         self._err_layout = None      # (group keys, index, source rows, weighting flags) of the last errors table
         self._all_idx = None         # (group keys, [(sub key, member indices)]) of the last *ALL merge
-        self._mask_cache = None      # (key, training mask) of the last fs_dict['Testing'] list (keep_resident only)
+        self._mask_cache = None      # (Testing list, probe, training mask, derived arrays) (keep_resident only)
         self.linear = linear
         self.cov = None
         self.fit_sam = None
@@ -82,17 +84,43 @@ class Solver:
     # ------------------------------------------------------------------------------
     # mask / weights exactly as the reference resolves them
     # ------------------------------------------------------------------------------
+    @staticmethod
+    def _list_probe(lst, n=257):
+        """A few hundred evenly spaced entries of a label list: a cheap fingerprint that notices in-place edits (a
+        cross-validation fold flips a contiguous tenth of ``Testing``) without walking a million Python objects."""
+        size = len(lst)
+        if size <= n:
+            return tuple(lst)
+        step = size / n
+        return tuple(lst[int(i * step)] for i in range(n)) + (lst[-1],)
+
+    def _cache_hit(self, cached_lists, cached_probes, lists):
+        """Identity of the list OBJECTS (the cache keeps them alive, so an address cannot be recycled) plus the probe."""
+        return (cached_lists is not None and len(cached_lists) == len(lists)
+                and all(c is l for c, l in zip(cached_lists, lists))
+                and all(p == self._list_probe(l) for p, l in zip(cached_probes, lists)))
+
+    def invalidate_row_caches(self):
+        """Forget everything derived from the row-label lists (training mask, category ids, table layouts).  Only
+        needed with ``keep_resident`` after editing a label list IN PLACE in a way the probe cannot see."""
+        self._mask_cache = None
+        self._cat_cache = None
+        self._cat_ctx = None
+        self._err_layout = None
+        self._all_idx = None
+
     def _training_mask(self, a, fs_dict, trainall):
         """svd.py:35-40 / ridge.py:28-33."""
         if fs_dict is not None:
             lst = fs_dict["Testing"]
             if self.keep_resident and isinstance(lst, list):
-                # re-weighting loops pass the same (large) Python list every time: convert it once
-                key = (id(lst), len(lst))
-                if self._mask_cache is not None and self._mask_cache[0] == key:
-                    return self._mask_cache[1]
+                # re-weighting loops pass the same (large) Python list every time: convert it once.  The cache holds
+                # the list itself and a probe of its content; without keep_resident nothing is cached.
+                mc = self._mask_cache
+                if mc is not None and self._cache_hit((mc[0],), (mc[1],), (lst,)):
+                    return mc[2]
                 mask = ~np.asarray(lst, dtype=bool)
-                self._mask_cache = (key, mask)
+                self._mask_cache = (lst, self._list_probe(lst), mask, None)
                 return mask
             return ~np.asarray(lst, dtype=bool)
         if trainall:
@@ -123,12 +151,12 @@ class Solver:
             raise IndexError("boolean index did not match indexed array along axis 0; size of axis is "
                              f"{m} but size of corresponding boolean axis is {len(training)}")
         # a cached mask (re-weighting loop) carries its row indices and uint8 form along
-        aux = self._mask_cache[2] if (self._mask_cache is not None and len(self._mask_cache) > 2
-                                      and self._mask_cache[1] is training) else None
+        mc = self._mask_cache
+        aux = mc[3] if (mc is not None and mc[2] is training) else None
         if aux is None:
             aux = (np.flatnonzero(training), training.astype(np.uint8))
-            if self._mask_cache is not None and self._mask_cache[1] is training:
-                self._mask_cache = (self._mask_cache[0], training, aux)
+            if mc is not None and mc[2] is training:
+                self._mask_cache = (mc[0], mc[1], training, aux)
         idx, mask_u8 = aux
         ntrain = idx.shape[0]
         # reference: aw = w[:, None] * a[training]  (numpy broadcasting on the row axis)
@@ -352,48 +380,55 @@ class Solver:
     # downstream of the fit (solver.py:108-133, 368-435)
     # ------------------------------------------------------------------------------
     def _offset(self):
-        """Insert a zero B0 per type when SNAP ``bzeroflag`` is set (solver.py:78-86)."""
-        num_types = self.config.sections["BISPECTRUM"].numtypes
-        if num_types > 1:
-            self.fit = self.fit.reshape(num_types, self.config.sections["BISPECTRUM"].ncoeff)
-            offsets = np.zeros((num_types, 1))
-            self.fit = np.concatenate([offsets, self.fit], axis=1)
-            self.fit = self.fit.reshape((-1, 1))
+        """SNAP with ``bzeroflag``: the fit has no constant term, the potential file wants one per type -- a zero B0
+        goes in front of every type's block of ``ncoeff`` coefficients (solver.py:78-103).  Shapes as in the
+        reference: several types -> column vector, one type -> flat vector; ``fit_sam`` (coefficient samples of the
+        UQ solvers, one row per sample) gets the same zeros."""
+        bis = self.config.sections["BISPECTRUM"]
+        ntypes, ncoeff = bis.numtypes, bis.ncoeff
+
+        def with_b0(rows):
+            blocks = np.asarray(rows, dtype=np.float64).reshape(-1, ntypes, ncoeff)
+            return np.pad(blocks, ((0, 0), (0, 0), (1, 0))).reshape(blocks.shape[0], ntypes * (ncoeff + 1))
+
+        if ntypes > 1:
+            self.fit = with_b0(self.fit).reshape(-1, 1)
+            if self.fit_sam is not None:
+                self.fit_sam = with_b0(self.fit_sam)
         else:
             self.fit = np.insert(self.fit, 0, 0)
-        if self.fit_sam is not None:
-            if num_types > 1:
-                offsets = np.zeros((num_types, 1))
-                nsam, ncf = self.fit_sam.shape
-                fit_sam = np.empty((nsam, ncf + num_types))
-                for isam, fit in enumerate(self.fit_sam.reshape(nsam, num_types, self.config.sections["BISPECTRUM"].ncoeff)):
-                    fit = np.concatenate([offsets, fit], axis=1)
-                    fit_sam[isam, :] = fit.reshape((-1,))
-                self.fit_sam = fit_sam + 0.0
-            else:
+            if self.fit_sam is not None:
                 self.fit_sam = np.insert(self.fit_sam, 0, 0, axis=1)
 
     @staticmethod
-    def _ncount_mae_rmse_rsq_unweighted_and_weighted(g):
-        """solver.py:108-133."""
-        from pandas import Series
+    def _host_error_sums(truths, preds, weights, cat, ncat):
+        """The ten sums of ``fsnap_error_stats`` (include/fsnap_hip.h) for rows that are on the host only (CPU process
+        groups, ``device_error_stats = False``): one ``bincount`` per sum.  Row ``c`` of the result belongs to
+        category ``c``; ``_metrics_from_sums`` turns it into the numbers of solver.py:108-133."""
+        t = np.asarray(truths, dtype=np.float64)
+        w = np.asarray(weights, dtype=np.float64)
+        r = t - np.asarray(preds, dtype=np.float64)
+        cat = np.asarray(cat, dtype=np.int64)
 
-        res = g["truths"] - g["preds"]
-        mae = np.mean(abs(res))
-        ssr = np.square(res).sum()
-        nconfig = len(g["truths"])
-        mse = ssr / nconfig
-        rmse = np.sqrt(mse)
-        rsq = 1 - ssr / np.sum(np.square(g["truths"] - (g["truths"] / nconfig).sum()))
-        w_res = g["weights"] * (g["truths"] - g["preds"])
-        w_mae = np.mean(abs(w_res))
-        w_ssr = np.square(w_res).sum()
-        w_nconfig = np.count_nonzero(g["weights"])
-        w_mse = w_ssr / w_nconfig
-        w_rmse = np.sqrt(w_mse)
-        w_rsq = 1 - w_ssr / np.sum(np.square((g["weights"] * g["truths"]) - (g["weights"] * g["truths"] / w_nconfig).sum()))
-        return Series({"ncount": nconfig, "mae": mae, "rmse": rmse, "rsq": rsq, "w_ncount": w_nconfig,
-                       "w_mae": w_mae, "w_rmse": w_rmse, "w_rsq": w_rsq})
+        def per_cat(x):
+            return np.bincount(cat, weights=x, minlength=ncat)
+
+        n = np.bincount(cat, minlength=ncat).astype(np.float64)
+        nw = per_cat((w != 0).astype(np.float64))
+        st, swt = per_cat(t), per_cat(w * t)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mean_t = np.where(n > 0, st / n, 0.0)
+            mean_wt = np.where(nw > 0, swt / nw, 0.0)
+        return np.stack([n, nw, st, swt, per_cat(np.abs(r)), per_cat(r * r), per_cat((t - mean_t[cat]) ** 2),
+                         per_cat(np.abs(w * r)), per_cat((w * r) ** 2), per_cat((w * t - mean_wt[cat]) ** 2)], axis=1)
+
+    def _host_error_tables(self, df):
+        """(per-group table, *ALL table) from a DataFrame with truths / preds / weights and the three label columns."""
+        gb = df.groupby(["Groups", "Testing", "Row_Type"], sort=True)
+        keys = list(gb.size().index)
+        st = self._host_error_sums(df["truths"].to_numpy(), df["preds"].to_numpy(), df["weights"].to_numpy(),
+                                   gb.ngroup().to_numpy(), len(keys))
+        return self._tables_from_sums(keys, st)
 
     @staticmethod
     def _metrics_from_sums(n, nw, st, swt, sar, srr, sct, sawr, swrr, scwt):
@@ -445,6 +480,10 @@ class Solver:
         beta = np.asarray(self.fit, dtype=np.float64).reshape(-1)
         # the category ids stay on the device between calls; (context, serial) tells whether they are still OURS
         mine = (not fresh) and self._cat_ctx is not None and self._cat_ctx == (id(ctx), getattr(ctx, "cat_serial", -1))
+        if len(keys) > self.MAX_DEVICE_CATEGORIES:
+            # more categories than the kernel's LDS table holds: predictions from the GPU GEMV, grouping on the host
+            preds, _ = ctx.predict(beta)
+            return keys, self._host_error_sums(b, preds, w, cat, len(keys))
         try:
             st = ctx.error_stats(beta, None if mine else cat, len(keys))
         except _capi.FsnapError:
@@ -499,18 +538,22 @@ class Solver:
 
     def _row_categories(self, fs_dict, m):
         """Category id of every row = index of its (Groups, Testing, Row_Type) key in sorted order (the order of the
-        reference's groupby).  Cached while the caller keeps passing the same label lists (re-weighting loops)."""
+        reference's groupby).  Like the reference the labels are re-read on every call; only with ``keep_resident``
+        (re-weighting loops that pass the same label lists every time) are the ids cached -- keyed on the list
+        objects themselves plus a probe of their content (``invalidate_row_caches`` drops them explicitly)."""
         from pandas import DataFrame
 
         lists = (fs_dict["Groups"], fs_dict["Testing"], fs_dict["Row_Type"])
-        key = (id(lists[0]), id(lists[1]), id(lists[2]), m)
-        if self._cat_cache is not None and self._cat_cache[0] == key:
-            return self._cat_cache[1], self._cat_cache[2], False
+        cc = self._cat_cache
+        if (self.keep_resident and cc is not None and cc[2] == m and all(isinstance(l, list) for l in lists)
+                and self._cache_hit(cc[0], cc[1], lists)):
+            return cc[3], cc[4], False
         gb = DataFrame({"Groups": lists[0], "Testing": lists[1], "Row_Type": lists[2]}).groupby(
             ["Groups", "Testing", "Row_Type"], sort=True)
         cat = gb.ngroup().to_numpy(dtype=np.int32)
         keys = list(gb.size().index)
-        self._cat_cache = (key, cat, keys)
+        probes = tuple(self._list_probe(l) for l in lists) if self.keep_resident else ()
+        self._cat_cache = (lists, probes, m, cat, keys)
         return cat, keys, True
 
     def _assemble_errors(self, grouped, allrows, layout_key=None):
@@ -644,17 +687,13 @@ class Solver:
         if self.config.sections["EXTRAS"].dump_dataframe:
             self.df.to_pickle(self.config.sections["EXTRAS"].dataframe_file)
         if self.fit is not None and not self.config.sections["SOLVER"].true_multinode:
-            fn = self._ncount_mae_rmse_rsq_unweighted_and_weighted
             if not multi and self.device_error_stats:
                 # single GPU: the rows are resident -- predictions and the grouped reductions run on the GPU
                 # (fsnap_error_stats); only the (groups x 10) table of sums comes back
                 grouped, allrows = self._device_error_tables(a, b, w, shared, fs_dict)
             else:
-                grouped = self.df.groupby(["Groups", "Testing", "Row_Type"])[["truths", "preds", "weights"]].apply(fn)
-                allrows = None
-            if allrows is None:
-                allrows = self.df.groupby(["Testing", "Row_Type"])[["truths", "preds", "weights"]].apply(fn)
-            layout_key = self._cat_cache[2] if (not multi and self.device_error_stats and self._cat_cache is not None) else None
+                grouped, allrows = self._host_error_tables(self.df)
+            layout_key = self._cat_cache[4] if (not multi and self.device_error_stats and self._cat_cache is not None) else None
             self.errors = self._assemble_errors(grouped, allrows, layout_key)
         if self.fit is not None:
             if (self.config.sections["CALCULATOR"].calculator == "LAMMPSSNAP"

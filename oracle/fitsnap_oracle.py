@@ -200,3 +200,4 @@ def anl_fit(a, b, w, testing=None, cov_nugget=0.0):
     bp = np.dot(res, res) / 2.0
     ap = (npt - nbas) / 2.0
     return fit, (bp / (ap - 1.0)) * invptp
+

@@ -211,7 +211,12 @@ def test_rank_sums_pool_to_the_single_process_error_table():
     grouped, allrows = s._tables_from_sums(gkeys, gst)
     got = s._assemble_errors(grouped, allrows, None)
     full = pd.DataFrame({"truths": truth, "preds": pred, "weights": w, "Groups": groups, "Testing": testing, "Row_Type": rtype})
-    fn = s._ncount_mae_rmse_rsq_unweighted_and_weighted
+    from oracle import fitsnap_oracle as orc
+
+    import pandas as pd
+
+    def fn(g):
+        return pd.Series(orc.error_row(g["truths"], g["preds"], g["weights"]))
     g_ref = full.groupby(["Groups", "Testing", "Row_Type"])[["truths", "preds", "weights"]].apply(fn)
     a_ref = full.groupby(["Testing", "Row_Type"])[["truths", "preds", "weights"]].apply(fn)
     want = s._assemble_errors(g_ref, a_ref, None)
@@ -264,3 +269,135 @@ def test_chemflag_descriptor_count_matches_reference(tmp_path):
     with pytest.raises(ValueError):
         Config(pt, str(ini), arguments_lst=["--overwrite"])
     pt.free()
+
+
+def test_rank_zero_decorators_and_timer(capsys):
+    pt = ParallelTools()
+    calls = []
+
+    @pt.rank_zero
+    def f(x, y=1):
+        calls.append((x, y))
+        return x + y
+
+    @pt.sub_rank_zero
+    def g():
+        return "head"
+
+    assert f(2, y=3) == 5 and g() == "head" and calls == [(2, 3)]
+    pt._rank, pt._sub_rank = 1, 1                    # decorators bind at decoration time, like the reference
+    assert f(1) == 2
+
+    @pt.rank_zero
+    def h():
+        calls.append("never")
+        return 1
+
+    assert h() is None and pt.sub_rank_zero(h)() is None and "never" not in calls
+    pt._rank = 0
+
+    @pt.single_timeit
+    def work(n, **kw):
+        return sum(range(n))
+
+    log = {}
+    assert work(10, log_time=log, log_name="W") == 45 and "W" in log and isinstance(log["W"], int)
+    assert work(10) == 45
+    assert "'work' took" in capsys.readouterr().out
+
+
+def test_distributed_list_refuses_length_changes():
+    from fitsnap_amd.parallel_tools import DistributedList
+
+    d = DistributedList(4)
+    d[0:2] = ["a", "b"]
+    d[2] = ["c"]
+    assert d[0:3] == ["a", "b", ["c"]] and len(d) == 4      # a single position stores the sequence itself (reference)
+    with pytest.raises(AssertionError):
+        d[0:2] = ["x"]
+    with pytest.raises(AssertionError):
+        d[2:6] = ["x", "y"]
+    with pytest.raises(AssertionError):
+        d[0:2] = ("x", "y")
+    with pytest.raises(NotImplementedError):
+        d["k"] = ["x"]
+    copy = d.get_list()
+    copy[0] = "changed"
+    assert d[0] == "a"
+
+
+def test_offset_handles_coefficient_samples():
+    pt = ParallelTools()
+    cfg = Config(pt, {"SOLVER": {"solver": "SVD"}, "BISPECTRUM": {"numTypes": 2, "twojmax": 2, "bzeroflag": 1, "type": "A B"}})
+    s = solver_factory.solver("SVD", pt, cfg)
+    n = cfg.sections["BISPECTRUM"].ncoeff
+    s.fit = np.arange(1.0, 2 * n + 1)
+    s.fit_sam = np.arange(1.0, 3 * 2 * n + 1).reshape(3, 2 * n)
+    sam = s.fit_sam.copy()
+    s._offset()
+    assert s.fit_sam.shape == (3, 2 * (n + 1))
+    for i in range(3):
+        blocks = s.fit_sam[i].reshape(2, n + 1)
+        assert np.all(blocks[:, 0] == 0) and np.array_equal(blocks[:, 1:].ravel(), sam[i])
+    cfg1 = Config(pt, {"SOLVER": {"solver": "SVD"}, "BISPECTRUM": {"numTypes": 1, "twojmax": 2, "bzeroflag": 1, "type": "A"}})
+    s1 = solver_factory.solver("SVD", pt, cfg1)
+    s1.fit = np.arange(1.0, n + 1)
+    s1.fit_sam = np.ones((2, n))
+    s1._offset()
+    assert s1.fit.shape == (n + 1,) and s1.fit[0] == 0 and s1.fit_sam.shape == (2, n + 1) and np.all(s1.fit_sam[:, 0] == 0)
+
+
+def test_host_error_tables_equal_the_reference_formulas_per_group():
+    import pandas as pd
+    from pandas.testing import assert_frame_equal
+    from oracle import fitsnap_oracle as orc
+
+    pt, cfg, s = make("RIDGE")
+    rng = np.random.default_rng(11)
+    m = 2000
+    df = pd.DataFrame({"truths": rng.standard_normal(m) * 3 + 1, "weights": rng.choice([0.0, 1.0, 25.0], size=m),
+                       "Groups": rng.choice(list("ABC"), size=m), "Testing": rng.random(m) < 0.2,
+                       "Row_Type": rng.choice(["Energy", "Force"], size=m)})
+    df["preds"] = df["truths"] + rng.standard_normal(m) * 0.1
+
+    def fn(g):
+        return pd.Series(orc.error_row(g["truths"], g["preds"], g["weights"]))
+
+    grouped, allrows = s._host_error_tables(df)
+    g_ref = df.groupby(["Groups", "Testing", "Row_Type"])[["truths", "preds", "weights"]].apply(fn)
+    a_ref = df.groupby(["Testing", "Row_Type"])[["truths", "preds", "weights"]].apply(fn)
+    assert_frame_equal(s._assemble_errors(grouped, allrows, None), s._assemble_errors(g_ref, a_ref, None),
+                       check_exact=False, rtol=1e-11, atol=1e-13)
+
+
+def test_label_caches_notice_new_and_edited_lists():
+    # the caches of a re-weighting loop were keyed on id() alone
+    pt, cfg, s = make("RIDGE")
+    s.keep_resident = True
+    m = 5000
+    a = np.zeros((m, 2))
+
+    def fresh(flip):
+        t = [False] * m
+        for i in range(0, m, 10):
+            t[i] = True
+        return [not x for x in t] if flip else t
+
+    first = s._training_mask(a, {"Testing": fresh(False)}, False).copy()
+    second = s._training_mask(a, {"Testing": fresh(True)}, False)        # same length, maybe the same address
+    assert np.array_equal(second, ~first)
+    lst = fresh(False)
+    m1 = s._training_mask(a, {"Testing": lst}, False)
+    assert s._training_mask(a, {"Testing": lst}, False) is m1            # same object, same content: cached
+    lst[: m // 10] = [True] * (m // 10)                                   # a cross-validation fold, edited in place
+    m2 = s._training_mask(a, {"Testing": lst}, False)
+    assert not m2[: m // 10].any()
+    fsd = {"Groups": ["g"] * m, "Testing": fresh(False), "Row_Type": ["Energy"] * m}
+    cat1, keys1, fresh1 = s._row_categories(fsd, m)
+    cat2, keys2, fresh2 = s._row_categories(fsd, m)
+    assert fresh1 and not fresh2 and keys2 is keys1
+    fsd["Testing"][: m // 10] = [True] * (m // 10)
+    cat3, keys3, fresh3 = s._row_categories(fsd, m)
+    assert fresh3 and (cat3[: m // 10] == keys3.index(("g", True, "Energy"))).all()
+    s.keep_resident = False                                                # default path: nothing is reused
+    assert s._row_categories(fsd, m)[2] and s._row_categories(fsd, m)[2]
