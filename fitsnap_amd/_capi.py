@@ -22,6 +22,8 @@ OK = 0
 E_ARG, E_HIP, E_STATE, E_NOMEM = -1, -2, -3, -4
 NUM_NOT_SPD, NUM_SINGULAR, NUM_NONFINITE = 1, 2, 3
 SOLVE_CHOL, SOLVE_LSTSQ, SOLVE_RIDGE, SOLVE_RIDGE_INV = 0, 1, 2, 3
+COMM_ID_BYTES = 128
+REDUCE_SUM, REDUCE_MAX, REDUCE_MIN = 0, 1, 2
 
 _P_D = POINTER(c_double)
 _P_U8 = POINTER(c_uint8)
@@ -60,6 +62,22 @@ SIGNATURES = {
     "fsnap_fit_resident": (c_int, [c_void_p, c_int, c_double, c_void_p, POINTER(c_int), POINTER(c_double), POINTER(c_void_p)]),
     "fsnap_solve_device_rhs": (c_int, [c_void_p, c_int, c_double, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int),
                                         POINTER(c_double)]),
+    "fsnap_comm_id": (c_int, [c_void_p]),
+    "fsnap_comm_init": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "fsnap_comm_destroy": (c_int, [c_void_p]),
+    "fsnap_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "fsnap_allreduce_device": (c_int, [c_void_p, c_void_p, c_int64]),
+    "fsnap_allreduce_host": (c_int, [c_void_p, c_void_p, c_int64, c_int]),
+    "fsnap_bcast_host": (c_int, [c_void_p, c_void_p, c_int64, c_int]),
+    "fsnap_allgather_host": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "fsnap_barrier": (c_int, [c_void_p]),
+    "fsnap_fit_dist": (c_int, [c_void_p, c_int, c_double, c_int64, c_void_p, POINTER(c_int), POINTER(c_double), POINTER(c_void_p)]),
+    "fsnap_dev_alloc": (c_int, [c_void_p, c_int64, POINTER(c_void_p)]),
+    "fsnap_dev_free": (c_int, [c_void_p, c_void_p]),
+    "fsnap_dev_sync": (c_int, [c_void_p]),
+    "fsnap_lstsq_rows": (c_int, [c_void_p, c_double, c_int64, c_void_p, POINTER(c_int), c_void_p]),
+    "fsnap_rowspace_factor": (c_int, [c_int64, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p]),
+    "fsnap_rowspace_solve": (c_int, [c_int64, c_void_p, c_void_p, c_double, c_void_p, POINTER(c_int), c_void_p]),
     "fsnap_timing": (c_int, [c_void_p, _P_D, c_int]),
     "fsnap_timing_history": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
     "fsnap_launch_info": (c_int, [c_void_p, POINTER(c_int64), c_int]),
@@ -165,6 +183,43 @@ def solve(kind: int, param: float, G: np.ndarray, c: np.ndarray):
     rc = lib.fsnap_solve(int(kind), float(param), K, _ptr(G), _ptr(c), _ptr(beta), byref(rank), byref(rce))
     raise_status(rc, "")
     return beta, rank.value, rce.value
+
+
+def comm_id() -> bytes:
+    """A fresh RCCL communicator id (rank 0 calls this and hands the 128 bytes to every rank)."""
+    lib = load_library()
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    rc = lib.fsnap_comm_id(buf)
+    if rc != OK:
+        raise FsnapError("fsnap_comm_id: " + (lib.fsnap_last_error(None) or b"").decode())
+    return buf.raw
+
+
+def rowspace_factor(G, Rhat=None, tol=1.0e-10):
+    """Host step of a row-space pass (fsnap_rowspace_factor): returns (Rp or None when converged, Rhat, info) with
+    info = (deviation, converged, shift).  ``Rhat=None`` starts a new factorisation."""
+    lib = load_library()
+    G = _f64(G, "G")
+    K = G.shape[0]
+    first = Rhat is None
+    Rhat = np.zeros((K, K)) if first else _f64(Rhat, "Rhat")
+    Rp = np.empty((K, K))
+    info = np.zeros(3)
+    raise_status(lib.fsnap_rowspace_factor(K, _ptr(G), int(first), float(tol), _ptr(Rhat), _ptr(Rp), _ptr(info)), "")
+    return (None if info[1] else Rp), Rhat, tuple(info)
+
+
+def rowspace_solve(Rhat, z, rcond=1.0e-13):
+    """K x K end of the row-space solve (fsnap_rowspace_solve): returns (beta, rank, info)."""
+    lib = load_library()
+    Rhat = _f64(Rhat, "Rhat")
+    z = _f64(z, "z")
+    K = z.shape[0]
+    beta = np.empty(K)
+    rank = c_int(0)
+    info = np.zeros(4)
+    raise_status(lib.fsnap_rowspace_solve(K, _ptr(Rhat), _ptr(z), float(rcond), _ptr(beta), byref(rank), _ptr(info)), "")
+    return beta, rank.value, tuple(info)
 
 
 class HipContext:
@@ -388,6 +443,85 @@ class HipContext:
         if rc != OK:
             raise_status(rc, (self._lib.fsnap_last_error(self._h) or b"").decode() if rc < 0 else "")
         return beta, rank.value, rce.value
+
+    # -- row-space least squares --------------------------------------------------------
+    def lstsq_rows(self, rcond: float, K: int = None):
+        """``lstsq(aw, bw, rcond)`` of the resident rows computed on the rows (fsnap_lstsq_rows); collective when the
+        context has a communicator.  Returns (beta, rank, info dict)."""
+        K = self.K if K is None else int(K)
+        beta = np.empty(K, dtype=np.float64)
+        rank = c_int(0)
+        info = np.zeros(8)
+        rc = self._lib.fsnap_lstsq_rows(self._h, float(rcond), K, _ptr(beta), byref(rank), _ptr(info))
+        if rc != OK:
+            raise_status(rc, (self._lib.fsnap_last_error(self._h) or b"").decode())
+        keys = ("passes", "deviation", "converged", "svd", "sigma_max", "sigma_min", "refine_step", "shift")
+        return beta, rank.value, dict(zip(keys, info.tolist()))
+
+    # -- multi-GPU (native RCCL) ----------------------------------------------------------
+    def comm_init(self, nranks: int, rank: int, ident: bytes):
+        if len(ident) != COMM_ID_BYTES:
+            raise ValueError("communicator id must be 128 bytes")
+        self._check(self._lib.fsnap_comm_init(self._h, int(nranks), int(rank), ctypes.c_char_p(ident)))
+
+    def comm_destroy(self):
+        self._check(self._lib.fsnap_comm_destroy(self._h))
+
+    def comm_info(self):
+        n, r = c_int(1), c_int(0)
+        self._check(self._lib.fsnap_comm_info(self._h, byref(n), byref(r)))
+        return n.value, r.value
+
+    def allreduce_device(self, d_ptr: int, n: int):
+        self._check(self._lib.fsnap_allreduce_device(self._h, c_void_p(d_ptr), int(n)))
+
+    def allreduce_host(self, arr: np.ndarray, op: int = REDUCE_SUM):
+        """In-place reduction of a C-contiguous float64 array over the ranks."""
+        if arr.dtype != np.float64 or not arr.flags["C_CONTIGUOUS"]:
+            raise ValueError("allreduce_host needs a C-contiguous float64 array")
+        if arr.size:
+            self._check(self._lib.fsnap_allreduce_host(self._h, _ptr(arr), arr.size, int(op)))
+        return arr
+
+    def bcast_bytes(self, data: bytes, nbytes: int, root: int = 0) -> bytes:
+        buf = ctypes.create_string_buffer(data if data is not None else b"", int(nbytes))
+        self._check(self._lib.fsnap_bcast_host(self._h, buf, int(nbytes), int(root)))
+        return buf.raw
+
+    def allgather_bytes(self, data: bytes, nranks: int) -> list:
+        """Equal-size byte strings of all ranks, in rank order."""
+        n = len(data)
+        out = ctypes.create_string_buffer(n * nranks)
+        self._check(self._lib.fsnap_allgather_host(self._h, ctypes.c_char_p(data), n, out))
+        raw = out.raw
+        return [raw[i * n:(i + 1) * n] for i in range(nranks)]
+
+    def barrier(self):
+        self._check(self._lib.fsnap_barrier(self._h))
+
+    def fit_dist(self, kind: int, param: float, K: int):
+        """One multi-GPU fit (fsnap_fit_dist): local statistics, in-place RCCL all-reduce, solve on every rank.
+        Returns (beta, rank, rcond_estimate, device address of the reduced statistics)."""
+        beta = np.empty(int(K), dtype=np.float64)
+        rank = c_int(0)
+        rce = c_double(0.0)
+        ptr = c_void_p()
+        rc = self._lib.fsnap_fit_dist(self._h, int(kind), float(param), int(K), _ptr(beta), byref(rank), byref(rce), byref(ptr))
+        if rc != OK:
+            raise_status(rc, (self._lib.fsnap_last_error(self._h) or b"").decode() if rc < 0 else "")
+        return beta, rank.value, rce.value, ptr.value
+
+    # -- raw device memory ----------------------------------------------------------------
+    def dev_alloc(self, nbytes: int) -> int:
+        ptr = c_void_p()
+        self._check(self._lib.fsnap_dev_alloc(self._h, int(nbytes), byref(ptr)))
+        return ptr.value
+
+    def dev_free(self, d_ptr: int):
+        self._check(self._lib.fsnap_dev_free(self._h, c_void_p(d_ptr)))
+
+    def sync(self):
+        self._check(self._lib.fsnap_dev_sync(self._h))
 
     # -- measurement -------------------------------------------------------------------
     def timing(self, n: int = 8):

@@ -17,8 +17,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "_lib")
 LIBNAME = "libfsnap_hip.so"
-SOURCES = ["fsnap_syrk.hip", "fsnap_rows.hip", "fsnap_chol.hip", "fsnap_capi.cpp", "fsnap_solve.cpp"]
-HEADERS = ["fsnap_kernels.h", "fsnap_device_common.h", os.path.join("..", "..", "include", "fsnap_hip.h")]
+SOURCES = ["fsnap_syrk.hip", "fsnap_rows.hip", "fsnap_chol.hip", "fsnap_trsm.hip", "fsnap_capi.cpp", "fsnap_comm.cpp",
+           "fsnap_rowspace.cpp", "fsnap_solve.cpp"]
+HEADERS = ["fsnap_kernels.h", "fsnap_device_common.h", "fsnap_ctx.h", os.path.join("..", "..", "include", "fsnap_hip.h")]
 ARCH = "gfx950"
 
 
@@ -58,7 +59,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
         cmd = [hipcc, *common]
-        if src == "fsnap_capi.cpp":
+        if src in ("fsnap_capi.cpp", "fsnap_comm.cpp", "fsnap_rowspace.cpp"):
             cmd += ["-x", "hip"]
         if src == "fsnap_solve.cpp":
             # host-only K x K solve: plain C++ (no device pass), AVX2+FMA baseline with AVX-512
@@ -76,7 +77,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{log}")
         if verbose and log.strip():
             print(log, file=sys.stderr)
-    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out, *objs, "-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
+    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out, *objs, "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-ldl"]
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")

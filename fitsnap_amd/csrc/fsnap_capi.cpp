@@ -22,117 +22,19 @@
 extern "C" int fsnap_solve_diag(int kind, double param, int64_t K, const double* G, const double* c, const double* diag,
                                 double* beta, int* rank, double* rcond_est);
 
-namespace {
+#include "fsnap_ctx.h"
 
-thread_local std::string g_last_error = "";
+namespace fsnap {
+std::string& library_error() {
+    static thread_local std::string text;
+    return text;
+}
+}  // namespace fsnap
 
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    bool ensure(size_t n) {
-        if (n <= bytes && p) return true;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
-        if (hipMalloc(&p, n) != hipSuccess) {
-            p = nullptr;
-            return false;
-        }
-        bytes = n;
-        return true;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
-    }
-};
-
-}  // namespace
-
-struct fsnap_ctx {
-    int device = 0;
-    int num_cu = 256;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[10] = {};
-    static constexpr int RING = 256;              // event triples of the last RING fits (fsnap_timing_history)
-    hipEvent_t ring[RING][3] = {};
-    int64_t nfit = 0;                             // fits launched so far
-    std::string err;
-
-    // rows
-    const double* dA = nullptr;
-    const double* db = nullptr;
-    int64_t m = 0, K = 0, lda = 0;
-    DevBuf ownA, ownb;
-    // weights
-    const double* dw = nullptr;
-    const unsigned char* dmask = nullptr;
-    DevBuf ownw, ownmask, ones;
-    // workspaces
-    DevBuf part, cpart, spart, packed, beta, preds, sse, aw, bw;
-    DevBuf st_raw, st_plan, st_frac, st_blank;   // staging of fsnap_assemble
-    DevBuf dsolve;                                // [beta | min pivot | status] of fsnap_solve_device
-    DevBuf dchol;                                 // padded work matrix of the blocked device Cholesky
-    DevBuf dcat, dstat;                           // fsnap_error_stats: row categories, partial tables + means
-    DevBuf wpack, wpack_spart;                    // kernel 1A: packed (w_eff, w_eff b) per row + partial b-only scalars
-    bool wpack_valid = false;                     // false after anything that can change b, w or the mask
-    int64_t dcat_rows = -1;                       // number of rows the categories on the device belong to
-    DevBuf du, dspart, dsvec;                     // refinement: row weights u, per-workgroup partials, s
-    double* pinned = nullptr;                     // page-locked host staging of the packed statistics: plain (coarse-grained)
-                                                  // pinned memory, the target of DMA copies only -- copies into COHERENT
-                                                  // host memory were bimodal (2 MB in 0.05 or in 8 ms)
-    size_t pinned_bytes = 0;
-    double* mirror = nullptr;                     // page-locked host mirror written by the reduction kernel itself
-    size_t mirror_bytes = 0;
-    const double* mirror_of = nullptr;            // device buffer the mirror currently reflects (nullptr = stale)
-    int64_t mirror_K = 0;                         // order of the system in the mirror
-    hipEvent_t mirror_ev = nullptr;               // recorded after the reduction that filled the mirror
-    // options
-    int opt_split = 0;        // 0 = auto
-    int opt_nt = 1;
-    int opt_nblocks = 0;      // 0 = auto
-    int opt_tiled = 0;        // force the general-K tiled kernel also for K <= 128
-    int opt_kernel = 0;       // 0 auto | 1 wave-triangle (kernel 1) | 2 LDS-shared, static per-wave bodies | 3 LDS-shared, generic
-    int opt_nsplit = 0;       // row splits of the tiled kernel (0 = auto)
-    int opt_xcd = 1;          // tiled kernel: contiguous work-item ranges per XCD
-    int opt_tiled2 = 0;       // K > 128: 1 = kernel 1T2 (one wave per SIMD, 32-tile items; measured no faster), 0 = kernel 1T
-    int opt_mirror = 1;       // fsnap_normal_eq_resident: reduction writes a page-locked host mirror (K <= 128)
-    int opt_device_solve = 0; // 0 = auto (K >= 384 on the GPU, blocked), 1 = every K (K <= 128: fsnap_chol_solve_k), 2 = never
-    int opt_ablate = 0;       // timing-only ablation of kernel 1L (diagnostics; results are wrong)
-    // cached launch plan of the tiled kernel (plan_tiled)
-    bool tplan_valid = false;
-    int64_t tplan_key[5] = {0, 0, 0, 0, 0};
-    int tplan[3] = {0, 0, 0};
-    int64_t tplan_cps = 0;
-    int tplan_items = 0;                          // kernel 1T2: work items per split (table in titems)
-    DevBuf titems;
-    // timing flags
-    bool t_syrk = false, t_upload = false, t_weight = false, t_predict = false;
-
-    int fail(int code, const char* fmt, ...) {
-        char buf[512];
-        va_list ap;
-        va_start(ap, fmt);
-        vsnprintf(buf, sizeof buf, fmt, ap);
-        va_end(ap);
-        err = buf;
-        g_last_error = buf;
-        return code;
-    }
-    int hipfail(hipError_t e, const char* what) {
-        return fail(e == hipErrorOutOfMemory ? FSNAP_E_NOMEM : FSNAP_E_HIP, "%s: %s", what, hipGetErrorString(e));
-    }
-};
+#define g_last_error (fsnap::library_error())
 
 namespace {
 
-#define FSNAP_HIP(call, what)                                \
-    do {                                                     \
-        hipError_t _e = (call);                              \
-        if (_e != hipSuccess) return ctx->hipfail(_e, what); \
-    } while (0)
 
 struct Geometry {
     int nblocks, split, threads;
@@ -393,11 +295,15 @@ int plan_tiled(fsnap_ctx* ctx, TiledGeometry* g) {
 // of partial b-only scalars in ctx->wpack_spart.
 int ensure_wpack(fsnap_ctx* ctx, int* npk) {
     *npk = fsnap::pack_weights_num_blocks(ctx->m);
+    if (ctx->wpack_override) {                     // rows and per-row pairs of the row-space passes (normal_eq_launch_on)
+        if (!ctx->wpack_spart.ensure((size_t)*npk * 4 * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(packed weights) failed");
+        return FSNAP_OK;
+    }
     if (!ctx->wpack.ensure((size_t)ctx->m * 16 + 64) || !ctx->wpack_spart.ensure((size_t)*npk * 4 * 8))
         return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(packed weights) failed");
     const bool caller_owned = ctx->db != (const double*)ctx->ownb.p || ctx->dw != (const double*)ctx->ownw.p ||
                               (ctx->dmask && ctx->dmask != (const unsigned char*)ctx->ownmask.p);
-    if (!ctx->wpack_valid || caller_owned) {
+    if (!ctx->wpack_valid || caller_owned || ctx->opt_repack) {
         FSNAP_HIP(fsnap::launch_pack_weights(ctx->db, ctx->dw, ctx->dmask, ctx->m, (double*)ctx->wpack.p,
                                              (double*)ctx->wpack_spart.p, ctx->stream),
                   "launch fsnap_pack_weights_k");
@@ -418,7 +324,7 @@ int launch_normal_eq_tiled(fsnap_ctx* ctx, double* d_packed, bool accumulate) {
     fsnap::TiledArgs a;
     a.A = ctx->dA;
     a.lda = ctx->lda;
-    a.wpack = (const double*)ctx->wpack.p;
+    a.wpack = ctx->wpack_override ? ctx->wpack_override : (const double*)ctx->wpack.p;
     a.m = ctx->m;
     a.K = (int)ctx->K;
     a.NSB = g.NSB;
@@ -489,7 +395,7 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
     if (g.acc || g.packed) {
         int npk = 0;
         if ((rc = ensure_wpack(ctx, &npk))) return rc;
-        a.wpack = (const double*)ctx->wpack.p;
+        a.wpack = ctx->wpack_override ? ctx->wpack_override : (const double*)ctx->wpack.p;
         spart_src = (const double*)ctx->wpack_spart.p;
         ns = npk;
     }
@@ -533,9 +439,35 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
 
 }  // namespace
 
+namespace fsnap {
+
+int wpack_current(fsnap_ctx* ctx) {
+    int rc, npk = 0;
+    if ((rc = check_rows(ctx)) || (rc = check_weights(ctx))) return rc;
+    return ensure_wpack(ctx, &npk);
+}
+
+int normal_eq_launch_on(fsnap_ctx* ctx, const double* Q, int64_t ldq, const double* qpack, double* d_packed) {
+    const double* const save_A = ctx->dA;
+    const int64_t save_lda = ctx->lda;
+    const int save_kernel = ctx->opt_kernel;
+    ctx->dA = Q;
+    ctx->lda = ldq;
+    ctx->opt_kernel = 0;                 // the default kernels (1A / 1P / tiled) read the per-row pairs
+    ctx->wpack_override = qpack;
+    const int rc = launch_normal_eq(ctx, d_packed);
+    ctx->wpack_override = nullptr;
+    ctx->opt_kernel = save_kernel;
+    ctx->dA = save_A;
+    ctx->lda = save_lda;
+    return rc;
+}
+
+}  // namespace fsnap
+
 extern "C" {
 
-int fsnap_version(void) { return 100; }
+int fsnap_version(void) { return 200; }
 
 int fsnap_device_count(int* count) {
     if (!count) return FSNAP_E_ARG;
@@ -603,6 +535,9 @@ int fsnap_ctx_destroy(fsnap_ctx* ctx) {
     if (!ctx) return FSNAP_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)fsnap_comm_destroy(ctx);
+    fsnap::rowspace_release(ctx);
+    ctx->commbuf.release();
     DevBuf* bufs[] = {&ctx->ownA, &ctx->ownb, &ctx->ownw, &ctx->ownmask, &ctx->ones, &ctx->part, &ctx->cpart,
                       &ctx->spart, &ctx->packed, &ctx->beta, &ctx->preds, &ctx->sse, &ctx->aw, &ctx->bw,
                       &ctx->st_raw, &ctx->st_plan, &ctx->st_frac, &ctx->st_blank, &ctx->dsolve, &ctx->dchol, &ctx->dcat, &ctx->dstat, &ctx->wpack, &ctx->wpack_spart,
@@ -659,6 +594,8 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
         ctx->opt_xcd = value != 0;
     } else if (!strcmp(key, "tiled2")) {
         ctx->opt_tiled2 = value != 0;
+    } else if (!strcmp(key, "repack")) {
+        ctx->opt_repack = value != 0;
     } else if (!strcmp(key, "nsplit")) {
         if (value < 0 || value > (1 << 24)) return ctx->fail(FSNAP_E_ARG, "nsplit out of range");
         ctx->opt_nsplit = (int)value;
@@ -1190,6 +1127,65 @@ int fsnap_fit_resident(fsnap_ctx* ctx, int kind, double param, double* beta, int
     if (rc) return rc;
     if (d_packed) *d_packed = dp;
     return fsnap_solve_device_rhs(ctx, kind, param, ctx->K, dp, nullptr, beta, rank, rcond_est);
+}
+
+int fsnap_fit_dist(fsnap_ctx* ctx, int kind, double param, int64_t K, double* beta, int* rank, double* rcond_est,
+                   double** d_packed) {
+    if (!ctx) return FSNAP_E_ARG;
+    if (!beta || K <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_fit_dist: bad argument");
+    int nranks = 1;
+    (void)fsnap_comm_info(ctx, &nranks, nullptr);
+    const bool have_rows = ctx->dA && ctx->m > 0;
+    if (have_rows && ctx->K != K) return ctx->fail(FSNAP_E_ARG, "fsnap_fit_dist: K = %lld but the resident rows have %lld columns",
+                                                   (long long)K, (long long)ctx->K);
+    if (nranks == 1) {
+        if (!have_rows) return ctx->fail(FSNAP_E_STATE, "no rows: call fsnap_upload_rows/fsnap_bind_rows first");
+        return fsnap_fit_resident(ctx, kind, param, beta, rank, rcond_est, d_packed);
+    }
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    const int64_t n = FSNAP_PACKED_LEN(K);
+    if (!ctx->packed.ensure((size_t)n * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(packed) failed");
+    double* dp = (double*)ctx->packed.p;
+    int rc;
+    if (have_rows) {
+        if ((rc = launch_normal_eq(ctx, dp))) return rc;
+    } else {
+        ctx->mirror_of = nullptr;
+        FSNAP_HIP(hipMemsetAsync(dp, 0, (size_t)n * 8, ctx->stream), "hipMemsetAsync(packed)");   // a rank without rows
+    }
+    if ((rc = fsnap_allreduce_device(ctx, dp, n))) return rc;
+    if ((rc = fsnap_mirror_packed(ctx, dp, K))) return rc;         // K < 384: page-locked mirror instead of a D2H copy
+    if (d_packed) *d_packed = dp;
+    return fsnap_solve_device_rhs(ctx, kind, param, K, dp, nullptr, beta, rank, rcond_est);
+}
+
+int fsnap_dev_alloc(fsnap_ctx* ctx, int64_t nbytes, void** d_ptr) {
+    if (!ctx) return FSNAP_E_ARG;
+    if (!d_ptr || nbytes <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_dev_alloc: bad argument");
+    *d_ptr = nullptr;
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    const hipError_t e = hipMalloc(d_ptr, (size_t)nbytes);
+    if (e != hipSuccess) {
+        *d_ptr = nullptr;
+        return ctx->hipfail(e, "hipMalloc");
+    }
+    return FSNAP_OK;
+}
+
+int fsnap_dev_free(fsnap_ctx* ctx, void* d_ptr) {
+    if (!ctx) return FSNAP_E_ARG;
+    if (!d_ptr) return FSNAP_OK;
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");     // nothing in flight may still use it
+    FSNAP_HIP(hipFree(d_ptr), "hipFree");
+    return FSNAP_OK;
+}
+
+int fsnap_dev_sync(fsnap_ctx* ctx) {
+    if (!ctx) return FSNAP_E_ARG;
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    return FSNAP_OK;
 }
 
 int fsnap_residual_rhs(fsnap_ctx* ctx, const double* beta, double* s, double* sse) {

@@ -1,0 +1,146 @@
+// fsnap_ctx.h — the context object behind the opaque fsnap_ctx of include/fsnap_hip.h, shared by the translation
+// units of the C-ABI layer (fsnap_capi.cpp: rows / statistics / solve; fsnap_comm.cpp: RCCL communicator;
+// fsnap_rowspace.cpp: row-space least squares).  Internal; not part of the public boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "../../include/fsnap_hip.h"
+
+namespace fsnap {
+
+// last error text of the calling thread when no context is at hand (fsnap_last_error(NULL))
+std::string& library_error();
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    bool ensure(size_t n) {
+        if (n <= bytes && p) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        if (hipMalloc(&p, n) != hipSuccess) {
+            p = nullptr;
+            return false;
+        }
+        bytes = n;
+        return true;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct Comm;       // fsnap_comm.cpp: RCCL communicator of this rank (nullptr = single GPU)
+struct RowSpace;   // fsnap_rowspace.cpp: buffers of the row-space least-squares path
+
+}  // namespace fsnap
+
+using fsnap::DevBuf;
+
+struct fsnap_ctx {
+    int device = 0;
+    int num_cu = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[10] = {};
+    static constexpr int RING = 256;              // event triples of the last RING fits (fsnap_timing_history)
+    hipEvent_t ring[RING][3] = {};
+    int64_t nfit = 0;                             // fits launched so far
+    std::string err;
+
+    // rows
+    const double* dA = nullptr;
+    const double* db = nullptr;
+    int64_t m = 0, K = 0, lda = 0;
+    DevBuf ownA, ownb;
+    // weights
+    const double* dw = nullptr;
+    const unsigned char* dmask = nullptr;
+    DevBuf ownw, ownmask, ones;
+    // workspaces
+    DevBuf part, cpart, spart, packed, beta, preds, sse, aw, bw;
+    DevBuf st_raw, st_plan, st_frac, st_blank;   // staging of fsnap_assemble
+    DevBuf dsolve;                                // [beta | min pivot | status] of fsnap_solve_device
+    DevBuf dchol;                                 // padded work matrix of the blocked device Cholesky
+    DevBuf dcat, dstat;                           // fsnap_error_stats: row categories, partial tables + means
+    DevBuf wpack, wpack_spart;                    // kernel 1A: packed (w_eff, w_eff b) per row + partial b-only scalars
+    bool wpack_valid = false;                     // false after anything that can change b, w or the mask
+    const double* wpack_override = nullptr;       // per-row pairs to use INSTEAD of wpack (row-space passes only)
+    int64_t dcat_rows = -1;                       // number of rows the categories on the device belong to
+    DevBuf du, dspart, dsvec;                     // refinement: row weights u, per-workgroup partials, s
+    double* pinned = nullptr;                     // page-locked host staging of the packed statistics: plain (coarse-grained)
+                                                  // pinned memory, the target of DMA copies only -- copies into COHERENT
+                                                  // host memory were bimodal (2 MB in 0.05 or in 8 ms)
+    size_t pinned_bytes = 0;
+    double* mirror = nullptr;                     // page-locked host mirror written by the reduction kernel itself
+    size_t mirror_bytes = 0;
+    const double* mirror_of = nullptr;            // device buffer the mirror currently reflects (nullptr = stale)
+    int64_t mirror_K = 0;                         // order of the system in the mirror
+    hipEvent_t mirror_ev = nullptr;               // recorded after the reduction that filled the mirror
+    // options
+    int opt_split = 0;        // 0 = auto
+    int opt_nt = 1;
+    int opt_nblocks = 0;      // 0 = auto
+    int opt_tiled = 0;        // force the general-K tiled kernel also for K <= 128
+    int opt_kernel = 0;       // 0 auto | 1 wave-triangle (kernel 1) | 2 LDS-shared, static per-wave bodies | 3 LDS-shared, generic
+    int opt_nsplit = 0;       // row splits of the tiled kernel (0 = auto)
+    int opt_xcd = 1;          // tiled kernel: contiguous work-item ranges per XCD
+    int opt_tiled2 = 0;       // K > 128: 1 = kernel 1T2 (one wave per SIMD, 32-tile items; measured no faster), 0 = kernel 1T
+    int opt_mirror = 1;       // fsnap_normal_eq_resident: reduction writes a page-locked host mirror (K <= 128)
+    int opt_device_solve = 0; // 0 = auto (K >= 384 on the GPU, blocked), 1 = every K (K <= 128: fsnap_chol_solve_k), 2 = never
+    int opt_ablate = 0;       // timing-only ablation of kernel 1L (diagnostics; results are wrong)
+    // cached launch plan of the tiled kernel (plan_tiled)
+    bool tplan_valid = false;
+    int64_t tplan_key[5] = {0, 0, 0, 0, 0};
+    int tplan[3] = {0, 0, 0};
+    int64_t tplan_cps = 0;
+    int tplan_items = 0;                          // kernel 1T2: work items per split (table in titems)
+    DevBuf titems;
+    // timing flags
+    bool t_syrk = false, t_upload = false, t_weight = false, t_predict = false;
+
+    // multi-GPU / row-space state owned by the other translation units
+    fsnap::Comm* comm = nullptr;
+    fsnap::RowSpace* rowspace = nullptr;
+    DevBuf commbuf;                               // device staging of host-buffer collectives
+    int opt_repack = 0;       // 1 = pack (w_eff, w_eff b) on every launch even when b / w / mask are context-owned
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        fsnap::library_error() = buf;
+        return code;
+    }
+    int hipfail(hipError_t e, const char* what) {
+        return fail(e == hipErrorOutOfMemory ? FSNAP_E_NOMEM : FSNAP_E_HIP, "%s: %s", what, hipGetErrorString(e));
+    }
+};
+
+
+#define FSNAP_HIP(call, what)                                \
+    do {                                                     \
+        hipError_t _e = (call);                              \
+        if (_e != hipSuccess) return ctx->hipfail(_e, what); \
+    } while (0)
+
+namespace fsnap {
+// fsnap_capi.cpp: statistics of OTHER rows than the resident ones with the resident rows' launch plan -- the passes
+// of the row-space solve run the same SYRK kernels on the orthogonalised copy Q (m x K, leading dimension ldq) with
+// per-row pairs qpack = (1, w_eff b); d_packed receives [Q^T Q | Q^T b_w | ...]
+int normal_eq_launch_on(fsnap_ctx* ctx, const double* Q, int64_t ldq, const double* qpack, double* d_packed);
+// fsnap_capi.cpp: makes sure ctx->wpack holds (w_eff, w_eff b) of the current b / w / mask
+int wpack_current(fsnap_ctx* ctx);
+// fsnap_rowspace.cpp
+void rowspace_release(fsnap_ctx* ctx);
+}  // namespace fsnap

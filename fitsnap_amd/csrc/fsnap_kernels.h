@@ -83,7 +83,7 @@ hipError_t launch_chol_large(const double* packed, const double* cvec, int n, do
 int gemv_num_blocks(int64_t m);
 hipError_t launch_gemv_rows(const double* A, int64_t lda, const double* beta, int64_t m, int K, double* preds,
                             const double* b, const double* w, const unsigned char* mask, double* sse_part,
-                            double* uout, hipStream_t st);
+                            double* uout, hipStream_t st, bool uplain = false);   // uplain: u = w (b - a.beta), not w^2 (...)
 int gemvT_num_blocks(int64_t m);
 int error_stats_num_blocks(int64_t m);
 // pass 0: partial[grid][ncat][4] = n, n_w, sum t, sum w t; pass 1: partial[grid][ncat][6] (see kernel 9)
@@ -91,5 +91,14 @@ hipError_t launch_error_stats(const double* truth, const double* pred, const dou
                               int pass, const double* means, double* partial, hipStream_t st);
 hipError_t launch_gemvT_rows(const double* A, int64_t lda, const double* u, int64_t m, int K, double* partial,
                              double* out, hipStream_t st);
+
+// Row-space solve (fsnap_trsm.hip).  Q <- X R^-1 by blocked substitution over the columns, one wave per 64 rows:
+// first pass X = diag(w_eff) A (src = A, leading dimension lds, per-row pairs wpack = (w_eff, w_eff b); rows with
+// w_eff = 0 become zero rows), later passes X = Q in place (src = Q, wpack = nullptr).  R: device, K16 x K16 row-major
+// upper triangular, K16 = K rounded up to 16, identity in the padding.
+hipError_t launch_trsm_rows(const double* src, int64_t lds, const double* wpack, double* Q, int64_t ldq, int64_t m, int K,
+                            const double* R, int K16, hipStream_t st);
+// qpack[row] = (w_eff != 0 ? 1 : 0, w_eff b): per-row pairs that make the SYRK kernels compute Q^T Q and Q^T (w b)
+hipError_t launch_qpack(const double* wpack, int64_t m, double* qpack, hipStream_t st);
 
 }  // namespace fsnap

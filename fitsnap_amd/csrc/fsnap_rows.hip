@@ -83,9 +83,11 @@ __global__ __launch_bounds__(256) void fsnap_gemv_rows_k(const double* __restric
                                                          const double* __restrict__ w,
                                                          const unsigned char* __restrict__ mask,
                                                          double* __restrict__ sse_part,
-                                                         double* __restrict__ uout) {
+                                                         double* __restrict__ uout, int uplain) {
     // uout (optional): u_i = mask_i * w_i^2 * (b_i - a_i . beta), the row weights of the
-    // refinement right-hand side  s = (wA)^T (wb - wA beta) = A^T u   (kernel 7)
+    // refinement right-hand side  s = (wA)^T (wb - wA beta) = A^T u   (kernel 7);
+    // uplain: u_i = mask_i * w_i * (b_i - a_i . beta) instead, the weighted residual itself (its product with the
+    // orthonormal factor Q of the row-space solve is the refinement right-hand side there)
     extern __shared__ __attribute__((aligned(16))) double sbeta[];
     for (int c = threadIdx.x; c < K; c += 256) sbeta[c] = beta[c];
     __syncthreads();
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void fsnap_gemv_rows_k(const double* __restric
                 const double wr = w[row];
                 const double rr = keep ? wr * (b[row] - s) : 0.0;
                 if (sse_part) sse = __builtin_fma(rr, rr, sse);
-                if (uout) uout[row] = keep ? wr * rr : 0.0;
+                if (uout) uout[row] = keep ? (uplain ? rr : wr * rr) : 0.0;
             }
         }
     }
@@ -478,10 +480,10 @@ int gemv_num_blocks(int64_t m) {
 
 hipError_t launch_gemv_rows(const double* A, int64_t lda, const double* beta, int64_t m, int K, double* preds,
                             const double* b, const double* w, const unsigned char* mask, double* sse_part,
-                            double* uout, hipStream_t st) {
+                            double* uout, hipStream_t st, bool uplain) {
     const int nb = gemv_num_blocks(m);
     hipLaunchKernelGGL(fsnap_gemv_rows_k, dim3((unsigned)nb), dim3(256), (size_t)K * sizeof(double), st, A, lda,
-                       beta, m, K, preds, b, w, mask, sse_part, uout);
+                       beta, m, K, preds, b, w, mask, sse_part, uout, uplain ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -626,6 +626,13 @@ struct PhaseTimer {   // FSNAP_SOLVE_TIMING=1: print the phases of the fast path
 extern "C" int fsnap_solve_diag(int kind, double param, int64_t K64, const double* G, const double* c, const double* diag,
                                 double* beta, int* rank_out, double* rcond_est);
 
+// In-place Cholesky U^T U of an n x n row-major matrix for the other translation units of the library (the row-space
+// passes, fsnap_rowspace.cpp): upper triangle in, U out, lower triangle must be zero on entry; n a multiple of 32 runs
+// the register-blocked variant at full speed.  Returns -1 or the failing pivot; *min_piv = smallest pivot before sqrt.
+extern "C" __attribute__((visibility("hidden"))) int fsnap_host_chol_upper(double* a, int n, double* min_piv) {
+    return fast_chol(a, n, min_piv);
+}
+
 extern "C" int fsnap_solve(int kind, double param, int64_t K64, const double* G, const double* c, double* beta,
                            int* rank_out, double* rcond_est) {
     return fsnap_solve_diag(kind, param, K64, G, c, nullptr, beta, rank_out, rcond_est);

@@ -18,9 +18,15 @@ underneath:
   examples/library/transpose_trick/example.py:245-246);
 * ``comm=None`` is the reference's "stubs" mode: one process, no collectives.
 
-``comm`` may be ``None`` (stubs), the string ``"torch"`` / ``True`` (use the default
-``torch.distributed`` process group, which must already be initialised) or a
-``torch.distributed.ProcessGroup``.
+``comm`` selects the transport of a multi-rank job:
+
+* ``None`` -- the reference's "stubs" mode: one process, no collectives;
+* ``"rccl"`` -- one process per GPU, NATIVE RCCL over xGMI behind the C ABI (``fsnap_comm_*``): no torch anywhere on the
+  linear path.  Rank / world size / device come from ``RANK`` / ``WORLD_SIZE`` / ``LOCAL_RANK`` (``torchrun`` sets
+  them), the communicator id travels through ``fitsnap_amd.rendezvous`` -- or through ``exchange_id`` (a callable
+  ``id_or_None -> id``, e.g. ``lambda b: mpi_comm.bcast(b, root=0)`` on the reference side);
+* ``"torch"`` / ``True`` / a ``torch.distributed.ProcessGroup`` -- an already initialised ``torch.distributed`` group
+  (gloo on CPUs in the world-size-2 tests; the NN solver's group): statistics are reduced through host tensors.
 """
 from __future__ import annotations
 
@@ -184,36 +190,143 @@ class SharedArray(StubsArray):
         self._nbytes = 0
 
 
+class _TorchTransport:
+    """Collectives over an initialised ``torch.distributed`` group (CPU tests with gloo, or a caller-owned group)."""
+
+    kind = "torch"
+
+    def __init__(self, group):
+        import torch.distributed as dist
+
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError("ParallelTools(comm=...) needs an initialised torch.distributed process group")
+        self._dist = dist
+        self._group = group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+        self.on_gpu = dist.get_backend(group) == "nccl"
+
+    def _device(self, pt):
+        import torch
+
+        return torch.device("cuda", pt.device_index()) if self.on_gpu else torch.device("cpu")
+
+    def allreduce_host(self, pt, arr, op):
+        import torch
+
+        t = torch.from_numpy(arr).to(self._device(pt))
+        red = {0: self._dist.ReduceOp.SUM, 1: self._dist.ReduceOp.MAX, 2: self._dist.ReduceOp.MIN}[op]
+        self._dist.all_reduce(t, op=red, group=self._group)
+        arr[...] = t.cpu().numpy()
+        return arr
+
+    def allgather_object(self, pt, obj):
+        out = [None] * self.size
+        self._dist.all_gather_object(out, obj, group=self._group)
+        return out
+
+    def bcast_object(self, pt, obj, src):
+        box = [obj]
+        self._dist.broadcast_object_list(box, src=src, group=self._group)
+        return box[0]
+
+    def barrier(self, pt):
+        self._dist.barrier(group=self._group)
+
+    def close(self, pt):
+        pass
+
+
+class _RcclTransport:
+    """Native RCCL: every collective is a call into libfsnap_hip on this rank's context (``fsnap_comm_*``)."""
+
+    kind = "rccl"
+
+    def __init__(self, exchange_id=None):
+        import os
+
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.size = int(os.environ.get("WORLD_SIZE", "1"))
+        self._exchange_id = exchange_id
+        self._joined = False
+        self.on_gpu = True
+
+    def join(self, pt):
+        """Collective, once: create this rank's context and enter the communicator."""
+        if self._joined:
+            return
+        from . import _capi, rendezvous
+
+        ctx = pt.hip()
+        if self._exchange_id is not None:
+            ident = self._exchange_id(_capi.comm_id() if self.rank == 0 else None)
+        else:
+            ident = rendezvous.exchange(self.rank, self.size, _capi.comm_id)
+        ctx.comm_init(self.size, self.rank, ident)
+        if self._exchange_id is None:
+            rendezvous.done(self.rank)
+        self._joined = True
+
+    def allreduce_host(self, pt, arr, op):
+        return pt.hip().allreduce_host(arr, op)
+
+    def _gather_blobs(self, pt, blob):
+        ctx = pt.hip()
+        sizes = np.zeros(self.size)
+        sizes[self.rank] = len(blob)
+        ctx.allreduce_host(sizes)
+        width = max(int(sizes.max()), 1)
+        parts = ctx.allgather_bytes(blob.ljust(width, b"\0"), self.size)
+        return [parts[r][:int(sizes[r])] for r in range(self.size)]
+
+    def allgather_object(self, pt, obj):
+        import pickle
+
+        return [pickle.loads(b) for b in self._gather_blobs(pt, pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL))]
+
+    def bcast_object(self, pt, obj, src):
+        import pickle
+
+        ctx = pt.hip()
+        blob = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL) if self.rank == src else b""
+        n = np.array([float(len(blob))])
+        ctx.allreduce_host(n, 1)                                   # max = the source's length
+        return pickle.loads(ctx.bcast_bytes(blob if self.rank == src else None, int(n[0]), src))
+
+    def barrier(self, pt):
+        pt.hip().barrier()
+
+    def close(self, pt):
+        pass                                                       # the context's destructor leaves the communicator
+
+
 class ParallelTools:
     """See module docstring.  Attribute names follow fitsnap3lib/parallel_tools.py:157-200."""
 
-    def __init__(self, comm=None):
+    def __init__(self, comm=None, exchange_id=None):
         self.check_fitsnap_exist = True
         self.create_shared_bool = True
         self.double_size = 8
         self._fp = None
         self._lmp = None
         self.logger = None
-        self._dist = None
-        self._group = None
         self._hip = None
         self._device_index = None
+        self._transport = None
         if comm is None or comm is False:
             self.stubs = 1
             self._comm = None
             self._rank = 0
             self._size = 1
         else:
-            import torch.distributed as dist
-
-            if not dist.is_available() or not dist.is_initialized():
-                raise RuntimeError("ParallelTools(comm=...) needs an initialised torch.distributed process group")
+            if isinstance(comm, str) and comm.lower() == "rccl":
+                self._transport = _RcclTransport(exchange_id)
+            else:
+                self._transport = _TorchTransport(None if comm in (True, "torch") else comm)
             self.stubs = 0
-            self._dist = dist
-            self._group = None if comm in (True, "torch") else comm
             self._comm = comm
-            self._rank = dist.get_rank(self._group)
-            self._size = dist.get_world_size(self._group)
+            self._rank = self._transport.rank
+            self._size = self._transport.size
         # one process per GPU: every rank is its own "node head" for its own rows
         self._sub_rank = 0
         self._sub_size = 1
@@ -222,10 +335,21 @@ class ParallelTools:
         self._node_index = self._rank
         self._number_of_nodes = self._size
         self._seed = 0.0
-        self._set_seed()
         self.shared_arrays = {}
         self.fitsnap_dict = {}
         self.local_lists = {}    # multi-rank: this rank's row-metadata lists after gather_fitsnap
+        if self.comm_kind == "rccl":
+            self._transport.join(self)
+        self._set_seed()
+
+    @property
+    def comm_kind(self):
+        """"stubs" | "rccl" (native, GPU) | "torch" (torch.distributed group)."""
+        return "stubs" if self._transport is None else self._transport.kind
+
+    @property
+    def multi(self):
+        return self._transport is not None and self._size > 1
 
     # -- rank helpers (parallel_tools.py:245-336) ---------------------------------------
     def get_rank(self):
@@ -292,46 +416,40 @@ class ParallelTools:
 
     # -- collectives (reference: mpi4py) ---------------------------------
     def all_barrier(self):
-        if not self.stubs:
-            self._dist.barrier(group=self._group)
+        if self._transport is not None:
+            self._transport.barrier(self)
 
     def sub_barrier(self):
         return
 
     def bcast_object(self, obj, src=0):
-        if self.stubs:
+        if self._transport is None or self._size == 1:
             return obj
-        box = [obj]
-        self._dist.broadcast_object_list(box, src=src, group=self._group)
-        return box[0]
+        return self._transport.bcast_object(self, obj, src)
 
-    def allreduce_scalar(self, value):
-        if self.stubs:
+    def allgather_object(self, obj):
+        """One Python object per rank, in rank order (``comm.allgather``)."""
+        if self._transport is None or self._size == 1:
+            return [obj]
+        return self._transport.allgather_object(self, obj)
+
+    def allreduce_host(self, arr, op=0):
+        """In-place reduction over the ranks of a C-contiguous float64 array on the host (op: 0 sum, 1 max, 2 min)."""
+        if self._transport is None or self._size == 1:
+            return arr
+        return self._transport.allreduce_host(self, arr, op)
+
+    def allreduce_scalar(self, value, op=0):
+        if self._transport is None or self._size == 1:
             return value
-        import torch
-
-        t = torch.tensor([float(value)], dtype=torch.float64, device=self._collective_device())
-        self._dist.all_reduce(t, group=self._group)
-        return float(t.item())
-
-    def _collective_device(self):
-        import torch
-
-        backend = self._dist.get_backend(self._group)
-        if backend == "nccl":
-            return torch.device("cuda", self.device_index())
-        return torch.device("cpu")
+        return float(self.allreduce_host(np.array([float(value)]), op)[0])
 
     def allreduce_statistics(self, packed):
-        """Sum the packed K x K statistics [G | c | bTb, sum_bw, n_train] over ranks — the
-        one data-path collective of a fit (reference form:
-        examples/library/transpose_trick/example.py:245-246, two MPI Allreduce calls).
-        ``packed`` is a torch tensor (cuda: RCCL over xGMI; cpu: gloo in the CPU tests);
-        reduced in place and returned."""
-        if self.stubs or self._size == 1:
-            return packed
-        self._dist.all_reduce(packed, op=self._dist.ReduceOp.SUM, group=self._group)
-        return packed
+        """Sum the packed K x K statistics [G | c | bTb, sum_bw, n_train] (host ndarray) over the ranks — the one
+        data-path collective of a fit (reference form: examples/library/transpose_trick/example.py:245-246, two MPI
+        Allreduce calls).  The native RCCL transport does not come through here for a fit: ``fsnap_fit_dist``
+        all-reduces the statistics in HBM on the kernels' stream."""
+        return self.allreduce_host(packed, 0)
 
     def gather_fitsnap(self, name, allgather=None):
         """All-gather a per-rank list held in ``fitsnap_dict`` (parallel_tools.py:426-441)."""
@@ -339,13 +457,11 @@ class ParallelTools:
             raise NameError("Dictionary element not yet in fitsnap_dictionary")
         if self.stubs:
             return
-        out = [None] * self._size
-        self._dist.all_gather_object(out, self.fitsnap_dict[name], group=self._group)
-        self.fitsnap_dict[name] = out
+        self.fitsnap_dict[name] = self.allgather_object(self.fitsnap_dict[name])
 
     def get_ncpn(self, nconfigs):
         """Number of configurations over all ranks (parallel_tools.py:562-577)."""
-        return int(self.allreduce_scalar(nconfigs)) if not self.stubs else nconfigs
+        return int(round(self.allreduce_scalar(nconfigs))) if not self.stubs else nconfigs
 
     # -- device -------------------------------------------------------------------------
     def device_index(self):
@@ -389,14 +505,14 @@ class ParallelTools:
         self.fitsnap_dict[name] = an_object
 
     def free(self):
-        """Free all shared arrays (parallel_tools.py:338-350) and the HBM mirror."""
+        """Free all shared arrays (parallel_tools.py:338-350), the HBM mirror and (native transport) the communicator."""
         for name in list(self.shared_arrays):
             try:
                 self.shared_arrays[name].win.Free()
             except Exception:
                 pass
         if self._hip is not None:
-            self._hip.close()
+            self._hip.close()                  # fsnap_ctx_destroy leaves the RCCL communicator first
             self._hip = None
 
     def slice_array(self, name):

@@ -33,8 +33,9 @@ class RIDGE(Solver):
         kind = _capi.SOLVE_RIDGE_INV if local else _capi.SOLVE_RIDGE
         if "EXTRAS" in self.config.sections and self.config.sections["EXTRAS"].apply_transpose:
             G, c, _ = self._fit_statistics(a, b, w, fs_dict, trainall)
+            fit = self._solve(kind, alval, G.T @ G, G.T @ c)
             if pt._rank == 0:
-                self.fit = self._solve(kind, alval, G.T @ G, G.T @ c)
+                self.fit = fit
             return
         fit = self._fit_and_solve(kind, alval, a, b, w, fs_dict, trainall)
         if self.refine_steps:        # off by default: the reference's ridge is itself a normal-equation solve

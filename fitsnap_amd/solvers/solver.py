@@ -61,9 +61,10 @@ class Solver:
         self._resident_key = None
         self._stats_host = None      # (G, c, scalars) of the last fit, host ndarrays (after all-reduce)
         self._stats_dev = None       # or (ctx, device address, K) while they are still in HBM only
-        self._stats_keepalive = None  # torch tensor that owns that device address (multi-GPU path)
         self.device_error_stats = True  # error_analysis: grouped reductions on the GPU (False = pandas groupby)
         self.last_rank = None
+        self.last_rcond = None
+        self.last_row_space = None   # diagnostics of the last row-space solve (passes, deviation, ...), or None
         self._checks()
 
     # ------------------------------------------------------------------------------
@@ -198,36 +199,11 @@ class Solver:
         self._resident_key = key
         return ctx
 
-    def _local_statistics_async(self, a, b, w_full, mask, shared_mode, packed_ptr, stream_handle):
-        """Launch this rank's fused kernel into a DEVICE packed buffer (multi-GPU path)."""
-        ctx = self._upload(a, b, shared_mode)
-        ctx.set_weights(w_full, None if mask.all() else mask)
-        ctx.set_stream(stream_handle)
-        ctx.normal_eq_async(packed_ptr)
-
     def _local_statistics(self, a, b, w_full, mask, shared_mode):
-        """This rank's (G, c, scalars) on the host (single-GPU path and CPU process groups)."""
+        """This rank's (G, c, scalars) on the host."""
         ctx = self._upload(a, b, shared_mode)
         ctx.set_weights(w_full, None if mask.all() else mask)
         return ctx.normal_eq()
-
-    def _allreduced_packed_device(self, a=None, b=None, w=None, fs_dict=None, trainall=False):
-        """Multi-GPU (nccl = RCCL) path: this rank's fused kernel into a device tensor, all-reduced in place on the
-        same stream.  Returns (packed torch tensor [G | c | scalars] on this rank's GPU, K)."""
-        import torch
-
-        pt = self.pt
-        a, b, w_full, mask, shared_mode = self._resolve_inputs(a, b, w, fs_dict, trainall)
-        if a.ndim != 2:
-            raise ValueError("the A matrix must be 2-D")
-        K = a.shape[1]
-        dev = torch.device("cuda", pt.device_index())
-        packed = torch.zeros(K * K + K + 3, dtype=torch.float64, device=dev)
-        if a.shape[0] > 0:
-            self._local_statistics_async(a, b, w_full, mask, shared_mode, packed.data_ptr(),
-                                         torch.cuda.current_stream(dev).cuda_stream)
-        pt.allreduce_statistics(packed)
-        return packed, K
 
     def _fit_statistics(self, a=None, b=None, w=None, fs_dict=None, trainall=False):
         """mask x weight x normal equations on this rank's GPU, summed over ranks.
@@ -239,33 +215,13 @@ class Solver:
         if a.ndim != 2:
             raise ValueError("the A matrix must be 2-D")
         K = a.shape[1]
-        n = K * K + K + 3
-        have_rows = a.shape[0] > 0
-        if pt.stubs or pt._size == 1:
-            G, c, s = self._local_statistics(a, b, w_full, mask, shared_mode) if have_rows else \
-                (np.zeros((K, K)), np.zeros(K), np.zeros(3))
+        if a.shape[0] > 0:
+            G, c, s = self._local_statistics(a, b, w_full, mask, shared_mode)
         else:
-            import torch
-
-            if pt._dist.get_backend(pt._group) == "nccl":
-                # statistics stay in HBM: kernel -> RCCL all-reduce on the same stream -> one D2H
-                dev = torch.device("cuda", pt.device_index())
-                packed = torch.zeros(n, dtype=torch.float64, device=dev)
-                if have_rows:
-                    self._local_statistics_async(a, b, w_full, mask, shared_mode, packed.data_ptr(),
-                                                 torch.cuda.current_stream(dev).cuda_stream)
-                pt.allreduce_statistics(packed)
-                host = packed.cpu().numpy()
-            else:
-                # CPU process group (gloo, used by the world_size-2 tests): reduce on the host
-                if have_rows:
-                    G, c, s = self._local_statistics(a, b, w_full, mask, shared_mode)
-                    host = np.concatenate([np.asarray(G).ravel(), c, s])
-                else:
-                    host = np.zeros(n)
-                packed = torch.from_numpy(np.ascontiguousarray(host))
-                pt.allreduce_statistics(packed)
-                host = packed.numpy()
+            G, c, s = np.zeros((K, K)), np.zeros(K), np.zeros(3)
+        if pt.multi:
+            host = np.concatenate([np.asarray(G, dtype=np.float64).ravel(), c, s])
+            pt.allreduce_statistics(host)
             G = host[:K * K].reshape(K, K).copy()
             c = host[K * K:K * K + K].copy()
             s = host[K * K + K:].copy()
@@ -274,78 +230,64 @@ class Solver:
 
     def _solve(self, kind, param, G, c):
         """Host K x K solve on statistics already on the host."""
-        beta, rank, _ = _capi.solve(kind, param, G, c)
-        self.last_rank = rank
+        beta, rank, rcond = _capi.solve(kind, param, G, c)
+        self.last_rank, self.last_rcond = rank, rcond
         return beta
 
     def _fit_and_solve(self, kind, param, a=None, b=None, w=None, fs_dict=None, trainall=False):
-        """The latency path of SVD / RIDGE in single-GPU mode: the statistics stay in HBM and
-        the K x K factorisation runs on the GPU (``fsnap_solve_device``; host fallback inside
-        the library for rank-deficient / ill-conditioned systems and K > 128); only beta
-        crosses PCIe.  ``last_statistics`` is then fetched lazily.  With several ranks the
-        all-reduced statistics are on the host already and rank 0 solves there."""
+        """The latency path of SVD / RIDGE: the statistics stay in HBM, the K x K system is solved through
+        ``fsnap_solve_device`` (page-locked mirror + host factorisation for small K, blocked Cholesky on the GPU for
+        large K) and only beta crosses PCIe; ``last_statistics`` is fetched lazily.
+
+        Multi-GPU job on the native RCCL transport: ``fsnap_fit_dist`` -- kernel, in-place all-reduce on the same
+        stream, solve -- on EVERY rank (deterministic solve of bit-identical sums: the ranks agree on beta, rank and
+        conditioning without a broadcast; ``perform_fit`` still publishes ``fit`` on rank 0 only, as the reference).
+        A ``torch.distributed`` group (CPU tests) reduces the statistics through the host instead."""
         pt = self.pt
-        if not (pt.stubs or pt._size == 1):
-            if pt._dist.get_backend(pt._group) == "nccl":
-                # kernel -> RCCL all-reduce on the same stream -> rank 0 solves straight from HBM
-                # (fsnap_solve_device: large K is factorised on the GPU, G is downloaded only on demand)
-                packed, K = self._allreduced_packed_device(a, b, w, fs_dict, trainall)
-                self._stats_host = None
-                self._stats_keepalive = packed
-                ctx = pt.hip()
-                self._stats_dev = (ctx, packed.data_ptr(), K)
-                if pt._rank != 0:
-                    return None
-                ctx.mirror_packed(packed.data_ptr(), K)       # K < 384: page-locked mirror instead of a D2H copy
-                beta, rank, _ = ctx.solve_device(kind, param, K, packed.data_ptr())
-                self.last_rank = rank
-                return beta
+        if pt.multi and pt.comm_kind != "rccl":
             G, c, _ = self._fit_statistics(a, b, w, fs_dict, trainall)
-            return self._solve(kind, param, G, c) if pt._rank == 0 else None
+            return self._solve(kind, param, G, c)
         a, b, w_full, mask, shared_mode = self._resolve_inputs(a, b, w, fs_dict, trainall)
         if a.ndim != 2:
             raise ValueError("the A matrix must be 2-D")
         K = a.shape[1]
-        if a.shape[0] == 0:
-            self._stats_host = (np.zeros((K, K)), np.zeros(K), np.zeros(3))
-            return self._solve(kind, param, *self._stats_host[:2])
-        ctx = self._upload(a, b, shared_mode)
-        ctx.set_weights(w_full, None if mask.all() else mask)
+        have_rows = a.shape[0] > 0
         self._stats_host = None
         self._stats_dev = None
-        beta, rank, _, ptr = ctx.fit_resident(kind, param)      # kernel + reduction + K x K solve, one library call
+        if not have_rows and not pt.multi:
+            self._stats_host = (np.zeros((K, K)), np.zeros(K), np.zeros(3))
+            return self._solve(kind, param, *self._stats_host[:2])
+        ctx = pt.hip()
+        if have_rows:
+            ctx = self._upload(a, b, shared_mode)
+            ctx.set_weights(w_full, None if mask.all() else mask)
+        if pt.multi:
+            beta, rank, rcond, ptr = ctx.fit_dist(kind, param, K)       # collective
+        else:
+            beta, rank, rcond, ptr = ctx.fit_resident(kind, param)      # kernel + reduction + K x K solve, one library call
         self._stats_dev = (ctx, ptr, K)
-        self.last_rank = rank
+        self.last_rank, self.last_rcond = rank, rcond
         return beta
+
+    def _rows_on_device(self):
+        """True when this rank's context holds rows (a rank of a multi-GPU job may own none)."""
+        ctx = self.pt._hip
+        return ctx is not None and ctx.m > 0
 
     def _refine(self, beta, kind, param, steps):
         """Iterative refinement of a least-squares / ridge solution with the residual formed
         from the ROWS (``fsnap_residual_rhs``: s = (wA)^T (wb - wA beta), two streaming passes
         over the resident A): G delta = s - alpha beta, beta += delta.  Takes the error of the
         normal-equation solve from ~kappa^2 eps to ~kappa eps (measured on the golden Ta set:
-        7e-8 -> 5e-13 vs the reference lstsq).  Collective in multi-rank mode."""
+        7e-8 -> 5e-13 vs the reference lstsq).  Collective in a multi-rank job: the right-hand side is all-reduced and
+        every rank solves the same system, so all ranks take the same number of steps."""
         pt = self.pt
-        multi = not (pt.stubs or pt._size == 1)
         alpha = param if kind in (_capi.SOLVE_RIDGE, _capi.SOLVE_RIDGE_INV) else 0.0
         G = None
         for _ in range(int(steps)):
-            if multi:
-                beta = pt.bcast_object(beta, src=0)
-            ctx = pt._hip
-            if ctx is not None and ctx.m > 0:
-                s, _ = ctx.residual_rhs(beta)
-            else:
-                s = np.zeros(len(beta))
-            if multi:
-                import torch
-
-                t = torch.from_numpy(np.ascontiguousarray(s))
-                if pt._dist.get_backend(pt._group) == "nccl":
-                    t = t.to(torch.device("cuda", pt.device_index()))
-                pt.allreduce_statistics(t)
-                s = t.cpu().numpy()
-            if pt._rank != 0:
-                continue
+            s = pt._hip.residual_rhs(beta)[0] if self._rows_on_device() else np.zeros(len(beta))
+            if pt.multi:
+                pt.allreduce_host(s)
             rhs = s - alpha * beta
             if self._stats_dev is not None and self._stats_host is None:
                 # statistics still in HBM: solve there (large K: blocked Cholesky on the GPU, G never crosses PCIe)
@@ -358,8 +300,33 @@ class Solver:
             if rank < len(beta):        # truncated (rank-deficient) solve: refinement is not meaningful
                 break
             beta = beta + delta
-            if not multi and np.max(np.abs(delta)) <= 1e-14 * np.max(np.abs(beta)):
+            if np.max(np.abs(delta)) <= 1e-14 * np.max(np.abs(beta)):
                 break
+        return beta
+
+    ROWSPACE_RCOND = 1.0e-11    # smallest pivot of the Jacobi-scaled Cholesky below which the statistics are not trusted
+
+    def _needs_row_space(self, K):
+        """After a LSTSQ solve from the statistics: did the K x K system resolve the problem?  No when the scaled
+        Cholesky met a pivot below ``ROWSPACE_RCOND`` (kappa of the equilibrated A_w beyond ~3e5: the refinement with
+        the normal matrix stops converging around 1e7) or when the solve dropped directions that are not simply
+        exactly-zero columns.  Same answer on every rank (the inputs are the all-reduced statistics)."""
+        rank, rcond = self.last_rank, getattr(self, "last_rcond", None)
+        if rank is None or rcond is None:
+            return False
+        if rank < K:
+            G = self.last_statistics[0]
+            zero_cols = int(np.count_nonzero(np.diag(G) == 0.0))
+            return rank < K - zero_cols or rcond < self.ROWSPACE_RCOND
+        return rcond < self.ROWSPACE_RCOND
+
+    def _row_space_fit(self, K, rcond):
+        """``lstsq(aw, bw, rcond)`` on the rows (``fsnap_lstsq_rows``): CholeskyQR passes on the GPU, dgelsd's K x K end
+        on the host.  The rows and weights of the fit that just ran are resident.  Collective in a multi-rank job."""
+        ctx = self.pt.hip()
+        beta, rank, info = ctx.lstsq_rows(rcond, K)
+        self.last_rank = rank
+        self.last_row_space = info
         return beta
 
     @property
@@ -496,6 +463,27 @@ class Solver:
         keys, st = self._device_error_sums(a, b, w, shared, fs_dict)
         return self._tables_from_sums(keys, st)
 
+    def _global_keys(self, keys):
+        """Sorted union over the ranks of the (group, testing, row type) keys.  The exchange is one small all-gather of
+        Python objects; a re-weighting loop (``keep_resident``) that keeps presenting the same local key list reuses
+        the union -- its per-candidate traffic is then the fixed-size table of doubles alone.  Collective: every rank
+        must take the same branch, which holds when all ranks run the same loop with ``keep_resident`` set alike."""
+        gk = getattr(self, "_gkeys_cache", None)
+        if self.keep_resident and gk is not None and gk[0] is keys:
+            return gk[1]
+        union = sorted({k for part in self.pt.allgather_object(list(keys)) for k in part})
+        self._gkeys_cache = (keys, union)
+        return union
+
+    def _allgather_tables(self, table):
+        """(ranks, len(table), 10) array of every rank's table of sums (equal shapes: rows follow the global keys)."""
+        pt = self.pt
+        table = np.ascontiguousarray(table, dtype=np.float64)
+        if pt.comm_kind == "rccl":
+            blobs = pt.hip().allgather_bytes(table.tobytes() or b"\0", pt._size)
+            return np.array([np.frombuffer(q[:table.nbytes], dtype=np.float64).reshape(table.shape) for q in blobs])
+        return np.array(pt.allgather_object(table))
+
     def _merge_rank_sums(self, parts):
         """Multi-GPU error analysis: every rank reduced ITS rows to (keys, sums); the union over the ranks is the
         table of all rows (a group may live on several ranks: its sums are pooled).  parts: [(keys, st), ...]."""
@@ -622,13 +610,13 @@ class Solver:
 
         self.errors = []
         pt = self.pt
-        multi = not (pt.stubs or pt._size == 1)
+        multi = pt.multi
         shared = a is None and b is None and w is None and fs_dict is None
         if multi:
             # One process per GPU: every rank owns the rows of ITS configurations.  The fit lives on
-            # rank 0 (reference semantics); broadcast it, predict the local rows on every GPU, gather
-            # (truth, prediction, weight, row labels) on rank 0, which builds the table.  The
-            # reference sees all rows on rank 0 through the node-shared array instead.
+            # rank 0 (reference semantics); broadcast it, evaluate the local rows on every GPU and bring
+            # only what the table needs to rank 0.  The reference sees all rows on rank 0 through the
+            # node-shared array instead.
             self.fit = pt.bcast_object(self.fit, src=0)
             if shared:
                 a = pt.shared_arrays["a"].array
@@ -637,22 +625,27 @@ class Solver:
                 local = pt.local_lists if getattr(pt, "local_lists", None) else pt.fitsnap_dict
             else:
                 local = fs_dict
-            # RCCL job with the rows resident on every rank's GPU: each rank reduces ITS rows to the (groups x 10)
-            # table of sums (fsnap_error_stats), only those tables travel, rank 0 pools them -- no per-row gather
-            # (the reference sees all rows on rank 0 through the node-shared array; SURVEY 8e: "reduce per-group
-            # error sums").  The per-row DataFrame is not built in this mode (EXTRAS dump_dataframe takes the gather).
+            # Rows resident on every rank's GPU: each rank reduces ITS rows to the (groups x 10) table of sums
+            # (fsnap_error_stats); the ranks agree on the union of their group keys, then ONE fixed-size all-gather of
+            # doubles brings the tables to rank 0, which pools them -- no per-row gather ("reduce
+            # per-group error sums").  The per-row DataFrame is not built in this mode (EXTRAS dump_dataframe takes
+            # the gather below).
             if (self.device_error_stats and self.fit is not None and not self.config.sections["EXTRAS"].dump_dataframe
-                    and not self.config.sections["SOLVER"].true_multinode and pt._dist.get_backend(pt._group) == "nccl"):
-                part = self._device_error_sums(a, b, w, shared, local) if len(b) > 0 else ([], np.zeros((0, 10)))
-                parts = [None] * pt._size
-                pt._dist.all_gather_object(parts, part, group=pt._group)
+                    and not self.config.sections["SOLVER"].true_multinode and pt._transport.on_gpu):
+                keys, st = self._device_error_sums(a, b, w, shared, local) if len(b) > 0 else ([], np.zeros((0, 10)))
+                gkeys = self._global_keys(keys)
+                table = np.zeros((len(gkeys), 10))
+                if len(keys):
+                    pos = {k: i for i, k in enumerate(gkeys)}
+                    table[[pos[k] for k in keys]] = np.asarray(st, dtype=np.float64).reshape(len(keys), 10)
+                tables = self._allgather_tables(table)
                 if pt._rank != 0:
                     self.fit = None
                     return
                 self._df = None
                 self._df_parts = None
-                gkeys, gst = self._merge_rank_sums([q for q in parts if q is not None])
-                grouped, allrows = self._tables_from_sums(gkeys, gst)
+                merged = np.array([self._pool_sums(rows[rows[:, 0] > 0]) for rows in np.swapaxes(tables, 0, 1)])
+                grouped, allrows = self._tables_from_sums(gkeys, merged.reshape(len(gkeys), 10))
                 self.errors = self._assemble_errors(grouped, allrows, None)
                 if (self.config.sections["CALCULATOR"].calculator == "LAMMPSSNAP"
                         and "BISPECTRUM" in self.config.sections and self.config.sections["BISPECTRUM"].bzeroflag):
@@ -662,8 +655,7 @@ class Solver:
             n = len(b)
             piece = {"truths": np.asarray(b), "preds": preds, "weights": np.asarray(w),
                      "lists": {k: v for k, v in local.items() if isinstance(v, list) and len(v) == n}}
-            parts = [None] * pt._size
-            pt._dist.all_gather_object(parts, piece, group=pt._group)
+            parts = pt.allgather_object(piece)
             if pt._rank != 0:
                 self.fit = None
                 return

@@ -10,11 +10,14 @@ from .solver import Solver
 
 
 class SVD(Solver):
-    """``perform_fit`` = reference semantics of ``lstsq(aw, bw, 1.0e-13)`` (svd.py:54),
-    computed from the GPU normal-equation statistics: Jacobi-scaled Cholesky with one
-    refinement step when the system is numerically full rank, truncated eigen
-    pseudo-inverse (minimum-norm, gelsd-like) otherwise.  Exactly-zero columns get a zero
-    coefficient, as lstsq's minimum-norm solution gives them."""
+    """``perform_fit`` = reference semantics of ``lstsq(aw, bw, 1.0e-13)`` (svd.py:54).
+
+    Well-conditioned systems (the common case; Ta: kappa 2.7e5): Jacobi-scaled Cholesky of the GPU normal-equation
+    statistics + two refinement steps with the row-space residual.  Ill-conditioned or rank-deficient systems (scaled
+    pivot below 1e-11, or directions dropped that are not zero columns): ``fsnap_lstsq_rows`` -- CholeskyQR passes over
+    the rows on the GPU and dgelsd's own K x K end (SVD of the triangular factor, singular values below
+    1e-13 sigma_max dropped, minimum-norm solution).  Exactly-zero columns get a zero coefficient, as lstsq's
+    minimum-norm solution gives them."""
 
     RCOND = 1.0e-13  # svd.py:54
 
@@ -23,6 +26,7 @@ class SVD(Solver):
         # lstsq works on A_w (error ~ kappa eps); the normal equations square kappa.  Two steps of
         # refinement with the row-space residual close that gap (Solver._refine).
         self.refine_steps = 2
+        self.row_space = True      # row-space (CholeskyQR + SVD) solve when the statistics are ill-conditioned
 
     def perform_fit(self, a=None, b=None, w=None, fs_dict=None, trainall=False):
         """Weighted least-squares fit; same call contract as the reference (svd.py:18-54).
@@ -33,14 +37,16 @@ class SVD(Solver):
         given, and nothing is left out if ``trainall`` is set (precedence: fs_dict, trainall, pt.fitsnap_dict).
         Collective in a multi-rank job; the coefficients end up in ``self.fit`` on rank 0 only."""
         pt = self.pt
-        # every rank contributes its rows' statistics; only rank 0 solves (svd.py:33)
+        # every rank contributes its rows' statistics; the coefficients are published on rank 0 (svd.py:33)
         if not ("EXTRAS" in self.config.sections and self.config.sections["EXTRAS"].apply_transpose):
+            self.last_row_space = None
             fit = self._fit_and_solve(_capi.SOLVE_LSTSQ, self.RCOND, a, b, w, fs_dict, trainall)
-            # refine only a full-rank solve; rank 0 decides, every rank follows (collective)
-            do_refine = bool(self.refine_steps) and (pt._rank != 0 or self.last_rank == len(fit))
-            if not (pt.stubs or pt._size == 1):
-                do_refine = pt.bcast_object(do_refine if pt._rank == 0 else None, src=0)
-            if do_refine:
+            K = len(fit)
+            on_gpu = pt.comm_kind != "torch" or not pt.multi
+            if self.row_space and on_gpu and self._needs_row_space(K):
+                # ill-conditioned or rank deficient: lstsq's answer lives in the rows, not in the K x K statistics
+                fit = self._row_space_fit(K, self.RCOND)
+            elif self.refine_steps and self.last_rank == K:
                 fit = self._refine(fit, _capi.SOLVE_LSTSQ, self.RCOND, self.refine_steps)
             if pt._rank == 0:
                 self.fit = fit

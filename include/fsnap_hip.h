@@ -7,8 +7,8 @@
  * matrix); no C++ exception ever crosses the boundary.  The caller owns every buffer it
  * passes.  Matrices are row-major fp64; sizes are int64_t; the training mask is uint8_t
  * with 1 = training row (the negation of the reference's fitsnap_dict['Testing']).
- * A context is bound to ONE GPU (one process per GPU; multi-GPU is done by the host
- * layer with one context per rank and an RCCL all-reduce of the packed statistics).
+ * A context is bound to ONE GPU (one process per GPU; a multi-GPU job gives every rank's
+ * context a native RCCL communicator, fsnap_comm_*, and all-reduces the packed statistics).
  * Calls on one context must not be made concurrently from several threads; the ctypes
  * shim releases the GIL for the duration of each call.
  *
@@ -70,7 +70,9 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * per-wave specialised bodies, 3 LDS-shared generic variant), "split" (1|2, sub-waves per row-wave of kernel 1),
  * "nontemporal" (0|1), "nblocks" (workgroups of the SYRK kernel), "tiled" (1 = force the
  * general-K tiled kernel also for K <= 128), "nsplit" (row splits of the tiled kernel), "mirror" (0|1, see fsnap_normal_eq_resident), "xcd" (0|1: tiled kernel deals contiguous work-item ranges to each XCD), "tiled2" (0|1: K > 128 on the one-wave-per-SIMD kernel with 64 x 128-column work items, default 0),
- * "device_solve" (fsnap_solve_device: 0 = auto: K >= 384 is factorised on the GPU by the blocked kernels; 1 = every K on the GPU; 2 = never).
+ * "device_solve" (fsnap_solve_device: 0 = auto: K >= 384 is factorised on the GPU by the blocked kernels; 1 = every K on the GPU; 2 = never),
+ * "repack" (1 = recompute the packed per-row weights (mask * w, mask * w * b) and the b-only scalars on EVERY fit even
+ * when b, w and the mask are context-owned and unchanged; default 0 = once per fsnap_set_weights / fsnap_upload_rows).
  * Unknown key -> FSNAP_E_ARG. */
 int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value);
 
@@ -220,6 +222,30 @@ int fsnap_fit_resident(fsnap_ctx* ctx, int kind, double param, double* beta, int
 int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, const double* d_packed, const double* rhs,
                            double* beta, int* rank, double* rcond_est);
 
+/* ---- row-space least squares (ill-conditioned / rank-deficient systems) --------------------------------------- */
+
+/* fit = scipy.linalg.lstsq(aw, bw, rcond) of the resident rows, computed on the ROWS like the reference's dgelsd
+ * (fitsnap3lib/solvers/svd.py:44-54) instead of from the normal equations -- for systems whose K x K statistics are
+ * numerically singular (kappa(A_w) beyond ~1e7) or rank deficient: shifted CholeskyQR passes on the GPU
+ * (A_w = Q R_hat, Q m x K with orthonormal columns, kept in HBM next to A), then the K x K end of dgelsd on R_hat
+ * (singular values below rcond * sigma_max dropped, minimum-norm solution) and one refinement step with the residual
+ * of the original rows.  Needs m * K * 8 more bytes of HBM.  Collective when the context has a communicator (a rank
+ * without rows passes K and contributes nothing).  *rank = numerical rank used.  info (may be NULL, 8 doubles):
+ * passes, last max|Q^T Q - I|, converged (0/1), SVD used (0 = back substitution), sigma_max, sigma_min estimate,
+ * relative size of the refinement step, last shift. */
+int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K, double* beta, int* rank, double* info);
+
+/* The two host steps of that solve for callers that run the passes themselves (rows streamed through
+ * fsnap_normal_eq_accumulate, or the CPU tests): no context, no GPU.
+ * fsnap_rowspace_factor: G = Gram matrix Q^T Q of the current Q (K x K).  first = 1 initialises R_hat (K x K,
+ *   A_w = Q R_hat) to the identity.  Unless first, a deviation max|G - I| <= tol means Q is done: info[1] = 1 and nothing
+ *   else changes.  Otherwise Rp (K x K, upper triangular) receives the factor to divide out (Q <- Q Rp^-1 by
+ *   substitution) and R_hat <- Rp R_hat.  info (may be NULL, 3 doubles): deviation, converged, shift.
+ * fsnap_rowspace_solve: beta = pinv_rcond(R_hat) z with z = Q^T (w b), dgelsd semantics; info (may be NULL, 4 doubles):
+ *   SVD used, sigma_max, sigma_min kept, Jacobi sweeps. */
+int fsnap_rowspace_factor(int64_t K, const double* G, int first, double tol, double* Rhat, double* Rp, double* info);
+int fsnap_rowspace_solve(int64_t K, const double* Rhat, const double* z, double rcond, double* beta, int* rank, double* info);
+
 /* Grouped error statistics of Solver.error_analysis (solver.py:108-133: the function applied to every
  * (Groups, Testing, Row_Type) group of the DataFrame, solver.py:391-405) for the resident rows and weights:
  * cat[m] (host) = category id of each row in [0, ncat) (negative = skip; NULL = the categories of the previous call
@@ -229,6 +255,62 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
  * rmse = sqrt(sum r^2 / n), rsq = 1 - sum r^2 / sum (t - mean)^2 (weighted: w_mae = sum|w r| / n,
  * w_rmse = sqrt(sum (w r)^2 / n_w), ...).  Predictions (GEMV) and both reduction passes run on the GPU. */
 int fsnap_error_stats(fsnap_ctx* ctx, const double* beta, const int32_t* cat, int ncat, double* stats);
+
+/* ---- multi-GPU: one process per GPU, native RCCL over xGMI ------------------------ */
+
+/* The reference's data-parallel form of this path (examples/library/transpose_trick/example.py:230-254): every MPI
+ * rank accumulates c += aw.T aw, d += aw.T bw over ITS configurations, then comm.Allreduce(c), comm.Allreduce(d)
+ * (:245-246) and one solve.  Here a rank is a process that owns one context (= one GPU) holding the rows of its
+ * configurations (config i -> rank i % nranks, fitsnap3lib/parallel_tools.py:612-651); the two Allreduce calls are
+ * ONE in-place ncclAllReduce(ncclDouble, ncclSum) of the packed statistics on the context's stream.  librccl is
+ * loaded on the first call of this group (dlopen), never at library load. */
+#define FSNAP_COMM_ID_BYTES 128
+
+/* Rank 0: create the communicator id (ncclGetUniqueId).  The caller distributes the 128 bytes to every rank by
+ * whatever it has -- mpi4py comm.bcast on the reference side, a file or a socket in fitsnap_amd/rendezvous.py. */
+int fsnap_comm_id(char* id);
+
+/* Collective: join the communicator of `nranks` ranks as `rank` (ncclCommInitRank on the context's device). */
+int fsnap_comm_init(fsnap_ctx* ctx, int nranks, int rank, const char* id);
+int fsnap_comm_destroy(fsnap_ctx* ctx);
+
+/* *nranks / *rank of the context's communicator (1 / 0 without one); either pointer may be NULL. */
+int fsnap_comm_info(fsnap_ctx* ctx, int* nranks, int* rank);
+
+/* In-place sum over the ranks of n doubles in DEVICE memory (e.g. the packed statistics of fsnap_normal_eq_async),
+ * asynchronous on the context's stream: comm.Allreduce(c), comm.Allreduce(d) of transpose_trick/example.py:245-246. */
+int fsnap_allreduce_device(fsnap_ctx* ctx, double* d_buf, int64_t n);
+
+/* Same for n doubles in HOST memory (staged through HBM; synchronous).  op: 0 = sum, 1 = max, 2 = min.  The scalar
+ * reductions around a fit: row / configuration counts (parallel_tools.py:562-577), the refinement right-hand side,
+ * the max-over-ranks wall time of the benchmark. */
+int fsnap_allreduce_host(fsnap_ctx* ctx, double* buf, int64_t n, int op);
+
+/* Broadcast nbytes of host memory from rank `root` (comm.bcast, parallel_tools.py:579-592); synchronous. */
+int fsnap_bcast_host(fsnap_ctx* ctx, void* buf, int64_t nbytes, int root);
+
+/* recv[rank * nbytes ...] = send of every rank (equal sizes; comm.allgather of the fixed-size error tables and of the
+ * pickled row-label lists, parallel_tools.py:426-441); host memory, synchronous. */
+int fsnap_allgather_host(fsnap_ctx* ctx, const void* send, int64_t nbytes, void* recv);
+
+/* All ranks reach this point and the context's stream is idle (comm.Barrier, parallel_tools.py:245-249). */
+int fsnap_barrier(fsnap_ctx* ctx);
+
+/* One call per fit of a multi-GPU job (the whole of transpose_trick/example.py:230-254 for resident rows): this
+ * rank's fused statistics, in-place all-reduce on the same stream, then the K x K solve of fsnap_solve_device -- on
+ * EVERY rank (the solve is deterministic and the ranks hold bit-identical sums, so no broadcast of beta is needed;
+ * the host layer keeps the reference's "fit on rank 0" contract).  K must be given because a rank may own no rows
+ * (it then contributes zeros).  Without a communicator this is fsnap_fit_resident.  *d_packed (may be NULL) receives
+ * the address of the reduced statistics (context-owned device memory, valid until the next fit). */
+int fsnap_fit_dist(fsnap_ctx* ctx, int kind, double param, int64_t K, double* beta, int* rank, double* rcond_est,
+                   double** d_packed);
+
+/* ---- raw device memory for callers without a HIP binding of their own --------------- */
+
+/* hipMalloc / hipFree on the context's device; fsnap_dev_sync waits for the context's stream. */
+int fsnap_dev_alloc(fsnap_ctx* ctx, int64_t nbytes, void** d_ptr);
+int fsnap_dev_free(fsnap_ctx* ctx, void* d_ptr);
+int fsnap_dev_sync(fsnap_ctx* ctx);
 
 /* ---- measurement ------------------------------------------------------------------ */
 
