@@ -106,12 +106,17 @@ def _preload_torch_hip_runtime():
         return
     if spec is None or not spec.submodule_search_locations:
         return
-    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    cand = os.path.join(libdir, "libamdhip64.so")
     if os.path.exists(cand):
         try:
             ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
         except OSError:
-            pass
+            return
+        # the RCCL that belongs to that runtime (fsnap_comm.cpp loads it lazily, on the first fsnap_comm_* call)
+        rccl = os.path.join(libdir, "librccl.so")
+        if os.path.exists(rccl):
+            os.environ.setdefault("FSNAP_RCCL_PATH", rccl)
 
 
 def load_library(build_if_missing: bool = True):

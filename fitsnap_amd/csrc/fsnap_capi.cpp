@@ -1133,12 +1133,10 @@ int fsnap_fit_dist(fsnap_ctx* ctx, int kind, double param, int64_t K, double* be
                    double** d_packed) {
     if (!ctx) return FSNAP_E_ARG;
     if (!beta || K <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_fit_dist: bad argument");
-    int nranks = 1;
-    (void)fsnap_comm_info(ctx, &nranks, nullptr);
     const bool have_rows = ctx->dA && ctx->m > 0;
     if (have_rows && ctx->K != K) return ctx->fail(FSNAP_E_ARG, "fsnap_fit_dist: K = %lld but the resident rows have %lld columns",
                                                    (long long)K, (long long)ctx->K);
-    if (nranks == 1) {
+    if (!ctx->comm) {
         if (!have_rows) return ctx->fail(FSNAP_E_STATE, "no rows: call fsnap_upload_rows/fsnap_bind_rows first");
         return fsnap_fit_resident(ctx, kind, param, beta, rank, rcond_est, d_packed);
     }

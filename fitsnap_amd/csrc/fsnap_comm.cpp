@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -36,8 +37,11 @@ static Rccl* rccl() {
     static bool tried = false;
     if (tried) return &r;
     tried = true;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // FSNAP_RCCL_PATH: the copy that belongs to the HIP runtime of this process (the ctypes shim points it at the
+    // librccl bundled with PyTorch when it mapped PyTorch's libamdhip64, so that one ROCm stack serves the process)
+    const char* names[] = {getenv("FSNAP_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
+        if (!n || !*n) continue;
         r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (r.handle) break;
     }

@@ -350,8 +350,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
     if (!beta || K64 <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_lstsq_rows: bad argument");
     const int K = (int)K64, K16 = (K + 15) & ~15;
     const int64_t npk = FSNAP_PACKED_LEN(K64);
-    int nranks = 1;
-    (void)fsnap_comm_info(ctx, &nranks, nullptr);
+    const int nranks = ctx->comm ? 2 : 1;     // "> 1" = collective (a communicator of one rank takes the same path)
     const bool have_rows = ctx->dA && ctx->m > 0;
     if (have_rows && ctx->K != K64)
         return ctx->fail(FSNAP_E_ARG, "fsnap_lstsq_rows: K = %d but the resident rows have %lld columns", K, (long long)ctx->K);

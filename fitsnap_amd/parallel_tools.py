@@ -313,6 +313,7 @@ class ParallelTools:
         self._hip = None
         self._device_index = None
         self._transport = None
+        self.force_multi = False
         if comm is None or comm is False:
             self.stubs = 1
             self._comm = None
@@ -349,7 +350,9 @@ class ParallelTools:
 
     @property
     def multi(self):
-        return self._transport is not None and self._size > 1
+        """More than one rank takes part (``force_multi``: run the collective code paths in a communicator of one
+        rank -- how the single-GPU test box exercises them)."""
+        return self._transport is not None and (self._size > 1 or self.force_multi)
 
     # -- rank helpers (parallel_tools.py:245-336) ---------------------------------------
     def get_rank(self):
@@ -423,24 +426,24 @@ class ParallelTools:
         return
 
     def bcast_object(self, obj, src=0):
-        if self._transport is None or self._size == 1:
+        if not self.multi:
             return obj
         return self._transport.bcast_object(self, obj, src)
 
     def allgather_object(self, obj):
         """One Python object per rank, in rank order (``comm.allgather``)."""
-        if self._transport is None or self._size == 1:
+        if not self.multi:
             return [obj]
         return self._transport.allgather_object(self, obj)
 
     def allreduce_host(self, arr, op=0):
         """In-place reduction over the ranks of a C-contiguous float64 array on the host (op: 0 sum, 1 max, 2 min)."""
-        if self._transport is None or self._size == 1:
+        if not self.multi:
             return arr
         return self._transport.allreduce_host(self, arr, op)
 
     def allreduce_scalar(self, value, op=0):
-        if self._transport is None or self._size == 1:
+        if not self.multi:
             return value
         return float(self.allreduce_host(np.array([float(value)]), op)[0])
 

@@ -18,19 +18,34 @@ class ANL(Solver):
 
     def perform_fit(self, a=None, b=None, w=None, trainall=False):
         pt, config = self.pt, self.config
-        if config.sections["EXTRAS"].apply_transpose:
-            raise NotImplementedError("ANL with EXTRAS.apply_transpose is not supported by the HIP path")
         G, c, s = self._fit_statistics(a, b, w, None, trainall)
         nbas = len(c)
         npt = float(s[2])
         cov_nugget = config.sections["SOLVER"].cov_nugget
-        invptp = np.linalg.pinv(G + cov_nugget * np.diag(np.ones((nbas,))))       # anl.py:39
-        invptp = invptp * 0.5 + invptp.T * 0.5                                     # anl.py:40
-        fit = np.dot(invptp, c)
-        # res = bw - aw @ fit; bp = res.res / 2  (anl.py:46-47): exact streamed residual on the GPU
-        ctx = pt.hip()
-        _, sse = ctx.predict(fit, want_preds=False, want_sse=True)
-        sse = pt.allreduce_scalar(sse) if not (pt.stubs or pt._size == 1) else sse
+        transposed = False
+        if config.sections["EXTRAS"].apply_transpose:
+            # anl.py:31-36: the regression is run on (aw.T aw, aw.T bw) = (G, c) instead of the rows when
+            # cond(aw)^2 = lambda_max(G) / lambda_min(G) < 1 / eps -- all of it K x K host algebra on the statistics
+            ev = np.linalg.eigvalsh(G)
+            if abs(ev[-1]) / max(abs(ev[0]), np.finfo(float).tiny) < 1.0 / np.finfo(float).eps:
+                transposed = True
+            else:
+                print("The Matrix is ill-conditioned for the transpose trick")
+        if transposed:
+            invptp = np.linalg.pinv(G.T @ G + cov_nugget * np.diag(np.ones((nbas,))))
+            invptp = invptp * 0.5 + invptp.T * 0.5
+            fit = np.dot(invptp, G.T @ c)
+            res = c - G @ fit
+            sse = float(res @ res)
+            npt = float(nbas)                       # the "rows" of the transposed system
+        else:
+            invptp = np.linalg.pinv(G + cov_nugget * np.diag(np.ones((nbas,))))       # anl.py:39
+            invptp = invptp * 0.5 + invptp.T * 0.5                                     # anl.py:40
+            fit = np.dot(invptp, c)
+            # res = bw - aw @ fit; bp = res.res / 2  (anl.py:46-47): exact streamed residual on the GPU
+            ctx = pt.hip()
+            _, sse = ctx.predict(fit, want_preds=False, want_sse=True)
+            sse = pt.allreduce_scalar(sse)
         bp = sse / 2.0
         ap = (npt - nbas) / 2.0
         sigmahat = bp / (ap - 1.0)

@@ -35,8 +35,14 @@ class ARD(Solver):
         G, c, s = self._fit_statistics(None, None, None, None, False)
         bb, sbw, n = float(s[0]), float(s[1]), float(s[2])
         var_bw = bb / n - (sbw / n) ** 2
+        host_sse = None
         if self.config.sections["EXTRAS"].apply_transpose:
-            raise NotImplementedError("ARD with EXTRAS.apply_transpose is not supported by the HIP path")
+            # ard.py:22-24: X = aw.T aw = G, y = aw.T bw = c -- the loop then runs on (G.T G, G.T c) with K "samples",
+            # and the residual of an iteration is the K-vector c - G coef (host)
+            X, y = G, c
+            G, c = X.T @ X, X.T @ y
+            bb, n, var_bw = float(y @ y), float(len(y)), float(np.var(y))
+            host_sse = lambda coef: float(np.sum((y - X @ coef) ** 2))    # noqa: E731
         ap = 1.0 / var_bw
         sec = self.config.sections["ARD"]
         pt.single_print("inverse variance in training data: %f, logscale for threshold_lambda: %f" % (ap, np.log10(ap)))
@@ -47,12 +53,12 @@ class ARD(Solver):
         else:
             hyper = dict(alpha_1=sec.scap * ap, alpha_2=sec.scap * ap, lambda_1=ap * sec.scai, lambda_2=ap * sec.scai,
                          threshold_lambda=10 ** (int(np.abs(np.log10(ap))) + sec.logcut))
-        coef = self._ard_loop(G, c, bb, n, var_bw, **hyper)
+        coef = self._ard_loop(G, c, bb, n, var_bw, host_sse=host_sse, **hyper)
         if pt._rank == 0:
             self.fit = coef
 
     # sklearn 1.7.2 linear_model/_bayes.py ARDRegression.fit, on (G, c) instead of (X, y)
-    def _ard_loop(self, G, c, bb, n_samples, var_y, alpha_1, alpha_2, lambda_1, lambda_2, threshold_lambda):
+    def _ard_loop(self, G, c, bb, n_samples, var_y, alpha_1, alpha_2, lambda_1, lambda_2, threshold_lambda, host_sse=None):
         K = len(c)
         eps = np.finfo(np.float64).eps
         coef_ = np.zeros(K)
@@ -66,6 +72,8 @@ class ARD(Solver):
             return pinvh(lambda_[keep] * np.eye(gram.shape[0]) + alpha_ * gram)
 
         def sse_of(coef_):
+            if host_sse is not None:
+                return host_sse(coef_)
             if self.exact_sse:
                 return self._device_sse(coef_)
             return float(bb - 2.0 * coef_ @ c + coef_ @ G @ coef_)

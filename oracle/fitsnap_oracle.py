@@ -189,9 +189,13 @@ from fitsnap_amd.synthetic import (SYNTH_CHUNK, SYNTH_SEED, synth_chunk, synth_p
                                    synth_testing_mask)
 
 
-def anl_fit(a, b, w, testing=None, cov_nugget=0.0):
-    """fitsnap3lib/solvers/anl.py:39-53: posterior mean and covariance of the Bayesian linear fit."""
+def anl_fit(a, b, w, testing=None, cov_nugget=0.0, apply_transpose=False):
+    """fitsnap3lib/solvers/anl.py:31-53: posterior mean and covariance of the Bayesian linear fit; with
+    EXTRAS.apply_transpose the regression runs on (aw.T aw, aw.T bw) when cond(aw)^2 < 1/eps (anl.py:31-36)."""
     aw, bw = weight_rows(a, b, w, testing)
+    if apply_transpose and np.linalg.cond(aw) ** 2 < 1 / np.finfo(float).eps:
+        bw = aw.T @ bw
+        aw = aw.T @ aw
     npt, nbas = aw.shape
     invptp = np.linalg.pinv(np.dot(aw.T, aw) + cov_nugget * np.diag(np.ones((nbas,))))
     invptp = invptp * 0.5 + invptp.T * 0.5
@@ -200,4 +204,3 @@ def anl_fit(a, b, w, testing=None, cov_nugget=0.0):
     bp = np.dot(res, res) / 2.0
     ap = (npt - nbas) / 2.0
     return fit, (bp / (ap - 1.0)) * invptp
-

@@ -143,6 +143,16 @@ def main():
             sanl.perform_fit(A, b, w, trainall=True)
             out["anl_fit"] = np.asarray(sanl.fit).copy()
             out["anl_cov"] = np.asarray(sanl.cov).copy()
+            # the same class with EXTRAS.apply_transpose (anl.py:31-36): the regression runs on (aw.T aw, aw.T bw)
+            pt = ParallelTools()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                cfg = Config(pt, settings("ANL", {"SOLVER": {"nsam": 0, "cov_nugget": 1.0e-10}, "EXTRAS": {"apply_transpose": 1}}),
+                             arguments_lst=["--overwrite"])
+            sanl = solver_factory.solver("ANL", pt, cfg)
+            sanl.perform_fit(A, b, w, trainall=True)
+            out["anl_transpose_fit"] = np.asarray(sanl.fit).copy()
+            out["anl_transpose_cov"] = np.asarray(sanl.cov).copy()
         finally:
             os.chdir(cwd)
     # error_analysis (solver.py:137-435) with synthetic group labels: per (group, weighting, train/test,

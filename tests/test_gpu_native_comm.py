@@ -1,0 +1,161 @@
+"""GPU (-m gpu): the native RCCL transport behind the C ABI (fsnap_comm_*, fsnap_fit_dist) -- the reference's
+comm.Allreduce(c), comm.Allreduce(d) + solve (examples/library/transpose_trick/example.py:245-254).
+
+One GPU is enough for the API (a communicator of ONE rank runs every collective); the two-process test needs two
+devices and is skipped otherwise (RCCL does not put two ranks on one device)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from fitsnap_amd import _capi
+from fitsnap_amd.config import Config
+from fitsnap_amd.parallel_tools import ParallelTools
+from fitsnap_amd.solvers import solver_factory
+from oracle import fitsnap_oracle as orc
+
+from conftest import maxrel
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_one_rank_communicator_runs_every_collective(ta):
+    A, b, w = ta
+    ctx = _capi.HipContext(0)
+    assert ctx.comm_info() == (1, 0)
+    ctx.comm_init(1, 0, _capi.comm_id())
+    assert ctx.comm_info() == (1, 0)
+    x = np.arange(7, dtype=np.float64) - 3.0
+    for op in (_capi.REDUCE_SUM, _capi.REDUCE_MAX, _capi.REDUCE_MIN):
+        assert np.array_equal(ctx.allreduce_host(x.copy(), op), x)
+    assert ctx.bcast_bytes(b"row labels", 10, 0) == b"row labels"
+    assert ctx.allgather_bytes(b"\x01\x02\x03", 1) == [b"\x01\x02\x03"]
+    ctx.barrier()
+    # one fit: statistics -> in-place all-reduce in HBM -> solve; equals the single-GPU call bit for bit
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w)
+    plain, rank0, rc0, _ = ctx.fit_resident(_capi.SOLVE_RIDGE, 1e-8)
+    dist, rank1, rc1, ptr = ctx.fit_dist(_capi.SOLVE_RIDGE, 1e-8, A.shape[1])
+    assert np.array_equal(plain, dist) and rank0 == rank1 and rc0 == rc1
+    G, c, s = ctx.download_packed(ptr, A.shape[1])
+    Gr, cr, sr = orc.normal_eq(A, b, w)
+    d = np.sqrt(np.diag(Gr))
+    assert np.max(np.abs(G - Gr) / (d[:, None] * d[None, :])) < 1e-12 and s[2] == sr[2]
+    with pytest.raises(ValueError):
+        ctx.fit_dist(_capi.SOLVE_RIDGE, 1e-8, A.shape[1] + 1)
+    with pytest.raises(_capi.FsnapError):
+        ctx.comm_init(1, 0, _capi.comm_id())               # one communicator per context
+    ctx.comm_destroy()
+    assert ctx.comm_info() == (1, 0)
+    with pytest.raises(_capi.FsnapError):
+        ctx.allreduce_host(x.copy())                       # no communicator any more
+    ctx.close()
+
+
+def test_large_k_fit_through_the_communicator():
+    # K = 480: the reduced statistics are factorised on the GPU (no mirror), straight after the all-reduce
+    rng = np.random.default_rng(480)
+    m, K = 5000, 480
+    A = rng.standard_normal((m, K))
+    b = rng.standard_normal(m)
+    w = rng.uniform(0.5, 2.0, m)
+    ctx = _capi.HipContext(0)
+    ctx.comm_init(1, 0, _capi.comm_id())
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w)
+    beta = ctx.fit_dist(_capi.SOLVE_RIDGE, 1e-8, K)[0]
+    assert maxrel(beta, orc.ridge_fit(A, b, w, 1e-8)) < 1e-6
+    ctx.close()
+
+
+def test_solver_classes_on_the_native_transport_in_a_one_rank_job(ta, ta_fits, monkeypatch):
+    # ParallelTools(comm="rccl") with the collective code paths forced on: fit_dist, all-reduced refinement,
+    # fixed-size error tables -- same results as the single-process run
+    from pandas.testing import assert_frame_equal
+
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    A, b, w = ta
+    pt = ParallelTools(comm="rccl")
+    pt.force_multi = True
+    assert pt.comm_kind == "rccl" and pt.multi and pt.hip().comm_info() == (1, 0)
+    assert pt.bcast_object({"a": [1, 2.5, "x"]}) == {"a": [1, 2.5, "x"]}
+    assert pt.allgather_object(("k", 3)) == [("k", 3)]
+    assert pt.get_ncpn(363) == 363
+    t = ta_fits["testing_mask"]
+    m = len(b)
+    fsd = {"Groups": [f"g{(i // 43) % 5}" for i in range(m)], "Testing": t.tolist(),
+           "Row_Type": ["Energy"] * 363 + ["Force"] * 12672 + ["Stress"] * 2178}
+    cfg = Config(pt, {"SOLVER": {"solver": "SVD"}})
+    s = solver_factory.solver("SVD", pt, cfg)
+    s.perform_fit(A, b, w[~t], fs_dict=fsd)
+    assert maxrel(s.fit, ta_fits["svd_mask"]) < 1e-9        # statistics + two all-reduced refinement steps
+    fit = s.fit.copy()
+    s.error_analysis(A, b, w, fsd)
+    multi_errors = s.errors.copy()
+    cfg = Config(pt, {"SOLVER": {"solver": "RIDGE"}, "RIDGE": {"alpha": 1e-8}})
+    r = solver_factory.solver("RIDGE", pt, cfg)
+    r.perform_fit(A, b, w, trainall=True)
+    assert maxrel(r.fit, ta_fits["ridge_sklearn_1e-8_all"]) < 1e-6
+    pt.free()
+    pt1 = ParallelTools()
+    s1 = solver_factory.solver("SVD", pt1, Config(pt1, {"SOLVER": {"solver": "SVD"}}))
+    s1.fit = fit
+    s1.error_analysis(A, b, w, fsd)
+    assert_frame_equal(multi_errors, s1.errors, check_exact=False, rtol=1e-11, atol=1e-13)
+    pt1.free()
+
+
+def test_bench_runs_the_multi_gpu_step_without_torch(tmp_path):
+    # bench.py --force-dist: communicator of one rank, fsnap_fit_dist per step; the process must not import torch
+    import json
+
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", FSNAP_COMM_FILE=str(tmp_path / "id"))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--rows", "65536", "--steps", "5",
+                          "--warmup", "2", "--preheat", "10", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["torch_imported"] is False and rec["n_gpus"] == 1 and rec["value"] > 0
+    assert rec["config"]["weights_packed_every_step"] is True
+
+
+@pytest.mark.skipif(_capi.device_count() < 2, reason="needs two GPUs: RCCL does not put two ranks on one device")
+def test_two_process_native_fit_matches_the_reference(tmp_path, ta, ta_fits):
+    A, b, w = ta
+    world = 2
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world),
+                   FSNAP_COMM_FILE=str(tmp_path / "comm_id"), MASTER_ADDR="127.0.0.1", MASTER_PORT="29655",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_native_worker.py"), str(tmp_path)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-4000:]
+    r0, r1 = (dict(np.load(tmp_path / f"rank{r}.npz")) for r in range(world))
+    assert not r0["torch_imported"] and not r1["torch_imported"]
+    t = np.random.default_rng(12345).random(len(b)) < 0.1
+    Gr, cr, sr = orc.normal_eq(A, b, w, t)
+    d = np.sqrt(np.diag(Gr))
+    for name in ("SVD", "RIDGE"):
+        assert np.array_equal(r0[f"{name}_G"], r1[f"{name}_G"])                 # bit-identical sums on every rank
+        assert np.max(np.abs(r0[f"{name}_G"] - Gr) / (d[:, None] * d[None, :])) < 1e-12 and r0[f"{name}_sc"][2] == sr[2]
+        assert f"{name}_fit" in r0 and f"{name}_fit" not in r1                  # fit on rank 0 only
+    assert maxrel(r0["SVD_fit"], orc.svd_fit(A, b, w, t)) < 1e-6
+    assert maxrel(r0["RIDGE_fit"], orc.ridge_fit(A, b, w, 1e-8, testing=t)) < 1e-6
+    # the ill-conditioned system of the worker, solved by the reference's lstsq on all rows
+    r = np.random.default_rng(77)
+    mm, K = 16000, 40
+    U, _ = np.linalg.qr(r.standard_normal((mm, K)))
+    V, _ = np.linalg.qr(r.standard_normal((K, K)))
+    X = (U * np.logspace(0, -10, K)) @ V.T
+    y = X @ r.standard_normal(K) + 1e-3 * r.standard_normal(mm)
+    ref = orc.svd_fit(X, y, np.ones(mm))
+    assert np.linalg.norm(r0["ill_fit"] - ref) <= 50 * 1e10 * np.finfo(float).eps * np.linalg.norm(ref)

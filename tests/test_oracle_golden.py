@@ -101,3 +101,10 @@ def test_anl_matches_reference_class(ta, ta_fits):
     A, b, w = ta
     fit, cov = orc.anl_fit(A, b, w, cov_nugget=1.0e-10)
     assert np.array_equal(fit, ta_fits["anl_fit"]) and np.array_equal(cov, ta_fits["anl_cov"])
+
+
+def test_anl_transpose_matches_reference_class(ta, ta_fits):
+    # EXTRAS.apply_transpose (anl.py:31-36) through the reference class itself
+    A, b, w = ta
+    fit, cov = orc.anl_fit(A, b, w, cov_nugget=1.0e-10, apply_transpose=True)
+    assert np.array_equal(fit, ta_fits["anl_transpose_fit"]) and np.array_equal(cov, ta_fits["anl_transpose_cov"])

@@ -1,0 +1,121 @@
+"""CPU: the host half of the row-space least-squares solve (fsnap_rowspace_factor / fsnap_rowspace_solve, no GPU) --
+numpy stands in for the two kernels of a pass (Q <- Q Rp^-1 by substitution = scipy solve_triangular, G = Q^T Q).
+Checked against the oracle's lstsq(aw, bw, 1e-13) (fitsnap3lib/solvers/svd.py:54): two backward-stable solvers differ
+by ~kappa eps, so that is the bar beyond kappa ~ 1e9; below it the north-star tolerance 1e-6 applies."""
+import numpy as np
+import pytest
+import scipy.linalg as sl
+
+from fitsnap_amd import _capi
+from oracle import fitsnap_oracle as orc
+
+EPS = np.finfo(float).eps
+
+
+def cholqr_lstsq(A, b, rcond=1.0e-13, maxpass=6):
+    """The algorithm of fsnap_lstsq_rows with numpy in place of the GPU passes."""
+    G = A.T @ A
+    Q = A.copy()
+    Rhat = None
+    passes = 0
+    for _ in range(maxpass):
+        Rp, Rhat, info = _capi.rowspace_factor(G, Rhat)
+        if Rp is None:
+            break
+        Q = sl.solve_triangular(Rp, Q.T, trans="T", lower=False).T
+        G = Q.T @ Q
+        passes += 1
+    beta, rank, sinfo = _capi.rowspace_solve(Rhat, Q.T @ b, rcond)
+    step, _, _ = _capi.rowspace_solve(Rhat, Q.T @ (b - A @ beta), rcond)
+    return beta + step, rank, passes, sinfo, Q, Rhat
+
+
+def conditioned(m, K, kappa, mode, seed):
+    r = np.random.default_rng(seed)
+    U, _ = np.linalg.qr(r.standard_normal((m, K)))
+    V, _ = np.linalg.qr(r.standard_normal((K, K)))
+    if mode == "geometric":
+        s = np.logspace(0, -np.log10(kappa), K)
+    else:                                   # one weak direction
+        s = np.ones(K)
+        s[-1] = 1.0 / kappa
+    return (U * s) @ V.T
+
+
+@pytest.mark.parametrize("mode", ["geometric", "one"])
+@pytest.mark.parametrize("kappa", [1e4, 1e8, 1e10, 1e12])
+def test_matches_lstsq_up_to_kappa_eps(kappa, mode):
+    m, K = 6000, 48
+    A = conditioned(m, K, kappa, mode, 3)
+    r = np.random.default_rng(4)
+    b = A @ r.standard_normal(K) + 1e-3 * r.standard_normal(m)
+    ref = orc.svd_fit(A, b, np.ones(m))
+    x, rank, passes, sinfo, Q, Rhat = cholqr_lstsq(A, b)
+    assert rank == K and 2 <= passes <= 4
+    assert np.abs(Q.T @ Q - np.eye(K)).max() < 1e-10                       # orthonormal columns
+    assert np.linalg.norm(Q @ Rhat - A) <= 50 * K * EPS * np.linalg.norm(A)  # A = Q R_hat to working precision
+    tol = max(1e-6 if kappa <= 1e8 else 0.0, 50 * kappa * EPS)
+    assert np.linalg.norm(x - ref) <= tol * np.linalg.norm(ref)
+    # what both solvers minimise agrees far below the coefficient tolerance
+    res, res_ref = np.linalg.norm(A @ x - b), np.linalg.norm(A @ ref - b)
+    assert res <= res_ref * (1 + 1e-9) and abs(res - res_ref) <= 1e-6 * res_ref
+
+
+def test_exact_rank_deficiency_gives_the_minimum_norm_solution():
+    r = np.random.default_rng(5)
+    m = 5000
+    A = r.standard_normal((m, 20))
+    A = np.hstack([A, A[:, :3], A[:, 3:5] @ r.standard_normal((2, 2)), np.zeros((m, 2))])   # duplicates, combinations, zeros
+    b = r.standard_normal(m)
+    ref = orc.svd_fit(A, b, np.ones(m))
+    x, rank, passes, sinfo, _, _ = cholqr_lstsq(A, b)
+    assert rank == 20 and sinfo[0] == 1.0                                   # SVD path, 7 directions dropped
+    assert np.linalg.norm(x - ref) <= 1e-9 * np.linalg.norm(ref)
+    assert np.all(x[-2:] == 0.0)                                            # zero columns: coefficient 0 (lstsq: minimum norm)
+    assert np.allclose(x[:3], x[20:23], rtol=1e-9)                          # duplicated columns share their coefficient
+
+
+def test_near_collinear_columns_kept_or_dropped_like_gelsd():
+    r = np.random.default_rng(6)
+    m, K = 4000, 12
+    base = r.standard_normal((m, K))
+    b = r.standard_normal(m)
+    for eps_col, expect_rank in ((1e-9, K + 1), (1e-15, K)):
+        A = np.hstack([base, base[:, :1] + eps_col * r.standard_normal((m, 1))])
+        _, _, rank_ref, _ = sl.lstsq(A, b, 1.0e-13)
+        ref = orc.svd_fit(A, b, np.ones(m))
+        x, rank, _, _, _, _ = cholqr_lstsq(A, b)
+        assert rank == rank_ref == expect_rank
+        if eps_col < 1e-13:     # direction dropped: a well-posed minimum-norm problem, tight agreement
+            assert np.linalg.norm(x - ref) <= 1e-8 * np.linalg.norm(ref)
+        else:                   # direction kept at kappa ~ 1e9 (coefficients +-5e6 that cancel): ~kappa eps each
+            assert np.linalg.norm(A @ (x - ref)) <= 1e-7 * np.linalg.norm(b)
+            assert np.linalg.norm(x - ref) <= 50 * 1e9 * EPS * np.linalg.norm(ref)
+
+
+def test_graded_columns_truncate_on_the_singular_values_of_aw_not_of_the_equilibrated_matrix():
+    # lstsq cuts on sigma(A_w): a column 1e-15 times smaller than the others is dropped although the column-scaled
+    # matrix is perfectly conditioned -- the Jacobi scaling inside the passes must not change that decision
+    r = np.random.default_rng(8)
+    m, K = 3000, 10
+    A = r.standard_normal((m, K)) * np.array([1.0] * (K - 2) + [1e-6, 1e-15])
+    b = r.standard_normal(m)
+    fit, _, rank_ref, _ = sl.lstsq(A, b, 1.0e-13)
+    x, rank, _, _, _, _ = cholqr_lstsq(A, b)
+    assert rank == rank_ref == K - 1
+    assert np.linalg.norm(x[:-1] - fit[:-1]) <= 1e-8 * np.linalg.norm(fit[:-1])
+    assert abs(x[-1]) <= 1e-9 * np.abs(fit[:-1]).max() and abs(fit[-1]) <= 1e-9 * np.abs(fit[:-1]).max()
+
+
+def test_factor_reports_convergence_and_refuses_non_finite_input():
+    Q, _ = np.linalg.qr(np.random.default_rng(1).standard_normal((200, 7)))
+    Rp, Rhat, info = _capi.rowspace_factor(Q.T @ Q)             # first pass always factorises
+    assert Rp is not None and info[0] < 1e-14
+    Rp2, Rhat2, info2 = _capi.rowspace_factor(Q.T @ Q, Rhat)
+    assert Rp2 is None and info2[1] == 1.0 and np.array_equal(Rhat2, Rhat)
+    bad = np.eye(3)
+    bad[1, 2] = np.nan
+    with pytest.raises(ValueError):
+        _capi.rowspace_factor(bad)
+    with pytest.raises(ValueError):
+        _capi.rowspace_solve(np.eye(3), np.array([1.0, np.inf, 0.0]))
