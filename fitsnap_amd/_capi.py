@@ -45,6 +45,7 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int]),
     "fsnap_download_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "fsnap_set_weights": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "fsnap_set_weights_train": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "fsnap_bind_weights": (c_int, [c_void_p, c_void_p, c_void_p]),
     "fsnap_normal_eq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fsnap_normal_eq_async": (c_int, [c_void_p, c_void_p]),
@@ -242,6 +243,7 @@ class HipContext:
         self.m = 0
         self.K = 0
         self._keep = []  # keep numpy buffers alive across async copies
+        self.resident_train_mask = None   # mask object last sent with set_weights_train (identity = still resident)
 
     # -- plumbing --------------------------------------------------------------------
     def _check(self, rc):
@@ -289,6 +291,8 @@ class HipContext:
             raise ValueError(f"b has shape {b.shape}, expected ({m},)")
         lda = A.strides[0] // 8
         self._check(self._lib.fsnap_upload_rows(self._h, _ptr(A), m, K, lda, _ptr(b)))
+        if m != self.m:
+            self.resident_train_mask = None
         self.m, self.K = m, K
 
     def bind_rows(self, dA_ptr: int, m: int, K: int, lda: int, db_ptr: int):
@@ -336,6 +340,23 @@ class HipContext:
             if mk.shape != (self.m,):
                 raise ValueError(f"mask has shape {mk.shape}, expected ({self.m},)")
         self._check(self._lib.fsnap_set_weights(self._h, _ptr(w), _ptr(mk)))
+        if mk is not None:
+            self.resident_train_mask = None          # the device mask buffer was overwritten
+
+    def set_weights_train(self, w_train: np.ndarray, mask=None, rank=None):
+        """One weight per TRAINING row (fsnap_set_weights_train); ``mask`` (uint8, 1 = train) and ``rank`` (int32
+        exclusive prefix sum of the mask) go along the first time and whenever the training set changes, ``None``
+        keeps the resident ones."""
+        w_train = _f64(w_train, "w")
+        mk = rk = None
+        if mask is not None:
+            mk = np.ascontiguousarray(mask, dtype=np.uint8)
+            rk = np.ascontiguousarray(rank, dtype=np.int32)
+            if mk.shape != (self.m,) or rk.shape != (self.m,):
+                raise ValueError(f"mask / rank must have shape ({self.m},)")
+        self._check(self._lib.fsnap_set_weights_train(self._h, _ptr(w_train), w_train.shape[0], _ptr(mk), _ptr(rk)))
+        if mask is not None:
+            self.resident_train_mask = mask          # the object whose content is on the device now
 
     def bind_weights(self, dw_ptr: int, dmask_ptr: int = 0):
         self._check(self._lib.fsnap_bind_weights(self._h, c_void_p(dw_ptr), c_void_p(dmask_ptr or None)))

@@ -127,6 +127,38 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
     return FSNAP_OK;
 }
 
+// Host memory -> device memory on the context's stream through the page-locked staging slots, WITHOUT a stream
+// synchronisation: the bytes are copied into a slot in 1 MiB pieces, each piece's DMA starts as soon as it is in the
+// slot (the memcpy of piece i + 1 overlaps the DMA of piece i), and the caller's buffer is free on return.  A slot is
+// reused only after the event of its previous DMA has completed.  Up to two independent transfers per slot rotation
+// (weights + mask); larger requests than a slot holds grow the slot.
+int staged_h2d(fsnap_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return FSNAP_OK;
+    const int slot = ctx->wstage_next;
+    ctx->wstage_next ^= 1;
+    if (ctx->wstage_ev[slot]) {
+        FSNAP_HIP(hipEventSynchronize(ctx->wstage_ev[slot]), "hipEventSynchronize(staging)");   // normally long done
+    } else {
+        FSNAP_HIP(hipEventCreateWithFlags(&ctx->wstage_ev[slot], hipEventDisableTiming), "hipEventCreate");
+    }
+    if (ctx->wstage_bytes[slot] < bytes) {
+        if (ctx->wstage[slot]) (void)hipHostFree(ctx->wstage[slot]);
+        ctx->wstage[slot] = nullptr;
+        ctx->wstage_bytes[slot] = 0;
+        if (hipHostMalloc((void**)&ctx->wstage[slot], bytes, hipHostMallocDefault) != hipSuccess)
+            return ctx->fail(FSNAP_E_NOMEM, "hipHostMalloc(%zu) for the weight staging failed", bytes);
+        ctx->wstage_bytes[slot] = bytes;
+    }
+    const size_t piece = (size_t)1 << 20;
+    for (size_t off = 0; off < bytes; off += piece) {
+        const size_t n = bytes - off < piece ? bytes - off : piece;
+        memcpy(ctx->wstage[slot] + off, (const char*)src + off, n);
+        FSNAP_HIP(hipMemcpyAsync((char*)dst + off, ctx->wstage[slot] + off, n, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(staged H2D)");
+    }
+    FSNAP_HIP(hipEventRecord(ctx->wstage_ev[slot], ctx->stream), "hipEventRecord");
+    return FSNAP_OK;
+}
+
 int check_rows(fsnap_ctx* ctx) {
     if (!ctx->dA || !ctx->db || ctx->m <= 0) return ctx->fail(FSNAP_E_STATE, "no rows: call fsnap_upload_rows/fsnap_bind_rows first");
     return FSNAP_OK;
@@ -543,6 +575,12 @@ int fsnap_ctx_destroy(fsnap_ctx* ctx) {
                       &ctx->st_raw, &ctx->st_plan, &ctx->st_frac, &ctx->st_blank, &ctx->dsolve, &ctx->dchol, &ctx->dcat, &ctx->dstat, &ctx->wpack, &ctx->wpack_spart,
                       &ctx->du, &ctx->dspart, &ctx->dsvec, &ctx->titems};
     for (DevBuf* b : bufs) b->release();
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->wstage[i]) (void)hipHostFree(ctx->wstage[i]);
+        if (ctx->wstage_ev[i]) (void)hipEventDestroy(ctx->wstage_ev[i]);
+    }
+    ctx->wtrain.release();
+    ctx->wrank.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->mirror) (void)hipHostFree(ctx->mirror);
     if (ctx->mirror_ev) (void)hipEventDestroy(ctx->mirror_ev);
@@ -636,6 +674,7 @@ int fsnap_upload_rows(fsnap_ctx* ctx, const double* A, int64_t m, int64_t K, int
     if (m != ctx->m) {  // weights / mask of a previous matrix no longer apply
         ctx->dw = nullptr;
         ctx->dmask = nullptr;
+        ctx->ntrain_resident = -1;
         ctx->ones.release();
     }
     ctx->m = m;
@@ -650,6 +689,7 @@ int fsnap_bind_rows(fsnap_ctx* ctx, const double* dA, int64_t m, int64_t K, int6
     if (m != ctx->m) {
         ctx->dw = nullptr;
         ctx->dmask = nullptr;
+        ctx->ntrain_resident = -1;
         ctx->ones.release();
     }
     ctx->dA = dA;
@@ -677,6 +717,7 @@ int fsnap_rows_alloc(fsnap_ctx* ctx, int64_t m, int64_t K) {
     ctx->wpack_valid = false;
     ctx->dw = (const double*)ctx->ownw.p;
     ctx->dmask = nullptr;
+    ctx->ntrain_resident = -1;
     ctx->ones.release();
     ctx->m = m;
     ctx->K = K;
@@ -760,17 +801,45 @@ int fsnap_set_weights(fsnap_ctx* ctx, const double* w, const uint8_t* mask) {
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     const size_t m = (size_t)ctx->m;
     if (!ctx->ownw.ensure(m * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(w) failed");
-    FSNAP_HIP(hipMemcpyAsync(ctx->ownw.p, w, m * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(w)");
+    if ((rc = staged_h2d(ctx, ctx->ownw.p, w, m * 8))) return rc;
     ctx->dw = (const double*)ctx->ownw.p;
     ctx->wpack_valid = false;
     if (mask) {
         if (!ctx->ownmask.ensure(m)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(mask) failed");
-        FSNAP_HIP(hipMemcpyAsync(ctx->ownmask.p, mask, m, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(mask)");
+        if ((rc = staged_h2d(ctx, ctx->ownmask.p, mask, m))) return rc;
         ctx->dmask = (const unsigned char*)ctx->ownmask.p;
+        ctx->ntrain_resident = -1;          // the mask buffer no longer matches the resident prefix sum
     } else {
         ctx->dmask = nullptr;
     }
-    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    return FSNAP_OK;     // asynchronous: the copies are ordered before everything launched later on this context
+}
+
+int fsnap_set_weights_train(fsnap_ctx* ctx, const double* w_train, int64_t ntrain, const uint8_t* mask, const int32_t* rank) {
+    if (!ctx) return FSNAP_E_ARG;
+    int rc;
+    if ((rc = check_rows(ctx))) return rc;
+    if (!w_train || ntrain < 0 || ntrain > ctx->m || (mask == nullptr) != (rank == nullptr))
+        return ctx->fail(FSNAP_E_ARG, "fsnap_set_weights_train: bad argument");
+    if (!mask && ctx->ntrain_resident != ntrain)
+        return ctx->fail(FSNAP_E_STATE, "fsnap_set_weights_train: no resident training mask with %lld training rows", (long long)ntrain);
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    const size_t m = (size_t)ctx->m;
+    if (!ctx->ownw.ensure(m * 8) || !ctx->wtrain.ensure((size_t)(ntrain > 0 ? ntrain : 1) * 8))
+        return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(w) failed");
+    if (mask) {
+        if (!ctx->ownmask.ensure(m) || !ctx->wrank.ensure(m * 4)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(mask) failed");
+        if ((rc = staged_h2d(ctx, ctx->ownmask.p, mask, m))) return rc;
+        if ((rc = staged_h2d(ctx, ctx->wrank.p, rank, m * 4))) return rc;
+        ctx->ntrain_resident = ntrain;
+    }
+    if ((rc = staged_h2d(ctx, ctx->wtrain.p, w_train, (size_t)ntrain * 8))) return rc;
+    FSNAP_HIP(fsnap::launch_expand_weights((const double*)ctx->wtrain.p, (const unsigned char*)ctx->ownmask.p,
+                                           (const int*)ctx->wrank.p, ctx->m, (double*)ctx->ownw.p, ctx->stream),
+              "launch fsnap_expand_weights_k");
+    ctx->dw = (const double*)ctx->ownw.p;
+    ctx->dmask = (const unsigned char*)ctx->ownmask.p;
+    ctx->wpack_valid = false;
     return FSNAP_OK;
 }
 
@@ -782,6 +851,7 @@ int fsnap_bind_weights(fsnap_ctx* ctx, const double* dw, const uint8_t* dmask) {
     ctx->dw = dw;
     ctx->dmask = dmask;
     ctx->wpack_valid = false;
+    ctx->ntrain_resident = -1;
     return FSNAP_OK;
 }
 

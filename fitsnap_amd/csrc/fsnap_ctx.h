@@ -106,6 +106,15 @@ struct fsnap_ctx {
     // timing flags
     bool t_syrk = false, t_upload = false, t_weight = false, t_predict = false;
 
+    // page-locked staging of fsnap_set_weights*: two slots used alternately, an event per slot marks the end of its
+    // DMA -- the call returns while the copy is still in flight (no stream synchronisation on the re-weighting path)
+    char* wstage[2] = {nullptr, nullptr};
+    size_t wstage_bytes[2] = {0, 0};
+    hipEvent_t wstage_ev[2] = {nullptr, nullptr};
+    int wstage_next = 0;
+    DevBuf wtrain, wrank;                         // compact training weights and the mask's exclusive prefix sum
+    int64_t ntrain_resident = -1;                 // training rows of the resident mask / prefix (-1 = none)
+
     // multi-GPU / row-space state owned by the other translation units
     fsnap::Comm* comm = nullptr;
     fsnap::RowSpace* rowspace = nullptr;

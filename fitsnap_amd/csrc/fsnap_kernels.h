@@ -85,6 +85,9 @@ hipError_t launch_gemv_rows(const double* A, int64_t lda, const double* beta, in
                             const double* b, const double* w, const unsigned char* mask, double* sse_part,
                             double* uout, hipStream_t st, bool uplain = false);   // uplain: u = w (b - a.beta), not w^2 (...)
 int gemvT_num_blocks(int64_t m);
+// w[row] = mask[row] ? wtrain[rank[row]] : 0   (rank = exclusive prefix sum of the mask)
+hipError_t launch_expand_weights(const double* wtrain, const unsigned char* mask, const int* rank, int64_t m, double* w,
+                                 hipStream_t st);
 int error_stats_num_blocks(int64_t m);
 // pass 0: partial[grid][ncat][4] = n, n_w, sum t, sum w t; pass 1: partial[grid][ncat][6] (see kernel 9)
 hipError_t launch_error_stats(const double* truth, const double* pred, const double* wgt, const int* cat, int64_t m, int ncat,

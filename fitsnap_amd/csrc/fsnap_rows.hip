@@ -6,6 +6,7 @@
 //   9   fsnap_error_stats_k    grouped error statistics of error_analysis     (solver.py:108-133)
 //   11  fsnap_pack_weights_k   (w_eff, w_eff b) per row + the b-only statistics, once per (b, w, mask)
 //   12  fsnap_mirror_copy_k    packed statistics + diag(G) into the page-locked host mirror (multi-GPU path)
+//   14  fsnap_expand_weights_k one weight per TRAINING row -> one weight per row (the reference's explicit-array quirk)
 // Every kernel here moves each byte once; the roofline is HBM bandwidth.
 #include "fsnap_device_common.h"
 #include "fsnap_kernels.h"
@@ -367,6 +368,20 @@ __global__ __launch_bounds__(256) void fsnap_pack_weights_k(const double* __rest
 }
 
 // ---------------------------------------------------------------------------------
+// Kernel 14: expand the weights of the TRAINING rows to one weight per row.  The reference's explicit-array quirk
+// (svd.py:46, ridge.py:39: ``w`` is multiplied into ``a[training]`` without being masked) hands the solver one weight
+// per training row; rank[row] = number of training rows before it (exclusive prefix sum of the mask, resident next to
+// the mask).  Replaces a scatter of m doubles on the host and the upload of the non-training entries.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsnap_expand_weights_k(const double* __restrict__ wtrain,
+                                                             const unsigned char* __restrict__ mask,
+                                                             const int* __restrict__ rank, int64_t m,
+                                                             double* __restrict__ w) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row < m) w[row] = mask[row] ? wtrain[rank[row]] : 0.0;
+}
+
+// ---------------------------------------------------------------------------------
 // host-side launchers (C++ linkage, used by fsnap_capi.cpp)
 // ---------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------
@@ -445,6 +460,14 @@ hipError_t launch_pack_weights(const double* b, const double* w, const unsigned 
                                double* spart, hipStream_t st) {
     hipLaunchKernelGGL(fsnap_pack_weights_k, dim3((unsigned)pack_weights_num_blocks(m)), dim3(256), 0, st, b, w, mask, m,
                        wpack, spart);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand_weights(const double* wtrain, const unsigned char* mask, const int* rank, int64_t m, double* w,
+                                 hipStream_t st) {
+    const int64_t nb = (m + 255) / 256;
+    if (nb > 0x7FFFFFFF) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fsnap_expand_weights_k, dim3((unsigned)nb), dim3(256), 0, st, wtrain, mask, rank, m, w);
     return hipGetLastError();
 }
 

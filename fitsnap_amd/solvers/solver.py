@@ -26,6 +26,22 @@ import numpy as np
 from .. import _capi
 
 
+class _TrainWeights:
+    """Weights of the TRAINING rows only, as the reference's explicit-array call hands them over (svd.py:46), plus what
+    the device needs to spread them over all rows: the uint8 mask and its exclusive prefix sum.  ``cached`` = the mask
+    arrays come from the solver's cache (a re-weighting loop), so the device copy of an earlier call may still be valid."""
+
+    __slots__ = ("w", "mask_u8", "rank", "idx", "cached")
+
+    def __init__(self, w, mask_u8, rank, idx, cached):
+        self.w, self.mask_u8, self.rank, self.idx, self.cached = w, mask_u8, rank, idx, cached
+
+    def full(self):
+        out = np.zeros(self.mask_u8.shape[0])
+        out[self.idx] = self.w
+        return out
+
+
 class Solver:
     """Base class for linear solvers (see module docstring)."""
 
@@ -153,12 +169,15 @@ class Solver:
                              f"{m} but size of corresponding boolean axis is {len(training)}")
         # a cached mask (re-weighting loop) carries its row indices and uint8 form along
         mc = self._mask_cache
-        aux = mc[3] if (mc is not None and mc[2] is training) else None
+        cached = mc is not None and mc[2] is training
+        aux = mc[3] if cached else None
         if aux is None:
-            aux = (np.flatnonzero(training), training.astype(np.uint8))
-            if mc is not None and mc[2] is training:
+            mask_u8 = training.astype(np.uint8)
+            rank = np.cumsum(mask_u8, dtype=np.int64) - mask_u8
+            aux = (np.flatnonzero(training), mask_u8, rank.astype(np.int32))
+            if cached:
                 self._mask_cache = (mc[0], mc[1], training, aux)
-        idx, mask_u8 = aux
+        idx, mask_u8, rank = aux
         ntrain = idx.shape[0]
         # reference: aw = w[:, None] * a[training]  (numpy broadcasting on the row axis)
         if w.ndim == 0 or w.shape[0] == 1:
@@ -167,8 +186,8 @@ class Solver:
             if ntrain == m:
                 w_full = w
             else:
-                w_full = np.zeros(m)
-                w_full[idx] = w
+                # one weight per training row: the GPU spreads them over the rows (fsnap_set_weights_train)
+                w_full = _TrainWeights(w, mask_u8, rank, idx, cached and mc[3] is not None)
         else:
             raise ValueError(f"operands could not be broadcast together with shapes ({w.shape[0]},1) ({ntrain},{a.shape[1]}) ")
         return a, b, w_full, mask_u8, False
@@ -176,6 +195,20 @@ class Solver:
     # ------------------------------------------------------------------------------
     # the hot path
     # ------------------------------------------------------------------------------
+    @staticmethod
+    def _push_weights(ctx, w_full, mask):
+        """Row weights and training mask of this fit onto the device."""
+        if isinstance(w_full, _TrainWeights):
+            if w_full.cached and getattr(ctx, "resident_train_mask", None) is w_full.mask_u8:
+                try:
+                    ctx.set_weights_train(w_full.w)             # mask and prefix sum of an earlier call are resident
+                    return
+                except _capi.FsnapError:
+                    pass                                        # somebody replaced them meanwhile: send them again
+            ctx.set_weights_train(w_full.w, w_full.mask_u8, w_full.rank)
+            return
+        ctx.set_weights(w_full, None if mask.all() else mask)
+
     def _upload(self, a, b, shared_mode):
         ctx = self.pt.hip()
         if shared_mode:
@@ -202,7 +235,7 @@ class Solver:
     def _local_statistics(self, a, b, w_full, mask, shared_mode):
         """This rank's (G, c, scalars) on the host."""
         ctx = self._upload(a, b, shared_mode)
-        ctx.set_weights(w_full, None if mask.all() else mask)
+        self._push_weights(ctx, w_full, mask)
         return ctx.normal_eq()
 
     def _fit_statistics(self, a=None, b=None, w=None, fs_dict=None, trainall=False):
@@ -260,7 +293,7 @@ class Solver:
         ctx = pt.hip()
         if have_rows:
             ctx = self._upload(a, b, shared_mode)
-            ctx.set_weights(w_full, None if mask.all() else mask)
+            self._push_weights(ctx, w_full, mask)
         if pt.multi:
             beta, rank, rcond, ptr = ctx.fit_dist(kind, param, K)       # collective
         else:

@@ -125,6 +125,15 @@ int fsnap_download_rows(fsnap_ctx* ctx, double* A, int64_t lda, double* b, doubl
  * memory.  pt.shared_arrays['w'].array and `training = [not elem for elem in
  * fitsnap_dict['Testing']]` (svd.py:35-44, ridge.py:28-37, ard.py:18-19). */
 int fsnap_set_weights(fsnap_ctx* ctx, const double* w, const uint8_t* mask);
+/* (fsnap_set_weights* copy the host arrays into page-locked staging before returning -- the caller may reuse them at
+ * once -- and hand the DMA to the context's stream without waiting for it.) */
+
+/* Re-weighting form of the reference's explicit-array call (svd.py:46, ridge.py:39: `w` multiplies `a[training]`
+ * without being masked, i.e. the caller hands ONE WEIGHT PER TRAINING ROW): w_train[ntrain] in row order.  mask[m]
+ * (1 = train) and rank[m] (rank[i] = number of training rows before row i) are host arrays, or both NULL to keep
+ * the mask of the previous call (the genetic-algorithm loop of examples/library/genetic_algorithm/libmod_optimize.py:
+ * 461-488 re-weights the same training set hundreds of times).  The per-row weights are expanded on the GPU. */
+int fsnap_set_weights_train(fsnap_ctx* ctx, const double* w_train, int64_t ntrain, const uint8_t* mask, const int32_t* rank);
 
 /* Same with device pointers (not copied, not owned). */
 int fsnap_bind_weights(fsnap_ctx* ctx, const double* dw, const uint8_t* dmask);

@@ -163,3 +163,49 @@ def test_repack_option_keeps_results_and_packs_every_fit(ctx, ta):
             assert np.array_equal(G, ref[0]) and np.array_equal(c, ref[1]) and np.array_equal(s, ref[2])
     finally:
         ctx.set_option("repack", 0)
+
+
+def test_training_weights_are_spread_on_the_device(ctx, ta, ta_fits):
+    # fsnap_set_weights_train: one weight per TRAINING row (the reference's explicit-array quirk, svd.py:46), mask and
+    # its prefix sum resident across re-weightings -- same statistics as the host-side scatter, bit for bit
+    A, b, w = ta
+    t = ta_fits["testing_mask"]
+    mask = (~t).astype(np.uint8)
+    rank = (np.cumsum(mask, dtype=np.int64) - mask).astype(np.int32)
+    ctx.upload_rows(A, b)
+    ctx.set_weights(np.where(t, 0.0, w), mask)
+    ref = ctx.normal_eq()
+    ctx.set_weights_train(np.ascontiguousarray(w[~t]), mask, rank)
+    got = ctx.normal_eq()
+    assert all(np.array_equal(x, y) for x, y in zip(got, ref))
+    for scale in (0.5, 3.0):                                   # resident mask: only the weights travel
+        ctx.set_weights_train(np.ascontiguousarray(scale * w[~t]))
+        G, c, s = ctx.normal_eq()
+        assert np.array_equal(G, scale * scale * ref[0]) if scale == 0.5 else np.allclose(G, scale * scale * ref[0], rtol=1e-15)
+        assert s[2] == ref[2][2]
+    ctx.set_weights(w)                                         # full weights, no mask: the resident mask survives
+    assert ctx.normal_eq()[2][2] == len(b)
+    ctx.set_weights_train(np.ascontiguousarray(w[~t]))
+    assert all(np.array_equal(x, y) for x, y in zip(ctx.normal_eq(), ref))
+    ctx.set_weights(w, mask)                                   # a mask uploaded without its prefix sum invalidates it
+    with pytest.raises(_capi.FsnapError):
+        ctx.set_weights_train(np.ascontiguousarray(w[~t]))
+    with pytest.raises(ValueError):
+        ctx.set_weights_train(np.ones(5), mask, rank[:-1])
+
+
+def test_reweighting_loop_through_the_solver_matches_independent_fits(ta, ta_fits):
+    # keep_resident: candidate weights travel compactly, the mask stays on the device; every candidate equals a fresh fit
+    A, b, w = ta
+    t = ta_fits["testing_mask"]
+    fsd = {"Testing": t.tolist()}
+    pt, s = make_solver("RIDGE", {"RIDGE": {"alpha": 1e-8}})
+    s.keep_resident = True
+    rng = np.random.default_rng(1)
+    for it in range(4):
+        wi = w * rng.uniform(0.5, 2.0, len(w))
+        s.perform_fit(A, b, wi[~t], fs_dict=fsd)
+        assert maxrel(s.fit, orc.ridge_fit(A, b, wi, 1e-8, testing=t)) < 1e-6
+        if it == 1:
+            s.pt.hip().set_weights(w, (t).astype(np.uint8))    # somebody else used the context meanwhile
+    pt.free()

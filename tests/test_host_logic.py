@@ -91,7 +91,9 @@ def test_mask_and_weight_resolution_follows_reference():
     testing = [False, True, False, False, True, False]
     # explicit arrays: w has one entry per TRAINING row (svd.py:46 multiplies unmasked w)
     A, B, wf, mask, shared = s._resolve_inputs(a, b, np.array([1.0, 2, 3, 4]), {"Testing": testing}, False)
-    assert not shared and mask.tolist() == [1, 0, 1, 1, 0, 1] and wf.tolist() == [1, 0, 2, 3, 0, 4]
+    # the training weights stay compact (the GPU spreads them over the rows); full() is the reference's aw row scaling
+    assert not shared and mask.tolist() == [1, 0, 1, 1, 0, 1] and wf.full().tolist() == [1, 0, 2, 3, 0, 4]
+    assert wf.w.tolist() == [1, 2, 3, 4] and wf.rank.tolist() == [0, 1, 1, 2, 3, 3] and wf.mask_u8.tolist() == mask.tolist()
     with pytest.raises(ValueError, match="could not be broadcast"):
         s._resolve_inputs(a, b, np.ones(6), {"Testing": testing}, False)
     # trainall
