@@ -261,20 +261,34 @@ __global__ __launch_bounds__(256) void fsnap_gemvT_rows_k(const double* __restri
         partial[(int64_t)blockIdx.x * K + c] = (sacc[c] + sacc[Kpad + c]) + (sacc[2 * Kpad + c] + sacc[3 * Kpad + c]);
 }
 
+// out[c] = sum over the per-workgroup partial vectors, fixed order.  A workgroup owns 16 columns: thread (column
+// c0 + (tid & 15), lane group g = tid >> 4) adds the partials g, g + 16, ... (four independent accumulators: the loads
+// of a thread are dependent only through the sums), then the 16 groups are folded through LDS in a fixed tree.  (One
+// thread per column walked 2048 partials one dependent load after the other: 143 us at K = 128 -- as long as the
+// streaming pass it finishes.)
 __global__ __launch_bounds__(256) void fsnap_colsum_partials_k(const double* __restrict__ partial, int nparts, int K,
                                                                double* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= K) return;
+    __shared__ double fold[16][17];
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int p = 0;
-    for (; p + 3 < nparts; p += 4) {
-        s0 += partial[(int64_t)p * K + c];
-        s1 += partial[(int64_t)(p + 1) * K + c];
-        s2 += partial[(int64_t)(p + 2) * K + c];
-        s3 += partial[(int64_t)(p + 3) * K + c];
+    if (c < K) {
+        int p = g;
+        for (; p + 48 < nparts; p += 64) {
+            s0 += partial[(int64_t)p * K + c];
+            s1 += partial[(int64_t)(p + 16) * K + c];
+            s2 += partial[(int64_t)(p + 32) * K + c];
+            s3 += partial[(int64_t)(p + 48) * K + c];
+        }
+        for (; p < nparts; p += 16) s0 += partial[(int64_t)p * K + c];
     }
-    for (; p < nparts; ++p) s0 += partial[(int64_t)p * K + c];
-    out[c] = (s0 + s1) + (s2 + s3);
+    fold[g][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    for (int h = 8; h > 0; h >>= 1) {
+        if (g < h) fold[g][cl] += fold[g + h][cl];
+        __syncthreads();
+    }
+    if (g == 0 && c < K) out[c] = fold[0][cl];
 }
 
 // ---------------------------------------------------------------------------------
@@ -445,7 +459,7 @@ hipError_t launch_gemvT_rows(const double* A, int64_t lda, const double* u, int6
         attr_set = true;
     }
     hipLaunchKernelGGL(fsnap_gemvT_rows_k, dim3((unsigned)nb), dim3(256), lds, st, A, lda, u, m, K, rpw, partial);
-    hipLaunchKernelGGL(fsnap_colsum_partials_k, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, partial, nb, K, out);
+    hipLaunchKernelGGL(fsnap_colsum_partials_k, dim3((unsigned)((K + 15) / 16)), dim3(256), 0, st, partial, nb, K, out);
     return hipGetLastError();
 }
 

@@ -21,10 +21,11 @@ for m, K, ngroups in ((15213, 31, 12), (1000000, 128, 40)):
     s.keep_resident = True
     times = []
     for it in range(8):
-        w_it = w * rng.uniform(0.5, 2.0)                       # a new candidate's weights
+        w_it = w * rng.uniform(0.5, 2.0)                       # a new candidate's weights ...
+        w_tr = w_it[~t]                                        # ... one per training row, as the reference's GA passes them
         t0 = time.perf_counter()
         s.fit = None
-        s.perform_fit(A, b, w_it[~t], fs_dict=fsd)
+        s.perform_fit(A, b, w_tr, fs_dict=fsd)
         t1 = time.perf_counter()
         s.error_analysis(A, b, w_it, fsd)
         rmse = s.errors.iloc[:, 2].to_numpy()[:3]
