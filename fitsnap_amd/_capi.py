@@ -76,6 +76,8 @@ SIGNATURES = {
     "fsnap_dev_alloc": (c_int, [c_void_p, c_int64, POINTER(c_void_p)]),
     "fsnap_dev_free": (c_int, [c_void_p, c_void_p]),
     "fsnap_dev_sync": (c_int, [c_void_p]),
+    "fsnap_dev_upload": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
+    "fsnap_dev_download": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "fsnap_lstsq_rows": (c_int, [c_void_p, c_double, c_int64, c_void_p, POINTER(c_int), c_void_p]),
     "fsnap_rowspace_factor": (c_int, [c_int64, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p]),
     "fsnap_rowspace_solve": (c_int, [c_int64, c_void_p, c_void_p, c_double, c_void_p, POINTER(c_int), c_void_p]),
@@ -545,6 +547,16 @@ class HipContext:
 
     def dev_free(self, d_ptr: int):
         self._check(self._lib.fsnap_dev_free(self._h, c_void_p(d_ptr)))
+
+    def dev_upload(self, d_ptr: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        self._check(self._lib.fsnap_dev_upload(self._h, c_void_p(d_ptr), _ptr(arr), arr.nbytes))
+
+    def dev_download(self, d_ptr: int, out: np.ndarray):
+        if not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("dev_download needs a C-contiguous array")
+        self._check(self._lib.fsnap_dev_download(self._h, _ptr(out), c_void_p(d_ptr), out.nbytes))
+        return out
 
     def sync(self):
         self._check(self._lib.fsnap_dev_sync(self._h))

@@ -1249,6 +1249,24 @@ int fsnap_dev_free(fsnap_ctx* ctx, void* d_ptr) {
     return FSNAP_OK;
 }
 
+int fsnap_dev_upload(fsnap_ctx* ctx, void* d_dst, const void* h_src, int64_t nbytes) {
+    if (!ctx) return FSNAP_E_ARG;
+    if (!d_dst || !h_src || nbytes <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_dev_upload: bad argument");
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    FSNAP_HIP(hipMemcpyAsync(d_dst, h_src, (size_t)nbytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(H2D)");
+    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    return FSNAP_OK;
+}
+
+int fsnap_dev_download(fsnap_ctx* ctx, void* h_dst, const void* d_src, int64_t nbytes) {
+    if (!ctx) return FSNAP_E_ARG;
+    if (!h_dst || !d_src || nbytes <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_dev_download: bad argument");
+    FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    FSNAP_HIP(hipMemcpyAsync(h_dst, d_src, (size_t)nbytes, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(D2H)");
+    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    return FSNAP_OK;
+}
+
 int fsnap_dev_sync(fsnap_ctx* ctx) {
     if (!ctx) return FSNAP_E_ARG;
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");

@@ -174,8 +174,11 @@ __global__ __launch_bounds__(1024) void fsnap_chol_solve_k(const double* __restr
 //   8d update    S22 -= U12^T U12 on the matrix pipe: one wave per 32 x 32 block pair (2 x 2 MFMA tiles),
 //                k = 64 rows in 16 MFMA steps -- a 64-row SYRK, the same operand trick as kernel 1; the strip is one
 //                more block column
-//   8e backsolve one workgroup: U x = y panel by panel from the bottom (64 x 64 triangular solve inside one wave,
-//                then y_r -= U[r, panel] x_panel for all rows above, one thread per row), beta = D x
+//   8d+8b fused  the launch that updates the trailing matrix of panel j also factorises the diagonal block of panel
+//                j + 1 (workgroup 0: its three block pairs first, then kernel 8b's body in its first wave): look-ahead
+//   8e backsolve U x = y from the bottom in macro-blocks of 256 rows: one workgroup solves the 256 x 256 diagonal block
+//                (wave 0 runs the dependency chain, the other waves apply the previous panel's x inside the block),
+//                then the whole chip applies the 256 new x to all rows above (a 256-column GEMV); beta = D x
 // status[0]: bit 0 = non-positive / non-finite diagonal of G + alpha I, bit 1 = failed pivot;
 // minpiv[p] = smallest pivot of panel p.
 // ---------------------------------------------------------------------------------
@@ -258,15 +261,22 @@ __device__ __forceinline__ double rsqrt_newton(double d) {
 // The next multiplier is read before the FMA of the current one and a scheduling barrier closes every (readlane,
 // readlane, fma) group: left alone, the scheduler hoists all broadcasts of a step, runs out of scalar registers and
 // spills them through v_writelane.
+// single-wave synchronisation of LDS traffic (kernel 8b runs in ONE wave, also when that wave is part of a larger
+// workgroup -- the fused update + diagonal kernel -- where s_barrier would wait for waves that are not coming)
+__device__ __forceinline__ void chol_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int a>
 __device__ __forceinline__ void chol_diag_step(d4 (&B)[4][4], double (*T)[17], double (*UT)[16], double* __restrict__ S,
                                                int ld, int jb, double* __restrict__ Y, int e, int kr, double& pmin,
                                                double& psum) {
     // diagonal block -> column e in every lane (the four lane groups hold identical copies)
-    __syncthreads();
+    chol_wave_sync();
 #pragma unroll
     for (int r = 0; r < 4; ++r) T[4 * r + kr][e] = B[a][a][r];
-    __syncthreads();
+    chol_wave_sync();
     double col[16], rinv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) col[r] = T[r][e];
@@ -296,7 +306,7 @@ __device__ __forceinline__ void chol_diag_step(d4 (&B)[4][4], double (*T)[17], d
             UT[e][r] = col[r];                              // UT[k][r] = U[r][k]: the multipliers of step k, contiguous
         }
     }
-    __syncthreads();
+    chol_wave_sync();
     // Y_a = U_aa^-1: lane e solves U y = e_e by back substitution.  The multipliers U[0..k-1][k] of step k are the
     // same for every lane and do not depend on y: they are read from LDS one step ahead.
     double y[16], mcur[16];
@@ -327,7 +337,7 @@ __device__ __forceinline__ void chol_diag_step(d4 (&B)[4][4], double (*T)[17], d
 #pragma unroll
             for (int r = 0; r < 16; ++r) T[r][e] = y[r];
         }
-        __syncthreads();
+        chol_wave_sync();
         double yt[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) yt[s] = T[4 * s + kr][e];
@@ -348,11 +358,11 @@ __device__ __forceinline__ void chol_diag_step(d4 (&B)[4][4], double (*T)[17], d
     }
 }
 
-__global__ __launch_bounds__(64) void fsnap_chol_diag_k(double* __restrict__ S, int ld, int jb, double* __restrict__ Y,
-                                                       int* __restrict__ status, double* __restrict__ minpiv) {
-    __shared__ double T[16][17];
-    __shared__ __attribute__((aligned(16))) double UT[16][16];
-    const int lane = threadIdx.x, e = lane & 15, kr = lane >> 4;
+// the whole of kernel 8b for the panel at jb, executed by ONE wave (lane = threadIdx.x & 63); T: 16 x 17 doubles of LDS
+__device__ __forceinline__ void chol_diag_body(double* __restrict__ S, int ld, int jb, double* __restrict__ Y,
+                                               int* __restrict__ status, double* __restrict__ minpiv, double (*T)[17],
+                                               double (*UT)[16], int lane) {
+    const int e = lane & 15, kr = lane >> 4;
     d4 B[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -376,6 +386,13 @@ __global__ __launch_bounds__(64) void fsnap_chol_diag_k(double* __restrict__ S, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) S[(size_t)(jb + 16 * a + 4 * r + kr) * ld + jb + 16 * b + e] = B[a][b][r];
     if (lane == 0) minpiv[jb / CHOL_NB] = pmin;
+}
+
+__global__ __launch_bounds__(64) void fsnap_chol_diag_k(double* __restrict__ S, int ld, int jb, double* __restrict__ Y,
+                                                       int* __restrict__ status, double* __restrict__ minpiv) {
+    __shared__ double T[16][17];
+    __shared__ __attribute__((aligned(16))) double UT[16][16];
+    chol_diag_body(S, ld, jb, Y, status, minpiv, T, UT, (int)threadIdx.x);
 }
 
 // 8c: blocked forward substitution on the matrix pipe.  One wave per 16-column strip of the columns right of the
@@ -417,13 +434,10 @@ __global__ __launch_bounds__(256) void fsnap_chol_tails_k(double* __restrict__ S
         for (int r = 0; r < 4; ++r) base[(size_t)(16 * b + 4 * r) * ld + c0 + e] = X[b][r];
 }
 
-__global__ __launch_bounds__(256) void fsnap_chol_update_k(double* __restrict__ S, int ld, int jb, int nblk,
-                                                          const int* __restrict__ status) {
-    if (*status) return;
-    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
-    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+// one 32 x 32 block pair of the trailing update (a 2 x 2 group of MFMA tiles), executed by one wave
+__device__ __forceinline__ void chol_update_pair(double* __restrict__ S, int ld, int jb, int nblk, int pair, int lane) {
+    const int e = lane & 15, kr = lane >> 4;
     const int ntri = nblk * (nblk + 1) / 2;
-    if (pair >= ntri + nblk) return;
     // pair -> (I, J), I <= J, row-major packed triangle over nblk 32-column blocks; then (I, strip) for every I
     int I, J;
     if (pair < ntri) {
@@ -484,59 +498,136 @@ __global__ __launch_bounds__(256) void fsnap_chol_update_k(double* __restrict__ 
     }
 }
 
-// 8e: the strip's first column now holds y = U^-T z; solve U x = y from the last panel upwards.  Per panel: wave 0
-// solves the 64 x 64 triangular system as a blocked substitution with the inverted 16 x 16 diagonal blocks of
-// kernel 8b (7 small matrix-vector products, multipliers broadcast with v_readlane; the 64-step scalar recurrence
-// took ~5 us per panel), then every thread takes rows above the panel: y_r -= U[r, panel] x_panel (64 contiguous
-// doubles per row).  The next panel's diagonal block and inverses are fetched into registers while that runs.
-// Dynamic LDS: two buffers of [U11 64 x 65 | Y 4 x 16 x 17] + x_panel (64) + y of the next panel (64).
-constexpr int CHOL_BS_BUF = CHOL_NB * (CHOL_NB + 1) + 4 * 16 * 17;
-constexpr size_t CHOL_BS_LDS = (size_t)(2 * CHOL_BS_BUF + 2 * CHOL_NB) * sizeof(double);
+// 8d + 8b fused ("look-ahead"): the trailing update of panel jb AND the factorisation of the NEXT diagonal block in one
+// launch.  Workgroup 0 updates the three block pairs that make up the next 64 x 64 diagonal block -- (0,0), (0,1),
+// (1,1) -- and its first wave then factorises that block (kernel 8b's body) while all other workgroups are still busy
+// with the rest of the trailing matrix: the 16 us single-wave recurrence leaves the serial chain of the panel loop
+// (was: diagonal 16 us -> tails 5 us -> update 7 us per panel, one after the other).
+__global__ __launch_bounds__(256) void fsnap_chol_update_diag_k(double* __restrict__ S, int ld, int jb, int nblk,
+                                                               int* __restrict__ status, double* __restrict__ Ynext,
+                                                               double* __restrict__ minpiv) {
+    __shared__ double T[16][17];
+    __shared__ __attribute__((aligned(16))) double UT[16][16];
+    if (*status) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0) {
+        if (wave < 3) chol_update_pair(S, ld, jb, nblk, wave == 2 ? nblk : wave, lane);
+        __syncthreads();
+        if (wave == 0) chol_diag_body(S, ld, jb + CHOL_NB, Ynext, status, minpiv, T, UT, lane);
+        return;
+    }
+    const int total = nblk * (nblk + 1) / 2 + nblk;
+    const int q = ((int)blockIdx.x - 1) * 4 + wave;        // the remaining pairs: all but 0, 1 and nblk
+    const int pair = q < nblk - 2 ? q + 2 : q + 3;
+    if (pair >= total) return;
+    chol_update_pair(S, ld, jb, nblk, pair, lane);
+}
+
+// 8e: the strip's first column now holds y = U^-T z; solve U x = y from the bottom in MACRO-BLOCKS of four panels
+// (256 rows).  Per macro-block two launches:
+//   fsnap_chol_backsolve_k   ONE workgroup solves the 256 x 256 diagonal block panel by panel, the two halves of a panel
+//     step running side by side (they used to alternate over ALL rows above: 13 us per panel, 326 us at K = 1595):
+//       wave 0 -- the dependency chain: y_pb minus U[pb, pb + 1] x_{pb+1} (a 64 x 64 block staged in LDS), then the
+//         64 x 64 triangular system as a blocked substitution with the inverted 16 x 16 diagonal blocks of kernel 8b
+//         (7 small matrix-vector products, multipliers broadcast with v_readlane);
+//       waves 1-15 -- one panel behind: y_r -= U[r, panel pb + 1] x_{pb+1} for the rows of the macro-block above panel pb
+//         (64 contiguous doubles per row); the finished values of the rows of panel pb - 1 go to LDS for the next step.
+//     The diagonal block, the block right of it and the inverses of the NEXT panel are fetched into registers meanwhile.
+//   fsnap_chol_backupdate_k  the whole chip applies the 256 new x to every row above the macro-block (one wave per row,
+//     a 256-column GEMV): one workgroup streaming those rows was bound by its own outstanding loads (~150 GB/s).
+// Dynamic LDS: two buffers of [U11 64 x 65 | Uoff 64 x 65 | Y 4 x 16 x 17] + 2 x x_panel (64) + 2 x y_panel (64).
+constexpr int CHOL_BS_BUF = 2 * CHOL_NB * (CHOL_NB + 1) + 4 * 16 * 17;
+constexpr size_t CHOL_BS_LDS = (size_t)(2 * CHOL_BS_BUF + 4 * CHOL_NB) * sizeof(double);
+constexpr int CHOL_BS_MACRO = 4;             // panels per macro-block
+
+__global__ __launch_bounds__(256) void fsnap_chol_backinit_k(const double* __restrict__ S, int ld, int np, double* __restrict__ zv,
+                                                            const int* __restrict__ status) {
+    if (*status) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < np) zv[i] = S[(size_t)i * ld + np];
+}
+
+// y_r -= U[r, c0 : c1] x[c0 : c1] for the rows r < nrows; one wave per row, c1 - c0 a multiple of 128
+__global__ __launch_bounds__(256) void fsnap_chol_backupdate_k(const double* __restrict__ S, int ld, double* zv, int c0, int c1,
+                                                              int nrows, const int* __restrict__ status) {
+    if (*status) return;
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const double* u = S + (size_t)r * ld;
+    double a0 = 0.0, a1 = 0.0;
+    for (int c = c0 + 2 * lane; c < c1; c += 128) {
+        const d2 uv = *reinterpret_cast<const d2*>(u + c);        // 16-byte aligned: ld, c0 multiples of 32
+        const d2 xv = *reinterpret_cast<const d2*>(zv + c);
+        a0 = __builtin_fma(uv[0], xv[0], a0);
+        a1 = __builtin_fma(uv[1], xv[1], a1);
+    }
+    double acc = a0 + a1;
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) acc += __shfl_xor(acc, sft, 64);
+    if (lane == 0) zv[r] -= acc;
+}
 
 __global__ __launch_bounds__(1024) void fsnap_chol_backsolve_k(const double* __restrict__ S, int ld, int np, int n,
-                                                              const double* __restrict__ Yall, double* __restrict__ zv,
+                                                              const double* __restrict__ Yall, double* zv,
                                                               const double* __restrict__ dsc, double* __restrict__ beta,
-                                                              const int* __restrict__ status) {
+                                                              const int* __restrict__ status, int p_lo, int p_hi) {
     extern __shared__ __attribute__((aligned(16))) double bs_lds[];
     if (*status) return;
-    double* xb = bs_lds + 2 * CHOL_BS_BUF;     // x of the current panel
-    double* ynext = xb + CHOL_NB;              // finished y of the next panel (rows jb - 64 .. jb - 1)
+    double* xbuf = bs_lds + 2 * CHOL_BS_BUF;   // x of the panel solved last / being solved (two slots)
+    double* ybuf = xbuf + 2 * CHOL_NB;         // y of the panel being solved / of the next one (two slots)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int npanel = np / CHOL_NB;
-    for (int i = tid; i < np; i += 1024) zv[i] = S[(size_t)i * ld + np];
-    if (tid < CHOL_NB) ynext[tid] = S[(size_t)(np - CHOL_NB + tid) * ld + np];
-    // thread t stages U11 elements t, t + 1024, ... and Y element t of a panel
-    double pu[4], py;
+    const int row_lo = p_lo * CHOL_NB;         // first row of the macro-block
+    if (tid < CHOL_NB) ybuf[tid] = zv[(p_hi - 1) * CHOL_NB + tid];      // slot 0: the macro-block's last panel
+    // thread t stages elements t, t + 1024, ... of U11 and of the block right of it, and Y element t of a panel
+    double pu[4], po[4], py;
     auto fetch = [&](int pb) {
         const int jb = pb * CHOL_NB;
+        const bool off = pb + 1 < p_hi;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int t = tid + 1024 * q;
-            pu[q] = S[(size_t)(jb + (t >> 6)) * ld + jb + (t & 63)];
+            const double* row = S + (size_t)(jb + (t >> 6)) * ld + jb + (t & 63);
+            pu[q] = row[0];
+            po[q] = off ? row[CHOL_NB] : 0.0;
         }
         py = Yall[(size_t)pb * 1024 + tid];
     };
     auto park = [&](int buf) {
         double* U11 = bs_lds + buf * CHOL_BS_BUF;
-        double* Ysm = U11 + CHOL_NB * (CHOL_NB + 1);
+        double* Uoff = U11 + CHOL_NB * (CHOL_NB + 1);
+        double* Ysm = Uoff + CHOL_NB * (CHOL_NB + 1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int t = tid + 1024 * q;
             U11[(t >> 6) * (CHOL_NB + 1) + (t & 63)] = pu[q];
+            Uoff[(t >> 6) * (CHOL_NB + 1) + (t & 63)] = po[q];
         }
         Ysm[(tid >> 4) * 17 + (tid & 15)] = py;      // (block, row) = tid >> 4, column = tid & 15
     };
-    fetch(npanel - 1);
+    fetch(p_hi - 1);
     park(0);
     __syncthreads();
-    for (int pb = npanel - 1; pb >= 0; --pb) {
+    for (int pb = p_hi - 1; pb >= p_lo; --pb) {
         const int jb = pb * CHOL_NB;
-        const int cur = (npanel - 1 - pb) & 1;
+        const int cur = (p_hi - 1 - pb) & 1;            // LDS buffer / x slot / y slot of this panel
         const double* U11 = bs_lds + cur * CHOL_BS_BUF;
-        const double* Ysm = U11 + CHOL_NB * (CHOL_NB + 1);
-        if (pb > 0) fetch(pb - 1);
+        const double* Uoff = U11 + CHOL_NB * (CHOL_NB + 1);
+        const double* Ysm = Uoff + CHOL_NB * (CHOL_NB + 1);
+        const double* xprev = xbuf + (cur ^ 1) * CHOL_NB;      // x of panel pb + 1
+        const bool have_prev = pb + 1 < p_hi;
+        if (pb > p_lo) fetch(pb - 1);
         if (wv == 0) {
-            double v = ynext[lane];
+            double v = ybuf[cur * CHOL_NB + lane];
+            if (have_prev) {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+                for (int k = 0; k < CHOL_NB; k += 2) {
+                    s0 = __builtin_fma(Uoff[lane * (CHOL_NB + 1) + k], xprev[k], s0);
+                    s1 = __builtin_fma(Uoff[lane * (CHOL_NB + 1) + k + 1], xprev[k + 1], s1);
+                }
+                v -= s0 + s1;
+            }
             const int blk = lane >> 4, i = lane & 15;
 #pragma unroll
             for (int b = 3; b >= 0; --b) {
@@ -554,34 +645,40 @@ __global__ __launch_bounds__(1024) void fsnap_chol_backsolve_k(const double* __r
                     if (blk < b) v -= sub;
                 }
             }
-            xb[lane] = v;
+            xbuf[cur * CHOL_NB + lane] = v;
             zv[jb + lane] = v;
-        }
-        __syncthreads();
-        // rows above the panel: y_r -= U[r, jb : jb + 64] x_panel
-        for (int r = tid; r < jb; r += 1024) {
-            const d2* u = reinterpret_cast<const d2*>(S + (size_t)r * ld + jb);   // 16-byte aligned: ld, jb multiples of 32
-            const double z0 = zv[r];
-            double a0 = 0.0, a1 = 0.0;
+        } else if (have_prev) {
+            // rows of the macro-block above panel pb: y_r -= U[r, panel pb + 1] x_{pb+1}; the rows of panel pb - 1 are then
+            // complete up to the contribution of x_pb, which wave 0 adds in the next step
+            const int cb = jb + CHOL_NB;                       // first column of panel pb + 1
+            for (int r = row_lo + tid - 64; r < jb; r += 960) {
+                const d2* u = reinterpret_cast<const d2*>(S + (size_t)r * ld + cb);   // 16-byte aligned: ld, cb multiples of 32
+                const double z0 = zv[r];
+                double a0 = 0.0, a1 = 0.0;
 #pragma unroll 1
-            for (int h = 0; h < 2; ++h) {          // 16 x 16-byte loads in flight (128-register budget of 1024 threads)
-                d2 uv[16];
+                for (int h = 0; h < 2; ++h) {          // 16 x 16-byte loads in flight (128-register budget of 1024 threads)
+                    d2 uv[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) uv[q] = u[16 * h + q];
+                    for (int q = 0; q < 16; ++q) uv[q] = u[16 * h + q];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    a0 = __builtin_fma(uv[q][0], xb[32 * h + 2 * q], a0);
-                    a1 = __builtin_fma(uv[q][1], xb[32 * h + 2 * q + 1], a1);
+                    for (int q = 0; q < 16; ++q) {
+                        a0 = __builtin_fma(uv[q][0], xprev[32 * h + 2 * q], a0);
+                        a1 = __builtin_fma(uv[q][1], xprev[32 * h + 2 * q + 1], a1);
+                    }
                 }
+                const double zn = z0 - (a0 + a1);
+                zv[r] = zn;
+                if (r >= jb - CHOL_NB) ybuf[(cur ^ 1) * CHOL_NB + r - (jb - CHOL_NB)] = zn;
             }
-            const double zn = z0 - (a0 + a1);
-            zv[r] = zn;
-            if (r >= jb - CHOL_NB) ynext[r - (jb - CHOL_NB)] = zn;
+        } else if (pb > p_lo) {
+            // first step of the macro-block: nothing to apply yet; the rows of the next panel come as they are
+            if (tid - 64 < CHOL_NB) ybuf[(cur ^ 1) * CHOL_NB + tid - 64] = zv[jb - CHOL_NB + (tid - 64)];
         }
-        if (pb > 0) park(cur ^ 1);
+        if (pb > p_lo) park(cur ^ 1);
         __syncthreads();
     }
-    for (int i = tid; i < n; i += 1024) beta[i] = zv[i] * dsc[i];
+    if (p_lo == 0)
+        for (int i = tid; i < n; i += 1024) beta[i] = zv[i] * dsc[i];
 }
 // ---------------------------------------------------------------------------------
 // host-side launchers (C++ linkage, used by fsnap_capi.cpp)
@@ -605,16 +702,18 @@ hipError_t launch_chol_large(const double* packed, const double* cvec, int n, do
                        minpiv, npanel);
     hipLaunchKernelGGL(fsnap_chol_prepare_s_k, dim3((ld + 255) / 256, np), dim3(256), 0, st, packed, n, np, alpha, dsc, z, S,
                        status);
+    hipLaunchKernelGGL(fsnap_chol_diag_k, dim3(1), dim3(64), 0, st, S, ld, 0, Yall, status, minpiv);
     for (int pb = 0; pb < npanel; ++pb) {
         const int jb = pb * CHOL_NB;
         double* Y = Yall + (size_t)pb * 1024;
-        hipLaunchKernelGGL(fsnap_chol_diag_k, dim3(1), dim3(64), 0, st, S, ld, jb, Y, status, minpiv);
         const int ntail = np - jb - CHOL_NB;
         const int nstrip = (ntail + CHOL_XS) / 16;
         hipLaunchKernelGGL(fsnap_chol_tails_k, dim3((nstrip + 3) / 4), dim3(256), 0, st, S, ld, jb, nstrip, Y, status);
         if (ntail > 0) {
-            const int nblk = ntail / 32, npair = nblk * (nblk + 1) / 2 + nblk;
-            hipLaunchKernelGGL(fsnap_chol_update_k, dim3((npair + 3) / 4), dim3(256), 0, st, S, ld, jb, nblk, status);
+            // trailing update of this panel + factorisation of the next diagonal block (look-ahead), one launch
+            const int nblk = ntail / 32, nrest = nblk * (nblk + 1) / 2 + nblk - 3;
+            hipLaunchKernelGGL(fsnap_chol_update_diag_k, dim3(1 + (nrest + 3) / 4), dim3(256), 0, st, S, ld, jb, nblk, status,
+                               Y + 1024, minpiv);
         }
     }
     static bool bs_attr_set = false;
@@ -623,7 +722,17 @@ hipError_t launch_chol_large(const double* packed, const double* cvec, int n, do
         if (e != hipSuccess) return e;
         bs_attr_set = true;
     }
-    hipLaunchKernelGGL(fsnap_chol_backsolve_k, dim3(1), dim3(1024), CHOL_BS_LDS, st, S, ld, np, n, Yall, z, dsc, beta, status);
+    hipLaunchKernelGGL(fsnap_chol_backinit_k, dim3((np + 255) / 256), dim3(256), 0, st, S, ld, np, z, status);
+    for (int hi = npanel; hi > 0; hi -= CHOL_BS_MACRO) {
+        const int lo = hi > CHOL_BS_MACRO ? hi - CHOL_BS_MACRO : 0;
+        hipLaunchKernelGGL(fsnap_chol_backsolve_k, dim3(1), dim3(1024), CHOL_BS_LDS, st, S, ld, np, n, Yall, z, dsc, beta, status,
+                           lo, hi);
+        if (lo > 0) {
+            const int nrows = lo * CHOL_NB;
+            hipLaunchKernelGGL(fsnap_chol_backupdate_k, dim3((nrows + 3) / 4), dim3(256), 0, st, S, ld, z, lo * CHOL_NB,
+                               hi * CHOL_NB, nrows, status);
+        }
+    }
     return hipGetLastError();
 }
 

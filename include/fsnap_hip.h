@@ -320,6 +320,9 @@ int fsnap_fit_dist(fsnap_ctx* ctx, int kind, double param, int64_t K, double* be
 int fsnap_dev_alloc(fsnap_ctx* ctx, int64_t nbytes, void** d_ptr);
 int fsnap_dev_free(fsnap_ctx* ctx, void* d_ptr);
 int fsnap_dev_sync(fsnap_ctx* ctx);
+/* Synchronous copies between host memory and memory of fsnap_dev_alloc (or any device pointer of this GPU). */
+int fsnap_dev_upload(fsnap_ctx* ctx, void* d_dst, const void* h_src, int64_t nbytes);
+int fsnap_dev_download(fsnap_ctx* ctx, void* h_dst, const void* d_src, int64_t nbytes);
 
 /* ---- measurement ------------------------------------------------------------------ */
 
