@@ -1025,10 +1025,11 @@ int fsnap_error_stats(fsnap_ctx* ctx, const double* beta, const int32_t* cat, in
     const size_t m = (size_t)ctx->m, K = (size_t)ctx->K;
     const int nb = fsnap::error_stats_num_blocks(ctx->m);
     if (!ctx->beta.ensure(K * 8) || !ctx->preds.ensure(m * 8) || !ctx->dcat.ensure(m * 4) ||
-        !ctx->dstat.ensure(((size_t)nb * ncat * 6 + (size_t)ncat * 2) * 8))
+        !ctx->dstat.ensure(((size_t)nb * ncat * 6 + (size_t)ncat * 2 + (size_t)ncat * 6) * 8))
         return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(error statistics) failed");
     double* d_partial = (double*)ctx->dstat.p;
     double* d_means = d_partial + (size_t)nb * ncat * 6;
+    double* d_table = d_means + (size_t)ncat * 2;                 // per-category sums of a pass, folded over the workgroups
     FSNAP_HIP(hipMemcpyAsync(ctx->beta.p, beta, K * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(beta)");
     if (cat) {
         FSNAP_HIP(hipMemcpyAsync(ctx->dcat.p, cat, m * 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(categories)");
@@ -1037,38 +1038,32 @@ int fsnap_error_stats(fsnap_ctx* ctx, const double* beta, const int32_t* cat, in
     FSNAP_HIP(fsnap::launch_gemv_rows(ctx->dA, ctx->lda, (const double*)ctx->beta.p, ctx->m, (int)ctx->K, (double*)ctx->preds.p,
                                       ctx->db, ctx->dw, nullptr, nullptr, nullptr, ctx->stream),
               "launch fsnap_gemv_rows_k");
-    std::vector<double> h((size_t)nb * ncat * 6), means((size_t)ncat * 2);
-    // pass 0: counts and sums -> category means
+    std::vector<double> h((size_t)ncat * 6), means((size_t)ncat * 2);
+    // pass 0: counts and sums -> category means.  The per-workgroup tables are folded on the device (fixed order); only
+    // ncat x 4 doubles come back (the host used to add 245 tables of ncat x 4 entries itself: ~1 ms at 240 categories)
     FSNAP_HIP(fsnap::launch_error_stats(ctx->db, (const double*)ctx->preds.p, ctx->dw, (const int*)ctx->dcat.p, ctx->m, ncat, 0,
                                         nullptr, d_partial, ctx->stream),
               "launch fsnap_error_stats_k");
-    FSNAP_HIP(hipMemcpyAsync(h.data(), d_partial, (size_t)nb * ncat * 4 * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(stats)");
+    FSNAP_HIP(fsnap::launch_colsum(d_partial, nb, ncat * 4, d_table, ctx->stream), "launch fsnap_colsum_partials_k");
+    FSNAP_HIP(hipMemcpyAsync(h.data(), d_table, (size_t)ncat * 4 * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(stats)");
     FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     for (int c = 0; c < ncat; ++c) {
-        long double a0 = 0, a1 = 0, a2 = 0, a3 = 0;   // fixed-order sum of the per-workgroup tables
-        for (int g = 0; g < nb; ++g) {
-            const double* e = h.data() + ((size_t)g * ncat + c) * 4;
-            a0 += e[0]; a1 += e[1]; a2 += e[2]; a3 += e[3];
-        }
+        const double* e = h.data() + (size_t)c * 4;
         double* o = stats + (size_t)c * 10;
-        o[0] = (double)a0; o[1] = (double)a1; o[2] = (double)a2; o[3] = (double)a3;
-        means[2 * c] = a0 > 0 ? (double)(a2 / a0) : 0.0;            // (truths / n).sum()
-        means[2 * c + 1] = a1 > 0 ? (double)(a3 / a1) : 0.0;        // (w * truths / n_w).sum()
+        o[0] = e[0]; o[1] = e[1]; o[2] = e[2]; o[3] = e[3];
+        means[2 * c] = e[0] > 0 ? e[2] / e[0] : 0.0;            // (truths / n).sum()
+        means[2 * c + 1] = e[1] > 0 ? e[3] / e[1] : 0.0;        // (w * truths / n_w).sum()
     }
     FSNAP_HIP(hipMemcpyAsync(d_means, means.data(), (size_t)ncat * 2 * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(means)");
     FSNAP_HIP(fsnap::launch_error_stats(ctx->db, (const double*)ctx->preds.p, ctx->dw, (const int*)ctx->dcat.p, ctx->m, ncat, 1,
                                         d_means, d_partial, ctx->stream),
               "launch fsnap_error_stats_k");
-    FSNAP_HIP(hipMemcpyAsync(h.data(), d_partial, (size_t)nb * ncat * 6 * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(stats)");
+    FSNAP_HIP(fsnap::launch_colsum(d_partial, nb, ncat * 6, d_table, ctx->stream), "launch fsnap_colsum_partials_k");
+    FSNAP_HIP(hipMemcpyAsync(h.data(), d_table, (size_t)ncat * 6 * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(stats)");
     FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     for (int c = 0; c < ncat; ++c) {
-        long double a[6] = {0, 0, 0, 0, 0, 0};
-        for (int g = 0; g < nb; ++g) {
-            const double* e = h.data() + ((size_t)g * ncat + c) * 6;
-            for (int k = 0; k < 6; ++k) a[k] += e[k];
-        }
         double* o = stats + (size_t)c * 10;
-        for (int k = 0; k < 6; ++k) o[4 + k] = (double)a[k];
+        for (int k = 0; k < 6; ++k) o[4 + k] = h[(size_t)c * 6 + k];
     }
     return FSNAP_OK;
 }

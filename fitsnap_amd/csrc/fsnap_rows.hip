@@ -463,6 +463,12 @@ hipError_t launch_gemvT_rows(const double* A, int64_t lda, const double* u, int6
     return hipGetLastError();
 }
 
+// out[c] = sum_p partial[p][c] for an nparts x ncols table, fixed order (kernel fsnap_colsum_partials_k)
+hipError_t launch_colsum(const double* partial, int nparts, int ncols, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(fsnap_colsum_partials_k, dim3((unsigned)((ncols + 15) / 16)), dim3(256), 0, st, partial, nparts, ncols, out);
+    return hipGetLastError();
+}
+
 int pack_weights_num_blocks(int64_t m) {
     int64_t nb = (m + 2047) / 2048;
     if (nb > 512) nb = 512;

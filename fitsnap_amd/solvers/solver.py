@@ -460,16 +460,17 @@ class Solver:
         from pandas import DataFrame, MultiIndex
 
         st = np.asarray(st, dtype=np.float64).reshape(len(keys), 10)
-        grouped = DataFrame(self._metrics_from_sums(*(st[:, k] for k in range(10))),
-                            index=MultiIndex.from_tuples(keys, names=["Groups", "Testing", "Row_Type"]))
-        # *ALL rows: pool the groups of one (Testing, Row_Type)
+        # what depends on the key list only (the two row indexes, the members of every *ALL row) is built once per list
         if self._all_idx is None or self._all_idx[0] is not keys:
             subs = sorted({(k[1], k[2]) for k in keys})
-            self._all_idx = (keys, [(tk, np.array([i for i, k in enumerate(keys) if (k[1], k[2]) == tk])) for tk in subs])
+            self._all_idx = (keys, [(tk, np.array([i for i, k in enumerate(keys) if (k[1], k[2]) == tk])) for tk in subs],
+                             MultiIndex.from_tuples(keys, names=["Groups", "Testing", "Row_Type"]),
+                             MultiIndex.from_tuples(subs, names=["Testing", "Row_Type"]))
+        grouped = DataFrame(self._metrics_from_sums(*(st[:, k] for k in range(10))), index=self._all_idx[2])
+        # *ALL rows: pool the groups of one (Testing, Row_Type)
         sub = [tk for tk, _ in self._all_idx[1]]
         pooled = np.array([self._pool_sums(st[idx]) for _, idx in self._all_idx[1]]).reshape(len(sub), 10)
-        allrows = DataFrame(self._metrics_from_sums(*(pooled[:, k] for k in range(10))),
-                            index=MultiIndex.from_tuples(sub, names=["Testing", "Row_Type"]))
+        allrows = DataFrame(self._metrics_from_sums(*(pooled[:, k] for k in range(10))), index=self._all_idx[3])
         return grouped, allrows
 
     def _device_error_sums(self, a, b, w, shared, fs_dict):
