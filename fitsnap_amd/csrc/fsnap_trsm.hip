@@ -21,7 +21,7 @@
 #include "fsnap_kernels.h"
 
 template <bool FIRST>
-__global__ __launch_bounds__(64, FIRST ? 2 : 4) void fsnap_trsm_rows_k(const double* __restrict__ src, int64_t lds_,
+__global__ __launch_bounds__(64, FIRST ? 2 : 3) void fsnap_trsm_rows_k(const double* __restrict__ src, int64_t lds_,
                                                         const double* __restrict__ wpack, double* Q, int64_t ldq,
                                                         int64_t m, int K, const double* __restrict__ R, int K16) {
     __shared__ double X[64][17];                  // 64 rows x 16 columns of the current block (+1: no bank conflicts)
@@ -36,20 +36,32 @@ __global__ __launch_bounds__(64, FIRST ? 2 : 4) void fsnap_trsm_rows_k(const dou
         d4 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-        // S_J accumulation over the solved blocks: MFMA operands A[i = lane & 15][k = lane >> 4], B[k][j = lane & 15]
+        // S_J accumulation over the solved blocks: MFMA operands A[i = lane & 15][k = lane >> 4], B[k][j = lane & 15].
+        // The k index of an MFMA is free as long as both operands agree: k-step s of lane group g takes column 4 g + s
+        // of the block (not 4 s + g), so a lane needs FOUR ADJACENT doubles of its row -- two 16-byte loads per row
+        // tile instead of four 8-byte ones, whole 32-byte sectors.  (A solved block kb < jb <= NB - 1 is never the
+        // partial last block: no column guard.)
         for (int kb = 0; kb < jb; ++kb) {
+            d2u qa[4], qb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int64_t r = row0 + t * 16 + e;
+                const double* p = Q + (r < m ? r : 0) * ldq + kb * 16 + 4 * g;
+                qa[t] = *reinterpret_cast<const d2u*>(p);
+                qb[t] = *reinterpret_cast<const d2u*>(p + 2);
+                if (r >= m) {
+                    qa[t] = (d2u){0.0, 0.0};
+                    qb[t] = (d2u){0.0, 0.0};
+                }
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int kk = kb * 16 + 4 * s + g;
-                const double bf = R[(size_t)kk * K16 + col];
-                double af[4];
+                const double bf = R[(size_t)(kb * 16 + 4 * g + s) * K16 + col];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const int64_t r = row0 + t * 16 + e;
-                    af[t] = (r < m && kk < K) ? Q[r * ldq + kk] : 0.0;
+                    const double af = (s < 2) ? qa[t][s & 1] : qb[t][s & 1];
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[t], 0, 0, 0);
                 }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t], bf, acc[t], 0, 0, 0);
             }
         }
         // X_J - S_J in the accumulator layout (row = (lane >> 4) + 4 v, column = lane & 15) -> LDS

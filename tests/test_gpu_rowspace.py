@@ -73,8 +73,10 @@ def test_svd_solver_ill_conditioned_matches_lstsq(kappa, mode):
     kw = np.linalg.cond(aw)
     tol = max(1e-6, 50 * kw * EPS)
     assert np.linalg.norm(x - ref) <= tol * np.linalg.norm(ref)
+    # with a non-zero residual r the minimiser's predictions move by ~kappa eps |r| under rounding, i.e. the residual
+    # norm itself by ~(kappa eps)^2 |r| / 2 -- for lstsq just as for us
     res, res_ref = np.linalg.norm(aw @ x - bw), np.linalg.norm(aw @ ref - bw)
-    assert res <= res_ref * (1 + 1e-9) and abs(res - res_ref) <= 1e-6 * res_ref
+    assert res <= res_ref * (1 + max(1e-9, 50 * (kw * EPS) ** 2)) and abs(res - res_ref) <= 1e-5 * res_ref
     truth = extended_precision_solution(aw, bw, ref)
     err, err_ref = np.linalg.norm(x - truth), np.linalg.norm(ref - truth)
     assert err <= 10 * max(err_ref, kw * EPS * np.linalg.norm(truth))
@@ -124,9 +126,10 @@ def test_near_collinear_column_kept_or_dropped_like_gelsd(eps_col, kept):
     pt.free()
 
 
-@pytest.mark.parametrize("K,m", [(31, 5003), (110, 12000), (128, 8192), (200, 6001), (64, 50)])
+@pytest.mark.parametrize("K,m", [(31, 5003), (110, 12000), (128, 8192), (200, 6001), (300, 5000), (64, 50)])
 def test_row_space_all_kernel_families_and_ragged_shapes(K, m):
-    # K = 31: kernel 1P on Q; 110: kernel 1A <7> with a partial last block; 128: 1A <8>; 200: tiled kernel;
+    # K = 31: kernel 1P on Q; 110: kernel 1A <7> with a partial last block; 128: 1A <8>; 200: tiled kernel; 300: beyond
+    # the LDS-resident variant of the orthogonalisation kernel (K > 256: solved blocks re-read from global memory);
     # m = 50 < K: rank deficient by shape (the SVD end picks the minimum-norm solution)
     kappa = 1e9
     r = np.random.default_rng(K)

@@ -58,7 +58,7 @@ def test_matches_lstsq_up_to_kappa_eps(kappa, mode):
     assert np.linalg.norm(x - ref) <= tol * np.linalg.norm(ref)
     # what both solvers minimise agrees far below the coefficient tolerance
     res, res_ref = np.linalg.norm(A @ x - b), np.linalg.norm(A @ ref - b)
-    assert res <= res_ref * (1 + 1e-9) and abs(res - res_ref) <= 1e-6 * res_ref
+    assert res <= res_ref * (1 + max(1e-9, 50 * (kappa * EPS) ** 2)) and abs(res - res_ref) <= 1e-5 * res_ref
 
 
 def test_exact_rank_deficiency_gives_the_minimum_norm_solution():
