@@ -240,6 +240,13 @@ def main():
         else:
             roofline = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": tf / PEAK_FP64_MFMA_TFLOPS, "achieved_GBps_algorithmic": gbs}
+        # what the matrix pipe executes: every 16 x 16 tile of the block triangle in full (the diagonal tiles' lower
+        # halves are redundant), 2 * 16 * 16 flop per row and tile; kernels 1A / 1P / 1 / 1L only
+        executed = None
+        if info["split"] != 0:
+            executed = info["NB"] * (info["NB"] + 1) // 2 * 512 * m
+        roofline.update({"executed_mfma_flops_per_launch": executed,
+                         "executed_over_algorithmic": (executed / flops_per_launch) if executed else None})
         roofline.update({"traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_name,
                          "kernel_ms_avg": syrk_avg_ms, "reduce_kernel_ms_avg": red_avg_ms,
                          "flops_per_launch": flops_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch})
