@@ -18,8 +18,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "_lib")
 LIBNAME = "libfsnap_hip.so"
 SOURCES = ["fsnap_syrk.hip", "fsnap_rows.hip", "fsnap_chol.hip", "fsnap_trsm.hip", "fsnap_capi.cpp", "fsnap_comm.cpp",
-           "fsnap_rowspace.cpp", "fsnap_solve.cpp"]
-HEADERS = ["fsnap_kernels.h", "fsnap_device_common.h", "fsnap_ctx.h", os.path.join("..", "..", "include", "fsnap_hip.h")]
+           "fsnap_rowspace.cpp", "fsnap_rowspace_host.cpp", "fsnap_solve.cpp"]
+HEADERS = ["fsnap_kernels.h", "fsnap_device_common.h", "fsnap_ctx.h", "fsnap_rowspace_host.h", os.path.join("..", "..", "include", "fsnap_hip.h")]
 ARCH = "gfx950"
 
 
@@ -61,7 +61,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         cmd = [hipcc, *common]
         if src in ("fsnap_capi.cpp", "fsnap_comm.cpp", "fsnap_rowspace.cpp"):
             cmd += ["-x", "hip"]
-        if src == "fsnap_solve.cpp":
+        if src in ("fsnap_solve.cpp", "fsnap_rowspace_host.cpp"):
             # host-only K x K solve: plain C++ (no device pass), AVX2+FMA baseline with AVX-512
             # function clones resolved at load time
             cmd = [hipcc, "-x", "c++", "-O3", "-std=c++17", "-fPIC", "-mavx2", "-mfma",

@@ -35,267 +35,13 @@
 #include "fsnap_ctx.h"
 #include "fsnap_kernels.h"
 
-extern "C" int fsnap_host_chol_upper(double* a, int n, double* min_piv);   // fsnap_solve.cpp
+#include "fsnap_rowspace_host.h"
 
-namespace {
-
+using fsnap_rs::FactorSolver;
+using fsnap_rs::factor_pass;
+using fsnap_rs::finite_all;
+using fsnap_rs::gram_deviation;
 using vec = std::vector<double>;
-const double EPS = std::numeric_limits<double>::epsilon();
-
-bool finite_all(const double* p, size_t n) {
-    double t = 0.0;
-    for (size_t i = 0; i < n; ++i) t += p[i] * 0.0;
-    return t == 0.0;
-}
-
-// max |G_ij - delta_ij| over the columns with a non-zero diagonal entry: how far Q is from orthonormal columns
-double gram_deviation(int K, const double* G) {
-    double dev = 0.0;
-    for (int a = 0; a < K; ++a) {
-        if (!(G[(size_t)a * K + a] > 0.0)) continue;
-        for (int b = 0; b < K; ++b) {
-            if (!(G[(size_t)b * K + b] > 0.0)) continue;
-            dev = std::fmax(dev, std::fabs(G[(size_t)a * K + b] - (a == b ? 1.0 : 0.0)));
-        }
-    }
-    return dev;
-}
-
-// ---- pass factor --------------------------------------------------------------------------------------------------
-// G: K x K Gram matrix of the current Q.  Columns with G_jj == 0 are inactive (zero columns of A_w: coefficient 0, as
-// lstsq's minimum-norm solution gives them); their row / column of Rp is the unit vector and their diagonal entry of
-// R_hat is set to 0.  Returns the deviation max |G_ij - delta_ij| over the active columns in *dev; when dev <= tol
-// nothing is factorised (*converged = 1).  Otherwise Rp (K x K, upper) receives the factor to divide out and
-// R_hat <- Rp R_hat.  first = 1: R_hat is initialised to the identity (and the deviation is not a stopping criterion).
-int factor_pass(int K, const double* G, int first, double tol, double* Rhat, double* Rp, double* dev_out, int* converged,
-                double* shift_out) {
-    if (!finite_all(G, (size_t)K * K)) return FSNAP_NUM_NONFINITE;
-    std::vector<int> act;
-    act.reserve(K);
-    for (int j = 0; j < K; ++j)
-        if (G[(size_t)j * K + j] > 0.0) act.push_back(j);
-    const int n = (int)act.size();
-    if (first) {
-        std::fill(Rhat, Rhat + (size_t)K * K, 0.0);
-        for (int j : act) Rhat[(size_t)j * K + j] = 1.0;
-    }
-    const double dev = gram_deviation(K, G);
-    if (dev_out) *dev_out = dev;
-    if (converged) *converged = 0;
-    if (shift_out) *shift_out = 0.0;
-    if (!first && dev <= tol) {
-        if (converged) *converged = 1;
-        return FSNAP_OK;
-    }
-    // identity everywhere, then the active block
-    std::fill(Rp, Rp + (size_t)K * K, 0.0);
-    for (int j = 0; j < K; ++j) Rp[(size_t)j * K + j] = 1.0;
-    if (n == 0) return FSNAP_OK;
-    // Jacobi scaling d, scaled active block padded to a multiple of 32 with an identity (full-speed factorisation)
-    vec d(n);
-    for (int a = 0; a < n; ++a) d[a] = std::sqrt(G[(size_t)act[a] * K + act[a]]);
-    const int np = (n >= 48 && (n & 31)) ? ((n + 31) & ~31) : n;
-    vec S((size_t)np * np), U((size_t)np * np);
-    double fro = 0.0;
-    for (int a = 0; a < n; ++a)
-        for (int b = a; b < n; ++b) {
-            // symmetrise defensively; the GPU reduction mirrors the triangle exactly
-            const double g = 0.5 * (G[(size_t)act[a] * K + act[b]] + G[(size_t)act[b] * K + act[a]]) / (d[a] * d[b]);
-            S[(size_t)a * np + b] = (a == b) ? 1.0 : g;
-            fro += (a == b ? 1.0 : 2.0) * g * g;
-        }
-    for (int a = n; a < np; ++a) S[(size_t)a * np + a] = 1.0;
-    fro = std::sqrt(fro);
-    // shift: a few times the rounding level of the Gram matrix (Fukaya et al. 2020 use 11 (mK + K(K+1)) u ||A||^2; the
-    // fixed-order MFMA sums here are far below that worst case).  A failed factorisation retries with 100 x the shift.
-    double shift = 4.0 * (n + 100.0) * EPS * fro;
-    int fail = 0;
-    for (int attempt = 0; attempt < 10; ++attempt) {
-        U = S;
-        for (int a = 0; a < n; ++a) U[(size_t)a * np + a] += shift;
-        double mp = 0.0;
-        fail = fsnap_host_chol_upper(U.data(), np, &mp);
-        if (fail < 0 && finite_all(U.data(), U.size())) break;
-        fail = 1;
-        shift *= 100.0;
-    }
-    if (fail >= 0) return FSNAP_NUM_NOT_SPD;
-    if (shift_out) *shift_out = shift;
-    // Rp = U diag(d) on the active block
-    for (int a = 0; a < n; ++a)
-        for (int b = a; b < n; ++b) Rp[(size_t)act[a] * K + act[b]] = U[(size_t)a * np + b] * d[b];
-    // R_hat <- Rp R_hat (both upper triangular; inactive rows of R_hat are zero rows and stay so)
-    vec out((size_t)n * K, 0.0);
-    for (int a = 0; a < n; ++a) {
-        double* o = out.data() + (size_t)a * K;
-        for (int b = a; b < n; ++b) {
-            const double f = Rp[(size_t)act[a] * K + act[b]];
-            if (f == 0.0) continue;
-            const double* r = Rhat + (size_t)act[b] * K;
-            for (int c = act[b]; c < K; ++c) o[c] += f * r[c];
-        }
-    }
-    for (int a = 0; a < n; ++a) memcpy(Rhat + (size_t)act[a] * K, out.data() + (size_t)a * K, (size_t)K * sizeof(double));
-    return FSNAP_OK;
-}
-
-// ---- the K x K end of dgelsd ---------------------------------------------------------------------------------------
-struct FactorSolver {
-    int K = 0, n = 0, rank = 0;
-    std::vector<int> act;
-    bool triangular = false;   // no singular value can be below the cut: back substitution
-    vec T;                     // n x n active block of R_hat (row-major, upper)
-    vec W, J, s2;              // SVD form: rows of W = sigma_i v_i^T (n x n), J = U^T (n x n), s2 = sigma_i^2
-    std::vector<char> keep;
-    double smax = 0.0, smin = 0.0;
-    int sweeps = 0;
-
-    void prepare(int K_, const double* Rhat, double rcond) {
-        K = K_;
-        act.clear();
-        for (int j = 0; j < K; ++j)
-            if (Rhat[(size_t)j * K + j] != 0.0) act.push_back(j);
-        n = (int)act.size();
-        rank = 0;
-        T.assign((size_t)n * n, 0.0);
-        for (int a = 0; a < n; ++a)
-            for (int b = a; b < n; ++b) T[(size_t)a * n + b] = Rhat[(size_t)act[a] * K + act[b]];
-        if (n == 0) return;
-        // Frobenius bounds: sigma_max <= ||T||_F, sigma_min >= 1 / ||T^-1||_F.  If even these cannot put a singular
-        // value below rcond * sigma_max, dgelsd would not truncate either and its solution is T^-1 z.
-        double fro = 0.0;
-        for (double v : T) fro += v * v;
-        fro = std::sqrt(fro);
-        double inv2 = 0.0;
-        bool ok = true;
-        {
-            vec X((size_t)n * n, 0.0);     // X = T^-1 by back substitution, column by column of the identity
-            for (int c = n - 1; c >= 0 && ok; --c) {
-                // solve T x = e_c: x_c = 1 / T_cc, x_i = -(sum_{k>i} T_ik x_k) / T_ii for i < c
-                X[(size_t)c * n + c] = 1.0 / T[(size_t)c * n + c];
-                for (int i = c - 1; i >= 0; --i) {
-                    double s = 0.0;
-                    const double* ti = T.data() + (size_t)i * n;
-                    for (int k = i + 1; k <= c; ++k) s += ti[k] * X[(size_t)k * n + c];
-                    X[(size_t)i * n + c] = -s / ti[i];
-                }
-            }
-            for (double v : X) inv2 += v * v;
-            ok = std::isfinite(inv2);
-        }
-        const double rc = rcond > 0.0 ? rcond : 0.0;
-        triangular = ok && (fro * std::sqrt(inv2) * rc < 0.5);
-        if (triangular) {
-            rank = n;
-            smax = fro;
-            smin = 1.0 / std::sqrt(inv2);
-            return;
-        }
-        jacobi_svd(rc);
-    }
-
-    // one-sided Jacobi on the ROWS of W = T (left rotations): J T = diag(sigma) V^T with J orthogonal.  Rows instead of
-    // columns because T is upper triangular (the preconditioned orientation of Drmac & Veselic) and rows are contiguous.
-    void jacobi_svd(double rcond) {
-        W = T;
-        J.assign((size_t)n * n, 0.0);
-        for (int i = 0; i < n; ++i) J[(size_t)i * n + i] = 1.0;
-        const double tol = std::sqrt((double)n) * EPS;
-        auto dot = [&](const double* x, const double* y) {
-            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-            int k = 0;
-            for (; k + 4 <= n; k += 4) {
-                a0 += x[k] * y[k];
-                a1 += x[k + 1] * y[k + 1];
-                a2 += x[k + 2] * y[k + 2];
-                a3 += x[k + 3] * y[k + 3];
-            }
-            for (; k < n; ++k) a0 += x[k] * y[k];
-            return (a0 + a1) + (a2 + a3);
-        };
-        vec nrm(n);
-        for (sweeps = 0; sweeps < 60; ++sweeps) {
-            int rotated = 0;
-            for (int i = 0; i < n; ++i) nrm[i] = dot(W.data() + (size_t)i * n, W.data() + (size_t)i * n);
-            for (int p = 0; p < n - 1; ++p)
-                for (int q = p + 1; q < n; ++q) {
-                    double* wp = W.data() + (size_t)p * n;
-                    double* wq = W.data() + (size_t)q * n;
-                    const double al = nrm[p], be = nrm[q];
-                    if (al == 0.0 || be == 0.0) continue;
-                    const double ga = dot(wp, wq);
-                    if (std::fabs(ga) <= tol * std::sqrt(al) * std::sqrt(be)) continue;
-                    ++rotated;
-                    const double zeta = (be - al) / (2.0 * ga);
-                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
-                    const double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
-                    for (int k = 0; k < n; ++k) {
-                        const double a = wp[k], b = wq[k];
-                        wp[k] = c * a - s * b;
-                        wq[k] = s * a + c * b;
-                    }
-                    double* jp = J.data() + (size_t)p * n;
-                    double* jq = J.data() + (size_t)q * n;
-                    for (int k = 0; k < n; ++k) {
-                        const double a = jp[k], b = jq[k];
-                        jp[k] = c * a - s * b;
-                        jq[k] = s * a + c * b;
-                    }
-                    nrm[p] = dot(wp, wp);       // recomputed, not updated: graded rows lose digits in the update formula
-                    nrm[q] = dot(wq, wq);
-                }
-            if (!rotated) break;
-        }
-        s2.resize(n);
-        smax = 0.0;
-        for (int i = 0; i < n; ++i) {
-            s2[i] = dot(W.data() + (size_t)i * n, W.data() + (size_t)i * n);
-            smax = std::fmax(smax, s2[i]);
-        }
-        keep.assign(n, 0);
-        rank = 0;
-        smin = std::sqrt(smax);
-        const double cut2 = rcond * rcond * smax;      // sigma_i > rcond sigma_max  <=>  sigma_i^2 > rcond^2 sigma_max^2
-        for (int i = 0; i < n; ++i)
-            if (s2[i] > cut2 && s2[i] > 0.0) {
-                keep[i] = 1;
-                ++rank;
-                smin = std::fmin(smin, std::sqrt(s2[i]));
-            }
-        smax = std::sqrt(smax);
-    }
-
-    // beta (K entries, zeros in inactive columns) = pinv(R_hat) z
-    void apply(const double* z, double* beta) const {
-        for (int j = 0; j < K; ++j) beta[j] = 0.0;
-        if (n == 0) return;
-        vec y(n);
-        for (int a = 0; a < n; ++a) y[a] = z[act[a]];
-        if (triangular) {
-            for (int i = n - 1; i >= 0; --i) {
-                const double* ti = T.data() + (size_t)i * n;
-                double s = y[i];
-                for (int k = i + 1; k < n; ++k) s -= ti[k] * y[k];
-                y[i] = s / ti[i];
-            }
-            for (int a = 0; a < n; ++a) beta[act[a]] = y[a];
-            return;
-        }
-        vec x(n, 0.0);
-        for (int i = 0; i < n; ++i) {
-            if (!keep[i]) continue;
-            const double* ji = J.data() + (size_t)i * n;
-            double t = 0.0;
-            for (int k = 0; k < n; ++k) t += ji[k] * y[k];
-            const double f = t / s2[i];
-            const double* wi = W.data() + (size_t)i * n;
-            for (int k = 0; k < n; ++k) x[k] += f * wi[k];
-        }
-        for (int a = 0; a < n; ++a) beta[act[a]] = x[a];
-    }
-};
-
-}  // namespace
 
 namespace fsnap {
 

@@ -1,0 +1,293 @@
+// fsnap_rowspace_host.cpp — host (K x K) half of the row-space least-squares path: the factor of a CholeskyQR pass and
+// the K x K end of dgelsd (back substitution or one-sided Jacobi SVD of the accumulated triangular factor).  Plain C++
+// compiled with AVX2 + FMA like fsnap_solve.cpp (the Jacobi sweeps are dot products and plane rotations of contiguous
+// rows); the GPU orchestration is in fsnap_rowspace.cpp, the algorithm is described there.
+// Reference semantics: scipy.linalg.lstsq(aw, bw, 1.0e-13), fitsnap3lib/solvers/svd.py:54.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "../../include/fsnap_hip.h"
+#include "fsnap_rowspace_host.h"
+
+extern "C" int fsnap_host_chol_upper(double* a, int n, double* min_piv);   // fsnap_solve.cpp
+
+namespace fsnap_rs {
+
+using vec = std::vector<double>;
+static const double EPS = std::numeric_limits<double>::epsilon();
+
+bool finite_all(const double* p, size_t n) {
+    double t = 0.0;
+    for (size_t i = 0; i < n; ++i) t += p[i] * 0.0;
+    return t == 0.0;
+}
+
+// max |G_ij - delta_ij| over the columns with a non-zero diagonal entry: how far Q is from orthonormal columns
+double gram_deviation(int K, const double* G) {
+    double dev = 0.0;
+    for (int a = 0; a < K; ++a) {
+        if (!(G[(size_t)a * K + a] > 0.0)) continue;
+        for (int b = 0; b < K; ++b) {
+            if (!(G[(size_t)b * K + b] > 0.0)) continue;
+            dev = std::fmax(dev, std::fabs(G[(size_t)a * K + b] - (a == b ? 1.0 : 0.0)));
+        }
+    }
+    return dev;
+}
+
+// ---- pass factor --------------------------------------------------------------------------------------------------
+// G: K x K Gram matrix of the current Q.  Columns with G_jj == 0 are inactive (zero columns of A_w: coefficient 0, as
+// lstsq's minimum-norm solution gives them); their row / column of Rp is the unit vector and their diagonal entry of
+// R_hat is set to 0.  Returns the deviation max |G_ij - delta_ij| over the active columns in *dev; when dev <= tol
+// nothing is factorised (*converged = 1).  Otherwise Rp (K x K, upper) receives the factor to divide out and
+// R_hat <- Rp R_hat.  first = 1: R_hat is initialised to the identity (and the deviation is not a stopping criterion).
+int factor_pass(int K, const double* G, int first, double tol, double* Rhat, double* Rp, double* dev_out, int* converged,
+                double* shift_out) {
+    if (!finite_all(G, (size_t)K * K)) return FSNAP_NUM_NONFINITE;
+    std::vector<int> act;
+    act.reserve(K);
+    for (int j = 0; j < K; ++j)
+        if (G[(size_t)j * K + j] > 0.0) act.push_back(j);
+    const int n = (int)act.size();
+    if (first) {
+        std::fill(Rhat, Rhat + (size_t)K * K, 0.0);
+        for (int j : act) Rhat[(size_t)j * K + j] = 1.0;
+    }
+    const double dev = gram_deviation(K, G);
+    if (dev_out) *dev_out = dev;
+    if (converged) *converged = 0;
+    if (shift_out) *shift_out = 0.0;
+    if (!first && dev <= tol) {
+        if (converged) *converged = 1;
+        return FSNAP_OK;
+    }
+    // identity everywhere, then the active block
+    std::fill(Rp, Rp + (size_t)K * K, 0.0);
+    for (int j = 0; j < K; ++j) Rp[(size_t)j * K + j] = 1.0;
+    if (n == 0) return FSNAP_OK;
+    // Jacobi scaling d, scaled active block padded to a multiple of 32 with an identity (full-speed factorisation)
+    vec d(n);
+    for (int a = 0; a < n; ++a) d[a] = std::sqrt(G[(size_t)act[a] * K + act[a]]);
+    const int np = (n >= 48 && (n & 31)) ? ((n + 31) & ~31) : n;
+    vec S((size_t)np * np), U((size_t)np * np);
+    double fro = 0.0;
+    for (int a = 0; a < n; ++a)
+        for (int b = a; b < n; ++b) {
+            // symmetrise defensively; the GPU reduction mirrors the triangle exactly
+            const double g = 0.5 * (G[(size_t)act[a] * K + act[b]] + G[(size_t)act[b] * K + act[a]]) / (d[a] * d[b]);
+            S[(size_t)a * np + b] = (a == b) ? 1.0 : g;
+            fro += (a == b ? 1.0 : 2.0) * g * g;
+        }
+    for (int a = n; a < np; ++a) S[(size_t)a * np + a] = 1.0;
+    fro = std::sqrt(fro);
+    // shift: a few times the rounding level of the Gram matrix (Fukaya et al. 2020 use 11 (mK + K(K+1)) u ||A||^2; the
+    // fixed-order MFMA sums here are far below that worst case).  A failed factorisation retries with 100 x the shift.
+    double shift = 4.0 * (n + 100.0) * EPS * fro;
+    int fail = 0;
+    for (int attempt = 0; attempt < 10; ++attempt) {
+        U = S;
+        for (int a = 0; a < n; ++a) U[(size_t)a * np + a] += shift;
+        double mp = 0.0;
+        fail = fsnap_host_chol_upper(U.data(), np, &mp);
+        if (fail < 0 && finite_all(U.data(), U.size())) break;
+        fail = 1;
+        shift *= 100.0;
+    }
+    if (fail >= 0) return FSNAP_NUM_NOT_SPD;
+    if (shift_out) *shift_out = shift;
+    // Rp = U diag(d) on the active block
+    for (int a = 0; a < n; ++a)
+        for (int b = a; b < n; ++b) Rp[(size_t)act[a] * K + act[b]] = U[(size_t)a * np + b] * d[b];
+    // R_hat <- Rp R_hat (both upper triangular; inactive rows of R_hat are zero rows and stay so)
+    vec out((size_t)n * K, 0.0);
+    for (int a = 0; a < n; ++a) {
+        double* o = out.data() + (size_t)a * K;
+        for (int b = a; b < n; ++b) {
+            const double f = Rp[(size_t)act[a] * K + act[b]];
+            if (f == 0.0) continue;
+            const double* r = Rhat + (size_t)act[b] * K;
+            for (int c = act[b]; c < K; ++c) o[c] += f * r[c];
+        }
+    }
+    for (int a = 0; a < n; ++a) memcpy(Rhat + (size_t)act[a] * K, out.data() + (size_t)a * K, (size_t)K * sizeof(double));
+    return FSNAP_OK;
+}
+
+// ---- the K x K end of dgelsd ---------------------------------------------------------------------------------------
+void FactorSolver::prepare(int K_, const double* Rhat, double rcond) {
+        K = K_;
+        act.clear();
+        for (int j = 0; j < K; ++j)
+            if (Rhat[(size_t)j * K + j] != 0.0) act.push_back(j);
+        n = (int)act.size();
+        rank = 0;
+        T.assign((size_t)n * n, 0.0);
+        for (int a = 0; a < n; ++a)
+            for (int b = a; b < n; ++b) T[(size_t)a * n + b] = Rhat[(size_t)act[a] * K + act[b]];
+        if (n == 0) return;
+        // Frobenius bounds: sigma_max <= ||T||_F, sigma_min >= 1 / ||T^-1||_F.  If even these cannot put a singular
+        // value below rcond * sigma_max, dgelsd would not truncate either and its solution is T^-1 z.
+        double fro = 0.0;
+        for (double v : T) fro += v * v;
+        fro = std::sqrt(fro);
+        double inv2 = 0.0;
+        bool ok = true;
+        {
+            vec X((size_t)n * n, 0.0);     // X = T^-1 by back substitution, column by column of the identity
+            for (int c = n - 1; c >= 0 && ok; --c) {
+                // solve T x = e_c: x_c = 1 / T_cc, x_i = -(sum_{k>i} T_ik x_k) / T_ii for i < c
+                X[(size_t)c * n + c] = 1.0 / T[(size_t)c * n + c];
+                for (int i = c - 1; i >= 0; --i) {
+                    double s = 0.0;
+                    const double* ti = T.data() + (size_t)i * n;
+                    for (int k = i + 1; k <= c; ++k) s += ti[k] * X[(size_t)k * n + c];
+                    X[(size_t)i * n + c] = -s / ti[i];
+                }
+            }
+            for (double v : X) inv2 += v * v;
+            ok = std::isfinite(inv2);
+        }
+        const double rc = rcond > 0.0 ? rcond : 0.0;
+        triangular = ok && (fro * std::sqrt(inv2) * rc < 0.5);
+        if (triangular) {
+            rank = n;
+            smax = fro;
+            smin = 1.0 / std::sqrt(inv2);
+            return;
+        }
+        jacobi_svd(rc);
+    }
+
+    // one-sided Jacobi on the ROWS of W = T (left rotations): J T = diag(sigma) V^T with J orthogonal.  Rows instead of
+    // columns because T is upper triangular (the preconditioned orientation of Drmac & Veselic) and rows are contiguous.
+namespace {
+
+// 8-wide fp64 vectors (two ymm operations under -mavx2): the Jacobi sweeps are dot products and plane rotations of
+// contiguous rows
+typedef double v8 __attribute__((vector_size(64)));
+typedef double v8u __attribute__((vector_size(64), aligned(8)));
+
+inline double dot_rows(const double* __restrict__ x, const double* __restrict__ y, int n) {
+    v8 a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
+    int k = 0;
+    for (; k + 16 <= n; k += 16) {
+        a0 += *(const v8u*)(x + k) * *(const v8u*)(y + k);
+        a1 += *(const v8u*)(x + k + 8) * *(const v8u*)(y + k + 8);
+    }
+    const v8 a = a0 + a1;
+    double t = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    for (; k < n; ++k) t += x[k] * y[k];
+    return t;
+}
+
+// (p, q) <- (c p - s q, s p + c q) on two rows
+inline void rotate_rows(double* __restrict__ p, double* __restrict__ q, double c, double s, int n) {
+    const v8 cv = {c, c, c, c, c, c, c, c}, sv = {s, s, s, s, s, s, s, s};
+    int k = 0;
+    for (; k + 8 <= n; k += 8) {
+        const v8 a = *(const v8u*)(p + k), b = *(const v8u*)(q + k);
+        *(v8u*)(p + k) = cv * a - sv * b;
+        *(v8u*)(q + k) = sv * a + cv * b;
+    }
+    for (; k < n; ++k) {
+        const double a = p[k], b = q[k];
+        p[k] = c * a - s * b;
+        q[k] = s * a + c * b;
+    }
+}
+
+}  // namespace
+
+// one-sided Jacobi on the ROWS of W = T (left rotations): J T = diag(sigma) V^T with J orthogonal.  Rows instead of
+// columns because T is upper triangular (the preconditioned orientation of Drmac & Veselic) and rows are contiguous.
+// J is carried along in the same rows (W | J side by side: one rotation call covers both).
+void FactorSolver::jacobi_svd(double rcond) {
+    const int n2 = 2 * n;
+    vec WJ((size_t)n * n2, 0.0);
+    for (int i = 0; i < n; ++i) {
+        memcpy(WJ.data() + (size_t)i * n2, T.data() + (size_t)i * n, (size_t)n * sizeof(double));
+        WJ[(size_t)i * n2 + n + i] = 1.0;
+    }
+    const double tol = std::sqrt((double)n) * EPS;
+    vec nrm(n);
+    for (sweeps = 0; sweeps < 60; ++sweeps) {
+        int rotated = 0;
+        for (int i = 0; i < n; ++i) nrm[i] = dot_rows(WJ.data() + (size_t)i * n2, WJ.data() + (size_t)i * n2, n);
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                double* wp = WJ.data() + (size_t)p * n2;
+                double* wq = WJ.data() + (size_t)q * n2;
+                const double al = nrm[p], be = nrm[q];
+                if (al == 0.0 || be == 0.0) continue;
+                const double ga = dot_rows(wp, wq, n);
+                if (std::fabs(ga) <= tol * std::sqrt(al) * std::sqrt(be)) continue;
+                ++rotated;
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
+                rotate_rows(wp, wq, c, s, n2);
+                nrm[p] = dot_rows(wp, wp, n);       // recomputed, not updated: graded rows lose digits in the update formula
+                nrm[q] = dot_rows(wq, wq, n);
+            }
+        if (!rotated) break;
+    }
+    W.assign((size_t)n * n, 0.0);
+    J.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) {
+        memcpy(W.data() + (size_t)i * n, WJ.data() + (size_t)i * n2, (size_t)n * sizeof(double));
+        memcpy(J.data() + (size_t)i * n, WJ.data() + (size_t)i * n2 + n, (size_t)n * sizeof(double));
+    }
+    auto dot = [&](const double* x, const double* y) { return dot_rows(x, y, n); };
+    s2.resize(n);
+        smax = 0.0;
+        for (int i = 0; i < n; ++i) {
+            s2[i] = dot(W.data() + (size_t)i * n, W.data() + (size_t)i * n);
+            smax = std::fmax(smax, s2[i]);
+        }
+        keep.assign(n, 0);
+        rank = 0;
+        smin = std::sqrt(smax);
+        const double cut2 = rcond * rcond * smax;      // sigma_i > rcond sigma_max  <=>  sigma_i^2 > rcond^2 sigma_max^2
+        for (int i = 0; i < n; ++i)
+            if (s2[i] > cut2 && s2[i] > 0.0) {
+                keep[i] = 1;
+                ++rank;
+                smin = std::fmin(smin, std::sqrt(s2[i]));
+            }
+        smax = std::sqrt(smax);
+    }
+
+    // beta (K entries, zeros in inactive columns) = pinv(R_hat) z
+void FactorSolver::apply(const double* z, double* beta) const {
+        for (int j = 0; j < K; ++j) beta[j] = 0.0;
+        if (n == 0) return;
+        vec y(n);
+        for (int a = 0; a < n; ++a) y[a] = z[act[a]];
+        if (triangular) {
+            for (int i = n - 1; i >= 0; --i) {
+                const double* ti = T.data() + (size_t)i * n;
+                double s = y[i];
+                for (int k = i + 1; k < n; ++k) s -= ti[k] * y[k];
+                y[i] = s / ti[i];
+            }
+            for (int a = 0; a < n; ++a) beta[act[a]] = y[a];
+            return;
+        }
+        vec x(n, 0.0);
+        for (int i = 0; i < n; ++i) {
+            if (!keep[i]) continue;
+            const double* ji = J.data() + (size_t)i * n;
+            double t = 0.0;
+            for (int k = 0; k < n; ++k) t += ji[k] * y[k];
+            const double f = t / s2[i];
+            const double* wi = W.data() + (size_t)i * n;
+            for (int k = 0; k < n; ++k) x[k] += f * wi[k];
+        }
+        for (int a = 0; a < n; ++a) beta[act[a]] = x[a];
+    }
+
+}  // namespace fsnap_rs
+
