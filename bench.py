@@ -111,7 +111,7 @@ def kernel_source_digest():
 
 
 def recorded_traffic(m, Kc, info, kernel_name):
-    """HBM bytes per launch of the dominant kernel from the PMC passes (scripts/pmc_traffic.sh ->
+    """HBM bytes per launch of the dominant kernel from the PMC passes (scripts/pmc_traffic.py ->
     profiles/pmc_traffic.json) -- only if they were collected for THIS kernel source, shape and launch geometry;
     otherwise null (a regressed or re-tuned kernel must be re-measured, not inherit an old number)."""
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")

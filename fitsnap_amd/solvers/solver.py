@@ -455,23 +455,35 @@ class Solver:
         return np.array([N, NW, s_t.sum(), s_wt.sum(), rows[:, 4].sum(), rows[:, 5].sum(), sct, rows[:, 7].sum(),
                          rows[:, 8].sum(), scwt])
 
-    def _tables_from_sums(self, keys, st):
-        """(per-group table, *ALL table) of solver.py:391-405 from the (len(keys), 10) array of sums."""
-        from pandas import DataFrame, MultiIndex
+    _METRIC_COLUMNS = ("ncount", "mae", "rmse", "rsq", "w_ncount", "w_mae", "w_rmse", "w_rsq")
+
+    def _metric_arrays(self, keys, st):
+        """((len(keys), 8) per-group metrics, (n_all, 8) *ALL metrics) of solver.py:391-405 from the (len(keys), 10) array
+        of sums, columns as in ``_METRIC_COLUMNS``; what depends on the key list only (the two row indexes, the members
+        of every *ALL row) is built once per list and kept in ``_all_idx``."""
+        from pandas import MultiIndex
 
         st = np.asarray(st, dtype=np.float64).reshape(len(keys), 10)
-        # what depends on the key list only (the two row indexes, the members of every *ALL row) is built once per list
         if self._all_idx is None or self._all_idx[0] is not keys:
             subs = sorted({(k[1], k[2]) for k in keys})
             self._all_idx = (keys, [(tk, np.array([i for i, k in enumerate(keys) if (k[1], k[2]) == tk])) for tk in subs],
                              MultiIndex.from_tuples(keys, names=["Groups", "Testing", "Row_Type"]),
                              MultiIndex.from_tuples(subs, names=["Testing", "Row_Type"]))
-        grouped = DataFrame(self._metrics_from_sums(*(st[:, k] for k in range(10))), index=self._all_idx[2])
+        gm = self._metrics_from_sums(*(st[:, k] for k in range(10)))
         # *ALL rows: pool the groups of one (Testing, Row_Type)
-        sub = [tk for tk, _ in self._all_idx[1]]
-        pooled = np.array([self._pool_sums(st[idx]) for _, idx in self._all_idx[1]]).reshape(len(sub), 10)
-        allrows = DataFrame(self._metrics_from_sums(*(pooled[:, k] for k in range(10))), index=self._all_idx[3])
-        return grouped, allrows
+        pooled = np.array([self._pool_sums(st[idx]) for _, idx in self._all_idx[1]]).reshape(len(self._all_idx[1]), 10)
+        am = self._metrics_from_sums(*(pooled[:, k] for k in range(10)))
+        cols = self._METRIC_COLUMNS
+        return (np.column_stack([np.asarray(gm[c], dtype=np.float64) for c in cols]),
+                np.column_stack([np.asarray(am[c], dtype=np.float64) for c in cols]))
+
+    def _tables_from_sums(self, keys, st):
+        """(per-group table, *ALL table) of solver.py:391-405 from the (len(keys), 10) array of sums."""
+        from pandas import DataFrame
+
+        gm, am = self._metric_arrays(keys, st)
+        cols = list(self._METRIC_COLUMNS)
+        return DataFrame(gm, index=self._all_idx[2], columns=cols), DataFrame(am, index=self._all_idx[3], columns=cols)
 
     def _device_error_sums(self, a, b, w, shared, fs_dict):
         """(sorted group keys, (len(keys), 10) sums) of the rows of THIS rank from fsnap_error_stats."""
@@ -602,6 +614,12 @@ class Solver:
 
         if layout_key is not None:
             lay = self._err_layout
+            if isinstance(grouped, np.ndarray):
+                # metric arrays of a re-weighting loop whose layout is known: one gather, one DataFrame
+                vals = np.vstack([allrows, grouped])[lay[2]]
+                errors = DataFrame(np.where(lay[3][:, None], vals[:, 4:], vals[:, :4]), index=lay[1], columns=names)
+                errors.ncount = errors.ncount.astype(int)
+                return errors
             if lay is None or lay[0] is not layout_key or lay[4] != (len(allrows), len(grouped)):
                 # tags: source row (the *ALL rows first) in the unweighted columns, -(source row) - 1 in the weighted ones
                 na, ng = len(allrows), len(grouped)
@@ -716,7 +734,14 @@ class Solver:
             if not multi and self.device_error_stats:
                 # single GPU: the rows are resident -- predictions and the grouped reductions run on the GPU
                 # (fsnap_error_stats); only the (groups x 10) table of sums comes back
-                grouped, allrows = self._device_error_tables(a, b, w, shared, fs_dict)
+                keys, st = self._device_error_sums(a, b, w, shared, fs_dict)
+                lay = self._err_layout
+                if lay is not None and lay[0] is keys:
+                    grouped, allrows = self._metric_arrays(keys, st)        # layout known: no intermediate DataFrames
+                    if lay[4] != (len(allrows), len(grouped)):
+                        grouped, allrows = self._tables_from_sums(keys, st)
+                else:
+                    grouped, allrows = self._tables_from_sums(keys, st)
             else:
                 grouped, allrows = self._host_error_tables(self.df)
             layout_key = self._cat_cache[4] if (not multi and self.device_error_stats and self._cat_cache is not None) else None
