@@ -42,7 +42,7 @@ static Rccl* rccl() {
     const char* names[] = {getenv("FSNAP_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
         if (!n || !*n) continue;
-        r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);   // LOCAL: its symbols must not interpose on libraries loaded later (PyTorch)
         if (r.handle) break;
     }
     if (!r.handle) {

@@ -25,7 +25,8 @@ __global__ __launch_bounds__(64, FIRST ? 2 : 3) void fsnap_trsm_rows_k(const dou
                                                         const double* __restrict__ wpack, double* Q, int64_t ldq,
                                                         int64_t m, int K, const double* __restrict__ R, int K16) {
     __shared__ double X[64][17];                  // 64 rows x 16 columns of the current block (+1: no bank conflicts)
-    __shared__ double Rs[16][16];                 // diagonal block R_JJ (read by all lanes at the same address: broadcast)
+    __shared__ double Rs[16][32];                 // diagonal block R_JJ, zero-padded to 32 columns (read by all lanes at the same
+                                                  // address: a broadcast)
     const int lane = threadIdx.x, e = lane & 15, g = lane >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * 64;
     const int NB = K16 >> 4;
@@ -84,18 +85,28 @@ __global__ __launch_bounds__(64, FIRST ? 2 : 3) void fsnap_trsm_rows_k(const dou
                 X[lr][e] = x - acc[t][v];
             }
 #pragma unroll
-        for (int v = 0; v < 4; ++v) Rs[g + 4 * v][e] = R[(size_t)(jb * 16 + g + 4 * v) * K16 + col];
+        for (int v = 0; v < 4; ++v) {
+            Rs[g + 4 * v][e] = R[(size_t)(jb * 16 + g + 4 * v) * K16 + col];
+            Rs[g + 4 * v][16 + e] = 0.0;
+        }
         __syncthreads();
-        // one row per lane, in place in LDS: q_j = (x_j - sum_{i<j} q_i R[i][j]) / R[j][j] within the diagonal block
-        // (rolled loops: the 136 multipliers stay in LDS, the register footprint stays small enough for four waves
-        // per SIMD -- the kernel's latency hiding is its occupancy)
+        // one row per lane, right-looking: q_i = x_i / R[i][i], then x_j -= q_i R[i][j] for the columns right of it -- the
+        // 15 updates of a step are independent FMAs, only the division sits on the chain (a left-looking loop with its
+        // operands in LDS was a chain of 120 dependent FMAs, each behind two LDS reads: ~7 us per block).  The row stays
+        // in 16 registers; each step shifts it left by one while updating (x[t] = x[t+1] - q R[i][i+1+t]), so the pivot is
+        // always x[0] and the loop can stay rolled (fully unrolled, the compiler hoists all 120 broadcasts of R_JJ and
+        // spills); the zero padding of Rs makes the reads past column 15 harmless.
         {
-            double* xr = &X[lane][0];
+            double x[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) x[j] = X[lane][j];
 #pragma unroll 1
-            for (int j = 0; j < 16; ++j) {
-                double sacc = xr[j];
-                for (int i = 0; i < j; ++i) sacc = __builtin_fma(-xr[i], Rs[i][j], sacc);
-                xr[j] = sacc / Rs[j][j];
+            for (int i = 0; i < 16; ++i) {
+                const double q = x[0] / Rs[i][i];
+                X[lane][i] = q;
+                const double* rr = &Rs[i][i + 1];
+#pragma unroll
+                for (int t = 0; t < 15; ++t) x[t] = __builtin_fma(-q, rr[t], x[t + 1]);
             }
         }
         __syncthreads();

@@ -42,7 +42,7 @@ class SVD(Solver):
             self.last_row_space = None
             fit = self._fit_and_solve(_capi.SOLVE_LSTSQ, self.RCOND, a, b, w, fs_dict, trainall)
             K = len(fit)
-            on_gpu = pt.comm_kind != "torch" or not pt.multi
+            on_gpu = (pt.comm_kind != "torch" or not pt.multi) and (self._rows_on_device() or pt.multi)
             if self.row_space and on_gpu and self._needs_row_space(K):
                 # ill-conditioned or rank deficient: lstsq's answer lives in the rows, not in the K x K statistics
                 fit = self._row_space_fit(K, self.RCOND)

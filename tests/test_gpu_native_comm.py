@@ -159,3 +159,17 @@ def test_two_process_native_fit_matches_the_reference(tmp_path, ta, ta_fits):
     y = X @ r.standard_normal(K) + 1e-3 * r.standard_normal(mm)
     ref = orc.svd_fit(X, y, np.ones(mm))
     assert np.linalg.norm(r0["ill_fit"] - ref) <= 50 * 1e10 * np.finfo(float).eps * np.linalg.norm(ref)
+
+
+def test_process_exits_cleanly_when_rccl_is_loaded_before_torch():
+    # librccl is dlopen'ed RTLD_LOCAL: with RTLD_GLOBAL its symbols interposed on the libraries a LATER `import torch`
+    # maps, and the process died at exit with "double free or corruption" (exit status 134) although everything had worked
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from fitsnap_amd import _capi\n"
+        "c = _capi.HipContext(0); c.comm_init(1, 0, _capi.comm_id()); c.barrier(); c.close()\n"
+        "import torch\n"
+        "x = torch.ones(8, device='cuda'); assert float(x.sum()) == 8.0\n"
+        "print('done')\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "done" in out.stdout, (out.returncode, out.stderr[-1500:])
