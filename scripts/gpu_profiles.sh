@@ -8,13 +8,13 @@ O=$R/gpurun_out/${tag}_profiles
 mkdir -p $O
 export TMPDIR=/tmp
 cd $R
-python bench.py --steps 50 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
-python bench.py --no-cpu-baseline --rows 1000000 --cols 31 --steps 30 --warmup 3 > $O/bench_1000000x31.json 2>> $O/bench.err
-python bench.py --no-cpu-baseline --rows 15213 --cols 31 --steps 30 --warmup 3 > $O/bench_15213x31.json 2>> $O/bench.err
-python bench.py --no-cpu-baseline --rows 15213 --cols 1595 --steps 20 --warmup 3 --preheat 100 > $O/bench_15213x1595.json 2>> $O/bench.err
-python bench.py --no-cpu-baseline --rows 367900 --cols 480 --steps 20 --warmup 3 --preheat 100 > $O/bench_367900x480.json 2>> $O/bench.err
-python bench.py --no-cpu-baseline --rows 1772880 --cols 110 --steps 30 --warmup 3 --preheat 150 > $O/bench_1772880x110.json 2>> $O/bench.err
-python bench.py --no-cpu-baseline --rows 13035 --cols 142 --steps 30 --warmup 3 --preheat 150 > $O/bench_13035x142.json 2>> $O/bench.err
+timeout 300 python bench.py --steps 50 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+timeout 300 python bench.py --no-cpu-baseline --rows 1000000 --cols 31 --steps 30 --warmup 3 > $O/bench_1000000x31.json 2>> $O/bench.err
+timeout 300 python bench.py --no-cpu-baseline --rows 15213 --cols 31 --steps 30 --warmup 3 > $O/bench_15213x31.json 2>> $O/bench.err
+timeout 300 python bench.py --no-cpu-baseline --rows 15213 --cols 1595 --steps 20 --warmup 3 --preheat 100 > $O/bench_15213x1595.json 2>> $O/bench.err
+timeout 300 python bench.py --no-cpu-baseline --rows 367900 --cols 480 --steps 20 --warmup 3 --preheat 100 > $O/bench_367900x480.json 2>> $O/bench.err
+timeout 300 python bench.py --no-cpu-baseline --rows 1772880 --cols 110 --steps 30 --warmup 3 --preheat 150 > $O/bench_1772880x110.json 2>> $O/bench.err
+timeout 300 python bench.py --no-cpu-baseline --rows 13035 --cols 142 --steps 30 --warmup 3 --preheat 150 > $O/bench_13035x142.json 2>> $O/bench.err
 timeout 200 python scripts/chol_large_test.py 2>&1 | grep "K=" > $O/chol_large_k_sweep.txt; cat $O/chol_large_k_sweep.txt
 timeout 300 python scripts/ga_loop_timing.py > $O/ga_loop.txt 2>&1; cat $O/ga_loop.txt
 cd /tmp
