@@ -8,7 +8,7 @@
 // orthonormal columns and A_w = Q R_hat to working precision for kappa up to ~1/eps (shifted CholeskyQR3, Fukaya et
 // al. 2020); the host then treats the K x K factor R_hat exactly as dgelsd treats its R (fsnap_rowspace.cpp).
 //
-// Kernel 13  fsnap_trsm_rows_k   one wave per 64 rows; column blocks of 16 in ascending order:
+// Kernel 13  fsnap_trsm_rows_k   (K > 128) one wave per 64 rows; column blocks of 16 in ascending order, left-looking:
 //     S_J = X_J - sum_{I<J} Q_I R_IJ      fp64 MFMA (v_mfma_f64_16x16x4_f64), A operand = the solved blocks of Q,
 //                                         read back from global memory (L1 / L2), B operand = R (L2-resident)
 //     Q_J = S_J R_JJ^-1                   true substitution (not a multiplication by an inverse: the backward error
@@ -123,6 +123,130 @@ __global__ __launch_bounds__(64, FIRST ? 2 : 3) void fsnap_trsm_rows_k(const dou
     }
 }
 
+// Kernel 13A (K <= 128, the default there): the same pass RIGHT-LOOKING with the wave's whole 64 x K row tile in the
+// accumulation registers (NB x 4 tiles of 16 x 16 = up to 256 registers, one wave per SIMD -- kernel 1A's register plan).
+// Kernel 13 above is left-looking: block J gathers the contributions of all solved blocks, which it re-reads from global
+// memory -- a wave's 64 KB of solved blocks once per later block, and the 256 resident waves of an XCD hold 16 MB of
+// them, four times its L2: 1.75-2.0 ms per pass at 10^6 x 128.  Here a solved block Q_J is applied to ALL later blocks
+// at once, X_L -= Q_J R_JL, straight from the LDS copy that the substitution produced (16 operand reads per block,
+// reused for every L); a row of A is read from HBM once, a row of Q written once, nothing is re-read.
+// LDS hand-off inside ONE wave (the workgroup of kernel 13A is a single wave): the LDS queue of a wave is in order, so a
+// read sees the wave's earlier writes -- only the compiler must not reorder them.  __syncthreads() would also wait for
+// the block's global STORES (s_waitcnt vmcnt(0)): ~4 us per column block with nothing else on the SIMD to run.
+__device__ __forceinline__ void trsm_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int NB, bool FIRST>
+__global__ __launch_bounds__(64, 1) void fsnap_trsm_acc_k(const double* __restrict__ src, int64_t lds_,
+                                                          const double* __restrict__ wpack, double* Q, int64_t ldq,
+                                                          int64_t m, int K, const double* __restrict__ R) {
+    constexpr int K16 = 16 * NB;
+    constexpr int RLD = K16 + 36;                 // row stride of the staged row block of R: even (16-byte row bases), >= 31
+                                                  // readable entries behind the last block's 16 columns, and the four k rows
+                                                  // of a B operand land on different banks
+    __shared__ double X[64][17];
+    __shared__ __attribute__((aligned(16))) double Rblk[16][RLD];   // rows 16 J .. 16 J + 15 of R from the diagonal block on
+    __shared__ double Rinv[16];                   // reciprocals of the diagonal of R_JJ: the division leaves the 16-step chain
+    const int lane = threadIdx.x, e = lane & 15, g = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    d4 acc[NB][4];
+    // the whole row tile, in the accumulator layout (tile rows g + 4 v, column e): 16 lanes read 128 contiguous bytes
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int J = 0; J < NB; ++J)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int64_t r = row0 + t * 16 + g + 4 * v;
+                const int col = J * 16 + e;
+                double x = 0.0;
+                if (r < m && col < K) x = FIRST ? src[r * lds_ + col] : Q[r * ldq + col];
+                acc[J][t][v] = x;
+            }
+    // first pass: the row weights commute with the solve, diag(w) (A R^-1) = (diag(w) A) R^-1 -- the rows are solved as
+    // they come and scaled when they are stored (no second copy of the tile while the loads are in flight); a zero weight
+    // stores a zero row whatever A holds (NaN in masked rows is legal input)
+    double wgt[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int64_t r = row0 + t * 16 + g + 4 * v;
+            wgt[t][v] = (FIRST && r < m) ? wpack[2 * r] : 1.0;
+        }
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+        const int col = J * 16 + e;
+        // block J -> LDS (row-per-lane layout for the substitution), with its diagonal block of R
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) X[t * 16 + g + 4 * v][e] = acc[J][t][v];
+        trsm_wave_sync();
+        // rows 16 J .. 16 J + 15 of R, from the diagonal block to the last column, straight into LDS: one asynchronous
+        // global_load_lds per row (lane l carries 16 bytes to row base + 16 l), no registers, all 16 in flight together.
+        // (Staged through registers, the compiler -- at 360+ live registers -- issued these ~20 loads one at a time,
+        // each behind a full s_waitcnt: ~12 us per column block, 60 % of the kernel's 1.5 ms.)
+        {
+            const int ncol = K16 - J * 16;
+            if (2 * lane < ncol) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(R + (size_t)(J * 16 + i) * K16 + J * 16 + 2 * lane),
+                        (__attribute__((address_space(3))) void*)&Rblk[i][0], 16, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the row block (and, in the first round, the row tile) has landed
+        trsm_wave_sync();
+        if (lane < 16) Rinv[lane] = 1.0 / Rblk[lane][lane];
+        trsm_wave_sync();
+        {
+            double x[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) x[j] = X[lane][j];
+#pragma unroll 1
+            for (int i = 0; i < 16; ++i) {
+                const double q = x[0] * Rinv[i];
+                X[lane][i] = q;
+                const double* rr = &Rblk[i][i + 1];
+#pragma unroll
+                for (int t = 0; t < 15; ++t) x[t] = __builtin_fma(-q, rr[t], x[t + 1]);
+            }
+        }
+        trsm_wave_sync();
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int64_t r = row0 + t * 16 + g + 4 * v;
+                if (r < m && col < K) {
+                    const double q = X[t * 16 + g + 4 * v][e];
+                    Q[r * ldq + col] = FIRST ? ((wgt[t][v] != 0.0) ? wgt[t][v] * q : 0.0) : q;
+                }
+            }
+        if (J + 1 < NB) {
+            // X_L -= Q_J R_JL for every later block: A operand (Q_J)[i = e][k = 4 s + g] from LDS, B operand R[k][j = e]
+            double af[4][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int sk = 0; sk < 4; ++sk) af[t][sk] = -X[t * 16 + e][4 * sk + g];
+#pragma unroll
+            for (int L = J + 1; L < NB; ++L)
+#pragma unroll
+                for (int sk = 0; sk < 4; ++sk) {
+                    const double bf = Rblk[4 * sk + g][(L - J) * 16 + e];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[L][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t][sk], bf, acc[L][t], 0, 0, 0);
+                }
+        }
+        trsm_wave_sync();    // X and Rs are reused by the next block
+    }
+}
+
 // per-row pairs for the SYRK kernels on Q: first component = "row takes part" (zero rows are skipped by the loads),
 // second = w_eff b, so that the kernels' c output is Q^T (w b)
 __global__ __launch_bounds__(256) void fsnap_qpack_k(const double* __restrict__ wpack, int64_t m, double* __restrict__ qpack) {
@@ -142,6 +266,22 @@ hipError_t launch_trsm_rows(const double* src, int64_t lds, const double* wpack,
                             const double* R, int K16, hipStream_t st) {
     const int64_t nb = (m + 63) / 64;
     if (nb > 0x7FFFFFFF) return hipErrorInvalidValue;
+    if (K16 <= 128) {
+        // kernel 13A: whole row tile in the accumulation registers
+        const dim3 grid((unsigned)nb), block(64);
+#define FSNAP_TRSM_ACC(NBV)                                                                                                  \
+    case NBV:                                                                                                                \
+        if (wpack) hipLaunchKernelGGL((fsnap_trsm_acc_k<NBV, true>), grid, block, 0, st, src, lds, wpack, Q, ldq, m, K, R);    \
+        else hipLaunchKernelGGL((fsnap_trsm_acc_k<NBV, false>), grid, block, 0, st, src, lds, wpack, Q, ldq, m, K, R);         \
+        break;
+        switch (K16 / 16) {
+            FSNAP_TRSM_ACC(1) FSNAP_TRSM_ACC(2) FSNAP_TRSM_ACC(3) FSNAP_TRSM_ACC(4)
+            FSNAP_TRSM_ACC(5) FSNAP_TRSM_ACC(6) FSNAP_TRSM_ACC(7) FSNAP_TRSM_ACC(8)
+            default: return hipErrorInvalidValue;
+        }
+#undef FSNAP_TRSM_ACC
+        return hipGetLastError();
+    }
     if (wpack)
         hipLaunchKernelGGL(fsnap_trsm_rows_k<true>, dim3((unsigned)nb), dim3(64), 0, st, src, lds, wpack, Q, ldq, m, K, R, K16);
     else
