@@ -9,11 +9,11 @@ falling back to this code.
 Pinning: every function below is checked in ``tests/test_oracle_golden.py`` against
 golden vectors produced by importing the *reference itself* in the build container
 (``tests/golden/make_golden.py`` -> ``tests/golden/ta_reference_fits.npz``) and against
-the reference's committed ``Ta_pot.snapcoeff`` / ``Ta_metrics.md``.  ARD is the one
-exception: the reference's ARD class does not run on scikit-learn >= 1.5
-(``n_iter=`` keyword, fitsnap3lib/solvers/ard.py:40-45) and no reference test pins its
-output, so ``ard_fit`` is **parity unpinned** beyond vectors captured from a direct
-scikit-learn call.
+the reference's committed ``Ta_pot.snapcoeff`` / ``Ta_metrics.md``.  ARD: the reference's class passes
+``n_iter=`` to ARDRegression (fitsnap3lib/solvers/ard.py:40-45), a keyword scikit-learn renamed to ``max_iter`` (1.3)
+and removed (1.5), so the golden generator runs the class with that one keyword forwarded under its new name and
+``ard_fit`` is pinned bit-for-bit to those vectors (all rows / testing mask / directmethod / non-default scap, scai,
+logcut / apply_transpose).  No test or fixture of the reference itself holds an ARD output.
 
 Reference citations are file:line into FitSNAP/FitSNAP (/root/reference at build time).
 """
@@ -140,12 +140,17 @@ def ard_hyper(bw, scap=1.0e-3, scai=1.0e-3, logcut=0.3):
 
 
 def ard_fit(a, b, w, testing=None, directmethod=False, alphabig=1.0e-12, lambdasmall=1.0e-6,
-            threshold_lambda=100000, scap=1.0e-3, scai=1.0e-3, logcut=0.3, max_iter=1000):
-    """fitsnap3lib/solvers/ard.py:18-48 with ``n_iter`` spelled ``max_iter`` (PARITY
-    UNPINNED, see module docstring).  Third-party arithmetic: scikit-learn ARDRegression."""
+            threshold_lambda=100000, scap=1.0e-3, scai=1.0e-3, logcut=0.3, max_iter=1000, apply_transpose=False):
+    """fitsnap3lib/solvers/ard.py:18-48 with ``n_iter`` spelled ``max_iter`` (scikit-learn renamed the keyword in 1.3
+    and dropped the old name in 1.5).  Pinned bit-for-bit by tests/test_oracle_golden.py to vectors produced by the
+    reference CLASS run with that one keyword forwarded (tests/golden/make_golden.py).  Third-party arithmetic:
+    scikit-learn ARDRegression."""
     from sklearn.linear_model import ARDRegression
 
     aw, bw = weight_rows(a, b, w, testing)
+    if apply_transpose:                                            # ard.py:22-24
+        bw = aw.T @ bw
+        aw = aw.T @ aw
     if directmethod:
         reg = ARDRegression(max_iter=max_iter, threshold_lambda=threshold_lambda, alpha_1=alphabig,
                             alpha_2=alphabig, lambda_1=lambdasmall, lambda_2=lambdasmall, fit_intercept=False)

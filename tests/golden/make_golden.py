@@ -191,6 +191,47 @@ def main():
         out["ard_all"] = reg.coef_.copy()
     except Exception as e:  # pragma: no cover
         print("ARD capture failed:", e)
+    # ARD through the REFERENCE CLASS (ard.py:15-49).  The class spells ARDRegression's iteration cap `n_iter`, a
+    # keyword scikit-learn renamed to `max_iter` in 1.3 and dropped in 1.5; the constructor the reference module sees
+    # is therefore the installed one with that single keyword forwarded under its new name.  Everything else -- the
+    # training mask, the row weighting, apply_transpose, the inverse-variance recipe for alpha/lambda/threshold_lambda,
+    # the directmethod branch -- is the reference's own code running.
+    try:
+        import fitsnap3lib.solvers.ard as ref_ard
+        from sklearn.linear_model import ARDRegression as _ARDRegression
+
+        def ard_with_renamed_keyword(n_iter=300, **kw):
+            return _ARDRegression(max_iter=n_iter, **kw)
+
+        ref_ard.ARDRegression = ard_with_renamed_keyword
+
+        def run_ard(extra, mask):
+            pt = ParallelTools()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                # the reference only builds config.sections['ARD'] when the input has an [ARD] section
+                ext = {"ARD": {"directmethod": 0}}
+                for k, v in (extra or {}).items():
+                    ext.setdefault(k, {}).update(v)
+                cfg = Config(pt, settings("ARD", ext), arguments_lst=["--overwrite"])
+            s = solver_factory.solver("ARD", pt, cfg)
+            pt.create_shared_array('a', m, K)
+            pt.create_shared_array('b', m)
+            pt.create_shared_array('w', m)
+            pt.shared_arrays['a'].array[:] = A
+            pt.shared_arrays['b'].array[:] = b
+            pt.shared_arrays['w'].array[:] = w
+            pt.fitsnap_dict['Testing'] = testing.tolist() if mask else [False] * m
+            s.perform_fit()
+            return np.asarray(s.fit, dtype=np.float64).copy()
+
+        out["ard_class_all"] = run_ard(None, False)
+        out["ard_class_mask"] = run_ard(None, True)
+        out["ard_class_direct"] = run_ard({"ARD": {"directmethod": 1}}, False)
+        out["ard_class_scaled"] = run_ard({"ARD": {"scap": 1.0e-2, "scai": 1.0e-4, "logcut": 1.0}}, True)
+        out["ard_class_transpose"] = run_ard({"EXTRAS": {"apply_transpose": 1}}, False)
+    except Exception as e:  # pragma: no cover
+        print("ARD reference-class run failed:", repr(e))
     np.savez_compressed(os.path.join(HERE, "ta_reference_fits.npz"), **out)
     np.savez_compressed(os.path.join(HERE, "ta_abw.npz"), A=A, b=b, w=w)
 

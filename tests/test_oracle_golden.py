@@ -2,6 +2,8 @@
 itself (tests/golden/ta_reference_fits.npz, produced by tests/golden/make_golden.py which
 imports /root/reference) and against the reference's committed Ta_pot.snapcoeff /
 Ta_metrics.md."""
+import warnings
+
 import numpy as np
 import pytest
 
@@ -82,12 +84,31 @@ def test_second_golden_set_xyz(ta):
 
 
 def test_ard_captured_vector(ta, ta_fits):
-    # parity UNPINNED against the reference class (it cannot run on sklearn >= 1.5); this pins
-    # the oracle to the vector captured from the direct scikit-learn call
+    # the direct scikit-learn call with the reference's recipe (captured before the class itself could be run)
     A, b, w = ta
     fit = orc.ard_fit(A, b, w, scap=1e-3, scai=1e-3, logcut=0.3)
-    assert np.array_equal(fit != 0, ta_fits["ard_all"] != 0)
-    assert maxrel(fit[fit != 0], ta_fits["ard_all"][fit != 0]) < 1e-9
+    assert np.array_equal(fit, ta_fits["ard_all"])
+    assert np.array_equal(ta_fits["ard_all"], ta_fits["ard_class_all"])
+
+
+@pytest.mark.parametrize("key,kw", [
+    ("ard_class_all", {}),
+    ("ard_class_mask", {"mask": True}),
+    ("ard_class_direct", {"directmethod": True}),
+    ("ard_class_scaled", {"mask": True, "scap": 1.0e-2, "scai": 1.0e-4, "logcut": 1.0}),
+    ("ard_class_transpose", {"apply_transpose": True}),
+])
+def test_ard_matches_the_reference_class(ta, ta_fits, key, kw):
+    # vectors from the reference's ARD class itself (ard.py:15-49), run by make_golden.py with ARDRegression's renamed
+    # iteration keyword forwarded; same scikit-learn here, so the restatement must reproduce them bit for bit
+    A, b, w = ta
+    kw = dict(kw)
+    testing = ta_fits["testing_mask"] if kw.pop("mask", False) else None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                             # the transposed Ta problem never converges
+        fit = orc.ard_fit(A, b, w, testing, **kw)
+    assert np.array_equal(fit, ta_fits[key])
+    assert 20 <= np.count_nonzero(fit) <= 31
 
 
 def test_synthetic_generator_is_deterministic():
