@@ -127,6 +127,9 @@ def load_library(build_if_missing: bool = True):
     global _lib
     if _lib is not None:
         return _lib
+    # multi-process GPU work (RCCL) shares buffers through dmabuf IPC; the legacy IPC mode is not supported by the
+    # host driver of the MI355X boxes (hipIpcGetMemHandle: invalid argument).  Must be set before the HSA runtime starts
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     _preload_torch_hip_runtime()
     path = _build.lib_path()
     if build_if_missing:
