@@ -12,5 +12,5 @@ timeout 300 python bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/benc
 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 python bench.py --force-dist --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_dist1.json 2> $out/bench_dist1.err; echo "bench dist rc=$?"
 timeout 300 python bench.py --steps 20 --warmup 5 --no-repack --no-cpu-baseline > $out/bench_norepack.json 2>> $out/bench.err
 head -c 1500 $out/bench.json; echo; head -c 600 $out/bench_dist1.json; echo
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/$out/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$out/rocprof.err)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/$out/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$out/rocprof.err)
 ls $out/prof 2>/dev/null | head
