@@ -250,17 +250,21 @@ __device__ __forceinline__ double rsqrt_newton(double d) {
 
 // 8b: ONE wave factorises the 64 x 64 diagonal block as a 4 x 4 grid of 16 x 16 blocks held in registers in the
 // MFMA accumulator layout (lane (k, e): rows 4r + k, column e of a block).  Per block step a:
-//   * the diagonal block goes through LDS into a column-per-lane layout and is factorised by the 16-step
-//     recurrence (pivot row entries broadcast with v_readlane; v_rsq_f64 + Newton instead of IEEE sqrt / divide),
-//     then inverted by back substitution in the same layout (Y_a = U_aa^-1, needed by kernels 8c and 8e);
-//   * U_ab = Y_a^T S_ab for the blocks right of it and S_bc -= U_ab^T U_ac for the blocks below: MFMAs whose operands
+//   * the 16 x 16 diagonal block is factorised WHERE IT IS: pivot j of the block sits in register j / 4 of the lanes
+//     with k = j % 4, and so does the whole pivot row -- which is exactly where an MFMA reads the k-slot j % 4 of BOTH
+//     operands.  The rank-1 update of a pivot is therefore ONE MFMA whose operands are the wave's own registers
+//     (A: the scaled row for the columns right of the pivot, zero elsewhere; B: the scaled row; the other three
+//     k-slots zero): no transpose through LDS, no broadcast of multipliers (the scalar recurrence it replaces took
+//     2 v_readlane + 1 FMA per multiplier: 360 such groups per block).  Only the pivot itself is broadcast
+//     (v_readlane), then v_rsq_f64 + Newton instead of IEEE sqrt / divide.
+//   * the same row operations applied to an identity block give Z = U_aa^-T (forward substitution on I), one more
+//     MFMA per pivot: the inverse Y_a = Z^T that kernels 8c and 8e need comes out of the same loop (it used to be a
+//     second 16-step recurrence, a third of the kernel's time);
+//   * U_ab = Z S_ab for the blocks right of it and S_bc -= U_ab^T U_ac for the blocks below: MFMAs whose operands
 //     are the accumulator registers themselves (the layout of a D tile is the layout of the B operand of k-step r
 //     and, transposed, of the A operand).
-// The scalar recurrence over all 64 columns (2016 broadcast + FMA groups, 9.7 k instructions, 22 us per block) was
-// half of the whole device solve; here 4 x 120 groups remain and the rest is 64 MFMAs.
-// The next multiplier is read before the FMA of the current one and a scheduling barrier closes every (readlane,
-// readlane, fma) group: left alone, the scheduler hoists all broadcasts of a step, runs out of scalar registers and
-// spills them through v_writelane.
+// History: scalar recurrence over all 64 columns 22 us per block; 16-column recurrences + MFMA 16.4 us; this form:
+// see DESIGN 4.
 // single-wave synchronisation of LDS traffic (kernel 8b runs in ONE wave, also when that wave is part of a larger
 // workgroup -- the fused update + diagonal kernel -- where s_barrier would wait for waves that are not coming)
 __device__ __forceinline__ void chol_wave_sync() {
@@ -272,75 +276,46 @@ template <int a>
 __device__ __forceinline__ void chol_diag_step(d4 (&B)[4][4], double (*T)[17], double (*UT)[16], double* __restrict__ S,
                                                int ld, int jb, double* __restrict__ Y, int e, int kr, double& pmin,
                                                double& psum) {
-    // diagonal block -> column e in every lane (the four lane groups hold identical copies)
-    chol_wave_sync();
+    (void)UT;
+    d4& D = B[a][a];
+    d4 Z;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) T[4 * r + kr][e] = B[a][a][r];
-    chol_wave_sync();
-    double col[16], rinv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) col[r] = T[r][e];
+    for (int r = 0; r < 4; ++r) Z[r] = (4 * r + kr == e) ? 1.0 : 0.0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const double d = readlane_f64(col[j], j);          // pivot (the same value in every lane)
+        const int q = j >> 2, k = j & 3;
+        const double d = readlane_f64(D[q], k * 16 + j);   // pivot (the same value in every lane)
         pmin = d < pmin ? d : pmin;                        // (a NaN pivot is caught by the sum)
         psum += d;
         const double inv = rsqrt_newton(d);
-        rinv[j] = inv;
-        col[j] = (e == j) ? d * inv : col[j] * inv;
-        if (j + 1 < 16) {
-            double f = readlane_f64(col[j], j + 1);
-#pragma unroll
-            for (int i = j + 1; i < 16; ++i) {
-                const double fn = (i + 1 < 16) ? readlane_f64(col[j], i + 1) : 0.0;
-                col[i] = __builtin_fma(-f, col[j], col[i]);    // S[i][e] -= U[j][i] * U[j][e]
-                __builtin_amdgcn_sched_barrier(0);
-                f = fn;
-            }
+        const bool own = (kr == k);                        // the lanes that hold row j
+        const double ud = D[q] * inv;                      // U[j][e] (e >= j; e == j: d / sqrt(d))
+        const double zd = Z[q] * inv;                      // (U^-T)[j][e]
+        const bool keep = own && e >= j;
+        D[q] = keep ? ud : D[q];                           // the strictly lower part keeps its (finite) input values
+        Z[q] = own ? zd : Z[q];
+        if (j < 15) {
+            const double aop = (own && e > j) ? -ud : 0.0;  // A[i][k] = -U[j][i] for the rows i > j
+            const double bop = keep ? ud : 0.0;             // B[k][e] = U[j][e]
+            const double zop = own ? zd : 0.0;
+            D = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, D, 0, 0, 0);     // S[i][e] -= U[j][i] U[j][e]
+            Z = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, zop, Z, 0, 0, 0);     // Z[i][e] -= U[j][i] Z[j][e]
         }
     }
-    if (kr == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (e >= r) S[(size_t)(jb + 16 * a + r) * ld + jb + 16 * a + e] = col[r];
-            UT[e][r] = col[r];                              // UT[k][r] = U[r][k]: the multipliers of step k, contiguous
-        }
-    }
+    for (int r = 0; r < 4; ++r)
+        if (e >= 4 * r + kr) S[(size_t)(jb + 16 * a + 4 * r + kr) * ld + jb + 16 * a + e] = D[r];
+    // Y_a = Z^T in the accumulator layout = the A operand of Z S_ab: through LDS
     chol_wave_sync();
-    // Y_a = U_aa^-1: lane e solves U y = e_e by back substitution.  The multipliers U[0..k-1][k] of step k are the
-    // same for every lane and do not depend on y: they are read from LDS one step ahead.
-    double y[16], mcur[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) y[r] = 0.0;
+    for (int r = 0; r < 4; ++r) T[4 * r + kr][e] = Z[r];
+    chol_wave_sync();
+    double yt[4];
 #pragma unroll
-    for (int r = 0; r < 15; ++r) mcur[r] = UT[15][r];
+    for (int s = 0; s < 4; ++s) yt[s] = T[e][4 * s + kr];               // Z[e][4 s + kr] = Y_a[4 s + kr][e]
 #pragma unroll
-    for (int k = 15; k >= 0; --k) {
-        double mnext[16];
-#pragma unroll
-        for (int r = 0; r + 1 < k; ++r) mnext[r] = UT[k - 1][r];
-        const double yk = ((k == e) ? 1.0 : y[k]) * rinv[k];
-        y[k] = yk;
-#pragma unroll
-        for (int r = 0; r < k; ++r) y[r] = __builtin_fma(-mcur[r], yk, y[r]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r + 1 < k; ++r) mcur[r] = mnext[r];
-    }
-    if (kr == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Y[(a * 16 + r) * 16 + e] = y[r];
-    }
+    for (int s = 0; s < 4; ++s) Y[(a * 16 + 4 * s + kr) * 16 + e] = yt[s];
     if constexpr (a < 3) {
-        // A operand of the substitution: (Y_a^T)[e][4 s + kr] = Y_a[4 s + kr][e], through LDS
-        if (kr == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) T[r][e] = y[r];
-        }
-        chol_wave_sync();
-        double yt[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) yt[s] = T[4 * s + kr][e];
 #pragma unroll
         for (int b = a + 1; b < 4; ++b) {
             d4 u = {0.0, 0.0, 0.0, 0.0};

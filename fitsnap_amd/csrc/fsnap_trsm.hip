@@ -176,9 +176,19 @@ __global__ __launch_bounds__(64, 1) void fsnap_trsm_acc_k(const double* __restri
             const int64_t r = row0 + t * 16 + g + 4 * v;
             wgt[t][v] = (FIRST && r < m) ? wpack[2 * r] : 1.0;
         }
+    double qst[4][4];                 // the block solved last, waiting for its stores
+    auto store_block = [&](int Jb) {
+        const int col = Jb * 16 + e;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int64_t r = row0 + t * 16 + g + 4 * v;
+                if (r < m && col < K) Q[r * ldq + col] = FIRST ? ((wgt[t][v] != 0.0) ? wgt[t][v] * qst[t][v] : 0.0) : qst[t][v];
+            }
+    };
 #pragma unroll
     for (int J = 0; J < NB; ++J) {
-        const int col = J * 16 + e;
         // block J -> LDS (row-per-lane layout for the substitution), with its diagonal block of R
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -200,33 +210,46 @@ __global__ __launch_bounds__(64, 1) void fsnap_trsm_acc_k(const double* __restri
             }
         }
         __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the row block (and, in the first round, the row tile) has landed
+        if (J > 0) store_block(J - 1);
         trsm_wave_sync();
         if (lane < 16) Rinv[lane] = 1.0 / Rblk[lane][lane];
         trsm_wave_sync();
         {
-            double x[16];
+            // two steps per trip, the multipliers of a step read from LDS one step ahead (the wave is alone on its SIMD:
+            // an LDS round trip inside the 16-step chain is paid in full)
+            double x[16], ra[15], rb[15];
 #pragma unroll
             for (int j = 0; j < 16; ++j) x[j] = X[lane][j];
-#pragma unroll 1
-            for (int i = 0; i < 16; ++i) {
-                const double q = x[0] * Rinv[i];
-                X[lane][i] = q;
-                const double* rr = &Rblk[i][i + 1];
 #pragma unroll
-                for (int t = 0; t < 15; ++t) x[t] = __builtin_fma(-q, rr[t], x[t + 1]);
+            for (int t = 0; t < 15; ++t) ra[t] = Rblk[0][1 + t];
+            double ia = Rinv[0];
+#pragma unroll 1
+            for (int i = 0; i < 16; i += 2) {
+                const double ib = Rinv[i + 1];
+#pragma unroll
+                for (int t = 0; t < 15; ++t) rb[t] = Rblk[i + 1][i + 2 + t];
+                double q = x[0] * ia;
+                X[lane][i] = q;
+#pragma unroll
+                for (int t = 0; t < 15; ++t) x[t] = __builtin_fma(-q, ra[t], x[t + 1]);
+                const int in = (i + 2) & 15;          // (the last trip reads row 0 again: in range, unused)
+                ia = Rinv[in];
+#pragma unroll
+                for (int t = 0; t < 15; ++t) ra[t] = Rblk[in][in + 1 + t];
+                q = x[0] * ib;
+                X[lane][i + 1] = q;
+#pragma unroll
+                for (int t = 0; t < 15; ++t) x[t] = __builtin_fma(-q, rb[t], x[t + 1]);
             }
         }
         trsm_wave_sync();
+        // the solved block back in the accumulator layout; its stores are issued one block LATE (right after the next
+        // block's staging wait): s_waitcnt vmcnt(0) also waits for stores, and with the stores issued just before it
+        // every block paid a full write round trip (PMC: 47 k of 182 k cycles per wave in s_waitcnt)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int64_t r = row0 + t * 16 + g + 4 * v;
-                if (r < m && col < K) {
-                    const double q = X[t * 16 + g + 4 * v][e];
-                    Q[r * ldq + col] = FIRST ? ((wgt[t][v] != 0.0) ? wgt[t][v] * q : 0.0) : q;
-                }
-            }
+            for (int v = 0; v < 4; ++v) qst[t][v] = X[t * 16 + g + 4 * v][e];
         if (J + 1 < NB) {
             // X_L -= Q_J R_JL for every later block: A operand (Q_J)[i = e][k = 4 s + g] from LDS, B operand R[k][j = e]
             double af[4][4];
@@ -245,6 +268,7 @@ __global__ __launch_bounds__(64, 1) void fsnap_trsm_acc_k(const double* __restri
         }
         trsm_wave_sync();    // X and Rs are reused by the next block
     }
+    store_block(NB - 1);
 }
 
 // per-row pairs for the SYRK kernels on Q: first component = "row takes part" (zero rows are skipped by the loads),

@@ -1,0 +1,140 @@
+// lat_bench.hip — single-wave instruction latencies on gfx950, in shader cycles (s_memtime) and wall-clock ticks.
+// The serial kernels of the device Cholesky (fsnap_chol.hip) run ONE wave through long dependent chains; this tool
+// measures what a link of such a chain costs: dependent / independent fp64 FMAs, v_rsq_f64, dependent fp64 MFMAs,
+// an MFMA whose result is broadcast with v_readlane into the next MFMA's operand (the pivot pattern), selects.
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/lat_bench tools/lat_bench.hip ; run: tools/lat_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int N = 256;
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k(double* out, const double* in, long long* cyc, long long* wall) {
+    const int lane = threadIdx.x;
+    double x = in[lane], y = in[lane + 64], z = in[lane + 128], w = in[lane + 192];
+    d4 acc = {x, y, z, w}, acc2 = {y, z, w, x};
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(x), "+v"(y), "+v"(z), "+v"(w)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const long long t0 = clock64(), w0 = wall_clock64();
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x), "+v"(y), "+v"(z), "+v"(acc), "+v"(acc2)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (MODE == 0) {          // dependent v_fma_f64
+#pragma unroll
+        for (int i = 0; i < N; ++i) x = __builtin_fma(x, y, z);
+    } else if constexpr (MODE == 1) {   // four independent v_fma_f64 chains
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i) {
+            x = __builtin_fma(x, y, z);
+            acc[0] = __builtin_fma(acc[0], y, z);
+            acc[1] = __builtin_fma(acc[1], y, z);
+            acc[2] = __builtin_fma(acc[2], y, z);
+        }
+    } else if constexpr (MODE == 2) {   // dependent v_rsq_f64
+#pragma unroll
+        for (int i = 0; i < N; ++i) x = __builtin_amdgcn_rsq(x);
+    } else if constexpr (MODE == 3) {   // dependent MFMA (accumulator chain)
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y, z, acc, 0, 0, 0);
+    } else if constexpr (MODE == 4) {   // two independent MFMA chains
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y, z, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, z, acc2, 0, 0, 0);
+        }
+    } else if constexpr (MODE == 5) {   // MFMA -> readlane of the result -> one multiply -> operand of the next MFMA
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double d = readlane_f64(acc[i & 3], (i * 17) & 63);
+            const double a = y * d;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, z, acc, 0, 0, 0);
+        }
+    } else if constexpr (MODE == 6) {   // the whole pivot link: readlane, rsq + 3 Newton steps, scale, select, MFMA
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double d = readlane_f64(acc[i & 3], (i * 17) & 63);
+            double r = __builtin_amdgcn_rsq(d);
+            const double h = 0.5 * d;
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const double e = __builtin_fma(-h * r, r, 0.5);
+                r = __builtin_fma(r, e, r);
+            }
+            const double u = acc[i & 3] * r;
+            const bool own = ((lane >> 4) == (i & 3));
+            acc[i & 3] = own ? u : acc[i & 3];
+            const double a = (own && (lane & 15) > (i & 15)) ? -u : 0.0;
+            const double b = own ? u : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+    } else if constexpr (MODE == 7) {   // dependent 64-bit selects
+#pragma unroll
+        for (int i = 0; i < N; ++i) x = ((lane + i) & 1) ? x : y + x;
+    } else if constexpr (MODE == 8) {   // readlane -> VALU -> readlane chain
+#pragma unroll
+        for (int i = 0; i < N; ++i) x = x + readlane_f64(x, (i * 17) & 63);
+    } else if constexpr (MODE == 9) {   // the pivot link with the MFMA replaced by nothing (VALU part alone)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double d = readlane_f64(x, (i * 17) & 63);
+            double r = __builtin_amdgcn_rsq(d);
+            const double h = 0.5 * d;
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const double e = __builtin_fma(-h * r, r, 0.5);
+                r = __builtin_fma(r, e, r);
+            }
+            x = x * r + y;
+        }
+    }
+    asm volatile("s_nop 0" : "+v"(x), "+v"(acc), "+v"(acc2)::"memory");     // the results exist here
+    __builtin_amdgcn_sched_barrier(0);
+    const long long t1 = clock64(), w1 = wall_clock64();
+    __builtin_amdgcn_sched_barrier(0);
+    out[lane] = x + acc[0] + acc[1] + acc[2] + acc[3] + acc2[0];
+    if (lane == 0) {
+        cyc[MODE] = t1 - t0;
+        wall[MODE] = w1 - w0;
+    }
+}
+
+int main() {
+    double *in, *out;
+    long long *cyc, *wall;
+    hipMalloc(&in, 256 * 8);
+    hipMalloc(&out, 64 * 8);
+    hipMalloc(&cyc, 16 * 8);
+    hipMalloc(&wall, 16 * 8);
+    double h[256];
+    for (int i = 0; i < 256; ++i) h[i] = 1.0 + 1e-3 * i;
+    hipMemcpy(in, h, sizeof h, hipMemcpyHostToDevice);
+    const char* names[] = {"dependent v_fma_f64", "4 independent v_fma_f64", "dependent v_rsq_f64", "dependent MFMA f64 16x16x4",
+                           "2 independent MFMA chains", "MFMA -> readlane -> mul -> MFMA", "full pivot link (rsq + Newton + selects + MFMA)",
+                           "dependent 64-bit select + add", "readlane -> add chain", "pivot link without the MFMA"};
+    for (int rep = 0; rep < 3; ++rep) {
+        k<0><<<1, 64>>>(out, in, cyc, wall);
+        k<1><<<1, 64>>>(out, in, cyc, wall);
+        k<2><<<1, 64>>>(out, in, cyc, wall);
+        k<3><<<1, 64>>>(out, in, cyc, wall);
+        k<4><<<1, 64>>>(out, in, cyc, wall);
+        k<5><<<1, 64>>>(out, in, cyc, wall);
+        k<6><<<1, 64>>>(out, in, cyc, wall);
+        k<7><<<1, 64>>>(out, in, cyc, wall);
+        k<8><<<1, 64>>>(out, in, cyc, wall);
+        k<9><<<1, 64>>>(out, in, cyc, wall);
+        hipDeviceSynchronize();
+    }
+    long long hc[16], hw[16];
+    hipMemcpy(hc, cyc, sizeof hc, hipMemcpyDeviceToHost);
+    hipMemcpy(hw, wall, sizeof hw, hipMemcpyDeviceToHost);
+    for (int m = 0; m < 10; ++m)
+        printf("%-52s %8.1f s_memtime ticks / link   %7.1f ns / link (100 MHz wall clock)\n", names[m], (double)hc[m] / N,
+               (double)hw[m] * 10.0 / N);
+    return 0;
+}
