@@ -47,6 +47,19 @@ namespace fsnap {
 
 struct RowSpace {
     DevBuf Q, qpack, Rdev, packed, rvec, dz, dzpart, beta;
+    // page-locked staging for what crosses PCIe every pass: the K x K statistics down, the factor up (from pageable
+    // memory each of these copies went through the runtime's own staging, ~40 us apiece)
+    double* pin = nullptr;
+    size_t pin_doubles = 0;
+    bool pin_ensure(size_t n) {
+        if (n <= pin_doubles) return true;
+        if (pin) (void)hipHostFree(pin);
+        pin = nullptr;
+        pin_doubles = 0;
+        if (hipHostMalloc((void**)&pin, n * sizeof(double), hipHostMallocDefault) != hipSuccess) return false;
+        pin_doubles = n;
+        return true;
+    }
 };
 
 void rowspace_release(fsnap_ctx* ctx) {
@@ -54,6 +67,7 @@ void rowspace_release(fsnap_ctx* ctx) {
     RowSpace* rs = ctx->rowspace;
     DevBuf* bufs[] = {&rs->Q, &rs->qpack, &rs->Rdev, &rs->packed, &rs->rvec, &rs->dz, &rs->dzpart, &rs->beta};
     for (DevBuf* b : bufs) b->release();
+    if (rs->pin) (void)hipHostFree(rs->pin);
     delete rs;
     ctx->rowspace = nullptr;
 }
@@ -110,7 +124,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
     fsnap::RowSpace* rs = ctx->rowspace;
     const size_t m = have_rows ? (size_t)ctx->m : 0;
     if (!rs->packed.ensure((size_t)npk * 8) || !rs->Rdev.ensure((size_t)K16 * K16 * 8) || !rs->beta.ensure((size_t)K * 8) ||
-        !rs->dz.ensure((size_t)K * 8))
+        !rs->dz.ensure((size_t)K * 8) || !rs->pin_ensure((size_t)npk + (size_t)K16 * K16 + 2 * (size_t)K))
         return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(row-space workspace) failed");
     if (have_rows) {
         const int nbt = fsnap::gemvT_num_blocks(ctx->m);
@@ -122,7 +136,10 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
     double* dQ = (double*)rs->Q.p;
     hipStream_t st = ctx->stream;
     int rc;
-    vec host((size_t)npk), Rhat((size_t)K * K), Rp((size_t)K * K), Rpad((size_t)K16 * K16), z((size_t)K);
+    vec Rhat((size_t)K * K), Rp((size_t)K * K), z((size_t)K);
+    double* const host = rs->pin;                        // [npk] statistics of the current Q
+    double* const Rpad = rs->pin + npk;                  // [K16 x K16] padded factor of the pass
+    double* const hvec = Rpad + (size_t)K16 * K16;       // [2 K] beta up, Q^T r down
 
     // statistics of the current Q (pass 0: of A_w), summed over the ranks, on the host
     auto gather_stats = [&](bool of_rows) -> int {
@@ -136,7 +153,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
             int r3 = fsnap_allreduce_device(ctx, dp, npk);
             if (r3) return r3;
         }
-        FSNAP_HIP(hipMemcpyAsync(host.data(), dp, (size_t)npk * 8, hipMemcpyDeviceToHost, st), "hipMemcpy(statistics)");
+        FSNAP_HIP(hipMemcpyAsync(host, dp, (size_t)npk * 8, hipMemcpyDeviceToHost, st), "hipMemcpy(statistics)");
         FSNAP_HIP(hipStreamSynchronize(st), "hipStreamSynchronize");
         return FSNAP_OK;
     };
@@ -152,17 +169,17 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
     double dev = 0.0, shift = 0.0;
     for (int pass = 1; pass <= maxpass; ++pass) {
         int conv = 0;
-        rc = factor_pass(K, host.data(), pass == 1, tol, Rhat.data(), Rp.data(), &dev, &conv, &shift);
+        rc = factor_pass(K, host, pass == 1, tol, Rhat.data(), Rp.data(), &dev, &conv, &shift);
         if (rc) return ctx->fail(rc, "row-space pass %d: the Gram matrix could not be factorised (status %d)", pass, rc);
         if (conv) {
             converged = 1;
             break;
         }
         // padded copy of the factor for the kernel
-        std::fill(Rpad.begin(), Rpad.end(), 0.0);
+        std::fill(Rpad, Rpad + (size_t)K16 * K16, 0.0);
         for (int i = 0; i < K16; ++i) Rpad[(size_t)i * K16 + i] = 1.0;
-        for (int i = 0; i < K; ++i) memcpy(Rpad.data() + (size_t)i * K16 + i, Rp.data() + (size_t)i * K + i, (size_t)(K - i) * 8);
-        FSNAP_HIP(hipMemcpyAsync(rs->Rdev.p, Rpad.data(), Rpad.size() * 8, hipMemcpyHostToDevice, st), "hipMemcpy(R)");
+        for (int i = 0; i < K; ++i) memcpy(Rpad + (size_t)i * K16 + i, Rp.data() + (size_t)i * K + i, (size_t)(K - i) * 8);
+        FSNAP_HIP(hipMemcpyAsync(rs->Rdev.p, Rpad, (size_t)K16 * K16 * 8, hipMemcpyHostToDevice, st), "hipMemcpy(R)");
         if (have_rows) {
             if (pass == 1)
                 FSNAP_HIP(fsnap::launch_trsm_rows(ctx->dA, ctx->lda, (const double*)ctx->wpack.p, dQ, K, ctx->m, K,
@@ -174,12 +191,12 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
         FSNAP_HIP(hipStreamSynchronize(st), "hipStreamSynchronize");      // Rpad is reused by the next pass
         passes = pass;
         if ((rc = gather_stats(false))) return rc;
-        memcpy(z.data(), host.data() + (size_t)K * K, (size_t)K * 8);     // z = Q^T (w b)
+        memcpy(z.data(), host + (size_t)K * K, (size_t)K * 8);     // z = Q^T (w b)
     }
     if (!converged) {
         // pass budget used up: judge the last Q as it is (the refinement step below absorbs what is left)
-        if (!finite_all(host.data(), (size_t)K * K)) return ctx->fail(FSNAP_NUM_NONFINITE, "row-space solve: non-finite Gram matrix");
-        dev = gram_deviation(K, host.data());
+        if (!finite_all(host, (size_t)K * K)) return ctx->fail(FSNAP_NUM_NONFINITE, "row-space solve: non-finite Gram matrix");
+        dev = gram_deviation(K, host);
         converged = dev <= tol;
     }
     if (passes == 0) return ctx->fail(FSNAP_E_STATE, "row-space solve made no pass");
@@ -194,13 +211,15 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
         vec dzh((size_t)K, 0.0), dbeta((size_t)K);
         if (have_rows) {
             const unsigned char* mask = ctx->dmask;
-            FSNAP_HIP(hipMemcpyAsync(rs->beta.p, beta, (size_t)K * 8, hipMemcpyHostToDevice, st), "hipMemcpy(beta)");
+            memcpy(hvec, beta, (size_t)K * 8);
+            FSNAP_HIP(hipMemcpyAsync(rs->beta.p, hvec, (size_t)K * 8, hipMemcpyHostToDevice, st), "hipMemcpy(beta)");
             FSNAP_HIP(fsnap::launch_gemv_rows(ctx->dA, ctx->lda, (const double*)rs->beta.p, ctx->m, K, nullptr, ctx->db, ctx->dw,
                                               mask, nullptr, (double*)rs->rvec.p, st, true), "launch fsnap_gemv_rows_k");
             FSNAP_HIP(fsnap::launch_gemvT_rows(dQ, K, (const double*)rs->rvec.p, ctx->m, K, (double*)rs->dzpart.p,
                                                (double*)rs->dz.p, st), "launch fsnap_gemvT_rows_k");
-            FSNAP_HIP(hipMemcpyAsync(dzh.data(), rs->dz.p, (size_t)K * 8, hipMemcpyDeviceToHost, st), "hipMemcpy(dz)");
+            FSNAP_HIP(hipMemcpyAsync(hvec + K, rs->dz.p, (size_t)K * 8, hipMemcpyDeviceToHost, st), "hipMemcpy(dz)");
             FSNAP_HIP(hipStreamSynchronize(st), "hipStreamSynchronize");
+            memcpy(dzh.data(), hvec + K, (size_t)K * 8);
         }
         if (nranks > 1 && (rc = fsnap_allreduce_host(ctx, dzh.data(), K, 0))) return rc;
         if (finite_all(dzh.data(), dzh.size())) {

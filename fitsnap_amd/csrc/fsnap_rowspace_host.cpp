@@ -136,16 +136,21 @@ void FactorSolver::prepare(int K_, const double* Rhat, double rcond) {
         double inv2 = 0.0;
         bool ok = true;
         {
-            vec X((size_t)n * n, 0.0);     // X = T^-1 by back substitution, column by column of the identity
-            for (int c = n - 1; c >= 0 && ok; --c) {
-                // solve T x = e_c: x_c = 1 / T_cc, x_i = -(sum_{k>i} T_ik x_k) / T_ii for i < c
-                X[(size_t)c * n + c] = 1.0 / T[(size_t)c * n + c];
-                for (int i = c - 1; i >= 0; --i) {
-                    double s = 0.0;
-                    const double* ti = T.data() + (size_t)i * n;
-                    for (int k = i + 1; k <= c; ++k) s += ti[k] * X[(size_t)k * n + c];
-                    X[(size_t)i * n + c] = -s / ti[i];
+            // X = T^-1 by back substitution, row by row from the bottom: X_i = (e_i - sum_{k>i} T_ik X_k) / T_ii -- every
+            // update is an axpy of contiguous rows (the column-by-column form walked X with stride n: 0.4 ms at n = 128)
+            vec X((size_t)n * n, 0.0);
+            for (int i = n - 1; i >= 0 && ok; --i) {
+                double* __restrict__ xi = X.data() + (size_t)i * n;
+                const double* ti = T.data() + (size_t)i * n;
+                xi[i] = 1.0;
+                for (int k = i + 1; k < n; ++k) {
+                    const double f = ti[k];
+                    if (f == 0.0) continue;
+                    const double* __restrict__ xk = X.data() + (size_t)k * n;
+                    for (int c = k; c < n; ++c) xi[c] -= f * xk[c];
                 }
+                const double inv = 1.0 / ti[i];
+                for (int c = i; c < n; ++c) xi[c] *= inv;
             }
             for (double v : X) inv2 += v * v;
             ok = std::isfinite(inv2);
