@@ -83,6 +83,7 @@ SIGNATURES = {
     "fsnap_rowspace_solve": (c_int, [c_int64, c_void_p, c_void_p, c_double, c_void_p, POINTER(c_int), c_void_p]),
     "fsnap_timing": (c_int, [c_void_p, _P_D, c_int]),
     "fsnap_timing_history": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
+    "fsnap_timing_count": (c_int, [c_void_p, c_void_p, c_void_p]),
     "fsnap_launch_info": (c_int, [c_void_p, POINTER(c_int64), c_int]),
 }
 
@@ -577,6 +578,12 @@ class HipContext:
         b = np.empty(int(n))
         self._check(self._lib.fsnap_timing_history(self._h, _ptr(a), _ptr(b), int(n)))
         return a, b
+
+    def timing_count(self):
+        """(event-bracketed SYRK launches, all SYRK launches) of this context so far (option ``timing_every``)."""
+        a, b = c_int64(0), c_int64(0)
+        self._check(self._lib.fsnap_timing_count(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
 
     def launch_info(self):
         info = (c_int64 * 8)()

@@ -72,7 +72,10 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * general-K tiled kernel also for K <= 128), "nsplit" (row splits of the tiled kernel), "mirror" (0|1, see fsnap_normal_eq_resident), "xcd" (0|1: tiled kernel deals contiguous work-item ranges to each XCD), "tiled2" (0|1: K > 128 on the one-wave-per-SIMD kernel with 64 x 128-column work items, default 0),
  * "device_solve" (fsnap_solve_device: 0 = auto: K >= 384 is factorised on the GPU by the blocked kernels; 1 = every K on the GPU; 2 = never),
  * "repack" (1 = recompute the packed per-row weights (mask * w, mask * w * b) and the b-only scalars on EVERY fit even
- * when b, w and the mask are context-owned and unchanged; default 0 = once per fsnap_set_weights / fsnap_upload_rows).
+ * when b, w and the mask are context-owned and unchanged; default 0 = once per fsnap_set_weights / fsnap_upload_rows),
+ * "timing_every" (N: HIP events bracket every N-th SYRK launch only -- an event record between two dependent kernels idles
+ * the stream for ~5.6 us; 0 = no events, default 1 = every launch; the first launch after the option is set is a sampled one; fsnap_timing /
+ * fsnap_timing_history see the sampled ones).
  * Unknown key -> FSNAP_E_ARG. */
 int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value);
 
@@ -332,10 +335,15 @@ int fsnap_dev_download(fsnap_ctx* ctx, void* h_dst, const void* d_src, int64_t n
  * Synchronises the context's stream.  n = number of entries of ms to fill (<= 8). */
 int fsnap_timing(fsnap_ctx* ctx, double* ms, int n);
 
-/* Kernel times (ms) of the last n fits launched on this context, oldest first (n <= 256): syrk_ms[i] = SYRK kernel,
+/* Kernel times (ms) of the last n event-bracketed fits (option "timing_every") of this context, oldest first (n <= 256): syrk_ms[i] = SYRK kernel,
  * reduce_ms[i] (may be NULL) = partial reduction.  HIP events on the kernels' stream, read after the fact, so a
  * timed loop does not have to synchronise for its measurements.  Synchronises the context's stream. */
 int fsnap_timing_history(fsnap_ctx* ctx, double* syrk_ms, double* reduce_ms, int n);
+
+/* How many SYRK launches this context has made (*launches) and how many of them were bracketed by events (*sampled:
+ * what fsnap_timing_history can return); either pointer may be NULL.  Measurement plumbing of bench.py, no reference
+ * counterpart. */
+int fsnap_timing_count(fsnap_ctx* ctx, int64_t* sampled, int64_t* launches);
 
 /* Launch geometry of the SYRK kernel for the current rows: info[0] = workgroups,
  * info[1] = threads per workgroup, info[2] = 4-row chunks per row-wave (kernel 1) / per
