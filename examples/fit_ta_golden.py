@@ -23,6 +23,7 @@ A, b, w = d["A"], d["b"], d["w"]
 ref = np.load(os.path.join(ROOT, "tests", "golden", "ta_reference_fits.npz"))
 
 pt = ParallelTools()                                        # one process, one GPU ("stubs" mode of the reference)
+pt.hip().set_option("timing_every", 1)                      # bracket every kernel launch with events (off by default)
 for name, extra, key in (("SVD", {}, "svd_all"), ("RIDGE", {"RIDGE": {"alpha": 1e-8}}, "ridge_sklearn_1e-8_all")):
     cfg = Config(pt, {"SOLVER": {"solver": name}, **extra})
     solver = solver_factory.solver(name, pt, cfg)

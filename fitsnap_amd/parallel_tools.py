@@ -484,6 +484,12 @@ class ParallelTools:
             from . import _capi
 
             self._hip = _capi.HipContext(self.device_index())
+            # kernel timing events off in the fit loop (an event record between two dependent kernels idles the stream
+            # for ~5.6 us: a third of a Ta-sized fit); FSNAP_KERNEL_TIMING=1 or ctx.set_option("timing_every", 1) turns
+            # them back on for diagnostics (ctx.timing())
+            import os
+
+            self._hip.set_option("timing_every", 1 if os.environ.get("FSNAP_KERNEL_TIMING", "0") not in ("", "0") else 0)
         return self._hip
 
     # -- shared arrays (parallel_tools.py:338-424) ----------------------------------------
