@@ -376,8 +376,15 @@ int launch_normal_eq_tiled(fsnap_ctx* ctx, double* d_packed, bool accumulate) {
     a.cpart = (double*)ctx->cpart.p;
     a.spart = (const double*)ctx->wpack_spart.p;
     a.ns = npk;
-    // waves of off-diagonal pairs never write their c slots: zero them once
-    FSNAP_HIP(hipMemsetAsync(a.cpart, 0, (size_t)g.nsplit * g.NSB * 4 * 64 * sizeof(double), ctx->stream), "hipMemsetAsync");
+    // every c slot (split, superblock, wave) is rewritten by the diagonal pair of its split on every launch (also by
+    // waves whose row range is empty: they store zeros), so the buffer is cleared only when its geometry changes -- a
+    // memset per fit was a 4 us kernel plus a stream boundary in front of a 27 us SYRK at the ACE shape 13 035 x 142
+    const int64_t cpart_key = ((int64_t)g.nsplit << 32) | (int64_t)g.NSB;
+    if (ctx->cpart_key != cpart_key || ctx->cpart_ptr != ctx->cpart.p) {
+        FSNAP_HIP(hipMemsetAsync(a.cpart, 0, (size_t)g.nsplit * g.NSB * 4 * 64 * sizeof(double), ctx->stream), "hipMemsetAsync");
+        ctx->cpart_key = cpart_key;
+        ctx->cpart_ptr = ctx->cpart.p;
+    }
     hipEvent_t* evs;
     if ((rc = fit_events(ctx, &evs))) return rc;
     if (evs) FSNAP_HIP(hipEventRecord(evs[0], ctx->stream), "hipEventRecord");
@@ -1202,6 +1209,9 @@ int fsnap_fit_resident(fsnap_ctx* ctx, int kind, double param, double* beta, int
     int rc = fsnap_normal_eq_resident(ctx, &dp);
     if (rc) return rc;
     if (d_packed) *d_packed = dp;
+    // 128 < K < 384 (tiled kernel, host factorisation): a copy kernel fills the page-locked mirror the host solve polls
+    // -- the D2H copy it replaces cost 10 us of launch latency + 7.7 us on the ACE shape (13 035 x 142: 95 us per fit)
+    if (ctx->mirror_of != dp && ctx->K > 128 && ctx->K < 384 && (rc = fsnap_mirror_packed(ctx, dp, ctx->K))) return rc;
     return fsnap_solve_device_rhs(ctx, kind, param, ctx->K, dp, nullptr, beta, rank, rcond_est);
 }
 

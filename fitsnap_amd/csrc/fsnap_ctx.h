@@ -52,6 +52,8 @@ struct fsnap_ctx {
     hipEvent_t ev[10] = {};
     static constexpr int RING = 256;              // event triples of the last RING fits (fsnap_timing_history)
     hipEvent_t ring[RING][3] = {};
+    int64_t cpart_key = -1;                       // geometry the tiled kernel's c partials were last cleared for
+    const void* cpart_ptr = nullptr;
     int64_t nlaunch = 0;                          // SYRK launches so far (sampled ones: nfit)
     int64_t timing_phase = 0;                     // launches since the option was last set
     int opt_timing_every = 1;                     // bracket every N-th SYRK launch with events (0: none)
