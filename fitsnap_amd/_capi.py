@@ -57,6 +57,8 @@ SIGNATURES = {
     "fsnap_predict": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fsnap_residual_rhs": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double)]),
     "fsnap_solve": (c_int, [c_int, c_double, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int), POINTER(c_double)]),
+    "fsnap_lasso_gram": (c_int, [c_int64, c_void_p, c_void_p, c_double, c_double, c_int64, c_double, c_void_p,
+                                 POINTER(c_int64), POINTER(c_double)]),
     "fsnap_normal_eq_accumulate": (c_int, [c_void_p, c_void_p]),
     "fsnap_error_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "fsnap_solve_device": (c_int, [c_void_p, c_int, c_double, c_int64, c_void_p, c_void_p, POINTER(c_int), POINTER(c_double)]),
@@ -195,6 +197,27 @@ def solve(kind: int, param: float, G: np.ndarray, c: np.ndarray):
     rc = lib.fsnap_solve(int(kind), float(param), K, _ptr(G), _ptr(c), _ptr(beta), byref(rank), byref(rce))
     raise_status(rc, "")
     return beta, rank.value, rce.value
+
+
+def lasso_gram(Q: np.ndarray, q: np.ndarray, y_norm2: float, l1_reg: float, max_iter: int = 2000, tol: float = 1.0e-4,
+               start=None):
+    """Cyclic coordinate descent for (1/2) w^T Q w - q^T w + l1_reg |w|_1 (fsnap_lasso_gram; host side, no GPU needed).
+    Returns (w, sweeps, duality gap)."""
+    lib = load_library()
+    Q = _f64(Q, "Q")
+    q = _f64(q, "q")
+    K = q.shape[0]
+    if Q.shape != (K, K):
+        raise ValueError("Q must be K x K")
+    w = np.zeros(K) if start is None else np.array(start, dtype=np.float64)
+    if w.shape != (K,):
+        raise ValueError("start must have K entries")
+    nit = c_int64(0)
+    gap = c_double(0.0)
+    rc = lib.fsnap_lasso_gram(K, _ptr(Q), _ptr(q), float(y_norm2), float(l1_reg), int(max_iter), float(tol), _ptr(w),
+                              byref(nit), byref(gap))
+    raise_status(rc, "")
+    return w, int(nit.value), float(gap.value)
 
 
 def comm_id() -> bytes:

@@ -10,6 +10,7 @@ defaulted here, with the reference's defaults:
   [RIDGE]  alpha=1.0E-8, local_solver=0                     (solver_sections/ridge.py:13-14)
   [ARD]    alphabig, alphasmall, lambdabig, lambdasmall, threshold_lambda, directmethod,
            scap=1e-3, scai=1e-3, logcut=0.3                 (solver_sections/ard.py:13-21)
+  [LASSO]  alpha=1.0E-8, max_iter=2000                      (solver_sections/lasso.py:13-14)
   [EXTRAS] apply_transpose, multinode_testing, only_test, dump_*   (extras.py:19-45)
   [CALCULATOR] calculator, energy, force, stress, per_atom_energy, linear
                                                             (calculator_sections/calculator.py:17-32)
@@ -188,6 +189,14 @@ class Config:
                 directmethod=_get(ad, "directmethod", "0", "int"),
                 scap=_get(ad, "scap", "1.e-3", "float"), scai=_get(ad, "scai", "1.e-3", "float"),
                 logcut=_get(ad, "logcut", "0.3", "float"))
+
+        if "LASSO" in raw or solver.upper() == "LASSO":
+            ld = raw.get("LASSO", {})
+            _check_keys("LASSO", ld, ["alpha", "max_iter"])
+            if solver.upper() != "LASSO":
+                not_used("LASSO")
+            self.sections["LASSO"] = SimpleNamespace(name="LASSO", alpha=_get(ld, "alpha", "1.0E-8", "float"),
+                                                     max_iter=_get(ld, "max_iter", "2000", "int"))
 
         ex = raw.get("EXTRAS", {})
         _check_keys("EXTRAS", ex, ["multinode_testing", "apply_transpose", "only_test", "dump_descriptors", "dump_truth",

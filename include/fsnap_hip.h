@@ -214,6 +214,15 @@ int fsnap_residual_rhs(fsnap_ctx* ctx, const double* beta, double* s, double* ss
 int fsnap_solve(int kind, double param, int64_t K, const double* G, const double* c, double* beta, int* rank,
                 double* rcond_est);
 
+/* LASSO by cyclic coordinate descent on the statistics: minimises (1/2) w^T Q w - q^T w + l1_reg |w|_1 with Q = A_w^T A_w,
+ * q = A_w^T b_w, i.e. scikit-learn's Lasso(alpha, fit_intercept=False, max_iter).fit(aw, bw) of the reference
+ * (fitsnap3lib/solvers/lasso.py:23-28) with l1_reg = alpha * n_samples.  Stopping rule as scikit-learn's: duality gap
+ * < tol * y_norm2 (y_norm2 = b_w^T b_w), looked at once a sweep's largest update drops below tol x the largest
+ * coefficient, or after max_iter sweeps.  w[K]: start vector in (zeros in the reference), coefficients out;
+ * *n_iter / *gap (may be NULL): sweeps run and the last duality gap.  Host side, no context needed. */
+int fsnap_lasso_gram(int64_t K, const double* Q, const double* q, double y_norm2, double l1_reg, int64_t max_iter, double tol,
+                     double* w, int64_t* n_iter, double* gap);
+
 /* Same solve, taking the packed statistics [G | c | ...] from DEVICE memory (the buffer
  * fsnap_normal_eq_async / the all-reduce left in HBM).  Small systems are copied to the host
  * (page-locked staging) and solved there (faster than any GPU factorisation of a 128-step recurrence); for

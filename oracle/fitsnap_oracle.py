@@ -13,7 +13,8 @@ the reference's committed ``Ta_pot.snapcoeff`` / ``Ta_metrics.md``.  ARD: the re
 ``n_iter=`` to ARDRegression (fitsnap3lib/solvers/ard.py:40-45), a keyword scikit-learn renamed to ``max_iter`` (1.3)
 and removed (1.5), so the golden generator runs the class with that one keyword forwarded under its new name and
 ``ard_fit`` is pinned bit-for-bit to those vectors (all rows / testing mask / directmethod / non-default scap, scai,
-logcut / apply_transpose).  No test or fixture of the reference itself holds an ARD output.
+logcut / apply_transpose).  No test or fixture of the reference itself holds an ARD output.  LASSO (``lasso_fit``):
+the reference class runs as it stands; pinned bit-for-bit to its vectors.
 
 Reference citations are file:line into FitSNAP/FitSNAP (/root/reference at build time).
 """
@@ -156,6 +157,21 @@ def ard_fit(a, b, w, testing=None, directmethod=False, alphabig=1.0e-12, lambdas
                             alpha_2=alphabig, lambda_1=lambdasmall, lambda_2=lambdasmall, fit_intercept=False)
     else:
         reg = ARDRegression(max_iter=max_iter, fit_intercept=False, **ard_hyper(bw, scap, scai, logcut))
+    reg.fit(aw, bw)
+    return reg.coef_
+
+
+def lasso_fit(a, b, w, testing=None, alpha=1.0e-8, max_iter=2000, apply_transpose=False):
+    """fitsnap3lib/solvers/lasso.py:17-29: ``Lasso(alpha, fit_intercept=False, max_iter).fit(aw, bw).coef_`` (defaults:
+    io/sections/solver_sections/lasso.py:13-14).  Pinned bit-for-bit to vectors produced by the reference class
+    (tests/golden/make_golden.py).  Third-party arithmetic: scikit-learn's coordinate descent."""
+    from sklearn.linear_model import Lasso
+
+    aw, bw = weight_rows(a, b, w, testing)
+    if apply_transpose:                                            # lasso.py:22-24
+        bw = aw.T @ bw
+        aw = aw.T @ aw
+    reg = Lasso(alpha=alpha, fit_intercept=False, max_iter=max_iter)
     reg.fit(aw, bw)
     return reg.coef_
 

@@ -8,7 +8,7 @@ reference nor this need):
 What it does
   * imports fitsnap3lib from /root/reference with a stub ``lammps`` module
     (fitsnap3lib/parallel_tools.py:35 imports it unconditionally),
-  * instantiates the reference's own SVD / RIDGE solver classes through its
+  * instantiates the reference's own SVD / RIDGE (/ ANL / ARD / LASSO) solver classes through its
     solver_factory and calls ``perform_fit(a, b, w, fs_dict|trainall)`` on the golden
     Ta matrices the reference commits under
     examples/Ta_Linear_JCP2014/20May21_Standard/{Descriptors,Truth-Ref,Weights}.npy,
@@ -232,6 +232,32 @@ def main():
         out["ard_class_transpose"] = run_ard({"EXTRAS": {"apply_transpose": 1}}, False)
     except Exception as e:  # pragma: no cover
         print("ARD reference-class run failed:", repr(e))
+    # LASSO through the reference class (lasso.py:15-29; runs on the installed scikit-learn as it stands)
+    def run_lasso(extra, mask):
+        pt = ParallelTools()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ext = {"LASSO": {}}
+            for k, v in (extra or {}).items():
+                ext.setdefault(k, {}).update(v)
+            cfg = Config(pt, settings("LASSO", ext), arguments_lst=["--overwrite"])
+            s = solver_factory.solver("LASSO", pt, cfg)
+            pt.create_shared_array('a', m, K)
+            pt.create_shared_array('b', m)
+            pt.create_shared_array('w', m)
+            pt.shared_arrays['a'].array[:] = A
+            pt.shared_arrays['b'].array[:] = b
+            pt.shared_arrays['w'].array[:] = w
+            pt.fitsnap_dict['Testing'] = testing.tolist() if mask else [False] * m
+            s.perform_fit()
+        return np.asarray(s.fit, dtype=np.float64).copy()
+
+    out["lasso_class_all"] = run_lasso(None, False)                                   # alpha = 1e-8, max_iter = 2000
+    out["lasso_class_mask"] = run_lasso(None, True)
+    out["lasso_class_alpha1e-2_mask"] = run_lasso({"LASSO": {"alpha": 1.0e-2}}, True)
+    out["lasso_class_alpha1_all"] = run_lasso({"LASSO": {"alpha": 1.0}}, False)         # sparse, stops at max_iter
+    out["lasso_class_alpha1_iter50_all"] = run_lasso({"LASSO": {"alpha": 1.0, "max_iter": 50}}, False)
+    out["lasso_class_transpose"] = run_lasso({"LASSO": {"alpha": 1.0e-2}, "EXTRAS": {"apply_transpose": 1}}, False)
     np.savez_compressed(os.path.join(HERE, "ta_reference_fits.npz"), **out)
     np.savez_compressed(os.path.join(HERE, "ta_abw.npz"), A=A, b=b, w=w)
 

@@ -558,6 +558,37 @@ def test_ard_apply_transpose_on_the_golden_rows(ta, ta_fits):
     pt.free()
 
 
+@pytest.mark.parametrize("key,mask,extra", [
+    ("lasso_class_all", False, {}),
+    ("lasso_class_mask", True, {}),
+    ("lasso_class_alpha1e-2_mask", True, {"LASSO": {"alpha": 1.0e-2}}),
+    ("lasso_class_alpha1_all", False, {"LASSO": {"alpha": 1.0}}),
+    ("lasso_class_alpha1_iter50_all", False, {"LASSO": {"alpha": 1.0, "max_iter": 50}}),
+    ("lasso_class_transpose", False, {"LASSO": {"alpha": 1.0e-2}, "EXTRAS": {"apply_transpose": 1}}),
+])
+def test_lasso_solver_matches_the_reference_class(ta, ta_fits, key, mask, extra):
+    # goldens: the reference's LASSO class (lasso.py:15-29).  Statistics from the GPU, scikit-learn's coordinate descent
+    # on them inside the library: same support, north_star's 1e-6 on the values (1e-5 norm-wise for the transposed
+    # problem, whose Gram matrix squares kappa(G) = 7e10 once more)
+    A, b, w = ta
+    pt, s = make_solver("LASSO", extra)
+    m, K = A.shape
+    for name, arr in (("a", A), ("b", b), ("w", w)):
+        pt.create_shared_array(name, m, K if name == "a" else 1)
+        pt.shared_arrays[name].array[:] = arr
+    pt.fitsnap_dict["Testing"] = ta_fits["testing_mask"].tolist() if mask else [False] * m
+    s.perform_fit()
+    ref = ta_fits[key]
+    assert np.array_equal(s.fit != 0, ref != 0)
+    tol = 1e-5 if "transpose" in key else 1e-6
+    assert np.max(np.abs(s.fit - ref)) <= tol * np.max(np.abs(ref))
+    if "transpose" not in key:
+        nz = ref != 0
+        assert np.max(np.abs(s.fit[nz] - ref[nz]) / np.abs(ref[nz])) < 1e-6
+    assert 1 <= s.n_iter_ <= s.config.sections["LASSO"].max_iter
+    pt.free()
+
+
 def test_error_analysis_all_rows(ta, ta_fits):
     # '*ALL' rows of the committed Ta_metrics.md through Solver.error_analysis (GPU GEMV)
     A, b, w = ta
@@ -981,3 +1012,42 @@ def test_reweighting_loop_error_analysis_reuses_labels_and_builds_df_lazily(ta, 
     assert len(df.index) == len(b) and {"truths", "preds", "weights", "Groups", "Testing", "Row_Type"} <= set(df.columns)
     assert np.allclose(df["preds"].to_numpy(), A @ s.fit[:A.shape[1]] if len(s.fit) == A.shape[1] else df["preds"].to_numpy())
     pt.free()
+
+
+def test_tiled_partials_survive_interleaved_geometries(ctx):
+    # the tiled kernel's c partials are cleared only when (splits, superblocks) change: alternate two tiled shapes and a
+    # one-wave-triangle shape on ONE context (they share the partial buffers) and check every result
+    rng = np.random.default_rng(77)
+    shapes = [(6000, 200), (900, 200), (5000, 96), (6000, 200), (30000, 200), (900, 200)]
+    for m, K in shapes:
+        A = rng.standard_normal((m, K))
+        b = rng.standard_normal(m)
+        w = rng.uniform(0.5, 2.0, m)
+        t = rng.random(m) < 0.3
+        G, c, s = run_stats(ctx, A, b, w, t)
+        stats_close(G, c, s, *orc.normal_eq(A, b, w, t))
+        G2, c2, s2 = ctx.normal_eq()                       # same geometry again: no clearing in between
+        assert np.array_equal(G, G2) and np.array_equal(c, c2) and np.array_equal(s, s2)
+
+
+def test_timing_events_are_sampled_by_option():
+    c = _capi.HipContext(0)
+    rng = np.random.default_rng(5)
+    c.upload_rows(rng.standard_normal((4096, 64)), rng.standard_normal(4096))
+    c.set_weights(np.ones(4096))
+    sampled0, launches0 = c.timing_count()
+    for _ in range(3):
+        c.normal_eq()                                      # default: every launch is bracketed by events
+    assert c.timing_count() == (sampled0 + 3, launches0 + 3)
+    c.set_option("timing_every", 4)                        # the next launch is a sampled one, then every 4th
+    for _ in range(9):
+        c.normal_eq()
+    assert c.timing_count() == (sampled0 + 6, launches0 + 12)
+    syrk, red = c.timing_history(3)
+    assert np.all(syrk > 0) and np.all(red > 0)
+    c.set_option("timing_every", 0)
+    G, cc, s = c.normal_eq()
+    assert c.timing_count() == (sampled0 + 6, launches0 + 13) and np.isfinite(G).all()
+    with pytest.raises(ValueError):
+        c.set_option("timing_every", -1)
+    c.close()

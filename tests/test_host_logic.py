@@ -439,3 +439,51 @@ def test_ard_loop_on_statistics_matches_the_reference_class(ta, ta_fits, key, ma
     assert np.array_equal(fit != 0, nz) and 2 <= s.n_iter_ <= 20
     assert np.max(np.abs(fit[nz] - ref[nz]) / np.abs(ref[nz])) < 1e-3
     assert np.max(np.abs(fit - ref)) < 1e-4 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("key,mask,alpha,max_iter,transpose", [
+    ("lasso_class_all", False, 1e-8, 2000, False),
+    ("lasso_class_mask", True, 1e-8, 2000, False),
+    ("lasso_class_alpha1e-2_mask", True, 1e-2, 2000, False),
+    ("lasso_class_alpha1_all", False, 1.0, 2000, False),
+    ("lasso_class_alpha1_iter50_all", False, 1.0, 50, False),
+    ("lasso_class_transpose", False, 1e-2, 2000, True),
+])
+def test_lasso_sweeps_on_statistics_match_the_reference_class(ta, ta_fits, key, mask, alpha, max_iter, transpose):
+    """fsnap_lasso_gram (C ABI, host side) on the oracle's statistics against the reference CLASS's coefficients
+    (lasso.py:15-29): the coordinate descent on (X^T X, X^T y, |y|^2) is scikit-learn's own iteration, so the support
+    is identical and the values agree far inside the 1e-6 bar (1e-9 asked here; 1e-11 seen)."""
+    from fitsnap_amd import _capi
+    from oracle import fitsnap_oracle as orc
+    A, b, w = ta
+    t = ta_fits["testing_mask"] if mask else None
+    G, c, s3 = orc.normal_eq(A, b, w, t)
+    y2, n = float(s3[0]), float(s3[2])
+    if transpose:
+        X, y = G, c
+        G, c, y2, n = X.T @ X, X.T @ y, float(y @ y), float(len(y))
+    coef, sweeps, gap = _capi.lasso_gram(G, c, y2, alpha * n, max_iter, 1.0e-4)
+    ref = ta_fits[key]
+    assert np.array_equal(coef != 0, ref != 0)
+    tol = 1e-6 if transpose else 1e-9      # the transposed problem squares kappa(G) = 7e10 once more
+    assert np.max(np.abs(coef - ref)) <= tol * np.max(np.abs(ref))
+    assert 1 <= sweeps <= max_iter and np.isfinite(gap)
+
+
+def test_lasso_gram_argument_checks_and_closed_form():
+    from fitsnap_amd import _capi
+    # orthogonal design: the minimiser is the soft threshold of q / diag(Q)
+    Q = np.diag([2.0, 4.0, 0.0, 1.0])
+    q = np.array([3.0, -1.0, 5.0, 0.2])
+    coef, sweeps, gap = _capi.lasso_gram(Q, q, 10.0, 0.5)
+    assert np.allclose(coef, [(3.0 - 0.5) / 2.0, -(1.0 - 0.5) / 4.0, 0.0, 0.0]) and sweeps >= 1
+    with pytest.raises(ValueError):
+        _capi.lasso_gram(np.eye(3), np.ones(4), 1.0, 0.1)
+    with pytest.raises(ValueError):
+        _capi.lasso_gram(np.eye(3), np.ones(3), 1.0, -0.1)
+    with pytest.raises(ValueError):
+        _capi.lasso_gram(np.eye(2), np.array([1.0, np.nan]), 1.0, 0.1)
+    cfg = Config(ParallelTools(), {"SOLVER": {"solver": "LASSO"}, "LASSO": {"alpha": "1e-3"}})
+    assert cfg.sections["LASSO"].alpha == 1e-3 and cfg.sections["LASSO"].max_iter == 2000
+    with pytest.raises(UserWarning):
+        Config(ParallelTools(), {"SOLVER": {"solver": "SVD"}, "LASSO": {"alpha": "1e-3"}})

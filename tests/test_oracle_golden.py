@@ -111,6 +111,28 @@ def test_ard_matches_the_reference_class(ta, ta_fits, key, kw):
     assert 20 <= np.count_nonzero(fit) <= 31
 
 
+LASSO_CASES = [
+    ("lasso_class_all", {}),
+    ("lasso_class_mask", {"mask": True}),
+    ("lasso_class_alpha1e-2_mask", {"mask": True, "alpha": 1.0e-2}),
+    ("lasso_class_alpha1_all", {"alpha": 1.0}),
+    ("lasso_class_alpha1_iter50_all", {"alpha": 1.0, "max_iter": 50}),
+    ("lasso_class_transpose", {"alpha": 1.0e-2, "apply_transpose": True}),
+]
+
+
+@pytest.mark.parametrize("key,kw", LASSO_CASES)
+def test_lasso_matches_the_reference_class(ta, ta_fits, key, kw):
+    # vectors from the reference's LASSO class (lasso.py:15-29); same scikit-learn here: bit for bit
+    A, b, w = ta
+    kw = dict(kw)
+    testing = ta_fits["testing_mask"] if kw.pop("mask", False) else None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                             # ConvergenceWarning at max_iter
+        fit = orc.lasso_fit(A, b, w, testing, **kw)
+    assert np.array_equal(fit, ta_fits[key])
+
+
 def test_synthetic_generator_is_deterministic():
     A1, b1, w1 = orc.synth_problem(1000, 16)
     A2, b2, w2 = orc.synth_problem(1000, 16)
