@@ -460,6 +460,8 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
         const size_t need = ((size_t)FSNAP_PACKED_LEN(ctx->K) + (size_t)ctx->K) * 8;   // + compact diagonal
         if (ctx->mirror_bytes < need) {
             if (ctx->mirror) (void)hipHostFree(ctx->mirror);
+    if (ctx->chol_host) (void)hipHostFree(ctx->chol_host);
+    if (ctx->chol_ev) (void)hipEventDestroy(ctx->chol_ev);
             ctx->mirror = nullptr;
             ctx->mirror_bytes = 0;
             // coherent (fine-grained) host memory: the kernel's stores are visible to the host once the event has completed
@@ -1132,7 +1134,20 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
         int* d_status = (int*)(dv + n + npanel);
         double* d_dsc = dv + head;
         double* d_z = d_dsc + np;
-        if (ctx->pinned_bytes < head * 8) {
+        // results come back through page-locked, GPU-visible host memory written by the last launch of the chain (the
+        // host polls an event: no D2H copy, whose launch latency was ~10 us); the plain staging buffer + copy remain
+        // as the fallback when that allocation fails
+        if (ctx->chol_host_bytes < head * 8) {
+            if (ctx->chol_host) (void)hipHostFree(ctx->chol_host);
+            ctx->chol_host = nullptr;
+            ctx->chol_host_bytes = 0;
+            if (hipHostMalloc((void**)&ctx->chol_host, head * 8, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
+                ctx->chol_host_bytes = head * 8;
+        }
+        if (ctx->chol_host && !ctx->chol_ev && hipEventCreateWithFlags(&ctx->chol_ev, hipEventDisableTiming) != hipSuccess)
+            ctx->chol_ev = nullptr;
+        double* host_out = (ctx->chol_host && ctx->chol_ev) ? ctx->chol_host : nullptr;
+        if (!host_out && ctx->pinned_bytes < head * 8) {
             if (ctx->pinned) (void)hipHostFree(ctx->pinned);
             ctx->pinned = nullptr;
             ctx->pinned_bytes = 0;
@@ -1146,12 +1161,27 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
             FSNAP_HIP(hipMemcpyAsync(ctx->dsvec.p, rhs, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(rhs)");
             d_rhs = (const double*)ctx->dsvec.p;
         }
+        // the status word lives behind beta and the pivots: its address depends on K.  The chain leaves it cleared; a
+        // clearing launch is needed only when this word has not been through a chain yet
+        const bool clear_status = ctx->chol_status_word != (const void*)d_status;
+        ctx->chol_status_word = host_out ? (const void*)d_status : nullptr;
         FSNAP_HIP(fsnap::launch_chol_large(d_packed, d_rhs, n, alpha, (double*)ctx->dchol.p, d_dsc, d_z, d_beta, d_status,
-                                           d_minpiv, ctx->stream),
+                                           d_minpiv, host_out, clear_status, ctx->stream),
                   "launch device Cholesky");
-        FSNAP_HIP(hipMemcpyAsync(ctx->pinned, dv, head * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(beta)");
-        FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
-        const double* h = ctx->pinned;
+        const double* h;
+        if (host_out) {
+            FSNAP_HIP(hipEventRecord(ctx->chol_ev, ctx->stream), "hipEventRecord");
+            while (true) {
+                const hipError_t q = hipEventQuery(ctx->chol_ev);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) return ctx->hipfail(q, "hipEventQuery");
+            }
+            h = host_out;
+        } else {
+            FSNAP_HIP(hipMemcpyAsync(ctx->pinned, dv, head * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(beta)");
+            FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+            h = ctx->pinned;
+        }
         int status;
         memcpy(&status, h + n + npanel, sizeof(int));
         double mp = 1.0e300;

@@ -515,13 +515,6 @@ constexpr int CHOL_BS_BUF = 2 * CHOL_NB * (CHOL_NB + 1) + 4 * 16 * 17;
 constexpr size_t CHOL_BS_LDS = (size_t)(2 * CHOL_BS_BUF + 4 * CHOL_NB) * sizeof(double);
 constexpr int CHOL_BS_MACRO = 4;             // panels per macro-block
 
-__global__ __launch_bounds__(256) void fsnap_chol_backinit_k(const double* __restrict__ S, int ld, int np, double* __restrict__ zv,
-                                                            const int* __restrict__ status) {
-    if (*status) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < np) zv[i] = S[(size_t)i * ld + np];
-}
-
 // y_r -= U[r, c0 : c1] x[c0 : c1] for the rows r < nrows; one wave per row, c1 - c0 a multiple of 128
 __global__ __launch_bounds__(256) void fsnap_chol_backupdate_k(const double* __restrict__ S, int ld, double* zv, int c0, int c1,
                                                               int nrows, const int* __restrict__ status) {
@@ -543,12 +536,29 @@ __global__ __launch_bounds__(256) void fsnap_chol_backupdate_k(const double* __r
     if (lane == 0) zv[r] -= acc;
 }
 
+// first = 1 (the launch of the bottom macro-block): also copies the strip's first column y = U^-T z into zv (was a launch of
+// its own).  host_out != null and p_lo == 0 (the last launch): beta, the panel pivots and the status word also go to
+// page-locked host memory -- [beta n | min pivots np / 64 | status] -- and the status word is cleared for the next
+// solve (was: a 4-byte memset launch in front of every solve and a D2H copy behind it).
 __global__ __launch_bounds__(1024) void fsnap_chol_backsolve_k(const double* __restrict__ S, int ld, int np, int n,
                                                               const double* __restrict__ Yall, double* zv,
                                                               const double* __restrict__ dsc, double* __restrict__ beta,
-                                                              const int* __restrict__ status, int p_lo, int p_hi) {
+                                                              int* status, int p_lo, int p_hi, int first,
+                                                              const double* __restrict__ minpiv, double* host_out) {
     extern __shared__ __attribute__((aligned(16))) double bs_lds[];
-    if (*status) return;
+    const int st_in = *status;
+    __syncthreads();                                   // every thread has read the status before thread 0 may clear it
+    if (st_in) {
+        if (p_lo == 0 && host_out && threadIdx.x == 0) {
+            reinterpret_cast<int*>(host_out + n + np / CHOL_NB)[0] = st_in;
+            *status = 0;
+        }
+        return;
+    }
+    if (first) {
+        for (int i = threadIdx.x; i < np; i += 1024) zv[i] = S[(size_t)i * ld + np];
+        __syncthreads();
+    }
     double* xbuf = bs_lds + 2 * CHOL_BS_BUF;   // x of the panel solved last / being solved (two slots)
     double* ybuf = xbuf + 2 * CHOL_NB;         // y of the panel being solved / of the next one (two slots)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -652,8 +662,17 @@ __global__ __launch_bounds__(1024) void fsnap_chol_backsolve_k(const double* __r
         if (pb > p_lo) park(cur ^ 1);
         __syncthreads();
     }
-    if (p_lo == 0)
-        for (int i = tid; i < n; i += 1024) beta[i] = zv[i] * dsc[i];
+    if (p_lo == 0) {
+        for (int i = tid; i < n; i += 1024) {
+            const double v = zv[i] * dsc[i];
+            beta[i] = v;
+            if (host_out) host_out[i] = v;
+        }
+        if (host_out) {
+            for (int p = tid; p < np / CHOL_NB; p += 1024) host_out[n + p] = minpiv[p];
+            if (tid == 0) reinterpret_cast<int*>(host_out + n + np / CHOL_NB)[0] = 0;
+        }
+    }
 }
 // ---------------------------------------------------------------------------------
 // host-side launchers (C++ linkage, used by fsnap_capi.cpp)
@@ -666,13 +685,18 @@ size_t chol_large_work_doubles(int n) {
 }
 
 hipError_t launch_chol_large(const double* packed, const double* cvec, int n, double alpha, double* work, double* dsc, double* z,
-                             double* beta, int* status, double* minpiv, hipStream_t st) {
+                             double* beta, int* status, double* minpiv, double* host_out, bool clear_status, hipStream_t st) {
     if (!cvec) cvec = packed + (size_t)n * n;
     const int np = (n + CHOL_NB - 1) / CHOL_NB * CHOL_NB, npanel = np / CHOL_NB, ld = np + CHOL_XS;
     double* S = work;
     double* Yall = work + (size_t)np * ld;
-    hipError_t e = hipMemsetAsync(status, 0, sizeof(int), st);
-    if (e != hipSuccess) return e;
+    hipError_t e;
+    // the status word is cleared by the last launch of the previous solve (host_out path); a launch of its own only the
+    // first time this buffer is used, or when the results still travel by D2H copy
+    if (clear_status || !host_out) {
+        e = hipMemsetAsync(status, 0, sizeof(int), st);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(fsnap_chol_prepare_d_k, dim3((np + 255) / 256), dim3(256), 0, st, packed, cvec, n, np, alpha, dsc, z, status,
                        minpiv, npanel);
     hipLaunchKernelGGL(fsnap_chol_prepare_s_k, dim3((ld + 255) / 256, np), dim3(256), 0, st, packed, n, np, alpha, dsc, z, S,
@@ -697,11 +721,10 @@ hipError_t launch_chol_large(const double* packed, const double* cvec, int n, do
         if (e != hipSuccess) return e;
         bs_attr_set = true;
     }
-    hipLaunchKernelGGL(fsnap_chol_backinit_k, dim3((np + 255) / 256), dim3(256), 0, st, S, ld, np, z, status);
     for (int hi = npanel; hi > 0; hi -= CHOL_BS_MACRO) {
         const int lo = hi > CHOL_BS_MACRO ? hi - CHOL_BS_MACRO : 0;
         hipLaunchKernelGGL(fsnap_chol_backsolve_k, dim3(1), dim3(1024), CHOL_BS_LDS, st, S, ld, np, n, Yall, z, dsc, beta, status,
-                           lo, hi);
+                           lo, hi, hi == npanel ? 1 : 0, minpiv, host_out);
         if (lo > 0) {
             const int nrows = lo * CHOL_NB;
             hipLaunchKernelGGL(fsnap_chol_backupdate_k, dim3((nrows + 3) / 4), dim3(256), 0, st, S, ld, z, lo * CHOL_NB,

@@ -52,6 +52,10 @@ struct fsnap_ctx {
     hipEvent_t ev[10] = {};
     static constexpr int RING = 256;              // event triples of the last RING fits (fsnap_timing_history)
     hipEvent_t ring[RING][3] = {};
+    double* chol_host = nullptr;                  // page-locked [beta | panel pivots | status] written by the device Cholesky
+    size_t chol_host_bytes = 0;
+    hipEvent_t chol_ev = nullptr;
+    const void* chol_status_word = nullptr;       // device status word the last chain left cleared
     int64_t cpart_key = -1;                       // geometry the tiled kernel's c partials were last cleared for
     const void* cpart_ptr = nullptr;
     int64_t nlaunch = 0;                          // SYRK launches so far (sampled ones: nfit)

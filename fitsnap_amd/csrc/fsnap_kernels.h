@@ -79,7 +79,7 @@ hipError_t launch_chol_solve(const double* packed, int K, double alpha, double* 
 // cvec: device right-hand side (NULL = the c part of packed)
 size_t chol_large_work_doubles(int n);
 hipError_t launch_chol_large(const double* packed, const double* cvec, int n, double alpha, double* work, double* dsc, double* z,
-                             double* beta, int* status, double* minpiv, hipStream_t st);
+                             double* beta, int* status, double* minpiv, double* host_out, bool clear_status, hipStream_t st);
 int gemv_num_blocks(int64_t m);
 hipError_t launch_gemv_rows(const double* A, int64_t lda, const double* beta, int64_t m, int K, double* preds,
                             const double* b, const double* w, const unsigned char* mask, double* sse_part,
