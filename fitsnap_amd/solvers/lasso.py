@@ -8,8 +8,6 @@ of the fused GPU statistics kernel (summed over the ranks) and the sweeps run on
 golden rows with identical sweep counts, and K^2 instead of m K flops per sweep."""
 from __future__ import annotations
 
-import numpy as np
-
 from .. import _capi
 from .solver import Solver
 
