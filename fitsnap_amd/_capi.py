@@ -86,6 +86,7 @@ SIGNATURES = {
     "fsnap_timing": (c_int, [c_void_p, _P_D, c_int]),
     "fsnap_timing_history": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
     "fsnap_timing_count": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "fsnap_rowspace_chain": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_double, c_void_p, POINTER(c_int), c_void_p]),
     "fsnap_launch_info": (c_int, [c_void_p, POINTER(c_int64), c_int]),
 }
 
@@ -218,6 +219,21 @@ def lasso_gram(Q: np.ndarray, q: np.ndarray, y_norm2: float, l1_reg: float, max_
                               byref(nit), byref(gap))
     raise_status(rc, "")
     return w, int(nit.value), float(gap.value)
+
+
+def rowspace_chain(factors, z, rcond, active=None):
+    """K x K end of the row-space solve on factors kept apart (fsnap_rowspace_chain): returns (beta, rank, info)."""
+    lib = load_library()
+    R = _f64(np.ascontiguousarray(np.stack([np.asarray(f, dtype=np.float64) for f in factors])), "factors")
+    nfac, K = R.shape[0], R.shape[1]
+    z = _f64(z, "z")
+    act = None if active is None else np.ascontiguousarray(np.asarray(active, dtype=np.uint8))
+    beta = np.empty(K)
+    rank = c_int(0)
+    info = np.zeros(4)
+    raise_status(lib.fsnap_rowspace_chain(K, nfac, _ptr(R), None if act is None else _ptr(act), _ptr(z), float(rcond), _ptr(beta),
+                                          byref(rank), _ptr(info)), "")
+    return beta, rank.value, {"chain": info[0], "norm_bound": info[1], "inverse_norm_bound": info[2], "cond_bound": info[3]}
 
 
 def comm_id() -> bytes:

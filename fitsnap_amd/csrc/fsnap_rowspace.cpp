@@ -37,6 +37,7 @@
 
 #include "fsnap_rowspace_host.h"
 
+using fsnap_rs::FactorChain;
 using fsnap_rs::FactorSolver;
 using fsnap_rs::factor_pass;
 using fsnap_rs::finite_all;
@@ -105,6 +106,42 @@ int fsnap_rowspace_solve(int64_t K, const double* Rhat, const double* z, double 
     return finite_all(beta, (size_t)K) ? FSNAP_OK : FSNAP_NUM_NONFINITE;
 }
 
+int fsnap_rowspace_chain(int64_t K64, int64_t nfac, const double* R, const unsigned char* active, const double* z, double rcond,
+                         double* beta, int* rank, double* info) {
+    if (!R || !z || !beta || K64 <= 0 || K64 > (1 << 20) || nfac < 1 || nfac > 16) return FSNAP_E_ARG;
+    const int K = (int)K64;
+    if (!finite_all(R, (size_t)nfac * K * K) || !finite_all(z, (size_t)K)) return FSNAP_NUM_NONFINITE;
+    FactorChain chain;
+    chain.K = K;
+    chain.active.assign((size_t)K, 1);
+    if (active)
+        for (int j = 0; j < K; ++j) chain.active[j] = active[j] ? 1 : 0;
+    for (int64_t k = 0; k < nfac; ++k) chain.push(R + (size_t)k * K * K);
+    double nrm = 0.0, inv = 0.0;
+    const double bound = chain.condition_bound(&nrm, &inv);
+    const bool use_chain = bound * (rcond > 0.0 ? rcond : 0.0) < 0.5;
+    int rk = 0;
+    if (use_chain) {
+        chain.solve(z, beta);
+        for (int j = 0; j < K; ++j) rk += chain.active[j] ? 1 : 0;
+    } else {
+        vec Rhat((size_t)K * K);
+        chain.product(Rhat.data());
+        FactorSolver fs;
+        fs.prepare(K, Rhat.data(), rcond);
+        fs.apply(z, beta);
+        rk = fs.rank;
+    }
+    if (rank) *rank = rk;
+    if (info) {
+        info[0] = use_chain ? 1.0 : 0.0;
+        info[1] = nrm;
+        info[2] = inv;
+        info[3] = bound;
+    }
+    return finite_all(beta, (size_t)K) ? FSNAP_OK : FSNAP_NUM_NONFINITE;
+}
+
 int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, int* rank_out, double* info) {
     if (!ctx) return FSNAP_E_ARG;
     if (!beta || K64 <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_lstsq_rows: bad argument");
@@ -136,7 +173,12 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
     double* dQ = (double*)rs->Q.p;
     hipStream_t st = ctx->stream;
     int rc;
-    vec Rhat((size_t)K * K), Rp((size_t)K * K), z((size_t)K);
+    // K > 256: the factors of the passes stay apart (FactorChain) and R_hat is only multiplied out when a truncation turns
+    // out to be needed; small K keeps the accumulated factor (the product is cheap there and the exact Frobenius bound of
+    // FactorSolver is sharper than the chain's estimate)
+    const bool chained = K > 256;
+    vec Rhat(chained ? 0 : (size_t)K * K), Rp((size_t)K * K), z((size_t)K);
+    FactorChain chain;
     double* const host = rs->pin;                        // [npk] statistics of the current Q
     double* const Rpad = rs->pin + npk;                  // [K16 x K16] padded factor of the pass
     double* const hvec = Rpad + (size_t)K16 * K16;       // [2 K] beta up, Q^T r down
@@ -169,12 +211,14 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
     double dev = 0.0, shift = 0.0;
     for (int pass = 1; pass <= maxpass; ++pass) {
         int conv = 0;
-        rc = factor_pass(K, host, pass == 1, tol, Rhat.data(), Rp.data(), &dev, &conv, &shift);
+        if (pass == 1 && chained) chain.start(K, host);
+        rc = factor_pass(K, host, pass == 1, tol, chained ? nullptr : Rhat.data(), Rp.data(), &dev, &conv, &shift);
         if (rc) return ctx->fail(rc, "row-space pass %d: the Gram matrix could not be factorised (status %d)", pass, rc);
         if (conv) {
             converged = 1;
             break;
         }
+        if (chained) chain.push(Rp.data());
         // padded copy of the factor for the kernel
         std::fill(Rpad, Rpad + (size_t)K16 * K16, 0.0);
         for (int i = 0; i < K16; ++i) Rpad[(size_t)i * K16 + i] = 1.0;
@@ -203,8 +247,22 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
     if (!finite_all(z.data(), z.size())) return ctx->fail(FSNAP_NUM_NONFINITE, "row-space solve: non-finite Q^T b");
 
     FactorSolver fs;
-    fs.prepare(K, Rhat.data(), rcond);
-    fs.apply(z.data(), beta);
+    bool use_chain = false;
+    double chain_norm = 0.0, chain_inv = 0.0;
+    if (chained) {
+        const double rc0 = rcond > 0.0 ? rcond : 0.0;
+        use_chain = chain.condition_bound(&chain_norm, &chain_inv) * rc0 < 0.5;      // no singular value can be cut
+        if (!use_chain) {
+            Rhat.assign((size_t)K * K, 0.0);
+            chain.product(Rhat.data());
+        }
+    }
+    if (!use_chain) fs.prepare(K, Rhat.data(), rcond);
+    auto apply = [&](const double* rhs, double* out) {
+        if (use_chain) chain.solve(rhs, out);
+        else fs.apply(rhs, out);
+    };
+    apply(z.data(), beta);
     // one refinement step with the residual of the original rows
     double rel_step = 0.0;
     {
@@ -223,7 +281,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
         }
         if (nranks > 1 && (rc = fsnap_allreduce_host(ctx, dzh.data(), K, 0))) return rc;
         if (finite_all(dzh.data(), dzh.size())) {
-            fs.apply(dzh.data(), dbeta.data());
+            apply(dzh.data(), dbeta.data());
             double nb = 0.0, nd = 0.0;
             for (int j = 0; j < K; ++j) {
                 nb = std::fmax(nb, std::fabs(beta[j]));
@@ -234,14 +292,17 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
             for (int j = 0; j < K; ++j) beta[j] += dbeta[j];
         }
     }
-    if (rank_out) *rank_out = fs.rank;
+    int nact = 0;
+    if (use_chain)
+        for (int j = 0; j < K; ++j) nact += chain.active[j] ? 1 : 0;
+    if (rank_out) *rank_out = use_chain ? nact : fs.rank;
     if (info) {
         info[0] = passes;
         info[1] = dev;
         info[2] = converged;
-        info[3] = fs.triangular ? 0.0 : 1.0;
-        info[4] = fs.smax;
-        info[5] = fs.smin;
+        info[3] = (use_chain || fs.triangular) ? 0.0 : 1.0;
+        info[4] = use_chain ? chain_norm : fs.smax;                       // chain: bounds, not singular values
+        info[5] = use_chain ? (chain_inv > 0.0 ? 1.0 / chain_inv : 0.0) : fs.smin;
         info[6] = rel_step;
         info[7] = shift;
     }

@@ -52,7 +52,7 @@ int factor_pass(int K, const double* G, int first, double tol, double* Rhat, dou
     for (int j = 0; j < K; ++j)
         if (G[(size_t)j * K + j] > 0.0) act.push_back(j);
     const int n = (int)act.size();
-    if (first) {
+    if (first && Rhat) {
         std::fill(Rhat, Rhat + (size_t)K * K, 0.0);
         for (int j : act) Rhat[(size_t)j * K + j] = 1.0;
     }
@@ -101,6 +101,13 @@ int factor_pass(int K, const double* G, int first, double tol, double* Rhat, dou
     // Rp = U diag(d) on the active block
     for (int a = 0; a < n; ++a)
         for (int b = a; b < n; ++b) Rp[(size_t)act[a] * K + act[b]] = U[(size_t)a * np + b] * d[b];
+    if (!Rhat) return FSNAP_OK;
+    if (first) {
+        // R_hat was the identity on the active block: the product is Rp's active block itself
+        for (int a = 0; a < n; ++a)
+            for (int b = a; b < n; ++b) Rhat[(size_t)act[a] * K + act[b]] = Rp[(size_t)act[a] * K + act[b]];
+        return FSNAP_OK;
+    }
     // R_hat <- Rp R_hat (both upper triangular; inactive rows of R_hat are zero rows and stay so)
     vec out((size_t)n * K, 0.0);
     for (int a = 0; a < n; ++a) {
@@ -117,6 +124,148 @@ int factor_pass(int K, const double* G, int first, double tol, double* Rhat, dou
 }
 
 // ---- the K x K end of dgelsd ---------------------------------------------------------------------------------------
+// ---- factor chain -------------------------------------------------------------------------------------------------
+namespace {
+
+// x <- T^-1 x for an upper triangular T (row-oriented: contiguous dot products)
+void solve_upper(int n, const double* T, double* x) {
+    for (int i = n - 1; i >= 0; --i) {
+        const double* ti = T + (size_t)i * n;
+        double s = x[i];
+        for (int k = i + 1; k < n; ++k) s -= ti[k] * x[k];
+        x[i] = s / ti[i];
+    }
+}
+
+// x <- T^-T x (forward substitution on T^T, written as axpys of the contiguous rows of T)
+void solve_upper_transposed(int n, const double* T, double* x) {
+    for (int i = 0; i < n; ++i) {
+        const double* ti = T + (size_t)i * n;
+        const double xi = x[i] / ti[i];
+        x[i] = xi;
+        if (xi != 0.0)
+            for (int k = i + 1; k < n; ++k) x[k] -= ti[k] * xi;
+    }
+}
+
+// Hager's / Higham's estimate of ||B||_1 for B = T^-1 (transposed = false) or B = T^-T (true): LAPACK dlacon's iteration
+double inverse_norm1_estimate(int n, const double* T, bool transposed) {
+    if (n == 0) return 0.0;
+    auto apply = [&](double* v, bool tr) { (tr != transposed) ? solve_upper_transposed(n, T, v) : solve_upper(n, T, v); };
+    vec x((size_t)n, 1.0 / n), y((size_t)n), zt((size_t)n);
+    double est = 0.0;
+    int jlast = -1;
+    for (int it = 0; it < 5; ++it) {
+        y = x;
+        apply(y.data(), false);                       // y = B x
+        double ny = 0.0;
+        for (double v : y) ny += std::fabs(v);
+        if (!(ny > est) && it > 0) break;
+        est = std::fmax(est, ny);
+        for (int i = 0; i < n; ++i) zt[i] = y[i] >= 0.0 ? 1.0 : -1.0;
+        apply(zt.data(), true);                       // z = B^T sign(y)
+        int j = 0;
+        double zmax = 0.0, ztx = 0.0;
+        for (int i = 0; i < n; ++i) {
+            if (std::fabs(zt[i]) > zmax) {
+                zmax = std::fabs(zt[i]);
+                j = i;
+            }
+            ztx += zt[i] * x[i];
+        }
+        if ((it > 0 && zmax <= ztx) || j == jlast) break;
+        jlast = j;
+        std::fill(x.begin(), x.end(), 0.0);
+        x[j] = 1.0;
+    }
+    // the alternating-sign probe that catches the cases the iteration misses
+    for (int i = 0; i < n; ++i) x[i] = ((i & 1) ? -1.0 : 1.0) * (1.0 + (n > 1 ? (double)i / (n - 1) : 0.0));
+    apply(x.data(), false);
+    double alt = 0.0;
+    for (double v : x) alt += std::fabs(v);
+    return std::fmax(est, 2.0 * alt / (3.0 * n));
+}
+
+}  // namespace
+
+void FactorChain::start(int K_, const double* G) {
+    K = K_;
+    R.clear();
+    active.assign((size_t)K, 0);
+    for (int j = 0; j < K; ++j) active[j] = G[(size_t)j * K + j] > 0.0;
+}
+
+double FactorChain::condition_bound(double* norm_out, double* inv_norm_out) const {
+    double nrm = 1.0, inv = 1.0;
+    vec colsum((size_t)K), dcolsum((size_t)K);
+    for (const vec& Rk : R) {
+        // ||R||_2 <= sqrt(||R||_1 ||R||_inf), both exact (a Frobenius norm would charge a near-identity factor sqrt(K));
+        // the same sweep measures E = R - I the same way
+        std::fill(colsum.begin(), colsum.end(), 0.0);
+        std::fill(dcolsum.begin(), dcolsum.end(), 0.0);
+        double n1 = 0.0, ninf = 0.0, e1n = 0.0, einfn = 0.0;
+        for (int i = 0; i < K; ++i) {
+            const double* ri = Rk.data() + (size_t)i * K;
+            double rs = 0.0, es = 0.0;
+            for (int c = i; c < K; ++c) {
+                const double a = std::fabs(ri[c]), e = std::fabs(ri[c] - (c == i ? 1.0 : 0.0));
+                rs += a;
+                es += e;
+                colsum[c] += a;
+                dcolsum[c] += e;
+            }
+            ninf = std::fmax(ninf, rs);
+            einfn = std::fmax(einfn, es);
+        }
+        for (int c = 0; c < K; ++c) {
+            n1 = std::fmax(n1, colsum[c]);
+            e1n = std::fmax(e1n, dcolsum[c]);
+        }
+        nrm *= std::sqrt(n1 * ninf);
+        const double enorm = std::sqrt(e1n * einfn);           // >= ||R - I||_2
+        if (enorm < 0.5) {
+            inv *= 1.0 / (1.0 - enorm);                        // Neumann series: the factors of the later passes
+        } else {
+            const double e1 = inverse_norm1_estimate(K, Rk.data(), false), einf = inverse_norm1_estimate(K, Rk.data(), true);
+            inv *= 3.0 * std::sqrt(e1 * einf);
+        }
+    }
+    if (norm_out) *norm_out = nrm;
+    if (inv_norm_out) *inv_norm_out = inv;
+    return nrm * inv;
+}
+
+void FactorChain::solve(const double* z, double* beta) const {
+    for (int j = 0; j < K; ++j) beta[j] = active[j] ? z[j] : 0.0;
+    for (size_t k = R.size(); k-- > 0;) solve_upper(K, R[k].data(), beta);      // latest factor first
+    for (int j = 0; j < K; ++j)
+        if (!active[j]) beta[j] = 0.0;
+}
+
+void FactorChain::product(double* Rhat) const {
+    std::fill(Rhat, Rhat + (size_t)K * K, 0.0);
+    if (R.empty()) return;
+    memcpy(Rhat, R[0].data(), (size_t)K * K * sizeof(double));
+    vec out((size_t)K);
+    for (size_t k = 1; k < R.size(); ++k) {
+        const double* Rp = R[k].data();
+        for (int a = 0; a < K; ++a) {              // row a of Rp R_hat needs rows >= a of R_hat only: in place, top down
+            std::fill(out.begin(), out.end(), 0.0);
+            for (int b = a; b < K; ++b) {
+                const double f = Rp[(size_t)a * K + b];
+                if (f == 0.0) continue;
+                const double* r = Rhat + (size_t)b * K;
+                for (int c = b; c < K; ++c) out[c] += f * r[c];
+            }
+            memcpy(Rhat + (size_t)a * K, out.data(), (size_t)K * sizeof(double));
+        }
+    }
+    for (int j = 0; j < K; ++j)
+        if (!active[j]) {
+            for (int c = 0; c < K; ++c) Rhat[(size_t)j * K + c] = 0.0;       // zero row, zero diagonal: "inactive"
+        }
+}
+
 void FactorSolver::prepare(int K_, const double* Rhat, double rcond) {
         K = K_;
         act.clear();

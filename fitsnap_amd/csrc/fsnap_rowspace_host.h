@@ -9,8 +9,25 @@ bool finite_all(const double* p, size_t n);
 // max |G_ij - delta_ij| over the columns with a non-zero diagonal entry
 double gram_deviation(int K, const double* G);
 // one pass: see fsnap_rowspace_host.cpp
+// Rhat may be NULL: the factor is then only returned in Rp (FactorChain keeps the factors apart)
 int factor_pass(int K, const double* G, int first, double tol, double* Rhat, double* Rp, double* dev_out, int* converged,
                 double* shift_out);
+
+// The factors of the passes kept apart: R_hat = R_p ... R_2 R_1 is never formed unless a truncation is needed.  Forming it
+// costs K^3 / 3 flops per pass on one host core -- 110 ms per pass at K = 1595, where the two GPU passes themselves take
+// 14 ms -- while solving through the chain is p back substitutions (K^2 / 2 flops each).
+struct FactorChain {
+    int K = 0;
+    std::vector<std::vector<double>> R;    // K x K, upper triangular, unit rows / columns for inactive columns
+    std::vector<char> active;              // columns with a non-zero diagonal entry of the first Gram matrix
+    void start(int K_, const double* G);
+    void push(const double* Rp) { R.emplace_back(Rp, Rp + (size_t)K * K); }
+    // upper estimate of ||R_hat||_2 ||R_hat^-1||_2: sqrt(||R||_1 ||R||_inf) x (3 x sqrt(est ||R^-1||_1 est ||R^-1||_inf)) per factor,
+    // the 1-norms by Hager / Higham's iteration (a lower bound that is rarely off by more than 3: the safety factor)
+    double condition_bound(double* norm_out, double* inv_norm_out) const;
+    void solve(const double* z, double* beta) const;      // beta = R_1^-1 ... R_p^-1 z, zeros in inactive columns
+    void product(double* Rhat) const;                     // R_hat, with zero diagonal entries for inactive columns
+};
 
 // the K x K end of dgelsd on the accumulated factor R_hat
 struct FactorSolver {

@@ -267,6 +267,16 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K, double* beta, int*
 int fsnap_rowspace_factor(int64_t K, const double* G, int first, double tol, double* Rhat, double* Rp, double* info);
 int fsnap_rowspace_solve(int64_t K, const double* Rhat, const double* z, double rcond, double* beta, int* rank, double* info);
 
+/* The same K x K end for K > 256, where fsnap_lstsq_rows keeps the factors of the passes apart: R = nfac upper triangular
+ * K x K factors, R[0] the first pass (R_hat = R[nfac-1] ... R[0] is NOT formed unless a truncation is needed: the product costs
+ * K^3 / 3 flops per pass on one host core).  beta = pinv_rcond(R_hat) z: by nfac back substitutions when an upper estimate
+ * of cond(R_hat) (sqrt(||R||_1 ||R||_inf) x Hager / Higham 1-norm estimates of the inverses, per factor) shows that no singular value can fall
+ * below rcond sigma_max, through the multiplied-out factor and fsnap_rowspace_solve's path otherwise.  active (may be NULL =
+ * all): columns that take part (zero columns of A_w get beta = 0).  info[4] = {1 if solved through the chain, bound on
+ * ||R_hat||, bound on ||R_hat^-1||, their product}.  Host side, no context needed. */
+int fsnap_rowspace_chain(int64_t K, int64_t nfac, const double* R, const unsigned char* active, const double* z, double rcond,
+                         double* beta, int* rank, double* info);
+
 /* Grouped error statistics of Solver.error_analysis (solver.py:108-133: the function applied to every
  * (Groups, Testing, Row_Type) group of the DataFrame, solver.py:391-405) for the resident rows and weights:
  * cat[m] (host) = category id of each row in [0, ncat) (negative = skip; NULL = the categories of the previous call

@@ -119,3 +119,68 @@ def test_factor_reports_convergence_and_refuses_non_finite_input():
         _capi.rowspace_factor(bad)
     with pytest.raises(ValueError):
         _capi.rowspace_solve(np.eye(3), np.array([1.0, np.inf, 0.0]))
+
+
+def _cholqr_factors(A, passes=2):
+    """Upper triangular factors of CholeskyQR passes on A (numpy), first pass first."""
+    Q, out = A, []
+    for _ in range(passes):
+        G = Q.T @ Q
+        d = np.sqrt(np.diag(G))
+        R = np.linalg.cholesky(G / np.outer(d, d) + 1e-13 * np.eye(len(d))).T * d
+        Q = sl.solve_triangular(R, Q.T, trans="T", lower=False).T
+        out.append(R)
+    return out
+
+
+@pytest.mark.parametrize("K,kappa,expect_chain", [(300, 1e3, True), (400, 1e7, True), (320, 1e11, False)])
+def test_factor_chain_solves_without_the_product(K, kappa, expect_chain):
+    """fsnap_rowspace_chain (what fsnap_lstsq_rows does for K > 256): the factors stay apart; the solve goes through them
+    by back substitution when the condition bound allows, through the multiplied-out factor + the SVD end otherwise.  Either
+    way the answer is pinv(R_hat) z, and the bound must really be an upper bound of cond_2(R_hat)."""
+    rng = np.random.default_rng(K)
+    m = 2 * K
+    U, _ = np.linalg.qr(rng.standard_normal((m, K)))
+    V, _ = np.linalg.qr(rng.standard_normal((K, K)))
+    A = (U * np.logspace(0, -np.log10(kappa), K)) @ V.T
+    factors = _cholqr_factors(A)
+    Rhat = factors[1] @ factors[0]
+    z = rng.standard_normal(K)
+    beta, rank, info = _capi.rowspace_chain(factors, z, 1.0e-13)
+    s = np.linalg.svd(Rhat, compute_uv=False)
+    assert info["cond_bound"] >= s[0] / s[-1]
+    assert bool(info["chain"]) == expect_chain and rank == K
+    ref = np.linalg.solve(Rhat, z)
+    assert np.linalg.norm(beta - ref) <= 1e-6 * np.linalg.norm(ref) * max(1.0, kappa * 1e-10)
+
+
+def test_factor_chain_inactive_columns_and_truncation():
+    rng = np.random.default_rng(9)
+    K = 280
+    A = rng.standard_normal((700, K))
+    A[:, 5] = 0.0                                                  # a zero column: inactive, coefficient 0
+    act = np.ones(K, dtype=np.uint8)
+    act[5] = 0
+    A5 = A.copy()
+    A5[:, 5] = rng.standard_normal(700)                            # any non-singular stand-in for the factorisation
+    factors = _cholqr_factors(A5)
+    for f in factors:                                              # unit row / column for the inactive column, as factor_pass does
+        f[5, :] = 0.0
+        f[:, 5] = 0.0
+        f[5, 5] = 1.0
+    z = rng.standard_normal(K)
+    beta, rank, info = _capi.rowspace_chain(factors, z, 1.0e-13, active=act)
+    assert info["chain"] == 1.0 and rank == K - 1 and beta[5] == 0.0
+    keep = act.astype(bool)
+    Rhat = (factors[1] @ factors[0])[np.ix_(keep, keep)]
+    assert np.allclose(beta[keep], np.linalg.solve(Rhat, z[keep]), rtol=1e-9, atol=1e-12)
+    # an exactly dependent column pair: the bound cannot certify the chain, the product + SVD end drops one direction
+    B = rng.standard_normal((700, K))
+    B[:, 7] = B[:, 3]
+    G = B.T @ B
+    d = np.sqrt(np.diag(G))
+    R = np.linalg.cholesky(G / np.outer(d, d) + 1e-12 * np.eye(K)).T * d
+    beta2, rank2, info2 = _capi.rowspace_chain([R], z, 1.0e-4)         # sigma_min ~ 1e-6 (the shift) is below the cut
+    assert info2["chain"] == 0.0 and rank2 == K - 1 and np.all(np.isfinite(beta2))
+    ref2, _, rank_ref, _ = sl.lstsq(R, z, cond=1.0e-4)
+    assert rank_ref == K - 1 and np.allclose(beta2, ref2, rtol=1e-7, atol=1e-9)
