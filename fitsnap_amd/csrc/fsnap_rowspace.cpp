@@ -36,6 +36,9 @@
 #include "fsnap_kernels.h"
 
 #include "fsnap_rowspace_host.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 using fsnap_rs::FactorChain;
 using fsnap_rs::FactorSolver;
@@ -199,7 +202,17 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
         FSNAP_HIP(hipStreamSynchronize(st), "hipStreamSynchronize");
         return FSNAP_OK;
     };
+    // FSNAP_ROWSPACE_TIMING=1: wall-clock marks of the host phases on stderr
+    const bool timing = getenv("FSNAP_ROWSPACE_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[fsnap_lstsq_rows] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     if ((rc = gather_stats(true))) return rc;
+    mark("statistics of the rows");
     if (have_rows) {
         // (w_eff, w_eff b) of the fit are current now (the launch above packed them if needed)
         FSNAP_HIP(fsnap::launch_qpack((const double*)ctx->wpack.p, ctx->m, (double*)rs->qpack.p, st), "launch fsnap_qpack_k");
@@ -218,6 +231,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
             converged = 1;
             break;
         }
+        mark("factor_pass");
         if (chained) chain.push(Rp.data());
         // padded copy of the factor for the kernel
         std::fill(Rpad, Rpad + (size_t)K16 * K16, 0.0);
@@ -234,7 +248,9 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
         }
         FSNAP_HIP(hipStreamSynchronize(st), "hipStreamSynchronize");      // Rpad is reused by the next pass
         passes = pass;
+        mark("factor upload + TRSM pass");
         if ((rc = gather_stats(false))) return rc;
+        mark("statistics of Q");
         memcpy(z.data(), host + (size_t)K * K, (size_t)K * 8);     // z = Q^T (w b)
     }
     if (!converged) {
@@ -258,6 +274,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
         }
     }
     if (!use_chain) fs.prepare(K, Rhat.data(), rcond);
+    mark("condition bound / prepare");
     auto apply = [&](const double* rhs, double* out) {
         if (use_chain) chain.solve(rhs, out);
         else fs.apply(rhs, out);
@@ -292,6 +309,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
             for (int j = 0; j < K; ++j) beta[j] += dbeta[j];
         }
     }
+    mark("solve + refinement step");
     int nact = 0;
     if (use_chain)
         for (int j = 0; j < K; ++j) nact += chain.active[j] ? 1 : 0;

@@ -20,9 +20,14 @@ using vec = std::vector<double>;
 static const double EPS = std::numeric_limits<double>::epsilon();
 
 bool finite_all(const double* p, size_t n) {
-    double t = 0.0;
-    for (size_t i = 0; i < n; ++i) t += p[i] * 0.0;
-    return t == 0.0;
+    // x * 0 is 0 for finite x and NaN for NaN / Inf; eight independent sums (one dependent chain costs 4 cycles per entry:
+    // 10 ms for the 1595 x 1595 statistics)
+    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8)
+        for (int k = 0; k < 8; ++k) t[k] += p[i + k] * 0.0;
+    for (; i < n; ++i) t[0] += p[i] * 0.0;
+    return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7])) == 0.0;
 }
 
 // max |G_ij - delta_ij| over the columns with a non-zero diagonal entry: how far Q is from orthonormal columns
@@ -72,7 +77,9 @@ int factor_pass(int K, const double* G, int first, double tol, double* Rhat, dou
     vec d(n);
     for (int a = 0; a < n; ++a) d[a] = std::sqrt(G[(size_t)act[a] * K + act[a]]);
     const int np = (n >= 48 && (n & 31)) ? ((n + 31) & ~31) : n;
-    vec S((size_t)np * np), U((size_t)np * np);
+    // scratch of two np x np matrices, kept between calls (a fresh 20 MB vector is 5 ms of page faults at K = 1595)
+    static thread_local vec S, U;
+    S.assign((size_t)np * np, 0.0);
     double fro = 0.0;
     for (int a = 0; a < n; ++a)
         for (int b = a; b < n; ++b) {

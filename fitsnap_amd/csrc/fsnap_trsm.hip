@@ -20,32 +20,35 @@
 #include "fsnap_device_common.h"
 #include "fsnap_kernels.h"
 
-template <bool FIRST>
+// TR = 16-row tiles per wave (4: 64 rows per wave; 2, 1: shorter tiles for short matrices -- the quadratic-SNAP shape
+// 15 213 x 1 595 gives only 238 waves of 64 rows for 1024 SIMDs, each with 79 200 MFMAs = 2.1 ms of matrix pipe to itself)
+template <bool FIRST, int TR>
 __global__ __launch_bounds__(64, FIRST ? 2 : 3) void fsnap_trsm_rows_k(const double* __restrict__ src, int64_t lds_,
                                                         const double* __restrict__ wpack, double* Q, int64_t ldq,
                                                         int64_t m, int K, const double* __restrict__ R, int K16) {
-    __shared__ double X[64][17];                  // 64 rows x 16 columns of the current block (+1: no bank conflicts)
+    constexpr int ROWS = 16 * TR;
+    __shared__ double X[ROWS][17];                // ROWS rows x 16 columns of the current block (+1: no bank conflicts)
     __shared__ double Rs[16][32];                 // diagonal block R_JJ, zero-padded to 32 columns (read by all lanes at the same
                                                   // address: a broadcast)
     const int lane = threadIdx.x, e = lane & 15, g = lane >> 4;
-    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
     const int NB = K16 >> 4;
     // first pass: X = diag(w_eff) A; a zero weight (masked row, zero weight) gives a zero row of Q whatever the row
     // of A holds (NaN in masked rows is legal input).  w_eff is re-read per column block (cached; keeps registers free).
     for (int jb = 0; jb < NB; ++jb) {
         const int col = jb * 16 + e;
-        d4 acc[4];
+        d4 acc[TR];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int t = 0; t < TR; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
         // S_J accumulation over the solved blocks: MFMA operands A[i = lane & 15][k = lane >> 4], B[k][j = lane & 15].
         // The k index of an MFMA is free as long as both operands agree: k-step s of lane group g takes column 4 g + s
         // of the block (not 4 s + g), so a lane needs FOUR ADJACENT doubles of its row -- two 16-byte loads per row
         // tile instead of four 8-byte ones, whole 32-byte sectors.  (A solved block kb < jb <= NB - 1 is never the
         // partial last block: no column guard.)
         for (int kb = 0; kb < jb; ++kb) {
-            d2u qa[4], qb[4];
+            d2u qa[TR], qb[TR];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < TR; ++t) {
                 const int64_t r = row0 + t * 16 + e;
                 const double* p = Q + (r < m ? r : 0) * ldq + kb * 16 + 4 * g;
                 qa[t] = *reinterpret_cast<const d2u*>(p);
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(64, FIRST ? 2 : 3) void fsnap_trsm_rows_k(const dou
             for (int s = 0; s < 4; ++s) {
                 const double bf = R[(size_t)(kb * 16 + 4 * g + s) * K16 + col];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < TR; ++t) {
                     const double af = (s < 2) ? qa[t][s & 1] : qb[t][s & 1];
                     acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[t], 0, 0, 0);
                 }
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(64, FIRST ? 2 : 3) void fsnap_trsm_rows_k(const dou
         }
         // X_J - S_J in the accumulator layout (row = (lane >> 4) + 4 v, column = lane & 15) -> LDS
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < TR; ++t)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int lr = t * 16 + g + 4 * v;
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(64, FIRST ? 2 : 3) void fsnap_trsm_rows_k(const dou
         // in 16 registers; each step shifts it left by one while updating (x[t] = x[t+1] - q R[i][i+1+t]), so the pivot is
         // always x[0] and the loop can stay rolled (fully unrolled, the compiler hoists all 120 broadcasts of R_JJ and
         // spills); the zero padding of Rs makes the reads past column 15 harmless.
-        {
+        if (lane < ROWS) {
             double x[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) x[j] = X[lane][j];
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(64, FIRST ? 2 : 3) void fsnap_trsm_rows_k(const dou
         __syncthreads();
         // store the block from LDS in the accumulator layout: 16 lanes write 16 adjacent doubles of a row
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < TR; ++t)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int lr = t * 16 + g + 4 * v;
@@ -306,10 +309,17 @@ hipError_t launch_trsm_rows(const double* src, int64_t lds, const double* wpack,
 #undef FSNAP_TRSM_ACC
         return hipGetLastError();
     }
-    if (wpack)
-        hipLaunchKernelGGL(fsnap_trsm_rows_k<true>, dim3((unsigned)nb), dim3(64), 0, st, src, lds, wpack, Q, ldq, m, K, R, K16);
-    else
-        hipLaunchKernelGGL(fsnap_trsm_rows_k<false>, dim3((unsigned)nb), dim3(64), 0, st, src, lds, wpack, Q, ldq, m, K, R, K16);
+    // kernel 13: 64-row tiles when there are rows for two rounds of waves, shorter tiles for short matrices
+#define FSNAP_TRSM_ROWS(TRV)                                                                                                 \
+    {                                                                                                                        \
+        const dim3 grid((unsigned)((m + 16 * TRV - 1) / (16 * TRV))), block(64);                                             \
+        if (wpack) hipLaunchKernelGGL((fsnap_trsm_rows_k<true, TRV>), grid, block, 0, st, src, lds, wpack, Q, ldq, m, K, R, K16); \
+        else hipLaunchKernelGGL((fsnap_trsm_rows_k<false, TRV>), grid, block, 0, st, src, lds, wpack, Q, ldq, m, K, R, K16);  \
+    }
+    if (m >= 64 * 2048) FSNAP_TRSM_ROWS(4)
+    else if (m >= 32 * 2048) FSNAP_TRSM_ROWS(2)
+    else FSNAP_TRSM_ROWS(1)
+#undef FSNAP_TRSM_ROWS
     return hipGetLastError();
 }
 

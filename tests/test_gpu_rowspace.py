@@ -200,3 +200,39 @@ def test_row_space_through_a_one_rank_communicator():
     assert rank0 == rank1 == 48 and info["converged"] == 1.0
     assert np.array_equal(plain, coll)
     ctx.close()
+
+
+@pytest.mark.parametrize("m", [9000, 70001, 140003])
+def test_lstsq_rows_general_k_kernel_every_row_tile_height(m):
+    # kernel 13 (K > 128) runs 16-, 32- or 64-row tiles per wave depending on the number of rows (short matrices would
+    # leave most SIMDs idle with 64-row tiles); K = 160 also takes the factor chain of the host end (K <= 256: product)
+    K = 160
+    r = np.random.default_rng(m)
+    A = conditioned(m, K, 1e6, "geometric", 3) * (10.0 ** r.uniform(-1, 1, size=K))
+    b = A @ r.standard_normal(K) + 1e-3 * r.standard_normal(m)
+    w = r.uniform(0.5, 2.0, m)
+    ctx = _capi.HipContext(0)
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w)
+    beta, rank, info = ctx.lstsq_rows(1.0e-13)
+    ref = orc.svd_fit(A, b, w)
+    assert rank == K and info["converged"] == 1.0
+    kw = np.linalg.cond(w[:, None] * A)
+    assert np.linalg.norm(beta - ref) <= max(1e-6, 50 * kw * EPS) * np.linalg.norm(ref)
+    ctx.close()
+
+
+def test_lstsq_rows_factor_chain_path_on_the_gpu():
+    # K = 300 > 256: the factors of the passes stay apart on the host (FactorChain); ill-conditioned enough for two passes
+    m, K = 20000, 300
+    A = conditioned(m, K, 1e7, "geometric", 8)
+    r = np.random.default_rng(1)
+    b = A @ r.standard_normal(K) + 1e-3 * r.standard_normal(m)
+    ctx = _capi.HipContext(0)
+    ctx.upload_rows(A, b)
+    ctx.set_weights(np.ones(m))
+    beta, rank, info = ctx.lstsq_rows(1.0e-13)
+    ref = orc.svd_fit(A, b, np.ones(m))
+    assert rank == K and info["converged"] == 1.0 and info["svd"] == 0.0 and info["passes"] >= 2
+    assert np.linalg.norm(beta - ref) <= max(1e-6, 50 * 1e7 * EPS) * np.linalg.norm(ref)
+    ctx.close()
