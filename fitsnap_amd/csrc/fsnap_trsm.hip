@@ -23,7 +23,7 @@
 // TR = 16-row tiles per wave (4: 64 rows per wave; 2, 1: shorter tiles for short matrices -- the quadratic-SNAP shape
 // 15 213 x 1 595 gives only 238 waves of 64 rows for 1024 SIMDs, each with 79 200 MFMAs = 2.1 ms of matrix pipe to itself)
 template <bool FIRST, int TR>
-__global__ __launch_bounds__(64, FIRST ? 2 : 3) void fsnap_trsm_rows_k(const double* __restrict__ src, int64_t lds_,
+__global__ __launch_bounds__(64, (FIRST || TR == 4) ? 2 : 3) void fsnap_trsm_rows_k(const double* __restrict__ src, int64_t lds_,
                                                         const double* __restrict__ wpack, double* Q, int64_t ldq,
                                                         int64_t m, int K, const double* __restrict__ R, int K16) {
     constexpr int ROWS = 16 * TR;
@@ -45,28 +45,46 @@ __global__ __launch_bounds__(64, FIRST ? 2 : 3) void fsnap_trsm_rows_k(const dou
         // of the block (not 4 s + g), so a lane needs FOUR ADJACENT doubles of its row -- two 16-byte loads per row
         // tile instead of four 8-byte ones, whole 32-byte sectors.  (A solved block kb < jb <= NB - 1 is never the
         // partial last block: no column guard.)
-        for (int kb = 0; kb < jb; ++kb) {
-            d2u qa[TR], qb[TR];
+        // software pipeline: the operands of block kb + 1 are requested before the MFMAs of block kb are issued (as a
+        // plain loop every trip paid an L2 round trip in front of its 4 TR MFMAs)
+        d2u qa[TR], qb[TR];
+        double bf[4];
+        auto fetch = [&](int kb, d2u (&a)[TR], d2u (&b)[TR], double (&f)[4]) {
 #pragma unroll
             for (int t = 0; t < TR; ++t) {
                 const int64_t r = row0 + t * 16 + e;
                 const double* p = Q + (r < m ? r : 0) * ldq + kb * 16 + 4 * g;
-                qa[t] = *reinterpret_cast<const d2u*>(p);
-                qb[t] = *reinterpret_cast<const d2u*>(p + 2);
+                a[t] = *reinterpret_cast<const d2u*>(p);
+                b[t] = *reinterpret_cast<const d2u*>(p + 2);
                 if (r >= m) {
-                    qa[t] = (d2u){0.0, 0.0};
-                    qb[t] = (d2u){0.0, 0.0};
+                    a[t] = (d2u){0.0, 0.0};
+                    b[t] = (d2u){0.0, 0.0};
                 }
             }
 #pragma unroll
+            for (int s = 0; s < 4; ++s) f[s] = R[(size_t)(kb * 16 + 4 * g + s) * K16 + col];
+        };
+        if (jb > 0) fetch(0, qa, qb, bf);
+        for (int kb = 0; kb < jb; ++kb) {
+            d2u na[TR], nb2[TR];
+            double nf[4];
+            const int kn = kb + 1 < jb ? kb + 1 : kb;          // (the last trip re-reads its own block: in range, unused)
+            fetch(kn, na, nb2, nf);
+#pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const double bf = R[(size_t)(kb * 16 + 4 * g + s) * K16 + col];
 #pragma unroll
                 for (int t = 0; t < TR; ++t) {
                     const double af = (s < 2) ? qa[t][s & 1] : qb[t][s & 1];
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf[s], acc[t], 0, 0, 0);
                 }
             }
+#pragma unroll
+            for (int t = 0; t < TR; ++t) {
+                qa[t] = na[t];
+                qb[t] = nb2[t];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bf[s] = nf[s];
         }
         // X_J - S_J in the accumulator layout (row = (lane >> 4) + 4 v, column = lane & 15) -> LDS
 #pragma unroll
@@ -309,15 +327,17 @@ hipError_t launch_trsm_rows(const double* src, int64_t lds, const double* wpack,
 #undef FSNAP_TRSM_ACC
         return hipGetLastError();
     }
-    // kernel 13: 64-row tiles when there are rows for two rounds of waves, shorter tiles for short matrices
+    // kernel 13: 64-row tiles when there is a wave of them for every SIMD, shorter tiles for short matrices
 #define FSNAP_TRSM_ROWS(TRV)                                                                                                 \
     {                                                                                                                        \
         const dim3 grid((unsigned)((m + 16 * TRV - 1) / (16 * TRV))), block(64);                                             \
         if (wpack) hipLaunchKernelGGL((fsnap_trsm_rows_k<true, TRV>), grid, block, 0, st, src, lds, wpack, Q, ldq, m, K, R, K16); \
         else hipLaunchKernelGGL((fsnap_trsm_rows_k<false, TRV>), grid, block, 0, st, src, lds, wpack, Q, ldq, m, K, R, K16);  \
     }
-    if (m >= 64 * 2048) FSNAP_TRSM_ROWS(4)
-    else if (m >= 32 * 2048) FSNAP_TRSM_ROWS(2)
+    // (measured: 100 000 x 256 0.45 ms with 64-row tiles, 0.62 ms with 32-row tiles; 15 213 x 1 595 6.0 / 3.5 ms with 64- /
+    // 16-row tiles)
+    if (m >= 64 * 1024) FSNAP_TRSM_ROWS(4)
+    else if (m >= 32 * 1024) FSNAP_TRSM_ROWS(2)
     else FSNAP_TRSM_ROWS(1)
 #undef FSNAP_TRSM_ROWS
     return hipGetLastError();
