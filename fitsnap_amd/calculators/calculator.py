@@ -14,6 +14,8 @@ Differences from the reference, by design:
 """
 from __future__ import annotations
 
+import itertools
+
 import numpy as np
 
 from ..parallel_tools import DistributedList
@@ -123,13 +125,18 @@ class Calculator:
         if self.pt.stubs != 1:
             # the arrays stay rank-local (one process per GPU): keep the lists that describe them
             self.pt.local_lists = {k: v.get_list() for k, v in self.pt.fitsnap_dict.items() if isinstance(v, DistributedList)}
-        for key in self.pt.fitsnap_dict.keys():
-            if isinstance(self.pt.fitsnap_dict[key], DistributedList):
-                self.pt.gather_fitsnap(key)
-                if self.pt.fitsnap_dict[key] is not None and self.pt.stubs != 1:
-                    self.pt.fitsnap_dict[key] = [item for sublist in self.pt.fitsnap_dict[key] for item in sublist]
-                elif self.pt.fitsnap_dict[key] is not None:
-                    self.pt.fitsnap_dict[key] = self.pt.fitsnap_dict[key].get_list()
+        single_process = self.pt.stubs == 1
+        for key, held in list(self.pt.fitsnap_dict.items()):
+            if not isinstance(held, DistributedList):
+                continue
+            self.pt.gather_fitsnap(key)
+            gathered = self.pt.fitsnap_dict[key]
+            if gathered is None:                       # a rank that does not receive the gathered lists
+                continue
+            if single_process:
+                self.pt.fitsnap_dict[key] = gathered.get_list()
+            else:                                      # one list per rank, in rank order: concatenate
+                self.pt.fitsnap_dict[key] = list(itertools.chain.from_iterable(gathered))
 
     def extras(self):
         """Descriptors.npy / Truth-Ref.npy / Weights.npy / FitSNAP.df dumps — the on-disk
@@ -150,8 +157,9 @@ class Calculator:
             df = pd.DataFrame(sa["a"].array)
             df["truths"] = sa["b"].array.tolist()
             df["weights"] = sa["w"].array.tolist()
-            for key in self.pt.fitsnap_dict.keys():
-                if isinstance(self.pt.fitsnap_dict[key], list) and len(self.pt.fitsnap_dict[key]) == len(df.index):
-                    df[key] = self.pt.fitsnap_dict[key]
+            nrows = len(df.index)
+            for key, labels in self.pt.fitsnap_dict.items():
+                if isinstance(labels, list) and len(labels) == nrows:      # per-row label lists become columns
+                    df[key] = labels
             df.to_pickle(ex.dataframe_file)
             del df

@@ -83,16 +83,22 @@ class LammpsBase(Calculator):
         raise NotImplementedError
 
     # -- atom extraction (lammps_base.py:233-253) -----------------------------------------
+    def _per_atom_integers(self, field, num_atoms):
+        """One integer per atom (``id`` / ``type``) as a flat array; LAMMPS Python modules differ in which numpy accessor
+        serves integer fields, so the dedicated one is the second choice."""
+        accessors = (self._lmp.numpy.extract_atom, getattr(self._lmp.numpy, "extract_atom_iarray", None))
+        failure = None
+        for accessor in accessors:
+            if accessor is None:
+                continue
+            try:
+                return accessor(name=field, nelem=num_atoms).ravel()
+            except Exception as err:           # noqa: BLE001 - whatever the binding raises, try the other accessor
+                failure = err
+        raise failure
+
     def _extract_atom_ids(self, num_atoms):
-        try:
-            ids = self._lmp.numpy.extract_atom(name="id", nelem=num_atoms).ravel()
-        except Exception:
-            ids = self._lmp.numpy.extract_atom_iarray(name="id", nelem=num_atoms).ravel()
-        return ids
+        return self._per_atom_integers("id", num_atoms)
 
     def _extract_atom_types(self, num_atoms):
-        try:
-            types = self._lmp.numpy.extract_atom(name="type", nelem=num_atoms).ravel()
-        except Exception:
-            types = self._lmp.numpy.extract_atom_iarray(name="type", nelem=num_atoms).ravel()
-        return types
+        return self._per_atom_integers("type", num_atoms)

@@ -529,18 +529,16 @@ class ParallelTools:
             raise IndexError("{} not found in shared objects".format(name))
         if name == "a":
             raise NotImplementedError("Slice A using new_slice_a")
-        s = slice(self._sub_rank, None, self._sub_size)
-        self.shared_arrays[name].sliced_array = self.shared_arrays[name].array[s][:]
+        shared = self.shared_arrays[name]
+        shared.sliced_array = shared.array[self._sub_rank::self._sub_size]
 
     def split_by_node(self, obj):
         """Round-robin split over ranks (parallel_tools.py:543-550): config i -> rank i % size."""
-        if isinstance(obj, list):
-            return obj[self._node_index::self._number_of_nodes]
+        mine = slice(self._node_index, None, self._number_of_nodes)
         if isinstance(obj, dict):
-            for key in obj:
-                obj[key] = obj[key][self._node_index::self._number_of_nodes]
+            obj.update({key: seq[mine] for key, seq in obj.items()})       # in place, like the reference
             return obj
-        return obj
+        return obj[mine] if isinstance(obj, list) else obj
 
     def new_slice_a(self, a_len=None):
         """Row-offset table (parallel_tools.py:594-651).  One process per GPU: every rank owns
@@ -575,17 +573,15 @@ class ParallelTools:
         lmp.close()
 
     def initialize_lammps(self, lammpslog=0, printlammps=0):
-        cmds = ["-screen", "none"]
-        if not lammpslog:
-            cmds += ["-log", "none"]
-        self._lmp = self._lammps_class()(cmdargs=cmds)
+        quiet = ("-screen", "none") + (() if lammpslog else ("-log", "none"))
+        self._lmp = self._lammps_class()(cmdargs=list(quiet))
         return self._lmp
 
     def close_lammps(self):
-        if self._lmp is not None:
-            self._lmp.close()
-            self._lmp = None
-        return self._lmp
+        handle, self._lmp = self._lmp, None
+        if handle is not None:
+            handle.close()
+        return None
 
     def exception(self, err):
         """Abort path (parallel_tools.py:840-860): no MPI.Abort here — re-raise."""
