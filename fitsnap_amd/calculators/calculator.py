@@ -40,7 +40,7 @@ class Calculator:
     def get_width(self):
         pass
 
-    def create_dicts(self, nconfigs):
+    def create_dicts(self, nconfigs: int) -> None:
         """calculator.py:27-38."""
         self.pt.add_2_fitsnap("Groups", DistributedList(nconfigs))
         self.pt.add_2_fitsnap("Configs", DistributedList(nconfigs))
@@ -96,13 +96,13 @@ class Calculator:
             self._rows_on_device = True
         self._batch = None
 
-    def process_configs(self, data, i):
+    def process_configs(self, data: dict, i: int):
         pass
 
-    def preprocess_configs(self, data, i):
+    def preprocess_configs(self, data: dict, i: int):
         pass
 
-    def preprocess_allocate(self, nconfigs):
+    def preprocess_allocate(self, nconfigs: int):
         pass
 
     def flush_rows(self):

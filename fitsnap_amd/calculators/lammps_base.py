@@ -41,7 +41,7 @@ class LammpsBase(Calculator):
         self._row_index = 0
 
     # -- per-configuration driver (lammps_base.py:52-125) --------------------------------
-    def process_configs(self, data, i):
+    def process_configs(self, data: dict, i: int):
         self._data = data
         self._i = i
         self._initialize_lammps()
@@ -52,7 +52,7 @@ class LammpsBase(Calculator):
         finally:
             self._lmp = self.pt.close_lammps()
 
-    def process_single(self, data, i=0):
+    def process_single(self, data: dict, i: int = 0):
         """(a, b, w) of ONE configuration without touching the shared arrays
         (lammps_base.py:101-125) — the transpose-trick feed."""
         self._data = data
@@ -66,7 +66,7 @@ class LammpsBase(Calculator):
             self._lmp = self.pt.close_lammps()
         return a, b, w
 
-    def _initialize_lammps(self, printlammps=0):
+    def _initialize_lammps(self, printlammps: int = 0):
         self._lmp = self.pt.initialize_lammps(getattr(self.config.args, "lammpslog", 0), printlammps)
 
     def _prepare_lammps(self):
@@ -97,8 +97,8 @@ class LammpsBase(Calculator):
                 failure = err
         raise failure
 
-    def _extract_atom_ids(self, num_atoms):
+    def _extract_atom_ids(self, num_atoms: int):
         return self._per_atom_integers("id", num_atoms)
 
-    def _extract_atom_types(self, num_atoms):
+    def _extract_atom_types(self, num_atoms: int):
         return self._per_atom_integers("type", num_atoms)

@@ -56,7 +56,7 @@ class DistributedList:
 
     __slots__ = ("_items",)
 
-    def __init__(self, proc_length):
+    def __init__(self, proc_length: int):
         self._items = [" "] * int(proc_length)
 
     def __len__(self):
@@ -110,16 +110,16 @@ class StubsArray:
         return self.array.nbytes
 
     # length getters of the MPI variant (parallel_tools.py:1014-1028)
-    def get_storage_length(self):
+    def get_storage_length(self) -> int:
         return self._length
 
-    def get_scraped_length(self):
+    def get_scraped_length(self) -> int:
         return self._length
 
-    def get_node_length(self):
+    def get_node_length(self) -> int:
         return self._length
 
-    def get_total_length(self):
+    def get_total_length(self) -> int:
         return self._length
 
 
@@ -168,16 +168,16 @@ class SharedArray(StubsArray):
     def get_memory(self):
         return self._nbytes
 
-    def get_scraped_length(self):
+    def get_scraped_length(self) -> int:
         return self._scraped_length
 
-    def get_node_length(self):
+    def get_node_length(self) -> int:
         return self._node_length
 
-    def get_total_length(self):
+    def get_total_length(self) -> int:
         return self._total_length
 
-    def multinode_lengths(self):
+    def multinode_lengths(self) -> None:
         """Total row count over ranks (reference: ScaLAPACK bookkeeping,
         parallel_tools.py:1030-1044).  Rows never move between ranks here."""
         pt = self._comms
@@ -370,7 +370,7 @@ class ParallelTools:
     def get_node(self):
         return self._node_index
 
-    def get_number_of_nodes(self):
+    def get_number_of_nodes(self) -> int:
         return self._number_of_nodes
 
     def _set_seed(self):
@@ -380,14 +380,14 @@ class ParallelTools:
     def get_seed(self):
         return self._seed
 
-    def single_print(self, *args, **kw):
+    def single_print(self, *args, **kw) -> None:
         if self._rank == 0:
             _printf(*args, file=self._fp)
 
-    def sub_print(self, *args, **kw):
+    def sub_print(self, *args, **kw) -> None:
         _printf("Node", self._node_index, ":", *args, file=self._fp)
 
-    def all_print(self, *args, **kw):
+    def all_print(self, *args, **kw) -> None:
         _printf("Rank", self._rank, ":", *args, file=self._fp)
 
     def _only_if(self, active, method):
@@ -462,7 +462,7 @@ class ParallelTools:
             return
         self.fitsnap_dict[name] = self.allgather_object(self.fitsnap_dict[name])
 
-    def get_ncpn(self, nconfigs):
+    def get_ncpn(self, nconfigs: int):
         """Number of configurations over all ranks (parallel_tools.py:562-577)."""
         return int(round(self.allreduce_scalar(nconfigs))) if not self.stubs else nconfigs
 
@@ -506,7 +506,7 @@ class ParallelTools:
         else:
             self.shared_arrays[name] = SharedArray(size1, size2=size2, dtype=dtype)
 
-    def add_2_fitsnap(self, name, an_object):
+    def add_2_fitsnap(self, name: str, an_object) -> None:
         if not isinstance(name, str):
             raise TypeError("name must be a string")
         if self.check_fitsnap_exist and name in self.fitsnap_dict:
@@ -524,7 +524,7 @@ class ParallelTools:
             self._hip.close()                  # fsnap_ctx_destroy leaves the RCCL communicator first
             self._hip = None
 
-    def slice_array(self, name):
+    def slice_array(self, name: str) -> None:
         if name not in self.shared_arrays:
             raise IndexError("{} not found in shared objects".format(name))
         if name == "a":
@@ -566,13 +566,13 @@ class ParallelTools:
                                "(this repository replaces the POST-LAMMPS path only)") from e
         return lammps
 
-    def check_lammps(self, lammps_noexceptions=0):
+    def check_lammps(self, lammps_noexceptions: int = 0) -> None:
         lmp = self._lammps_class()(cmdargs=["-screen", "none", "-log", "none"])
         if not (lmp.has_exceptions or lammps_noexceptions):
             raise Exception("Fitting interrupted! LAMMPS not compiled with C++ exceptions handling enabled")
         lmp.close()
 
-    def initialize_lammps(self, lammpslog=0, printlammps=0):
+    def initialize_lammps(self, lammpslog: int = 0, printlammps: int = 0):
         quiet = ("-screen", "none") + (() if lammpslog else ("-log", "none"))
         self._lmp = self._lammps_class()(cmdargs=list(quiet))
         return self._lmp
