@@ -36,6 +36,13 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert sorted(_capi.SIGNATURES) == declared
 
 
+def test_integration_document_names_every_entry_point():
+    # INTEGRATION.md is the reference-side binding guide: an entry point that is not in it cannot be bound
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [name for name in _declared_functions() if name not in doc]
+    assert not missing, f"INTEGRATION.md does not mention {missing}"
+
+
 def test_no_gpu_means_loud_failure():
     if _capi.device_count() > 0:
         pytest.skip("a GPU is present")
