@@ -22,6 +22,7 @@ OK = 0
 E_ARG, E_HIP, E_STATE, E_NOMEM = -1, -2, -3, -4
 NUM_NOT_SPD, NUM_SINGULAR, NUM_NONFINITE = 1, 2, 3
 SOLVE_CHOL, SOLVE_LSTSQ, SOLVE_RIDGE, SOLVE_RIDGE_INV = 0, 1, 2, 3
+SOLVE_LSTSQ_PROBE, SOLVE_RIDGE_PROBE = 4, 5     # same, but an unresolved system comes back at once with rank = -1
 COMM_ID_BYTES = 128
 REDUCE_SUM, REDUCE_MAX, REDUCE_MIN = 0, 1, 2
 

@@ -261,11 +261,48 @@ class Solver:
         self.last_statistics = (G, c, s)
         return G, c, s
 
+    LAPACK_FALLBACK_K = 256     # above this the truncating fallback of a K x K solve runs in LAPACK (numpy.linalg.eigh)
+
     def _solve(self, kind, param, G, c):
         """Host K x K solve on statistics already on the host."""
-        beta, rank, rcond = _capi.solve(kind, param, G, c)
+        K = len(c)
+        probe = {_capi.SOLVE_LSTSQ: _capi.SOLVE_LSTSQ_PROBE, _capi.SOLVE_RIDGE: _capi.SOLVE_RIDGE_PROBE}.get(kind)
+        if probe is not None and K > self.LAPACK_FALLBACK_K:
+            beta, rank, rcond = _capi.solve(probe, param, G, c)
+            if rank < 0:
+                beta, rank = self._truncated_eigen_solve(kind, param, G, c)
+        else:
+            beta, rank, rcond = _capi.solve(kind, param, G, c)
         self.last_rank, self.last_rcond = rank, rcond
         return beta
+
+    @staticmethod
+    def _truncated_eigen_solve(kind, param, G, c):
+        """The library's fallback for statistics no Cholesky resolves (``fsnap_solve``: eigenvalues below the cut
+        dropped -- gelsd's truncation seen through G for LSTSQ, sklearn Ridge's SVD fallback for RIDGE), with LAPACK's
+        symmetric eigensolver in place of the library's cyclic Jacobi sweeps, which take O(K^3) each on one core
+        (58 s at K = 1595 against ~1 s here).  Returns (beta, rank)."""
+        G = np.asarray(G, dtype=np.float64)
+        c = np.asarray(c, dtype=np.float64)
+        K = len(c)
+        ridge = kind in (_capi.SOLVE_RIDGE, _capi.SOLVE_RIDGE_PROBE)
+        alpha = float(param) if ridge else 0.0
+        # exactly-zero columns (zero row and column of a Gram matrix, c_j = 0): beta_j = 0 with or without a ridge term;
+        # left in, LAPACK's tridiagonalisation smears their unit eigenvectors over the other near-null directions
+        keep = np.diag(G) != 0.0
+        beta = np.zeros(K)
+        n = int(np.count_nonzero(keep))
+        if n == 0:
+            return beta, 0
+        M = 0.5 * (G[np.ix_(keep, keep)] + G[np.ix_(keep, keep)].T)
+        M[np.diag_indices(n)] += alpha
+        ev, V = np.linalg.eigh(M)
+        eps = np.finfo(np.float64).eps
+        cut = 4.0 * n * eps if ridge else max(float(param) ** 2 if param > 0 else 0.0, 4.0 * n * eps)
+        used = ev > cut * np.max(np.abs(ev))
+        Vu = V[:, used]
+        beta[keep] = Vu @ ((Vu.T @ c[keep]) / ev[used])
+        return beta, int(np.count_nonzero(used))
 
     def _fit_and_solve(self, kind, param, a=None, b=None, w=None, fs_dict=None, trainall=False):
         """The latency path of SVD / RIDGE: the statistics stay in HBM, the K x K system is solved through
@@ -300,6 +337,18 @@ class Solver:
             beta, rank, rcond, ptr = ctx.fit_resident(kind, param)      # kernel + reduction + K x K solve, one library call
         self._stats_dev = (ctx, ptr, K)
         self.last_rank, self.last_rcond = rank, rcond
+        return beta
+
+    def _resolve_probe(self, kind, param, beta):
+        """After a ``*_PROBE`` solve that came back unresolved (rank -1) and with no better path to take: finish with the
+        truncating solve on the downloaded statistics (LAPACK for large K).  Same on every rank."""
+        if self.last_rank is None or self.last_rank >= 0:
+            return beta
+        G, c, _ = self.last_statistics
+        base = _capi.SOLVE_LSTSQ if kind == _capi.SOLVE_LSTSQ_PROBE else _capi.SOLVE_RIDGE
+        rcond = self.last_rcond
+        beta = self._solve(base, param, G, c)
+        self.last_rcond = rcond if rcond is not None else self.last_rcond
         return beta
 
     def _rows_on_device(self):

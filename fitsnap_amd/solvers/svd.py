@@ -40,14 +40,19 @@ class SVD(Solver):
         # every rank contributes its rows' statistics; the coefficients are published on rank 0 (svd.py:33)
         if not ("EXTRAS" in self.config.sections and self.config.sections["EXTRAS"].apply_transpose):
             self.last_row_space = None
-            fit = self._fit_and_solve(_capi.SOLVE_LSTSQ, self.RCOND, a, b, w, fs_dict, trainall)
+            # PROBE: a system the Cholesky factorisations cannot resolve comes back at once (rank -1) instead of going
+            # through the library's eigen-truncation of G -- that answer would be discarded for the row-space solve anyway,
+            # and at K = 1595 the Jacobi sweeps behind it take a minute
+            fit = self._fit_and_solve(_capi.SOLVE_LSTSQ_PROBE, self.RCOND, a, b, w, fs_dict, trainall)
             K = len(fit)
             on_gpu = (pt.comm_kind != "torch" or not pt.multi) and (self._rows_on_device() or pt.multi)
             if self.row_space and on_gpu and self._needs_row_space(K):
                 # ill-conditioned or rank deficient: lstsq's answer lives in the rows, not in the K x K statistics
                 fit = self._row_space_fit(K, self.RCOND)
-            elif self.refine_steps and self.last_rank == K:
-                fit = self._refine(fit, _capi.SOLVE_LSTSQ, self.RCOND, self.refine_steps)
+            else:
+                fit = self._resolve_probe(_capi.SOLVE_LSTSQ_PROBE, self.RCOND, fit)
+                if self.refine_steps and self.last_rank == K:
+                    fit = self._refine(fit, _capi.SOLVE_LSTSQ, self.RCOND, self.refine_steps)
             if pt._rank == 0:
                 self.fit = fit
             return

@@ -99,6 +99,35 @@ def test_quadratic_snap_shape_at_full_size():
     pt.free()
 
 
+def test_quadratic_snap_shape_ill_conditioned_takes_the_row_space_path():
+    # the same shape with kappa(A_w) = 1e9 (descriptor products of a quadratic model are nearly dependent): the SVD solver
+    # must leave the normal equations for the row-space solve (K > 256: factors kept apart on the host, 16-row tiles in the
+    # orthogonalisation kernel) and still match lstsq(1e-13) on the rows -- and must get there quickly: the K x K solve is
+    # asked for with FSNAP_SOLVE_LSTSQ_PROBE, so the statistics the Cholesky cannot resolve come straight back instead of
+    # going through the library's Jacobi eigen-truncation first (58 s at this K before that)
+    import time
+    m, K = 4_001, 1_595
+    rng = np.random.default_rng(1595)
+    U, _ = np.linalg.qr(rng.standard_normal((m, K)))
+    V, _ = np.linalg.qr(rng.standard_normal((K, K)))
+    A = (U * np.logspace(0, -9, K)) @ V.T
+    b = A @ rng.standard_normal(K) + 1e-4 * rng.standard_normal(m)
+    w = rng.uniform(0.5, 2.0, m)
+    pt, sol = make_solver("SVD")
+    t0 = time.perf_counter()
+    sol.perform_fit(A, b, w, trainall=True)
+    assert time.perf_counter() - t0 < 10.0
+    info = sol.last_row_space
+    assert info is not None and info["converged"] == 1.0 and sol.last_rank == K
+    ref = orc.svd_fit(A, b, w)
+    aw, bw = w[:, None] * A, w * b
+    kw = 2.0 * 1e9 / 0.5                                              # kappa(A) x the spread of the row weights: an upper bound
+    assert np.linalg.norm(sol.fit - ref) <= max(1e-6, 50 * kw * np.finfo(float).eps) * np.linalg.norm(ref)
+    res, res_ref = np.linalg.norm(aw @ sol.fit - bw), np.linalg.norm(aw @ ref - bw)
+    assert abs(res - res_ref) <= 1e-6 * res_ref
+    pt.free()
+
+
 def test_inp_shape_at_full_size(ctx):
     m, K = 367_900, 480
     A, b, w = orc.synth_problem(m, K)

@@ -487,3 +487,53 @@ def test_lasso_gram_argument_checks_and_closed_form():
     assert cfg.sections["LASSO"].alpha == 1e-3 and cfg.sections["LASSO"].max_iter == 2000
     with pytest.raises(UserWarning):
         Config(ParallelTools(), {"SOLVER": {"solver": "SVD"}, "LASSO": {"alpha": "1e-3"}})
+
+
+def _ill_conditioned_statistics(K, rank_def=0, seed=0):
+    rng = np.random.default_rng(seed)
+    m = 3 * K
+    U, _ = np.linalg.qr(rng.standard_normal((m, K)))
+    V, _ = np.linalg.qr(rng.standard_normal((K, K)))
+    s = np.logspace(0, -9, K)
+    if rank_def:
+        s[-rank_def:] = 0.0
+    A = (U * s) @ V.T
+    b = rng.standard_normal(m)
+    return A.T @ A, A.T @ b
+
+
+@pytest.mark.parametrize("kind,probe,param", [("LSTSQ", "LSTSQ_PROBE", 1.0e-13), ("RIDGE", "RIDGE_PROBE", 1.0e-30)])
+def test_probe_solve_kinds_return_unresolved_instead_of_the_eigen_fallback(kind, probe, param):
+    from fitsnap_amd import _capi
+    G, c = _ill_conditioned_statistics(96, rank_def=3)
+    full, rank_full, _ = _capi.solve(getattr(_capi, "SOLVE_" + kind), param, G, c)
+    beta, rank, rcond = _capi.solve(getattr(_capi, "SOLVE_" + probe), param, G, c)
+    assert rank == -1 and np.all(beta == 0.0) and rcond < 1e-9
+    assert 0 < rank_full < 96 and np.all(np.isfinite(full))
+    # a system the Cholesky resolves is solved as usual
+    Gw = G + np.eye(96) * np.trace(G) / 96
+    b1, r1, _ = _capi.solve(getattr(_capi, "SOLVE_" + probe), param, Gw, c)
+    b0, r0, _ = _capi.solve(getattr(_capi, "SOLVE_" + kind), param, Gw, c)
+    assert r1 == r0 == 96 and np.array_equal(b1, b0)
+
+
+@pytest.mark.parametrize("kind,param", [("LSTSQ", 1.0e-13), ("RIDGE", 1.0e-30)])
+def test_large_k_truncating_fallback_in_lapack_matches_the_library(kind, param):
+    """Solver._solve above LAPACK_FALLBACK_K: probe first, numpy.linalg.eigh for the truncation -- the same answer as the
+    library's own (Jacobi) fallback, which stays in charge up to K = 256."""
+    from fitsnap_amd import _capi
+    from fitsnap_amd.solvers.solver import Solver
+    K = 288
+    G, c = _ill_conditioned_statistics(K, rank_def=2, seed=3)
+    G[:, 7] = 0.0
+    G[7, :] = 0.0
+    c[7] = 0.0                                                 # an exactly-zero column on top
+    k = getattr(_capi, "SOLVE_" + kind)
+    ref, rank_ref, _ = _capi.solve(k, param, G, c)             # library fallback (cyclic Jacobi)
+    s = Solver.__new__(Solver)
+    beta = Solver._solve(s, k, param, G, c)
+    assert s.last_rank == rank_ref and beta[7] == 0.0
+    # both are truncated pseudo-inverse solves with the same cut: compare where it matters, on G beta
+    assert np.linalg.norm(G @ (beta - ref)) <= 1e-8 * np.linalg.norm(c)
+    # the kept eigenvalues closest to the cut (4 n eps lambda_max) carry a relative error of ~1e-3 in either solver
+    assert np.linalg.norm(beta - ref) <= 5e-3 * np.linalg.norm(ref)
