@@ -82,6 +82,7 @@ SIGNATURES = {
     "fsnap_dev_upload": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "fsnap_dev_download": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "fsnap_lstsq_rows": (c_int, [c_void_p, c_double, c_int64, c_void_p, POINTER(c_int), c_void_p]),
+    "fsnap_set_dense_pinv": (c_int, [c_void_p, c_void_p, c_void_p]),
     "fsnap_rowspace_factor": (c_int, [c_int64, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p]),
     "fsnap_rowspace_solve": (c_int, [c_int64, c_void_p, c_void_p, c_double, c_void_p, POINTER(c_int), c_void_p]),
     "fsnap_timing": (c_int, [c_void_p, _P_D, c_int]),
@@ -237,6 +238,40 @@ def rowspace_chain(factors, z, rcond, active=None):
     return beta, rank.value, {"chain": info[0], "norm_bound": info[1], "inverse_norm_bound": info[2], "cond_bound": info[3]}
 
 
+DENSE_PINV_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int64, c_int64, POINTER(c_double), c_double, POINTER(c_double),
+                                 POINTER(c_double), POINTER(c_int))
+
+
+def make_dense_pinv():
+    """The hook ``fsnap_set_dense_pinv`` takes (include/fsnap_hip.h): x = pinv_rcond(T) y through LAPACK's divide-and-conquer
+    SVD (scipy.linalg.svd, gesdd), the decomposition cached per ``token`` -- the K x K end of dgelsd for factors too large
+    for the library's Jacobi sweeps.  Returns the ctypes callback object (keep it alive while it is installed)."""
+    cache = {}
+
+    def pinv_apply(user, token, n, T_p, rcond, y_p, x_p, rank_p):
+        try:
+            import scipy.linalg as sl
+
+            n = int(n)
+            held = cache.get("svd")
+            if held is None or held[0] != (token, n):
+                T = np.ctypeslib.as_array(T_p, shape=(n, n))
+                U, sv, Vt = sl.svd(T, full_matrices=False, lapack_driver="gesdd")
+                keep = sv > rcond * sv[0] if (n and sv[0] > 0.0) else np.zeros(n, dtype=bool)   # gelsd's cut
+                held = ((token, n), U[:, keep].copy(), sv[keep].copy(), Vt[keep].copy())
+                cache["svd"] = held
+            _, Uk, sk, Vk = held
+            y = np.ctypeslib.as_array(y_p, shape=(n,))
+            x = np.ctypeslib.as_array(x_p, shape=(n,))
+            x[:] = Vk.T @ ((Uk.T @ y) / sk)
+            rank_p[0] = int(sk.size)
+            return 0
+        except Exception:       # noqa: BLE001 - any failure: the library falls back on its own SVD
+            return 1
+
+    return DENSE_PINV_FN(pinv_apply)
+
+
 def comm_id() -> bytes:
     """A fresh RCCL communicator id (rank 0 calls this and hands the 128 bytes to every rank)."""
     lib = load_library()
@@ -290,6 +325,9 @@ class HipContext:
         self.K = 0
         self._keep = []  # keep numpy buffers alive across async copies
         self.resident_train_mask = None   # mask object last sent with set_weights_train (identity = still resident)
+        # LAPACK's SVD for the large truncated K x K solves of the row-space path (the library's own is a Jacobi SVD)
+        self._dense_pinv = make_dense_pinv()
+        self._lib.fsnap_set_dense_pinv(self._h, ctypes.cast(self._dense_pinv, c_void_p), None)
 
     # -- plumbing --------------------------------------------------------------------
     def _check(self, rc):

@@ -127,6 +127,9 @@ struct fsnap_ctx {
     // multi-GPU / row-space state owned by the other translation units
     fsnap::Comm* comm = nullptr;
     fsnap::RowSpace* rowspace = nullptr;
+    int (*dense_pinv)(void*, int64_t, int64_t, const double*, double, const double*, double*, int*) = nullptr;
+    void* dense_pinv_user = nullptr;
+    int64_t dense_pinv_token = 0;
     DevBuf commbuf;                               // device staging of host-buffer collectives
     int opt_repack = 0;       // 1 = pack (w_eff, w_eff b) on every launch even when b / w / mask are context-owned
 

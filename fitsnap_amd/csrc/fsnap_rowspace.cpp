@@ -145,6 +145,13 @@ int fsnap_rowspace_chain(int64_t K64, int64_t nfac, const double* R, const unsig
     return finite_all(beta, (size_t)K) ? FSNAP_OK : FSNAP_NUM_NONFINITE;
 }
 
+int fsnap_set_dense_pinv(fsnap_ctx* ctx, fsnap_dense_pinv_fn fn, void* user) {
+    if (!ctx) return FSNAP_E_ARG;
+    ctx->dense_pinv = fn;
+    ctx->dense_pinv_user = user;
+    return FSNAP_OK;
+}
+
 int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, int* rank_out, double* info) {
     if (!ctx) return FSNAP_E_ARG;
     if (!beta || K64 <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_lstsq_rows: bad argument");
@@ -273,7 +280,14 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
             chain.product(Rhat.data());
         }
     }
-    if (!use_chain) fs.prepare(K, Rhat.data(), rcond);
+    if (!use_chain) {
+        if (ctx->dense_pinv) {
+            fs.external = reinterpret_cast<FactorSolver::pinv_fn>(ctx->dense_pinv);
+            fs.external_user = ctx->dense_pinv_user;
+            fs.token = ++ctx->dense_pinv_token;
+        }
+        fs.prepare(K, Rhat.data(), rcond);
+    }
     mark("condition bound / prepare");
     auto apply = [&](const double* rhs, double* out) {
         if (use_chain) chain.solve(rhs, out);
@@ -318,7 +332,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
         info[0] = passes;
         info[1] = dev;
         info[2] = converged;
-        info[3] = (use_chain || fs.triangular) ? 0.0 : 1.0;
+        info[3] = (use_chain || fs.triangular) ? 0.0 : (fs.use_external ? 2.0 : 1.0);      // 2: the host language's SVD
         info[4] = use_chain ? chain_norm : fs.smax;                       // chain: bounds, not singular values
         info[5] = use_chain ? (chain_inv > 0.0 ? 1.0 / chain_inv : 0.0) : fs.smin;
         info[6] = rel_step;

@@ -319,6 +319,22 @@ void FactorSolver::prepare(int K_, const double* Rhat, double rcond) {
             smin = 1.0 / std::sqrt(inv2);
             return;
         }
+        rcond_used = rc;
+        use_external = false;
+        if (external && n > 256) {
+            // try the host language's dense kernel on a probe right-hand side; it also tells the rank
+            vec y((size_t)n, 0.0), x((size_t)n, 0.0);
+            y[0] = 1.0;
+            int rk = 0;
+            if (external(external_user, token, n, T.data(), rc, y.data(), x.data(), &rk) == 0 && rk >= 0 && rk <= n &&
+                finite_all(x.data(), x.size())) {
+                use_external = true;
+                rank = rk;
+                smax = fro;
+                smin = 0.0;
+                return;
+            }
+        }
         jacobi_svd(rc);
     }
 
@@ -438,6 +454,15 @@ void FactorSolver::apply(const double* z, double* beta) const {
             return;
         }
         vec x(n, 0.0);
+        if (use_external) {
+            int rk = 0;
+            if (external(external_user, token, n, T.data(), rcond_used, y.data(), x.data(), &rk) == 0) {
+                for (int a = 0; a < n; ++a) beta[act[a]] = x[a];
+                return;
+            }
+            // the hook failed after having worked in prepare(): leave zeros (the caller's finiteness / rank checks see it)
+            return;
+        }
         for (int i = 0; i < n; ++i) {
             if (!keep[i]) continue;
             const double* ji = J.data() + (size_t)i * n;

@@ -39,6 +39,14 @@ struct FactorSolver {
     std::vector<char> keep;
     double smax = 0.0, smin = 0.0;
     int sweeps = 0;
+    // optional dense kernel of the host language for large truncated solves (include/fsnap_hip.h: fsnap_dense_pinv_fn)
+    typedef int (*pinv_fn)(void* user, long long token, long long n, const double* T, double rcond, const double* y, double* x,
+                           int* rank);
+    pinv_fn external = nullptr;
+    void* external_user = nullptr;
+    long long token = 0;
+    double rcond_used = 0.0;
+    mutable bool use_external = false;
     void prepare(int K_, const double* Rhat, double rcond);
     void jacobi_svd(double rcond);
     void apply(const double* z, double* beta) const;   // beta (K entries, zeros in inactive columns) = pinv(R_hat) z

@@ -251,6 +251,16 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
 
 /* ---- row-space least squares (ill-conditioned / rank-deficient systems) --------------------------------------- */
 
+/* Optional dense kernel of the host language for the K x K end of fsnap_lstsq_rows when a TRUNCATION is needed and the
+ * factor is large (K > 256): x = pinv_rcond(T) y for the n x n upper triangular T (row-major), singular values below
+ * rcond * sigma_max dropped, *rank = number kept.  `token` changes with every new T (a caller may cache its
+ * decomposition per token; two applications per solve).  Return 0 on success; anything else makes the library fall back
+ * on its own one-sided Jacobi SVD -- exact, but O(n^3) per sweep on one core (~20 s at n = 1595, where LAPACK's gesdd
+ * takes ~1 s).  fn = NULL removes the hook.  The Python host layer installs scipy.linalg.svd. */
+typedef int (*fsnap_dense_pinv_fn)(void* user, int64_t token, int64_t n, const double* T, double rcond, const double* y,
+                                   double* x, int* rank);
+int fsnap_set_dense_pinv(fsnap_ctx* ctx, fsnap_dense_pinv_fn fn, void* user);
+
 /* fit = scipy.linalg.lstsq(aw, bw, rcond) of the resident rows, computed on the ROWS like the reference's dgelsd
  * (fitsnap3lib/solvers/svd.py:44-54) instead of from the normal equations -- for systems whose K x K statistics are
  * numerically singular (kappa(A_w) beyond ~1e7) or rank deficient: shifted CholeskyQR passes on the GPU

@@ -236,3 +236,38 @@ def test_lstsq_rows_factor_chain_path_on_the_gpu():
     assert rank == K and info["converged"] == 1.0 and info["svd"] == 0.0 and info["passes"] >= 2
     assert np.linalg.norm(beta - ref) <= max(1e-6, 50 * 1e7 * EPS) * np.linalg.norm(ref)
     ctx.close()
+
+
+@pytest.mark.parametrize("case", ["duplicated", "fewer_rows_than_columns"])
+def test_large_k_truncated_solve_runs_in_lapack(case):
+    # K > 256 and a truncation is needed: the K x K end goes through the dense-pinv hook the Python layer installs
+    # (scipy's gesdd) instead of the library's Jacobi SVD (~20 s at K = 1595); info["svd"] == 2 says so
+    r = np.random.default_rng(17)
+    K = 320
+    if case == "duplicated":
+        m = 2500
+        A = r.standard_normal((m, K))
+        A[:, 300] = A[:, 5]
+        A[:, 310] = A[:, 6] - 2.0 * A[:, 7]
+    else:
+        m = 200
+        A = r.standard_normal((m, K))
+    b = r.standard_normal(m)
+    w = r.uniform(0.5, 2.0, m)
+    _, _, rank_ref, _ = sl.lstsq(w[:, None] * A, w * b, 1.0e-13)
+    ref = orc.svd_fit(A, b, w)
+    pt, s = make_svd()
+    s.perform_fit(A, b, w, trainall=True)
+    assert s.last_row_space is not None and s.last_row_space["svd"] == 2.0
+    assert s.last_rank == rank_ref == (K - 2 if case == "duplicated" else m)
+    assert np.linalg.norm(s.fit - ref) <= 1e-7 * np.linalg.norm(ref)
+    pt.free()
+    # without the hook the library's own SVD gives the same answer
+    ctx = _capi.HipContext(0)
+    ctx._lib.fsnap_set_dense_pinv(ctx._h, None, None)
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w)
+    beta, rank, info = ctx.lstsq_rows(1.0e-13)
+    assert info["svd"] == 1.0 and rank == rank_ref
+    assert np.linalg.norm(beta - ref) <= 1e-7 * np.linalg.norm(ref)
+    ctx.close()

@@ -184,3 +184,23 @@ def test_factor_chain_inactive_columns_and_truncation():
     assert info2["chain"] == 0.0 and rank2 == K - 1 and np.all(np.isfinite(beta2))
     ref2, _, rank_ref, _ = sl.lstsq(R, z, cond=1.0e-4)
     assert rank_ref == K - 1 and np.allclose(beta2, ref2, rtol=1e-7, atol=1e-9)
+
+
+def test_dense_pinv_hook_is_gelsd_on_the_factor():
+    """The callback the Python layer hands to fsnap_set_dense_pinv (LAPACK SVD of the K x K factor), driven directly."""
+    import ctypes
+    rng = np.random.default_rng(4)
+    n = 40
+    T = np.triu(rng.standard_normal((n, n))) + 3.0 * np.eye(n)
+    T[:, 9] = T[:, 2]                                              # exactly dependent columns: one direction to drop
+    T = np.triu(T)
+    T = np.ascontiguousarray(T)
+    y = rng.standard_normal(n)
+    x = np.zeros(n)
+    rank = ctypes.c_int(-1)
+    cb = _capi.make_dense_pinv()
+    dp = ctypes.POINTER(ctypes.c_double)
+    for token in (1, 1, 2):                                        # second call reuses the cached decomposition
+        rc = cb(None, token, n, T.ctypes.data_as(dp), 1.0e-10, y.ctypes.data_as(dp), x.ctypes.data_as(dp), ctypes.byref(rank))
+        ref, _, rank_ref, _ = sl.lstsq(T, y, cond=1.0e-10)
+        assert rc == 0 and rank.value == rank_ref and np.allclose(x, ref, rtol=1e-9, atol=1e-11)
