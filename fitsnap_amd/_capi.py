@@ -22,7 +22,9 @@ OK = 0
 E_ARG, E_HIP, E_STATE, E_NOMEM = -1, -2, -3, -4
 NUM_NOT_SPD, NUM_SINGULAR, NUM_NONFINITE = 1, 2, 3
 SOLVE_CHOL, SOLVE_LSTSQ, SOLVE_RIDGE, SOLVE_RIDGE_INV = 0, 1, 2, 3
-SOLVE_LSTSQ_PROBE, SOLVE_RIDGE_PROBE = 4, 5     # same, but an unresolved system comes back at once with rank = -1
+SOLVE_LSTSQ_PROBE, SOLVE_RIDGE_PROBE, SOLVE_RIDGE_INV_PROBE = 4, 5, 6     # same, but an unresolved system comes back at once with rank = -1
+PROBE_OF = {SOLVE_LSTSQ: SOLVE_LSTSQ_PROBE, SOLVE_RIDGE: SOLVE_RIDGE_PROBE, SOLVE_RIDGE_INV: SOLVE_RIDGE_INV_PROBE}
+BASE_OF = {v: k for k, v in PROBE_OF.items()}
 COMM_ID_BYTES = 128
 REDUCE_SUM, REDUCE_MAX, REDUCE_MIN = 0, 1, 2
 

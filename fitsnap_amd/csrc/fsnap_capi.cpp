@@ -1096,10 +1096,11 @@ int fsnap_solve_device(fsnap_ctx* ctx, int kind, double param, int64_t K, const 
 int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, const double* d_packed, const double* rhs,
                            double* beta, int* rank, double* rcond_est) {
     if (!ctx) return FSNAP_E_ARG;
-    if (!d_packed || !beta || K <= 0 || kind < FSNAP_SOLVE_CHOL || kind > FSNAP_SOLVE_RIDGE_PROBE)
+    if (!d_packed || !beta || K <= 0 || kind < FSNAP_SOLVE_CHOL || kind > FSNAP_SOLVE_RIDGE_INV_PROBE)
         return ctx->fail(FSNAP_E_ARG, "fsnap_solve_device: bad argument");
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
-    const double alpha = (kind == FSNAP_SOLVE_RIDGE || kind == FSNAP_SOLVE_RIDGE_INV || kind == FSNAP_SOLVE_RIDGE_PROBE) ? param : 0.0;
+    const double alpha = (kind == FSNAP_SOLVE_RIDGE || kind == FSNAP_SOLVE_RIDGE_INV || kind == FSNAP_SOLVE_RIDGE_PROBE ||
+                          kind == FSNAP_SOLVE_RIDGE_INV_PROBE) ? param : 0.0;
     if (K <= 128 && ctx->opt_device_solve == 1 && !rhs) {
         if (!ctx->dsolve.ensure((size_t)(K + 2) * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(solve) failed");
         double host[130];

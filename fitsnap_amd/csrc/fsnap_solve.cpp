@@ -645,10 +645,11 @@ extern "C" __attribute__((visibility("hidden"))) int fsnap_solve_diag(int kind, 
                                                                       int* rank_out, double* rcond_est) {
     PhaseTimer timer;
     if (!G || !c || !beta || K64 <= 0 || K64 > (1 << 20)) return FSNAP_E_ARG;
-    if (kind < FSNAP_SOLVE_CHOL || kind > FSNAP_SOLVE_RIDGE_PROBE) return FSNAP_E_ARG;
-    const bool probe = kind == FSNAP_SOLVE_LSTSQ_PROBE || kind == FSNAP_SOLVE_RIDGE_PROBE;    // no eigen fallback
+    if (kind < FSNAP_SOLVE_CHOL || kind > FSNAP_SOLVE_RIDGE_INV_PROBE) return FSNAP_E_ARG;
+    const bool probe = kind >= FSNAP_SOLVE_LSTSQ_PROBE;                     // no eigen / LU fallback
     if (kind == FSNAP_SOLVE_LSTSQ_PROBE) kind = FSNAP_SOLVE_LSTSQ;
     if (kind == FSNAP_SOLVE_RIDGE_PROBE) kind = FSNAP_SOLVE_RIDGE;
+    if (kind == FSNAP_SOLVE_RIDGE_INV_PROBE) kind = FSNAP_SOLVE_RIDGE_INV;
     const int K = (int)K64;
     if (!std::isfinite(param)) return FSNAP_NUM_NONFINITE;
     const double alpha = (kind == FSNAP_SOLVE_RIDGE || kind == FSNAP_SOLVE_RIDGE_INV) ? param : 0.0;

@@ -37,12 +37,11 @@ class RIDGE(Solver):
             if pt._rank == 0:
                 self.fit = fit
             return
-        if kind == _capi.SOLVE_RIDGE:
-            # sklearn's Cholesky -> SVD fallback: the truncating solve runs in LAPACK for large K (Solver._solve)
-            fit = self._fit_and_solve(_capi.SOLVE_RIDGE_PROBE, alval, a, b, w, fs_dict, trainall)
-            fit = self._resolve_probe(_capi.SOLVE_RIDGE_PROBE, alval, fit)
-        else:
-            fit = self._fit_and_solve(kind, alval, a, b, w, fs_dict, trainall)
+        # what lies behind the Cholesky factorisations -- sklearn's SVD fallback (RIDGE), np.linalg.inv's LU (local solver)
+        # -- runs in LAPACK for large K (Solver._solve); the library's own versions are single-core Jacobi / scalar LU
+        probe = _capi.PROBE_OF[kind]
+        fit = self._fit_and_solve(probe, alval, a, b, w, fs_dict, trainall)
+        fit = self._resolve_probe(probe, alval, fit)
         if self.refine_steps:        # off by default: the reference's ridge is itself a normal-equation solve
             fit = self._refine(fit, kind, alval, self.refine_steps)
         if pt._rank == 0:

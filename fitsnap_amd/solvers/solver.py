@@ -266,10 +266,13 @@ class Solver:
     def _solve(self, kind, param, G, c):
         """Host K x K solve on statistics already on the host."""
         K = len(c)
-        probe = {_capi.SOLVE_LSTSQ: _capi.SOLVE_LSTSQ_PROBE, _capi.SOLVE_RIDGE: _capi.SOLVE_RIDGE_PROBE}.get(kind)
+        probe = _capi.PROBE_OF.get(kind)
         if probe is not None and K > self.LAPACK_FALLBACK_K:
             beta, rank, rcond = _capi.solve(probe, param, G, c)
-            if rank < 0:
+            if rank < 0 and kind == _capi.SOLVE_RIDGE_INV:
+                # regressor.py:15 itself: np.linalg.inv raises LinAlgError on a singular matrix, as the reference does
+                beta, rank = np.linalg.inv(np.asarray(G) + float(param) * np.eye(K)) @ np.asarray(c), K
+            elif rank < 0:
                 beta, rank = self._truncated_eigen_solve(kind, param, G, c)
         else:
             beta, rank, rcond = _capi.solve(kind, param, G, c)
@@ -345,7 +348,7 @@ class Solver:
         if self.last_rank is None or self.last_rank >= 0:
             return beta
         G, c, _ = self.last_statistics
-        base = _capi.SOLVE_LSTSQ if kind == _capi.SOLVE_LSTSQ_PROBE else _capi.SOLVE_RIDGE
+        base = _capi.BASE_OF[kind]
         rcond = self.last_rcond
         beta = self._solve(base, param, G, c)
         self.last_rcond = rcond if rcond is not None else self.last_rcond

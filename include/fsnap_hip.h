@@ -41,12 +41,13 @@ typedef struct fsnap_ctx fsnap_ctx;
 #define FSNAP_SOLVE_LSTSQ 1      /* min-norm least squares, param = rcond  (svd.py:54 lstsq(aw,bw,1e-13)) */
 #define FSNAP_SOLVE_RIDGE 2      /* (G + alpha I) beta = c, param = alpha (ridge.py:47-57, sklearn Ridge) */
 #define FSNAP_SOLVE_RIDGE_INV 3  /* beta = inv(G + alpha I) c             (regressor.py:10-16 Local_Ridge) */
-/* LSTSQ / RIDGE without the truncating fallback: when no Cholesky factorisation resolves the system the call returns
+/* LSTSQ / RIDGE / RIDGE_INV without the fallback behind the Cholesky factorisations: when no Cholesky factorisation resolves the system the call returns
  * FSNAP_OK at once with *rank = -1 and beta = 0 (and *rcond_est = the smallest scaled pivot met) instead of running the
  * cyclic-Jacobi eigendecomposition -- O(K^3) per sweep on one core: 58 s at K = 1595.  For callers that have something
  * better to fall back on: the rows (fsnap_lstsq_rows) or a LAPACK eigensolver. */
 #define FSNAP_SOLVE_LSTSQ_PROBE 4
 #define FSNAP_SOLVE_RIDGE_PROBE 5
+#define FSNAP_SOLVE_RIDGE_INV_PROBE 6 /* ... instead of the scalar LU with partial pivoting (np.linalg.inv semantics) */
 
 /* packed statistics buffer: [ G (K*K row-major) | c (K) | bTb, sum(w*b), n_train ] */
 #define FSNAP_PACKED_LEN(K) ((int64_t)(K) * (K) + (K) + 3)

@@ -517,6 +517,28 @@ def test_probe_solve_kinds_return_unresolved_instead_of_the_eigen_fallback(kind,
     assert r1 == r0 == 96 and np.array_equal(b1, b0)
 
 
+def test_large_k_local_ridge_fallback_is_numpy_inv():
+    # regressor.py:15 semantics for a matrix no Cholesky resolves: np.linalg.inv in the host layer for K > 256 (the
+    # library's scalar LU with partial pivoting below that)
+    from fitsnap_amd import _capi
+    from fitsnap_amd.solvers.solver import Solver
+    K = 288
+    rng = np.random.default_rng(5)
+    Q, _ = np.linalg.qr(rng.standard_normal((K, K)))
+    ev = np.logspace(0, -8, K)
+    ev[-3:] *= -1.0                                             # three small negative eigenvalues: Cholesky fails, LU does not care
+    G = (Q * ev) @ Q.T
+    G = 0.5 * (G + G.T)
+    c = rng.standard_normal(K)
+    beta_p, rank_p, _ = _capi.solve(_capi.SOLVE_RIDGE_INV_PROBE, 0.0, G, c)
+    assert rank_p == -1 and np.all(beta_p == 0.0)
+    s = Solver.__new__(Solver)
+    beta = Solver._solve(s, _capi.SOLVE_RIDGE_INV, 0.0, G, c)
+    assert s.last_rank == K and np.array_equal(beta, np.linalg.inv(G) @ c)
+    lib, _, _ = _capi.solve(_capi.SOLVE_RIDGE_INV, 0.0, G, c)   # the library's own LU: same system, same answer
+    assert np.linalg.norm(lib - beta) <= 1e-6 * np.linalg.norm(beta)
+
+
 @pytest.mark.parametrize("kind,param", [("LSTSQ", 1.0e-13), ("RIDGE", 1.0e-30)])
 def test_large_k_truncating_fallback_in_lapack_matches_the_library(kind, param):
     """Solver._solve above LAPACK_FALLBACK_K: probe first, numpy.linalg.eigh for the truncation -- the same answer as the
