@@ -22,8 +22,9 @@ struct FactorChain {
     std::vector<char> active;              // columns with a non-zero diagonal entry of the first Gram matrix
     void start(int K_, const double* G);
     void push(const double* Rp) { R.emplace_back(Rp, Rp + (size_t)K * K); }
-    // upper estimate of ||R_hat||_2 ||R_hat^-1||_2: sqrt(||R||_1 ||R||_inf) x (3 x sqrt(est ||R^-1||_1 est ||R^-1||_inf)) per factor,
-    // the 1-norms by Hager / Higham's iteration (a lower bound that is rarely off by more than 3: the safety factor)
+    // upper estimate of ||R_hat||_2 ||R_hat^-1||_2, per factor: sqrt(||R||_1 ||R||_inf) (exact) x an estimate of ||R^-1||_2 --
+    // the smaller of 3 x sqrt(est_1 est_inf) (Hager / Higham's 1-norm estimator) and 2 x inverse iteration on R^T R; a
+    // Neumann bound 1 / (1 - ||R - I||) for the near-identity factors of the later passes
     double condition_bound(double* norm_out, double* inv_norm_out) const;
     void solve(const double* z, double* beta) const;      // beta = R_1^-1 ... R_p^-1 z, zeros in inactive columns
     void product(double* Rhat) const;                     // R_hat, with zero diagonal entries for inactive columns

@@ -133,7 +133,7 @@ def _cholqr_factors(A, passes=2):
     return out
 
 
-@pytest.mark.parametrize("K,kappa,expect_chain", [(300, 1e3, True), (400, 1e7, True), (320, 1e11, False)])
+@pytest.mark.parametrize("K,kappa,expect_chain", [(300, 1e3, True), (400, 1e7, True), (320, 1e11, True), (320, 3e12, False)])
 def test_factor_chain_solves_without_the_product(K, kappa, expect_chain):
     """fsnap_rowspace_chain (what fsnap_lstsq_rows does for K > 256): the factors stay apart; the solve goes through them
     by back substitution when the condition bound allows, through the multiplied-out factor + the SVD end otherwise.  Either
