@@ -559,3 +559,16 @@ def test_large_k_truncating_fallback_in_lapack_matches_the_library(kind, param):
     assert np.linalg.norm(G @ (beta - ref)) <= 1e-8 * np.linalg.norm(c)
     # the kept eigenvalues closest to the cut (4 n eps lambda_max) carry a relative error of ~1e-3 in either solver
     assert np.linalg.norm(beta - ref) <= 5e-3 * np.linalg.norm(ref)
+
+
+def test_scalapack_name_resolves_and_refuses_testing_rows():
+    """``solver = ScaLAPACK`` (the reference's multi-node lstsq, scalapack.py:9-45) maps onto the multi-GPU least-squares
+    path; like the reference it refuses rows marked for testing -- before any GPU work."""
+    pt = ParallelTools()
+    cfg = Config(pt, {"SOLVER": {"solver": "ScaLAPACK"}})
+    assert cfg.sections["SOLVER"].true_multinode == 1
+    s = solver_factory.solver("ScaLAPACK", pt, cfg)
+    assert type(s).__name__ == "ScaLAPACK" and isinstance(s, Solver) and s.refine_steps == 2
+    pt.fitsnap_dict["Testing"] = [False, True, False]
+    with pytest.raises(NotImplementedError, match="ScaLAPACK solver"):
+        s.perform_fit()
