@@ -1,37 +1,47 @@
 #!/usr/bin/env python
-"""bench.py — BASELINE.json metric: training rows/sec through A^T A + solve on a synthetic
-10^6 x 128 fp64 A-matrix per GPU (configs[1]: RIDGE normal equations), 1/2/4/8 MI355X.
+"""bench.py — BASELINE.json metric: training rows/sec through A^T A + solve on a synthetic 10^6 x 128 fp64 A-matrix
+(configs[1]: RIDGE normal equations) at 1 / 2 / 4 / 8 MI355X.
 
-    python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus N --steps K --warmup W            # N > 1: this script starts the N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-The launcher only provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*: this script imports neither torch nor
-torch.distributed.  Everything on the GPU goes through the C ABI (include/fsnap_hip.h) via ctypes, including the
-multi-GPU exchange (native RCCL: fsnap_comm_*, fsnap_fit_dist).
+One process per GPU.  Under a launcher (RANK / LOCAL_RANK / WORLD_SIZE in the environment) the process IS one rank;
+without one, `--gpus N` > 1 makes this process the launcher: it starts N ranks of itself (one per visible device, a
+private communicator-id file and job token in the environment), passes rank 0's JSON line through, and turns the
+first failing rank into ONE line on stderr and a non-zero exit status for the whole job.  The script imports neither
+torch nor torch.distributed: everything on the GPU goes through the C ABI (include/fsnap_hip.h) via ctypes, including
+the multi-GPU exchange (native RCCL: fsnap_comm_*, fsnap_fit_dist).
 
-One "step" = one complete fit of the resident rows, ALL of it inside the timed region: packing of the per-row
-weights (mask x w, mask x w x b and the three b-only scalars; option repack = 1 forces it on every fit although b, w
-and the mask do not change between steps), fused mask x weight x fp64-MFMA normal equations, partial reduction,
+One "step" = one complete fit of the rows resident on the GPUs, ALL of it inside the timed region: packing of the
+per-row weights (mask x w, mask x w x b and the three b-only scalars; option repack = 1 forces it on every fit although
+b, w and the mask do not change between steps), fused mask x weight x fp64-MFMA normal equations, partial reduction,
 (N > 1) one in-place ncclAllReduce of the packed K x K statistics on the same stream, K x K ridge solve through
 fsnap_solve_device (K = 128: Jacobi-scaled Cholesky on the host from the page-locked mirror; K >= 384: blocked
 Cholesky on the GPU) -> beta on the host of every rank.  A, b, w are resident in HBM before the timed region (the
 PCIe-inclusive rate is reported separately, never as `value`).
 
-Steady state: an MI355X that has been idle needs ~35 ms of sustained load before its clocks settle
-(scripts/ramptest.py).  Before the W warm-up steps the benchmark therefore runs `--preheat` (default 300) additional
-UNTIMED steps of the same workload -- a fixed count, so that every rank executes the same number of collectives.
-The timed region is still exactly K steps between barrier + stream synchronisation on both sides.
-Weak scaling: every rank owns 10^6 rows of its own (disjoint synthetic row blocks);
-value = N * rows_per_gpu * steps / max-over-ranks wall time.
+Two scalings of the same metric (`--scaling strong|weak|both`, default both):
+* strong -- BASELINE.json's literal metric "10^6 x 128 ... at 1/2/4/8 GPU": the SAME 10^6 rows, row-sharded N ways
+  (rank r owns rows [r 10^6 / N, (r+1) 10^6 / N) of the N = 1 problem, so every N fits the identical system);
+  `value` = 10^6 * steps / max-over-ranks wall time, `"scaling": "strong"`;
+* weak -- 10^6 rows PER GPU (disjoint synthetic row blocks): `weak_value` = N * 10^6 * steps / max-over-ranks time.
+At N = 1 the two are the same run.  With `--scaling weak` the line's `value` is the weak number and `"scaling": "weak"`.
 
-Rank 0 prints ONE JSON line (see the bench contract in the task statement) with two extra objects: `roofline`
+Steady state: an MI355X that has been idle needs ~35 ms of sustained load before its clocks settle
+(scripts/ramptest.py).  Before the W warm-up steps every mode therefore runs `--preheat` (default 300) additional
+UNTIMED steps of the same workload -- a fixed count, so that every rank executes the same number of collectives.
+The timed region is exactly K steps between barrier + stream synchronisation on both sides.
+
+Rank 0 prints ONE JSON line (see the bench contract in the task statement) with extra objects: `roofline`
 (fp64-MFMA roofline of the SYRK kernel -- HBM roofline when K <= 80, where the kernel is bandwidth-bound -- measured
 live with HIP events on the kernel's stream around every `--timing-every`-th launch of the timed region, the first
-included: an event record between two dependent kernels idles the stream for ~5.6 us on this runtime, two per step =
-10.4 us of a 0.33 ms step, so the instrument samples instead of bracketing every launch; `--timing-every 1` is the
-old behaviour) and `cpu_baseline` (the oracle's restatement of the reference's numpy
-path timed on this box's host cores; N = 1 only; a reported baseline, not the target).
+included: an event record between two dependent kernels idles the stream for ~5.6 us on this runtime, so the
+instrument samples instead of bracketing every launch), `per_rank` (kernel_ms and allreduce_ms of every rank: HIP
+events around the SYRK kernel and around the collective on each rank's own stream), `n_ranks_seen` (fsnap_comm_info),
+for N > 1 `dist_solve_ab` (the same strong-scaling steps with option dist_solve = 1: reduce to rank 0 -> solve ->
+broadcast beta) and, at N = 1, `cpu_baseline` (the oracle's restatement of the reference's numpy path timed on this
+box's host cores; a reported baseline, not the target).
 """
 from __future__ import annotations
 
@@ -39,7 +49,9 @@ import argparse
 import hashlib
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -47,22 +59,25 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ROWS_PER_GPU = 1_000_000
+ROWS = 1_000_000
 K = 128
 ALPHA = 1.0e-8                 # reference default, io/sections/solver_sections/ridge.py:13
 PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X vendor fp64 matrix peak
 PEAK_HBM_GBPS = 8000.0         # MI355X HBM3E (MI355X_MICROARCH.md)
-RANK_ROW_STRIDE = 16 * 65536   # >= ROWS_PER_GPU, multiple of the generator's 64 Ki-row chunk
+RANK_ROW_STRIDE = 16 * 65536   # weak scaling: row-block stride between ranks, >= ROWS, multiple of the generator's chunk
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scaling", choices=("strong", "weak", "both"), default="both",
+                    help="strong: --rows rows in total, split over the GPUs (BASELINE's metric, `value`); weak: --rows rows "
+                         "per GPU (`weak_value`); both (default)")
     ap.add_argument("--preheat", type=int, default=300,
                     help="untimed steps before the warm-up, to bring the GPU to its steady clock (0 = none)")
-    ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default: BASELINE config)")
+    ap.add_argument("--rows", type=int, default=ROWS, help="rows of the problem (strong) / per GPU (weak)")
     ap.add_argument("--cols", type=int, default=K)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-repack", action="store_true",
@@ -70,13 +85,101 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="diagnostics: run the multi-GPU step (RCCL all-reduce, fsnap_fit_dist) in a communicator of ONE "
                          "rank, to measure its fixed overhead against the single-GPU step")
-    ap.add_argument("--timing-every", type=int, default=8,
+    ap.add_argument("--dist-solve-ab", type=int, default=-1,
+                    help="1 / 0: time the reduce -> solve on rank 0 -> broadcast variant next to the all-reduce one "
+                         "(default: only when N > 1)")
+    ap.add_argument("--timing-every", type=int, default=4,
                     help="HIP events bracket every N-th kernel launch of the timed region (an event record between two "
                          "dependent kernels idles the stream ~5.6 us; 1 = every launch)")
+    ap.add_argument("--job-timeout", type=float, default=1800.0, help="launcher: seconds before a hung job is killed")
     ap.add_argument("--option", action="append", default=[], help="kernel option key=value (split, nontemporal, nblocks)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without a launcher's environment
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """Start args.gpus ranks of this script (one per device) and relay rank 0's JSON line.  Returns the exit status of
+    the job: 0, or the status of the first rank that failed (the others are terminated), or 124 on --job-timeout."""
+    n = args.gpus
+    workdir = tempfile.mkdtemp(prefix="fsnap_bench_")
+    base = dict(os.environ)
+    base.update({
+        "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+        "MASTER_PORT": base.get("MASTER_PORT") or str(_free_port()),
+        "FSNAP_COMM_FILE": os.path.join(workdir, "comm_id"),           # a file this job owns ...
+        "FSNAP_COMM_TOKEN": hashlib.sha256(os.urandom(32)).hexdigest(),  # ... and a token only its ranks know
+        "FSNAP_BENCH_SPAWNED": "1",
+        "HSA_ENABLE_IPC_MODE_LEGACY": base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+    })
+    procs = []
+    for rank in range(n):
+        env = dict(base, RANK=str(rank), LOCAL_RANK=str(rank))
+        # rank 0 inherits stdout (the JSON line); everybody's stderr is the launcher's
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if rank == 0 else subprocess.DEVNULL))
+    deadline = time.monotonic() + args.job_timeout
+    status = 0
+    failed = None
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                pending.discard(r)
+                if rc != 0 and failed is None:
+                    failed, status = r, rc
+            if failed is not None and pending:
+                # the survivors sit in (bounded) waits for the rank that is gone: give them a moment to report, then stop them
+                grace = time.monotonic() + 10.0
+                while pending and time.monotonic() < grace:
+                    pending = {r for r in pending if procs[r].poll() is None}
+                    time.sleep(0.05)
+                for r in pending:
+                    procs[r].terminate()
+                for r in pending:
+                    try:
+                        procs[r].wait(timeout=10.0)
+                    except subprocess.TimeoutExpired:
+                        procs[r].kill()
+                pending = set()
+            if pending and time.monotonic() > deadline:
+                failed, status = -1, 124
+                for r in pending:
+                    procs[r].kill()
+                pending = set()
+            time.sleep(0.02)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        try:
+            for name in os.listdir(workdir):
+                os.remove(os.path.join(workdir, name))
+            os.rmdir(workdir)
+        except OSError:
+            pass
+    if failed is not None:
+        what = f"rank {failed} exited with status {status}" if failed >= 0 else f"no result after {args.job_timeout:.0f} s"
+        sys.stderr.write(f"bench.py: {n}-GPU job failed: {what}; all ranks stopped\n")
+        return status if status else 1
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(A, b, w, beta_gpu):
     """Reference algorithm (oracle restatement) on the host cores, bounded sample."""
     from oracle import fitsnap_oracle as orc
@@ -118,58 +221,79 @@ def kernel_source_digest():
 
 def recorded_traffic(m, Kc, info, kernel_name):
     """HBM bytes per launch of the dominant kernel from the PMC passes (scripts/pmc_traffic.py ->
-    profiles/pmc_traffic.json) -- only if they were collected for THIS kernel source, shape and launch geometry;
-    otherwise null (a regressed or re-tuned kernel must be re-measured, not inherit an old number)."""
+    profiles/pmc_traffic.json: one record, or a list of records for several shapes) -- only if a record was collected
+    for THIS kernel source, shape and launch geometry; otherwise null (a regressed or re-tuned kernel must be
+    re-measured, not inherit an old number)."""
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        rec = json.load(open(tfile))
+        recs = json.load(open(tfile))
     except Exception:
         return None, "no profiles/pmc_traffic.json"
+    if isinstance(recs, dict):
+        recs = [recs]
     want = {"rows": m, "K": Kc, "kernel": kernel_name, "workgroups": info["workgroups"], "threads": info["threads"],
             "chunks_per_wave": info["chunks_per_wave"], "source_sha256": kernel_source_digest()}
-    for k, v in want.items():
-        if rec.get(k) != v:
-            return None, f"profiles/pmc_traffic.json was recorded for {k} = {rec.get(k)!r}, this run has {v!r}"
-    return rec.get("hbm_bytes_per_launch"), rec.get("source")
+    shapes = ", ".join(f"{r.get('rows')} x {r.get('K')}" for r in recs)
+    why = f"profiles/pmc_traffic.json was recorded for {shapes}, this run has {m} x {Kc}"
+    for rec in recs:
+        miss = [k for k, v in want.items() if rec.get(k) != v]
+        if not miss:
+            return rec.get("hbm_bytes_per_launch"), rec.get("source")
+        if rec.get("rows") == m and rec.get("K") == Kc:
+            k = miss[0]
+            why = f"profiles/pmc_traffic.json was recorded for {k} = {rec.get(k)!r}, this run has {want[k]!r}"
+    return None, why
 
 
-def main():
-    args = parse()
-    # exactly ONE line on stdout: libraries underneath (RCCL prints a version banner through C stdio, which surfaces
-    # at exit, after everything Python printed) get stderr as their fd 1; the JSON line goes to the real stdout
-    sys.stdout.flush()
-    real_stdout = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
+def kernel_name_of(info):
+    if info["split"] == 0:
+        return "fsnap_syrk_tiled"
+    if info["kernel_or_pairs"] == 4:
+        return f"fsnap_syrk_wave_p<{info['NB']}>"
+    if info["kernel_or_pairs"] == 3:
+        return f"fsnap_syrk_acc<{info['NB']}>"
+    if info["kernel_or_pairs"] == 2:
+        return f"fsnap_syrk_lds_static<{info['NB']},{info['threads'] // 64}>"
+    return f"fsnap_syrk_wave<{info['NB']},{info['split']}>"
 
-    from fitsnap_amd import _capi, rendezvous
-    from fitsnap_amd.synthetic import synth_problem   # input data; oracle/ is imported by the cpu_baseline leg only
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    if _capi.device_count() < 1:
-        raise SystemExit("bench.py needs a gfx950 GPU (no CPU fallback)")
-    multi = world > 1 or args.force_dist
+def synth_rows(lo, hi, total, Kc):
+    """Rows [lo, hi) of the `total`-row synthetic problem exactly as the one-GPU run generates them (the generator
+    works in 64 Ki-row chunks; a partial last chunk draws its noise differently from a full one, so every chunk is
+    generated at the length it has in the N = 1 problem and then cut)."""
+    from fitsnap_amd.synthetic import SYNTH_CHUNK, synth_chunk, synth_params
 
-    m, Kc = args.rows, args.cols
-    A, b, w = synth_problem(m, Kc, row_offset=rank * RANK_ROW_STRIDE)
+    scales, beta_star = synth_params(Kc)
+    A = np.empty((hi - lo, Kc))
+    b = np.empty(hi - lo)
+    w = np.empty(hi - lo)
+    for ci in range(lo // SYNTH_CHUNK, (hi + SYNTH_CHUNK - 1) // SYNTH_CHUNK if hi > lo else 0):
+        c0 = ci * SYNTH_CHUNK
+        rows = min(SYNTH_CHUNK, total - c0)
+        Ac, bc, wc = synth_chunk(ci, rows, Kc, beta_star, scales)
+        a, z = max(lo, c0), min(hi, c0 + rows)
+        A[a - lo:z - lo], b[a - lo:z - lo], w[a - lo:z - lo] = Ac[a - c0:z - c0], bc[a - c0:z - c0], wc[a - c0:z - c0]
+    return A, b, w
 
-    ctx = _capi.HipContext(local_rank % _capi.device_count())
-    if multi:
-        ctx.comm_init(world, rank, rendezvous.exchange(rank, world, _capi.comm_id))     # native RCCL, no torch
-        rendezvous.done(rank)
-    for kv in args.option:
-        k, v = kv.split("=")
-        ctx.set_option(k, int(v))
-    repack = not args.no_repack
-    ctx.set_option("repack", 1 if repack else 0)
+
+def run_mode(ctx, args, mode, rank, world, multi, _capi):
+    """One scaling mode on this rank: resident rows, pre-heat, warm-up, K timed steps.  Returns a dict (complete on
+    every rank: the per-rank numbers are exchanged with one small all-reduce)."""
+    from fitsnap_amd.synthetic import synth_problem
+
+    Kc = args.cols
+    if mode == "weak":
+        m_total = args.rows * world
+        A, b, w = synth_problem(args.rows, Kc, row_offset=rank * RANK_ROW_STRIDE)
+    else:
+        m_total = args.rows
+        lo, hi = args.rows * rank // world, args.rows * (rank + 1) // world
+        A, b, w = synth_rows(lo, hi, args.rows, Kc)
+    m = len(b)
     ctx.upload_rows(A, b)
     ctx.set_weights(w)
     upload_ms = ctx.timing()["upload_ms"]
     info = ctx.launch_info()
-    n = Kc * Kc + Kc + 3
 
     def step():
         if multi:
@@ -182,43 +306,132 @@ def main():
         else:
             ctx.sync()
 
-    ctx.set_option("timing_every", 0)
-    for _ in range(max(0, args.preheat)):
-        step()
-    for _ in range(args.warmup):
-        step()
-    fence()
-    # kernel timing of the timed region: HIP events on the kernel's stream around every N-th launch (always the first)
-    every = max(1, args.timing_every)
-    sampled0 = ctx.timing_count()[0]
-    ctx.set_option("timing_every", every)             # the next launch (timed step 0) is a sampled one
-    t0 = time.perf_counter()
-    beta = None
-    for _ in range(args.steps):
-        beta = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    # kernel times of the timed steps: HIP events recorded on the kernel's stream around every launch, read now
-    nh = min(ctx.timing_count()[0] - sampled0, 256)
-    syrk_hist, red_hist = ctx.timing_history(nh)
-    syrk_avg_ms, red_avg_ms = float(np.mean(syrk_hist)), float(np.mean(red_hist))
+    def timed(dist_solve):
+        if multi:
+            ctx.set_option("dist_solve", dist_solve)
+        ctx.set_option("timing_every", 0)
+        for _ in range(max(0, args.preheat) if dist_solve == 0 else 20):
+            step()
+        for _ in range(args.warmup):
+            step()
+        fence()
+        # kernel timing of the timed region: HIP events on the kernel's stream around every N-th launch (always the first)
+        every = max(1, args.timing_every)
+        sampled0 = ctx.timing_count()[0]
+        ctx.set_option("timing_every", every)             # the next launch (timed step 0) is a sampled one
+        t0 = time.perf_counter()
+        beta = None
+        for _ in range(args.steps):
+            beta = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        ctx.set_option("timing_every", 0)
+        # kernel times of the timed steps: HIP events recorded on the kernel's stream, read now
+        nh = min(ctx.timing_count()[0] - sampled0, 256)
+        syrk_hist, red_hist = ctx.timing_history(nh)
+        comm_hist = ctx.timing_history_comm(nh) if multi else np.full(nh, -1.0)
+        comm_ms = float(np.mean(comm_hist[comm_hist >= 0])) if np.any(comm_hist >= 0) else 0.0
+        return elapsed, beta, float(np.mean(syrk_hist)), float(np.mean(red_hist)), comm_ms, nh
+
+    elapsed, beta, syrk_ms, red_ms, comm_ms, nh = timed(0)
+    # per-rank numbers, max-over-ranks wall time
+    per_rank = np.zeros((world, 4))
+    per_rank[rank] = (elapsed, syrk_ms, comm_ms, float(m))
     if multi:
-        mx = np.array([elapsed, syrk_avg_ms])
-        ctx.allreduce_host(mx, _capi.REDUCE_MAX)
-        elapsed, syrk_avg_ms = float(mx[0]), float(mx[1])
+        ctx.allreduce_host(per_rank.reshape(-1), _capi.REDUCE_SUM)
+    out = {
+        "mode": mode, "rows_total": m_total, "rows_this_rank": m, "elapsed": float(per_rank[:, 0].max()), "beta": beta,
+        "kernel_ms": [float(x) for x in per_rank[:, 1]], "allreduce_ms": [float(x) for x in per_rank[:, 2]],
+        "rows_per_rank": [int(x) for x in per_rank[:, 3]], "elapsed_per_rank_s": [float(x) for x in per_rank[:, 0]],
+        "reduce_ms": red_ms, "sampled": nh, "info": info, "upload_ms": upload_ms, "A": A, "b": b, "w": w,
+    }
+    ab = args.dist_solve_ab if args.dist_solve_ab >= 0 else (1 if world > 1 else 0)
+    if multi and ab and mode != "weak":
+        e1, beta1, _, _, c1, _ = timed(1)
+        e = np.array([e1])
+        ctx.allreduce_host(e, _capi.REDUCE_MAX)
+        ctx.set_option("dist_solve", 0)
+        out["dist_solve_ab"] = {
+            "allreduce_solve_everywhere_ms_per_step": out["elapsed"] / args.steps * 1e3,
+            "reduce_solve_on_rank0_bcast_ms_per_step": float(e[0]) / args.steps * 1e3,
+            "same_beta": bool(np.array_equal(beta, beta1)), "reduce_ms_rank0": c1,
+        }
+    return out
+
+
+def run_rank(args):
+    # exactly ONE line on stdout: libraries underneath (RCCL prints a version banner through C stdio, which surfaces
+    # at exit, after everything Python printed) get stderr as their fd 1; the JSON line goes to the real stdout
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE = {world} ranks")
+
+    from fitsnap_amd import rendezvous
+
+    if os.environ.get("FSNAP_BENCH_DRYRUN"):
+        # launch-path check without a GPU (tests/test_bench_launch_cpu.py): rendezvous only, with a stand-in id
+        ident = rendezvous.exchange(rank, world, lambda: hashlib.sha256(os.urandom(16)).digest() * 4)
+        time.sleep(0.2)                                        # every rank has read the id before rank 0 removes it
+        rendezvous.done(rank)
+        rec = {"dryrun": True, "rank": rank, "world": world, "local_rank": local_rank, "id_sha256": hashlib.sha256(ident).hexdigest()}
+        sys.stderr.write("FSNAP_BENCH_DRYRUN " + json.dumps(rec) + "\n")
+        if rank == 0:
+            real_stdout.write(json.dumps(rec) + "\n")
+            real_stdout.flush()
+        return
+
+    from fitsnap_amd import _capi
+
+    ndev = _capi.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a gfx950 GPU (no CPU fallback)")
+    if local_world > ndev:
+        raise SystemExit(f"bench.py: {local_world} ranks on this node but only {ndev} GPU(s) visible (RCCL does not put two "
+                         "ranks on one device)")
+    multi = world > 1 or args.force_dist
+
+    ctx = _capi.HipContext(local_rank % ndev)
+    n_seen = 1
+    if multi:
+        ctx.comm_init(world, rank, rendezvous.exchange(rank, world, _capi.comm_id))     # native RCCL, no torch
+        rendezvous.done(rank)
+        n_seen = ctx.comm_info()[0]
+    for kv in args.option:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
+    repack = not args.no_repack
+    ctx.set_option("repack", 1 if repack else 0)
+
+    Kc = args.cols
+    modes = ["strong", "weak"] if args.scaling == "both" else [args.scaling]
+    results = {}
+    for mode in modes:
+        if mode == "weak" and "strong" in results and world == 1:
+            results["weak"] = results["strong"]            # one GPU: the same rows, the same run
+            continue
+        results[mode] = run_mode(ctx, args, mode, rank, world, multi, _capi)
+    head = results[modes[0]]                               # what `value` reports
 
     # stand-alone row-weighting kernel (north_star: achieved HBM GB/s), measured outside the timed region
     wk = None
     if rank == 0 and world == 1:
         try:
-            d_aw = ctx.dev_alloc(m * Kc * 8)
-            d_bw = ctx.dev_alloc(m * 8)
+            m1 = head["rows_this_rank"]
+            d_aw = ctx.dev_alloc(m1 * Kc * 8)
+            d_bw = ctx.dev_alloc(m1 * 8)
             wms = []
             for i in range(6):
                 ctx.weight_rows_device(d_aw, Kc, d_bw)
                 wms.append(ctx.timing()["weight_ms"])
             wms = float(np.mean(wms[1:]))
-            wbytes = (16 * Kc + 24) * m                      # read A, b, w; write aw, bw
+            wbytes = (16 * Kc + 24) * m1                     # read A, b, w; write aw, bw
             wk = {"kernel": "fsnap_weight_rows_k", "bound": "hbm", "ms": wms, "achieved": wbytes / (wms * 1e-3) / 1e9,
                   "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": wbytes / (wms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                   "algorithmic_bytes_per_launch": wbytes}
@@ -228,20 +441,13 @@ def main():
             wk = {"error": str(e)}
 
     if rank == 0:
-        total_rows = world * m
-        flops_per_launch = (Kc * Kc + 3 * Kc) * m          # K^2 + 3K flop/row x rows per launch
-        bytes_per_launch = (8 * Kc + 16) * m               # A row + b + w per row, A read once
-        if info["split"] == 0:
-            kernel_name = "fsnap_syrk_tiled"
-        elif info["kernel_or_pairs"] == 4:
-            kernel_name = f"fsnap_syrk_wave_p<{info['NB']}>"
-        elif info["kernel_or_pairs"] == 3:
-            kernel_name = f"fsnap_syrk_acc<{info['NB']}>"
-        elif info["kernel_or_pairs"] == 2:
-            kernel_name = f"fsnap_syrk_lds_static<{info['NB']},{info['threads'] // 64}>"
-        else:
-            kernel_name = f"fsnap_syrk_wave<{info['NB']},{info['split']}>"
-        traffic, traffic_source = recorded_traffic(m, Kc, info, kernel_name)
+        info = head["info"]
+        m0 = head["rows_this_rank"]                        # rows one launch of rank 0's kernel processes
+        syrk_avg_ms = head["kernel_ms"][0]
+        flops_per_launch = (Kc * Kc + 3 * Kc) * m0         # K^2 + 3K flop/row x rows per launch
+        bytes_per_launch = (8 * Kc + 16) * m0              # A row + b + w per row, A read once
+        kernel_name = kernel_name_of(info)
+        traffic, traffic_source = recorded_traffic(m0, Kc, info, kernel_name)
         tf = flops_per_launch / (syrk_avg_ms * 1e-3) / 1e12
         gbs = bytes_per_launch / (syrk_avg_ms * 1e-3) / 1e9
         if Kc <= 80:
@@ -255,50 +461,88 @@ def main():
         # halves are redundant), 2 * 16 * 16 flop per row and tile; kernels 1A / 1P / 1 / 1L only
         executed = None
         if info["split"] != 0:
-            executed = info["NB"] * (info["NB"] + 1) // 2 * 512 * m
+            executed = info["NB"] * (info["NB"] + 1) // 2 * 512 * m0
         roofline.update({"executed_mfma_flops_per_launch": executed,
                          "executed_over_algorithmic": (executed / flops_per_launch) if executed else None})
         roofline.update({"traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_name,
-                         "kernel_ms_avg": syrk_avg_ms, "reduce_kernel_ms_avg": red_avg_ms,
-                         "kernel_timing": f"HIP events on the kernel's stream around every {every}. launch of the timed "
-                                          f"region ({nh} of {args.steps} launches)",
+                         "kernel_ms_avg": syrk_avg_ms, "reduce_kernel_ms_avg": head["reduce_ms"],
+                         "rows_per_launch": m0, "rank": 0,
+                         "kernel_timing": f"HIP events on the kernel's stream around every {max(1, args.timing_every)}. launch "
+                                          f"of the timed region ({head['sampled']} of {args.steps} launches)",
                          "flops_per_launch": flops_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch})
+        n = Kc * Kc + Kc + 3
+
+        def rate(res):
+            return res["rows_total"] * args.steps / res["elapsed"]
+
         out = {
-            "metric": "training rows/sec through A^T A + solve, 10^6 x 128 fp64 per GPU",
-            "value": total_rows * args.steps / elapsed,
+            "metric": f"training rows/sec through A^T A + solve, {args.rows} x {Kc} fp64" +
+                      (" in total over the GPUs (strong scaling)" if head["mode"] == "strong" else " per GPU (weak scaling)"),
+            "value": rate(head),
             "unit": "rows/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "preheat_steps": max(0, args.preheat),
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": head["elapsed"] / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": head["mode"],
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"synthetic {m} x {Kc} fp64 A per GPU (SURVEY 8d generator), RIDGE alpha=1e-8 "
-                            "normal equations (BASELINE configs[1]), A/b/w resident in HBM",
-                "rows_per_gpu": m, "K": Kc, "solver": "RIDGE",
+                "workload": (f"synthetic {args.rows} x {Kc} fp64 A (SURVEY 8d generator), RIDGE alpha=1e-8 normal equations "
+                             f"(BASELINE configs[1]), A/b/w resident in HBM; strong: these rows split over {world} GPU(s); "
+                             f"weak: {args.rows} rows on every GPU"),
+                "rows": args.rows, "K": Kc, "solver": "RIDGE",
                 "parallelism": f"dp{world}: rows sharded by rank, one in-place ncclAllReduce of {n} doubles per fit "
                                "(native RCCL behind the C ABI, no torch), solve on every rank",
                 "weights_packed_every_step": repack,
                 "launch": info,
             },
+            "n_ranks_seen": n_seen,
+            "per_rank": {"mode": head["mode"], "rows": head["rows_per_rank"], "kernel_ms": head["kernel_ms"],
+                         "allreduce_ms": head["allreduce_ms"], "wall_s": head["elapsed_per_rank_s"]},
             "roofline": roofline,
             "weighting_kernel": wk,
-            "h2d_upload_ms": upload_ms,
-            "h2d_inclusive_rows_per_s": m / ((upload_ms + elapsed / args.steps * 1e3) * 1e-3),
+            "h2d_upload_ms": head["upload_ms"],
+            "h2d_inclusive_rows_per_s": m0 / ((head["upload_ms"] + head["elapsed"] / args.steps * 1e3) * 1e-3),
             "torch_imported": "torch" in sys.modules,
+            "launched_by": "bench.py" if os.environ.get("FSNAP_BENCH_SPAWNED") else ("launcher" if "RANK" in os.environ else "direct"),
         }
+        for mode in ("strong", "weak"):
+            if mode in results:
+                res = results[mode]
+                out[f"{mode}_value"] = rate(res)
+                out[f"{mode}_ms_per_step"] = res["elapsed"] / args.steps * 1e3
+                if mode != head["mode"]:
+                    out[f"{mode}_per_rank"] = {"rows": res["rows_per_rank"], "kernel_ms": res["kernel_ms"],
+                                               "allreduce_ms": res["allreduce_ms"]}
+        if "dist_solve_ab" in head:
+            out["dist_solve_ab"] = head["dist_solve_ab"]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(A, b, w, beta)
+            out["cpu_baseline"] = cpu_baseline(head["A"], head["b"], head["w"], head["beta"])
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()
     if multi:
         ctx.barrier()
     ctx.close()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    rank = os.environ.get("RANK", "0")
+    world = os.environ.get("WORLD_SIZE", "1")
+    try:
+        run_rank(args)
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001 - one line, then out: interpreter teardown may wait on a stuck stream
+        sys.stderr.write(f"bench.py: rank {rank} of {world} failed: {type(e).__name__}: {e}\n")
+        sys.stderr.flush()
+        os._exit(1)
 
 
 if __name__ == "__main__":

@@ -44,6 +44,7 @@ SIGNATURES = {
     "fsnap_upload_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "fsnap_bind_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "fsnap_rows_alloc": (c_int, [c_void_p, c_int64, c_int64]),
+    "fsnap_drop_rows": (c_int, [c_void_p]),
     "fsnap_assemble": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int]),
     "fsnap_download_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
@@ -90,6 +91,7 @@ SIGNATURES = {
     "fsnap_timing": (c_int, [c_void_p, _P_D, c_int]),
     "fsnap_timing_history": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
     "fsnap_timing_count": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "fsnap_timing_history_comm": (c_int, [c_void_p, c_void_p, c_int]),
     "fsnap_rowspace_chain": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_double, c_void_p, POINTER(c_int), c_void_p]),
     "fsnap_launch_info": (c_int, [c_void_p, POINTER(c_int64), c_int]),
 }
@@ -385,6 +387,12 @@ class HipContext:
         self._check(self._lib.fsnap_bind_rows(self._h, c_void_p(dA_ptr), m, K, lda, c_void_p(db_ptr)))
         self.m, self.K = m, K
 
+    def drop_rows(self):
+        """No rows on this context any more (a rank of a multi-GPU job that owns none for the next fit)."""
+        self._check(self._lib.fsnap_drop_rows(self._h))
+        self.m = 0
+        self.resident_train_mask = None
+
     def rows_alloc(self, m: int, K: int):
         self._check(self._lib.fsnap_rows_alloc(self._h, int(m), int(K)))
         self.m, self.K = int(m), int(K)
@@ -658,6 +666,12 @@ class HipContext:
         b = np.empty(int(n))
         self._check(self._lib.fsnap_timing_history(self._h, _ptr(a), _ptr(b), int(n)))
         return a, b
+
+    def timing_history_comm(self, n: int):
+        """Collective time (ms) on this rank's stream for the last ``n`` event-bracketed fits, -1 where a fit had none."""
+        a = np.empty(int(n))
+        self._check(self._lib.fsnap_timing_history_comm(self._h, _ptr(a), int(n)))
+        return a
 
     def timing_count(self):
         """(event-bracketed SYRK launches, all SYRK launches) of this context so far (option ``timing_every``)."""

@@ -190,14 +190,17 @@ struct TiledGeometry {
 // reduce 4.3 us), i.e. 11 us of a 0.34 ms headline step; *slot stays null on the launches that are not sampled.
 int fit_events(fsnap_ctx* ctx, hipEvent_t** slot) {
     *slot = nullptr;
+    ctx->cur_events = nullptr;
     ++ctx->nlaunch;
     const int64_t phase = ctx->timing_phase++;         // 0 right after the option was set: that launch is sampled
     if (ctx->opt_timing_every <= 0 || phase % ctx->opt_timing_every != 0) return FSNAP_OK;
     hipEvent_t* sl = ctx->ring[ctx->nfit % fsnap_ctx::RING];
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 4; ++i)
         if (!sl[i]) FSNAP_HIP(hipEventCreate(&sl[i]), "hipEventCreate");
+    ctx->ring_comm[ctx->nfit % fsnap_ctx::RING] = false;
     ++ctx->nfit;
     *slot = sl;
+    ctx->cur_events = sl;
     return FSNAP_OK;
 }
 
@@ -582,8 +585,9 @@ int fsnap_ctx_create(int device, fsnap_ctx** out) {
 int fsnap_ctx_destroy(fsnap_ctx* ctx) {
     if (!ctx) return FSNAP_OK;
     (void)hipSetDevice(ctx->device);
+    if (ctx->stream && !ctx->comm_broken) (void)hipStreamSynchronize(ctx->stream);
+    (void)fsnap_comm_destroy(ctx);                    // a broken communicator is aborted: its stuck kernel leaves the stream
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    (void)fsnap_comm_destroy(ctx);
     fsnap::rowspace_release(ctx);
     ctx->commbuf.release();
     DevBuf* bufs[] = {&ctx->ownA, &ctx->ownb, &ctx->ownw, &ctx->ownmask, &ctx->ones, &ctx->part, &ctx->cpart,
@@ -654,6 +658,9 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
         ctx->timing_phase = 0;
     } else if (!strcmp(key, "repack")) {
         ctx->opt_repack = value != 0;
+    } else if (!strcmp(key, "dist_solve")) {
+        if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "dist_solve must be 0 (solve on every rank) or 1 (rank 0 solves and broadcasts)");
+        ctx->opt_dist_solve = (int)value;
     } else if (!strcmp(key, "nsplit")) {
         if (value < 0 || value > (1 << 24)) return ctx->fail(FSNAP_E_ARG, "nsplit out of range");
         ctx->opt_nsplit = (int)value;
@@ -700,6 +707,26 @@ int fsnap_upload_rows(fsnap_ctx* ctx, const double* A, int64_t m, int64_t K, int
     ctx->m = m;
     ctx->K = K;
     ctx->lda = K;
+    return FSNAP_OK;
+}
+
+int fsnap_drop_rows(fsnap_ctx* ctx) {
+    if (!ctx) return FSNAP_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream && !ctx->comm_broken) (void)hipStreamSynchronize(ctx->stream);   // a launch may still read them
+    ctx->dA = nullptr;
+    ctx->db = nullptr;
+    ctx->dw = nullptr;
+    ctx->dmask = nullptr;
+    ctx->m = 0;
+    ctx->ntrain_resident = -1;
+    ctx->wpack_valid = false;
+    ctx->mirror_of = nullptr;
+    ctx->ownA.release();
+    ctx->ownb.release();
+    ctx->ownw.release();
+    ctx->ownmask.release();
+    ctx->ones.release();
     return FSNAP_OK;
 }
 
@@ -1172,15 +1199,13 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
         const double* h;
         if (host_out) {
             FSNAP_HIP(hipEventRecord(ctx->chol_ev, ctx->stream), "hipEventRecord");
-            while (true) {
-                const hipError_t q = hipEventQuery(ctx->chol_ev);
-                if (q == hipSuccess) break;
-                if (q != hipErrorNotReady) return ctx->hipfail(q, "hipEventQuery");
-            }
+            int wrc;
+            if ((wrc = fsnap::wait_stream(ctx, ctx->chol_ev, "device Cholesky"))) return wrc;
             h = host_out;
         } else {
             FSNAP_HIP(hipMemcpyAsync(ctx->pinned, dv, head * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(beta)");
-            FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+            int wrc;
+            if ((wrc = fsnap::wait_stream(ctx, nullptr, "device Cholesky"))) return wrc;
             h = ctx->pinned;
         }
         int status;
@@ -1205,11 +1230,8 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
     // statistics already mirrored in page-locked host memory by the reduction kernel: wait for it (polling the
     // event: the blocking wait's wake-up latency is several microseconds) and solve
     if (ctx->mirror_of == d_packed && ctx->mirror && K == ctx->mirror_K) {
-        while (true) {
-            const hipError_t q = hipEventQuery(ctx->mirror_ev);
-            if (q == hipSuccess) break;
-            if (q != hipErrorNotReady) return ctx->hipfail(q, "hipEventQuery");
-        }
+        int wrc;
+        if ((wrc = fsnap::wait_stream(ctx, ctx->mirror_ev, "statistics mirror"))) return wrc;
         const double* Gm = ctx->mirror;
         const int rcm = fsnap_solve_diag(kind, param, K, Gm, rhs ? rhs : Gm + K * K, Gm + K * K + K + 3, beta, rank, rcond_est);
         if (rcm) ctx->fail(rcm, "fsnap_solve: numerical status %d", rcm);
@@ -1226,7 +1248,10 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
         ctx->pinned_bytes = need;
     }
     FSNAP_HIP(hipMemcpyAsync(ctx->pinned, d_packed, need, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(G)");
-    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    {
+        int wrc;
+        if ((wrc = fsnap::wait_stream(ctx, nullptr, "statistics download"))) return wrc;
+    }
     const double* G = ctx->pinned;
     const int rc = fsnap_solve(kind, param, K, G, rhs ? rhs : G + K * K, beta, rank, rcond_est);
     if (rc) ctx->fail(rc, "fsnap_solve: numerical status %d", rc);
@@ -1249,29 +1274,65 @@ int fsnap_fit_resident(fsnap_ctx* ctx, int kind, double param, double* beta, int
 int fsnap_fit_dist(fsnap_ctx* ctx, int kind, double param, int64_t K, double* beta, int* rank, double* rcond_est,
                    double** d_packed) {
     if (!ctx) return FSNAP_E_ARG;
+    if (d_packed) *d_packed = nullptr;
     if (!beta || K <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_fit_dist: bad argument");
-    const bool have_rows = ctx->dA && ctx->m > 0;
-    if (have_rows && ctx->K != K) return ctx->fail(FSNAP_E_ARG, "fsnap_fit_dist: K = %lld but the resident rows have %lld columns",
-                                                   (long long)K, (long long)ctx->K);
-    if (!ctx->comm) {
-        if (!have_rows) return ctx->fail(FSNAP_E_STATE, "no rows: call fsnap_upload_rows/fsnap_bind_rows first");
-        return fsnap_fit_resident(ctx, kind, param, beta, rank, rcond_est, d_packed);
-    }
+    // no silent single-GPU fallback: a job that lost its communicator (context re-created after ParallelTools.free())
+    // would otherwise fit every rank's own shard and publish rank 0's as the global fit
+    if (!ctx->comm) return ctx->fail(FSNAP_E_STATE, "fsnap_fit_dist: no communicator (fsnap_comm_init first; single-GPU fits call fsnap_fit_resident)");
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     const int64_t n = FSNAP_PACKED_LEN(K);
+    // the one thing a rank cannot recover from locally: without the buffer it cannot take part in the collective at all
+    // (its peers run into FSNAP_COMM_TIMEOUT)
     if (!ctx->packed.ensure((size_t)n * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(packed) failed");
     double* dp = (double*)ctx->packed.p;
-    int rc;
-    if (have_rows) {
-        if ((rc = launch_normal_eq(ctx, dp))) return rc;
+    // Everything that can fail on THIS rank alone happens before the collective -- and must not keep the rank out of
+    // it (the peers would wait forever): a rank that fails contributes a buffer of NaNs, every rank then sees
+    // non-finite statistics and returns FSNAP_NUM_NONFINITE, the failing rank returns its own error.
+    const bool have_rows = ctx->dA && ctx->m > 0;
+    int local_rc = FSNAP_OK;
+    std::string local_err;
+    ctx->cur_events = nullptr;
+    if (have_rows && ctx->K != K) {
+        local_rc = ctx->fail(FSNAP_E_ARG, "fsnap_fit_dist: K = %lld but the resident rows have %lld columns", (long long)K,
+                             (long long)ctx->K);
+    } else if (have_rows) {
+        local_rc = launch_normal_eq(ctx, dp);
     } else {
         ctx->mirror_of = nullptr;
-        FSNAP_HIP(hipMemsetAsync(dp, 0, (size_t)n * 8, ctx->stream), "hipMemsetAsync(packed)");   // a rank without rows
+        if (hipMemsetAsync(dp, 0, (size_t)n * 8, ctx->stream) != hipSuccess)   // a rank without rows
+            local_rc = ctx->fail(FSNAP_E_HIP, "hipMemsetAsync(packed) failed");
     }
-    if ((rc = fsnap_allreduce_device(ctx, dp, n))) return rc;
-    if ((rc = fsnap_mirror_packed(ctx, dp, K))) return rc;         // K < 384: page-locked mirror instead of a D2H copy
-    if (d_packed) *d_packed = dp;
-    return fsnap_solve_device_rhs(ctx, kind, param, K, dp, nullptr, beta, rank, rcond_est);
+    if (local_rc != FSNAP_OK) {
+        local_err = ctx->err;
+        ctx->mirror_of = nullptr;
+        ctx->cur_events = nullptr;
+        (void)hipMemsetAsync(dp, 0xFF, (size_t)n * 8, ctx->stream);            // all bits set = NaN in every double
+    }
+    hipEvent_t* evs = ctx->cur_events;
+    int rc;
+    if (ctx->opt_dist_solve == 1 && ctx->comm) {
+        // A/B variant: reduce to rank 0, solve there, broadcast [beta | rank | rcond | status]
+        rc = fsnap::dist_reduce_solve_bcast(ctx, kind, param, K, dp, evs, beta, rank, rcond_est);
+        int nr = 1, me = 0;
+        (void)fsnap_comm_info(ctx, &nr, &me);
+        if (d_packed && me == 0) *d_packed = dp;       // the other ranks hold only their own sums: not handed out
+    } else {
+        if ((rc = fsnap_allreduce_device(ctx, dp, n))) return rc;
+        if (evs) {
+            FSNAP_HIP(hipEventRecord(evs[3], ctx->stream), "hipEventRecord");
+            ctx->ring_comm[(ctx->nfit - 1) % fsnap_ctx::RING] = true;
+        }
+        if (local_rc == FSNAP_OK) {
+            if ((rc = fsnap_mirror_packed(ctx, dp, K))) return rc;     // K < 384: page-locked mirror instead of a D2H copy
+            if (d_packed) *d_packed = dp;
+            rc = fsnap_solve_device_rhs(ctx, kind, param, K, dp, nullptr, beta, rank, rcond_est);
+        }
+    }
+    if (local_rc != FSNAP_OK) return ctx->fail(local_rc, "%s", local_err.c_str());
+    if (rc == FSNAP_NUM_NONFINITE)
+        ctx->fail(rc, "non-finite statistics after the all-reduce: NaN/Inf in a training row of some rank, or a rank failed "
+                      "before the collective (see that rank's error)");
+    return rc;
 }
 
 int fsnap_dev_alloc(fsnap_ctx* ctx, int64_t nbytes, void** d_ptr) {
@@ -1390,6 +1451,24 @@ int fsnap_timing_history(fsnap_ctx* ctx, double* syrk_ms, double* reduce_ms, int
         if (reduce_ms) {
             FSNAP_HIP(hipEventElapsedTime(&t, sl[1], sl[2]), "hipEventElapsedTime");
             reduce_ms[i] = t;
+        }
+    }
+    return FSNAP_OK;
+}
+
+int fsnap_timing_history_comm(fsnap_ctx* ctx, double* allreduce_ms, int n) {
+    if (!ctx || !allreduce_ms || n < 0) return FSNAP_E_ARG;
+    if (n > fsnap_ctx::RING || n > ctx->nfit) return ctx->fail(FSNAP_E_ARG, "fsnap_timing_history_comm: only the last %d fits are kept",
+                                                             (int)(ctx->nfit < fsnap_ctx::RING ? ctx->nfit : fsnap_ctx::RING));
+    int wrc;
+    if ((wrc = fsnap::wait_stream(ctx, nullptr, "timing history"))) return wrc;
+    for (int i = 0; i < n; ++i) {
+        const int64_t k = (ctx->nfit - n + i) % fsnap_ctx::RING;
+        float t = 0.f;
+        allreduce_ms[i] = -1.0;                         // not a multi-GPU fit
+        if (ctx->ring_comm[k]) {
+            FSNAP_HIP(hipEventElapsedTime(&t, ctx->ring[k][2], ctx->ring[k][3]), "hipEventElapsedTime");
+            allreduce_ms[i] = t;
         }
     }
     return FSNAP_OK;

@@ -12,9 +12,13 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <future>
+#include <memory>
 #include <new>
+#include <thread>
 
 #include "fsnap_ctx.h"
 
@@ -25,7 +29,9 @@ struct Rccl {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclReduce) Reduce = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -61,7 +67,9 @@ static Rccl* rccl() {
     r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.CommAbort = (decltype(r.CommAbort))sym("ncclCommAbort");
     r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+    r.Reduce = (decltype(r.Reduce))sym("ncclReduce");
     r.Broadcast = (decltype(r.Broadcast))sym("ncclBroadcast");
     r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
@@ -76,6 +84,44 @@ struct Comm {
     ncclComm_t nccl = nullptr;
     int nranks = 1, rank = 0;
 };
+
+double comm_timeout_s() {
+    static const double t = [] {
+        const char* e = getenv("FSNAP_COMM_TIMEOUT");
+        const double v = e && *e ? atof(e) : 300.0;
+        return v > 0.0 ? v : 300.0;
+    }();
+    return t;
+}
+
+int wait_stream(fsnap_ctx* ctx, hipEvent_t ev, const char* what) {
+    const bool bounded = ctx->comm != nullptr;
+    if (!bounded && !ev) {
+        FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+        return FSNAP_OK;
+    }
+    // busy poll (the blocking wait's wake-up latency is several microseconds); the clock is read every 1024 polls
+    std::chrono::steady_clock::time_point deadline;
+    bool armed = false;
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = ev ? hipEventQuery(ev) : hipStreamQuery(ctx->stream);
+        if (q == hipSuccess) return FSNAP_OK;
+        if (q != hipErrorNotReady) return ctx->hipfail(q, ev ? "hipEventQuery" : "hipStreamQuery");
+        if (bounded && (spins & 1023u) == 1023u) {
+            const auto now = std::chrono::steady_clock::now();
+            if (!armed) {
+                deadline = now + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(comm_timeout_s()));
+                armed = true;
+            } else if (now > deadline) {
+                ctx->comm_broken = true;
+                return ctx->fail(FSNAP_E_HIP,
+                                 "rank %d of %d: %s did not finish within %.0f s (FSNAP_COMM_TIMEOUT) behind a collective: a peer "
+                                 "rank died or never reached it",
+                                 ctx->comm->rank, ctx->comm->nranks, what, comm_timeout_s());
+            }
+        }
+    }
+}
 
 }  // namespace fsnap
 
@@ -133,7 +179,33 @@ int fsnap_comm_init(fsnap_ctx* ctx, int nranks, int rank, const char* id) {
     if (!c) return ctx->fail(FSNAP_E_NOMEM, "out of host memory");
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
-    const ncclResult_t e = r->CommInitRank(&c->nccl, nranks, uid, rank);
+    // ncclCommInitRank blocks until ALL ranks have joined; with a rank missing (crashed before this point, stale id) it
+    // never returns and cannot be cancelled.  It therefore runs in a thread of its own: after FSNAP_COMM_TIMEOUT seconds
+    // this call gives up with an error and leaves the thread behind (the process is expected to exit).
+    struct Shared {
+        std::promise<ncclResult_t> done;
+        ncclComm_t nccl = nullptr;
+    };
+    auto sh = std::make_shared<Shared>();
+    std::future<ncclResult_t> fut = sh->done.get_future();
+    const int device = ctx->device;
+    auto init = r->CommInitRank;
+    std::thread([sh, init, uid, nranks, rank, device]() {
+        (void)hipSetDevice(device);
+        ncclComm_t comm = nullptr;
+        const ncclResult_t e = init(&comm, nranks, uid, rank);
+        sh->nccl = comm;
+        sh->done.set_value(e);
+    }).detach();
+    if (fut.wait_for(std::chrono::duration<double>(fsnap::comm_timeout_s())) != std::future_status::ready) {
+        delete c;
+        return ctx->fail(FSNAP_E_HIP,
+                         "ncclCommInitRank: rank %d of %d did not complete within %.0f s (FSNAP_COMM_TIMEOUT): a rank is missing "
+                         "or holds a different communicator id",
+                         rank, nranks, fsnap::comm_timeout_s());
+    }
+    const ncclResult_t e = fut.get();
+    c->nccl = sh->nccl;
     if (e != ncclSuccess) {
         delete c;
         return nccl_fail(ctx, r, e, "ncclCommInitRank");
@@ -149,10 +221,17 @@ int fsnap_comm_destroy(fsnap_ctx* ctx) {
     if (!ctx->comm) return FSNAP_OK;
     Rccl* r = fsnap::rccl();
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->comm->nccl && r->handle) (void)r->CommDestroy(ctx->comm->nccl);
+    if (ctx->comm_broken) {
+        // a wait behind a collective ran out: the stream holds an RCCL kernel that waits for a dead peer.  Abort makes
+        // that kernel leave; synchronising first would hang
+        if (ctx->comm->nccl && r->handle && r->CommAbort) (void)r->CommAbort(ctx->comm->nccl);
+    } else {
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->comm->nccl && r->handle) (void)r->CommDestroy(ctx->comm->nccl);
+    }
     delete ctx->comm;
     ctx->comm = nullptr;
+    ctx->comm_broken = false;
     return FSNAP_OK;
 }
 
@@ -186,8 +265,7 @@ int fsnap_allreduce_host(fsnap_ctx* ctx, double* buf, int64_t n, int op) {
     FSNAP_HIP(hipMemcpyAsync(ctx->commbuf.p, buf, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(H2D)");
     FSNAP_NCCL(r->AllReduce(ctx->commbuf.p, ctx->commbuf.p, (size_t)n, ncclDouble, rop, ctx->comm->nccl, ctx->stream), "ncclAllReduce");
     FSNAP_HIP(hipMemcpyAsync(buf, ctx->commbuf.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(D2H)");
-    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
-    return FSNAP_OK;
+    return fsnap::wait_stream(ctx, nullptr, "all-reduce");
 }
 
 int fsnap_bcast_host(fsnap_ctx* ctx, void* buf, int64_t nbytes, int root) {
@@ -203,8 +281,7 @@ int fsnap_bcast_host(fsnap_ctx* ctx, void* buf, int64_t nbytes, int root) {
     FSNAP_NCCL(r->Broadcast(ctx->commbuf.p, ctx->commbuf.p, (size_t)nbytes, ncclUint8, root, ctx->comm->nccl, ctx->stream), "ncclBroadcast");
     if (ctx->comm->rank != root)
         FSNAP_HIP(hipMemcpyAsync(buf, ctx->commbuf.p, (size_t)nbytes, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(D2H)");
-    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
-    return FSNAP_OK;
+    return fsnap::wait_stream(ctx, nullptr, "broadcast");
 }
 
 int fsnap_allgather_host(fsnap_ctx* ctx, const void* send, int64_t nbytes, void* recv) {
@@ -221,8 +298,7 @@ int fsnap_allgather_host(fsnap_ctx* ctx, const void* send, int64_t nbytes, void*
     FSNAP_HIP(hipMemcpyAsync(d_send, send, nb, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(H2D)");
     FSNAP_NCCL(r->AllGather(d_send, d_recv, nb, ncclUint8, ctx->comm->nccl, ctx->stream), "ncclAllGather");
     FSNAP_HIP(hipMemcpyAsync(recv, d_recv, total, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(D2H)");
-    FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
-    return FSNAP_OK;
+    return fsnap::wait_stream(ctx, nullptr, "all-gather");
 }
 
 int fsnap_barrier(fsnap_ctx* ctx) {
@@ -237,3 +313,49 @@ int fsnap_barrier(fsnap_ctx* ctx) {
 }
 
 }  // extern "C"
+
+namespace fsnap {
+
+int dist_reduce_solve_bcast(fsnap_ctx* ctx, int kind, double param, int64_t K, double* dp, hipEvent_t* evs, double* beta,
+                            int* rank, double* rcond_est) {
+    Rccl* r;
+    int rc;
+    if ((rc = need_comm(ctx, &r))) return rc;
+    const int64_t n = FSNAP_PACKED_LEN(K);
+    const bool root = ctx->comm->rank == 0;
+    FSNAP_NCCL(r->Reduce(dp, dp, (size_t)n, ncclDouble, ncclSum, 0, ctx->comm->nccl, ctx->stream), "ncclReduce");
+    if (evs) {
+        FSNAP_HIP(hipEventRecord(evs[3], ctx->stream), "hipEventRecord");
+        ctx->ring_comm[(ctx->nfit - 1) % fsnap_ctx::RING] = true;
+    }
+    // message: [beta (K) | rank | rcond | status]
+    const size_t words = (size_t)K + 3;
+    if (!ctx->commbuf.ensure(words * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(collective staging) failed");
+    std::unique_ptr<double[]> msg(new (std::nothrow) double[words]);
+    if (!msg) return ctx->fail(FSNAP_E_NOMEM, "out of host memory");
+    int solve_rc = FSNAP_OK;
+    if (root) {
+        int rk = 0;
+        double rce = 0.0;
+        for (size_t i = 0; i < words; ++i) msg[i] = 0.0;
+        solve_rc = fsnap_mirror_packed(ctx, dp, K);
+        if (solve_rc == FSNAP_OK) solve_rc = fsnap_solve_device_rhs(ctx, kind, param, K, dp, nullptr, msg.get(), &rk, &rce);
+        msg[K] = (double)rk;
+        msg[K + 1] = rce;
+        msg[K + 2] = (double)solve_rc;
+        // a failed solve still sends its status: the other ranks are waiting in the broadcast
+        FSNAP_HIP(hipMemcpyAsync(ctx->commbuf.p, msg.get(), words * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(H2D)");
+    }
+    FSNAP_NCCL(r->Broadcast(ctx->commbuf.p, ctx->commbuf.p, words, ncclDouble, 0, ctx->comm->nccl, ctx->stream), "ncclBroadcast");
+    if (!root) FSNAP_HIP(hipMemcpyAsync(msg.get(), ctx->commbuf.p, words * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(D2H)");
+    if ((rc = wait_stream(ctx, nullptr, "broadcast of the fit"))) return rc;
+    for (int64_t i = 0; i < K; ++i) beta[i] = msg[i];
+    if (rank) *rank = (int)msg[K];
+    if (rcond_est) *rcond_est = msg[K + 1];
+    const int status = (int)msg[K + 2];
+    if (status != FSNAP_OK && !root) ctx->fail(status, "fsnap_fit_dist: the solve on rank 0 returned status %d", status);
+    return status;
+}
+
+}  // namespace fsnap
+

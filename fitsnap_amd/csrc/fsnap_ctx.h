@@ -50,8 +50,11 @@ struct fsnap_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev[10] = {};
-    static constexpr int RING = 256;              // event triples of the last RING fits (fsnap_timing_history)
-    hipEvent_t ring[RING][3] = {};
+    static constexpr int RING = 256;              // event sets of the last RING fits (fsnap_timing_history): before SYRK,
+                                                  // after SYRK, after the reduction, after the all-reduce (fsnap_fit_dist)
+    hipEvent_t ring[RING][4] = {};
+    bool ring_comm[RING] = {};                    // slot's 4th event was recorded (a multi-GPU fit)
+    hipEvent_t* cur_events = nullptr;             // event set of the fit being launched (nullptr: not a sampled one)
     double* chol_host = nullptr;                  // page-locked [beta | panel pivots | status] written by the device Cholesky
     size_t chol_host_bytes = 0;
     hipEvent_t chol_ev = nullptr;
@@ -132,6 +135,8 @@ struct fsnap_ctx {
     int64_t dense_pinv_token = 0;
     DevBuf commbuf;                               // device staging of host-buffer collectives
     int opt_repack = 0;       // 1 = pack (w_eff, w_eff b) on every launch even when b / w / mask are context-owned
+    int opt_dist_solve = 0;   // fsnap_fit_dist: 0 = all-reduce + solve on every rank, 1 = reduce to rank 0 + solve there + broadcast beta
+    bool comm_broken = false; // a bounded wait behind a collective ran out: the stream may hold a stuck RCCL kernel
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -156,6 +161,18 @@ struct fsnap_ctx {
     } while (0)
 
 namespace fsnap {
+// fsnap_comm.cpp: seconds a wait behind a collective may take (FSNAP_COMM_TIMEOUT, default 300)
+double comm_timeout_s();
+// fsnap_comm.cpp: wait for the context's stream (ev == nullptr) or for an event on it.  Without a communicator this is
+// a plain busy poll / hipStreamSynchronize; with one the wait is bounded by FSNAP_COMM_TIMEOUT -- a peer that died
+// before its collective leaves this rank's stream stuck in an RCCL kernel -- and runs out with FSNAP_E_HIP + one line
+// in fsnap_last_error; the communicator is then aborted instead of destroyed when the context goes away.
+int wait_stream(fsnap_ctx* ctx, hipEvent_t ev, const char* what);
+// fsnap_comm.cpp: the reduce-to-root form of a multi-GPU fit (option dist_solve = 1): ncclReduce of the packed statistics to
+// rank 0, fsnap_solve_device there, ncclBroadcast of [beta | rank | rcond | status]; evs[3] (may be null) is recorded
+// behind the reduce
+int dist_reduce_solve_bcast(fsnap_ctx* ctx, int kind, double param, int64_t K, double* dp, hipEvent_t* evs, double* beta,
+                            int* rank, double* rcond_est);
 // fsnap_capi.cpp: statistics of OTHER rows than the resident ones with the resident rows' launch plan -- the passes
 // of the row-space solve run the same SYRK kernels on the orthogonalised copy Q (m x K, leading dimension ldq) with
 // per-row pairs qpack = (1, w_eff b); d_packed receives [Q^T Q | Q^T b_w | ...]

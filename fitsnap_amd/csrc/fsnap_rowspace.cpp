@@ -30,6 +30,7 @@
 #include <cstring>
 #include <limits>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "fsnap_ctx.h"
@@ -158,11 +159,23 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
     const int K = (int)K64, K16 = (K + 15) & ~15;
     const int64_t npk = FSNAP_PACKED_LEN(K64);
     const int nranks = ctx->comm ? 2 : 1;     // "> 1" = collective (a communicator of one rank takes the same path)
-    const bool have_rows = ctx->dA && ctx->m > 0;
+    bool have_rows = ctx->dA && ctx->m > 0;
+    // Failures that only THIS rank sees must not keep it out of the first collective (its peers would wait until
+    // FSNAP_COMM_TIMEOUT): the rank then contributes NaN statistics, every rank stops at the first factorisation with
+    // FSNAP_NUM_NONFINITE, and this rank reports its own error.
+    int local_rc = FSNAP_OK;
+    std::string local_err;
+    auto local_fail = [&](int code) {
+        if (local_rc == FSNAP_OK) {
+            local_rc = code;
+            local_err = ctx->err;
+        }
+    };
     if (have_rows && ctx->K != K64)
-        return ctx->fail(FSNAP_E_ARG, "fsnap_lstsq_rows: K = %d but the resident rows have %lld columns", K, (long long)ctx->K);
+        local_fail(ctx->fail(FSNAP_E_ARG, "fsnap_lstsq_rows: K = %d but the resident rows have %lld columns", K, (long long)ctx->K));
     if (!have_rows && nranks == 1) return ctx->fail(FSNAP_E_STATE, "no rows: call fsnap_upload_rows/fsnap_bind_rows first");
-    if (have_rows && !ctx->dw) return ctx->fail(FSNAP_E_STATE, "no weights: call fsnap_set_weights/fsnap_bind_weights first");
+    if (have_rows && !ctx->dw) local_fail(ctx->fail(FSNAP_E_STATE, "no weights: call fsnap_set_weights/fsnap_bind_weights first"));
+    if (local_rc != FSNAP_OK && nranks == 1) return local_rc;
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     if (!ctx->rowspace) {
         ctx->rowspace = new (std::nothrow) fsnap::RowSpace();
@@ -170,14 +183,17 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
     }
     fsnap::RowSpace* rs = ctx->rowspace;
     const size_t m = have_rows ? (size_t)ctx->m : 0;
+    // the small K x K workspaces: without them this rank cannot even take part in the collective
     if (!rs->packed.ensure((size_t)npk * 8) || !rs->Rdev.ensure((size_t)K16 * K16 * 8) || !rs->beta.ensure((size_t)K * 8) ||
         !rs->dz.ensure((size_t)K * 8) || !rs->pin_ensure((size_t)npk + (size_t)K16 * K16 + 2 * (size_t)K))
         return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(row-space workspace) failed");
-    if (have_rows) {
+    if (have_rows && local_rc == FSNAP_OK) {
         const int nbt = fsnap::gemvT_num_blocks(ctx->m);
         if (!rs->Q.ensure(m * (size_t)K * 8 + 256) || !rs->qpack.ensure(m * 16 + 64) || !rs->rvec.ensure(m * 8) ||
-            !rs->dzpart.ensure((size_t)nbt * K * 8))
-            return ctx->fail(FSNAP_E_NOMEM, "hipMalloc of %zu bytes for the orthogonalised rows failed", m * (size_t)K * 8);
+            !rs->dzpart.ensure((size_t)nbt * K * 8)) {
+            local_fail(ctx->fail(FSNAP_E_NOMEM, "hipMalloc of %zu bytes for the orthogonalised rows failed", m * (size_t)K * 8));
+            if (nranks == 1) return local_rc;
+        }
     }
     double* dp = (double*)rs->packed.p;
     double* dQ = (double*)rs->Q.p;
@@ -195,19 +211,24 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
 
     // statistics of the current Q (pass 0: of A_w), summed over the ranks, on the host
     auto gather_stats = [&](bool of_rows) -> int {
-        if (have_rows) {
+        if (local_rc == FSNAP_OK && have_rows) {
             int r2 = of_rows ? fsnap_normal_eq_async(ctx, dp) : fsnap::normal_eq_launch_on(ctx, dQ, K, (const double*)rs->qpack.p, dp);
-            if (r2) return r2;
-        } else {
+            if (r2) {
+                if (nranks == 1) return r2;
+                local_fail(r2);
+            }
+        } else if (local_rc == FSNAP_OK) {
             FSNAP_HIP(hipMemsetAsync(dp, 0, (size_t)npk * 8, st), "hipMemsetAsync(packed)");
         }
+        if (local_rc != FSNAP_OK) (void)hipMemsetAsync(dp, 0xFF, (size_t)npk * 8, st);     // NaN in every double
         if (nranks > 1) {
             int r3 = fsnap_allreduce_device(ctx, dp, npk);
             if (r3) return r3;
         }
         FSNAP_HIP(hipMemcpyAsync(host, dp, (size_t)npk * 8, hipMemcpyDeviceToHost, st), "hipMemcpy(statistics)");
-        FSNAP_HIP(hipStreamSynchronize(st), "hipStreamSynchronize");
-        return FSNAP_OK;
+        int r4 = fsnap::wait_stream(ctx, nullptr, "statistics of a row-space pass");
+        if (r4) return r4;
+        return local_rc != FSNAP_OK ? ctx->fail(local_rc, "%s", local_err.c_str()) : FSNAP_OK;
     };
     // FSNAP_ROWSPACE_TIMING=1: wall-clock marks of the host phases on stderr
     const bool timing = getenv("FSNAP_ROWSPACE_TIMING") != nullptr;
@@ -233,6 +254,9 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
         int conv = 0;
         if (pass == 1 && chained) chain.start(K, host);
         rc = factor_pass(K, host, pass == 1, tol, chained ? nullptr : Rhat.data(), Rp.data(), &dev, &conv, &shift);
+        if (rc == FSNAP_NUM_NONFINITE && nranks > 1)
+            return ctx->fail(rc, "row-space pass %d: non-finite statistics after the all-reduce (NaN/Inf in a training row of some "
+                                 "rank, or a rank failed before the collective: see that rank's error)", pass);
         if (rc) return ctx->fail(rc, "row-space pass %d: the Gram matrix could not be factorised (status %d)", pass, rc);
         if (conv) {
             converged = 1;
@@ -253,7 +277,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
                 FSNAP_HIP(fsnap::launch_trsm_rows(dQ, K, nullptr, dQ, K, ctx->m, K, (const double*)rs->Rdev.p, K16, st),
                           "launch fsnap_trsm_rows_k");
         }
-        FSNAP_HIP(hipStreamSynchronize(st), "hipStreamSynchronize");      // Rpad is reused by the next pass
+        if ((rc = fsnap::wait_stream(ctx, nullptr, "row-space pass"))) return rc;      // Rpad is reused by the next pass
         passes = pass;
         mark("factor upload + TRSM pass");
         if ((rc = gather_stats(false))) return rc;
@@ -307,7 +331,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
             FSNAP_HIP(fsnap::launch_gemvT_rows(dQ, K, (const double*)rs->rvec.p, ctx->m, K, (double*)rs->dzpart.p,
                                                (double*)rs->dz.p, st), "launch fsnap_gemvT_rows_k");
             FSNAP_HIP(hipMemcpyAsync(hvec + K, rs->dz.p, (size_t)K * 8, hipMemcpyDeviceToHost, st), "hipMemcpy(dz)");
-            FSNAP_HIP(hipStreamSynchronize(st), "hipStreamSynchronize");
+            if ((rc = fsnap::wait_stream(ctx, nullptr, "row-space refinement"))) return rc;
             memcpy(dzh.data(), hvec + K, (size_t)K * 8);
         }
         if (nranks > 1 && (rc = fsnap_allreduce_host(ctx, dzh.data(), K, 0))) return rc;

@@ -251,13 +251,14 @@ class _RcclTransport:
         self._joined = False
         self.on_gpu = True
 
-    def join(self, pt):
-        """Collective, once: create this rank's context and enter the communicator."""
+    def join(self, pt, ctx):
+        """Collective, once per context: enter the communicator with this rank's (new) context ``ctx``.  Runs again
+        after ``ParallelTools.free()`` destroyed the context together with its communicator -- on every rank, because
+        ``free()`` is called on every rank."""
         if self._joined:
             return
         from . import _capi, rendezvous
 
-        ctx = pt.hip()
         if self._exchange_id is not None:
             ident = self._exchange_id(_capi.comm_id() if self.rank == 0 else None)
         else:
@@ -297,7 +298,7 @@ class _RcclTransport:
         pt.hip().barrier()
 
     def close(self, pt):
-        pass                                                       # the context's destructor leaves the communicator
+        self._joined = False                                       # the context's destructor left the communicator
 
 
 class ParallelTools:
@@ -340,7 +341,7 @@ class ParallelTools:
         self.fitsnap_dict = {}
         self.local_lists = {}    # multi-rank: this rank's row-metadata lists after gather_fitsnap
         if self.comm_kind == "rccl":
-            self._transport.join(self)
+            self.hip()                                             # creates the context and joins the communicator
         self._set_seed()
 
     @property
@@ -490,6 +491,15 @@ class ParallelTools:
             import os
 
             self._hip.set_option("timing_every", 1 if os.environ.get("FSNAP_KERNEL_TIMING", "0") not in ("", "0") else 0)
+            if self.comm_kind == "rccl":
+                # a context without a communicator in a multi-rank job would fit this rank's shard alone: a context
+                # (re-)created after free() joins again before anybody can use it (collective)
+                try:
+                    self._transport.join(self, self._hip)
+                except BaseException:
+                    self._hip.close()
+                    self._hip = None
+                    raise
         return self._hip
 
     # -- shared arrays (parallel_tools.py:338-424) ----------------------------------------
@@ -523,6 +533,8 @@ class ParallelTools:
         if self._hip is not None:
             self._hip.close()                  # fsnap_ctx_destroy leaves the RCCL communicator first
             self._hip = None
+        if self._transport is not None:
+            self._transport.close(self)        # native transport: the next hip() joins a new communicator
 
     def slice_array(self, name: str) -> None:
         if name not in self.shared_arrays:

@@ -334,6 +334,9 @@ class Solver:
         if have_rows:
             ctx = self._upload(a, b, shared_mode)
             self._push_weights(ctx, w_full, mask)
+        elif ctx.m > 0:
+            ctx.drop_rows()                 # rows of an EARLIER fit must not stand in for this rank's empty share
+            self._resident_key = None
         if pt.multi:
             beta, rank, rcond, ptr = ctx.fit_dist(kind, param, K)       # collective
         else:

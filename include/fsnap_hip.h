@@ -82,7 +82,10 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * when b, w and the mask are context-owned and unchanged; default 0 = once per fsnap_set_weights / fsnap_upload_rows),
  * "timing_every" (N: HIP events bracket every N-th SYRK launch only -- an event record between two dependent kernels idles
  * the stream for ~5.6 us; 0 = no events, default 1 = every launch; the first launch after the option is set is a sampled one; fsnap_timing /
- * fsnap_timing_history see the sampled ones).
+ * fsnap_timing_history see the sampled ones),
+ * "dist_solve" (fsnap_fit_dist: 0 = in-place all-reduce + solve on every rank, the default; 1 = reduce to rank 0, solve there,
+ * broadcast [beta | rank | rcond | status] -- for A/B runs of the scaling benchmark; the reduced statistics then exist on
+ * rank 0 only and *d_packed comes back NULL on the other ranks).
  * Unknown key -> FSNAP_E_ARG. */
 int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value);
 
@@ -100,6 +103,12 @@ int fsnap_upload_rows(fsnap_ctx* ctx, const double* A, int64_t m, int64_t K, int
 /* Same, but A and b already live in device memory (not copied, not owned; the A
  * allocation must be readable for 16 bytes past its last element). */
 int fsnap_bind_rows(fsnap_ctx* ctx, const double* dA, int64_t m, int64_t K, int64_t lda, const double* db);
+
+/* This context holds no rows any more (context-owned copies are freed, bound ones forgotten): what a rank of a
+ * multi-GPU job calls when the configurations dealt to it for the NEXT fit are none (config i -> rank i % nranks,
+ * fitsnap3lib/parallel_tools.py:612-651, with fewer configurations than ranks) -- fsnap_fit_dist / fsnap_lstsq_rows
+ * then contribute zeros instead of the rows of an earlier fit. */
+int fsnap_drop_rows(fsnap_ctx* ctx);
 
 /* Allocate resident, zero-filled A (m x K), b[m], w[m] in HBM without a host copy: the
  * device-side counterpart of Calculator.create_a -> pt.create_shared_array('a'|'b'|'w')
@@ -314,6 +323,14 @@ int fsnap_error_stats(fsnap_ctx* ctx, const double* beta, const int32_t* cat, in
  * loaded on the first call of this group (dlopen), never at library load. */
 #define FSNAP_COMM_ID_BYTES 128
 
+/* Every wait behind a collective (fsnap_comm_init itself, the host-buffer collectives, the solve that follows the
+ * all-reduce of a fit) is bounded by the environment variable FSNAP_COMM_TIMEOUT (seconds, default 300): when a peer died
+ * or never arrived the call returns FSNAP_E_HIP with one line in fsnap_last_error naming rank, world size and the wait
+ * that ran out, instead of hanging; the context then aborts its communicator (ncclCommAbort) when it is destroyed.
+ * A failure that only ONE rank sees before a collective of fsnap_fit_dist / fsnap_lstsq_rows (wrong K, no weights, an
+ * allocation that failed) does not keep that rank out of the collective: it contributes NaN statistics, so that every
+ * rank returns FSNAP_NUM_NONFINITE from the same call and the failing rank returns its own error. */
+
 /* Rank 0: create the communicator id (ncclGetUniqueId).  The caller distributes the 128 bytes to every rank by
  * whatever it has -- mpi4py comm.bcast on the reference side, a file or a socket in fitsnap_amd/rendezvous.py. */
 int fsnap_comm_id(char* id);
@@ -348,8 +365,10 @@ int fsnap_barrier(fsnap_ctx* ctx);
  * rank's fused statistics, in-place all-reduce on the same stream, then the K x K solve of fsnap_solve_device -- on
  * EVERY rank (the solve is deterministic and the ranks hold bit-identical sums, so no broadcast of beta is needed;
  * the host layer keeps the reference's "fit on rank 0" contract).  K must be given because a rank may own no rows
- * (it then contributes zeros).  Without a communicator this is fsnap_fit_resident.  *d_packed (may be NULL) receives
- * the address of the reduced statistics (context-owned device memory, valid until the next fit). */
+ * (it then contributes zeros).  Without a communicator: FSNAP_E_STATE (a single-GPU fit is fsnap_fit_resident; there is
+ * no silent fallback that would fit one rank's shard).  *d_packed (may be NULL) receives the address of the reduced
+ * statistics (context-owned device memory, valid until the next fit).  Option "dist_solve" = 1 selects the
+ * reduce -> solve on rank 0 -> broadcast form. */
 int fsnap_fit_dist(fsnap_ctx* ctx, int kind, double param, int64_t K, double* beta, int* rank, double* rcond_est,
                    double** d_packed);
 
@@ -375,6 +394,11 @@ int fsnap_timing(fsnap_ctx* ctx, double* ms, int n);
  * reduce_ms[i] (may be NULL) = partial reduction.  HIP events on the kernels' stream, read after the fact, so a
  * timed loop does not have to synchronise for its measurements.  Synchronises the context's stream. */
 int fsnap_timing_history(fsnap_ctx* ctx, double* syrk_ms, double* reduce_ms, int n);
+
+/* For the same n event-bracketed fits: allreduce_ms[i] = time between the end of this rank's partial reduction and the end
+ * of the collective of fsnap_fit_dist on this rank's stream (ncclAllReduce, or ncclReduce with dist_solve = 1) -- it
+ * includes waiting for the slowest peer -- or -1 for a fit without a collective.  Synchronises the context's stream. */
+int fsnap_timing_history_comm(fsnap_ctx* ctx, double* allreduce_ms, int n);
 
 /* How many SYRK launches this context has made (*launches) and how many of them were bracketed by events (*sampled:
  * what fsnap_timing_history can return); either pointer may be NULL.  Measurement plumbing of bench.py, no reference

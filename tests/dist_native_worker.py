@@ -58,6 +58,30 @@ def main(outdir):
     assert s.last_row_space is not None and s.last_row_space["converged"] == 1.0
     if rank == 0:
         out["ill_fit"] = s.fit.copy()
+    # a rank WITHOUT rows: everything on rank 0, the other ranks hold rows of the fits above and must drop them
+    cfg = Config(pt, {"SOLVER": {"solver": "RIDGE"}, "RIDGE": {"alpha": 1e-8}})
+    s = solver_factory.solver("RIDGE", pt, cfg)
+    if rank == 0:
+        s.perform_fit(A, b, w, trainall=True)
+        out["zero_fit"] = s.fit.copy()
+    else:
+        s.perform_fit(A[:0], b[:0], w[:0], trainall=True)
+    out["zero_G"] = s.last_statistics[0]
+    out["zero_rows_resident"] = np.array(pt.hip().m)
+    # K = 480 through the C ABI: all-reduce in HBM, blocked Cholesky on the GPU of every rank; then the
+    # reduce -> solve on rank 0 -> broadcast variant of the same fit
+    from fitsnap_amd import _capi
+
+    r = np.random.default_rng(480)
+    A4, b4, w4 = r.standard_normal((6000, 480)), r.standard_normal(6000), r.uniform(0.5, 2.0, 6000)
+    sel = (np.arange(6000) // 100 % world) == rank
+    ctx = pt.hip()
+    ctx.upload_rows(A4[sel], b4[sel])
+    ctx.set_weights(w4[sel])
+    out["k480_beta"] = ctx.fit_dist(_capi.SOLVE_RIDGE, 1e-8, 480)[0]
+    ctx.set_option("dist_solve", 1)
+    out["k480_beta_root"] = ctx.fit_dist(_capi.SOLVE_RIDGE, 1e-8, 480)[0]
+    ctx.set_option("dist_solve", 0)
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
     pt.all_barrier()
     pt.free()

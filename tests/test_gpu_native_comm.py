@@ -55,6 +55,59 @@ def test_one_rank_communicator_runs_every_collective(ta):
     ctx.close()
 
 
+def test_fit_dist_needs_a_communicator_and_survives_a_rank_local_failure(ta):
+    A, b, w = ta
+    K = A.shape[1]
+    ctx = _capi.HipContext(0)
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w)
+    with pytest.raises(_capi.FsnapError, match="no communicator"):
+        ctx.fit_dist(_capi.SOLVE_RIDGE, 1e-8, K)                    # no silent single-GPU fallback
+    ctx.comm_init(1, 0, _capi.comm_id())
+    ctx.set_option("timing_every", 1)
+    ref = ctx.fit_dist(_capi.SOLVE_RIDGE, 1e-8, K)[0]
+    # a failure only this rank sees (wrong K): it still takes part in the collective (NaN statistics), reports ITS error,
+    # and the communicator is in step for the next fit
+    with pytest.raises(ValueError, match="columns"):
+        ctx.fit_dist(_capi.SOLVE_RIDGE, 1e-8, K + 1)
+    again = ctx.fit_dist(_capi.SOLVE_RIDGE, 1e-8, K)[0]
+    assert np.array_equal(ref, again)
+    # reduce -> solve on rank 0 -> broadcast: same bits; the collective of every sampled fit was timed on the stream
+    ctx.set_option("dist_solve", 1)
+    root, rank, rcond, ptr = ctx.fit_dist(_capi.SOLVE_RIDGE, 1e-8, K)
+    assert np.array_equal(ref, root) and rank == K and ptr
+    ctx.set_option("dist_solve", 0)
+    t = ctx.timing_history_comm(3)
+    assert t.shape == (3,) and np.all(t >= 0.0) and np.all(t < 50.0)
+    # a rank without rows: zeros into the collective (here: a singular system -> the ridge term alone)
+    ctx.drop_rows()
+    beta0 = ctx.fit_dist(_capi.SOLVE_RIDGE, 1e-8, K)[0]
+    assert np.array_equal(beta0, np.zeros(K))
+    ctx.close()
+
+
+def test_a_context_recreated_after_free_joins_the_communicator_again(ta, monkeypatch):
+    # ParallelTools.free() destroys the context and with it the communicator; the next pt.hip() must not hand out a
+    # context without one (fsnap_fit_dist would have fitted this rank's shard alone)
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    A, b, w = ta
+    pt = ParallelTools(comm="rccl")
+    pt.force_multi = True
+    first = pt.hip()
+    assert pt._transport._joined
+    pt.free()
+    assert pt._hip is None and not pt._transport._joined
+    second = pt.hip()
+    assert second is not first and pt._transport._joined
+    second.upload_rows(A, b)
+    second.set_weights(w)
+    beta = second.fit_dist(_capi.SOLVE_RIDGE, 1e-8, A.shape[1])[0]          # raises FSNAP_E_STATE without a communicator
+    assert maxrel(beta, orc.ridge_fit(A, b, w, 1e-8)) < 1e-6
+    pt.free()
+
+
 def test_large_k_fit_through_the_communicator():
     # K = 480: the reduced statistics are factorised on the GPU (no mirror), straight after the all-reduce
     rng = np.random.default_rng(480)
@@ -116,14 +169,30 @@ def test_bench_runs_the_multi_gpu_step_without_torch(tmp_path):
 
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", FSNAP_COMM_FILE=str(tmp_path / "id"))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--rows", "65536", "--steps", "5",
-                          "--warmup", "2", "--preheat", "10", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
-                         timeout=600)
+                          "--warmup", "2", "--preheat", "10", "--no-cpu-baseline", "--timing-every", "1", "--dist-solve-ab", "1"],
+                         env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
     rec = json.loads(lines[0])
     assert rec["torch_imported"] is False and rec["n_gpus"] == 1 and rec["value"] > 0
     assert rec["config"]["weights_packed_every_step"] is True
+    # one GPU: strong = weak = the same run; the collective of the sampled fits was timed; fsnap_comm_info saw one rank
+    assert rec["scaling"] == "strong" and rec["strong_value"] == rec["weak_value"] == rec["value"]
+    assert rec["n_ranks_seen"] == 1 and len(rec["per_rank"]["kernel_ms"]) == 1 and rec["per_rank"]["allreduce_ms"][0] > 0.0
+    assert rec["dist_solve_ab"]["same_beta"] is True
+
+
+def test_bench_launcher_refuses_more_ranks_than_devices():
+    # `bench.py --gpus N` starts its own ranks; with fewer devices than ranks every rank says so and the job fails with
+    # one summary line instead of hanging in RCCL's bootstrap
+    n = _capi.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    env["FSNAP_COMM_TIMEOUT"] = "60"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--rows", "65536", "--steps", "2",
+                          "--warmup", "1", "--preheat", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and out.stdout.strip() == ""
+    assert f"only {n - 1} GPU(s) visible" in out.stderr and f"bench.py: {n}-GPU job failed" in out.stderr
 
 
 @pytest.mark.skipif(_capi.device_count() < 2, reason="needs two GPUs: RCCL does not put two ranks on one device")
@@ -133,8 +202,8 @@ def test_two_process_native_fit_matches_the_reference(tmp_path, ta, ta_fits):
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world),
-                   FSNAP_COMM_FILE=str(tmp_path / "comm_id"), MASTER_ADDR="127.0.0.1", MASTER_PORT="29655",
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   FSNAP_COMM_FILE=str(tmp_path / "comm_id"), FSNAP_COMM_TOKEN="two-process test", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29655", HSA_ENABLE_IPC_MODE_LEGACY="0", FSNAP_COMM_TIMEOUT="120")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_native_worker.py"), str(tmp_path)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = [p.communicate(timeout=600)[0] for p in procs]
@@ -159,6 +228,17 @@ def test_two_process_native_fit_matches_the_reference(tmp_path, ta, ta_fits):
     y = X @ r.standard_normal(K) + 1e-3 * r.standard_normal(mm)
     ref = orc.svd_fit(X, y, np.ones(mm))
     assert np.linalg.norm(r0["ill_fit"] - ref) <= 50 * 1e10 * np.finfo(float).eps * np.linalg.norm(ref)
+    # a rank with ZERO rows (rank 1 owns nothing), right after fits in which it did own rows
+    assert maxrel(r0["zero_fit"], orc.ridge_fit(A, b, w, 1e-8)) < 1e-6 and np.array_equal(r0["zero_G"], r1["zero_G"])
+    assert int(r1["zero_rows_resident"]) == 0
+    # K = 480: the all-reduced statistics are factorised by the device Cholesky on every rank; both solve variants agree
+    r = np.random.default_rng(480)
+    A4, b4, w4 = r.standard_normal((6000, 480)), r.standard_normal(6000), r.uniform(0.5, 2.0, 6000)
+    ref4 = orc.ridge_fit(A4, b4, w4, 1e-8)
+    for rr in (r0, r1):
+        assert maxrel(rr["k480_beta"], ref4) < 1e-6
+        assert np.array_equal(rr["k480_beta_root"], r0["k480_beta_root"]) and maxrel(rr["k480_beta_root"], ref4) < 1e-6
+    assert np.array_equal(r0["k480_beta"], r1["k480_beta"])                    # deterministic solve of identical sums
 
 
 def test_process_exits_cleanly_when_rccl_is_loaded_before_torch():

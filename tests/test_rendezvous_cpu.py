@@ -46,10 +46,61 @@ def test_every_rank_receives_rank_zeros_id(tmp_path, transport):
         assert p.exitcode == 0
     assert got == {r: bytes([17]) * 128 for r in range(world)}
     if transport == "file":
-        assert not (tmp_path / "id").exists()             # rank 0 cleaned up
+        assert not (tmp_path / "id.g0").exists() and not (tmp_path / "id").exists()             # rank 0 cleaned up
 
 
 def test_single_rank_needs_no_exchange():
     from fitsnap_amd import rendezvous
 
     assert rendezvous.exchange(0, 1, lambda: b"x" * 128) == b"x" * 128
+
+
+def test_stale_and_foreign_files_are_not_accepted(tmp_path, monkeypatch):
+    # a file of the right size left by a crashed job (other token), then the real one: the reader must wait for the real one
+    import threading
+    import time
+
+    from fitsnap_amd import rendezvous
+
+    monkeypatch.setenv("FSNAP_COMM_FILE", str(tmp_path / "id"))
+    monkeypatch.setenv("FSNAP_COMM_TOKEN", "this job")
+    monkeypatch.setenv("FSNAP_COMM_TIMEOUT", "30")
+    monkeypatch.setitem(rendezvous._state, "generation", 0)
+    stale = rendezvous._pack(b"\0" * 16, b"S" * 128)
+    (tmp_path / "id.g0").write_bytes(stale)
+    good = rendezvous._pack(rendezvous._token(0), b"G" * 128)
+
+    def publish():
+        time.sleep(0.5)
+        tmp = tmp_path / "x.tmp"
+        tmp.write_bytes(good)
+        os.replace(tmp, tmp_path / "id.g0")
+
+    t = threading.Thread(target=publish)
+    t.start()
+    assert rendezvous.exchange(1, 2, lambda: b"?" * 128) == b"G" * 128
+    t.join()
+    # a second communicator of the same process: another generation = another file name and another token
+    assert rendezvous._state["generation"] == 1
+    monkeypatch.setenv("FSNAP_COMM_TIMEOUT", "1")
+    with pytest.raises(TimeoutError, match="rank 0 never published"):
+        rendezvous.exchange(1, 2, lambda: b"?" * 128)             # id.g1 does not exist: the g0 file is NOT re-read
+    assert rendezvous._token(0) != rendezvous._token(1)
+
+
+def test_rank_zero_replaces_a_leftover_file_and_writes_it_private(tmp_path, monkeypatch):
+    import stat
+
+    from fitsnap_amd import rendezvous
+
+    monkeypatch.setenv("FSNAP_COMM_FILE", str(tmp_path / "id"))
+    monkeypatch.setitem(rendezvous._state, "generation", 0)
+    (tmp_path / "id.g0").write_bytes(b"junk")
+    ident = rendezvous.exchange(0, 2, lambda: b"N" * 128)
+    raw = (tmp_path / "id.g0").read_bytes()
+    assert ident == b"N" * 128 and rendezvous._unpack(raw, rendezvous._token(0)) == ident
+    assert stat.S_IMODE(os.stat(tmp_path / "id.g0").st_mode) == 0o600
+    rendezvous.done(0)
+    assert not (tmp_path / "id.g0").exists()
+    d = rendezvous._private_dir()
+    assert stat.S_IMODE(os.stat(d).st_mode) == 0o700 and os.stat(d).st_uid == os.getuid()
