@@ -121,9 +121,8 @@ int fsnap_rowspace_chain(int64_t K64, int64_t nfac, const double* R, const unsig
     if (active)
         for (int j = 0; j < K; ++j) chain.active[j] = active[j] ? 1 : 0;
     for (int64_t k = 0; k < nfac; ++k) chain.push(R + (size_t)k * K * K);
-    double nrm = 0.0, inv = 0.0;
-    const double bound = chain.condition_bound(&nrm, &inv);
-    const bool use_chain = bound * (rcond > 0.0 ? rcond : 0.0) < 0.5;
+    double nrm = 0.0, inv = 0.0, bound = 0.0;
+    const bool use_chain = chain.certified(rcond, &nrm, &inv, &bound);
     int rk = 0;
     if (use_chain) {
         chain.solve(z, beta);
@@ -297,8 +296,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
     bool use_chain = false;
     double chain_norm = 0.0, chain_inv = 0.0;
     if (chained) {
-        const double rc0 = rcond > 0.0 ? rcond : 0.0;
-        use_chain = chain.condition_bound(&chain_norm, &chain_inv) * rc0 < 0.5;      // no singular value can be cut
+        use_chain = chain.certified(rcond, &chain_norm, &chain_inv, nullptr);         // no singular value can be cut
         if (!use_chain) {
             Rhat.assign((size_t)K * K, 0.0);
             chain.product(Rhat.data());

@@ -26,6 +26,10 @@ struct FactorChain {
     // the smaller of 3 x sqrt(est_1 est_inf) (Hager / Higham's 1-norm estimator) and 2 x inverse iteration on R^T R; a
     // Neumann bound 1 / (1 - ||R - I||) for the near-identity factors of the later passes
     double condition_bound(double* norm_out, double* inv_norm_out) const;
+    // may the chain be solved through without a truncation for this rcond?  Only when the ESTIMATE (condition_bound:
+    // lower-bound estimators x safety factors -- not a bound) leaves two orders of margin: estimate x rcond < 1e-2.
+    // Otherwise the caller multiplies the factors out and FactorSolver decides with provable Frobenius bounds / the SVD.
+    bool certified(double rcond, double* norm_out, double* inv_norm_out, double* bound_out) const;
     void solve(const double* z, double* beta) const;      // beta = R_1^-1 ... R_p^-1 z, zeros in inactive columns
     void product(double* Rhat) const;                     // R_hat, with zero diagonal entries for inactive columns
 };

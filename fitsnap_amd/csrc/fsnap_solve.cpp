@@ -596,10 +596,26 @@ int fast_chol(double* u, int n, double* mp2) {
             const char* e = std::getenv("FSNAP_CHOL_THREADS");
             return e ? std::atoi(e) : 0;
         }();
-        // Host threads are opt-in (FSNAP_CHOL_THREADS): inside a CPU-quota'd container the spinning barriers of the
-        // threaded driver made the factorisation SLOWER on the MI355X boxes (K = 1595: 18 -> 23-41 ms, K = 480:
-        // 0.4 -> 2.3 ms with 4 threads); large systems are factorised on the GPU instead (fsnap_solve_device).
-        int nt = nt_env > 0 ? nt_env : 1;
+        // Host threads: FSNAP_CHOL_THREADS when set; else min(8, cores) -- unless the process runs under a CPU quota
+        // (cgroup cpu.max / cfs_quota_us): there the spinning barriers of the threaded driver made the factorisation
+        // SLOWER on the MI355X boxes (K = 1595: 18 -> 23-41 ms, K = 480: 0.4 -> 2.3 ms with 4 threads), so a quota'd
+        // container stays on one thread.  Large systems of a fit are factorised on the GPU anyway (fsnap_solve_device);
+        // this is the factorisation of the row-space chain and of callers that hold the statistics on the host.
+        static const int nt_auto = [] {
+            auto quota = [](const char* path, bool v2) -> bool {
+                FILE* f = std::fopen(path, "r");
+                if (!f) return false;
+                char buf[64] = {0};
+                const bool got = std::fgets(buf, sizeof buf, f) != nullptr;
+                std::fclose(f);
+                if (!got) return false;
+                return v2 ? std::strncmp(buf, "max", 3) != 0 : std::atol(buf) > 0;
+            };
+            if (quota("/sys/fs/cgroup/cpu.max", true) || quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", false)) return 1;
+            const unsigned hc = std::thread::hardware_concurrency();
+            return (int)(hc >= 8 ? 8 : (hc > 0 ? hc : 1));
+        }();
+        int nt = nt_env > 0 ? nt_env : nt_auto;
         if (nt > n / 160) nt = n / 160;          // >= 5 column chunks per thread
         if (nt > 1) return chol_upper_rb_mt(u, n, mp2, nbk, nt);
         return chol_upper_rb(u, n, mp2, nbk);

@@ -340,6 +340,7 @@ class ParallelTools:
         self.shared_arrays = {}
         self.fitsnap_dict = {}
         self.local_lists = {}    # multi-rank: this rank's row-metadata lists after gather_fitsnap
+        self.labels_version = 0  # bumped by touch_labels(); solvers with trust_label_version key their label caches on it
         if self.comm_kind == "rccl":
             self.hip()                                             # creates the context and joins the communicator
         self._set_seed()
@@ -515,6 +516,12 @@ class ParallelTools:
             self.shared_arrays[name] = SharedArray(size1, size2=size2, dtype=dtype, multinode=tm, comms=self)
         else:
             self.shared_arrays[name] = SharedArray(size1, size2=size2, dtype=dtype)
+
+    def touch_labels(self) -> None:
+        """A row-label list (``Testing``, ``Groups``, ``Row_Type``) was edited IN PLACE: solvers that were told to trust
+        the version (``solver.trust_label_version = True`` with ``keep_resident``) drop what they derived from it.  Without
+        that promise the solvers fingerprint the whole content of the lists on every call and need no notice."""
+        self.labels_version += 1
 
     def add_2_fitsnap(self, name: str, an_object) -> None:
         if not isinstance(name, str):

@@ -63,11 +63,12 @@ class Solver:
         self.w = None
         self._df = None              # error_analysis DataFrame, built on first access (see the df property)
         self._df_parts = None
-        self._cat_cache = None       # (label lists, probes, m, category ids, group keys) of the last error_analysis
+        self._cat_cache = None       # (label lists, content stamp, m, category ids, group keys) of the last error_analysis
         self._cat_ctx = None         # context that holds those category ids on the device
         self._err_layout = None      # (group keys, index, source rows, weighting flags) of the last errors table
         self._all_idx = None         # (group keys, [(sub key, member indices)]) of the last *ALL merge
-        self._mask_cache = None      # (Testing list, probe, training mask, derived arrays) (keep_resident only)
+        self._mask_cache = None      # (Testing list, content stamp, training mask, derived arrays) (keep_resident only)
+        self.trust_label_version = False   # keep_resident: key the label caches on pt.labels_version instead of the content
         self.linear = linear
         self.cov = None
         self.fit_sam = None
@@ -91,6 +92,25 @@ class Solver:
     def fit_gather(self):
         pass
 
+    def prepare_data(self, a, b, w, fs_dict):
+        """``aw, bw`` = the training rows of ``a`` and ``b`` multiplied by their weights (reference:
+        fitsnap3lib/solvers/solver.py:50-76), by the stand-alone wavefront weighting kernel (``fsnap_weight_rows``:
+        HBM-bound, one 4-row group per wave) on the resident rows; the rows of the testing set are dropped on the host.
+        ``fs_dict = None`` trains on all rows; explicit arrays take one weight per TRAINING row like the reference
+        (``w[:, np.newaxis] * a[training]``, solver.py:75), ``a = b = w = None`` takes the shared arrays (the reference's
+        own last line indexes ``a`` unconditionally and raises there; its evident intent is what happens here).
+        Products of two doubles: bit-identical to numpy."""
+        a_, b_, w_full, mask, shared_mode = self._resolve_inputs(a, b, w, fs_dict, fs_dict is None)
+        if np.ndim(a_) != 2:
+            raise ValueError("the A matrix must be 2-D")
+        ctx = self._upload(a_, b_, shared_mode)
+        self._push_weights(ctx, w_full, mask)
+        aw, bw = ctx.weight_rows()
+        if not mask.all():
+            keep = mask.astype(bool)
+            aw, bw = aw[keep], bw[keep]
+        return aw, bw
+
     def _checks(self):
         # fitsnap3lib/solvers/solver.py:106-107
         calc = self.config.sections["CALCULATOR"]
@@ -101,25 +121,34 @@ class Solver:
     # ------------------------------------------------------------------------------
     # mask / weights exactly as the reference resolves them
     # ------------------------------------------------------------------------------
-    @staticmethod
-    def _list_probe(lst, n=257):
-        """A few hundred evenly spaced entries of a label list: a cheap fingerprint that notices in-place edits (a
-        cross-validation fold flips a contiguous tenth of ``Testing``) without walking a million Python objects."""
-        size = len(lst)
-        if size <= n:
-            return tuple(lst)
-        step = size / n
-        return tuple(lst[int(i * step)] for i in range(n)) + (lst[-1],)
+    def _labels_stamp(self, lists):
+        """What a cache derived from row-label lists is valid for (``keep_resident`` only): a fingerprint of their whole
+        CONTENT -- ``hash(tuple(lst))`` walks every entry (13 ms for 10^6 bools, 25 ms for 10^6 strings; numpy arrays: a
+        digest of their bytes, ~1 ms) -- so that an in-place edit of ANY entry (one configuration moved between folds)
+        is seen, as in the reference, which re-reads the labels on every call.  A sampled probe (rounds 1-2) missed edits
+        of less than ~0.4 % of a list.  A caller that wants the walk gone promises not to edit the lists without saying so:
+        ``solver.trust_label_version = True`` keys the caches on the identity of the list objects plus
+        ``pt.labels_version``, which ``pt.touch_labels()`` bumps."""
+        if self.trust_label_version:
+            return ("version", getattr(self.pt, "labels_version", 0)) + tuple(id(l) for l in lists)
+        out = []
+        for l in lists:
+            if isinstance(l, np.ndarray):
+                import hashlib
 
-    def _cache_hit(self, cached_lists, cached_probes, lists):
-        """Identity of the list OBJECTS (the cache keeps them alive, so an address cannot be recycled) plus the probe."""
+                out.append((l.shape, l.dtype.str, hashlib.blake2b(np.ascontiguousarray(l).tobytes(), digest_size=16).digest()))
+            else:
+                out.append((len(l), hash(tuple(l))))
+        return ("content",) + tuple(out)
+
+    def _cache_hit(self, cached_lists, cached_stamp, lists):
+        """Same list objects (the cache keeps them alive, so an address cannot be recycled) with the same content."""
         return (cached_lists is not None and len(cached_lists) == len(lists)
                 and all(c is l for c, l in zip(cached_lists, lists))
-                and all(p == self._list_probe(l) for p, l in zip(cached_probes, lists)))
+                and cached_stamp == self._labels_stamp(lists))
 
     def invalidate_row_caches(self):
-        """Forget everything derived from the row-label lists (training mask, category ids, table layouts).  Only
-        needed with ``keep_resident`` after editing a label list IN PLACE in a way the probe cannot see."""
+        """Forget everything derived from the row-label lists (training mask, category ids, table layouts)."""
         self._mask_cache = None
         self._cat_cache = None
         self._cat_ctx = None
@@ -130,14 +159,15 @@ class Solver:
         """svd.py:35-40 / ridge.py:28-33."""
         if fs_dict is not None:
             lst = fs_dict["Testing"]
-            if self.keep_resident and isinstance(lst, list):
-                # re-weighting loops pass the same (large) Python list every time: convert it once.  The cache holds
-                # the list itself and a probe of its content; without keep_resident nothing is cached.
+            if self.keep_resident and isinstance(lst, (list, np.ndarray)):
+                # re-weighting loops pass the same (large) label list every time: what is derived from it (row indices,
+                # prefix sums, the mask resident on the GPU) is kept while the list's content stays the same.  The cache
+                # holds the list itself and a stamp of its whole content; without keep_resident nothing is cached.
                 mc = self._mask_cache
-                if mc is not None and self._cache_hit((mc[0],), (mc[1],), (lst,)):
+                if mc is not None and self._cache_hit((mc[0],), mc[1], (lst,)):
                     return mc[2]
                 mask = ~np.asarray(lst, dtype=bool)
-                self._mask_cache = (lst, self._list_probe(lst), mask, None)
+                self._mask_cache = (lst, self._labels_stamp((lst,)), mask, None)
                 return mask
             return ~np.asarray(lst, dtype=bool)
         if trainall:
@@ -629,20 +659,20 @@ class Solver:
         """Category id of every row = index of its (Groups, Testing, Row_Type) key in sorted order (the order of the
         reference's groupby).  Like the reference the labels are re-read on every call; only with ``keep_resident``
         (re-weighting loops that pass the same label lists every time) are the ids cached -- keyed on the list
-        objects themselves plus a probe of their content (``invalidate_row_caches`` drops them explicitly)."""
+        objects themselves plus a stamp of their whole content (``_labels_stamp``)."""
         from pandas import DataFrame
 
         lists = (fs_dict["Groups"], fs_dict["Testing"], fs_dict["Row_Type"])
         cc = self._cat_cache
-        if (self.keep_resident and cc is not None and cc[2] == m and all(isinstance(l, list) for l in lists)
+        if (self.keep_resident and cc is not None and cc[2] == m and all(isinstance(l, (list, np.ndarray)) for l in lists)
                 and self._cache_hit(cc[0], cc[1], lists)):
             return cc[3], cc[4], False
         gb = DataFrame({"Groups": lists[0], "Testing": lists[1], "Row_Type": lists[2]}).groupby(
             ["Groups", "Testing", "Row_Type"], sort=True)
         cat = gb.ngroup().to_numpy(dtype=np.int32)
         keys = list(gb.size().index)
-        probes = tuple(self._list_probe(l) for l in lists) if self.keep_resident else ()
-        self._cat_cache = (lists, probes, m, cat, keys)
+        stamp = self._labels_stamp(lists) if self.keep_resident else None
+        self._cat_cache = (lists, stamp, m, cat, keys)
         return cat, keys, True
 
     def _assemble_errors(self, grouped, allrows, layout_key=None):

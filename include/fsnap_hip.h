@@ -298,8 +298,11 @@ int fsnap_rowspace_solve(int64_t K, const double* Rhat, const double* z, double 
  * K^3 / 3 flops per pass on one host core).  beta = pinv_rcond(R_hat) z: by nfac back substitutions when an upper estimate
  * of cond(R_hat) (sqrt(||R||_1 ||R||_inf) x Hager / Higham 1-norm estimates of the inverses, per factor) shows that no singular value can fall
  * below rcond sigma_max, through the multiplied-out factor and fsnap_rowspace_solve's path otherwise.  active (may be NULL =
- * all): columns that take part (zero columns of A_w get beta = 0).  info[4] = {1 if solved through the chain, bound on
- * ||R_hat||, bound on ||R_hat^-1||, their product}.  Host side, no context needed. */
+ * all): columns that take part (zero columns of A_w get beta = 0).  The chain is taken only when the estimate of cond(R_hat)
+ * leaves two orders of margin (estimate x rcond < 1e-2: the estimators are lower bounds x safety factors, not bounds);
+ * otherwise the multiplied-out factor is judged with provable Frobenius bounds and, if those cannot exclude a truncation,
+ * by the SVD.  info[4] = {1 if solved through the chain, estimate of ||R_hat||, of ||R_hat^-1||, their product}.  Host side,
+ * no context needed. */
 int fsnap_rowspace_chain(int64_t K, int64_t nfac, const double* R, const unsigned char* active, const double* z, double rcond,
                          double* beta, int* rank, double* info);
 

@@ -7,18 +7,15 @@ from fitsnap_amd.parallel_tools import ParallelTools
 from fitsnap_amd.solvers import solver_factory
 from fitsnap_amd import synthetic as orc  # input data only
 
-for m, K, ngroups in ((15213, 31, 12), (1000000, 128, 40)):
-    A, b, w = orc.synth_problem(m, K)
-    rng = np.random.default_rng(3)
-    groups = [f"g{g:02d}" for g in np.sort(rng.integers(0, ngroups, size=m))]
-    testing = (rng.random(m) < 0.1).tolist()
-    row_type = [("Energy", "Force", "Stress")[i % 3] for i in range(m)]
-    fsd = {"Groups": groups, "Testing": testing, "Row_Type": row_type}
-    t = np.asarray(testing)
+
+def loop(A, b, w, fsd, t, trust, rng):
+    # trust = False: the label lists are fingerprinted in full on every call (an in-place edit of any entry is seen);
+    # trust = True: the caller promises pt.touch_labels() after an edit, the caches are keyed on that version
     pt = ParallelTools()
     cfg = Config(pt, {"SOLVER": {"solver": "RIDGE"}, "RIDGE": {"alpha": 1e-8}})
     s = solver_factory.solver("RIDGE", pt, cfg)
     s.keep_resident = True
+    s.trust_label_version = trust
     times = []
     for it in range(8):
         w_it = w * rng.uniform(0.5, 2.0)                       # a new candidate's weights ...
@@ -31,7 +28,21 @@ for m, K, ngroups in ((15213, 31, 12), (1000000, 128, 40)):
         rmse = s.errors.iloc[:, 2].to_numpy()[:3]
         t2 = time.perf_counter()
         times.append((t1 - t0, t2 - t1))
-    tt = np.array(times[2:])
-    print(f"{m} x {K}, {ngroups} groups: perform_fit {tt[:,0].mean()*1e3:.2f} ms, error_analysis {tt[:,1].mean()*1e3:.2f} ms per candidate "
-          f"(first call: {times[0][0]*1e3:.1f} + {times[0][1]*1e3:.1f} ms); rmse {rmse}")
     pt.free()
+    return times, rmse
+
+
+for m, K, ngroups in ((15213, 31, 12), (1000000, 128, 40)):
+    A, b, w = orc.synth_problem(m, K)
+    rng = np.random.default_rng(3)
+    groups = [f"g{g:02d}" for g in np.sort(rng.integers(0, ngroups, size=m))]
+    testing = (rng.random(m) < 0.1).tolist()
+    row_type = [("Energy", "Force", "Stress")[i % 3] for i in range(m)]
+    fsd = {"Groups": groups, "Testing": testing, "Row_Type": row_type}
+    t = np.asarray(testing)
+    for trust in (False, True):
+        times, rmse = loop(A, b, w, fsd, t, trust, rng)
+        tt = np.array(times[2:])
+        how = "trusted by version (pt.touch_labels)" if trust else "fingerprinted in full every call"
+        print(f"{m} x {K}, {ngroups} groups, labels {how}: perform_fit {tt[:,0].mean()*1e3:.2f} ms, error_analysis "
+              f"{tt[:,1].mean()*1e3:.2f} ms per candidate (first call: {times[0][0]*1e3:.1f} + {times[0][1]*1e3:.1f} ms); rmse {rmse}")

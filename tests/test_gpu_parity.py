@@ -1029,6 +1029,60 @@ def test_reweighting_loop_error_analysis_reuses_labels_and_builds_df_lazily(ta, 
     pt.free()
 
 
+def test_prepare_data_is_bitwise_the_reference_product(ta, ta_fits):
+    # Solver.prepare_data (reference solvers/solver.py:50-76): aw, bw of the training rows through fsnap_weight_rows
+    A, b, w = ta
+    t = ta_fits["testing_mask"]
+    pt, s = make_solver("SVD")
+    aw, bw = s.prepare_data(A, b, w[~t], {"Testing": t.tolist()})          # one weight per training row, as the reference
+    aw_ref, bw_ref = orc.weight_rows(A, b, w, t)
+    assert aw.shape == aw_ref.shape and np.array_equal(aw, aw_ref) and np.array_equal(bw, bw_ref)
+    aw, bw = s.prepare_data(A, b, w, None)                                   # no dictionary: every row trains
+    aw_ref, bw_ref = orc.weight_rows(A, b, w)
+    assert np.array_equal(aw, aw_ref) and np.array_equal(bw, bw_ref)
+    # shared arrays + the job's own Testing list
+    pt.create_shared_array("a", A.shape[0], A.shape[1])
+    pt.create_shared_array("b", len(b))
+    pt.create_shared_array("w", len(b))
+    pt.shared_arrays["a"].array[:] = A
+    pt.shared_arrays["b"].array[:] = b
+    pt.shared_arrays["w"].array[:] = w
+    aw, bw = s.prepare_data(None, None, None, {"Testing": t.tolist()})
+    aw_ref, bw_ref = orc.weight_rows(A, b, w, t)
+    assert np.array_equal(aw, aw_ref) and np.array_equal(bw, bw_ref)
+    pt.free()
+
+
+def test_one_label_flipped_in_place_changes_the_fit_and_the_error_table(ta, ta_fits):
+    # keep_resident caches (training mask on the device, category ids) must follow an in-place edit of ONE entry of the
+    # label lists at any index: fit and error table equal a fresh solver's (the reference re-reads the labels every call)
+    from pandas.testing import assert_frame_equal
+
+    A, b, w = ta
+    t = ta_fits["testing_mask"].copy()
+    row_type = ["Energy"] * 363 + ["Force"] * 12672 + ["Stress"] * 2178
+    fsd = {"Groups": [str(g) for g in ta_fits["ea_groups"]], "Testing": t.tolist(), "Row_Type": row_type}
+    pt, s = make_solver("RIDGE")
+    s.keep_resident = True
+    s.perform_fit(A, b, w[~t], fs_dict=fsd)
+    s.error_analysis(A, b, w, fsd)
+    before = s.fit.copy()
+    m = len(b)
+    sampled = {int(i * (m / 257)) for i in range(257)} | {m - 1}
+    k = next(i for i in range(200, m) if i not in sampled and not t[i] and w[i] > 0)   # an energy row in training
+    fsd["Testing"][k] = True                                                    # in place: the list objects stay the same
+    t[k] = True
+    s.perform_fit(A, b, w[~t], fs_dict=fsd)
+    s.error_analysis(A, b, w, fsd)
+    pt2, s2 = make_solver("RIDGE")
+    s2.perform_fit(A, b, w[~t], fs_dict={key: list(v) for key, v in fsd.items()})
+    s2.error_analysis(A, b, w, {key: list(v) for key, v in fsd.items()})
+    assert np.array_equal(s.fit, s2.fit) and not np.array_equal(s.fit, before)
+    assert_frame_equal(s.errors, s2.errors, check_exact=False, rtol=1e-12, atol=0.0)
+    pt.free()
+    pt2.free()
+
+
 def test_tiled_partials_survive_interleaved_geometries(ctx):
     # the tiled kernel's c partials are cleared only when (splits, superblocks) change: alternate two tiled shapes and a
     # one-wave-triangle shape on ONE context (they share the partial buffers) and check every result

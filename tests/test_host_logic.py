@@ -405,6 +405,49 @@ def test_label_caches_notice_new_and_edited_lists():
     assert s._row_categories(fsd, m)[2] and s._row_categories(fsd, m)[2]
 
 
+def test_label_caches_see_a_single_flipped_entry_anywhere():
+    # VERDICT r2 / ADVICE r2: a 257-sample probe missed in-place edits of < 0.4 % of a list (one configuration moved
+    # between folds) and the fit silently used the stale mask.  The stamp covers the whole content now.
+    pt, cfg, s = make("RIDGE")
+    s.keep_resident = True
+    m = 100_003
+    a = np.zeros((m, 2))
+    lst = [(i % 10) == 0 for i in range(m)]
+    sampled = {int(i * (m / 257)) for i in range(257)} | {m - 1}              # what rounds 1-2 looked at
+    flip = next(i for i in range(5000, m) if i not in sampled and not lst[i])
+    m1 = s._training_mask(a, {"Testing": lst}, False)
+    assert s._training_mask(a, {"Testing": lst}, False) is m1
+    lst[flip] = True                                                          # ONE entry, in place
+    m2 = s._training_mask(a, {"Testing": lst}, False)
+    assert m2 is not m1 and not m2[flip] and m1[flip] and np.count_nonzero(m1 != m2) == 1
+    assert np.array_equal(m2, ~np.asarray(lst))                              # = what a fresh solver derives
+    groups = [f"g{i % 7}" for i in range(m)]
+    fsd = {"Groups": groups, "Testing": lst, "Row_Type": ["Energy"] * m}
+    cat1, keys1, fresh1 = s._row_categories(fsd, m)
+    assert fresh1 and not s._row_categories(fsd, m)[2]
+    j = next(i for i in range(60_000, m) if i not in sampled)
+    groups[j] = "moved"                                                       # one row changes its group, in place
+    cat2, keys2, fresh2 = s._row_categories(fsd, m)
+    pt2, cfg2, s2 = make("RIDGE")
+    cat_ref, keys_ref, _ = s2._row_categories(fsd, m)
+    assert fresh2 and keys2 == keys_ref and np.array_equal(cat2, cat_ref) and any(k[0] == "moved" for k in keys2)
+    # numpy label arrays: validated by a digest of their bytes
+    arr = np.asarray(lst)
+    n1 = s._training_mask(a, {"Testing": arr}, False)
+    assert s._training_mask(a, {"Testing": arr}, False) is n1
+    arr[flip] = False
+    n2 = s._training_mask(a, {"Testing": arr}, False)
+    assert n2 is not n1 and n2[flip]
+    # the caller's promise instead of the walk: caches keyed on pt.labels_version, edits announced by touch_labels()
+    s.trust_label_version = True
+    t1 = s._training_mask(a, {"Testing": lst}, False)
+    lst[flip] = False
+    assert s._training_mask(a, {"Testing": lst}, False) is t1                # not announced: the caller broke the promise
+    pt.touch_labels()
+    t2 = s._training_mask(a, {"Testing": lst}, False)
+    assert t2 is not t1 and t2[flip]
+
+
 @pytest.mark.parametrize("key,mask,direct,scap,scai,logcut", [
     ("ard_class_all", False, False, 1e-3, 1e-3, 0.3),
     ("ard_class_mask", True, False, 1e-3, 1e-3, 0.3),
