@@ -99,7 +99,25 @@ hipError_t launch_gemvT_rows(const double* A, int64_t lda, const double* u, int6
 // Row-space solve (fsnap_trsm.hip).  Q <- X R^-1 by blocked substitution over the columns, one wave per 64 rows:
 // first pass X = diag(w_eff) A (src = A, leading dimension lds, per-row pairs wpack = (w_eff, w_eff b); rows with
 // w_eff = 0 become zero rows), later passes X = Q in place (src = Q, wpack = nullptr).  R: device, K16 x K16 row-major
-// upper triangular, K16 = K rounded up to 16, identity in the padding.
+// upper triangular, K16 = K rounded up to 16, identity in the padding, FOLLOWED by the inverses of its K16 / 16 diagonal
+// 16 x 16 blocks ([block][16][16], row-major, upper triangular: what kernel 13B multiplies by and refines against):
+// trsm_factor_doubles(K16) doubles in all, the second part filled by trsm_invert_diagonal_blocks on the host.
+inline size_t trsm_factor_doubles(int K16) { return (size_t)K16 * K16 + (size_t)K16 * 16; }
+inline void trsm_invert_diagonal_blocks(double* Rpad, int K16) {
+    double* inv = Rpad + (size_t)K16 * K16;
+    for (int jb = 0; jb < K16 / 16; ++jb) {
+        const double* T = Rpad + (size_t)(jb * 16) * K16 + jb * 16;      // T[i][j] = T[i * K16 + j]
+        double* X = inv + (size_t)jb * 256;
+        // X = T^-1 column by column: T x_c = e_c, back substitution (x_c has zeros below row c)
+        for (int c = 0; c < 16; ++c) {
+            for (int i = 15; i >= 0; --i) {
+                double v = (i == c) ? 1.0 : 0.0;
+                for (int k = i + 1; k <= c; ++k) v -= T[(size_t)i * K16 + k] * X[k * 16 + c];
+                X[i * 16 + c] = (i <= c) ? v / T[(size_t)i * K16 + i] : 0.0;
+            }
+        }
+    }
+}
 hipError_t launch_trsm_rows(const double* src, int64_t lds, const double* wpack, double* Q, int64_t ldq, int64_t m, int K,
                             const double* R, int K16, hipStream_t st);
 // qpack[row] = (w_eff != 0 ? 1 : 0, w_eff b): per-row pairs that make the SYRK kernels compute Q^T Q and Q^T (w b)

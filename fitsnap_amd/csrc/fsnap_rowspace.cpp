@@ -183,8 +183,9 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
     fsnap::RowSpace* rs = ctx->rowspace;
     const size_t m = have_rows ? (size_t)ctx->m : 0;
     // the small K x K workspaces: without them this rank cannot even take part in the collective
-    if (!rs->packed.ensure((size_t)npk * 8) || !rs->Rdev.ensure((size_t)K16 * K16 * 8) || !rs->beta.ensure((size_t)K * 8) ||
-        !rs->dz.ensure((size_t)K * 8) || !rs->pin_ensure((size_t)npk + (size_t)K16 * K16 + 2 * (size_t)K))
+    const size_t rdoubles = fsnap::trsm_factor_doubles(K16);       // padded factor + the inverses of its 16 x 16 diagonal blocks
+    if (!rs->packed.ensure((size_t)npk * 8) || !rs->Rdev.ensure(rdoubles * 8) || !rs->beta.ensure((size_t)K * 8) ||
+        !rs->dz.ensure((size_t)K * 8) || !rs->pin_ensure((size_t)npk + rdoubles + 2 * (size_t)K))
         return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(row-space workspace) failed");
     if (have_rows && local_rc == FSNAP_OK) {
         const int nbt = fsnap::gemvT_num_blocks(ctx->m);
@@ -205,8 +206,8 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
     vec Rhat(chained ? 0 : (size_t)K * K), Rp((size_t)K * K), z((size_t)K);
     FactorChain chain;
     double* const host = rs->pin;                        // [npk] statistics of the current Q
-    double* const Rpad = rs->pin + npk;                  // [K16 x K16] padded factor of the pass
-    double* const hvec = Rpad + (size_t)K16 * K16;       // [2 K] beta up, Q^T r down
+    double* const Rpad = rs->pin + npk;                  // [K16 x K16] padded factor of the pass | [K16 / 16][16][16] inverse blocks
+    double* const hvec = Rpad + rdoubles;                // [2 K] beta up, Q^T r down
 
     // statistics of the current Q (pass 0: of A_w), summed over the ranks, on the host
     auto gather_stats = [&](bool of_rows) -> int {
@@ -267,7 +268,8 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
         std::fill(Rpad, Rpad + (size_t)K16 * K16, 0.0);
         for (int i = 0; i < K16; ++i) Rpad[(size_t)i * K16 + i] = 1.0;
         for (int i = 0; i < K; ++i) memcpy(Rpad + (size_t)i * K16 + i, Rp.data() + (size_t)i * K + i, (size_t)(K - i) * 8);
-        FSNAP_HIP(hipMemcpyAsync(rs->Rdev.p, Rpad, (size_t)K16 * K16 * 8, hipMemcpyHostToDevice, st), "hipMemcpy(R)");
+        fsnap::trsm_invert_diagonal_blocks(Rpad, K16);
+        FSNAP_HIP(hipMemcpyAsync(rs->Rdev.p, Rpad, rdoubles * 8, hipMemcpyHostToDevice, st), "hipMemcpy(R)");
         if (have_rows) {
             if (pass == 1)
                 FSNAP_HIP(fsnap::launch_trsm_rows(ctx->dA, ctx->lda, (const double*)ctx->wpack.p, dQ, K, ctx->m, K,

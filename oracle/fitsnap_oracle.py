@@ -161,6 +161,74 @@ def ard_fit(a, b, w, testing=None, directmethod=False, alphabig=1.0e-12, lambdas
     return reg.coef_
 
 
+def ard_fit_extended(a, b, w, testing=None, directmethod=False, alphabig=1.0e-12, lambdasmall=1.0e-6,
+                     threshold_lambda=100000, scap=1.0e-3, scai=1.0e-3, logcut=0.3, max_iter=1000, tol=1.0e-3):
+    """The SAME iteration in extended precision (numpy longdouble: 64-bit mantissa on x86): scikit-learn 1.7.2
+    ``ARDRegression.fit`` / ``_update_sigma`` (linear_model/_bayes.py) as called by fitsnap3lib/solvers/ard.py:18-48, with
+    the Gram matrix, the residual and the K x K inverse (Cholesky of the column-equilibrated matrix) all formed in long
+    double.  Test yardstick only: on the Ta rows the reference class's own float64 answer sits 3e-4 (element-wise) from
+    this one -- ``pinvh(lambda I + alpha X^T X)`` on columns that span 15 decades loses kappa eps -- so "who is closer to
+    the exact iteration" is what a 1e-6 bar can be held against, not the float64 golden itself.  Returns (coef, n_iter)."""
+    LD = np.longdouble
+    aw, bw = weight_rows(a, b, w, testing)
+    if directmethod:
+        hyper = dict(threshold_lambda=threshold_lambda, alpha_1=alphabig, alpha_2=alphabig, lambda_1=lambdasmall, lambda_2=lambdasmall)
+    else:
+        hyper = ard_hyper(bw, scap, scai, logcut)
+    a1, a2, l1, l2, thr = (hyper[k] for k in ("alpha_1", "alpha_2", "lambda_1", "lambda_2", "threshold_lambda"))
+    awl, bwl = aw.astype(LD), bw.astype(LD)
+    G, c = awl.T @ awl, awl.T @ bwl
+    K = len(c)
+    n = LD(len(bw))
+    d = np.sqrt(np.diag(G))
+    d[d == 0] = 1
+    Gh = G / np.outer(d, d)
+
+    def spd_inverse(M):
+        k = M.shape[0]
+        L = np.zeros_like(M)
+        for j in range(k):
+            L[j, j] = np.sqrt(M[j, j] - np.dot(L[j, :j], L[j, :j]))
+            for i in range(j + 1, k):
+                L[i, j] = (M[i, j] - np.dot(L[i, :j], L[j, :j])) / L[j, j]
+        Li = np.zeros_like(M)
+        for j in range(k):
+            Li[j, j] = 1 / L[j, j]
+            for i in range(j + 1, k):
+                Li[i, j] = -np.dot(L[i, j:i], Li[j:i, j]) / L[i, i]
+        return Li.T @ Li
+
+    def sigma_of(alpha_, lambda_, keep):
+        dk = d[keep]
+        return spd_inverse(np.diag(lambda_[keep] / dk ** 2) + alpha_ * Gh[np.ix_(keep, keep)]) / np.outer(dk, dk)
+
+    eps = np.finfo(np.float64).eps
+    coef_ = np.zeros(K, dtype=LD)
+    keep = np.ones(K, dtype=bool)
+    alpha_ = LD(1.0) / (LD(np.var(bw)) + eps)
+    lambda_ = np.ones(K, dtype=LD)
+    coef_old = None
+    it = 0
+    for it in range(max_iter):
+        sigma_ = sigma_of(alpha_, lambda_, keep)
+        coef_[keep] = alpha_ * (sigma_ @ c[keep])
+        sse_ = np.sum((bwl - awl @ coef_) ** 2)
+        gamma_ = 1 - lambda_[keep] * np.diag(sigma_)
+        lambda_[keep] = (gamma_ + 2 * l1) / (coef_[keep] ** 2 + 2 * l2)
+        alpha_ = (n - gamma_.sum() + 2 * a1) / (sse_ + 2 * a2)
+        keep = lambda_ < thr
+        coef_[~keep] = 0
+        if it > 0 and np.sum(np.abs(coef_old - coef_)) < tol:
+            break
+        coef_old = coef_.copy()
+        if not keep.any():
+            break
+    if keep.any():
+        sigma_ = sigma_of(alpha_, lambda_, keep)
+        coef_[keep] = alpha_ * (sigma_ @ c[keep])
+    return np.asarray(coef_, dtype=np.float64), it + 1
+
+
 def lasso_fit(a, b, w, testing=None, alpha=1.0e-8, max_iter=2000, apply_transpose=False):
     """fitsnap3lib/solvers/lasso.py:17-29: ``Lasso(alpha, fit_intercept=False, max_iter).fit(aw, bw).coef_`` (defaults:
     io/sections/solver_sections/lasso.py:13-14).  Pinned bit-for-bit to vectors produced by the reference class

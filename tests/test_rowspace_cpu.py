@@ -12,7 +12,31 @@ from oracle import fitsnap_oracle as orc
 EPS = np.finfo(float).eps
 
 
-def cholqr_lstsq(A, b, rcond=1.0e-13, maxpass=6):
+def trsm_substitution(R, X):
+    """Q = X R^-1 by substitution: kernels 13 / 13A."""
+    return sl.solve_triangular(R, X.T, trans="T", lower=False).T
+
+
+def trsm_block_inverse(R, X, nb=16):
+    """Q = X R^-1 the way kernel 13B does it (fsnap_trsm.hip): right-looking over 16-column blocks; a diagonal block is
+    solved as q0 = x T^-1, r = x - q0 T, q = q0 + r T^-1 with the explicit inverse of the 16 x 16 block (one step of
+    iterative refinement on top of the multiplication by the inverse), everything else is matrix products."""
+    K = R.shape[0]
+    S = X.copy()
+    Q = np.empty_like(X)
+    for j0 in range(0, K, nb):
+        j1 = min(j0 + nb, K)
+        T = R[j0:j1, j0:j1]
+        Tinv = sl.solve_triangular(T, np.eye(j1 - j0))
+        x = S[:, j0:j1]
+        q = x @ Tinv
+        q = q + (x - q @ T) @ Tinv
+        Q[:, j0:j1] = q
+        S[:, j1:] -= q @ R[j0:j1, j1:]
+    return Q
+
+
+def cholqr_lstsq(A, b, rcond=1.0e-13, maxpass=6, trsm=trsm_substitution):
     """The algorithm of fsnap_lstsq_rows with numpy in place of the GPU passes."""
     G = A.T @ A
     Q = A.copy()
@@ -22,7 +46,7 @@ def cholqr_lstsq(A, b, rcond=1.0e-13, maxpass=6):
         Rp, Rhat, info = _capi.rowspace_factor(G, Rhat)
         if Rp is None:
             break
-        Q = sl.solve_triangular(Rp, Q.T, trans="T", lower=False).T
+        Q = trsm(Rp, Q)
         G = Q.T @ Q
         passes += 1
     beta, rank, sinfo = _capi.rowspace_solve(Rhat, Q.T @ b, rcond)
@@ -42,15 +66,18 @@ def conditioned(m, K, kappa, mode, seed):
     return (U * s) @ V.T
 
 
+@pytest.mark.parametrize("trsm", [trsm_substitution, trsm_block_inverse], ids=["substitution", "block_inverse_refined"])
 @pytest.mark.parametrize("mode", ["geometric", "one"])
 @pytest.mark.parametrize("kappa", [1e4, 1e8, 1e10, 1e12])
-def test_matches_lstsq_up_to_kappa_eps(kappa, mode):
+def test_matches_lstsq_up_to_kappa_eps(kappa, mode, trsm):
+    # both forms of the pass: kernels 13 / 13A divide by R with a substitution, kernel 13B (K > 128) multiplies by the
+    # inverses of the 16 x 16 diagonal blocks and refines once -- same orthogonality, same A = Q R_hat, same coefficients
     m, K = 6000, 48
     A = conditioned(m, K, kappa, mode, 3)
     r = np.random.default_rng(4)
     b = A @ r.standard_normal(K) + 1e-3 * r.standard_normal(m)
     ref = orc.svd_fit(A, b, np.ones(m))
-    x, rank, passes, sinfo, Q, Rhat = cholqr_lstsq(A, b)
+    x, rank, passes, sinfo, Q, Rhat = cholqr_lstsq(A, b, trsm=trsm)
     assert rank == K and 2 <= passes <= 4
     assert np.abs(Q.T @ Q - np.eye(K)).max() < 1e-10                       # orthonormal columns
     assert np.linalg.norm(Q @ Rhat - A) <= 50 * K * EPS * np.linalg.norm(A)  # A = Q R_hat to working precision
