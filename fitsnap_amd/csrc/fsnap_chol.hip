@@ -675,6 +675,117 @@ __global__ __launch_bounds__(1024) void fsnap_chol_backsolve_k(const double* __r
     }
 }
 // ---------------------------------------------------------------------------------
+// Factor-only use of kernels 8b-8d: the pass factor of the row-space solve (fsnap_rowspace.cpp, shifted CholeskyQR)
+//   R_p = chol(D^-1 G D^-1 + s I) D,   D = diag(sqrt(G_jj)),
+// for K >= 384, where the host factorisation (one core: 12 ms at K = 1595, 22 ms with the scaling passes around it, twice
+// per call) was the largest item of an ill-conditioned fit.  The reduced Gram matrix is already in HBM; the factor goes
+// straight into the layout the row-space pass reads (kernel 13B: K16 x K16 padded R + the inverses of its 16 x 16 diagonal
+// blocks, which are the Y blocks of kernel 8b scaled by 1 / D) and comes back to the host once, for the K x K end.
+// Columns with G_jj <= 0 (zero columns of A_w) are inactive: unit row / column, as in fsnap_rs::factor_pass.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsnap_chol_factor_prepare_d_k(const double* __restrict__ G, int n, int np,
+                                                                    double* __restrict__ dsc, int* __restrict__ status,
+                                                                    double* __restrict__ minpiv, int npanel) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < npanel) minpiv[i] = 1.0e300;
+    if (i >= np) return;
+    double d = 0.0;                                        // 0 marks an inactive / padding column
+    if (i < n) {
+        const double g = G[(size_t)i * n + i];
+        if (!__builtin_isfinite(g)) atomicOr(status, 1);
+        else if (g > 0.0) d = 1.0 / sqrt(g);
+    }
+    dsc[i] = d;
+}
+
+__global__ __launch_bounds__(256) void fsnap_chol_factor_prepare_s_k(const double* __restrict__ G, int n, int np, double shift,
+                                                                    const double* __restrict__ dsc, double* __restrict__ S,
+                                                                    int* __restrict__ status) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    const int ld = np + CHOL_XS;
+    if (j >= ld) return;
+    double v = 0.0;
+    if (j < np) {
+        const double di = dsc[i], dj = dsc[j];
+        if (i < n && j < n && di > 0.0 && dj > 0.0) {
+            // symmetrised like the host pass (the reduction mirrors the triangle exactly; defensive)
+            const double g = 0.5 * (G[(size_t)i * n + j] + G[(size_t)j * n + i]);
+            v = (i == j) ? 1.0 + shift : g * di * dj;
+            if (!__builtin_isfinite(v)) atomicOr(status, 1);
+        } else {
+            v = (i == j) ? 1.0 : 0.0;
+        }
+    }
+    S[(size_t)i * ld + j] = v;                             // (the right-hand-side strip stays zero: nothing to carry)
+}
+
+// One sweep over the Gram matrix on the device, a workgroup per row: out[a] = max_b |G_ab - delta_ab| and out[n + a] = sum_b of
+// the squared Jacobi-scaled entries (unit diagonal), both over the columns with a positive diagonal entry; a NaN / Inf anywhere
+// in the row makes out[a] NaN.  What the host needs to steer a pass (convergence test, shift) without the K x K matrix itself:
+// the host sweep over 20 MB cost 3 ms per pass at K = 1595.  Fixed-order reductions.
+__global__ __launch_bounds__(256) void fsnap_gram_scan_k(const double* __restrict__ G, int n, double* __restrict__ out) {
+    __shared__ double smax[256], ssum[256];
+    const int a = blockIdx.x, tid = threadIdx.x;
+    const double ga = G[(size_t)a * n + a];
+    const bool act_a = ga > 0.0;
+    const double ia = act_a ? 1.0 / sqrt(ga) : 0.0;
+    double dmax = 0.0, f = 0.0, bad = 0.0;
+    for (int b = tid; b < n; b += 256) {
+        const double g = G[(size_t)a * n + b];
+        bad += g * 0.0;                                   // NaN for NaN / Inf
+        const double gb = G[(size_t)b * n + b];
+        if (act_a && gb > 0.0) {
+            const double dv = fabs(g - (a == b ? 1.0 : 0.0));
+            dmax = dv > dmax ? dv : dmax;
+            const double sc = (a == b) ? 1.0 : g * ia * (1.0 / sqrt(gb));
+            f += sc * sc;
+        }
+    }
+    smax[tid] = (bad == 0.0) ? dmax : __builtin_nan("");
+    ssum[tid] = f;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) {
+            const double x = smax[tid], y = smax[tid + w];
+            smax[tid] = (x != x || y != y) ? __builtin_nan("") : (x > y ? x : y);
+            ssum[tid] += ssum[tid + w];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out[a] = smax[0];
+        out[n + a] = ssum[0];
+    }
+}
+
+// R[i][j] = U[i][j] sqrt(G_jj) into the K16 x K16 layout of the row-space pass, then the inverse blocks
+// T_J^-1 = diag(1 / sqrt(G_jj)) Y_J (Y_J = U_JJ^-1 from kernel 8b).  One thread per element.
+__global__ __launch_bounds__(256) void fsnap_chol_extract_factor_k(const double* __restrict__ S, const double* __restrict__ Yall,
+                                                                  const double* __restrict__ dsc, int n, int np, int K16,
+                                                                  double* __restrict__ Rout) {
+    const int ld = np + CHOL_XS;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t nR = (int64_t)K16 * K16;
+    if (idx < nR) {
+        const int i = (int)(idx / K16), j = (int)(idx % K16);
+        double v = 0.0;
+        if (j >= i) {
+            const double dj = dsc[j];
+            v = S[(size_t)i * ld + j] * (dj > 0.0 ? 1.0 / dj : 1.0);
+        }
+        Rout[idx] = v;
+    } else if (idx < nR + (int64_t)K16 * 16) {
+        const int64_t q = idx - nR;
+        const int jb = (int)(q >> 8), k = (int)((q >> 4) & 15), c = (int)(q & 15);
+        const int row = jb * 16 + k;
+        const double dk = dsc[row];
+        const double y = Yall[(size_t)(row / CHOL_NB) * 1024 + (size_t)((row % CHOL_NB) / 16) * 256 + k * 16 + c];
+        Rout[idx] = (dk > 0.0 ? dk : 1.0) * y;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // host-side launchers (C++ linkage, used by fsnap_capi.cpp)
 // ---------------------------------------------------------------------------------
 namespace fsnap {
@@ -731,6 +842,40 @@ hipError_t launch_chol_large(const double* packed, const double* cvec, int n, do
                                hi * CHOL_NB, nrows, status);
         }
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_chol_factor(const double* G, int n, double shift, double* work, double* dsc, int* status, double* minpiv,
+                              int K16, double* Rout, hipStream_t st) {
+    const int np = (n + CHOL_NB - 1) / CHOL_NB * CHOL_NB, npanel = np / CHOL_NB, ld = np + CHOL_XS;
+    double* S = work;
+    double* Yall = work + (size_t)np * ld;
+    hipError_t e = hipMemsetAsync(status, 0, sizeof(int), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fsnap_chol_factor_prepare_d_k, dim3((np + 255) / 256), dim3(256), 0, st, G, n, np, dsc, status, minpiv, npanel);
+    hipLaunchKernelGGL(fsnap_chol_factor_prepare_s_k, dim3((ld + 255) / 256, np), dim3(256), 0, st, G, n, np, shift, dsc, S, status);
+    hipLaunchKernelGGL(fsnap_chol_diag_k, dim3(1), dim3(64), 0, st, S, ld, 0, Yall, status, minpiv);
+    for (int pb = 0; pb < npanel; ++pb) {
+        const int jb = pb * CHOL_NB;
+        double* Y = Yall + (size_t)pb * 1024;
+        const int ntail = np - jb - CHOL_NB;
+        // (the strip is carried along as in the solve: it is zero here and costs one block column)
+        const int nstrip = (ntail + CHOL_XS) / 16;
+        hipLaunchKernelGGL(fsnap_chol_tails_k, dim3((nstrip + 3) / 4), dim3(256), 0, st, S, ld, jb, nstrip, Y, status);
+        if (ntail > 0) {
+            const int nblk = ntail / 32, nrest = nblk * (nblk + 1) / 2 + nblk - 3;
+            hipLaunchKernelGGL(fsnap_chol_update_diag_k, dim3(1 + (nrest + 3) / 4), dim3(256), 0, st, S, ld, jb, nblk, status,
+                               Y + 1024, minpiv);
+        }
+    }
+    const int64_t total = (int64_t)K16 * K16 + (int64_t)K16 * 16;
+    hipLaunchKernelGGL(fsnap_chol_extract_factor_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, S, Yall, dsc, n, np, K16,
+                       Rout);
+    return hipGetLastError();
+}
+
+hipError_t launch_gram_scan(const double* G, int n, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(fsnap_gram_scan_k, dim3((unsigned)n), dim3(256), 0, st, G, n, out);
     return hipGetLastError();
 }
 

@@ -80,6 +80,15 @@ hipError_t launch_chol_solve(const double* packed, int K, double alpha, double* 
 size_t chol_large_work_doubles(int n);
 hipError_t launch_chol_large(const double* packed, const double* cvec, int n, double alpha, double* work, double* dsc, double* z,
                              double* beta, int* status, double* minpiv, double* host_out, bool clear_status, hipStream_t st);
+// factor only (pass factor of the row-space solve, K >= 384): R = chol(D^-1 G D^-1 + shift I) D for the n x n Gram matrix G in
+// device memory, written as the K16 x K16 padded factor + inverse blocks that launch_trsm_rows reads (trsm_factor_doubles(K16)
+// doubles at Rout); status: bit 0 non-finite input, bit 1 failed pivot (retry with a larger shift).  work / dsc / minpiv as
+// for launch_chol_large.
+hipError_t launch_chol_factor(const double* G, int n, double shift, double* work, double* dsc, int* status, double* minpiv,
+                              int K16, double* Rout, hipStream_t st);
+// out[0 .. n) = row maxima of |G - I|, out[n .. 2 n) = row sums of the squared Jacobi-scaled entries (active columns; NaN row
+// maximum = non-finite input): the steering numbers of a row-space pass, so that G itself can stay in HBM
+hipError_t launch_gram_scan(const double* G, int n, double* out, hipStream_t st);
 int gemv_num_blocks(int64_t m);
 hipError_t launch_gemv_rows(const double* A, int64_t lda, const double* beta, int64_t m, int K, double* preds,
                             const double* b, const double* w, const unsigned char* mask, double* sse_part,

@@ -51,7 +51,25 @@ using vec = std::vector<double>;
 namespace fsnap {
 
 struct RowSpace {
-    DevBuf Q, qpack, Rdev, packed, rvec, dz, dzpart, beta;
+    DevBuf Q, qpack, Rdev, packed, rvec, dz, dzpart, beta, scan;
+    // page-locked K x K blocks, one per pass, that receive the factors of the device factorisation and stay in place for
+    // the K x K end (FactorChain::push_view)
+    std::vector<double*> pinfac;
+    std::vector<size_t> pinfac_doubles;
+    double* pinfac_get(size_t idx, size_t n) {
+        if (pinfac.size() <= idx) {
+            pinfac.resize(idx + 1, nullptr);
+            pinfac_doubles.resize(idx + 1, 0);
+        }
+        if (pinfac_doubles[idx] < n) {
+            if (pinfac[idx]) (void)hipHostFree(pinfac[idx]);
+            pinfac[idx] = nullptr;
+            pinfac_doubles[idx] = 0;
+            if (hipHostMalloc((void**)&pinfac[idx], n * sizeof(double), hipHostMallocDefault) != hipSuccess) return nullptr;
+            pinfac_doubles[idx] = n;
+        }
+        return pinfac[idx];
+    }
     // page-locked staging for what crosses PCIe every pass: the K x K statistics down, the factor up (from pageable
     // memory each of these copies went through the runtime's own staging, ~40 us apiece)
     double* pin = nullptr;
@@ -70,9 +88,11 @@ struct RowSpace {
 void rowspace_release(fsnap_ctx* ctx) {
     if (!ctx->rowspace) return;
     RowSpace* rs = ctx->rowspace;
-    DevBuf* bufs[] = {&rs->Q, &rs->qpack, &rs->Rdev, &rs->packed, &rs->rvec, &rs->dz, &rs->dzpart, &rs->beta};
+    DevBuf* bufs[] = {&rs->Q, &rs->qpack, &rs->Rdev, &rs->packed, &rs->rvec, &rs->dz, &rs->dzpart, &rs->beta, &rs->scan};
     for (DevBuf* b : bufs) b->release();
     if (rs->pin) (void)hipHostFree(rs->pin);
+    for (double* p : rs->pinfac)
+        if (p) (void)hipHostFree(p);
     delete rs;
     ctx->rowspace = nullptr;
 }
@@ -203,7 +223,14 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
     // out to be needed; small K keeps the accumulated factor (the product is cheap there and the exact Frobenius bound of
     // FactorSolver is sharper than the chain's estimate)
     const bool chained = K > 256;
-    vec Rhat(chained ? 0 : (size_t)K * K), Rp((size_t)K * K), z((size_t)K);
+    // K >= 384 with the factors kept apart: the Gram matrix is factorised where it is, in HBM (kernels 8b-8d in their
+    // factor-only form), the factor lands in the layout the pass reads, and one D2H copy per pass brings it to the host for
+    // the K x K end -- the host factorisation (one core) was 2 x 22 ms of a 125 ms call at K = 1595.  The host then needs
+    // only the diagonal, Q^T (w b) and two steering numbers per pass (fsnap_gram_scan_k), not the K x K matrix.
+    const bool device_factor = chained && K >= 384 && ctx->opt_device_solve != 2;
+    if (device_factor && !rs->scan.ensure((size_t)2 * K * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(row-space workspace) failed");
+    vec Rhat(chained ? 0 : (size_t)K * K), Rp(device_factor ? 0 : (size_t)K * K), z((size_t)K), scanh(device_factor ? (size_t)2 * K : 0);
+    double scan_dev = 0.0, scan_fro = 0.0;
     FactorChain chain;
     double* const host = rs->pin;                        // [npk] statistics of the current Q
     double* const Rpad = rs->pin + npk;                  // [K16 x K16] padded factor of the pass | [K16 / 16][16][16] inverse blocks
@@ -225,10 +252,36 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
             int r3 = fsnap_allreduce_device(ctx, dp, npk);
             if (r3) return r3;
         }
-        FSNAP_HIP(hipMemcpyAsync(host, dp, (size_t)npk * 8, hipMemcpyDeviceToHost, st), "hipMemcpy(statistics)");
+        if (device_factor) {
+            // diagonal (to its places in the host copy), Q^T (w b) + scalars, row maxima / sums of the scan
+            FSNAP_HIP(fsnap::launch_gram_scan(dp, K, (double*)rs->scan.p, st), "launch fsnap_gram_scan_k");
+            FSNAP_HIP(hipMemcpy2DAsync(host, (size_t)(K + 1) * 8, dp, (size_t)(K + 1) * 8, 8, (size_t)K, hipMemcpyDeviceToHost, st),
+                      "hipMemcpy(diagonal)");
+            FSNAP_HIP(hipMemcpyAsync(host + (size_t)K * K, dp + (size_t)K * K, (size_t)(K + 3) * 8, hipMemcpyDeviceToHost, st),
+                      "hipMemcpy(statistics)");
+            FSNAP_HIP(hipMemcpyAsync(scanh.data(), rs->scan.p, (size_t)2 * K * 8, hipMemcpyDeviceToHost, st), "hipMemcpy(scan)");
+        } else {
+            FSNAP_HIP(hipMemcpyAsync(host, dp, (size_t)npk * 8, hipMemcpyDeviceToHost, st), "hipMemcpy(statistics)");
+        }
         int r4 = fsnap::wait_stream(ctx, nullptr, "statistics of a row-space pass");
         if (r4) return r4;
-        return local_rc != FSNAP_OK ? ctx->fail(local_rc, "%s", local_err.c_str()) : FSNAP_OK;
+        if (local_rc != FSNAP_OK) return ctx->fail(local_rc, "%s", local_err.c_str());
+        if (device_factor) {
+            double dv = 0.0, f2 = 0.0;
+            bool finite = true;
+            for (int a = 0; a < K; ++a) {
+                finite = finite && (scanh[a] == scanh[a]);
+                dv = std::fmax(dv, scanh[a]);
+                f2 += scanh[(size_t)K + a];
+            }
+            scan_dev = dv;
+            scan_fro = std::sqrt(f2);
+            if (!finite || !std::isfinite(f2))
+                return ctx->fail(FSNAP_NUM_NONFINITE, nranks > 1 ? "row-space solve: non-finite statistics after the all-reduce (NaN/Inf in a training row of "
+                                                                   "some rank, or a rank failed before the collective: see that rank's error)"
+                                                                 : "row-space solve: non-finite Gram matrix");
+        }
+        return FSNAP_OK;
     };
     // FSNAP_ROWSPACE_TIMING=1: wall-clock marks of the host phases on stderr
     const bool timing = getenv("FSNAP_ROWSPACE_TIMING") != nullptr;
@@ -253,6 +306,35 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
     for (int pass = 1; pass <= maxpass; ++pass) {
         int conv = 0;
         if (pass == 1 && chained) chain.start(K, host);
+        if (device_factor) {
+            dev = scan_dev;
+            if (pass > 1 && dev <= tol) {
+                converged = 1;
+                break;
+            }
+            const double fro = scan_fro;
+            const int np64 = (K + 63) / 64 * 64, npanel = np64 / 64;
+            if (!ctx->dchol.ensure(fsnap::chol_large_work_doubles(K) * 8) || !ctx->dsolve.ensure(((size_t)np64 + npanel + 2) * 8))
+                return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(device Cholesky) failed");
+            double* d_dsc = (double*)ctx->dsolve.p;
+            double* d_minpiv = d_dsc + np64;
+            int* d_status = (int*)(d_minpiv + npanel);
+            ctx->chol_status_word = nullptr;                  // the buffer of fsnap_solve_device's chain is reused here
+            // shift: a few times the rounding level of the Gram matrix, x 100 and again when a pivot fails (as factor_pass)
+            shift = 4.0 * (K + 100.0) * std::numeric_limits<double>::epsilon() * fro;
+            int status = 0;
+            for (int attempt = 0; attempt < 10; ++attempt) {
+                FSNAP_HIP(fsnap::launch_chol_factor(dp, K, shift, (double*)ctx->dchol.p, d_dsc, d_status, d_minpiv, K16,
+                                                    (double*)rs->Rdev.p, st), "launch device Cholesky (factor)");
+                FSNAP_HIP(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, st), "hipMemcpy(status)");
+                if ((rc = fsnap::wait_stream(ctx, nullptr, "pass factor"))) return rc;
+                if (status == 0) break;
+                if (status & 1) return ctx->fail(FSNAP_NUM_NONFINITE, "row-space pass %d: non-finite Gram matrix", pass);
+                shift *= 100.0;
+            }
+            if (status != 0) return ctx->fail(FSNAP_NUM_NOT_SPD, "row-space pass %d: the Gram matrix could not be factorised", pass);
+            mark("factor (device)");
+        } else {
         rc = factor_pass(K, host, pass == 1, tol, chained ? nullptr : Rhat.data(), Rp.data(), &dev, &conv, &shift);
         if (rc == FSNAP_NUM_NONFINITE && nranks > 1)
             return ctx->fail(rc, "row-space pass %d: non-finite statistics after the all-reduce (NaN/Inf in a training row of some "
@@ -270,6 +352,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
         for (int i = 0; i < K; ++i) memcpy(Rpad + (size_t)i * K16 + i, Rp.data() + (size_t)i * K + i, (size_t)(K - i) * 8);
         fsnap::trsm_invert_diagonal_blocks(Rpad, K16);
         FSNAP_HIP(hipMemcpyAsync(rs->Rdev.p, Rpad, rdoubles * 8, hipMemcpyHostToDevice, st), "hipMemcpy(R)");
+        }
         if (have_rows) {
             if (pass == 1)
                 FSNAP_HIP(fsnap::launch_trsm_rows(ctx->dA, ctx->lda, (const double*)ctx->wpack.p, dQ, K, ctx->m, K,
@@ -277,6 +360,15 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
             else
                 FSNAP_HIP(fsnap::launch_trsm_rows(dQ, K, nullptr, dQ, K, ctx->m, K, (const double*)rs->Rdev.p, K16, st),
                           "launch fsnap_trsm_rows_k");
+        }
+        if (device_factor) {
+            // the factor for the K x K end, behind the pass on the same stream: K x K compact into a page-locked block of its
+            // own, where it stays (no second copy)
+            double* hf = rs->pinfac_get((size_t)pass - 1, (size_t)K * K);
+            if (!hf) return ctx->fail(FSNAP_E_NOMEM, "hipHostMalloc(factor staging) failed");
+            FSNAP_HIP(hipMemcpy2DAsync(hf, (size_t)K * 8, rs->Rdev.p, (size_t)K16 * 8, (size_t)K * 8, (size_t)K, hipMemcpyDeviceToHost, st),
+                      "hipMemcpy(factor)");
+            chain.push_view(hf);
         }
         if ((rc = fsnap::wait_stream(ctx, nullptr, "row-space pass"))) return rc;      // Rpad is reused by the next pass
         passes = pass;
@@ -287,8 +379,12 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
     }
     if (!converged) {
         // pass budget used up: judge the last Q as it is (the refinement step below absorbs what is left)
-        if (!finite_all(host, (size_t)K * K)) return ctx->fail(FSNAP_NUM_NONFINITE, "row-space solve: non-finite Gram matrix");
-        dev = gram_deviation(K, host);
+        if (device_factor) {
+            dev = scan_dev;
+        } else {
+            if (!finite_all(host, (size_t)K * K)) return ctx->fail(FSNAP_NUM_NONFINITE, "row-space solve: non-finite Gram matrix");
+            dev = gram_deviation(K, host);
+        }
         converged = dev <= tol;
     }
     if (passes == 0) return ctx->fail(FSNAP_E_STATE, "row-space solve made no pass");

@@ -1,6 +1,7 @@
 // fsnap_rowspace_host.h — the K x K host algebra of the row-space least-squares path (fsnap_rowspace_host.cpp), shared
 // with its GPU orchestration (fsnap_rowspace.cpp).  Internal; the public entry points are in include/fsnap_hip.h.
 #pragma once
+#include <algorithm>
 #include <vector>
 
 namespace fsnap_rs {
@@ -8,6 +9,10 @@ namespace fsnap_rs {
 bool finite_all(const double* p, size_t n);
 // max |G_ij - delta_ij| over the columns with a non-zero diagonal entry
 double gram_deviation(int K, const double* G);
+// one sweep over a Gram matrix: FSNAP_NUM_NONFINITE if it holds NaN / Inf; *dev = max |G_ij - delta_ij| and *fro = Frobenius norm
+// of the Jacobi-scaled matrix (unit diagonal), both over the columns with a positive diagonal entry -- what a pass needs from
+// the host when the factorisation itself runs on the GPU
+int gram_scan(int K, const double* G, double* dev, double* fro);
 // one pass: see fsnap_rowspace_host.cpp
 // Rhat may be NULL: the factor is then only returned in Rp (FactorChain keeps the factors apart)
 int factor_pass(int K, const double* G, int first, double tol, double* Rhat, double* Rp, double* dev_out, int* converged,
@@ -18,10 +23,18 @@ int factor_pass(int K, const double* G, int first, double tol, double* Rhat, dou
 // 14 ms -- while solving through the chain is p back substitutions (K^2 / 2 flops each).
 struct FactorChain {
     int K = 0;
-    std::vector<std::vector<double>> R;    // K x K, upper triangular, unit rows / columns for inactive columns
+    std::vector<const double*> R;          // the factors: K x K row-major (leading dimension K), upper triangular, unit rows /
+                                           // columns for inactive columns
+    std::vector<std::vector<double>> own;  // storage of the factors this chain copied (push); push_view keeps a pointer only
     std::vector<char> active;              // columns with a non-zero diagonal entry of the first Gram matrix
     void start(int K_, const double* G);
-    void push(const double* Rp) { R.emplace_back(Rp, Rp + (size_t)K * K); }
+    void push(const double* Rp) {
+        own.emplace_back(Rp, Rp + (size_t)K * K);
+        R.push_back(own.back().data());
+    }
+    // a factor that stays where it is (page-locked staging of the device factorisation: a copy of 20 MB is 3 ms at
+    // K = 1595); the memory must outlive the chain's use
+    void push_view(const double* Rp) { R.push_back(Rp); }
     // upper estimate of ||R_hat||_2 ||R_hat^-1||_2, per factor: sqrt(||R||_1 ||R||_inf) (exact) x an estimate of ||R^-1||_2 --
     // the smaller of 3 x sqrt(est_1 est_inf) (Hager / Higham's 1-norm estimator) and 2 x inverse iteration on R^T R; a
     // Neumann bound 1 / (1 - ||R - I||) for the near-identity factors of the later passes
