@@ -233,7 +233,7 @@ int plan_tiled(fsnap_ctx* ctx, TiledGeometry* g) {
     const int64_t m = ctx->m, K = ctx->K;
     if (K > 32768) return ctx->fail(FSNAP_E_ARG, "K = %lld too large", (long long)K);
     if (ctx->tplan_valid && ctx->tplan_key[0] == m && ctx->tplan_key[1] == K && ctx->tplan_key[2] == ctx->lda &&
-        ctx->tplan_key[3] == ctx->opt_nsplit && ctx->tplan_key[4] == ctx->opt_xcd + 2 * ctx->opt_tiled2) {
+        ctx->tplan_key[3] == ctx->opt_nsplit && ctx->tplan_key[4] == ctx->opt_xcd + 4 * ctx->opt_tiled2) {
         g->NSB = ctx->tplan[0];
         g->npairs = ctx->tplan[1];
         g->nsplit = ctx->tplan[2];
@@ -323,7 +323,7 @@ int plan_tiled(fsnap_ctx* ctx, TiledGeometry* g) {
     ctx->tplan_key[1] = K;
     ctx->tplan_key[2] = ctx->lda;
     ctx->tplan_key[3] = ctx->opt_nsplit;
-    ctx->tplan_key[4] = ctx->opt_xcd + 2 * ctx->opt_tiled2;
+    ctx->tplan_key[4] = ctx->opt_xcd + 4 * ctx->opt_tiled2;
     ctx->tplan[0] = g->NSB;
     ctx->tplan[1] = g->npairs;
     ctx->tplan[2] = g->nsplit;
@@ -375,6 +375,7 @@ int launch_normal_eq_tiled(fsnap_ctx* ctx, double* d_packed, bool accumulate) {
     a.chunks_per_split = g.cps;
     a.nontemporal = false;  // rows are re-read by the other column pairs: keep them cached
     a.xcd_map = ctx->opt_xcd != 0;
+    a.xcd_order = ctx->opt_xcd == 2 ? 2 : 1;
     a.part = (double*)ctx->part.p;
     a.cpart = (double*)ctx->cpart.p;
     a.spart = (const double*)ctx->wpack_spart.p;
@@ -649,7 +650,8 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
         ctx->opt_mirror = value != 0;
         ctx->mirror_of = nullptr;
     } else if (!strcmp(key, "xcd")) {
-        ctx->opt_xcd = value != 0;
+        if (value < 0 || value > 2) return ctx->fail(FSNAP_E_ARG, "xcd must be 0, 1 (split-major ranges per XCD) or 2 (class-major)");
+        ctx->opt_xcd = (int)value;
     } else if (!strcmp(key, "tiled2")) {
         ctx->opt_tiled2 = value != 0;
     } else if (!strcmp(key, "timing_every")) {

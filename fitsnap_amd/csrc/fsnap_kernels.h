@@ -38,6 +38,7 @@ struct TiledArgs {
     int64_t chunks_per_split;   // 4-row chunks per split (each split = 4 waves)
     bool nontemporal;
     bool xcd_map = true;        // contiguous (split, pair) ranges per XCD (L2 sharing of row slabs)
+    int xcd_order = 1;          // 1: (split, pair) order inside an XCD; 2: class-major (equal-cost items side by side)
     double* part;               // [nsplit*npairs][16][4][64]
     double* cpart;              // [(nsplit*NSB)*4][4][16]
     const double* spart;        // [ns][4]: partial b-only scalars of fsnap_pack_weights_k

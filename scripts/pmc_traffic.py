@@ -37,7 +37,7 @@ def main(pmc_dir, bench_json):
         "hbm_bytes_per_launch": int(round((2.0 * fetch + write) * 1024)),
         "fetch_size_kb": fetch, "write_size_kb": write,
         "dispatches": [len(vals["FETCH_SIZE"]), len(vals["WRITE_SIZE"])],
-        "rows": rec["config"]["rows_per_gpu"], "K": rec["config"]["K"], "kernel": kernel,
+        "rows": rec["roofline"]["rows_per_launch"], "K": rec["config"]["K"], "kernel": kernel,
         "workgroups": launch["workgroups"], "threads": launch["threads"], "chunks_per_wave": launch["chunks_per_wave"],
         "source_sha256": kernel_source_digest(),
         "algorithmic_bytes_per_launch": rec["roofline"]["algorithmic_bytes_per_launch"],
