@@ -64,6 +64,9 @@ SIGNATURES = {
     "fsnap_lasso_gram": (c_int, [c_int64, c_void_p, c_void_p, c_double, c_double, c_int64, c_double, c_void_p,
                                  POINTER(c_int64), POINTER(c_double)]),
     "fsnap_normal_eq_accumulate": (c_int, [c_void_p, c_void_p]),
+    "fsnap_assemble_accumulate": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int,
+                                          c_void_p]),
     "fsnap_error_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "fsnap_solve_device": (c_int, [c_void_p, c_int, c_double, c_int64, c_void_p, c_void_p, POINTER(c_int), POINTER(c_double)]),
     "fsnap_fit_resident": (c_int, [c_void_p, c_int, c_double, c_void_p, POINTER(c_int), POINTER(c_double), POINTER(c_void_p)]),
@@ -415,6 +418,29 @@ class HipContext:
             self._h, _ptr(raw), raw.shape[0], raw.shape[1], n, int(row0), _ptr(src_row), _ptr(kind), _ptr(frac), _ptr(d),
             _ptr(truth), _ptr(weight), _ptr(fractions) if fractions.size else None, fractions.shape[0], _ptr(blank2J),
             int(ntypes), int(ncoeff), int(offcol)))
+
+    def assemble_accumulate(self, raw, src_row, kind, frac, d, truth, weight, fractions, blank2J, ntypes, ncoeff, offcol,
+                            d_packed_ptr: int):
+        """`process_single` + `c += aw.T @ aw; d += aw.T @ bw` (transpose_trick/example.py:230-237) for a batch, with the
+        rows formed in registers: the packed statistics at ``d_packed_ptr`` (device) += those of the batch."""
+        raw = np.ascontiguousarray(raw, dtype=np.float64)
+        src_row = np.ascontiguousarray(src_row, dtype=np.int64)
+        kind = np.ascontiguousarray(kind, dtype=np.int32)
+        frac = np.ascontiguousarray(frac, dtype=np.int32)
+        d = np.ascontiguousarray(d, dtype=np.float64)
+        truth = np.ascontiguousarray(truth, dtype=np.float64)
+        weight = np.ascontiguousarray(weight, dtype=np.float64)
+        fractions = np.ascontiguousarray(fractions, dtype=np.float64).reshape(-1, ntypes)
+        blank2J = np.ascontiguousarray(blank2J, dtype=np.float64)
+        n = len(src_row)
+        if not (len(kind) == len(frac) == len(d) == len(truth) == len(weight) == n):
+            raise ValueError("plan arrays must have equal length")
+        if raw.ndim != 2 or len(blank2J) != ntypes * (ncoeff + offcol):
+            raise ValueError("raw must be 2-d and blank2J must have ntypes * (ncoeff + offcol) entries")
+        self._check(self._lib.fsnap_assemble_accumulate(
+            self._h, _ptr(raw), raw.shape[0], raw.shape[1], n, _ptr(src_row), _ptr(kind), _ptr(frac), _ptr(d),
+            _ptr(truth), _ptr(weight), _ptr(fractions) if fractions.size else None, fractions.shape[0], _ptr(blank2J),
+            int(ntypes), int(ncoeff), int(offcol), c_void_p(d_packed_ptr)))
 
     def download_rows(self, want_a=True, want_b=True, want_w=True, out_a=None, out_b=None, out_w=None):
         A = (out_a if out_a is not None else np.empty((self.m, self.K))) if want_a else None

@@ -66,6 +66,23 @@ class LammpsBase(Calculator):
             self._lmp = self.pt.close_lammps()
         return a, b, w
 
+    def accumulate_single(self, data: dict, i: int, d_packed_ptr: int):
+        """``process_single`` fused with the accumulation that follows it in the reference's memory-lean driver
+        (examples/library/transpose_trick/example.py:230-237: ``a, b, w = process_single(...)``, ``c += aw.T @ aw``,
+        ``d += aw.T @ bw``): the packed statistics at ``d_packed_ptr`` (device memory, ``K*K + K + 3`` doubles, zeroed
+        before the first configuration) += those of this configuration.  Its rows exist in registers only
+        (``fsnap_assemble_accumulate``).  Returns the number of rows."""
+        self._data = data
+        self._i = i
+        self._initialize_lammps()
+        try:
+            self._prepare_lammps()
+            self._run_lammps()
+            n = self._accumulate_lammps_single(d_packed_ptr)
+        finally:
+            self._lmp = self.pt.close_lammps()
+        return n
+
     def _initialize_lammps(self, printlammps: int = 0):
         self._lmp = self.pt.initialize_lammps(getattr(self.config.args, "lammpslog", 0), printlammps)
 
@@ -80,6 +97,9 @@ class LammpsBase(Calculator):
         raise NotImplementedError
 
     def _collect_lammps_single(self):
+        raise NotImplementedError
+
+    def _accumulate_lammps_single(self, d_packed_ptr):
         raise NotImplementedError
 
     # -- atom extraction (lammps_base.py:233-253) -----------------------------------------

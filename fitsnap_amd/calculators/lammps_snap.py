@@ -162,6 +162,18 @@ class _LinearAssembly:
                      0 if sec.bzeroflag else 1)
         return ctx.download_rows()
 
+    # -- single configuration, fused with `c += aw.T @ aw; d += aw.T @ bw`: no rows anywhere ---
+    def _accumulate_lammps_single(self, d_packed_ptr):
+        sec = self._sec()
+        raw, lmp_types, vol = self._extract_config()
+        frac = None if sec.bzeroflag else type_fractions(self._data["AtomTypes"], sec.type_mapping, sec.numtypes)
+        plan, _ = self._plan(0, -1 if frac is None else 0, lmp_types, vol)
+        fr = np.zeros((0, sec.numtypes)) if frac is None else frac.reshape(1, -1)
+        self.pt.hip().assemble_accumulate(raw, plan["src_row"], plan["kind"], plan["frac"], plan["d"], plan["truth"],
+                                          plan["weight"], fr, np.asarray(sec.blank2J, dtype=np.float64), sec.numtypes,
+                                          sec.ncoeff, 0 if sec.bzeroflag else 1, d_packed_ptr)
+        return len(plan["src_row"])
+
 
 class LammpsSnap(_LinearAssembly, LammpsBase):
     """[CALCULATOR] calculator = LAMMPSSNAP"""

@@ -229,29 +229,23 @@ double tiled_makespan_units(const std::vector<int>& tiles, int64_t n, int64_t ch
     return makespan;
 }
 
-int plan_tiled(fsnap_ctx* ctx, TiledGeometry* g) {
-    const int64_t m = ctx->m, K = ctx->K;
+// geometry of the tiled kernels for m rows of K columns (leading dimension lda); table: kernel 1T2's work items
+// (allow_t2), empty for kernel 1T.  Pure function of the shape and the context's options.
+int tiled_geometry(fsnap_ctx* ctx, int64_t m, int64_t K, int64_t lda, bool allow_t2, TiledGeometry* g, std::vector<int>* table_out) {
     if (K > 32768) return ctx->fail(FSNAP_E_ARG, "K = %lld too large", (long long)K);
-    if (ctx->tplan_valid && ctx->tplan_key[0] == m && ctx->tplan_key[1] == K && ctx->tplan_key[2] == ctx->lda &&
-        ctx->tplan_key[3] == ctx->opt_nsplit && ctx->tplan_key[4] == ctx->opt_xcd + 4 * ctx->opt_tiled2) {
-        g->NSB = ctx->tplan[0];
-        g->npairs = ctx->tplan[1];
-        g->nsplit = ctx->tplan[2];
-        g->cps = ctx->tplan_cps;
-        g->items_per_split = ctx->tplan_items;
-        return FSNAP_OK;
-    }
     g->NSB = (int)((K + 63) / 64);
     g->npairs = g->NSB * (g->NSB + 1) / 2;
     const int64_t nchunks = (m + 3) / 4;
-    const int64_t bytes = m * ctx->lda * 8;
+    const int64_t bytes = m * lda * 8;
     // keep a split's rows resident in the Infinity Cache (256 MiB) while all pairs sweep them
     const int64_t min_split_cache = (bytes + (96ll << 20) - 1) / (96ll << 20);
     // work items of one split and their cost in MFMA tiles per chunk
     const int tail = (int)(K & 63);
     const bool half = tail != 0 && tail <= 32;                   // last superblock: second 32-column group empty
-    const bool t2 = ctx->opt_tiled2 != 0 && g->NSB >= 3;
-    std::vector<int> tiles, table;
+    const bool t2 = allow_t2 && ctx->opt_tiled2 != 0 && g->NSB >= 3;
+    std::vector<int> tiles;
+    std::vector<int>& table = *table_out;
+    table.clear();
     if (t2) {
         // kernel 1T2: superblock I against consecutive pairs (J, J + 1) right of it (32 tiles, heaviest first), then
         // the lone last column of the rows with an odd count (16 tiles), then the diagonal (10 tiles)
@@ -306,14 +300,32 @@ int plan_tiled(fsnap_ctx* ctx, TiledGeometry* g) {
     int64_t cps = (nchunks + nsplit - 1) / nsplit;
     cps = (cps + 3) / 4 * 4;
     // 32-bit buffer offsets per wave
-    const int64_t max_cpw = (int64_t)0xFFF00000 / (ctx->lda * 32);
-    if (max_cpw < 1) return ctx->fail(FSNAP_E_ARG, "leading dimension %lld too large", (long long)ctx->lda);
+    const int64_t max_cpw = (int64_t)0xFFF00000 / (lda * 32);
+    if (max_cpw < 1) return ctx->fail(FSNAP_E_ARG, "leading dimension %lld too large", (long long)lda);
     if (cps / 4 > max_cpw) cps = max_cpw * 4;
     nsplit = (nchunks + cps - 1) / cps;
     if ((int64_t)g->npairs * nsplit > 0x7FFFFFFF) return ctx->fail(FSNAP_E_ARG, "too many workgroups");
     g->nsplit = (int)nsplit;
     g->cps = cps;
-    if (t2) {
+    return FSNAP_OK;
+}
+
+// the same for the resident rows, cached per shape
+int plan_tiled(fsnap_ctx* ctx, TiledGeometry* g) {
+    const int64_t m = ctx->m, K = ctx->K;
+    if (ctx->tplan_valid && ctx->tplan_key[0] == m && ctx->tplan_key[1] == K && ctx->tplan_key[2] == ctx->lda &&
+        ctx->tplan_key[3] == ctx->opt_nsplit && ctx->tplan_key[4] == ctx->opt_xcd + 4 * ctx->opt_tiled2) {
+        g->NSB = ctx->tplan[0];
+        g->npairs = ctx->tplan[1];
+        g->nsplit = ctx->tplan[2];
+        g->cps = ctx->tplan_cps;
+        g->items_per_split = ctx->tplan_items;
+        return FSNAP_OK;
+    }
+    std::vector<int> table;
+    int rc;
+    if ((rc = tiled_geometry(ctx, m, K, ctx->lda, true, g, &table))) return rc;
+    if (g->items_per_split > 0) {
         if (!ctx->titems.ensure(table.size() * sizeof(int))) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(work items) failed");
         FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");      // a launch may still read the old table
         FSNAP_HIP(hipMemcpy(ctx->titems.p, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy(work items)");
@@ -774,30 +786,36 @@ int fsnap_rows_alloc(fsnap_ctx* ctx, int64_t m, int64_t K) {
     return FSNAP_OK;
 }
 
-int fsnap_assemble(fsnap_ctx* ctx, const double* raw, int64_t raw_rows, int64_t raw_ld, int64_t nrows, int64_t row0,
-                   const int64_t* src_row, const int32_t* kind, const int32_t* frac, const double* d,
-                   const double* truth, const double* weight, const double* fractions, int64_t nfrac,
-                   const double* blank2J, int32_t ntypes, int32_t ncoeff, int32_t offcol) {
-    if (!ctx) return FSNAP_E_ARG;
-    int rc;
-    if ((rc = check_rows(ctx))) return rc;
-    if (ctx->dA != (const double*)ctx->ownA.p || ctx->dw != (const double*)ctx->ownw.p)
-        return ctx->fail(FSNAP_E_STATE, "fsnap_assemble needs rows allocated by fsnap_rows_alloc");
+namespace {
+
+struct AssemblyPlanDev {           // device views of a staged batch (fsnap_assemble / fsnap_assemble_accumulate)
+    const double* raw;
+    const int64_t* src_row;
+    const int *kind, *frac;
+    const double *d, *truth, *weight, *fractions, *blank2J;
+};
+
+// argument checks and H2D staging shared by the two assembly entry points; K = ntypes * (ncoeff + offcol)
+int stage_assembly(fsnap_ctx* ctx, const char* who, const double* raw, int64_t raw_rows, int64_t raw_ld, int64_t nrows,
+                   const int64_t* src_row, const int32_t* kind, const int32_t* frac, const double* d, const double* truth,
+                   const double* weight, const double* fractions, int64_t nfrac, const double* blank2J, int32_t ntypes,
+                   int32_t ncoeff, int32_t offcol, AssemblyPlanDev* out) {
     if (!raw || !src_row || !kind || !frac || !d || !truth || !weight || !blank2J || raw_rows <= 0 || nrows <= 0 ||
-        row0 < 0 || row0 + nrows > ctx->m || ntypes <= 0 || ncoeff <= 0 || (offcol != 0 && offcol != 1) ||
-        raw_ld < (int64_t)ntypes * ncoeff + 1 || (int64_t)ntypes * (ncoeff + offcol) != ctx->K || (nfrac > 0 && !fractions))
-        return ctx->fail(FSNAP_E_ARG, "fsnap_assemble: bad argument");
+        ntypes <= 0 || ncoeff <= 0 || (offcol != 0 && offcol != 1) || raw_ld < (int64_t)ntypes * ncoeff + 1 ||
+        (nfrac > 0 && !fractions) || raw_rows > 0x7FFFFFFF)
+        return ctx->fail(FSNAP_E_ARG, "%s: bad argument", who);
     for (int64_t r = 0; r < nrows; ++r)
         if (src_row[r] < 0 || src_row[r] >= raw_rows || kind[r] < 0 || kind[r] > 3 || frac[r] >= nfrac)
-            return ctx->fail(FSNAP_E_ARG, "fsnap_assemble: plan entry %lld out of range", (long long)r);
+            return ctx->fail(FSNAP_E_ARG, "%s: plan entry %lld out of range", who, (long long)r);
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    const int64_t K = (int64_t)ntypes * (ncoeff + offcol);
     const size_t rawb = (size_t)raw_rows * raw_ld * 8;
     // plan layout on the device: src_row (8n) | d (8n) | truth (8n) | weight (8n) | kind (4n) | frac (4n)
     const size_t n = (size_t)nrows;
     const size_t planb = n * 40;
     const size_t fracb = (size_t)(nfrac > 0 ? nfrac : 1) * ntypes * 8;
     if (!ctx->st_raw.ensure(rawb) || !ctx->st_plan.ensure(planb) || !ctx->st_frac.ensure(fracb) ||
-        !ctx->st_blank.ensure((size_t)ctx->K * 8))
+        !ctx->st_blank.ensure((size_t)K * 8))
         return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(assembly staging) failed");
     char* pl = (char*)ctx->st_plan.p;
     hipStream_t st = ctx->stream;
@@ -811,15 +829,102 @@ int fsnap_assemble(fsnap_ctx* ctx, const double* raw, int64_t raw_rows, int64_t 
     if (nfrac > 0)
         FSNAP_HIP(hipMemcpyAsync(ctx->st_frac.p, fractions, (size_t)nfrac * ntypes * 8, hipMemcpyHostToDevice, st),
                   "hipMemcpy(fractions)");
-    FSNAP_HIP(hipMemcpyAsync(ctx->st_blank.p, blank2J, (size_t)ctx->K * 8, hipMemcpyHostToDevice, st), "hipMemcpy(blank2J)");
+    FSNAP_HIP(hipMemcpyAsync(ctx->st_blank.p, blank2J, (size_t)K * 8, hipMemcpyHostToDevice, st), "hipMemcpy(blank2J)");
+    out->raw = (const double*)ctx->st_raw.p;
+    out->src_row = (const int64_t*)pl;
+    out->d = (const double*)(pl + n * 8);
+    out->truth = (const double*)(pl + n * 16);
+    out->weight = (const double*)(pl + n * 24);
+    out->kind = (const int*)(pl + n * 32);
+    out->frac = (const int*)(pl + n * 36);
+    out->fractions = (const double*)ctx->st_frac.p;
+    out->blank2J = (const double*)ctx->st_blank.p;
+    return FSNAP_OK;
+}
+
+}  // namespace
+
+int fsnap_assemble(fsnap_ctx* ctx, const double* raw, int64_t raw_rows, int64_t raw_ld, int64_t nrows, int64_t row0,
+                   const int64_t* src_row, const int32_t* kind, const int32_t* frac, const double* d,
+                   const double* truth, const double* weight, const double* fractions, int64_t nfrac,
+                   const double* blank2J, int32_t ntypes, int32_t ncoeff, int32_t offcol) {
+    if (!ctx) return FSNAP_E_ARG;
+    int rc;
+    if ((rc = check_rows(ctx))) return rc;
+    if (ctx->dA != (const double*)ctx->ownA.p || ctx->dw != (const double*)ctx->ownw.p)
+        return ctx->fail(FSNAP_E_STATE, "fsnap_assemble needs rows allocated by fsnap_rows_alloc");
+    if (nrows <= 0 || row0 < 0 || row0 + nrows > ctx->m || ntypes <= 0 || ncoeff <= 0 || (offcol != 0 && offcol != 1) ||
+        (int64_t)ntypes * (ncoeff + offcol) != ctx->K)
+        return ctx->fail(FSNAP_E_ARG, "fsnap_assemble: bad argument");
+    AssemblyPlanDev pd;
+    if ((rc = stage_assembly(ctx, "fsnap_assemble", raw, raw_rows, raw_ld, nrows, src_row, kind, frac, d, truth, weight,
+                             fractions, nfrac, blank2J, ntypes, ncoeff, offcol, &pd)))
+        return rc;
+    hipStream_t st = ctx->stream;
     ctx->wpack_valid = false;      // the kernel below writes b and w of these rows
-    FSNAP_HIP(fsnap::launch_assemble((const double*)ctx->st_raw.p, raw_ld, nrows, (const int64_t*)pl,
-                                     (const int*)(pl + n * 32), (const int*)(pl + n * 36), (const double*)(pl + n * 8),
-                                     (const double*)(pl + n * 16), (const double*)(pl + n * 24),
-                                     (const double*)ctx->st_frac.p, (const double*)ctx->st_blank.p, ntypes, ncoeff,
-                                     offcol, (double*)ctx->ownA.p + row0 * ctx->lda, ctx->lda,
-                                     (double*)ctx->ownb.p + row0, (double*)ctx->ownw.p + row0, st),
+    FSNAP_HIP(fsnap::launch_assemble(pd.raw, raw_ld, nrows, pd.src_row, pd.kind, pd.frac, pd.d, pd.truth, pd.weight,
+                                     pd.fractions, pd.blank2J, ntypes, ncoeff, offcol,
+                                     (double*)ctx->ownA.p + row0 * ctx->lda, ctx->lda, (double*)ctx->ownb.p + row0,
+                                     (double*)ctx->ownw.p + row0, st),
               "launch fsnap_assemble_k");
+    FSNAP_HIP(hipStreamSynchronize(st), "hipStreamSynchronize");   // host staging may be reused by the caller
+    return FSNAP_OK;
+}
+
+int fsnap_assemble_accumulate(fsnap_ctx* ctx, const double* raw, int64_t raw_rows, int64_t raw_ld, int64_t nrows,
+                              const int64_t* src_row, const int32_t* kind, const int32_t* frac, const double* d,
+                              const double* truth, const double* weight, const double* fractions, int64_t nfrac,
+                              const double* blank2J, int32_t ntypes, int32_t ncoeff, int32_t offcol, double* d_packed) {
+    if (!ctx) return FSNAP_E_ARG;
+    if (!d_packed) return ctx->fail(FSNAP_E_ARG, "fsnap_assemble_accumulate: d_packed is NULL");
+    int rc;
+    AssemblyPlanDev pd;
+    if ((rc = stage_assembly(ctx, "fsnap_assemble_accumulate", raw, raw_rows, raw_ld, nrows, src_row, kind, frac, d, truth,
+                             weight, fractions, nfrac, blank2J, ntypes, ncoeff, offcol, &pd)))
+        return rc;
+    const int64_t K = (int64_t)ntypes * (ncoeff + offcol);
+    // geometry of the tiled kernel for a batch of this shape as fsnap_rows_alloc would hold it (lda = K): the fused
+    // launch sums in the order of fsnap_assemble + fsnap_normal_eq_accumulate on the tiled kernel
+    TiledGeometry g;
+    std::vector<int> unused;
+    if ((rc = tiled_geometry(ctx, nrows, K, K, false, &g, &unused))) return rc;
+    const int npk = fsnap::pack_weights_num_blocks(nrows);
+    const size_t recb = fsnap::assemble_row_record_bytes();
+    // per-row scratch: b | w | (w_eff, w_eff b) pairs | row records -- 48 bytes per row, nothing of A
+    if (!ctx->fz_rows.ensure((size_t)nrows * (16 + recb + 16) + 64) || !ctx->fz_spart.ensure((size_t)npk * 4 * 8) ||
+        !ctx->fz_part.ensure((size_t)g.nsplit * g.npairs * 4096 * sizeof(double)) ||
+        !ctx->fz_cpart.ensure((size_t)g.nsplit * g.NSB * 4 * 64 * sizeof(double)))
+        return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(fused assembly scratch) failed");
+    hipStream_t st = ctx->stream;
+    double* db = (double*)ctx->fz_rows.p;
+    double* dw = db + nrows;
+    double* wpack = dw + nrows;
+    char* recs = (char*)(wpack + 2 * nrows);
+    FSNAP_HIP(fsnap::launch_assemble_bw(pd.raw, raw_ld, nrows, pd.src_row, pd.kind, pd.frac, pd.d, pd.truth, pd.weight,
+                                        ntypes * ncoeff, db, dw, recs, st),
+              "launch fsnap_assemble_bw_k");
+    FSNAP_HIP(fsnap::launch_pack_weights(db, dw, nullptr, nrows, wpack, (double*)ctx->fz_spart.p, st),
+              "launch fsnap_pack_weights_k");
+    fsnap::TiledArgs a;
+    a.A = nullptr;
+    a.lda = K;
+    a.wpack = wpack;
+    a.m = nrows;
+    a.K = (int)K;
+    a.NSB = g.NSB;
+    a.npairs = g.npairs;
+    a.nsplit = g.nsplit;
+    a.chunks_per_split = g.cps;
+    a.nontemporal = false;
+    a.xcd_map = ctx->opt_xcd != 0;
+    a.part = (double*)ctx->fz_part.p;
+    a.cpart = (double*)ctx->fz_cpart.p;
+    a.spart = (const double*)ctx->fz_spart.p;
+    a.ns = npk;
+    // c slots of waves that own no rows are written (zeros) by the kernel, like kernel 1T's: no memset
+    FSNAP_HIP(fsnap::launch_assemble_syrk(pd.raw, raw_ld, recs, pd.d, pd.fractions, pd.blank2J, ntypes, ncoeff, offcol, a, st),
+              "launch fsnap_assemble_syrk_k");
+    FSNAP_HIP(fsnap::launch_reduce_tiled(a, d_packed, true, st), "launch fsnap_reduce_tiled");
     FSNAP_HIP(hipStreamSynchronize(st), "hipStreamSynchronize");   // host staging may be reused by the caller
     return FSNAP_OK;
 }

@@ -79,6 +79,7 @@ struct fsnap_ctx {
     // workspaces
     DevBuf part, cpart, spart, packed, beta, preds, sse, aw, bw;
     DevBuf st_raw, st_plan, st_frac, st_blank;   // staging of fsnap_assemble
+    DevBuf fz_rows, fz_spart, fz_part, fz_cpart; // fsnap_assemble_accumulate: per-row scratch (no A) and partials
     DevBuf dsolve;                                // [beta | min pivot | status] of fsnap_solve_device
     DevBuf dchol;                                 // padded work matrix of the blocked device Cholesky
     DevBuf dcat, dstat;                           // fsnap_error_stats: row categories, partial tables + means

@@ -73,6 +73,13 @@ hipError_t launch_assemble(const double* raw, int64_t raw_ld, int64_t nrows, con
                            const int* frac, const double* dval, const double* truth, const double* weight,
                            const double* fractions, const double* blank2J, int ntypes, int ncoeff, int off, double* A,
                            int64_t lda, double* b, double* w, hipStream_t st);
+// fused assembly + accumulation (fsnap_fused.hip): b, w, 16-byte row records; then kernel 1T's partials from the raw batch
+size_t assemble_row_record_bytes();
+hipError_t launch_assemble_bw(const double* raw, int64_t raw_ld, int64_t nrows, const int64_t* src_row, const int* kind,
+                              const int* frac, const double* d, const double* truth, const double* weight, int icolref,
+                              double* b, double* w, void* recs, hipStream_t st);
+hipError_t launch_assemble_syrk(const double* raw, int64_t raw_ld, const void* recs, const double* dval, const double* fractions,
+                                const double* blank2J, int ntypes, int ncoeff, int off, const TiledArgs& a, hipStream_t st);
 hipError_t launch_mirror_copy(const double* src, int K, double* mirror, hipStream_t st);
 hipError_t launch_chol_solve(const double* packed, int K, double alpha, double* out, hipStream_t st);
 // blocked Cholesky solve for large K: work (chol_large_work_doubles(K) doubles), dsc, z (np = K rounded up to 64),

@@ -180,6 +180,21 @@ int fsnap_normal_eq_async(fsnap_ctx* ctx, double* d_packed);
  * and dropped, so A never has to be resident as a whole.  Asynchronous. */
 int fsnap_normal_eq_accumulate(fsnap_ctx* ctx, double* d_packed);
 
+/* The same loop with the assembly fused in -- `a, b, w = process_single(configuration)`, `c += aw.T @ aw`,
+ * `d += aw.T @ bw` of examples/library/transpose_trick/example.py:230-237 in ONE pass: the rows of the batch are formed
+ * in registers from the raw LAMMPS arrays (the transform of fsnap_assemble: lammps_snap.py:391-556, lammps_pace.py:
+ * 369-509), weighted and fed to the matrix pipe; A is never written to (or read from) device memory, the context needs
+ * no resident rows and the ones it holds are left alone.  Arguments as fsnap_assemble (no row0: nothing is stored);
+ * every row of the batch is a training row with weight[r] (rows of kind 3 carry weight 0, as there).
+ * d_packed (device, FSNAP_PACKED_LEN(K) doubles, K = ntypes * (ncoeff + offcol), zeroed by the caller before the
+ * first batch) += [G | c | b.W^2.b, sum(w b), rows].  Bit-identical to fsnap_assemble into resident rows followed by
+ * fsnap_normal_eq_accumulate with the tiled kernel (option "tiled" = 1; the default for K > 128).  Synchronous (the
+ * host arrays may be reused on return). */
+int fsnap_assemble_accumulate(fsnap_ctx* ctx, const double* raw, int64_t raw_rows, int64_t raw_ld, int64_t nrows,
+                              const int64_t* src_row, const int32_t* kind, const int32_t* frac, const double* d,
+                              const double* truth, const double* weight, const double* fractions, int64_t nfrac,
+                              const double* blank2J, int32_t ntypes, int32_t ncoeff, int32_t offcol, double* d_packed);
+
 /* Same as fsnap_normal_eq_async into a context-owned device buffer whose address is
  * returned in *d_packed (valid until the next call on this context); asynchronous.
  * For K <= 128 the reduction kernel also writes the statistics into a page-locked host mirror

@@ -215,3 +215,140 @@ def test_pace_assembled_rows_match_reference_bitwise(name, capsys):
     if name.endswith("_nan"):
         assert "applying np.nan_to_num()" in capsys.readouterr().out        # lammps_pace.py:399-403
     pt.free()
+
+
+# ---- f3 in its literal form: assembly fused into the accumulation (fsnap_assemble_accumulate) ------------------------
+
+def _two_step_accumulate(ctx2, plan_args, total_ptr):
+    """fsnap_rows_alloc + fsnap_assemble + fsnap_normal_eq_accumulate: the rows go through HBM."""
+    raw, src_row, kind, frac, d, truth, weight, fractions, blank2J, ntypes, ncoeff, offcol = plan_args
+    ctx2.rows_alloc(len(src_row), ntypes * (ncoeff + offcol))
+    ctx2.assemble(raw, 0, src_row, kind, frac, d, truth, weight, fractions, blank2J, ntypes, ncoeff, offcol)
+    ctx2.normal_eq_accumulate(total_ptr)
+
+
+def _synthetic_batch(rng, nconf, natoms, ntypes, ncoeff, offcol, bik=False):
+    """Raw `compute snap` blocks + row plans of `nconf` configurations in the shapes LAMMPS hands over
+    (bik rows | 3 N force rows | 6 virial rows; last column = reference potential)."""
+    from fitsnap_amd.calculators.row_plan import config_row_plan
+    raws, plans, fracs = [], [], []
+    row0 = 0
+    for ic in range(nconf):
+        n = int(natoms[ic % len(natoms)])
+        nraw = (n if bik else 1) + 3 * n + 6
+        raw = rng.standard_normal((nraw, ntypes * ncoeff + 1)) * rng.uniform(0.1, 30.0)
+        types = rng.integers(1, ntypes + 1, n).astype(np.int32)
+        plan, _ = config_row_plan(n, types, rng.uniform(50.0, 500.0), rng.standard_normal() * n,
+                                  rng.standard_normal((n, 3)), rng.standard_normal((3, 3)), rng.uniform(10.0, 200.0),
+                                  rng.uniform(0.5, 2.0), rng.uniform(1e-8, 1e-6), True, True, True, bik, row0,
+                                  ic if offcol else -1)
+        raws.append(raw)
+        plans.append(plan)
+        fr = np.bincount(types - 1, minlength=ntypes) / n
+        fracs.append(fr)
+        row0 += nraw
+    plan = {k: np.concatenate([p[k] for p in plans]) for k in plans[0]}
+    fractions = np.array(fracs) if offcol else np.zeros((0, ntypes))
+    blank2J = np.ones(ntypes * (ncoeff + offcol))
+    blank2J[rng.random(len(blank2J)) < 0.1] = 0.0
+    return (np.concatenate(raws, axis=0), plan["src_row"], plan["kind"], plan["frac"], plan["d"], plan["truth"],
+            plan["weight"], fractions, blank2J, ntypes, ncoeff, offcol)
+
+
+@pytest.mark.parametrize("shape", [
+    dict(nconf=3, natoms=[7, 12, 5], ntypes=1, ncoeff=30, offcol=1),                 # K = 31, one superblock
+    dict(nconf=40, natoms=[54, 31, 64], ntypes=2, ncoeff=55, offcol=0),              # K = 110: two superblocks, ragged
+    dict(nconf=25, natoms=[40, 64], ntypes=1, ncoeff=128, offcol=0),                 # K = 128: two full superblocks
+    dict(nconf=30, natoms=[100, 87], ntypes=2, ncoeff=90, offcol=1, bik=True),       # K = 182 > 128: tiled is the default
+    dict(nconf=6, natoms=[16], ntypes=1, ncoeff=299, offcol=1),                      # K = 300, few rows per wave
+])
+def test_fused_assembly_accumulation_is_bitwise_the_two_step_path(shape):
+    # fsnap_assemble_accumulate vs fsnap_assemble into resident rows + fsnap_normal_eq_accumulate on the tiled kernel:
+    # identical bits in G, c and the scalars, batch after batch; and the sums are the oracle's
+    import torch
+    from fitsnap_amd import _capi
+    rng = np.random.default_rng(4100 + shape["ncoeff"])
+    K = shape["ntypes"] * (shape["ncoeff"] + shape["offcol"])
+    dev = torch.device("cuda", 0)
+    fused = torch.zeros(K * K + K + 3, dtype=torch.float64, device=dev)
+    steps = torch.zeros_like(fused)
+    c1, c2 = _capi.HipContext(0), _capi.HipContext(0)
+    c2.set_option("tiled", 1)
+    rows = []
+    for batch in range(3):
+        args = _synthetic_batch(rng, **shape)
+        c1.assemble_accumulate(*args, fused.data_ptr())
+        _two_step_accumulate(c2, args, steps.data_ptr())
+        rows.append(c2.download_rows())
+        torch.cuda.synchronize()
+        assert np.array_equal(fused.cpu().numpy(), steps.cpu().numpy()), f"batch {batch}"
+    A = np.concatenate([r[0] for r in rows])
+    b = np.concatenate([r[1] for r in rows])
+    w = np.concatenate([r[2] for r in rows])
+    G, c, s = c1.download_packed(fused.data_ptr(), K)
+    Go, co, so = orc.normal_eq(A, b, w)
+    scale = np.sqrt(np.outer(np.diag(Go), np.diag(Go))) + 1e-300
+    assert np.max(np.abs(G - Go) / scale) < 1e-12
+    assert np.max(np.abs(c - co)) <= 1e-12 * np.sqrt(np.max(np.diag(Go)) * so[0])
+    assert np.allclose(s, so, rtol=1e-12, atol=0.0)
+    c1.close()
+    c2.close()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_accumulate_single_matches_process_single_statistics_bitwise(name):
+    # plugin level: calc.accumulate_single(data, i, ptr) == process_single + `c += aw.T @ aw; d += aw.T @ bw`
+    # (transpose_trick/example.py:230-237) on the reference's own golden configurations
+    import torch
+    from fitsnap_amd import _capi
+    g = CASES[name]
+    pt, cfg, calc = build(g)
+    data = data_dicts(g)
+    K = calc.get_width()
+    dev = torch.device("cuda", 0)
+    fused = torch.zeros(K * K + K + 3, dtype=torch.float64, device=dev)
+    steps = torch.zeros_like(fused)
+    c2 = _capi.HipContext(0)
+    c2.set_option("tiled", 1)
+    nrows = 0
+    Gn, cn = np.zeros((K, K)), np.zeros(K)
+    for i, c in enumerate(g["configs"]):
+        serve(c)
+        nrows += calc.accumulate_single(data[i], i, fused.data_ptr())
+        serve(c)
+        a, b, w = calc.process_single(data[i], i)
+        c2.upload_rows(a, b)
+        c2.set_weights(w)
+        c2.normal_eq_accumulate(steps.data_ptr())
+        aw, bw = w[:, None] * a, w * b
+        Gn += aw.T @ aw
+        cn += aw.T @ bw
+    torch.cuda.synchronize()
+    assert nrows == len(g["b"])
+    assert np.array_equal(fused.cpu().numpy(), steps.cpu().numpy())
+    G, cc, s = pt.hip().download_packed(fused.data_ptr(), K)
+    scale = np.sqrt(np.outer(np.diag(Gn), np.diag(Gn))) + 1e-300
+    assert np.max(np.abs(G - Gn) / scale) < 1e-12
+    assert np.max(np.abs(cc - cn)) <= 1e-12 * max(np.max(np.abs(cn)), 1e-300) + 1e-12 * np.sqrt(np.max(np.diag(Gn)) * s[0])
+    assert s[2] == nrows                                  # every row of the loop is a training row
+    c2.close()
+    pt.free()
+
+
+def test_assemble_accumulate_rejects_bad_plans():
+    import torch
+    from fitsnap_amd import _capi
+    rng = np.random.default_rng(5)
+    args = list(_synthetic_batch(rng, nconf=1, natoms=[4], ntypes=1, ncoeff=5, offcol=0))
+    K = 5
+    total = torch.zeros(K * K + K + 3, dtype=torch.float64, device=torch.device("cuda", 0))
+    ctx = _capi.HipContext(0)
+    bad = list(args)
+    bad[1] = args[1].copy()
+    bad[1][0] = len(args[0])                     # source row past the raw block
+    with pytest.raises(ValueError, match="plan entry 0 out of range"):
+        ctx.assemble_accumulate(*bad, total.data_ptr())
+    with pytest.raises(ValueError, match="d_packed is NULL"):
+        ctx.assemble_accumulate(*args, 0)         # no destination
+    assert not total.cpu().numpy().any()
+    ctx.close()
