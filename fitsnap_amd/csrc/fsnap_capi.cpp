@@ -461,6 +461,14 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
         spart_src = (const double*)ctx->wpack_spart.p;
         ns = npk;
     }
+    if (g.packed && ctx->opt_interleave) {
+        // kernel 1P, interleaved chunks: one advancing front of addresses over the whole matrix -- every row-wave's
+        // descriptor then spans the matrix, so its last chunk slot (+ the overshoot of the unrolled loop: 8 more
+        // rounds of the grid) must stay within a 32-bit buffer offset
+        const int64_t nchunks = (ctx->m + 3) / 4;
+        const int64_t reach = (nchunks + 9 * (int64_t)g.nblocks * 4) * ctx->lda * 32;
+        a.interleave = reach < (int64_t)0xFFF00000;
+    }
     hipEvent_t* evs;
     if ((rc = fit_events(ctx, &evs))) return rc;
     if (evs) FSNAP_HIP(hipEventRecord(evs[0], ctx->stream), "hipEventRecord");
@@ -672,6 +680,11 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
         ctx->timing_phase = 0;
     } else if (!strcmp(key, "repack")) {
         ctx->opt_repack = value != 0;
+    } else if (!strcmp(key, "interleave")) {
+        ctx->opt_interleave = value != 0;
+    } else if (!strcmp(key, "comm_timeout")) {
+        if (value < 0 || value > 86400) return ctx->fail(FSNAP_E_ARG, "comm_timeout must be 0 (FSNAP_COMM_TIMEOUT) ... 86400 seconds");
+        ctx->opt_comm_timeout = (int)value;
     } else if (!strcmp(key, "dist_solve")) {
         if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "dist_solve must be 0 (solve on every rank) or 1 (rank 0 solves and broadcasts)");
         ctx->opt_dist_solve = (int)value;

@@ -94,6 +94,8 @@ double comm_timeout_s() {
     return t;
 }
 
+double comm_timeout_s(const fsnap_ctx* ctx) { return ctx && ctx->opt_comm_timeout > 0 ? (double)ctx->opt_comm_timeout : comm_timeout_s(); }
+
 int wait_stream(fsnap_ctx* ctx, hipEvent_t ev, const char* what) {
     const bool bounded = ctx->comm != nullptr;
     if (!bounded && !ev) {
@@ -110,14 +112,14 @@ int wait_stream(fsnap_ctx* ctx, hipEvent_t ev, const char* what) {
         if (bounded && (spins & 1023u) == 1023u) {
             const auto now = std::chrono::steady_clock::now();
             if (!armed) {
-                deadline = now + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(comm_timeout_s()));
+                deadline = now + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(comm_timeout_s(ctx)));
                 armed = true;
             } else if (now > deadline) {
                 ctx->comm_broken = true;
                 return ctx->fail(FSNAP_E_HIP,
-                                 "rank %d of %d: %s did not finish within %.0f s (FSNAP_COMM_TIMEOUT) behind a collective: a peer "
-                                 "rank died or never reached it",
-                                 ctx->comm->rank, ctx->comm->nranks, what, comm_timeout_s());
+                                 "rank %d of %d: %s did not finish within %.0f s (FSNAP_COMM_TIMEOUT / option comm_timeout) behind a "
+                                 "collective: a peer rank died or never reached it",
+                                 ctx->comm->rank, ctx->comm->nranks, what, comm_timeout_s(ctx));
             }
         }
     }
@@ -197,12 +199,12 @@ int fsnap_comm_init(fsnap_ctx* ctx, int nranks, int rank, const char* id) {
         sh->nccl = comm;
         sh->done.set_value(e);
     }).detach();
-    if (fut.wait_for(std::chrono::duration<double>(fsnap::comm_timeout_s())) != std::future_status::ready) {
+    if (fut.wait_for(std::chrono::duration<double>(fsnap::comm_timeout_s(ctx))) != std::future_status::ready) {
         delete c;
         return ctx->fail(FSNAP_E_HIP,
                          "ncclCommInitRank: rank %d of %d did not complete within %.0f s (FSNAP_COMM_TIMEOUT): a rank is missing "
                          "or holds a different communicator id",
-                         rank, nranks, fsnap::comm_timeout_s());
+                         rank, nranks, fsnap::comm_timeout_s(ctx));
     }
     const ncclResult_t e = fut.get();
     c->nccl = sh->nccl;

@@ -100,6 +100,7 @@ struct fsnap_ctx {
     // options
     int opt_split = 0;        // 0 = auto
     int opt_nt = 1;
+    bool opt_interleave = false;  // kernel 1P: row-waves take every NW-th chunk (one address front) instead of contiguous ranges (A/B: no difference measured)
     int opt_nblocks = 0;      // 0 = auto
     int opt_tiled = 0;        // force the general-K tiled kernel also for K <= 128
     int opt_kernel = 0;       // 0 auto | 1 wave-triangle (kernel 1) | 2 LDS-shared, static per-wave bodies | 3 LDS-shared, generic
@@ -136,6 +137,7 @@ struct fsnap_ctx {
     int64_t dense_pinv_token = 0;
     DevBuf commbuf;                               // device staging of host-buffer collectives
     int opt_repack = 0;       // 1 = pack (w_eff, w_eff b) on every launch even when b / w / mask are context-owned
+    int opt_comm_timeout = 0; // seconds; 0 = FSNAP_COMM_TIMEOUT (default 300): bound of every wait behind a collective of THIS context
     int opt_dist_solve = 0;   // fsnap_fit_dist: 0 = all-reduce + solve on every rank, 1 = reduce to rank 0 + solve there + broadcast beta
     bool comm_broken = false; // a bounded wait behind a collective ran out: the stream may hold a stuck RCCL kernel
 
@@ -163,7 +165,8 @@ struct fsnap_ctx {
 
 namespace fsnap {
 // fsnap_comm.cpp: seconds a wait behind a collective may take (FSNAP_COMM_TIMEOUT, default 300)
-double comm_timeout_s();
+double comm_timeout_s();                      // FSNAP_COMM_TIMEOUT (seconds, default 300)
+double comm_timeout_s(const fsnap_ctx* ctx);  // the context's option comm_timeout, else the above
 // fsnap_comm.cpp: wait for the context's stream (ev == nullptr) or for an event on it.  Without a communicator this is
 // a plain busy poll / hipStreamSynchronize; with one the wait is bounded by FSNAP_COMM_TIMEOUT -- a peer that died
 // before its collective leaves this rank's stream stuck in an RCCL kernel -- and runs out with FSNAP_E_HIP + one line

@@ -24,6 +24,7 @@ struct SyrkArgs {
     double* cpart;              // [nblocks*4][NB][16]
     double* spart;              // [nblocks*4][4]
     const double* wpack = nullptr;  // kernel 1A: packed (w_eff, w_eff * b) per row (launch_pack_weights)
+    bool interleave = false;        // kernel 1P: row-waves take every NW-th chunk instead of a contiguous range
 };
 
 struct TiledArgs {

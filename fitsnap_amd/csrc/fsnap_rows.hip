@@ -18,55 +18,60 @@
 // One wave per 4-row group (grid-stride only beyond 2^34 rows), 16-byte vector accesses.  HBM-bound:
 // 16K + 24 bytes per row.
 // ---------------------------------------------------------------------------------
+template <int lanes_log2>
 __global__ __launch_bounds__(256) void fsnap_weight_rows_k(const double* __restrict__ A, int64_t lda,
                                                            const double* __restrict__ b,
                                                            const double* __restrict__ w,
                                                            const unsigned char* __restrict__ mask, int64_t m,
-                                                           int K, double* __restrict__ aw, int64_t ldaw,
-                                                           double* __restrict__ bw) {
-    // One wave handles 4 consecutive rows per iteration (4 independent 16-byte loads per lane in
-    // flight before the first store: memory-level parallelism for the HBM stream).
+                                                           int K, double* __restrict__ aw,
+                                                           int64_t ldaw, double* __restrict__ bw) {
+    // L = 2^lanes_log2 lanes share a row (two adjacent columns per lane and pass over the row: L = 64 from K = 65 on,
+    // 16 at the Ta width K = 31 -- with 64 lanes on a 31-column row three quarters of every access are idle lanes
+    // and the kernel streamed 2.5 TB/s), a wave covers 64 / L rows per pass and four passes per iteration: four
+    // independent 16-byte loads per lane in flight before the first store.
+    // 16-byte accesses for every K and leading dimension: the vector types are 8-byte aligned (rows of an odd width
+    // start on odd multiples of 8 bytes), the upper half of a row's last pair is the neighbour's first element when K
+    // is odd -- read (the allocation is readable 16 bytes past its end) but neither used nor overwritten.
     const int lane = threadIdx.x & 63;
+    constexpr int L = 1 << lanes_log2, G = 64 >> lanes_log2;
+    const int sub = lane >> lanes_log2, cl = lane & (L - 1);      // L = 64: sub == 0, every row test below is wave-uniform
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwave = (int64_t)gridDim.x * 4;
-    const bool vec2 = ((K & 1) == 0) && ((lda & 1) == 0) && ((ldaw & 1) == 0);
-    for (int64_t row0 = wave * 4; row0 < m; row0 += nwave * 4) {
+    constexpr int64_t per_iter = 4 * (int64_t)G;
+    for (int64_t row0 = wave * per_iter; row0 < m; row0 += nwave * per_iter) {
         double wv[4];
-        bool keep[4];
+        bool keep[4], in[4];
+        int64_t rows[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int64_t row = row0 + r;
-            const bool in = row < m;
-            keep[r] = in && (mask[in ? row : 0] != 0);
-            wv[r] = in ? w[row] : 0.0;
+            rows[r] = row0 + (int64_t)r * G + sub;
+            in[r] = rows[r] < m;
+            keep[r] = in[r] && (mask[in[r] ? rows[r] : 0] != 0);
+            wv[r] = in[r] ? w[rows[r]] : 0.0;
         }
-        if (vec2) {
-            for (int c = 2 * lane; c < K; c += 128) {
-                d2u x[4];
+        for (int c = 2 * cl; c < K; c += 2 * L) {
+            // the four loads go out unconditionally (rows past the end re-read the last row): a lane-dependent branch
+            // around a load puts it into a basic block of its own, and the loads of an iteration leave one by one
+            d2u x[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (row0 + r < m) x[r] = __builtin_nontemporal_load(reinterpret_cast<const d2u*>(A + (row0 + r) * lda + c));
+            for (int r = 0; r < 4; ++r)
+                x[r] = __builtin_nontemporal_load(reinterpret_cast<const d2u*>(A + (in[r] ? rows[r] : m - 1) * lda + c));
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (row0 + r < m) {
-                        d2u y;
-                        y[0] = keep[r] ? wv[r] * x[r][0] : 0.0;
-                        y[1] = keep[r] ? wv[r] * x[r][1] : 0.0;
-                        __builtin_nontemporal_store(y, reinterpret_cast<d2u*>(aw + (row0 + r) * ldaw + c));
-                    }
+            for (int r = 0; r < 4; ++r) {
+                if (in[r]) {
+                    d2u y;
+                    y[0] = keep[r] ? wv[r] * x[r][0] : 0.0;
+                    y[1] = keep[r] ? wv[r] * x[r][1] : 0.0;
+                    double* dst = aw + rows[r] * ldaw + c;
+                    if (c + 1 < K) __builtin_nontemporal_store(y, reinterpret_cast<d2u*>(dst));
+                    else __builtin_nontemporal_store(y[0], dst);
                 }
             }
-        } else {
-            for (int c = lane; c < K; c += 64) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (row0 + r < m) aw[(row0 + r) * ldaw + c] = keep[r] ? wv[r] * A[(row0 + r) * lda + c] : 0.0;
-            }
         }
-        if (lane < 4 && row0 + lane < m) {
-            const int64_t row = row0 + lane;
-            const bool kp = mask[row] != 0;
-            bw[row] = kp ? w[row] * b[row] : 0.0;
+        if (cl == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (in[r]) bw[rows[r]] = keep[r] ? wv[r] * b[rows[r]] : 0.0;
         }
     }
 }
@@ -96,36 +101,48 @@ __global__ __launch_bounds__(256) void fsnap_gemv_rows_k(const double* __restric
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwave = (int64_t)gridDim.x * 4;
     double sse = 0.0;
-    for (int64_t r0 = wave * 4; r0 < m; r0 += nwave * 4) {
-        const int64_t row = r0 + kr;
-        double s = 0.0;
-        if (row < m) {
-            const double* src = A + row * lda;
-            if (((K | lda) & 1) == 0) {   // 16-byte loads: two adjacent columns per lane, two accumulators
-                double s1 = 0.0;
-                for (int c = 2 * e; c < K; c += 32) {
-                    const d2u x = __builtin_nontemporal_load(reinterpret_cast<const d2u*>(src + c));
-                    s = __builtin_fma(x[0], sbeta[c], s);
-                    s1 = __builtin_fma(x[1], sbeta[c + 1], s1);
-                }
-                s += s1;
-            } else {
-                for (int c = e; c < K; c += 16) s = __builtin_fma(src[c], sbeta[c], s);
+    // two 4-row groups per iteration (rows r0 + kr and r0 + 4 + kr): on narrow rows one group is a single load per lane
+    // followed by the dependent lane reduction -- K = 31 ran at 4.1 TB/s with one
+    for (int64_t r0 = wave * 8; r0 < m; r0 += nwave * 8) {
+        const int64_t rowA = r0 + kr, rowB = r0 + 4 + kr;
+        const bool inA = rowA < m, inB = rowB < m;
+        double sA = 0.0, sB = 0.0, tA = 0.0, tB = 0.0;
+        {
+            // 16-byte loads (8-byte aligned vector type: any K, any lda): two adjacent columns per lane, two
+            // accumulators; the upper half of an odd row's last pair belongs to the next row and is selected away
+            const double* srcA = A + (inA ? rowA : 0) * lda;
+            const double* srcB = A + (inB ? rowB : 0) * lda;
+            for (int c = 2 * e; c < K; c += 32) {
+                const d2u x = __builtin_nontemporal_load(reinterpret_cast<const d2u*>(srcA + c));
+                const d2u y = __builtin_nontemporal_load(reinterpret_cast<const d2u*>(srcB + c));
+                const bool two = c + 1 < K;
+                const double be0 = sbeta[c], be1 = two ? sbeta[c + 1] : 0.0;
+                sA = __builtin_fma(x[0], be0, sA);
+                tA = __builtin_fma(two ? x[1] : 0.0, be1, tA);
+                sB = __builtin_fma(y[0], be0, sB);
+                tB = __builtin_fma(two ? y[1] : 0.0, be1, tB);
             }
+            sA += tA;
+            sB += tB;
         }
-        // reduce over the 16 lanes of the row group
-        s += __shfl_xor(s, 8, 64);
-        s += __shfl_xor(s, 4, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 1, 64);
-        if (row < m && e == 0) {
-            if (preds) preds[row] = s;
-            if (sse_part || uout) {
-                const bool keep = mask ? (mask[row] != 0) : true;
-                const double wr = w[row];
-                const double rr = keep ? wr * (b[row] - s) : 0.0;
-                if (sse_part) sse = __builtin_fma(rr, rr, sse);
-                if (uout) uout[row] = keep ? (uplain ? rr : wr * rr) : 0.0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int64_t row = half ? rowB : rowA;
+            double s = half ? sB : sA;
+            // reduce over the 16 lanes of the row group
+            s += __shfl_xor(s, 8, 64);
+            s += __shfl_xor(s, 4, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 1, 64);
+            if (row < m && e == 0) {
+                if (preds) preds[row] = s;
+                if (sse_part || uout) {
+                    const bool keep = mask ? (mask[row] != 0) : true;
+                    const double wr = w[row];
+                    const double rr = keep ? wr * (b[row] - s) : 0.0;
+                    if (sse_part) sse = __builtin_fma(rr, rr, sse);
+                    if (uout) uout[row] = keep ? (uplain ? rr : wr * rr) : 0.0;
+                }
             }
         }
     }
@@ -211,54 +228,61 @@ __global__ __launch_bounds__(256) void fsnap_assemble_k(const double* __restrict
 // ("corrected semi-normal equations": G delta = (wA)^T (wb - wA beta), beta += delta), which
 // takes the error of the normal-equation solve from ~kappa^2 eps back to ~kappa eps — what
 // keeps the GPU path within 1e-6 of the reference's lstsq (svd.py:54) on ill-conditioned A.
-// Workgroup = row range; wave v takes rows v, v+4, ...; lane l owns columns 2l, 2l+1 (+128 j).
+// Workgroup = row range, cut into 4 * 64 / L interleaved row streams; a lane owns two adjacent columns per pass.
 // Per-workgroup partial vectors are written to spart2[wg][K] and summed in fixed order.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void fsnap_gemvT_rows_k(const double* __restrict__ A, int64_t lda,
                                                           const double* __restrict__ u, int64_t m, int K,
-                                                          int64_t rows_per_wg, double* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) double sacc[];   // 4 waves x Kpad
+                                                          int lanes_log2, int64_t rows_per_wg,
+                                                          double* __restrict__ partial) {
+    // L = 2^lanes_log2 lanes cover a row (two adjacent columns per lane and pass), so a wave runs 64 / L row streams
+    // side by side (L = 64: one; the Ta width K = 31: four -- with one stream three quarters of the lanes of every load
+    // were idle: 2.9 TB/s); stream i of the workgroup's 4 * 64 / L takes rows i, i + NS, ..., two rows in flight each.
+    extern __shared__ __attribute__((aligned(16))) double sacc[];   // NS streams x Kpad
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int L = 1 << lanes_log2, G = 64 >> lanes_log2, NS = 4 * G;
+    const int sub = lane >> lanes_log2, cl = lane & (L - 1);
+    const int sidx = wv * G + sub;
     const int Kpad = (K + 1) & ~1;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
     int64_t r1 = r0 + rows_per_wg;
     if (r1 > m) r1 = m;
-    const bool vec2 = ((K | lda) & 1) == 0;
-    for (int c0 = 0; c0 < K; c0 += 128) {
-        const int c = c0 + 2 * lane;
+    for (int c0 = 0; c0 < K; c0 += 2 * L) {
+        const int c = c0 + 2 * cl;
         double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
         if (c < K) {
-            int64_t row = r0 + wv;
-            for (; row + 4 < r1; row += 8) {   // two rows in flight per wave
-                const double u0 = u[row], u1 = u[row + 4];
-                double x0, x1, y0, y1;
-                if (vec2) {
-                    const d2u x = *reinterpret_cast<const d2u*>(A + row * lda + c);
-                    const d2u y = *reinterpret_cast<const d2u*>(A + (row + 4) * lda + c);
-                    x0 = x[0]; x1 = x[1]; y0 = y[0]; y1 = y[1];
-                } else {
-                    x0 = A[row * lda + c]; x1 = (c + 1 < K) ? A[row * lda + c + 1] : 0.0;
-                    y0 = A[(row + 4) * lda + c]; y1 = (c + 1 < K) ? A[(row + 4) * lda + c + 1] : 0.0;
-                }
+            // 16-byte loads for any K and lda (8-byte aligned vector type); the upper half of an odd row's last
+            // pair is the next row's first element: selected away
+            const bool two = c + 1 < K;
+            int64_t row = r0 + sidx;
+            for (; row + NS < r1; row += 2 * NS) {   // two rows in flight per stream
+                const double u0 = u[row], u1 = u[row + NS];
+                const d2u x = *reinterpret_cast<const d2u*>(A + row * lda + c);
+                const d2u y = *reinterpret_cast<const d2u*>(A + (row + NS) * lda + c);
+                const double x0 = x[0], x1 = two ? x[1] : 0.0, y0 = y[0], y1 = two ? y[1] : 0.0;
                 a0 = __builtin_fma(x0, u0, a0);
                 a1 = __builtin_fma(x1, u0, a1);
                 b0 = __builtin_fma(y0, u1, b0);
                 b1 = __builtin_fma(y1, u1, b1);
             }
-            for (; row < r1; row += 4) {
+            for (; row < r1; row += NS) {
                 const double u0 = u[row];
                 const double x0 = A[row * lda + c];
-                const double x1 = (c + 1 < K) ? A[row * lda + c + 1] : 0.0;
+                const double x1 = two ? A[row * lda + c + 1] : 0.0;
                 a0 = __builtin_fma(x0, u0, a0);
                 a1 = __builtin_fma(x1, u0, a1);
             }
-            sacc[wv * Kpad + c] = a0 + b0;
-            if (c + 1 < K) sacc[wv * Kpad + c + 1] = a1 + b1;
+            sacc[sidx * Kpad + c] = a0 + b0;
+            if (two) sacc[sidx * Kpad + c + 1] = a1 + b1;
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < K; c += 256)
-        partial[(int64_t)blockIdx.x * K + c] = (sacc[c] + sacc[Kpad + c]) + (sacc[2 * Kpad + c] + sacc[3 * Kpad + c]);
+    for (int c = threadIdx.x; c < K; c += 256) {
+        double t = 0.0;
+        for (int i = 0; i < NS; i += 4)          // fixed order: streams in fours, as the four waves used to be summed
+            t += (sacc[i * Kpad + c] + sacc[(i + 1) * Kpad + c]) + (sacc[(i + 2) * Kpad + c] + sacc[(i + 3) * Kpad + c]);
+        partial[(int64_t)blockIdx.x * K + c] = t;
+    }
 }
 
 // out[c] = sum over the per-workgroup partial vectors, fixed order.  A workgroup owns 16 columns: thread (column
@@ -416,13 +440,25 @@ namespace fsnap {
 hipError_t launch_weight_rows(const double* A, int64_t lda, const double* b, const double* w,
                               const unsigned char* mask, int64_t m, int K, double* aw, int64_t ldaw,
                               double* bw, hipStream_t st) {
-    // one 4-row group per wave, no grid-stride loop (tools/weight_rows_variants.hip, 10^6 x 128: 6.35 TB/s against
+    // one group of rows per wave, no grid-stride loop (tools/weight_rows_variants.hip, 10^6 x 128: 6.35 TB/s against
     // 5.25 TB/s for 2048 looping workgroups and 5.5-5.8 TB/s for a plain 16-byte copy of the same bytes in a loop)
-    int64_t nb = (m + 15) / 16;
+    int lanes_log2 = 6;                         // lanes per row: the power of two that covers K / 2 column pairs, <= 64
+    while (lanes_log2 > 2 && (1 << (lanes_log2 - 1)) * 2 >= K) --lanes_log2;
+    const int64_t rows_per_wg = 4 * 4 * (int64_t)(64 >> lanes_log2);
+    int64_t nb = (m + rows_per_wg - 1) / rows_per_wg;
     if (nb > (1ll << 30)) nb = 1ll << 30;   // the kernel's loop covers the rest
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(fsnap_weight_rows_k, dim3((unsigned)nb), dim3(256), 0, st, A, lda, b, w, mask, m, K, aw,
-                       ldaw, bw);
+#define FSNAP_LAUNCH(LG)                                                                                        \
+    hipLaunchKernelGGL((fsnap_weight_rows_k<LG>), dim3((unsigned)nb), dim3(256), 0, st, A, lda, b, w, mask, m, K, aw, \
+                       ldaw, bw)
+    switch (lanes_log2) {
+        case 2: FSNAP_LAUNCH(2); break;
+        case 3: FSNAP_LAUNCH(3); break;
+        case 4: FSNAP_LAUNCH(4); break;
+        case 5: FSNAP_LAUNCH(5); break;
+        default: FSNAP_LAUNCH(6); break;
+    }
+#undef FSNAP_LAUNCH
     return hipGetLastError();
 }
 
@@ -449,7 +485,9 @@ hipError_t launch_gemvT_rows(const double* A, int64_t lda, const double* u, int6
                              double* out, hipStream_t st) {
     const int nb = gemvT_num_blocks(m);
     const int64_t rpw = (m + nb - 1) / nb;
-    const size_t lds = (size_t)4 * ((K + 1) & ~1) * sizeof(double);
+    int lanes_log2 = 6;                         // lanes per row: the power of two that covers K / 2 column pairs, <= 64
+    while (lanes_log2 > 2 && (1 << (lanes_log2 - 1)) * 2 >= K) --lanes_log2;
+    const size_t lds = (size_t)4 * (64 >> lanes_log2) * ((K + 1) & ~1) * sizeof(double);
     if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
@@ -458,7 +496,7 @@ hipError_t launch_gemvT_rows(const double* A, int64_t lda, const double* u, int6
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(fsnap_gemvT_rows_k, dim3((unsigned)nb), dim3(256), lds, st, A, lda, u, m, K, rpw, partial);
+    hipLaunchKernelGGL(fsnap_gemvT_rows_k, dim3((unsigned)nb), dim3(256), lds, st, A, lda, u, m, K, lanes_log2, rpw, partial);
     hipLaunchKernelGGL(fsnap_colsum_partials_k, dim3((unsigned)((K + 15) / 16)), dim3(256), 0, st, partial, nb, K, out);
     return hipGetLastError();
 }
@@ -515,7 +553,7 @@ hipError_t launch_error_stats(const double* truth, const double* pred, const dou
 }
 
 int gemv_num_blocks(int64_t m) {
-    int64_t nb = (m + 15) / 16;
+    int64_t nb = (m + 31) / 32;
     if (nb > 256 * 8) nb = 256 * 8;   // measured at 10^6 x 128: 2048 workgroups 6.9 TB/s, 8192: 6.8, one pass per wave: 5.8
     if (nb < 1) nb = 1;
     return (int)nb;

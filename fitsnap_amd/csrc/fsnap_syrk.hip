@@ -473,6 +473,32 @@ __device__ __forceinline__ void issue_rows(RawM<NB>& r, const WaveBufsP& wb, uns
     }
 }
 
+// the same with the packed pair that gates the rows handed in (kernel 1P keeps the pairs in a ring of their own)
+template <int NB, bool NT>
+__device__ __forceinline__ void issue_rows_w(RawM<NB>& r, const u4& wp, const WaveBufsP& wb, unsigned cl) {
+    const unsigned soff = cl * wb.chunk_bytes;
+    constexpr int AUX = NT ? 2 : 0;
+    const bool keep = pack_keep(wp);
+    const unsigned va = keep ? wb.voffA : FSNAP_OOB_VOFF;
+#pragma unroll
+    for (int j = 0; j < NB / 2; ++j) r.pr[j] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, va + 256u * j, soff, AUX);
+    if (NB & 1) {
+        const unsigned vtl = keep ? wb.voffT : FSNAP_OOB_VOFF;
+        r.tail = __builtin_amdgcn_raw_buffer_load_b64(wb.A, vtl, soff, AUX);
+    }
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>) -- ring slots stay
+// register names
+template <class F, int... I>
+__device__ __forceinline__ void wave_p_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void wave_p_for(F&& f) {
+    wave_p_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 // piece P of the refill of raw set r (one load instruction per MFMA slot: a block of back-to-back VMEM
 // instructions holds the in-order wave at the address path while the matrix pipe drains)
 template <int NB, bool NT, int P>
@@ -696,30 +722,52 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
 template <int NB, bool FULLK, bool NT>
 __global__ __launch_bounds__(256, 2) void fsnap_syrk_wave_p(const double* __restrict__ A, int64_t lda,
                                                             const double* __restrict__ wpack, int64_t m, int K,
-                                                            int64_t chunks_per_wave, double* __restrict__ part,
-                                                            double* __restrict__ cpart) {
+                                                            int64_t chunks_per_wave, int interleave,
+                                                            double* __restrict__ part, double* __restrict__ cpart) {
     constexpr int NTILE = NB * (NB + 1) / 2;
     __shared__ double lds[2 * NTILE * 256];
     const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
     const int rw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t rowwave = (int64_t)blockIdx.x * 4 + rw;
     const int64_t nchunks = (m + 3) >> 2;
-    int64_t c0 = rowwave * chunks_per_wave;
-    int64_t c1 = c0 + chunks_per_wave;
-    if (c1 > nchunks) c1 = nchunks;
-    if (c0 > c1) c0 = c1;
+    // Which chunks a row-wave takes.  interleave = 0: a contiguous range of chunks_per_wave chunks.  interleave = 1: chunk
+    // rowwave, rowwave + NW, rowwave + 2 NW, ... (NW = row-waves of the grid): at any moment the chip reads ONE advancing
+    // front of consecutive addresses instead of thousands of separate streams (the stand-alone weighting kernel gained
+    // 5.25 -> 6.4 TB/s when it dropped its looping workgroups).  An A/B switch (option "interleave", off by default): at
+    // 10^6 ... 10^7 x 31 both orders stream at the same rate, 5.3 TB/s on the boxes of round 3.  Needs the whole matrix
+    // within reach of a 32-bit buffer offset.
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    int64_t c0, stride, ncl64;
+    if (interleave) {
+        c0 = rowwave < nchunks ? rowwave : nchunks;
+        stride = nwaves;
+        ncl64 = rowwave < nchunks ? (nchunks - rowwave + nwaves - 1) / nwaves : 0;
+    } else {
+        c0 = rowwave * chunks_per_wave;
+        int64_t c1 = c0 + chunks_per_wave;
+        if (c1 > nchunks) c1 = nchunks;
+        if (c0 > c1) c0 = c1;
+        stride = 1;
+        ncl64 = c1 - c0;
+    }
     const int64_t row0 = c0 << 2;
-    int64_t row1 = c1 << 2;
+    // the descriptors end where the wave's last chunk ends (interleaved: at the end of the matrix): chunk slots past
+    // the wave's range read zeros
+    int64_t row1 = interleave ? m : ((c0 + ncl64) << 2);
     if (row1 > m) row1 = m;
-    const int64_t nrow = row1 > row0 ? row1 - row0 : 0;
+    const int64_t nrow = (ncl64 > 0 && row1 > row0) ? row1 - row0 : 0;
     WaveBufsP wb;
     wb.A = make_rsrc(A + row0 * lda, (unsigned)(nrow * lda * 8 + (nrow ? 16 : 0)));
     wb.wp = make_rsrc(wpack + 2 * row0, (unsigned)(nrow * 16));
     wb.voffA = (unsigned)((kr * lda + 2 * e) * 8);
     wb.voffT = (unsigned)((kr * lda + 16 * (NB - 1) + e) * 8);
     wb.voffP = (unsigned)(kr * 16);
-    wb.chunk_bytes = (unsigned)(lda * 32);
-    const unsigned ncl = (unsigned)(c1 - c0);
+    wb.chunk_bytes = (unsigned)(stride * lda * 32);
+    const unsigned pack_bytes = (unsigned)(stride * 64);
+    const unsigned ncl = (unsigned)ncl64;
+    auto load_pack_s = [&](unsigned cl) -> u4 {
+        return __builtin_amdgcn_raw_buffer_load_b128(wb.wp, wb.voffP, cl * pack_bytes, 0);
+    };
 
     d4 acc[NTILE];
 #pragma unroll
@@ -731,46 +779,54 @@ __global__ __launch_bounds__(256, 2) void fsnap_syrk_wave_p(const double* __rest
         V[p] = 0.0;
     }
     double wbcur = 0.0;
-    RawM<NB> r0, r1, r2;
-    // step c: MFMAs of chunk c (operands V prepared one step ago), V <- chunk c + 1 (raw set RN), rows of chunk c + 3
-    // into the raw set RF consumed one step ago (its packed weights arrived during the last step), packed weights of
-    // chunk c + 4 into RN.  Chunk slots past the wave's range read zeros (bounds-checked descriptors).
-#define FSNAP_STEP_P(RF, RN, CLF)                                                                \
-    {                                                                                            \
-        const d2 wpn = __builtin_bit_cast(d2, RN.wp);                                            \
-        RN.wp = load_pack(wb, (CLF) + 1);                                                        \
-        issue_rows<NB, NT>(RF, wb, (CLF));                                                       \
-        _Pragma("unroll") for (int p = 0; p < NB; ++p) {                                         \
-            _Pragma("unroll") for (int q = p; q < NB; ++q) {                                     \
-                acc[tri_index(p, q, NB)] =                                                       \
-                    __builtin_amdgcn_mfma_f64_16x16x4f64(V[p], V[q], acc[tri_index(p, q, NB)], 0, 0, 0); \
-            }                                                                                    \
-        }                                                                                        \
-        _Pragma("unroll") for (int p = 0; p < NB; ++p) cacc[p] = __builtin_fma(V[p], wbcur, cacc[p]); \
-        _Pragma("unroll") for (int p = 0; p < NB; ++p) V[p] = weighted_block<NB, FULLK>(RN, p, wpn[0], K, e); \
-        wbcur = wpn[1];                                                                          \
-    }
+    // Software pipeline over rings of registers with compile-time slots.  Step c: the packed pair of chunk c + 2 D - 1, the
+    // rows of chunk c + D (gated by ITS packed pair, requested D - 1 steps ago), the MFMAs of chunk c (operands V prepared
+    // one step ago), V <- chunk c + 1.  Rows are consumed D - 1 steps after their request.  With NB <= 2 a step is three
+    // MFMAs (~200 cycles): the first version of this loop (three row sets, the packed pair one step ahead of the rows it
+    // gates) waited for a memory round trip per step -- the ISA showed the row loads sunk behind the wait for their pair
+    // and consumed at the top of the next iteration.  Chunk slots past the wave's range read zeros (bounds-checked
+    // descriptors).
+    constexpr int D = NB <= 2 ? 4 : 3, W = 2 * D;
+    RawM<NB> R[D];
+    u4 P[W];
     if (ncl > 0) {
-        r0.wp = load_pack(wb, 0);
-        r1.wp = load_pack(wb, 1);
-        r2.wp = load_pack(wb, 2);
-        issue_rows<NB, NT>(r0, wb, 0);
-        issue_rows<NB, NT>(r1, wb, 1);
-        issue_rows<NB, NT>(r2, wb, 2);
+        wave_p_for<W - 1>([&](auto x) { P[x] = load_pack_s((unsigned)x); });
+        wave_p_for<D>([&](auto x) { issue_rows_w<NB, NT>(R[x], P[x], wb, (unsigned)x); });
         {
-            const d2 wp0 = __builtin_bit_cast(d2, r0.wp);
+            const d2 wp0 = __builtin_bit_cast(d2, P[0]);
 #pragma unroll
-            for (int p = 0; p < NB; ++p) V[p] = weighted_block<NB, FULLK>(r0, p, wp0[0], K, e);
+            for (int p = 0; p < NB; ++p) V[p] = weighted_block<NB, FULLK>(R[0], p, wp0[0], K, e);
             wbcur = wp0[1];
         }
-        r0.wp = load_pack(wb, 3);
-        for (unsigned cl = 0; cl < ncl; cl += 3) {
-            FSNAP_STEP_P(r0, r1, cl + 3)
-            FSNAP_STEP_P(r1, r2, cl + 4)
-            FSNAP_STEP_P(r2, r0, cl + 5)
+        for (unsigned cl = 0; cl < ncl; cl += W) {
+            wave_p_for<W>([&](auto u_) {
+                constexpr int u = decltype(u_)::value;                  // chunk c = cl + u: c % W == u
+                const d2 wpn = __builtin_bit_cast(d2, P[(u + 1) % W]);  // weights of chunk c + 1
+                // the pair of chunk c - 1 + W goes into the slot of chunk c - 1: the slot of chunk c is still alive in
+                // this step (wbcur is its upper half -- loading over it makes the allocator keep two copies of the ring
+                // and rotate them with moves at the loop end, behind a wait for every load in flight)
+                P[(u + W - 1) % W] = load_pack_s(cl + u + W - 1);
+                issue_rows_w<NB, NT>(R[u % D], P[(u + D) % W], wb, cl + u + D);
+                // the requests stay at the head of their step: left to itself the scheduler sinks them towards their
+                // consumers' step and hoists the waits (the whole point is the distance between the two)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int p = 0; p < NB; ++p) {
+#pragma unroll
+                    for (int q = p; q < NB; ++q) {
+                        acc[tri_index(p, q, NB)] =
+                            __builtin_amdgcn_mfma_f64_16x16x4f64(V[p], V[q], acc[tri_index(p, q, NB)], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < NB; ++p) cacc[p] = __builtin_fma(V[p], wbcur, cacc[p]);
+#pragma unroll
+                for (int p = 0; p < NB; ++p) V[p] = weighted_block<NB, FULLK>(R[(u + 1) % D], p, wpn[0], K, e);
+                wbcur = wpn[1];
+                __builtin_amdgcn_sched_barrier(0);
+            });
         }
     }
-#undef FSNAP_STEP_P
 
     // fold the four row-waves through LDS ({2,3} -> {0,1}, then 1 -> 0): one partial triangle per workgroup
     {
@@ -2234,7 +2290,7 @@ static hipError_t launch_syrk_wave_p_nb(const SyrkArgs& a, hipStream_t st) {
     if (!a.wpack) return hipErrorInvalidValue;
 #define FSNAP_LAUNCH(FK, NTL)                                                                                       \
     hipLaunchKernelGGL((fsnap_syrk_wave_p<NB, FK, NTL>), grid, block, 0, st, a.A, a.lda, a.wpack, a.m, a.K,         \
-                       a.chunks_per_wave, a.part, a.cpart)
+                       a.chunks_per_wave, a.interleave ? 1 : 0, a.part, a.cpart)
     if (fullk) {
         if (a.nontemporal) FSNAP_LAUNCH(true, true);
         else FSNAP_LAUNCH(true, false);

@@ -75,7 +75,8 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
 
 /* Tuning knobs (all optional; 0 = auto): "kernel" (1 wave-triangle, 2 LDS-shared rows with
  * per-wave specialised bodies, 3 LDS-shared generic variant), "split" (1|2, sub-waves per row-wave of kernel 1),
- * "nontemporal" (0|1), "nblocks" (workgroups of the SYRK kernel), "tiled" (1 = force the
+ * "nontemporal" (0|1), "interleave" (0|1, default 0; 1: the K <= 80 kernel deals the 4-row chunks round-robin to its waves -- one
+ * advancing front of addresses -- instead of one contiguous range per wave: an A/B switch, no difference measured), "nblocks" (workgroups of the SYRK kernel), "tiled" (1 = force the
  * general-K tiled kernel also for K <= 128), "nsplit" (row splits of the tiled kernel), "mirror" (0|1, see fsnap_normal_eq_resident), "xcd" (0|1: tiled kernel deals contiguous work-item ranges to each XCD), "tiled2" (0|1: K > 128 on the one-wave-per-SIMD kernel with 64 x 128-column work items, default 0),
  * "device_solve" (fsnap_solve_device: 0 = auto: K >= 384 is factorised on the GPU by the blocked kernels; 1 = every K on the GPU; 2 = never),
  * "repack" (1 = recompute the packed per-row weights (mask * w, mask * w * b) and the b-only scalars on EVERY fit even
@@ -85,7 +86,9 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * fsnap_timing_history see the sampled ones),
  * "dist_solve" (fsnap_fit_dist: 0 = in-place all-reduce + solve on every rank, the default; 1 = reduce to rank 0, solve there,
  * broadcast [beta | rank | rcond | status] -- for A/B runs of the scaling benchmark; the reduced statistics then exist on
- * rank 0 only and *d_packed comes back NULL on the other ranks).
+ * rank 0 only and *d_packed comes back NULL on the other ranks),
+ * "comm_timeout" (seconds, 0 = the FSNAP_COMM_TIMEOUT environment default: bound of every wait behind a collective of this
+ * context and of fsnap_comm_init -- a phase that may fail without taking the job with it sets a short one).
  * Unknown key -> FSNAP_E_ARG. */
 int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value);
 

@@ -183,6 +183,24 @@ def test_bench_runs_the_multi_gpu_step_without_torch(tmp_path):
     assert rec["dist_solve_ab"]["same_beta"] is True
 
 
+def test_bench_reports_its_scaling_numbers_when_the_optional_ab_leg_fails(tmp_path):
+    # the reduce-to-root A/B runs last, under its own short collective deadline; when it fails the line is printed
+    # without it and the process ends with status 0
+    import json
+
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", FSNAP_COMM_FILE=str(tmp_path / "id"),
+               FSNAP_BENCH_FAIL_AB="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--rows", "65536", "--steps", "3",
+                          "--warmup", "1", "--preheat", "5", "--no-cpu-baseline", "--dist-solve-ab", "1"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["value"] > 0 and "injected" in rec["dist_solve_ab"]["error"]
+    assert "dist_solve A/B failed" in out.stderr
+
+
 def test_bench_launcher_refuses_more_ranks_than_devices():
     # `bench.py --gpus N` starts its own ranks; with fewer devices than ranks every rank says so and the job fails with
     # one summary line instead of hanging in RCCL's bootstrap
