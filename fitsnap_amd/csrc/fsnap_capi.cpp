@@ -388,6 +388,7 @@ int launch_normal_eq_tiled(fsnap_ctx* ctx, double* d_packed, bool accumulate) {
     a.nontemporal = false;  // rows are re-read by the other column pairs: keep them cached
     a.xcd_map = ctx->opt_xcd != 0;
     a.xcd_order = ctx->opt_xcd == 2 ? 2 : 1;
+    a.ring = ctx->opt_tiled_ring;
     a.part = (double*)ctx->part.p;
     a.cpart = (double*)ctx->cpart.p;
     a.spart = (const double*)ctx->wpack_spart.p;
@@ -680,6 +681,9 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
         ctx->timing_phase = 0;
     } else if (!strcmp(key, "repack")) {
         ctx->opt_repack = value != 0;
+    } else if (!strcmp(key, "tiled_ring")) {
+        if (value < 0 || value > 3) return ctx->fail(FSNAP_E_ARG, "tiled_ring must be 0 ... 3");
+        ctx->opt_tiled_ring = (int)value;
     } else if (!strcmp(key, "interleave")) {
         ctx->opt_interleave = value != 0;
     } else if (!strcmp(key, "comm_timeout")) {

@@ -100,6 +100,7 @@ struct fsnap_ctx {
     // options
     int opt_split = 0;        // 0 = auto
     int opt_nt = 1;
+    int opt_tiled_ring = 3;       // kernel 1T: bit 0 diagonal / bit 1 off-diagonal items on the ring form of the pipeline
     bool opt_interleave = false;  // kernel 1P: row-waves take every NW-th chunk (one address front) instead of contiguous ranges (A/B: no difference measured)
     int opt_nblocks = 0;      // 0 = auto
     int opt_tiled = 0;        // force the general-K tiled kernel also for K <= 128

@@ -40,6 +40,7 @@ struct TiledArgs {
     bool nontemporal;
     bool xcd_map = true;        // contiguous (split, pair) ranges per XCD (L2 sharing of row slabs)
     int xcd_order = 1;          // 1: (split, pair) order inside an XCD; 2: class-major (equal-cost items side by side)
+    int ring = 3;               // kernel 1T: bit 0 = diagonal items, bit 1 = off-diagonal items on the ring form of the pipeline
     double* part;               // [nsplit*npairs][16][4][64]
     double* cpart;              // [(nsplit*NSB)*4][4][16]
     const double* spart;        // [ns][4]: partial b-only scalars of fsnap_pack_weights_k

@@ -1542,6 +1542,23 @@ __device__ __forceinline__ void issue_rows_t(RawT& r, const WaveBufsT& wb, unsig
     }
 }
 
+// the same with the packed pair that gates the rows handed in (ring form of the pipeline)
+template <bool DIAG, int EDGE, bool NT>
+__device__ __forceinline__ void issue_rows_tw(RawT& r, const u4& wp, const WaveBufsT& wb, unsigned voffI, unsigned voffJ,
+                                              unsigned cl) {
+    const unsigned soff = cl * wb.chunk_bytes;
+    constexpr int AUX = NT ? 2 : 0;
+    const bool keep = pack_keep(wp);
+    const unsigned vi = keep ? voffI : FSNAP_OOB_VOFF;
+    r.pi[0] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, vi, soff, AUX);
+    if (!(DIAG && EDGE == 2)) r.pi[1] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, vi + 256u, soff, AUX);
+    if (!DIAG) {
+        const unsigned vj = keep ? voffJ : FSNAP_OOB_VOFF;
+        r.pj[0] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, vj, soff, AUX);
+        if (EDGE != 2) r.pj[1] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, vj + 256u, soff, AUX);
+    }
+}
+
 // MFMA operands of one chunk.  Diagonal pair (I == J): the same registers w a serve both sides.  Off-diagonal
 // pair: the weight goes on ONE side, (w^2 a_I) x a_J -- the J side is used as loaded (no VALU instruction at all;
 // fp64 MFMAs and VALU instructions serialise on the SIMD, the first version of this kernel spent ~40 VALU
@@ -1577,7 +1594,7 @@ __device__ __forceinline__ void prep_t(double (&vI)[4], double (&vJ)[4], const R
     }
 }
 
-template <bool DIAG, int EDGE, bool NT>
+template <bool DIAG, int EDGE, bool NT, bool RING = false>
 __device__ __forceinline__ void syrk_tiled_body(const double* __restrict__ A, int64_t lda,
                                                 const double* __restrict__ wpack, int64_t m, int K, int I, int J,
                                                 int64_t c0, int64_t c1, int wv_in_wg, double* lds,
@@ -1608,6 +1625,47 @@ __device__ __forceinline__ void syrk_tiled_body(const double* __restrict__ A, in
     constexpr int QMAX = (EDGE == 2) ? 2 : 4;              // 16-column blocks of the J side that hold columns < K
     constexpr int PMAX = (DIAG && EDGE == 2) ? 2 : 4;
 
+    if constexpr (RING) {
+        // Kernel 1P's pipeline (rings with compile-time slots: three row sets, six packed pairs, the pair of chunk c + 5
+        // loaded into the slot of chunk c - 1).  The three-set form below keeps a pair in its row set and reloads that
+        // slot while the old pair is still needed (its weight at the end of the step, its w b as wbcur in the next one):
+        // the allocator then holds two copies of the pairs and rotates them with moves at the loop end -- behind a wait
+        // for nearly every load in flight (diagonal items: s_waitcnt vmcnt(1) once per three chunks).
+        constexpr int D = 3, W = 6;
+        RawT R[D];
+        u4 P[W];
+        if (ncl > 0) {
+            wave_p_for<W - 1>([&](auto x) { load_pack_d<DIAG>(P[x], wb, (unsigned)x); });
+            wave_p_for<D>([&](auto x) { issue_rows_tw<DIAG, EDGE, NT>(R[x], P[x], wb, voffI, voffJ, (unsigned)x); });
+            {
+                const d2 wp0 = __builtin_bit_cast(d2, P[0]);
+                prep_t<DIAG, EDGE>(vI, vJ, R[0], wp0[0], 64 * I, 64 * J, K, e);
+                wbcur = wp0[1];
+            }
+            for (unsigned cl = 0; cl < ncl; cl += W) {
+                wave_p_for<W>([&](auto u_) {
+                    constexpr int u = decltype(u_)::value;
+                    const d2 wpn = __builtin_bit_cast(d2, P[(u + 1) % W]);
+                    load_pack_d<DIAG>(P[(u + W - 1) % W], wb, cl + u + W - 1);
+                    issue_rows_tw<DIAG, EDGE, NT>(R[u % D], P[(u + D) % W], wb, voffI, voffJ, cl + u + D);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int p = 0; p < PMAX; ++p) {
+#pragma unroll
+                        for (int q = (DIAG ? p : 0); q < QMAX; ++q)
+                            acc[p * 4 + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(vI[p], DIAG ? vI[q] : vJ[q], acc[p * 4 + q], 0, 0, 0);
+                    }
+                    if (DIAG) {
+#pragma unroll
+                        for (int p = 0; p < PMAX; ++p) cacc[p] = __builtin_fma(vI[p], wbcur, cacc[p]);
+                    }
+                    prep_t<DIAG, EDGE>(vI, vJ, R[(u + 1) % D], wpn[0], 64 * I, 64 * J, K, e);
+                    wbcur = wpn[1];
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+        }
+    } else {
     // step c: MFMAs of chunk c (operands prepared one step ago), operands of chunk c + 1 from raw set RN, rows of
     // chunk c + 3 into the raw set RF consumed one step ago (its packed weights arrived during the last step),
     // packed weights of chunk c + 4 into RN.  The packed load goes out before the row loads (in-order vmcnt).
@@ -1647,6 +1705,7 @@ __device__ __forceinline__ void syrk_tiled_body(const double* __restrict__ A, in
         }
     }
 #undef FSNAP_STEP_T
+    }
 
     // fold the 4 waves through LDS ({2,3} -> {0,1}, 1 -> 0), then one partial per workgroup
     {
@@ -1695,7 +1754,7 @@ template <bool NT>
 __global__ __launch_bounds__(256, 2) void fsnap_syrk_tiled(const double* __restrict__ A, int64_t lda,
                                                            const double* __restrict__ wpack, int64_t m, int K,
                                                            int NSB, int npairs, int64_t chunks_per_split,
-                                                           int nitems, int xcd_map,
+                                                           int nitems, int xcd_map, int ring,
                                                            double* __restrict__ part, double* __restrict__ cpart) {
     __shared__ double lds[2 * 16 * 256];
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1783,9 +1842,17 @@ __global__ __launch_bounds__(256, 2) void fsnap_syrk_tiled(const double* __restr
     const int tail = K & 63;
     const int edge = (J == NSB - 1 && tail != 0) ? (tail <= 32 ? 2 : 4) : 0;
     if (I == J) {
-        if (edge == 2) syrk_tiled_body<true, 2, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+        if (ring) {     // diagonal items on the ring form of the pipeline (see syrk_tiled_body)
+            if (edge == 2) syrk_tiled_body<true, 2, NT, true>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+            else if (edge == 4) syrk_tiled_body<true, 4, NT, true>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+            else syrk_tiled_body<true, 0, NT, true>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+        } else if (edge == 2) syrk_tiled_body<true, 2, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
         else if (edge == 4) syrk_tiled_body<true, 4, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
         else syrk_tiled_body<true, 0, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+    } else if (ring & 2) {
+        if (edge == 2) syrk_tiled_body<false, 2, NT, true>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+        else if (edge == 4) syrk_tiled_body<false, 4, NT, true>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+        else syrk_tiled_body<false, 0, NT, true>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
     } else {
         if (edge == 2) syrk_tiled_body<false, 2, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
         else if (edge == 4) syrk_tiled_body<false, 4, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
@@ -2365,10 +2432,10 @@ hipError_t launch_syrk_tiled(const TiledArgs& a, hipStream_t st) {
     dim3 grid((unsigned)(xmode ? 8 * per_xcd : nitems)), block(256);
     if (a.nontemporal)
         hipLaunchKernelGGL((fsnap_syrk_tiled<true>), grid, block, 0, st, a.A, a.lda, a.wpack, a.m, a.K, a.NSB,
-                           a.npairs, a.chunks_per_split, nitems, xmode, a.part, a.cpart);
+                           a.npairs, a.chunks_per_split, nitems, xmode, a.ring, a.part, a.cpart);
     else
         hipLaunchKernelGGL((fsnap_syrk_tiled<false>), grid, block, 0, st, a.A, a.lda, a.wpack, a.m, a.K, a.NSB,
-                           a.npairs, a.chunks_per_split, nitems, xmode, a.part, a.cpart);
+                           a.npairs, a.chunks_per_split, nitems, xmode, a.ring, a.part, a.cpart);
     return hipGetLastError();
 }
 

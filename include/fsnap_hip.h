@@ -78,6 +78,8 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * "nontemporal" (0|1), "interleave" (0|1, default 0; 1: the K <= 80 kernel deals the 4-row chunks round-robin to its waves -- one
  * advancing front of addresses -- instead of one contiguous range per wave: an A/B switch, no difference measured), "nblocks" (workgroups of the SYRK kernel), "tiled" (1 = force the
  * general-K tiled kernel also for K <= 128), "nsplit" (row splits of the tiled kernel), "mirror" (0|1, see fsnap_normal_eq_resident), "xcd" (0|1: tiled kernel deals contiguous work-item ranges to each XCD), "tiled2" (0|1: K > 128 on the one-wave-per-SIMD kernel with 64 x 128-column work items, default 0),
+ * "tiled_ring" (0 ... 3, default 3: bit 0 / bit 1 put the diagonal / off-diagonal work items of the tiled kernel on the ring form of its
+ * load pipeline; 0 = the three-set form of round 2, for A/B runs -- same bits either way),
  * "device_solve" (fsnap_solve_device: 0 = auto: K >= 384 is factorised on the GPU by the blocked kernels; 1 = every K on the GPU; 2 = never),
  * "repack" (1 = recompute the packed per-row weights (mask * w, mask * w * b) and the b-only scalars on EVERY fit even
  * when b, w and the mask are context-owned and unchanged; default 0 = once per fsnap_set_weights / fsnap_upload_rows),
