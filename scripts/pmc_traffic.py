@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """profiles/pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of rocprofv3 over bench.py.
 
-    python scripts/pmc_traffic.py <dir with pass*/..pmc_counter_collection.csv> <bench json of the same command>
+    python scripts/pmc_traffic.py <dir with pass*/..pmc_counter_collection.csv> <bench json of the same command> [--append]
+
+profiles/pmc_traffic.json is a LIST of records, the headline shape first; --append adds the record (or replaces the one of the
+same shape) instead of starting the list over.
 
 HBM bytes per launch of the dominant kernel = (FETCH_SIZE x 2 [gfx950 tallies a 128-byte request as 64 bytes,
 MI355X_MICROARCH.md "HBM"] + WRITE_SIZE) x 1024 [the counters are in KiB], averaged over the dispatches of the kernel
@@ -19,7 +22,7 @@ sys.path.insert(0, ROOT)
 from bench import kernel_source_digest  # noqa: E402
 
 
-def main(pmc_dir, bench_json):
+def main(pmc_dir, bench_json, append=False):
     rec = json.load(open(bench_json))
     kernel = rec["roofline"]["kernel"]
     base = kernel.split("<")[0]
@@ -45,9 +48,17 @@ def main(pmc_dir, bench_json):
                   "(FETCH_SIZE x 2 [gfx950 half-count correction] + WRITE_SIZE) x 1024",
     }
     out["traffic_over_algorithmic"] = out["hbm_bytes_per_launch"] / out["algorithmic_bytes_per_launch"]
-    json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    recs = []
+    if append and os.path.exists(path):
+        recs = json.load(open(path))
+        if isinstance(recs, dict):
+            recs = [recs]
+        recs = [r for r in recs if not (r.get("rows") == out["rows"] and r.get("K") == out["K"])]
+    recs.append(out)
+    json.dump(recs, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], "--append" in sys.argv[3:])
