@@ -286,7 +286,15 @@ int tiled_geometry(fsnap_ctx* ctx, int64_t m, int64_t K, int64_t lda, bool allow
         for (int64_t n = n_lo; n <= n_hi; ++n) {
             const int64_t cps = (nchunks + n - 1) / n;
             const int64_t cpw = (cps + 3) / 4;
-            const double cost = unit * tiled_makespan_units(tiles, n, cpw, groups, slots, ovh) + (double)n * (double)part_bytes / 3.0e12;
+            // Long items drift apart: the pairs of a split start together and share every row segment through their
+            // XCD's L2, but they cost 16 / 10 / 8 / 3 tiles per chunk, and the longer they run the less of a split's rows is
+            // still in L2 when the slower ones get there (367 900 x 480: 7.4 GB fetched per launch for a 1.4 GB matrix, the
+            // kernel at 5.2 TB/s of fabric traffic as much memory- as MFMA-bound).  Measured with the split count forced
+            // (round 3): the kernel time grows by ~2e-4 per chunk a wave owns -- 367 900 x 480: 64 splits 1.44 ms, 128
+            // 1.40, 192 1.37; 200 000 x 1 000: 23 splits 3.83 ms, 64 3.48 -- and by a quarter of that when the whole
+            // matrix stays in the Infinity Cache (15 213 x 1 595).
+            const double drift = 1.0 + (bytes > (200ll << 20) ? 2.0e-4 : 0.5e-4) * (double)cpw;
+            const double cost = unit * drift * tiled_makespan_units(tiles, n, cpw, groups, slots, ovh) + (double)n * (double)part_bytes / 3.0e12;
             if (cost < best) {
                 best = cost;
                 nsplit = n;
