@@ -1,4 +1,8 @@
-mkdir -p gpurun_out/v24; cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-run() { r=$1; c=$2; shift 2; timeout 120 python bench.py --rows $r --cols $c --steps 12 --warmup 3 --preheat 40 --no-cpu-baseline --scaling strong "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$r x $c $*', round(r['kernel_ms_avg']*1e3,1),'us', round(r['frac'],3), 'reduce', round(r['reduce_kernel_ms_avg']*1e3,1), 'step', round(d['ms_per_step']*1e3,1), 'nsplit', d['config']['launch']['nsplit'], 'cpw', d['config']['launch']['chunks_per_wave'])"; }
-for shp in "367900 480" "15213 1595" "200000 1000" "1000000 256" "13035 142" "100000 300" "50000 640" "1772880 142" "4001 1595"; do run $shp; done 2>&1 | tee gpurun_out/v24/splits.txt
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py tests/test_gpu_assembly.py -x -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -3
+mkdir -p gpurun_out/v26; cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+timeout 300 python bench.py --no-cpu-baseline --rows 1000000 --cols 31 --steps 30 --warmup 3 > gpurun_out/v26/bench_1000000x31.json 2>/dev/null
+timeout 300 python bench.py --no-cpu-baseline --rows 15213 --cols 31 --steps 30 --warmup 3 > gpurun_out/v26/bench_15213x31.json 2>/dev/null
+timeout 300 python bench.py --no-cpu-baseline --rows 10000000 --cols 31 --steps 30 --warmup 3 > gpurun_out/v26/bench_10000000x31.json 2>/dev/null
+python -c "
+import json
+for s in ('1000000x31','15213x31','10000000x31'):
+    d=json.loads(open('gpurun_out/v26/bench_%s.json'%s).read()); print(s, d['ms_per_step'], d['roofline']['kernel_ms_avg'], d['roofline']['frac'], d['weighting_kernel']['frac'])"
