@@ -830,7 +830,7 @@ int stage_assembly(fsnap_ctx* ctx, const char* who, const double* raw, int64_t r
         (nfrac > 0 && !fractions) || raw_rows > 0x7FFFFFFF)
         return ctx->fail(FSNAP_E_ARG, "%s: bad argument", who);
     for (int64_t r = 0; r < nrows; ++r)
-        if (src_row[r] < 0 || src_row[r] >= raw_rows || kind[r] < 0 || kind[r] > 3 || frac[r] >= nfrac)
+        if (src_row[r] < 0 || src_row[r] >= raw_rows || kind[r] < 0 || kind[r] > 3 || frac[r] >= nfrac || frac[r] < -1)
             return ctx->fail(FSNAP_E_ARG, "%s: plan entry %lld out of range", who, (long long)r);
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     const int64_t K = (int64_t)ntypes * (ncoeff + offcol);
