@@ -493,8 +493,6 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
         const size_t need = ((size_t)FSNAP_PACKED_LEN(ctx->K) + (size_t)ctx->K) * 8;   // + compact diagonal
         if (ctx->mirror_bytes < need) {
             if (ctx->mirror) (void)hipHostFree(ctx->mirror);
-    if (ctx->chol_host) (void)hipHostFree(ctx->chol_host);
-    if (ctx->chol_ev) (void)hipEventDestroy(ctx->chol_ev);
             ctx->mirror = nullptr;
             ctx->mirror_bytes = 0;
             // coherent (fine-grained) host memory: the kernel's stores are visible to the host once the event has completed
@@ -634,6 +632,8 @@ int fsnap_ctx_destroy(fsnap_ctx* ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->mirror) (void)hipHostFree(ctx->mirror);
     if (ctx->mirror_ev) (void)hipEventDestroy(ctx->mirror_ev);
+    if (ctx->chol_host) (void)hipHostFree(ctx->chol_host);
+    if (ctx->chol_ev) (void)hipEventDestroy(ctx->chol_ev);
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto& sl : ctx->ring)

@@ -35,6 +35,10 @@ struct DevBuf {
         p = nullptr;
         bytes = 0;
     }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }      // every buffer of a context goes with it (fsnap_ctx_destroy selects the device first)
 };
 
 struct Comm;       // fsnap_comm.cpp: RCCL communicator of this rank (nullptr = single GPU)

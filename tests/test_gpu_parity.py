@@ -262,6 +262,24 @@ def test_ridge_fit_k142_ace_shape():
     pt.free()
 
 
+def test_one_context_alternates_between_device_and_host_factorisation():
+    # a context that has factorised on the GPU (page-locked result block of the device Cholesky) and then fits a narrow
+    # problem (page-locked mirror of the statistics, allocated on first use) must still own the first block afterwards:
+    # the mirror's (re)allocation used to free it and leave the pointer behind
+    c = _capi.HipContext(0)
+    for K, m in ((480, 6000), (31, 5000), (480, 6000), (128, 9000), (512, 4000), (64, 3000), (480, 6000)):
+        rng = np.random.default_rng(7000 + K)
+        A = rng.standard_normal((m, K))
+        b = rng.standard_normal(m)
+        w = rng.uniform(0.5, 2.0, m)
+        c.upload_rows(A, b)
+        c.set_weights(w)
+        beta, rank, _, _ = c.fit_resident(_capi.SOLVE_RIDGE, 1e-8)
+        ref = orc.ridge_fit(A, b, w, 1e-8, local_solver=True)
+        assert rank == K and np.max(np.abs(beta - ref)) / np.max(np.abs(ref)) < 1e-9, (K, m)
+    c.close()
+
+
 @pytest.mark.parametrize("K,m", [(257, 3001), (320, 4000), (480, 6000), (1000, 5000), (1595, 7000)])
 def test_large_k_device_cholesky_matches_host_solve(ctx, K, m):
     # fsnap_solve_device factorises large systems on the GPU (blocked kernels 8a-8e); same answer as the host solver and
