@@ -183,6 +183,27 @@ def test_bench_runs_the_multi_gpu_step_without_torch(tmp_path):
     assert rec["dist_solve_ab"]["same_beta"] is True
 
 
+def test_bench_single_gpu_line_carries_the_contract_fields_and_the_pipelined_leg():
+    # plain `python bench.py` on one GPU: ONE JSON line with the driver's fields, roofline + cpu_baseline objects, and the
+    # two-fits-in-flight leg as an extra object (same coefficients, never `value`)
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "131072", "--steps", "6", "--warmup", "2",
+                          "--preheat", "10"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in rec, key
+    assert rec["n_gpus"] == 1 and rec["steps"] == 6 and rec["dtype"] == "f64" and rec["roofline"]["bound"] in ("mfma", "hbm")
+    assert rec["cpu_baseline"]["kind"] in ("port", "reference") and rec["cpu_baseline"]["value"] > 0
+    pl = rec["pipelined"]
+    assert pl["fits_in_flight"] == 2 and pl["same_beta_as_headline"] is True and pl["value"] > 0
+
+
 def test_bench_reports_its_scaling_numbers_when_the_optional_ab_leg_fails(tmp_path):
     # the reduce-to-root A/B runs last, under its own short collective deadline; when it fails the line is printed
     # without it and the process ends with status 0
