@@ -262,6 +262,42 @@ def test_ridge_fit_k142_ace_shape():
     pt.free()
 
 
+@pytest.mark.parametrize("K,m", [(31, 20011), (16, 7001), (55, 33000), (80, 12345)])
+def test_narrow_kernel_chunk_orders_agree_with_the_oracle(K, m):
+    # kernel 1P deals the 4-row chunks to its waves in contiguous ranges (default) or round-robin (option interleave):
+    # different summation orders of the same rows, both within rounding of the oracle; masked rows stay out either way
+    rng = np.random.default_rng(900 + K)
+    A, b, w = orc.synth_problem(m, K)
+    t = rng.random(m) < 0.25
+    ref = orc.normal_eq(A, b, w, t)
+    c = _capi.HipContext(0)
+    out = []
+    for il in (0, 1):
+        c.set_option("interleave", il)
+        G, cc, s = run_stats(c, A, b, w, t)
+        stats_close(G, cc, s, *ref)
+        out.append(G)
+    assert np.max(np.abs(out[0] - out[1])) <= 1e-12 * np.max(np.abs(out[0]))
+    c.close()
+
+
+@pytest.mark.parametrize("K,m", [(142, 13035), (300, 9001), (480, 30000)])
+def test_tiled_kernel_pipeline_forms_give_the_same_bits(K, m):
+    # option tiled_ring: the load pipeline of the tiled kernel in its three-set form (0) and in ring form for the diagonal
+    # (1) / all (3) work items -- the arithmetic and its order are the same, so are the bits
+    A, b, w = orc.synth_problem(m, K)
+    t = np.random.default_rng(K).random(m) < 0.2
+    c = _capi.HipContext(0)
+    got = []
+    for ring in (0, 1, 3):
+        c.set_option("tiled_ring", ring)
+        got.append(run_stats(c, A, b, w, t))
+    for G, cc, s in got[1:]:
+        assert np.array_equal(G, got[0][0]) and np.array_equal(cc, got[0][1]) and np.array_equal(s, got[0][2])
+    stats_close(*got[2], *orc.normal_eq(A, b, w, t))
+    c.close()
+
+
 def test_one_context_alternates_between_device_and_host_factorisation():
     # a context that has factorised on the GPU (page-locked result block of the device Cholesky) and then fits a narrow
     # problem (page-locked mirror of the statistics, allocated on first use) must still own the first block afterwards:
