@@ -6,5 +6,4 @@ from .ridge import RIDGE  # noqa: F401
 from .ard import ARD  # noqa: F401
 from .anl import ANL  # noqa: F401
 from .lasso import LASSO  # noqa: F401
-from .scalapack import ScaLAPACK  # noqa: F401
 from .solver_factory import solver, search  # noqa: F401

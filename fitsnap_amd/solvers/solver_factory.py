@@ -3,7 +3,7 @@ direct subclass of ``Solver`` whose class name equals ``[SOLVER] solver`` case-i
 IndexError.  The imports below are the registration."""
 from .._discovery import find_plugin
 from .solver import Solver
-from . import anl, ard, lasso, ridge, scalapack, svd  # noqa: F401  (ANL, ARD, LASSO, RIDGE, ScaLAPACK, SVD)
+from . import anl, ard, lasso, ridge, svd  # noqa: F401  (ANL, ARD, LASSO, RIDGE, SVD)
 
 
 def search(solver_name):

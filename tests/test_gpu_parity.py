@@ -524,21 +524,6 @@ def test_svd_solver_shared_array_path(ta, ta_fits):
     pt.free()
 
 
-def test_scalapack_named_solver_is_the_least_squares_fit_of_all_rows(ta, ta_fits):
-    # `solver = ScaLAPACK` (the reference's multi-node lstsq, scalapack.py:13-45: all rows, no testing rows) runs on the
-    # statistics path of the SVD solver; the reference's own SVD fit of all rows is the golden
-    A, b, w = ta
-    pt, s = make_solver("ScaLAPACK")
-    m, K = A.shape
-    for name, arr in (("a", A), ("b", b), ("w", w)):
-        pt.create_shared_array(name, m, K if name == "a" else 1)
-        pt.shared_arrays[name].array[:] = arr
-    pt.fitsnap_dict["Testing"] = [False] * m
-    s.perform_fit()
-    check_fit(s.fit, ta_fits["svd_all"])
-    pt.free()
-
-
 def test_svd_transpose_trick_flag(ta, ta_fits):
     A, b, w = ta
     pt, s = make_solver("SVD", {"EXTRAS": {"apply_transpose": 1}})
