@@ -293,7 +293,10 @@ int tiled_geometry(fsnap_ctx* ctx, int64_t m, int64_t K, int64_t lda, bool allow
             // (round 3): the kernel time grows by ~2e-4 per chunk a wave owns -- 367 900 x 480: 64 splits 1.44 ms, 128
             // 1.40, 192 1.37; 200 000 x 1 000: 23 splits 3.83 ms, 64 3.48 -- and by a quarter of that when the whole
             // matrix stays in the Infinity Cache (15 213 x 1 595).
-            const double drift = 1.0 + (bytes > (200ll << 20) ? 2.0e-4 : 0.5e-4) * (double)cpw;
+            // (scaled by how much there is to share: a row segment is wanted by NSB pairs -- with 3 superblocks at most 3 x
+            // the matrix can be fetched, and many splits only buy a long reduction: 1 772 880 x 142 took 744)
+            const double share = std::min(1.0, (double)(g->NSB - 1) / 7.0);
+            const double drift = 1.0 + share * (bytes > (200ll << 20) ? 2.0e-4 : 0.5e-4) * (double)cpw;
             const double cost = unit * drift * tiled_makespan_units(tiles, n, cpw, groups, slots, ovh) + (double)n * (double)part_bytes / 3.0e12;
             if (cost < best) {
                 best = cost;
