@@ -708,5 +708,9 @@ class HipContext:
     def launch_info(self):
         info = (c_int64 * 8)()
         self._check(self._lib.fsnap_launch_info(self._h, info, 8))
-        return {"workgroups": info[0], "threads": info[1], "chunks_per_wave": info[2], "NB": info[3],
-                "split": info[4], "compute_units": info[5], "kernel_or_pairs": info[6], "nsplit": info[7]}
+        out = {"workgroups": info[0], "threads": info[1], "chunks_per_wave": info[2], "NB": info[3],
+               "split": info[4], "compute_units": info[5], "kernel_or_pairs": info[6], "nsplit": info[7]}
+        if info[4] != 0:            # not the tiled kernel: the last slot says whether kernel 1A packs its rows' weights itself
+            out["nsplit"] = 0
+            out["fused_pack"] = info[7]
+        return out

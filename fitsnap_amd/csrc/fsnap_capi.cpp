@@ -19,6 +19,8 @@
 #include "fsnap_kernels.h"
 
 // fsnap_solve with a contiguous copy of diag(G) (fsnap_solve.cpp; not part of the public ABI)
+extern "C" int fsnap_solve_diag_upper(int kind, double param, int64_t K, const double* G, const double* c, const double* diag,
+                                      double* beta, int* rank, double* rcond_est);
 extern "C" int fsnap_solve_diag(int kind, double param, int64_t K, const double* G, const double* c, const double* diag,
                                 double* beta, int* rank, double* rcond_est);
 
@@ -43,7 +45,15 @@ struct Geometry {
     int lds_waves;  // 0 = kernel 1 (wave-triangle); 8 / 16 = kernel 1L (LDS-shared) with that many waves
     bool acc;       // kernel 1A: whole triangle in one wave (accumulation registers), one wave per SIMD
     bool packed;    // kernel 1P: kernel 1 on packed weights (K <= 80)
+    bool fused_pack = false;   // kernel 1A packs (w_eff, w_eff b) of its rows into LDS itself: no fsnap_pack_weights_k launch
 };
+
+// widest system the accumulator-resident kernel 1A takes (NB = 9 column blocks: the ACE width 142 of
+// examples/Ta_PACE_RIDGE); option acc_max_k = 128 sends 129 ... 144 columns back to the tiled kernel (A/B)
+inline bool use_tiled(const fsnap_ctx* ctx) {
+    const bool acc_kernel = ctx->opt_kernel == 0 || ctx->opt_kernel == 7;    // the A/B kernels stop at 128 columns
+    return ctx->opt_tiled || ctx->K > (acc_kernel ? ctx->opt_acc_max_k : 128);
+}
 
 int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
     const int K = (int)ctx->K;
@@ -71,6 +81,8 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
         g->split = 1;
         g->threads = 256;
         g->acc = true;
+        // fused packing: the workgroup's per-row pairs must fit the LDS; the row-space passes bring pairs of their own
+        g->fused_pack = ctx->opt_fused_pack && !ctx->wpack_override && cpw <= fsnap::syrk_acc_max_fused_cpw();
         return FSNAP_OK;
     }
     if (g->NB >= 6 && ctx->opt_kernel != 1) {
@@ -434,7 +446,7 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
     int rc;
     ctx->mirror_of = nullptr;
     if ((rc = check_rows(ctx)) || (rc = check_weights(ctx))) return rc;
-    if (ctx->K > 128 || ctx->opt_tiled) return launch_normal_eq_tiled(ctx, d_packed, accumulate);
+    if (use_tiled(ctx)) return launch_normal_eq_tiled(ctx, d_packed, accumulate);
     Geometry g;
     if ((rc = plan_geometry(ctx, &g))) return rc;
     const unsigned char* mask = ctx->dmask;
@@ -466,7 +478,9 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
     a.spart = (double*)ctx->spart.p;
     int ns = -1;                      // scalar partials: from the SYRK kernel, or (kernel 1A) from the weight packing
     const double* spart_src = a.spart;
-    if (g.acc || g.packed) {
+    if (g.acc && g.fused_pack) {
+        a.fused_pack = true;          // b, w, mask -> pairs in LDS + the b-only scalars per row-wave, inside the SYRK launch
+    } else if (g.acc || g.packed) {
         int npk = 0;
         if ((rc = ensure_wpack(ctx, &npk))) return rc;
         a.wpack = ctx->wpack_override ? ctx->wpack_override : (const double*)ctx->wpack.p;
@@ -506,14 +520,16 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
             ctx->mirror_ev = nullptr;
         if (ctx->mirror && ctx->mirror_ev) mirror = ctx->mirror;
     }
+    const bool upper_mirror = mirror && ctx->opt_mirror_upper && ctx->opt_reduce == 0;
     FSNAP_HIP(fsnap::launch_reduce(a.part, a.cpart, spart_src, g.nblocks, cs_per_block, ns, a.K, d_packed, mirror, accumulate,
-                                   ctx->stream),
+                                   ctx->stream, ctx->opt_reduce, upper_mirror),
               "launch fsnap_reduce_partials");
     if (evs) FSNAP_HIP(hipEventRecord(evs[2], ctx->stream), "hipEventRecord");
     if (mirror) {
         FSNAP_HIP(hipEventRecord(ctx->mirror_ev, ctx->stream), "hipEventRecord");
         ctx->mirror_of = d_packed;
         ctx->mirror_K = ctx->K;
+        ctx->mirror_upper = upper_mirror;
     }
     if (evs) ctx->t_syrk = true;
     return FSNAP_OK;
@@ -703,6 +719,17 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
     } else if (!strcmp(key, "dist_solve")) {
         if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "dist_solve must be 0 (solve on every rank) or 1 (rank 0 solves and broadcasts)");
         ctx->opt_dist_solve = (int)value;
+    } else if (!strcmp(key, "reduce")) {
+        if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "reduce must be 0 (kernel 2b) or 1 (kernel 2)");
+        ctx->opt_reduce = (int)value;
+    } else if (!strcmp(key, "mirror_upper")) {
+        ctx->opt_mirror_upper = value != 0;
+    } else if (!strcmp(key, "fused_pack")) {
+        ctx->opt_fused_pack = value != 0;
+    } else if (!strcmp(key, "acc_max_k")) {
+        if (value != 128 && value != 144) return ctx->fail(FSNAP_E_ARG, "acc_max_k must be 128 or 144");
+        ctx->opt_acc_max_k = (int)value;
+        ctx->tplan_valid = false;
     } else if (!strcmp(key, "nsplit")) {
         if (value < 0 || value > (1 << 24)) return ctx->fail(FSNAP_E_ARG, "nsplit out of range");
         ctx->opt_nsplit = (int)value;
@@ -1105,6 +1132,7 @@ int fsnap_mirror_packed(fsnap_ctx* ctx, const double* d_packed, int64_t K) {
     FSNAP_HIP(hipEventRecord(ctx->mirror_ev, ctx->stream), "hipEventRecord");
     ctx->mirror_of = d_packed;
     ctx->mirror_K = K;
+    ctx->mirror_upper = false;
     return FSNAP_OK;
 }
 
@@ -1368,7 +1396,8 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
         int wrc;
         if ((wrc = fsnap::wait_stream(ctx, ctx->mirror_ev, "statistics mirror"))) return wrc;
         const double* Gm = ctx->mirror;
-        const int rcm = fsnap_solve_diag(kind, param, K, Gm, rhs ? rhs : Gm + K * K, Gm + K * K + K + 3, beta, rank, rcond_est);
+        const int rcm = (ctx->mirror_upper ? fsnap_solve_diag_upper : fsnap_solve_diag)(kind, param, K, Gm, rhs ? rhs : Gm + K * K,
+                                                                                         Gm + K * K + K + 3, beta, rank, rcond_est);
         if (rcm) ctx->fail(rcm, "fsnap_solve: numerical status %d", rcm);
         return rcm;
     }
@@ -1621,7 +1650,7 @@ int fsnap_launch_info(fsnap_ctx* ctx, int64_t* info, int n) {
     int rc;
     if ((rc = check_rows(ctx))) return rc;
     int64_t out[8] = {0, 0, 0, 0, 0, ctx->num_cu, 0, 0};
-    if (ctx->K > 128 || ctx->opt_tiled) {
+    if (use_tiled(ctx)) {
         TiledGeometry t;
         if ((rc = plan_tiled(ctx, &t))) return rc;
         out[0] = (int64_t)(t.items_per_split > 0 ? t.items_per_split : t.npairs) * t.nsplit;
@@ -1639,7 +1668,8 @@ int fsnap_launch_info(fsnap_ctx* ctx, int64_t* info, int n) {
         out[2] = g.cpw;
         out[3] = g.NB;
         out[4] = g.split;
-        out[6] = g.acc ? 3 : (g.packed ? 4 : (g.lds_waves ? 2 : 1));  // kernel id: 1 = wave-triangle, 2 = LDS-shared, 3 = one-wave triangle (1A), 4 = wave-triangle on packed weights (1P)
+        out[6] = g.acc ? 3 : (g.packed ? 4 : (g.lds_waves ? 2 : 1));
+        out[7] = g.fused_pack ? 1 : 0;  // kernel id: 1 = wave-triangle, 2 = LDS-shared, 3 = one-wave triangle (1A), 4 = wave-triangle on packed weights (1P)
     }
     for (int i = 0; i < n; ++i) info[i] = out[i];
     return FSNAP_OK;

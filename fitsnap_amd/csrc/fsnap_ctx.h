@@ -100,6 +100,7 @@ struct fsnap_ctx {
     size_t mirror_bytes = 0;
     const double* mirror_of = nullptr;            // device buffer the mirror currently reflects (nullptr = stale)
     int64_t mirror_K = 0;                         // order of the system in the mirror
+    bool mirror_upper = false;                    // only the upper triangle of the mirror's G is meaningful (kernel 2b)
     hipEvent_t mirror_ev = nullptr;               // recorded after the reduction that filled the mirror
     // options
     int opt_split = 0;        // 0 = auto
@@ -141,6 +142,10 @@ struct fsnap_ctx {
     void* dense_pinv_user = nullptr;
     int64_t dense_pinv_token = 0;
     DevBuf commbuf;                               // device staging of host-buffer collectives
+    int opt_reduce = 0;       // reduction of kernel 1 / 1A / 1P partials: 0 = kernel 2b, 1 = kernel 2 (A/B)
+    int opt_mirror_upper = 1; // kernel 2b writes the host mirror's triangle once per element (upper positions)
+    int opt_fused_pack = 1;   // kernel 1A forms the per-row pairs of its rows in LDS itself (no packing launch) when they fit
+    int opt_acc_max_k = 144;  // widest system on kernel 1A (144 = nine column blocks; 128: 129 ... 144 columns on the tiled kernel)
     int opt_repack = 0;       // 1 = pack (w_eff, w_eff b) on every launch even when b / w / mask are context-owned
     int opt_comm_timeout = 0; // seconds; 0 = FSNAP_COMM_TIMEOUT (default 300): bound of every wait behind a collective of THIS context
     int opt_dist_solve = 0;   // fsnap_fit_dist: 0 = all-reduce + solve on every rank, 1 = reduce to rank 0 + solve there + broadcast beta

@@ -25,6 +25,8 @@ struct SyrkArgs {
     double* spart;              // [nblocks*4][4]
     const double* wpack = nullptr;  // kernel 1A: packed (w_eff, w_eff * b) per row (launch_pack_weights)
     bool interleave = false;        // kernel 1P: row-waves take every NW-th chunk instead of a contiguous range
+    bool fused_pack = false;        // kernel 1A: the kernel packs (w_eff, w_eff b) of its rows into LDS itself (b, w, mask,
+                                    // spart instead of wpack; needs chunks_per_wave <= syrk_acc_max_fused_cpw())
 };
 
 struct TiledArgs {
@@ -56,11 +58,15 @@ hipError_t launch_syrk(const SyrkArgs& a, hipStream_t st);
 hipError_t launch_syrk_wave_p(const SyrkArgs& a, hipStream_t st);   // K <= 80, packed weights (a.wpack)
 hipError_t launch_syrk_lds(const SyrkArgs& a, hipStream_t st);
 hipError_t launch_syrk_acc(const SyrkArgs& a, hipStream_t st);
+int64_t syrk_acc_max_fused_cpw();
 // mirror: optional page-locked HOST buffer that receives the same packed statistics (zero-copy D2H)
 // accumulate: out += statistics instead of out = statistics
 // ns: number of scalar partials in spart (< 0: nblocks * cs_per_block, like the c partials)
+// variant: 0 = kernel 2b (all loads of a thread in flight), 1 = kernel 2 (A/B); upper_mirror: the mirror receives the
+// triangle at its upper positions only (kernel 2b)
 hipError_t launch_reduce(const double* part, const double* cpart, const double* spart, int nblocks,
-                         int cs_per_block, int ns, int K, double* out, double* mirror, bool accumulate, hipStream_t st);
+                         int cs_per_block, int ns, int K, double* out, double* mirror, bool accumulate, hipStream_t st,
+                         int variant = 0, bool upper_mirror = false);
 int pack_weights_num_blocks(int64_t m);
 // wpack[m][2] = (w_eff, w_eff * b); spart[pack_weights_num_blocks(m)][4] = partial b^T W^2 b, sum(w b), n_train, 0
 hipError_t launch_pack_weights(const double* b, const double* w, const unsigned char* mask, int64_t m, double* wpack,

@@ -641,6 +641,12 @@ struct PhaseTimer {   // FSNAP_SOLVE_TIMING=1: print the phases of the fast path
 
 extern "C" int fsnap_solve_diag(int kind, double param, int64_t K64, const double* G, const double* c, const double* diag,
                                 double* beta, int* rank_out, double* rcond_est);
+extern "C" int fsnap_solve_diag_upper(int kind, double param, int64_t K64, const double* G, const double* c, const double* diag,
+                                      double* beta, int* rank_out, double* rcond_est);
+namespace {
+int solve_impl(int kind, double param, int64_t K64, const double* G, const double* c, const double* diag, double* beta,
+               int* rank_out, double* rcond_est, bool upper_only);
+}
 
 // In-place Cholesky U^T U of an n x n row-major matrix for the other translation units of the library (the row-space
 // passes, fsnap_rowspace.cpp): upper triangle in, U out, lower triangle must be zero on entry; n a multiple of 32 runs
@@ -659,6 +665,20 @@ extern "C" int fsnap_solve(int kind, double param, int64_t K64, const double* G,
 extern "C" __attribute__((visibility("hidden"))) int fsnap_solve_diag(int kind, double param, int64_t K64, const double* G,
                                                                       const double* c, const double* diag, double* beta,
                                                                       int* rank_out, double* rcond_est) {
+    return solve_impl(kind, param, K64, G, c, diag, beta, rank_out, rcond_est, false);
+}
+
+// the same on a matrix of which only the UPPER triangle (row i: columns >= i) is meaningful -- the host mirror the
+// reduction kernel fills with one PCIe write per element; whatever sits below the diagonal is never read
+extern "C" __attribute__((visibility("hidden"))) int fsnap_solve_diag_upper(int kind, double param, int64_t K64, const double* G,
+                                                                            const double* c, const double* diag, double* beta,
+                                                                            int* rank_out, double* rcond_est) {
+    return solve_impl(kind, param, K64, G, c, diag, beta, rank_out, rcond_est, true);
+}
+
+namespace {
+int solve_impl(int kind, double param, int64_t K64, const double* G, const double* c, const double* diag, double* beta,
+               int* rank_out, double* rcond_est, bool upper_only) {
     PhaseTimer timer;
     if (!G || !c || !beta || K64 <= 0 || K64 > (1 << 20)) return FSNAP_E_ARG;
     if (kind < FSNAP_SOLVE_CHOL || kind > FSNAP_SOLVE_RIDGE_INV_PROBE) return FSNAP_E_ARG;
@@ -716,6 +736,16 @@ extern "C" __attribute__((visibility("hidden"))) int fsnap_solve_diag(int kind, 
                 }
                 int j = 0;
                 for (; j + 8 <= j0; j += 8) *(v8du*)(ui + j) = zero;
+                if (upper_only && j + 8 <= K) {
+                    // the vector that holds the diagonal: what lies left of it was never written by the device
+                    typedef long long v8l __attribute__((vector_size(64)));
+                    const v8l lanes = {0, 1, 2, 3, 4, 5, 6, 7};
+                    const v8l keep = (lanes + (long long)j) >= (long long)i;
+                    const v8d g0 = (v8d)((v8l)(*(const v8du*)(gi + j)) & keep);
+                    chk0 += g0 * zero;
+                    *(v8du*)(ui + j) = g0 * dv * *(const v8du*)(dsc.data() + j);
+                    j += 8;
+                }
                 for (; j + 16 <= K; j += 16) {
                     const v8d g0 = *(const v8du*)(gi + j), g1 = *(const v8du*)(gi + j + 8);
                     chk0 += g0 * zero;
@@ -723,9 +753,15 @@ extern "C" __attribute__((visibility("hidden"))) int fsnap_solve_diag(int kind, 
                     *(v8du*)(ui + j) = g0 * dv * *(const v8du*)(dsc.data() + j);
                     *(v8du*)(ui + j + 8) = g1 * dv * *(const v8du*)(dsc.data() + j + 8);
                 }
+                for (; j + 8 <= K; j += 8) {
+                    const v8d g0 = *(const v8du*)(gi + j);
+                    chk0 += g0 * zero;
+                    *(v8du*)(ui + j) = g0 * dv * *(const v8du*)(dsc.data() + j);
+                }
                 for (; j < K; ++j) {
-                    ui[j] = gi[j] * di * dsc[j];
-                    chk += gi[j] * 0.0;
+                    const double gij = (upper_only && j < i) ? 0.0 : gi[j];
+                    ui[j] = gij * di * dsc[j];
+                    chk += gij * 0.0;
                 }
                 for (; j < Kp; ++j) ui[j] = 0.0;
                 ui[i] = (gi[i] + alpha) * di * di;
@@ -756,6 +792,13 @@ extern "C" __attribute__((visibility("hidden"))) int fsnap_solve_diag(int kind, 
         }
     }
 
+    static thread_local vec Gfull;
+    if (upper_only) {                    // the general path reads both triangles: mirror the meaningful one
+        Gfull.resize((size_t)K * K);
+        for (int i = 0; i < K; ++i)
+            for (int j = i; j < K; ++j) Gfull[(size_t)i * K + j] = Gfull[(size_t)j * K + i] = G[(size_t)i * K + j];
+        G = Gfull.data();
+    }
     if (!all_finite(G, (size_t)K * K) || !all_finite(c, K)) return FSNAP_NUM_NONFINITE;
     // active columns: drop exactly-zero columns when there is no ridge shift
     static thread_local Reduced R;
@@ -836,6 +879,8 @@ extern "C" __attribute__((visibility("hidden"))) int fsnap_solve_diag(int kind, 
     }
     return FSNAP_E_ARG;
 }
+
+}  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
 // LASSO on the statistics (fitsnap3lib/solvers/lasso.py:17-29: sklearn Lasso(alpha, fit_intercept=False, max_iter) on

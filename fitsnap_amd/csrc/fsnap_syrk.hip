@@ -373,8 +373,8 @@ __device__ unsigned long long fsnap_trace_wave[4096 * 16 * 4];
 // ---------------------------------------------------------------------------------
 namespace {
 
-template <int T>
-__device__ __forceinline__ void acc_mfma(double a, double b, d4 (&vt)[4]) {
+template <int T, int NV>
+__device__ __forceinline__ void acc_mfma(double a, double b, d4 (&vt)[NV]) {
     if constexpr (T < 32) {
         asm volatile("v_mfma_f64_16x16x4_f64 a[%2:%3], %0, %1, a[%2:%3]" : : "v"(a), "v"(b), "n"(8 * T), "n"(8 * T + 7));
     } else {
@@ -391,8 +391,8 @@ __device__ __forceinline__ void acc_zero_all(std::integer_sequence<int, R...>) {
     (acc_zero_reg<R>(), ...);
 }
 
-template <int T>
-__device__ __forceinline__ d4 acc_read(const d4 (&vt)[4]) {
+template <int T, int NV>
+__device__ __forceinline__ d4 acc_read(const d4 (&vt)[NV]) {
     if constexpr (T >= 32) {
         return vt[T - 32];
     } else {
@@ -414,15 +414,15 @@ __device__ __forceinline__ d4 acc_read(const d4 (&vt)[4]) {
     }
 }
 
-template <int TB, int N, int... U>
-__device__ __forceinline__ void acc_read_range(d4 (&tmp)[N], const d4 (&vt)[4], std::integer_sequence<int, U...>) {
-    ((tmp[U] = acc_read<TB + U>(vt)), ...);
+template <int TB, int N, int NV, int... U>
+__device__ __forceinline__ void acc_read_range(d4 (&tmp)[N], const d4 (&vt)[NV], std::integer_sequence<int, U...>) {
+    ((tmp[U] = acc_read<TB + U, NV>(vt)), ...);
 }
 
 // row p of the triangle: tiles (p, p..NB-1)
-template <int NB, int P, int... Q>
-__device__ __forceinline__ void acc_row(const double (&V)[NB], d4 (&vt)[4], std::integer_sequence<int, Q...>) {
-    (acc_mfma<tri_index(P, P + Q, NB)>(V[P], V[P + Q], vt), ...);
+template <int NB, int P, int NV, int... Q>
+__device__ __forceinline__ void acc_row(const double (&V)[NB], d4 (&vt)[NV], std::integer_sequence<int, Q...>) {
+    (acc_mfma<tri_index(P, P + Q, NB), NV>(V[P], V[P + Q], vt), ...);
 }
 
 // Raw loads of kernel 1A.  Per row the kernel needs three numbers that do not depend on A: keep (training row?),
@@ -527,6 +527,69 @@ __device__ __forceinline__ double weighted_block(const RawM<NB>& r, int j, doubl
     return (32 * (j >> 1) + 2 * e + (j & 1) < K) ? x : 0.0;
 }
 
+// The packed pair of chunk cl.  PACK = false: from the wpack array in HBM (fsnap_pack_weights_k, or the per-row pairs
+// of a row-space pass).  PACK = true: from the wave's own LDS region, filled by the kernel's prologue (pack_rows_to_lds)
+// -- lpk = region + 2 * kr doubles; lanes of one row group read the same 16 bytes (broadcast).
+template <bool PACK>
+__device__ __forceinline__ u4 load_pack_x(const WaveBufsP& wb, const double* lpk, unsigned cl) {
+    if constexpr (PACK) return __builtin_bit_cast(u4, *reinterpret_cast<const d2*>(lpk + (size_t)cl * 8));
+    else return load_pack(wb, cl);
+}
+
+// Prologue of kernel 1A with PACK = true: the wave forms (w_eff, w_eff b) of ITS rows in its own LDS region -- what
+// fsnap_pack_weights_k wrote to HBM in a launch of its own (9.8 us + a stream boundary in front of every fit whose
+// weights changed) -- and the three statistics that do not involve A.  region_rows = 4 x (chunks per wave + the
+// overshoot of the unrolled loop); rows past the wave's range read zeros through the bounds-checked descriptors and
+// become (0, 0) pairs, which is what the loop's look-ahead expects there.  PB x 3 loads in flight per lane.
+__device__ __forceinline__ void pack_rows_to_lds(const double* __restrict__ b, const double* __restrict__ w,
+                                                 const unsigned char* __restrict__ mask, int64_t row0, int64_t nrow,
+                                                 unsigned region_rows, double* lpw, int lane, double* sout) {
+    constexpr int PB = 8;
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(b + row0, (unsigned)(nrow * 8));
+    const __amdgpu_buffer_rsrc_t rw_ = make_rsrc(w + row0, (unsigned)(nrow * 8));
+    const __amdgpu_buffer_rsrc_t rm = make_rsrc(mask + row0, (unsigned)nrow);
+    double bb = 0.0, sb = 0.0, cnt = 0.0;
+    for (unsigned r0 = 0; r0 < region_rows; r0 += 64u * PB) {
+        u2 bv[PB], wv[PB];
+        unsigned char mk[PB];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const unsigned row = r0 + 64u * u + (unsigned)lane;
+            bv[u] = __builtin_amdgcn_raw_buffer_load_b64(rb, row * 8u, 0, 0);
+            wv[u] = __builtin_amdgcn_raw_buffer_load_b64(rw_, row * 8u, 0, 0);
+            mk[u] = __builtin_amdgcn_raw_buffer_load_b8(rm, row, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const unsigned row = r0 + 64u * u + (unsigned)lane;
+            const bool keep = (mk[u] != 0);
+            const double wvv = keep ? __builtin_bit_cast(double, wv[u]) : 0.0;
+            const double wbv = keep ? wvv * __builtin_bit_cast(double, bv[u]) : 0.0;
+            if (row < region_rows) {
+                d2 o;
+                o[0] = wvv;
+                o[1] = wbv;
+                *reinterpret_cast<d2*>(lpw + (size_t)row * 2) = o;
+            }
+            bb = __builtin_fma(wbv, wbv, bb);
+            sb += wbv;
+            cnt += keep ? 1.0 : 0.0;
+        }
+    }
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) {       // fixed butterfly: deterministic
+        bb += __shfl_xor(bb, sh, 64);
+        sb += __shfl_xor(sb, sh, 64);
+        cnt += __shfl_xor(cnt, sh, 64);
+    }
+    if (lane == 0) {
+        sout[0] = bb;
+        sout[1] = sb;
+        sout[2] = cnt;
+        sout[3] = 0.0;
+    }
+}
+
 // Slot P of a step (between row P and row P + 1 of the MFMAs).  The pieces are independent of each other (a wave
 // issues in order: a dependent chain here would hold back row P + 1):
 //   V[P] <- w * raw block P        cacc[P-1] += V[P-1] * wbv        one load of the refill
@@ -549,18 +612,19 @@ __device__ __forceinline__ void acc_slot(double (&V)[NB], const RawM<NB>& RN, do
 // packed weights PKEEP of that chunk, which were loaded TWO steps ago: the packed pairs stream from HBM like the
 // rows, and a wave that needs one only a step (~1 us) after issuing its load stalls on it (the packs live in a ring of
 // six registers of their own, PLOAD is the slot for chunk c + 5).  The packed load goes out BEFORE the row loads:
-// vmcnt retires in order, so a later wait for it does not drain the row loads issued here.
-template <int NB, bool FULLK, bool NT, int... P>
-__device__ __forceinline__ void acc_step(double (&V)[NB], d4 (&vt)[4], RawM<NB>& RF, const RawM<NB>& RN, const WaveBufsP& wb,
-                                         unsigned cl_fill, int K, int e, double (&cacc)[NB], double& wbp, const u4& PW,
-                                         const u4& PKEEP, u4& PLOAD, std::integer_sequence<int, P...>) {
+// vmcnt retires in order, so a later wait for it does not drain the row loads issued here.  (PACK: the pairs come
+// from LDS with the same ring; the distance is then far more than the ~100 cycles an LDS read takes.)
+template <int NB, bool FULLK, bool NT, bool PACK, int NV, int... P>
+__device__ __forceinline__ void acc_step(double (&V)[NB], d4 (&vt)[NV], RawM<NB>& RF, const RawM<NB>& RN, const WaveBufsP& wb,
+                                         const double* lpk, unsigned cl_fill, int K, int e, double (&cacc)[NB], double& wbp,
+                                         const u4& PW, const u4& PKEEP, u4& PLOAD, std::integer_sequence<int, P...>) {
     const d2 wpn = __builtin_bit_cast(d2, PW);
     const double wv = wpn[0], wbv = wpn[1];
     const bool keep = pack_keep(PKEEP);
     const unsigned va = keep ? wb.voffA : FSNAP_OOB_VOFF;
     const unsigned vtl = (NB & 1) ? (keep ? wb.voffT : FSNAP_OOB_VOFF) : 0u;
 #if !defined(FSNAP_ACC_ABL) || !(FSNAP_ACC_ABL & 1)   // tools/syrk_trace.hip diagnostics: 1 = no loads, 2 = no VALU work
-    PLOAD = load_pack(wb, cl_fill + 2);
+    PLOAD = load_pack_x<PACK>(wb, lpk, cl_fill + 2);
 #endif
     __builtin_amdgcn_sched_barrier(0);
 #if defined(FSNAP_ACC_ABL) && (FSNAP_ACC_ABL & 2)
@@ -573,16 +637,27 @@ __device__ __forceinline__ void acc_step(double (&V)[NB], d4 (&vt)[4], RawM<NB>&
 #endif
 }
 
+// LDS of kernel 1A: all 160 KiB of the CU (one workgroup per CU).  The epilogue folds the four row-waves' triangles
+// through it in parts of at most 20 tiles (4 slots x 20 x 2 KiB); with PACK the same space first holds the per-row
+// pairs of the workgroup's rows: 4 x (chunks per wave + FSNAP_ACC_PACK_PAD) x 64 bytes.
+constexpr int FSNAP_ACC_LDS_DOUBLES = 20480;
+constexpr int FSNAP_ACC_PACK_PAD = 12;     // chunk slots the unrolled loop may look past a wave's last chunk (<= ncl + 9)
+
 }  // namespace
 
-template <int NB, bool FULLK, bool NT>
+template <int NB, bool FULLK, bool NT, bool PACK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restrict__ wpack, int64_t m, int K,
-               int64_t chunks_per_wave, double* __restrict__ part, double* __restrict__ cpart) {
+               int64_t chunks_per_wave, double* __restrict__ part, double* __restrict__ cpart,
+               const double* __restrict__ bvec, const double* __restrict__ wvec, const unsigned char* __restrict__ mask,
+               double* __restrict__ spart) {
 
     constexpr int NTILE = NB * (NB + 1) / 2;
-    constexpr int HALF = (NTILE + 1) / 2;
-    __shared__ double lds[4 * HALF * 256];
+    constexpr int NV = NTILE > 32 ? NTILE - 32 : 1;      // tiles beyond the 32 that fill a[0:255] live in VGPRs
+    constexpr int NPART = (NTILE * 1024 + FSNAP_ACC_LDS_DOUBLES - 1) / FSNAP_ACC_LDS_DOUBLES;
+    constexpr int PER = (NTILE + NPART - 1) / NPART;     // tiles per part of the epilogue fold (NB = 8: 18, NB = 9: 15)
+    static_assert(4 * PER * 256 <= FSNAP_ACC_LDS_DOUBLES, "fold part does not fit the LDS");
+    __shared__ __attribute__((aligned(16))) double lds[FSNAP_ACC_LDS_DOUBLES];
 #ifdef FSNAP_TRACE
     const unsigned long long trace_t0 = wall_clock64();
     const unsigned long long trace_c0 = __builtin_readcyclecounter();
@@ -601,20 +676,28 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
     const int64_t nrow = row1 > row0 ? row1 - row0 : 0;
     WaveBufsP wb;
     wb.A = make_rsrc(A + row0 * lda, (unsigned)(nrow * lda * 8 + (nrow ? 16 : 0)));
-    wb.wp = make_rsrc(wpack + 2 * row0, (unsigned)(nrow * 16));
+    wb.wp = make_rsrc(PACK ? nullptr : wpack + 2 * row0, PACK ? 0u : (unsigned)(nrow * 16));
     wb.voffA = (unsigned)((kr * lda + 2 * e) * 8);
     wb.voffT = (unsigned)((kr * lda + 16 * (NB - 1) + e) * 8);
     wb.voffP = (unsigned)(kr * 16);
     wb.chunk_bytes = (unsigned)(lda * 32);
     const unsigned ncl = (unsigned)(c1 - c0);
 
+    const double* lpk = nullptr;
+    if constexpr (PACK) {
+        const unsigned region_rows = (unsigned)(chunks_per_wave + FSNAP_ACC_PACK_PAD) * 4u;
+        double* lpw = lds + (size_t)rw * region_rows * 2;
+        pack_rows_to_lds(bvec, wvec, mask, row0, nrow, region_rows, lpw, lane, spart + rowwave * 4);
+        lpk = lpw + 2 * kr;
+    }
+
     // the compiler must count a[0:255] as used (register allocation granule of the kernel descriptor): the
     // clobber makes its resource analysis see the highest accumulation register
     asm volatile("" : : : "a0", "a255");
     acc_zero_all(std::make_integer_sequence<int, 256>{});
-    d4 vt[4];
+    d4 vt[NV];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) vt[u] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int u = 0; u < NV; ++u) vt[u] = d4{0.0, 0.0, 0.0, 0.0};
     double cacc[NB], V[NB];
 #pragma unroll
     for (int p = 0; p < NB; ++p) cacc[p] = 0.0;
@@ -622,9 +705,9 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
     RawM<NB> r0, r1, r2;
     constexpr auto rows = std::make_integer_sequence<int, NB>{};
     if (ncl > 0) {
-        r0.wp = load_pack(wb, 0);
-        r1.wp = load_pack(wb, 1);
-        r2.wp = load_pack(wb, 2);
+        r0.wp = load_pack_x<PACK>(wb, lpk, 0);
+        r1.wp = load_pack_x<PACK>(wb, lpk, 1);
+        r2.wp = load_pack_x<PACK>(wb, lpk, 2);
         issue_rows<NB, NT>(r0, wb, 0);
         issue_rows<NB, NT>(r1, wb, 1);
         issue_rows<NB, NT>(r2, wb, 2);
@@ -639,23 +722,26 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
         }
         // ring of packed weights: slot (c mod 6) holds the pair of chunk c; steps use c + 1 (weights), c + 3 (row
         // mask of the refill) and load c + 5
-        u4 pk0 = r0.wp, pk1 = r1.wp, pk2 = r2.wp, pk3 = load_pack(wb, 3), pk4 = load_pack(wb, 4), pk5 = {0u, 0u, 0u, 0u};
+        u4 pk0 = r0.wp, pk1 = r1.wp, pk2 = r2.wp, pk3 = load_pack_x<PACK>(wb, lpk, 3), pk4 = load_pack_x<PACK>(wb, lpk, 4),
+           pk5 = {0u, 0u, 0u, 0u};
         (void)pk0;
         // step cl: MFMAs of chunk cl (in V), V <- chunk cl+1, rows of chunk cl+3 into the raw set freed one step ago,
         // packed weights of chunk cl+5.  Chunk slots past the wave's range read zeros (bounds-checked descriptors).
         double wbp = 0.0;   // chunk 0 is fully accounted for by the prologue
         for (unsigned cl = 0; cl < ncl; cl += 6) {
-            acc_step<NB, FULLK, NT>(V, vt, r0, r1, wb, cl + 3, K, e, cacc, wbp, pk1, pk3, pk5, rows);
-            acc_step<NB, FULLK, NT>(V, vt, r1, r2, wb, cl + 4, K, e, cacc, wbp, pk2, pk4, pk0, rows);
-            acc_step<NB, FULLK, NT>(V, vt, r2, r0, wb, cl + 5, K, e, cacc, wbp, pk3, pk5, pk1, rows);
-            acc_step<NB, FULLK, NT>(V, vt, r0, r1, wb, cl + 6, K, e, cacc, wbp, pk4, pk0, pk2, rows);
-            acc_step<NB, FULLK, NT>(V, vt, r1, r2, wb, cl + 7, K, e, cacc, wbp, pk5, pk1, pk3, rows);
-            acc_step<NB, FULLK, NT>(V, vt, r2, r0, wb, cl + 8, K, e, cacc, wbp, pk0, pk2, pk4, rows);
+            acc_step<NB, FULLK, NT, PACK>(V, vt, r0, r1, wb, lpk, cl + 3, K, e, cacc, wbp, pk1, pk3, pk5, rows);
+            acc_step<NB, FULLK, NT, PACK>(V, vt, r1, r2, wb, lpk, cl + 4, K, e, cacc, wbp, pk2, pk4, pk0, rows);
+            acc_step<NB, FULLK, NT, PACK>(V, vt, r2, r0, wb, lpk, cl + 5, K, e, cacc, wbp, pk3, pk5, pk1, rows);
+            acc_step<NB, FULLK, NT, PACK>(V, vt, r0, r1, wb, lpk, cl + 6, K, e, cacc, wbp, pk4, pk0, pk2, rows);
+            acc_step<NB, FULLK, NT, PACK>(V, vt, r1, r2, wb, lpk, cl + 7, K, e, cacc, wbp, pk5, pk1, pk3, rows);
+            acc_step<NB, FULLK, NT, PACK>(V, vt, r2, r0, wb, lpk, cl + 8, K, e, cacc, wbp, pk0, pk2, pk4, rows);
         }
         cacc[NB - 1] = __builtin_fma(V[NB - 1], wbp, cacc[NB - 1]);   // last prepared chunk (zeros past the range)
     }
     // the last MFMAs (16 passes) must have left the pipe before their accumulators are read
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(vt[0]), "+v"(vt[1]), "+v"(vt[2]), "+v"(vt[3]));
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(vt[0]));
+#pragma unroll
+    for (int u = 1; u < NV; ++u) asm volatile("" : "+v"(vt[u]));
 #ifdef FSNAP_TRACE
     if (threadIdx.x == 0 && blockIdx.x < 4096) {   // loop only (the epilogue is timed by the kernel duration)
         const int64_t wg = blockIdx.x;
@@ -667,16 +753,17 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
     }
 #endif
 
-    // epilogue: fold the four row-waves through LDS in two halves of the triangle.  Every wave parks its tiles of
-    // the half (4 slots x HALF tiles x 2 KiB = 144 KiB at K = 128), then wave r sums a quarter of the tiles over the
+    // epilogue: fold the four row-waves through LDS in NPART parts of the triangle.  Every wave parks its tiles of
+    // the part (4 slots x PER tiles x 2 KiB = 144 KiB at K = 128), then wave r sums a quarter of the tiles over the
     // four slots in a fixed order and stores them: one partial triangle per workgroup, all four waves busy.
+    if constexpr (PACK) __syncthreads();       // the other waves may still be reading their pairs from this space
     double* pw = part + (int64_t)blockIdx.x * (int64_t)(NTILE * 256);
-    auto fold_half = [&](auto half_tag) {
-        constexpr int H = decltype(half_tag)::value;
-        constexpr int TB = H * HALF;
-        constexpr int NT_H = (TB + HALF <= NTILE) ? HALF : (NTILE - TB);
+    auto fold_part = [&](auto part_tag) {
+        constexpr int H = decltype(part_tag)::value;
+        constexpr int TB = H * PER;
+        constexpr int NT_H = (TB + PER <= NTILE) ? PER : (NTILE - TB);
         constexpr int Q = (NT_H + 3) / 4;
-        double* slot = lds + (size_t)rw * HALF * 256;
+        double* slot = lds + (size_t)rw * PER * 256;
         {
             d4 tmp[NT_H];
             acc_read_range<TB>(tmp, vt, std::make_integer_sequence<int, NT_H>{});
@@ -690,14 +777,13 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int o = (u * 4 + i) * 64 + lane;
-                const double s01 = lds[o] + lds[HALF * 256 + o];
-                pw[((TB + u) * 4 + i) * 64 + lane] = (s01 + lds[2 * HALF * 256 + o]) + lds[3 * HALF * 256 + o];
+                const double s01 = lds[o] + lds[PER * 256 + o];
+                pw[((TB + u) * 4 + i) * 64 + lane] = (s01 + lds[2 * PER * 256 + o]) + lds[3 * PER * 256 + o];
             }
         }
-        if (H == 0) __syncthreads();
+        if (H + 1 < NPART) __syncthreads();
     };
-    fold_half(std::integral_constant<int, 0>{});
-    fold_half(std::integral_constant<int, 1>{});
+    wave_p_for<NPART>(fold_part);
 
     double* cw = cpart + rowwave * (int64_t)(NB * 16);
 #pragma unroll
@@ -972,6 +1058,105 @@ __global__ __launch_bounds__(1024) void fsnap_reduce_partials(const double* __re
                 if (mirror) mirror[(int64_t)K * K + K + j] = val;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 2b: the same reduction with every load of a thread in flight at once (default; option reduce = 1 keeps
+// kernel 2 for A/B).  Kernel 2 gives a thread 8-byte loads and, for the 256 partials of a one-workgroup-per-CU launch,
+// runs them as FOUR dependent round trips (its 8-deep loop needs >= 512 partials): 12.3 us for 19 MB that sit in
+// L2 / Infinity Cache.  Here a workgroup of 256 threads owns 32 consecutive elements: thread (slice = tid >> 4,
+// sub = tid & 15) takes elements 2 sub, 2 sub + 1 (one 16-byte load per partial) of partials slice, slice + 16, ...,
+// sixteen loads in flight per batch (all of them when there are 256 partials); fixed summation order: per thread four
+// interleaved accumulators, then the 16 slices in order through LDS.  Regions (triangle | c | scalars) start on
+// workgroup boundaries.  upper_mirror: the host mirror receives every triangle element ONCE, at its upper-triangle
+// position [min(r, c)][max(r, c)] (diagonal tiles in full) -- half the PCIe writes; the host solve reads the mirror as
+// an upper triangle then (fsnap_solve_diag_upper).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsnap_reduce_partials2(const double* __restrict__ part,
+                                                              const double* __restrict__ cpart,
+                                                              const double* __restrict__ spart, int nblocks,
+                                                              int cs_per_block, int ns, int NB, int K,
+                                                              double* __restrict__ out, double* __restrict__ mirror,
+                                                              int accumulate, int upper_mirror) {
+    __shared__ __attribute__((aligned(16))) double red[16][32];
+    const int NTILE = NB * (NB + 1) / 2;
+    const int nG = NTILE * 256, nC = NB * 16;
+    const int gG = nG / 32, gC = (nC + 31) / 32;
+    const int tid = threadIdx.x, sub = tid & 15, slice = tid >> 4;
+    const int b = blockIdx.x;
+    int region, e0, nel, np;
+    const double* src;
+    int64_t stride;
+    if (b < gG) {
+        region = 0; e0 = b * 32; nel = nG; np = nblocks; src = part; stride = nG;
+    } else if (b < gG + gC) {
+        region = 1; e0 = (b - gG) * 32; nel = nC; np = nblocks * cs_per_block; src = cpart; stride = nC;
+    } else {
+        region = 2; e0 = 0; nel = 4; np = ns >= 0 ? ns : nblocks * cs_per_block; src = spart; stride = 4;
+    }
+    const int el = e0 + 2 * sub;
+    d2 a0 = {0.0, 0.0}, a1 = a0, a2 = a0, a3 = a0;
+    if (el < nel) {
+        const double* s0 = src + el;
+        int p = slice;
+        for (; p + 240 < np; p += 256) {
+            d2 x[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) x[j] = *reinterpret_cast<const d2*>(s0 + (int64_t)(p + 16 * j) * stride);
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) {
+                a0 += x[j];
+                a1 += x[j + 1];
+                a2 += x[j + 2];
+                a3 += x[j + 3];
+            }
+        }
+        for (; p < np; p += 16) a0 += *reinterpret_cast<const d2*>(s0 + (int64_t)p * stride);
+    }
+    const d2 sv = (a0 + a1) + (a2 + a3);
+    *reinterpret_cast<d2*>(&red[slice][2 * sub]) = sv;
+    __syncthreads();
+    if (tid >= 32) return;
+    const int idx = e0 + tid;
+    if (idx >= nel) return;
+    double tot = red[0][tid];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) tot += red[k][tid];
+    if (region == 0) {
+        const int t = idx >> 8, rem = idx & 255, i = rem >> 6, ln = rem & 63;
+        int p = 0;
+        while (p + 1 < NB && tri_index(p + 1, p + 1, NB) <= t) ++p;
+        const int q = p + (t - tri_index(p, p, NB));
+        const int ep = (ln >> 4) + 4 * i, eq = ln & 15;
+        const int r = col_of(p, ep, NB), c = col_of(q, eq, NB);
+        if (r < K && c < K) {
+            const double val = accumulate ? out[(int64_t)r * K + c] + tot : tot;
+            out[(int64_t)r * K + c] = val;
+            if (p != q) out[(int64_t)c * K + r] = val;
+            if (mirror) {
+                if (upper_mirror) {
+                    const int lo = r < c ? r : c, hi = r < c ? c : r;
+                    if (p != q) mirror[(int64_t)lo * K + hi] = val;
+                    else mirror[(int64_t)r * K + c] = val;
+                } else {
+                    mirror[(int64_t)r * K + c] = val;
+                    if (p != q) mirror[(int64_t)c * K + r] = val;
+                }
+                if (r == c) mirror[(int64_t)K * K + K + 3 + r] = val;
+            }
+        }
+    } else if (region == 1) {
+        const int cidx = col_of(idx >> 4, idx & 15, NB);
+        if (cidx < K) {
+            const double val = accumulate ? out[(int64_t)K * K + cidx] + tot : tot;
+            out[(int64_t)K * K + cidx] = val;
+            if (mirror) mirror[(int64_t)K * K + cidx] = val;
+        }
+    } else if (idx < 3) {
+        const double val = accumulate ? out[(int64_t)K * K + K + idx] + tot : tot;
+        out[(int64_t)K * K + K + idx] = val;
+        if (mirror) mirror[(int64_t)K * K + K + idx] = val;
     }
 }
 
@@ -2335,17 +2520,23 @@ template <int NB>
 static hipError_t launch_syrk_acc_nb(const SyrkArgs& a, hipStream_t st) {
     dim3 grid((unsigned)a.nblocks), block(256);
     const bool fullk = (a.K == 16 * NB);
-    if (!a.wpack) return hipErrorInvalidValue;
-#define FSNAP_LAUNCH(FK, NTL)                                                                                       \
-    hipLaunchKernelGGL((fsnap_syrk_acc<NB, FK, NTL>), grid, block, 0, st, a.A, a.lda, a.wpack, a.m, a.K,            \
-                       a.chunks_per_wave, a.part, a.cpart)
+    if (a.fused_pack ? (!a.b || !a.w || !a.mask || !a.spart) : !a.wpack) return hipErrorInvalidValue;
+#define FSNAP_LAUNCH(FK, NTL, PK)                                                                                   \
+    hipLaunchKernelGGL((fsnap_syrk_acc<NB, FK, NTL, PK>), grid, block, 0, st, a.A, a.lda, a.wpack, a.m, a.K,        \
+                       a.chunks_per_wave, a.part, a.cpart, a.b, a.w, a.mask, a.spart)
+#define FSNAP_LAUNCH_PK(FK, NTL)                 \
+    do {                                         \
+        if (a.fused_pack) FSNAP_LAUNCH(FK, NTL, true); \
+        else FSNAP_LAUNCH(FK, NTL, false);       \
+    } while (0)
     if (fullk) {
-        if (a.nontemporal) FSNAP_LAUNCH(true, true);
-        else FSNAP_LAUNCH(true, false);
+        if (a.nontemporal) FSNAP_LAUNCH_PK(true, true);
+        else FSNAP_LAUNCH_PK(true, false);
     } else {
-        if (a.nontemporal) FSNAP_LAUNCH(false, true);
-        else FSNAP_LAUNCH(false, false);
+        if (a.nontemporal) FSNAP_LAUNCH_PK(false, true);
+        else FSNAP_LAUNCH_PK(false, false);
     }
+#undef FSNAP_LAUNCH_PK
 #undef FSNAP_LAUNCH
     return hipGetLastError();
 }
@@ -2381,12 +2572,16 @@ hipError_t launch_syrk_wave_p(const SyrkArgs& a, hipStream_t st) {
     }
 }
 
+// LDS budget of the fused packing: chunks per wave that fit next to the look-ahead pad
+int64_t syrk_acc_max_fused_cpw() { return FSNAP_ACC_LDS_DOUBLES / 32 - FSNAP_ACC_PACK_PAD; }
+
 // kernel 1A: a.nblocks workgroups of 4 row-waves, a.chunks_per_wave chunks per row-wave
 hipError_t launch_syrk_acc(const SyrkArgs& a, hipStream_t st) {
     switch (syrk_num_blocks(a.K)) {
         case 6: return launch_syrk_acc_nb<6>(a, st);
         case 7: return launch_syrk_acc_nb<7>(a, st);
         case 8: return launch_syrk_acc_nb<8>(a, st);
+        case 9: return launch_syrk_acc_nb<9>(a, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -2414,12 +2609,19 @@ hipError_t launch_syrk(const SyrkArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_reduce(const double* part, const double* cpart, const double* spart, int nblocks,
-                         int cs_per_block, int ns, int K, double* out, double* mirror, bool accumulate, hipStream_t st) {
+                         int cs_per_block, int ns, int K, double* out, double* mirror, bool accumulate, hipStream_t st,
+                         int variant, bool upper_mirror) {
     const int NB = syrk_num_blocks(K);
-    const int nelem = NB * (NB + 1) / 2 * 256 + NB * 16 + 4;
-    dim3 grid((unsigned)((nelem + 15) / 16)), block(1024);
-    hipLaunchKernelGGL(fsnap_reduce_partials, grid, block, 0, st, part, cpart, spart, nblocks, cs_per_block, ns, NB, K, out, mirror,
-                       accumulate ? 1 : 0);
+    if (variant == 1) {       // kernel 2 (A/B)
+        const int nelem = NB * (NB + 1) / 2 * 256 + NB * 16 + 4;
+        dim3 grid((unsigned)((nelem + 15) / 16)), block(1024);
+        hipLaunchKernelGGL(fsnap_reduce_partials, grid, block, 0, st, part, cpart, spart, nblocks, cs_per_block, ns, NB, K, out,
+                           mirror, accumulate ? 1 : 0);
+        return hipGetLastError();
+    }
+    const int ngroups = NB * (NB + 1) / 2 * 8 + (NB * 16 + 31) / 32 + 1;
+    hipLaunchKernelGGL(fsnap_reduce_partials2, dim3((unsigned)ngroups), dim3(256), 0, st, part, cpart, spart, nblocks,
+                       cs_per_block, ns, NB, K, out, mirror, accumulate ? 1 : 0, upper_mirror ? 1 : 0);
     return hipGetLastError();
 }
 

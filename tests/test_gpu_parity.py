@@ -56,9 +56,11 @@ def test_ta_golden_statistics(ctx, ta, ta_fits):
     stats_close(G, c, s, *orc.normal_eq(A, b, w, t))
 
 
-@pytest.mark.parametrize("K", [1, 2, 15, 16, 17, 30, 31, 32, 33, 48, 55, 64, 79, 80, 96, 97, 110, 112, 113, 127, 128])
+@pytest.mark.parametrize("K", [1, 2, 15, 16, 17, 30, 31, 32, 33, 48, 55, 64, 79, 80, 96, 97, 110, 112, 113, 127, 128,
+                               129, 137, 142, 143, 144])
 def test_statistics_all_column_block_shapes(ctx, K):
-    # every NB (1..8), odd/even NB tails, K odd (unaligned 16-byte loads), both SPLIT paths
+    # every NB (1..9), odd/even NB tails, K odd (unaligned 16-byte loads), both SPLIT paths; 129 ... 144: kernel 1A with
+    # nine column blocks (45 tiles: 32 in the accumulation registers, 13 in VGPRs; the ACE width 142 of Ta_PACE_RIDGE)
     rng = np.random.default_rng(K)
     m = 4099 + 7 * K                      # ragged: not a multiple of 4 or of the chunk pipeline
     A = rng.standard_normal((m, K)) * (10.0 ** rng.uniform(-3, 3, size=K))
@@ -66,6 +68,8 @@ def test_statistics_all_column_block_shapes(ctx, K):
     w = rng.choice([100.0, 1.0, 1e-8], size=m, p=[0.03, 0.83, 0.14])
     t = rng.random(m) < 0.2
     G, c, s = run_stats(ctx, A, b, w, t)
+    if K > 128:
+        assert ctx.launch_info()["kernel_or_pairs"] == 3
     stats_close(G, c, s, *orc.normal_eq(A, b, w, t))
 
 
@@ -168,7 +172,7 @@ def test_kernel_variants_agree(ctx, kernel, K):
 
 
 @pytest.mark.parametrize("m", [1, 3, 4, 13, 47, 48, 49, 191, 193, 1000, 12289])
-@pytest.mark.parametrize("K", [97, 128])
+@pytest.mark.parametrize("K", [97, 128, 142])
 def test_one_wave_triangle_kernel_tiny_and_ragged_row_counts(ctx, m, K):
     # kernel 1A (default for 80 < K <= 128): row-waves without rows, partial 3-chunk pipeline groups, masked tails
     rng = np.random.default_rng(7000 + 13 * m + K)
@@ -208,11 +212,13 @@ def test_general_k_tiled_kernel(ctx, K, m, tiled2):
     w = rng.choice([100.0, 1.0, 1e-8], size=m, p=[0.03, 0.83, 0.14])
     t = rng.random(m) < 0.1
     ctx.set_option("tiled2", tiled2)
+    ctx.set_option("acc_max_k", 128)          # 129 ... 144 columns are kernel 1A's by default: keep the tiled kernel covered there
     try:
         G, c, s = run_stats(ctx, A, b, w, t)
         assert ctx.launch_info()["split"] == 0
     finally:
         ctx.set_option("tiled2", 0)
+        ctx.set_option("acc_max_k", 144)
     stats_close(G, c, s, *orc.normal_eq(A, b, w, t), tol=2e-12)
 
 
@@ -231,8 +237,12 @@ def test_tiled_kernel_masked_rows_may_hold_garbage(ctx, K):
     A2[t] = np.nan
     b2[t] = np.inf
     w2[t] = -np.inf
-    G, c, s = run_stats(ctx, A2, b2, w2, t)
-    assert ctx.launch_info()["split"] == 0
+    ctx.set_option("acc_max_k", 128)
+    try:
+        G, c, s = run_stats(ctx, A2, b2, w2, t)
+        assert ctx.launch_info()["split"] == 0
+    finally:
+        ctx.set_option("acc_max_k", 144)
     stats_close(G, c, s, *orc.normal_eq(A, b, w, t), tol=2e-12)
     assert np.isfinite(G).all() and np.isfinite(c).all() and np.isfinite(s).all()
 
@@ -288,6 +298,7 @@ def test_tiled_kernel_pipeline_forms_give_the_same_bits(K, m):
     A, b, w = orc.synth_problem(m, K)
     t = np.random.default_rng(K).random(m) < 0.2
     c = _capi.HipContext(0)
+    c.set_option("acc_max_k", 128)
     got = []
     for ring in (0, 1, 3):
         c.set_option("tiled_ring", ring)
@@ -996,7 +1007,7 @@ def test_error_analysis_device_and_pandas_paths_agree(ta, ta_fits):
     assert ok.all()
 
 
-@pytest.mark.parametrize("K", [100, 128])
+@pytest.mark.parametrize("K", [100, 128, 142])
 def test_one_wave_triangle_kernel_masked_rows_may_hold_garbage(ctx, K):
     # kernel 1A applies the row mask through out-of-range load offsets: NaN / Inf in A, b AND w of test rows must not
     # reach the statistics (the reference drops those rows by fancy indexing, svd.py:44-46)
@@ -1033,6 +1044,39 @@ def test_one_wave_triangle_kernel_strided_rows(ctx):
     G, c, s = ctx.normal_eq()
     assert ctx.launch_info()["kernel_or_pairs"] == 3
     stats_close(G, c, s, *orc.normal_eq(A, b, w))
+
+
+@pytest.mark.parametrize("K,m", [(96, 30011), (110, 1772), (128, 250003), (142, 13035), (144, 70001)])
+def test_fused_packing_gives_the_bits_of_the_packing_kernel(K, m):
+    # kernel 1A forms (w_eff, w_eff b) of its rows in LDS itself (option fused_pack, default) instead of reading the pairs
+    # fsnap_pack_weights_k wrote to HBM: the same numbers reach the same instructions in the same order -> G and c carry
+    # the same bits; the three b-only scalars are summed per row-wave instead of per packing workgroup (same to rounding,
+    # the training-row count exactly).  NaN / Inf in b and w of masked rows stay out in both forms.
+    rng = np.random.default_rng(4000 + K)
+    A, b, w = orc.synth_problem(m, K)
+    t = rng.random(m) < 0.2
+    b2, w2 = b.copy(), w.copy()
+    b2[t] = np.nan
+    w2[t] = np.inf
+    ref = orc.normal_eq(A, b, w, t)
+    c = _capi.HipContext(0)
+    got = []
+    for fused in (1, 0):
+        c.set_option("fused_pack", fused)
+        got.append(run_stats(c, A, b2, w2, t))
+        info = c.launch_info()
+        assert info["kernel_or_pairs"] == 3 and info["fused_pack"] == fused
+        stats_close(*got[-1], *ref)
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    assert got[0][2][2] == got[1][2][2]
+    assert np.allclose(got[0][2], got[1][2], rtol=1e-13, atol=0)
+    # a second weight set on the resident rows: nothing stale survives in the LDS / HBM pairs
+    w3 = w * rng.uniform(0.5, 2.0, m)
+    for fused in (1, 0):
+        c.set_option("fused_pack", fused)
+        c.set_weights(w3, (~t).astype(np.uint8))
+        stats_close(*c.normal_eq(), *orc.normal_eq(A, b, w3, t))
+    c.close()
 
 
 @pytest.mark.parametrize("K", [31, 128, 200])
