@@ -90,6 +90,9 @@ def parse(argv=None):
                          "(default: only when N > 1)")
     ap.add_argument("--pipelined", type=int, default=1,
                     help="1 / 0: also report the throughput with two fits in flight (N = 1 only; an extra object, never `value`)")
+    ap.add_argument("--svd-solver", type=int, default=1,
+                    help="N = 1: also time the reference's default solver (SVD: probe solve + 2 one-pass refinement steps, the "
+                         "plugin class, and the row-space path on an ill-conditioned copy); reported as `svd_solver`, never `value`")
     ap.add_argument("--ab-timeout", type=int, default=30,
                     help="seconds a collective of the optional dist_solve A/B leg may take before that leg is given up (the scaling numbers measured before it are reported either way)")
     ap.add_argument("--timing-every", type=int, default=4,
@@ -204,7 +207,7 @@ def cpu_baseline(A, b, w, beta_gpu):
     t0 = time.perf_counter()
     orc.svd_fit(A[:ms], b[:ms], w[:ms])
     t_svd = time.perf_counter() - t0
-    rel = float(np.max(np.abs(beta_gpu - beta) / np.maximum(np.abs(beta), 1e-300)))
+    rel = None if beta_gpu is None else float(np.max(np.abs(beta_gpu - beta) / np.maximum(np.abs(beta), 1e-300)))
     return {
         "value": m / t_ridge, "unit": "rows/s", "cores": int(threads), "kind": "port",
         "sample": f"oracle ridge_fit (weight + X^T X + Cholesky, reference ridge.py:37-59) on all {m} rows: "
@@ -430,6 +433,91 @@ def run_pipelined(args, head, dev, _capi):
             c.close()
 
 
+def run_svd_solver(ctx, args, head, dev, _capi):
+    """The reference's DEFAULT solver (io/sections/solver_sections/solver.py:15 -> solvers/svd.py:54, lstsq on the weighted
+    rows) on the same resident rows, outside the headline protocol (never `value`):
+      * `steps`: what SVD.perform_fit runs per fit on a well-conditioned system, at the level of the headline step
+        (weights resident, one library call per stage): probe solve of the statistics + 2 refinement steps, each ONE
+        pass over the rows (fsnap_residual_rhs, kernels 4 + 7 fused) + a K x K solve;
+      * `class_perform_fit`: the plugin class itself with keep_resident (adds what the class does per call: the staged
+        upload of one weight per training row, label handling);
+      * `row_space`: the same class on an ill-conditioned copy of the problem (one column nearly dependent on another,
+        kappa ~ 1e9): CholeskyQR passes over the rows (fsnap_lstsq_rows)."""
+    out = {}
+    try:
+        from fitsnap_amd.config import Config
+        from fitsnap_amd.parallel_tools import ParallelTools
+        from fitsnap_amd.solvers import solver_factory
+
+        A, b, w = head["A"], head["b"], head["w"]
+        m, Kc = A.shape
+        RCOND, NREF = 1.0e-13, 2
+        ctx.upload_rows(A, b)
+        ctx.set_weights(w)
+        ctx.set_option("timing_every", 0)
+
+        def svd_step():
+            beta, rank, _, ptr = ctx.fit_resident(_capi.SOLVE_LSTSQ_PROBE, RCOND)
+            for _ in range(NREF):
+                s = ctx.residual_rhs(beta)[0]
+                delta = ctx.solve_device(_capi.SOLVE_LSTSQ, RCOND, Kc, ptr, rhs=s)[0]
+                beta = beta + delta
+            return beta, rank
+
+        for _ in range(20):
+            svd_step()
+        ctx.sync()
+        n = max(5, min(args.steps, 50))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            beta, rank = svd_step()
+        ctx.sync()
+        el = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ctx.residual_rhs(beta)
+        ctx.sync()
+        el_res = time.perf_counter() - t0
+        out["steps"] = {"ms_per_fit": el / n * 1e3, "rows_per_s": m * n / el, "refinement_steps": NREF, "rank": int(rank),
+                        "residual_rhs_ms_per_call": el_res / n * 1e3,
+                        "residual_rhs_GBps": (8 * Kc + 17) * m / (el_res / n) / 1e9,
+                        "protocol": "fsnap_fit_resident(LSTSQ_PROBE) + 2 x (fsnap_residual_rhs: one pass over the rows + "
+                                    "fsnap_solve_device_rhs), weights resident"}
+        pt = ParallelTools()
+        cfg = Config(pt, {"SOLVER": {"solver": "SVD"}})
+        sv = solver_factory.solver("SVD", pt, cfg)
+        sv.keep_resident = True
+
+        def class_fit(Ax, nrep):
+            ts = []
+            for _ in range(nrep + 2):
+                t0 = time.perf_counter()
+                sv.fit = None
+                sv.perform_fit(Ax, b, w, trainall=True)
+                ts.append(time.perf_counter() - t0)
+            return float(np.mean(ts[2:])) * 1e3
+
+        ms_cls = class_fit(A, 8)
+        fit_cls = np.array(sv.fit)
+        out["class_perform_fit"] = {"ms_per_fit": ms_cls, "rows_per_s": m / (ms_cls * 1e-3),
+                                    "max_rel_diff_vs_steps": float(np.max(np.abs(fit_cls - beta) / np.maximum(np.abs(beta), 1e-300)))}
+        if Kc >= 2:
+            Ai = A.copy()
+            Ai[:, Kc - 1] = Ai[:, 0] * (np.linalg.norm(A[:, Kc - 1]) / max(np.linalg.norm(A[:, 0]), 1e-300)) + 1.0e-9 * A[:, Kc - 1]
+            ms_rs = class_fit(Ai, 3)
+            rs = sv.last_row_space
+            out["row_space"] = {"ms_per_fit": ms_rs, "rows_per_s": m / (ms_rs * 1e-3), "used_row_space": rs is not None,
+                                "info": {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in (rs or {}).items()}
+                                if isinstance(rs, dict) else str(rs)}
+        pt.free()
+        # leave the headline rows in place for whatever follows
+        ctx.upload_rows(A, b)
+        ctx.set_weights(w)
+    except Exception as e:  # pragma: no cover - optional leg
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
 def run_rank(args):
     # exactly ONE line on stdout: libraries underneath (RCCL prints a version banner through C stdio, which surfaces
     # at exit, after everything Python printed) get stderr as their fd 1; the JSON line goes to the real stdout
@@ -498,9 +586,14 @@ def run_rank(args):
     if rank == 0 and world == 1 and not args.force_dist and args.pipelined:
         pipelined = run_pipelined(args, head, local_rank % ndev, _capi)
 
-    # stand-alone row-weighting kernel (north_star: achieved HBM GB/s), measured outside the timed region
+    svd_extra = None
+    if rank == 0 and world == 1 and not args.force_dist and args.svd_solver:
+        svd_extra = run_svd_solver(ctx, args, head, local_rank % ndev, _capi)
+
+    # stand-alone row-weighting kernel (north_star: achieved HBM GB/s), measured outside the timed region (on rank 0's
+    # rows; in a multi-GPU job the other ranks wait at the closing barrier meanwhile)
     wk = None
-    if rank == 0 and world == 1:
+    if rank == 0:
         try:
             m1 = head["rows_this_rank"]
             d_aw = ctx.dev_alloc(m1 * Kc * 8)
@@ -601,8 +694,20 @@ def run_rank(args):
             out["dist_solve_ab"] = ab
         if pipelined is not None:
             out["pipelined"] = pipelined
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(head["A"], head["b"], head["w"], head["beta"])
+        if svd_extra is not None:
+            out["svd_solver"] = svd_extra
+        if not args.no_cpu_baseline:
+            if world == 1:
+                out["cpu_baseline"] = cpu_baseline(head["A"], head["b"], head["w"], head["beta"])
+            else:
+                # rank 0 regenerates the whole problem of the strong-scaling run (the ranks hold slices of exactly these
+                # rows) and times the oracle on it, like the N = 1 line; the other ranks wait at the closing barrier
+                from fitsnap_amd.synthetic import synth_problem
+
+                strong = results.get("strong")
+                Af, bf, wf = synth_problem(args.rows, Kc)
+                out["cpu_baseline"] = cpu_baseline(Af, bf, wf, strong["beta"] if strong is not None else None)
+                del Af, bf, wf
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()
     if ab is not None and "error" in ab:

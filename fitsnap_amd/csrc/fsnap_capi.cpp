@@ -719,6 +719,9 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
     } else if (!strcmp(key, "dist_solve")) {
         if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "dist_solve must be 0 (solve on every rank) or 1 (rank 0 solves and broadcasts)");
         ctx->opt_dist_solve = (int)value;
+    } else if (!strcmp(key, "fused_residual")) {
+        if (value < 0 || value > 2) return ctx->fail(FSNAP_E_ARG, "fused_residual must be 0 (two kernels), 1 (one pass, prefetch) or 2 (one pass)");
+        ctx->opt_fused_residual = (int)value;
     } else if (!strcmp(key, "reduce")) {
         if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "reduce must be 0 (kernel 2b) or 1 (kernel 2)");
         ctx->opt_reduce = (int)value;
@@ -1553,8 +1556,11 @@ int fsnap_residual_rhs(fsnap_ctx* ctx, const double* beta, double* s, double* ss
     if (!beta || !s) return ctx->fail(FSNAP_E_ARG, "fsnap_residual_rhs: NULL argument");
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     const size_t m = (size_t)ctx->m, K = (size_t)ctx->K;
-    const int nb = fsnap::gemv_num_blocks(ctx->m), nbt = fsnap::gemvT_num_blocks(ctx->m);
-    if (!ctx->beta.ensure(K * 8) || !ctx->du.ensure(m * 8) || !ctx->dspart.ensure((size_t)nbt * K * 8) ||
+    // K <= 256: kernels 4 + 7 fused, the rows are read once (option fused_residual = 0: the two-kernel form, A/B)
+    const bool fused = ctx->opt_fused_residual && K <= 256;
+    const int nb = fused ? fsnap::residual_num_blocks(ctx->m) : fsnap::gemv_num_blocks(ctx->m);
+    const int nbt = fused ? nb : fsnap::gemvT_num_blocks(ctx->m);
+    if (!ctx->beta.ensure(K * 8) || (!fused && !ctx->du.ensure(m * 8)) || !ctx->dspart.ensure((size_t)nbt * K * 8) ||
         !ctx->dsvec.ensure(K * 8) || (sse && !ctx->sse.ensure((size_t)nb * 8)))
         return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(refinement) failed");
     const unsigned char* mask = ctx->dmask;
@@ -1563,12 +1569,19 @@ int fsnap_residual_rhs(fsnap_ctx* ctx, const double* beta, double* s, double* ss
         mask = (const unsigned char*)ctx->ones.p;
     }
     FSNAP_HIP(hipMemcpyAsync(ctx->beta.p, beta, K * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(beta)");
-    FSNAP_HIP(fsnap::launch_gemv_rows(ctx->dA, ctx->lda, (const double*)ctx->beta.p, ctx->m, (int)ctx->K, nullptr, ctx->db,
-                                      ctx->dw, mask, sse ? (double*)ctx->sse.p : nullptr, (double*)ctx->du.p, ctx->stream),
-              "launch fsnap_gemv_rows_k");
-    FSNAP_HIP(fsnap::launch_gemvT_rows(ctx->dA, ctx->lda, (const double*)ctx->du.p, ctx->m, (int)ctx->K,
-                                       (double*)ctx->dspart.p, (double*)ctx->dsvec.p, ctx->stream),
-              "launch fsnap_gemvT_rows_k");
+    if (fused) {
+        FSNAP_HIP(fsnap::launch_residual_rows(ctx->dA, ctx->lda, (const double*)ctx->beta.p, ctx->m, (int)ctx->K, ctx->db, ctx->dw,
+                                              mask, (double*)ctx->dspart.p, sse ? (double*)ctx->sse.p : nullptr,
+                                              (double*)ctx->dsvec.p, ctx->stream, ctx->opt_fused_residual != 2),
+                  "launch fsnap_residual_rows_k");
+    } else {
+        FSNAP_HIP(fsnap::launch_gemv_rows(ctx->dA, ctx->lda, (const double*)ctx->beta.p, ctx->m, (int)ctx->K, nullptr, ctx->db,
+                                          ctx->dw, mask, sse ? (double*)ctx->sse.p : nullptr, (double*)ctx->du.p, ctx->stream),
+                  "launch fsnap_gemv_rows_k");
+        FSNAP_HIP(fsnap::launch_gemvT_rows(ctx->dA, ctx->lda, (const double*)ctx->du.p, ctx->m, (int)ctx->K,
+                                           (double*)ctx->dspart.p, (double*)ctx->dsvec.p, ctx->stream),
+                  "launch fsnap_gemvT_rows_k");
+    }
     FSNAP_HIP(hipMemcpyAsync(s, ctx->dsvec.p, K * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(s)");
     if (sse) {
         std::string tmp;

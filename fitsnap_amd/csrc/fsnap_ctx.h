@@ -142,6 +142,7 @@ struct fsnap_ctx {
     void* dense_pinv_user = nullptr;
     int64_t dense_pinv_token = 0;
     DevBuf commbuf;                               // device staging of host-buffer collectives
+    int opt_fused_residual = 1;   // fsnap_residual_rhs: one pass over the rows for K <= 256 (0: kernels 4 + 7, two passes)
     int opt_reduce = 0;       // reduction of kernel 1 / 1A / 1P partials: 0 = kernel 2b, 1 = kernel 2 (A/B)
     int opt_mirror_upper = 1; // kernel 2b writes the host mirror's triangle once per element (upper positions)
     int opt_fused_pack = 1;   // kernel 1A forms the per-row pairs of its rows in LDS itself (no packing launch) when they fit

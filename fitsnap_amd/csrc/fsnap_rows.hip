@@ -285,6 +285,139 @@ __global__ __launch_bounds__(256) void fsnap_gemvT_rows_k(const double* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Kernel 4+7: one-pass refinement right-hand side  s = (wA)^T (wb - wA beta)  of the SVD solver's corrected semi-normal
+// step (svd.py:54 is lstsq on the weighted rows; this keeps the normal-equation solve at its accuracy) -- kernels 4 and 7
+// fused: a row is read ONCE and stays in registers between the two uses,
+//     r_i = keep_i w_i (b_i - a_i . beta)      lane reduction over the 16 lanes of the row (the bits of kernel 4)
+//     s  += a_i (w_i r_i)                      per-lane column accumulators, folded in a fixed order at the end
+// plus the weighted SSE sum r_i^2.  16 lanes per row, a wave takes 8 rows per step (two groups of four) and prefetches the
+// next step's rows into a second register set before it works on the current ones.  Rows that do not take part (test
+// rows, rows past m) are zeroed by selects: NaN / Inf in them reach nothing.  K <= 32 NJ (NJ <= 8: 64 VGPRs of row data
+// per set); wider systems keep the two-kernel form.  HBM-bound: 8K + 17 bytes per row.
+// Per-workgroup partial vectors partial[wg][K] (fold: kernel fsnap_colsum_partials_k), sse_part[wg].
+// ---------------------------------------------------------------------------------
+template <int NJ>
+struct ResidualRows {
+    d2u x[2][NJ];
+    double bb[2], ww[2];
+    bool keep[2];
+};
+
+template <int NJ, bool PF>
+__global__ __launch_bounds__(256) void fsnap_residual_rows_k(const double* __restrict__ A, int64_t lda,
+                                                             const double* __restrict__ beta, int64_t m, int K,
+                                                             const double* __restrict__ b, const double* __restrict__ w,
+                                                             const unsigned char* __restrict__ mask,
+                                                             double* __restrict__ partial, double* __restrict__ sse_part) {
+    constexpr int KP = NJ * 32;
+    __shared__ __attribute__((aligned(16))) double sbeta[KP];
+    __shared__ double fold[4][KP];
+    __shared__ double wsum[4];
+    for (int c = threadIdx.x; c < KP; c += 256) sbeta[c] = c < K ? beta[c] : 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4, wv = threadIdx.x >> 6;
+    bool v1[NJ], v2[NJ];
+    int coff[NJ];
+    double be0[NJ], be1[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = 2 * e + 32 * j;
+        v1[j] = c < K;
+        v2[j] = c + 1 < K;
+        coff[j] = v1[j] ? c : 0;          // lanes past the row's end re-read its first pair (selected away)
+        be0[j] = sbeta[c];
+        be1[j] = sbeta[c + 1];
+    }
+    double a0[NJ], a1[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) a0[j] = a1[j] = 0.0;
+    double sse = 0.0;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv, step = (int64_t)gridDim.x * 4 * 8;
+
+    auto fetch = [&](int64_t r0, ResidualRows<NJ>& R) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t row = r0 + 4 * h + kr;
+            const bool in = row < m;
+            const int64_t rr = in ? row : 0;
+            R.keep[h] = in && (mask[rr] != 0);
+            R.bb[h] = b[rr];
+            R.ww[h] = w[rr];
+            const double* src = A + rr * lda;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) R.x[h][j] = __builtin_nontemporal_load(reinterpret_cast<const d2u*>(src + coff[j]));
+        }
+    };
+    auto process = [&](const ResidualRows<NJ>& R) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double x0[NJ], x1[NJ];
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                x0[j] = (R.keep[h] && v1[j]) ? R.x[h][j][0] : 0.0;
+                x1[j] = (R.keep[h] && v2[j]) ? R.x[h][j][1] : 0.0;
+                s0 = __builtin_fma(x0[j], be0[j], s0);
+                s1 = __builtin_fma(x1[j], be1[j], s1);
+            }
+            double sd = s0 + s1;
+            sd += __shfl_xor(sd, 8, 64);
+            sd += __shfl_xor(sd, 4, 64);
+            sd += __shfl_xor(sd, 2, 64);
+            sd += __shfl_xor(sd, 1, 64);
+            const double rr = R.keep[h] ? R.ww[h] * (R.bb[h] - sd) : 0.0;
+            const double u = R.keep[h] ? R.ww[h] * rr : 0.0;
+            if (e == 0) sse = __builtin_fma(rr, rr, sse);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                a0[j] = __builtin_fma(x0[j], u, a0[j]);
+                a1[j] = __builtin_fma(x1[j], u, a1[j]);
+            }
+        }
+    };
+
+    int64_t r0 = wave * 8;
+    if constexpr (PF) {
+        ResidualRows<NJ> R0, R1;
+        if (r0 < m) fetch(r0, R0);
+        for (; r0 < m; r0 += 2 * step) {
+            const bool more = r0 + step < m;
+            if (more) fetch(r0 + step, R1);
+            process(R0);
+            if (more) {
+                if (r0 + 2 * step < m) fetch(r0 + 2 * step, R0);
+                process(R1);
+            }
+        }
+    } else {            // no second register set: more waves per SIMD cover the latency instead (A/B)
+        ResidualRows<NJ> R0;
+        for (; r0 < m; r0 += step) {
+            fetch(r0, R0);
+            process(R0);
+        }
+    }
+    // fold: the four row groups of a wave (lanes e, e + 16, e + 32, e + 48), then the four waves through LDS, fixed order
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        a0[j] += __shfl_xor(a0[j], 16, 64);
+        a0[j] += __shfl_xor(a0[j], 32, 64);
+        a1[j] += __shfl_xor(a1[j], 16, 64);
+        a1[j] += __shfl_xor(a1[j], 32, 64);
+        if (kr == 0) {
+            fold[wv][2 * e + 32 * j] = a0[j];
+            fold[wv][2 * e + 32 * j + 1] = a1[j];
+        }
+    }
+    sse += __shfl_xor(sse, 16, 64);
+    sse += __shfl_xor(sse, 32, 64);
+    if (lane == 0) wsum[wv] = sse;
+    __syncthreads();
+    for (int c = threadIdx.x; c < K; c += 256)
+        partial[(int64_t)blockIdx.x * K + c] = (fold[0][c] + fold[1][c]) + (fold[2][c] + fold[3][c]);
+    if (threadIdx.x == 0 && sse_part) sse_part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
 // out[c] = sum over the per-workgroup partial vectors, fixed order.  A workgroup owns 16 columns: thread (column
 // c0 + (tid & 15), lane group g = tid >> 4) adds the partials g, g + 16, ... (four independent accumulators: the loads
 // of a thread are dependent only through the sums), then the 16 groups are folded through LDS in a fixed tree.  (One
@@ -565,6 +698,44 @@ hipError_t launch_gemv_rows(const double* A, int64_t lda, const double* beta, in
     const int nb = gemv_num_blocks(m);
     hipLaunchKernelGGL(fsnap_gemv_rows_k, dim3((unsigned)nb), dim3(256), (size_t)K * sizeof(double), st, A, lda,
                        beta, m, K, preds, b, w, mask, sse_part, uout, uplain ? 1 : 0);
+    return hipGetLastError();
+}
+
+int residual_num_blocks(int64_t m) {
+    int64_t nb = (m + 31) / 32;
+    if (nb > 256 * 6) nb = 256 * 6;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+// fused refinement right-hand side (K <= 256): partial[residual_num_blocks(m)][K], sse_part[residual_num_blocks(m)] (or
+// nullptr), out[K]
+hipError_t launch_residual_rows(const double* A, int64_t lda, const double* beta, int64_t m, int K, const double* b,
+                                const double* w, const unsigned char* mask, double* partial, double* sse_part, double* out,
+                                hipStream_t st, bool prefetch) {
+    const int nb = residual_num_blocks(m);
+    const int nj = (K + 31) / 32;
+#define FSNAP_LAUNCH(NJ)                                                                                                   \
+    do {                                                                                                                   \
+        if (prefetch)                                                                                                      \
+            hipLaunchKernelGGL((fsnap_residual_rows_k<NJ, true>), dim3((unsigned)nb), dim3(256), 0, st, A, lda, beta, m, K, b, \
+                               w, mask, partial, sse_part);                                                                \
+        else                                                                                                               \
+            hipLaunchKernelGGL((fsnap_residual_rows_k<NJ, false>), dim3((unsigned)nb), dim3(256), 0, st, A, lda, beta, m, K, \
+                               b, w, mask, partial, sse_part);                                                             \
+    } while (0)
+    switch (nj) {
+        case 1: FSNAP_LAUNCH(1); break;
+        case 2: FSNAP_LAUNCH(2); break;
+        case 3: FSNAP_LAUNCH(3); break;
+        case 4: FSNAP_LAUNCH(4); break;
+        case 5: FSNAP_LAUNCH(5); break;
+        case 6: FSNAP_LAUNCH(6); break;
+        case 7: case 8: FSNAP_LAUNCH(8); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef FSNAP_LAUNCH
+    hipLaunchKernelGGL(fsnap_colsum_partials_k, dim3((unsigned)((K + 15) / 16)), dim3(256), 0, st, partial, nb, K, out);
     return hipGetLastError();
 }
 

@@ -543,13 +543,13 @@ __device__ __forceinline__ u4 load_pack_x(const WaveBufsP& wb, const double* lpk
 // become (0, 0) pairs, which is what the loop's look-ahead expects there.  PB x 3 loads in flight per lane.
 __device__ __forceinline__ void pack_rows_to_lds(const double* __restrict__ b, const double* __restrict__ w,
                                                  const unsigned char* __restrict__ mask, int64_t row0, int64_t nrow,
-                                                 unsigned region_rows, double* lpw, int lane, double* sout) {
-    constexpr int PB = 8;
+                                                 unsigned wave_rows, unsigned region_rows, double* lpw, int lane, double* sout) {
+    constexpr int PB = 16;     // 16 x 64 rows per batch: the 980 rows a wave owns at 10^6 x 128 are ONE round trip to HBM
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(b + row0, (unsigned)(nrow * 8));
     const __amdgpu_buffer_rsrc_t rw_ = make_rsrc(w + row0, (unsigned)(nrow * 8));
     const __amdgpu_buffer_rsrc_t rm = make_rsrc(mask + row0, (unsigned)nrow);
     double bb = 0.0, sb = 0.0, cnt = 0.0;
-    for (unsigned r0 = 0; r0 < region_rows; r0 += 64u * PB) {
+    for (unsigned r0 = 0; r0 < wave_rows; r0 += 64u * PB) {
         u2 bv[PB], wv[PB];
         unsigned char mk[PB];
 #pragma unroll
@@ -565,7 +565,7 @@ __device__ __forceinline__ void pack_rows_to_lds(const double* __restrict__ b, c
             const bool keep = (mk[u] != 0);
             const double wvv = keep ? __builtin_bit_cast(double, wv[u]) : 0.0;
             const double wbv = keep ? wvv * __builtin_bit_cast(double, bv[u]) : 0.0;
-            if (row < region_rows) {
+            if (row < wave_rows) {
                 d2 o;
                 o[0] = wvv;
                 o[1] = wbv;
@@ -575,6 +575,11 @@ __device__ __forceinline__ void pack_rows_to_lds(const double* __restrict__ b, c
             sb += wbv;
             cnt += keep ? 1.0 : 0.0;
         }
+    }
+    // the look-ahead pad behind the wave's rows: zeros, no loads
+    for (unsigned row = wave_rows + (unsigned)lane; row < region_rows; row += 64u) {
+        const d2 z = {0.0, 0.0};
+        *reinterpret_cast<d2*>(lpw + (size_t)row * 2) = z;
     }
 #pragma unroll
     for (int sh = 1; sh < 64; sh <<= 1) {       // fixed butterfly: deterministic
@@ -685,9 +690,10 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
 
     const double* lpk = nullptr;
     if constexpr (PACK) {
-        const unsigned region_rows = (unsigned)(chunks_per_wave + FSNAP_ACC_PACK_PAD) * 4u;
+        const unsigned wave_rows = (unsigned)chunks_per_wave * 4u;
+        const unsigned region_rows = wave_rows + FSNAP_ACC_PACK_PAD * 4u;
         double* lpw = lds + (size_t)rw * region_rows * 2;
-        pack_rows_to_lds(bvec, wvec, mask, row0, nrow, region_rows, lpw, lane, spart + rowwave * 4);
+        pack_rows_to_lds(bvec, wvec, mask, row0, nrow, wave_rows, region_rows, lpw, lane, spart + rowwave * 4);
         lpk = lpw + 2 * kr;
     }
 
@@ -2027,7 +2033,7 @@ __global__ __launch_bounds__(256, 2) void fsnap_syrk_tiled(const double* __restr
     const int tail = K & 63;
     const int edge = (J == NSB - 1 && tail != 0) ? (tail <= 32 ? 2 : 4) : 0;
     if (I == J) {
-        if (ring) {     // diagonal items on the ring form of the pipeline (see syrk_tiled_body)
+        if (ring & 1) {     // diagonal items on the ring form of the pipeline (see syrk_tiled_body)
             if (edge == 2) syrk_tiled_body<true, 2, NT, true>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
             else if (edge == 4) syrk_tiled_body<true, 4, NT, true>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
             else syrk_tiled_body<true, 0, NT, true>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);

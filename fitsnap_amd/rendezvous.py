@@ -16,7 +16,9 @@ What keeps a rank from picking up the WRONG id (``ncclCommInitRank`` with mismat
   the identity of the launcher process they share (pid + start time of the parent) -- and of the GENERATION: the n-th
   communicator a process creates uses the n-th file name and the n-th token, so two communicators created back to back
   can never read each other's id.  A file left by a crashed job carries another token and is ignored (rank 0 also
-  unlinks whatever it finds under its name before publishing).  Ranks started by hand from different shells have no
+  unlinks whatever it finds under its name before publishing), and a file that carries the RIGHT token but has not been
+  touched since before the reader started is ignored too: a live rank 0 refreshes its file's mtime four times a second
+  until ``done()``, a crashed job's file goes stale at once.  Ranks started by hand from different shells have no
   launcher in common: give them the same ``FSNAP_COMM_TOKEN``;
 * the default file lives in a directory of this user's own (mode 0700, ownership checked), the file is created 0600.
 
@@ -30,7 +32,12 @@ import os
 import socket
 import stat
 import tempfile
+import threading
 import time
+
+_IMPORTED_AT = time.time()          # "this process is at least this old": a published id must not be older (see _via_file)
+_FRESH_SLACK_S = 5.0
+_KEEPALIVE_S = 0.25
 
 ID_BYTES = 128
 _MAGIC = b"FSNAPID1"
@@ -115,6 +122,20 @@ def _via_file(path, rank, make_id, token):
         with os.fdopen(fd, "wb") as f:
             f.write(_pack(token, ident))
         os.replace(tmp, path)                      # atomic: a reader sees nothing or the whole message
+        # keep the file's mtime current while this job is alive and still joining: a reader ignores a file that has not
+        # been touched since before the reader itself started -- that is what a job leaves behind which crashed between
+        # publishing and done() and is re-launched under the same token (same parent, same port, no FSNAP_COMM_TOKEN)
+        stop = threading.Event()
+
+        def keepalive():
+            while not stop.wait(_KEEPALIVE_S):
+                try:
+                    os.utime(path, None)
+                except OSError:
+                    return
+
+        threading.Thread(target=keepalive, name="fsnap-comm-id-keepalive", daemon=True).start()
+        _state["keepalive"] = stop
         return ident
     timeout = _timeout_s()
     deadline = time.monotonic() + timeout
@@ -123,8 +144,9 @@ def _via_file(path, rank, make_id, token):
         try:
             with open(path, "rb") as f:
                 msg = f.read(_MSG_BYTES + 1)
+                fresh = os.fstat(f.fileno()).st_mtime >= _IMPORTED_AT - _FRESH_SLACK_S
             ident = _unpack(msg, token)
-            if ident is not None:
+            if ident is not None and fresh:        # a live rank 0 touches its file every _KEEPALIVE_S seconds
                 return ident
             foreign = foreign or len(msg) > 0
         except FileNotFoundError:
@@ -191,7 +213,7 @@ def _via_tcp(rank, world, make_id, token):
         time.sleep(0.01)
 
 
-_state = {"path": None, "generation": 0}
+_state = {"path": None, "generation": 0, "keepalive": None}
 
 
 def exchange(rank: int, world: int, make_id) -> bytes:
@@ -213,6 +235,9 @@ def exchange(rank: int, world: int, make_id) -> bytes:
 def done(rank: int):
     """After every rank has joined the communicator: rank 0 removes the id file."""
     path, _state["path"] = _state["path"], None
+    stop, _state["keepalive"] = _state.get("keepalive"), None
+    if stop is not None:
+        stop.set()
     if rank == 0 and path:
         try:
             os.remove(path)

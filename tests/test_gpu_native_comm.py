@@ -19,6 +19,16 @@ from oracle import fitsnap_oracle as orc
 from conftest import maxrel
 
 pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -239,10 +249,11 @@ def test_two_process_native_fit_matches_the_reference(tmp_path, ta, ta_fits):
     A, b, w = ta
     world = 2
     procs = []
+    port = str(_free_port())          # one port for the job, free now (a fixed number collides with whatever else runs on the box)
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world),
                    FSNAP_COMM_FILE=str(tmp_path / "comm_id"), FSNAP_COMM_TOKEN="two-process test", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT="29655", HSA_ENABLE_IPC_MODE_LEGACY="0", FSNAP_COMM_TIMEOUT="120")
+                   MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0", FSNAP_COMM_TIMEOUT="120")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_native_worker.py"), str(tmp_path)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = [p.communicate(timeout=600)[0] for p in procs]

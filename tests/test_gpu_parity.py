@@ -932,6 +932,41 @@ def test_residual_rhs_general_k(ctx, K):
     assert np.max(np.abs(s - aw.T @ r) / (np.abs(aw).T @ np.abs(r))) < 1e-13
 
 
+@pytest.mark.parametrize("K,m", [(7, 1003), (31, 15213), (64, 9001), (110, 20011), (128, 50001), (142, 13035), (200, 7001),
+                                 (256, 4099)])
+def test_one_pass_residual_rhs(ctx, K, m):
+    # fsnap_residual_rhs for K <= 256: kernels 4 + 7 fused, every row read once (option fused_residual: 1 = with the
+    # next rows prefetched into a second register set, 2 = without, 0 = the two-kernel form).  All three against the
+    # oracle's s = aw^T (bw - aw beta) and SSE on the training rows; NaN / Inf in A, b, w of test rows reach nothing in the
+    # fused forms (the reference drops those rows by fancy indexing, svd.py:44-46).
+    rng = np.random.default_rng(6000 + K)
+    A, b, w = orc.synth_problem(m, K)
+    t = rng.random(m) < 0.2
+    beta = rng.standard_normal(K) * 0.1
+    aw, bw = orc.weight_rows(A, b, w, t)
+    r = bw - aw @ beta
+    ref, scale = aw.T @ r, np.abs(aw).T @ np.abs(r)
+    A2, b2, w2 = A.copy(), b.copy(), w.copy()
+    A2[t] = np.nan
+    b2[t] = np.inf
+    w2[t] = -np.inf
+    got = {}
+    try:
+        for mode in (1, 2, 0):
+            ctx.set_option("fused_residual", mode)
+            dirty = mode != 0                      # the two-kernel form multiplies masked rows by u = 0: finite rows only
+            ctx.upload_rows(A2 if dirty else A, b2 if dirty else b)
+            ctx.set_weights(w2 if dirty else w, (~t).astype(np.uint8))
+            s, sse = ctx.residual_rhs(beta, want_sse=True)
+            assert np.isfinite(s).all()
+            assert np.max(np.abs(s - ref) / scale) < 1e-13
+            assert abs(sse - r @ r) <= 1e-12 * (r @ r)
+            got[mode] = s
+    finally:
+        ctx.set_option("fused_residual", 1)
+    assert np.max(np.abs(got[1] - got[0]) / scale) < 1e-14 and np.array_equal(got[1], got[2])
+
+
 def test_refinement_recovers_lstsq_accuracy(ta, ta_fits):
     # golden Ta set: plain normal equations 7e-8 from the reference SVD; refined: < 1e-10
     A, b, w = ta

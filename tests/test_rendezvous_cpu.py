@@ -104,3 +104,39 @@ def test_rank_zero_replaces_a_leftover_file_and_writes_it_private(tmp_path, monk
     assert not (tmp_path / "id.g0").exists()
     d = rendezvous._private_dir()
     assert stat.S_IMODE(os.stat(d).st_mode) == 0o700 and os.stat(d).st_uid == os.getuid()
+
+
+def test_a_file_of_this_job_left_by_a_crashed_launch_is_not_accepted(tmp_path, monkeypatch):
+    # same token (same parent, same port, no FSNAP_COMM_TOKEN: a re-launch after a crash between publish and done()), but
+    # the file has not been touched since long before this reader started: ignored until the live rank 0 publishes
+    import threading
+    import time
+
+    from fitsnap_amd import rendezvous
+
+    monkeypatch.setenv("FSNAP_COMM_FILE", str(tmp_path / "id"))
+    monkeypatch.setenv("FSNAP_COMM_TOKEN", "relaunched job")
+    monkeypatch.setenv("FSNAP_COMM_TIMEOUT", "30")
+    monkeypatch.setitem(rendezvous._state, "generation", 0)
+    old = rendezvous._pack(rendezvous._token(0), b"O" * 128)          # the RIGHT token, the WRONG (dead) communicator
+    (tmp_path / "id.g0").write_bytes(old)
+    past = time.time() - 3600.0
+    os.utime(tmp_path / "id.g0", (past, past))
+    got = {}
+
+    def rank0():
+        time.sleep(0.5)
+        got["id0"] = rendezvous._via_file(str(tmp_path / "id.g0"), 0, lambda: b"L" * 128, rendezvous._token(0))
+
+    t = threading.Thread(target=rank0)
+    t.start()
+    assert rendezvous.exchange(1, 2, lambda: b"?" * 128) == b"L" * 128
+    t.join()
+    assert got["id0"] == b"L" * 128
+    # the live rank 0 keeps its file fresh until done()
+    m0 = os.stat(tmp_path / "id.g0").st_mtime
+    time.sleep(3 * rendezvous._KEEPALIVE_S + 0.1)
+    assert os.stat(tmp_path / "id.g0").st_mtime > m0
+    rendezvous.done(0)
+    time.sleep(2 * rendezvous._KEEPALIVE_S)
+    assert rendezvous._state["keepalive"] is None
