@@ -132,6 +132,9 @@ struct fsnap_ctx {
     size_t wstage_bytes[2] = {0, 0};
     hipEvent_t wstage_ev[2] = {nullptr, nullptr};
     int wstage_next = 0;
+    // page-locked double buffer of fsnap_upload_rows (two 32 MiB slots: host threads fill one while the DMA drains the other)
+    char* rstage[2] = {nullptr, nullptr};
+    hipEvent_t rstage_ev[2] = {nullptr, nullptr};
     DevBuf wtrain, wrank;                         // compact training weights and the mask's exclusive prefix sum
     int64_t ntrain_resident = -1;                 // training rows of the resident mask / prefix (-1 = none)
 
@@ -142,6 +145,7 @@ struct fsnap_ctx {
     void* dense_pinv_user = nullptr;
     int64_t dense_pinv_token = 0;
     DevBuf commbuf;                               // device staging of host-buffer collectives
+    int opt_staged_upload = 1;    // fsnap_upload_rows: matrices >= 8 MiB through the page-locked double buffer (0: pageable hipMemcpy)
     int opt_fused_residual = 1;   // fsnap_residual_rhs: one pass over the rows for K <= 256 (0: kernels 4 + 7, two passes)
     int opt_reduce = 0;       // reduction of kernel 1 / 1A / 1P partials: 0 = kernel 2b, 1 = kernel 2 (A/B)
     int opt_mirror_upper = 1; // kernel 2b writes the host mirror's triangle once per element (upper positions)

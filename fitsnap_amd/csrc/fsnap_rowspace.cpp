@@ -292,11 +292,18 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
         fprintf(stderr, "[fsnap_lstsq_rows] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
+    // (w_eff, w_eff b) per row in HBM: the first pass and the qpack pairs read them.  The statistics launch does not leave
+    // them behind any more (kernel 1A packs its rows' pairs in LDS): pack them unless they are current -- BEFORE the first
+    // collective, so that a rank that fails here stops everybody at the first factorisation (NaN statistics)
+    if (have_rows && local_rc == FSNAP_OK && (rc = fsnap::wpack_current(ctx))) {
+        if (nranks == 1) return rc;
+        local_fail(rc);
+    }
     if ((rc = gather_stats(true))) return rc;
     mark("statistics of the rows");
     if (have_rows) {
-        // (w_eff, w_eff b) of the fit are current now (the launch above packed them if needed)
-        FSNAP_HIP(fsnap::launch_qpack((const double*)ctx->wpack.p, ctx->m, (double*)rs->qpack.p, st), "launch fsnap_qpack_k");
+        if (local_rc == FSNAP_OK)
+            FSNAP_HIP(fsnap::launch_qpack((const double*)ctx->wpack.p, ctx->m, (double*)rs->qpack.p, st), "launch fsnap_qpack_k");
         FSNAP_HIP(hipMemsetAsync((char*)rs->Q.p + m * (size_t)K * 8, 0, 256, st), "hipMemsetAsync");   // tail pad of the SYRK loads
     }
     const double tol = 1.0e-10;

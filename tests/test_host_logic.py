@@ -448,6 +448,61 @@ def test_label_caches_see_a_single_flipped_entry_anywhere():
     assert t2 is not t1 and t2[flip]
 
 
+def test_label_containers_ndarray_and_categorical_are_stamped_by_content():
+    # the whole-content fingerprint of Python lists made the default keep_resident loop 8-12 x slower; row labels
+    # handed over as numpy arrays (bool / fixed-width strings) or pandas Categoricals are fingerprinted through their
+    # buffers (xxh3, no copy) -- same guarantees: same object + same content = cached, any in-place edit = re-derived,
+    # and the category ids / keys equal what the lists give
+    import pandas as pd
+
+    pt, cfg, s = make("RIDGE")
+    s.keep_resident = True
+    m = 50_021
+    rng = np.random.default_rng(5)
+    a = np.zeros((m, 2))
+    groups_l = [f"g{g:02d}" for g in np.sort(rng.integers(0, 17, size=m))]
+    testing_l = (rng.random(m) < 0.1).tolist()
+    rtype_l = [("Energy", "Force", "Stress")[i % 3] for i in range(m)]
+    pt0, cfg0, s0 = make("RIDGE")
+    cat_ref, keys_ref, _ = s0._row_categories({"Groups": groups_l, "Testing": testing_l, "Row_Type": rtype_l}, m)
+    forms = {
+        "ndarray": {"Groups": np.asarray(groups_l), "Testing": np.asarray(testing_l), "Row_Type": np.asarray(rtype_l)},
+        "categorical": {"Groups": pd.Categorical(groups_l), "Testing": np.asarray(testing_l), "Row_Type": pd.Categorical(rtype_l)},
+    }
+    for name, fsd in forms.items():
+        s.invalidate_row_caches()
+        m1 = s._training_mask(a, fsd, False)
+        assert s._training_mask(a, fsd, False) is m1 and np.array_equal(m1, ~np.asarray(testing_l))
+        cat, keys, fresh = s._row_categories(fsd, m)
+        assert fresh and [tuple(k) for k in keys] == [tuple(k) for k in keys_ref] and np.array_equal(cat, cat_ref), name
+        assert not s._row_categories(fsd, m)[2]                        # same objects, same content: cached
+        j = int(np.flatnonzero(~np.asarray(testing_l))[1234])
+        fsd["Testing"][j] = True                                       # one row moved to the test set, in place
+        m2 = s._training_mask(a, fsd, False)
+        assert m2 is not m1 and not m2[j] and np.count_nonzero(m1 != m2) == 1
+        cat2, keys2, fresh2 = s._row_categories(fsd, m)
+        assert fresh2 and cat2[j] != cat[j]
+        fsd["Testing"][j] = False
+        if name == "ndarray":
+            fsd["Groups"][j] = "zzz"                                   # one row changes its group, in place
+        else:
+            fsd["Groups"] = fsd["Groups"].add_categories("zzz")
+            fsd["Groups"][j] = "zzz"
+        cat3, keys3, fresh3 = s._row_categories(fsd, m)
+        assert fresh3 and any(k[0] == "zzz" for k in keys3)
+    # stamps: equal content = equal stamp, whatever the object; one flipped bit = another stamp
+    x = np.asarray(testing_l)
+    y = x.copy()
+    assert s._labels_stamp((x,)) == s._labels_stamp((y,))
+    y[7] = not y[7]
+    assert s._labels_stamp((x,)) != s._labels_stamp((y,))
+    assert s._labels_stamp((groups_l,)) == s._labels_stamp((list(groups_l),))
+    g2 = list(groups_l)
+    g2[100] = "other"
+    assert s._labels_stamp((groups_l,)) != s._labels_stamp((g2,))
+    assert s._labels_stamp((np.asarray(groups_l)[::2],)) == s._labels_stamp((np.asarray(groups_l[::2]),))   # non-contiguous view
+
+
 @pytest.mark.parametrize("key,mask,direct,scap,scai,logcut", [
     ("ard_class_all", False, False, 1e-3, 1e-3, 0.3),
     ("ard_class_mask", True, False, 1e-3, 1e-3, 0.3),
