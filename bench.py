@@ -299,7 +299,9 @@ def run_mode(ctx, args, mode, rank, world, multi, _capi):
     m = len(b)
     ctx.upload_rows(A, b)
     ctx.set_weights(w)
-    upload_ms = ctx.timing()["upload_ms"]
+    tim = ctx.timing()
+    upload_ms = tim["upload_ms"]
+    upload_how = {"pageable_probe_GBps": tim.get("upload_probe_GBps"), "page_locked_double_buffer": tim.get("upload_staged")}
     info = ctx.launch_info()
 
     def step():
@@ -350,7 +352,7 @@ def run_mode(ctx, args, mode, rank, world, multi, _capi):
         "mode": mode, "rows_total": m_total, "rows_this_rank": m, "elapsed": float(per_rank[:, 0].max()), "beta": beta,
         "kernel_ms": [float(x) for x in per_rank[:, 1]], "allreduce_ms": [float(x) for x in per_rank[:, 2]],
         "rows_per_rank": [int(x) for x in per_rank[:, 3]], "elapsed_per_rank_s": [float(x) for x in per_rank[:, 0]],
-        "reduce_ms": red_ms, "sampled": nh, "info": info, "upload_ms": upload_ms, "A": A, "b": b, "w": w,
+        "reduce_ms": red_ms, "sampled": nh, "info": info, "upload_ms": upload_ms, "upload_how": upload_how, "A": A, "b": b, "w": w,
     }
     out["timed"] = timed
     return out
@@ -678,6 +680,7 @@ def run_rank(args):
             "roofline": roofline,
             "weighting_kernel": wk,
             "h2d_upload_ms": head["upload_ms"],
+            "h2d_upload_path": head["upload_how"],
             "h2d_inclusive_rows_per_s": m0 / ((head["upload_ms"] + head["elapsed"] / args.steps * 1e3) * 1e-3),
             "torch_imported": "torch" in sys.modules,
             "launched_by": "bench.py" if os.environ.get("FSNAP_BENCH_SPAWNED") else ("launcher" if "RANK" in os.environ else "direct"),

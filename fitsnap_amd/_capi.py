@@ -686,7 +686,8 @@ class HipContext:
         """HIP-event timings (ms); ``n`` = how many leading entries to evaluate (2 = kernels of the last fit only)."""
         ms = (c_double * 8)()
         self._check(self._lib.fsnap_timing(self._h, ms, int(n)))
-        return {"syrk_ms": ms[0], "reduce_ms": ms[1], "upload_ms": ms[2], "weight_ms": ms[3], "predict_ms": ms[4]}
+        return {"syrk_ms": ms[0], "reduce_ms": ms[1], "upload_ms": ms[2], "weight_ms": ms[3], "predict_ms": ms[4],
+                "upload_probe_GBps": ms[5], "upload_staged": bool(ms[6])}
 
     def timing_history(self, n: int):
         """(syrk_ms, reduce_ms) arrays of the last ``n`` fits (oldest first), read from HIP events after the fact."""

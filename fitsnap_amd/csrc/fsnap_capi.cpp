@@ -6,6 +6,8 @@
 // fsnap_solve.cpp.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -781,7 +783,8 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
         if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "dist_solve must be 0 (solve on every rank) or 1 (rank 0 solves and broadcasts)");
         ctx->opt_dist_solve = (int)value;
     } else if (!strcmp(key, "staged_upload")) {
-        ctx->opt_staged_upload = value != 0;
+        if (value < 0 || value > 2) return ctx->fail(FSNAP_E_ARG, "staged_upload must be 0 (pageable copy), 1 (probe) or 2 (double buffer)");
+        ctx->opt_staged_upload = (int)value;
     } else if (!strcmp(key, "fused_residual")) {
         if (value < 0 || value > 2) return ctx->fail(FSNAP_E_ARG, "fused_residual must be 0 (two kernels), 1 (one pass, prefetch) or 2 (one pass)");
         ctx->opt_fused_residual = (int)value;
@@ -819,21 +822,51 @@ int fsnap_upload_rows(fsnap_ctx* ctx, const double* A, int64_t m, int64_t K, int
         return ctx->fail(FSNAP_E_NOMEM, "hipMalloc of %zu bytes for A failed", abytes);
     FSNAP_HIP(hipEventRecord(ctx->ev[3], ctx->stream), "hipEventRecord");
     FSNAP_HIP(hipMemsetAsync((char*)ctx->ownA.p + abytes, 0, 256, ctx->stream), "hipMemsetAsync");
-    // large matrices through the page-locked double buffer (option staged_upload = 0: the runtime's pageable copy, A/B)
+    // Large matrices: which way is faster depends on the box.  The runtime's pageable copy pins the caller's pages and lets the
+    // DMA engine read them in place -- 38 GB/s where that is cheap (huge pages), 10 GB/s where it is not (measured on two
+    // boxes of this pool); the page-locked double buffer (staged_rows_h2d) costs host memcpy time instead -- 10 GB/s inside
+    // a CPU-quota'd container, PCIe rate with free cores.  Option staged_upload: 0 = pageable copy, 2 = double buffer,
+    // 1 (default) = time the first 64 MiB through the pageable copy and keep it if it runs at >= 20 GB/s, else send the rest
+    // through the double buffer.
+    size_t done_rows = 0;
     int staged = FSNAP_E_STATE;
-    if (ctx->opt_staged_upload && abytes >= ((size_t)8 << 20) && (size_t)K * 8 <= ((size_t)32 << 20)) {
-        staged = staged_rows_h2d(ctx, ctx->ownA.p, A, (size_t)m, (size_t)K * 8, (size_t)lda * 8);
-        if (staged != FSNAP_OK && staged != FSNAP_E_NOMEM) return staged;
-    }
-    if (staged != FSNAP_OK) {
+    const bool big = abytes >= ((size_t)256 << 20) && (size_t)K * 8 <= ((size_t)32 << 20);
+    bool use_staged = ctx->opt_staged_upload == 2 && abytes >= ((size_t)8 << 20) && (size_t)K * 8 <= ((size_t)32 << 20);
+    if (ctx->opt_staged_upload == 1 && big) {
+        const size_t probe_rows = std::min<size_t>((size_t)m, (((size_t)64 << 20) + (size_t)K * 8 - 1) / ((size_t)K * 8));
+        FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+        const auto t0 = std::chrono::steady_clock::now();
         if (lda == K) {
-            FSNAP_HIP(hipMemcpyAsync(ctx->ownA.p, A, abytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(A)");
+            FSNAP_HIP(hipMemcpyAsync(ctx->ownA.p, A, probe_rows * (size_t)K * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(A)");
         } else {
-            FSNAP_HIP(hipMemcpy2DAsync(ctx->ownA.p, (size_t)K * 8, A, (size_t)lda * 8, (size_t)K * 8, (size_t)m,
+            FSNAP_HIP(hipMemcpy2DAsync(ctx->ownA.p, (size_t)K * 8, A, (size_t)lda * 8, (size_t)K * 8, probe_rows,
                                        hipMemcpyHostToDevice, ctx->stream),
                       "hipMemcpy2D(A)");
         }
+        FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        done_rows = probe_rows;
+        use_staged = (double)(probe_rows * (size_t)K * 8) / sec < 20.0e9;
+        ctx->upload_probe_gbps = (double)(probe_rows * (size_t)K * 8) / sec / 1e9;
     }
+    const size_t rest = (size_t)m - done_rows;
+    if (use_staged && rest > 0) {
+        staged = staged_rows_h2d(ctx, (char*)ctx->ownA.p + done_rows * (size_t)K * 8, A + done_rows * (size_t)lda, rest,
+                                 (size_t)K * 8, (size_t)lda * 8);
+        if (staged != FSNAP_OK && staged != FSNAP_E_NOMEM) return staged;
+    }
+    if (staged != FSNAP_OK && rest > 0) {
+        if (lda == K) {
+            FSNAP_HIP(hipMemcpyAsync((char*)ctx->ownA.p + done_rows * (size_t)K * 8, A + done_rows * (size_t)lda, rest * (size_t)K * 8,
+                                     hipMemcpyHostToDevice, ctx->stream),
+                      "hipMemcpy(A)");
+        } else {
+            FSNAP_HIP(hipMemcpy2DAsync((char*)ctx->ownA.p + done_rows * (size_t)K * 8, (size_t)K * 8, A + done_rows * (size_t)lda,
+                                       (size_t)lda * 8, (size_t)K * 8, rest, hipMemcpyHostToDevice, ctx->stream),
+                      "hipMemcpy2D(A)");
+        }
+    }
+    ctx->upload_staged = staged == FSNAP_OK;
     FSNAP_HIP(hipMemcpyAsync(ctx->ownb.p, b, (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(b)");
     FSNAP_HIP(hipEventRecord(ctx->ev[4], ctx->stream), "hipEventRecord");
     FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");  // host buffers may be reused now
@@ -950,7 +983,7 @@ int stage_assembly(fsnap_ctx* ctx, const char* who, const double* raw, int64_t r
     hipStream_t st = ctx->stream;
     // the raw LAMMPS block of the batch (tens of MB): through the page-locked double buffer like fsnap_upload_rows
     int staged = FSNAP_E_STATE;
-    if (ctx->opt_staged_upload && rawb >= ((size_t)8 << 20) && st == ctx->stream) {
+    if (ctx->opt_staged_upload == 2 && rawb >= ((size_t)8 << 20) && st == ctx->stream) {
         staged = staged_rows_h2d(ctx, ctx->st_raw.p, raw, (size_t)raw_rows, (size_t)raw_ld * 8, (size_t)raw_ld * 8);
         if (staged != FSNAP_OK && staged != FSNAP_E_NOMEM) return staged;
     }
@@ -1688,6 +1721,8 @@ int fsnap_timing(fsnap_ctx* ctx, double* ms, int n) {
     if (n > 2 && ctx->t_upload && hipEventElapsedTime(&t, ctx->ev[3], ctx->ev[4]) == hipSuccess) out[2] = t;
     if (n > 3 && ctx->t_weight && hipEventElapsedTime(&t, ctx->ev[5], ctx->ev[6]) == hipSuccess) out[3] = t;
     if (n > 4 && ctx->t_predict && hipEventElapsedTime(&t, ctx->ev[7], ctx->ev[8]) == hipSuccess) out[4] = t;
+    out[5] = ctx->upload_probe_gbps;          // last large fsnap_upload_rows: rate of the probed pageable copy (0: no probe)
+    out[6] = ctx->upload_staged ? 1.0 : 0.0;  // ... and whether the rest went through the page-locked double buffer
     for (int i = 0; i < n; ++i) ms[i] = out[i];
     return FSNAP_OK;
 }

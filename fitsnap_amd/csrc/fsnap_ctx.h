@@ -145,7 +145,9 @@ struct fsnap_ctx {
     void* dense_pinv_user = nullptr;
     int64_t dense_pinv_token = 0;
     DevBuf commbuf;                               // device staging of host-buffer collectives
-    int opt_staged_upload = 1;    // fsnap_upload_rows: matrices >= 8 MiB through the page-locked double buffer (0: pageable hipMemcpy)
+    int opt_staged_upload = 1;    // fsnap_upload_rows: 0 pageable hipMemcpy | 2 page-locked double buffer | 1 probe the first 64 MiB, then the faster
+    double upload_probe_gbps = 0.0;   // what the probe of the last large upload measured (pageable copy, GB/s)
+    bool upload_staged = false;       // the last upload went through the double buffer
     int opt_fused_residual = 1;   // fsnap_residual_rhs: one pass over the rows for K <= 256 (0: kernels 4 + 7, two passes)
     int opt_reduce = 0;       // reduction of kernel 1 / 1A / 1P partials: 0 = kernel 2b, 1 = kernel 2 (A/B)
     int opt_mirror_upper = 1; // kernel 2b writes the host mirror's triangle once per element (upper positions)

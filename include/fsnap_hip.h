@@ -90,7 +90,17 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * broadcast [beta | rank | rcond | status] -- for A/B runs of the scaling benchmark; the reduced statistics then exist on
  * rank 0 only and *d_packed comes back NULL on the other ranks),
  * "comm_timeout" (seconds, 0 = the FSNAP_COMM_TIMEOUT environment default: bound of every wait behind a collective of this
- * context and of fsnap_comm_init -- a phase that may fail without taking the job with it sets a short one).
+ * context and of fsnap_comm_init -- a phase that may fail without taking the job with it sets a short one),
+ * "fused_pack" (0|1, default 1: the 80 < K <= 144 kernel forms the per-row pairs (mask * w, mask * w * b) of its rows in LDS inside
+ * the SYRK launch -- no packing launch, nothing of them in HBM -- whenever a workgroup's rows fit; 0 = separate packing kernel, A/B),
+ * "acc_max_k" (144 | 128: widest system on the accumulator-resident kernel; 128 sends 129 ... 144 columns to the tiled kernel, A/B),
+ * "reduce" (0 = reduction kernel 2b with every load of a thread in flight, the default; 1 = its predecessor, A/B),
+ * "mirror_upper" (0|1, default 1: the reduction writes the host mirror's triangle once per element, at its upper position),
+ * "fused_residual" (fsnap_residual_rhs for K <= 256: 1 = one pass over the rows with the next rows prefetched, the default;
+ * 2 = one pass without the second register set; 0 = the two-kernel form, two passes),
+ * "staged_upload" (fsnap_upload_rows of >= 256 MiB: 1 = time the first 64 MiB through the runtime's pageable copy and keep it
+ * when it runs at >= 20 GB/s, else send the rest through a page-locked double buffer filled by host threads, the default;
+ * 0 = pageable copy; 2 = double buffer; FSNAP_UPLOAD_THREADS = host threads of the double buffer, default 4).
  * Unknown key -> FSNAP_E_ARG. */
 int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value);
 
@@ -409,7 +419,8 @@ int fsnap_dev_download(fsnap_ctx* ctx, void* h_dst, const void* d_src, int64_t n
 
 /* HIP-event timings of the last fsnap_normal_eq* call, milliseconds:
  * ms[0] = SYRK kernel, ms[1] = partial reduction kernel, ms[2] = last H2D upload,
- * ms[3] = last stand-alone weighting kernel, ms[4] = last predict kernel.
+ * ms[3] = last stand-alone weighting kernel, ms[4] = last predict kernel; about the last large fsnap_upload_rows:
+ * ms[5] = GB/s of the probed pageable copy (0: not probed), ms[6] = 1 if the rest went through the page-locked double buffer.
  * Synchronises the context's stream.  n = number of entries of ms to fill (<= 8). */
 int fsnap_timing(fsnap_ctx* ctx, double* ms, int n);
 

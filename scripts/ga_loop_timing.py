@@ -40,9 +40,13 @@ for m, K, ngroups in ((15213, 31, 12), (1000000, 128, 40)):
     row_type = [("Energy", "Force", "Stress")[i % 3] for i in range(m)]
     fsd = {"Groups": groups, "Testing": testing, "Row_Type": row_type}
     t = np.asarray(testing)
-    for trust in (False, True):
-        times, rmse = loop(A, b, w, fsd, t, trust, rng)
+    import pandas as pd
+    fsd_np = {"Groups": pd.Categorical(groups), "Testing": np.asarray(testing), "Row_Type": pd.Categorical(row_type)}
+    for trust, labels in ((False, fsd), (False, fsd_np), (True, fsd)):
+        times, rmse = loop(A, b, w, labels, t, trust, rng)
         tt = np.array(times[2:])
-        how = "trusted by version (pt.touch_labels)" if trust else "fingerprinted in full every call"
+        how = ("trusted by version (pt.touch_labels)" if trust else
+               "Python lists, fingerprinted in full every call" if labels is fsd else
+               "numpy bool array + pandas Categoricals, fingerprinted in full every call (xxh3 over their buffers)")
         print(f"{m} x {K}, {ngroups} groups, labels {how}: perform_fit {tt[:,0].mean()*1e3:.2f} ms, error_analysis "
               f"{tt[:,1].mean()*1e3:.2f} ms per candidate (first call: {times[0][0]*1e3:.1f} + {times[0][1]*1e3:.1f} ms); rmse {rmse}")
