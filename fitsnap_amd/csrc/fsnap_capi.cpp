@@ -782,6 +782,9 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
     } else if (!strcmp(key, "dist_solve")) {
         if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "dist_solve must be 0 (solve on every rank) or 1 (rank 0 solves and broadcasts)");
         ctx->opt_dist_solve = (int)value;
+    } else if (!strcmp(key, "reduce_triangle")) {
+        if (value < -1 || value > 1) return ctx->fail(FSNAP_E_ARG, "reduce_triangle must be -1 (K >= 256), 0 (never) or 1 (always)");
+        ctx->opt_reduce_triangle = (int)value;
     } else if (!strcmp(key, "staged_upload")) {
         if (value < 0 || value > 2) return ctx->fail(FSNAP_E_ARG, "staged_upload must be 0 (pageable copy), 1 (probe) or 2 (double buffer)");
         ctx->opt_staged_upload = (int)value;
@@ -1560,7 +1563,8 @@ int fsnap_fit_dist(fsnap_ctx* ctx, int kind, double param, int64_t K, double* be
     const int64_t n = FSNAP_PACKED_LEN(K);
     // the one thing a rank cannot recover from locally: without the buffer it cannot take part in the collective at all
     // (its peers run into FSNAP_COMM_TIMEOUT)
-    if (!ctx->packed.ensure((size_t)n * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(packed) failed");
+    if (!ctx->packed.ensure((size_t)n * 8) || !fsnap::allreduce_packed_reserve(ctx, K))
+        return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(packed) failed");
     double* dp = (double*)ctx->packed.p;
     // Everything that can fail on THIS rank alone happens before the collective -- and must not keep the rank out of
     // it (the peers would wait forever): a rank that fails contributes a buffer of NaNs, every rank then sees
@@ -1594,7 +1598,7 @@ int fsnap_fit_dist(fsnap_ctx* ctx, int kind, double param, int64_t K, double* be
         (void)fsnap_comm_info(ctx, &nr, &me);
         if (d_packed && me == 0) *d_packed = dp;       // the other ranks hold only their own sums: not handed out
     } else {
-        if ((rc = fsnap_allreduce_device(ctx, dp, n))) return rc;
+        if ((rc = fsnap::allreduce_packed(ctx, dp, K))) return rc;       // wide systems: the upper triangle only
         if (evs) {
             FSNAP_HIP(hipEventRecord(evs[3], ctx->stream), "hipEventRecord");
             ctx->ring_comm[(ctx->nfit - 1) % fsnap_ctx::RING] = true;

@@ -22,6 +22,7 @@
 #include <thread>
 
 #include "fsnap_ctx.h"
+#include "fsnap_kernels.h"
 
 namespace fsnap {
 
@@ -255,6 +256,37 @@ int fsnap_allreduce_device(fsnap_ctx* ctx, double* d_buf, int64_t n) {
     FSNAP_NCCL(r->AllReduce(d_buf, d_buf, (size_t)n, ncclDouble, ncclSum, ctx->comm->nccl, ctx->stream), "ncclAllReduce");
     return FSNAP_OK;
 }
+
+}  // extern "C"
+
+namespace fsnap {
+// In-place sum over the ranks of the packed statistics [G | c | scalars] of a K-column system.  Wide systems (option
+// reduce_triangle: -1 = from 256 columns on, 0 = never, 1 = always) travel as [upper triangle | c | scalars] --
+// K (K + 1) / 2 + K + 3 doubles instead of K^2 + K + 3 -- between a pack and an unpack kernel on the same stream; the
+// unpack mirrors the triangle, so the reduced G is symmetric to the last bit either way.
+static bool triangle_form(const fsnap_ctx* ctx, int64_t K) {
+    return ctx->opt_reduce_triangle == 1 || (ctx->opt_reduce_triangle < 0 && K >= 256);
+}
+
+// the buffer of the triangle form, to be reserved where a rank may still fail alone (BEFORE its first collective)
+bool allreduce_packed_reserve(fsnap_ctx* ctx, int64_t K) {
+    return !triangle_form(ctx, K) || ctx->tribuf.ensure((size_t)(K * (K + 1) / 2 + K + 3) * 8);
+}
+
+int allreduce_packed(fsnap_ctx* ctx, double* dp, int64_t K) {
+    if (!triangle_form(ctx, K)) return fsnap_allreduce_device(ctx, dp, FSNAP_PACKED_LEN(K));
+    const int64_t nt = K * (K + 1) / 2 + K + 3;
+    if (!ctx->tribuf.ensure((size_t)nt * 8))          // reserved by the callers before their first collective
+        return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(triangle payload) failed");
+    FSNAP_HIP(fsnap::launch_tri_pack(dp, (int)K, (double*)ctx->tribuf.p, ctx->stream), "launch fsnap_tri_pack_k");
+    const int rc = fsnap_allreduce_device(ctx, (double*)ctx->tribuf.p, nt);
+    if (rc) return rc;
+    FSNAP_HIP(fsnap::launch_tri_unpack((const double*)ctx->tribuf.p, (int)K, dp, ctx->stream), "launch fsnap_tri_unpack_k");
+    return FSNAP_OK;
+}
+}  // namespace fsnap
+
+extern "C" {
 
 int fsnap_allreduce_host(fsnap_ctx* ctx, double* buf, int64_t n, int op) {
     if (!ctx) return FSNAP_E_ARG;

@@ -145,6 +145,8 @@ struct fsnap_ctx {
     void* dense_pinv_user = nullptr;
     int64_t dense_pinv_token = 0;
     DevBuf commbuf;                               // device staging of host-buffer collectives
+    DevBuf tribuf;                                // [upper triangle | c | scalars]: all-reduce payload of wide systems
+    int opt_reduce_triangle = -1;                 // all-reduce the triangle only: -1 = K >= 256, 0 = never, 1 = always
     int opt_staged_upload = 1;    // fsnap_upload_rows: 0 pageable hipMemcpy | 2 page-locked double buffer | 1 probe the first 64 MiB, then the faster
     double upload_probe_gbps = 0.0;   // what the probe of the last large upload measured (pageable copy, GB/s)
     bool upload_staged = false;       // the last upload went through the double buffer
@@ -192,6 +194,10 @@ int wait_stream(fsnap_ctx* ctx, hipEvent_t ev, const char* what);
 // fsnap_comm.cpp: the reduce-to-root form of a multi-GPU fit (option dist_solve = 1): ncclReduce of the packed statistics to
 // rank 0, fsnap_solve_device there, ncclBroadcast of [beta | rank | rcond | status]; evs[3] (may be null) is recorded
 // behind the reduce
+// fsnap_comm.cpp: in-place sum over the ranks of packed statistics [G | c | scalars]; wide systems as a triangle (option
+// reduce_triangle)
+int allreduce_packed(fsnap_ctx* ctx, double* dp, int64_t K);
+bool allreduce_packed_reserve(fsnap_ctx* ctx, int64_t K);     // its buffer, to be reserved before a caller's first collective
 int dist_reduce_solve_bcast(fsnap_ctx* ctx, int kind, double param, int64_t K, double* dp, hipEvent_t* evs, double* beta,
                             int* rank, double* rcond_est);
 // fsnap_capi.cpp: statistics of OTHER rows than the resident ones with the resident rows' launch plan -- the passes

@@ -89,6 +89,9 @@ hipError_t launch_assemble_bw(const double* raw, int64_t raw_ld, int64_t nrows, 
 hipError_t launch_assemble_syrk(const double* raw, int64_t raw_ld, const void* recs, const double* dval, const double* fractions,
                                 const double* blank2J, int ntypes, int ncoeff, int off, const TiledArgs& a, hipStream_t st);
 hipError_t launch_mirror_copy(const double* src, int K, double* mirror, hipStream_t st);
+// packed [G | c | scalars] <-> [upper triangle of G row-major | c | scalars]: the payload of the multi-GPU all-reduce for wide systems
+hipError_t launch_tri_pack(const double* packed, int K, double* tri, hipStream_t st);
+hipError_t launch_tri_unpack(const double* tri, int K, double* packed, hipStream_t st);
 hipError_t launch_chol_solve(const double* packed, int K, double alpha, double* out, hipStream_t st);
 // blocked Cholesky solve for large K: work (chol_large_work_doubles(K) doubles), dsc, z (np = K rounded up to 64),
 // beta (K), status (1 int), minpiv (np / 64) are device scratch / outputs

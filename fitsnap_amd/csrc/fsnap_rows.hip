@@ -568,6 +568,42 @@ __global__ __launch_bounds__(256) void fsnap_mirror_copy_k(const double* __restr
     else if (i < n + K) mirror[i] = src[(size_t)(i - n) * K + (i - n)];
 }
 
+// ---------------------------------------------------------------------------------
+// Kernels 17 / 18: packed statistics [G | c | scalars] <-> [upper triangle of G, row-major | c | scalars].  The multi-GPU
+// fit all-reduces K (K + 1) / 2 + K + 3 doubles instead of K^2 + K + 3 (20.4 -> 10.2 MB at K = 1595: the collective is
+// most of what a wide fit costs beyond one GPU) and mirrors the triangle afterwards -- which also makes the reduced G
+// symmetric to the last bit (two positions of a full buffer fall into different chunks of the ring and may be summed
+// over the ranks in different orders).  One workgroup row per matrix row; the tail (c, scalars) rides in the last rows.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsnap_tri_pack_k(const double* __restrict__ packed, int K, double* __restrict__ tri) {
+    const int64_t i = blockIdx.y;
+    const int64_t T = (int64_t)K * (K + 1) / 2;
+    if (i < K) {
+        const int64_t off = i * K - i * (i - 1) / 2 - i;          // tri index of (i, j) = off + j
+        for (int64_t j = i + (int64_t)blockIdx.x * 256 + threadIdx.x; j < K; j += (int64_t)gridDim.x * 256)
+            tri[off + j] = packed[i * K + j];
+    } else {
+        for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < K + 3; t += (int64_t)gridDim.x * 256)
+            tri[T + t] = packed[(int64_t)K * K + t];
+    }
+}
+
+__global__ __launch_bounds__(256) void fsnap_tri_unpack_k(const double* __restrict__ tri, int K, double* __restrict__ packed) {
+    const int64_t i = blockIdx.y;
+    const int64_t T = (int64_t)K * (K + 1) / 2;
+    if (i < K) {
+        const int64_t off = i * K - i * (i - 1) / 2 - i;
+        for (int64_t j = i + (int64_t)blockIdx.x * 256 + threadIdx.x; j < K; j += (int64_t)gridDim.x * 256) {
+            const double v = tri[off + j];
+            packed[i * K + j] = v;
+            packed[j * K + i] = v;
+        }
+    } else {
+        for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < K + 3; t += (int64_t)gridDim.x * 256)
+            packed[(int64_t)K * K + t] = tri[T + t];
+    }
+}
+
 namespace fsnap {
 
 hipError_t launch_weight_rows(const double* A, int64_t lda, const double* b, const double* w,
@@ -736,6 +772,16 @@ hipError_t launch_residual_rows(const double* A, int64_t lda, const double* beta
     }
 #undef FSNAP_LAUNCH
     hipLaunchKernelGGL(fsnap_colsum_partials_k, dim3((unsigned)((K + 15) / 16)), dim3(256), 0, st, partial, nb, K, out);
+    return hipGetLastError();
+}
+
+// packed [G | c | scalars] -> tri [upper triangle | c | scalars] (K (K + 1) / 2 + K + 3 doubles) and back (mirrors the triangle)
+hipError_t launch_tri_pack(const double* packed, int K, double* tri, hipStream_t st) {
+    hipLaunchKernelGGL(fsnap_tri_pack_k, dim3((unsigned)((K + 1023) / 1024), (unsigned)(K + 1)), dim3(256), 0, st, packed, K, tri);
+    return hipGetLastError();
+}
+hipError_t launch_tri_unpack(const double* tri, int K, double* packed, hipStream_t st) {
+    hipLaunchKernelGGL(fsnap_tri_unpack_k, dim3((unsigned)((K + 1023) / 1024), (unsigned)(K + 1)), dim3(256), 0, st, tri, K, packed);
     return hipGetLastError();
 }
 

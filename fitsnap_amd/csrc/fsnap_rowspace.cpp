@@ -204,7 +204,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
     const size_t m = have_rows ? (size_t)ctx->m : 0;
     // the small K x K workspaces: without them this rank cannot even take part in the collective
     const size_t rdoubles = fsnap::trsm_factor_doubles(K16);       // padded factor + the inverses of its 16 x 16 diagonal blocks
-    if (!rs->packed.ensure((size_t)npk * 8) || !rs->Rdev.ensure(rdoubles * 8) || !rs->beta.ensure((size_t)K * 8) ||
+    if (!rs->packed.ensure((size_t)npk * 8) || (nranks > 1 && !fsnap::allreduce_packed_reserve(ctx, K)) || !rs->Rdev.ensure(rdoubles * 8) || !rs->beta.ensure((size_t)K * 8) ||
         !rs->dz.ensure((size_t)K * 8) || !rs->pin_ensure((size_t)npk + rdoubles + 2 * (size_t)K))
         return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(row-space workspace) failed");
     if (have_rows && local_rc == FSNAP_OK) {
@@ -249,7 +249,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
         }
         if (local_rc != FSNAP_OK) (void)hipMemsetAsync(dp, 0xFF, (size_t)npk * 8, st);     // NaN in every double
         if (nranks > 1) {
-            int r3 = fsnap_allreduce_device(ctx, dp, npk);
+            int r3 = fsnap::allreduce_packed(ctx, dp, K);
             if (r3) return r3;
         }
         if (device_factor) {

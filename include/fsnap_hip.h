@@ -98,6 +98,9 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * "mirror_upper" (0|1, default 1: the reduction writes the host mirror's triangle once per element, at its upper position),
  * "fused_residual" (fsnap_residual_rhs for K <= 256: 1 = one pass over the rows with the next rows prefetched, the default;
  * 2 = one pass without the second register set; 0 = the two-kernel form, two passes),
+ * "reduce_triangle" (fsnap_fit_dist / fsnap_lstsq_rows: -1 = systems of >= 256 columns all-reduce [upper triangle | c | scalars],
+ * K (K + 1) / 2 + K + 3 doubles, between a pack and an unpack kernel, the default; 0 = always the full K^2 + K + 3; 1 = always
+ * the triangle -- every rank of a job must use the same setting),
  * "staged_upload" (fsnap_upload_rows of >= 256 MiB: 1 = time the first 64 MiB through the runtime's pageable copy and keep it
  * when it runs at >= 20 GB/s, else send the rest through a page-locked double buffer filled by host threads, the default;
  * 0 = pageable copy; 2 = double buffer; FSNAP_UPLOAD_THREADS = host threads of the double buffer, default 4).

@@ -65,6 +65,34 @@ def test_one_rank_communicator_runs_every_collective(ta):
     ctx.close()
 
 
+@pytest.mark.parametrize("K,m", [(31, 4001), (142, 6007), (300, 5003), (480, 6000)])
+def test_triangle_payload_of_the_all_reduce_gives_the_same_statistics(K, m):
+    # option reduce_triangle: the multi-GPU fit all-reduces [upper triangle | c | scalars] (K (K + 1) / 2 + K + 3 doubles)
+    # between a pack and an unpack kernel instead of the mirrored K^2 + K + 3 (default from 256 columns on).  In a
+    # communicator of one rank: the reduced buffer, the fit, rank and conditioning carry the same bits in both forms, G is
+    # exactly symmetric, and the device Cholesky (K = 480) reads the unpacked buffer
+    A, b, w = orc.synth_problem(m, K)
+    ctx = _capi.HipContext(0)
+    ctx.comm_init(1, 0, _capi.comm_id())
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w)
+    got = []
+    for tri in (0, 1, -1):
+        ctx.set_option("reduce_triangle", tri)
+        beta, rank, rc, ptr = ctx.fit_dist(_capi.SOLVE_RIDGE, 1e-8, K)
+        G, c, s = ctx.download_packed(ptr, K)
+        assert np.array_equal(G, G.T)
+        got.append((beta, rank, rc, G, c, s))
+    for g in got[1:]:
+        assert all(np.array_equal(x, y) for x, y in zip(g, got[0]))
+    Gr, cr, sr = orc.normal_eq(A, b, w)
+    d = np.sqrt(np.diag(Gr))
+    assert np.max(np.abs(got[1][3] - Gr) / (d[:, None] * d[None, :])) < 2e-12 and got[1][5][2] == sr[2]
+    ref = orc.ridge_fit(A, b, w, 1e-8)
+    assert maxrel(got[1][0], ref) < 1e-6
+    ctx.close()
+
+
 def test_fit_dist_needs_a_communicator_and_survives_a_rank_local_failure(ta):
     A, b, w = ta
     K = A.shape[1]
