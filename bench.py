@@ -301,7 +301,7 @@ def run_mode(ctx, args, mode, rank, world, multi, _capi):
     ctx.set_weights(w)
     tim = ctx.timing()
     upload_ms = tim["upload_ms"]
-    upload_how = {"pageable_probe_GBps": tim.get("upload_probe_GBps"), "page_locked_double_buffer": tim.get("upload_staged")}
+    upload_how = {"host_fill_probe_GBps": tim.get("upload_probe_GBps"), "page_locked_double_buffer": tim.get("upload_staged")}
     info = ctx.launch_info()
 
     def step():

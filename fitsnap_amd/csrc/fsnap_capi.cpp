@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -22,6 +23,9 @@
 #include "fsnap_kernels.h"
 
 // fsnap_solve with a contiguous copy of diag(G) (fsnap_solve.cpp; not part of the public ABI)
+extern "C" int fsnap_solve_diag_tagged(int kind, double param, int64_t K, const double* G, const double* c, const double* diag,
+                                       double* beta, int* rank, double* rcond_est, int upper, const void* owner,
+                                       unsigned long long generation);
 extern "C" int fsnap_solve_diag_upper(int kind, double param, int64_t K, const double* G, const double* c, const double* diag,
                                       double* beta, int* rank, double* rcond_est);
 extern "C" int fsnap_solve_diag(int kind, double param, int64_t K, const double* G, const double* c, const double* diag,
@@ -40,6 +44,12 @@ std::string& library_error() {
 
 namespace {
 
+// process-wide fill counter of the host mirrors: a (context, generation) tag is never reused, not even by a context that is
+// created at the address of a destroyed one
+unsigned long long next_mirror_generation() {
+    static std::atomic<unsigned long long> counter{0};
+    return ++counter;
+}
 
 struct Geometry {
     int nblocks, split, threads;
@@ -179,10 +189,18 @@ int staged_h2d(fsnap_ctx* ctx, void* dst, const void* src, size_t bytes) {
 // 1 GB matrix of the headline shape ran at 10 GB/s on one box and 37 GB/s on another (the runtime pins or stages the
 // user's pages itself, single-threaded); rows with a leading dimension wider than the row are packed on the way.
 // Returns with every byte handed to the stream (the caller's buffer is free); not synchronised.
-int staged_rows_h2d(fsnap_ctx* ctx, void* dst, const void* src, size_t rows, size_t row_bytes, size_t src_pitch) {
+// probe (optional): after two pieces the host-side fill rate (bytes copied into the slots per second of memcpy time) is
+// compared with min_fill_rate; below it the function stops, *rows_done says how far it got, and the caller sends the rest
+// another way.
+int staged_rows_h2d(fsnap_ctx* ctx, void* dst, const void* src, size_t rows, size_t row_bytes, size_t src_pitch,
+                    double min_fill_rate = 0.0, size_t* rows_done = nullptr, double* fill_rate = nullptr) {
     const size_t total = rows * row_bytes;
+    if (rows_done) *rows_done = 0;
     if (total == 0) return FSNAP_OK;
-    const size_t slot_bytes = (size_t)32 << 20;
+    const size_t slot_bytes = (size_t)16 << 20;
+    double fill_s = 0.0;
+    size_t fill_bytes = 0;
+    int pieces = 0;
     for (int i = 0; i < 2; ++i) {
         if (!ctx->rstage[i] && hipHostMalloc((void**)&ctx->rstage[i], slot_bytes, hipHostMallocDefault) != hipSuccess) {
             ctx->rstage[i] = nullptr;
@@ -215,6 +233,7 @@ int staged_rows_h2d(fsnap_ctx* ctx, void* dst, const void* src, size_t rows, siz
             }
         };
         const int nt = (nr * row_bytes >= ((size_t)4 << 20)) ? nthreads : 1;
+        const auto tf0 = std::chrono::steady_clock::now();
         if (nt <= 1) {
             copy_part(0, nr);
         } else {
@@ -224,10 +243,15 @@ int staged_rows_h2d(fsnap_ctx* ctx, void* dst, const void* src, size_t rows, siz
             copy_part(0, nr / nt);
             for (auto& x : th) x.join();
         }
+        fill_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();
+        fill_bytes += nr * row_bytes;
         FSNAP_HIP(hipMemcpyAsync((char*)dst + r0 * row_bytes, stage, nr * row_bytes, hipMemcpyHostToDevice, ctx->stream),
                   "hipMemcpy(staged rows)");
         FSNAP_HIP(hipEventRecord(ctx->rstage_ev[slot], ctx->stream), "hipEventRecord");
         used[slot] = true;
+        if (rows_done) *rows_done = r0 + nr;
+        if (fill_rate) *fill_rate = fill_s > 0.0 ? (double)fill_bytes / fill_s : 0.0;
+        if (++pieces == 2 && min_fill_rate > 0.0 && fill_s > 0.0 && (double)fill_bytes / fill_s < min_fill_rate) return FSNAP_OK;
     }
     return FSNAP_OK;
 }
@@ -591,6 +615,7 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
         ctx->mirror_of = d_packed;
         ctx->mirror_K = ctx->K;
         ctx->mirror_upper = upper_mirror;
+        ctx->mirror_gen = next_mirror_generation();
     }
     if (evs) ctx->t_syrk = true;
     return FSNAP_OK;
@@ -825,40 +850,31 @@ int fsnap_upload_rows(fsnap_ctx* ctx, const double* A, int64_t m, int64_t K, int
         return ctx->fail(FSNAP_E_NOMEM, "hipMalloc of %zu bytes for A failed", abytes);
     FSNAP_HIP(hipEventRecord(ctx->ev[3], ctx->stream), "hipEventRecord");
     FSNAP_HIP(hipMemsetAsync((char*)ctx->ownA.p + abytes, 0, 256, ctx->stream), "hipMemsetAsync");
-    // Large matrices: which way is faster depends on the box.  The runtime's pageable copy pins the caller's pages and lets the
-    // DMA engine read them in place -- 38 GB/s where that is cheap (huge pages), 10 GB/s where it is not (measured on two
-    // boxes of this pool); the page-locked double buffer (staged_rows_h2d) costs host memcpy time instead -- 10 GB/s inside
-    // a CPU-quota'd container, PCIe rate with free cores.  Option staged_upload: 0 = pageable copy, 2 = double buffer,
-    // 1 (default) = time the first 64 MiB through the pageable copy and keep it if it runs at >= 20 GB/s, else send the rest
-    // through the double buffer.
+    // Large matrices: which way is faster depends on the box.  The runtime's pageable copy of a matrix this size pins the
+    // caller's pages and lets the DMA engine read them in place -- 38 GB/s where pinning is cheap, 10 GB/s where it is not
+    // (both measured on boxes of this pool; small pageable copies go through the runtime's own single-threaded staging and
+    // say nothing about the large ones: a 64 MiB probe ran at 7 GB/s on the box whose 1 GB copy ran at 38).  The page-locked
+    // double buffer (staged_rows_h2d) costs host memcpy time instead -- 10 GB/s inside a CPU-quota'd container, PCIe rate
+    // with free cores.  Option staged_upload: 0 = pageable copy, 2 = double buffer, 1 (default) = start with the double
+    // buffer, look at the rate at which the host fills its first two 16 MiB slots, and hand the rest to the pageable copy
+    // when that is below 20 GB/s.
     size_t done_rows = 0;
     int staged = FSNAP_E_STATE;
-    const bool big = abytes >= ((size_t)256 << 20) && (size_t)K * 8 <= ((size_t)32 << 20);
-    bool use_staged = ctx->opt_staged_upload == 2 && abytes >= ((size_t)8 << 20) && (size_t)K * 8 <= ((size_t)32 << 20);
-    if (ctx->opt_staged_upload == 1 && big) {
-        const size_t probe_rows = std::min<size_t>((size_t)m, (((size_t)64 << 20) + (size_t)K * 8 - 1) / ((size_t)K * 8));
-        FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
-        const auto t0 = std::chrono::steady_clock::now();
-        if (lda == K) {
-            FSNAP_HIP(hipMemcpyAsync(ctx->ownA.p, A, probe_rows * (size_t)K * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(A)");
-        } else {
-            FSNAP_HIP(hipMemcpy2DAsync(ctx->ownA.p, (size_t)K * 8, A, (size_t)lda * 8, (size_t)K * 8, probe_rows,
-                                       hipMemcpyHostToDevice, ctx->stream),
-                      "hipMemcpy2D(A)");
-        }
-        FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
-        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        done_rows = probe_rows;
-        use_staged = (double)(probe_rows * (size_t)K * 8) / sec < 20.0e9;
-        ctx->upload_probe_gbps = (double)(probe_rows * (size_t)K * 8) / sec / 1e9;
+    const bool fits = (size_t)K * 8 <= ((size_t)16 << 20);
+    if (ctx->opt_staged_upload == 2 && abytes >= ((size_t)8 << 20) && fits) {
+        staged = staged_rows_h2d(ctx, ctx->ownA.p, A, (size_t)m, (size_t)K * 8, (size_t)lda * 8, 0.0, &done_rows);
+        if (staged != FSNAP_OK && staged != FSNAP_E_NOMEM) return staged;
+        if (staged != FSNAP_OK) done_rows = 0;
+    } else if (ctx->opt_staged_upload == 1 && abytes >= ((size_t)256 << 20) && fits) {
+        double rate = 0.0;
+        staged = staged_rows_h2d(ctx, ctx->ownA.p, A, (size_t)m, (size_t)K * 8, (size_t)lda * 8, 20.0e9, &done_rows, &rate);
+        if (staged != FSNAP_OK && staged != FSNAP_E_NOMEM) return staged;
+        if (staged != FSNAP_OK) done_rows = 0;
+        ctx->upload_probe_gbps = rate / 1e9;
     }
     const size_t rest = (size_t)m - done_rows;
-    if (use_staged && rest > 0) {
-        staged = staged_rows_h2d(ctx, (char*)ctx->ownA.p + done_rows * (size_t)K * 8, A + done_rows * (size_t)lda, rest,
-                                 (size_t)K * 8, (size_t)lda * 8);
-        if (staged != FSNAP_OK && staged != FSNAP_E_NOMEM) return staged;
-    }
-    if (staged != FSNAP_OK && rest > 0) {
+    if (rest > 0) {
+        staged = FSNAP_E_STATE;                 // (part of) the matrix goes through the runtime's pageable copy
         if (lda == K) {
             FSNAP_HIP(hipMemcpyAsync((char*)ctx->ownA.p + done_rows * (size_t)K * 8, A + done_rows * (size_t)lda, rest * (size_t)K * 8,
                                      hipMemcpyHostToDevice, ctx->stream),
@@ -1249,6 +1265,7 @@ int fsnap_mirror_packed(fsnap_ctx* ctx, const double* d_packed, int64_t K) {
     ctx->mirror_of = d_packed;
     ctx->mirror_K = K;
     ctx->mirror_upper = false;
+    ctx->mirror_gen = next_mirror_generation();
     return FSNAP_OK;
 }
 
@@ -1512,8 +1529,9 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
         int wrc;
         if ((wrc = fsnap::wait_stream(ctx, ctx->mirror_ev, "statistics mirror"))) return wrc;
         const double* Gm = ctx->mirror;
-        const int rcm = (ctx->mirror_upper ? fsnap_solve_diag_upper : fsnap_solve_diag)(kind, param, K, Gm, rhs ? rhs : Gm + K * K,
-                                                                                         Gm + K * K + K + 3, beta, rank, rcond_est);
+        // tagged with (context, fill count of the mirror): the refinement solves of a fit reuse the factor of its first solve
+        const int rcm = fsnap_solve_diag_tagged(kind, param, K, Gm, rhs ? rhs : Gm + K * K, Gm + K * K + K + 3, beta, rank, rcond_est,
+                                                ctx->mirror_upper ? 1 : 0, ctx, ctx->mirror_gen);
         if (rcm) ctx->fail(rcm, "fsnap_solve: numerical status %d", rcm);
         return rcm;
     }

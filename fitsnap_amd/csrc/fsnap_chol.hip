@@ -272,7 +272,7 @@ __device__ __forceinline__ void chol_wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int a>
+template <int a, int V>
 __device__ __forceinline__ void chol_diag_step(d4 (&B)[4][4], double (*T)[17], double (*UT)[16], double* __restrict__ S,
                                                int ld, int jb, double* __restrict__ Y, int e, int kr, double& pmin,
                                                double& psum) {
@@ -281,25 +281,111 @@ __device__ __forceinline__ void chol_diag_step(d4 (&B)[4][4], double (*T)[17], d
     d4 Z;
 #pragma unroll
     for (int r = 0; r < 4; ++r) Z[r] = (4 * r + kr == e) ? 1.0 : 0.0;
+    // The pivot chain, three forms (V; FSNAP_CHOL_DIAG selects, A/B):
+    //   0  pivot j read back from the rank-1 MFMA of step j - 1: MFMA -> v_readlane -> rsq + Newton -> scale -> MFMA;
+    //   1  pivot j + 1 formed on the side from two entries of the block as step j found it,
+    //      d_{j+1} = D[j+1][j+1] - (D[j][j+1] / sqrt(d_j))^2 (one multiply and one FMA behind 1/sqrt(d_j); the same value
+    //      as the MFMA's own: one fused multiply-add on the same operands), so that the 16 passes of the MFMA leave the
+    //      chain; instruction order left to the compiler;
+    //   2  the same with the order fixed by hand: D's MFMA, the next pivot and the first Newton step, Z's MFMA (the matrix
+    //      pipe takes one fp64 MFMA per 64 cycles: the second one waits in front of whatever follows it), the rest of Newton.
+    if constexpr (V == 0) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int q = j >> 2, k = j & 3;
-        const double d = readlane_f64(D[q], k * 16 + j);   // pivot (the same value in every lane)
-        pmin = d < pmin ? d : pmin;                        // (a NaN pivot is caught by the sum)
-        psum += d;
-        const double inv = rsqrt_newton(d);
-        const bool own = (kr == k);                        // the lanes that hold row j
-        const double ud = D[q] * inv;                      // U[j][e] (e >= j; e == j: d / sqrt(d))
-        const double zd = Z[q] * inv;                      // (U^-T)[j][e]
-        const bool keep = own && e >= j;
-        D[q] = keep ? ud : D[q];                           // the strictly lower part keeps its (finite) input values
-        Z[q] = own ? zd : Z[q];
-        if (j < 15) {
-            const double aop = (own && e > j) ? -ud : 0.0;  // A[i][k] = -U[j][i] for the rows i > j
-            const double bop = keep ? ud : 0.0;             // B[k][e] = U[j][e]
-            const double zop = own ? zd : 0.0;
-            D = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, D, 0, 0, 0);     // S[i][e] -= U[j][i] U[j][e]
-            Z = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, zop, Z, 0, 0, 0);     // Z[i][e] -= U[j][i] Z[j][e]
+        for (int j = 0; j < 16; ++j) {
+            const int q = j >> 2, k = j & 3;
+            const double d = readlane_f64(D[q], k * 16 + j);   // pivot (the same value in every lane)
+            pmin = d < pmin ? d : pmin;                        // (a NaN pivot is caught by the sum)
+            psum += d;
+            const double inv = rsqrt_newton(d);
+            const bool own = (kr == k);                        // the lanes that hold row j
+            const double ud = D[q] * inv;                      // U[j][e] (e >= j; e == j: d / sqrt(d))
+            const double zd = Z[q] * inv;                      // (U^-T)[j][e]
+            const bool keep = own && e >= j;
+            D[q] = keep ? ud : D[q];                           // the strictly lower part keeps its (finite) input values
+            Z[q] = own ? zd : Z[q];
+            if (j < 15) {
+                const double aop = (own && e > j) ? -ud : 0.0;  // A[i][k] = -U[j][i] for the rows i > j
+                const double bop = keep ? ud : 0.0;             // B[k][e] = U[j][e]
+                const double zop = own ? zd : 0.0;
+                D = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, D, 0, 0, 0);     // S[i][e] -= U[j][i] U[j][e]
+                Z = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, zop, Z, 0, 0, 0);     // Z[i][e] -= U[j][i] Z[j][e]
+            }
+        }
+    } else if constexpr (V == 1) {
+        double dcur = readlane_f64(D[0], 0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int q = j >> 2, k = j & 3;
+            const double d = dcur;
+            pmin = d < pmin ? d : pmin;
+            psum += d;
+            const double inv = rsqrt_newton(d);
+            if (j < 15) {
+                const int q1 = (j + 1) >> 2, k1 = (j + 1) & 3;
+                const double t = readlane_f64(D[q], k * 16 + j + 1);        // D[j][j + 1] before this step's scaling
+                const double pn = readlane_f64(D[q1], k1 * 16 + j + 1);     // D[j + 1][j + 1] before this step's update
+                const double u = t * inv;
+                dcur = __builtin_fma(-u, u, pn);
+            }
+            const bool own = (kr == k);
+            const double ud = D[q] * inv;
+            const double zd = Z[q] * inv;
+            const bool keep = own && e >= j;
+            D[q] = keep ? ud : D[q];
+            Z[q] = own ? zd : Z[q];
+            if (j < 15) {
+                const double aop = (own && e > j) ? -ud : 0.0;
+                const double bop = keep ? ud : 0.0;
+                const double zop = own ? zd : 0.0;
+                D = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, D, 0, 0, 0);
+                Z = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, zop, Z, 0, 0, 0);
+            }
+        }
+    } else {
+        double dcur = readlane_f64(D[0], 0);
+        double inv = rsqrt_newton(dcur);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int q = j >> 2, k = j & 3;
+            const double d = dcur;
+            pmin = d < pmin ? d : pmin;
+            psum += d;
+            double t = 0.0, pn = 0.0;
+            if (j < 15) {
+                const int q1 = (j + 1) >> 2, k1 = (j + 1) & 3;
+                t = readlane_f64(D[q], k * 16 + j + 1);
+                pn = readlane_f64(D[q1], k1 * 16 + j + 1);
+            }
+            const bool own = (kr == k);
+            const double ud = D[q] * inv;
+            const double zd = Z[q] * inv;
+            const bool keep = own && e >= j;
+            D[q] = keep ? ud : D[q];
+            Z[q] = own ? zd : Z[q];
+            if (j < 15) {
+                const double aop = (own && e > j) ? -ud : 0.0;
+                const double bop = keep ? ud : 0.0;
+                const double zop = own ? zd : 0.0;
+                D = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, D, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const double u = t * inv;
+                dcur = __builtin_fma(-u, u, pn);
+                double y = __builtin_amdgcn_rsq(dcur);
+                const double h = 0.5 * dcur;
+                {
+                    const double e1 = __builtin_fma(-h * y, y, 0.5);
+                    y = __builtin_fma(y, e1, y);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                Z = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, zop, Z, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const double e1 = __builtin_fma(-h * y, y, 0.5);
+                    y = __builtin_fma(y, e1, y);
+                }
+                inv = y;
+            }
         }
     }
 #pragma unroll
@@ -334,7 +420,8 @@ __device__ __forceinline__ void chol_diag_step(d4 (&B)[4][4], double (*T)[17], d
 }
 
 // the whole of kernel 8b for the panel at jb, executed by ONE wave (lane = threadIdx.x & 63); T: 16 x 17 doubles of LDS
-__device__ __forceinline__ void chol_diag_body(double* __restrict__ S, int ld, int jb, double* __restrict__ Y,
+template <int V>
+__device__ __forceinline__ void chol_diag_body_v(double* __restrict__ S, int ld, int jb, double* __restrict__ Y,
                                                int* __restrict__ status, double* __restrict__ minpiv, double (*T)[17],
                                                double (*UT)[16], int lane) {
     const int e = lane & 15, kr = lane >> 4;
@@ -346,10 +433,10 @@ __device__ __forceinline__ void chol_diag_body(double* __restrict__ S, int ld, i
 #pragma unroll
             for (int r = 0; r < 4; ++r) B[a][b][r] = S[(size_t)(jb + 16 * a + 4 * r + kr) * ld + jb + 16 * b + e];
     double pmin = 1.0e300, psum = 0.0;
-    chol_diag_step<0>(B, T, UT, S, ld, jb, Y, e, kr, pmin, psum);
-    chol_diag_step<1>(B, T, UT, S, ld, jb, Y, e, kr, pmin, psum);
-    chol_diag_step<2>(B, T, UT, S, ld, jb, Y, e, kr, pmin, psum);
-    chol_diag_step<3>(B, T, UT, S, ld, jb, Y, e, kr, pmin, psum);
+    chol_diag_step<0, V>(B, T, UT, S, ld, jb, Y, e, kr, pmin, psum);
+    chol_diag_step<1, V>(B, T, UT, S, ld, jb, Y, e, kr, pmin, psum);
+    chol_diag_step<2, V>(B, T, UT, S, ld, jb, Y, e, kr, pmin, psum);
+    chol_diag_step<3, V>(B, T, UT, S, ld, jb, Y, e, kr, pmin, psum);
     if (!(pmin > 0.0) || !__builtin_isfinite(psum)) {      // non-positive, NaN or infinite pivot
         if (lane == 0) atomicOr(status, 2);
         return;
@@ -363,11 +450,20 @@ __device__ __forceinline__ void chol_diag_body(double* __restrict__ S, int ld, i
     if (lane == 0) minpiv[jb / CHOL_NB] = pmin;
 }
 
+// variant: wave-uniform (a kernel argument; FSNAP_CHOL_DIAG on the host side)
+__device__ __forceinline__ void chol_diag_body(double* __restrict__ S, int ld, int jb, double* __restrict__ Y,
+                                               int* __restrict__ status, double* __restrict__ minpiv, double (*T)[17],
+                                               double (*UT)[16], int lane, int variant) {
+    if (variant == 0) chol_diag_body_v<0>(S, ld, jb, Y, status, minpiv, T, UT, lane);
+    else if (variant == 1) chol_diag_body_v<1>(S, ld, jb, Y, status, minpiv, T, UT, lane);
+    else chol_diag_body_v<2>(S, ld, jb, Y, status, minpiv, T, UT, lane);
+}
+
 __global__ __launch_bounds__(64) void fsnap_chol_diag_k(double* __restrict__ S, int ld, int jb, double* __restrict__ Y,
-                                                       int* __restrict__ status, double* __restrict__ minpiv) {
+                                                       int* __restrict__ status, double* __restrict__ minpiv, int variant) {
     __shared__ double T[16][17];
     __shared__ __attribute__((aligned(16))) double UT[16][16];
-    chol_diag_body(S, ld, jb, Y, status, minpiv, T, UT, (int)threadIdx.x);
+    chol_diag_body(S, ld, jb, Y, status, minpiv, T, UT, (int)threadIdx.x, variant);
 }
 
 // 8c: blocked forward substitution on the matrix pipe.  One wave per 16-column strip of the columns right of the
@@ -480,7 +576,7 @@ __device__ __forceinline__ void chol_update_pair(double* __restrict__ S, int ld,
 // (was: diagonal 16 us -> tails 5 us -> update 7 us per panel, one after the other).
 __global__ __launch_bounds__(256) void fsnap_chol_update_diag_k(double* __restrict__ S, int ld, int jb, int nblk,
                                                                int* __restrict__ status, double* __restrict__ Ynext,
-                                                               double* __restrict__ minpiv) {
+                                                               double* __restrict__ minpiv, int variant) {
     __shared__ double T[16][17];
     __shared__ __attribute__((aligned(16))) double UT[16][16];
     if (*status) return;
@@ -488,7 +584,7 @@ __global__ __launch_bounds__(256) void fsnap_chol_update_diag_k(double* __restri
     if (blockIdx.x == 0) {
         if (wave < 3) chol_update_pair(S, ld, jb, nblk, wave == 2 ? nblk : wave, lane);
         __syncthreads();
-        if (wave == 0) chol_diag_body(S, ld, jb + CHOL_NB, Ynext, status, minpiv, T, UT, lane);
+        if (wave == 0) chol_diag_body(S, ld, jb + CHOL_NB, Ynext, status, minpiv, T, UT, lane, variant);
         return;
     }
     const int total = nblk * (nblk + 1) / 2 + nblk;
@@ -795,6 +891,16 @@ size_t chol_large_work_doubles(int n) {
     return np * (np + CHOL_XS) + (np / CHOL_NB) * 1024;     // work matrix + strip, Y blocks of every panel
 }
 
+// pivot-chain form of kernel 8b (see chol_diag_step): FSNAP_CHOL_DIAG = 0 | 1 | 2
+static int chol_diag_variant() {
+    static const int v = [] {
+        const char* e = getenv("FSNAP_CHOL_DIAG");
+        const int x = e ? atoi(e) : 2;
+        return x < 0 || x > 2 ? 2 : x;
+    }();
+    return v;
+}
+
 hipError_t launch_chol_large(const double* packed, const double* cvec, int n, double alpha, double* work, double* dsc, double* z,
                              double* beta, int* status, double* minpiv, double* host_out, bool clear_status, hipStream_t st) {
     if (!cvec) cvec = packed + (size_t)n * n;
@@ -812,7 +918,7 @@ hipError_t launch_chol_large(const double* packed, const double* cvec, int n, do
                        minpiv, npanel);
     hipLaunchKernelGGL(fsnap_chol_prepare_s_k, dim3((ld + 255) / 256, np), dim3(256), 0, st, packed, n, np, alpha, dsc, z, S,
                        status);
-    hipLaunchKernelGGL(fsnap_chol_diag_k, dim3(1), dim3(64), 0, st, S, ld, 0, Yall, status, minpiv);
+    hipLaunchKernelGGL(fsnap_chol_diag_k, dim3(1), dim3(64), 0, st, S, ld, 0, Yall, status, minpiv, chol_diag_variant());
     for (int pb = 0; pb < npanel; ++pb) {
         const int jb = pb * CHOL_NB;
         double* Y = Yall + (size_t)pb * 1024;
@@ -823,7 +929,7 @@ hipError_t launch_chol_large(const double* packed, const double* cvec, int n, do
             // trailing update of this panel + factorisation of the next diagonal block (look-ahead), one launch
             const int nblk = ntail / 32, nrest = nblk * (nblk + 1) / 2 + nblk - 3;
             hipLaunchKernelGGL(fsnap_chol_update_diag_k, dim3(1 + (nrest + 3) / 4), dim3(256), 0, st, S, ld, jb, nblk, status,
-                               Y + 1024, minpiv);
+                               Y + 1024, minpiv, chol_diag_variant());
         }
     }
     static bool bs_attr_set = false;
@@ -854,7 +960,7 @@ hipError_t launch_chol_factor(const double* G, int n, double shift, double* work
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fsnap_chol_factor_prepare_d_k, dim3((np + 255) / 256), dim3(256), 0, st, G, n, np, dsc, status, minpiv, npanel);
     hipLaunchKernelGGL(fsnap_chol_factor_prepare_s_k, dim3((ld + 255) / 256, np), dim3(256), 0, st, G, n, np, shift, dsc, S, status);
-    hipLaunchKernelGGL(fsnap_chol_diag_k, dim3(1), dim3(64), 0, st, S, ld, 0, Yall, status, minpiv);
+    hipLaunchKernelGGL(fsnap_chol_diag_k, dim3(1), dim3(64), 0, st, S, ld, 0, Yall, status, minpiv, chol_diag_variant());
     for (int pb = 0; pb < npanel; ++pb) {
         const int jb = pb * CHOL_NB;
         double* Y = Yall + (size_t)pb * 1024;
@@ -865,7 +971,7 @@ hipError_t launch_chol_factor(const double* G, int n, double shift, double* work
         if (ntail > 0) {
             const int nblk = ntail / 32, nrest = nblk * (nblk + 1) / 2 + nblk - 3;
             hipLaunchKernelGGL(fsnap_chol_update_diag_k, dim3(1 + (nrest + 3) / 4), dim3(256), 0, st, S, ld, jb, nblk, status,
-                               Y + 1024, minpiv);
+                               Y + 1024, minpiv, chol_diag_variant());
         }
     }
     const int64_t total = (int64_t)K16 * K16 + (int64_t)K16 * 16;

@@ -100,6 +100,7 @@ struct fsnap_ctx {
     size_t mirror_bytes = 0;
     const double* mirror_of = nullptr;            // device buffer the mirror currently reflects (nullptr = stale)
     int64_t mirror_K = 0;                         // order of the system in the mirror
+    unsigned long long mirror_gen = 0;            // fills of the mirror so far: (context, mirror_gen) tags one content of it
     bool mirror_upper = false;                    // only the upper triangle of the mirror's G is meaningful (kernel 2b)
     hipEvent_t mirror_ev = nullptr;               // recorded after the reduction that filled the mirror
     // options
@@ -132,7 +133,7 @@ struct fsnap_ctx {
     size_t wstage_bytes[2] = {0, 0};
     hipEvent_t wstage_ev[2] = {nullptr, nullptr};
     int wstage_next = 0;
-    // page-locked double buffer of fsnap_upload_rows (two 32 MiB slots: host threads fill one while the DMA drains the other)
+    // page-locked double buffer of fsnap_upload_rows (two 16 MiB slots: host threads fill one while the DMA drains the other)
     char* rstage[2] = {nullptr, nullptr};
     hipEvent_t rstage_ev[2] = {nullptr, nullptr};
     DevBuf wtrain, wrank;                         // compact training weights and the mask's exclusive prefix sum
@@ -148,8 +149,8 @@ struct fsnap_ctx {
     DevBuf tribuf;                                // [upper triangle | c | scalars]: all-reduce payload of wide systems
     int opt_reduce_triangle = -1;                 // all-reduce the triangle only: -1 = K >= 256, 0 = never, 1 = always
     int opt_staged_upload = 1;    // fsnap_upload_rows: 0 pageable hipMemcpy | 2 page-locked double buffer | 1 probe the first 64 MiB, then the faster
-    double upload_probe_gbps = 0.0;   // what the probe of the last large upload measured (pageable copy, GB/s)
-    bool upload_staged = false;       // the last upload went through the double buffer
+    double upload_probe_gbps = 0.0;   // rate at which the host filled the first page-locked slots of the last large upload (GB/s)
+    bool upload_staged = false;       // the whole of the last upload went through the double buffer
     int opt_fused_residual = 1;   // fsnap_residual_rhs: one pass over the rows for K <= 256 (0: kernels 4 + 7, two passes)
     int opt_reduce = 0;       // reduction of kernel 1 / 1A / 1P partials: 0 = kernel 2b, 1 = kernel 2 (A/B)
     int opt_mirror_upper = 1; // kernel 2b writes the host mirror's triangle once per element (upper positions)

@@ -645,7 +645,7 @@ extern "C" int fsnap_solve_diag_upper(int kind, double param, int64_t K64, const
                                       double* beta, int* rank_out, double* rcond_est);
 namespace {
 int solve_impl(int kind, double param, int64_t K64, const double* G, const double* c, const double* diag, double* beta,
-               int* rank_out, double* rcond_est, bool upper_only);
+               int* rank_out, double* rcond_est, bool upper_only, const void* owner = nullptr, unsigned long long generation = 0);
 }
 
 // In-place Cholesky U^T U of an n x n row-major matrix for the other translation units of the library (the row-space
@@ -676,9 +676,20 @@ extern "C" __attribute__((visibility("hidden"))) int fsnap_solve_diag_upper(int 
     return solve_impl(kind, param, K64, G, c, diag, beta, rank_out, rcond_est, true);
 }
 
+// The same with a tag of the matrix: (owner, generation) names ONE content of G (the context's host mirror after its
+// n-th fill).  A second solve with the same tag, kind and parameter -- the refinement steps of the SVD solver solve
+// G delta = s two more times per fit -- reuses the Cholesky factor the first one left in this thread's workspace and
+// runs the two triangular sweeps only (3.5 instead of 23 us at K = 128).  upper != 0: fsnap_solve_diag_upper semantics.
+extern "C" __attribute__((visibility("hidden"))) int fsnap_solve_diag_tagged(int kind, double param, int64_t K64, const double* G,
+                                                                             const double* c, const double* diag, double* beta,
+                                                                             int* rank_out, double* rcond_est, int upper,
+                                                                             const void* owner, unsigned long long generation) {
+    return solve_impl(kind, param, K64, G, c, diag, beta, rank_out, rcond_est, upper != 0, owner, generation);
+}
+
 namespace {
 int solve_impl(int kind, double param, int64_t K64, const double* G, const double* c, const double* diag, double* beta,
-               int* rank_out, double* rcond_est, bool upper_only) {
+               int* rank_out, double* rcond_est, bool upper_only, const void* owner, unsigned long long generation) {
     PhaseTimer timer;
     if (!G || !c || !beta || K64 <= 0 || K64 > (1 << 20)) return FSNAP_E_ARG;
     if (kind < FSNAP_SOLVE_CHOL || kind > FSNAP_SOLVE_RIDGE_INV_PROBE) return FSNAP_E_ARG;
@@ -706,6 +717,28 @@ int solve_impl(int kind, double param, int64_t K64, const double* G, const doubl
         // hosts K = 512 took 0.9 or 8.9 ms depending on the physical pages of the run -- one more chunk of padding
         if (Kp >= 384 && (Kp & 127) == 0) Kp += 32;
         static thread_local vec U, dsc, z;
+        // the factor this thread's workspace holds: valid for one tagged content of G (see fsnap_solve_diag_tagged)
+        static thread_local struct { const void* owner; unsigned long long gen; int K; double alpha, mp2; } held = {nullptr, 0, 0, 0.0, 0.0};
+        if (owner && held.owner == owner && held.gen == generation && held.K == K && held.alpha == alpha &&
+            U.size() == (size_t)Kp * Kp) {
+            bool fin = true;
+            for (int i = 0; i < K; ++i) {
+                z[i] = c[i] * dsc[i];
+                fin = fin && (c[i] - c[i] == 0.0);
+            }
+            if (fin) {
+                for (int i = K; i < Kp; ++i) z[i] = 0.0;
+                chol_solve(U.data(), Kp, z.data());
+                for (int i = 0; i < K; ++i) beta[i] = z[i] * dsc[i];
+                timer.lap("tri solves (factor reused)");
+                if (all_finite(beta, K)) {
+                    if (rank_out) *rank_out = K;
+                    if (rcond_est) *rcond_est = held.mp2;
+                    return FSNAP_OK;
+                }
+            }
+        }
+        held.owner = nullptr;                 // the workspace is about to be overwritten
         U.resize((size_t)Kp * Kp);
         dsc.resize(Kp);
         z.resize(Kp);
@@ -786,6 +819,13 @@ int solve_impl(int kind, double param, int64_t K64, const double* G, const doubl
                 if (all_finite(beta, K)) {
                     if (rank_out) *rank_out = K;
                     if (rcond_est) *rcond_est = mp2;
+                    if (owner) {
+                        held.owner = owner;
+                        held.gen = generation;
+                        held.K = K;
+                        held.alpha = alpha;
+                        held.mp2 = mp2;
+                    }
                     return FSNAP_OK;
                 }
             }

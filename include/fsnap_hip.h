@@ -101,9 +101,9 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * "reduce_triangle" (fsnap_fit_dist / fsnap_lstsq_rows: -1 = systems of >= 256 columns all-reduce [upper triangle | c | scalars],
  * K (K + 1) / 2 + K + 3 doubles, between a pack and an unpack kernel, the default; 0 = always the full K^2 + K + 3; 1 = always
  * the triangle -- every rank of a job must use the same setting),
- * "staged_upload" (fsnap_upload_rows of >= 256 MiB: 1 = time the first 64 MiB through the runtime's pageable copy and keep it
- * when it runs at >= 20 GB/s, else send the rest through a page-locked double buffer filled by host threads, the default;
- * 0 = pageable copy; 2 = double buffer; FSNAP_UPLOAD_THREADS = host threads of the double buffer, default 4).
+ * "staged_upload" (fsnap_upload_rows of >= 256 MiB: 1 = start through a page-locked double buffer filled by host threads and,
+ * if the host fills its first two 16 MiB slots at less than 20 GB/s, hand the rest to the runtime's pageable copy, the
+ * default; 0 = pageable copy; 2 = double buffer; FSNAP_UPLOAD_THREADS = host threads of the double buffer, default 4).
  * Unknown key -> FSNAP_E_ARG. */
 int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value);
 
@@ -423,7 +423,8 @@ int fsnap_dev_download(fsnap_ctx* ctx, void* h_dst, const void* d_src, int64_t n
 /* HIP-event timings of the last fsnap_normal_eq* call, milliseconds:
  * ms[0] = SYRK kernel, ms[1] = partial reduction kernel, ms[2] = last H2D upload,
  * ms[3] = last stand-alone weighting kernel, ms[4] = last predict kernel; about the last large fsnap_upload_rows:
- * ms[5] = GB/s of the probed pageable copy (0: not probed), ms[6] = 1 if the rest went through the page-locked double buffer.
+ * ms[5] = GB/s at which the host filled the first page-locked slots (0: not probed), ms[6] = 1 if the whole matrix went
+ * through the page-locked double buffer.
  * Synchronises the context's stream.  n = number of entries of ms to fill (<= 8). */
 int fsnap_timing(fsnap_ctx* ctx, double* ms, int n);
 
