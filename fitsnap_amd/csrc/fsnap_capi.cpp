@@ -851,13 +851,13 @@ int fsnap_upload_rows(fsnap_ctx* ctx, const double* A, int64_t m, int64_t K, int
     FSNAP_HIP(hipEventRecord(ctx->ev[3], ctx->stream), "hipEventRecord");
     FSNAP_HIP(hipMemsetAsync((char*)ctx->ownA.p + abytes, 0, 256, ctx->stream), "hipMemsetAsync");
     // Large matrices: which way is faster depends on the box.  The runtime's pageable copy of a matrix this size pins the
-    // caller's pages and lets the DMA engine read them in place -- 38 GB/s where pinning is cheap, 10 GB/s where it is not
-    // (both measured on boxes of this pool; small pageable copies go through the runtime's own single-threaded staging and
-    // say nothing about the large ones: a 64 MiB probe ran at 7 GB/s on the box whose 1 GB copy ran at 38).  The page-locked
-    // double buffer (staged_rows_h2d) costs host memcpy time instead -- 10 GB/s inside a CPU-quota'd container, PCIe rate
-    // with free cores.  Option staged_upload: 0 = pageable copy, 2 = double buffer, 1 (default) = start with the double
-    // buffer, look at the rate at which the host fills its first two 16 MiB slots, and hand the rest to the pageable copy
-    // when that is below 20 GB/s.
+    // caller's pages and lets the DMA engine read them in place: 1.03 GB in 27 ms (38 GB/s) on the boxes of round 4, 100 ms
+    // on the driver's box of round 3.  The page-locked double buffer (staged_rows_h2d) costs host memcpy time instead: 104 ms
+    // on the round-4 boxes, whose CPU quota holds four copying threads at ~10 GB/s together, and the first touch of its
+    // freshly pinned slots alone cost ~60 ms there (0.6 GB/s over the first 32 MiB) -- a probe of either path on a small
+    // piece says nothing about the large copy (a 64 MiB pageable probe ran at 7 GB/s where the 1 GB copy ran at 38).
+    // So the default stays the pageable copy (option staged_upload = 0); 2 = double buffer (hosts with free cores and slow
+    // pinning), 1 = double buffer that hands the rest to the pageable copy when its first two slots fill at < 20 GB/s.
     size_t done_rows = 0;
     int staged = FSNAP_E_STATE;
     const bool fits = (size_t)K * 8 <= ((size_t)16 << 20);

@@ -460,20 +460,19 @@ __device__ __forceinline__ void chol_diag_body(double* __restrict__ S, int ld, i
 }
 
 __global__ __launch_bounds__(64) void fsnap_chol_diag_k(double* __restrict__ S, int ld, int jb, double* __restrict__ Y,
-                                                       int* __restrict__ status, double* __restrict__ minpiv, int variant) {
+                                                       int* __restrict__ status, double* __restrict__ minpiv, int variant,
+                                                       int* __restrict__ flag) {
     __shared__ double T[16][17];
     __shared__ __attribute__((aligned(16))) double UT[16][16];
+    if (threadIdx.x == 0 && flag) *flag = 0;          // hand-off word of the fused panel launches: cleared once per factorisation
     chol_diag_body(S, ld, jb, Y, status, minpiv, T, UT, (int)threadIdx.x, variant);
 }
 
 // 8c: blocked forward substitution on the matrix pipe.  One wave per 16-column strip of the columns right of the
 // panel (trailing columns + the right-hand-side strip).
-__global__ __launch_bounds__(256) void fsnap_chol_tails_k(double* __restrict__ S, int ld, int jb, int nstrip,
-                                                         const double* __restrict__ Y, const int* __restrict__ status) {
-    if (*status) return;
-    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
-    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (strip >= nstrip) return;
+__device__ __forceinline__ void chol_tails_strip(double* __restrict__ S, int ld, int jb, int strip,
+                                                 const double* __restrict__ Y, int lane) {
+    const int e = lane & 15, kr = lane >> 4;
     const int c0 = jb + CHOL_NB + 16 * strip;
     double* base = S + (size_t)(jb + kr) * ld;     // row jb + kr
     d4 X[4];
@@ -505,9 +504,18 @@ __global__ __launch_bounds__(256) void fsnap_chol_tails_k(double* __restrict__ S
         for (int r = 0; r < 4; ++r) base[(size_t)(16 * b + 4 * r) * ld + c0 + e] = X[b][r];
 }
 
+__global__ __launch_bounds__(256) void fsnap_chol_tails_k(double* __restrict__ S, int ld, int jb, int nstrip,
+                                                         const double* __restrict__ Y, const int* __restrict__ status) {
+    if (*status) return;
+    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (strip >= nstrip) return;
+    chol_tails_strip(S, ld, jb, strip, Y, (int)(threadIdx.x & 63));
+}
+
 // one 32 x 32 block pair of the trailing update (a 2 x 2 group of MFMA tiles), executed by one wave
+__device__ __forceinline__ void chol_update_pair_ij(double* __restrict__ S, int ld, int jb, int I, int J, int lane);
+
 __device__ __forceinline__ void chol_update_pair(double* __restrict__ S, int ld, int jb, int nblk, int pair, int lane) {
-    const int e = lane & 15, kr = lane >> 4;
     const int ntri = nblk * (nblk + 1) / 2;
     // pair -> (I, J), I <= J, row-major packed triangle over nblk 32-column blocks; then (I, strip) for every I
     int I, J;
@@ -523,6 +531,13 @@ __device__ __forceinline__ void chol_update_pair(double* __restrict__ S, int ld,
         I = pair - ntri;
         J = nblk;          // je + 32 nblk = np: the right-hand-side strip
     }
+    chol_update_pair_ij(S, ld, jb, I, J, lane);
+}
+
+// block pair (I, J) of the trailing matrix behind panel jb (32-column blocks counted from the end of the panel; J = number of
+// blocks: the right-hand-side strip)
+__device__ __forceinline__ void chol_update_pair_ij(double* __restrict__ S, int ld, int jb, int I, int J, int lane) {
+    const int e = lane & 15, kr = lane >> 4;
     const int je = jb + CHOL_NB;
     const int cI = je + 32 * I, cJ = je + 32 * J;
     const double* base = S + (size_t)(jb + kr) * ld;
@@ -592,6 +607,115 @@ __global__ __launch_bounds__(256) void fsnap_chol_update_diag_k(double* __restri
     const int pair = q < nblk - 2 ? q + 2 : q + 3;
     if (pair >= total) return;
     chol_update_pair(S, ld, jb, nblk, pair, lane);
+}
+
+// 8d + 8b + 8c fused ("one launch per panel", FSNAP_CHOL_FUSED = 1; NOT the default: it measured slower, see chol_fused()): the launch that updates the trailing
+// matrix behind panel jb and factorises the next diagonal block ALSO runs the row tails of that next panel, so that a
+// panel costs one launch instead of two (a launch that does almost nothing still holds the stream for 4-5 us on this part:
+// 25 of them were ~110 of the 700 us of a K = 1595 solve).  Inside the launch the tails wait for the diagonal block behind
+// a flag:
+//   * workgroup 0, waves 0-2: the three block pairs of the next diagonal block; wave 0 then factorises it (kernel 8b's
+//     body), releases its stores (agent scope) and publishes `gen` in *flag -- also when a pivot failed (status is set then
+//     and nobody uses the result);
+//   * one "column wave" per 32-column block J >= 2 of the trailing matrix (and one for the right-hand-side strip): it
+//     updates the two block pairs (0, J), (1, J) -- the rows of the NEXT panel in its own columns, which nobody else
+//     touches --, polls the flag (relaxed agent-scope loads with s_sleep, BOUNDED: a wave that gives up sets status bit 2
+//     and the host falls back on its own factorisation; nothing can hang), acquires, and runs kernel 8c's substitution on
+//     its two 16-column strips;
+//   * the remaining waves: the block pairs (I, J) with I >= 2, as before.
+// Column waves need workgroup 0 to be running while they wait: workgroups are dispatched in index order on this part and
+// the grid of the shapes this path serves (K <= ~2000: <= 504 workgroups at two per CU) is resident as a whole; the bound
+// on the wait is the answer to everything else.
+constexpr int CHOL_FLAG_SPINS = 1 << 18;      // x s_sleep 16 (~1024 cycles): ~0.1 s
+
+__device__ __forceinline__ void chol_publish(int* flag, int gen) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the compiler may drop the wait behind the write-back (guide, G16)
+    __hip_atomic_store(flag, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ bool chol_wait_flag(const int* flag, int gen) {
+    int n = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) {
+        __builtin_amdgcn_s_sleep(16);
+        if (++n > CHOL_FLAG_SPINS) return false;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+}
+
+__global__ __launch_bounds__(256) void fsnap_chol_panel_k(double* __restrict__ S, int ld, int jb, int nblk,
+                                                         int* __restrict__ status, double* __restrict__ Ynext,
+                                                         double* __restrict__ minpiv, int variant, int* __restrict__ flag,
+                                                         int gen) {
+    __shared__ double T[16][17];
+    __shared__ __attribute__((aligned(16))) double UT[16][16];
+    if (*status) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gw = (int)blockIdx.x * 4 + wave;                 // global wave index
+    // waves 0-2: diagonal pairs (+ wave 0: the factorisation); waves 3 ... 3 + ncol - 1: column waves J = 2 ... nblk;
+    // then the rest pairs
+    const int ncol = nblk - 1;
+    if (blockIdx.x == 0) {
+        if (wave < 3) chol_update_pair_ij(S, ld, jb, wave == 2 ? 1 : 0, wave == 0 ? 0 : 1, lane);
+        // (the barrier below is reached by all four waves of workgroup 0: wave 3, a column wave, does its pairs first)
+        int J3 = 0;
+        if (wave == 3 && ncol > 0) {
+            J3 = 2;
+            chol_update_pair_ij(S, ld, jb, 0, J3, lane);
+            chol_update_pair_ij(S, ld, jb, 1, J3, lane);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            chol_diag_body(S, ld, jb + CHOL_NB, Ynext, status, minpiv, T, UT, lane, variant);
+            chol_publish(flag, gen);
+        } else if (wave == 3 && ncol > 0) {
+            if (!chol_wait_flag(flag, gen)) {
+                if (lane == 0) atomicOr(status, 4);
+                return;
+            }
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+            chol_tails_strip(S, ld, jb + CHOL_NB, 2 * J3 - 4, Ynext, lane);
+            chol_tails_strip(S, ld, jb + CHOL_NB, 2 * J3 - 3, Ynext, lane);
+        }
+        return;
+    }
+    const int cw = gw - 4;                                     // 0 ...: column waves J = 3 ..., then rest pairs
+    if (cw < ncol - 1) {
+        const int J = 3 + cw;                                  // J == nblk: the right-hand-side strip
+        chol_update_pair_ij(S, ld, jb, 0, J, lane);
+        chol_update_pair_ij(S, ld, jb, 1, J, lane);
+        if (!chol_wait_flag(flag, gen)) {
+            if (lane == 0) atomicOr(status, 4);
+            return;
+        }
+        if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        chol_tails_strip(S, ld, jb + CHOL_NB, 2 * J - 4, Ynext, lane);
+        chol_tails_strip(S, ld, jb + CHOL_NB, 2 * J - 3, Ynext, lane);
+        return;
+    }
+    // rest: pairs (I, J), 2 <= I <= J < nblk (packed triangle over nblk - 2 blocks), then (I, nblk) for 2 <= I < nblk
+    const int q = cw - (ncol > 1 ? ncol - 1 : 0);
+    const int nb2 = nblk - 2;
+    if (nb2 <= 0) return;
+    const int ntri2 = nb2 * (nb2 + 1) / 2;
+    int I, J;
+    if (q < ntri2) {
+        I = 0;
+        int rem = q;
+        while (rem >= nb2 - I) {
+            rem -= nb2 - I;
+            ++I;
+        }
+        J = I + rem + 2;
+        I += 2;
+    } else if (q < ntri2 + nb2) {
+        I = q - ntri2 + 2;
+        J = nblk;
+    } else {
+        return;
+    }
+    chol_update_pair_ij(S, ld, jb, I, J, lane);
 }
 
 // 8e: the strip's first column now holds y = U^-T z; solve U x = y from the bottom in MACRO-BLOCKS of four panels
@@ -888,7 +1012,7 @@ namespace fsnap {
 
 size_t chol_large_work_doubles(int n) {
     const size_t np = (size_t)(n + CHOL_NB - 1) / CHOL_NB * CHOL_NB;
-    return np * (np + CHOL_XS) + (np / CHOL_NB) * 1024;     // work matrix + strip, Y blocks of every panel
+    return np * (np + CHOL_XS) + (np / CHOL_NB) * 1024 + 8;     // work matrix + strip, Y blocks of every panel, hand-off word
 }
 
 // pivot-chain form of kernel 8b (see chol_diag_step): FSNAP_CHOL_DIAG = 0 | 1 | 2
@@ -901,12 +1025,57 @@ static int chol_diag_variant() {
     return v;
 }
 
+// FSNAP_CHOL_FUSED = 1: one launch per panel (kernel fsnap_chol_panel_k); default 0: two launches per panel (tails; update +
+// next diagonal block), the form of rounds 2-3 -- which measured FASTER: K = 1595 0.692 ms against 0.840 ms fused, K = 480
+// 0.222 / 0.261 (profiles/r04_chol_fused_ab.txt): the column waves of the fused launch run their two strips one after the
+// other behind the flag (the tails launch gives every strip a wave of its own), ~50 polling waves sit beside the single wave
+// that factorises the diagonal block, and the hand-off costs a release + an acquire per panel -- together more than the
+// ~4.5 us launch they replace.
+static bool chol_fused() {
+    static const bool v = [] {
+        const char* e = getenv("FSNAP_CHOL_FUSED");
+        return e && atoi(e) != 0;
+    }();
+    return v;
+}
+
+// the panel loop behind the first diagonal block (kernel 8b on panel 0 has run): row tails of panel 0, then per panel ONE
+// launch (update behind panel pb + diagonal block and row tails of panel pb + 1) -- or the two-launch form
+static void launch_chol_panels(double* S, int ld, int np, double* Yall, int* status, double* minpiv, int* flag, hipStream_t st) {
+    const int npanel = np / CHOL_NB;
+    const bool fused = chol_fused();
+    for (int pb = 0; pb < npanel; ++pb) {
+        const int jb = pb * CHOL_NB;
+        double* Y = Yall + (size_t)pb * 1024;
+        const int ntail = np - jb - CHOL_NB;
+        const int nstrip = (ntail + CHOL_XS) / 16;
+        if (pb == 0 || !fused)
+            hipLaunchKernelGGL(fsnap_chol_tails_k, dim3((nstrip + 3) / 4), dim3(256), 0, st, S, ld, jb, nstrip, Y, status);
+        if (ntail > 0) {
+            const int nblk = ntail / 32;
+            if (fused) {
+                // waves: 3 diagonal pairs + (nblk - 1) column waves + the pairs with I >= 2
+                const int nb2 = nblk - 2;
+                const int nwaves = 4 + (nblk - 2 > 0 ? nblk - 2 : 0) + (nb2 > 0 ? nb2 * (nb2 + 1) / 2 + nb2 : 0);
+                hipLaunchKernelGGL(fsnap_chol_panel_k, dim3((nwaves + 3) / 4), dim3(256), 0, st, S, ld, jb, nblk, status, Y + 1024,
+                                   minpiv, chol_diag_variant(), flag, pb + 1);
+            } else {
+                // trailing update of this panel + factorisation of the next diagonal block (look-ahead), one launch
+                const int nrest = nblk * (nblk + 1) / 2 + nblk - 3;
+                hipLaunchKernelGGL(fsnap_chol_update_diag_k, dim3(1 + (nrest + 3) / 4), dim3(256), 0, st, S, ld, jb, nblk, status,
+                                   Y + 1024, minpiv, chol_diag_variant());
+            }
+        }
+    }
+}
+
 hipError_t launch_chol_large(const double* packed, const double* cvec, int n, double alpha, double* work, double* dsc, double* z,
                              double* beta, int* status, double* minpiv, double* host_out, bool clear_status, hipStream_t st) {
     if (!cvec) cvec = packed + (size_t)n * n;
     const int np = (n + CHOL_NB - 1) / CHOL_NB * CHOL_NB, npanel = np / CHOL_NB, ld = np + CHOL_XS;
     double* S = work;
     double* Yall = work + (size_t)np * ld;
+    int* flag = (int*)(Yall + (size_t)npanel * 1024);      // hand-off word of the fused panel launches
     hipError_t e;
     // the status word is cleared by the last launch of the previous solve (host_out path); a launch of its own only the
     // first time this buffer is used, or when the results still travel by D2H copy
@@ -918,20 +1087,8 @@ hipError_t launch_chol_large(const double* packed, const double* cvec, int n, do
                        minpiv, npanel);
     hipLaunchKernelGGL(fsnap_chol_prepare_s_k, dim3((ld + 255) / 256, np), dim3(256), 0, st, packed, n, np, alpha, dsc, z, S,
                        status);
-    hipLaunchKernelGGL(fsnap_chol_diag_k, dim3(1), dim3(64), 0, st, S, ld, 0, Yall, status, minpiv, chol_diag_variant());
-    for (int pb = 0; pb < npanel; ++pb) {
-        const int jb = pb * CHOL_NB;
-        double* Y = Yall + (size_t)pb * 1024;
-        const int ntail = np - jb - CHOL_NB;
-        const int nstrip = (ntail + CHOL_XS) / 16;
-        hipLaunchKernelGGL(fsnap_chol_tails_k, dim3((nstrip + 3) / 4), dim3(256), 0, st, S, ld, jb, nstrip, Y, status);
-        if (ntail > 0) {
-            // trailing update of this panel + factorisation of the next diagonal block (look-ahead), one launch
-            const int nblk = ntail / 32, nrest = nblk * (nblk + 1) / 2 + nblk - 3;
-            hipLaunchKernelGGL(fsnap_chol_update_diag_k, dim3(1 + (nrest + 3) / 4), dim3(256), 0, st, S, ld, jb, nblk, status,
-                               Y + 1024, minpiv, chol_diag_variant());
-        }
-    }
+    hipLaunchKernelGGL(fsnap_chol_diag_k, dim3(1), dim3(64), 0, st, S, ld, 0, Yall, status, minpiv, chol_diag_variant(), flag);
+    launch_chol_panels(S, ld, np, Yall, status, minpiv, flag, st);
     static bool bs_attr_set = false;
     if (!bs_attr_set) {
         e = hipFuncSetAttribute((const void*)fsnap_chol_backsolve_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHOL_BS_LDS);
@@ -956,24 +1113,13 @@ hipError_t launch_chol_factor(const double* G, int n, double shift, double* work
     const int np = (n + CHOL_NB - 1) / CHOL_NB * CHOL_NB, npanel = np / CHOL_NB, ld = np + CHOL_XS;
     double* S = work;
     double* Yall = work + (size_t)np * ld;
+    int* flag = (int*)(Yall + (size_t)npanel * 1024);      // hand-off word of the fused panel launches
     hipError_t e = hipMemsetAsync(status, 0, sizeof(int), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fsnap_chol_factor_prepare_d_k, dim3((np + 255) / 256), dim3(256), 0, st, G, n, np, dsc, status, minpiv, npanel);
     hipLaunchKernelGGL(fsnap_chol_factor_prepare_s_k, dim3((ld + 255) / 256, np), dim3(256), 0, st, G, n, np, shift, dsc, S, status);
-    hipLaunchKernelGGL(fsnap_chol_diag_k, dim3(1), dim3(64), 0, st, S, ld, 0, Yall, status, minpiv, chol_diag_variant());
-    for (int pb = 0; pb < npanel; ++pb) {
-        const int jb = pb * CHOL_NB;
-        double* Y = Yall + (size_t)pb * 1024;
-        const int ntail = np - jb - CHOL_NB;
-        // (the strip is carried along as in the solve: it is zero here and costs one block column)
-        const int nstrip = (ntail + CHOL_XS) / 16;
-        hipLaunchKernelGGL(fsnap_chol_tails_k, dim3((nstrip + 3) / 4), dim3(256), 0, st, S, ld, jb, nstrip, Y, status);
-        if (ntail > 0) {
-            const int nblk = ntail / 32, nrest = nblk * (nblk + 1) / 2 + nblk - 3;
-            hipLaunchKernelGGL(fsnap_chol_update_diag_k, dim3(1 + (nrest + 3) / 4), dim3(256), 0, st, S, ld, jb, nblk, status,
-                               Y + 1024, minpiv, chol_diag_variant());
-        }
-    }
+    hipLaunchKernelGGL(fsnap_chol_diag_k, dim3(1), dim3(64), 0, st, S, ld, 0, Yall, status, minpiv, chol_diag_variant(), flag);
+    launch_chol_panels(S, ld, np, Yall, status, minpiv, flag, st);      // (the strip is carried along as in the solve: zero here)
     const int64_t total = (int64_t)K16 * K16 + (int64_t)K16 * 16;
     hipLaunchKernelGGL(fsnap_chol_extract_factor_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, S, Yall, dsc, n, np, K16,
                        Rout);

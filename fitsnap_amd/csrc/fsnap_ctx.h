@@ -148,7 +148,7 @@ struct fsnap_ctx {
     DevBuf commbuf;                               // device staging of host-buffer collectives
     DevBuf tribuf;                                // [upper triangle | c | scalars]: all-reduce payload of wide systems
     int opt_reduce_triangle = -1;                 // all-reduce the triangle only: -1 = K >= 256, 0 = never, 1 = always
-    int opt_staged_upload = 1;    // fsnap_upload_rows: 0 pageable hipMemcpy | 2 page-locked double buffer | 1 probe the first 64 MiB, then the faster
+    int opt_staged_upload = 0;    // fsnap_upload_rows: 0 pageable hipMemcpy (default) | 2 page-locked double buffer | 1 double buffer, probed
     double upload_probe_gbps = 0.0;   // rate at which the host filled the first page-locked slots of the last large upload (GB/s)
     bool upload_staged = false;       // the whole of the last upload went through the double buffer
     int opt_fused_residual = 1;   // fsnap_residual_rhs: one pass over the rows for K <= 256 (0: kernels 4 + 7, two passes)

@@ -101,9 +101,11 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * "reduce_triangle" (fsnap_fit_dist / fsnap_lstsq_rows: -1 = systems of >= 256 columns all-reduce [upper triangle | c | scalars],
  * K (K + 1) / 2 + K + 3 doubles, between a pack and an unpack kernel, the default; 0 = always the full K^2 + K + 3; 1 = always
  * the triangle -- every rank of a job must use the same setting),
- * "staged_upload" (fsnap_upload_rows of >= 256 MiB: 1 = start through a page-locked double buffer filled by host threads and,
- * if the host fills its first two 16 MiB slots at less than 20 GB/s, hand the rest to the runtime's pageable copy, the
- * default; 0 = pageable copy; 2 = double buffer; FSNAP_UPLOAD_THREADS = host threads of the double buffer, default 4).
+ * "staged_upload" (fsnap_upload_rows: 0 = the runtime's pageable copy, the default -- it pins the caller's pages and reads them
+ * in place, 27 ms for 1.03 GB where pinning is cheap; 2 = a page-locked double buffer filled by FSNAP_UPLOAD_THREADS (default 4)
+ * host threads while the DMA drains the other slot -- 104 ms on the same box, whose CPU quota holds the host copies at
+ * ~10 GB/s: an option for hosts with free cores and slow pinning; 1 = double buffer, handing the rest to the pageable copy when
+ * the host fills its first two 16 MiB slots at less than 20 GB/s).
  * Unknown key -> FSNAP_E_ARG. */
 int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value);
 
