@@ -358,6 +358,25 @@ def test_large_k_device_cholesky_matches_host_solve(ctx, K, m):
         assert np.max(np.abs(beta_dev - ref)) / scale < 1e-8
 
 
+@pytest.mark.parametrize("env", [{"FSNAP_CHOL_FUSED": "1"}, {"FSNAP_CHOL_DIAG": "0"}, {"FSNAP_CHOL_DIAG": "1"}])
+def test_device_cholesky_ab_forms_solve_the_same_systems(env):
+    # the forms of the blocked device Cholesky kept for A/B behind environment switches (read once per process): the
+    # one-launch-per-panel kernel with its in-launch flag hand-off, and the pivot chains 0 / 1 of the diagonal block
+    import os
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "chol_large_test.py"), "257", "480", "1595"],
+                         env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = re.findall(r"K=\s*(\d+)\s+gpu\s+[\d.]+ ms \(rel ([\d.e+-]+), min pivot ([\d.e+-]+)\).*rhs-variant rel ([\d.e+-]+)", out.stdout)
+    assert [int(r[0]) for r in rows] == [257, 480, 1595], out.stdout
+    for _, rel, piv, rel2 in rows:
+        assert float(rel) < 1e-11 and float(rel2) < 1e-11 and float(piv) > 1e-3      # solved on the GPU (min pivot reported), accurately
+
+
 @pytest.mark.parametrize("K", [40, 128, 200])
 def test_mirror_packed_serves_statistics_modified_in_hbm(ctx, K):
     # fsnap_mirror_packed: the multi-GPU path all-reduces the packed statistics in place; the page-locked host mirror
