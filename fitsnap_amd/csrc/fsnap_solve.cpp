@@ -239,6 +239,33 @@ FSNAP_CLONES void chol_trailing_chunks(double* a, int n, int jb, int je, int fir
                 *(v8du*)(r3) = y30; *(v8du*)(r3 + 8) = y31; *(v8du*)(r3 + 16) = y32; *(v8du*)(r3 + 24) = y33;
             }
         }
+        if (cw == 16) {               // half chunk at the right edge (n = 16 mod 32: the ACE width 142 pads to 144, not 160)
+            for (; i + 4 <= i_end; i += 4) {
+                double* r0 = a + (size_t)i * n + c0;
+                double* r1 = r0 + n;
+                double* r2 = r1 + n;
+                double* r3 = r2 + n;
+                v8d y00 = *(const v8du*)(r0), y01 = *(const v8du*)(r0 + 8);
+                v8d y10 = *(const v8du*)(r1), y11 = *(const v8du*)(r1 + 8);
+                v8d y20 = *(const v8du*)(r2), y21 = *(const v8du*)(r2 + 8);
+                v8d y30 = *(const v8du*)(r3), y31 = *(const v8du*)(r3 + 8);
+                const double* uk = a + (size_t)jb * n;
+                for (int k = 0; k < nk; ++k, uk += n) {
+                    const v8d u0 = *(const v8du*)(uk + c0), u1 = *(const v8du*)(uk + c0 + 8);
+                    const double f0 = uk[i], f1 = uk[i + 1], f2 = uk[i + 2], f3 = uk[i + 3];
+                    const v8d b0 = {f0, f0, f0, f0, f0, f0, f0, f0}, b1 = {f1, f1, f1, f1, f1, f1, f1, f1};
+                    const v8d b2 = {f2, f2, f2, f2, f2, f2, f2, f2}, b3 = {f3, f3, f3, f3, f3, f3, f3, f3};
+                    y00 -= b0 * u0; y01 -= b0 * u1;
+                    y10 -= b1 * u0; y11 -= b1 * u1;
+                    y20 -= b2 * u0; y21 -= b2 * u1;
+                    y30 -= b3 * u0; y31 -= b3 * u1;
+                }
+                *(v8du*)(r0) = y00; *(v8du*)(r0 + 8) = y01;
+                *(v8du*)(r1) = y10; *(v8du*)(r1 + 8) = y11;
+                *(v8du*)(r2) = y20; *(v8du*)(r2 + 8) = y21;
+                *(v8du*)(r3) = y30; *(v8du*)(r3 + 8) = y31;
+            }
+        }
         for (; i < i_end; ++i) {      // leftover rows / ragged last chunk
             double* ri = a + (size_t)i * n + c0;
             const double* uk = a + (size_t)jb * n;
@@ -712,7 +739,8 @@ int solve_impl(int kind, double param, int64_t K64, const double* G, const doubl
         // The register-blocked factorisation works on 32-column chunks; a partial last chunk runs a much slower
         // remainder path (K = 184: 0.30 ms, K = 192: 0.12 ms).  So the scaled matrix is padded to a multiple of 32 with
         // an identity block (pivots 1, solution components 0): Kp = leading dimension and order of the padded system.
-        int Kp = (K >= 48 && (K & 31) != 0) ? ((K + 31) & ~31) : K;
+        // (a final HALF chunk of 16 columns has a register-blocked path of its own: K = 142 pads to 144, not 160)
+        int Kp = (K >= 48 && (K & 15) != 0) ? ((K + 15) & ~15) : K;
         // a row stride that is a multiple of 1 KiB maps the rows of a column onto a few cache sets: on the MI355X
         // hosts K = 512 took 0.9 or 8.9 ms depending on the physical pages of the run -- one more chunk of padding
         if (Kp >= 384 && (Kp & 127) == 0) Kp += 32;
