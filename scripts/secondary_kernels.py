@@ -33,7 +33,10 @@ def timed(name, fn):
 
 
 timed("predict+sse (fsnap_gemv_rows_k)", lambda: ctx.predict(beta, want_preds=False, want_sse=True))
-timed("residual_rhs (fsnap_gemv_rows_k + fsnap_gemvT_rows_k)", lambda: ctx.residual_rhs(beta))
+timed("residual_rhs, one pass (fsnap_residual_rows_k + fold)", lambda: ctx.residual_rhs(beta))
+ctx.set_option("fused_residual", 0)
+timed("residual_rhs, two passes (fsnap_gemv_rows_k + fsnap_gemvT_rows_k)", lambda: ctx.residual_rhs(beta))
+ctx.set_option("fused_residual", 1)
 cat = (np.arange(m) // 250) % 120
 ctx.error_stats(beta, cat.astype(np.int32), 120)
 timed("error_stats (gemv + 2 x fsnap_error_stats_k)", lambda: ctx.error_stats(beta, None, 120))
@@ -56,6 +59,11 @@ c31 = _capi.HipContext(0)
 c31.upload_rows(A31, b31)
 c31.set_weights(w31)
 timed("K=31 statistics (fsnap_syrk_wave_p<2>)", lambda: c31.normal_eq())
+beta31 = c31.fit_resident(_capi.SOLVE_RIDGE, 1e-8)[0]
+timed("K=31 residual_rhs, one pass (fsnap_residual_rows_k<1>)", lambda: c31.residual_rhs(beta31))
+c31.set_option("fused_residual", 0)
+timed("K=31 residual_rhs, two passes", lambda: c31.residual_rhs(beta31))
+c31.set_option("fused_residual", 1)
 nrows, ncoef = 32768, 110
 raw = np.random.default_rng(1).standard_normal((nrows, ncoef + 1))
 ca = _capi.HipContext(0)
@@ -66,7 +74,8 @@ timed("assemble 32768 x 110 (fsnap_assemble_k, incl. H2D of the 29 MB batch)",
       lambda: ca.assemble(raw, 0, plan["src_row"], plan["kind"], plan["frac"], plan["d"], plan["truth"], plan["weight"],
                           np.zeros((0, 1)), np.ones(ncoef), 1, ncoef, 0))
 bytes_per_launch = {
-    "fsnap_gemv_rows_k": (8 * K + 8) * m, "fsnap_gemvT_rows_k": (8 * K + 8) * m, "fsnap_error_stats_k": 28 * m,
+    "fsnap_gemv_rows_k": (8 * K + 8) * m, "fsnap_gemvT_rows_k": (8 * K + 8) * m, "fsnap_residual_rows_k<4>": (8 * K + 17) * m,
+    "fsnap_residual_rows_k<1>(K=31)": (8 * 31 + 17) * m, "fsnap_error_stats_k": 28 * m,
     "fsnap_pack_weights_k": 33 * m, "fsnap_expand_weights_k": 21 * m, "fsnap_trsm_rows_k": 16 * K * m,
     "fsnap_syrk_wave_p(K=31)": (8 * 31 + 16) * m, "fsnap_assemble_k": 16 * ncoef * nrows, "fsnap_qpack_k": 32 * m,
 }
