@@ -814,7 +814,7 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
         if (value < 0 || value > 2) return ctx->fail(FSNAP_E_ARG, "staged_upload must be 0 (pageable copy), 1 (probe) or 2 (double buffer)");
         ctx->opt_staged_upload = (int)value;
     } else if (!strcmp(key, "fused_residual")) {
-        if (value < 0 || value > 2) return ctx->fail(FSNAP_E_ARG, "fused_residual must be 0 (two kernels), 1 (one pass, prefetch) or 2 (one pass)");
+        if (value < 0 || value > 2) return ctx->fail(FSNAP_E_ARG, "fused_residual must be 0 (two kernels), 1 (one pass) or 2 (one pass, register prefetch)");
         ctx->opt_fused_residual = (int)value;
     } else if (!strcmp(key, "reduce")) {
         if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "reduce must be 0 (kernel 2b) or 1 (kernel 2)");
@@ -1704,7 +1704,7 @@ int fsnap_residual_rhs(fsnap_ctx* ctx, const double* beta, double* s, double* ss
     if (fused) {
         FSNAP_HIP(fsnap::launch_residual_rows(ctx->dA, ctx->lda, (const double*)ctx->beta.p, ctx->m, (int)ctx->K, ctx->db, ctx->dw,
                                               mask, (double*)ctx->dspart.p, sse ? (double*)ctx->sse.p : nullptr,
-                                              (double*)ctx->dsvec.p, ctx->stream, ctx->opt_fused_residual != 2),
+                                              (double*)ctx->dsvec.p, ctx->stream, ctx->opt_fused_residual == 2),
                   "launch fsnap_residual_rows_k");
     } else {
         FSNAP_HIP(fsnap::launch_gemv_rows(ctx->dA, ctx->lda, (const double*)ctx->beta.p, ctx->m, (int)ctx->K, nullptr, ctx->db,

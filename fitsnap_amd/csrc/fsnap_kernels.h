@@ -118,7 +118,7 @@ int residual_num_blocks(int64_t m);
 // sse_part[residual_num_blocks(m)] per-workgroup partial SSE (nullptr: none), out[K]
 hipError_t launch_residual_rows(const double* A, int64_t lda, const double* beta, int64_t m, int K, const double* b,
                                 const double* w, const unsigned char* mask, double* partial, double* sse_part, double* out,
-                                hipStream_t st, bool prefetch = true);
+                                hipStream_t st, bool prefetch = false);
 hipError_t launch_colsum(const double* partial, int nparts, int ncols, double* out, hipStream_t st);
 // w[row] = mask[row] ? wtrain[rank[row]] : 0   (rank = exclusive prefix sum of the mask)
 hipError_t launch_expand_weights(const double* wtrain, const unsigned char* mask, const int* rank, int64_t m, double* w,

@@ -291,8 +291,10 @@ __global__ __launch_bounds__(256) void fsnap_gemvT_rows_k(const double* __restri
 // fused: a row is read ONCE and stays in registers between the two uses,
 //     r_i = keep_i w_i (b_i - a_i . beta)      lane reduction over the 16 lanes of the row (the bits of kernel 4)
 //     s  += a_i (w_i r_i)                      per-lane column accumulators, folded in a fixed order at the end
-// plus the weighted SSE sum r_i^2.  16 lanes per row, a wave takes 8 rows per step (two groups of four) and prefetches the
-// next step's rows into a second register set before it works on the current ones.  Rows that do not take part (test
+// plus the weighted SSE sum r_i^2.  16 lanes per row, a wave takes 8 rows per step (two groups of four); the latency of a
+// step's loads is covered by the other waves of the SIMD (4 at K = 128, 8 at K = 31).  PF = true prefetches the next step's
+// rows into a second register set instead -- half the waves per SIMD, and slower at every shape measured (10^6 x 128: 0.207
+// against 0.198 ms per call, 4 10^6 x 31: 0.356 / 0.238, 200 000 x 200: 0.119 / 0.094; kept for A/B, option fused_residual = 2).  Rows that do not take part (test
 // rows, rows past m) are zeroed by selects: NaN / Inf in them reach nothing.  K <= 32 NJ (NJ <= 8: 64 VGPRs of row data
 // per set); wider systems keep the two-kernel form.  HBM-bound: 8K + 17 bytes per row.
 // Per-workgroup partial vectors partial[wg][K] (fold: kernel fsnap_colsum_partials_k), sse_part[wg].
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(256) void fsnap_residual_rows_k(const double* __res
                 process(R1);
             }
         }
-    } else {            // no second register set: more waves per SIMD cover the latency instead (A/B)
+    } else {            // no second register set: more waves per SIMD cover the latency (the default)
         ResidualRows<NJ> R0;
         for (; r0 < m; r0 += step) {
             fetch(r0, R0);
@@ -738,8 +740,13 @@ hipError_t launch_gemv_rows(const double* A, int64_t lda, const double* beta, in
 }
 
 int residual_num_blocks(int64_t m) {
+    static const int cap = [] {
+        const char* e = getenv("FSNAP_RESIDUAL_BLOCKS");       // tuning aid: workgroups of the one-pass residual kernel
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 256 * 6;
+    }();
     int64_t nb = (m + 31) / 32;
-    if (nb > 256 * 6) nb = 256 * 6;
+    if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
