@@ -1690,7 +1690,7 @@ int fsnap_residual_rhs(fsnap_ctx* ctx, const double* beta, double* s, double* ss
     const size_t m = (size_t)ctx->m, K = (size_t)ctx->K;
     // K <= 256: kernels 4 + 7 fused, the rows are read once (option fused_residual = 0: the two-kernel form, A/B)
     const bool fused = ctx->opt_fused_residual && K <= 256;
-    const int nb = fused ? fsnap::residual_num_blocks(ctx->m) : fsnap::gemv_num_blocks(ctx->m);
+    const int nb = fused ? fsnap::residual_num_blocks(ctx->m, (int)ctx->K) : fsnap::gemv_num_blocks(ctx->m);
     const int nbt = fused ? nb : fsnap::gemvT_num_blocks(ctx->m);
     if (!ctx->beta.ensure(K * 8) || (!fused && !ctx->du.ensure(m * 8)) || !ctx->dspart.ensure((size_t)nbt * K * 8) ||
         !ctx->dsvec.ensure(K * 8) || (sse && !ctx->sse.ensure((size_t)nb * 8)))

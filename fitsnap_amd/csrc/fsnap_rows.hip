@@ -739,12 +739,19 @@ hipError_t launch_gemv_rows(const double* A, int64_t lda, const double* beta, in
     return hipGetLastError();
 }
 
-int residual_num_blocks(int64_t m) {
-    static const int cap = [] {
-        const char* e = getenv("FSNAP_RESIDUAL_BLOCKS");       // tuning aid: workgroups of the one-pass residual kernel
+// workgroups of the one-pass residual kernel: one resident round of the chip -- 256 CUs x the workgroups per CU the
+// register budget of the instantiation admits (waves per SIMD: 8 / 7 / 5 / 4 / 4 / 3 / 2 for NJ = 1 / 2 / 3 / 4 / 5 / 6 / 8).
+// Measured (scripts/residual_probe.py): 10^6 x 128 0.198 ms per call with 1536 workgroups, 0.188 with 1024, 0.199 with 512;
+// 4 10^6 x 31 0.238 / 0.312 / 0.492.
+int residual_num_blocks(int64_t m, int K) {
+    static const int forced = [] {
+        const char* e = getenv("FSNAP_RESIDUAL_BLOCKS");       // tuning aid
         const int v = e ? atoi(e) : 0;
-        return v > 0 ? v : 256 * 6;
+        return v > 0 ? v : 0;
     }();
+    const int nj = (K + 31) / 32;
+    const int per_cu = nj <= 1 ? 8 : nj == 2 ? 7 : nj == 3 ? 5 : nj <= 5 ? 4 : nj == 6 ? 3 : 2;
+    const int cap = forced ? forced : 256 * per_cu;
     int64_t nb = (m + 31) / 32;
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
@@ -756,7 +763,7 @@ int residual_num_blocks(int64_t m) {
 hipError_t launch_residual_rows(const double* A, int64_t lda, const double* beta, int64_t m, int K, const double* b,
                                 const double* w, const unsigned char* mask, double* partial, double* sse_part, double* out,
                                 hipStream_t st, bool prefetch) {
-    const int nb = residual_num_blocks(m);
+    const int nb = residual_num_blocks(m, K);
     const int nj = (K + 31) / 32;
 #define FSNAP_LAUNCH(NJ)                                                                                                   \
     do {                                                                                                                   \

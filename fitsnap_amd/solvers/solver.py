@@ -235,14 +235,25 @@ class Solver:
         mc = self._mask_cache
         cached = mc is not None and mc[2] is training
         aux = mc[3] if cached else None
-        if aux is None:
+        if aux is not None:
+            idx, mask_u8, rank = aux
+            ntrain = idx.shape[0]
+        else:
             mask_u8 = training.astype(np.uint8)
-            rank = np.cumsum(mask_u8, dtype=np.int64) - mask_u8
-            aux = (np.flatnonzero(training), mask_u8, rank.astype(np.int32))
-            if cached:
-                self._mask_cache = (mc[0], mc[1], training, aux)
-        idx, mask_u8, rank = aux
-        ntrain = idx.shape[0]
+            ntrain = int(np.count_nonzero(mask_u8))
+            idx = rank = None
+
+        def train_aux():
+            # row indices and exclusive prefix sum of the mask: only a fit that hands over one weight per TRAINING row of a
+            # partly masked matrix needs them (5 ms of numpy at 10^6 rows: not on the path of `trainall` / full-weight calls)
+            nonlocal idx, rank, aux
+            if aux is None:
+                rk = np.cumsum(mask_u8, dtype=np.int64) - mask_u8
+                idx, rank = np.flatnonzero(training), rk.astype(np.int32)
+                aux = (idx, mask_u8, rank)
+                if cached:
+                    self._mask_cache = (mc[0], mc[1], training, aux)
+
         # reference: aw = w[:, None] * a[training]  (numpy broadcasting on the row axis)
         if w.ndim == 0 or w.shape[0] == 1:
             w_full = np.full(m, float(w.reshape(-1)[0]))
@@ -251,7 +262,9 @@ class Solver:
                 w_full = w
             else:
                 # one weight per training row: the GPU spreads them over the rows (fsnap_set_weights_train)
-                w_full = _TrainWeights(w, mask_u8, rank, idx, cached and mc[3] is not None)
+                had = cached and mc[3] is not None
+                train_aux()
+                w_full = _TrainWeights(w, mask_u8, rank, idx, had)
         else:
             raise ValueError(f"operands could not be broadcast together with shapes ({w.shape[0]},1) ({ntrain},{a.shape[1]}) ")
         return a, b, w_full, mask_u8, False
