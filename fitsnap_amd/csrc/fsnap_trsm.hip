@@ -693,7 +693,13 @@ hipError_t launch_trsm_rows(const double* src, int64_t lds, const double* wpack,
                             const double* R, int K16, hipStream_t st) {
     const int64_t nb = (m + 63) / 64;
     if (nb > 0x7FFFFFFF) return hipErrorInvalidValue;
-    if (K16 <= 128) {
+    // FSNAP_TRSM_KERNEL=14: the panel kernel 13B also for K <= 128 (one panel: its block solve on the matrix pipe against
+    // kernel 13A's substitution on the VALU; A/B)
+    static const bool panel_always = [] {
+        const char* e = getenv("FSNAP_TRSM_KERNEL");
+        return e && atoi(e) == 14;
+    }();
+    if (K16 <= 128 && !panel_always) {
         // kernel 13A: whole row tile in the accumulation registers
         const dim3 grid((unsigned)nb), block(64);
 #define FSNAP_TRSM_ACC(NBV)                                                                                                  \
