@@ -1264,7 +1264,7 @@ int fsnap_mirror_packed(fsnap_ctx* ctx, const double* d_packed, int64_t K) {
     FSNAP_HIP(hipEventRecord(ctx->mirror_ev, ctx->stream), "hipEventRecord");
     ctx->mirror_of = d_packed;
     ctx->mirror_K = K;
-    ctx->mirror_upper = false;
+    ctx->mirror_upper = true;                   // the copy kernel fills the upper triangle (from the pair of the diagonal on)
     ctx->mirror_gen = next_mirror_generation();
     return FSNAP_OK;
 }

@@ -564,10 +564,26 @@ __global__ __launch_bounds__(256) void fsnap_expand_weights_k(const double* __re
 // D2H copy (SDMA launch latency + a blocking stream wait) by a 3 us kernel and an event the host polls.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void fsnap_mirror_copy_k(const double* __restrict__ src, int K, double* __restrict__ mirror) {
-    const int n = K * K + K + 3;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) mirror[i] = src[i];
-    else if (i < n + K) mirror[i] = src[(size_t)(i - n) * K + (i - n)];
+    // Row i of G from the pair that holds its diagonal to the end of the row (the host solve reads the mirror as an upper
+    // triangle: fsnap_solve_diag_upper), two columns per thread when the row base is 16-byte aligned; the last grid row
+    // carries c, the scalars and the compact diagonal.  Half the PCIe writes of a full copy.
+    const int i = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (i < K) {
+        const int64_t base = (int64_t)i * K;
+        const int j = (i & ~1) + 2 * t;
+        if (j >= K) return;
+        if (((base + j) & 1) == 0 && j + 1 < K) {
+            *reinterpret_cast<d2*>(mirror + base + j) = *reinterpret_cast<const d2*>(src + base + j);
+        } else {
+            mirror[base + j] = src[base + j];
+            if (j + 1 < K) mirror[base + j + 1] = src[base + j + 1];
+        }
+    } else {
+        const int64_t n = (int64_t)K * K;
+        for (int u = t; u < 2 * K + 3; u += (int)gridDim.x * 256)
+            mirror[n + u] = u < K + 3 ? src[n + u] : src[(int64_t)(u - K - 3) * K + (u - K - 3)];
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -800,8 +816,7 @@ hipError_t launch_tri_unpack(const double* tri, int K, double* packed, hipStream
 }
 
 hipError_t launch_mirror_copy(const double* src, int K, double* mirror, hipStream_t st) {
-    const int n = K * K + 2 * K + 3;
-    hipLaunchKernelGGL(fsnap_mirror_copy_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, K, mirror);
+    hipLaunchKernelGGL(fsnap_mirror_copy_k, dim3((unsigned)((K / 2 + 256) / 256), (unsigned)(K + 1)), dim3(256), 0, st, src, K, mirror);
     return hipGetLastError();
 }
 

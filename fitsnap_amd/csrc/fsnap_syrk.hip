@@ -734,13 +734,22 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
         // step cl: MFMAs of chunk cl (in V), V <- chunk cl+1, rows of chunk cl+3 into the raw set freed one step ago,
         // packed weights of chunk cl+5.  Chunk slots past the wave's range read zeros (bounds-checked descriptors).
         double wbp = 0.0;   // chunk 0 is fully accounted for by the prologue
-        for (unsigned cl = 0; cl < ncl; cl += 6) {
+        // The ring of pairs has period six, the raw sets period three: the loop runs six steps per trip while more than three
+        // chunks remain, and a last half trip of three steps for 1 ... 3 leftover chunks (a wave of a 125 000-row shard owns 31
+        // chunks: 33 steps instead of 36; the steps past the range multiply zeros).
+        unsigned cl = 0;
+        for (; cl + 3 < ncl; cl += 6) {
             acc_step<NB, FULLK, NT, PACK>(V, vt, r0, r1, wb, lpk, cl + 3, K, e, cacc, wbp, pk1, pk3, pk5, rows);
             acc_step<NB, FULLK, NT, PACK>(V, vt, r1, r2, wb, lpk, cl + 4, K, e, cacc, wbp, pk2, pk4, pk0, rows);
             acc_step<NB, FULLK, NT, PACK>(V, vt, r2, r0, wb, lpk, cl + 5, K, e, cacc, wbp, pk3, pk5, pk1, rows);
             acc_step<NB, FULLK, NT, PACK>(V, vt, r0, r1, wb, lpk, cl + 6, K, e, cacc, wbp, pk4, pk0, pk2, rows);
             acc_step<NB, FULLK, NT, PACK>(V, vt, r1, r2, wb, lpk, cl + 7, K, e, cacc, wbp, pk5, pk1, pk3, rows);
             acc_step<NB, FULLK, NT, PACK>(V, vt, r2, r0, wb, lpk, cl + 8, K, e, cacc, wbp, pk0, pk2, pk4, rows);
+        }
+        if (cl < ncl) {
+            acc_step<NB, FULLK, NT, PACK>(V, vt, r0, r1, wb, lpk, cl + 3, K, e, cacc, wbp, pk1, pk3, pk5, rows);
+            acc_step<NB, FULLK, NT, PACK>(V, vt, r1, r2, wb, lpk, cl + 4, K, e, cacc, wbp, pk2, pk4, pk0, rows);
+            acc_step<NB, FULLK, NT, PACK>(V, vt, r2, r0, wb, lpk, cl + 5, K, e, cacc, wbp, pk3, pk5, pk1, rows);
         }
         cacc[NB - 1] = __builtin_fma(V[NB - 1], wbp, cacc[NB - 1]);   // last prepared chunk (zeros past the range)
     }
