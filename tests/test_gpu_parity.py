@@ -1133,6 +1133,34 @@ def test_fused_packing_gives_the_bits_of_the_packing_kernel(K, m):
     c.close()
 
 
+@pytest.mark.parametrize("mode,m,K,pad", [(2, 70001, 128, 0), (2, 50003, 110, 7), (1, 300007, 128, 0), (1, 270001, 120, 5)])
+def test_row_upload_paths_deliver_the_same_rows(mode, m, K, pad):
+    # fsnap_upload_rows through the page-locked double buffer (option staged_upload = 2; 1 = double buffer that may hand the
+    # rest to the pageable copy after looking at its first two slots): the rows on the device are the caller's rows,
+    # bit for bit, also when a leading dimension wider than the row is packed on the way
+    rng = np.random.default_rng(10 * mode + K)
+    big = rng.standard_normal((m, K + pad))
+    A = big[:, :K]                                   # a view with lda = K + pad
+    b = rng.standard_normal(m)
+    c = _capi.HipContext(0)
+    c.set_option("staged_upload", mode)
+    c.upload_rows(A, b)
+    A2, b2, _ = c.download_rows(want_w=False)
+    assert np.array_equal(A2, A) and np.array_equal(b2, b)
+    tim = c.timing()
+    assert tim["upload_ms"] > 0.0
+    if mode == 2:
+        assert tim["upload_staged"]
+    c.set_weights(np.ones(m))
+    G, cc, sc = c.normal_eq()
+    c.set_option("staged_upload", 0)
+    c.upload_rows(A, b)
+    c.set_weights(np.ones(m))
+    G0, c0, s0 = c.normal_eq()
+    assert np.array_equal(G, G0) and np.array_equal(cc, c0) and np.array_equal(sc, s0)
+    c.close()
+
+
 @pytest.mark.parametrize("K", [31, 128, 200])
 def test_streaming_accumulation_matches_one_shot(ctx, K):
     # fsnap_normal_eq_accumulate: per-batch `c += cm; d += dm` (transpose_trick/example.py:230-237) on the device;
