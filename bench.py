@@ -264,6 +264,18 @@ def kernel_name_of(info):
     return f"fsnap_syrk_wave<{info['NB']},{info['split']}>"
 
 
+def _single_blas_thread():
+    """Context manager: BLAS / OpenMP pools limited to one thread (no-op without threadpoolctl)."""
+    try:
+        from threadpoolctl import threadpool_limits
+
+        return threadpool_limits(limits=1)
+    except Exception:  # pragma: no cover
+        import contextlib
+
+        return contextlib.nullcontext()
+
+
 def synth_rows(lo, hi, total, Kc):
     """Rows [lo, hi) of the `total`-row synthetic problem exactly as the one-GPU run generates them (the generator
     works in 64 Ki-row chunks; a partial last chunk draws its noise differently from a full one, so every chunk is
@@ -289,16 +301,22 @@ def run_mode(ctx, args, mode, rank, world, multi, _capi):
     from fitsnap_amd.synthetic import synth_problem
 
     Kc = args.cols
-    if mode == "weak":
-        m_total = args.rows * world
-        A, b, w = synth_problem(args.rows, Kc, row_offset=rank * RANK_ROW_STRIDE)
-    else:
-        m_total = args.rows
-        lo, hi = args.rows * rank // world, args.rows * (rank + 1) // world
-        A, b, w = synth_rows(lo, hi, args.rows, Kc)
+    # The boxes run under a CPU quota: a burst of BLAS threads (the generator's `A @ beta`, 64 OpenBLAS threads that keep
+    # spinning after every call) can leave the process throttled -- descheduled for tens of milliseconds -- right when the
+    # timed region starts (seen on small shapes, whose pre-heat is short: 1.5 ms per step instead of 0.065).  So the rows are
+    # generated on one thread and the process idles for a quota period before it starts issuing fits.
+    with _single_blas_thread():
+        if mode == "weak":
+            m_total = args.rows * world
+            A, b, w = synth_problem(args.rows, Kc, row_offset=rank * RANK_ROW_STRIDE)
+        else:
+            m_total = args.rows
+            lo, hi = args.rows * rank // world, args.rows * (rank + 1) // world
+            A, b, w = synth_rows(lo, hi, args.rows, Kc)
     m = len(b)
     ctx.upload_rows(A, b)
     ctx.set_weights(w)
+    time.sleep(0.25)
     tim = ctx.timing()
     upload_ms = tim["upload_ms"]
     upload_how = {"host_fill_probe_GBps": tim.get("upload_probe_GBps"), "page_locked_double_buffer": tim.get("upload_staged")}

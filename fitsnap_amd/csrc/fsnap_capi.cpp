@@ -149,6 +149,9 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
     if (nblocks > 0x7FFFFFF) return ctx->fail(FSNAP_E_ARG, "too many workgroups");
     g->nblocks = (int)nblocks;
     g->cpw = cpw;
+    // kernel 1P packs the pairs of its rows itself when they fit its LDS budget (contiguous chunk ranges only)
+    g->fused_pack = g->packed && ctx->opt_fused_pack && !ctx->wpack_override && !ctx->opt_interleave &&
+                    cpw <= fsnap::syrk_wave_p_max_fused_cpw(K, wg_per_cu);
     return FSNAP_OK;
 }
 
@@ -563,7 +566,7 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
     a.spart = (double*)ctx->spart.p;
     int ns = -1;                      // scalar partials: from the SYRK kernel, or (kernel 1A) from the weight packing
     const double* spart_src = a.spart;
-    if (g.acc && g.fused_pack) {
+    if ((g.acc || g.packed) && g.fused_pack) {
         a.fused_pack = true;          // b, w, mask -> pairs in LDS + the b-only scalars per row-wave, inside the SYRK launch
     } else if (g.acc || g.packed) {
         int npk = 0;

@@ -25,7 +25,7 @@ struct SyrkArgs {
     double* spart;              // [nblocks*4][4]
     const double* wpack = nullptr;  // kernel 1A: packed (w_eff, w_eff * b) per row (launch_pack_weights)
     bool interleave = false;        // kernel 1P: row-waves take every NW-th chunk instead of a contiguous range
-    bool fused_pack = false;        // kernel 1A: the kernel packs (w_eff, w_eff b) of its rows into LDS itself (b, w, mask,
+    bool fused_pack = false;        // kernels 1A / 1P: the kernel packs (w_eff, w_eff b) of its rows into LDS itself (b, w, mask,
                                     // spart instead of wpack; needs chunks_per_wave <= syrk_acc_max_fused_cpw())
 };
 
@@ -59,6 +59,7 @@ hipError_t launch_syrk_wave_p(const SyrkArgs& a, hipStream_t st);   // K <= 80, 
 hipError_t launch_syrk_lds(const SyrkArgs& a, hipStream_t st);
 hipError_t launch_syrk_acc(const SyrkArgs& a, hipStream_t st);
 int64_t syrk_acc_max_fused_cpw();
+int64_t syrk_wave_p_max_fused_cpw(int K, int wg_per_cu);   // kernel 1P: same for its (smaller, shared) LDS budget
 // mirror: optional page-locked HOST buffer that receives the same packed statistics (zero-copy D2H)
 // accumulate: out += statistics instead of out = statistics
 // ns: number of scalar partials in spart (< 0: nblocks * cs_per_block, like the c partials)

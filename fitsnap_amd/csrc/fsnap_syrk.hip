@@ -820,13 +820,22 @@ fsnap_syrk_acc(const double* __restrict__ A, int64_t lda, const double* __restri
 // per SIMD (compiler-scheduled code, no hand placement): the waves cover each other's load latency.
 // Partial layout = kernel 1 / 1A: part[workgroup][NT][4][64] | cpart[rowwave][NB][16].
 // ---------------------------------------------------------------------------------
-template <int NB, bool FULLK, bool NT>
+// PACK (round 4): like kernel 1A the wave forms the (w_eff, w_eff b) pairs of its rows in LDS in a prologue
+// (pack_rows_to_lds) instead of reading what fsnap_pack_weights_k wrote to HBM -- no packing launch in front of a fit of the
+// Ta width (15 213 x 31: 35.6 -> 30 us per fit).  The LDS is dynamic: max(fold buffer, 4 x (chunks per wave + pad) x 64 B of
+// pairs); the pairs go first, the fold reuses the space behind a barrier.  Contiguous chunk ranges only (no `interleave`).
+constexpr int FSNAP_WAVE_P_PACK_PAD = 16;      // chunk slots the loop may look past a wave's last chunk (<= ncl + 2 W - 3, W <= 8)
+
+template <int NB, bool FULLK, bool NT, bool PACK>
 __global__ __launch_bounds__(256, 2) void fsnap_syrk_wave_p(const double* __restrict__ A, int64_t lda,
                                                             const double* __restrict__ wpack, int64_t m, int K,
                                                             int64_t chunks_per_wave, int interleave,
-                                                            double* __restrict__ part, double* __restrict__ cpart) {
+                                                            double* __restrict__ part, double* __restrict__ cpart,
+                                                            const double* __restrict__ bvec, const double* __restrict__ wvec,
+                                                            const unsigned char* __restrict__ mask,
+                                                            double* __restrict__ spart) {
     constexpr int NTILE = NB * (NB + 1) / 2;
-    __shared__ double lds[2 * NTILE * 256];
+    extern __shared__ __attribute__((aligned(16))) double lds[];      // >= 2 * NTILE * 256 doubles (launcher)
     const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
     const int rw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t rowwave = (int64_t)blockIdx.x * 4 + rw;
@@ -859,15 +868,24 @@ __global__ __launch_bounds__(256, 2) void fsnap_syrk_wave_p(const double* __rest
     const int64_t nrow = (ncl64 > 0 && row1 > row0) ? row1 - row0 : 0;
     WaveBufsP wb;
     wb.A = make_rsrc(A + row0 * lda, (unsigned)(nrow * lda * 8 + (nrow ? 16 : 0)));
-    wb.wp = make_rsrc(wpack + 2 * row0, (unsigned)(nrow * 16));
+    wb.wp = make_rsrc(PACK ? nullptr : wpack + 2 * row0, PACK ? 0u : (unsigned)(nrow * 16));
     wb.voffA = (unsigned)((kr * lda + 2 * e) * 8);
     wb.voffT = (unsigned)((kr * lda + 16 * (NB - 1) + e) * 8);
     wb.voffP = (unsigned)(kr * 16);
     wb.chunk_bytes = (unsigned)(stride * lda * 32);
     const unsigned pack_bytes = (unsigned)(stride * 64);
     const unsigned ncl = (unsigned)ncl64;
+    const double* lpk = nullptr;
+    if constexpr (PACK) {
+        const unsigned wave_rows = (unsigned)chunks_per_wave * 4u;
+        const unsigned region_rows = wave_rows + FSNAP_WAVE_P_PACK_PAD * 4u;
+        double* lpw = lds + (size_t)rw * region_rows * 2;
+        pack_rows_to_lds(bvec, wvec, mask, row0, nrow, wave_rows, region_rows, lpw, lane, spart + rowwave * 4);
+        lpk = lpw + 2 * kr;
+    }
     auto load_pack_s = [&](unsigned cl) -> u4 {
-        return __builtin_amdgcn_raw_buffer_load_b128(wb.wp, wb.voffP, cl * pack_bytes, 0);
+        if constexpr (PACK) return __builtin_bit_cast(u4, *reinterpret_cast<const d2*>(lpk + (size_t)cl * 8));
+        else return __builtin_amdgcn_raw_buffer_load_b128(wb.wp, wb.voffP, cl * pack_bytes, 0);
     };
 
     d4 acc[NTILE];
@@ -930,6 +948,7 @@ __global__ __launch_bounds__(256, 2) void fsnap_syrk_wave_p(const double* __rest
     }
 
     // fold the four row-waves through LDS ({2,3} -> {0,1}, then 1 -> 0): one partial triangle per workgroup
+    if constexpr (PACK) __syncthreads();       // the other waves may still be reading their pairs from this space
     {
         double* slot_hi = lds + (size_t)((rw & 1) * NTILE) * 256;
         if (rw >= 2) {
@@ -2560,19 +2579,40 @@ template <int NB>
 static hipError_t launch_syrk_wave_p_nb(const SyrkArgs& a, hipStream_t st) {
     dim3 grid((unsigned)a.nblocks), block(256);
     const bool fullk = (a.K == 16 * NB);
-    if (!a.wpack) return hipErrorInvalidValue;
-#define FSNAP_LAUNCH(FK, NTL)                                                                                       \
-    hipLaunchKernelGGL((fsnap_syrk_wave_p<NB, FK, NTL>), grid, block, 0, st, a.A, a.lda, a.wpack, a.m, a.K,         \
-                       a.chunks_per_wave, a.interleave ? 1 : 0, a.part, a.cpart)
+    if (a.fused_pack ? (!a.b || !a.w || !a.mask || !a.spart || a.interleave) : !a.wpack) return hipErrorInvalidValue;
+    constexpr size_t fold_bytes = (size_t)2 * (NB * (NB + 1) / 2) * 256 * sizeof(double);
+    const size_t pair_bytes = a.fused_pack ? (size_t)4 * (size_t)(a.chunks_per_wave + FSNAP_WAVE_P_PACK_PAD) * 64 : 0;
+    const size_t lds = pair_bytes > fold_bytes ? pair_bytes : fold_bytes;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;           // (the planner keeps the pairs within the default dynamic limit)
+#define FSNAP_LAUNCH(FK, NTL, PK)                                                                                      \
+    hipLaunchKernelGGL((fsnap_syrk_wave_p<NB, FK, NTL, PK>), grid, block, lds, st, a.A, a.lda, a.wpack, a.m, a.K,       \
+                       a.chunks_per_wave, a.interleave ? 1 : 0, a.part, a.cpart, a.b, a.w, a.mask, a.spart)
+#define FSNAP_LAUNCH_PK(FK, NTL)                       \
+    do {                                               \
+        if (a.fused_pack) FSNAP_LAUNCH(FK, NTL, true); \
+        else FSNAP_LAUNCH(FK, NTL, false);             \
+    } while (0)
     if (fullk) {
-        if (a.nontemporal) FSNAP_LAUNCH(true, true);
-        else FSNAP_LAUNCH(true, false);
+        if (a.nontemporal) FSNAP_LAUNCH_PK(true, true);
+        else FSNAP_LAUNCH_PK(true, false);
     } else {
-        if (a.nontemporal) FSNAP_LAUNCH(false, true);
-        else FSNAP_LAUNCH(false, false);
+        if (a.nontemporal) FSNAP_LAUNCH_PK(false, true);
+        else FSNAP_LAUNCH_PK(false, false);
     }
+#undef FSNAP_LAUNCH_PK
 #undef FSNAP_LAUNCH
     return hipGetLastError();
+}
+
+// chunks per wave up to which kernel 1P packs its rows' pairs itself: the pairs of a workgroup must fit next to the other
+// resident workgroups' LDS (wg_per_cu of them per CU) and within the 64 KiB a launch may ask for without an attribute
+int64_t syrk_wave_p_max_fused_cpw(int K, int wg_per_cu) {
+    const int NB = syrk_num_blocks(K);
+    const int64_t fold_bytes = (int64_t)2 * (NB * (NB + 1) / 2) * 256 * 8;
+    int64_t budget = (int64_t)160 * 1024 / (wg_per_cu > 0 ? wg_per_cu : 1);
+    if (budget > 64 * 1024) budget = 64 * 1024;
+    if (budget < fold_bytes) budget = fold_bytes;               // the fold buffer is there anyway: pairs up to its size cost nothing
+    return budget / 256 - FSNAP_WAVE_P_PACK_PAD;
 }
 
 // kernel 1P (K <= 80): a.nblocks workgroups of 4 row-waves, a.chunks_per_wave chunks per row-wave
