@@ -1248,7 +1248,7 @@ int fsnap_mirror_packed(fsnap_ctx* ctx, const double* d_packed, int64_t K) {
     if (!ctx) return FSNAP_E_ARG;
     if (!d_packed || K <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_mirror_packed: bad argument");
     ctx->mirror_of = nullptr;
-    if (K >= 384 || !ctx->opt_mirror) return FSNAP_OK;     // large systems are factorised on the GPU: nothing to mirror
+    if ((K >= fsnap::DEVICE_CHOL_MIN_K && ctx->opt_device_solve != 2) || !ctx->opt_mirror) return FSNAP_OK;     // factorised on the GPU: nothing to mirror
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     const size_t need = ((size_t)FSNAP_PACKED_LEN(K) + (size_t)K) * 8;
     if (ctx->mirror_bytes < need) {
@@ -1448,9 +1448,9 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
         }
     }
     // large systems: blocked Cholesky on the GPU (kernels 8a-8e); option device_solve = 2 disables it
-    // (measured, scripts/chol_large_test.py: K = 384: 0.30 ms against 0.33 ms for the host factorisation, 768: 0.63 / 2.6,
-    // 1595: 1.5 / 17.5; below ~384 columns the host is faster: the panel kernels are latency-bound launches)
-    if ((K >= 384 || (K > 128 && ctx->opt_device_solve == 1)) && ctx->opt_device_solve != 2) {
+    // (threshold and measurements: fsnap::DEVICE_CHOL_MIN_K; below it the host is faster: the panel kernels are latency-bound
+    // launches)
+    if ((K >= fsnap::DEVICE_CHOL_MIN_K || (K > 128 && ctx->opt_device_solve == 1)) && ctx->opt_device_solve != 2) {
         const int n = (int)K, np = (n + 63) / 64 * 64, npanel = np / 64;
         const size_t head = (size_t)n + npanel + 1;            // [beta | min pivots | status]
         if (!ctx->dchol.ensure(fsnap::chol_large_work_doubles(n) * 8) || !ctx->dsolve.ensure((head + 2 * (size_t)np) * 8))
@@ -1566,9 +1566,9 @@ int fsnap_fit_resident(fsnap_ctx* ctx, int kind, double param, double* beta, int
     int rc = fsnap_normal_eq_resident(ctx, &dp);
     if (rc) return rc;
     if (d_packed) *d_packed = dp;
-    // 128 < K < 384 (tiled kernel, host factorisation): a copy kernel fills the page-locked mirror the host solve polls
+    // tiled kernel + host factorisation (144 < K < DEVICE_CHOL_MIN_K): a copy kernel fills the page-locked mirror the host solve polls
     // -- the D2H copy it replaces cost 10 us of launch latency + 7.7 us on the ACE shape (13 035 x 142: 95 us per fit)
-    if (ctx->mirror_of != dp && ctx->K > 128 && ctx->K < 384 && (rc = fsnap_mirror_packed(ctx, dp, ctx->K))) return rc;
+    if (ctx->mirror_of != dp && ctx->K > 128 && (rc = fsnap_mirror_packed(ctx, dp, ctx->K))) return rc;     // (no-op from DEVICE_CHOL_MIN_K on)
     return fsnap_solve_device_rhs(ctx, kind, param, ctx->K, dp, nullptr, beta, rank, rcond_est);
 }
 
@@ -1625,7 +1625,7 @@ int fsnap_fit_dist(fsnap_ctx* ctx, int kind, double param, int64_t K, double* be
             ctx->ring_comm[(ctx->nfit - 1) % fsnap_ctx::RING] = true;
         }
         if (local_rc == FSNAP_OK) {
-            if ((rc = fsnap_mirror_packed(ctx, dp, K))) return rc;     // K < 384: page-locked mirror instead of a D2H copy
+            if ((rc = fsnap_mirror_packed(ctx, dp, K))) return rc;     // host-factorised orders: page-locked mirror instead of a D2H copy
             if (d_packed) *d_packed = dp;
             rc = fsnap_solve_device_rhs(ctx, kind, param, K, dp, nullptr, beta, rank, rcond_est);
         }

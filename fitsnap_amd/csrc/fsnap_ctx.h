@@ -12,6 +12,12 @@
 
 namespace fsnap {
 
+// From this order on fsnap_solve_device factorises on the GPU (blocked kernels 8a-8e), below it on the host.  Measured
+// (scripts/chol_large_test.py, round 4, EPYC 9575F host): K = 256 0.118 ms GPU / 0.130 host, 272 0.147 / 0.145, 288 0.147 /
+// 0.162, 320 0.147 / 0.203, 352 0.171 / 0.249, 384 0.171 / 0.357; 192 0.091 / 0.073.  (384 until round 4: the device chain was
+// 0.30 ms there when the threshold was set.)
+constexpr int64_t DEVICE_CHOL_MIN_K = 288;
+
 // last error text of the calling thread when no context is at hand (fsnap_last_error(NULL))
 std::string& library_error();
 

@@ -80,7 +80,7 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * general-K tiled kernel also for K <= 128), "nsplit" (row splits of the tiled kernel), "mirror" (0|1, see fsnap_normal_eq_resident), "xcd" (0|1: tiled kernel deals contiguous work-item ranges to each XCD), "tiled2" (0|1: K > 128 on the one-wave-per-SIMD kernel with 64 x 128-column work items, default 0),
  * "tiled_ring" (0 ... 3, default 3: bit 0 / bit 1 put the diagonal / off-diagonal work items of the tiled kernel on the ring form of its
  * load pipeline; 0 = the three-set form of round 2, for A/B runs -- same bits either way),
- * "device_solve" (fsnap_solve_device: 0 = auto: K >= 384 is factorised on the GPU by the blocked kernels; 1 = every K on the GPU; 2 = never),
+ * "device_solve" (fsnap_solve_device: 0 = auto: K >= 288 is factorised on the GPU by the blocked kernels; 1 = every K on the GPU; 2 = never),
  * "repack" (1 = recompute the packed per-row weights (mask * w, mask * w * b) and the b-only scalars on EVERY fit even
  * when b, w and the mask are context-owned and unchanged; default 0 = once per fsnap_set_weights / fsnap_upload_rows),
  * "timing_every" (N: HIP events bracket every N-th SYRK launch only -- an event record between two dependent kernels idles
@@ -226,7 +226,7 @@ int fsnap_normal_eq_resident(fsnap_ctx* ctx, double** d_packed);
 /* Mirror packed statistics that live in device memory (e.g. the buffer a RCCL all-reduce just summed over the ranks,
  * the reference's comm.Allreduce(c), comm.Allreduce(d) in examples/library/transpose_trick/example.py:245-246) into
  * the context's page-locked host mirror; asynchronous (a small copy kernel + an event on the context's stream).  A
- * following fsnap_solve_device on the same pointer then needs no D2H copy.  No-op for K >= 384 (those are factorised
+ * following fsnap_solve_device on the same pointer then needs no D2H copy.  No-op for K >= 288 (those are factorised
  * on the GPU).  The caller must not modify the buffer between this call and the solve. */
 int fsnap_mirror_packed(fsnap_ctx* ctx, const double* d_packed, int64_t K);
 
@@ -277,7 +277,7 @@ int fsnap_lasso_gram(int64_t K, const double* Q, const double* q, double y_norm2
 /* Same solve, taking the packed statistics [G | c | ...] from DEVICE memory (the buffer
  * fsnap_normal_eq_async / the all-reduce left in HBM).  Small systems are copied to the host
  * (page-locked staging) and solved there (faster than any GPU factorisation of a 128-step recurrence); for
- * K >= 384 (option "device_solve") a blocked Cholesky runs on the GPU and only beta crosses PCIe, provided the
+ * K >= 288 (option "device_solve") a blocked Cholesky runs on the GPU and only beta crosses PCIe, provided the
  * system is well conditioned after Jacobi scaling -- otherwise the general host path decides.  Same status codes and semantics as fsnap_solve. */
 int fsnap_solve_device(fsnap_ctx* ctx, int kind, double param, int64_t K, const double* d_packed, double* beta,
                        int* rank, double* rcond_est);
