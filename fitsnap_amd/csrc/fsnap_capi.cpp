@@ -80,7 +80,8 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
         // kernel 1A: one 4-wave workgroup per CU, every wave streams its own rows and owns the whole triangle
         const int64_t nchunks = (m + 3) / 4;
         int64_t nblocks = ctx->opt_nblocks > 0 ? ctx->opt_nblocks : (int64_t)ctx->num_cu;
-        const int64_t max_blocks = (nchunks + 47) / 48;   // >= 12 chunks per row-wave
+        const int64_t min_cpw = ctx->opt_acc_min_cpw > 0 ? ctx->opt_acc_min_cpw : 12;
+        const int64_t max_blocks = (nchunks + 4 * min_cpw - 1) / (4 * min_cpw);   // >= min_cpw chunks per row-wave (option acc_min_cpw)
         if (nblocks > max_blocks) nblocks = max_blocks;
         if (nblocks < 1) nblocks = 1;
         int64_t cpw = (nchunks + nblocks * 4 - 1) / (nblocks * 4);
@@ -810,6 +811,9 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
     } else if (!strcmp(key, "dist_solve")) {
         if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "dist_solve must be 0 (solve on every rank) or 1 (rank 0 solves and broadcasts)");
         ctx->opt_dist_solve = (int)value;
+    } else if (!strcmp(key, "acc_min_cpw")) {
+        if (value < 0 || value > 4096) return ctx->fail(FSNAP_E_ARG, "acc_min_cpw out of range");
+        ctx->opt_acc_min_cpw = (int)value;
     } else if (!strcmp(key, "reduce_triangle")) {
         if (value < -1 || value > 1) return ctx->fail(FSNAP_E_ARG, "reduce_triangle must be -1 (K >= 256), 0 (never) or 1 (always)");
         ctx->opt_reduce_triangle = (int)value;

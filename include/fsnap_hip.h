@@ -93,6 +93,8 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * context and of fsnap_comm_init -- a phase that may fail without taking the job with it sets a short one),
  * "fused_pack" (0|1, default 1: the 80 < K <= 144 kernel forms the per-row pairs (mask * w, mask * w * b) of its rows in LDS inside
  * the SYRK launch -- no packing launch, nothing of them in HBM -- whenever a workgroup's rows fit; 0 = separate packing kernel, A/B),
+ * "acc_min_cpw" (tuning aid: fewest 4-row chunks per row-wave of the 80 < K <= 144 kernel before its grid shrinks below one workgroup
+ * per CU; 0 = default 12 -- 6 ... 9 measured within noise of it on 13 035 x 142 and 15 213 x 128),
  * "acc_max_k" (144 | 128: widest system on the accumulator-resident kernel; 128 sends 129 ... 144 columns to the tiled kernel, A/B),
  * "reduce" (0 = reduction kernel 2b with every load of a thread in flight, the default; 1 = its predecessor, A/B),
  * "mirror_upper" (0|1, default 1: the reduction writes the host mirror's triangle once per element, at its upper position),
