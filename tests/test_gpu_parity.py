@@ -1162,6 +1162,61 @@ def test_row_upload_paths_deliver_the_same_rows(mode, m, K, pad):
     c.close()
 
 
+@pytest.mark.parametrize("K", [31, 128, 142])
+def test_weights_bound_in_caller_memory_are_read_afresh_by_every_fit(K):
+    # fsnap_bind_rows / fsnap_bind_weights: rows, weights and mask live in memory the caller owns and may change between fits
+    # without telling the library.  The kernels that pack the per-row pairs themselves read b, w and the mask in every launch;
+    # the packing-kernel form (fused_pack = 0) re-packs on every launch for caller-owned memory.  Both see an in-place edit.
+    import torch
+
+    rng = np.random.default_rng(700 + K)
+    m = 40007
+    A, b, w = orc.synth_problem(m, K)
+    t = rng.random(m) < 0.15
+    dev = torch.device("cuda", 0)
+    dA = torch.zeros(m * K + 4, dtype=torch.float64, device=dev)     # 16 readable bytes (and more) behind the last row
+    dA[: m * K].copy_(torch.from_numpy(np.ascontiguousarray(A).reshape(-1)))
+    db = torch.from_numpy(b).to(dev)
+    dw = torch.from_numpy(w).to(dev)
+    dm = torch.from_numpy((~t).astype(np.uint8)).to(dev)
+    torch.cuda.synchronize()
+    for fused in (1, 0):
+        c = _capi.HipContext(0)
+        c.set_option("fused_pack", fused)
+        c.bind_rows(dA.data_ptr(), m, K, K, db.data_ptr())
+        c.bind_weights(dw.data_ptr(), dm.data_ptr())
+        stats_close(*c.normal_eq(), *orc.normal_eq(A, b, w, t))
+        w2 = w * rng.uniform(0.5, 2.0, m)
+        t2 = rng.random(m) < 0.3
+        dw.copy_(torch.from_numpy(w2))                               # in place, same addresses
+        dm.copy_(torch.from_numpy((~t2).astype(np.uint8)))
+        torch.cuda.synchronize()
+        stats_close(*c.normal_eq(), *orc.normal_eq(A, b, w2, t2))
+        dw.copy_(torch.from_numpy(w))
+        dm.copy_(torch.from_numpy((~t).astype(np.uint8)))
+        torch.cuda.synchronize()
+        c.close()
+
+
+def test_fused_packing_falls_back_when_a_workgroups_rows_do_not_fit_the_lds(ctx):
+    # few workgroups (option nblocks) -> thousands of chunks per row-wave: their pairs do not fit the 160 KiB of LDS, the
+    # launch reads pairs packed by fsnap_pack_weights_k instead -- same statistics
+    A, b, w = orc.synth_problem(120001, 128)
+    t = np.random.default_rng(5).random(len(b)) < 0.2
+    ref = orc.normal_eq(A, b, w, t)
+    ctx.set_option("nblocks", 8)
+    try:
+        got = run_stats(ctx, A, b, w, t)
+        info = ctx.launch_info()
+        assert info["kernel_or_pairs"] == 3 and info["fused_pack"] == 0 and info["chunks_per_wave"] > 628
+    finally:
+        ctx.set_option("nblocks", 0)
+    stats_close(*got, *ref)
+    got2 = run_stats(ctx, A, b, w, t)
+    assert ctx.launch_info()["fused_pack"] == 1
+    stats_close(*got2, *ref)
+
+
 @pytest.mark.parametrize("K", [31, 128, 200])
 def test_streaming_accumulation_matches_one_shot(ctx, K):
     # fsnap_normal_eq_accumulate: per-batch `c += cm; d += dm` (transpose_trick/example.py:230-237) on the device;
