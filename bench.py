@@ -255,6 +255,8 @@ def recorded_traffic(m, Kc, info, kernel_name):
 def kernel_name_of(info):
     if info["split"] == 0:
         return "fsnap_syrk_tiled"
+    if info["kernel_or_pairs"] == 5:
+        return f"fsnap_syrk_quad<{info['NB']}>"
     if info["kernel_or_pairs"] == 4:
         return f"fsnap_syrk_wave_p<{info['NB']}>"
     if info["kernel_or_pairs"] == 3:

@@ -59,13 +59,41 @@ struct Geometry {
     bool acc;       // kernel 1A: whole triangle in one wave (accumulation registers), one wave per SIMD
     bool packed;    // kernel 1P: kernel 1 on packed weights (K <= 80)
     bool fused_pack = false;   // kernel 1A packs (w_eff, w_eff b) of its rows into LDS itself: no fsnap_pack_weights_k launch
+    bool quad = false;         // kernel 1Q: the triangle dealt to the four waves of a workgroup (144 < K <= 256); cpw = chunks per workgroup
 };
+
+// rows below which the tiled kernel keeps 145 ... 256 columns: kernel 1Q writes one partial triangle per workgroup
+// (2 KiB x 55 ... 136 tiles), which short systems do not amortise
+constexpr int64_t QUAD_MIN_ROWS = 8192;
+constexpr int64_t QUAD_MIN_CPG = 24;        // fewest 4-row chunks per workgroup before the grid shrinks
+
+// chunks per workgroup of kernel 1Q for this context's rows, 0 = kernel 1Q does not take them
+int64_t quad_chunks_per_wg(const fsnap_ctx* ctx, int64_t* nblocks_out) {
+    const bool default_kernel = ctx->opt_kernel == 0 || ctx->opt_kernel == 7;
+    if (!ctx->opt_quad || !default_kernel || ctx->opt_tiled || ctx->wpack_override || !ctx->opt_fused_pack) return 0;
+    if (ctx->K <= 144 || ctx->K > 256 || ctx->K <= ctx->opt_acc_max_k) return 0;
+    const int64_t min_rows = ctx->opt_quad_min_rows >= 0 ? ctx->opt_quad_min_rows : QUAD_MIN_ROWS;
+    if (ctx->m < min_rows || ctx->m < 4) return 0;
+    const int64_t nchunks = (ctx->m + 3) / 4;
+    int64_t nblocks = ctx->opt_nblocks > 0 ? ctx->opt_nblocks : (int64_t)ctx->num_cu;
+    const int64_t max_blocks = (nchunks + QUAD_MIN_CPG - 1) / QUAD_MIN_CPG;
+    if (nblocks > max_blocks) nblocks = max_blocks;
+    if (nblocks < 1) nblocks = 1;
+    const int64_t cpg = (nchunks + nblocks - 1) / nblocks;
+    const int64_t off_limit = (int64_t)0xFFF00000;
+    if (cpg > fsnap::syrk_quad_max_cpg() || cpg > off_limit / (ctx->lda * 32)) return 0;    // pairs beyond the LDS / 32-bit offsets: tiled kernel
+    nblocks = (nchunks + cpg - 1) / cpg;
+    if (nblocks_out) *nblocks_out = nblocks;
+    return cpg;
+}
 
 // widest system the accumulator-resident kernel 1A takes (NB = 9 column blocks: the ACE width 142 of
 // examples/Ta_PACE_RIDGE); option acc_max_k = 128 sends 129 ... 144 columns back to the tiled kernel (A/B)
 inline bool use_tiled(const fsnap_ctx* ctx) {
     const bool acc_kernel = ctx->opt_kernel == 0 || ctx->opt_kernel == 7;    // the A/B kernels stop at 128 columns
-    return ctx->opt_tiled || ctx->K > (acc_kernel ? ctx->opt_acc_max_k : 128);
+    if (ctx->opt_tiled) return true;
+    if (ctx->K <= (acc_kernel ? ctx->opt_acc_max_k : 128)) return false;
+    return quad_chunks_per_wg(ctx, nullptr) == 0;
 }
 
 int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
@@ -76,6 +104,19 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
     const int64_t off_limit = (int64_t)0xFFF00000;  // 32-bit buffer offsets, 1 MiB of slack for prefetch overshoot
     g->acc = false;
     g->packed = false;
+    if (g->NB >= 10) {
+        // kernel 1Q (use_tiled() sent everything else of this width to the tiled kernel)
+        int64_t nblocks = 0;
+        const int64_t cpg = quad_chunks_per_wg(ctx, &nblocks);
+        if (cpg <= 0) return ctx->fail(FSNAP_E_ARG, "no accumulator-resident kernel for %d columns", K);
+        g->nblocks = (int)nblocks;
+        g->cpw = cpg;
+        g->split = 1;
+        g->threads = 256;
+        g->quad = true;
+        g->fused_pack = true;
+        return FSNAP_OK;
+    }
     if (g->NB >= 6 && (ctx->opt_kernel == 7 || ctx->opt_kernel == 0)) {
         // kernel 1A: one 4-wave workgroup per CU, every wave streams its own rows and owns the whole triangle
         const int64_t nchunks = (m + 3) / 4;
@@ -567,7 +608,7 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
     a.spart = (double*)ctx->spart.p;
     int ns = -1;                      // scalar partials: from the SYRK kernel, or (kernel 1A) from the weight packing
     const double* spart_src = a.spart;
-    if ((g.acc || g.packed) && g.fused_pack) {
+    if ((g.acc || g.packed || g.quad) && g.fused_pack) {
         a.fused_pack = true;          // b, w, mask -> pairs in LDS + the b-only scalars per row-wave, inside the SYRK launch
     } else if (g.acc || g.packed) {
         int npk = 0;
@@ -587,7 +628,8 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
     hipEvent_t* evs;
     if ((rc = fit_events(ctx, &evs))) return rc;
     if (evs) FSNAP_HIP(hipEventRecord(evs[0], ctx->stream), "hipEventRecord");
-    if (g.acc) FSNAP_HIP(fsnap::launch_syrk_acc(a, ctx->stream), "launch fsnap_syrk_acc");
+    if (g.quad) FSNAP_HIP(fsnap::launch_syrk_quad(a, ctx->stream), "launch fsnap_syrk_quad");
+    else if (g.acc) FSNAP_HIP(fsnap::launch_syrk_acc(a, ctx->stream), "launch fsnap_syrk_acc");
     else if (g.packed) FSNAP_HIP(fsnap::launch_syrk_wave_p(a, ctx->stream), "launch fsnap_syrk_wave_p");
     else if (g.lds_waves) FSNAP_HIP(fsnap::launch_syrk_lds(a, ctx->stream), "launch fsnap_syrk_lds");
     else FSNAP_HIP(fsnap::launch_syrk(a, ctx->stream), "launch fsnap_syrk_wave");
@@ -811,6 +853,12 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
     } else if (!strcmp(key, "dist_solve")) {
         if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "dist_solve must be 0 (solve on every rank) or 1 (rank 0 solves and broadcasts)");
         ctx->opt_dist_solve = (int)value;
+    } else if (!strcmp(key, "quad")) {
+        if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "quad must be 0 or 1");
+        ctx->opt_quad = (int)value;
+    } else if (!strcmp(key, "quad_min_rows")) {
+        if (value < -1) return ctx->fail(FSNAP_E_ARG, "quad_min_rows must be >= -1");
+        ctx->opt_quad_min_rows = value;
     } else if (!strcmp(key, "acc_min_cpw")) {
         if (value < 0 || value > 4096) return ctx->fail(FSNAP_E_ARG, "acc_min_cpw out of range");
         ctx->opt_acc_min_cpw = (int)value;
@@ -1822,8 +1870,8 @@ int fsnap_launch_info(fsnap_ctx* ctx, int64_t* info, int n) {
         out[2] = g.cpw;
         out[3] = g.NB;
         out[4] = g.split;
-        out[6] = g.acc ? 3 : (g.packed ? 4 : (g.lds_waves ? 2 : 1));
-        out[7] = g.fused_pack ? 1 : 0;  // kernel id: 1 = wave-triangle, 2 = LDS-shared, 3 = one-wave triangle (1A), 4 = wave-triangle on packed weights (1P)
+        out[6] = g.quad ? 5 : g.acc ? 3 : (g.packed ? 4 : (g.lds_waves ? 2 : 1));
+        out[7] = g.fused_pack ? 1 : 0;  // kernel id: 1 = wave-triangle, 2 = LDS-shared, 3 = one-wave triangle (1A), 4 = wave-triangle on packed weights (1P), 5 = triangle dealt to the four waves of a workgroup (1Q; chunks per WORKGROUP)
     }
     for (int i = 0; i < n; ++i) info[i] = out[i];
     return FSNAP_OK;

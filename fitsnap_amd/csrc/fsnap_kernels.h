@@ -58,6 +58,9 @@ hipError_t launch_syrk(const SyrkArgs& a, hipStream_t st);
 hipError_t launch_syrk_wave_p(const SyrkArgs& a, hipStream_t st);   // K <= 80, packed weights (a.wpack)
 hipError_t launch_syrk_lds(const SyrkArgs& a, hipStream_t st);
 hipError_t launch_syrk_acc(const SyrkArgs& a, hipStream_t st);
+// kernel 1Q (144 < K <= 256, fsnap_syrk_quad.hip): a.chunks_per_wave = chunks per WORKGROUP; always packs the pairs itself
+hipError_t launch_syrk_quad(const SyrkArgs& a, hipStream_t st);
+int64_t syrk_quad_max_cpg();
 int64_t syrk_acc_max_fused_cpw();
 int64_t syrk_wave_p_max_fused_cpw(int K, int wg_per_cu);   // kernel 1P: same for its (smaller, shared) LDS budget
 // mirror: optional page-locked HOST buffer that receives the same packed statistics (zero-copy D2H)

@@ -1,0 +1,473 @@
+// fsnap_syrk_quad.hip — kernel 1Q: fused mask x weight x SYRK for 144 < K <= 256 (gfx950 only).
+//
+// The statistics of the linear fit, G = (wA)^T (wA), c = (wA)^T (wb) and the three scalars
+// (fitsnap3lib/solvers/ridge.py:40-49, svd.py:35-54 after the transpose trick), for the widths between kernel 1A
+// (one wave holds the whole tile triangle: NB <= 9 column blocks) and the widths where the tiled kernel 1T has
+// enough equal work items (K >~ 300): three-element SNAP (168), four-element SNAP (220 + offsets), short ACE bases.
+//
+// Kernel 1A's plan with the triangle DEALT TO THE FOUR WAVES OF A WORKGROUP: NB = 10 ... 16 column blocks are 55 ...
+// 136 accumulator tiles, 14 ... 34 per wave (32 in the accumulation registers a[0:255], up to two more in VGPRs).
+// The four waves sweep the SAME rows -- the workgroup's contiguous row range -- each with its own loads: a wave
+// reads the column blocks its tile rows touch (all of them for the wave that owns tile row 0) straight into
+// MFMA-fragment registers, three chunks ahead, exactly like kernel 1A; the first wave to ask brings a row in from
+// HBM, the other three find it in L2 / L1 (the workgroup lives on one CU).  No LDS traffic and no barrier in the
+// loop, one wave per SIMD.  HBM sees every row once; the L1 sees it up to four times: 32 KiB per 4-row chunk and
+// 1300 ... 2200 cycles of matrix pipe at K = 256.
+// Whole tile ROWS (tiles (p, p .. NB-1), A operand block p) are dealt so that the four tile counts differ by at
+// most one (quad_rows below); inside a wave the rows run in ascending order, so column block j of the NEXT chunk
+// can overwrite V[j] as soon as the last tile row p <= j of this wave has been issued (kernel 1A's single operand
+// set).  c = (wA)^T (wb) rides along on the VALU, its column blocks dealt to the waves that hold them, fewest
+// multiplies first.  The per-row pairs (w_eff, w_eff b) of the workgroup's rows are formed in LDS by the prologue
+// (all 256 threads), like kernel 1A with fused packing; the b-only scalars leave from there.
+// Partials: part[workgroup][NT][4][64] -- every tile written by the one wave that owns it, no fold --,
+// cpart[workgroup * 4 + wave][NB][16] (zeros for the blocks another wave owns), spart[workgroup * 4 + wave][4]:
+// the layout of kernel 1A, reduced by the same kernel 2b.  No floating-point atomics; bit-identical run to run.
+#include <utility>
+
+#include "fsnap_device_common.h"
+#include "fsnap_kernels.h"
+
+namespace {
+
+__host__ __device__ constexpr int quad_tri_index(int p, int q, int NB) { return p * NB - (p * (p - 1)) / 2 + (q - p); }
+
+// tile rows of wave w for NB column blocks (-1 ends the list): the lengths NB - p of a wave's rows add up to
+// ceil or floor of NB (NB + 1) / 8 -- checked by the static_asserts below
+constexpr int QUAD_ROWS[7][4][7] = {
+    /* NB = 10: 14 14 14 13 */ {{0, 6, -1}, {1, 5, -1}, {2, 4, -1}, {3, 7, 8, 9, -1}},
+    /* NB = 11: 17 17 17 15 */ {{0, 5, -1}, {1, 4, -1}, {2, 3, -1}, {6, 7, 8, 9, 10, -1}},
+    /* NB = 12: 20 20 20 18 */ {{0, 4, -1}, {1, 3, -1}, {2, 5, 9, -1}, {6, 7, 8, 10, 11, -1}},
+    /* NB = 13: 23 23 23 22 */ {{0, 3, -1}, {1, 2, -1}, {4, 5, 7, -1}, {6, 8, 9, 10, 11, 12, -1}},
+    /* NB = 14: 27 26 26 26 */ {{0, 1, -1}, {2, 3, 11, -1}, {4, 5, 7, -1}, {6, 8, 9, 10, 12, 13, -1}},
+    /* NB = 15: 30 30 30 30 */ {{0, 1, 14, -1}, {2, 3, 10, -1}, {4, 5, 6, -1}, {7, 8, 9, 11, 12, 13, -1}},
+    /* NB = 16: 34 34 34 34 */ {{0, 1, 13, -1}, {2, 3, 9, -1}, {4, 5, 6, 15, -1}, {7, 8, 10, 11, 12, 14, -1}},
+};
+
+constexpr int QUAD_MAXT = 34;
+
+struct QuadPlan {
+    int n;                  // tiles of this wave
+    int jmin;               // first column block it reads
+    int tp[QUAD_MAXT], tq[QUAD_MAXT];
+    int rf_lo[QUAD_MAXT], rf_hi[QUAD_MAXT];   // after tile i: refresh V[rf_lo .. rf_hi) with the next chunk (empty unless i ends a tile row)
+    int cown[16];           // 1 = this wave accumulates c for column block j
+};
+
+constexpr QuadPlan quad_plan(int NB, int w) {
+    QuadPlan P{};
+    const int(&rows)[7] = QUAD_ROWS[NB - 10][w];
+    int n = 0;
+    P.jmin = rows[0];
+    for (int i = 0; i < 7 && rows[i] >= 0; ++i) {
+        const int p = rows[i];
+        const int pnext = (i + 1 < 7 && rows[i + 1] >= 0) ? rows[i + 1] : NB;
+        for (int q = p; q < NB; ++q) {
+            P.tp[n] = p;
+            P.tq[n] = q;
+            P.rf_lo[n] = 0;
+            P.rf_hi[n] = 0;
+            ++n;
+        }
+        P.rf_lo[n - 1] = p;
+        P.rf_hi[n - 1] = pnext;
+    }
+    P.n = n;
+    // c: column block j goes to the wave with the least VALU work so far among those that hold it (jmin <= j)
+    int load[4] = {0, 0, 0, 0};
+    int jm[4] = {0, 0, 0, 0};
+    for (int v = 0; v < 4; ++v) {
+        jm[v] = QUAD_ROWS[NB - 10][v][0];
+        load[v] = NB - jm[v];
+    }
+    for (int j = NB - 1; j >= 0; --j) {
+        int best = -1;
+        for (int v = 3; v >= 0; --v)
+            if (jm[v] <= j && (best < 0 || load[v] < load[best])) best = v;
+        load[best] += 1;
+        P.cown[j] = (best == w) ? 1 : 0;
+    }
+    return P;
+}
+
+constexpr bool quad_plans_cover(int NB) {
+    int seen[16 * 17 / 2] = {};
+    int mx = 0, mn = 1000;
+    for (int w = 0; w < 4; ++w) {
+        const QuadPlan P = quad_plan(NB, w);
+        if (P.n > QUAD_MAXT) return false;
+        mx = P.n > mx ? P.n : mx;
+        mn = P.n < mn ? P.n : mn;
+        for (int i = 0; i < P.n; ++i) seen[quad_tri_index(P.tp[i], P.tq[i], NB)] += 1;
+        for (int i = 1; i < P.n; ++i)
+            if (P.tp[i] < P.tp[i - 1]) return false;          // ascending tile rows
+    }
+    for (int t = 0; t < NB * (NB + 1) / 2; ++t)
+        if (seen[t] != 1) return false;
+    return mx - mn <= 2;
+}
+static_assert(quad_plans_cover(10) && quad_plans_cover(11) && quad_plans_cover(12) && quad_plans_cover(13) &&
+                  quad_plans_cover(14) && quad_plans_cover(15) && quad_plans_cover(16),
+              "every tile of the triangle belongs to exactly one wave");
+
+template <int NB, int W>
+struct QuadPlanOf {
+    static constexpr QuadPlan P = quad_plan(NB, W);
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t quad_rsrc(const void* p, unsigned bytes) {
+    // dword3 0x00020000: raw buffer, 32-bit data format (gfx9-family encoding)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+constexpr unsigned QUAD_OOB_VOFF = 0xFFFFF000u;    // beyond any workgroup's buffer (plan: < 0xFFF00010): reads back zeros
+
+// accumulator tile T of a wave: a[8T : 8T + 7] for T < 32, VGPRs beyond
+template <int T, int NV>
+__device__ __forceinline__ void quad_mfma(double a, double b, d4 (&vt)[NV]) {
+    if constexpr (T < 32) {
+        asm volatile("v_mfma_f64_16x16x4_f64 a[%2:%3], %0, %1, a[%2:%3]" : : "v"(a), "v"(b), "n"(8 * T), "n"(8 * T + 7));
+    } else {
+        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(vt[T - 32]) : "v"(a), "v"(b));
+    }
+}
+template <int R>
+__device__ __forceinline__ void quad_zero_reg() {
+    asm volatile("v_accvgpr_write_b32 a[%0], 0" : : "n"(R));
+}
+template <int... R>
+__device__ __forceinline__ void quad_zero_all(std::integer_sequence<int, R...>) {
+    (quad_zero_reg<R>(), ...);
+}
+template <int T, int NV>
+__device__ __forceinline__ d4 quad_read(const d4 (&vt)[NV]) {
+    if constexpr (T >= 32) {
+        return vt[T - 32];
+    } else {
+        unsigned r0, r1, r2, r3, r4, r5, r6, r7;
+        asm volatile(
+            "v_accvgpr_read_b32 %0, a[%8]\n\tv_accvgpr_read_b32 %1, a[%9]\n\t"
+            "v_accvgpr_read_b32 %2, a[%10]\n\tv_accvgpr_read_b32 %3, a[%11]\n\t"
+            "v_accvgpr_read_b32 %4, a[%12]\n\tv_accvgpr_read_b32 %5, a[%13]\n\t"
+            "v_accvgpr_read_b32 %6, a[%14]\n\tv_accvgpr_read_b32 %7, a[%15]"
+            : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3), "=v"(r4), "=v"(r5), "=v"(r6), "=v"(r7)
+            : "n"(8 * T), "n"(8 * T + 1), "n"(8 * T + 2), "n"(8 * T + 3), "n"(8 * T + 4), "n"(8 * T + 5), "n"(8 * T + 6),
+              "n"(8 * T + 7));
+        d4 x;
+        x[0] = __builtin_bit_cast(double, ((unsigned long long)r1 << 32) | r0);
+        x[1] = __builtin_bit_cast(double, ((unsigned long long)r3 << 32) | r2);
+        x[2] = __builtin_bit_cast(double, ((unsigned long long)r5 << 32) | r4);
+        x[3] = __builtin_bit_cast(double, ((unsigned long long)r7 << 32) | r6);
+        return x;
+    }
+}
+
+template <class F, int... I>
+__device__ __forceinline__ void quad_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void quad_for(F&& f) {
+    quad_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Raw loads of one 4-row chunk for a wave that reads column blocks 2 PR0 .. NB - 1: 16-byte loads give a lane two
+// ADJACENT columns, which go to two column blocks (even / odd columns of a 32-column group, fsnap_syrk.hip); an odd
+// NB ends with a plain 16-column block.
+template <int NB, int PR0>
+struct QuadRaw {
+    static constexpr int NPR = NB / 2 - PR0;
+    u4 pr[NPR > 0 ? NPR : 1];
+    u2 tail;
+};
+
+struct QuadBufs {
+    __amdgpu_buffer_rsrc_t A;
+    unsigned voffA;        // (kr * lda + 2 e) * 8 + 256 PR0
+    unsigned voffT;        // (kr * lda + 16 (NB - 1) + e) * 8
+    unsigned chunk_bytes;  // 4 * lda * 8
+};
+
+__device__ __forceinline__ bool quad_keep(const u4& wp) {
+    return ((wp[0] | (wp[1] & 0x7FFFFFFFu)) != 0u);      // w_eff != +-0
+}
+
+template <int NB, int PR0, int P>
+__device__ __forceinline__ void quad_issue_piece(QuadRaw<NB, PR0>& r, const QuadBufs& wb, unsigned cl, unsigned va, unsigned vtl) {
+    constexpr int NPR = QuadRaw<NB, PR0>::NPR;
+    const unsigned soff = cl * wb.chunk_bytes;
+    if constexpr (P < NPR) r.pr[P] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, va + 256u * P, soff, 0);
+    if constexpr ((NB & 1) && P == NPR) r.tail = __builtin_amdgcn_raw_buffer_load_b64(wb.A, vtl, soff, 0);
+}
+
+template <int NB, int PR0>
+__device__ __forceinline__ void quad_issue_rows(QuadRaw<NB, PR0>& r, const u4& wp, const QuadBufs& wb, unsigned cl) {
+    const bool keep = quad_keep(wp);
+    const unsigned va = keep ? wb.voffA : QUAD_OOB_VOFF;
+    const unsigned vtl = keep ? wb.voffT : QUAD_OOB_VOFF;
+    quad_for<QuadRaw<NB, PR0>::NPR + (NB & 1)>([&](auto pc) { quad_issue_piece<NB, PR0, decltype(pc)::value>(r, wb, cl, va, vtl); });
+}
+
+// w * (raw value of column block J); columns >= K (last block / block pair only) are zeroed by a select
+template <int NB, int PR0, bool FULLK, int J>
+__device__ __forceinline__ double quad_weighted(const QuadRaw<NB, PR0>& r, double wv, int K, int e) {
+    if constexpr ((NB & 1) && J == NB - 1) {
+        const double x = wv * __builtin_bit_cast(double, r.tail);
+        if (FULLK) return x;
+        return (16 * (NB - 1) + e < K) ? x : 0.0;
+    } else {
+        const double x = wv * __builtin_bit_cast(d2, r.pr[(J >> 1) - PR0])[J & 1];
+        constexpr int last_pair = (NB & 1) ? -1 : NB / 2 - 1;
+        if (FULLK || (J >> 1) != last_pair) return x;
+        return (32 * (J >> 1) + 2 * e + (J & 1) < K) ? x : 0.0;
+    }
+}
+
+constexpr int QUAD_LDS_DOUBLES = 20480;   // all 160 KiB of the CU: the per-row pairs of the workgroup's rows
+constexpr int QUAD_PACK_PAD = 12;         // chunk slots the unrolled loop may look past the last chunk (<= ncl + 9)
+
+// One step: the MFMAs of the chunk held in V, with the preparation of the next chunk (raw set RN, pair PW) in
+// between: the refill of the raw set consumed a step ago (rows of chunk cl_fill, gated by PKEEP) goes out one load
+// per MFMA at the start of the step; V[j] takes the next chunk as soon as the wave's last tile row <= j is issued.
+template <int NB, int W, bool FULLK, int NV>
+__device__ __forceinline__ void quad_step(double (&V)[NB], d4 (&vt)[NV], QuadRaw<NB, (QuadPlanOf<NB, W>::P.jmin >> 1)>& RF,
+                                          const QuadRaw<NB, (QuadPlanOf<NB, W>::P.jmin >> 1)>& RN, const QuadBufs& wb,
+                                          const double* lpk, unsigned cl_fill, int K, int e, double (&cacc)[NB], const u4& PW,
+                                          const u4& PKEEP, u4& PLOAD) {
+    using PL = QuadPlanOf<NB, W>;
+    constexpr int PR0 = PL::P.jmin >> 1;
+    constexpr int NPIECE = QuadRaw<NB, PR0>::NPR + (NB & 1);
+    const d2 wpn = __builtin_bit_cast(d2, PW);
+    const double wv = wpn[0], wbv = wpn[1];
+    const bool keep = quad_keep(PKEEP);
+    const unsigned va = keep ? wb.voffA : QUAD_OOB_VOFF;
+    const unsigned vtl = (NB & 1) ? (keep ? wb.voffT : QUAD_OOB_VOFF) : 0u;
+    PLOAD = __builtin_bit_cast(u4, *reinterpret_cast<const d2*>(lpk + (size_t)(cl_fill + 2) * 8));
+    __builtin_amdgcn_sched_barrier(0);
+    quad_for<PL::P.n>([&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        constexpr int TP = PL::P.tp[I], TQ = PL::P.tq[I], LO = PL::P.rf_lo[I], HI = PL::P.rf_hi[I];
+        quad_mfma<I, NV>(V[TP], V[TQ], vt);
+        if constexpr (I < NPIECE) {
+            quad_issue_piece<NB, PR0, I>(RF, wb, cl_fill, va, vtl);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (HI > LO) {
+            quad_for<HI - LO>([&](auto jc) {
+                constexpr int J = LO + decltype(jc)::value;
+                constexpr int OWN = PL::P.cown[J];
+                V[J] = quad_weighted<NB, PR0, FULLK, J>(RN, wv, K, e);
+                if constexpr (OWN != 0) cacc[J] = __builtin_fma(V[J], wbv, cacc[J]);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    });
+}
+
+template <int NB, int W, bool FULLK>
+__device__ __forceinline__ void quad_wave(const double* __restrict__ A, int64_t lda, int K, int64_t row0, int64_t nrow, unsigned ncl,
+                                          const double* lpk, double* __restrict__ pw, double* __restrict__ cw, int lane) {
+    using PL = QuadPlanOf<NB, W>;
+    constexpr int JMIN = PL::P.jmin, NTW = PL::P.n;
+    constexpr int PR0 = JMIN >> 1;
+    constexpr int NV = NTW > 32 ? NTW - 32 : 1;
+    using Raw = QuadRaw<NB, PR0>;
+    const int e = lane & 15, kr = lane >> 4;
+    QuadBufs wb;
+    wb.A = quad_rsrc(A + row0 * lda, (unsigned)(nrow * lda * 8 + (nrow ? 16 : 0)));
+    wb.voffA = (unsigned)((kr * lda + 2 * e) * 8) + 256u * PR0;
+    wb.voffT = (unsigned)((kr * lda + 16 * (NB - 1) + e) * 8);
+    wb.chunk_bytes = (unsigned)(lda * 32);
+    lpk += 2 * kr;
+
+    d4 vt[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) vt[u] = d4{0.0, 0.0, 0.0, 0.0};
+    double cacc[NB], V[NB];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+        cacc[p] = 0.0;
+        V[p] = 0.0;
+    }
+    auto pair_of = [&](unsigned cl) { return __builtin_bit_cast(u4, *reinterpret_cast<const d2*>(lpk + (size_t)cl * 8)); };
+    if (ncl > 0) {
+        Raw r0, r1, r2;
+        u4 pk0 = pair_of(0), pk1 = pair_of(1), pk2 = pair_of(2);
+        quad_issue_rows<NB, PR0>(r0, pk0, wb, 0);
+        quad_issue_rows<NB, PR0>(r1, pk1, wb, 1);
+        quad_issue_rows<NB, PR0>(r2, pk2, wb, 2);
+        {   // chunk 0 -> V
+            const d2 wp0 = __builtin_bit_cast(d2, pk0);
+            const double wv = wp0[0], wbv = wp0[1];
+            quad_for<NB - JMIN>([&](auto jc) {
+                constexpr int J = JMIN + decltype(jc)::value;
+                constexpr int OWN = PL::P.cown[J];
+                V[J] = quad_weighted<NB, PR0, FULLK, J>(r0, wv, K, e);
+                if constexpr (OWN != 0) cacc[J] = __builtin_fma(V[J], wbv, cacc[J]);
+            });
+        }
+        // ring of pairs: slot (c mod 6) holds the pair of chunk c; a step uses c + 1 (weights), c + 3 (row mask of
+        // the refill) and loads c + 5 (kernel 1A's loop, fsnap_syrk.hip)
+        u4 pk3 = pair_of(3), pk4 = pair_of(4), pk5 = {0u, 0u, 0u, 0u};
+        (void)pk0;
+        unsigned cl = 0;
+        for (; cl + 3 < ncl; cl += 6) {
+            quad_step<NB, W, FULLK>(V, vt, r0, r1, wb, lpk, cl + 3, K, e, cacc, pk1, pk3, pk5);
+            quad_step<NB, W, FULLK>(V, vt, r1, r2, wb, lpk, cl + 4, K, e, cacc, pk2, pk4, pk0);
+            quad_step<NB, W, FULLK>(V, vt, r2, r0, wb, lpk, cl + 5, K, e, cacc, pk3, pk5, pk1);
+            quad_step<NB, W, FULLK>(V, vt, r0, r1, wb, lpk, cl + 6, K, e, cacc, pk4, pk0, pk2);
+            quad_step<NB, W, FULLK>(V, vt, r1, r2, wb, lpk, cl + 7, K, e, cacc, pk5, pk1, pk3);
+            quad_step<NB, W, FULLK>(V, vt, r2, r0, wb, lpk, cl + 8, K, e, cacc, pk0, pk2, pk4);
+        }
+        if (cl < ncl) {
+            quad_step<NB, W, FULLK>(V, vt, r0, r1, wb, lpk, cl + 3, K, e, cacc, pk1, pk3, pk5);
+            quad_step<NB, W, FULLK>(V, vt, r1, r2, wb, lpk, cl + 4, K, e, cacc, pk2, pk4, pk0);
+            quad_step<NB, W, FULLK>(V, vt, r2, r0, wb, lpk, cl + 5, K, e, cacc, pk3, pk5, pk1);
+        }
+    }
+    // the last MFMAs (16 passes) must have left the pipe before their accumulators are read
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(vt[0]));
+#pragma unroll
+    for (int u = 1; u < NV; ++u) asm volatile("" : "+v"(vt[u]));
+    // every tile straight to its place in the workgroup's partial triangle
+    quad_for<NTW>([&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        constexpr int T = quad_tri_index(PL::P.tp[I], PL::P.tq[I], NB);
+        const d4 x = quad_read<I, NV>(vt);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pw[(T * 4 + i) * 64 + lane] = x[i];
+    });
+    quad_for<NB>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        constexpr int OWN = PL::P.cown[J];
+        double sm = 0.0;
+        if constexpr (OWN != 0) {
+            sm = cacc[J];
+            sm += __shfl_xor(sm, 16, 64);
+            sm += __shfl_xor(sm, 32, 64);
+        }
+        if (kr == 0) cw[J * 16 + e] = sm;
+    });
+}
+
+}  // namespace
+
+template <int NB, bool FULLK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void
+fsnap_syrk_quad(const double* __restrict__ A, int64_t lda, int64_t m, int K, int64_t chunks_per_wg, double* __restrict__ part,
+                double* __restrict__ cpart, const double* __restrict__ bvec, const double* __restrict__ wvec,
+                const unsigned char* __restrict__ mask, double* __restrict__ spart) {
+    constexpr int NTILE = NB * (NB + 1) / 2;
+    __shared__ __attribute__((aligned(16))) double lds[QUAD_LDS_DOUBLES];
+    const int lane = threadIdx.x & 63;
+    const int rw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t nchunks = (m + 3) >> 2;
+    int64_t c0 = (int64_t)blockIdx.x * chunks_per_wg;
+    int64_t c1 = c0 + chunks_per_wg;
+    if (c1 > nchunks) c1 = nchunks;
+    if (c0 > c1) c0 = c1;
+    const int64_t row0 = c0 << 2;
+    int64_t row1 = c1 << 2;
+    if (row1 > m) row1 = m;
+    const int64_t nrow = row1 > row0 ? row1 - row0 : 0;
+    const unsigned ncl = (unsigned)(c1 - c0);
+
+    // prologue: (w_eff, w_eff b) of the workgroup's rows -> LDS, thread t takes rows t, t + 256, ... (bounds-checked
+    // loads: rows past the range read zeros and become (0, 0) pairs, what the loop's look-ahead expects); the
+    // b-only scalars of a wave's share leave as that wave's partial
+    {
+        const unsigned wg_rows = (unsigned)chunks_per_wg * 4u;
+        const unsigned region_rows = wg_rows + QUAD_PACK_PAD * 4u;
+        const __amdgpu_buffer_rsrc_t rb = quad_rsrc(bvec + row0, (unsigned)(nrow * 8));
+        const __amdgpu_buffer_rsrc_t rw_ = quad_rsrc(wvec + row0, (unsigned)(nrow * 8));
+        const __amdgpu_buffer_rsrc_t rm = quad_rsrc(mask + row0, (unsigned)nrow);
+        constexpr int PB = 8;
+        double bb = 0.0, sb = 0.0, cnt = 0.0;
+        for (unsigned r0 = 0; r0 < region_rows; r0 += 256u * PB) {
+            u2 bv[PB], wv[PB];
+            unsigned char mk[PB];
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const unsigned row = r0 + 256u * u + threadIdx.x;
+                bv[u] = __builtin_amdgcn_raw_buffer_load_b64(rb, row * 8u, 0, 0);
+                wv[u] = __builtin_amdgcn_raw_buffer_load_b64(rw_, row * 8u, 0, 0);
+                mk[u] = __builtin_amdgcn_raw_buffer_load_b8(rm, row, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const unsigned row = r0 + 256u * u + threadIdx.x;
+                const bool keep = (mk[u] != 0);
+                const double wvv = keep ? __builtin_bit_cast(double, wv[u]) : 0.0;
+                const double wbv = keep ? wvv * __builtin_bit_cast(double, bv[u]) : 0.0;
+                if (row < region_rows) {
+                    d2 o;
+                    o[0] = wvv;
+                    o[1] = wbv;
+                    *reinterpret_cast<d2*>(lds + (size_t)row * 2) = o;
+                }
+                bb = __builtin_fma(wbv, wbv, bb);
+                sb += wbv;
+                cnt += keep ? 1.0 : 0.0;
+            }
+        }
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) {       // fixed butterfly: deterministic
+            bb += __shfl_xor(bb, sh, 64);
+            sb += __shfl_xor(sb, sh, 64);
+            cnt += __shfl_xor(cnt, sh, 64);
+        }
+        if (lane == 0) {
+            double* so = spart + ((int64_t)blockIdx.x * 4 + rw) * 4;
+            so[0] = bb;
+            so[1] = sb;
+            so[2] = cnt;
+            so[3] = 0.0;
+        }
+    }
+    __syncthreads();
+
+    // the compiler must count a[0:255] as used (register allocation granule of the kernel descriptor)
+    asm volatile("" : : : "a0", "a255");
+    quad_zero_all(std::make_integer_sequence<int, 256>{});
+    double* pw = part + (int64_t)blockIdx.x * (int64_t)(NTILE * 256);
+    double* cw = cpart + ((int64_t)blockIdx.x * 4 + rw) * (int64_t)(NB * 16);
+    switch (rw) {
+        case 0: quad_wave<NB, 0, FULLK>(A, lda, K, row0, nrow, ncl, lds, pw, cw, lane); break;
+        case 1: quad_wave<NB, 1, FULLK>(A, lda, K, row0, nrow, ncl, lds, pw, cw, lane); break;
+        case 2: quad_wave<NB, 2, FULLK>(A, lda, K, row0, nrow, ncl, lds, pw, cw, lane); break;
+        default: quad_wave<NB, 3, FULLK>(A, lda, K, row0, nrow, ncl, lds, pw, cw, lane); break;
+    }
+}
+
+namespace fsnap {
+
+// chunks per workgroup up to which the workgroup's per-row pairs fit the LDS next to the look-ahead pad
+int64_t syrk_quad_max_cpg() { return QUAD_LDS_DOUBLES / 8 - QUAD_PACK_PAD; }
+
+template <int NB>
+static hipError_t launch_syrk_quad_nb(const SyrkArgs& a, hipStream_t st) {
+    dim3 grid((unsigned)a.nblocks), block(256);
+    if (!a.b || !a.w || !a.mask || !a.spart || a.chunks_per_wave > syrk_quad_max_cpg()) return hipErrorInvalidValue;
+    if (a.K == 16 * NB)
+        hipLaunchKernelGGL((fsnap_syrk_quad<NB, true>), grid, block, 0, st, a.A, a.lda, a.m, a.K, a.chunks_per_wave, a.part, a.cpart,
+                           a.b, a.w, a.mask, a.spart);
+    else
+        hipLaunchKernelGGL((fsnap_syrk_quad<NB, false>), grid, block, 0, st, a.A, a.lda, a.m, a.K, a.chunks_per_wave, a.part, a.cpart,
+                           a.b, a.w, a.mask, a.spart);
+    return hipGetLastError();
+}
+
+// kernel 1Q: a.nblocks workgroups, a.chunks_per_wave = 4-row chunks per WORKGROUP (its four waves sweep the same rows)
+hipError_t launch_syrk_quad(const SyrkArgs& a, hipStream_t st) {
+    switch ((a.K + 15) / 16) {
+        case 10: return launch_syrk_quad_nb<10>(a, st);
+        case 11: return launch_syrk_quad_nb<11>(a, st);
+        case 12: return launch_syrk_quad_nb<12>(a, st);
+        case 13: return launch_syrk_quad_nb<13>(a, st);
+        case 14: return launch_syrk_quad_nb<14>(a, st);
+        case 15: return launch_syrk_quad_nb<15>(a, st);
+        case 16: return launch_syrk_quad_nb<16>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace fsnap

@@ -73,6 +73,107 @@ def test_statistics_all_column_block_shapes(ctx, K):
     stats_close(G, c, s, *orc.normal_eq(A, b, w, t))
 
 
+# ---------------------------------------------------------------------------------------
+# kernel 1Q: 145 ... 256 columns, the tile triangle dealt to the four waves of a workgroup (fsnap_syrk_quad.hip)
+# ---------------------------------------------------------------------------------------
+@pytest.fixture()
+def qctx(ctx):
+    ctx.set_option("quad_min_rows", 0)          # short test systems: kernel 1Q takes them too
+    yield ctx
+    ctx.set_option("quad_min_rows", -1)
+
+
+@pytest.mark.parametrize("K", [145, 150, 159, 160, 161, 168, 175, 176, 177, 191, 192, 193, 200, 207, 208, 209, 223, 224, 225,
+                               239, 240, 241, 255, 256])
+def test_quad_kernel_statistics_all_column_block_shapes(qctx, K):
+    # NB = 10 ... 16: odd / even block counts, K a multiple of 16 (no column select) and not, the last block nearly empty
+    rng = np.random.default_rng(K)
+    m = 6151 + 11 * K                     # ragged: not a multiple of 4, uneven chunk ranges per workgroup
+    A = rng.standard_normal((m, K)) * (10.0 ** rng.uniform(-3, 3, size=K))
+    b = rng.standard_normal(m)
+    w = rng.choice([100.0, 1.0, 1e-8], size=m, p=[0.03, 0.83, 0.14])
+    t = rng.random(m) < 0.2
+    G, c, s = run_stats(qctx, A, b, w, t)
+    info = qctx.launch_info()
+    assert info["kernel_or_pairs"] == 5 and info["NB"] == (K + 15) // 16
+    stats_close(G, c, s, *orc.normal_eq(A, b, w, t))
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 7, 63, 64, 65, 257, 1023, 1025])
+@pytest.mark.parametrize("K", [168, 256])
+def test_quad_kernel_tiny_and_ragged_row_counts(qctx, m, K):
+    rng = np.random.default_rng(1000 + m + K)
+    A = rng.standard_normal((m, K))
+    b = rng.standard_normal(m)
+    w = rng.uniform(0.5, 2.0, m)
+    G, c, s = run_stats(qctx, A, b, w)
+    if m >= 4:
+        assert qctx.launch_info()["kernel_or_pairs"] == 5
+    stats_close(G, c, s, *orc.normal_eq(A, b, w), tol=1e-11)
+
+
+def test_quad_kernel_never_fetches_masked_rows_and_pads(qctx):
+    # NaN / Inf in test rows and zero-weight rows, a leading dimension wider than the row with NaN in the padding columns
+    rng = np.random.default_rng(77)
+    m, K, lda = 9001, 200, 211
+    Abig = np.full((m, lda), np.nan)
+    A = rng.standard_normal((m, K))
+    b = rng.standard_normal(m)
+    w = rng.uniform(0.5, 2.0, m)
+    t = rng.random(m) < 0.25
+    w[rng.random(m) < 0.1] = 0.0
+    A[t] = np.nan
+    A[w == 0.0] = np.inf
+    Abig[:, :K] = A
+    qctx.upload_rows(Abig[:, :K], b)            # (a strided view: the leading dimension is lda)
+    qctx.set_weights(w, (~t).astype(np.uint8))
+    G, c, s = qctx.normal_eq()
+    assert qctx.launch_info()["kernel_or_pairs"] == 5
+    Aclean = np.where((t | (w == 0.0))[:, None], 0.0, A)
+    stats_close(G, c, s, *orc.normal_eq(Aclean, b, w, t))
+
+
+@pytest.mark.parametrize("K", [168, 200, 256])
+def test_quad_kernel_agrees_with_the_tiled_kernel_and_the_oracle(ctx, K):
+    A, b, w = orc.synth_problem(60013, K)
+    t = np.random.default_rng(K).random(len(b)) < 0.15
+    ref = orc.normal_eq(A, b, w, t)
+    got = run_stats(ctx, A, b, w, t)
+    assert ctx.launch_info()["kernel_or_pairs"] == 5        # 60 013 rows: kernel 1Q by default
+    stats_close(*got, *ref)
+    again = ctx.normal_eq()
+    assert all(np.array_equal(x, y) for x, y in zip(got, again))           # run-to-run bit-identical
+    ctx.set_option("quad", 0)
+    try:
+        tiled = ctx.normal_eq()
+        assert ctx.launch_info()["split"] == 0                              # the tiled kernel
+    finally:
+        ctx.set_option("quad", 1)
+    stats_close(*tiled, *ref)
+    # streaming accumulation (fsnap_normal_eq_accumulate) through kernel 1Q: two batches add up to the whole
+    import torch
+    total = torch.zeros(K * K + K + 3, dtype=torch.float64, device=torch.device("cuda", 0))
+    h = len(b) // 2 + 3
+    for lo, hi in ((0, h), (h, len(b))):
+        ctx.upload_rows(A[lo:hi], b[lo:hi])
+        ctx.set_weights(w[lo:hi], (~t[lo:hi]).astype(np.uint8))
+        ctx.normal_eq_accumulate(total.data_ptr())
+        assert ctx.launch_info()["kernel_or_pairs"] == 5
+    stats_close(*ctx.download_packed(total.data_ptr(), K), *ref, tol=2e-12)
+
+
+def test_quad_kernel_fit_matches_the_oracle_solve(ctx):
+    # the whole fit at the three-element SNAP width: statistics from kernel 1Q, host mirror written by the reduction, host solve
+    A, b, w = orc.synth_problem(80000, 168)
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w)
+    beta = ctx.fit_resident(_capi.SOLVE_RIDGE, 1e-8)[0]
+    assert ctx.launch_info()["kernel_or_pairs"] == 5
+    G, c, s = orc.normal_eq(A, b, w)
+    ref = np.linalg.solve(G + 1e-8 * np.eye(168), c)
+    assert np.max(np.abs(beta - ref)) <= 1e-9 * np.max(np.abs(ref))
+
+
 @pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 1023, 1025])
 def test_statistics_tiny_and_ragged_row_counts(ctx, m):
     rng = np.random.default_rng(100 + m)
