@@ -217,10 +217,12 @@ def cpu_baseline(A, b, w, beta_gpu):
     }
 
 
-def kernel_source_digest():
-    """sha256 of the SYRK kernel sources: ties a recorded PMC traffic number to the code it was measured on."""
+def kernel_source_digest(kernel_name=""):
+    """sha256 of the sources of the named SYRK kernel (fsnap_syrk_quad<...> lives in a file of its own): ties a recorded
+    PMC traffic number to the code it was measured on."""
     h = hashlib.sha256()
-    for name in ("fsnap_syrk.hip", "fsnap_device_common.h"):
+    main = "fsnap_syrk_quad.hip" if kernel_name.startswith("fsnap_syrk_quad") else "fsnap_syrk.hip"
+    for name in (main, "fsnap_device_common.h"):
         with open(os.path.join(ROOT, "fitsnap_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
@@ -239,7 +241,7 @@ def recorded_traffic(m, Kc, info, kernel_name):
     if isinstance(recs, dict):
         recs = [recs]
     want = {"rows": m, "K": Kc, "kernel": kernel_name, "workgroups": info["workgroups"], "threads": info["threads"],
-            "chunks_per_wave": info["chunks_per_wave"], "source_sha256": kernel_source_digest()}
+            "chunks_per_wave": info["chunks_per_wave"], "source_sha256": kernel_source_digest(kernel_name)}
     shapes = ", ".join(f"{r.get('rows')} x {r.get('K')}" for r in recs)
     why = f"profiles/pmc_traffic.json was recorded for {shapes}, this run has {m} x {Kc}"
     for rec in recs:

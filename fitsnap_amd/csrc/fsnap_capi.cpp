@@ -70,18 +70,19 @@ constexpr int64_t QUAD_MIN_CPG = 24;        // fewest 4-row chunks per workgroup
 // chunks per workgroup of kernel 1Q for this context's rows, 0 = kernel 1Q does not take them
 int64_t quad_chunks_per_wg(const fsnap_ctx* ctx, int64_t* nblocks_out) {
     const bool default_kernel = ctx->opt_kernel == 0 || ctx->opt_kernel == 7;
-    if (!ctx->opt_quad || !default_kernel || ctx->opt_tiled || ctx->wpack_override || !ctx->opt_fused_pack) return 0;
+    if (!ctx->opt_quad || !default_kernel || ctx->opt_tiled) return 0;
     if (ctx->K <= 144 || ctx->K > 256 || ctx->K <= ctx->opt_acc_max_k) return 0;
     const int64_t min_rows = ctx->opt_quad_min_rows >= 0 ? ctx->opt_quad_min_rows : QUAD_MIN_ROWS;
     if (ctx->m < min_rows || ctx->m < 4) return 0;
     const int64_t nchunks = (ctx->m + 3) / 4;
     int64_t nblocks = ctx->opt_nblocks > 0 ? ctx->opt_nblocks : (int64_t)ctx->num_cu;
-    const int64_t max_blocks = (nchunks + QUAD_MIN_CPG - 1) / QUAD_MIN_CPG;
+    const int64_t min_cpg = ctx->opt_quad_min_cpg > 0 ? ctx->opt_quad_min_cpg : QUAD_MIN_CPG;
+    const int64_t max_blocks = (nchunks + min_cpg - 1) / min_cpg;
     if (nblocks > max_blocks) nblocks = max_blocks;
     if (nblocks < 1) nblocks = 1;
     const int64_t cpg = (nchunks + nblocks - 1) / nblocks;
     const int64_t off_limit = (int64_t)0xFFF00000;
-    if (cpg > fsnap::syrk_quad_max_cpg() || cpg > off_limit / (ctx->lda * 32)) return 0;    // pairs beyond the LDS / 32-bit offsets: tiled kernel
+    if (cpg > off_limit / (ctx->lda * 32)) return 0;    // a workgroup's rows beyond 32-bit buffer offsets: tiled kernel
     nblocks = (nchunks + cpg - 1) / cpg;
     if (nblocks_out) *nblocks_out = nblocks;
     return cpg;
@@ -114,7 +115,8 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
         g->split = 1;
         g->threads = 256;
         g->quad = true;
-        g->fused_pack = true;
+        // fused packing: the workgroup's per-row pairs must fit the LDS; the row-space passes bring pairs of their own
+        g->fused_pack = ctx->opt_fused_pack && !ctx->wpack_override && cpg <= fsnap::syrk_quad_max_cpg();
         return FSNAP_OK;
     }
     if (g->NB >= 6 && (ctx->opt_kernel == 7 || ctx->opt_kernel == 0)) {
@@ -610,7 +612,7 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
     const double* spart_src = a.spart;
     if ((g.acc || g.packed || g.quad) && g.fused_pack) {
         a.fused_pack = true;          // b, w, mask -> pairs in LDS + the b-only scalars per row-wave, inside the SYRK launch
-    } else if (g.acc || g.packed) {
+    } else if (g.acc || g.packed || g.quad) {
         int npk = 0;
         if ((rc = ensure_wpack(ctx, &npk))) return rc;
         a.wpack = ctx->wpack_override ? ctx->wpack_override : (const double*)ctx->wpack.p;
@@ -856,6 +858,9 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
     } else if (!strcmp(key, "quad")) {
         if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "quad must be 0 or 1");
         ctx->opt_quad = (int)value;
+    } else if (!strcmp(key, "quad_min_cpg")) {
+        if (value < 0 || value > 4096) return ctx->fail(FSNAP_E_ARG, "quad_min_cpg out of range");
+        ctx->opt_quad_min_cpg = (int)value;
     } else if (!strcmp(key, "quad_min_rows")) {
         if (value < -1) return ctx->fail(FSNAP_E_ARG, "quad_min_rows must be >= -1");
         ctx->opt_quad_min_rows = value;

@@ -18,7 +18,9 @@
 // can overwrite V[j] as soon as the last tile row p <= j of this wave has been issued (kernel 1A's single operand
 // set).  c = (wA)^T (wb) rides along on the VALU, its column blocks dealt to the waves that hold them, fewest
 // multiplies first.  The per-row pairs (w_eff, w_eff b) of the workgroup's rows are formed in LDS by the prologue
-// (all 256 threads), like kernel 1A with fused packing; the b-only scalars leave from there.
+// (all 256 threads), like kernel 1A with fused packing; the b-only scalars leave from there.  PACK = false reads
+// the pairs from HBM instead (fsnap_pack_weights_k, or the pairs a row-space pass brings; workgroups whose rows'
+// pairs do not fit the LDS).
 // Partials: part[workgroup][NT][4][64] -- every tile written by the one wave that owns it, no fold --,
 // cpart[workgroup * 4 + wave][NB][16] (zeros for the blocks another wave owns), spart[workgroup * 4 + wave][4]:
 // the layout of kernel 1A, reduced by the same kernel 2b.  No floating-point atomics; bit-identical run to run.
@@ -181,11 +183,21 @@ struct QuadRaw {
 };
 
 struct QuadBufs {
-    __amdgpu_buffer_rsrc_t A;
+    __amdgpu_buffer_rsrc_t A, wp;
     unsigned voffA;        // (kr * lda + 2 e) * 8 + 256 PR0
     unsigned voffT;        // (kr * lda + 16 (NB - 1) + e) * 8
+    unsigned voffP;        // kr * 16 (pairs in HBM)
     unsigned chunk_bytes;  // 4 * lda * 8
 };
+
+// The pair (w_eff, w_eff b) of the lane's row of chunk cl.  PACK: from the workgroup's LDS region, filled by the
+// prologue (lpk = region + 2 kr doubles).  Otherwise from the wpack array in HBM (fsnap_pack_weights_k, or the
+// per-row pairs of a row-space pass) through a bounds-checked descriptor: chunks past the range read (0, 0).
+template <bool PACK>
+__device__ __forceinline__ u4 quad_pair(const QuadBufs& wb, const double* lpk, unsigned cl) {
+    if constexpr (PACK) return __builtin_bit_cast(u4, *reinterpret_cast<const d2*>(lpk + (size_t)cl * 8));
+    else return __builtin_amdgcn_raw_buffer_load_b128(wb.wp, wb.voffP, cl * 64u, 0);
+}
 
 __device__ __forceinline__ bool quad_keep(const u4& wp) {
     return ((wp[0] | (wp[1] & 0x7FFFFFFFu)) != 0u);      // w_eff != +-0
@@ -222,13 +234,17 @@ __device__ __forceinline__ double quad_weighted(const QuadRaw<NB, PR0>& r, doubl
     }
 }
 
+#ifndef FSNAP_QUAD_SYNC
+#define FSNAP_QUAD_SYNC 1
+#endif
+constexpr bool QUAD_SYNC = FSNAP_QUAD_SYNC != 0;
 constexpr int QUAD_LDS_DOUBLES = 20480;   // all 160 KiB of the CU: the per-row pairs of the workgroup's rows
 constexpr int QUAD_PACK_PAD = 12;         // chunk slots the unrolled loop may look past the last chunk (<= ncl + 9)
 
 // One step: the MFMAs of the chunk held in V, with the preparation of the next chunk (raw set RN, pair PW) in
 // between: the refill of the raw set consumed a step ago (rows of chunk cl_fill, gated by PKEEP) goes out one load
 // per MFMA at the start of the step; V[j] takes the next chunk as soon as the wave's last tile row <= j is issued.
-template <int NB, int W, bool FULLK, int NV>
+template <int NB, int W, bool FULLK, bool PACK, int NV>
 __device__ __forceinline__ void quad_step(double (&V)[NB], d4 (&vt)[NV], QuadRaw<NB, (QuadPlanOf<NB, W>::P.jmin >> 1)>& RF,
                                           const QuadRaw<NB, (QuadPlanOf<NB, W>::P.jmin >> 1)>& RN, const QuadBufs& wb,
                                           const double* lpk, unsigned cl_fill, int K, int e, double (&cacc)[NB], const u4& PW,
@@ -241,7 +257,7 @@ __device__ __forceinline__ void quad_step(double (&V)[NB], d4 (&vt)[NV], QuadRaw
     const bool keep = quad_keep(PKEEP);
     const unsigned va = keep ? wb.voffA : QUAD_OOB_VOFF;
     const unsigned vtl = (NB & 1) ? (keep ? wb.voffT : QUAD_OOB_VOFF) : 0u;
-    PLOAD = __builtin_bit_cast(u4, *reinterpret_cast<const d2*>(lpk + (size_t)(cl_fill + 2) * 8));
+    PLOAD = quad_pair<PACK>(wb, lpk, cl_fill + 2);      // before the row loads: vmcnt retires in order
     __builtin_amdgcn_sched_barrier(0);
     quad_for<PL::P.n>([&](auto ic) {
         constexpr int I = decltype(ic)::value;
@@ -263,9 +279,10 @@ __device__ __forceinline__ void quad_step(double (&V)[NB], d4 (&vt)[NV], QuadRaw
     });
 }
 
-template <int NB, int W, bool FULLK>
-__device__ __forceinline__ void quad_wave(const double* __restrict__ A, int64_t lda, int K, int64_t row0, int64_t nrow, unsigned ncl,
-                                          const double* lpk, double* __restrict__ pw, double* __restrict__ cw, int lane) {
+template <int NB, int W, bool FULLK, bool PACK>
+__device__ __forceinline__ void quad_wave(const double* __restrict__ A, int64_t lda, const double* __restrict__ wpack, int K,
+                                          int64_t row0, int64_t nrow, unsigned ncl, const double* lpk, double* __restrict__ pw,
+                                          double* __restrict__ cw, int lane) {
     using PL = QuadPlanOf<NB, W>;
     constexpr int JMIN = PL::P.jmin, NTW = PL::P.n;
     constexpr int PR0 = JMIN >> 1;
@@ -274,10 +291,12 @@ __device__ __forceinline__ void quad_wave(const double* __restrict__ A, int64_t 
     const int e = lane & 15, kr = lane >> 4;
     QuadBufs wb;
     wb.A = quad_rsrc(A + row0 * lda, (unsigned)(nrow * lda * 8 + (nrow ? 16 : 0)));
+    wb.wp = quad_rsrc(PACK ? nullptr : wpack + 2 * row0, PACK ? 0u : (unsigned)(nrow * 16));
+    wb.voffP = (unsigned)(kr * 16);
     wb.voffA = (unsigned)((kr * lda + 2 * e) * 8) + 256u * PR0;
     wb.voffT = (unsigned)((kr * lda + 16 * (NB - 1) + e) * 8);
     wb.chunk_bytes = (unsigned)(lda * 32);
-    lpk += 2 * kr;
+    if (PACK) lpk += 2 * kr;
 
     d4 vt[NV];
 #pragma unroll
@@ -288,7 +307,7 @@ __device__ __forceinline__ void quad_wave(const double* __restrict__ A, int64_t 
         cacc[p] = 0.0;
         V[p] = 0.0;
     }
-    auto pair_of = [&](unsigned cl) { return __builtin_bit_cast(u4, *reinterpret_cast<const d2*>(lpk + (size_t)cl * 8)); };
+    auto pair_of = [&](unsigned cl) { return quad_pair<PACK>(wb, lpk, cl); };
     if (ncl > 0) {
         Raw r0, r1, r2;
         u4 pk0 = pair_of(0), pk1 = pair_of(1), pk2 = pair_of(2);
@@ -311,17 +330,22 @@ __device__ __forceinline__ void quad_wave(const double* __restrict__ A, int64_t 
         (void)pk0;
         unsigned cl = 0;
         for (; cl + 3 < ncl; cl += 6) {
-            quad_step<NB, W, FULLK>(V, vt, r0, r1, wb, lpk, cl + 3, K, e, cacc, pk1, pk3, pk5);
-            quad_step<NB, W, FULLK>(V, vt, r1, r2, wb, lpk, cl + 4, K, e, cacc, pk2, pk4, pk0);
-            quad_step<NB, W, FULLK>(V, vt, r2, r0, wb, lpk, cl + 5, K, e, cacc, pk3, pk5, pk1);
-            quad_step<NB, W, FULLK>(V, vt, r0, r1, wb, lpk, cl + 6, K, e, cacc, pk4, pk0, pk2);
-            quad_step<NB, W, FULLK>(V, vt, r1, r2, wb, lpk, cl + 7, K, e, cacc, pk5, pk1, pk3);
-            quad_step<NB, W, FULLK>(V, vt, r2, r0, wb, lpk, cl + 8, K, e, cacc, pk0, pk2, pk4);
+            quad_step<NB, W, FULLK, PACK>(V, vt, r0, r1, wb, lpk, cl + 3, K, e, cacc, pk1, pk3, pk5);
+            quad_step<NB, W, FULLK, PACK>(V, vt, r1, r2, wb, lpk, cl + 4, K, e, cacc, pk2, pk4, pk0);
+            quad_step<NB, W, FULLK, PACK>(V, vt, r2, r0, wb, lpk, cl + 5, K, e, cacc, pk3, pk5, pk1);
+            quad_step<NB, W, FULLK, PACK>(V, vt, r0, r1, wb, lpk, cl + 6, K, e, cacc, pk4, pk0, pk2);
+            quad_step<NB, W, FULLK, PACK>(V, vt, r1, r2, wb, lpk, cl + 7, K, e, cacc, pk5, pk1, pk3);
+            quad_step<NB, W, FULLK, PACK>(V, vt, r2, r0, wb, lpk, cl + 8, K, e, cacc, pk0, pk2, pk4);
+            // keep the four waves on the same rows: their tile counts differ by up to two (NB = 11: 17 / 17 / 17 / 15), and a
+            // wave that runs ahead by more than its share of the L2 (4 MiB for the 32 workgroups of an XCD) makes the other
+            // three fetch the rows again -- 1 772 880 x 168: 1.5 x the algorithmic bytes past the L2 without this, 1.0 x with
+            // it.  A bare s_barrier: no wait for the loads in flight; every wave runs the same number of trips.
+            if (QUAD_SYNC) __builtin_amdgcn_s_barrier();
         }
         if (cl < ncl) {
-            quad_step<NB, W, FULLK>(V, vt, r0, r1, wb, lpk, cl + 3, K, e, cacc, pk1, pk3, pk5);
-            quad_step<NB, W, FULLK>(V, vt, r1, r2, wb, lpk, cl + 4, K, e, cacc, pk2, pk4, pk0);
-            quad_step<NB, W, FULLK>(V, vt, r2, r0, wb, lpk, cl + 5, K, e, cacc, pk3, pk5, pk1);
+            quad_step<NB, W, FULLK, PACK>(V, vt, r0, r1, wb, lpk, cl + 3, K, e, cacc, pk1, pk3, pk5);
+            quad_step<NB, W, FULLK, PACK>(V, vt, r1, r2, wb, lpk, cl + 4, K, e, cacc, pk2, pk4, pk0);
+            quad_step<NB, W, FULLK, PACK>(V, vt, r2, r0, wb, lpk, cl + 5, K, e, cacc, pk3, pk5, pk1);
         }
     }
     // the last MFMAs (16 passes) must have left the pipe before their accumulators are read
@@ -351,13 +375,13 @@ __device__ __forceinline__ void quad_wave(const double* __restrict__ A, int64_t 
 
 }  // namespace
 
-template <int NB, bool FULLK>
+template <int NB, bool FULLK, bool PACK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void
-fsnap_syrk_quad(const double* __restrict__ A, int64_t lda, int64_t m, int K, int64_t chunks_per_wg, double* __restrict__ part,
-                double* __restrict__ cpart, const double* __restrict__ bvec, const double* __restrict__ wvec,
-                const unsigned char* __restrict__ mask, double* __restrict__ spart) {
+fsnap_syrk_quad(const double* __restrict__ A, int64_t lda, const double* __restrict__ wpack, int64_t m, int K, int64_t chunks_per_wg,
+                double* __restrict__ part, double* __restrict__ cpart, const double* __restrict__ bvec,
+                const double* __restrict__ wvec, const unsigned char* __restrict__ mask, double* __restrict__ spart) {
     constexpr int NTILE = NB * (NB + 1) / 2;
-    __shared__ __attribute__((aligned(16))) double lds[QUAD_LDS_DOUBLES];
+    __shared__ __attribute__((aligned(16))) double lds[PACK ? QUAD_LDS_DOUBLES : 2];
     const int lane = threadIdx.x & 63;
     const int rw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t nchunks = (m + 3) >> 2;
@@ -374,7 +398,7 @@ fsnap_syrk_quad(const double* __restrict__ A, int64_t lda, int64_t m, int K, int
     // prologue: (w_eff, w_eff b) of the workgroup's rows -> LDS, thread t takes rows t, t + 256, ... (bounds-checked
     // loads: rows past the range read zeros and become (0, 0) pairs, what the loop's look-ahead expects); the
     // b-only scalars of a wave's share leave as that wave's partial
-    {
+    if constexpr (PACK) {
         const unsigned wg_rows = (unsigned)chunks_per_wg * 4u;
         const unsigned region_rows = wg_rows + QUAD_PACK_PAD * 4u;
         const __amdgpu_buffer_rsrc_t rb = quad_rsrc(bvec + row0, (unsigned)(nrow * 8));
@@ -422,8 +446,8 @@ fsnap_syrk_quad(const double* __restrict__ A, int64_t lda, int64_t m, int K, int
             so[2] = cnt;
             so[3] = 0.0;
         }
+        __syncthreads();
     }
-    __syncthreads();
 
     // the compiler must count a[0:255] as used (register allocation granule of the kernel descriptor)
     asm volatile("" : : : "a0", "a255");
@@ -431,10 +455,10 @@ fsnap_syrk_quad(const double* __restrict__ A, int64_t lda, int64_t m, int K, int
     double* pw = part + (int64_t)blockIdx.x * (int64_t)(NTILE * 256);
     double* cw = cpart + ((int64_t)blockIdx.x * 4 + rw) * (int64_t)(NB * 16);
     switch (rw) {
-        case 0: quad_wave<NB, 0, FULLK>(A, lda, K, row0, nrow, ncl, lds, pw, cw, lane); break;
-        case 1: quad_wave<NB, 1, FULLK>(A, lda, K, row0, nrow, ncl, lds, pw, cw, lane); break;
-        case 2: quad_wave<NB, 2, FULLK>(A, lda, K, row0, nrow, ncl, lds, pw, cw, lane); break;
-        default: quad_wave<NB, 3, FULLK>(A, lda, K, row0, nrow, ncl, lds, pw, cw, lane); break;
+        case 0: quad_wave<NB, 0, FULLK, PACK>(A, lda, wpack, K, row0, nrow, ncl, lds, pw, cw, lane); break;
+        case 1: quad_wave<NB, 1, FULLK, PACK>(A, lda, wpack, K, row0, nrow, ncl, lds, pw, cw, lane); break;
+        case 2: quad_wave<NB, 2, FULLK, PACK>(A, lda, wpack, K, row0, nrow, ncl, lds, pw, cw, lane); break;
+        default: quad_wave<NB, 3, FULLK, PACK>(A, lda, wpack, K, row0, nrow, ncl, lds, pw, cw, lane); break;
     }
 }
 
@@ -446,17 +470,24 @@ int64_t syrk_quad_max_cpg() { return QUAD_LDS_DOUBLES / 8 - QUAD_PACK_PAD; }
 template <int NB>
 static hipError_t launch_syrk_quad_nb(const SyrkArgs& a, hipStream_t st) {
     dim3 grid((unsigned)a.nblocks), block(256);
-    if (!a.b || !a.w || !a.mask || !a.spart || a.chunks_per_wave > syrk_quad_max_cpg()) return hipErrorInvalidValue;
-    if (a.K == 16 * NB)
-        hipLaunchKernelGGL((fsnap_syrk_quad<NB, true>), grid, block, 0, st, a.A, a.lda, a.m, a.K, a.chunks_per_wave, a.part, a.cpart,
-                           a.b, a.w, a.mask, a.spart);
-    else
-        hipLaunchKernelGGL((fsnap_syrk_quad<NB, false>), grid, block, 0, st, a.A, a.lda, a.m, a.K, a.chunks_per_wave, a.part, a.cpart,
-                           a.b, a.w, a.mask, a.spart);
+    if (a.fused_pack ? (!a.b || !a.w || !a.mask || !a.spart || a.chunks_per_wave > syrk_quad_max_cpg()) : !a.wpack)
+        return hipErrorInvalidValue;
+#define FSNAP_LAUNCH(FK, PK)                                                                                                   \
+    hipLaunchKernelGGL((fsnap_syrk_quad<NB, FK, PK>), grid, block, 0, st, a.A, a.lda, a.wpack, a.m, a.K, a.chunks_per_wave, a.part, \
+                       a.cpart, a.b, a.w, a.mask, a.spart)
+    if (a.K == 16 * NB) {
+        if (a.fused_pack) FSNAP_LAUNCH(true, true);
+        else FSNAP_LAUNCH(true, false);
+    } else {
+        if (a.fused_pack) FSNAP_LAUNCH(false, true);
+        else FSNAP_LAUNCH(false, false);
+    }
+#undef FSNAP_LAUNCH
     return hipGetLastError();
 }
 
-// kernel 1Q: a.nblocks workgroups, a.chunks_per_wave = 4-row chunks per WORKGROUP (its four waves sweep the same rows)
+// kernel 1Q: a.nblocks workgroups, a.chunks_per_wave = 4-row chunks per WORKGROUP (its four waves sweep the same rows);
+// a.fused_pack: the kernel forms the per-row pairs itself (b, w, mask, spart), otherwise it reads a.wpack
 hipError_t launch_syrk_quad(const SyrkArgs& a, hipStream_t st) {
     switch ((a.K + 15) / 16) {
         case 10: return launch_syrk_quad_nb<10>(a, st);

@@ -42,7 +42,7 @@ def main(pmc_dir, bench_json, append=False):
         "dispatches": [len(vals["FETCH_SIZE"]), len(vals["WRITE_SIZE"])],
         "rows": rec["roofline"]["rows_per_launch"], "K": rec["config"]["K"], "kernel": kernel,
         "workgroups": launch["workgroups"], "threads": launch["threads"], "chunks_per_wave": launch["chunks_per_wave"],
-        "source_sha256": kernel_source_digest(),
+        "source_sha256": kernel_source_digest(kernel),
         "algorithmic_bytes_per_launch": rec["roofline"]["algorithmic_bytes_per_launch"],
         "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py, kernel {kernel}: "
                   "(FETCH_SIZE x 2 [gfx950 half-count correction] + WRITE_SIZE) x 1024",

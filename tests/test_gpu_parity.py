@@ -162,6 +162,29 @@ def test_quad_kernel_agrees_with_the_tiled_kernel_and_the_oracle(ctx, K):
     stats_close(*ctx.download_packed(total.data_ptr(), K), *ref, tol=2e-12)
 
 
+@pytest.mark.parametrize("K", [150, 176, 256])
+def test_quad_kernel_on_pairs_packed_in_hbm_gives_the_bits_of_the_fused_form(qctx, K):
+    # option fused_pack = 0: fsnap_pack_weights_k writes the per-row pairs to HBM and kernel 1Q reads them from there (what a
+    # workgroup does whose rows' pairs do not fit the LDS, and what the row-space passes do with pairs of their own): the same
+    # pairs, the same arithmetic in the same order -> identical G and c
+    rng = np.random.default_rng(300 + K)
+    m = 30011
+    A = rng.standard_normal((m, K))
+    b = rng.standard_normal(m)
+    w = rng.uniform(0.1, 3.0, m)
+    t = rng.random(m) < 0.3
+    fused = run_stats(qctx, A, b, w, t)
+    assert qctx.launch_info()["kernel_or_pairs"] == 5 and qctx.launch_info()["fused_pack"] == 1
+    qctx.set_option("fused_pack", 0)
+    try:
+        plain = qctx.normal_eq()
+        assert qctx.launch_info()["kernel_or_pairs"] == 5 and qctx.launch_info()["fused_pack"] == 0
+    finally:
+        qctx.set_option("fused_pack", 1)
+    assert np.array_equal(fused[0], plain[0]) and np.array_equal(fused[1], plain[1])
+    stats_close(*plain, *orc.normal_eq(A, b, w, t))
+
+
 def test_quad_kernel_fit_matches_the_oracle_solve(ctx):
     # the whole fit at the three-element SNAP width: statistics from kernel 1Q, host mirror written by the reduction, host solve
     A, b, w = orc.synth_problem(80000, 168)
