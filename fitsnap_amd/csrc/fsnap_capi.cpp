@@ -59,11 +59,11 @@ struct Geometry {
     bool acc;       // kernel 1A: whole triangle in one wave (accumulation registers), one wave per SIMD
     bool packed;    // kernel 1P: kernel 1 on packed weights (K <= 80)
     bool fused_pack = false;   // kernel 1A packs (w_eff, w_eff b) of its rows into LDS itself: no fsnap_pack_weights_k launch
-    bool quad = false;         // kernel 1Q: the triangle dealt to the four waves of a workgroup (144 < K <= 256); cpw = chunks per workgroup
+    bool quad = false;         // kernel 1Q: the triangle dealt to the four waves of a workgroup (144 < K <= 288); cpw = chunks per workgroup
 };
 
-// rows below which the tiled kernel keeps 145 ... 256 columns: kernel 1Q writes one partial triangle per workgroup
-// (2 KiB x 55 ... 136 tiles), which short systems do not amortise
+// rows below which the tiled kernel keeps 145 ... 288 columns: kernel 1Q writes one partial triangle per workgroup
+// (2 KiB x 55 ... 171 tiles), which short systems do not amortise
 constexpr int64_t QUAD_MIN_ROWS = 8192;
 constexpr int64_t QUAD_MIN_CPG = 24;        // fewest 4-row chunks per workgroup before the grid shrinks
 
@@ -71,7 +71,7 @@ constexpr int64_t QUAD_MIN_CPG = 24;        // fewest 4-row chunks per workgroup
 int64_t quad_chunks_per_wg(const fsnap_ctx* ctx, int64_t* nblocks_out) {
     const bool default_kernel = ctx->opt_kernel == 0 || ctx->opt_kernel == 7;
     if (!ctx->opt_quad || !default_kernel || ctx->opt_tiled) return 0;
-    if (ctx->K <= 144 || ctx->K > 256 || ctx->K <= ctx->opt_acc_max_k) return 0;
+    if (ctx->K <= 144 || ctx->K > 288 || ctx->K <= ctx->opt_acc_max_k) return 0;
     const int64_t min_rows = ctx->opt_quad_min_rows >= 0 ? ctx->opt_quad_min_rows : QUAD_MIN_ROWS;
     if (ctx->m < min_rows || ctx->m < 4) return 0;
     const int64_t nchunks = (ctx->m + 3) / 4;

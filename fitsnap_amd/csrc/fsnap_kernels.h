@@ -58,7 +58,7 @@ hipError_t launch_syrk(const SyrkArgs& a, hipStream_t st);
 hipError_t launch_syrk_wave_p(const SyrkArgs& a, hipStream_t st);   // K <= 80, packed weights (a.wpack)
 hipError_t launch_syrk_lds(const SyrkArgs& a, hipStream_t st);
 hipError_t launch_syrk_acc(const SyrkArgs& a, hipStream_t st);
-// kernel 1Q (144 < K <= 256, fsnap_syrk_quad.hip): a.chunks_per_wave = chunks per WORKGROUP; pairs from a.wpack or (a.fused_pack,
+// kernel 1Q (144 < K <= 288, fsnap_syrk_quad.hip): a.chunks_per_wave = chunks per WORKGROUP; pairs from a.wpack or (a.fused_pack,
 // chunks per workgroup <= syrk_quad_max_cpg()) formed by the kernel
 hipError_t launch_syrk_quad(const SyrkArgs& a, hipStream_t st);
 int64_t syrk_quad_max_cpg();

@@ -1,20 +1,20 @@
-// fsnap_syrk_quad.hip — kernel 1Q: fused mask x weight x SYRK for 144 < K <= 256 (gfx950 only).
+// fsnap_syrk_quad.hip — kernel 1Q: fused mask x weight x SYRK for 144 < K <= 288 (gfx950 only).
 //
 // The statistics of the linear fit, G = (wA)^T (wA), c = (wA)^T (wb) and the three scalars
 // (fitsnap3lib/solvers/ridge.py:40-49, svd.py:35-54 after the transpose trick), for the widths between kernel 1A
 // (one wave holds the whole tile triangle: NB <= 9 column blocks) and the widths where the tiled kernel 1T has
-// enough equal work items (K >~ 300): three-element SNAP (168), four-element SNAP (220 + offsets), short ACE bases.
+// enough equal work items (K >~ 300): three- / four- / five-element SNAP (168, 220 + offsets, 275), short ACE bases.
 //
-// Kernel 1A's plan with the triangle DEALT TO THE FOUR WAVES OF A WORKGROUP: NB = 10 ... 16 column blocks are 55 ...
-// 136 accumulator tiles, 14 ... 34 per wave (32 in the accumulation registers a[0:255], up to two more in VGPRs).
+// Kernel 1A's plan with the triangle DEALT TO THE FOUR WAVES OF A WORKGROUP: NB = 10 ... 18 column blocks are 55 ...
+// 171 accumulator tiles, 14 ... 43 per wave (32 in the accumulation registers a[0:255], up to eleven more in VGPRs).
 // The four waves sweep the SAME rows -- the workgroup's contiguous row range -- each with its own loads: a wave
 // reads the column blocks its tile rows touch (all of them for the wave that owns tile row 0) straight into
-// MFMA-fragment registers, three chunks ahead, exactly like kernel 1A; the first wave to ask brings a row in from
-// HBM, the other three find it in L2 / L1 (the workgroup lives on one CU).  No LDS traffic and no barrier in the
-// loop, one wave per SIMD.  HBM sees every row once; the L1 sees it up to four times: 32 KiB per 4-row chunk and
-// 1300 ... 2200 cycles of matrix pipe at K = 256.
+// MFMA-fragment registers, three chunks ahead (two from 17 blocks on), like kernel 1A; the first wave to ask brings
+// a row in from HBM, the other three are merged with it in the L1 or find the row in L2 (the workgroup lives on one
+// CU).  No LDS traffic for the rows, one wave per SIMD; one bare s_barrier per six-chunk trip keeps the four waves
+// on the same rows.  HBM sees every row once: 32 KiB per 4-row chunk and 2200 cycles of matrix pipe at K = 256.
 // Whole tile ROWS (tiles (p, p .. NB-1), A operand block p) are dealt so that the four tile counts differ by at
-// most one (quad_rows below); inside a wave the rows run in ascending order, so column block j of the NEXT chunk
+// most two (QUAD_ROWS below); inside a wave the rows run in ascending order, so column block j of the NEXT chunk
 // can overwrite V[j] as soon as the last tile row p <= j of this wave has been issued (kernel 1A's single operand
 // set).  c = (wA)^T (wb) rides along on the VALU, its column blocks dealt to the waves that hold them, fewest
 // multiplies first.  The per-row pairs (w_eff, w_eff b) of the workgroup's rows are formed in LDS by the prologue
@@ -35,7 +35,7 @@ __host__ __device__ constexpr int quad_tri_index(int p, int q, int NB) { return 
 
 // tile rows of wave w for NB column blocks (-1 ends the list): the lengths NB - p of a wave's rows add up to
 // ceil or floor of NB (NB + 1) / 8 -- checked by the static_asserts below
-constexpr int QUAD_ROWS[7][4][7] = {
+constexpr int QUAD_ROWS[9][4][9] = {
     /* NB = 10: 14 14 14 13 */ {{0, 6, -1}, {1, 5, -1}, {2, 4, -1}, {3, 7, 8, 9, -1}},
     /* NB = 11: 17 17 17 15 */ {{0, 5, -1}, {1, 4, -1}, {2, 3, -1}, {6, 7, 8, 9, 10, -1}},
     /* NB = 12: 20 20 20 18 */ {{0, 4, -1}, {1, 3, -1}, {2, 5, 9, -1}, {6, 7, 8, 10, 11, -1}},
@@ -43,26 +43,29 @@ constexpr int QUAD_ROWS[7][4][7] = {
     /* NB = 14: 27 26 26 26 */ {{0, 1, -1}, {2, 3, 11, -1}, {4, 5, 7, -1}, {6, 8, 9, 10, 12, 13, -1}},
     /* NB = 15: 30 30 30 30 */ {{0, 1, 14, -1}, {2, 3, 10, -1}, {4, 5, 6, -1}, {7, 8, 9, 11, 12, 13, -1}},
     /* NB = 16: 34 34 34 34 */ {{0, 1, 13, -1}, {2, 3, 9, -1}, {4, 5, 6, 15, -1}, {7, 8, 10, 11, 12, 14, -1}},
+    /* NB = 17: 38 38 38 39 */ {{0, 1, 12, -1}, {2, 3, 8, -1}, {4, 5, 6, 15, -1}, {7, 9, 10, 11, 13, 14, 16, -1}},
+    /* NB = 18: 43 43 43 42 */ {{0, 1, 10, -1}, {2, 3, 6, -1}, {4, 5, 7, 13, -1}, {8, 9, 11, 12, 14, 15, 16, 17, -1}},
 };
 
-constexpr int QUAD_MAXT = 34;
+constexpr int QUAD_MAXT = 43;
+constexpr int QUAD_MAXNB = 18;
 
 struct QuadPlan {
     int n;                  // tiles of this wave
     int jmin;               // first column block it reads
     int tp[QUAD_MAXT], tq[QUAD_MAXT];
     int rf_lo[QUAD_MAXT], rf_hi[QUAD_MAXT];   // after tile i: refresh V[rf_lo .. rf_hi) with the next chunk (empty unless i ends a tile row)
-    int cown[16];           // 1 = this wave accumulates c for column block j
+    int cown[QUAD_MAXNB];   // 1 = this wave accumulates c for column block j
 };
 
 constexpr QuadPlan quad_plan(int NB, int w) {
     QuadPlan P{};
-    const int(&rows)[7] = QUAD_ROWS[NB - 10][w];
+    const int(&rows)[9] = QUAD_ROWS[NB - 10][w];
     int n = 0;
     P.jmin = rows[0];
-    for (int i = 0; i < 7 && rows[i] >= 0; ++i) {
+    for (int i = 0; i < 9 && rows[i] >= 0; ++i) {
         const int p = rows[i];
-        const int pnext = (i + 1 < 7 && rows[i + 1] >= 0) ? rows[i + 1] : NB;
+        const int pnext = (i + 1 < 9 && rows[i + 1] >= 0) ? rows[i + 1] : NB;
         for (int q = p; q < NB; ++q) {
             P.tp[n] = p;
             P.tq[n] = q;
@@ -92,7 +95,7 @@ constexpr QuadPlan quad_plan(int NB, int w) {
 }
 
 constexpr bool quad_plans_cover(int NB) {
-    int seen[16 * 17 / 2] = {};
+    int seen[QUAD_MAXNB * (QUAD_MAXNB + 1) / 2] = {};
     int mx = 0, mn = 1000;
     for (int w = 0; w < 4; ++w) {
         const QuadPlan P = quad_plan(NB, w);
@@ -108,7 +111,7 @@ constexpr bool quad_plans_cover(int NB) {
     return mx - mn <= 2;
 }
 static_assert(quad_plans_cover(10) && quad_plans_cover(11) && quad_plans_cover(12) && quad_plans_cover(13) &&
-                  quad_plans_cover(14) && quad_plans_cover(15) && quad_plans_cover(16),
+                  quad_plans_cover(14) && quad_plans_cover(15) && quad_plans_cover(16) && quad_plans_cover(17) && quad_plans_cover(18),
               "every tile of the triangle belongs to exactly one wave");
 
 template <int NB, int W>
@@ -309,11 +312,15 @@ __device__ __forceinline__ void quad_wave(const double* __restrict__ A, int64_t 
     }
     auto pair_of = [&](unsigned cl) { return quad_pair<PACK>(wb, lpk, cl); };
     if (ncl > 0) {
+        // raw sets in flight: three (kernel 1A's pipeline) up to 16 column blocks; two from 17 on, where the wave that owns tile
+        // row 0 holds 36 registers per set and up to 11 accumulator tiles in VGPRs -- a chunk is 2 500+ cycles of matrix pipe
+        // there, two of them cover the memory round trip
+        constexpr int DEPTH = NB >= 17 ? 2 : 3;
         Raw r0, r1, r2;
         u4 pk0 = pair_of(0), pk1 = pair_of(1), pk2 = pair_of(2);
         quad_issue_rows<NB, PR0>(r0, pk0, wb, 0);
         quad_issue_rows<NB, PR0>(r1, pk1, wb, 1);
-        quad_issue_rows<NB, PR0>(r2, pk2, wb, 2);
+        if constexpr (DEPTH == 3) quad_issue_rows<NB, PR0>(r2, pk2, wb, 2);
         {   // chunk 0 -> V
             const d2 wp0 = __builtin_bit_cast(d2, pk0);
             const double wv = wp0[0], wbv = wp0[1];
@@ -324,28 +331,46 @@ __device__ __forceinline__ void quad_wave(const double* __restrict__ A, int64_t 
                 if constexpr (OWN != 0) cacc[J] = __builtin_fma(V[J], wbv, cacc[J]);
             });
         }
-        // ring of pairs: slot (c mod 6) holds the pair of chunk c; a step uses c + 1 (weights), c + 3 (row mask of
-        // the refill) and loads c + 5 (kernel 1A's loop, fsnap_syrk.hip)
-        u4 pk3 = pair_of(3), pk4 = pair_of(4), pk5 = {0u, 0u, 0u, 0u};
+        // ring of pairs: slot (c mod 6) holds the pair of chunk c; a step uses c + 1 (weights), c + DEPTH (row mask of
+        // the refill) and loads c + DEPTH + 2 (kernel 1A's loop, fsnap_syrk.hip)
+        u4 pk3 = pair_of(3), pk4 = {0u, 0u, 0u, 0u}, pk5 = {0u, 0u, 0u, 0u};
+        if constexpr (DEPTH == 3) pk4 = pair_of(4);
         (void)pk0;
         unsigned cl = 0;
-        for (; cl + 3 < ncl; cl += 6) {
-            quad_step<NB, W, FULLK, PACK>(V, vt, r0, r1, wb, lpk, cl + 3, K, e, cacc, pk1, pk3, pk5);
-            quad_step<NB, W, FULLK, PACK>(V, vt, r1, r2, wb, lpk, cl + 4, K, e, cacc, pk2, pk4, pk0);
-            quad_step<NB, W, FULLK, PACK>(V, vt, r2, r0, wb, lpk, cl + 5, K, e, cacc, pk3, pk5, pk1);
-            quad_step<NB, W, FULLK, PACK>(V, vt, r0, r1, wb, lpk, cl + 6, K, e, cacc, pk4, pk0, pk2);
-            quad_step<NB, W, FULLK, PACK>(V, vt, r1, r2, wb, lpk, cl + 7, K, e, cacc, pk5, pk1, pk3);
-            quad_step<NB, W, FULLK, PACK>(V, vt, r2, r0, wb, lpk, cl + 8, K, e, cacc, pk0, pk2, pk4);
-            // keep the four waves on the same rows: their tile counts differ by up to two (NB = 11: 17 / 17 / 17 / 15), and a
-            // wave that runs ahead by more than its share of the L2 (4 MiB for the 32 workgroups of an XCD) makes the other
-            // three fetch the rows again -- 1 772 880 x 168: 1.5 x the algorithmic bytes past the L2 without this, 1.0 x with
-            // it.  A bare s_barrier: no wait for the loads in flight; every wave runs the same number of trips.
-            if (QUAD_SYNC) __builtin_amdgcn_s_barrier();
-        }
-        if (cl < ncl) {
-            quad_step<NB, W, FULLK, PACK>(V, vt, r0, r1, wb, lpk, cl + 3, K, e, cacc, pk1, pk3, pk5);
-            quad_step<NB, W, FULLK, PACK>(V, vt, r1, r2, wb, lpk, cl + 4, K, e, cacc, pk2, pk4, pk0);
-            quad_step<NB, W, FULLK, PACK>(V, vt, r2, r0, wb, lpk, cl + 5, K, e, cacc, pk3, pk5, pk1);
+        // keep the four waves on the same rows (the barrier at the end of a trip): their tile counts differ by up to two
+        // (NB = 11: 17 / 17 / 17 / 15), and a wave that runs ahead by more than its share of the L2 (4 MiB for the 32 workgroups
+        // of an XCD) makes the other three fetch the rows again -- 1 772 880 x 168: 1.5 x the algorithmic bytes past the L2
+        // without it, 1.0 x with it.  A bare s_barrier: no wait for the loads in flight; every wave runs the same number of trips.
+        if constexpr (DEPTH == 3) {
+            for (; cl + 3 < ncl; cl += 6) {
+                quad_step<NB, W, FULLK, PACK>(V, vt, r0, r1, wb, lpk, cl + 3, K, e, cacc, pk1, pk3, pk5);
+                quad_step<NB, W, FULLK, PACK>(V, vt, r1, r2, wb, lpk, cl + 4, K, e, cacc, pk2, pk4, pk0);
+                quad_step<NB, W, FULLK, PACK>(V, vt, r2, r0, wb, lpk, cl + 5, K, e, cacc, pk3, pk5, pk1);
+                quad_step<NB, W, FULLK, PACK>(V, vt, r0, r1, wb, lpk, cl + 6, K, e, cacc, pk4, pk0, pk2);
+                quad_step<NB, W, FULLK, PACK>(V, vt, r1, r2, wb, lpk, cl + 7, K, e, cacc, pk5, pk1, pk3);
+                quad_step<NB, W, FULLK, PACK>(V, vt, r2, r0, wb, lpk, cl + 8, K, e, cacc, pk0, pk2, pk4);
+                if (QUAD_SYNC) __builtin_amdgcn_s_barrier();
+            }
+            if (cl < ncl) {
+                quad_step<NB, W, FULLK, PACK>(V, vt, r0, r1, wb, lpk, cl + 3, K, e, cacc, pk1, pk3, pk5);
+                quad_step<NB, W, FULLK, PACK>(V, vt, r1, r2, wb, lpk, cl + 4, K, e, cacc, pk2, pk4, pk0);
+                quad_step<NB, W, FULLK, PACK>(V, vt, r2, r0, wb, lpk, cl + 5, K, e, cacc, pk3, pk5, pk1);
+            }
+        } else {
+            for (; cl + 3 < ncl; cl += 6) {
+                quad_step<NB, W, FULLK, PACK>(V, vt, r0, r1, wb, lpk, cl + 2, K, e, cacc, pk1, pk2, pk4);
+                quad_step<NB, W, FULLK, PACK>(V, vt, r1, r0, wb, lpk, cl + 3, K, e, cacc, pk2, pk3, pk5);
+                quad_step<NB, W, FULLK, PACK>(V, vt, r0, r1, wb, lpk, cl + 4, K, e, cacc, pk3, pk4, pk0);
+                quad_step<NB, W, FULLK, PACK>(V, vt, r1, r0, wb, lpk, cl + 5, K, e, cacc, pk4, pk5, pk1);
+                quad_step<NB, W, FULLK, PACK>(V, vt, r0, r1, wb, lpk, cl + 6, K, e, cacc, pk5, pk0, pk2);
+                quad_step<NB, W, FULLK, PACK>(V, vt, r1, r0, wb, lpk, cl + 7, K, e, cacc, pk0, pk1, pk3);
+                if (QUAD_SYNC) __builtin_amdgcn_s_barrier();
+            }
+            if (cl < ncl) {
+                quad_step<NB, W, FULLK, PACK>(V, vt, r0, r1, wb, lpk, cl + 2, K, e, cacc, pk1, pk2, pk4);
+                quad_step<NB, W, FULLK, PACK>(V, vt, r1, r0, wb, lpk, cl + 3, K, e, cacc, pk2, pk3, pk5);
+                quad_step<NB, W, FULLK, PACK>(V, vt, r0, r1, wb, lpk, cl + 4, K, e, cacc, pk3, pk4, pk0);
+            }
         }
     }
     // the last MFMAs (16 passes) must have left the pipe before their accumulators are read
@@ -497,6 +522,8 @@ hipError_t launch_syrk_quad(const SyrkArgs& a, hipStream_t st) {
         case 14: return launch_syrk_quad_nb<14>(a, st);
         case 15: return launch_syrk_quad_nb<15>(a, st);
         case 16: return launch_syrk_quad_nb<16>(a, st);
+        case 17: return launch_syrk_quad_nb<17>(a, st);
+        case 18: return launch_syrk_quad_nb<18>(a, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -95,9 +95,10 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * the SYRK launch -- no packing launch, nothing of them in HBM -- whenever a workgroup's rows fit; 0 = separate packing kernel, A/B),
  * "acc_min_cpw" (tuning aid: fewest 4-row chunks per row-wave of the 80 < K <= 144 kernel before its grid shrinks below one workgroup
  * per CU; 0 = default 12 -- 6 ... 9 measured within noise of it on 13 035 x 142 and 15 213 x 128),
- * "quad" (0|1, default 1: 145 ... 256 columns go to kernel 1Q -- the tile triangle dealt to the four waves of a workgroup, which sweep
+ * "quad" (0|1, default 1: 145 ... 288 columns go to kernel 1Q -- the tile triangle dealt to the four waves of a workgroup, which sweep
  * the same rows, fsnap_syrk_quad.hip -- when the system has at least "quad_min_rows" rows (-1 = default 8192) and a workgroup's per-row
- * pairs fit the LDS (up to ~2.6 M rows); 0 = the tiled kernel there, A/B),
+ * pairs fit the LDS (up to ~2.6 M rows; beyond, the pairs are packed into HBM first); 0 = the tiled kernel there, A/B;
+ * "quad_min_cpg": fewest 4-row chunks per workgroup of that kernel before its grid shrinks, 0 = default 24, tuning aid),
  * "acc_max_k" (144 | 128: widest system on the accumulator-resident kernel; 128 sends 129 ... 144 columns to the tiled kernel, A/B),
  * "reduce" (0 = reduction kernel 2b with every load of a thread in flight, the default; 1 = its predecessor, A/B),
  * "mirror_upper" (0|1, default 1: the reduction writes the host mirror's triangle once per element, at its upper position),

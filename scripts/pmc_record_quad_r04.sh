@@ -1,5 +1,5 @@
 #!/bin/bash
-# Add the kernel-1Q shapes to profiles/pmc_traffic.json (records are tied to a digest of fsnap_syrk_quad.hip +
+# Add the kernel-1Q shapes (10^6 x 256, 1 772 880 x 168, 367 900 x 200, 10^6 x 275) to profiles/pmc_traffic.json (records are tied to a digest of fsnap_syrk_quad.hip +
 # fsnap_device_common.h): FETCH_SIZE / WRITE_SIZE passes + SQ / GRBM passes, bench lines of the same shapes.
 # Usage: gpurun -- 'bash scripts/pmc_record_quad_r04.sh'; then copy gpurun_out/r04_pmcq/pmc_traffic_record.json to profiles/pmc_traffic.json.
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -27,9 +27,10 @@ pmc_shape () {   # rows cols
 pmc_shape 1000000 256
 pmc_shape 1772880 168
 pmc_shape 367900 200
+pmc_shape 1000000 275
 cp profiles/pmc_traffic.json $O/pmc_traffic_record.json
 # bench lines with the record in place (traffic filled in), and two more widths
-for shape in "1000000 256" "1772880 168" "367900 200" "500000 224" "100000 192" "100000 168"; do
+for shape in "1000000 256" "1772880 168" "367900 200" "1000000 275" "367900 288" "1000000 264" "100000 272" "500000 224" "100000 192" "100000 168"; do
   set -- $shape
   timeout 300 python bench.py --rows $1 --cols $2 --steps 50 --warmup 5 --preheat 150 --no-cpu-baseline --svd-solver 0 --pipelined 0 > $O/bench_$1x$2.json 2>> $O/bench.err
 python - <<PY

@@ -84,9 +84,10 @@ def qctx(ctx):
 
 
 @pytest.mark.parametrize("K", [145, 150, 159, 160, 161, 168, 175, 176, 177, 191, 192, 193, 200, 207, 208, 209, 223, 224, 225,
-                               239, 240, 241, 255, 256])
+                               239, 240, 241, 255, 256, 257, 264, 272, 273, 275, 287, 288])
 def test_quad_kernel_statistics_all_column_block_shapes(qctx, K):
-    # NB = 10 ... 16: odd / even block counts, K a multiple of 16 (no column select) and not, the last block nearly empty
+    # NB = 10 ... 18: odd / even block counts, K a multiple of 16 (no column select) and not, the last block nearly empty;
+    # 17 and 18 blocks run the two-set load pipeline with up to 11 accumulator tiles in VGPRs
     rng = np.random.default_rng(K)
     m = 6151 + 11 * K                     # ragged: not a multiple of 4, uneven chunk ranges per workgroup
     A = rng.standard_normal((m, K)) * (10.0 ** rng.uniform(-3, 3, size=K))
@@ -100,7 +101,7 @@ def test_quad_kernel_statistics_all_column_block_shapes(qctx, K):
 
 
 @pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 7, 63, 64, 65, 257, 1023, 1025])
-@pytest.mark.parametrize("K", [168, 256])
+@pytest.mark.parametrize("K", [168, 256, 275])
 def test_quad_kernel_tiny_and_ragged_row_counts(qctx, m, K):
     rng = np.random.default_rng(1000 + m + K)
     A = rng.standard_normal((m, K))
@@ -133,7 +134,7 @@ def test_quad_kernel_never_fetches_masked_rows_and_pads(qctx):
     stats_close(G, c, s, *orc.normal_eq(Aclean, b, w, t))
 
 
-@pytest.mark.parametrize("K", [168, 200, 256])
+@pytest.mark.parametrize("K", [168, 200, 256, 275])
 def test_quad_kernel_agrees_with_the_tiled_kernel_and_the_oracle(ctx, K):
     A, b, w = orc.synth_problem(60013, K)
     t = np.random.default_rng(K).random(len(b)) < 0.15
@@ -162,7 +163,7 @@ def test_quad_kernel_agrees_with_the_tiled_kernel_and_the_oracle(ctx, K):
     stats_close(*ctx.download_packed(total.data_ptr(), K), *ref, tol=2e-12)
 
 
-@pytest.mark.parametrize("K", [150, 176, 256])
+@pytest.mark.parametrize("K", [150, 176, 256, 288])
 def test_quad_kernel_on_pairs_packed_in_hbm_gives_the_bits_of_the_fused_form(qctx, K):
     # option fused_pack = 0: fsnap_pack_weights_k writes the per-row pairs to HBM and kernel 1Q reads them from there (what a
     # workgroup does whose rows' pairs do not fit the LDS, and what the row-space passes do with pairs of their own): the same
