@@ -639,7 +639,9 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
     // K <= 128 and the context owns the output: the reduction also writes a page-locked host mirror, so the solve
     // needs no D2H copy (the copy's launch latency was 12 us of a 440 us step)
     double* mirror = nullptr;
-    if (want_mirror && ctx->opt_mirror) {
+    // (a system the GPU factorises -- fsnap_solve_device_rhs's rule -- needs no mirror: 288 columns on kernel 1Q)
+    const bool device_factor = (ctx->K >= fsnap::DEVICE_CHOL_MIN_K || (ctx->K > 128 && ctx->opt_device_solve == 1)) && ctx->opt_device_solve != 2;
+    if (want_mirror && ctx->opt_mirror && !device_factor) {
         const size_t need = ((size_t)FSNAP_PACKED_LEN(ctx->K) + (size_t)ctx->K) * 8;   // + compact diagonal
         if (ctx->mirror_bytes < need) {
             if (ctx->mirror) (void)hipHostFree(ctx->mirror);

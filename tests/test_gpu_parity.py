@@ -186,16 +186,20 @@ def test_quad_kernel_on_pairs_packed_in_hbm_gives_the_bits_of_the_fused_form(qct
     stats_close(*plain, *orc.normal_eq(A, b, w, t))
 
 
-def test_quad_kernel_fit_matches_the_oracle_solve(ctx):
-    # the whole fit at the three-element SNAP width: statistics from kernel 1Q, host mirror written by the reduction, host solve
-    A, b, w = orc.synth_problem(80000, 168)
+@pytest.mark.parametrize("K,m", [(168, 80000), (275, 40000), (288, 40000)])
+def test_quad_kernel_fit_matches_the_oracle_solve(ctx, K, m):
+    # the whole fit: statistics from kernel 1Q; 168 / 275 columns: host mirror written by the reduction, host solve;
+    # 288 columns: no mirror, the GPU factorises (DEVICE_CHOL_MIN_K)
+    A, b, w = orc.synth_problem(m, K)
     ctx.upload_rows(A, b)
     ctx.set_weights(w)
     beta = ctx.fit_resident(_capi.SOLVE_RIDGE, 1e-8)[0]
     assert ctx.launch_info()["kernel_or_pairs"] == 5
     G, c, s = orc.normal_eq(A, b, w)
-    ref = np.linalg.solve(G + 1e-8 * np.eye(168), c)
+    ref = np.linalg.solve(G + 1e-8 * np.eye(K), c)
     assert np.max(np.abs(beta - ref)) <= 1e-9 * np.max(np.abs(ref))
+    again = ctx.fit_resident(_capi.SOLVE_RIDGE, 1e-8)[0]
+    assert np.array_equal(beta, again)
 
 
 @pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 1023, 1025])
