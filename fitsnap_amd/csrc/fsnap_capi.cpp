@@ -1750,8 +1750,8 @@ int fsnap_residual_rhs(fsnap_ctx* ctx, const double* beta, double* s, double* ss
     if (!beta || !s) return ctx->fail(FSNAP_E_ARG, "fsnap_residual_rhs: NULL argument");
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     const size_t m = (size_t)ctx->m, K = (size_t)ctx->K;
-    // K <= 256: kernels 4 + 7 fused, the rows are read once (option fused_residual = 0: the two-kernel form, A/B)
-    const bool fused = ctx->opt_fused_residual && K <= 256;
+    // K <= 288: kernels 4 + 7 fused, the rows are read once (option fused_residual = 0: the two-kernel form, A/B)
+    const bool fused = ctx->opt_fused_residual && K <= 288;
     const int nb = fused ? fsnap::residual_num_blocks(ctx->m, (int)ctx->K) : fsnap::gemv_num_blocks(ctx->m);
     const int nbt = fused ? nb : fsnap::gemvT_num_blocks(ctx->m);
     if (!ctx->beta.ensure(K * 8) || (!fused && !ctx->du.ensure(m * 8)) || !ctx->dspart.ensure((size_t)nbt * K * 8) ||

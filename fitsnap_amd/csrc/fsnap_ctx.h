@@ -157,7 +157,7 @@ struct fsnap_ctx {
     int opt_staged_upload = 0;    // fsnap_upload_rows: 0 pageable hipMemcpy (default) | 2 page-locked double buffer | 1 double buffer, probed
     double upload_probe_gbps = 0.0;   // rate at which the host filled the first page-locked slots of the last large upload (GB/s)
     bool upload_staged = false;       // the whole of the last upload went through the double buffer
-    int opt_fused_residual = 1;   // fsnap_residual_rhs, K <= 256: 1 one pass over the rows | 2 one pass, next rows prefetched into a second
+    int opt_fused_residual = 1;   // fsnap_residual_rhs, K <= 288: 1 one pass over the rows | 2 one pass, next rows prefetched into a second
                                   // register set (measured slower: fewer waves per SIMD) | 0 kernels 4 + 7, two passes
     int opt_reduce = 0;       // reduction of kernel 1 / 1A / 1P partials: 0 = kernel 2b, 1 = kernel 2 (A/B)
     int opt_mirror_upper = 1; // kernel 2b writes the host mirror's triangle once per element (upper positions)

@@ -119,7 +119,7 @@ hipError_t launch_gemv_rows(const double* A, int64_t lda, const double* beta, in
                             double* uout, hipStream_t st, bool uplain = false);   // uplain: u = w (b - a.beta), not w^2 (...)
 int gemvT_num_blocks(int64_t m);
 int residual_num_blocks(int64_t m, int K);
-// one-pass s = (wA)^T (wb - wA beta) for K <= 256 (kernels 4 + 7 fused): partial[residual_num_blocks(m, K)][K] scratch,
+// one-pass s = (wA)^T (wb - wA beta) for K <= 288 (kernels 4 + 7 fused): partial[residual_num_blocks(m, K)][K] scratch,
 // sse_part[residual_num_blocks(m, K)] per-workgroup partial SSE (nullptr: none), out[K]
 hipError_t launch_residual_rows(const double* A, int64_t lda, const double* beta, int64_t m, int K, const double* b,
                                 const double* w, const unsigned char* mask, double* partial, double* sse_part, double* out,

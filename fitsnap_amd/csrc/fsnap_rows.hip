@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void fsnap_gemvT_rows_k(const double* __restri
 // step's loads is covered by the other waves of the SIMD (4 at K = 128, 8 at K = 31).  PF = true prefetches the next step's
 // rows into a second register set instead -- half the waves per SIMD, and slower at every shape measured (10^6 x 128: 0.207
 // against 0.198 ms per call, 4 10^6 x 31: 0.356 / 0.238, 200 000 x 200: 0.119 / 0.094; kept for A/B, option fused_residual = 2).  Rows that do not take part (test
-// rows, rows past m) are zeroed by selects: NaN / Inf in them reach nothing.  K <= 32 NJ (NJ <= 8: 64 VGPRs of row data
+// rows, rows past m) are zeroed by selects: NaN / Inf in them reach nothing.  K <= 32 NJ (NJ <= 9: 72 VGPRs of row data
 // per set); wider systems keep the two-kernel form.  HBM-bound: 8K + 17 bytes per row.
 // Per-workgroup partial vectors partial[wg][K] (fold: kernel fsnap_colsum_partials_k), sse_part[wg].
 // ---------------------------------------------------------------------------------
@@ -766,7 +766,7 @@ int residual_num_blocks(int64_t m, int K) {
         return v > 0 ? v : 0;
     }();
     const int nj = (K + 31) / 32;
-    const int per_cu = nj <= 1 ? 8 : nj == 2 ? 7 : nj == 3 ? 5 : nj <= 5 ? 4 : nj == 6 ? 3 : 2;
+    const int per_cu = nj <= 1 ? 8 : nj == 2 ? 7 : nj == 3 ? 5 : nj <= 5 ? 4 : nj == 6 ? 3 : 2;      // (7 ... 9: 2)
     const int cap = forced ? forced : 256 * per_cu;
     int64_t nb = (m + 31) / 32;
     if (nb > cap) nb = cap;
@@ -774,7 +774,7 @@ int residual_num_blocks(int64_t m, int K) {
     return (int)nb;
 }
 
-// fused refinement right-hand side (K <= 256): partial[residual_num_blocks(m)][K], sse_part[residual_num_blocks(m)] (or
+// fused refinement right-hand side (K <= 288): partial[residual_num_blocks(m)][K], sse_part[residual_num_blocks(m)] (or
 // nullptr), out[K]
 hipError_t launch_residual_rows(const double* A, int64_t lda, const double* beta, int64_t m, int K, const double* b,
                                 const double* w, const unsigned char* mask, double* partial, double* sse_part, double* out,
@@ -798,6 +798,7 @@ hipError_t launch_residual_rows(const double* A, int64_t lda, const double* beta
         case 5: FSNAP_LAUNCH(5); break;
         case 6: FSNAP_LAUNCH(6); break;
         case 7: case 8: FSNAP_LAUNCH(8); break;
+        case 9: FSNAP_LAUNCH(9); break;          // 257 ... 288 columns: the widths kernel 1Q still takes
         default: return hipErrorInvalidValue;
     }
 #undef FSNAP_LAUNCH

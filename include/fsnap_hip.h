@@ -102,7 +102,7 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * "acc_max_k" (144 | 128: widest system on the accumulator-resident kernel; 128 sends 129 ... 144 columns to the tiled kernel, A/B),
  * "reduce" (0 = reduction kernel 2b with every load of a thread in flight, the default; 1 = its predecessor, A/B),
  * "mirror_upper" (0|1, default 1: the reduction writes the host mirror's triangle once per element, at its upper position),
- * "fused_residual" (fsnap_residual_rhs for K <= 256: 1 = one pass over the rows, the default; 2 = one pass with the next rows
+ * "fused_residual" (fsnap_residual_rhs for K <= 288: 1 = one pass over the rows, the default; 2 = one pass with the next rows
  * prefetched into a second register set -- measured slower, fewer waves per SIMD; 0 = the two-kernel form, two passes),
  * "reduce_triangle" (fsnap_fit_dist / fsnap_lstsq_rows: -1 = systems of >= 256 columns all-reduce [upper triangle | c | scalars],
  * K (K + 1) / 2 + K + 3 doubles, between a pack and an unpack kernel, the default; 0 = always the full K^2 + K + 3; 1 = always

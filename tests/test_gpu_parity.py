@@ -1081,9 +1081,9 @@ def test_residual_rhs_general_k(ctx, K):
 
 
 @pytest.mark.parametrize("K,m", [(7, 1003), (31, 15213), (64, 9001), (110, 20011), (128, 50001), (142, 13035), (200, 7001),
-                                 (256, 4099)])
+                                 (256, 4099), (257, 3001), (275, 9001), (288, 5003)])
 def test_one_pass_residual_rhs(ctx, K, m):
-    # fsnap_residual_rhs for K <= 256: kernels 4 + 7 fused, every row read once (option fused_residual: 1 = the default
+    # fsnap_residual_rhs for K <= 288: kernels 4 + 7 fused, every row read once (option fused_residual: 1 = the default
     # form, 2 = with the next rows prefetched into a second register set, 0 = the two-kernel form).  All three against the
     # oracle's s = aw^T (bw - aw beta) and SSE on the training rows; NaN / Inf in A, b, w of test rows reach nothing in the
     # fused forms (the reference drops those rows by fancy indexing, svd.py:44-46).
