@@ -65,12 +65,13 @@ def test_one_rank_communicator_runs_every_collective(ta):
     ctx.close()
 
 
-@pytest.mark.parametrize("K,m", [(31, 4001), (142, 6007), (300, 5003), (480, 6000)])
+@pytest.mark.parametrize("K,m", [(31, 4001), (142, 6007), (200, 12001), (264, 9001), (300, 5003), (480, 6000)])
 def test_triangle_payload_of_the_all_reduce_gives_the_same_statistics(K, m):
     # option reduce_triangle: the multi-GPU fit all-reduces [upper triangle | c | scalars] (K (K + 1) / 2 + K + 3 doubles)
     # between a pack and an unpack kernel instead of the mirrored K^2 + K + 3 (default from 256 columns on).  In a
     # communicator of one rank: the reduced buffer, the fit, rank and conditioning carry the same bits in both forms, G is
-    # exactly symmetric, and the device Cholesky (K = 480) reads the unpacked buffer
+    # exactly symmetric, and the device Cholesky (K = 480) reads the unpacked buffer.  200 / 264 columns: statistics from kernel 1Q
+    # (>= 8 192 rows), mirror filled by the copy kernel behind the all-reduce, host solve
     A, b, w = orc.synth_problem(m, K)
     ctx = _capi.HipContext(0)
     ctx.comm_init(1, 0, _capi.comm_id())
