@@ -18,7 +18,7 @@ import itertools
 
 import numpy as np
 
-from ..parallel_tools import DistributedList
+from ..parallel_tools import DistributedList, LabelList
 
 
 class Calculator:
@@ -124,7 +124,8 @@ class Calculator:
         self.flush_rows()
         if self.pt.stubs != 1:
             # the arrays stay rank-local (one process per GPU): keep the lists that describe them
-            self.pt.local_lists = {k: v.get_list() for k, v in self.pt.fitsnap_dict.items() if isinstance(v, DistributedList)}
+            self.pt.local_lists = {k: LabelList(v.get_list()) for k, v in self.pt.fitsnap_dict.items()
+                                   if isinstance(v, DistributedList)}
         single_process = self.pt.stubs == 1
         for key, held in list(self.pt.fitsnap_dict.items()):
             if not isinstance(held, DistributedList):
@@ -133,10 +134,12 @@ class Calculator:
             gathered = self.pt.fitsnap_dict[key]
             if gathered is None:                       # a rank that does not receive the gathered lists
                 continue
+            # LabelList: a list (what the reference's consumers expect) that counts its edits, so the solvers need not
+            # re-read every entry per call to know that a mask / category ids derived from it still hold
             if single_process:
-                self.pt.fitsnap_dict[key] = gathered.get_list()
+                self.pt.fitsnap_dict[key] = LabelList(gathered.get_list())
             else:                                      # one list per rank, in rank order: concatenate
-                self.pt.fitsnap_dict[key] = list(itertools.chain.from_iterable(gathered))
+                self.pt.fitsnap_dict[key] = LabelList(itertools.chain.from_iterable(gathered))
 
     def extras(self):
         """Descriptors.npy / Truth-Ref.npy / Weights.npy / FitSNAP.df dumps — the on-disk

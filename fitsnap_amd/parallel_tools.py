@@ -85,6 +85,46 @@ class DistributedList:
         return deepcopy(self._items)
 
 
+class LabelList(list):
+    """A ``list`` of row labels (``Testing`` / ``Groups`` / ``Row_Type`` ...) that counts its edits.
+
+    The reference keeps one Python list per label in ``pt.fitsnap_dict`` and its consumers index, slice, iterate and
+    ``isinstance(x, list)``-test them (fitsnap3lib/solvers/solver.py:384-389) -- all of which a subclass of ``list``
+    keeps.  What it adds is ``version``: every in-place edit (item / slice assignment, ``append``, ``sort`` ...) bumps
+    it, so a solver that derived a training mask or category ids from 10^6 entries can tell in O(1) that they still
+    hold (``Solver._labels_stamp``) instead of hashing the whole list on every call (9-26 ms per list at 10^6 rows,
+    profiles/r04_ga_loop.txt).  This package's own producers (``gather_fitsnap``, ``FitSnap.load_descriptors``) hand out
+    ``LabelList``s; a plain list handed in by a foreign caller keeps working through the content fingerprint."""
+
+    __slots__ = ("version",)
+
+    def __init__(self, *args):
+        super().__init__(*args)
+        self.version = 0
+
+    def _edits(name):                                          # noqa: N805 - class-body helper
+        base = getattr(list, name)
+
+        def method(self, *args, **kw):
+            self.version += 1
+            return base(self, *args, **kw)
+
+        method.__name__ = name
+        method.__doc__ = base.__doc__
+        return method
+
+    for _name in ("__setitem__", "__delitem__", "__iadd__", "__imul__", "append", "extend", "insert", "pop", "remove",
+                  "clear", "sort", "reverse"):
+        locals()[_name] = _edits(_name)
+    del _name, _edits
+
+    def __reduce_ex__(self, protocol):
+        return (LabelList, (list(self),))
+
+    def copy(self):
+        return LabelList(self)
+
+
 class StubsArray:
     """Plain ndarray holder (fitsnap3lib/parallel_tools.py:1047-1077).  Unlike the
     reference (``np.ndarray(shape)`` = uninitialised memory, Appendix A of SURVEY.md) the
@@ -314,7 +354,11 @@ class ParallelTools:
         self._hip = None
         self._device_index = None
         self._transport = None
-        self.force_multi = False
+        # FSNAP_FORCE_MULTI=1: run the collective code paths in a communicator of ONE rank (how a single-GPU box exercises
+        # what a multi-GPU job does; tests and `python -m fitsnap3 --comm rccl` alike)
+        import os
+
+        self.force_multi = os.environ.get("FSNAP_FORCE_MULTI", "0") not in ("", "0")
         if comm is None or comm is False:
             self.stubs = 1
             self._comm = None
@@ -462,7 +506,10 @@ class ParallelTools:
             raise NameError("Dictionary element not yet in fitsnap_dictionary")
         if self.stubs:
             return
-        self.fitsnap_dict[name] = self.allgather_object(self.fitsnap_dict[name])
+        held = self.fitsnap_dict[name]
+        if isinstance(held, DistributedList):
+            held = held._items                                 # ships the plain list, not the wrapper
+        self.fitsnap_dict[name] = self.allgather_object(held)
 
     def get_ncpn(self, nconfigs: int):
         """Number of configurations over all ranks (parallel_tools.py:562-577)."""

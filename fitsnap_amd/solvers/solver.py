@@ -60,6 +60,11 @@ def _is_label_container(x) -> bool:
 
 def _content_stamp(labels):
     """Fingerprint of the whole content of one row-label container (see ``Solver._labels_stamp``)."""
+    version = getattr(labels, "version", None)
+    if version is not None and isinstance(labels, list):
+        # parallel_tools.LabelList counts its own edits: (object, edit count, length) pins the content in O(1).  The
+        # caches keep the list object alive (``_cache_hit`` compares by identity first), so the address cannot be recycled
+        return ("counted", id(labels), version, len(labels))
     if isinstance(labels, np.ndarray):
         if labels.dtype != object:
             arr = labels if labels.flags.c_contiguous else np.ascontiguousarray(labels)
@@ -71,7 +76,11 @@ def _content_stamp(labels):
     n = len(labels)
     if n and isinstance(labels[0], str):
         try:
-            return (n, "str", _digest("\0".join(labels).encode()))
+            joined = "\0".join(labels)
+            # a label that itself holds the separator could collide with a different split of the same text
+            # (['a\0', 'b'] vs ['a', '\0b']): such lists take the generic walk
+            if joined.count("\0") == n - 1:
+                return (n, "str", _digest(joined.encode()))
         except TypeError:                    # mixed entries: the generic walk
             pass
     return (n, hash(tuple(labels)))
@@ -231,28 +240,27 @@ class Solver:
         if len(training) != m:
             raise IndexError("boolean index did not match indexed array along axis 0; size of axis is "
                              f"{m} but size of corresponding boolean axis is {len(training)}")
-        # a cached mask (re-weighting loop) carries its row indices and uint8 form along
+        # a cached mask (re-weighting loop) carries its uint8 form and count along -- and, once a fit asked for them, the
+        # row indices and prefix sum: aux = [idx | None, mask_u8, rank | None, ntrain].  The SAME mask_u8 object comes back
+        # on every call, so that identity-keyed residency checks downstream (``_push_weights``) can hit
         mc = self._mask_cache
         cached = mc is not None and mc[2] is training
         aux = mc[3] if cached else None
-        if aux is not None:
-            idx, mask_u8, rank = aux
-            ntrain = idx.shape[0]
-        else:
+        if aux is None:
             mask_u8 = training.astype(np.uint8)
-            ntrain = int(np.count_nonzero(mask_u8))
-            idx = rank = None
+            aux = [None, mask_u8, None, int(np.count_nonzero(mask_u8))]
+            if cached:
+                self._mask_cache = (mc[0], mc[1], training, aux)
+        idx, mask_u8, rank, ntrain = aux
 
         def train_aux():
             # row indices and exclusive prefix sum of the mask: only a fit that hands over one weight per TRAINING row of a
             # partly masked matrix needs them (5 ms of numpy at 10^6 rows: not on the path of `trainall` / full-weight calls)
-            nonlocal idx, rank, aux
-            if aux is None:
+            nonlocal idx, rank
+            if idx is None:
                 rk = np.cumsum(mask_u8, dtype=np.int64) - mask_u8
                 idx, rank = np.flatnonzero(training), rk.astype(np.int32)
-                aux = (idx, mask_u8, rank)
-                if cached:
-                    self._mask_cache = (mc[0], mc[1], training, aux)
+                aux[0], aux[2] = idx, rank                  # in place: the cache entry (if any) holds this very list
 
         # reference: aw = w[:, None] * a[training]  (numpy broadcasting on the row axis)
         if w.ndim == 0 or w.shape[0] == 1:
@@ -262,7 +270,7 @@ class Solver:
                 w_full = w
             else:
                 # one weight per training row: the GPU spreads them over the rows (fsnap_set_weights_train)
-                had = cached and mc[3] is not None
+                had = cached and idx is not None
                 train_aux()
                 w_full = _TrainWeights(w, mask_u8, rank, idx, had)
         else:
@@ -698,8 +706,8 @@ class Solver:
                     df["preds"] = self.predict_rows() if shared else self.predict_rows(a, b)
             df["weights"] = np.asarray(w).tolist()
             for key in fs_dict.keys():
-                if isinstance(fs_dict[key], list) and len(fs_dict[key]) == len(df.index):
-                    df[key] = fs_dict[key]
+                if _is_label_container(fs_dict[key]) and len(fs_dict[key]) == len(df.index):
+                    df[key] = list(fs_dict[key]) if isinstance(fs_dict[key], list) else fs_dict[key]
             self._df = df
         return self._df
 
@@ -844,7 +852,7 @@ class Solver:
             preds = (self.predict_rows() if shared else self.predict_rows(a, b)) if self.fit is not None else None
             n = len(b)
             piece = {"truths": np.asarray(b), "preds": preds, "weights": np.asarray(w),
-                     "lists": {k: v for k, v in local.items() if isinstance(v, list) and len(v) == n}}
+                     "lists": {k: list(v) for k, v in local.items() if _is_label_container(v) and len(v) == n}}
             parts = pt.allgather_object(piece)
             if pt._rank != 0:
                 self.fit = None

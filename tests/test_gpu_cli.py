@@ -43,3 +43,52 @@ def test_python_m_fitsnap3_reproduces_committed_potential(tmp_path, ta, ta_fits,
     assert "('*ALL', 'Unweighted', 'Training', 'Energy')" in md
     row = [ln for ln in md.splitlines() if "('*ALL', 'Unweighted', 'Training', 'Energy')" in ln][0].split("|")
     assert int(row[2]) == 363 and float(row[3]) == pytest.approx(ta_fits["metrics_all"][0][1], rel=6e-6)
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_cli(tmp_path, world, rank, extra_env, extra_args=()):
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world),
+               FSNAP_COMM_FILE=str(tmp_path / "comm_id"), FSNAP_COMM_TOKEN="cli test", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               FSNAP_COMM_TIMEOUT="120", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), **extra_env)
+    return subprocess.Popen([sys.executable, "-m", "fitsnap3", "Ta.in", "--descriptors", str(tmp_path), "--overwrite", *extra_args],
+                            cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+
+def _check_outputs(tmp_path, ta_fits):
+    coeffs = parse_snapcoeff(tmp_path / "Ta_pot.snapcoeff")
+    standard = parse_snapcoeff(os.path.join(GOLDEN, "Ta_pot.snapcoeff"))
+    assert len(coeffs) == len(standard) == 31
+    assert np.max(np.abs(coeffs - standard)) < 1e-6 and np.max(np.abs(coeffs - standard) / np.abs(standard)) < 1e-6
+    md = (tmp_path / "Ta_metrics.md").read_text()
+    row = [ln for ln in md.splitlines() if "('*ALL', 'Unweighted', 'Training', 'Energy')" in ln][0].split("|")
+    assert int(row[2]) == 363 and float(row[3]) == pytest.approx(ta_fits["metrics_all"][0][1], rel=6e-6)
+
+
+def test_python_m_fitsnap3_in_a_one_rank_rccl_job_runs_the_collective_path(tmp_path, ta, ta_fits):
+    # `--comm auto` with WORLD_SIZE = 1 would be the single-process flow; FSNAP_FORCE_MULTI=1 makes the entry point open
+    # the native RCCL communicator and run fsnap_fit_dist + the pooled error analysis in a communicator of one rank --
+    # everything a multi-GPU launch does except a second device
+    from test_cli_dist_cpu import write_dump
+
+    write_dump(tmp_path, ta)
+    p = _run_cli(tmp_path, 1, 0, {"FSNAP_FORCE_MULTI": "1"}, ("--comm", "rccl"))
+    log = p.communicate(timeout=600)[0]
+    assert p.returncode == 0, log[-3000:]
+    _check_outputs(tmp_path, ta_fits)
+
+
+@pytest.mark.skipif(__import__("fitsnap_amd._capi", fromlist=["x"]).device_count() < 2,
+                    reason="needs two GPUs: RCCL does not put two ranks on one device")
+def test_python_m_fitsnap3_on_two_gpus_shards_by_configuration(tmp_path, ta, ta_fits):
+    from test_cli_dist_cpu import write_dump
+
+    write_dump(tmp_path, ta)
+    procs = [_run_cli(tmp_path, 2, r, {}) for r in range(2)]
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-4000:]
+    _check_outputs(tmp_path, ta_fits)
