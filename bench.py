@@ -91,7 +91,7 @@ def parse(argv=None):
     ap.add_argument("--pipelined", type=int, default=1,
                     help="1 / 0: also report the throughput with two fits in flight (N = 1 only; an extra object, never `value`)")
     ap.add_argument("--svd-solver", type=int, default=1,
-                    help="N = 1: also time the reference's default solver (SVD: probe solve + 2 one-pass refinement steps, the "
+                    help="N = 1: also time the reference's default solver (SVD: probe solve + up to 2 one-pass refinement steps, the "
                          "plugin class, and the row-space path on an ill-conditioned copy); reported as `svd_solver`, never `value`")
     ap.add_argument("--ab-timeout", type=int, default=30,
                     help="seconds a collective of the optional dist_solve A/B leg may take before that leg is given up (the scaling numbers measured before it are reported either way)")
@@ -461,7 +461,7 @@ def run_svd_solver(ctx, args, head, dev, _capi):
     """The reference's DEFAULT solver (io/sections/solver_sections/solver.py:15 -> solvers/svd.py:54, lstsq on the weighted
     rows) on the same resident rows, outside the headline protocol (never `value`):
       * `steps`: what SVD.perform_fit runs per fit on a well-conditioned system, at the level of the headline step
-        (weights resident, one library call per stage): probe solve of the statistics + 2 refinement steps, each ONE
+        (weights resident, one library call per stage): probe solve of the statistics + up to 2 refinement steps (stop rule of Solver._refine), each ONE
         pass over the rows (fsnap_residual_rhs, kernels 4 + 7 fused) + a K x K solve;
       * `class_perform_fit`: the plugin class itself with keep_resident (adds what the class does per call: the staged
         upload of one weight per training row, label handling);
@@ -480,12 +480,25 @@ def run_svd_solver(ctx, args, head, dev, _capi):
         ctx.set_weights(w)
         ctx.set_option("timing_every", 0)
 
+        from fitsnap_amd.solvers.solver import refinement_done, refinement_skip
+
         def svd_step():
-            beta, rank, _, ptr = ctx.fit_resident(_capi.SOLVE_LSTSQ_PROBE, RCOND)
-            for _ in range(NREF):
-                s = ctx.residual_rhs(beta)[0]
-                delta = ctx.solve_device(_capi.SOLVE_LSTSQ, RCOND, Kc, ptr, rhs=s)[0]
-                beta = beta + delta
+            # the steps of SVD.perform_fit / Solver._refine, stop rule included: how many refinement passes a fit takes
+            # follows the conditioning the Cholesky reports (refinement_skip / refinement_done), at most NREF
+            beta, rank, rcond, ptr = ctx.fit_resident(_capi.SOLVE_LSTSQ_PROBE, RCOND)
+            taken = 0
+            if not refinement_skip(Kc, rcond):
+                prev = float(np.max(np.abs(beta)))
+                for _ in range(NREF):
+                    s = ctx.residual_rhs(beta)[0]
+                    delta = ctx.solve_device(_capi.SOLVE_LSTSQ, RCOND, Kc, ptr, rhs=s)[0]
+                    beta = beta + delta
+                    taken += 1
+                    step = float(np.max(np.abs(delta)))
+                    if refinement_done(Kc, step, prev, float(np.max(np.abs(beta))), rcond):
+                        break
+                    prev = step
+            svd_step.taken, svd_step.rcond = taken, float(rcond)
             return beta, rank
 
         for _ in range(20):
@@ -502,11 +515,13 @@ def run_svd_solver(ctx, args, head, dev, _capi):
             ctx.residual_rhs(beta)
         ctx.sync()
         el_res = time.perf_counter() - t0
-        out["steps"] = {"ms_per_fit": el / n * 1e3, "rows_per_s": m * n / el, "refinement_steps": NREF, "rank": int(rank),
+        out["steps"] = {"ms_per_fit": el / n * 1e3, "rows_per_s": m * n / el, "refinement_steps": int(svd_step.taken), "refinement_steps_max": NREF,
+                        "rcond_est": svd_step.rcond, "rank": int(rank),
                         "residual_rhs_ms_per_call": el_res / n * 1e3,
                         "residual_rhs_GBps": (8 * Kc + 17) * m / (el_res / n) / 1e9,
-                        "protocol": "fsnap_fit_resident(LSTSQ_PROBE) + 2 x (fsnap_residual_rhs: one pass over the rows + "
-                                    "fsnap_solve_device_rhs), weights resident"}
+                        "protocol": "fsnap_fit_resident(LSTSQ_PROBE) + refinement_steps x (fsnap_residual_rhs: one pass over the "
+                                    "rows + fsnap_solve_device_rhs), weights resident; the stop rule of Solver._refine "
+                                    "(refinement_done: what is left is below lstsq's own kappa eps) decides the count"}
         pt = ParallelTools()
         cfg = Config(pt, {"SOLVER": {"solver": "SVD"}})
         sv = solver_factory.solver("SVD", pt, cfg)
@@ -524,6 +539,7 @@ def run_svd_solver(ctx, args, head, dev, _capi):
         ms_cls = class_fit(A, 8)
         fit_cls = np.array(sv.fit)
         out["class_perform_fit"] = {"ms_per_fit": ms_cls, "rows_per_s": m / (ms_cls * 1e-3),
+                                    "refinement_steps": int(sv.last_refine_steps),
                                     "max_rel_diff_vs_steps": float(np.max(np.abs(fit_cls - beta) / np.maximum(np.abs(beta), 1e-300)))}
         if Kc >= 2:
             Ai = A.copy()

@@ -871,6 +871,29 @@ def test_full_size_linearity_and_parity(ctx, big):
     pt.free()
 
 
+@pytest.mark.parametrize("masked", [False, True], ids=["all_train", "ten_percent_testing"])
+def test_full_size_svd_and_ridge_variants_match_the_reference_solvers(big, masked):
+    # SURVEY 8(d)'s variants of BASELINE configs[1] at 10^6 x 128: the reference's DEFAULT solver (SVD = lstsq on the
+    # weighted training rows, svd.py:44-54) and RIDGE with the reference's default alpha = 1e-4
+    # (io/sections/solver_sections/ridge.py:13), with all rows training and with the 10 % testing mask; tolerance 1e-6
+    # relative per coefficient (north_star).  The weights go in as the reference passes them: one per TRAINING row.
+    A, b, w = big
+    t = orc.synth_testing_mask(len(b)) if masked else None
+    fsd = {"Testing": t.tolist()} if masked else None
+    w_train = w[~t] if masked else w
+    pt, sol = make_solver("SVD")
+    sol.perform_fit(A, b, w_train, fs_dict=fsd, trainall=not masked)
+    assert sol.last_row_space is None and sol.last_rank == 128       # well conditioned: statistics + refinement, not the row-space solve
+    assert sol.last_refine_steps <= sol.refine_steps
+    assert maxrel(sol.fit, orc.svd_fit(A, b, w, t)) < 1e-6
+    pt.free()
+    for alpha in (1e-4, 1e-8):
+        pt, sol = make_solver("RIDGE", {"RIDGE": {"alpha": alpha}})
+        sol.perform_fit(A, b, w_train, fs_dict=fsd, trainall=not masked)
+        assert maxrel(sol.fit, orc.ridge_fit(A, b, w, alpha, testing=t)) < 1e-6
+        pt.free()
+
+
 # ---------------------------------------------------------------------------------------
 # K x K solve on the device (fsnap_solve_device) vs the host solver
 # ---------------------------------------------------------------------------------------
