@@ -857,6 +857,10 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
     } else if (!strcmp(key, "dist_solve")) {
         if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "dist_solve must be 0 (solve on every rank) or 1 (rank 0 solves and broadcasts)");
         ctx->opt_dist_solve = (int)value;
+    } else if (!strcmp(key, "chol_form")) {
+        if (value < -1 || value > 5 || value == 3)
+            return ctx->fail(FSNAP_E_ARG, "chol_form must be -1 (default), 0, 1, 2 (single-wave diagonal block), 4 or 5");
+        ctx->opt_chol_form = (int)value;
     } else if (!strcmp(key, "quad")) {
         if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "quad must be 0 or 1");
         ctx->opt_quad = (int)value;
@@ -1552,7 +1556,7 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
         const bool clear_status = ctx->chol_status_word != (const void*)d_status;
         ctx->chol_status_word = host_out ? (const void*)d_status : nullptr;
         FSNAP_HIP(fsnap::launch_chol_large(d_packed, d_rhs, n, alpha, (double*)ctx->dchol.p, d_dsc, d_z, d_beta, d_status,
-                                           d_minpiv, host_out, clear_status, ctx->stream),
+                                           d_minpiv, host_out, clear_status, ctx->opt_chol_form, ctx->stream),
                   "launch device Cholesky");
         const double* h;
         if (host_out) {

@@ -468,6 +468,239 @@ __global__ __launch_bounds__(64) void fsnap_chol_diag_k(double* __restrict__ S, 
     chol_diag_body(S, ld, jb, Y, status, minpiv, T, UT, (int)threadIdx.x, variant);
 }
 
+// ---------------------------------------------------------------------------------
+// 8b4 (round 5): the 64 x 64 diagonal block on FOUR waves (one per SIMD of the CU), the default form.
+//
+// The single-wave form above spends 12.5 us per block: 64 pivots x (two fp64 MFMAs at 64 cycles each on ONE matrix pipe
+// + ~25 VALU issues), and the 25 blocks of a K = 1595 solve are a serial chain.  Here wave w OWNS the 16-column strip w of
+// the block -- the tiles T[0][w] ... T[w][w] in the accumulator layout -- and the block becomes a pipeline down the
+// diagonal:
+//   * block step a: wave a (the owner) factorises T[a][a] where it is, one rank-1 MFMA per pivot as before, but WITHOUT
+//     the second MFMA on the inverse; per pivot it publishes the sixteen multipliers -U[j][i] (the A operand of that MFMA)
+//     and 1/sqrt(d_j) in LDS (slot p = 16 a + j: two ds_write, no barrier);
+//   * the waves c > a apply the same sixteen row operations to THEIR tile T[a][c] (scale row j, one MFMA with the
+//     published A operand and their own scaled row as B operand): after pivot 15 the tile IS U_ac -- no inverse, no
+//     triangular solve on the chain.  A consumer's chain is one dependent MFMA per pivot (65 cycles), shorter than the
+//     owner's (pivot -> rsq + Newton -> scale -> MFMA), so it follows the owner one LDS round trip behind;
+//   * Schur updates T[b][c] -= U_ab^T U_ac (b = a + 1 ... c) run in wave c: U_ac are its own registers (B operand), U_ab
+//     for b < c comes from wave b through LDS lane for lane (an accumulator tile is, as it stands, the A operand of
+//     U_ab^T X); the NEXT owner (c = a + 1) needs only its own registers: 4 MFMAs between the last pivot of block a and the
+//     first pivot of block a + 1;
+//   * the inverses Y_a = U_aa^-1 that kernels 8c / 8e need leave the chain: a wave that has nothing else to do replays the
+//     published row operations on an identity tile (wave a for a < 3 once its block is done, wave 0 for block 3, following
+//     wave 3's pivots as a consumer would).
+// Hand-offs are polled in LDS (the owner never waits for anybody, so nothing can deadlock; every poll is bounded and a wave
+// that gives up sets status bit 2: the host then factorises itself).  LDS executes the DS instructions of a wave in
+// order: the writer stores payload then marker, the reader loads marker then payload in ONE round trip and retries when
+// the marker was not there yet.
+// ---------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) Diag4Lds {
+    double slot[64][16];       // multipliers of pivot p: -U[j][i] for i > j, 0 elsewhere
+    double inv[64];            // 1/sqrt(d_p); 0.0 = not published yet
+    double dummy[64];          // where the lanes that have nothing to publish store
+    double tile[3][4][64];     // U_01, U_02, U_12 handed from wave b to the waves right of it (accumulator layout, lane for lane)
+    int tflag[4];              // [0] U_01, [1] U_02, [2] U_12 published
+    double T[4][16][17];       // per-wave transpose scratch of the inverses
+};
+
+constexpr int CHOL_D4_SPINS = 1 << 17;        // polls of one hand-off before a wave gives up (~10 ms)
+
+__device__ __forceinline__ int diag4_tile_index(int a, int b) { return a == 0 ? b - 1 : 2; }     // (0,1) (0,2) (1,2)
+
+// clears the hand-off markers; every wave of the workgroup calls it, then ONE __syncthreads() before the first use
+__device__ __forceinline__ void diag4_lds_reset(Diag4Lds& L, int tid) {
+    if (tid < 64) L.inv[tid] = 0.0;
+    if (tid < 4) L.tflag[tid] = 0;
+}
+
+// the sixteen multipliers and 1/sqrt(d) of pivot p, as published by the owner; *ok cleared when the wait ran out
+__device__ __forceinline__ void diag4_poll(const Diag4Lds& L, int p, int e, double& inv, double& mult, bool& ok) {
+    int n = 0;
+    do {
+        inv = *(const volatile double*)&L.inv[p];
+        mult = *(const volatile double*)&L.slot[p][e];
+    } while (inv == 0.0 && ++n < CHOL_D4_SPINS);
+    if (inv == 0.0) ok = false;
+}
+
+// row operations of block step A applied to the tile X = T[A][c] of a wave c > A: X becomes U_Ac
+template <int A>
+__device__ __forceinline__ void diag4_consume(d4& X, const Diag4Lds& L, int e, int kr, bool& ok) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int q = j >> 2, k = j & 3;
+        double inv, mult;
+        diag4_poll(L, 16 * A + j, e, inv, mult, ok);
+        const bool own = (kr == k);
+        const double xs = X[q] * inv;                      // row j of U_Ac
+        X[q] = own ? xs : X[q];
+        if (j < 15) {
+            const double aop = own ? mult : 0.0;           // A[i][k] = -U[j][i], rows i > j
+            const double bop = own ? xs : 0.0;             // B[k][e] = U_Ac[j][e]
+            X = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, X, 0, 0, 0);
+        }
+    }
+}
+
+// Y_A = U_AA^-1: the published row operations of block A replayed on an identity tile (Z = U_AA^-T), transposed through
+// this wave's scratch, stored for kernels 8c / 8e
+template <int A>
+__device__ __forceinline__ void diag4_inverse(Diag4Lds& L, double (*T)[17], double* __restrict__ Y, int e, int kr, bool& ok) {
+    d4 Z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Z[r] = (4 * r + kr == e) ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int q = j >> 2, k = j & 3;
+        double inv, mult;
+        diag4_poll(L, 16 * A + j, e, inv, mult, ok);
+        const bool own = (kr == k);
+        const double zd = Z[q] * inv;
+        Z[q] = own ? zd : Z[q];
+        if (j < 15) {
+            const double aop = own ? mult : 0.0;
+            const double zop = own ? zd : 0.0;
+            Z = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, zop, Z, 0, 0, 0);
+        }
+    }
+    chol_wave_sync();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[4 * r + kr][e] = Z[r];
+    chol_wave_sync();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) Y[(A * 16 + 4 * s + kr) * 16 + e] = T[e][4 * s + kr];      // Y_A[4 s + kr][e] = Z[e][4 s + kr]
+}
+
+// Wave W of the four: Tl[a] = T[a][W] (a <= W) on entry, already holding everything the panels left of this block
+// contributed.  On exit the strip of U is in S, the inverses this wave is responsible for are in Y.
+template <int W>
+__device__ __forceinline__ void chol_diag4_wave(d4 (&Tl)[4], Diag4Lds& L, double* S, int ld, int jb,
+                                                double* __restrict__ Y, int* __restrict__ status,
+                                                double* __restrict__ minpiv, int lane) {
+    const int e = lane & 15, kr = lane >> 4;
+    bool ok = true;
+    // ---- block steps left of the own one: this wave is a consumer -----------------------------------------------
+#pragma unroll
+    for (int a = 0; a < W; ++a) {
+        d4& X = Tl[a];
+        if (a == 0) diag4_consume<0>(X, L, e, kr, ok);
+        else if (a == 1) diag4_consume<1>(X, L, e, kr, ok);
+        else diag4_consume<2>(X, L, e, kr, ok);
+        if (a + 1 == W) {
+            // next owner: its diagonal tile needs nothing but its own registers -- first thing after the last pivot
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Tl[W] = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[s], X[s], Tl[W], 0, 0, 0);
+        }
+        if (W < 3) {
+            // U_aW for the waves right of this one (payload, then marker)
+            const int ti = diag4_tile_index(a, W);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) *(volatile double*)&L.tile[ti][s][lane] = X[s];
+            *(volatile int*)&L.tflag[ti] = 1;
+        }
+        if (a + 1 < W) {
+            // T[b][W] -= U_ab^T U_aW, b = a + 1 ... W - 1 with U_ab from wave b, then b = W from the own registers
+#pragma unroll
+            for (int b = a + 1; b < W; ++b) {
+                const int ti = diag4_tile_index(a, b);
+                int n = 0;
+                while (*(const volatile int*)&L.tflag[ti] == 0 && ++n < CHOL_D4_SPINS) {
+                }
+                if (n >= CHOL_D4_SPINS) ok = false;
+                double at[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) at[s] = *(const volatile double*)&L.tile[ti][s][lane];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) Tl[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-at[s], X[s], Tl[b], 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Tl[W] = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[s], X[s], Tl[W], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(size_t)(jb + 16 * a + 4 * r + kr) * ld + jb + 16 * W + e] = X[r];
+    }
+    // ---- the own block step: owner ------------------------------------------------------------------------------
+    d4& D = Tl[W];
+    double pmin = 1.0e300, psum = 0.0;
+    double dcur = readlane_f64(D[0], 0);
+    double inv = rsqrt_newton(dcur);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int q = j >> 2, k = j & 3;
+        pmin = dcur < pmin ? dcur : pmin;                  // (a NaN pivot is caught by the sum)
+        psum += dcur;
+        double t = 0.0, pn = 0.0;
+        if (j < 15) {
+            const int q1 = (j + 1) >> 2, k1 = (j + 1) & 3;
+            t = readlane_f64(D[q], k * 16 + j + 1);        // D[j][j + 1] before this step's scaling
+            pn = readlane_f64(D[q1], k1 * 16 + j + 1);     // D[j + 1][j + 1] before this step's update
+        }
+        const bool own = (kr == k);
+        const double ud = D[q] * inv;                      // U[j][e]
+        const bool keep = own && e >= j;
+        D[q] = keep ? ud : D[q];
+        const double aop = (own && e > j) ? -ud : 0.0;
+        // publish: the multipliers from the lanes that hold row j, then the marker (= 1/sqrt(d), never 0 for a finite pivot)
+        *(volatile double*)(own ? &L.slot[16 * W + j][e] : &L.dummy[lane]) = aop;
+        *(volatile double*)&L.inv[16 * W + j] = inv;
+        if (j < 15) {
+            const double bop = keep ? ud : 0.0;
+            D = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, D, 0, 0, 0);
+            const double u = t * inv;
+            dcur = __builtin_fma(-u, u, pn);               // the MFMA's own value for D[j + 1][j + 1], one FMA behind 1/sqrt(d_j)
+            inv = rsqrt_newton(dcur);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (e >= 4 * r + kr) S[(size_t)(jb + 16 * W + 4 * r + kr) * ld + jb + 16 * W + e] = D[r];
+    if (!(pmin > 0.0) || !__builtin_isfinite(psum)) {      // non-positive, NaN or infinite pivot
+        if (lane == 0) atomicOr(status, 2);
+    } else if (lane == 0) {
+        // positive doubles order like their bit patterns: the panel's smallest pivot over the four owners
+        atomicMin(reinterpret_cast<unsigned long long*>(minpiv + jb / CHOL_NB), (unsigned long long)__double_as_longlong(pmin));
+    }
+    // ---- inverses -----------------------------------------------------------------------------------------------
+    double(*T)[17] = L.T[W];
+    if (W == 0) {
+        diag4_inverse<0>(L, T, Y, e, kr, ok);
+        diag4_inverse<3>(L, T, Y, e, kr, ok);              // follows wave 3's pivots
+    } else if (W == 1) {
+        diag4_inverse<1>(L, T, Y, e, kr, ok);
+    } else if (W == 2) {
+        diag4_inverse<2>(L, T, Y, e, kr, ok);
+    }
+    if (!ok && lane == 0) atomicOr(status, 2);
+}
+
+// (S here is where the FACTOR goes: the work matrix itself in the in-place forms, the second matrix in the one-launch form)
+__device__ __forceinline__ void chol_diag4_dispatch(d4 (&Tl)[4], Diag4Lds& L, double* S, int ld, int jb,
+                                                    double* __restrict__ Y, int* __restrict__ status,
+                                                    double* __restrict__ minpiv, int wave, int lane) {
+    if (wave == 0) chol_diag4_wave<0>(Tl, L, S, ld, jb, Y, status, minpiv, lane);
+    else if (wave == 1) chol_diag4_wave<1>(Tl, L, S, ld, jb, Y, status, minpiv, lane);
+    else if (wave == 2) chol_diag4_wave<2>(Tl, L, S, ld, jb, Y, status, minpiv, lane);
+    else chol_diag4_wave<3>(Tl, L, S, ld, jb, Y, status, minpiv, lane);
+}
+
+// the first diagonal block of a factorisation: tiles straight from the work matrix
+__global__ __launch_bounds__(256) void fsnap_chol_diag4_k(const double* S, double* Uf, int ld, int jb, double* __restrict__ Y,
+                                                         int* __restrict__ status, double* __restrict__ minpiv,
+                                                         int* __restrict__ flag) {
+    __shared__ Diag4Lds L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, e = lane & 15, kr = lane >> 4;
+    if (threadIdx.x == 0 && flag) *flag = 0;
+    diag4_lds_reset(L, (int)threadIdx.x);
+    d4 Tl[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            Tl[a][r] = (a <= wave) ? S[(size_t)(jb + 16 * a + 4 * r + kr) * ld + jb + 16 * wave + e] : 0.0;
+    __syncthreads();
+    chol_diag4_dispatch(Tl, L, Uf, ld, jb, Y, status, minpiv, wave, lane);
+}
+
 // 8c: blocked forward substitution on the matrix pipe.  One wave per 16-column strip of the columns right of the
 // panel (trailing columns + the right-hand-side strip).
 __device__ __forceinline__ void chol_tails_strip(double* __restrict__ S, int ld, int jb, int strip,
@@ -607,6 +840,243 @@ __global__ __launch_bounds__(256) void fsnap_chol_update_diag_k(double* __restri
     const int pair = q < nblk - 2 ? q + 2 : q + 3;
     if (pair >= total) return;
     chol_update_pair(S, ld, jb, nblk, pair, lane);
+}
+
+// 8d + 8b4 fused ("look-ahead"): workgroup 0 forms the tiles of the NEXT diagonal block in registers -- wave w the tiles
+// (0..w, w): target values minus the 64-row product of the current panel's row tails -- and factorises them with the
+// four-wave pipeline without a trip through memory; all other workgroups update the rest of the trailing matrix
+__global__ __launch_bounds__(256) void fsnap_chol_update_diag4_k(double* __restrict__ S, int ld, int jb, int nblk,
+                                                                int* __restrict__ status, double* __restrict__ Ynext,
+                                                                double* __restrict__ minpiv) {
+    __shared__ Diag4Lds L;
+    if (*status) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0) {
+        diag4_lds_reset(L, (int)threadIdx.x);
+        __syncthreads();
+        const int e = lane & 15, kr = lane >> 4;
+        const int nb = jb + CHOL_NB;
+        const double* base = S + (size_t)(jb + kr) * ld + nb;          // row jb + kr of the panel, first column of the next block
+        double y[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) y[s] = base[(size_t)(4 * s) * ld + 16 * wave + e];
+        d4 Tl[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (a <= wave) {                                            // (wave-uniform)
+                double x[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) x[s] = (a == wave) ? y[s] : base[(size_t)(4 * s) * ld + 16 * a + e];
+                d4 acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = S[(size_t)(nb + 16 * a + 4 * r + kr) * ld + nb + 16 * wave + e];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[s], y[s], acc, 0, 0, 0);
+                Tl[a] = acc;
+            } else {
+                Tl[a] = d4{0.0, 0.0, 0.0, 0.0};
+            }
+        }
+        chol_diag4_dispatch(Tl, L, S, ld, nb, Ynext, status, minpiv, wave, lane);
+        return;
+    }
+    const int total = nblk * (nblk + 1) / 2 + nblk;
+    const int q = ((int)blockIdx.x - 1) * 4 + wave;        // the remaining pairs: all but 0, 1 and nblk
+    const int pair = q < nblk - 2 ? q + 2 : q + 3;
+    if (pair >= total) return;
+    chol_update_pair(S, ld, jb, nblk, pair, lane);
+}
+
+// ---------------------------------------------------------------------------------
+// 8s (round 5, the default): ONE launch per panel.  The launch behind panel jb computes the panel's row tails, updates the
+// trailing matrix with them AND factorises the next diagonal block -- without a hand-off between workgroups, because every
+// wave computes the row tails it needs ITSELF (the matrix pipe has the time: a K = 1595 solve is 17 us of MFMA work in a
+// 0.5 ms chain).  The two-launch form paid per panel: tails launch 4.8 us + boundary + update / diagonal launch + boundary.
+//   * the factor goes to a SECOND matrix Uf (same layout as the work matrix S): S keeps the Schur complements, so a wave
+//     that reads the raw rows of the panel never races with the wave that writes their substituted form;
+//   * a bulk wave owns one 32 x 32 block pair (I, J) as before: it substitutes the four 16-column strips of the panel's
+//     rows in its block columns I and J (kernel 8c's blocked substitution, in registers: 4 x 40 MFMAs), multiplies them
+//     (64 MFMAs: an accumulator tile is already the A / B operand) and updates its tiles of S in place; the waves of the
+//     pairs (J, J), and the pair (nblk - 1, nblk) for the right-hand-side strip, also store their strips into Uf;
+//   * workgroup 0 is the critical chain: wave w substitutes strip w of the NEXT diagonal block's columns, the four waves
+//     exchange the strips through LDS (an accumulator tile is the A operand lane for lane), wave w forms the tiles
+//     (0..w, w) of the next diagonal block in registers and the four-wave pipeline of kernel 8b4 factorises it.
+// ---------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) Step4Lds {
+    Diag4Lds d;
+    double xs[3][16][64];      // substituted strips of waves 0-2 (4 tiles x 4 registers, lane for lane)
+    int xflag[4];
+};
+
+// row tails of ONE 16-column strip (first column c0) of the panel at jb, in registers: X[b][s] = row 16 b + 4 s + kr, column e
+// of U12 = U11^-T S12.  Raw rows from S, the diagonal block's factor from Uf, its inverted 16 x 16 blocks from Y.
+__device__ __forceinline__ void chol_tails_regs(const double* S, const double* Uf, int ld, int jb, int c0,
+                                                const double* __restrict__ Y, int lane, d4 (&X)[4]) {
+    const int e = lane & 15, kr = lane >> 4;
+    const double* base = S + (size_t)(jb + kr) * ld;
+    const double* ubase = Uf + (size_t)(jb + kr) * ld;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) X[b][s] = base[(size_t)(16 * b + 4 * s) * ld + c0 + e];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        d4 acc = X[b];
+#pragma unroll
+        for (int bp = 0; bp < b; ++bp)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double a = -ubase[(size_t)(16 * bp + 4 * s) * ld + jb + 16 * b + e];   // -L[16b+e][16bp+4s+kr]
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[bp][s], acc, 0, 0, 0);
+            }
+        d4 xb = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double t = Y[(b * 16 + 4 * s + kr) * 16 + e];   // (Y_b^T)[e][4s+kr]
+            xb = __builtin_amdgcn_mfma_f64_16x16x4f64(t, acc[s], xb, 0, 0, 0);
+        }
+        X[b] = xb;
+    }
+}
+
+__device__ __forceinline__ void chol_strip_store(double* Uf, int ld, int jb, int c0, const d4 (&X)[4], int lane) {
+    const int e = lane & 15, kr = lane >> 4;
+    double* base = Uf + (size_t)(jb + kr) * ld;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) base[(size_t)(16 * b + 4 * r) * ld + c0 + e] = X[b][r];
+}
+
+// the right-hand-side strip alone (behind the LAST panel there is no trailing matrix, but the forward sweep still needs it),
+// and any other use of the substitution with separate input / output matrices: one wave per 16-column strip from column c0
+__global__ __launch_bounds__(256) void fsnap_chol_tails2_k(const double* S, double* Uf, int ld, int jb, int c0, int nstrip,
+                                                          const double* __restrict__ Y, const int* __restrict__ status) {
+    if (*status) return;
+    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (strip >= nstrip) return;
+    d4 X[4];
+    chol_tails_regs(S, Uf, ld, jb, c0 + 16 * strip, Y, (int)(threadIdx.x & 63), X);
+    chol_strip_store(Uf, ld, jb, c0 + 16 * strip, X, (int)(threadIdx.x & 63));
+}
+
+__global__ __launch_bounds__(256, 2) void fsnap_chol_step4_k(double* S, double* Uf, int ld, int jb, int nblk,
+                                                         int* __restrict__ status, const double* __restrict__ Y,
+                                                         double* __restrict__ Ynext, double* __restrict__ minpiv) {
+    __shared__ Step4Lds L;
+    if (*status) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = lane & 15, kr = lane >> 4;
+    const int je = jb + CHOL_NB;
+    if (blockIdx.x == 0) {
+        diag4_lds_reset(L.d, (int)threadIdx.x);
+        if (threadIdx.x < 4) L.xflag[threadIdx.x] = 0;
+        __syncthreads();
+        d4 X[4];
+        chol_tails_regs(S, Uf, ld, jb, je + 16 * wave, Y, lane, X);
+        if (wave < 3) {                                        // (wave-uniform) payload, then marker
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) *(volatile double*)&L.xs[wave][4 * b + r][lane] = X[b][r];
+            *(volatile int*)&L.xflag[wave] = 1;
+        }
+        chol_strip_store(Uf, ld, jb, je + 16 * wave, X, lane);
+        d4 Tl[4];
+        bool ok = true;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (a <= wave) {                                    // (wave-uniform)
+                d4 acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = S[(size_t)(je + 16 * a + 4 * r + kr) * ld + je + 16 * wave + e];
+                if (a == wave) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[b][r], X[b][r], acc, 0, 0, 0);
+                } else {
+                    int n = 0;
+                    while (*(const volatile int*)&L.xflag[a] == 0 && ++n < CHOL_D4_SPINS) {
+                    }
+                    if (n >= CHOL_D4_SPINS) ok = false;
+                    double xa[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) xa[q] = *(const volatile double*)&L.xs[a][q][lane];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[4 * b + r], X[b][r], acc, 0, 0, 0);
+                }
+                Tl[a] = acc;
+            } else {
+                Tl[a] = d4{0.0, 0.0, 0.0, 0.0};
+            }
+        }
+        if (!ok && lane == 0) atomicOr(status, 2);
+        chol_diag4_dispatch(Tl, L.d, Uf, ld, je, Ynext, status, minpiv, wave, lane);
+        return;
+    }
+    // bulk: one 32 x 32 block pair per wave, all pairs but (0,0), (0,1), (1,1)
+    const int total = nblk * (nblk + 1) / 2 + nblk;
+    const int q = ((int)blockIdx.x - 1) * 4 + wave;
+    const int pair = q < nblk - 2 ? q + 2 : q + 3;
+    if (pair >= total) return;
+    const int ntri = nblk * (nblk + 1) / 2;
+    int I, J;
+    if (pair < ntri) {
+        I = 0;
+        int rem = pair;
+        while (rem >= nblk - I) {
+            rem -= nblk - I;
+            ++I;
+        }
+        J = I + rem;
+    } else {
+        I = pair - ntri;
+        J = nblk;          // the right-hand-side strip
+    }
+    const int cI = je + 32 * I, cJ = je + 32 * J;
+    // the two strips of block column J stay in registers; the strips of block column I are substituted one at a time (register
+    // budget: two waves per SIMD)
+    d4 XJ0[4], XJ1[4];
+    chol_tails_regs(S, Uf, ld, jb, cJ, Y, lane, XJ0);
+    chol_tails_regs(S, Uf, ld, jb, cJ + 16, Y, lane, XJ1);
+    if (I == J || (J == nblk && I == nblk - 1)) {              // this wave's J strips are the factor's rows: store them
+        chol_strip_store(Uf, ld, jb, cJ, XJ0, lane);
+        chol_strip_store(Uf, ld, jb, cJ + 16, XJ1, lane);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        d4 XI[4];
+        if (I == J) {                                           // (wave-uniform)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) XI[b] = h ? XJ1[b] : XJ0[b];
+        } else {
+            chol_tails_regs(S, Uf, ld, jb, cI + 16 * h, Y, lane, XI);
+        }
+        d4 a0, a1;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const double* p = S + (size_t)(cI + 16 * h + kr + 4 * r4) * ld;
+            a0[r4] = p[cJ + e];
+            a1[r4] = p[cJ + 16 + e];
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-XI[b][r], XJ0[b][r], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-XI[b][r], XJ1[b][r], a1, 0, 0, 0);
+            }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            double* p = S + (size_t)(cI + 16 * h + kr + 4 * r4) * ld;
+            p[cJ + e] = a0[r4];
+            p[cJ + 16 + e] = a1[r4];
+        }
+    }
 }
 
 // 8d + 8b + 8c fused ("one launch per panel", FSNAP_CHOL_FUSED = 1; NOT the default: it measured slower, see chol_fused()): the launch that updates the trailing
@@ -1012,17 +1482,38 @@ namespace fsnap {
 
 size_t chol_large_work_doubles(int n) {
     const size_t np = (size_t)(n + CHOL_NB - 1) / CHOL_NB * CHOL_NB;
-    return np * (np + CHOL_XS) + (np / CHOL_NB) * 1024 + 8;     // work matrix + strip, Y blocks of every panel, hand-off word
+    // work matrix + strip, Y blocks of every panel, hand-off word, the factor matrix of the one-launch-per-panel form
+    return 2 * np * (np + CHOL_XS) + (np / CHOL_NB) * 1024 + 8;
 }
 
-// pivot-chain form of kernel 8b (see chol_diag_step): FSNAP_CHOL_DIAG = 0 | 1 | 2
+// where the factor ends up: the work matrix itself (in-place forms), or the second matrix behind Y blocks and hand-off word
+static double* chol_factor_matrix(double* work, int np, int form);
+
+// form of the panel loop, FSNAP_CHOL_DIAG =
+//   5 (default)  ONE launch per panel (kernel 8s: every wave substitutes the row tails it needs itself; factor in a second
+//                matrix), diagonal block on four waves (kernel 8b4);
+//   4            two launches per panel (tails; update + next diagonal block), diagonal block on four waves;
+//   0 | 1 | 2    two launches per panel, the single-wave kernel 8b with the pivot chains of chol_diag_step (rounds 2-4; what
+//                the flag-synchronised panel launch FSNAP_CHOL_FUSED = 1 uses)
 static int chol_diag_variant() {
     static const int v = [] {
         const char* e = getenv("FSNAP_CHOL_DIAG");
-        const int x = e ? atoi(e) : 2;
-        return x < 0 || x > 2 ? 2 : x;
+        const int x = e ? atoi(e) : 5;
+        return (x < 0 || x > 5 || x == 3) ? 5 : x;
     }();
     return v;
+}
+
+int chol_default_form() { return chol_diag_variant(); }
+
+static int chol_resolve_form(int form) { return (form < 0 || form > 5 || form == 3) ? chol_diag_variant() : form; }
+
+static void launch_first_diag(double* S, double* Uf, int ld, double* Yall, int* status, double* minpiv, int* flag, int form,
+                              hipStream_t st) {
+    if (form >= 4)
+        hipLaunchKernelGGL(fsnap_chol_diag4_k, dim3(1), dim3(256), 0, st, (const double*)S, Uf, ld, 0, Yall, status, minpiv, flag);
+    else
+        hipLaunchKernelGGL(fsnap_chol_diag_k, dim3(1), dim3(64), 0, st, S, ld, 0, Yall, status, minpiv, form, flag);
 }
 
 // FSNAP_CHOL_FUSED = 1: one launch per panel (kernel fsnap_chol_panel_k); default 0: two launches per panel (tails; update +
@@ -1039,38 +1530,64 @@ static bool chol_fused() {
     return v;
 }
 
+static double* chol_factor_matrix(double* work, int np, int form) {
+    if (form != 5 || chol_fused()) return work;
+    const size_t ld = (size_t)np + CHOL_XS;
+    return work + (size_t)np * ld + (size_t)(np / CHOL_NB) * 1024 + 8;
+}
+
 // the panel loop behind the first diagonal block (kernel 8b on panel 0 has run): row tails of panel 0, then per panel ONE
 // launch (update behind panel pb + diagonal block and row tails of panel pb + 1) -- or the two-launch form
-static void launch_chol_panels(double* S, int ld, int np, double* Yall, int* status, double* minpiv, int* flag, hipStream_t st) {
+static void launch_chol_panels(double* S, double* Uf, int ld, int np, double* Yall, int* status, double* minpiv, int* flag,
+                               int form, hipStream_t st) {
     const int npanel = np / CHOL_NB;
     const bool fused = chol_fused();
+    const int form1 = form >= 4 ? 2 : form;                 // the flag-synchronised panel launch keeps the single-wave block
     for (int pb = 0; pb < npanel; ++pb) {
         const int jb = pb * CHOL_NB;
         double* Y = Yall + (size_t)pb * 1024;
         const int ntail = np - jb - CHOL_NB;
         const int nstrip = (ntail + CHOL_XS) / 16;
+        const int nblk = ntail / 32;
+        if (form == 5 && !fused) {
+            // ONE launch per panel: row tails (every wave its own), trailing update, next diagonal block; S -> Uf
+            if (ntail > 0) {
+                const int nrest = nblk * (nblk + 1) / 2 + nblk - 3;
+                hipLaunchKernelGGL(fsnap_chol_step4_k, dim3(1 + (nrest + 3) / 4), dim3(256), 0, st, S, Uf, ld, jb, nblk, status,
+                                   (const double*)Y, Y + 1024, minpiv);
+            } else {
+                hipLaunchKernelGGL(fsnap_chol_tails2_k, dim3(1), dim3(256), 0, st, (const double*)S, Uf, ld, jb, np, CHOL_XS / 16,
+                                   (const double*)Y, (const int*)status);
+            }
+            continue;
+        }
         if (pb == 0 || !fused)
             hipLaunchKernelGGL(fsnap_chol_tails_k, dim3((nstrip + 3) / 4), dim3(256), 0, st, S, ld, jb, nstrip, Y, status);
         if (ntail > 0) {
-            const int nblk = ntail / 32;
             if (fused) {
                 // waves: 3 diagonal pairs + (nblk - 1) column waves + the pairs with I >= 2
                 const int nb2 = nblk - 2;
                 const int nwaves = 4 + (nblk - 2 > 0 ? nblk - 2 : 0) + (nb2 > 0 ? nb2 * (nb2 + 1) / 2 + nb2 : 0);
                 hipLaunchKernelGGL(fsnap_chol_panel_k, dim3((nwaves + 3) / 4), dim3(256), 0, st, S, ld, jb, nblk, status, Y + 1024,
-                                   minpiv, chol_diag_variant(), flag, pb + 1);
+                                   minpiv, form1, flag, pb + 1);
             } else {
                 // trailing update of this panel + factorisation of the next diagonal block (look-ahead), one launch
                 const int nrest = nblk * (nblk + 1) / 2 + nblk - 3;
-                hipLaunchKernelGGL(fsnap_chol_update_diag_k, dim3(1 + (nrest + 3) / 4), dim3(256), 0, st, S, ld, jb, nblk, status,
-                                   Y + 1024, minpiv, chol_diag_variant());
+                if (form == 4)
+                    hipLaunchKernelGGL(fsnap_chol_update_diag4_k, dim3(1 + (nrest + 3) / 4), dim3(256), 0, st, S, ld, jb, nblk,
+                                       status, Y + 1024, minpiv);
+                else
+                    hipLaunchKernelGGL(fsnap_chol_update_diag_k, dim3(1 + (nrest + 3) / 4), dim3(256), 0, st, S, ld, jb, nblk,
+                                       status, Y + 1024, minpiv, form);
             }
         }
     }
 }
 
 hipError_t launch_chol_large(const double* packed, const double* cvec, int n, double alpha, double* work, double* dsc, double* z,
-                             double* beta, int* status, double* minpiv, double* host_out, bool clear_status, hipStream_t st) {
+                             double* beta, int* status, double* minpiv, double* host_out, bool clear_status, int form,
+                             hipStream_t st) {
+    form = chol_resolve_form(form);
     if (!cvec) cvec = packed + (size_t)n * n;
     const int np = (n + CHOL_NB - 1) / CHOL_NB * CHOL_NB, npanel = np / CHOL_NB, ld = np + CHOL_XS;
     double* S = work;
@@ -1087,8 +1604,9 @@ hipError_t launch_chol_large(const double* packed, const double* cvec, int n, do
                        minpiv, npanel);
     hipLaunchKernelGGL(fsnap_chol_prepare_s_k, dim3((ld + 255) / 256, np), dim3(256), 0, st, packed, n, np, alpha, dsc, z, S,
                        status);
-    hipLaunchKernelGGL(fsnap_chol_diag_k, dim3(1), dim3(64), 0, st, S, ld, 0, Yall, status, minpiv, chol_diag_variant(), flag);
-    launch_chol_panels(S, ld, np, Yall, status, minpiv, flag, st);
+    double* Uf = chol_factor_matrix(work, np, form);       // where the factor ends up (S itself in the in-place forms)
+    launch_first_diag(S, Uf, ld, Yall, status, minpiv, flag, form, st);
+    launch_chol_panels(S, Uf, ld, np, Yall, status, minpiv, flag, form, st);
     static bool bs_attr_set = false;
     if (!bs_attr_set) {
         e = hipFuncSetAttribute((const void*)fsnap_chol_backsolve_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHOL_BS_LDS);
@@ -1097,11 +1615,11 @@ hipError_t launch_chol_large(const double* packed, const double* cvec, int n, do
     }
     for (int hi = npanel; hi > 0; hi -= CHOL_BS_MACRO) {
         const int lo = hi > CHOL_BS_MACRO ? hi - CHOL_BS_MACRO : 0;
-        hipLaunchKernelGGL(fsnap_chol_backsolve_k, dim3(1), dim3(1024), CHOL_BS_LDS, st, S, ld, np, n, Yall, z, dsc, beta, status,
-                           lo, hi, hi == npanel ? 1 : 0, minpiv, host_out);
+        hipLaunchKernelGGL(fsnap_chol_backsolve_k, dim3(1), dim3(1024), CHOL_BS_LDS, st, (const double*)Uf, ld, np, n, Yall, z, dsc,
+                           beta, status, lo, hi, hi == npanel ? 1 : 0, minpiv, host_out);
         if (lo > 0) {
             const int nrows = lo * CHOL_NB;
-            hipLaunchKernelGGL(fsnap_chol_backupdate_k, dim3((nrows + 3) / 4), dim3(256), 0, st, S, ld, z, lo * CHOL_NB,
+            hipLaunchKernelGGL(fsnap_chol_backupdate_k, dim3((nrows + 3) / 4), dim3(256), 0, st, (const double*)Uf, ld, z, lo * CHOL_NB,
                                hi * CHOL_NB, nrows, status);
         }
     }
@@ -1109,7 +1627,8 @@ hipError_t launch_chol_large(const double* packed, const double* cvec, int n, do
 }
 
 hipError_t launch_chol_factor(const double* G, int n, double shift, double* work, double* dsc, int* status, double* minpiv,
-                              int K16, double* Rout, hipStream_t st) {
+                              int K16, double* Rout, int form, hipStream_t st) {
+    form = chol_resolve_form(form);
     const int np = (n + CHOL_NB - 1) / CHOL_NB * CHOL_NB, npanel = np / CHOL_NB, ld = np + CHOL_XS;
     double* S = work;
     double* Yall = work + (size_t)np * ld;
@@ -1118,11 +1637,12 @@ hipError_t launch_chol_factor(const double* G, int n, double shift, double* work
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fsnap_chol_factor_prepare_d_k, dim3((np + 255) / 256), dim3(256), 0, st, G, n, np, dsc, status, minpiv, npanel);
     hipLaunchKernelGGL(fsnap_chol_factor_prepare_s_k, dim3((ld + 255) / 256, np), dim3(256), 0, st, G, n, np, shift, dsc, S, status);
-    hipLaunchKernelGGL(fsnap_chol_diag_k, dim3(1), dim3(64), 0, st, S, ld, 0, Yall, status, minpiv, chol_diag_variant(), flag);
-    launch_chol_panels(S, ld, np, Yall, status, minpiv, flag, st);      // (the strip is carried along as in the solve: zero here)
+    double* Uf = chol_factor_matrix(work, np, form);
+    launch_first_diag(S, Uf, ld, Yall, status, minpiv, flag, form, st);
+    launch_chol_panels(S, Uf, ld, np, Yall, status, minpiv, flag, form, st);  // (the strip is carried along as in the solve: zero here)
     const int64_t total = (int64_t)K16 * K16 + (int64_t)K16 * 16;
-    hipLaunchKernelGGL(fsnap_chol_extract_factor_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, S, Yall, dsc, n, np, K16,
-                       Rout);
+    hipLaunchKernelGGL(fsnap_chol_extract_factor_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const double*)Uf, Yall,
+                       dsc, n, np, K16, Rout);
     return hipGetLastError();
 }
 

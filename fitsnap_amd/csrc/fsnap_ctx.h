@@ -163,6 +163,7 @@ struct fsnap_ctx {
     int opt_mirror_upper = 1; // kernel 2b writes the host mirror's triangle once per element (upper positions)
     int opt_fused_pack = 1;   // kernel 1A forms the per-row pairs of its rows in LDS itself (no packing launch) when they fit
     int opt_acc_min_cpw = 0;  // kernel 1A: fewest 4-row chunks per row-wave before the grid shrinks (0 = default)
+    int opt_chol_form = -1;   // panel loop of the device Cholesky: -1 = default (FSNAP_CHOL_DIAG, else 5: one launch per panel, four-wave diagonal block); 0 | 1 | 2 | 4: the A/B forms (fsnap_chol.hip)
     int opt_quad = 1;         // kernel 1Q (144 < K <= 288: the triangle dealt to the four waves of a workgroup); 0 = tiled kernel there
     int64_t opt_quad_min_rows = -1;   // fewest rows for kernel 1Q (-1 = default)
     int opt_quad_min_cpg = 0;         // kernel 1Q: fewest 4-row chunks per workgroup before the grid shrinks (0 = default)

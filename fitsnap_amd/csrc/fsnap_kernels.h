@@ -103,13 +103,18 @@ hipError_t launch_chol_solve(const double* packed, int K, double alpha, double* 
 // cvec: device right-hand side (NULL = the c part of packed)
 size_t chol_large_work_doubles(int n);
 hipError_t launch_chol_large(const double* packed, const double* cvec, int n, double alpha, double* work, double* dsc, double* z,
-                             double* beta, int* status, double* minpiv, double* host_out, bool clear_status, hipStream_t st);
+                             double* beta, int* status, double* minpiv, double* host_out, bool clear_status, int form,
+                             hipStream_t st);
+// `form` of the panel loop (option "chol_form"): 5 = one launch per panel + four-wave diagonal block (default), 4 = two launches
+// per panel + four-wave block, 0 | 1 | 2 = two launches per panel + the single-wave block with pivot chain 0 / 1 / 2 (rounds 2-4);
+// -1 = chol_default_form() (FSNAP_CHOL_DIAG, else 5)
+int chol_default_form();
 // factor only (pass factor of the row-space solve, K >= 384): R = chol(D^-1 G D^-1 + shift I) D for the n x n Gram matrix G in
 // device memory, written as the K16 x K16 padded factor + inverse blocks that launch_trsm_rows reads (trsm_factor_doubles(K16)
 // doubles at Rout); status: bit 0 non-finite input, bit 1 failed pivot (retry with a larger shift).  work / dsc / minpiv as
 // for launch_chol_large.
 hipError_t launch_chol_factor(const double* G, int n, double shift, double* work, double* dsc, int* status, double* minpiv,
-                              int K16, double* Rout, hipStream_t st);
+                              int K16, double* Rout, int form, hipStream_t st);
 // out[0 .. n) = row maxima of |G - I|, out[n .. 2 n) = row sums of the squared Jacobi-scaled entries (active columns; NaN row
 // maximum = non-finite input): the steering numbers of a row-space pass, so that G itself can stay in HBM
 hipError_t launch_gram_scan(const double* G, int n, double* out, hipStream_t st);

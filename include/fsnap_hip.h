@@ -81,6 +81,9 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * "tiled_ring" (0 ... 3, default 3: bit 0 / bit 1 put the diagonal / off-diagonal work items of the tiled kernel on the ring form of its
  * load pipeline; 0 = the three-set form of round 2, for A/B runs -- same bits either way),
  * "device_solve" (fsnap_solve_device: 0 = auto: K >= 288 is factorised on the GPU by the blocked kernels; 1 = every K on the GPU; 2 = never),
+ * "chol_form" (panel loop of that GPU factorisation: -1 = default -- the FSNAP_CHOL_DIAG environment variable, else 5; 5 = ONE launch
+ * per 64-row panel, every wave substituting the row tails it needs itself, diagonal block on four waves; 4 = two launches per panel,
+ * four-wave diagonal block; 0 | 1 | 2 = two launches per panel, single-wave diagonal block with pivot chain 0 / 1 / 2 (rounds 2-4); A/B),
  * "repack" (1 = recompute the packed per-row weights (mask * w, mask * w * b) and the b-only scalars on EVERY fit even
  * when b, w and the mask are context-owned and unchanged; default 0 = once per fsnap_set_weights / fsnap_upload_rows),
  * "timing_every" (N: HIP events bracket every N-th SYRK launch only -- an event record between two dependent kernels idles

@@ -487,10 +487,13 @@ def test_large_k_device_cholesky_matches_host_solve(ctx, K, m):
         assert np.max(np.abs(beta_dev - ref)) / scale < 1e-8
 
 
-@pytest.mark.parametrize("env", [{"FSNAP_CHOL_FUSED": "1"}, {"FSNAP_CHOL_DIAG": "0"}, {"FSNAP_CHOL_DIAG": "1"}])
+@pytest.mark.parametrize("env", [{"FSNAP_CHOL_FUSED": "1"}, {"FSNAP_CHOL_DIAG": "0"}, {"FSNAP_CHOL_DIAG": "1"}, {"FSNAP_CHOL_DIAG": "2"},
+                                 {"FSNAP_CHOL_DIAG": "4"}, {"FSNAP_CHOL_DIAG": "5"}])
 def test_device_cholesky_ab_forms_solve_the_same_systems(env):
-    # the forms of the blocked device Cholesky kept for A/B behind environment switches (read once per process): the
-    # one-launch-per-panel kernel with its in-launch flag hand-off, and the pivot chains 0 / 1 of the diagonal block
+    # the forms of the blocked device Cholesky (option "chol_form"; here through the environment default, read once per
+    # process): 5 = one launch per panel + four-wave diagonal block (the default), 4 = two launches per panel + four-wave
+    # block, 0 / 1 / 2 = the single-wave block of rounds 2-4 with its three pivot chains, and the flag-synchronised
+    # one-launch kernel of round 4
     import os
     import re
     import subprocess
