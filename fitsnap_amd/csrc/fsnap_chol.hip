@@ -494,6 +494,15 @@ __global__ __launch_bounds__(64) void fsnap_chol_diag_k(double* __restrict__ S, 
 // order: the writer stores payload then marker, the reader loads marker then payload in ONE round trip and retries when
 // the marker was not there yet.
 // ---------------------------------------------------------------------------------
+// LDS hand-off accesses: `volatile` through a generic pointer compiles to FLAT loads / stores (the aperture path: several hundred
+// cycles per access and both wait counters) -- the address space has to be spelled out for ds_read / ds_write
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) int lds_i32;
+__device__ __forceinline__ double lds_ld(const double* p) { return *(const volatile lds_f64*)p; }
+__device__ __forceinline__ void lds_st(double* p, double v) { *(volatile lds_f64*)p = v; }
+__device__ __forceinline__ int lds_ld(const int* p) { return *(const volatile lds_i32*)p; }
+__device__ __forceinline__ void lds_st(int* p, int v) { *(volatile lds_i32*)p = v; }
+
 struct __attribute__((aligned(16))) Diag4Lds {
     double slot[64][16];       // multipliers of pivot p: -U[j][i] for i > j, 0 elsewhere
     double inv[64];            // 1/sqrt(d_p); 0.0 = not published yet
@@ -513,24 +522,31 @@ __device__ __forceinline__ void diag4_lds_reset(Diag4Lds& L, int tid) {
     if (tid < 4) L.tflag[tid] = 0;
 }
 
-// the sixteen multipliers and 1/sqrt(d) of pivot p, as published by the owner; *ok cleared when the wait ran out
-__device__ __forceinline__ void diag4_poll(const Diag4Lds& L, int p, int e, double& inv, double& mult, bool& ok) {
+// the sixteen multipliers and 1/sqrt(d) of pivot p, as published by the owner: one look (marker first, then payload)
+__device__ __forceinline__ void diag4_peek(const Diag4Lds& L, int p, int e, double& inv, double& mult) {
+    inv = lds_ld(&L.inv[p]);
+    mult = lds_ld(&L.slot[p][e]);
+}
+
+// ... looked at again until the marker is there; *ok cleared when the wait ran out
+__device__ __forceinline__ void diag4_wait(const Diag4Lds& L, int p, int e, double& inv, double& mult, bool& ok) {
     int n = 0;
-    do {
-        inv = *(const volatile double*)&L.inv[p];
-        mult = *(const volatile double*)&L.slot[p][e];
-    } while (inv == 0.0 && ++n < CHOL_D4_SPINS);
+    while (inv == 0.0 && ++n < CHOL_D4_SPINS) diag4_peek(L, p, e, inv, mult);
     if (inv == 0.0) ok = false;
 }
 
-// row operations of block step A applied to the tile X = T[A][c] of a wave c > A: X becomes U_Ac
+// row operations of block step A applied to the tile X = T[A][c] of a wave c > A: X becomes U_Ac.  The look at pivot j + 1
+// is issued BEFORE the MFMA of pivot j, so that its LDS round trip runs beside the matrix pipe instead of behind it.
 template <int A>
 __device__ __forceinline__ void diag4_consume(d4& X, const Diag4Lds& L, int e, int kr, bool& ok) {
+    double inv, mult;
+    diag4_peek(L, 16 * A, e, inv, mult);
+    diag4_wait(L, 16 * A, e, inv, mult, ok);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int q = j >> 2, k = j & 3;
-        double inv, mult;
-        diag4_poll(L, 16 * A + j, e, inv, mult, ok);
+        double inv1 = 1.0, mult1 = 0.0;
+        if (j < 15) diag4_peek(L, 16 * A + j + 1, e, inv1, mult1);
         const bool own = (kr == k);
         const double xs = X[q] * inv;                      // row j of U_Ac
         X[q] = own ? xs : X[q];
@@ -538,6 +554,9 @@ __device__ __forceinline__ void diag4_consume(d4& X, const Diag4Lds& L, int e, i
             const double aop = own ? mult : 0.0;           // A[i][k] = -U[j][i], rows i > j
             const double bop = own ? xs : 0.0;             // B[k][e] = U_Ac[j][e]
             X = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, X, 0, 0, 0);
+            diag4_wait(L, 16 * A + j + 1, e, inv1, mult1, ok);
+            inv = inv1;
+            mult = mult1;
         }
     }
 }
@@ -549,11 +568,14 @@ __device__ __forceinline__ void diag4_inverse(Diag4Lds& L, double (*T)[17], doub
     d4 Z;
 #pragma unroll
     for (int r = 0; r < 4; ++r) Z[r] = (4 * r + kr == e) ? 1.0 : 0.0;
+    double inv, mult;
+    diag4_peek(L, 16 * A, e, inv, mult);
+    diag4_wait(L, 16 * A, e, inv, mult, ok);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int q = j >> 2, k = j & 3;
-        double inv, mult;
-        diag4_poll(L, 16 * A + j, e, inv, mult, ok);
+        double inv1 = 1.0, mult1 = 0.0;
+        if (j < 15) diag4_peek(L, 16 * A + j + 1, e, inv1, mult1);
         const bool own = (kr == k);
         const double zd = Z[q] * inv;
         Z[q] = own ? zd : Z[q];
@@ -561,6 +583,9 @@ __device__ __forceinline__ void diag4_inverse(Diag4Lds& L, double (*T)[17], doub
             const double aop = own ? mult : 0.0;
             const double zop = own ? zd : 0.0;
             Z = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, zop, Z, 0, 0, 0);
+            diag4_wait(L, 16 * A + j + 1, e, inv1, mult1, ok);
+            inv = inv1;
+            mult = mult1;
         }
     }
     chol_wave_sync();
@@ -595,8 +620,8 @@ __device__ __forceinline__ void chol_diag4_wave(d4 (&Tl)[4], Diag4Lds& L, double
             // U_aW for the waves right of this one (payload, then marker)
             const int ti = diag4_tile_index(a, W);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) *(volatile double*)&L.tile[ti][s][lane] = X[s];
-            *(volatile int*)&L.tflag[ti] = 1;
+            for (int s = 0; s < 4; ++s) lds_st(&L.tile[ti][s][lane], X[s]);
+            lds_st(&L.tflag[ti], 1);
         }
         if (a + 1 < W) {
             // T[b][W] -= U_ab^T U_aW, b = a + 1 ... W - 1 with U_ab from wave b, then b = W from the own registers
@@ -604,12 +629,12 @@ __device__ __forceinline__ void chol_diag4_wave(d4 (&Tl)[4], Diag4Lds& L, double
             for (int b = a + 1; b < W; ++b) {
                 const int ti = diag4_tile_index(a, b);
                 int n = 0;
-                while (*(const volatile int*)&L.tflag[ti] == 0 && ++n < CHOL_D4_SPINS) {
+                while (lds_ld(&L.tflag[ti]) == 0 && ++n < CHOL_D4_SPINS) {
                 }
                 if (n >= CHOL_D4_SPINS) ok = false;
                 double at[4];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) at[s] = *(const volatile double*)&L.tile[ti][s][lane];
+                for (int s = 0; s < 4; ++s) at[s] = lds_ld(&L.tile[ti][s][lane]);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) Tl[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-at[s], X[s], Tl[b], 0, 0, 0);
             }
@@ -641,8 +666,8 @@ __device__ __forceinline__ void chol_diag4_wave(d4 (&Tl)[4], Diag4Lds& L, double
         D[q] = keep ? ud : D[q];
         const double aop = (own && e > j) ? -ud : 0.0;
         // publish: the multipliers from the lanes that hold row j, then the marker (= 1/sqrt(d), never 0 for a finite pivot)
-        *(volatile double*)(own ? &L.slot[16 * W + j][e] : &L.dummy[lane]) = aop;
-        *(volatile double*)&L.inv[16 * W + j] = inv;
+        lds_st(own ? &L.slot[16 * W + j][e] : &L.dummy[lane], aop);
+        lds_st(&L.inv[16 * W + j], inv);
         if (j < 15) {
             const double bop = keep ? ud : 0.0;
             D = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, D, 0, 0, 0);
@@ -978,8 +1003,8 @@ __global__ __launch_bounds__(256, 2) void fsnap_chol_step4_k(double* S, double* 
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) *(volatile double*)&L.xs[wave][4 * b + r][lane] = X[b][r];
-            *(volatile int*)&L.xflag[wave] = 1;
+                for (int r = 0; r < 4; ++r) lds_st(&L.xs[wave][4 * b + r][lane], X[b][r]);
+            lds_st(&L.xflag[wave], 1);
         }
         chol_strip_store(Uf, ld, jb, je + 16 * wave, X, lane);
         d4 Tl[4];
@@ -997,12 +1022,12 @@ __global__ __launch_bounds__(256, 2) void fsnap_chol_step4_k(double* S, double* 
                         for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[b][r], X[b][r], acc, 0, 0, 0);
                 } else {
                     int n = 0;
-                    while (*(const volatile int*)&L.xflag[a] == 0 && ++n < CHOL_D4_SPINS) {
+                    while (lds_ld(&L.xflag[a]) == 0 && ++n < CHOL_D4_SPINS) {
                     }
                     if (n >= CHOL_D4_SPINS) ok = false;
                     double xa[16];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) xa[q] = *(const volatile double*)&L.xs[a][q][lane];
+                    for (int q = 0; q < 16; ++q) xa[q] = lds_ld(&L.xs[a][q][lane]);
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
 #pragma unroll
