@@ -248,6 +248,19 @@ __device__ __forceinline__ double rsqrt_newton(double d) {
     return y;
 }
 
+// the same with TWO Newton steps: v_rsq_f64 is good to ~2^-23 relative, one step squares that (x 1.5): 2^-45, 2^-90 -- the
+// third step of rsqrt_newton changes nothing but the chain (tools/lat_bench: 60 -> 50 cycles per pivot)
+__device__ __forceinline__ double rsqrt_newton2(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double e = __builtin_fma(-h * y, y, 0.5);
+        y = __builtin_fma(y, e, y);
+    }
+    return y;
+}
+
 // 8b: ONE wave factorises the 64 x 64 diagonal block as a 4 x 4 grid of 16 x 16 blocks held in registers in the
 // MFMA accumulator layout (lane (k, e): rows 4r + k, column e of a block).  Per block step a:
 //   * the 16 x 16 diagonal block is factorised WHERE IT IS: pivot j of the block sits in register j / 4 of the lanes
@@ -503,6 +516,28 @@ __device__ __forceinline__ void lds_st(double* p, double v) { *(volatile lds_f64
 __device__ __forceinline__ int lds_ld(const int* p) { return *(const volatile lds_i32*)p; }
 __device__ __forceinline__ void lds_st(int* p, int v) { *(volatile lds_i32*)p = v; }
 
+// A/B switches of kernel 8b4 (tools/chol_pipeline_check.hip builds the variants)
+#ifndef FSNAP_D4_NEWTON
+#define FSNAP_D4_NEWTON 2      // Newton steps behind v_rsq_f64 on the owner's chain
+#endif
+#ifndef FSNAP_D4_SLEEP
+#define FSNAP_D4_SLEEP 1       // s_sleep between two looks at a marker that is not there yet
+#endif
+#ifndef FSNAP_D4_DEFER
+#define FSNAP_D4_DEFER 1       // stores of the consumed tiles behind the owner phase
+#endif
+#ifndef FSNAP_D4_HALF
+#define FSNAP_D4_HALF 1        // the next owner's diagonal update as two MFMA chains
+#endif
+
+#ifdef FSNAP_CHOL_TRACE
+// tools/chol_diag4_trace.hip: shader-clock stamps of the four waves (entry, end of each consumer step, owner start / end, exit)
+__device__ long long chol_trace_buf[4][8];
+#define CHOL_STAMP(w, i) do { if (lane == 0) chol_trace_buf[w][i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define CHOL_STAMP(w, i) do { } while (0)
+#endif
+
 struct __attribute__((aligned(16))) Diag4Lds {
     double slot[64][16];       // multipliers of pivot p: -U[j][i] for i > j, 0 elsewhere
     double inv[64];            // 1/sqrt(d_p); 0.0 = not published yet
@@ -531,7 +566,12 @@ __device__ __forceinline__ void diag4_peek(const Diag4Lds& L, int p, int e, doub
 // ... looked at again until the marker is there; *ok cleared when the wait ran out
 __device__ __forceinline__ void diag4_wait(const Diag4Lds& L, int p, int e, double& inv, double& mult, bool& ok) {
     int n = 0;
-    while (inv == 0.0 && ++n < CHOL_D4_SPINS) diag4_peek(L, p, e, inv, mult);
+    while (inv == 0.0 && ++n < CHOL_D4_SPINS) {
+#if FSNAP_D4_SLEEP
+        __builtin_amdgcn_s_sleep(1);                       // the owner shares the LDS queue with three pollers
+#endif
+        diag4_peek(L, p, e, inv, mult);
+    }
     if (inv == 0.0) ok = false;
 }
 
@@ -604,6 +644,8 @@ __device__ __forceinline__ void chol_diag4_wave(d4 (&Tl)[4], Diag4Lds& L, double
                                                 double* __restrict__ minpiv, int lane) {
     const int e = lane & 15, kr = lane >> 4;
     bool ok = true;
+    d4 held = {0.0, 0.0, 0.0, 0.0};
+    CHOL_STAMP(W, 0);
     // ---- block steps left of the own one: this wave is a consumer -----------------------------------------------
 #pragma unroll
     for (int a = 0; a < W; ++a) {
@@ -612,9 +654,20 @@ __device__ __forceinline__ void chol_diag4_wave(d4 (&Tl)[4], Diag4Lds& L, double
         else if (a == 1) diag4_consume<1>(X, L, e, kr, ok);
         else diag4_consume<2>(X, L, e, kr, ok);
         if (a + 1 == W) {
-            // next owner: its diagonal tile needs nothing but its own registers -- first thing after the last pivot
+            // next owner: its diagonal tile needs nothing but its own registers -- first thing after the last pivot, as two
+            // chains of two MFMAs (a chain of four on one accumulator is 4 x 65 cycles on the hand-over)
+#if FSNAP_D4_HALF
+            d4 half = {0.0, 0.0, 0.0, 0.0};
+            Tl[W] = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[0], X[0], Tl[W], 0, 0, 0);
+            half = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[1], X[1], half, 0, 0, 0);
+            Tl[W] = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[2], X[2], Tl[W], 0, 0, 0);
+            half = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[3], X[3], half, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Tl[W][r] += half[r];
+#else
 #pragma unroll
             for (int s = 0; s < 4; ++s) Tl[W] = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[s], X[s], Tl[W], 0, 0, 0);
+#endif
         }
         if (W < 3) {
             // U_aW for the waves right of this one (payload, then marker)
@@ -641,14 +694,22 @@ __device__ __forceinline__ void chol_diag4_wave(d4 (&Tl)[4], Diag4Lds& L, double
 #pragma unroll
             for (int s = 0; s < 4; ++s) Tl[W] = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[s], X[s], Tl[W], 0, 0, 0);
         }
+        // the finished tile U_aW goes out at once -- except on the hand-over to the own block step (a + 1 == W), where the
+        // stores wait behind the owner phase (FSNAP_D4_DEFER; `held` is a copy: see the note at the deferred store)
+        if (!FSNAP_D4_DEFER || a + 1 < W) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) S[(size_t)(jb + 16 * a + 4 * r + kr) * ld + jb + 16 * W + e] = X[r];
+            for (int r = 0; r < 4; ++r) S[(size_t)(jb + 16 * a + 4 * r + kr) * ld + jb + 16 * W + e] = X[r];
+        } else {
+            held = X;
+        }
+        CHOL_STAMP(W, 1 + a);
     }
+    CHOL_STAMP(W, 4);
     // ---- the own block step: owner ------------------------------------------------------------------------------
     d4& D = Tl[W];
     double pmin = 1.0e300, psum = 0.0;
     double dcur = readlane_f64(D[0], 0);
-    double inv = rsqrt_newton(dcur);
+    double inv = FSNAP_D4_NEWTON == 2 ? rsqrt_newton2(dcur) : rsqrt_newton(dcur);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int q = j >> 2, k = j & 3;
@@ -673,8 +734,17 @@ __device__ __forceinline__ void chol_diag4_wave(d4 (&Tl)[4], Diag4Lds& L, double
             D = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, D, 0, 0, 0);
             const double u = t * inv;
             dcur = __builtin_fma(-u, u, pn);               // the MFMA's own value for D[j + 1][j + 1], one FMA behind 1/sqrt(d_j)
-            inv = rsqrt_newton(dcur);
+            inv = FSNAP_D4_NEWTON == 2 ? rsqrt_newton2(dcur) : rsqrt_newton(dcur);
         }
+    }
+    CHOL_STAMP(W, 5);
+    // the strip of U: the tiles above the diagonal (kept in registers until here: their stores are off the hand-over), then
+    // the diagonal tile's upper triangle
+    // (storing Tl[a] itself here, for every a < W, produced stale tiles in the fused launches -- the values before the row
+    // operations -- although the same code was right in the stand-alone kernel: tools/chol_pipeline_check.hip, round 5)
+    if (FSNAP_D4_DEFER && W > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(size_t)(jb + 16 * (W - 1) + 4 * r + kr) * ld + jb + 16 * W + e] = held[r];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -696,6 +766,7 @@ __device__ __forceinline__ void chol_diag4_wave(d4 (&Tl)[4], Diag4Lds& L, double
         diag4_inverse<2>(L, T, Y, e, kr, ok);
     }
     if (!ok && lane == 0) atomicOr(status, 2);
+    CHOL_STAMP(W, 6);
 }
 
 // (S here is where the FACTOR goes: the work matrix itself in the in-place forms, the second matrix in the one-launch form)
@@ -725,6 +796,29 @@ __global__ __launch_bounds__(256) void fsnap_chol_diag4_k(const double* S, doubl
     __syncthreads();
     chol_diag4_dispatch(Tl, L, Uf, ld, jb, Y, status, minpiv, wave, lane);
 }
+
+#ifdef FSNAP_CHOL_TRACE
+// the block factorised TWICE in one launch (tools/chol_diag4_trace.hip): the stamps are those of the second pass, whose code
+// is in the instruction cache -- every wave of kernel 8b4 otherwise runs ITS instantiation of the pipeline exactly once
+__global__ __launch_bounds__(256) void fsnap_chol_diag4_twice_k(const double* S, double* Uf, int ld, int jb, double* __restrict__ Y,
+                                                               int* __restrict__ status, double* __restrict__ minpiv) {
+    __shared__ Diag4Lds L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, e = lane & 15, kr = lane >> 4;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+        diag4_lds_reset(L, (int)threadIdx.x);
+        d4 Tl[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Tl[a][r] = (a <= wave) ? S[(size_t)(jb + 16 * a + 4 * r + kr) * ld + jb + 16 * wave + e] : 0.0;
+        __syncthreads();
+        chol_diag4_dispatch(Tl, L, Uf, ld, jb, Y, status, minpiv, wave, lane);
+    }
+}
+#endif
 
 // 8c: blocked forward substitution on the matrix pipe.  One wave per 16-column strip of the columns right of the
 // panel (trailing columns + the right-hand-side strip).
@@ -1228,7 +1322,7 @@ __global__ __launch_bounds__(256) void fsnap_chol_panel_k(double* __restrict__ S
 // Dynamic LDS: two buffers of [U11 64 x 65 | Uoff 64 x 65 | Y 4 x 16 x 17] + 2 x x_panel (64) + 2 x y_panel (64).
 constexpr int CHOL_BS_BUF = 2 * CHOL_NB * (CHOL_NB + 1) + 4 * 16 * 17;
 constexpr size_t CHOL_BS_LDS = (size_t)(2 * CHOL_BS_BUF + 4 * CHOL_NB) * sizeof(double);
-constexpr int CHOL_BS_MACRO = 4;             // panels per macro-block
+constexpr int CHOL_BS_MACRO = 8;             // panels per macro-block (4 until round 5: 13 instead of 7 launches at K = 1595)
 
 // y_r -= U[r, c0 : c1] x[c0 : c1] for the rows r < nrows; one wave per row, c1 - c0 a multiple of 128
 __global__ __launch_bounds__(256) void fsnap_chol_backupdate_k(const double* __restrict__ S, int ld, double* zv, int c0, int c1,

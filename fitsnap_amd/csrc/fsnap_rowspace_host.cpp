@@ -457,7 +457,7 @@ void FactorSolver::prepare(int K_, const double* Rhat, double rcond) {
         double fro = 0.0;
         for (double v : T) fro += v * v;
         fro = std::sqrt(fro);
-        double inv2 = 0.0;
+        double inv2 = 0.0, fro2 = fro, inv_norm = 0.0;
         bool ok = true;
         {
             // X = T^-1 by back substitution, row by row from the bottom: X_i = (e_i - sum_{k>i} T_ik X_k) / T_ii -- every
@@ -478,13 +478,37 @@ void FactorSolver::prepare(int K_, const double* Rhat, double rcond) {
             }
             for (double v : X) inv2 += v * v;
             ok = std::isfinite(inv2);
+            // a second provable pair, usually sharper on graded factors: ||B||_2 <= sqrt(||B||_1 ||B||_inf) for B = T and for
+            // B = T^-1 (both matrices are at hand).  The Frobenius norm charges up to sqrt(n) per factor -- at n = 128 a system
+            // with cond ~ 1e9 and rcond = 1e-13 missed the certificate by that margin and paid 1.8 ms of Jacobi sweeps for a
+            // solution that back substitution gives in 10 us (profiles/r05_lstsq_rows_phases.txt)
+            auto one_inf = [n = this->n](const double* B) {
+                vec col((size_t)n, 0.0);
+                double ninf = 0.0;
+                for (int i = 0; i < n; ++i) {
+                    double rs = 0.0;
+                    for (int c = i; c < n; ++c) {
+                        const double a = std::fabs(B[(size_t)i * n + c]);
+                        rs += a;
+                        col[c] += a;
+                    }
+                    ninf = std::fmax(ninf, rs);
+                }
+                double n1 = 0.0;
+                for (int c = 0; c < n; ++c) n1 = std::fmax(n1, col[c]);
+                return std::sqrt(n1 * ninf);
+            };
+            if (ok) {
+                fro2 = std::fmin(fro, one_inf(T.data()));
+                inv_norm = std::fmin(std::sqrt(inv2), one_inf(X.data()));
+            }
         }
         const double rc = rcond > 0.0 ? rcond : 0.0;
-        triangular = ok && (fro * std::sqrt(inv2) * rc < 0.5);
+        triangular = ok && (fro2 * inv_norm * rc < 0.5);
         if (triangular) {
             rank = n;
-            smax = fro;
-            smin = 1.0 / std::sqrt(inv2);
+            smax = fro2;
+            smin = 1.0 / inv_norm;
             return;
         }
         rcond_used = rc;

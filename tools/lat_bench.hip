@@ -92,6 +92,109 @@ __global__ __launch_bounds__(64) void k(double* out, const double* in, long long
             }
             x = x * r + y;
         }
+    } else if constexpr (MODE == 10) {  // 1/sqrt from an f32 seed: cvt, v_rsq_f32, cvt, 2 Newton steps (24 -> 48 -> 96 bits)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double r = (double)__builtin_amdgcn_rsqf((float)x);
+            const double h = 0.5 * x;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const double e = __builtin_fma(-h * r, r, 0.5);
+                r = __builtin_fma(r, e, r);
+            }
+            x = r + y;
+        }
+    } else if constexpr (MODE == 11) {  // v_rsq_f64 + 2 Newton steps
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double r = __builtin_amdgcn_rsq(x);
+            const double h = 0.5 * x;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const double e = __builtin_fma(-h * r, r, 0.5);
+                r = __builtin_fma(r, e, r);
+            }
+            x = r + y;
+        }
+    } else if constexpr (MODE == 12) {  // v_rsq_f64 + 3 Newton steps (the chain of kernel 8b)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double r = __builtin_amdgcn_rsq(x);
+            const double h = 0.5 * x;
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const double e = __builtin_fma(-h * r, r, 0.5);
+                r = __builtin_fma(r, e, r);
+            }
+            x = r + y;
+        }
+    } else if constexpr (MODE == 13) {  // LDS round trip: ds_write_b64 -> ds_read_b64 of the same word -> add
+        __shared__ double sh[64];
+        typedef __attribute__((address_space(3))) double lds_f64;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            *(volatile lds_f64*)&sh[lane] = x;
+            x = *(volatile lds_f64*)&sh[lane] + y;
+        }
+    } else if constexpr (MODE == 15 || MODE == 16 || MODE == 17) {
+        // the owner's pivot loop of kernel 8b4 (side chain for the next pivot, one MFMA per pivot), 16 tiles of 16 pivots;
+        // 16: with the LDS publication; 17: publication + write-back of the scaled row deferred behind the MFMA
+        __shared__ double slot[16][16], invs[16], dummy[64];
+        typedef __attribute__((address_space(3))) double lds_f64;
+        const int e = lane & 15, kr = lane >> 4;
+#pragma unroll 1
+        for (int rep = 0; rep < N / 16; ++rep) {
+            d4 D = acc;
+            double dcur = readlane_f64(D[0], 0);
+            double inv = __builtin_amdgcn_rsq(dcur);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int q = j >> 2, kk = j & 3;
+                double t = 0.0, pn = 0.0;
+                if (j < 15) {
+                    const int q1 = (j + 1) >> 2, k1 = (j + 1) & 3;
+                    t = readlane_f64(D[q], kk * 16 + j + 1);
+                    pn = readlane_f64(D[q1], k1 * 16 + j + 1);
+                }
+                const bool own = (kr == kk);
+                const double ud = D[q] * inv;
+                const bool keep = own && e >= j;
+                const double aop = (own && e > j) ? -ud : 0.0;
+                if constexpr (MODE != 17) D[q] = keep ? ud : D[q];
+                if constexpr (MODE == 16) {
+                    *(volatile lds_f64*)(own ? &slot[j][e] : &dummy[lane]) = aop;
+                    *(volatile lds_f64*)&invs[j] = inv;
+                }
+                if (j < 15) {
+                    const double bop = keep ? ud : 0.0;
+                    d4 Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, D, 0, 0, 0);
+                    if constexpr (MODE == 17) {
+                        *(volatile lds_f64*)(own ? &slot[j][e] : &dummy[lane]) = aop;
+                        *(volatile lds_f64*)&invs[j] = inv;
+                        Dn[q] = keep ? ud : Dn[q];
+                    }
+                    D = Dn;
+                    const double u = t * inv;
+                    dcur = __builtin_fma(-u, u, pn);
+                    double r = __builtin_amdgcn_rsq(dcur);
+                    const double h = 0.5 * dcur;
+#pragma unroll
+                    for (int it = 0; it < 3; ++it) {
+                        const double ee = __builtin_fma(-h * r, r, 0.5);
+                        r = __builtin_fma(r, ee, r);
+                    }
+                    inv = r;
+                }
+            }
+            acc[0] += D[0] * 1e-30 + 1.0;      // keeps the tiles apart (and the diagonal positive)
+            acc[1] += D[1] * 1e-30;
+        }
+    } else if constexpr (MODE == 14) {  // MFMA -> VALU read of the accumulator -> MFMA operand (no readlane)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double a = y * acc[i & 3];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, z, acc, 0, 0, 0);
+        }
     }
     asm volatile("s_nop 0" : "+v"(x), "+v"(acc), "+v"(acc2)::"memory");     // the results exist here
     __builtin_amdgcn_sched_barrier(0);
@@ -109,14 +212,17 @@ int main() {
     long long *cyc, *wall;
     hipMalloc(&in, 256 * 8);
     hipMalloc(&out, 64 * 8);
-    hipMalloc(&cyc, 16 * 8);
-    hipMalloc(&wall, 16 * 8);
+    hipMalloc(&cyc, 32 * 8);
+    hipMalloc(&wall, 32 * 8);
     double h[256];
     for (int i = 0; i < 256; ++i) h[i] = 1.0 + 1e-3 * i;
     hipMemcpy(in, h, sizeof h, hipMemcpyHostToDevice);
     const char* names[] = {"dependent v_fma_f64", "4 independent v_fma_f64", "dependent v_rsq_f64", "dependent MFMA f64 16x16x4",
                            "2 independent MFMA chains", "MFMA -> readlane -> mul -> MFMA", "full pivot link (rsq + Newton + selects + MFMA)",
-                           "dependent 64-bit select + add", "readlane -> add chain", "pivot link without the MFMA"};
+                           "dependent 64-bit select + add", "readlane -> add chain", "pivot link without the MFMA",
+                           "rsq from f32 seed + 2 Newton + add", "v_rsq_f64 + 2 Newton + add", "v_rsq_f64 + 3 Newton + add",
+                           "LDS write -> read -> add", "MFMA -> mul of the accumulator -> MFMA", "8b4 owner pivot (no LDS)", "8b4 owner pivot + LDS publication",
+                           "8b4 owner pivot, publication + write-back behind the MFMA"};
     for (int rep = 0; rep < 3; ++rep) {
         k<0><<<1, 64>>>(out, in, cyc, wall);
         k<1><<<1, 64>>>(out, in, cyc, wall);
@@ -128,12 +234,20 @@ int main() {
         k<7><<<1, 64>>>(out, in, cyc, wall);
         k<8><<<1, 64>>>(out, in, cyc, wall);
         k<9><<<1, 64>>>(out, in, cyc, wall);
+        k<10><<<1, 64>>>(out, in, cyc, wall);
+        k<11><<<1, 64>>>(out, in, cyc, wall);
+        k<12><<<1, 64>>>(out, in, cyc, wall);
+        k<13><<<1, 64>>>(out, in, cyc, wall);
+        k<14><<<1, 64>>>(out, in, cyc, wall);
+        k<15><<<1, 64>>>(out, in, cyc, wall);
+        k<16><<<1, 64>>>(out, in, cyc, wall);
+        k<17><<<1, 64>>>(out, in, cyc, wall);
         hipDeviceSynchronize();
     }
-    long long hc[16], hw[16];
+    long long hc[32], hw[32];
     hipMemcpy(hc, cyc, sizeof hc, hipMemcpyDeviceToHost);
     hipMemcpy(hw, wall, sizeof hw, hipMemcpyDeviceToHost);
-    for (int m = 0; m < 10; ++m)
+    for (int m = 0; m < 18; ++m)
         printf("%-52s %8.1f s_memtime ticks / link   %7.1f ns / link (100 MHz wall clock)\n", names[m], (double)hc[m] / N,
                (double)hw[m] * 10.0 / N);
     return 0;
