@@ -257,6 +257,8 @@ def recorded_traffic(m, Kc, info, kernel_name):
 def kernel_name_of(info):
     if info["split"] == 0:
         return "fsnap_syrk_tiled"
+    if info["kernel_or_pairs"] == 6:
+        return f"fsnap_syrk_quadc<{info['NB']}>"
     if info["kernel_or_pairs"] == 5:
         return f"fsnap_syrk_quad<{info['NB']}>"
     if info["kernel_or_pairs"] == 4:

@@ -51,6 +51,13 @@ unsigned long long next_mirror_generation() {
     return ++counter;
 }
 
+// the one rule for "fsnap_solve_device factorises this K x K system on the GPU" (blocked kernels 8a-8s): launch_normal_eq and
+// fsnap_mirror_packed skip the host mirror then, fsnap_solve_device_rhs takes the device path
+inline bool device_factor(const fsnap_ctx* ctx, int64_t K) {
+    if (ctx->opt_device_solve == 2) return false;
+    return K >= fsnap::DEVICE_CHOL_MIN_K || (K > 128 && ctx->opt_device_solve == 1);
+}
+
 struct Geometry {
     int nblocks, split, threads;
     int64_t cpw;
@@ -60,22 +67,34 @@ struct Geometry {
     bool packed;    // kernel 1P: kernel 1 on packed weights (K <= 80)
     bool fused_pack = false;   // kernel 1A packs (w_eff, w_eff b) of its rows into LDS itself: no fsnap_pack_weights_k launch
     bool quad = false;         // kernel 1Q: the triangle dealt to the four waves of a workgroup (144 < K <= 288); cpw = chunks per workgroup
+    int cluster = 1;           // kernel 1QC (288 < K <= 512): workgroups per cluster; nblocks = clusters, cpw = chunks per cluster
 };
 
 // rows below which the tiled kernel keeps 145 ... 288 columns: kernel 1Q writes one partial triangle per workgroup
 // (2 KiB x 55 ... 171 tiles), which short systems do not amortise
 constexpr int64_t QUAD_MIN_ROWS = 8192;
 constexpr int64_t QUAD_MIN_CPG = 24;        // fewest 4-row chunks per workgroup before the grid shrinks
+// kernel 1QC (289 ... 512 columns on clusters of workgroups) against the tiled kernel, round 5 (profiles/r05_quadc_ab.txt):
+// 500 000 x 368 1.19 against 1.24 ms, 367 900 x 480 1.40 / 1.38 ms (with 1.43 instead of 6.14 GB of HBM reads and a 17 instead of
+// 42 us reduction: the complete fit 1.61 / 1.62 ms), 200 000 x 320 0.41 / 0.37, 100 000 x 512 0.51 / 0.43: a cluster's partial
+// triangle (up to 1 MiB) and its prologue want ~5 000 rows per cluster to amortise
+constexpr int64_t QUADC_MIN_ROWS = 300000;
 
-// chunks per workgroup of kernel 1Q for this context's rows, 0 = kernel 1Q does not take them
+// chunks per workgroup of kernel 1Q (per CLUSTER of kernel 1QC, 288 < K <= 512) for this context's rows, 0 = neither kernel
+// takes them
 int64_t quad_chunks_per_wg(const fsnap_ctx* ctx, int64_t* nblocks_out) {
     const bool default_kernel = ctx->opt_kernel == 0 || ctx->opt_kernel == 7;
     if (!ctx->opt_quad || !default_kernel || ctx->opt_tiled) return 0;
-    if (ctx->K <= 144 || ctx->K > 288 || ctx->K <= ctx->opt_acc_max_k) return 0;
-    const int64_t min_rows = ctx->opt_quad_min_rows >= 0 ? ctx->opt_quad_min_rows : QUAD_MIN_ROWS;
+    if (ctx->K <= 144 || ctx->K > 512 || ctx->K <= ctx->opt_acc_max_k) return 0;
+    const int cluster = fsnap::syrk_quad_cluster((int)ctx->K);
+    // kernel 1QC exists with fused packing only: pairs brought by a row-space pass, or rows beyond the LDS, stay on the tiled kernel
+    if (cluster > 1 && !ctx->opt_quad_cluster) return 0;
+    if (cluster > 1 && (!ctx->opt_fused_pack || ctx->wpack_override)) return 0;
+    const int64_t min_rows = ctx->opt_quad_min_rows >= 0 ? ctx->opt_quad_min_rows : (cluster > 1 ? QUADC_MIN_ROWS : QUAD_MIN_ROWS);
     if (ctx->m < min_rows || ctx->m < 4) return 0;
     const int64_t nchunks = (ctx->m + 3) / 4;
     int64_t nblocks = ctx->opt_nblocks > 0 ? ctx->opt_nblocks : (int64_t)ctx->num_cu;
+    nblocks /= cluster;                                  // clusters
     const int64_t min_cpg = ctx->opt_quad_min_cpg > 0 ? ctx->opt_quad_min_cpg : QUAD_MIN_CPG;
     const int64_t max_blocks = (nchunks + min_cpg - 1) / min_cpg;
     if (nblocks > max_blocks) nblocks = max_blocks;
@@ -83,6 +102,7 @@ int64_t quad_chunks_per_wg(const fsnap_ctx* ctx, int64_t* nblocks_out) {
     const int64_t cpg = (nchunks + nblocks - 1) / nblocks;
     const int64_t off_limit = (int64_t)0xFFF00000;
     if (cpg > off_limit / (ctx->lda * 32)) return 0;    // a workgroup's rows beyond 32-bit buffer offsets: tiled kernel
+    if (cluster > 1 && cpg > fsnap::syrk_quad_max_cpg()) return 0;
     nblocks = (nchunks + cpg - 1) / cpg;
     if (nblocks_out) *nblocks_out = nblocks;
     return cpg;
@@ -115,6 +135,7 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
         g->split = 1;
         g->threads = 256;
         g->quad = true;
+        g->cluster = fsnap::syrk_quad_cluster(K);
         // fused packing: the workgroup's per-row pairs must fit the LDS; the row-space passes bring pairs of their own
         g->fused_pack = ctx->opt_fused_pack && !ctx->wpack_override && cpg <= fsnap::syrk_quad_max_cpg();
         return FSNAP_OK;
@@ -587,7 +608,7 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
         mask = (const unsigned char*)ctx->ones.p;
     }
     const int NT = g.NB * (g.NB + 1) / 2;
-    const int cs_per_block = g.lds_waves ? 1 : 4;   // kernel 1L folds c / scalars per workgroup
+    const int cs_per_block = g.lds_waves ? 1 : 4 * g.cluster;   // kernel 1L folds c / scalars per workgroup; kernel 1QC: 4 per member
     if (!ctx->part.ensure((size_t)g.nblocks * NT * 256 * sizeof(double)) ||
         !ctx->cpart.ensure((size_t)g.nblocks * cs_per_block * g.NB * 16 * sizeof(double)) ||
         !ctx->spart.ensure((size_t)g.nblocks * cs_per_block * 4 * sizeof(double)))
@@ -630,6 +651,17 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
     hipEvent_t* evs;
     if ((rc = fit_events(ctx, &evs))) return rc;
     if (evs) FSNAP_HIP(hipEventRecord(evs[0], ctx->stream), "hipEventRecord");
+    if (g.quad && g.cluster > 1) {
+        const size_t need = (size_t)g.nblocks * 4 * sizeof(int);
+        if (ctx->quad_flow.bytes < need) {
+            if (!ctx->quad_flow.ensure(need)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(flow words) failed");
+            FSNAP_HIP(hipMemsetAsync(ctx->quad_flow.p, 0, ctx->quad_flow.bytes, ctx->stream), "hipMemset(flow words)");
+            ctx->quad_flow_tag = 0;
+        }
+        ctx->quad_flow_tag += 1 << 20;
+        a.flow_words = (int*)ctx->quad_flow.p;
+        a.flow_tag = ctx->quad_flow_tag | (ctx->opt_quad_flow & 0xFF);   // low byte: flow-control mode (2 bits) and lead (6 bits)
+    }
     if (g.quad) FSNAP_HIP(fsnap::launch_syrk_quad(a, ctx->stream), "launch fsnap_syrk_quad");
     else if (g.acc) FSNAP_HIP(fsnap::launch_syrk_acc(a, ctx->stream), "launch fsnap_syrk_acc");
     else if (g.packed) FSNAP_HIP(fsnap::launch_syrk_wave_p(a, ctx->stream), "launch fsnap_syrk_wave_p");
@@ -639,9 +671,8 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
     // K <= 128 and the context owns the output: the reduction also writes a page-locked host mirror, so the solve
     // needs no D2H copy (the copy's launch latency was 12 us of a 440 us step)
     double* mirror = nullptr;
-    // (a system the GPU factorises -- fsnap_solve_device_rhs's rule -- needs no mirror: 288 columns on kernel 1Q)
-    const bool device_factor = (ctx->K >= fsnap::DEVICE_CHOL_MIN_K || (ctx->K > 128 && ctx->opt_device_solve == 1)) && ctx->opt_device_solve != 2;
-    if (want_mirror && ctx->opt_mirror && !device_factor) {
+    // (a system the GPU factorises -- fsnap_solve_device_rhs's rule -- needs no mirror: DEVICE_CHOL_MIN_K columns and more)
+    if (want_mirror && ctx->opt_mirror && !device_factor(ctx, ctx->K)) {
         const size_t need = ((size_t)FSNAP_PACKED_LEN(ctx->K) + (size_t)ctx->K) * 8;   // + compact diagonal
         if (ctx->mirror_bytes < need) {
             if (ctx->mirror) (void)hipHostFree(ctx->mirror);
@@ -864,6 +895,13 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
     } else if (!strcmp(key, "quad")) {
         if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "quad must be 0 or 1");
         ctx->opt_quad = (int)value;
+    } else if (!strcmp(key, "quad_flow")) {
+        if (value < 0 || value > 255 || (value & 3) == 3)
+            return ctx->fail(FSNAP_E_ARG, "quad_flow = mode + 4 * lead: mode 0 (off), 1 (look at the end of a trip) or 2 (at its start), lead 0 ... 63 trips");
+        ctx->opt_quad_flow = (int)value;
+    } else if (!strcmp(key, "quad_cluster")) {
+        if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "quad_cluster must be 0 or 1");
+        ctx->opt_quad_cluster = (int)value;
     } else if (!strcmp(key, "quad_min_cpg")) {
         if (value < 0 || value > 4096) return ctx->fail(FSNAP_E_ARG, "quad_min_cpg out of range");
         ctx->opt_quad_min_cpg = (int)value;
@@ -1311,7 +1349,7 @@ int fsnap_mirror_packed(fsnap_ctx* ctx, const double* d_packed, int64_t K) {
     if (!ctx) return FSNAP_E_ARG;
     if (!d_packed || K <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_mirror_packed: bad argument");
     ctx->mirror_of = nullptr;
-    if ((K >= fsnap::DEVICE_CHOL_MIN_K && ctx->opt_device_solve != 2) || !ctx->opt_mirror) return FSNAP_OK;     // factorised on the GPU: nothing to mirror
+    if (device_factor(ctx, K) || !ctx->opt_mirror) return FSNAP_OK;     // factorised on the GPU: nothing to mirror
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     const size_t need = ((size_t)FSNAP_PACKED_LEN(K) + (size_t)K) * 8;
     if (ctx->mirror_bytes < need) {
@@ -1513,7 +1551,7 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
     // large systems: blocked Cholesky on the GPU (kernels 8a-8e); option device_solve = 2 disables it
     // (threshold and measurements: fsnap::DEVICE_CHOL_MIN_K; below it the host is faster: the panel kernels are latency-bound
     // launches)
-    if ((K >= fsnap::DEVICE_CHOL_MIN_K || (K > 128 && ctx->opt_device_solve == 1)) && ctx->opt_device_solve != 2) {
+    if (device_factor(ctx, K)) {
         const int n = (int)K, np = (n + 63) / 64 * 64, npanel = np / 64;
         const size_t head = (size_t)n + npanel + 1;            // [beta | min pivots | status]
         if (!ctx->dchol.ensure(fsnap::chol_large_work_doubles(n) * 8) || !ctx->dsolve.ensure((head + 2 * (size_t)np) * 8))
@@ -1881,7 +1919,7 @@ int fsnap_launch_info(fsnap_ctx* ctx, int64_t* info, int n) {
         out[2] = g.cpw;
         out[3] = g.NB;
         out[4] = g.split;
-        out[6] = g.quad ? 5 : g.acc ? 3 : (g.packed ? 4 : (g.lds_waves ? 2 : 1));
+        out[6] = g.quad ? (g.cluster > 1 ? 6 : 5) : g.acc ? 3 : (g.packed ? 4 : (g.lds_waves ? 2 : 1));
         out[7] = g.fused_pack ? 1 : 0;  // kernel id: 1 = wave-triangle, 2 = LDS-shared, 3 = one-wave triangle (1A), 4 = wave-triangle on packed weights (1P), 5 = triangle dealt to the four waves of a workgroup (1Q; chunks per WORKGROUP)
     }
     for (int i = 0; i < n; ++i) info[i] = out[i];

@@ -1322,7 +1322,7 @@ __global__ __launch_bounds__(256) void fsnap_chol_panel_k(double* __restrict__ S
 // Dynamic LDS: two buffers of [U11 64 x 65 | Uoff 64 x 65 | Y 4 x 16 x 17] + 2 x x_panel (64) + 2 x y_panel (64).
 constexpr int CHOL_BS_BUF = 2 * CHOL_NB * (CHOL_NB + 1) + 4 * 16 * 17;
 constexpr size_t CHOL_BS_LDS = (size_t)(2 * CHOL_BS_BUF + 4 * CHOL_NB) * sizeof(double);
-constexpr int CHOL_BS_MACRO = 8;             // panels per macro-block (4 until round 5: 13 instead of 7 launches at K = 1595)
+constexpr int CHOL_BS_MACRO = 4;             // panels per macro-block (8 measured slower: K = 1595 0.569 against 0.543 ms, profiles/r05_chol_large_k_sweep.txt)
 
 // y_r -= U[r, c0 : c1] x[c0 : c1] for the rows r < nrows; one wave per row, c1 - c0 a multiple of 128
 __global__ __launch_bounds__(256) void fsnap_chol_backupdate_k(const double* __restrict__ S, int ld, double* zv, int c0, int c1,

@@ -15,8 +15,10 @@ namespace fsnap {
 // From this order on fsnap_solve_device factorises on the GPU (blocked kernels 8a-8e), below it on the host.  Measured
 // (scripts/chol_large_test.py, round 4, EPYC 9575F host): K = 256 0.118 ms GPU / 0.130 host, 272 0.147 / 0.145, 288 0.147 /
 // 0.162, 320 0.147 / 0.203, 352 0.171 / 0.249, 384 0.171 / 0.357; 192 0.091 / 0.073.  (384 until round 4: the device chain was
-// 0.30 ms there when the threshold was set.)
-constexpr int64_t DEVICE_CHOL_MIN_K = 288;
+// 0.30 ms there when the threshold was set.)  Round 5 (one launch per panel, four-wave diagonal block): K = 192 0.076 ms GPU /
+// 0.066 host, 224 0.097 / 0.094, 256 0.096 / 0.131, 288 0.117 / 0.170, 320 0.117 / 0.204, 384 0.138 / 0.356 -- the padded order
+// (multiple of 64) sets the GPU's time, so the threshold sits at the first order of the 256 bucket the host no longer wins.
+constexpr int64_t DEVICE_CHOL_MIN_K = 232;
 
 // last error text of the calling thread when no context is at hand (fsnap_last_error(NULL))
 std::string& library_error();
@@ -88,6 +90,8 @@ struct fsnap_ctx {
     DevBuf ownw, ownmask, ones;
     // workspaces
     DevBuf part, cpart, spart, packed, beta, preds, sse, aw, bw;
+    DevBuf quad_flow;            // kernel 1QC: flow-control words of the clusters (zeroed when allocated, never reset)
+    int quad_flow_tag = 0;       // + 2^20 per launch of kernel 1QC
     DevBuf st_raw, st_plan, st_frac, st_blank;   // staging of fsnap_assemble
     DevBuf fz_rows, fz_spart, fz_part, fz_cpart; // fsnap_assemble_accumulate: per-row scratch (no A) and partials
     DevBuf dsolve;                                // [beta | min pivot | status] of fsnap_solve_device
@@ -120,8 +124,8 @@ struct fsnap_ctx {
     int opt_nsplit = 0;       // row splits of the tiled kernel (0 = auto)
     int opt_xcd = 1;          // tiled kernel: contiguous work-item ranges per XCD
     int opt_tiled2 = 0;       // K > 128: 1 = kernel 1T2 (one wave per SIMD, 32-tile items; measured no faster), 0 = kernel 1T
-    int opt_mirror = 1;       // fsnap_normal_eq_resident: reduction writes a page-locked host mirror (K <= 128)
-    int opt_device_solve = 0; // 0 = auto (K >= 384 on the GPU, blocked), 1 = every K (K <= 128: fsnap_chol_solve_k), 2 = never
+    int opt_mirror = 1;       // fsnap_normal_eq_resident / fsnap_mirror_packed: a page-locked host mirror of the statistics for every system the HOST factorises (K < DEVICE_CHOL_MIN_K)
+    int opt_device_solve = 0; // 0 = auto (K >= DEVICE_CHOL_MIN_K on the GPU, blocked kernels), 1 = every K (K <= 128: fsnap_chol_solve_k), 2 = never
     int opt_ablate = 0;       // timing-only ablation of kernel 1L (diagnostics; results are wrong)
     // cached launch plan of the tiled kernel (plan_tiled)
     bool tplan_valid = false;
@@ -164,6 +168,8 @@ struct fsnap_ctx {
     int opt_fused_pack = 1;   // kernel 1A forms the per-row pairs of its rows in LDS itself (no packing launch) when they fit
     int opt_acc_min_cpw = 0;  // kernel 1A: fewest 4-row chunks per row-wave before the grid shrinks (0 = default)
     int opt_chol_form = -1;   // panel loop of the device Cholesky: -1 = default (FSNAP_CHOL_DIAG, else 5: one launch per panel, four-wave diagonal block); 0 | 1 | 2 | 4: the A/B forms (fsnap_chol.hip)
+    int opt_quad_flow = 2 + 4 * 2;   // kernel 1QC: flow control between the members of a cluster: mode (0 off, 1 look at the end of a trip, 2 at its start) + 4 x lead (trips a member may run ahead)
+    int opt_quad_cluster = 1; // kernel 1QC (288 < K <= 512: kernel 1Q's plan on a cluster of 2 / 4 workgroups of one XCD); 0 = tiled kernel there
     int opt_quad = 1;         // kernel 1Q (144 < K <= 288: the triangle dealt to the four waves of a workgroup); 0 = tiled kernel there
     int64_t opt_quad_min_rows = -1;   // fewest rows for kernel 1Q (-1 = default)
     int opt_quad_min_cpg = 0;         // kernel 1Q: fewest 4-row chunks per workgroup before the grid shrinks (0 = default)

@@ -25,6 +25,8 @@ struct SyrkArgs {
     double* spart;              // [nblocks*4][4]
     const double* wpack = nullptr;  // kernel 1A: packed (w_eff, w_eff * b) per row (launch_pack_weights)
     bool interleave = false;        // kernel 1P: row-waves take every NW-th chunk instead of a contiguous range
+    int* flow_words = nullptr;      // kernel 1QC: flow-control words, 4 ints per cluster (zero once, never reset)
+    int flow_tag = 0;               // kernel 1QC: + 2^20 per launch
     bool fused_pack = false;        // kernels 1A / 1P: the kernel packs (w_eff, w_eff b) of its rows into LDS itself (b, w, mask,
                                     // spart instead of wpack; needs chunks_per_wave <= syrk_acc_max_fused_cpw())
 };
@@ -62,6 +64,9 @@ hipError_t launch_syrk_acc(const SyrkArgs& a, hipStream_t st);
 // chunks per workgroup <= syrk_quad_max_cpg()) formed by the kernel
 hipError_t launch_syrk_quad(const SyrkArgs& a, hipStream_t st);
 int64_t syrk_quad_max_cpg();
+// workgroups per cluster for K columns: 1 = kernel 1Q (K <= 288), 2 / 4 = kernel 1QC (289 ... 512 columns; a.nblocks = clusters,
+// a.chunks_per_wave = chunks per cluster, fused packing only)
+int syrk_quad_cluster(int K);
 int64_t syrk_acc_max_fused_cpw();
 int64_t syrk_wave_p_max_fused_cpw(int K, int wg_per_cu);   // kernel 1P: same for its (smaller, shared) LDS budget
 // mirror: optional page-locked HOST buffer that receives the same packed statistics (zero-copy D2H)

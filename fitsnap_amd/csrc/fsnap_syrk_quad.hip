@@ -48,7 +48,41 @@ constexpr int QUAD_ROWS[9][4][9] = {
 };
 
 constexpr int QUAD_MAXT = 43;
-constexpr int QUAD_MAXNB = 18;
+constexpr int QUAD_MAXNB = 32;
+constexpr int QUAD_MAXW = 16;
+
+// Kernel 1QC (round 5): 289 ... 512 columns (NB = 19 ... 32: 190 ... 528 tiles) do not fit the accumulators of one
+// workgroup.  The same plan on a CLUSTER of workgroups placed on one XCD -- 2 workgroups (8 waves) up to 23 column blocks (at most 38 tiles per wave),
+// 4 workgroups (16 waves) beyond: whole tile rows dealt to the 4 C waves, the longest row first to the least loaded wave.
+__host__ __device__ constexpr int quad_cluster(int NB) { return NB <= 18 ? 1 : (NB <= 23 ? 2 : 4); }
+__host__ __device__ constexpr int quad_waves(int NB) { return 4 * quad_cluster(NB); }
+
+struct QuadDeal {
+    int r[QUAD_MAXW][9];     // tile rows of every wave, ascending, -1 ends a list
+};
+
+constexpr QuadDeal quad_deal(int NB) {
+    QuadDeal D{};
+    const int NW = quad_waves(NB);
+    for (int v = 0; v < QUAD_MAXW; ++v)
+        for (int i = 0; i < 9; ++i) D.r[v][i] = -1;
+    if (NB <= 18) {
+        for (int v = 0; v < 4; ++v)
+            for (int i = 0; i < 9; ++i) D.r[v][i] = QUAD_ROWS[NB - 10][v][i];
+        return D;
+    }
+    int load[QUAD_MAXW] = {};
+    int cnt[QUAD_MAXW] = {};
+    for (int p = 0; p < NB; ++p) {          // row lengths NB - p descend: longest processing time first
+        int best = 0;
+        for (int v = 1; v < NW; ++v)
+            if (load[v] < load[best]) best = v;
+        if (cnt[best] < 9) D.r[best][cnt[best]] = p;
+        cnt[best] += 1;
+        load[best] += NB - p;
+    }
+    return D;
+}
 
 struct QuadPlan {
     int n;                  // tiles of this wave
@@ -60,33 +94,39 @@ struct QuadPlan {
 
 constexpr QuadPlan quad_plan(int NB, int w) {
     QuadPlan P{};
-    const int(&rows)[9] = QUAD_ROWS[NB - 10][w];
+    const QuadDeal DL = quad_deal(NB);
+    const int(&rows)[9] = DL.r[w];
     int n = 0;
     P.jmin = rows[0];
     for (int i = 0; i < 9 && rows[i] >= 0; ++i) {
         const int p = rows[i];
         const int pnext = (i + 1 < 9 && rows[i + 1] >= 0) ? rows[i + 1] : NB;
         for (int q = p; q < NB; ++q) {
-            P.tp[n] = p;
-            P.tq[n] = q;
-            P.rf_lo[n] = 0;
-            P.rf_hi[n] = 0;
+            if (n < QUAD_MAXT) {
+                P.tp[n] = p;
+                P.tq[n] = q;
+                P.rf_lo[n] = 0;
+                P.rf_hi[n] = 0;
+            }
             ++n;
         }
-        P.rf_lo[n - 1] = p;
-        P.rf_hi[n - 1] = pnext;
+        if (n <= QUAD_MAXT) {
+            P.rf_lo[n - 1] = p;
+            P.rf_hi[n - 1] = pnext;
+        }
     }
     P.n = n;
     // c: column block j goes to the wave with the least VALU work so far among those that hold it (jmin <= j)
-    int load[4] = {0, 0, 0, 0};
-    int jm[4] = {0, 0, 0, 0};
-    for (int v = 0; v < 4; ++v) {
-        jm[v] = QUAD_ROWS[NB - 10][v][0];
+    const int NW = quad_waves(NB);
+    int load[QUAD_MAXW] = {};
+    int jm[QUAD_MAXW] = {};
+    for (int v = 0; v < NW; ++v) {
+        jm[v] = DL.r[v][0];
         load[v] = NB - jm[v];
     }
     for (int j = NB - 1; j >= 0; --j) {
         int best = -1;
-        for (int v = 3; v >= 0; --v)
+        for (int v = NW - 1; v >= 0; --v)
             if (jm[v] <= j && (best < 0 || load[v] < load[best])) best = v;
         load[best] += 1;
         P.cown[j] = (best == w) ? 1 : 0;
@@ -97,9 +137,10 @@ constexpr QuadPlan quad_plan(int NB, int w) {
 constexpr bool quad_plans_cover(int NB) {
     int seen[QUAD_MAXNB * (QUAD_MAXNB + 1) / 2] = {};
     int mx = 0, mn = 1000;
-    for (int w = 0; w < 4; ++w) {
+    const int NW = quad_waves(NB);
+    for (int w = 0; w < NW; ++w) {
         const QuadPlan P = quad_plan(NB, w);
-        if (P.n > QUAD_MAXT) return false;
+        if (P.n > QUAD_MAXT || P.n < 1) return false;
         mx = P.n > mx ? P.n : mx;
         mn = P.n < mn ? P.n : mn;
         for (int i = 0; i < P.n; ++i) seen[quad_tri_index(P.tp[i], P.tq[i], NB)] += 1;
@@ -108,11 +149,16 @@ constexpr bool quad_plans_cover(int NB) {
     }
     for (int t = 0; t < NB * (NB + 1) / 2; ++t)
         if (seen[t] != 1) return false;
-    return mx - mn <= 2;
+    // one workgroup: the four counts within two of each other; a cluster: no wave above the accumulators + 8 tiles in VGPRs
+    return NW == 4 ? mx - mn <= 2 : mx <= 40;
 }
 static_assert(quad_plans_cover(10) && quad_plans_cover(11) && quad_plans_cover(12) && quad_plans_cover(13) &&
                   quad_plans_cover(14) && quad_plans_cover(15) && quad_plans_cover(16) && quad_plans_cover(17) && quad_plans_cover(18),
               "every tile of the triangle belongs to exactly one wave");
+static_assert(quad_plans_cover(19) && quad_plans_cover(20) && quad_plans_cover(21) && quad_plans_cover(22) &&
+                  quad_plans_cover(23) && quad_plans_cover(24) && quad_plans_cover(25) && quad_plans_cover(26) && quad_plans_cover(27) &&
+                  quad_plans_cover(28) && quad_plans_cover(29) && quad_plans_cover(30) && quad_plans_cover(31) && quad_plans_cover(32),
+              "every tile of the triangle belongs to exactly one wave of the cluster");
 
 template <int NB, int W>
 struct QuadPlanOf {
@@ -282,10 +328,62 @@ __device__ __forceinline__ void quad_step(double (&V)[NB], d4 (&vt)[NV], QuadRaw
     });
 }
 
-template <int NB, int W, bool FULLK, bool PACK>
+// Flow control of a cluster (kernel 1QC): the workgroups of a cluster sweep the SAME rows, each for its share of the tile
+// triangle; HBM should see a row once and the XCD's L2 (4 MiB for up to 16 clusters) serve the other reads, so no member
+// may run more than `lead` trips (of six 4-row chunks) ahead of the slowest.  Wave 3 of every member (never the wave that owns tile row 0, the longest) publishes its trip
+// count (+ the launch's tag: the words are never reset) and waits -- BOUNDED: this is a hint for the cache, nothing depends
+// on it; a member that gives up simply streams on -- before the trip's barrier releases its workgroup.
+struct QuadFlow {
+    int* word;              // this cluster's words: one per member
+    int members, me, tag;
+    int lead;               // trips a member may run ahead of the slowest
+    int mode;               // 0 = no flow control, 1 = publish + look at the end of a trip, 2 = publish + look at the START of the
+                            // trip, judge at its end (the three device-scope round trips run beside the trip's MFMAs)
+};
+constexpr int QUAD_FLOW_SPINS = 4096;        // x s_sleep 2 (~130 cycles) ~ 0.2 ms per trip at most
+
+struct QuadSeen {
+    int p[3];
+};
+
+// lane 0 of wave 0 of a member: publish "trip `trip` done", note where the peers stand (relaxed device-scope loads: L2)
+__device__ __forceinline__ QuadSeen quad_flow_look(const QuadFlow& f, int trip, int lane) {
+    QuadSeen s;
+    s.p[0] = s.p[1] = s.p[2] = 0x7FFFFFFF;
+    if (lane == 0) {
+        __hip_atomic_store(f.word + f.me, f.tag + trip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int peer = (f.me + 1 + k) & 3;
+            if (peer < f.members && peer != f.me) s.p[k] = __hip_atomic_load(f.word + peer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    return s;
+}
+
+// ... and wait (bounded) for every peer that stood more than `lead` trips behind `trip`
+__device__ __forceinline__ void quad_flow_wait(const QuadFlow& f, const QuadSeen& s, int trip, int lane) {
+    if (lane == 0) {
+        const int need = f.tag + trip - f.lead;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int peer = (f.me + 1 + k) & 3;
+            if (peer >= f.members || peer == f.me) continue;
+            // (a word of an EARLIER launch compares below `need`: tags grow by 2^20 per launch; wrap-around is harmless --
+            // a wrong verdict only ends or prolongs a bounded wait)
+            int v = s.p[k], n = 0;
+            while (v - need < 0 && ++n < QUAD_FLOW_SPINS) {
+                __builtin_amdgcn_s_sleep(2);
+                v = __hip_atomic_load(f.word + peer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+template <int NB, int W, bool FULLK, bool PACK, bool FLOW = false>
 __device__ __forceinline__ void quad_wave(const double* __restrict__ A, int64_t lda, const double* __restrict__ wpack, int K,
                                           int64_t row0, int64_t nrow, unsigned ncl, const double* lpk, double* __restrict__ pw,
-                                          double* __restrict__ cw, int lane) {
+                                          double* __restrict__ cw, int lane, const QuadFlow* flow = nullptr) {
     using PL = QuadPlanOf<NB, W>;
     constexpr int JMIN = PL::P.jmin, NTW = PL::P.n;
     constexpr int PR0 = JMIN >> 1;
@@ -343,12 +441,19 @@ __device__ __forceinline__ void quad_wave(const double* __restrict__ A, int64_t 
         // without it, 1.0 x with it.  A bare s_barrier: no wait for the loads in flight; every wave runs the same number of trips.
         if constexpr (DEPTH == 3) {
             for (; cl + 3 < ncl; cl += 6) {
+                QuadSeen seen{};
+                if constexpr (FLOW && (W & 3) == 3)
+                    if (flow->mode == 2) seen = quad_flow_look(*flow, (int)(cl / 6), lane);
                 quad_step<NB, W, FULLK, PACK>(V, vt, r0, r1, wb, lpk, cl + 3, K, e, cacc, pk1, pk3, pk5);
                 quad_step<NB, W, FULLK, PACK>(V, vt, r1, r2, wb, lpk, cl + 4, K, e, cacc, pk2, pk4, pk0);
                 quad_step<NB, W, FULLK, PACK>(V, vt, r2, r0, wb, lpk, cl + 5, K, e, cacc, pk3, pk5, pk1);
                 quad_step<NB, W, FULLK, PACK>(V, vt, r0, r1, wb, lpk, cl + 6, K, e, cacc, pk4, pk0, pk2);
                 quad_step<NB, W, FULLK, PACK>(V, vt, r1, r2, wb, lpk, cl + 7, K, e, cacc, pk5, pk1, pk3);
                 quad_step<NB, W, FULLK, PACK>(V, vt, r2, r0, wb, lpk, cl + 8, K, e, cacc, pk0, pk2, pk4);
+                if constexpr (FLOW && (W & 3) == 3) {
+                    if (flow->mode == 1) seen = quad_flow_look(*flow, (int)(cl / 6) + 1, lane);
+                    if (flow->mode) quad_flow_wait(*flow, seen, (int)(cl / 6) + (flow->mode == 1 ? 1 : 0), lane);
+                }
                 if (QUAD_SYNC) __builtin_amdgcn_s_barrier();
             }
             if (cl < ncl) {
@@ -358,12 +463,19 @@ __device__ __forceinline__ void quad_wave(const double* __restrict__ A, int64_t 
             }
         } else {
             for (; cl + 3 < ncl; cl += 6) {
+                QuadSeen seen{};
+                if constexpr (FLOW && (W & 3) == 3)
+                    if (flow->mode == 2) seen = quad_flow_look(*flow, (int)(cl / 6), lane);
                 quad_step<NB, W, FULLK, PACK>(V, vt, r0, r1, wb, lpk, cl + 2, K, e, cacc, pk1, pk2, pk4);
                 quad_step<NB, W, FULLK, PACK>(V, vt, r1, r0, wb, lpk, cl + 3, K, e, cacc, pk2, pk3, pk5);
                 quad_step<NB, W, FULLK, PACK>(V, vt, r0, r1, wb, lpk, cl + 4, K, e, cacc, pk3, pk4, pk0);
                 quad_step<NB, W, FULLK, PACK>(V, vt, r1, r0, wb, lpk, cl + 5, K, e, cacc, pk4, pk5, pk1);
                 quad_step<NB, W, FULLK, PACK>(V, vt, r0, r1, wb, lpk, cl + 6, K, e, cacc, pk5, pk0, pk2);
                 quad_step<NB, W, FULLK, PACK>(V, vt, r1, r0, wb, lpk, cl + 7, K, e, cacc, pk0, pk1, pk3);
+                if constexpr (FLOW && (W & 3) == 3) {
+                    if (flow->mode == 1) seen = quad_flow_look(*flow, (int)(cl / 6) + 1, lane);
+                    if (flow->mode) quad_flow_wait(*flow, seen, (int)(cl / 6) + (flow->mode == 1 ? 1 : 0), lane);
+                }
                 if (QUAD_SYNC) __builtin_amdgcn_s_barrier();
             }
             if (cl < ncl) {
@@ -487,6 +599,122 @@ fsnap_syrk_quad(const double* __restrict__ A, int64_t lda, const double* __restr
     }
 }
 
+// Kernel 1QC: kernel 1Q's plan on a cluster of C = quad_cluster(NB) workgroups (NB = 19 ... 32 column blocks: 289 ... 512
+// columns).  Grid: 8 C clusters-per-XCD slots -- block b runs on XCD b % 8 (observed placement, used for speed only): member c
+// of cluster (j, x) is block x + 8 (c + C j), so the members of a cluster share an L2.  Every member forms the per-row pairs
+// of the cluster's rows in ITS LDS (17 bytes per row against 8 K: nothing), member 0 alone reports the b-only scalars.
+// Partials in kernel 1Q's layout with "workgroup" read as "cluster": part[cluster][NT][4][64] (every tile written by the one
+// wave of the cluster that owns it), cpart[cluster * 4 C + wave][NB][16], spart[cluster * 4 C + wave][4]; kernel 2b reduces
+// them with cs_per_block = 4 C.  Always the select form of the last column block (FULLK = false) and fused packing.
+template <int NB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void
+fsnap_syrk_quadc(const double* __restrict__ A, int64_t lda, int64_t m, int K, int64_t chunks_per_cluster, int nclusters,
+                 double* __restrict__ part, double* __restrict__ cpart, const double* __restrict__ bvec,
+                 const double* __restrict__ wvec, const unsigned char* __restrict__ mask, double* __restrict__ spart,
+                 int* __restrict__ flow_words, int flow_tag) {
+    constexpr int NTILE = NB * (NB + 1) / 2;
+    constexpr int C = quad_cluster(NB), NW = 4 * C;
+    __shared__ __attribute__((aligned(16))) double lds[QUAD_LDS_DOUBLES];
+    const int lane = threadIdx.x & 63;
+    const int rw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
+    const int member = slot % C, cluster = (slot / C) * 8 + xcd;
+    if (cluster >= nclusters) return;
+    const int64_t nchunks = (m + 3) >> 2;
+    int64_t c0 = (int64_t)cluster * chunks_per_cluster;
+    int64_t c1 = c0 + chunks_per_cluster;
+    if (c1 > nchunks) c1 = nchunks;
+    if (c0 > c1) c0 = c1;
+    const int64_t row0 = c0 << 2;
+    int64_t row1 = c1 << 2;
+    if (row1 > m) row1 = m;
+    const int64_t nrow = row1 > row0 ? row1 - row0 : 0;
+    const unsigned ncl = (unsigned)(c1 - c0);
+    const int W = 4 * member + rw;
+
+    // prologue (kernel 1Q's): (w_eff, w_eff b) of the cluster's rows -> this member's LDS; the b-only scalars from member 0
+    {
+        const unsigned wg_rows = (unsigned)chunks_per_cluster * 4u;
+        const unsigned region_rows = wg_rows + QUAD_PACK_PAD * 4u;
+        const __amdgpu_buffer_rsrc_t rb = quad_rsrc(bvec + row0, (unsigned)(nrow * 8));
+        const __amdgpu_buffer_rsrc_t rw_ = quad_rsrc(wvec + row0, (unsigned)(nrow * 8));
+        const __amdgpu_buffer_rsrc_t rm = quad_rsrc(mask + row0, (unsigned)nrow);
+        constexpr int PB = 8;
+        double bb = 0.0, sb = 0.0, cnt = 0.0;
+        for (unsigned r0 = 0; r0 < region_rows; r0 += 256u * PB) {
+            u2 bv[PB], wv[PB];
+            unsigned char mk[PB];
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const unsigned row = r0 + 256u * u + threadIdx.x;
+                bv[u] = __builtin_amdgcn_raw_buffer_load_b64(rb, row * 8u, 0, 0);
+                wv[u] = __builtin_amdgcn_raw_buffer_load_b64(rw_, row * 8u, 0, 0);
+                mk[u] = __builtin_amdgcn_raw_buffer_load_b8(rm, row, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const unsigned row = r0 + 256u * u + threadIdx.x;
+                const bool keep = (mk[u] != 0);
+                const double wvv = keep ? __builtin_bit_cast(double, wv[u]) : 0.0;
+                const double wbv = keep ? wvv * __builtin_bit_cast(double, bv[u]) : 0.0;
+                if (row < region_rows) {
+                    d2 o;
+                    o[0] = wvv;
+                    o[1] = wbv;
+                    *reinterpret_cast<d2*>(lds + (size_t)row * 2) = o;
+                }
+                bb = __builtin_fma(wbv, wbv, bb);
+                sb += wbv;
+                cnt += keep ? 1.0 : 0.0;
+            }
+        }
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) {       // fixed butterfly: deterministic
+            bb += __shfl_xor(bb, sh, 64);
+            sb += __shfl_xor(sb, sh, 64);
+            cnt += __shfl_xor(cnt, sh, 64);
+        }
+        if (lane == 0) {
+            double* so = spart + ((int64_t)cluster * NW + W) * 4;
+            const bool rep = member == 0;
+            so[0] = rep ? bb : 0.0;
+            so[1] = rep ? sb : 0.0;
+            so[2] = rep ? cnt : 0.0;
+            so[3] = 0.0;
+        }
+        __syncthreads();
+    }
+
+    asm volatile("" : : : "a0", "a255");
+    quad_zero_all(std::make_integer_sequence<int, 256>{});
+    double* pw = part + (int64_t)cluster * (int64_t)(NTILE * 256);
+    double* cw = cpart + ((int64_t)cluster * NW + W) * (int64_t)(NB * 16);
+    QuadFlow flow;
+    flow.word = flow_words + (int64_t)cluster * 4;
+    flow.members = C;
+    flow.me = member;
+    flow.tag = flow_tag & ~0xFF;
+    flow.mode = flow_tag & 3;
+    flow.lead = (flow_tag >> 2) & 63;
+#define FSNAP_QC_CASE(WV) \
+    case WV: quad_wave<NB, WV, false, true, true>(A, lda, nullptr, K, row0, nrow, ncl, lds, pw, cw, lane, &flow); break;
+    switch (W) {
+        FSNAP_QC_CASE(0) FSNAP_QC_CASE(1) FSNAP_QC_CASE(2) FSNAP_QC_CASE(3) FSNAP_QC_CASE(4) FSNAP_QC_CASE(5) FSNAP_QC_CASE(6)
+        default:
+            if constexpr (C == 2) {
+                quad_wave<NB, 7, false, true, true>(A, lda, nullptr, K, row0, nrow, ncl, lds, pw, cw, lane, &flow);
+            } else {
+                switch (W) {
+                    FSNAP_QC_CASE(7) FSNAP_QC_CASE(8) FSNAP_QC_CASE(9) FSNAP_QC_CASE(10) FSNAP_QC_CASE(11) FSNAP_QC_CASE(12)
+                    FSNAP_QC_CASE(13) FSNAP_QC_CASE(14)
+                    default: quad_wave<NB, (C == 4 ? 15 : 7), false, true, true>(A, lda, nullptr, K, row0, nrow, ncl, lds, pw, cw, lane, &flow); break;
+                }
+            }
+            break;
+    }
+#undef FSNAP_QC_CASE
+}
+
 namespace fsnap {
 
 // chunks per workgroup up to which the workgroup's per-row pairs fit the LDS next to the look-ahead pad
@@ -511,6 +739,20 @@ static hipError_t launch_syrk_quad_nb(const SyrkArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// kernel 1QC (NB = 19 ... 32): a.nblocks CLUSTERS of quad_cluster(NB) workgroups, a.chunks_per_wave = chunks per cluster,
+// a.flow_words (4 ints per cluster, zero-initialised once, never reset) and a.flow_tag (+ 2^20 per launch)
+template <int NB>
+static hipError_t launch_syrk_quadc_nb(const SyrkArgs& a, hipStream_t st) {
+    constexpr int C = quad_cluster(NB);
+    if (!a.b || !a.w || !a.mask || !a.spart || !a.flow_words || a.chunks_per_wave > syrk_quad_max_cpg()) return hipErrorInvalidValue;
+    const unsigned per_xcd = (unsigned)((a.nblocks + 7) / 8) * C;
+    hipLaunchKernelGGL((fsnap_syrk_quadc<NB>), dim3(8 * per_xcd), dim3(256), 0, st, a.A, a.lda, a.m, a.K, a.chunks_per_wave,
+                       (int)a.nblocks, a.part, a.cpart, a.b, a.w, a.mask, a.spart, a.flow_words, a.flow_tag);
+    return hipGetLastError();
+}
+
+int syrk_quad_cluster(int K) { return quad_cluster((K + 15) / 16); }
+
 // kernel 1Q: a.nblocks workgroups, a.chunks_per_wave = 4-row chunks per WORKGROUP (its four waves sweep the same rows);
 // a.fused_pack: the kernel forms the per-row pairs itself (b, w, mask, spart), otherwise it reads a.wpack
 hipError_t launch_syrk_quad(const SyrkArgs& a, hipStream_t st) {
@@ -524,6 +766,20 @@ hipError_t launch_syrk_quad(const SyrkArgs& a, hipStream_t st) {
         case 16: return launch_syrk_quad_nb<16>(a, st);
         case 17: return launch_syrk_quad_nb<17>(a, st);
         case 18: return launch_syrk_quad_nb<18>(a, st);
+        case 19: return launch_syrk_quadc_nb<19>(a, st);
+        case 20: return launch_syrk_quadc_nb<20>(a, st);
+        case 21: return launch_syrk_quadc_nb<21>(a, st);
+        case 22: return launch_syrk_quadc_nb<22>(a, st);
+        case 23: return launch_syrk_quadc_nb<23>(a, st);
+        case 24: return launch_syrk_quadc_nb<24>(a, st);
+        case 25: return launch_syrk_quadc_nb<25>(a, st);
+        case 26: return launch_syrk_quadc_nb<26>(a, st);
+        case 27: return launch_syrk_quadc_nb<27>(a, st);
+        case 28: return launch_syrk_quadc_nb<28>(a, st);
+        case 29: return launch_syrk_quadc_nb<29>(a, st);
+        case 30: return launch_syrk_quadc_nb<30>(a, st);
+        case 31: return launch_syrk_quadc_nb<31>(a, st);
+        case 32: return launch_syrk_quadc_nb<32>(a, st);
         default: return hipErrorInvalidValue;
     }
 }

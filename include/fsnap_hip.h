@@ -80,7 +80,7 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * general-K tiled kernel also for K <= 128), "nsplit" (row splits of the tiled kernel), "mirror" (0|1, see fsnap_normal_eq_resident), "xcd" (0|1: tiled kernel deals contiguous work-item ranges to each XCD), "tiled2" (0|1: K > 128 on the one-wave-per-SIMD kernel with 64 x 128-column work items, default 0),
  * "tiled_ring" (0 ... 3, default 3: bit 0 / bit 1 put the diagonal / off-diagonal work items of the tiled kernel on the ring form of its
  * load pipeline; 0 = the three-set form of round 2, for A/B runs -- same bits either way),
- * "device_solve" (fsnap_solve_device: 0 = auto: K >= 288 is factorised on the GPU by the blocked kernels; 1 = every K on the GPU; 2 = never),
+ * "device_solve" (fsnap_solve_device: 0 = auto: K >= 232 is factorised on the GPU by the blocked kernels; 1 = every K on the GPU; 2 = never),
  * "chol_form" (panel loop of that GPU factorisation: -1 = default -- the FSNAP_CHOL_DIAG environment variable, else 5; 5 = ONE launch
  * per 64-row panel, every wave substituting the row tails it needs itself, diagonal block on four waves; 4 = two launches per panel,
  * four-wave diagonal block; 0 | 1 | 2 = two launches per panel, single-wave diagonal block with pivot chain 0 / 1 / 2 (rounds 2-4); A/B),
@@ -102,6 +102,13 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * the same rows, fsnap_syrk_quad.hip -- when the system has at least "quad_min_rows" rows (-1 = default 8192) and a workgroup's per-row
  * pairs fit the LDS (up to ~2.6 M rows; beyond, the pairs are packed into HBM first); 0 = the tiled kernel there, A/B;
  * "quad_min_cpg": fewest 4-row chunks per workgroup of that kernel before its grid shrinks, 0 = default 24, tuning aid),
+ * "quad_cluster" (0|1, default 1: 289 ... 512 columns go to kernel 1QC -- kernel 1Q's plan on a cluster of 2 (up to 368 columns) or 4
+ * workgroups placed on one XCD, which sweep the same rows behind a bounded flow-control counter so that HBM sees every row once --
+ * when the rows' pairs fit the LDS (fused packing, up to ~650 000 rows on 256 CUs) and the system has at least 300 000 rows
+ * ("quad_min_rows" overrides; shorter systems are faster on the tiled kernel); 0 = the tiled kernel there, A/B;
+ * "quad_flow" = mode + 4 x lead: that kernel's flow control between the workgroups of a cluster -- mode 0 off (1.8 x the
+ * algorithmic HBM reads at 367 900 x 480, 2 % faster), 1 = every member publishes its trip count and looks at its peers at the end
+ * of a trip, 2 (default) = at the start of the trip, judged at its end; lead (default 2) = trips a member may run ahead),
  * "acc_max_k" (144 | 128: widest system on the accumulator-resident kernel; 128 sends 129 ... 144 columns to the tiled kernel, A/B),
  * "reduce" (0 = reduction kernel 2b with every load of a thread in flight, the default; 1 = its predecessor, A/B),
  * "mirror_upper" (0|1, default 1: the reduction writes the host mirror's triangle once per element, at its upper position),
@@ -235,7 +242,7 @@ int fsnap_normal_eq_resident(fsnap_ctx* ctx, double** d_packed);
 /* Mirror packed statistics that live in device memory (e.g. the buffer a RCCL all-reduce just summed over the ranks,
  * the reference's comm.Allreduce(c), comm.Allreduce(d) in examples/library/transpose_trick/example.py:245-246) into
  * the context's page-locked host mirror; asynchronous (a small copy kernel + an event on the context's stream).  A
- * following fsnap_solve_device on the same pointer then needs no D2H copy.  No-op for K >= 288 (those are factorised
+ * following fsnap_solve_device on the same pointer then needs no D2H copy.  No-op for K >= 232 (those are factorised
  * on the GPU).  The caller must not modify the buffer between this call and the solve. */
 int fsnap_mirror_packed(fsnap_ctx* ctx, const double* d_packed, int64_t K);
 
@@ -286,7 +293,7 @@ int fsnap_lasso_gram(int64_t K, const double* Q, const double* q, double y_norm2
 /* Same solve, taking the packed statistics [G | c | ...] from DEVICE memory (the buffer
  * fsnap_normal_eq_async / the all-reduce left in HBM).  Small systems are copied to the host
  * (page-locked staging) and solved there (faster than any GPU factorisation of a 128-step recurrence); for
- * K >= 288 (option "device_solve") a blocked Cholesky runs on the GPU and only beta crosses PCIe, provided the
+ * K >= 232 (option "device_solve") a blocked Cholesky runs on the GPU and only beta crosses PCIe, provided the
  * system is well conditioned after Jacobi scaling -- otherwise the general host path decides.  Same status codes and semantics as fsnap_solve. */
 int fsnap_solve_device(fsnap_ctx* ctx, int kind, double param, int64_t K, const double* d_packed, double* beta,
                        int* rank, double* rcond_est);

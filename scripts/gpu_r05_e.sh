@@ -1,0 +1,37 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r05_e
+mkdir -p $O
+export TMPDIR=/tmp
+cd $R
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "cluster_quad" > $O/pytest_cluster.txt 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_cluster.txt
+B="timeout 300 python bench.py --no-cpu-baseline --svd-solver 0 --pipelined 0"
+for shape in "367900 480" "500000 368"; do set -- $shape
+  for fl in 0 1 2; do
+  $B --rows $1 --cols $2 --steps 20 --warmup 3 --preheat 100 --option quad_flow=$fl > $O/bench_$1x$2_flow$fl.json 2>> $O/bench.err
+  python - <<PY
+import json
+try:
+    d=json.loads(open("$O/bench_$1x$2_flow$fl.json").read()); r=d["roofline"]
+    print("$1x$2 flow $fl", "ms/step %.4f" % d["ms_per_step"], "kernel", r.get("kernel"), "%.4f ms" % r.get("kernel_ms_avg", 0), "frac %.3f" % r["frac"], "reduce", r.get("reduce_kernel_ms_avg"))
+except Exception as e: print("$1x$2", "$fl", "failed", e)
+PY
+  done
+done
+cd /tmp
+SB="python $R/bench.py --rows 367900 --cols 480 --steps 4 --warmup 1 --preheat 20 --no-cpu-baseline --svd-solver 0 --pipelined 0"
+for fl in 0 2; do
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_flow$fl -o pmc -- $SB --option quad_flow=$fl > $O/pmc_flow$fl.log 2>&1
+python - <<PY
+import csv,glob
+for f in glob.glob("$O/pmc_flow$fl/**/*counter_collection.csv", recursive=True):
+    tot={}; cnt={}
+    for row in csv.DictReader(open(f)):
+        k=row["Kernel_Name"][:40]
+        if row["Counter_Name"]=="FETCH_SIZE":
+            tot[k]=tot.get(k,0)+float(row["Counter_Value"]); cnt[k]=cnt.get(k,0)+1
+    for k in tot:
+        if "syrk" in k: print("flow $fl", k, "FETCH_SIZE per launch (KB)", tot[k]/cnt[k], "-> x2 x1024 = %.3f GB" % (tot[k]/cnt[k]*2*1024/1e9))
+PY
+done
+find $O -name "*.db" -delete

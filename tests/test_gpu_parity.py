@@ -100,6 +100,52 @@ def test_quad_kernel_statistics_all_column_block_shapes(qctx, K):
     stats_close(G, c, s, *orc.normal_eq(A, b, w, t))
 
 
+@pytest.mark.parametrize("K", [289, 300, 304, 305, 320, 321, 336, 337, 352, 353, 368, 369, 384, 385, 400, 401, 416, 417, 432, 433,
+                               448, 449, 464, 465, 479, 480, 481, 496, 497, 511, 512])
+def test_cluster_quad_kernel_statistics_all_column_block_shapes(qctx, K):
+    # kernel 1QC, NB = 19 ... 32: kernel 1Q's plan on a cluster of 2 (up to 23 column blocks) or 4 workgroups of one XCD --
+    # odd / even block counts, K a multiple of 16 and not, the last block nearly empty; ragged row ranges per cluster;
+    # rows of the testing set and tiny / huge weights as in the reference's weighting (svd.py:35-46)
+    rng = np.random.default_rng(K)
+    m = 9151 + 13 * K
+    A = rng.standard_normal((m, K)) * (10.0 ** rng.uniform(-3, 3, size=K))
+    b = rng.standard_normal(m)
+    w = rng.choice([100.0, 1.0, 1e-8], size=m, p=[0.03, 0.83, 0.14])
+    t = rng.random(m) < 0.2
+    G, c, s = run_stats(qctx, A, b, w, t)
+    info = qctx.launch_info()
+    assert info["kernel_or_pairs"] == 6 and info["NB"] == (K + 15) // 16
+    stats_close(G, c, s, *orc.normal_eq(A, b, w, t))
+    # the tiled kernel (option quad_cluster = 0) on the same rows: same statistics to rounding
+    qctx.set_option("quad_cluster", 0)
+    try:
+        G2, c2, s2 = run_stats(qctx, A, b, w, t)
+        assert qctx.launch_info()["kernel_or_pairs"] != 6
+    finally:
+        qctx.set_option("quad_cluster", 1)
+    stats_close(G2, c2, s2, G, c, s)
+
+
+@pytest.mark.parametrize("K,m", [(480, 367900), (320, 200003)])
+def test_cluster_quad_kernel_is_bit_identical_run_to_run_and_fits_like_the_oracle(ctx, K, m):
+    # InP's width (examples/InP_JPCA2020: 367 900 x 480) at full size: fixed-order sums -> the same bits on every launch (the
+    # flow control between the members of a cluster only paces them); fit through the C ABI vs a dense solve of the oracle's
+    # statistics
+    A, b, w = orc.synth_problem(m, K)
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w)
+    first = ctx.normal_eq()
+    assert ctx.launch_info()["kernel_or_pairs"] == 6
+    for _ in range(3):
+        again = ctx.normal_eq()
+        assert all(np.array_equal(x, y) for x, y in zip(first, again))
+    beta = ctx.fit_resident(_capi.SOLVE_RIDGE, 1e-8)[0]
+    G, c, s = orc.normal_eq(A, b, w)
+    stats_close(*first, G, c, s)
+    ref = np.linalg.solve(G + 1e-8 * np.eye(K), c)
+    assert np.max(np.abs(beta - ref)) <= 1e-9 * np.max(np.abs(ref))
+
+
 @pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 7, 63, 64, 65, 257, 1023, 1025])
 @pytest.mark.parametrize("K", [168, 256, 275])
 def test_quad_kernel_tiny_and_ragged_row_counts(qctx, m, K):
@@ -188,8 +234,8 @@ def test_quad_kernel_on_pairs_packed_in_hbm_gives_the_bits_of_the_fused_form(qct
 
 @pytest.mark.parametrize("K,m", [(168, 80000), (275, 40000), (288, 40000)])
 def test_quad_kernel_fit_matches_the_oracle_solve(ctx, K, m):
-    # the whole fit: statistics from kernel 1Q; 168 / 275 columns: host mirror written by the reduction, host solve;
-    # 288 columns: no mirror, the GPU factorises (DEVICE_CHOL_MIN_K)
+    # the whole fit: statistics from kernel 1Q; 168 columns: host mirror written by the reduction, host solve;
+    # 275 / 288 columns: no mirror, the GPU factorises (DEVICE_CHOL_MIN_K = 232)
     A, b, w = orc.synth_problem(m, K)
     ctx.upload_rows(A, b)
     ctx.set_weights(w)
