@@ -127,7 +127,8 @@ def test_cluster_quad_kernel_statistics_all_column_block_shapes(qctx, K):
 
 
 @pytest.mark.parametrize("K,m", [(480, 367900), (320, 200003)])
-def test_cluster_quad_kernel_is_bit_identical_run_to_run_and_fits_like_the_oracle(ctx, K, m):
+def test_cluster_quad_kernel_is_bit_identical_run_to_run_and_fits_like_the_oracle(qctx, K, m):
+    ctx = qctx
     # InP's width (examples/InP_JPCA2020: 367 900 x 480) at full size: fixed-order sums -> the same bits on every launch (the
     # flow control between the members of a cluster only paces them); fit through the C ABI vs a dense solve of the oracle's
     # statistics
