@@ -306,6 +306,169 @@ __device__ __forceinline__ void trsm_static_for(F&& f) {
     trsm_static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
+// Kernel 13C (round 5; K <= 128): kernel 13A's pass with TWO waves per SIMD.  Kernel 13A keeps a wave's whole 64 x K tile in
+// the accumulation registers -- one wave per SIMD, and of the 48 us a tile takes only 12 are matrix pipe and 13 the VALU
+// substitution: the rest are LDS hand-overs, the staging of R and the tile load with nothing else on the SIMD to run
+// (profiles/r04_trsm_13a_vs_13b.txt).  Here a wave holds a 64 x 64 PANEL of its rows (128 accumulation registers), so two
+// waves fit a SIMD and one wave's substitution runs beside the other's MFMAs and waits:
+//   panel P of a row tile:  S_P = sum_{I < P} Q_I R_IP   left-looking: the solved panels of the wave's OWN rows come back from
+//                                                        L2 (just written; 32 KiB per tile and earlier panel), R from L2
+//                           Q_P = (X_P - S_P) R_PP^-1    right-looking inside the panel, block by block as kernel 13A: the
+//                                                        16-step substitution one row per lane on the VALU (all 64 lanes),
+//                                                        updates of the later blocks of the panel on the matrix pipe with the
+//                                                        B operands (rows of R) straight from L2 into registers
+// The same MFMA count as kernel 13A (nothing is computed twice); LDS per wave 11 KiB (X 64 x 17, the diagonal block).  The row
+// weights of the first pass are applied when a panel is LOADED (the solved panels a later panel reads back must be the
+// weighted ones); a zero weight makes a zero row whatever A holds.  In place in the later passes: a panel of X is read in full
+// before any of it is overwritten, earlier panels are read back solved.
+template <int NB, bool FIRST>
+__global__ __launch_bounds__(64, 2) void fsnap_trsm_acc2_k(const double* __restrict__ src, int64_t lds_,
+                                                           const double* __restrict__ wpack, double* Q, int64_t ldq,
+                                                           int64_t m, int K, const double* __restrict__ R) {
+    constexpr int K16 = 16 * NB;
+    constexpr int NP = (NB + 3) / 4;
+    __shared__ double X[64][17];
+    __shared__ double Rd[16][18];                 // diagonal block R_JJ (every lane reads the same entry: a broadcast)
+    __shared__ double Rinv[16];
+    __shared__ double Wl[64];                     // first pass: the row weights of the tile
+    const int lane = threadIdx.x, e = lane & 15, g = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    if constexpr (FIRST) {
+        Wl[lane] = (row0 + lane < m) ? wpack[2 * (row0 + lane)] : 0.0;
+        trsm_wave_sync();
+    }
+    trsm_static_for<NP>([&](auto pc) {
+        constexpr int P = decltype(pc)::value;
+        constexpr int NBP = (NB - 4 * P) < 4 ? (NB - 4 * P) : 4;       // blocks of this panel
+        d4 acc[NBP][4];
+        // the panel of the row tile in the accumulator layout (tile rows g + 4 v, column e): straight into the accumulators ...
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int64_t r = row0 + t * 16 + g + 4 * v;
+#pragma unroll
+                for (int jb = 0; jb < NBP; ++jb) {
+                    const int col = (4 * P + jb) * 16 + e;
+                    double x = 0.0;
+                    if (r < m && col < K) x = FIRST ? src[r * lds_ + col] : Q[r * ldq + col];
+                    acc[jb][t][v] = x;
+                }
+            }
+        // ... and weighted in place in the first pass (a zero weight makes a zero row whatever A holds); the 64 weights of the
+        // tile wait in LDS (kept in registers next to the 64 values of a lane they spilled), four at a time
+        if constexpr (FIRST) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const double wgt = Wl[t * 16 + g + 4 * v];
+#pragma unroll
+                    for (int jb = 0; jb < NBP; ++jb) acc[jb][t][v] = (wgt != 0.0) ? wgt * acc[jb][t][v] : 0.0;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // left-looking: X_P -= Q_I R_IP over the solved panels (all of them complete: 4 blocks of 16 columns)
+        if constexpr (P > 0) {
+#pragma unroll 1
+            for (int kb = 0; kb < 4 * P; ++kb) {
+                // A operand (Q)[i = e][k]: k-step s of lane group g takes column 4 g + s of the block (kernel 13's pairing:
+                // four adjacent doubles of the lane's row, two 16-byte loads); B operand R[16 kb + 4 g + s][column]
+                d2u qa[4], qb[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int64_t r = row0 + t * 16 + e;
+                    const double* p = Q + (r < m ? r : 0) * ldq + kb * 16 + 4 * g;
+                    qa[t] = *reinterpret_cast<const d2u*>(p);
+                    qb[t] = *reinterpret_cast<const d2u*>(p + 2);
+                    if (r >= m) {
+                        qa[t] = (d2u){0.0, 0.0};
+                        qb[t] = (d2u){0.0, 0.0};
+                    }
+                }
+#pragma unroll
+                for (int sk = 0; sk < 4; ++sk) {
+                    double bf[NBP];
+#pragma unroll
+                    for (int jb = 0; jb < NBP; ++jb) bf[jb] = R[(size_t)(kb * 16 + 4 * g + sk) * K16 + (4 * P + jb) * 16 + e];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const double af = -((sk < 2) ? qa[t][sk & 1] : qb[t][sk & 1]);
+#pragma unroll
+                        for (int jb = 0; jb < NBP; ++jb)
+                            acc[jb][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf[jb], acc[jb][t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // right-looking inside the panel
+        trsm_static_for<NBP>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            constexpr int JG = 4 * P + J;                                // block index in the matrix
+            // B operands of this block's updates, requested before the substitution: rows 16 JG + 4 sk + g of R
+            double bfu[(NBP - J - 1) > 0 ? (NBP - J - 1) : 1][4];
+#pragma unroll
+            for (int L = J + 1; L < NBP; ++L)
+#pragma unroll
+                for (int sk = 0; sk < 4; ++sk) bfu[L - J - 1][sk] = R[(size_t)(JG * 16 + 4 * sk + g) * K16 + (4 * P + L) * 16 + e];
+            // block J -> LDS in the row-per-lane layout, with its diagonal block of R
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) X[t * 16 + g + 4 * v][e] = acc[J][t][v];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Rd[g + 4 * v][e] = R[(size_t)(JG * 16 + g + 4 * v) * K16 + JG * 16 + e];
+            trsm_wave_sync();
+            if (lane < 16) Rinv[lane] = 1.0 / Rd[lane][lane];
+            trsm_wave_sync();
+            {
+                double x[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) x[j] = X[lane][j];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const double q = x[i] * Rinv[i];
+                    x[i] = q;
+#pragma unroll
+                    for (int j = i + 1; j < 16; ++j) x[j] = __builtin_fma(-q, Rd[i][j], x[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) X[lane][j] = x[j];
+            }
+            trsm_wave_sync();
+            // the solved block: out to Q in the accumulator layout, and as the A operand of the updates inside the panel
+            {
+                const int col = JG * 16 + e;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int64_t r = row0 + t * 16 + g + 4 * v;
+                        if (r < m && col < K) Q[r * ldq + col] = X[t * 16 + g + 4 * v][e];
+                    }
+            }
+            if constexpr (J + 1 < NBP) {
+                double af[4][4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int sk = 0; sk < 4; ++sk) af[t][sk] = -X[t * 16 + e][4 * sk + g];
+#pragma unroll
+                for (int L = J + 1; L < NBP; ++L)
+#pragma unroll
+                    for (int sk = 0; sk < 4; ++sk)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            acc[L][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t][sk], bfu[L - J - 1][sk], acc[L][t], 0, 0, 0);
+            }
+            trsm_wave_sync();    // X and Rd are reused by the next block
+        });
+        // the panel's stores must have landed before the next panel reads them back as operands (same wave, same addresses)
+        if constexpr (P + 1 < NP) __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
+    });
+}
+
 // Kernel 13B (K > 128, the default there): the pass in PANELS of 128 columns with a 16 TR x 128 row tile per wave in the
 // accumulators -- kernel 13 above re-reads every solved 16-column block once per LATER 16-column block (K / 32 times per
 // row on average: 50 x at K = 1595) with four MFMAs between two L2 round trips, and reaches 14-23 % of the matrix peak.
@@ -699,6 +862,27 @@ hipError_t launch_trsm_rows(const double* src, int64_t lds, const double* wpack,
         const char* e = getenv("FSNAP_TRSM_KERNEL");
         return e && atoi(e) == 14;
     }();
+    // K <= 128: the first pass (row weights, rows of A with their own stride) on kernel 13A; the later passes (in place on Q) on
+    // kernel 13C -- 64-column panels, two waves per SIMD.  tools/trsm_check, 10^6 rows, round 5 (13A / 13C, ms): K = 128 0.740 /
+    // 0.652, 110 0.643 / 0.658, 96 0.519 / 0.423, 64 0.250 / 0.236, 31 0.136 / 0.109; first pass 128 0.787 / 1.165 (its 64 loads of
+    // A plus the weights do not fit two waves' register budget: 140 bytes per lane spill), 96 0.551 / 0.810.
+    // FSNAP_TRSM_KERNEL = 12: kernel 13A for every pass (A/B)
+    static const bool acc_only = [] {
+        const char* e = getenv("FSNAP_TRSM_KERNEL");
+        return e && atoi(e) == 12;
+    }();
+    if (K16 <= 128 && !panel_always && !wpack && !acc_only) {
+        const dim3 grid((unsigned)nb), block(64);
+#define FSNAP_TRSM_ACC2(NBV) \
+    case NBV: hipLaunchKernelGGL((fsnap_trsm_acc2_k<NBV, false>), grid, block, 0, st, src, lds, wpack, Q, ldq, m, K, R); break;
+        switch (K16 / 16) {
+            FSNAP_TRSM_ACC2(1) FSNAP_TRSM_ACC2(2) FSNAP_TRSM_ACC2(3) FSNAP_TRSM_ACC2(4)
+            FSNAP_TRSM_ACC2(5) FSNAP_TRSM_ACC2(6) FSNAP_TRSM_ACC2(7) FSNAP_TRSM_ACC2(8)
+            default: return hipErrorInvalidValue;
+        }
+#undef FSNAP_TRSM_ACC2
+        return hipGetLastError();
+    }
     if (K16 <= 128 && !panel_always) {
         // kernel 13A: whole row tile in the accumulation registers
         const dim3 grid((unsigned)nb), block(64);
