@@ -42,10 +42,15 @@ for m, K, ngroups in ((15213, 31, 12), (1000000, 128, 40)):
     t = np.asarray(testing)
     import pandas as pd
     fsd_np = {"Groups": pd.Categorical(groups), "Testing": np.asarray(testing), "Row_Type": pd.Categorical(row_type)}
-    for trust, labels in ((False, fsd), (False, fsd_np), (True, fsd)):
+    from fitsnap_amd.parallel_tools import LabelList
+    # what this package's own producers hand out (Calculator.collect_distributed_lists, FitSnap.load_descriptors): lists that
+    # count their in-place edits -- the whole-content fingerprint is O(1)
+    fsd_ll = {k: LabelList(v) for k, v in fsd.items()}
+    for trust, labels in ((False, fsd_ll), (False, fsd), (False, fsd_np), (True, fsd)):
         times, rmse = loop(A, b, w, labels, t, trust, rng)
         tt = np.array(times[2:])
         how = ("trusted by version (pt.touch_labels)" if trust else
+               "LabelList (package-produced: a list that counts its edits)" if labels is fsd_ll else
                "Python lists, fingerprinted in full every call" if labels is fsd else
                "numpy bool array + pandas Categoricals, fingerprinted in full every call (xxh3 over their buffers)")
         print(f"{m} x {K}, {ngroups} groups, labels {how}: perform_fit {tt[:,0].mean()*1e3:.2f} ms, error_analysis "

@@ -556,6 +556,42 @@ def test_device_cholesky_ab_forms_solve_the_same_systems(env):
         assert float(rel) < 1e-11 and float(rel2) < 1e-11 and float(piv) > 1e-3      # solved on the GPU (min pivot reported), accurately
 
 
+@pytest.mark.parametrize("K", [232, 300, 383])
+def test_device_cholesky_forms_agree_near_the_pivot_threshold(ctx, K):
+    # option "chol_form": the panel loops of the device Cholesky (5 = one launch per panel + four-wave diagonal block, the
+    # default; 4 = two launches per panel + four-wave block; 0 / 2 = the single-wave block with the pivot read back from the
+    # MFMA / formed on a side chain) on systems whose smallest scaled pivot sits on either side of the 1e-3 acceptance
+    # threshold: the forms must report the same pivot (to rounding), take the same accept / fall-back decision, and agree on
+    # beta.  (In forms 2 / 4 / 5 the diagonal of U is d * (1 / sqrt(d)) from the side chain, not sqrt of the stored pivot.)
+    rng = np.random.default_rng(7000 + K)
+    m = 3 * K
+    base = rng.standard_normal((m, K))
+    for eps_col in (6e-2, 2e-2):                                  # pivot of the near-dependent column ~ eps_col^2
+        A = base.copy()
+        A[:, K - 1] = A[:, 0] + eps_col * A[:, K - 1]
+        b = rng.standard_normal(m)
+        ctx.upload_rows(A, b)
+        ctx.set_weights(np.ones(m))
+        ptr = ctx.normal_eq_resident()
+        got = {}
+        ctx.set_option("device_solve", 1)
+        try:
+            for form in (5, 4, 2, 0):
+                ctx.set_option("chol_form", form)
+                got[form] = ctx.solve_device(_capi.SOLVE_CHOL, 0.0, K, ptr)
+        finally:
+            ctx.set_option("chol_form", -1)
+            ctx.set_option("device_solve", 0)
+        beta0, rank0, rcond0 = got[0]
+        assert rank0 == K
+        for form in (5, 4, 2):
+            beta, rank, rcond = got[form]
+            assert rank == rank0 and rcond == pytest.approx(rcond0, rel=1e-9)
+            assert np.max(np.abs(beta - beta0)) <= 1e-9 * np.max(np.abs(beta0))
+        # one case on each side of the threshold, whatever path produced the accepted answer
+        assert (rcond0 > 1e-3) == (eps_col == 6e-2)
+
+
 @pytest.mark.parametrize("K", [40, 128, 200])
 def test_mirror_packed_serves_statistics_modified_in_hbm(ctx, K):
     # fsnap_mirror_packed: the multi-GPU path all-reduces the packed statistics in place; the page-locked host mirror
