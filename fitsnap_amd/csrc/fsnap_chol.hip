@@ -529,6 +529,13 @@ __device__ __forceinline__ void lds_st(int* p, int v) { *(volatile lds_i32*)p = 
 #ifndef FSNAP_D4_HALF
 #define FSNAP_D4_HALF 1        // the next owner's diagonal update as two MFMA chains
 #endif
+#ifndef FSNAP_D4_RANK4
+#define FSNAP_D4_RANK4 0       // 1: pivots in groups of four (the 4 x 4 block factorised on uniform values, TWO MFMAs per group).
+                               // Built, parity-tested (tools/chol_pipeline_check -DFSNAP_D4_RANK4=1) and NOT faster: tools/lat_bench
+                               // puts a group at 1087 cycles = 272 per pivot (ten v_readlane pairs 200, the 4 x 4 factorisation + W on
+                               // uniform values 390, two MFMAs + masks 353, selects the rest) against 225 for the one-MFMA-per-pivot
+                               // step; K = 1595 534 us either way (profiles/r05_chol_forms.txt)
+#endif
 
 #ifdef FSNAP_CHOL_TRACE
 // tools/chol_diag4_trace.hip: shader-clock stamps of the four waves (entry, end of each consumer step, owner start / end, exit)
@@ -542,6 +549,9 @@ struct __attribute__((aligned(16))) Diag4Lds {
     double slot[64][16];       // multipliers of pivot p: -U[j][i] for i > j, 0 elsewhere
     double inv[64];            // 1/sqrt(d_p); 0.0 = not published yet
     double dummy[64];          // where the lanes that have nothing to publish store
+    double gw[16][64];         // rank-4 form: per pivot group (block, q) the A operand of the group's row transformation ...
+    double gu[16][64];         // ... and of its rank-4 update, lane for lane
+    int gflag[16];             // group published
     double tile[3][4][64];     // U_01, U_02, U_12 handed from wave b to the waves right of it (accumulator layout, lane for lane)
     int tflag[4];              // [0] U_01, [1] U_02, [2] U_12 published
     double T[4][16][17];       // per-wave transpose scratch of the inverses
@@ -555,6 +565,7 @@ __device__ __forceinline__ int diag4_tile_index(int a, int b) { return a == 0 ? 
 __device__ __forceinline__ void diag4_lds_reset(Diag4Lds& L, int tid) {
     if (tid < 64) L.inv[tid] = 0.0;
     if (tid < 4) L.tflag[tid] = 0;
+    if (tid < 16) L.gflag[tid] = 0;
 }
 
 // the sixteen multipliers and 1/sqrt(d) of pivot p, as published by the owner: one look (marker first, then payload)
@@ -601,6 +612,105 @@ __device__ __forceinline__ void diag4_consume(d4& X, const Diag4Lds& L, int e, i
     }
 }
 
+// ---- rank-4 form (FSNAP_D4_RANK4) -------------------------------------------------------------------------------------
+// Four pivots at a time.  Rows 4 q .. 4 q + 3 of a tile are register q of the four lane groups -- the four k-slots of ONE
+// MFMA.  The owner reads the 4 x 4 diagonal block of the group (10 values, v_readlane), factorises it on uniform values (four
+// rsq + Newton chains, a dozen FMAs), forms W = U4^-T, and then
+//     rows' = W rows            one MFMA: A operand = W scattered to the lanes (i = e, k = kr), B operand = register q as it is;
+//                               the result's register q ARE the four finished rows of U
+//     D    -= U_cols^T U_rows   one MFMA, rank 4: A operand = -rows' masked to the columns right of the group
+// Two MFMAs and one accumulator round trip per four pivots instead of four of each -- on paper; measured it is a wash (see the
+// switch FSNAP_D4_RANK4 above), so the default stays one MFMA per pivot.  The consumers and the inverses replay a group with the two published A
+// operands: 8 dependent MFMAs per block step instead of 16.
+struct Rank4 {
+    double aW, aU;
+};
+
+template <int Q>
+__device__ __forceinline__ Rank4 diag4_group_factor(d4& D, int e, int kr, double& pmin, double& psum) {
+    const double b00 = readlane_f64(D[Q], 4 * Q), b01 = readlane_f64(D[Q], 4 * Q + 1), b02 = readlane_f64(D[Q], 4 * Q + 2),
+                 b03 = readlane_f64(D[Q], 4 * Q + 3);
+    const double b11 = readlane_f64(D[Q], 16 + 4 * Q + 1), b12 = readlane_f64(D[Q], 16 + 4 * Q + 2),
+                 b13 = readlane_f64(D[Q], 16 + 4 * Q + 3);
+    const double b22 = readlane_f64(D[Q], 32 + 4 * Q + 2), b23 = readlane_f64(D[Q], 32 + 4 * Q + 3);
+    const double b33 = readlane_f64(D[Q], 48 + 4 * Q + 3);
+    const double i0 = rsqrt_newton2(b00);
+    const double u01 = b01 * i0, u02 = b02 * i0, u03 = b03 * i0;
+    const double d1 = __builtin_fma(-u01, u01, b11);
+    const double i1 = rsqrt_newton2(d1);
+    const double u12 = __builtin_fma(-u01, u02, b12) * i1, u13 = __builtin_fma(-u01, u03, b13) * i1;
+    const double d2 = __builtin_fma(-u12, u12, __builtin_fma(-u02, u02, b22));
+    const double i2 = rsqrt_newton2(d2);
+    const double u23 = __builtin_fma(-u12, u13, __builtin_fma(-u02, u03, b23)) * i2;
+    const double d3 = __builtin_fma(-u23, u23, __builtin_fma(-u13, u13, __builtin_fma(-u03, u03, b33)));
+    const double i3 = rsqrt_newton2(d3);
+    const double m01 = b00 < d1 ? b00 : d1, m23 = d2 < d3 ? d2 : d3, m = m01 < m23 ? m01 : m23;
+    pmin = m < pmin ? m : pmin;                         // (a NaN pivot is caught by the sum)
+    psum += (b00 + d1) + (d2 + d3);
+    // W = U4^-T, row by row: W_k = i_k (e_k - sum_{m < k} u_mk W_m)
+    const double w00 = i0;
+    const double w10 = -i1 * u01 * w00, w11 = i1;
+    const double w20 = i2 * (-u02 * w00 - u12 * w10), w21 = -i2 * u12 * w11, w22 = i2;
+    const double w30 = i3 * (-u03 * w00 - u13 * w10 - u23 * w20), w31 = i3 * (-u13 * w11 - u23 * w21), w32 = -i3 * u23 * w22,
+                 w33 = i3;
+    // A operand of rows' = W rows: lane (k = kr, e) holds W[e - 4 Q][k] (lower triangular), zero outside the group's columns
+    const int i = e - 4 * Q;
+    const double c0 = i == 0 ? w00 : i == 1 ? w10 : i == 2 ? w20 : i == 3 ? w30 : 0.0;
+    const double c1 = i == 1 ? w11 : i == 2 ? w21 : i == 3 ? w31 : 0.0;
+    const double c2 = i == 2 ? w22 : i == 3 ? w32 : 0.0;
+    const double c3 = i == 3 ? w33 : 0.0;
+    Rank4 g;
+    g.aW = kr == 0 ? c0 : kr == 1 ? c1 : kr == 2 ? c2 : c3;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    const d4 Z0 = __builtin_amdgcn_mfma_f64_16x16x4f64(g.aW, D[Q], zero, 0, 0, 0);
+    const double un = Z0[Q];                            // the four finished rows of U (lane group kr: row 4 Q + kr)
+    D[Q] = un;
+    g.aU = (e > 4 * Q + 3) ? -un : 0.0;
+    return g;
+}
+
+__device__ __forceinline__ void diag4_group_peek(const Diag4Lds& L, int grp, int lane, int& flag, double& aW, double& aU) {
+    flag = lds_ld(&L.gflag[grp]);                       // marker first, then payload: one round trip
+    aW = lds_ld(&L.gw[grp][lane]);
+    aU = lds_ld(&L.gu[grp][lane]);
+}
+
+__device__ __forceinline__ void diag4_group_wait(const Diag4Lds& L, int grp, int lane, int& flag, double& aW, double& aU, bool& ok) {
+    int n = 0;
+    while (flag == 0 && ++n < CHOL_D4_SPINS) {
+#if FSNAP_D4_SLEEP
+        __builtin_amdgcn_s_sleep(1);
+#endif
+        diag4_group_peek(L, grp, lane, flag, aW, aU);
+    }
+    if (flag == 0) ok = false;
+}
+
+// the four groups of block step A replayed on a tile X (a consumer's T[A][c], or the identity for the inverse)
+template <int A>
+__device__ __forceinline__ void diag4_replay(d4& X, const Diag4Lds& L, int lane, bool& ok) {
+    int flag;
+    double aW, aU;
+    diag4_group_peek(L, 4 * A, lane, flag, aW, aU);
+    diag4_group_wait(L, 4 * A, lane, flag, aW, aU, ok);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int flag1 = 1;
+        double aW1 = 0.0, aU1 = 0.0;
+        if (q < 3) diag4_group_peek(L, 4 * A + q + 1, lane, flag1, aW1, aU1);      // its LDS round trip runs beside the MFMAs
+        const d4 zero = {0.0, 0.0, 0.0, 0.0};
+        const d4 Z0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aW, X[q], zero, 0, 0, 0);
+        const double xn = Z0[q];
+        X[q] = xn;
+        if (q < 3) {
+            X = __builtin_amdgcn_mfma_f64_16x16x4f64(aU, xn, X, 0, 0, 0);
+            diag4_group_wait(L, 4 * A + q + 1, lane, flag1, aW1, aU1, ok);
+            aW = aW1;
+            aU = aU1;
+        }
+    }
+}
+
 // Y_A = U_AA^-1: the published row operations of block A replayed on an identity tile (Z = U_AA^-T), transposed through
 // this wave's scratch, stored for kernels 8c / 8e
 template <int A>
@@ -608,6 +718,9 @@ __device__ __forceinline__ void diag4_inverse(Diag4Lds& L, double (*T)[17], doub
     d4 Z;
 #pragma unroll
     for (int r = 0; r < 4; ++r) Z[r] = (4 * r + kr == e) ? 1.0 : 0.0;
+#if FSNAP_D4_RANK4
+    diag4_replay<A>(Z, L, 16 * kr + e, ok);
+#else
     double inv, mult;
     diag4_peek(L, 16 * A, e, inv, mult);
     diag4_wait(L, 16 * A, e, inv, mult, ok);
@@ -628,6 +741,7 @@ __device__ __forceinline__ void diag4_inverse(Diag4Lds& L, double (*T)[17], doub
             mult = mult1;
         }
     }
+#endif
     chol_wave_sync();
 #pragma unroll
     for (int r = 0; r < 4; ++r) T[4 * r + kr][e] = Z[r];
@@ -650,9 +764,15 @@ __device__ __forceinline__ void chol_diag4_wave(d4 (&Tl)[4], Diag4Lds& L, double
 #pragma unroll
     for (int a = 0; a < W; ++a) {
         d4& X = Tl[a];
+#if FSNAP_D4_RANK4
+        if (a == 0) diag4_replay<0>(X, L, lane, ok);
+        else if (a == 1) diag4_replay<1>(X, L, lane, ok);
+        else diag4_replay<2>(X, L, lane, ok);
+#else
         if (a == 0) diag4_consume<0>(X, L, e, kr, ok);
         else if (a == 1) diag4_consume<1>(X, L, e, kr, ok);
         else diag4_consume<2>(X, L, e, kr, ok);
+#endif
         if (a + 1 == W) {
             // next owner: its diagonal tile needs nothing but its own registers -- first thing after the last pivot, as two
             // chains of two MFMAs (a chain of four on one accumulator is 4 x 65 cycles on the hand-over)
@@ -708,6 +828,23 @@ __device__ __forceinline__ void chol_diag4_wave(d4 (&Tl)[4], Diag4Lds& L, double
     // ---- the own block step: owner ------------------------------------------------------------------------------
     d4& D = Tl[W];
     double pmin = 1.0e300, psum = 0.0;
+#if FSNAP_D4_RANK4
+    {
+        auto group = [&](auto qc) {
+            constexpr int Q = decltype(qc)::value;
+            const Rank4 g = diag4_group_factor<Q>(D, e, kr, pmin, psum);
+            // publish the two A operands of the group (payload, then marker), then the rank-4 update of the rows below
+            lds_st(&L.gw[4 * W + Q][lane], g.aW);
+            lds_st(&L.gu[4 * W + Q][lane], g.aU);
+            lds_st(&L.gflag[4 * W + Q], 1);
+            if constexpr (Q < 3) D = __builtin_amdgcn_mfma_f64_16x16x4f64(g.aU, D[Q], D, 0, 0, 0);
+        };
+        group(std::integral_constant<int, 0>{});
+        group(std::integral_constant<int, 1>{});
+        group(std::integral_constant<int, 2>{});
+        group(std::integral_constant<int, 3>{});
+    }
+#else
     double dcur = readlane_f64(D[0], 0);
     double inv = FSNAP_D4_NEWTON == 2 ? rsqrt_newton2(dcur) : rsqrt_newton(dcur);
 #pragma unroll
@@ -737,6 +874,7 @@ __device__ __forceinline__ void chol_diag4_wave(d4 (&Tl)[4], Diag4Lds& L, double
             inv = FSNAP_D4_NEWTON == 2 ? rsqrt_newton2(dcur) : rsqrt_newton(dcur);
         }
     }
+#endif
     CHOL_STAMP(W, 5);
     // the strip of U: the tiles above the diagonal (kept in registers until here: their stores are off the hand-over), then
     // the diagonal tile's upper triangle

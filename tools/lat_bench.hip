@@ -189,6 +189,64 @@ __global__ __launch_bounds__(64) void k(double* out, const double* in, long long
             acc[0] += D[0] * 1e-30 + 1.0;      // keeps the tiles apart (and the diagonal positive)
             acc[1] += D[1] * 1e-30;
         }
+    } else if constexpr (MODE >= 18 && MODE <= 22) {
+        // the rank-4 pivot group of kernel 8b4 and its parts: 18 whole group, 19 the ten v_readlane pairs alone, 20 the 4 x 4
+        // factorisation + W on uniform values alone, 21 the operand selects + the two MFMAs alone, 22 whole group without readlanes
+        const int e = lane & 15, kr = lane >> 4;
+#pragma unroll 1
+        for (int rep = 0; rep < N / 4; ++rep) {
+            constexpr int Q = 1;
+            d4 D = acc;
+            double b00, b01, b02, b03, b11, b12, b13, b22, b23, b33;
+            if constexpr (MODE == 18 || MODE == 19) {
+                b00 = readlane_f64(D[Q], 4 * Q); b01 = readlane_f64(D[Q], 4 * Q + 1); b02 = readlane_f64(D[Q], 4 * Q + 2); b03 = readlane_f64(D[Q], 4 * Q + 3);
+                b11 = readlane_f64(D[Q], 16 + 4 * Q + 1); b12 = readlane_f64(D[Q], 16 + 4 * Q + 2); b13 = readlane_f64(D[Q], 16 + 4 * Q + 3);
+                b22 = readlane_f64(D[Q], 32 + 4 * Q + 2); b23 = readlane_f64(D[Q], 32 + 4 * Q + 3); b33 = readlane_f64(D[Q], 48 + 4 * Q + 3);
+            } else {
+                b00 = x + 4.0; b01 = y * 0.01; b02 = z * 0.01; b03 = w * 0.01; b11 = x + 5.0; b12 = y * 0.02; b13 = z * 0.02; b22 = x + 6.0; b23 = w * 0.02; b33 = x + 7.0;
+            }
+            if constexpr (MODE == 19) {
+                acc[0] += ((b00 + b01) + (b02 + b03)) + ((b11 + b12) + (b13 + b22)) + (b23 + b33);
+                continue;
+            }
+            double aW = y, un = z;
+            if constexpr (MODE != 21) {
+                auto rs = [](double d) { double r = __builtin_amdgcn_rsq(d); const double h = 0.5 * d;
+                                         for (int it = 0; it < 2; ++it) { const double ee = __builtin_fma(-h * r, r, 0.5); r = __builtin_fma(r, ee, r); } return r; };
+                const double i0 = rs(b00);
+                const double u01 = b01 * i0, u02 = b02 * i0, u03 = b03 * i0;
+                const double d1 = __builtin_fma(-u01, u01, b11);
+                const double i1 = rs(d1);
+                const double u12 = __builtin_fma(-u01, u02, b12) * i1, u13 = __builtin_fma(-u01, u03, b13) * i1;
+                const double d2 = __builtin_fma(-u12, u12, __builtin_fma(-u02, u02, b22));
+                const double i2 = rs(d2);
+                const double u23 = __builtin_fma(-u12, u13, __builtin_fma(-u02, u03, b23)) * i2;
+                const double d3 = __builtin_fma(-u23, u23, __builtin_fma(-u13, u13, __builtin_fma(-u03, u03, b33)));
+                const double i3 = rs(d3);
+                const double w00 = i0, w10 = -i1 * u01 * w00, w11 = i1, w20 = i2 * (-u02 * w00 - u12 * w10), w21 = -i2 * u12 * w11, w22 = i2;
+                const double w30 = i3 * (-u03 * w00 - u13 * w10 - u23 * w20), w31 = i3 * (-u13 * w11 - u23 * w21), w32 = -i3 * u23 * w22, w33 = i3;
+                if constexpr (MODE == 20) {
+                    x = x * 0.5 + 1e-3 * (((w00 + w10) + (w11 + w20)) + ((w21 + w22) + (w30 + w31)) + (w32 + w33));
+                    continue;
+                }
+                const int i = e - 4 * Q;
+                const double c0 = i == 0 ? w00 : i == 1 ? w10 : i == 2 ? w20 : i == 3 ? w30 : 0.0;
+                const double c1 = i == 1 ? w11 : i == 2 ? w21 : i == 3 ? w31 : 0.0;
+                const double c2 = i == 2 ? w22 : i == 3 ? w32 : 0.0;
+                const double c3 = i == 3 ? w33 : 0.0;
+                aW = kr == 0 ? c0 : kr == 1 ? c1 : kr == 2 ? c2 : c3;
+            }
+            const d4 zero = {0.0, 0.0, 0.0, 0.0};
+            const d4 Z0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aW, D[Q], zero, 0, 0, 0);
+            un = Z0[Q];
+            D[Q] = un;
+            const double aU = (e > 4 * Q + 3) ? -un : 0.0;
+            D = __builtin_amdgcn_mfma_f64_16x16x4f64(aU, un, D, 0, 0, 0);
+            acc[0] = D[0] * 1e-30 + 4.0;
+            acc[1] = D[1] * 1e-30 + 4.0 + 1e-3 * lane;
+            acc[2] = D[2] * 1e-30 + 3.0;
+            acc[3] = D[3] * 1e-30 + 5.0;
+        }
     } else if constexpr (MODE == 14) {  // MFMA -> VALU read of the accumulator -> MFMA operand (no readlane)
 #pragma unroll
         for (int i = 0; i < N; ++i) {
@@ -222,7 +280,9 @@ int main() {
                            "dependent 64-bit select + add", "readlane -> add chain", "pivot link without the MFMA",
                            "rsq from f32 seed + 2 Newton + add", "v_rsq_f64 + 2 Newton + add", "v_rsq_f64 + 3 Newton + add",
                            "LDS write -> read -> add", "MFMA -> mul of the accumulator -> MFMA", "8b4 owner pivot (no LDS)", "8b4 owner pivot + LDS publication",
-                           "8b4 owner pivot, publication + write-back behind the MFMA"};
+                           "8b4 owner pivot, publication + write-back behind the MFMA",
+                           "rank-4 group (4 pivots): whole", "rank-4 group: the ten v_readlane pairs alone", "rank-4 group: 4 x 4 factorisation + W alone",
+                           "rank-4 group: two MFMAs + masks alone", "rank-4 group without the readlanes"};
     for (int rep = 0; rep < 3; ++rep) {
         k<0><<<1, 64>>>(out, in, cyc, wall);
         k<1><<<1, 64>>>(out, in, cyc, wall);
@@ -242,13 +302,18 @@ int main() {
         k<15><<<1, 64>>>(out, in, cyc, wall);
         k<16><<<1, 64>>>(out, in, cyc, wall);
         k<17><<<1, 64>>>(out, in, cyc, wall);
+        k<18><<<1, 64>>>(out, in, cyc, wall);
+        k<19><<<1, 64>>>(out, in, cyc, wall);
+        k<20><<<1, 64>>>(out, in, cyc, wall);
+        k<21><<<1, 64>>>(out, in, cyc, wall);
+        k<22><<<1, 64>>>(out, in, cyc, wall);
         hipDeviceSynchronize();
     }
     long long hc[32], hw[32];
     hipMemcpy(hc, cyc, sizeof hc, hipMemcpyDeviceToHost);
     hipMemcpy(hw, wall, sizeof hw, hipMemcpyDeviceToHost);
-    for (int m = 0; m < 18; ++m)
-        printf("%-52s %8.1f s_memtime ticks / link   %7.1f ns / link (100 MHz wall clock)\n", names[m], (double)hc[m] / N,
+    for (int m = 0; m < 23; ++m)
+        printf("%-60s %8.1f s_memtime ticks / link   %7.1f ns / link (100 MHz wall clock)\n", names[m], (double)hc[m] / N,
                (double)hw[m] * 10.0 / N);
     return 0;
 }
