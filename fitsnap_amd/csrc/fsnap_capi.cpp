@@ -285,12 +285,18 @@ int staged_rows_h2d(fsnap_ctx* ctx, void* dst, const void* src, size_t rows, siz
     }();
     const bool dense = src_pitch == row_bytes;
     size_t rows_per_piece = slot_bytes / row_bytes;
-    if (rows_per_piece < 1) return FSNAP_E_ARG;
-    bool used[2] = {false, false};
+    if (rows_per_piece < 1) return FSNAP_E_NOMEM;      // a row wider than a slot: the caller falls back on the plain copy
+    // `rstage_busy[slot]`: a DMA out of this slot was enqueued and its event not waited for since -- kept in the CONTEXT: a
+    // call that returned early (a failed copy further on, a failing plan copy of the assembly before its stream
+    // synchronisation) must not let the next call fill a slot the DMA engine is still reading
+    bool* used = ctx->rstage_busy;
     int slot = 0;
     for (size_t r0 = 0; r0 < rows; r0 += rows_per_piece, slot ^= 1) {
         const size_t nr = rows - r0 < rows_per_piece ? rows - r0 : rows_per_piece;
-        if (used[slot]) FSNAP_HIP(hipEventSynchronize(ctx->rstage_ev[slot]), "hipEventSynchronize(row staging)");
+        if (used[slot]) {
+            FSNAP_HIP(hipEventSynchronize(ctx->rstage_ev[slot]), "hipEventSynchronize(row staging)");
+            used[slot] = false;
+        }
         char* stage = ctx->rstage[slot];
         const char* from = (const char*)src + r0 * src_pitch;
         auto copy_part = [&](size_t a, size_t b) {           // rows [a, b) of this piece

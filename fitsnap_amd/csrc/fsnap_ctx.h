@@ -146,6 +146,7 @@ struct fsnap_ctx {
     // page-locked double buffer of fsnap_upload_rows (two 16 MiB slots: host threads fill one while the DMA drains the other)
     char* rstage[2] = {nullptr, nullptr};
     hipEvent_t rstage_ev[2] = {nullptr, nullptr};
+    bool rstage_busy[2] = {false, false};   // a DMA out of the slot is (possibly) still in flight: wait for its event before refilling
     DevBuf wtrain, wrank;                         // compact training weights and the mask's exclusive prefix sum
     int64_t ntrain_resident = -1;                 // training rows of the resident mask / prefix (-1 = none)
 

@@ -140,11 +140,18 @@ def _via_file(path, rank, make_id, token):
     timeout = _timeout_s()
     deadline = time.monotonic() + timeout
     foreign = False
+    first_mtime = None
     while time.monotonic() < deadline:
         try:
             with open(path, "rb") as f:
                 msg = f.read(_MSG_BYTES + 1)
-                fresh = os.fstat(f.fileno()).st_mtime >= _IMPORTED_AT - _FRESH_SLACK_S
+                mtime = os.fstat(f.fileno()).st_mtime
+            # "fresh" = written by a LIVE rank 0: either its mtime is not older than this process (same clock: one node, or a
+            # file server in step with it, up to _FRESH_SLACK_S), or -- whatever the clocks say (a shared file system whose
+            # server is minutes off) -- this reader has seen the mtime MOVE: only the keepalive of a live rank 0 touches it
+            if first_mtime is None:
+                first_mtime = mtime
+            fresh = mtime >= _IMPORTED_AT - _FRESH_SLACK_S or mtime != first_mtime
             ident = _unpack(msg, token)
             if ident is not None and fresh:        # a live rank 0 touches its file every _KEEPALIVE_S seconds
                 return ident
@@ -221,6 +228,7 @@ def exchange(rank: int, world: int, make_id) -> bytes:
     (every rank of a job creates its communicators in the same order)."""
     if world == 1:
         return make_id()
+    _stop_keepalive()                              # of an earlier exchange() that was never followed by done()
     generation = _state["generation"]
     _state["generation"] = generation + 1
     token = _token(generation)
@@ -228,16 +236,24 @@ def exchange(rank: int, world: int, make_id) -> bytes:
     if path or _single_node(world):
         path = f"{path}.g{generation}" if path else _default_file(generation)
         _state["path"] = path
-        return _via_file(path, rank, make_id, token)
+        try:
+            return _via_file(path, rank, make_id, token)
+        except BaseException:
+            _stop_keepalive()                      # rank 0 failed after publishing: nobody will call done()
+            raise
     return _via_tcp(rank, world, make_id, token)
+
+
+def _stop_keepalive():
+    stop, _state["keepalive"] = _state.get("keepalive"), None
+    if stop is not None:
+        stop.set()
 
 
 def done(rank: int):
     """After every rank has joined the communicator: rank 0 removes the id file."""
     path, _state["path"] = _state["path"], None
-    stop, _state["keepalive"] = _state.get("keepalive"), None
-    if stop is not None:
-        stop.set()
+    _stop_keepalive()
     if rank == 0 and path:
         try:
             os.remove(path)
