@@ -108,7 +108,8 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * ("quad_min_rows" overrides; shorter systems are faster on the tiled kernel); 0 = the tiled kernel there, A/B;
  * "quad_flow" = mode + 4 x lead: that kernel's flow control between the workgroups of a cluster -- mode 0 off (1.8 x the
  * algorithmic HBM reads at 367 900 x 480, 2 % faster), 1 = every member publishes its trip count and looks at its peers at the end
- * of a trip, 2 (default) = at the start of the trip, judged at its end; lead (default 2) = trips a member may run ahead),
+ * of a trip, 2 (default) = at the start of the trip, judged at its end; lead = trips a member may run ahead (default 63 = by cluster
+ * size: 0 for clusters of two, 2 for clusters of four)),
  * "acc_max_k" (144 | 128: widest system on the accumulator-resident kernel; 128 sends 129 ... 144 columns to the tiled kernel, A/B),
  * "reduce" (0 = reduction kernel 2b with every load of a thread in flight, the default; 1 = its predecessor, A/B),
  * "mirror_upper" (0|1, default 1: the reduction writes the host mirror's triangle once per element, at its upper position),
