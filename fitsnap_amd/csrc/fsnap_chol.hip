@@ -1583,24 +1583,29 @@ __global__ __launch_bounds__(1024) void fsnap_chol_backsolve_k(const double* __r
             // rows of the macro-block above panel pb: y_r -= U[r, panel pb + 1] x_{pb+1}; the rows of panel pb - 1 are then
             // complete up to the contribution of x_pb, which wave 0 adds in the next step
             const int cb = jb + CHOL_NB;                       // first column of panel pb + 1
-            for (int r = row_lo + tid - 64; r < jb; r += 960) {
-                const d2* u = reinterpret_cast<const d2*>(S + (size_t)r * ld + cb);   // 16-byte aligned: ld, cb multiples of 32
+            // FOUR lanes per row, 16 columns each: all eight 16-byte loads of a lane in flight at once (one thread per row walked
+            // its 64 columns in two dependent rounds of sixteen loads: the round trips, not the arithmetic, set a panel step)
+            const int q4 = (tid - 64) & 3;
+            for (int r = row_lo + ((tid - 64) >> 2); r < jb; r += 240) {
+                const d2* u = reinterpret_cast<const d2*>(S + (size_t)r * ld + cb + 16 * q4);   // 16-byte aligned: ld, cb multiples of 32
+                d2 uv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) uv[q] = u[q];
                 const double z0 = zv[r];
                 double a0 = 0.0, a1 = 0.0;
-#pragma unroll 1
-                for (int h = 0; h < 2; ++h) {          // 16 x 16-byte loads in flight (128-register budget of 1024 threads)
-                    d2 uv[16];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) uv[q] = u[16 * h + q];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        a0 = __builtin_fma(uv[q][0], xprev[32 * h + 2 * q], a0);
-                        a1 = __builtin_fma(uv[q][1], xprev[32 * h + 2 * q + 1], a1);
-                    }
+                for (int q = 0; q < 8; ++q) {
+                    a0 = __builtin_fma(uv[q][0], xprev[16 * q4 + 2 * q], a0);
+                    a1 = __builtin_fma(uv[q][1], xprev[16 * q4 + 2 * q + 1], a1);
                 }
-                const double zn = z0 - (a0 + a1);
-                zv[r] = zn;
-                if (r >= jb - CHOL_NB) ybuf[(cur ^ 1) * CHOL_NB + r - (jb - CHOL_NB)] = zn;
+                double acc = a0 + a1;
+                acc += __shfl_xor(acc, 1, 64);                 // the four lanes of a row are neighbours (tid - 64 is a multiple of 4 apart)
+                acc += __shfl_xor(acc, 2, 64);
+                if (q4 == 0) {
+                    const double zn = z0 - acc;
+                    zv[r] = zn;
+                    if (r >= jb - CHOL_NB) ybuf[(cur ^ 1) * CHOL_NB + r - (jb - CHOL_NB)] = zn;
+                }
             }
         } else if (pb > p_lo) {
             // first step of the macro-block: nothing to apply yet; the rows of the next panel come as they are
