@@ -664,14 +664,14 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
             FSNAP_HIP(hipMemsetAsync(ctx->quad_flow.p, 0, ctx->quad_flow.bytes, ctx->stream), "hipMemset(flow words)");
             ctx->quad_flow_tag = 0;
         }
-        ctx->quad_flow_tag += 1 << 20;
+        ctx->quad_flow_tag += 1u << 20;                                  // (unsigned: wraps after 4096 launches, see quad_flow_wait)
         a.flow_words = (int*)ctx->quad_flow.p;
         // low byte: flow-control mode (2 bits) and lead (6 bits).  Lead 63 = by cluster size, as measured (HBM reads / algorithmic):
         // clusters of 4 (367 900 x 480) lead 2: 1.01 x, lead 4: 1.5 x; clusters of 2 (500 000 x 368: twice as many clusters share an
         // XCD's L2) lead 0: 1.01 x, lead 1: 1.33 x, lead 2: 1.78 x -- at the same kernel time in every case
         int flow = ctx->opt_quad_flow & 0xFF;
         if ((flow >> 2) == 63) flow = (flow & 3) | ((g.cluster == 2 ? 0 : 2) << 2);
-        a.flow_tag = ctx->quad_flow_tag | flow;
+        a.flow_tag = (int)(ctx->quad_flow_tag | (unsigned)flow);
     }
     if (g.quad) FSNAP_HIP(fsnap::launch_syrk_quad(a, ctx->stream), "launch fsnap_syrk_quad");
     else if (g.acc) FSNAP_HIP(fsnap::launch_syrk_acc(a, ctx->stream), "launch fsnap_syrk_acc");

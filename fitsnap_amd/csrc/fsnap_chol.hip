@@ -935,6 +935,79 @@ __global__ __launch_bounds__(256) void fsnap_chol_diag4_k(const double* S, doubl
     chol_diag4_dispatch(Tl, L, Uf, ld, jb, Y, status, minpiv, wave, lane);
 }
 
+// 8a + 8b4 fused (round 5, one-launch-per-panel form): scaling of the whole matrix AND the first diagonal block in ONE launch.
+// Workgroup 0 is the four-wave pipeline on the first 64 x 64 block, which it scales itself straight from the packed statistics
+// (the long pole of the launch starts at once); workgroup b > 0 writes a 256-column piece of one row of the scaled work matrix
+// (+ the right-hand-side strip), computing 1/sqrt(G_jj + alpha) of its columns on the fly from the diagonal instead of waiting for
+// a launch that fills `dsc` -- the three launches prepare_d | prepare_s | diag of a solve (16-20 us of a K = 256 solve's 95) become one.
+__global__ __launch_bounds__(256) void fsnap_chol_prepare_diag4_k(const double* __restrict__ packed, const double* __restrict__ cvec,
+                                                                 int n, int np, double alpha, double* __restrict__ dsc,
+                                                                 double* __restrict__ S, double* Uf, double* __restrict__ Y,
+                                                                 int* __restrict__ status, double* __restrict__ minpiv,
+                                                                 int npanel, int* __restrict__ flag) {
+    __shared__ Diag4Lds L;
+    __shared__ double d0[CHOL_NB];
+    const int ld = np + CHOL_XS;
+    const int nx = (ld + 255) / 256;
+    auto scale_of = [&](int i, bool& ok) {
+        if (i >= n) return 1.0;
+        const double g = packed[(size_t)i * n + i] + alpha;
+        ok = (g > 0.0) && __builtin_isfinite(g);
+        return ok ? 1.0 / sqrt(g) : 0.0;
+    };
+    if (blockIdx.x == 0) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, e = lane & 15, kr = lane >> 4;
+        if (threadIdx.x == 0 && flag) *flag = 0;
+        if ((int)threadIdx.x < npanel) minpiv[threadIdx.x] = 1.0e300;
+        for (int p = 256 + (int)threadIdx.x; p < npanel; p += 256) minpiv[p] = 1.0e300;
+        diag4_lds_reset(L, (int)threadIdx.x);
+        if (threadIdx.x < CHOL_NB) {
+            bool ok = true;
+            d0[threadIdx.x] = scale_of((int)threadIdx.x, ok);
+        }
+        __syncthreads();
+        d4 Tl[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * a + 4 * r + kr, j = 16 * wave + e;
+                double v = 0.0;
+                if (a <= wave) {
+                    if (i < n && j < n) v = (packed[(size_t)i * n + j] + ((i == j) ? alpha : 0.0)) * d0[i] * d0[j];
+                    else v = (i == j) ? 1.0 : 0.0;
+                }
+                Tl[a][r] = v;
+            }
+        chol_diag4_dispatch(Tl, L, Uf, ld, 0, Y, status, minpiv, wave, lane);
+        return;
+    }
+    const int b = (int)blockIdx.x - 1;
+    const int i = b / nx, j = (b % nx) * 256 + (int)threadIdx.x;
+    if (j >= ld) return;
+    bool oki = true;
+    const double di = scale_of(i, oki);
+    const double ci = (i < n) ? cvec[i] : 0.0;
+    const bool finite_c = __builtin_isfinite(ci);
+    if (j == 0) {
+        dsc[i] = (i < n) ? (oki && finite_c ? di : 0.0) : 1.0;
+        if (i < n && !(oki && finite_c)) atomicOr(status, 1);
+    }
+    double v;
+    if (j >= np) {
+        v = (j == np && i < n && oki && finite_c) ? ci * di : 0.0;
+    } else if (i < n && j < n) {
+        bool okj = true;
+        const double dj = scale_of(j, okj);
+        const double g = packed[(size_t)i * n + j] + ((i == j) ? alpha : 0.0);
+        v = g * (oki && finite_c ? di : 0.0) * dj;
+        if (!__builtin_isfinite(v)) atomicOr(status, 1);
+    } else {
+        v = (i == j) ? 1.0 : 0.0;
+    }
+    S[(size_t)i * ld + j] = v;
+}
+
 #ifdef FSNAP_CHOL_TRACE
 // the block factorised TWICE in one launch (tools/chol_diag4_trace.hip): the stamps are those of the second pass, whose code
 // is in the instruction cache -- every wave of kernel 8b4 otherwise runs ITS instantiation of the pipeline exactly once
@@ -1203,18 +1276,6 @@ __device__ __forceinline__ void chol_strip_store(double* Uf, int ld, int jb, int
     for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) base[(size_t)(16 * b + 4 * r) * ld + c0 + e] = X[b][r];
-}
-
-// the right-hand-side strip alone (behind the LAST panel there is no trailing matrix, but the forward sweep still needs it),
-// and any other use of the substitution with separate input / output matrices: one wave per 16-column strip from column c0
-__global__ __launch_bounds__(256) void fsnap_chol_tails2_k(const double* S, double* Uf, int ld, int jb, int c0, int nstrip,
-                                                          const double* __restrict__ Y, const int* __restrict__ status) {
-    if (*status) return;
-    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (strip >= nstrip) return;
-    d4 X[4];
-    chol_tails_regs(S, Uf, ld, jb, c0 + 16 * strip, Y, (int)(threadIdx.x & 63), X);
-    chol_strip_store(Uf, ld, jb, c0 + 16 * strip, X, (int)(threadIdx.x & 63));
 }
 
 __global__ __launch_bounds__(256, 2) void fsnap_chol_step4_k(double* S, double* Uf, int ld, int jb, int nblk,
@@ -1491,7 +1552,8 @@ __global__ __launch_bounds__(1024) void fsnap_chol_backsolve_k(const double* __r
                                                               const double* __restrict__ Yall, double* zv,
                                                               const double* __restrict__ dsc, double* __restrict__ beta,
                                                               int* status, int p_lo, int p_hi, int first,
-                                                              const double* __restrict__ minpiv, double* host_out) {
+                                                              const double* __restrict__ minpiv, double* host_out,
+                                                              const double* __restrict__ Sraw) {
     extern __shared__ __attribute__((aligned(16))) double bs_lds[];
     const int st_in = *status;
     __syncthreads();                                   // every thread has read the status before thread 0 may clear it
@@ -1503,7 +1565,10 @@ __global__ __launch_bounds__(1024) void fsnap_chol_backsolve_k(const double* __r
         return;
     }
     if (first) {
-        for (int i = threadIdx.x; i < np; i += 1024) zv[i] = S[(size_t)i * ld + np];
+        // Sraw != null (one-launch-per-panel form): the strip rows of the LAST panel were never substituted (there is no launch
+        // behind the last panel) -- they come raw from the work matrix and wave 0 runs their forward substitution below
+        for (int i = threadIdx.x; i < np; i += 1024)
+            zv[i] = (Sraw && i >= np - CHOL_NB) ? Sraw[(size_t)i * ld + np] : S[(size_t)i * ld + np];
         __syncthreads();
     }
     double* xbuf = bs_lds + 2 * CHOL_BS_BUF;   // x of the panel solved last / being solved (two slots)
@@ -1540,6 +1605,23 @@ __global__ __launch_bounds__(1024) void fsnap_chol_backsolve_k(const double* __r
     fetch(p_hi - 1);
     park(0);
     __syncthreads();
+    if (first && Sraw) {
+        // y_last = U11^-T z_last for the last panel: 64 steps, one wave, U11 from the LDS copy just parked (row k is read by
+        // the lanes right of k: conflict-free), multipliers broadcast with v_readlane
+        if (wv == 0) {
+            const double* U11 = bs_lds;
+            double v = ybuf[lane];
+            const double invd = 1.0 / U11[lane * (CHOL_NB + 1) + lane];
+#pragma unroll 8
+            for (int k = 0; k < CHOL_NB; ++k) {
+                const double yk = readlane_f64(v, k) * readlane_f64(invd, k);
+                if (lane == k) v = yk;
+                if (lane > k) v = __builtin_fma(-U11[k * (CHOL_NB + 1) + lane], yk, v);
+            }
+            ybuf[lane] = v;
+        }
+        __syncthreads();
+    }
     for (int pb = p_hi - 1; pb >= p_lo; --pb) {
         const int jb = pb * CHOL_NB;
         const int cur = (p_hi - 1 - pb) & 1;            // LDS buffer / x slot / y slot of this panel
@@ -1817,10 +1899,9 @@ static void launch_chol_panels(double* S, double* Uf, int ld, int np, double* Ya
                 const int nrest = nblk * (nblk + 1) / 2 + nblk - 3;
                 hipLaunchKernelGGL(fsnap_chol_step4_k, dim3(1 + (nrest + 3) / 4), dim3(256), 0, st, S, Uf, ld, jb, nblk, status,
                                    (const double*)Y, Y + 1024, minpiv);
-            } else {
-                hipLaunchKernelGGL(fsnap_chol_tails2_k, dim3(1), dim3(256), 0, st, (const double*)S, Uf, ld, jb, np, CHOL_XS / 16,
-                                   (const double*)Y, (const int*)status);
             }
+            // (behind the LAST panel there is nothing to launch: the forward substitution of its right-hand-side rows is the
+            // first thing the back substitution does, fsnap_chol_backsolve_k with Sraw; the factor-only use has no strip)
             continue;
         }
         if (pb == 0 || !fused)
@@ -1862,12 +1943,20 @@ hipError_t launch_chol_large(const double* packed, const double* cvec, int n, do
         e = hipMemsetAsync(status, 0, sizeof(int), st);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(fsnap_chol_prepare_d_k, dim3((np + 255) / 256), dim3(256), 0, st, packed, cvec, n, np, alpha, dsc, z, status,
-                       minpiv, npanel);
-    hipLaunchKernelGGL(fsnap_chol_prepare_s_k, dim3((ld + 255) / 256, np), dim3(256), 0, st, packed, n, np, alpha, dsc, z, S,
-                       status);
     double* Uf = chol_factor_matrix(work, np, form);       // where the factor ends up (S itself in the in-place forms)
-    launch_first_diag(S, Uf, ld, Yall, status, minpiv, flag, form, st);
+    const bool one_launch = form == 5 && Uf != S;
+    if (one_launch) {
+        // scaling + first diagonal block in one launch (workgroup 0: the four-wave pipeline)
+        const int nx = (ld + 255) / 256;
+        hipLaunchKernelGGL(fsnap_chol_prepare_diag4_k, dim3((unsigned)(1 + np * nx)), dim3(256), 0, st, packed, cvec, n, np, alpha, dsc,
+                           S, Uf, Yall, status, minpiv, npanel, flag);
+    } else {
+        hipLaunchKernelGGL(fsnap_chol_prepare_d_k, dim3((np + 255) / 256), dim3(256), 0, st, packed, cvec, n, np, alpha, dsc, z,
+                           status, minpiv, npanel);
+        hipLaunchKernelGGL(fsnap_chol_prepare_s_k, dim3((ld + 255) / 256, np), dim3(256), 0, st, packed, n, np, alpha, dsc, z, S,
+                           status);
+        launch_first_diag(S, Uf, ld, Yall, status, minpiv, flag, form, st);
+    }
     launch_chol_panels(S, Uf, ld, np, Yall, status, minpiv, flag, form, st);
     static bool bs_attr_set = false;
     if (!bs_attr_set) {
@@ -1878,7 +1967,7 @@ hipError_t launch_chol_large(const double* packed, const double* cvec, int n, do
     for (int hi = npanel; hi > 0; hi -= CHOL_BS_MACRO) {
         const int lo = hi > CHOL_BS_MACRO ? hi - CHOL_BS_MACRO : 0;
         hipLaunchKernelGGL(fsnap_chol_backsolve_k, dim3(1), dim3(1024), CHOL_BS_LDS, st, (const double*)Uf, ld, np, n, Yall, z, dsc,
-                           beta, status, lo, hi, hi == npanel ? 1 : 0, minpiv, host_out);
+                           beta, status, lo, hi, hi == npanel ? 1 : 0, minpiv, host_out, one_launch ? (const double*)S : (const double*)nullptr);
         if (lo > 0) {
             const int nrows = lo * CHOL_NB;
             hipLaunchKernelGGL(fsnap_chol_backupdate_k, dim3((nrows + 3) / 4), dim3(256), 0, st, (const double*)Uf, ld, z, lo * CHOL_NB,

@@ -91,7 +91,7 @@ struct fsnap_ctx {
     // workspaces
     DevBuf part, cpart, spart, packed, beta, preds, sse, aw, bw;
     DevBuf quad_flow;            // kernel 1QC: flow-control words of the clusters (zeroed when allocated, never reset)
-    int quad_flow_tag = 0;       // + 2^20 per launch of kernel 1QC
+    unsigned quad_flow_tag = 0;  // + 2^20 per launch of kernel 1QC (wraps)
     DevBuf st_raw, st_plan, st_frac, st_blank;   // staging of fsnap_assemble
     DevBuf fz_rows, fz_spart, fz_part, fz_cpart; // fsnap_assemble_accumulate: per-row scratch (no A) and partials
     DevBuf dsolve;                                // [beta | min pivot | status] of fsnap_solve_device

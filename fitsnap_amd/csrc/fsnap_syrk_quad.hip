@@ -351,7 +351,7 @@ __device__ __forceinline__ QuadSeen quad_flow_look(const QuadFlow& f, int trip, 
     QuadSeen s;
     s.p[0] = s.p[1] = s.p[2] = 0x7FFFFFFF;
     if (lane == 0) {
-        __hip_atomic_store(f.word + f.me, f.tag + trip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(f.word + f.me, (int)((unsigned)f.tag + (unsigned)trip), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int peer = (f.me + 1 + k) & 3;
@@ -364,15 +364,15 @@ __device__ __forceinline__ QuadSeen quad_flow_look(const QuadFlow& f, int trip, 
 // ... and wait (bounded) for every peer that stood more than `lead` trips behind `trip`
 __device__ __forceinline__ void quad_flow_wait(const QuadFlow& f, const QuadSeen& s, int trip, int lane) {
     if (lane == 0) {
-        const int need = f.tag + trip - f.lead;
+        // serial-number arithmetic on 32-bit words: tags grow by 2^20 per launch and wrap after 4096 launches; a word of an
+        // EARLIER launch compares below `need` (and a wrong verdict would only end or prolong a bounded wait)
+        const unsigned need = (unsigned)f.tag + (unsigned)trip - (unsigned)f.lead;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int peer = (f.me + 1 + k) & 3;
             if (peer >= f.members || peer == f.me) continue;
-            // (a word of an EARLIER launch compares below `need`: tags grow by 2^20 per launch; wrap-around is harmless --
-            // a wrong verdict only ends or prolongs a bounded wait)
             int v = s.p[k], n = 0;
-            while (v - need < 0 && ++n < QUAD_FLOW_SPINS) {
+            while ((int)((unsigned)v - need) < 0 && ++n < QUAD_FLOW_SPINS) {
                 __builtin_amdgcn_s_sleep(2);
                 v = __hip_atomic_load(f.word + peer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
