@@ -540,9 +540,13 @@ __device__ __forceinline__ void lds_st(int* p, int v) { *(volatile lds_i32*)p = 
 #ifdef FSNAP_CHOL_TRACE
 // tools/chol_diag4_trace.hip: shader-clock stamps of the four waves (entry, end of each consumer step, owner start / end, exit)
 __device__ long long chol_trace_buf[4][8];
+__device__ long long chol_trace_step[4][4];
+__device__ long long chol_trace_last[4];         // when a consumer had block step A's LAST pivot in hand      // kernel 8s, workgroup 0: entry, strip substituted, tiles formed
 #define CHOL_STAMP(w, i) do { if (lane == 0) chol_trace_buf[w][i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define CHOL_STAMP_STEP(w, i) do { if (lane == 0) chol_trace_step[w][i] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define CHOL_STAMP(w, i) do { } while (0)
+#define CHOL_STAMP_STEP(w, i) do { } while (0)
 #endif
 
 struct __attribute__((aligned(16))) Diag4Lds {
@@ -608,6 +612,9 @@ __device__ __forceinline__ void diag4_consume(d4& X, const Diag4Lds& L, int e, i
             diag4_wait(L, 16 * A + j + 1, e, inv1, mult1, ok);
             inv = inv1;
             mult = mult1;
+#ifdef FSNAP_CHOL_TRACE
+            if (j == 14 && kr == 0 && e == 0) chol_trace_last[A] = (long long)__builtin_readcyclecounter();   // (last writer wins: the slowest consumer)
+#endif
         }
     }
 }
@@ -1238,33 +1245,53 @@ struct __attribute__((aligned(16))) Step4Lds {
     int xflag[4];
 };
 
-// row tails of ONE 16-column strip (first column c0) of the panel at jb, in registers: X[b][s] = row 16 b + 4 s + kr, column e
-// of U12 = U11^-T S12.  Raw rows from S, the diagonal block's factor from Uf, its inverted 16 x 16 blocks from Y.
-__device__ __forceinline__ void chol_tails_regs(const double* S, const double* Uf, int ld, int jb, int c0,
-                                                const double* __restrict__ Y, int lane, d4 (&X)[4]) {
+// The operands of a panel's blocked substitution that do not depend on the strip: the off-diagonal tiles of the diagonal block's
+// factor (as A operands, negated) and its inverted 16 x 16 diagonal blocks.  Loaded ONCE per wave, up front: fetched inside the
+// substitution they cost a round trip to L2 / HBM per block step on the launch's critical chain (tools/chol_pipeline_check with
+// -DFSNAP_CHOL_TRACE: workgroup 0 had its strip substituted 5 400 cycles into the launch, 2 600 of them MFMAs).
+struct TailOps {
+    double l[6][4];        // pairs (b, bp), bp < b: index b (b - 1) / 2 + bp; l[.][s] = -L[16 b + e][16 bp + 4 s + kr]
+    double y[4][4];        // y[b][s] = (Y_b^T)[e][4 s + kr]
+};
+
+__device__ __forceinline__ void chol_tail_ops_load(const double* Uf, int ld, int jb, const double* __restrict__ Y, int lane,
+                                                   TailOps& o) {
+    const int e = lane & 15, kr = lane >> 4;
+    const double* ubase = Uf + (size_t)(jb + kr) * ld;
+#pragma unroll
+    for (int b = 1; b < 4; ++b)
+#pragma unroll
+        for (int bp = 0; bp < b; ++bp)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) o.l[b * (b - 1) / 2 + bp][s] = -ubase[(size_t)(16 * bp + 4 * s) * ld + jb + 16 * b + e];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o.y[b][s] = Y[(b * 16 + 4 * s + kr) * 16 + e];
+}
+
+// raw rows of ONE 16-column strip (first column c0) of the panel at jb: X[b][s] = row 16 b + 4 s + kr, column e
+__device__ __forceinline__ void chol_strip_load(const double* S, int ld, int jb, int c0, int lane, d4 (&X)[4]) {
     const int e = lane & 15, kr = lane >> 4;
     const double* base = S + (size_t)(jb + kr) * ld;
-    const double* ubase = Uf + (size_t)(jb + kr) * ld;
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int s = 0; s < 4; ++s) X[b][s] = base[(size_t)(16 * b + 4 * s) * ld + c0 + e];
+}
+
+// the blocked substitution U12 = U11^-T S12 of a strip held in registers (kernel 8c's, 40 MFMAs): X in, row tails out
+__device__ __forceinline__ void chol_tails_compute(d4 (&X)[4], const TailOps& o) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         d4 acc = X[b];
 #pragma unroll
         for (int bp = 0; bp < b; ++bp)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const double a = -ubase[(size_t)(16 * bp + 4 * s) * ld + jb + 16 * b + e];   // -L[16b+e][16bp+4s+kr]
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[bp][s], acc, 0, 0, 0);
-            }
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.l[b * (b - 1) / 2 + bp][s], X[bp][s], acc, 0, 0, 0);
         d4 xb = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const double t = Y[(b * 16 + 4 * s + kr) * 16 + e];   // (Y_b^T)[e][4s+kr]
-            xb = __builtin_amdgcn_mfma_f64_16x16x4f64(t, acc[s], xb, 0, 0, 0);
-        }
+        for (int s = 0; s < 4; ++s) xb = __builtin_amdgcn_mfma_f64_16x16x4f64(o.y[b][s], acc[s], xb, 0, 0, 0);
         X[b] = xb;
     }
 }
@@ -1289,9 +1316,21 @@ __global__ __launch_bounds__(256, 2) void fsnap_chol_step4_k(double* S, double* 
     if (blockIdx.x == 0) {
         diag4_lds_reset(L.d, (int)threadIdx.x);
         if (threadIdx.x < 4) L.xflag[threadIdx.x] = 0;
+        CHOL_STAMP_STEP(wave, 0);
         __syncthreads();
+        // every load of the prologue goes out first: the strip's raw rows, the substitution's operands, the target tiles
         d4 X[4];
-        chol_tails_regs(S, Uf, ld, jb, je + 16 * wave, Y, lane, X);
+        TailOps ops;
+        chol_strip_load(S, ld, jb, je + 16 * wave, lane, X);
+        chol_tail_ops_load(Uf, ld, jb, Y, lane, ops);
+        d4 Tl[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Tl[a][r] = (a <= wave) ? S[(size_t)(je + 16 * a + 4 * r + kr) * ld + je + 16 * wave + e] : 0.0;
+        chol_tails_compute(X, ops);
+        CHOL_STAMP_STEP(wave, 1);
         if (wave < 3) {                                        // (wave-uniform) payload, then marker
 #pragma unroll
             for (int b = 0; b < 4; ++b)
@@ -1299,15 +1338,13 @@ __global__ __launch_bounds__(256, 2) void fsnap_chol_step4_k(double* S, double* 
                 for (int r = 0; r < 4; ++r) lds_st(&L.xs[wave][4 * b + r][lane], X[b][r]);
             lds_st(&L.xflag[wave], 1);
         }
-        chol_strip_store(Uf, ld, jb, je + 16 * wave, X, lane);
-        d4 Tl[4];
         bool ok = true;
+        // own tile first (own registers: wave 0 starts its pivots from here), then the tiles above it with the strips of the
+        // waves left of this one
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
+        for (int a = 3; a >= 0; --a) {
             if (a <= wave) {                                    // (wave-uniform)
-                d4 acc;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = S[(size_t)(je + 16 * a + 4 * r + kr) * ld + je + 16 * wave + e];
+                d4 acc = Tl[a];
                 if (a == wave) {
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
@@ -1328,12 +1365,13 @@ __global__ __launch_bounds__(256, 2) void fsnap_chol_step4_k(double* S, double* 
                             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[4 * b + r], X[b][r], acc, 0, 0, 0);
                 }
                 Tl[a] = acc;
-            } else {
-                Tl[a] = d4{0.0, 0.0, 0.0, 0.0};
             }
         }
+        chol_strip_store(Uf, ld, jb, je + 16 * wave, X, lane);  // (off the chain: behind the tiles)
         if (!ok && lane == 0) atomicOr(status, 2);
+        CHOL_STAMP_STEP(wave, 2);
         chol_diag4_dispatch(Tl, L.d, Uf, ld, je, Ynext, status, minpiv, wave, lane);
+        CHOL_STAMP_STEP(wave, 3);
         return;
     }
     // bulk: one 32 x 32 block pair per wave, all pairs but (0,0), (0,1), (1,1)
@@ -1359,8 +1397,12 @@ __global__ __launch_bounds__(256, 2) void fsnap_chol_step4_k(double* S, double* 
     // the two strips of block column J stay in registers; the strips of block column I are substituted one at a time (register
     // budget: two waves per SIMD)
     d4 XJ0[4], XJ1[4];
-    chol_tails_regs(S, Uf, ld, jb, cJ, Y, lane, XJ0);
-    chol_tails_regs(S, Uf, ld, jb, cJ + 16, Y, lane, XJ1);
+    TailOps ops;
+    chol_strip_load(S, ld, jb, cJ, lane, XJ0);
+    chol_strip_load(S, ld, jb, cJ + 16, lane, XJ1);
+    chol_tail_ops_load(Uf, ld, jb, Y, lane, ops);
+    chol_tails_compute(XJ0, ops);
+    chol_tails_compute(XJ1, ops);
     if (I == J || (J == nblk && I == nblk - 1)) {              // this wave's J strips are the factor's rows: store them
         chol_strip_store(Uf, ld, jb, cJ, XJ0, lane);
         chol_strip_store(Uf, ld, jb, cJ + 16, XJ1, lane);
@@ -1372,7 +1414,8 @@ __global__ __launch_bounds__(256, 2) void fsnap_chol_step4_k(double* S, double* 
 #pragma unroll
             for (int b = 0; b < 4; ++b) XI[b] = h ? XJ1[b] : XJ0[b];
         } else {
-            chol_tails_regs(S, Uf, ld, jb, cI + 16 * h, Y, lane, XI);
+            chol_strip_load(S, ld, jb, cI + 16 * h, lane, XI);
+            chol_tails_compute(XI, ops);
         }
         d4 a0, a1;
 #pragma unroll

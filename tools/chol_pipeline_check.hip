@@ -92,6 +92,23 @@ int main(int argc, char** argv) {
             den += ref[i] * ref[i];
         }
         printf("form %d: status %d, rel err %.3e, %.1f us (launch + sync, best of 10)\n", form, st, (double)sqrtl(num / den), best);
+#ifdef FSNAP_CHOL_TRACE
+        if (form == 5) {
+            // the LAST panel launch of the solve (kernel 8s, workgroup 0): where its ~17 us go, in shader cycles from the entry
+            long long ts[4][4], tb[4][8];
+            CK(hipMemcpyFromSymbol(ts, HIP_SYMBOL(chol_trace_step), sizeof(ts)));
+            CK(hipMemcpyFromSymbol(tb, HIP_SYMBOL(chol_trace_buf), sizeof(tb)));
+            long long t0 = ts[0][0];
+            for (int w = 1; w < 4; ++w) t0 = ts[w][0] < t0 ? ts[w][0] : t0;
+            printf("  wave  entry  strip_substituted  tiles_formed  own_start  own_end  pipeline_exit   (cycles)\n");
+            long long tl[4];
+            CK(hipMemcpyFromSymbol(tl, HIP_SYMBOL(chol_trace_last), sizeof(tl)));
+            printf("  last pivot of block step 0 / 1 / 2 in a consumer's hands at %lld / %lld / %lld\n", tl[0] - t0, tl[1] - t0, tl[2] - t0);
+            for (int w = 0; w < 4; ++w)
+                printf("  %4d %6lld %18lld %13lld %10lld %8lld %14lld\n", w, ts[w][0] - t0, ts[w][1] - t0, ts[w][2] - t0, tb[w][4] - t0,
+                       tb[w][5] - t0, ts[w][3] - t0);
+        }
+#endif
     }
     return 0;
 }
