@@ -341,20 +341,31 @@ __global__ __launch_bounds__(64, 2) void fsnap_trsm_acc2_k(const double* __restr
         constexpr int P = decltype(pc)::value;
         constexpr int NBP = (NB - 4 * P) < 4 ? (NB - 4 * P) : 4;       // blocks of this panel
         d4 acc[NBP][4];
-        // the panel of the row tile in the accumulator layout (tile rows g + 4 v, column e): straight into the accumulators ...
+        // the panel of the row tile in the accumulator layout (tile rows g + 4 v, column e): straight into the accumulators,
+        // through a bounds-checked buffer descriptor over the tile's rows -- ONE 32-bit offset per row of the lane (16 registers)
+        // + immediates for the column blocks instead of 64 pointer pairs (which spilled in the first-pass form), and rows past
+        // the end of the matrix read zeros in hardware
+        {
+            const double* tbase = FIRST ? src + row0 * lds_ : Q + row0 * ldq;
+            const int64_t tld = FIRST ? lds_ : ldq;
+            const int64_t trows = (m - row0) < 64 ? (m - row0) : 64;
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(tbase), 0, (int)(trows * tld * 8), 0x00020000);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int64_t r = row0 + t * 16 + g + 4 * v;
+                for (int v = 0; v < 4; ++v) {
+                    const unsigned voff = (unsigned)(((int64_t)(t * 16 + g + 4 * v) * tld + e) * 8);
 #pragma unroll
-                for (int jb = 0; jb < NBP; ++jb) {
-                    const int col = (4 * P + jb) * 16 + e;
-                    double x = 0.0;
-                    if (r < m && col < K) x = FIRST ? src[r * lds_ + col] : Q[r * ldq + col];
-                    acc[jb][t][v] = x;
+                    for (int jb = 0; jb < NBP; ++jb) {
+                        const int col = (4 * P + jb) * 16 + e;
+                        const u2 raw = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + (unsigned)((4 * P + jb) * 128), 0, 0);
+                        const double x = __builtin_bit_cast(double, raw);
+                        // (a column >= K of the last block lies in the NEXT row when lda == K: selected away, not masked by the descriptor)
+                        acc[jb][t][v] = (col < K) ? x : 0.0;
+                    }
                 }
-            }
+        }
         // ... and weighted in place in the first pass (a zero weight makes a zero row whatever A holds); the 64 weights of the
         // tile wait in LDS (kept in registers next to the 64 values of a lane they spilled), four at a time
         if constexpr (FIRST) {
@@ -862,19 +873,22 @@ hipError_t launch_trsm_rows(const double* src, int64_t lds, const double* wpack,
         const char* e = getenv("FSNAP_TRSM_KERNEL");
         return e && atoi(e) == 14;
     }();
-    // K <= 128: the first pass (row weights, rows of A with their own stride) on kernel 13A; the later passes (in place on Q) on
-    // kernel 13C -- 64-column panels, two waves per SIMD.  tools/trsm_check, 10^6 rows, round 5 (13A / 13C, ms): K = 128 0.740 /
-    // 0.652, 110 0.643 / 0.658, 96 0.519 / 0.423, 64 0.250 / 0.236, 31 0.136 / 0.109; first pass 128 0.787 / 1.165 (its 64 loads of
-    // A plus the weights do not fit two waves' register budget: 140 bytes per lane spill), 96 0.551 / 0.810.
+    // K <= 128: kernel 13C (64-column panels, two waves per SIMD) for every pass.  tools/trsm_check, 10^6 rows, round 5 (13A / 13C,
+    // ms): in-place passes K = 128 0.737 / 0.590, 110 0.642 / 0.535, 96 0.517 / 0.383, 64 0.249 / 0.201, 31 0.135 / 0.108; first pass
+    // (row weights, rows of A) 128 0.765 / 0.709, 110 0.690 / 0.701, 96 0.546 / 0.479, 64 0.348 / 0.219, 31 0.171 / 0.171 (its
+    // first-pass form still spills 60 bytes per lane; with pointer loads instead of the buffer descriptor: 140-270 bytes, 1.17 ms).
     // FSNAP_TRSM_KERNEL = 12: kernel 13A for every pass (A/B)
     static const bool acc_only = [] {
         const char* e = getenv("FSNAP_TRSM_KERNEL");
         return e && atoi(e) == 12;
     }();
-    if (K16 <= 128 && !panel_always && !wpack && !acc_only) {
+    if (K16 <= 128 && !panel_always && !acc_only) {
         const dim3 grid((unsigned)nb), block(64);
-#define FSNAP_TRSM_ACC2(NBV) \
-    case NBV: hipLaunchKernelGGL((fsnap_trsm_acc2_k<NBV, false>), grid, block, 0, st, src, lds, wpack, Q, ldq, m, K, R); break;
+#define FSNAP_TRSM_ACC2(NBV)                                                                                                 \
+    case NBV:                                                                                                                \
+        if (wpack) hipLaunchKernelGGL((fsnap_trsm_acc2_k<NBV, true>), grid, block, 0, st, src, lds, wpack, Q, ldq, m, K, R);   \
+        else hipLaunchKernelGGL((fsnap_trsm_acc2_k<NBV, false>), grid, block, 0, st, src, lds, wpack, Q, ldq, m, K, R);        \
+        break;
         switch (K16 / 16) {
             FSNAP_TRSM_ACC2(1) FSNAP_TRSM_ACC2(2) FSNAP_TRSM_ACC2(3) FSNAP_TRSM_ACC2(4)
             FSNAP_TRSM_ACC2(5) FSNAP_TRSM_ACC2(6) FSNAP_TRSM_ACC2(7) FSNAP_TRSM_ACC2(8)
