@@ -122,7 +122,7 @@ int fsnap_rowspace_solve(int64_t K, const double* Rhat, const double* z, double 
     fs.apply(z, beta);
     if (rank) *rank = fs.rank;
     if (info) {
-        info[0] = fs.triangular ? 0.0 : 1.0;
+        info[0] = fs.triangular ? 0.0 : (fs.deflated ? 3.0 : 1.0);
         info[1] = fs.smax;
         info[2] = fs.smin;
         info[3] = fs.sweeps;
@@ -459,7 +459,8 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
         info[0] = passes;
         info[1] = dev;
         info[2] = converged;
-        info[3] = (use_chain || fs.triangular) ? 0.0 : (fs.use_external ? 2.0 : 1.0);      // 2: the host language's SVD
+        info[3] = (use_chain || fs.triangular) ? 0.0 : (fs.deflated ? 3.0 : (fs.use_external ? 2.0 : 1.0));      // 2: the host language's SVD,
+                                                                                // 3: dropped triplets projected away (deflate)
         info[4] = use_chain ? chain_norm : fs.smax;                       // chain: bounds, not singular values
         info[5] = use_chain ? (chain_inv > 0.0 ? 1.0 / chain_inv : 0.0) : fs.smin;
         info[6] = rel_step;

@@ -52,6 +52,10 @@ struct FactorSolver {
     int K = 0, n = 0, rank = 0;
     std::vector<int> act;
     bool triangular = false;   // no singular value can be below the cut: back substitution
+    bool deflated = false;     // a few (ncut <= 4) singular values are below the cut and every other one provably above it: back
+                               // substitution between two projections (deflate), no SVD
+    int ncut = 0;
+    std::vector<double> Uc, Vc;   // the dropped triplets' left / right singular vectors (ncut x n each, orthonormal rows)
     std::vector<double> T;     // n x n active block of R_hat (row-major, upper)
     std::vector<double> W, J, s2;   // SVD form: rows of W = sigma_i v_i^T (n x n), J = U^T (n x n), s2 = sigma_i^2
     std::vector<char> keep;
@@ -67,6 +71,7 @@ struct FactorSolver {
     mutable bool use_external = false;
     void prepare(int K_, const double* Rhat, double rcond);
     void jacobi_svd(double rcond);
+    bool deflate(double rcond, std::vector<double>& X, double norm_bound);   // X = T^-1 on entry (overwritten)
     void apply(const double* z, double* beta) const;   // beta (K entries, zeros in inactive columns) = pinv(R_hat) z
 };
 

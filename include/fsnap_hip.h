@@ -330,8 +330,11 @@ int fsnap_set_dense_pinv(fsnap_ctx* ctx, fsnap_dense_pinv_fn fn, void* user);
  * (singular values below rcond * sigma_max dropped, minimum-norm solution) and one refinement step with the residual
  * of the original rows.  Needs m * K * 8 more bytes of HBM.  Collective when the context has a communicator (a rank
  * without rows passes K and contributes nothing).  *rank = numerical rank used.  info (may be NULL, 8 doubles):
- * passes, last max|Q^T Q - I|, converged (0/1), SVD used (0 = back substitution), sigma_max, sigma_min estimate,
- * relative size of the refinement step, last shift. */
+ * passes, last max|Q^T Q - I|, converged (0/1), how the K x K end was solved (0 = back substitution: nothing to drop;
+ * 3 = back substitution between two projections: 1...4 dropped directions found by subspace iteration, every other
+ * singular value certified above the cut; 1 = the library's one-sided Jacobi SVD; 2 = the host language's dense kernel),
+ * sigma_max, sigma_min estimate (bounds unless the SVD ran), relative size of the refinement step, last shift.
+ * FSNAP_ROWSPACE_DEFLATE=0 in the environment takes form 3 out (A/B). */
 int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K, double* beta, int* rank, double* info);
 
 /* The two host steps of that solve for callers that run the passes themselves (rows streamed through
@@ -341,7 +344,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K, double* beta, int*
  *   else changes.  Otherwise Rp (K x K, upper triangular) receives the factor to divide out (Q <- Q Rp^-1 by
  *   substitution) and R_hat <- Rp R_hat.  info (may be NULL, 3 doubles): deviation, converged, shift.
  * fsnap_rowspace_solve: beta = pinv_rcond(R_hat) z with z = Q^T (w b), dgelsd semantics; info (may be NULL, 4 doubles):
- *   SVD used, sigma_max, sigma_min kept, Jacobi sweeps. */
+ *   how it was solved (0 / 3 / 1 as in fsnap_lstsq_rows), sigma_max, sigma_min kept, Jacobi sweeps. */
 int fsnap_rowspace_factor(int64_t K, const double* G, int first, double tol, double* Rhat, double* Rp, double* info);
 int fsnap_rowspace_solve(int64_t K, const double* Rhat, const double* z, double rcond, double* beta, int* rank, double* info);
 

@@ -240,8 +240,10 @@ def test_lstsq_rows_factor_chain_path_on_the_gpu():
 
 @pytest.mark.parametrize("case", ["duplicated", "fewer_rows_than_columns"])
 def test_large_k_truncated_solve_runs_in_lapack(case):
-    # K > 256 and a truncation is needed: the K x K end goes through the dense-pinv hook the Python layer installs
-    # (scipy's gesdd) instead of the library's Jacobi SVD (~20 s at K = 1595); info["svd"] == 2 says so
+    # K > 256 and a truncation is needed.  Two dependent columns: the two dropped directions are projected away around a back
+    # substitution (FactorSolver::deflate, info["svd"] == 3), no SVD at all.  120 dropped directions: the K x K end goes
+    # through the dense-pinv hook the Python layer installs (scipy's gesdd) instead of the library's Jacobi SVD (~20 s at
+    # K = 1595); info["svd"] == 2 says so
     r = np.random.default_rng(17)
     K = 320
     if case == "duplicated":
@@ -258,7 +260,7 @@ def test_large_k_truncated_solve_runs_in_lapack(case):
     ref = orc.svd_fit(A, b, w)
     pt, s = make_svd()
     s.perform_fit(A, b, w, trainall=True)
-    assert s.last_row_space is not None and s.last_row_space["svd"] == 2.0
+    assert s.last_row_space is not None and s.last_row_space["svd"] == (3.0 if case == "duplicated" else 2.0)
     assert s.last_rank == rank_ref == (K - 2 if case == "duplicated" else m)
     assert np.linalg.norm(s.fit - ref) <= 1e-7 * np.linalg.norm(ref)
     pt.free()
@@ -268,6 +270,6 @@ def test_large_k_truncated_solve_runs_in_lapack(case):
     ctx.upload_rows(A, b)
     ctx.set_weights(w)
     beta, rank, info = ctx.lstsq_rows(1.0e-13)
-    assert info["svd"] == 1.0 and rank == rank_ref
+    assert info["svd"] == (3.0 if case == "duplicated" else 1.0) and rank == rank_ref
     assert np.linalg.norm(beta - ref) <= 1e-7 * np.linalg.norm(ref)
     ctx.close()

@@ -240,3 +240,81 @@ def test_dense_pinv_hook_is_gelsd_on_the_factor():
         rc = cb(None, token, n, T.ctypes.data_as(dp), 1.0e-10, y.ctypes.data_as(dp), x.ctypes.data_as(dp), ctypes.byref(rank))
         ref, _, rank_ref, _ = sl.lstsq(T, y, cond=1.0e-10)
         assert rc == 0 and rank.value == rank_ref and np.allclose(x, ref, rtol=1e-9, atol=1e-11)
+
+
+def _factor_with_dependent_columns(n, ndep, kept_cond, seed, noise=0.0):
+    """Upper-triangular factor of a matrix whose `ndep` columns are combinations of three others (+ relative `noise`)."""
+    r = np.random.default_rng(seed)
+    A = r.standard_normal((4 * n, n)) * np.exp(r.uniform(np.log(1.0 / kept_cond), 0.0, n))[None, :]
+    dep = r.choice(n, ndep, replace=False)
+    others = np.setdiff1d(np.arange(n), dep)
+    for d in dep:
+        pick = r.choice(others, 3, replace=False)
+        col = A[:, pick] @ r.standard_normal(3)
+        A[:, d] = col * (np.linalg.norm(A[:, d]) / np.linalg.norm(col))
+        if noise:
+            A[:, d] += noise * np.linalg.norm(A[:, d]) / np.sqrt(4 * n) * r.standard_normal(4 * n)
+    R = np.linalg.qr(A, mode="r")
+    sg = np.sign(np.diag(R))
+    sg[sg == 0] = 1.0
+    return R * sg[:, None], r.standard_normal(n)
+
+
+@pytest.mark.parametrize("n", [64, 128, 200])
+@pytest.mark.parametrize("ndep", [1, 2, 3, 4])
+@pytest.mark.parametrize("kept_cond,noise", [(1e2, 0.0), (1e4, 1e-15), (1e6, 0.0)])
+def test_a_few_dropped_directions_are_projected_away_without_the_svd(n, ndep, kept_cond, noise, monkeypatch):
+    # the K x K end with 1...4 singular values below the cut and a gap above them (duplicated / combined descriptor columns):
+    # info[0] == 3 says the truncated solution came from back substitution between two projections (FactorSolver::deflate);
+    # it agrees with the library's own Jacobi SVD (FSNAP_ROWSPACE_DEFLATE=0) to ~eps x the condition of the kept part and
+    # with LAPACK's gelsd as closely as the Jacobi SVD does
+    R, z = _factor_with_dependent_columns(n, ndep, kept_cond, seed=1000 * n + 10 * ndep + int(np.log10(kept_cond)), noise=noise)
+    ref, _, rank_ref, sv = np.linalg.lstsq(R, z, rcond=1.0e-13)
+    assert rank_ref == n - ndep
+    beta, rank, info = _capi.rowspace_solve(R, z, 1.0e-13)
+    assert rank == rank_ref and info[0] == 3.0
+    assert info[1] <= sv[0] * (1 + 1e-12) and info[1] >= 0.5 * sv[0]            # sigma_max from below
+    assert info[2] <= sv[rank - 1] * (1 + 1e-9) and info[2] >= sv[rank - 1] / (4 * np.sqrt(n))   # smallest kept one from below
+    monkeypatch.setenv("FSNAP_ROWSPACE_DEFLATE", "0")
+    beta_j, rank_j, info_j = _capi.rowspace_solve(R, z, 1.0e-13)
+    monkeypatch.delenv("FSNAP_ROWSPACE_DEFLATE")
+    assert rank_j == rank and info_j[0] == 1.0
+    scale = np.abs(beta_j).max()
+    assert np.abs(beta - beta_j).max() <= 200 * kept_cond * EPS * scale
+    err, err_j = np.abs(beta - ref).max(), np.abs(beta_j - ref).max()
+    assert err <= 2.0 * err_j + 200 * kept_cond * EPS * scale
+
+
+def test_the_projection_path_steps_aside_when_it_cannot_call_the_rank():
+    n = 128
+    r = np.random.default_rng(77)
+    U, _ = np.linalg.qr(r.standard_normal((n, n)))
+    V, _ = np.linalg.qr(r.standard_normal((n, n)))
+    z = r.standard_normal(n)
+
+    def solve(s):
+        R = np.linalg.qr((U * s) @ V.T, mode="r")
+        sg = np.sign(np.diag(R))
+        return _capi.rowspace_solve(R * sg[:, None], z, 1.0e-13), np.linalg.lstsq(R * sg[:, None], z, rcond=1.0e-13)
+
+    base = np.sort(np.exp(r.uniform(np.log(1e-3), 0.0, n)))[::-1]
+    base[0] = 1.0
+    # (a) five values below the cut: more than the projection path takes on
+    s = base.copy()
+    s[-5:] = 1e-16 * np.array([1, 2, 3, 4, 5.0])
+    (beta, rank, info), (ref, _, rk, _) = solve(s)
+    assert rank == rk == n - 5 and info[0] == 1.0
+    # (b) a value 1.5 x above the cut (kept, kappa ~ 7e12): the certificate of the deflated inverse cannot close
+    s = base.copy()
+    s[-1] = 1.5e-13
+    (beta, rank, info), (ref, _, rk, _) = solve(s)
+    assert rank == rk == n and info[0] == 1.0
+    # (c) one below, one just above the cut
+    s = base.copy()
+    s[-2:] = [2.0e-13, 1e-15]
+    (beta, rank, info), (ref, _, rk, _) = solve(s)
+    assert rank == rk == n - 1 and info[0] == 1.0
+    # (d) no gap at all: a geometric ladder down through the cut
+    s = np.logspace(0, -16, n)
+    (beta, rank, info), (ref, _, rk, _) = solve(s)
+    assert rank == rk and info[0] == 1.0
