@@ -168,6 +168,7 @@ struct fsnap_ctx {
     int opt_mirror_upper = 1; // kernel 2b writes the host mirror's triangle once per element (upper positions)
     int opt_fused_pack = 1;   // kernel 1A forms the per-row pairs of its rows in LDS itself (no packing launch) when they fit
     int opt_acc_min_cpw = 0;  // kernel 1A: fewest 4-row chunks per row-wave before the grid shrinks (0 = default)
+    int opt_rowspace_reuse = 0;  // one-shot, set by the caller right before fsnap_lstsq_rows: the statistics of the fit that just ran (still in the page-locked mirror) are those of the rows as they are now -- the first pass starts from them
     int opt_chol_form = -1;   // panel loop of the device Cholesky: -1 = default (FSNAP_CHOL_DIAG, else 5: one launch per panel, four-wave diagonal block); 0 | 1 | 2 | 4: the A/B forms (fsnap_chol.hip)
     int opt_quad_flow = 2 + 4 * 63;  // kernel 1QC (lead 63 = by cluster size: 0 for clusters of 2, 2 for clusters of 4): flow control between the members of a cluster: mode (0 off, 1 look at the end of a trip, 2 at its start) + 4 x lead (trips a member may run ahead)
     int opt_quad_cluster = 1; // kernel 1QC (288 < K <= 512: kernel 1Q's plan on a cluster of 2 / 4 workgroups of one XCD); 0 = tiled kernel there

@@ -564,6 +564,10 @@ class Solver:
         """``lstsq(aw, bw, rcond)`` on the rows (``fsnap_lstsq_rows``): CholeskyQR passes on the GPU, dgelsd's K x K end
         on the host.  The rows and weights of the fit that just ran are resident.  Collective in a multi-rank job."""
         ctx = self.pt.hip()
+        if not self.pt.multi and self._stats_dev is not None and self._stats_dev[0] is ctx and self._stats_dev[2] == K:
+            # the fit from the statistics that sent us here ran on these rows, weights and mask a moment ago: the first
+            # CholeskyQR pass starts from its Gram matrix instead of computing it again (one-shot, see include/fsnap_hip.h)
+            ctx.set_option("rowspace_reuse_stats", 1)
         beta, rank, info = ctx.lstsq_rows(rcond, K)
         self.last_rank = rank
         self.last_row_space = info

@@ -115,6 +115,10 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * "mirror_upper" (0|1, default 1: the reduction writes the host mirror's triangle once per element, at its upper position),
  * "fused_residual" (fsnap_residual_rhs for K <= 288: 1 = one pass over the rows, the default; 2 = one pass with the next rows
  * prefetched into a second register set -- measured slower, fewer waves per SIMD; 0 = the two-kernel form, two passes),
+ * "rowspace_reuse_stats" (one-shot, cleared by the next fsnap_lstsq_rows: 1 = the caller states that the fit from the statistics
+ * which just ran -- fsnap_fit_resident on this context -- saw the rows, weights and mask as they are now; a single-rank
+ * fsnap_lstsq_rows on a system the host factorises then starts its first pass from that fit's statistics, still in the page-locked
+ * mirror, instead of computing them again: 0.35 ms of a 10^6 x 128 call),
  * "reduce_triangle" (fsnap_fit_dist / fsnap_lstsq_rows: -1 = systems of >= 256 columns all-reduce [upper triangle | c | scalars],
  * K (K + 1) / 2 + K + 3 doubles, between a pack and an unpack kernel, the default; 0 = always the full K^2 + K + 3; 1 = always
  * the triangle -- every rank of a job must use the same setting),
