@@ -537,6 +537,17 @@ __device__ __forceinline__ void lds_st(int* p, int v) { *(volatile lds_i32*)p = 
                                // step; K = 1595 534 us either way (profiles/r05_chol_forms.txt)
 #endif
 
+#ifndef FSNAP_D4_REDUNDANT
+#define FSNAP_D4_REDUNDANT 0   // 1: every wave right of a block step's owner factorises ITS OWN copy of the step's diagonal tile (handed over
+                               //    once, before the first pivot) instead of replaying the owner's pivots one LDS hand-off at a time.  Bit-identical
+                               //    results, no LDS traffic inside a block step -- and SLOWER: K = 1595 597 against 537 us, 256: 101 / 89, 480: 190 / 165
+                               //    (tools/chol_pipeline_check, profiles/r05_chol_forms.txt).  A consumer's step on its private copy takes as long as
+                               //    the owner's (~4 600-5 100 cycles for 16 pivots), and it now sits ON the critical path in front of the next owner's
+                               //    step (+ the tile hand-over, ~6 750 cycles from one owner's start to the next) where the replay form overlaps all
+                               //    but the last pivot with the owner (~6 100-6 600).  So the ~300 cycles per pivot in situ are the chain itself, not
+                               //    the polling.  Kept as an A/B build switch.
+#endif
+
 #ifdef FSNAP_CHOL_TRACE
 // tools/chol_diag4_trace.hip: shader-clock stamps of the four waves (entry, end of each consumer step, owner start / end, exit)
 __device__ long long chol_trace_buf[4][8];
@@ -558,6 +569,8 @@ struct __attribute__((aligned(16))) Diag4Lds {
     int gflag[16];             // group published
     double tile[3][4][64];     // U_01, U_02, U_12 handed from wave b to the waves right of it (accumulator layout, lane for lane)
     int tflag[4];              // [0] U_01, [1] U_02, [2] U_12 published
+    double dtile[4][4][64];    // redundant form: the diagonal tile of block step a as its owner holds it BEFORE the first pivot (accumulator layout)
+    int dflag[4];              // ... published
     double T[4][16][17];       // per-wave transpose scratch of the inverses
 };
 
@@ -569,6 +582,7 @@ __device__ __forceinline__ int diag4_tile_index(int a, int b) { return a == 0 ? 
 __device__ __forceinline__ void diag4_lds_reset(Diag4Lds& L, int tid) {
     if (tid < 64) L.inv[tid] = 0.0;
     if (tid < 4) L.tflag[tid] = 0;
+    if (tid < 4) L.dflag[tid] = 0;
     if (tid < 16) L.gflag[tid] = 0;
 }
 
@@ -914,10 +928,178 @@ __device__ __forceinline__ void chol_diag4_wave(d4 (&Tl)[4], Diag4Lds& L, double
     CHOL_STAMP(W, 6);
 }
 
+// ---- redundant form (FSNAP_D4_REDUNDANT = 1; measured slower, see the switch) ----------------------------------------------------
+// In the form above the owner of a block step publishes every pivot (16 multipliers + 1/sqrt(d)) through LDS and three consumers
+// poll for it: 312 cycles per pivot in situ against 225 for the chain alone (tools/lat_bench), and a hand-over of ~1 150 cycles
+// from one owner to the next.  Here the owner hands its diagonal tile over ONCE, before its first pivot (2 KB, payload then
+// marker), and every wave right of it runs the owner's own chain on a private copy -- the same instructions on the same values,
+// so every wave holds bit-identical multipliers -- with the row operations on its own tile T[a][W] as one more MFMA per pivot
+// that issues inside the chain's VALU stretch (readlane, rsqrt + Newton, scaling: the matrix pipe is idle there).  No LDS
+// traffic inside a block step, nobody polls while somebody computes, all four waves run the same code (instruction cache).
+// The owner carries the identity tile in the same slot: Z = U_aa^-T comes out of its own pass (no replay afterwards).
+//   X: the wave's tile of this block step (consumer) / the identity (owner); D: the diagonal tile, factorised in place
+template <bool OWNER>
+__device__ __forceinline__ void diag4r_step(d4& D, d4& X, int e, int kr, double& pmin, double& psum) {
+    double dcur = readlane_f64(D[0], 0);
+    double inv = FSNAP_D4_NEWTON == 2 ? rsqrt_newton2(dcur) : rsqrt_newton(dcur);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int q = j >> 2, k = j & 3;
+        if (OWNER) {
+            pmin = dcur < pmin ? dcur : pmin;              // (a NaN pivot is caught by the sum)
+            psum += dcur;
+        }
+        double t = 0.0, pn = 0.0;
+        if (j < 15) {
+            const int q1 = (j + 1) >> 2, k1 = (j + 1) & 3;
+            t = readlane_f64(D[q], k * 16 + j + 1);        // D[j][j + 1] before this step's scaling
+            pn = readlane_f64(D[q1], k1 * 16 + j + 1);     // D[j + 1][j + 1] before this step's update
+        }
+        const bool own = (kr == k);
+        const double ud = D[q] * inv;                      // U[j][e]
+        const bool keep = own && e >= j;
+        D[q] = keep ? ud : D[q];
+        const double aop = (own && e > j) ? -ud : 0.0;     // A[i][k] = -U[j][i], rows i > j
+        const double xs = X[q] * inv;                      // row j of U_aW (of Z)
+        X[q] = own ? xs : X[q];
+        if (j < 15) {
+            const double bop = keep ? ud : 0.0;
+            D = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, D, 0, 0, 0);
+            X = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, own ? xs : 0.0, X, 0, 0, 0);
+            const double u = t * inv;
+            dcur = __builtin_fma(-u, u, pn);               // the MFMA's own value for D[j + 1][j + 1], one FMA behind 1/sqrt(d_j)
+            inv = FSNAP_D4_NEWTON == 2 ? rsqrt_newton2(dcur) : rsqrt_newton(dcur);
+        }
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void chol_diag4r_wave(d4 (&Tl)[4], Diag4Lds& L, double* S, int ld, int jb,
+                                                 double* __restrict__ Y, int* __restrict__ status,
+                                                 double* __restrict__ minpiv, int lane) {
+    const int e = lane & 15, kr = lane >> 4;
+    bool ok = true;
+    d4 held = {0.0, 0.0, 0.0, 0.0};
+    double pmin = 1.0e300, psum = 0.0;
+    CHOL_STAMP(W, 0);
+    // ---- block steps left of the own one: the step's diagonal tile from its owner, then its pivots on the own tile ------------
+#pragma unroll
+    for (int a = 0; a < W; ++a) {
+        d4& X = Tl[a];
+        d4 Dc;
+        {
+            int n = 0;
+            while (lds_ld(&L.dflag[a]) == 0 && ++n < CHOL_D4_SPINS) {
+#if FSNAP_D4_SLEEP
+                __builtin_amdgcn_s_sleep(1);
+#endif
+            }
+            if (n >= CHOL_D4_SPINS) ok = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Dc[r] = lds_ld(&L.dtile[a][r][lane]);
+        }
+        double unused0 = 0.0, unused1 = 0.0;
+        diag4r_step<false>(Dc, X, e, kr, unused0, unused1);
+        if (a + 1 == W) {
+            // next owner: its diagonal tile needs nothing but its own registers -- first thing after the last pivot, as two
+            // chains of two MFMAs, then straight to the waves right of it
+            d4 half = {0.0, 0.0, 0.0, 0.0};
+            Tl[W] = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[0], X[0], Tl[W], 0, 0, 0);
+            half = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[1], X[1], half, 0, 0, 0);
+            Tl[W] = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[2], X[2], Tl[W], 0, 0, 0);
+            half = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[3], X[3], half, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Tl[W][r] += half[r];
+            if (W < 3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lds_st(&L.dtile[W][r][lane], Tl[W][r]);
+                lds_st(&L.dflag[W], 1);
+            }
+        }
+        if (W < 3) {
+            // U_aW for the waves right of this one (payload, then marker)
+            const int ti = diag4_tile_index(a, W);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) lds_st(&L.tile[ti][s][lane], X[s]);
+            lds_st(&L.tflag[ti], 1);
+        }
+        if (a + 1 < W) {
+            // T[b][W] -= U_ab^T U_aW, b = a + 1 ... W - 1 with U_ab from wave b, then b = W from the own registers
+#pragma unroll
+            for (int b = a + 1; b < W; ++b) {
+                const int ti = diag4_tile_index(a, b);
+                int n = 0;
+                while (lds_ld(&L.tflag[ti]) == 0 && ++n < CHOL_D4_SPINS) {
+                }
+                if (n >= CHOL_D4_SPINS) ok = false;
+                double at[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) at[s] = lds_ld(&L.tile[ti][s][lane]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) Tl[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-at[s], X[s], Tl[b], 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Tl[W] = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[s], X[s], Tl[W], 0, 0, 0);
+        }
+        // the finished tile U_aW goes out at once -- except on the hand-over to the own block step, where the stores wait behind
+        // the owner phase (`held` is a copy: see the note in chol_diag4_wave)
+        if (a + 1 < W) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(size_t)(jb + 16 * a + 4 * r + kr) * ld + jb + 16 * W + e] = X[r];
+        } else {
+            held = X;
+        }
+        CHOL_STAMP(W, 1 + a);
+    }
+    CHOL_STAMP(W, 4);
+    // ---- the own block step -------------------------------------------------------------------------------------------------------
+    d4& D = Tl[W];
+    if (W == 0 && W < 3) {
+        // (the later owners published theirs right behind their diagonal update above)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds_st(&L.dtile[0][r][lane], D[r]);
+        lds_st(&L.dflag[0], 1);
+    }
+    d4 Z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Z[r] = (4 * r + kr == e) ? 1.0 : 0.0;
+    diag4r_step<true>(D, Z, e, kr, pmin, psum);
+    CHOL_STAMP(W, 5);
+    if (W > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(size_t)(jb + 16 * (W - 1) + 4 * r + kr) * ld + jb + 16 * W + e] = held[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (e >= 4 * r + kr) S[(size_t)(jb + 16 * W + 4 * r + kr) * ld + jb + 16 * W + e] = D[r];
+    if (!(pmin > 0.0) || !__builtin_isfinite(psum)) {      // non-positive, NaN or infinite pivot
+        if (lane == 0) atomicOr(status, 2);
+    } else if (lane == 0) {
+        atomicMin(reinterpret_cast<unsigned long long*>(minpiv + jb / CHOL_NB), (unsigned long long)__double_as_longlong(pmin));
+    }
+    // Y_W = U_WW^-1 = Z^T, through this wave's transpose scratch
+    double(*T)[17] = L.T[W];
+    chol_wave_sync();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[4 * r + kr][e] = Z[r];
+    chol_wave_sync();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) Y[(W * 16 + 4 * s + kr) * 16 + e] = T[e][4 * s + kr];
+    if (!ok && lane == 0) atomicOr(status, 2);
+    CHOL_STAMP(W, 6);
+}
+
 // (S here is where the FACTOR goes: the work matrix itself in the in-place forms, the second matrix in the one-launch form)
 __device__ __forceinline__ void chol_diag4_dispatch(d4 (&Tl)[4], Diag4Lds& L, double* S, int ld, int jb,
                                                     double* __restrict__ Y, int* __restrict__ status,
                                                     double* __restrict__ minpiv, int wave, int lane) {
+#if FSNAP_D4_REDUNDANT
+    if (wave == 0) chol_diag4r_wave<0>(Tl, L, S, ld, jb, Y, status, minpiv, lane);
+    else if (wave == 1) chol_diag4r_wave<1>(Tl, L, S, ld, jb, Y, status, minpiv, lane);
+    else if (wave == 2) chol_diag4r_wave<2>(Tl, L, S, ld, jb, Y, status, minpiv, lane);
+    else chol_diag4r_wave<3>(Tl, L, S, ld, jb, Y, status, minpiv, lane);
+    return;
+#endif
     if (wave == 0) chol_diag4_wave<0>(Tl, L, S, ld, jb, Y, status, minpiv, lane);
     else if (wave == 1) chol_diag4_wave<1>(Tl, L, S, ld, jb, Y, status, minpiv, lane);
     else if (wave == 2) chol_diag4_wave<2>(Tl, L, S, ld, jb, Y, status, minpiv, lane);
