@@ -899,6 +899,8 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
     } else if (!strcmp(key, "dist_solve")) {
         if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "dist_solve must be 0 (solve on every rank) or 1 (rank 0 solves and broadcasts)");
         ctx->opt_dist_solve = (int)value;
+    } else if (!strcmp(key, "rowspace_reuse_stats")) {
+        ctx->opt_rowspace_reuse = value != 0;
     } else if (!strcmp(key, "chol_form")) {
         if (value < -1 || value > 5 || value == 3)
             return ctx->fail(FSNAP_E_ARG, "chol_form must be -1 (default), 0, 1, 2 (single-wave diagonal block), 4 or 5");

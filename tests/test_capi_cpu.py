@@ -43,6 +43,25 @@ def test_integration_document_names_every_entry_point():
     assert not missing, f"INTEGRATION.md does not mention {missing}"
 
 
+def test_every_documented_option_is_accepted_and_every_option_the_host_layer_sets_exists():
+    # fsnap_set_option's keys live in three places: the header's comment, the strcmp chain of fsnap_capi.cpp and the
+    # set_option() calls of the Python host layer.  (A key that only the host layer knows fails on the GPU box only.)
+    header = open(os.path.join(ROOT, "include", "fsnap_hip.h")).read()
+    end = header.index("int fsnap_set_option(")
+    documented = set(re.findall(r'"([a-z][a-z0-9_]+)"', header[header.rindex("/*", 0, end):end]))
+    source = open(os.path.join(ROOT, "fitsnap_amd", "csrc", "fsnap_capi.cpp")).read()
+    accepted = set(re.findall(r'strcmp\(key, "([a-z0-9_]+)"\)', source))
+    assert documented <= accepted, f"documented but not accepted: {sorted(documented - accepted)}"
+    assert accepted - documented <= {"ablate"}, f"accepted but not documented: {sorted(accepted - documented)}"
+    used = set()
+    for base, _, files in os.walk(os.path.join(ROOT, "fitsnap_amd")):
+        for name in files:
+            if name.endswith(".py"):
+                used |= set(re.findall(r'set_option\(\s*"([a-z0-9_]+)"', open(os.path.join(base, name)).read()))
+    used |= set(re.findall(r'set_option\(\s*"([a-z0-9_]+)"', open(os.path.join(ROOT, "bench.py")).read()))
+    assert used and used <= accepted, f"set by the host layer but unknown to the library: {sorted(used - accepted)}"
+
+
 def test_no_gpu_means_loud_failure():
     if _capi.device_count() > 0:
         pytest.skip("a GPU is present")
