@@ -482,9 +482,10 @@ inline void project_out(int n, int nq, const double* Q, double* x) {
 
 namespace {
 
-constexpr int DB = 8;      // block width of the subspace iteration: up to 4 dropped directions + guard vectors
+// DB = block width of the subspace iteration: the dropped directions + guard vectors (8: up to 4 dropped; 32: up to 24)
 
 // W <- T^-1 W / W <- T^-T W for an n x DB block stored row-major (the DB right-hand sides of a row are contiguous)
+template <int DB>
 void solve_upper_block(int n, const double* T, double* W) {
     for (int i = n - 1; i >= 0; --i) {
         const double* ti = T + (size_t)i * n;
@@ -500,6 +501,7 @@ void solve_upper_block(int n, const double* T, double* W) {
     }
 }
 
+template <int DB>
 void solve_upper_transposed_block(int n, const double* T, double* W) {
     for (int i = 0; i < n; ++i) {
         const double* ti = T + (size_t)i * n;
@@ -515,6 +517,7 @@ void solve_upper_transposed_block(int n, const double* T, double* W) {
 }
 
 // orthonormal columns by modified Gram-Schmidt, twice; a column that vanishes is replaced by a pseudo-random one
+template <int DB>
 void orthonormalise_block(int n, double* W) {
     unsigned long long state = 0xD1B54A32D192ED03ull;
     for (int c = 0; c < DB; ++c) {
@@ -544,6 +547,7 @@ void orthonormalise_block(int n, double* W) {
 
 // SVD of a DB x DB matrix G (row-major) by one-sided Jacobi on its columns: G Q = P diag(sig), sorted descending.
 // P and Q are returned row-major (columns = singular vectors).
+template <int DB>
 void small_svd(const double* G, double* P, double* sig, double* Q) {
     double M[DB][DB], R[DB][DB];
     for (int i = 0; i < DB; ++i)
@@ -602,22 +606,21 @@ void small_svd(const double* G, double* P, double* sig, double* Q) {
 // and a comfortable gap above them.  dgelsd's answer is then x = sum_{kept} v_i (u_i . y) / sigma_i, and the kept part of T^-1
 // is what is left of it after the dropped triplets are projected away:
 //     x = (I - Vc Vc^T) T^-1 (I - Uc Uc^T) y.
-// The dropped triplets come from subspace (block inverse) iteration on T with DB = 8 vectors -- two block back substitutions per
-// step, the dropped directions converge at (sigma_dropped / sigma_9th-smallest)^2 per step however they cluster among themselves
-// -- started from the heaviest rows of T^-1, with a Rayleigh-Ritz step (SVD of the 8 x 8 matrix V^T T^-1 U) in every iteration.
+// The dropped triplets come from subspace (block inverse) iteration on T with DB = 8 vectors (up to 4 dropped directions; when
+// there are more, once again with 32 vectors: up to 24) -- two block back substitutions per step, the dropped directions
+// converge at (sigma_dropped / sigma_(DB+1)th-smallest)^2 per step however they cluster among themselves -- started from the
+// heaviest rows of T^-1, with a Rayleigh-Ritz step (SVD of the DB x DB matrix V^T T^-1 U) in every iteration.
 // Ritz values of T^-1 never exceed its singular values, so a Ritz sigma below rcond x a LOWER bound of sigma_max (power
 // iteration) is a dropped direction for certain; and the method is only used when the deflated inverse
 //     X - sum_c v_c u_c^T / sigma_c
 // passes the same norm certificate the triangular case uses (with margin 0.1): every remaining singular value is then above the
-// cut.  Anything else -- more than 4 dropped values, a sigma too close to the cut to call, slow convergence, a certificate that
-// does not close -- returns false and the Jacobi SVD decides.  n = 128: ~0.2 ms against 1.7 ms of Jacobi sweeps.
-bool FactorSolver::deflate(double rc, std::vector<double>& X, double norm_bound) {
-    constexpr int MAXCUT = 4, MAXIT = 10;
-    if (const char* e = getenv("FSNAP_ROWSPACE_DEFLATE"))           // A/B switch: 0 = always the Jacobi SVD
-        if (e[0] == '0') return false;
-    if (n < 4 * DB) return false;                                   // small systems: the Jacobi SVD costs microseconds
-    const double lower = norm2_estimate(n, T.data(), 12);          // <= sigma_max
-    if (!(lower > 0.0) || !std::isfinite(lower)) return false;
+// cut.  Anything else -- more than 24 dropped values, a system narrower than 4 DB, a sigma too close to the cut to call, slow
+// convergence, a certificate that does not close -- returns 0 and the Jacobi SVD decides.  n = 128, one dropped direction: ~0.25 ms
+// against 1.8 ms of Jacobi sweeps.
+template <int DB, int MAXCUT>
+int FactorSolver::deflate_width(double rc, std::vector<double>& X, double norm_bound, double lower) {
+    constexpr int MAXIT = 10;
+    if (n < 4 * DB) return 0;                                       // small systems: the Jacobi SVD costs little
     const double cut = rc * lower;
     // start: the DB heaviest rows of the inverse (row i of T^-1 is sum_k v_k[i] / sigma_k u_k^T)
     vec U((size_t)n * DB), W((size_t)n * DB), V((size_t)n * DB), Z((size_t)n * DB);
@@ -627,11 +630,11 @@ bool FactorSolver::deflate(double rc, std::vector<double>& X, double norm_bound)
         std::partial_sort(heavy.begin(), heavy.begin() + DB, heavy.end(),
                           [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
         for (int c = 0; c < DB; ++c) {
-            if (!std::isfinite(heavy[c].first)) return false;
+            if (!std::isfinite(heavy[c].first)) return 0;
             const double* row = X.data() + (size_t)heavy[c].second * n;
             for (int k = 0; k < n; ++k) U[(size_t)k * DB + c] = row[k];
         }
-        orthonormalise_block(n, U.data());
+        orthonormalise_block<DB>(n, U.data());
     }
     double G[DB * DB], P[DB * DB], Q[DB * DB], sig[DB];
     vec uc((size_t)MAXCUT * n), vc((size_t)MAXCUT * n);
@@ -642,9 +645,9 @@ bool FactorSolver::deflate(double rc, std::vector<double>& X, double norm_bound)
     double prev_worst = 1.0;
     for (int it = 0; it < MAXIT && !conv; ++it) {
         W = U;
-        solve_upper_block(n, T.data(), W.data());                   // W = T^-1 U
+        solve_upper_block<DB>(n, T.data(), W.data());                   // W = T^-1 U
         V = W;
-        orthonormalise_block(n, V.data());
+        orthonormalise_block<DB>(n, V.data());
         for (int a = 0; a < DB; ++a)
             for (int b = 0; b < DB; ++b) {
                 double t = 0.0;
@@ -652,14 +655,14 @@ bool FactorSolver::deflate(double rc, std::vector<double>& X, double norm_bound)
                 G[a * DB + b] = t;                                  // G = V^T T^-1 U
             }
         for (double g : G)
-            if (!std::isfinite(g)) return false;
-        small_svd(G, P, sig, Q);                                    // T^-1 (U Q) ~ (V P) diag(sig): Ritz triplets of the inverse
+            if (!std::isfinite(g)) return 0;
+        small_svd<DB>(G, P, sig, Q);                                    // T^-1 (U Q) ~ (V P) diag(sig): Ritz triplets of the inverse
         k = 0;
         while (k < DB && sig[k] > 0.0 && 1.0 / sig[k] <= cut) ++k;
-        if (k > MAXCUT) return false;
-        if (k == 0 && it >= 2) return false;                        // nothing certainly below the cut: the SVD decides
+        if (k > MAXCUT) return -1;                                  // more dropped directions than this width takes on
+        if (k == 0 && it >= 2) return 0;                        // nothing certainly below the cut: the SVD decides
         Z = V;
-        solve_upper_transposed_block(n, T.data(), Z.data());        // Z = T^-T V
+        solve_upper_transposed_block<DB>(n, T.data(), Z.data());        // Z = T^-T V
         // converged when the dropped Ritz vectors span a singular subspace: T^-T (their v's) lies inside the span of their u's.
         // (Not triplet by triplet: values at the rounding level of T mix freely among themselves from one solve to the next,
         // the SUBSPACE is what the projections of apply() need and what is well determined.)
@@ -687,7 +690,7 @@ bool FactorSolver::deflate(double rc, std::vector<double>& X, double norm_bound)
             const double before = std::sqrt(dot_n(un.data(), un.data(), n));
             project_out(n, k, uc.data(), un.data());
             const double after = std::sqrt(dot_n(un.data(), un.data(), n));
-            if (!(before > 0.0) || !std::isfinite(before)) return false;
+            if (!(before > 0.0) || !std::isfinite(before)) return 0;
             worst = std::fmax(worst, after / before);
         }
         // done at the rounding floor -- or where the iteration stops improving: the floor sits at ~eps x the condition of the KEPT part
@@ -695,10 +698,10 @@ bool FactorSolver::deflate(double rc, std::vector<double>& X, double norm_bound)
         prev_worst = worst;
         if (!conv) {
             U = Z;
-            orthonormalise_block(n, U.data());
+            orthonormalise_block<DB>(n, U.data());
         }
     }
-    if (!conv) return false;
+    if (!conv) return 0;
     Uc.assign(uc.begin(), uc.begin() + (size_t)k * n);
     Vc.assign(vc.begin(), vc.begin() + (size_t)k * n);
     // what is left of the inverse: (I - Vc Vc^T) X (I - Uc Uc^T), the operator apply() uses.  (Subtracting v u^T / sigma instead
@@ -728,15 +731,28 @@ bool FactorSolver::deflate(double rc, std::vector<double>& X, double norm_bound)
     }
     double fr = 0.0;
     for (double x : X) fr += x * x;
-    if (!std::isfinite(fr)) return false;
+    if (!std::isfinite(fr)) return 0;
     const double inv_norm = std::fmin(std::sqrt(fr), one_inf_norm(n, X.data()));
-    if (!(norm_bound * inv_norm * rc < 0.1)) return false;
+    if (!(norm_bound * inv_norm * rc < 0.1)) return 0;
     deflated = true;
     ncut = k;
     rank = n - k;
     smax = lower;                // a lower estimate of sigma_max (power iteration) ...
     smin = 1.0 / inv_norm;       // ... and a lower bound of the smallest kept singular value
-    return true;
+    return 1;
+}
+
+
+// 1 ... 4 dropped directions with 8 vectors; when there are more, once again with 32 vectors (up to 24; X is only touched
+// after the iteration has converged).  false = the SVD decides.
+bool FactorSolver::deflate(double rc, std::vector<double>& X, double norm_bound) {
+    if (const char* e = getenv("FSNAP_ROWSPACE_DEFLATE"))           // A/B switch: 0 = always the Jacobi SVD
+        if (e[0] == '0') return false;
+    const double lower = norm2_estimate(n, T.data(), 12);          // <= sigma_max
+    if (!(lower > 0.0) || !std::isfinite(lower)) return false;
+    int r = deflate_width<8, 4>(rc, X, norm_bound, lower);
+    if (r < 0) r = deflate_width<32, 24>(rc, X, norm_bound, lower);
+    return r == 1;
 }
 
 void FactorSolver::prepare(int K_, const double* Rhat, double rcond) {

@@ -52,7 +52,7 @@ struct FactorSolver {
     int K = 0, n = 0, rank = 0;
     std::vector<int> act;
     bool triangular = false;   // no singular value can be below the cut: back substitution
-    bool deflated = false;     // a few (ncut <= 4) singular values are below the cut and every other one provably above it: back
+    bool deflated = false;     // a few (ncut <= 24) singular values are below the cut and every other one provably above it: back
                                // substitution between two projections (deflate), no SVD
     int ncut = 0;
     std::vector<double> Uc, Vc;   // the dropped triplets' left / right singular vectors (ncut x n each, orthonormal rows)
@@ -72,6 +72,8 @@ struct FactorSolver {
     void prepare(int K_, const double* Rhat, double rcond);
     void jacobi_svd(double rcond);
     bool deflate(double rcond, std::vector<double>& X, double norm_bound);   // X = T^-1 on entry (overwritten)
+    template <int DB, int MAXCUT>
+    int deflate_width(double rcond, std::vector<double>& X, double norm_bound, double lower);   // 1 done, 0 no, -1 more than MAXCUT
     void apply(const double* z, double* beta) const;   // beta (K entries, zeros in inactive columns) = pinv(R_hat) z
 };
 

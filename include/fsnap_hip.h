@@ -335,7 +335,7 @@ int fsnap_set_dense_pinv(fsnap_ctx* ctx, fsnap_dense_pinv_fn fn, void* user);
  * of the original rows.  Needs m * K * 8 more bytes of HBM.  Collective when the context has a communicator (a rank
  * without rows passes K and contributes nothing).  *rank = numerical rank used.  info (may be NULL, 8 doubles):
  * passes, last max|Q^T Q - I|, converged (0/1), how the K x K end was solved (0 = back substitution: nothing to drop;
- * 3 = back substitution between two projections: 1...4 dropped directions found by subspace iteration, every other
+ * 3 = back substitution between two projections: 1...24 dropped directions found by subspace iteration, every other
  * singular value certified above the cut; 1 = the library's one-sided Jacobi SVD; 2 = the host language's dense kernel),
  * sigma_max, sigma_min estimate (bounds unless the SVD ran), relative size of the refinement step, last shift.
  * FSNAP_ROWSPACE_DEFLATE=0 in the environment takes form 3 out (A/B). */

@@ -299,11 +299,11 @@ def test_the_projection_path_steps_aside_when_it_cannot_call_the_rank():
 
     base = np.sort(np.exp(r.uniform(np.log(1e-3), 0.0, n)))[::-1]
     base[0] = 1.0
-    # (a) five values below the cut: more than the projection path takes on
+    # (a) thirty values below the cut: more than the projection path takes on (4 with 8 vectors, 24 with 32)
     s = base.copy()
-    s[-5:] = 1e-16 * np.array([1, 2, 3, 4, 5.0])
+    s[-30:] = 1e-16 * np.arange(1, 31)
     (beta, rank, info), (ref, _, rk, _) = solve(s)
-    assert rank == rk == n - 5 and info[0] == 1.0
+    assert rank == rk == n - 30 and info[0] == 1.0
     # (b) a value 1.5 x above the cut (kept, kappa ~ 7e12): the certificate of the deflated inverse cannot close
     s = base.copy()
     s[-1] = 1.5e-13
@@ -318,3 +318,20 @@ def test_the_projection_path_steps_aside_when_it_cannot_call_the_rank():
     s = np.logspace(0, -16, n)
     (beta, rank, info), (ref, _, rk, _) = solve(s)
     assert rank == rk and info[0] == 1.0
+
+
+@pytest.mark.parametrize("n,ndep", [(128, 5), (128, 12), (200, 8), (200, 24), (320, 17)])
+def test_more_than_four_dropped_directions_take_the_wide_block(n, ndep, monkeypatch):
+    # 5 ... 24 dependent columns: the subspace iteration runs again with 32 vectors (FactorSolver::deflate)
+    R, z = _factor_with_dependent_columns(n, ndep, 1e4, seed=7 * n + ndep, noise=1e-15 if ndep % 2 else 0.0)
+    ref, _, rank_ref, sv = np.linalg.lstsq(R, z, rcond=1.0e-13)
+    assert rank_ref == n - ndep
+    beta, rank, info = _capi.rowspace_solve(R, z, 1.0e-13)
+    assert rank == rank_ref and info[0] == 3.0
+    monkeypatch.setenv("FSNAP_ROWSPACE_DEFLATE", "0")
+    beta_j, rank_j, info_j = _capi.rowspace_solve(R, z, 1.0e-13)
+    monkeypatch.delenv("FSNAP_ROWSPACE_DEFLATE")
+    assert rank_j == rank and info_j[0] == 1.0
+    scale = np.abs(beta_j).max()
+    assert np.abs(beta - beta_j).max() <= 200 * 1e4 * EPS * scale
+    assert np.abs(beta - ref).max() <= 2.0 * np.abs(beta_j - ref).max() + 200 * 1e4 * EPS * scale
