@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <new>
 #include <queue>
 #include <string>
@@ -1637,6 +1638,17 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
                 if (rcond_est) *rcond_est = mp;
                 return FSNAP_OK;
             }
+        }
+        // A probe (FSNAP_SOLVE_*_PROBE: "come straight back when no Cholesky factorisation resolves the system") whose
+        // factorisation met a non-positive pivot, or one below the host path's own acceptance threshold 64 n eps, is unresolved
+        // for the host Cholesky too -- the same algorithm on the same matrix.  Downloading G (20 MB at K = 1595) for two more
+        // failing factorisations cost 36 ms of an 87 ms ill-conditioned SVD fit at 15 213 x 1 595.
+        if (kind >= FSNAP_SOLVE_LSTSQ_PROBE && !(status & 1) &&
+            ((status & 2) || !(mp > 64.0 * n * std::numeric_limits<double>::epsilon()))) {
+            for (int i = 0; i < n; ++i) beta[i] = 0.0;
+            if (rank) *rank = -1;
+            if (rcond_est) *rcond_est = (mp > 0.0 && mp < 1.0e300) ? mp : 0.0;
+            return FSNAP_OK;
         }
         // ill-conditioned / indefinite / non-finite: the general host path decides
     }

@@ -6,8 +6,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
+#include <functional>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #include "../../include/fsnap_hip.h"
@@ -16,9 +20,70 @@
 extern "C" int fsnap_host_chol_upper(double* a, int n, double* min_piv);   // fsnap_solve.cpp
 
 namespace fsnap_rs {
+// FSNAP_ROWSPACE_TIMING=1 (the switch of fsnap_lstsq_rows' phase marks): wall time of the host phases below on stderr
+struct HostProf {
+    const char* what;
+    std::chrono::steady_clock::time_point t0;
+    explicit HostProf(const char* w) : what(w), t0(std::chrono::steady_clock::now()) {}
+    ~HostProf() {
+        if (getenv("FSNAP_ROWSPACE_TIMING"))
+            fprintf(stderr, "[fsnap_rowspace_host]   %-30s %8.3f ms\n", what,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
 
 using vec = std::vector<double>;
 static const double EPS = std::numeric_limits<double>::epsilon();
+
+// ---- host threads for the O(n^3) / many-solve phases of large systems ---------------------------------------------------------
+// At K = 1595 the K x K end of an ill-conditioned fit was 115 ms (condition estimate: ~100 triangular solves of 10 MB each) to
+// 436 ms (product of the factors + explicit inverse + subspace iteration) of host time on ONE core behind 9 ms of GPU passes
+// (profiles/r05_rowspace_large_k.txt).  The loops below split over FSNAP_HOST_THREADS threads (default: up to 16) from n = 384 on;
+// threads are created per phase (a phase is milliseconds, a thread start ~50 us) and joined before it returns.  Every split is
+// over independent outputs (rows, columns, whole estimators): the results do not depend on the thread count.
+static int host_threads(int n) {
+    if (n < 384) return 1;
+    static const int cap = [] {
+        const char* e = getenv("FSNAP_HOST_THREADS");
+        int v = e && *e ? atoi(e) : 16;
+        const unsigned hc = std::thread::hardware_concurrency();
+        if (hc > 0 && v > (int)hc) v = (int)hc;
+        return v < 1 ? 1 : (v > 64 ? 64 : v);
+    }();
+    return cap;
+}
+
+// f(t) for t = 0 .. nt - 1, the caller being thread 0
+template <class F>
+static void run_threads(int nt, F&& f) {
+    if (nt <= 1) {
+        f(0);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve((size_t)nt - 1);
+    int started = 1;
+    for (int t = 1; t < nt; ++t) {
+        try {
+            th.emplace_back([&f, t] { f(t); });
+            ++started;
+        } catch (...) {
+            break;                                  // no more threads to be had: the caller takes the rest
+        }
+    }
+    f(0);
+    for (int t = started; t < nt; ++t) f(t);
+    for (auto& x : th) x.join();
+}
+
+// independent tasks, at most `nt` at a time (task i runs on thread i % nt)
+static void run_tasks(int nt, std::vector<std::function<void()>>& tasks) {
+    const int n = (int)tasks.size();
+    if (nt > n) nt = n;
+    run_threads(nt, [&](int t) {
+        for (int i = t; i < n; i += nt) tasks[i]();
+    });
+}
 
 bool finite_all(const double* p, size_t n) {
     // x * 0 is 0 for finite x and NaN for NaN / Inf; eight independent sums (one dependent chain costs 4 cycles per entry:
@@ -223,7 +288,8 @@ double inverse_norm1_estimate(int n, const double* T, bool transposed) {
 // pseudo-random vector; the Rayleigh quotients increase towards the largest eigenvalue of (T^T T)^-1, so the result is a
 // LOWER estimate -- a few per cent low after a dozen steps unless the start vector is nearly orthogonal to the whole
 // cluster of smallest singular directions.  Cost: 2 * steps * n^2 / 2 flops.
-double inverse_norm2_estimate(int n, const double* T, int steps = 14) {
+double inverse_norm2_estimate(int n, const double* T, int steps = 14, int snap_steps = 0, double* snap = nullptr) {
+    if (snap) *snap = 0.0;
     if (n == 0) return 0.0;
     vec v((size_t)n);
     unsigned long long state = 0x9E3779B97F4A7C15ull;
@@ -242,33 +308,45 @@ double inverse_norm2_estimate(int n, const double* T, int steps = 14) {
         double nn = 0.0;
         for (double x : v) nn += x * x;
         nn = std::sqrt(nn);
-        if (!(nn > 0.0) || !std::isfinite(nn)) return std::numeric_limits<double>::infinity();
+        if (!(nn > 0.0) || !std::isfinite(nn)) {
+            if (snap && it < snap_steps) *snap = std::numeric_limits<double>::infinity();
+            return std::numeric_limits<double>::infinity();
+        }
         est = std::sqrt(nn);                          // ||(T^T T)^-1 v|| -> 1 / sigma_min^2 for unit v
+        if (snap && it + 1 == snap_steps) *snap = est;     // what `snap_steps` steps alone would have returned
         for (double& x : v) x /= nn;
     }
     return est;
 }
 
-// ||T||_2 by power iteration on T^T T (upper triangular T, row-major): a lower estimate, close after a dozen steps
+// ||T||_2 by power iteration on T^T T (upper triangular T, row-major): a lower estimate, close after a dozen steps.
+// One pass over T per step (w_i = t_i . v and v' += w_i t_i use the same row); the rows are cut into a FIXED number of chunks
+// with a partial v' each, summed in chunk order -- the value does not depend on how many threads ran the chunks.
 double norm2_estimate(int n, const double* T, int steps = 12) {
     if (n == 0) return 0.0;
-    vec v((size_t)n, 1.0 / std::sqrt((double)n)), w((size_t)n);
+    const int nchunk = n >= 384 ? 16 : 1, nt = std::min(host_threads(n), nchunk);
+    vec v((size_t)n, 1.0 / std::sqrt((double)n)), part((size_t)nchunk * n);
     double est = 0.0;
     for (int it = 0; it < steps; ++it) {
-        for (int i = 0; i < n; ++i) {                 // w = T v
-            const double* ti = T + (size_t)i * n;
-            double acc = 0.0;
-            for (int k = i; k < n; ++k) acc += ti[k] * v[k];
-            w[i] = acc;
-        }
-        std::fill(v.begin(), v.end(), 0.0);           // v = T^T w
-        for (int i = 0; i < n; ++i) {
-            const double* ti = T + (size_t)i * n;
-            const double wi = w[i];
-            for (int k = i; k < n; ++k) v[k] += ti[k] * wi;
-        }
+        run_threads(nt, [&](int t) {
+            for (int ch = t; ch < nchunk; ch += nt) {
+                double* __restrict__ pv = part.data() + (size_t)ch * n;
+                std::fill(pv, pv + n, 0.0);
+                for (int i = ch; i < n; i += nchunk) {            // rows dealt round-robin: row i costs n - i
+                    const double* __restrict__ ti = T + (size_t)i * n;
+                    double acc = 0.0;
+                    for (int k = i; k < n; ++k) acc += ti[k] * v[k];
+                    for (int k = i; k < n; ++k) pv[k] += ti[k] * acc;
+                }
+            }
+        });
         double nn = 0.0;
-        for (double x : v) nn += x * x;
+        for (int k = 0; k < n; ++k) {
+            double t2 = 0.0;
+            for (int ch = 0; ch < nchunk; ++ch) t2 += part[(size_t)ch * n + k];
+            v[k] = t2;
+            nn += t2 * t2;
+        }
         nn = std::sqrt(nn);
         if (!(nn > 0.0) || !std::isfinite(nn)) return nn;
         est = std::sqrt(nn);                          // ||T^T T v|| -> sigma_max^2 for unit v
@@ -288,49 +366,89 @@ void FactorChain::start(int K_, const double* G) {
     for (int j = 0; j < K; ++j) active[j] = G[(size_t)j * K + j] > 0.0;
 }
 
-double FactorChain::condition_bound(double* norm_out, double* inv_norm_out) const {
-    double nrm = 1.0, inv = 1.0;
-    vec colsum((size_t)K), dcolsum((size_t)K);
-    for (const double* Rk : R) {
-        // ||R||_2 <= sqrt(||R||_1 ||R||_inf), both exact (a Frobenius norm would charge a near-identity factor sqrt(K));
-        // the same sweep measures E = R - I the same way
-        std::fill(colsum.begin(), colsum.end(), 0.0);
-        std::fill(dcolsum.begin(), dcolsum.end(), 0.0);
-        double n1 = 0.0, ninf = 0.0, e1n = 0.0, einfn = 0.0;
-        for (int i = 0; i < K; ++i) {
-            const double* ri = Rk + (size_t)i * K;
-            double rs = 0.0, es = 0.0;
-            for (int c = i; c < K; ++c) {
-                const double a = std::fabs(ri[c]), e = std::fabs(ri[c] - (c == i ? 1.0 : 0.0));
-                rs += a;
-                es += e;
-                colsum[c] += a;
-                dcolsum[c] += e;
+// Everything condition_bound() and certified() need to know about the factors, gathered once: per factor ONE sweep for the exact
+// norm pairs of R and of E = R - I, and -- unless the factor is near the identity (the later passes: Neumann bound, no iteration) --
+// Hager's estimator for R^-1 and R^-T and inverse iteration on R^T R (14 steps, with the value after 3 steps kept: the quick look
+// of certified() uses that one).  The sweeps and the three estimators of every factor are independent tasks on the host threads
+// (~50 triangular solves of 10 MB each per factor at K = 1595: 115 ms on one core).
+struct ChainLook {
+    double n1 = 0.0, ninf = 0.0, enorm = 0.0, rmax = 0.0, dmax = 0.0;      // ||R||_1, ||R||_inf, sqrt(||E||_1 ||E||_inf), max |r_ij|, max 1 / |r_ii|
+    double h1 = 0.0, hinf = 0.0, inv2_3 = 0.0, inv2_14 = 0.0;
+    bool near_identity = false;
+};
+
+static std::vector<ChainLook> chain_looks(int K, const std::vector<const double*>& R) {
+    HostProf hp_("chain: sweeps + estimators");
+    std::vector<ChainLook> L(R.size());
+    const int nt = host_threads(K);
+    std::vector<std::function<void()>> tasks;
+    for (size_t f = 0; f < R.size(); ++f)
+        tasks.emplace_back([&, f] {
+            const double* Rk = R[f];
+            ChainLook& l = L[f];
+            vec colsum((size_t)K, 0.0), dcolsum((size_t)K, 0.0);
+            double ninf = 0.0, einfn = 0.0, rmax = 0.0, dmax = 0.0;
+            for (int i = 0; i < K; ++i) {
+                const double* ri = Rk + (size_t)i * K;
+                double rs = 0.0, es = 0.0;
+                for (int c = i; c < K; ++c) {
+                    const double a = std::fabs(ri[c]), e = std::fabs(ri[c] - (c == i ? 1.0 : 0.0));
+                    rs += a;
+                    es += e;
+                    colsum[c] += a;
+                    dcolsum[c] += e;
+                    rmax = std::fmax(rmax, a);
+                }
+                ninf = std::fmax(ninf, rs);
+                einfn = std::fmax(einfn, es);
+                const double d = std::fabs(ri[i]);
+                dmax = std::fmax(dmax, d > 0.0 ? 1.0 / d : std::numeric_limits<double>::infinity());
             }
-            ninf = std::fmax(ninf, rs);
-            einfn = std::fmax(einfn, es);
-        }
-        for (int c = 0; c < K; ++c) {
-            n1 = std::fmax(n1, colsum[c]);
-            e1n = std::fmax(e1n, dcolsum[c]);
-        }
+            double n1 = 0.0, e1n = 0.0;
+            for (int c = 0; c < K; ++c) {
+                n1 = std::fmax(n1, colsum[c]);
+                e1n = std::fmax(e1n, dcolsum[c]);
+            }
+            // (the entries below the diagonal of a factor are zero: the full-matrix maximum of the earlier code is this one)
+            l.n1 = n1;
+            l.ninf = ninf;
+            l.enorm = std::sqrt(e1n * einfn);           // >= ||R - I||_2
+            l.rmax = rmax;
+            l.dmax = dmax;
+            l.near_identity = l.enorm < 0.5;
+        });
+    run_tasks(nt, tasks);
+    tasks.clear();
+    for (size_t f = 0; f < R.size(); ++f) {
+        if (L[f].near_identity) continue;
+        tasks.emplace_back([&, f] { L[f].h1 = inverse_norm1_estimate(K, R[f], false); });
+        tasks.emplace_back([&, f] { L[f].hinf = inverse_norm1_estimate(K, R[f], true); });
+        tasks.emplace_back([&, f] { L[f].inv2_14 = inverse_norm2_estimate(K, R[f], 14, 3, &L[f].inv2_3); });
+    }
+    run_tasks(nt, tasks);
+    return L;
+}
+
+// the full estimate from the looks: nrm x inv
+static double chain_bound_from(int K, const std::vector<const double*>& R, const std::vector<ChainLook>& L, double* norm_out,
+                               double* inv_norm_out) {
+    double nrm = 1.0, inv = 1.0;
+    for (size_t f = 0; f < R.size(); ++f) {
+        const ChainLook& l = L[f];
         // sqrt(||R||_1 ||R||_inf) is a true bound but overshoots a graded factor by one or two orders; power iteration
         // approaches ||R||_2 from below: x 1.25, and never below the largest entry
-        double rmax = 0.0;
-        for (size_t q = 0; q < (size_t)K * K; ++q) rmax = std::fmax(rmax, std::fabs(Rk[q]));
-        nrm *= std::fmin(std::sqrt(n1 * ninf), std::fmax(1.25 * norm2_estimate(K, Rk), rmax));
-        const double enorm = std::sqrt(e1n * einfn);           // >= ||R - I||_2
-        if (enorm < 0.5) {
-            inv *= 1.0 / (1.0 - enorm);                        // Neumann series: the factors of the later passes
+        if (l.near_identity) nrm *= std::fmin(std::sqrt(l.n1 * l.ninf), 1.0 + l.enorm);          // ||I + E||_2 <= 1 + ||E||_2
+        else nrm *= std::fmin(std::sqrt(l.n1 * l.ninf), std::fmax(1.25 * norm2_estimate(K, R[f]), l.rmax));
+        if (l.near_identity) {
+            inv *= 1.0 / (1.0 - l.enorm);                      // Neumann series: the factors of the later passes
         } else {
             // the sharper of two upper estimates of ||R^-1||_2: the 1- / inf-norm pair (Hager / Higham's estimator x 3) and
             // inverse iteration on R^T R (x 2: it approaches 1 / sigma_min from below)
-            const double e1 = inverse_norm1_estimate(K, Rk, false), einf = inverse_norm1_estimate(K, Rk, true);
-            const double by_norm1 = 3.0 * std::sqrt(e1 * einf);
-            const double by_iteration = 2.0 * inverse_norm2_estimate(K, Rk);
+            const double by_norm1 = 3.0 * std::sqrt(l.h1 * l.hinf);
+            const double by_iteration = 2.0 * l.inv2_14;
             // never below what either estimator has actually SEEN (each is a lower bound of its own norm):
             // ||B||_2 >= ||B||_1 / sqrt(n)
-            const double floor2 = std::fmax(e1, einf) / std::sqrt((double)K);
+            const double floor2 = std::fmax(l.h1, l.hinf) / std::sqrt((double)K);
             inv *= std::fmax(std::fmin(by_norm1, by_iteration), floor2);
         }
     }
@@ -339,60 +457,26 @@ double FactorChain::condition_bound(double* norm_out, double* inv_norm_out) cons
     return nrm * inv;
 }
 
+double FactorChain::condition_bound(double* norm_out, double* inv_norm_out) const {
+    return chain_bound_from(K, R, chain_looks(K, R), norm_out, inv_norm_out);
+}
+
 bool FactorChain::certified(double rcond, double* norm_out, double* inv_norm_out, double* bound_out) const {
+    HostProf hp_("certified");
     const double rc = rcond > 0.0 ? rcond : 0.0;
+    const std::vector<ChainLook> L = chain_looks(K, R);
     // A quick look first: ||R||_2 <= sqrt(||R||_1 ||R||_inf) (exact) and, for ||R^-1||_2, the largest of three lower
-    // estimates (three steps of inverse iteration, Hager's 1- / inf-norm pair, the inverse's diagonal), times 10.  When even that leaves FOUR orders of margin the full
-    // estimators below -- ~50 triangular solves per factor, 58 ms of a 125 ms call at K = 1595 -- have nothing to add.
+    // estimates (three steps of inverse iteration, Hager's 1- / inf-norm pair, the inverse's diagonal), times 10 -- inverse
+    // iteration approaches ||R^-1||_2 from BELOW, and on a steeply graded factor three steps from a flat start can sit far below
+    // it; the exact lower bound max_i 1 / |r_ii| and Hager's estimates (dlacon's iteration is exact on graded triangular factors
+    // in all but contrived cases) keep the quick look honest.  When even that leaves FOUR orders of margin the sharper
+    // combination below has nothing to add.
     {
         double nrm = 1.0, inv = 1.0;
-        vec colsum((size_t)K);
-        for (const double* Rk : R) {
-            std::fill(colsum.begin(), colsum.end(), 0.0);
-            double ninf = 0.0, n1 = 0.0;
-            for (int i = 0; i < K; ++i) {
-                const double* ri = Rk + (size_t)i * K;
-                double rs = 0.0;
-                for (int c = i; c < K; ++c) {
-                    const double a = std::fabs(ri[c]);
-                    rs += a;
-                    colsum[c] += a;
-                }
-                ninf = std::fmax(ninf, rs);
-            }
-            for (int c = 0; c < K; ++c) n1 = std::fmax(n1, colsum[c]);
-            nrm *= std::sqrt(n1 * ninf);
-            // a near-identity factor (the later passes): Neumann bound 1 / (1 - ||R - I||), exact, no iteration
-            double e1n = 0.0, einfn = 0.0;
-            std::fill(colsum.begin(), colsum.end(), 0.0);
-            for (int i = 0; i < K; ++i) {
-                const double* ri = Rk + (size_t)i * K;
-                double es = 0.0;
-                for (int c = i; c < K; ++c) {
-                    const double ee = std::fabs(ri[c] - (c == i ? 1.0 : 0.0));
-                    es += ee;
-                    colsum[c] += ee;
-                }
-                einfn = std::fmax(einfn, es);
-            }
-            for (int c = 0; c < K; ++c) e1n = std::fmax(e1n, colsum[c]);
-            const double enorm = std::sqrt(e1n * einfn);
-            if (enorm < 0.5) {
-                inv *= 1.0 / (1.0 - enorm);
-            } else {
-                // inverse iteration approaches ||R^-1||_2 from BELOW, and on a steeply graded factor three steps from a
-                // flat start can sit far below it.  Two cheap companions keep the quick look honest: the exact lower
-                // bound max_i 1 / |r_ii| (the diagonal of the inverse), and Hager's 1-norm / inf-norm estimates
-                // (||B||_2 <= sqrt(||B||_1 ||B||_inf); dlacon's iteration is exact on graded triangular factors in all
-                // but contrived cases).  The largest of the three, times 10, goes into the product.
-                double dmax = 0.0;
-                for (int i = 0; i < K; ++i) {
-                    const double d = std::fabs(Rk[(size_t)i * K + i]);
-                    dmax = std::fmax(dmax, d > 0.0 ? 1.0 / d : std::numeric_limits<double>::infinity());
-                }
-                const double hager = std::sqrt(inverse_norm1_estimate(K, Rk, false) * inverse_norm1_estimate(K, Rk, true));
-                inv *= 10.0 * std::fmax(std::fmax(inverse_norm2_estimate(K, Rk, 3), dmax), hager);
-            }
+        for (const ChainLook& l : L) {
+            nrm *= std::sqrt(l.n1 * l.ninf);
+            if (l.near_identity) inv *= 1.0 / (1.0 - l.enorm);
+            else inv *= 10.0 * std::fmax(std::fmax(l.inv2_3, l.dmax), std::sqrt(l.h1 * l.hinf));
         }
         if (std::isfinite(nrm * inv) && nrm * inv * rc < 1.0e-4) {
             if (norm_out) *norm_out = nrm;
@@ -401,7 +485,7 @@ bool FactorChain::certified(double rcond, double* norm_out, double* inv_norm_out
             return true;
         }
     }
-    const double est = condition_bound(norm_out, inv_norm_out);
+    const double est = chain_bound_from(K, R, L, norm_out, inv_norm_out);
     if (bound_out) *bound_out = est;
     // two orders of margin over estimators that sit 2-8 x above the truth in the tests but are NOT bounds (power / inverse
     // iteration and Hager's estimator approach the norms from below).  Without that margin the caller multiplies the
@@ -419,22 +503,28 @@ void FactorChain::solve(const double* z, double* beta) const {
 }
 
 void FactorChain::product(double* Rhat) const {
+    HostProf hp_("product");
     std::fill(Rhat, Rhat + (size_t)K * K, 0.0);
     if (R.empty()) return;
     memcpy(Rhat, R[0], (size_t)K * K * sizeof(double));
-    vec out((size_t)K);
+    const int nt = host_threads(K);
+    vec next(R.size() > 1 ? (size_t)K * K : 0);
     for (size_t k = 1; k < R.size(); ++k) {
         const double* Rp = R[k];
-        for (int a = 0; a < K; ++a) {              // row a of Rp R_hat needs rows >= a of R_hat only: in place, top down
-            std::fill(out.begin(), out.end(), 0.0);
-            for (int b = a; b < K; ++b) {
-                const double f = Rp[(size_t)a * K + b];
-                if (f == 0.0) continue;
-                const double* r = Rhat + (size_t)b * K;
-                for (int c = b; c < K; ++c) out[c] += f * r[c];
+        // row a of Rp R_hat = sum_{b >= a} Rp[a][b] R_hat[b][b:]: rows are independent (dealt round-robin: row a costs (K - a)^2 / 2)
+        run_threads(nt, [&](int t) {
+            for (int a = t; a < K; a += nt) {
+                double* __restrict__ out = next.data() + (size_t)a * K;
+                std::fill(out, out + K, 0.0);
+                for (int b = a; b < K; ++b) {
+                    const double f = Rp[(size_t)a * K + b];
+                    if (f == 0.0) continue;
+                    const double* __restrict__ r = Rhat + (size_t)b * K;
+                    for (int c = b; c < K; ++c) out[c] += f * r[c];
+                }
             }
-            memcpy(Rhat + (size_t)a * K, out.data(), (size_t)K * sizeof(double));
-        }
+        });
+        memcpy(Rhat, next.data(), (size_t)K * K * sizeof(double));
     }
     for (int j = 0; j < K; ++j)
         if (!active[j]) {
@@ -484,36 +574,57 @@ namespace {
 
 // DB = block width of the subspace iteration: the dropped directions + guard vectors (8: up to 4 dropped; 32: up to 24)
 
-// W <- T^-1 W / W <- T^-T W for an n x DB block stored row-major (the DB right-hand sides of a row are contiguous)
+// Storage of an n x DB block of vectors: GROUPS of four columns (one AVX2 vector), each group an n x 4 row-major panel of its own --
+// a substitution walks one panel top to bottom or back (51 KB at n = 1595: it stays in L1 / L2), instead of touching one 32-byte
+// piece of every 256-byte row of an n x 32 array (19 ms per block solve at n = 1595, DB = 32: L2-bandwidth bound).
+constexpr int BCW = 4;
+inline size_t bix(int n, int i, int c) { return ((size_t)(c / BCW) * n + (size_t)i) * BCW + (size_t)(c % BCW); }
+
+// W <- T^-1 W / W <- T^-T W for an n x DB block.  The right-hand sides are independent: the column groups are dealt to the host threads.
 template <int DB>
 void solve_upper_block(int n, const double* T, double* W) {
-    for (int i = n - 1; i >= 0; --i) {
-        const double* ti = T + (size_t)i * n;
-        double acc[DB];
-        for (int c = 0; c < DB; ++c) acc[c] = W[(size_t)i * DB + c];
-        for (int k = i + 1; k < n; ++k) {
-            const double f = ti[k];
-            const double* wk = W + (size_t)k * DB;
-            for (int c = 0; c < DB; ++c) acc[c] -= f * wk[c];
+    constexpr int CW = BCW, NG = DB / CW;
+    static_assert(DB % CW == 0, "block width");
+    run_threads(std::min(host_threads(n), NG), [&](int t) {
+        const int nt = std::min(host_threads(n), NG);
+        for (int g = t; g < NG; g += nt) {
+            double* Wg = W + (size_t)g * n * CW;
+            for (int i = n - 1; i >= 0; --i) {
+                const double* ti = T + (size_t)i * n;
+                double acc[CW];
+                for (int c = 0; c < CW; ++c) acc[c] = Wg[(size_t)i * CW + c];
+                for (int k = i + 1; k < n; ++k) {
+                    const double f = ti[k];
+                    const double* wk = Wg + (size_t)k * CW;
+                    for (int c = 0; c < CW; ++c) acc[c] -= f * wk[c];
+                }
+                const double inv = 1.0 / ti[i];
+                for (int c = 0; c < CW; ++c) Wg[(size_t)i * CW + c] = acc[c] * inv;
+            }
         }
-        const double inv = 1.0 / ti[i];
-        for (int c = 0; c < DB; ++c) W[(size_t)i * DB + c] = acc[c] * inv;
-    }
+    });
 }
 
 template <int DB>
 void solve_upper_transposed_block(int n, const double* T, double* W) {
-    for (int i = 0; i < n; ++i) {
-        const double* ti = T + (size_t)i * n;
-        const double inv = 1.0 / ti[i];
-        double zi[DB];
-        for (int c = 0; c < DB; ++c) W[(size_t)i * DB + c] = zi[c] = W[(size_t)i * DB + c] * inv;
-        for (int k = i + 1; k < n; ++k) {
-            const double f = ti[k];
-            double* wk = W + (size_t)k * DB;
-            for (int c = 0; c < DB; ++c) wk[c] -= f * zi[c];
+    constexpr int CW = BCW, NG = DB / CW;
+    run_threads(std::min(host_threads(n), NG), [&](int t) {
+        const int nt = std::min(host_threads(n), NG);
+        for (int g = t; g < NG; g += nt) {
+            double* Wg = W + (size_t)g * n * CW;
+            for (int i = 0; i < n; ++i) {
+                const double* ti = T + (size_t)i * n;
+                const double inv = 1.0 / ti[i];
+                double zi[CW];
+                for (int c = 0; c < CW; ++c) Wg[(size_t)i * CW + c] = zi[c] = Wg[(size_t)i * CW + c] * inv;
+                for (int k = i + 1; k < n; ++k) {
+                    const double f = ti[k];
+                    double* wk = Wg + (size_t)k * CW;
+                    for (int c = 0; c < CW; ++c) wk[c] -= f * zi[c];
+                }
+            }
         }
-    }
+    });
 }
 
 // orthonormal columns by modified Gram-Schmidt, twice; a column that vanishes is replaced by a pseudo-random one
@@ -523,23 +634,23 @@ void orthonormalise_block(int n, double* W) {
     for (int c = 0; c < DB; ++c) {
         for (int attempt = 0; attempt < 3; ++attempt) {
             double before = 0.0;
-            for (int i = 0; i < n; ++i) before += W[(size_t)i * DB + c] * W[(size_t)i * DB + c];
+            for (int i = 0; i < n; ++i) before += W[bix(n, i, c)] * W[bix(n, i, c)];
             for (int rep = 0; rep < 2; ++rep)
                 for (int p = 0; p < c; ++p) {
                     double t = 0.0;
-                    for (int i = 0; i < n; ++i) t += W[(size_t)i * DB + p] * W[(size_t)i * DB + c];
-                    for (int i = 0; i < n; ++i) W[(size_t)i * DB + c] -= t * W[(size_t)i * DB + p];
+                    for (int i = 0; i < n; ++i) t += W[bix(n, i, p)] * W[bix(n, i, c)];
+                    for (int i = 0; i < n; ++i) W[bix(n, i, c)] -= t * W[bix(n, i, p)];
                 }
             double nn = 0.0;
-            for (int i = 0; i < n; ++i) nn += W[(size_t)i * DB + c] * W[(size_t)i * DB + c];
+            for (int i = 0; i < n; ++i) nn += W[bix(n, i, c)] * W[bix(n, i, c)];
             if (nn > 1.0e-24 * before && nn > 0.0 && std::isfinite(nn)) {
                 const double f = 1.0 / std::sqrt(nn);
-                for (int i = 0; i < n; ++i) W[(size_t)i * DB + c] *= f;
+                for (int i = 0; i < n; ++i) W[bix(n, i, c)] *= f;
                 break;
             }
             for (int i = 0; i < n; ++i) {          // (numerically) inside the span of the earlier columns: start over
                 state = state * 6364136223846793005ull + 1442695040888963407ull;
-                W[(size_t)i * DB + c] = ((double)(state >> 11) / 9007199254740992.0) - 0.5;
+                W[bix(n, i, c)] = ((double)(state >> 11) / 9007199254740992.0) - 0.5;
             }
         }
     }
@@ -626,16 +737,20 @@ int FactorSolver::deflate_width(double rc, std::vector<double>& X, double norm_b
     vec U((size_t)n * DB), W((size_t)n * DB), V((size_t)n * DB), Z((size_t)n * DB);
     {
         std::vector<std::pair<double, int>> heavy((size_t)n);
-        for (int i = 0; i < n; ++i) heavy[i] = {dot_n(X.data() + (size_t)i * n, X.data() + (size_t)i * n, n), i};
+        run_threads(host_threads(n), [&](int t) {
+            const int nt = host_threads(n);
+            for (int i = t; i < n; i += nt) heavy[i] = {dot_n(X.data() + (size_t)i * n, X.data() + (size_t)i * n, n), i};
+        });
         std::partial_sort(heavy.begin(), heavy.begin() + DB, heavy.end(),
                           [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
         for (int c = 0; c < DB; ++c) {
             if (!std::isfinite(heavy[c].first)) return 0;
             const double* row = X.data() + (size_t)heavy[c].second * n;
-            for (int k = 0; k < n; ++k) U[(size_t)k * DB + c] = row[k];
+            for (int k = 0; k < n; ++k) U[bix(n, k, c)] = row[k];
         }
         orthonormalise_block<DB>(n, U.data());
     }
+    HostProf hp5_("deflate: iteration + rest");
     double G[DB * DB], P[DB * DB], Q[DB * DB], sig[DB];
     vec uc((size_t)MAXCUT * n), vc((size_t)MAXCUT * n);
     double sc[MAXCUT];
@@ -651,7 +766,7 @@ int FactorSolver::deflate_width(double rc, std::vector<double>& X, double norm_b
         for (int a = 0; a < DB; ++a)
             for (int b = 0; b < DB; ++b) {
                 double t = 0.0;
-                for (int i = 0; i < n; ++i) t += V[(size_t)i * DB + a] * W[(size_t)i * DB + b];
+                for (int i = 0; i < n; ++i) t += V[bix(n, i, a)] * W[bix(n, i, b)];
                 G[a * DB + b] = t;                                  // G = V^T T^-1 U
             }
         for (double g : G)
@@ -673,8 +788,8 @@ int FactorSolver::deflate_width(double rc, std::vector<double>& X, double norm_b
             for (int i = 0; i < n; ++i) {
                 double tu = 0.0, tv = 0.0;
                 for (int b = 0; b < DB; ++b) {
-                    tu += U[(size_t)i * DB + b] * Q[b * DB + c];
-                    tv += V[(size_t)i * DB + b] * P[b * DB + c];
+                    tu += U[bix(n, i, b)] * Q[b * DB + c];
+                    tv += V[bix(n, i, b)] * P[b * DB + c];
                 }
                 u[i] = tu;
                 v[i] = tv;
@@ -684,7 +799,7 @@ int FactorSolver::deflate_width(double rc, std::vector<double>& X, double norm_b
         for (int c = 0; c < k; ++c) {
             for (int i = 0; i < n; ++i) {
                 double tz = 0.0;
-                for (int b = 0; b < DB; ++b) tz += Z[(size_t)i * DB + b] * P[b * DB + c];
+                for (int b = 0; b < DB; ++b) tz += Z[bix(n, i, b)] * P[b * DB + c];
                 un[i] = tz;
             }
             const double before = std::sqrt(dot_n(un.data(), un.data(), n));
@@ -707,32 +822,55 @@ int FactorSolver::deflate_width(double rc, std::vector<double>& X, double norm_b
     // what is left of the inverse: (I - Vc Vc^T) X (I - Uc Uc^T), the operator apply() uses.  (Subtracting v u^T / sigma instead
     // fails for values at the rounding level of T: X holds ITS OWN rounding-level values for those directions.)
     {
-        vec t((size_t)n);
-        for (int c = 0; c < k; ++c) {
-            const double* u = Uc.data() + (size_t)c * n;
-            for (int i = 0; i < n; ++i) {                       // X <- X - (X u) u^T
+        HostProf hp4_("deflate: projections of X");
+        const int nt = host_threads(n);
+        // X <- X (I - Uc^T Uc): row by row, the dropped u's one after the other on the row while it is in L1 (one pass over X)
+        run_threads(nt, [&](int t) {
+            for (int i = t; i < n; i += nt) {
                 double* xi = X.data() + (size_t)i * n;
-                const double f = dot_n(xi, u, n);
-                for (int j = 0; j < n; ++j) xi[j] -= f * u[j];
+                for (int c = 0; c < k; ++c) {
+                    const double* u = Uc.data() + (size_t)c * n;
+                    const double f = dot_n(xi, u, n);
+                    for (int j = 0; j < n; ++j) xi[j] -= f * u[j];
+                }
             }
-        }
-        for (int c = 0; c < k; ++c) {
-            const double* v = Vc.data() + (size_t)c * n;
-            std::fill(t.begin(), t.end(), 0.0);                 // t = v^T X; X <- X - v t
-            for (int i = 0; i < n; ++i) {
-                const double* xi = X.data() + (size_t)i * n;
-                for (int j = 0; j < n; ++j) t[j] += v[i] * xi[j];
+        });
+        // X <- (I - Vc^T Vc) X: columns are independent -- blocks of 64 columns (n x 64 doubles stay in L2 over the k vectors)
+        const int nblk = (n + 63) / 64;
+        run_threads(nt, [&](int t) {
+            double tb[64];
+            for (int blk = t; blk < nblk; blk += nt) {
+                const int c0 = blk * 64, cw = std::min(64, n - c0);
+                for (int c = 0; c < k; ++c) {
+                    const double* v = Vc.data() + (size_t)c * n;
+                    for (int j = 0; j < cw; ++j) tb[j] = 0.0;
+                    for (int i = 0; i < n; ++i) {
+                        const double* xi = X.data() + (size_t)i * n + c0;
+                        const double vi = v[i];
+                        for (int j = 0; j < cw; ++j) tb[j] += vi * xi[j];
+                    }
+                    for (int i = 0; i < n; ++i) {
+                        double* xi = X.data() + (size_t)i * n + c0;
+                        const double vi = v[i];
+                        for (int j = 0; j < cw; ++j) xi[j] -= vi * tb[j];
+                    }
+                }
             }
-            for (int i = 0; i < n; ++i) {
-                double* xi = X.data() + (size_t)i * n;
-                for (int j = 0; j < n; ++j) xi[j] -= v[i] * t[j];
-            }
-        }
+        });
     }
-    double fr = 0.0;
-    for (double x : X) fr += x * x;
+    double fr = 0.0, oi = 0.0;
+    {
+        std::vector<std::function<void()>> tasks;
+        tasks.emplace_back([&] {
+            double t2 = 0.0;
+            for (double x : X) t2 += x * x;
+            fr = t2;
+        });
+        tasks.emplace_back([&] { oi = one_inf_norm(n, X.data()); });
+        run_tasks(host_threads(n), tasks);
+    }
     if (!std::isfinite(fr)) return 0;
-    const double inv_norm = std::fmin(std::sqrt(fr), one_inf_norm(n, X.data()));
+    const double inv_norm = std::fmin(std::sqrt(fr), oi);
     if (!(norm_bound * inv_norm * rc < 0.1)) return 0;
     deflated = true;
     ncut = k;
@@ -743,19 +881,27 @@ int FactorSolver::deflate_width(double rc, std::vector<double>& X, double norm_b
 }
 
 
-// 1 ... 4 dropped directions with 8 vectors; when there are more, once again with 32 vectors (up to 24; X is only touched
-// after the iteration has converged).  false = the SVD decides.
+// 1 ... 4 dropped directions with 8 vectors; when there are more, once again with 16 (up to 10) and with 32 vectors (up to 24; X is
+// only touched after the iteration has converged, and the first Rayleigh-Ritz step already tells that a width is too narrow).
+// false = the SVD decides.
 bool FactorSolver::deflate(double rc, std::vector<double>& X, double norm_bound) {
+    HostProf hp_("deflate");
     if (const char* e = getenv("FSNAP_ROWSPACE_DEFLATE"))           // A/B switch: 0 = always the Jacobi SVD
         if (e[0] == '0') return false;
-    const double lower = norm2_estimate(n, T.data(), 12);          // <= sigma_max
+    double lower;
+    {
+        HostProf hp3_("deflate: sigma_max estimate");
+        lower = norm2_estimate(n, T.data(), 12);          // <= sigma_max
+    }
     if (!(lower > 0.0) || !std::isfinite(lower)) return false;
     int r = deflate_width<8, 4>(rc, X, norm_bound, lower);
+    if (r < 0) r = deflate_width<16, 10>(rc, X, norm_bound, lower);
     if (r < 0) r = deflate_width<32, 24>(rc, X, norm_bound, lower);
     return r == 1;
 }
 
 void FactorSolver::prepare(int K_, const double* Rhat, double rcond) {
+    HostProf hp_("prepare (all)");
         K = K_;
         act.clear();
         for (int j = 0; j < K; ++j)
@@ -778,28 +924,48 @@ void FactorSolver::prepare(int K_, const double* Rhat, double rcond) {
         // X = T^-1 by back substitution, row by row from the bottom: X_i = (e_i - sum_{k>i} T_ik X_k) / T_ii -- every
         // update is an axpy of contiguous rows (the column-by-column form walked X with stride n: 0.4 ms at n = 128)
         vec X((size_t)n * n, 0.0);
-        for (int i = n - 1; i >= 0 && ok; --i) {
-            double* __restrict__ xi = X.data() + (size_t)i * n;
-            const double* ti = T.data() + (size_t)i * n;
-            xi[i] = 1.0;
-            for (int k = i + 1; k < n; ++k) {
-                const double f = ti[k];
-                if (f == 0.0) continue;
-                const double* __restrict__ xk = X.data() + (size_t)k * n;
-                for (int c = k; c < n; ++c) xi[c] -= f * xk[c];
+        {
+            HostProf hp2_("prepare: inverse + norms");
+            // columns are independent (X e_c = T^-1 e_c): blocks of 64 columns dealt round-robin to the threads, every element
+            // accumulated in the same order whatever the split
+            const int nt = host_threads(n), nblk = (n + 63) / 64;
+            run_threads(nt, [&](int t) {
+                for (int blk = t; blk < nblk; blk += nt) {
+                    const int c0 = blk * 64, c1 = std::min(n, c0 + 64);
+                    for (int i = c1 - 1; i >= 0; --i) {
+                        double* __restrict__ xi = X.data() + (size_t)i * n;
+                        const double* ti = T.data() + (size_t)i * n;
+                        if (i >= c0) xi[i] = 1.0;
+                        for (int k = i + 1; k < c1; ++k) {
+                            const double f = ti[k];
+                            if (f == 0.0) continue;
+                            const double* __restrict__ xk = X.data() + (size_t)k * n;
+                            for (int c = std::max(k, c0); c < c1; ++c) xi[c] -= f * xk[c];
+                        }
+                        const double inv = 1.0 / ti[i];
+                        for (int c = std::max(i, c0); c < c1; ++c) xi[c] *= inv;
+                    }
+                }
+            });
+            double bt = fro, bx = 0.0;
+            std::vector<std::function<void()>> tasks;
+            tasks.emplace_back([&] {
+                double t2 = 0.0;
+                for (double v : X) t2 += v * v;
+                inv2 = t2;
+            });
+            tasks.emplace_back([&] { bt = one_inf_norm(n, T.data()); });
+            tasks.emplace_back([&] { bx = one_inf_norm(n, X.data()); });
+            run_tasks(nt, tasks);
+            ok = std::isfinite(inv2);
+            // a second provable pair, usually sharper on graded factors: ||B||_2 <= sqrt(||B||_1 ||B||_inf) for B = T and for
+            // B = T^-1 (both matrices are at hand).  The Frobenius norm charges up to sqrt(n) per factor -- at n = 128 a system
+            // with cond ~ 1e9 and rcond = 1e-13 missed the certificate by that margin and paid 1.8 ms of Jacobi sweeps for a
+            // solution that back substitution gives in 10 us (profiles/r05_lstsq_rows_phases.txt)
+            if (ok) {
+                fro2 = std::fmin(fro, bt);
+                inv_norm = std::fmin(std::sqrt(inv2), bx);
             }
-            const double inv = 1.0 / ti[i];
-            for (int c = i; c < n; ++c) xi[c] *= inv;
-        }
-        for (double v : X) inv2 += v * v;
-        ok = std::isfinite(inv2);
-        // a second provable pair, usually sharper on graded factors: ||B||_2 <= sqrt(||B||_1 ||B||_inf) for B = T and for
-        // B = T^-1 (both matrices are at hand).  The Frobenius norm charges up to sqrt(n) per factor -- at n = 128 a system
-        // with cond ~ 1e9 and rcond = 1e-13 missed the certificate by that margin and paid 1.8 ms of Jacobi sweeps for a
-        // solution that back substitution gives in 10 us (profiles/r05_lstsq_rows_phases.txt)
-        if (ok) {
-            fro2 = std::fmin(fro, one_inf_norm(n, T.data()));
-            inv_norm = std::fmin(std::sqrt(inv2), one_inf_norm(n, X.data()));
         }
         const double rc = rcond > 0.0 ? rcond : 0.0;
         triangular = ok && (fro2 * inv_norm * rc < 0.5);

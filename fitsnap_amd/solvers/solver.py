@@ -554,6 +554,8 @@ class Solver:
         rank, rcond = self.last_rank, getattr(self, "last_rcond", None)
         if rank is None or rcond is None:
             return False
+        if rank < 0:            # a probe that came back unresolved: no need to look at the statistics
+            return True
         if rank < K:
             G = self.last_statistics[0]
             zero_cols = int(np.count_nonzero(np.diag(G) == 0.0))
