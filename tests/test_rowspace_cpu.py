@@ -2,12 +2,16 @@
 numpy stands in for the two kernels of a pass (Q <- Q Rp^-1 by substitution = scipy solve_triangular, G = Q^T Q).
 Checked against the oracle's lstsq(aw, bw, 1e-13) (fitsnap3lib/solvers/svd.py:54): two backward-stable solvers differ
 by ~kappa eps, so that is the bar beyond kappa ~ 1e9; below it the north-star tolerance 1e-6 applies."""
+import os
+
 import numpy as np
 import pytest
 import scipy.linalg as sl
 
 from fitsnap_amd import _capi
 from oracle import fitsnap_oracle as orc
+
+from conftest import ROOT
 
 EPS = np.finfo(float).eps
 
@@ -335,3 +339,45 @@ def test_more_than_four_dropped_directions_take_the_wide_block(n, ndep, monkeypa
     scale = np.abs(beta_j).max()
     assert np.abs(beta - beta_j).max() <= 200 * 1e4 * EPS * scale
     assert np.abs(beta - ref).max() <= 2.0 * np.abs(beta_j - ref).max() + 200 * 1e4 * EPS * scale
+
+
+_THREAD_PROBE = r"""
+import sys, hashlib, numpy as np
+sys.path.insert(0, sys.argv[1])
+from fitsnap_amd import _capi
+K = 448
+rng = np.random.default_rng(5)
+U, _ = np.linalg.qr(rng.standard_normal((2 * K, K)))
+V, _ = np.linalg.qr(rng.standard_normal((K, K)))
+for spec, ndep in ((np.logspace(0, -9, K), 0), (np.logspace(0, -4, K), 5), (np.logspace(0, -4, K), 14)):
+    A = (U * spec) @ V.T
+    if ndep:
+        dep = rng.choice(K, ndep, replace=False)
+        others = np.setdiff1d(np.arange(K), dep)
+        for d in dep:
+            A[:, d] = A[:, rng.choice(others, 3, replace=False)] @ rng.standard_normal(3)
+    R1 = np.linalg.qr(A, mode="r")
+    R1 = R1 * np.sign(np.diag(R1))[:, None]
+    R2 = np.eye(K) + 1e-2 * np.triu(rng.standard_normal((K, K))) / K
+    z = rng.standard_normal(K)
+    beta, rank, info = _capi.rowspace_chain([R1, R2], z, 1e-13)
+    print(rank, info["chain"], repr(info["cond_bound"]), hashlib.sha256(beta.tobytes()).hexdigest())
+"""
+
+
+def test_large_k_host_phases_do_not_depend_on_the_thread_count(tmp_path):
+    # from 384 columns on the K x K end runs on FSNAP_HOST_THREADS threads (estimators as tasks, cooperative substitutions,
+    # product / inverse / projections by rows or columns): bit-identical coefficients and bounds with 1, 3 and 7 threads --
+    # a chain that is certified, one with 5 dropped directions (16 vectors) and one with 14 (32 vectors)
+    import subprocess
+    import sys
+
+    script = tmp_path / "probe.py"
+    script.write_text(_THREAD_PROBE)
+    outs = []
+    for nt in ("1", "3", "7"):
+        env = dict(os.environ, FSNAP_HOST_THREADS=nt)
+        outs.append(subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600, check=True).stdout)
+    assert outs[0] == outs[1] == outs[2]
+    lines = outs[0].strip().splitlines()
+    assert len(lines) == 3 and lines[0].startswith("448 1.0") and lines[1].startswith("443 0.0") and lines[2].startswith("434 0.0")
