@@ -226,30 +226,91 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
 // slot (the memcpy of piece i + 1 overlaps the DMA of piece i), and the caller's buffer is free on return.  A slot is
 // reused only after the event of its previous DMA has completed.  Up to two independent transfers per slot rotation
 // (weights + mask); larger requests than a slot holds grow the slot.
+// A few MB of host data (one weight per row, a mask, the rank array) -> device memory, ordered before everything launched later
+// on the context's stream; the caller's buffer is free when the function returns.  Two ways:
+//   1 staged    pieces of 1 MB through a page-locked slot: the caller's thread copies piece i + 1 while the DMA engine drains
+//               piece i; returns when the last piece is queued.  Host time 0.23 ms for 8 MB (memcpy 0.16 + 8 DMA calls).
+//   0 pageable  ONE hipMemcpyAsync from the caller's buffer and a wait for it (the runtime may read the buffer after the call
+//               returns, so the wait is what frees it).  0.15 ms for 8 MB, 0.26 for 14 MB on the round-5 boxes
+//               (profiles/r05_class_overhead.txt) -- the runtime pins the pages in place and the copy runs at PCIe speed,
+//               where the staged form is bound by one core's memcpy.
+// Which one is faster depends on the box (a pageable copy of 1 GB ran at 10 GB/s on one and 37 GB/s on another): from 1 MB on,
+// the first three uploads go the pageable way and the next three the staged way, each timed until the data is on the device
+// (the first of either kind not counted); the better one is kept for the context.  FSNAP_H2D_SMALL=pageable|staged fixes the choice.
+static int h2d_forced() {
+    static const int v = [] {
+        const char* e = getenv("FSNAP_H2D_SMALL");
+        if (!e) return -1;
+        if (!strcmp(e, "pageable")) return 0;
+        if (!strcmp(e, "staged")) return 1;
+        return -1;
+    }();
+    return v;
+}
+
 int staged_h2d(fsnap_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return FSNAP_OK;
-    const int slot = ctx->wstage_next;
-    ctx->wstage_next ^= 1;
-    if (ctx->wstage_ev[slot]) {
-        FSNAP_HIP(hipEventSynchronize(ctx->wstage_ev[slot]), "hipEventSynchronize(staging)");   // normally long done
+    int method = 1, probing = 0;
+    if (bytes >= ((size_t)1 << 20)) {
+        if (h2d_forced() >= 0) method = h2d_forced();
+        else if (ctx->h2d_method >= 0) method = ctx->h2d_method;
+        else {
+            probing = 1;
+            method = ctx->h2d_probes < 3 ? 0 : 1;
+        }
+    }
+    if ((method == 0 || probing) && !ctx->h2d_ev &&
+        hipEventCreateWithFlags(&ctx->h2d_ev, hipEventDisableTiming) != hipSuccess) {
+        ctx->h2d_ev = nullptr;
+        method = 1;
+        probing = 0;
+    }
+    std::chrono::steady_clock::time_point t0;
+    if (probing) {
+        int wrc;
+        if ((wrc = fsnap::wait_stream(ctx, nullptr, "upload probe"))) return wrc;      // time the copy, not what is queued before it
+        t0 = std::chrono::steady_clock::now();
+    }
+    if (method == 0) {
+        FSNAP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(H2D)");
+        FSNAP_HIP(hipEventRecord(ctx->h2d_ev, ctx->stream), "hipEventRecord");
+        int wrc;
+        if ((wrc = fsnap::wait_stream(ctx, ctx->h2d_ev, "upload"))) return wrc;
     } else {
-        FSNAP_HIP(hipEventCreateWithFlags(&ctx->wstage_ev[slot], hipEventDisableTiming), "hipEventCreate");
+        const int slot = ctx->wstage_next;
+        ctx->wstage_next ^= 1;
+        if (ctx->wstage_ev[slot]) {
+            FSNAP_HIP(hipEventSynchronize(ctx->wstage_ev[slot]), "hipEventSynchronize(staging)");   // normally long done
+        } else {
+            FSNAP_HIP(hipEventCreateWithFlags(&ctx->wstage_ev[slot], hipEventDisableTiming), "hipEventCreate");
+        }
+        if (ctx->wstage_bytes[slot] < bytes) {
+            if (ctx->wstage[slot]) (void)hipHostFree(ctx->wstage[slot]);
+            ctx->wstage[slot] = nullptr;
+            ctx->wstage_bytes[slot] = 0;
+            if (hipHostMalloc((void**)&ctx->wstage[slot], bytes, hipHostMallocDefault) != hipSuccess)
+                return ctx->fail(FSNAP_E_NOMEM, "hipHostMalloc(%zu) for the weight staging failed", bytes);
+            ctx->wstage_bytes[slot] = bytes;
+        }
+        const size_t piece = (size_t)1 << 20;
+        for (size_t off = 0; off < bytes; off += piece) {
+            const size_t n = bytes - off < piece ? bytes - off : piece;
+            memcpy(ctx->wstage[slot] + off, (const char*)src + off, n);
+            FSNAP_HIP(hipMemcpyAsync((char*)dst + off, ctx->wstage[slot] + off, n, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(staged H2D)");
+        }
+        FSNAP_HIP(hipEventRecord(ctx->wstage_ev[slot], ctx->stream), "hipEventRecord");
+        if (probing) {
+            int wrc;
+            if ((wrc = fsnap::wait_stream(ctx, ctx->wstage_ev[slot], "upload probe"))) return wrc;
+        }
     }
-    if (ctx->wstage_bytes[slot] < bytes) {
-        if (ctx->wstage[slot]) (void)hipHostFree(ctx->wstage[slot]);
-        ctx->wstage[slot] = nullptr;
-        ctx->wstage_bytes[slot] = 0;
-        if (hipHostMalloc((void**)&ctx->wstage[slot], bytes, hipHostMallocDefault) != hipSuccess)
-            return ctx->fail(FSNAP_E_NOMEM, "hipHostMalloc(%zu) for the weight staging failed", bytes);
-        ctx->wstage_bytes[slot] = bytes;
+    if (probing) {
+        // per byte, so that a mask (1 byte per row) and the weights (8) of the same fit can share the probes
+        const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / (double)bytes;
+        const bool first_of_its_kind = ctx->h2d_probes == 0 || ctx->h2d_probes == 3;      // pays the runtime's first-use costs: not counted
+        if (!first_of_its_kind && t < ctx->h2d_best[method]) ctx->h2d_best[method] = t;
+        if (++ctx->h2d_probes >= 6) ctx->h2d_method = ctx->h2d_best[0] <= ctx->h2d_best[1] ? 0 : 1;
     }
-    const size_t piece = (size_t)1 << 20;
-    for (size_t off = 0; off < bytes; off += piece) {
-        const size_t n = bytes - off < piece ? bytes - off : piece;
-        memcpy(ctx->wstage[slot] + off, (const char*)src + off, n);
-        FSNAP_HIP(hipMemcpyAsync((char*)dst + off, ctx->wstage[slot] + off, n, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(staged H2D)");
-    }
-    FSNAP_HIP(hipEventRecord(ctx->wstage_ev[slot], ctx->stream), "hipEventRecord");
     return FSNAP_OK;
 }
 
@@ -832,6 +893,7 @@ int fsnap_ctx_destroy(fsnap_ctx* ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->mirror) (void)hipHostFree(ctx->mirror);
     if (ctx->mirror_ev) (void)hipEventDestroy(ctx->mirror_ev);
+    if (ctx->h2d_ev) (void)hipEventDestroy(ctx->h2d_ev);
     if (ctx->chol_host) (void)hipHostFree(ctx->chol_host);
     if (ctx->chol_ev) (void)hipEventDestroy(ctx->chol_ev);
     for (auto& ev : ctx->ev)

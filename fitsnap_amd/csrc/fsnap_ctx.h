@@ -143,6 +143,11 @@ struct fsnap_ctx {
     size_t wstage_bytes[2] = {0, 0};
     hipEvent_t wstage_ev[2] = {nullptr, nullptr};
     int wstage_next = 0;
+    // small host -> device uploads (weights, masks): which way is faster on THIS box is measured on the first calls (see staged_h2d)
+    int h2d_method = -1;                   // -1 undecided, 0 = the runtime's pageable copy (waited for), 1 = page-locked staging
+    int h2d_probes = 0;
+    double h2d_best[2] = {1.0e30, 1.0e30}; // seconds until the data was on the device, best of the probes
+    hipEvent_t h2d_ev = nullptr;
     // page-locked double buffer of fsnap_upload_rows (two 16 MiB slots: host threads fill one while the DMA drains the other)
     char* rstage[2] = {nullptr, nullptr};
     hipEvent_t rstage_ev[2] = {nullptr, nullptr};
