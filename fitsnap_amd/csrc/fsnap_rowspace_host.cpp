@@ -255,11 +255,12 @@ void solve_upper_transposed(int n, const double* T, double* x) {
 // operations in the same order whatever the number of threads (also with one): the result does not depend on it.  The workers
 // spin (then yield) between the solves of an estimator -- the serial work in between is microseconds -- and are joined with it.
 class SpinBarrier {
-    const int n;
+    int n;
     std::atomic<int> arrived{0}, gen{0};
 
 public:
     explicit SpinBarrier(int n_) : n(n_) {}
+    void resize(int n_) { n = n_; }                     // before the first wait only
     void wait() {
         if (n <= 1) return;
         const int g = gen.load(std::memory_order_acquire);
@@ -355,16 +356,18 @@ class TriTeam {
 public:
     // `want` threads (the caller included); small systems keep the single-thread substitutions
     TriTeam(int n_, int want) : n(n_), nt(team_size(n_, want)), bar(team_size(n_, want)) {
+        int started = 1;
         for (int t = 1; t < nt; ++t) {
             try {
                 workers.emplace_back(&TriTeam::worker, this, t);
+                ++started;
             } catch (...) {
-                // cannot happen silently: the barrier counts nt participants.  Leave the threads that started and run alone.
-                post(-1, nullptr, nullptr);
-                for (auto& w : workers) w.join();
-                workers.clear();
-                throw;
+                break;                                  // no more threads to be had: a smaller team (the workers are still parked)
             }
+        }
+        if (started != nt) {
+            nt = started;
+            bar.resize(started);
         }
     }
     ~TriTeam() {
