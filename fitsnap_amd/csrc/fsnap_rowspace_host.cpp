@@ -54,6 +54,20 @@ static int host_threads(int n) {
     return cap;
 }
 
+// ... and no more threads than the work feeds: a thread start costs ~30 us, so every thread should get a few hundred microseconds
+// of it (3e5 multiply-adds of these memory-bound loops).  At n = 480 a power-iteration step is 30 us of work: 16 threads per
+// step made it 1 ms.
+static int threads_for(int n, double work) {
+    const int cap = host_threads(n);
+    static const double grain = [] {
+        const char* e = getenv("FSNAP_HOST_GRAIN");              // multiply-adds per thread (tuning aid)
+        const double v = e && *e ? atof(e) : 3.0e5;
+        return v >= 1.0e3 ? v : 3.0e5;
+    }();
+    const double want = work / grain;
+    return want < 2.0 ? 1 : (want > (double)cap ? cap : (int)want);
+}
+
 // f(t) for t = 0 .. nt - 1, the caller being thread 0
 template <class F>
 static void run_threads(int nt, F&& f) {
@@ -351,7 +365,7 @@ class TriTeam {
         x = x_;
         job_gen.fetch_add(1, std::memory_order_release);
     }
-    static int team_size(int n, int want) { return n < 384 ? 1 : std::max(1, std::min(want, 8)); }
+    static int team_size(int n, int want) { return n < 1024 ? 1 : std::max(1, std::min(want, 8)); }      // (a solve at n = 480 is 30 us of work)
 
 public:
     // `want` threads (the caller included); small systems keep the single-thread substitutions
@@ -476,11 +490,14 @@ double inverse_norm2_estimate(int n, const double* T, int steps = 14, int snap_s
 // with a partial v' each, summed in chunk order -- the value does not depend on how many threads ran the chunks.
 double norm2_estimate(int n, const double* T, int steps = 12) {
     if (n == 0) return 0.0;
-    const int nchunk = n >= 384 ? 16 : 1, nt = std::min(host_threads(n), nchunk);
+    const int nchunk = n >= 384 ? 16 : 1, nt = std::min(threads_for(n, 0.5 * (double)n * n * steps), nchunk);      // (one set of threads for all steps)
     vec v((size_t)n, 1.0 / std::sqrt((double)n)), part((size_t)nchunk * n);
-    double est = 0.0;
-    for (int it = 0; it < steps; ++it) {
-        run_threads(nt, [&](int t) {
+    double est = 0.0, bad = 0.0;
+    bool stop = false;
+    // ONE set of threads for all the steps (a barrier after the partial products, one after the reduction by thread 0)
+    SpinBarrier bar(nt);
+    run_threads(nt, [&](int t) {
+        for (int it = 0; it < steps; ++it) {
             for (int ch = t; ch < nchunk; ch += nt) {
                 double* __restrict__ pv = part.data() + (size_t)ch * n;
                 std::fill(pv, pv + n, 0.0);
@@ -491,20 +508,29 @@ double norm2_estimate(int n, const double* T, int steps = 12) {
                     for (int k = i; k < n; ++k) pv[k] += ti[k] * acc;
                 }
             }
-        });
-        double nn = 0.0;
-        for (int k = 0; k < n; ++k) {
-            double t2 = 0.0;
-            for (int ch = 0; ch < nchunk; ++ch) t2 += part[(size_t)ch * n + k];
-            v[k] = t2;
-            nn += t2 * t2;
+            bar.wait();
+            if (t == 0) {
+                double nn = 0.0;
+                for (int k = 0; k < n; ++k) {
+                    double t2 = 0.0;
+                    for (int ch = 0; ch < nchunk; ++ch) t2 += part[(size_t)ch * n + k];
+                    v[k] = t2;
+                    nn += t2 * t2;
+                }
+                nn = std::sqrt(nn);
+                if (!(nn > 0.0) || !std::isfinite(nn)) {
+                    bad = nn;
+                    stop = true;
+                } else {
+                    est = std::sqrt(nn);                  // ||T^T T v|| -> sigma_max^2 for unit v
+                    for (double& x : v) x /= nn;
+                }
+            }
+            bar.wait();
+            if (stop) return;
         }
-        nn = std::sqrt(nn);
-        if (!(nn > 0.0) || !std::isfinite(nn)) return nn;
-        est = std::sqrt(nn);                          // ||T^T T v|| -> sigma_max^2 for unit v
-        for (double& x : v) x /= nn;
-    }
-    return est;
+    });
+    return stop ? bad : est;
 }
 
 }  // namespace
@@ -532,7 +558,7 @@ struct ChainLook {
 static std::vector<ChainLook> chain_looks(int K, const std::vector<const double*>& R) {
     HostProf hp_("chain: sweeps + estimators");
     std::vector<ChainLook> L(R.size());
-    const int nt = host_threads(K);
+    const int nt = threads_for(K, 30.0 * (double)K * K);          // (the estimators of one factor: ~50 substitutions of K^2 / 2)
     std::vector<std::function<void()>> tasks;
     for (size_t f = 0; f < R.size(); ++f)
         tasks.emplace_back([&, f] {
@@ -665,7 +691,7 @@ void FactorChain::product(double* Rhat) const {
     std::fill(Rhat, Rhat + (size_t)K * K, 0.0);
     if (R.empty()) return;
     memcpy(Rhat, R[0], (size_t)K * K * sizeof(double));
-    const int nt = host_threads(K);
+    const int nt = threads_for(K, (double)K * K * K / 3.0);
     vec next(R.size() > 1 ? (size_t)K * K : 0);
     for (size_t k = 1; k < R.size(); ++k) {
         const double* Rp = R[k];
@@ -743,8 +769,8 @@ template <int DB>
 void solve_upper_block(int n, const double* T, double* W) {
     constexpr int CW = BCW, NG = DB / CW;
     static_assert(DB % CW == 0, "block width");
-    run_threads(std::min(host_threads(n), NG), [&](int t) {
-        const int nt = std::min(host_threads(n), NG);
+    const int nt = std::min(threads_for(n, 0.5 * (double)n * n * DB), NG);
+    run_threads(nt, [&](int t) {
         for (int g = t; g < NG; g += nt) {
             double* Wg = W + (size_t)g * n * CW;
             for (int i = n - 1; i >= 0; --i) {
@@ -766,8 +792,8 @@ void solve_upper_block(int n, const double* T, double* W) {
 template <int DB>
 void solve_upper_transposed_block(int n, const double* T, double* W) {
     constexpr int CW = BCW, NG = DB / CW;
-    run_threads(std::min(host_threads(n), NG), [&](int t) {
-        const int nt = std::min(host_threads(n), NG);
+    const int nt = std::min(threads_for(n, 0.5 * (double)n * n * DB), NG);
+    run_threads(nt, [&](int t) {
         for (int g = t; g < NG; g += nt) {
             double* Wg = W + (size_t)g * n * CW;
             for (int i = 0; i < n; ++i) {
@@ -895,8 +921,9 @@ int FactorSolver::deflate_width(double rc, std::vector<double>& X, double norm_b
     vec U((size_t)n * DB), W((size_t)n * DB), V((size_t)n * DB), Z((size_t)n * DB);
     {
         std::vector<std::pair<double, int>> heavy((size_t)n);
-        run_threads(host_threads(n), [&](int t) {
-            const int nt = host_threads(n);
+        const int nth = threads_for(n, (double)n * n);
+        run_threads(nth, [&](int t) {
+            const int nt = nth;
             for (int i = t; i < n; i += nt) heavy[i] = {dot_n(X.data() + (size_t)i * n, X.data() + (size_t)i * n, n), i};
         });
         std::partial_sort(heavy.begin(), heavy.begin() + DB, heavy.end(),
@@ -981,7 +1008,7 @@ int FactorSolver::deflate_width(double rc, std::vector<double>& X, double norm_b
     // fails for values at the rounding level of T: X holds ITS OWN rounding-level values for those directions.)
     {
         HostProf hp4_("deflate: projections of X");
-        const int nt = host_threads(n);
+        const int nt = threads_for(n, 2.0 * (double)n * n * k);
         // X <- X (I - Uc^T Uc): row by row, the dropped u's one after the other on the row while it is in L1 (one pass over X)
         run_threads(nt, [&](int t) {
             for (int i = t; i < n; i += nt) {
@@ -1025,7 +1052,7 @@ int FactorSolver::deflate_width(double rc, std::vector<double>& X, double norm_b
             fr = t2;
         });
         tasks.emplace_back([&] { oi = one_inf_norm(n, X.data()); });
-        run_tasks(host_threads(n), tasks);
+        run_tasks(threads_for(n, 2.0 * (double)n * n), tasks);
     }
     if (!std::isfinite(fr)) return 0;
     const double inv_norm = std::fmin(std::sqrt(fr), oi);
@@ -1086,7 +1113,7 @@ void FactorSolver::prepare(int K_, const double* Rhat, double rcond) {
             HostProf hp2_("prepare: inverse + norms");
             // columns are independent (X e_c = T^-1 e_c): blocks of 64 columns dealt round-robin to the threads, every element
             // accumulated in the same order whatever the split
-            const int nt = host_threads(n), nblk = (n + 63) / 64;
+            const int nt = threads_for(n, (double)n * n * n / 3.0), nblk = (n + 63) / 64;
             run_threads(nt, [&](int t) {
                 for (int blk = t; blk < nblk; blk += nt) {
                     const int c0 = blk * 64, c1 = std::min(n, c0 + 64);
