@@ -49,6 +49,29 @@ static int host_threads(int n) {
         int v = e && *e ? atoi(e) : 16;
         const unsigned hc = std::thread::hardware_concurrency();
         if (hc > 0 && v > (int)hc) v = (int)hc;
+        if (!(e && *e)) {
+            // a cgroup CPU quota (cpu.max "quota period", or cfs_quota_us / cfs_period_us): more runnable threads than the
+            // quota pays for are throttled for the rest of the period -- never more threads than whole CPUs of quota
+            double cpus = 0.0;
+            if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+                char q[32] = {0};
+                double period = 0.0;
+                if (fscanf(f, "%31s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0.0) cpus = atof(q) / period;
+                fclose(f);
+            } else {
+                double quota = -1.0, period = 0.0;
+                if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+                    if (fscanf(g, "%lf", &quota) != 1) quota = -1.0;
+                    fclose(g);
+                }
+                if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                    if (fscanf(g, "%lf", &period) != 1) period = 0.0;
+                    fclose(g);
+                }
+                if (quota > 0.0 && period > 0.0) cpus = quota / period;
+            }
+            if (cpus > 0.0 && (double)v > cpus) v = cpus < 1.0 ? 1 : (int)cpus;
+        }
         return v < 1 ? 1 : (v > 64 ? 64 : v);
     }();
     return cap;
