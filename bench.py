@@ -187,6 +187,24 @@ def spawn_ranks(args):
 # ---------------------------------------------------------------------------------------------------------------------
 # one rank
 # ---------------------------------------------------------------------------------------------------------------------
+def cpu_quota_cpus():
+    """CPUs of a cgroup quota (cpu.max "quota period" / cfs_quota_us, cfs_period_us), None without one."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p = float(f.read())
+        return q / p if q > 0 and p > 0 else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(A, b, w, beta_gpu):
     """Reference algorithm (oracle restatement) on the host cores, bounded sample."""
     from oracle import fitsnap_oracle as orc
@@ -198,6 +216,17 @@ def cpu_baseline(A, b, w, beta_gpu):
         threads = max([p[1] for p in pools] + [1])
     except Exception:
         pools, threads = [], os.cpu_count() or 1
+    # a cgroup CPU quota (the MI355X boxes: cpu.max = 16 CPUs of 256): BLAS threads beyond it only get throttled -- the baseline
+    # runs with as many threads as the quota pays for, and `cores` says that number
+    quota = cpu_quota_cpus()
+    limiter = None
+    if quota is not None and quota < threads:
+        try:
+            from threadpoolctl import threadpool_limits
+            limiter = threadpool_limits(limits=max(1, int(quota)))
+            threads = max(1, int(quota))
+        except Exception:
+            limiter = None
     # RIDGE path of the reference (ridge.py:37-59): weighting + normal equations + Cholesky, all rows
     t0 = time.perf_counter()
     beta = orc.ridge_fit(A, b, w, ALPHA)
@@ -207,9 +236,11 @@ def cpu_baseline(A, b, w, beta_gpu):
     t0 = time.perf_counter()
     orc.svd_fit(A[:ms], b[:ms], w[:ms])
     t_svd = time.perf_counter() - t0
+    if limiter is not None:
+        limiter.restore_original_limits()
     rel = None if beta_gpu is None else float(np.max(np.abs(beta_gpu - beta) / np.maximum(np.abs(beta), 1e-300)))
     return {
-        "value": m / t_ridge, "unit": "rows/s", "cores": int(threads), "kind": "port",
+        "value": m / t_ridge, "unit": "rows/s", "cores": int(threads), "kind": "port", "cpu_quota_cpus": quota,
         "sample": f"oracle ridge_fit (weight + X^T X + Cholesky, reference ridge.py:37-59) on all {m} rows: "
                   f"{t_ridge:.2f} s; oracle svd_fit (lstsq, svd.py:54) on {ms} rows: {t_svd:.2f} s",
         "svd_lstsq_rows_per_s": ms / t_svd, "host_cpu_count": os.cpu_count(), "blas": pools,
