@@ -666,6 +666,7 @@ int launch_normal_eq_tiled(fsnap_ctx* ctx, double* d_packed, bool accumulate) {
 int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false, bool accumulate = false) {
     int rc;
     ctx->mirror_of = nullptr;
+    ctx->chol_factor_of = nullptr;              // the statistics are about to change: the factor on the device is of the old ones
     if ((rc = check_rows(ctx)) || (rc = check_weights(ctx))) return rc;
     if (use_tiled(ctx)) return launch_normal_eq_tiled(ctx, d_packed, accumulate);
     Geometry g;
@@ -962,6 +963,9 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
     } else if (!strcmp(key, "dist_solve")) {
         if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "dist_solve must be 0 (solve on every rank) or 1 (rank 0 solves and broadcasts)");
         ctx->opt_dist_solve = (int)value;
+    } else if (!strcmp(key, "chol_reuse")) {
+        ctx->opt_chol_reuse = value != 0;
+        ctx->chol_factor_of = nullptr;
     } else if (!strcmp(key, "rowspace_reuse_stats")) {
         ctx->opt_rowspace_reuse = value != 0;
     } else if (!strcmp(key, "chol_form")) {
@@ -1605,6 +1609,7 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
     const double alpha = (kind == FSNAP_SOLVE_RIDGE || kind == FSNAP_SOLVE_RIDGE_INV || kind == FSNAP_SOLVE_RIDGE_PROBE ||
                           kind == FSNAP_SOLVE_RIDGE_INV_PROBE) ? param : 0.0;
     if (K <= 128 && ctx->opt_device_solve == 1 && !rhs) {
+        ctx->chol_factor_of = nullptr;              // (this path reuses the buffer that holds the scaling of a blocked factorisation)
         if (!ctx->dsolve.ensure((size_t)(K + 2) * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(solve) failed");
         double host[130];
         FSNAP_HIP(fsnap::launch_chol_solve(d_packed, (int)K, alpha, (double*)ctx->dsolve.p, ctx->stream),
@@ -1665,6 +1670,34 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
             FSNAP_HIP(hipMemcpyAsync(ctx->dsvec.p, rhs, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(rhs)");
             d_rhs = (const double*)ctx->dsvec.p;
         }
+        // a right-hand side of its own for statistics this context has just factorised (the refinement steps of a fit): the
+        // factor, the scaling and the inverses of the diagonal blocks are still in the work buffers -- two sweeps instead of a
+        // factorisation (kernel 8f + the backward sweep)
+        const int form_now = ctx->opt_chol_form < 0 ? fsnap::chol_default_form() : ctx->opt_chol_form;
+        const bool reuse = rhs && host_out && ctx->opt_chol_reuse && ctx->chol_factor_of == d_packed && ctx->chol_factor_K == K &&
+                           ctx->chol_factor_alpha == alpha && ctx->chol_factor_form == form_now;
+        if (reuse) {
+            FSNAP_HIP(fsnap::launch_chol_resolve(d_rhs, n, (double*)ctx->dchol.p, d_dsc, d_z, d_beta, d_status, d_minpiv, host_out,
+                                                 form_now, ctx->stream),
+                      "launch device Cholesky (sweeps)");
+            FSNAP_HIP(hipEventRecord(ctx->chol_ev, ctx->stream), "hipEventRecord");
+            int wrc;
+            if ((wrc = fsnap::wait_stream(ctx, ctx->chol_ev, "device Cholesky sweeps"))) return wrc;
+            int status;
+            memcpy(&status, host_out + n + npanel, sizeof(int));
+            bool fin = status == 0;
+            for (int i = 0; i < n && fin; ++i) fin = (host_out[i] - host_out[i] == 0.0);
+            if (fin) {
+                double mp = 1.0e300;
+                for (int p = 0; p < npanel; ++p) mp = host_out[n + p] < mp ? host_out[n + p] : mp;
+                for (int i = 0; i < n; ++i) beta[i] = host_out[i];
+                if (rank) *rank = n;
+                if (rcond_est) *rcond_est = mp;
+                return FSNAP_OK;
+            }
+            ctx->chol_factor_of = nullptr;          // (a non-finite right-hand side: the full path below reports it)
+        }
+        ctx->chol_factor_of = nullptr;
         // the status word lives behind beta and the pivots: its address depends on K.  The chain leaves it cleared; a
         // clearing launch is needed only when this word has not been through a chain yet
         const bool clear_status = ctx->chol_status_word != (const void*)d_status;
@@ -1698,6 +1731,11 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
                 for (int i = 0; i < n; ++i) beta[i] = h[i];
                 if (rank) *rank = n;
                 if (rcond_est) *rcond_est = mp;
+                // the factor of these statistics stays on the device for further right-hand sides
+                ctx->chol_factor_of = d_packed;
+                ctx->chol_factor_K = K;
+                ctx->chol_factor_alpha = alpha;
+                ctx->chol_factor_form = form_now;
                 return FSNAP_OK;
             }
         }
@@ -1851,6 +1889,7 @@ int fsnap_dev_upload(fsnap_ctx* ctx, void* d_dst, const void* h_src, int64_t nby
     if (!ctx) return FSNAP_E_ARG;
     if (!d_dst || !h_src || nbytes <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_dev_upload: bad argument");
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    ctx->chol_factor_of = nullptr;              // (the destination may be a statistics buffer)
     FSNAP_HIP(hipMemcpyAsync(d_dst, h_src, (size_t)nbytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(H2D)");
     FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     return FSNAP_OK;

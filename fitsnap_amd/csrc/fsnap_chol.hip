@@ -1934,6 +1934,60 @@ __global__ __launch_bounds__(1024) void fsnap_chol_backsolve_k(const double* __r
     }
 }
 // ---------------------------------------------------------------------------------
+// Kernel 8f: y = U^-T (D r) with the factor a solve left behind -- the forward sweep for ONE MORE right-hand side (the
+// refinement steps of the SVD solver solve G delta = s with the G of the fit: the factorisation itself carries the first
+// right-hand side along as a strip, a second one used to pay the whole factorisation again: 0.54 ms at K = 1595, 0.17 at 480).
+// One workgroup: per 64-row panel the diagonal block goes through LDS, wave 0 runs its 64-step substitution (multipliers
+// broadcast with v_readlane), then every thread takes columns right of the panel, z_k -= sum_i U[i][k] y_i (64 independent
+// loads per column, coalesced over the threads).  The factor is read once: 10 MB at K = 1595 through one CU.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void fsnap_chol_forward_k(const double* __restrict__ Uf, int ld, int np, int n,
+                                                            const double* __restrict__ rhs, const double* __restrict__ dsc,
+                                                            double* __restrict__ zv, const int* __restrict__ status) {
+    __shared__ double U11[CHOL_NB * (CHOL_NB + 1)];
+    __shared__ double ysm[CHOL_NB];
+    if (*status) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < np; i += 1024) zv[i] = (i < n) ? rhs[i] * dsc[i] : 0.0;
+    __syncthreads();
+    for (int jb = 0; jb < np; jb += CHOL_NB) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = tid + 1024 * q;
+            U11[(t >> 6) * (CHOL_NB + 1) + (t & 63)] = Uf[(size_t)(jb + (t >> 6)) * ld + jb + (t & 63)];
+        }
+        if (tid < CHOL_NB) ysm[tid] = zv[jb + tid];
+        __syncthreads();
+        if (wv == 0) {
+            double v = ysm[lane];
+            const double invd = 1.0 / U11[lane * (CHOL_NB + 1) + lane];
+#pragma unroll 8
+            for (int k = 0; k < CHOL_NB; ++k) {
+                const double yk = readlane_f64(v, k) * readlane_f64(invd, k);
+                if (lane == k) v = yk;
+                if (lane > k) v = __builtin_fma(-U11[k * (CHOL_NB + 1) + lane], yk, v);
+            }
+            ysm[lane] = v;
+            zv[jb + lane] = v;
+        }
+        __syncthreads();
+        for (int k = jb + CHOL_NB + tid; k < np; k += 1024) {
+            const double* u = Uf + (size_t)jb * ld + k;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 4
+            for (int i = 0; i < CHOL_NB; i += 4) {
+                a0 = __builtin_fma(u[(size_t)i * ld], ysm[i], a0);
+                a1 = __builtin_fma(u[(size_t)(i + 1) * ld], ysm[i + 1], a1);
+                a2 = __builtin_fma(u[(size_t)(i + 2) * ld], ysm[i + 2], a2);
+                a3 = __builtin_fma(u[(size_t)(i + 3) * ld], ysm[i + 3], a3);
+            }
+            zv[k] -= (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // Factor-only use of kernels 8b-8d: the pass factor of the row-space solve (fsnap_rowspace.cpp, shifted CholeskyQR)
 //   R_p = chol(D^-1 G D^-1 + s I) D,   D = diag(sqrt(G_jj)),
 // for K >= 384, where the host factorisation (one core: 12 ms at K = 1595, 22 ms with the scaling passes around it, twice
@@ -2197,6 +2251,39 @@ hipError_t launch_chol_large(const double* packed, const double* cvec, int n, do
             const int nrows = lo * CHOL_NB;
             hipLaunchKernelGGL(fsnap_chol_backupdate_k, dim3((nrows + 3) / 4), dim3(256), 0, st, (const double*)Uf, ld, z, lo * CHOL_NB,
                                hi * CHOL_NB, nrows, status);
+        }
+    }
+    return hipGetLastError();
+}
+
+// One more right-hand side for the factor the last launch_chol_large(n, form) left in `work` (same work, dsc, z, minpiv buffers):
+// kernel 8f, then the backward sweep as in launch_chol_large.  d_rhs: n doubles in device memory (unscaled).
+hipError_t launch_chol_resolve(const double* d_rhs, int n, double* work, const double* dsc, double* z, double* beta, int* status,
+                               const double* minpiv, double* host_out, int form, hipStream_t st) {
+    form = chol_resolve_form(form);
+    const int np = (n + CHOL_NB - 1) / CHOL_NB * CHOL_NB, npanel = np / CHOL_NB, ld = np + CHOL_XS;
+    double* Yall = work + (size_t)np * ld;
+    const double* Uf = chol_factor_matrix(work, np, form);
+    hipError_t e;
+    if (!host_out) {
+        e = hipMemsetAsync(status, 0, sizeof(int), st);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(fsnap_chol_forward_k, dim3(1), dim3(1024), 0, st, Uf, ld, np, n, d_rhs, dsc, z, (const int*)status);
+    static bool bs_attr_set = false;
+    if (!bs_attr_set) {
+        e = hipFuncSetAttribute((const void*)fsnap_chol_backsolve_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHOL_BS_LDS);
+        if (e != hipSuccess) return e;
+        bs_attr_set = true;
+    }
+    for (int hi = npanel; hi > 0; hi -= CHOL_BS_MACRO) {
+        const int lo = hi > CHOL_BS_MACRO ? hi - CHOL_BS_MACRO : 0;
+        hipLaunchKernelGGL(fsnap_chol_backsolve_k, dim3(1), dim3(1024), CHOL_BS_LDS, st, Uf, ld, np, n, (const double*)Yall, z, dsc, beta,
+                           status, lo, hi, 0, minpiv, host_out, (const double*)nullptr);
+        if (lo > 0) {
+            const int nrows = lo * CHOL_NB;
+            hipLaunchKernelGGL(fsnap_chol_backupdate_k, dim3((nrows + 3) / 4), dim3(256), 0, st, Uf, ld, z, lo * CHOL_NB, hi * CHOL_NB,
+                               nrows, (const int*)status);
         }
     }
     return hipGetLastError();

@@ -253,6 +253,7 @@ int fsnap_allreduce_device(fsnap_ctx* ctx, double* d_buf, int64_t n) {
     int rc;
     if ((rc = need_comm(ctx, &r))) return rc;
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    ctx->chol_factor_of = nullptr;              // (the buffer may be statistics a factor on the device belongs to)
     FSNAP_NCCL(r->AllReduce(d_buf, d_buf, (size_t)n, ncclDouble, ncclSum, ctx->comm->nccl, ctx->stream), "ncclAllReduce");
     return FSNAP_OK;
 }

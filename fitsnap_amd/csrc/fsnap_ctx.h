@@ -143,6 +143,12 @@ struct fsnap_ctx {
     size_t wstage_bytes[2] = {0, 0};
     hipEvent_t wstage_ev[2] = {nullptr, nullptr};
     int wstage_next = 0;
+    // the factor in `dchol`: of which statistics buffer / order / shift / panel-loop form (nullptr = none; cleared by every launch that
+    // rewrites statistics or the work matrix)
+    const double* chol_factor_of = nullptr;
+    int64_t chol_factor_K = 0;
+    double chol_factor_alpha = 0.0;
+    int chol_factor_form = -2;
     // small host -> device uploads (weights, masks): which way is faster on THIS box is measured on the first calls (see staged_h2d)
     int h2d_method = -1;                   // -1 undecided, 0 = the runtime's pageable copy (waited for), 1 = page-locked staging
     int h2d_probes = 0;
@@ -174,6 +180,7 @@ struct fsnap_ctx {
     int opt_fused_pack = 1;   // kernel 1A forms the per-row pairs of its rows in LDS itself (no packing launch) when they fit
     int opt_acc_min_cpw = 0;  // kernel 1A: fewest 4-row chunks per row-wave before the grid shrinks (0 = default)
     int opt_rowspace_reuse = 0;  // one-shot, set by the caller right before fsnap_lstsq_rows: the statistics of the fit that just ran (still in the page-locked mirror) are those of the rows as they are now -- the first pass starts from them
+    int opt_chol_reuse = 1;   // fsnap_solve_device_rhs with a right-hand side of its own (refinement): 1 = forward + backward sweep with the factor the last solve of the same statistics left on the device, 0 = factorise again (A/B)
     int opt_chol_form = -1;   // panel loop of the device Cholesky: -1 = default (FSNAP_CHOL_DIAG, else 5: one launch per panel, four-wave diagonal block); 0 | 1 | 2 | 4: the A/B forms (fsnap_chol.hip)
     int opt_quad_flow = 2 + 4 * 63;  // kernel 1QC (lead 63 = by cluster size: 0 for clusters of 2, 2 for clusters of 4): flow control between the members of a cluster: mode (0 off, 1 look at the end of a trip, 2 at its start) + 4 x lead (trips a member may run ahead)
     int opt_quad_cluster = 1; // kernel 1QC (288 < K <= 512: kernel 1Q's plan on a cluster of 2 / 4 workgroups of one XCD); 0 = tiled kernel there

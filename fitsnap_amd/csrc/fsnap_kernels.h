@@ -112,6 +112,9 @@ hipError_t launch_chol_large(const double* packed, const double* cvec, int n, do
                              hipStream_t st);
 // `form` of the panel loop (option "chol_form"): 5 = one launch per panel + four-wave diagonal block (default), 4 = two launches
 // per panel + four-wave block, 0 | 1 | 2 = two launches per panel + the single-wave block with pivot chain 0 / 1 / 2 (rounds 2-4);
+// one more right-hand side (n doubles, device) for the factor the last launch_chol_large of the same n / form left in `work`
+hipError_t launch_chol_resolve(const double* d_rhs, int n, double* work, const double* dsc, double* z, double* beta, int* status,
+                               const double* minpiv, double* host_out, int form, hipStream_t st);
 // -1 = chol_default_form() (FSNAP_CHOL_DIAG, else 5)
 int chol_default_form();
 // factor only (pass factor of the row-space solve, K >= 384): R = chol(D^-1 G D^-1 + shift I) D for the n x n Gram matrix G in

@@ -343,6 +343,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
             double* d_minpiv = d_dsc + np64;
             int* d_status = (int*)(d_minpiv + npanel);
             ctx->chol_status_word = nullptr;                  // the buffer of fsnap_solve_device's chain is reused here
+            ctx->chol_factor_of = nullptr;                    // ... and so is the work matrix: no factor of a fit in it any more
             // shift: a few times the rounding level of the Gram matrix, x 100 and again when a pivot fails (as factor_pass)
             shift = 4.0 * (K + 100.0) * std::numeric_limits<double>::epsilon() * fro;
             int status = 0;

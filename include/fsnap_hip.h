@@ -115,6 +115,10 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * "mirror_upper" (0|1, default 1: the reduction writes the host mirror's triangle once per element, at its upper position),
  * "fused_residual" (fsnap_residual_rhs for K <= 288: 1 = one pass over the rows, the default; 2 = one pass with the next rows
  * prefetched into a second register set -- measured slower, fewer waves per SIMD; 0 = the two-kernel form, two passes),
+ * "chol_reuse" (0|1, default 1: fsnap_solve_device_rhs with a right-hand side of its own -- the refinement steps of a fit -- runs
+ * a forward and a backward sweep with the factor that the last solve of the same statistics, order and shift left on the device
+ * (kernel 8f + 8e: 0.2 instead of 0.54 ms at K = 1595); 0 = factorise again, A/B.  Every launch that rewrites statistics, an
+ * all-reduce or an upload into device memory forgets the factor),
  * "rowspace_reuse_stats" (one-shot, cleared by the next fsnap_lstsq_rows: 1 = the caller states that the fit from the statistics
  * which just ran -- fsnap_fit_resident on this context -- saw the rows, weights and mask as they are now; a single-rank
  * fsnap_lstsq_rows on a system the host factorises then starts its first pass from that fit's statistics, still in the page-locked

@@ -534,6 +534,68 @@ def test_large_k_device_cholesky_matches_host_solve(ctx, K, m):
         assert np.max(np.abs(beta_dev - ref)) / scale < 1e-8
 
 
+@pytest.mark.parametrize("K,m", [(232, 2500), (257, 3001), (480, 6000), (1000, 5000), (1595, 7000)])
+@pytest.mark.parametrize("form", [5, 4, 2])
+def test_device_cholesky_factor_is_reused_for_further_right_hand_sides(ctx, K, m, form):
+    # the refinement steps of a fit solve G delta = s with the G that was just factorised on the GPU: fsnap_solve_device_rhs
+    # then runs a forward (kernel 8f) and a backward sweep with the factor left on the device (option "chol_reuse", default 1)
+    # instead of factorising again -- same answers as the full path and as a dense solve, for RIDGE and LSTSQ, in every panel-loop
+    # form; new statistics, a different shift or another buffer forget the factor
+    rng = np.random.default_rng(9000 + K)
+    A = rng.standard_normal((m, K)) * (10.0 ** rng.uniform(-1, 1, size=K))
+    b = rng.standard_normal(m)
+    w = rng.uniform(0.5, 2.0, m)
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w)
+    ctx.set_option("chol_form", form)
+    ctx.set_option("device_solve", 1)
+    try:
+        ptr = ctx.normal_eq_resident()
+        G, c, _ = ctx.download_packed(ptr, K)
+        for kind, param in ((_capi.SOLVE_RIDGE, 1e-6), (_capi.SOLVE_LSTSQ, 1e-13)):
+            alpha = param if kind == _capi.SOLVE_RIDGE else 0.0
+            M = G + alpha * np.eye(K)
+            beta0, rank, rcond = ctx.solve_device(kind, param, K, ptr)
+            assert rank == K
+            for trial in range(3):
+                rhs = rng.standard_normal(K) * np.abs(c).max()
+                ctx.set_option("chol_reuse", 1)
+                ctx.solve_device(kind, param, K, ptr)                       # (option changes forget the factor: factorise)
+                x_reuse, rk1, rc1 = ctx.solve_device(kind, param, K, ptr, rhs=rhs)
+                ctx.set_option("chol_reuse", 0)
+                x_full, rk0, rc0 = ctx.solve_device(kind, param, K, ptr, rhs=rhs)
+                ref = np.linalg.solve(M, rhs)
+                scale = np.abs(ref).max()
+                assert rk1 == rk0 == K and rc1 == rc0
+                assert np.abs(x_reuse - x_full).max() <= 1e-10 * scale
+                assert np.abs(x_reuse - ref).max() <= 1e-8 * scale
+            # the first right-hand side again through the sweeps: the fit's own coefficients
+            ctx.set_option("chol_reuse", 1)
+            ctx.solve_device(kind, param, K, ptr)
+            again = ctx.solve_device(kind, param, K, ptr, rhs=c)[0]
+            assert np.abs(again - beta0).max() <= 1e-10 * np.abs(beta0).max()
+        # new statistics behind the same pointer: the factor of the old ones must not answer
+        ctx.set_option("chol_reuse", 1)
+        ctx.solve_device(_capi.SOLVE_RIDGE, 1e-6, K, ptr)
+        w2 = w * rng.uniform(0.2, 5.0, m)
+        ctx.set_weights(w2)
+        ptr2 = ctx.normal_eq_resident()
+        G2, c2, _ = ctx.download_packed(ptr2, K)
+        rhs = rng.standard_normal(K)
+        x = ctx.solve_device(_capi.SOLVE_RIDGE, 1e-6, K, ptr2, rhs=rhs)[0]
+        ref = np.linalg.solve(G2 + 1e-6 * np.eye(K), rhs)
+        assert np.abs(x - ref).max() <= 1e-8 * np.abs(ref).max()
+        # ... nor for another shift
+        ctx.solve_device(_capi.SOLVE_RIDGE, 1e-6, K, ptr2)
+        x = ctx.solve_device(_capi.SOLVE_RIDGE, 1e-2, K, ptr2, rhs=rhs)[0]
+        ref = np.linalg.solve(G2 + 1e-2 * np.eye(K), rhs)
+        assert np.abs(x - ref).max() <= 1e-8 * np.abs(ref).max()
+    finally:
+        ctx.set_option("device_solve", 0)
+        ctx.set_option("chol_form", -1)
+        ctx.set_option("chol_reuse", 1)
+
+
 @pytest.mark.parametrize("env", [{"FSNAP_CHOL_FUSED": "1"}, {"FSNAP_CHOL_DIAG": "0"}, {"FSNAP_CHOL_DIAG": "1"}, {"FSNAP_CHOL_DIAG": "2"},
                                  {"FSNAP_CHOL_DIAG": "4"}, {"FSNAP_CHOL_DIAG": "5"}])
 def test_device_cholesky_ab_forms_solve_the_same_systems(env):
