@@ -1248,6 +1248,8 @@ int fsnap_assemble_accumulate(fsnap_ctx* ctx, const double* raw, int64_t raw_row
                               const double* blank2J, int32_t ntypes, int32_t ncoeff, int32_t offcol, double* d_packed) {
     if (!ctx) return FSNAP_E_ARG;
     if (!d_packed) return ctx->fail(FSNAP_E_ARG, "fsnap_assemble_accumulate: d_packed is NULL");
+    ctx->chol_factor_of = nullptr;              // the statistics in d_packed change: neither a factor on the device ...
+    if (ctx->mirror_of == d_packed) ctx->mirror_of = nullptr;      // ... nor the host mirror is of them any more
     int rc;
     AssemblyPlanDev pd;
     if ((rc = stage_assembly(ctx, "fsnap_assemble_accumulate", raw, raw_rows, raw_ld, nrows, src_row, kind, frac, d, truth,
