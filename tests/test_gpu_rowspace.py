@@ -273,3 +273,34 @@ def test_large_k_truncated_solve_runs_in_lapack(case):
     assert info["svd"] == (3.0 if case == "duplicated" else 1.0) and rank == rank_ref
     assert np.linalg.norm(beta - ref) <= 1e-7 * np.linalg.norm(ref)
     ctx.close()
+
+
+@pytest.mark.parametrize("K,m,masked", [(128, 20011, False), (96, 9001, True), (200, 12000, False)])
+def test_first_pass_from_the_statistics_of_the_fit_that_just_ran(K, m, masked):
+    # option "rowspace_reuse_stats" (one-shot; Solver._row_space_fit sets it): the first CholeskyQR pass starts from the Gram
+    # matrix that fsnap_fit_resident computed a moment ago on the same rows, weights and mask (still in the page-locked mirror)
+    # instead of computing it again -- bit-identical coefficients, and the option is used up by ONE call
+    r = np.random.default_rng(700 + K)
+    A = r.standard_normal((m, K))
+    A[:, K - 1] = A[:, 0] * 1.5 + 1e-9 * A[:, K - 1]                   # kappa ~ 1e9: what sends the SVD solver to the rows
+    b = r.standard_normal(m)
+    w = r.uniform(0.5, 2.0, m)
+    mask = (r.random(m) > 0.1).astype(np.uint8) if masked else None
+    ctx = _capi.HipContext(0)
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w, mask)
+    plain, rank0, info0 = ctx.lstsq_rows(1.0e-13)
+    ctx.fit_resident(_capi.SOLVE_LSTSQ_PROBE, 1.0e-13)
+    ctx.set_option("rowspace_reuse_stats", 1)
+    kept, rank1, info1 = ctx.lstsq_rows(1.0e-13)
+    assert rank1 == rank0 and np.array_equal(kept, plain) and info1["passes"] == info0["passes"]
+    again, rank2, _ = ctx.lstsq_rows(1.0e-13)                          # the option is gone: statistics computed afresh, same answer
+    assert rank2 == rank0 and np.array_equal(again, plain)
+    # new weights after the fit: a caller that still sets the option gets the statistics of the OLD weights only if it lies
+    # about them -- the host layer sets the option right behind its own fit, never across set_weights; here the honest order
+    ctx.set_weights(2.0 * w, mask)
+    ctx.fit_resident(_capi.SOLVE_LSTSQ_PROBE, 1.0e-13)
+    ctx.set_option("rowspace_reuse_stats", 1)
+    scaled, rank3, _ = ctx.lstsq_rows(1.0e-13)
+    assert rank3 == rank0 and np.abs(scaled - plain).max() <= 1e-9 * np.abs(plain).max()      # lstsq is invariant under a uniform weight scale
+    ctx.close()
