@@ -70,7 +70,10 @@ static int host_threads(int n) {
                 }
                 if (quota > 0.0 && period > 0.0) cpus = quota / period;
             }
-            if (cpus > 0.0 && (double)v > cpus) v = cpus < 1.0 ? 1 : (int)cpus;
+            // ... and not all of it: the caller's other threads (the HIP runtime's, a spinning stream wait) run on the same quota, and
+            // a cgroup that overdraws it is stopped for the rest of the 100 ms period (seen as 80 ms outliers of a 17 ms phase
+            // with 16 threads on a 16-CPU quota): three quarters
+            if (cpus > 0.0 && (double)v > 0.75 * cpus) v = 0.75 * cpus < 1.0 ? 1 : (int)(0.75 * cpus);
         }
         return v < 1 ? 1 : (v > 64 ? 64 : v);
     }();
@@ -511,9 +514,11 @@ double inverse_norm2_estimate(int n, const double* T, int steps = 14, int snap_s
 // ||T||_2 by power iteration on T^T T (upper triangular T, row-major): a lower estimate, close after a dozen steps.
 // One pass over T per step (w_i = t_i . v and v' += w_i t_i use the same row); the rows are cut into a FIXED number of chunks
 // with a partial v' each, summed in chunk order -- the value does not depend on how many threads ran the chunks.
-double norm2_estimate(int n, const double* T, int steps = 12) {
+double norm2_estimate(int n, const double* T, int steps = 12, int threads = 0) {
     if (n == 0) return 0.0;
-    const int nchunk = n >= 384 ? 16 : 1, nt = std::min(threads_for(n, 0.5 * (double)n * n * steps), nchunk);      // (one set of threads for all steps)
+    // (one set of threads for all steps; `threads` > 0: the caller's share when other estimators run beside this one)
+    const int nchunk = n >= 384 ? 16 : 1;
+    const int nt = std::min(std::min(threads_for(n, 0.5 * (double)n * n * steps), threads > 0 ? threads : 64), nchunk);
     vec v((size_t)n, 1.0 / std::sqrt((double)n)), part((size_t)nchunk * n);
     double est = 0.0, bad = 0.0;
     bool stop = false;
@@ -574,7 +579,7 @@ void FactorChain::start(int K_, const double* G) {
 // (~50 triangular solves of 10 MB each per factor at K = 1595: 115 ms on one core).
 struct ChainLook {
     double n1 = 0.0, ninf = 0.0, enorm = 0.0, rmax = 0.0, dmax = 0.0;      // ||R||_1, ||R||_inf, sqrt(||E||_1 ||E||_inf), max |r_ij|, max 1 / |r_ii|
-    double h1 = 0.0, hinf = 0.0, inv2_3 = 0.0, inv2_14 = 0.0;
+    double h1 = 0.0, hinf = 0.0, inv2_3 = 0.0, inv2_14 = 0.0, norm2 = 0.0;      // (norm2: power iteration, a lower estimate of ||R||_2)
     bool near_identity = false;
 };
 
@@ -623,11 +628,15 @@ static std::vector<ChainLook> chain_looks(int K, const std::vector<const double*
     int nest = 0;
     for (size_t f = 0; f < R.size(); ++f) nest += L[f].near_identity ? 0 : 3;
     // the estimators run side by side, each with a team for its substitutions; the inverse iteration is the long one (28 solves
-    // against <= 11): it gets half of the threads
-    const int per_task = nest > 0 ? std::max(1, nt / nest) : 1, long_task = nest > 0 ? std::max(1, (2 * nt) / std::max(nest + 1, 4)) : 1;
+    // against <= 11): it gets the largest share.  The power iteration for ||R||_2 (only the sharper bound behind the quick look
+    // uses it) runs beside them instead of after them: 12 passes over the factor that were 12 ms of a 45 ms fit at K = 1595.
+    const int nfac = nest / 3;
+    const int long_task = nfac > 0 ? std::max(1, (3 * nt) / (8 * nfac)) : 1, power_task = nfac > 0 ? std::max(1, nt / (4 * nfac)) : 1,
+              per_task = nfac > 0 ? std::max(1, (3 * nt) / (16 * nfac)) : 1;
     for (size_t f = 0; f < R.size(); ++f) {
         if (L[f].near_identity) continue;
         tasks.emplace_back([&, f] { L[f].inv2_14 = inverse_norm2_estimate(K, R[f], 14, 3, &L[f].inv2_3, long_task); });
+        tasks.emplace_back([&, f] { L[f].norm2 = norm2_estimate(K, R[f], 12, power_task); });
         tasks.emplace_back([&, f] { L[f].h1 = inverse_norm1_estimate(K, R[f], false, per_task); });
         tasks.emplace_back([&, f] { L[f].hinf = inverse_norm1_estimate(K, R[f], true, per_task); });
     }
@@ -644,7 +653,7 @@ static double chain_bound_from(int K, const std::vector<const double*>& R, const
         // sqrt(||R||_1 ||R||_inf) is a true bound but overshoots a graded factor by one or two orders; power iteration
         // approaches ||R||_2 from below: x 1.25, and never below the largest entry
         if (l.near_identity) nrm *= std::fmin(std::sqrt(l.n1 * l.ninf), 1.0 + l.enorm);          // ||I + E||_2 <= 1 + ||E||_2
-        else nrm *= std::fmin(std::sqrt(l.n1 * l.ninf), std::fmax(1.25 * norm2_estimate(K, R[f]), l.rmax));
+        else nrm *= std::fmin(std::sqrt(l.n1 * l.ninf), std::fmax(1.25 * l.norm2, l.rmax));
         if (l.near_identity) {
             inv *= 1.0 / (1.0 - l.enorm);                      // Neumann series: the factors of the later passes
         } else {
