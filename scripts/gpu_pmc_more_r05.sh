@@ -18,7 +18,8 @@ pmc_shape () {
   timeout 300 python bench.py --rows $rows --cols $cols --steps 20 --warmup 3 --preheat 100 --no-cpu-baseline --svd-solver 0 --pipelined 0 $extra > $O/pmc_bench_${rows}x${cols}.json 2>> $O/bench.err
 }
 cd $R
-for s in "15213 31" "1000000 31" "13035 142" "1772880 168" "367900 288" "100000 168"; do set -- $s
+# PMC_SHAPES="100000x192 13035x256" overrides the list
+for s in ${PMC_SHAPES:-15213x31 1000000x31 13035x142 1772880x168 367900x288 100000x168}; do set -- ${s%x*} ${s#*x}
   pmc_shape $1 $2 ""
   python scripts/pmc_traffic.py $O/pmc_$1x$2 $O/pmc_bench_$1x$2.json --append > $O/pmc_traffic_$1x$2.json 2> $O/pmc_traffic_$1x$2.err
   tail -c 400 $O/pmc_traffic_$1x$2.json; echo
