@@ -98,6 +98,9 @@ def parse(argv=None):
     ap.add_argument("--timing-every", type=int, default=4,
                     help="HIP events bracket every N-th kernel launch of the timed region (an event record between two "
                          "dependent kernels idles the stream ~5.6 us; 1 = every launch)")
+    ap.add_argument("--transport", choices=["rccl", "p2p"], default=os.environ.get("FSNAP_DIST_TRANSPORT") or "rccl",
+                    help="exchange step of a multi-rank run: native RCCL (default) or the one-shot peer-to-peer all-reduce over hipIpc "
+                         "windows (one node; ranks may SHARE a device, which RCCL refuses -- how N > 1 runs on a one-GPU box)")
     ap.add_argument("--job-timeout", type=float, default=1800.0, help="launcher: seconds before a hung job is killed")
     ap.add_argument("--option", action="append", default=[], help="kernel option key=value (split, nontemporal, nblocks)")
     return ap.parse_args(argv)
@@ -626,7 +629,7 @@ def run_rank(args):
     ndev = _capi.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a gfx950 GPU (no CPU fallback)")
-    if local_world > ndev:
+    if local_world > ndev and args.transport != "p2p":
         raise SystemExit(f"bench.py: {local_world} ranks on this node but only {ndev} GPU(s) visible (RCCL does not put two "
                          "ranks on one device)")
     multi = world > 1 or args.force_dist
@@ -634,7 +637,7 @@ def run_rank(args):
     ctx = _capi.HipContext(local_rank % ndev)
     n_seen = 1
     if multi:
-        ctx.comm_init(world, rank, rendezvous.exchange(rank, world, _capi.comm_id))     # native RCCL, no torch
+        ctx.comm_init(world, rank, rendezvous.exchange(rank, world, lambda: _capi.comm_id(args.transport)))     # native, no torch
         rendezvous.done(rank)
         n_seen = ctx.comm_info()[0]
     for kv in args.option:
@@ -653,6 +656,8 @@ def run_rank(args):
         results[mode] = run_mode(ctx, args, mode, rank, world, multi, _capi)
     head = results[modes[0]]                               # what `value` reports
     ab_wanted = args.dist_solve_ab if args.dist_solve_ab >= 0 else (1 if world > 1 else 0)
+    if multi and ctx.comm_transport() == "p2p":
+        ab_wanted = 0                                      # reduce -> solve -> broadcast is an A/B form of the RCCL transport only
     ab = None
     if multi and ab_wanted and "strong" in results:
         ab = run_dist_solve_ab(ctx, args, results["strong"], rank, world, _capi)
@@ -748,6 +753,8 @@ def run_rank(args):
                 "launch": info,
             },
             "n_ranks_seen": n_seen,
+            "transport": ctx.comm_transport() if multi else "none",
+            "ranks_per_device": max(1, -(-local_world // ndev)),
             "per_rank": {"mode": head["mode"], "rows": head["rows_per_rank"], "kernel_ms": head["kernel_ms"],
                          "allreduce_ms": head["allreduce_ms"], "wall_s": head["elapsed_per_rank_s"]},
             "roofline": roofline,

@@ -61,6 +61,7 @@ SIGNATURES = {
     "fsnap_predict": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fsnap_residual_rhs": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double)]),
     "fsnap_solve": (c_int, [c_int, c_double, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int), POINTER(c_double)]),
+    "fsnap_cond_info": (c_int, [c_void_p]),
     "fsnap_lasso_gram": (c_int, [c_int64, c_void_p, c_void_p, c_double, c_double, c_int64, c_double, c_void_p,
                                  POINTER(c_int64), POINTER(c_double)]),
     "fsnap_normal_eq_accumulate": (c_int, [c_void_p, c_void_p]),
@@ -73,6 +74,8 @@ SIGNATURES = {
     "fsnap_solve_device_rhs": (c_int, [c_void_p, c_int, c_double, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int),
                                         POINTER(c_double)]),
     "fsnap_comm_id": (c_int, [c_void_p]),
+    "fsnap_comm_id_p2p": (c_int, [c_void_p]),
+    "fsnap_comm_transport": (c_int, [c_void_p, POINTER(c_int)]),
     "fsnap_comm_init": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "fsnap_comm_destroy": (c_int, [c_void_p]),
     "fsnap_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
@@ -209,6 +212,14 @@ def solve(kind: int, param: float, G: np.ndarray, c: np.ndarray):
     return beta, rank.value, rce.value
 
 
+def cond_info():
+    """(smallest scaled pivot, lambda_min estimate from the factor, S^-1 applications, 0 host / 1 device factor) of the
+    calling thread's last K x K solve (fsnap_cond_info)."""
+    info = np.zeros(4)
+    raise_status(load_library().fsnap_cond_info(_ptr(info)), "")
+    return float(info[0]), float(info[1]), int(info[2]), int(info[3])
+
+
 def lasso_gram(Q: np.ndarray, q: np.ndarray, y_norm2: float, l1_reg: float, max_iter: int = 2000, tol: float = 1.0e-4,
                start=None):
     """Cyclic coordinate descent for (1/2) w^T Q w - q^T w + l1_reg |w|_1 (fsnap_lasso_gram; host side, no GPU needed).
@@ -279,13 +290,30 @@ def make_dense_pinv():
     return DENSE_PINV_FN(pinv_apply)
 
 
-def comm_id() -> bytes:
-    """A fresh RCCL communicator id (rank 0 calls this and hands the 128 bytes to every rank)."""
+TRANSPORTS = ("none", "rccl", "p2p")
+
+
+def comm_id(transport: str = None) -> bytes:
+    """A fresh communicator id (rank 0 calls this and hands the 128 bytes to every rank).  ``transport``: "rccl", "p2p"
+    (the one-shot peer-to-peer all-reduce over hipIpc windows, csrc/fsnap_p2p.cpp) or None = FSNAP_DIST_TRANSPORT, else
+    RCCL.  The transport travels with the id: ``comm_init`` recognises it."""
     lib = load_library()
     buf = ctypes.create_string_buffer(COMM_ID_BYTES)
-    rc = lib.fsnap_comm_id(buf)
+    if transport not in (None, "rccl", "p2p"):
+        raise ValueError(f"unknown transport {transport!r}: 'rccl' or 'p2p'")
+    if transport is None:
+        transport = "p2p" if os.environ.get("FSNAP_DIST_TRANSPORT") == "p2p" else "rccl"
+    if transport == "p2p":
+        rc, name = lib.fsnap_comm_id_p2p(buf), "fsnap_comm_id_p2p"
+    else:
+        env = os.environ.pop("FSNAP_DIST_TRANSPORT", None)      # (fsnap_comm_id honours the variable by itself)
+        try:
+            rc, name = lib.fsnap_comm_id(buf), "fsnap_comm_id"
+        finally:
+            if env is not None:
+                os.environ["FSNAP_DIST_TRANSPORT"] = env
     if rc != OK:
-        raise FsnapError("fsnap_comm_id: " + (lib.fsnap_last_error(None) or b"").decode())
+        raise FsnapError(f"{name}: " + (lib.fsnap_last_error(None) or b"").decode())
     return buf.raw
 
 
@@ -613,6 +641,12 @@ class HipContext:
 
     def comm_destroy(self):
         self._check(self._lib.fsnap_comm_destroy(self._h))
+
+    def comm_transport(self) -> str:
+        """"none" | "rccl" | "p2p": what this context's communicator runs on."""
+        t = c_int(0)
+        self._check(self._lib.fsnap_comm_transport(self._h, byref(t)))
+        return TRANSPORTS[t.value]
 
     def comm_info(self):
         n, r = c_int(1), c_int(0)

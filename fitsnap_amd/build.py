@@ -17,9 +17,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "_lib")
 LIBNAME = "libfsnap_hip.so"
-SOURCES = ["fsnap_syrk.hip", "fsnap_syrk_quad.hip", "fsnap_rows.hip", "fsnap_chol.hip", "fsnap_trsm.hip", "fsnap_fused.hip", "fsnap_capi.cpp", "fsnap_comm.cpp",
+SOURCES = ["fsnap_syrk.hip", "fsnap_syrk_quad.hip", "fsnap_rows.hip", "fsnap_chol.hip", "fsnap_trsm.hip", "fsnap_fused.hip", "fsnap_capi.cpp", "fsnap_comm.cpp", "fsnap_p2p.cpp",
            "fsnap_rowspace.cpp", "fsnap_rowspace_host.cpp", "fsnap_solve.cpp"]
-HEADERS = ["fsnap_kernels.h", "fsnap_device_common.h", "fsnap_ctx.h", "fsnap_rowspace_host.h", os.path.join("..", "..", "include", "fsnap_hip.h")]
+HEADERS = ["fsnap_kernels.h", "fsnap_device_common.h", "fsnap_ctx.h", "fsnap_rowspace_host.h", "fsnap_condest.h", "fsnap_p2p.h", os.path.join("..", "..", "include", "fsnap_hip.h")]
 ARCH = "gfx950"
 
 
@@ -56,10 +56,18 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     objs = []
     common = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(HERE, "..", "include")]
     procs = []
+    # objects are kept between builds (fitsnap_amd/_lib/obj/, git-ignored and not shipped): a translation unit is
+    # recompiled only when it, a header or its command line changed -- the SYRK kernels alone take three minutes
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hh = hashlib.sha256()
+    for name in HEADERS:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            hh.update(f.read())
     for src in SOURCES:
-        obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         cmd = [hipcc, *common]
-        if src in ("fsnap_capi.cpp", "fsnap_comm.cpp", "fsnap_rowspace.cpp"):
+        if src in ("fsnap_capi.cpp", "fsnap_comm.cpp", "fsnap_p2p.cpp", "fsnap_rowspace.cpp"):
             cmd += ["-x", "hip"]
         if src in ("fsnap_solve.cpp", "fsnap_rowspace_host.cpp"):
             # host-only K x K solve: plain C++ (no device pass), AVX2+FMA baseline with AVX-512
@@ -67,25 +75,35 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             cmd = [hipcc, "-x", "c++", "-O3", "-std=c++17", "-fPIC", "-mavx2", "-mfma",
                    "-I", os.path.join(HERE, "..", "include")]
         cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
+        objs.append(obj)
+        with open(os.path.join(CSRC, src), "rb") as f:
+            odig = hashlib.sha256(hh.digest() + " ".join(cmd).encode() + f.read()).hexdigest()
+        ostamp = obj + ".sha256"
+        if not force and os.path.exists(obj) and os.path.exists(ostamp):
+            with open(ostamp) as f:
+                if f.read().strip() == odig:
+                    continue
+        if os.path.exists(ostamp):
+            os.remove(ostamp)
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        objs.append(obj)
-    for src, p in procs:
+        procs.append((src, ostamp, odig, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = None
+    for src, ostamp, odig, p in procs:
         log, _ = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {src}:\n{log}")
+            failed = failed or f"hipcc failed on {src}:\n{log}"
+            continue
+        with open(ostamp, "w") as f:
+            f.write(odig + "\n")
         if verbose and log.strip():
             print(log, file=sys.stderr)
+    if failed:
+        raise RuntimeError(failed)
     link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out, *objs, "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-ldl"]
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
-    for obj in objs:
-        try:
-            os.remove(obj)
-        except OSError:
-            pass
     with open(stamp, "w") as f:
         f.write(digest + "\n")
     return out

@@ -45,7 +45,12 @@ def main(argv=None):
     ap.add_argument("--relative", "-r", action="store_true")
     ap.add_argument("--comm", default="auto", choices=["auto", "none", "rccl", "torch"],
                     help="communicator of a multi-process launch (auto: native RCCL when WORLD_SIZE > 1)")
+    ap.add_argument("--transport", default=None, choices=["rccl", "p2p"],
+                    help="exchange step of the native communicator: RCCL (default) or the one-shot peer-to-peer all-reduce over "
+                         "hipIpc windows (one node; ranks may share a device).  Same as FSNAP_DIST_TRANSPORT")
     ns = ap.parse_args(argv)
+    if ns.transport:
+        os.environ["FSNAP_DIST_TRANSPORT"] = ns.transport      # rank 0 creates the id; the transport travels with it
     from .fitsnap import FitSnap
 
     arglist = [f for f, on in (("--overwrite", ns.overwrite), ("--nofit", ns.nofit), ("--verbose", ns.verbose),
@@ -59,8 +64,20 @@ def main(argv=None):
                                "with the reference's dumped Descriptors.npy / Truth-Ref.npy / Weights.npy")
         fs.pt.all_barrier()
         fs.perform_fit()
-        fs.write_output()
-        fs.pt.all_barrier()                 # nobody leaves (and tears the communicator down) while rank 0 still writes
+        # only rank 0 writes.  Nobody leaves (and tears the communicator down) while it still does -- and when it FAILS
+        # there (an existing file without --overwrite), every rank hears of it in the same collective instead of sitting in a
+        # barrier until FSNAP_COMM_TIMEOUT
+        failure = None
+        try:
+            fs.write_output()
+        except Exception as e:              # noqa: BLE001 -- re-raised below, on every rank
+            failure = e
+        if fs.pt.multi:
+            said = fs.pt.bcast_object(None if failure is None or fs.pt.get_rank() != 0 else f"{type(failure).__name__}: {failure}", src=0)
+            if failure is None and said is not None:
+                failure = RuntimeError(f"rank 0 failed while writing the output: {said}")
+        if failure is not None:
+            raise failure
     except Exception as e:
         fs.pt.exception(e)
     return 0

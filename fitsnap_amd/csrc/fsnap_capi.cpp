@@ -31,8 +31,10 @@ extern "C" int fsnap_solve_diag_upper(int kind, double param, int64_t K, const d
                                       double* beta, int* rank, double* rcond_est);
 extern "C" int fsnap_solve_diag(int kind, double param, int64_t K, const double* G, const double* c, const double* diag,
                                 double* beta, int* rank, double* rcond_est);
+extern "C" void fsnap_cond_note(double min_pivot, double lambda_min, int steps, int where);
 
 #include "fsnap_ctx.h"
+#include "fsnap_condest.h"
 
 namespace fsnap {
 std::string& library_error() {
@@ -1694,7 +1696,8 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
                 for (int p = 0; p < npanel; ++p) mp = host_out[n + p] < mp ? host_out[n + p] : mp;
                 for (int i = 0; i < n; ++i) beta[i] = host_out[i];
                 if (rank) *rank = n;
-                if (rcond_est) *rcond_est = mp;
+                if (rcond_est) *rcond_est = ctx->chol_factor_rcond;         // of the factor, as its own solve reported it
+                fsnap_cond_note(ctx->chol_factor_piv, ctx->chol_factor_lam, 0, 1);
                 return FSNAP_OK;
             }
             ctx->chol_factor_of = nullptr;          // (a non-finite right-hand side: the full path below reports it)
@@ -1731,14 +1734,75 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
             for (int i = 0; i < n; ++i) fin = fin && (h[i] - h[i] == 0.0);
             if (fin) {
                 for (int i = 0; i < n; ++i) beta[i] = h[i];
-                if (rank) *rank = n;
-                if (rcond_est) *rcond_est = mp;
-                // the factor of these statistics stays on the device for further right-hand sides
-                ctx->chol_factor_of = d_packed;
-                ctx->chol_factor_K = K;
-                ctx->chol_factor_alpha = alpha;
-                ctx->chol_factor_form = form_now;
-                return FSNAP_OK;
+                // LSTSQ stands in for an SVD of the rows, which knows the conditioning; the smallest pivot bounds lambda_min of
+                // the scaled matrix from above only.  Ask the factor (fsnap_condest.h): each Lanczos step is one forward +
+                // backward sweep with the factor that is on the device anyway (kernels 8f + 8e with a unit "scaling", so that
+                // the sweeps apply S^-1 itself), 2 ... 5 steps.  Same bits on every rank: deterministic kernels on
+                // bit-identical statistics.
+                fsnap::CondEstimate ce;
+                const bool lstsq = kind == FSNAP_SOLVE_LSTSQ || kind == FSNAP_SOLVE_LSTSQ_PROBE;
+                if (lstsq) {
+                    if (ctx->dunit_n < (size_t)np) {
+                        if (!ctx->dunit.ensure((size_t)np * 8) || !ctx->dsvec.ensure((size_t)n * 8))
+                            return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(unit vector) failed");
+                        std::vector<double> one((size_t)np, 1.0);
+                        FSNAP_HIP(hipMemcpy(ctx->dunit.p, one.data(), (size_t)np * 8, hipMemcpyHostToDevice), "hipMemcpy(unit vector)");
+                        ctx->dunit_n = (size_t)np;
+                    } else if (!ctx->dsvec.ensure((size_t)n * 8)) {
+                        return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(rhs) failed");
+                    }
+                    int apply_rc = FSNAP_OK;
+                    auto apply_inv = [&](double* v) -> bool {
+                        if (hipMemcpyAsync(ctx->dsvec.p, v, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return false;
+                        if (fsnap::launch_chol_resolve((const double*)ctx->dsvec.p, n, (double*)ctx->dchol.p, (const double*)ctx->dunit.p, d_z,
+                                                       d_beta, d_status, d_minpiv, host_out, form_now, ctx->stream) != hipSuccess)
+                            return false;
+                        const double* r;
+                        if (host_out) {
+                            if (hipEventRecord(ctx->chol_ev, ctx->stream) != hipSuccess) return false;
+                            if ((apply_rc = fsnap::wait_stream(ctx, ctx->chol_ev, "condition estimate"))) return false;
+                            r = host_out;
+                        } else {
+                            if (hipMemcpyAsync(ctx->pinned, dv, head * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
+                            if ((apply_rc = fsnap::wait_stream(ctx, nullptr, "condition estimate"))) return false;
+                            r = ctx->pinned;
+                        }
+                        int st2;
+                        memcpy(&st2, r + n + npanel, sizeof(int));
+                        if (st2 != 0) return false;
+                        for (int i = 0; i < n; ++i) v[i] = r[i];
+                        return true;
+                    };
+                    ce = fsnap::lanczos_lambda_min(n, apply_inv, 2, 5);
+                    if (apply_rc) return apply_rc;
+                }
+                const double rc_est = (ce.steps && ce.lambda_min < mp) ? ce.lambda_min : mp;
+                fsnap_cond_note(mp, ce.lambda_min, ce.steps, 1);
+                if (!ce.steps || ce.lambda_min > 64.0 * n * std::numeric_limits<double>::epsilon()) {
+                    if (rank) *rank = n;
+                    if (rcond_est) *rcond_est = rc_est;
+                    // the factor of these statistics stays on the device for further right-hand sides.  Only for the
+                    // context's OWN statistics buffer: every launch that rewrites it clears the tag, while a caller-owned
+                    // device buffer can change behind the library's back (a torch tensor accumulated between solves)
+                    if (d_packed == (const double*)ctx->packed.p) {
+                        ctx->chol_factor_of = d_packed;
+                        ctx->chol_factor_K = K;
+                        ctx->chol_factor_alpha = alpha;
+                        ctx->chol_factor_form = form_now;
+                        ctx->chol_factor_rcond = rc_est;
+                        ctx->chol_factor_piv = mp;
+                        ctx->chol_factor_lam = ce.lambda_min;
+                    }
+                    return FSNAP_OK;
+                }
+                // every pivot passed and the factor still says lambda_min is at the rounding level of the statistics: for
+                // a probe that is "unresolved" (the caller goes to the rows); the plain kinds take the general host path
+                if (kind >= FSNAP_SOLVE_LSTSQ_PROBE) {
+                    for (int i = 0; i < n; ++i) beta[i] = 0.0;
+                    if (rank) *rank = -1;
+                    if (rcond_est) *rcond_est = rc_est > 0.0 ? rc_est : 0.0;
+                    return FSNAP_OK;
+                }
             }
         }
         // A probe (FSNAP_SOLVE_*_PROBE: "come straight back when no Cholesky factorisation resolves the system") whose

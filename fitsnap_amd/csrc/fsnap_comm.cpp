@@ -23,6 +23,7 @@
 
 #include "fsnap_ctx.h"
 #include "fsnap_kernels.h"
+#include "fsnap_p2p.h"
 
 namespace fsnap {
 
@@ -83,7 +84,8 @@ static Rccl* rccl() {
 }
 
 struct Comm {
-    ncclComm_t nccl = nullptr;
+    ncclComm_t nccl = nullptr;     // transport 1: RCCL
+    P2P* p2p = nullptr;            // transport 2: one-shot all-reduce over hipIpc-mapped windows (fsnap_p2p.cpp)
     int nranks = 1, rank = 0;
 };
 
@@ -109,7 +111,16 @@ int wait_stream(fsnap_ctx* ctx, hipEvent_t ev, const char* what) {
     bool armed = false;
     for (unsigned spins = 0;; ++spins) {
         const hipError_t q = ev ? hipEventQuery(ev) : hipStreamQuery(ctx->stream);
-        if (q == hipSuccess) return FSNAP_OK;
+        if (q == hipSuccess) {
+            if (bounded && p2p_failed(ctx->comm->p2p)) {          // the bounded wait INSIDE a peer-to-peer kernel ran out
+                ctx->comm_broken = true;
+                return ctx->fail(FSNAP_E_HIP,
+                                 "rank %d of %d: a peer's statistics did not arrive within %.0f s (FSNAP_COMM_TIMEOUT / option "
+                                 "comm_timeout) in the peer-to-peer all-reduce before %s: a peer rank died or never reached it",
+                                 ctx->comm->rank, ctx->comm->nranks, comm_timeout_s(ctx), what);
+            }
+            return FSNAP_OK;
+        }
         if (q != hipErrorNotReady) return ctx->hipfail(q, ev ? "hipEventQuery" : "hipStreamQuery");
         if (bounded && (spins & 1023u) == 1023u) {
             const auto now = std::chrono::steady_clock::now();
@@ -145,8 +156,8 @@ int nccl_fail(fsnap_ctx* ctx, Rccl* r, ncclResult_t e, const char* what) {
     } while (0)
 
 int need_comm(fsnap_ctx* ctx, Rccl** r) {
-    if (!ctx->comm || !ctx->comm->nccl) return ctx->fail(FSNAP_E_STATE, "no communicator: call fsnap_comm_init first");
-    *r = fsnap::rccl();
+    if (!ctx->comm || !(ctx->comm->nccl || ctx->comm->p2p)) return ctx->fail(FSNAP_E_STATE, "no communicator: call fsnap_comm_init first");
+    *r = ctx->comm->p2p ? nullptr : fsnap::rccl();
     return FSNAP_OK;
 }
 
@@ -154,8 +165,15 @@ int need_comm(fsnap_ctx* ctx, Rccl** r) {
 
 extern "C" {
 
+int fsnap_comm_id_p2p(char* id) {
+    if (!id) return FSNAP_E_ARG;
+    return fsnap::p2p_make_id(id);
+}
+
 int fsnap_comm_id(char* id) {
     if (!id) return FSNAP_E_ARG;
+    const char* tr = getenv("FSNAP_DIST_TRANSPORT");
+    if (tr && !strcmp(tr, "p2p")) return fsnap::p2p_make_id(id);
     Rccl* r = fsnap::rccl();
     if (!r->handle) {
         fsnap::library_error() = r->why;
@@ -176,6 +194,21 @@ int fsnap_comm_init(fsnap_ctx* ctx, int nranks, int rank, const char* id) {
     if (!ctx) return FSNAP_E_ARG;
     if (!id || nranks < 1 || rank < 0 || rank >= nranks) return ctx->fail(FSNAP_E_ARG, "fsnap_comm_init: bad argument");
     if (ctx->comm) return ctx->fail(FSNAP_E_STATE, "fsnap_comm_init: this context already has a communicator");
+    if (fsnap::p2p_is_id(id)) {               // the transport travels with the id: every rank takes the same one
+        FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+        Comm* c = new (std::nothrow) Comm();
+        if (!c) return ctx->fail(FSNAP_E_NOMEM, "out of host memory");
+        const int rc = fsnap::p2p_init(ctx, nranks, rank, id, &c->p2p);
+        if (rc) {
+            delete c;
+            ctx->comm_broken = false;
+            return rc;
+        }
+        c->nranks = nranks;
+        c->rank = rank;
+        ctx->comm = c;
+        return FSNAP_OK;
+    }
     Rccl* r = fsnap::rccl();
     if (!r->handle) return ctx->fail(FSNAP_E_HIP, "%s", r->why.c_str());
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
@@ -223,8 +256,17 @@ int fsnap_comm_init(fsnap_ctx* ctx, int nranks, int rank, const char* id) {
 int fsnap_comm_destroy(fsnap_ctx* ctx) {
     if (!ctx) return FSNAP_E_ARG;
     if (!ctx->comm) return FSNAP_OK;
-    Rccl* r = fsnap::rccl();
     (void)hipSetDevice(ctx->device);
+    if (ctx->comm->p2p) {
+        // a kernel whose wait ran out has left by itself (its wait is bounded too): the stream can always be drained
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        fsnap::p2p_destroy(ctx, ctx->comm->p2p, ctx->comm_broken);
+        delete ctx->comm;
+        ctx->comm = nullptr;
+        ctx->comm_broken = false;
+        return FSNAP_OK;
+    }
+    Rccl* r = fsnap::rccl();
     if (ctx->comm_broken) {
         // a wait behind a collective ran out: the stream holds an RCCL kernel that waits for a dead peer.  Abort makes
         // that kernel leave; synchronising first would hang
@@ -236,6 +278,12 @@ int fsnap_comm_destroy(fsnap_ctx* ctx) {
     delete ctx->comm;
     ctx->comm = nullptr;
     ctx->comm_broken = false;
+    return FSNAP_OK;
+}
+
+int fsnap_comm_transport(fsnap_ctx* ctx, int* transport) {
+    if (!ctx) return FSNAP_E_ARG;
+    if (transport) *transport = !ctx->comm ? 0 : (ctx->comm->p2p ? 2 : 1);
     return FSNAP_OK;
 }
 
@@ -254,6 +302,7 @@ int fsnap_allreduce_device(fsnap_ctx* ctx, double* d_buf, int64_t n) {
     if ((rc = need_comm(ctx, &r))) return rc;
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     ctx->chol_factor_of = nullptr;              // (the buffer may be statistics a factor on the device belongs to)
+    if (ctx->comm->p2p) return fsnap::p2p_allreduce_device(ctx, ctx->comm->p2p, d_buf, n);
     FSNAP_NCCL(r->AllReduce(d_buf, d_buf, (size_t)n, ncclDouble, ncclSum, ctx->comm->nccl, ctx->stream), "ncclAllReduce");
     return FSNAP_OK;
 }
@@ -296,6 +345,7 @@ int fsnap_allreduce_host(fsnap_ctx* ctx, double* buf, int64_t n, int op) {
     int rc;
     if ((rc = need_comm(ctx, &r))) return rc;
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    if (ctx->comm->p2p) return fsnap::p2p_allreduce_host(ctx, ctx->comm->p2p, buf, n, op);      // host mailboxes: no launch, no staging
     if (!ctx->commbuf.ensure((size_t)n * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(collective staging) failed");
     const ncclRedOp_t rop = op == 0 ? ncclSum : (op == 1 ? ncclMax : ncclMin);
     FSNAP_HIP(hipMemcpyAsync(ctx->commbuf.p, buf, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(H2D)");
@@ -311,6 +361,7 @@ int fsnap_bcast_host(fsnap_ctx* ctx, void* buf, int64_t nbytes, int root) {
     if ((rc = need_comm(ctx, &r))) return rc;
     if (!buf || nbytes <= 0 || root < 0 || root >= ctx->comm->nranks) return ctx->fail(FSNAP_E_ARG, "fsnap_bcast_host: bad argument");
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    if (ctx->comm->p2p) return fsnap::p2p_bcast_host(ctx, ctx->comm->p2p, buf, (size_t)nbytes, root);
     if (!ctx->commbuf.ensure((size_t)nbytes)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(collective staging) failed");
     if (ctx->comm->rank == root)
         FSNAP_HIP(hipMemcpyAsync(ctx->commbuf.p, buf, (size_t)nbytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(H2D)");
@@ -327,6 +378,7 @@ int fsnap_allgather_host(fsnap_ctx* ctx, const void* send, int64_t nbytes, void*
     if ((rc = need_comm(ctx, &r))) return rc;
     if (!send || !recv || nbytes <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_allgather_host: bad argument");
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    if (ctx->comm->p2p) return fsnap::p2p_allgather_host(ctx, ctx->comm->p2p, send, (size_t)nbytes, recv);
     const size_t nb = (size_t)nbytes, total = nb * (size_t)ctx->comm->nranks;
     if (!ctx->commbuf.ensure(nb + total)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(collective staging) failed");
     char* d_send = (char*)ctx->commbuf.p;
@@ -344,6 +396,11 @@ int fsnap_barrier(fsnap_ctx* ctx) {
         FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
         return FSNAP_OK;
     }
+    if (ctx->comm->p2p) {
+        int rc;
+        if ((rc = fsnap::wait_stream(ctx, nullptr, "barrier"))) return rc;
+        return fsnap::p2p_barrier(ctx, ctx->comm->p2p);
+    }
     double one = 1.0;
     return fsnap_allreduce_host(ctx, &one, 1, 0);      // a 1-element all-reduce + stream synchronisation
 }
@@ -357,6 +414,9 @@ int dist_reduce_solve_bcast(fsnap_ctx* ctx, int kind, double param, int64_t K, d
     Rccl* r;
     int rc;
     if ((rc = need_comm(ctx, &r))) return rc;
+    if (ctx->comm->p2p)
+        return ctx->fail(FSNAP_E_STATE, "option dist_solve = 1 (reduce to rank 0, solve, broadcast) is an A/B form of the RCCL transport; the "
+                                        "peer-to-peer transport has the all-reduce form only");
     const int64_t n = FSNAP_PACKED_LEN(K);
     const bool root = ctx->comm->rank == 0;
     // message: [beta (K) | rank | rcond | status].  Everything that can fail on THIS rank alone is allocated before the

@@ -28,6 +28,24 @@
 #include <vector>
 
 #include "../../include/fsnap_hip.h"
+#include "fsnap_condest.h"
+
+// What the last K x K solve of this thread learned about the conditioning (fsnap_cond_info): smallest scaled pivot,
+// lambda_min estimate from the factor (0 when none was taken), applications of S^-1, 0 = host factor / 1 = device factor.
+static thread_local double g_cond_info[4] = {0.0, 0.0, 0.0, 0.0};
+
+extern "C" __attribute__((visibility("hidden"))) void fsnap_cond_note(double min_pivot, double lambda_min, int steps, int where) {
+    g_cond_info[0] = min_pivot;
+    g_cond_info[1] = lambda_min;
+    g_cond_info[2] = (double)steps;
+    g_cond_info[3] = (double)where;
+}
+
+extern "C" int fsnap_cond_info(double* info) {
+    if (!info) return FSNAP_E_ARG;
+    for (int i = 0; i < 4; ++i) info[i] = g_cond_info[i];
+    return FSNAP_OK;
+}
 
 namespace {
 
@@ -468,7 +486,7 @@ bool all_finite(const double* p, size_t n) {
 // Jacobi-scaled Cholesky solve with one refinement step.  Returns -1 ok, else failing
 // pivot.  min_piv2 = smallest relative squared pivot of the scaled matrix (a cheap
 // lower-bound style estimate of 1/cond).
-int scaled_chol_solve(const vec& M, const vec& rhs, int n, vec& x, double* min_piv2) {
+int scaled_chol_solve(const vec& M, const vec& rhs, int n, vec& x, double* min_piv2, fsnap::CondEstimate* cond = nullptr) {
     vec d(n), y(n);
     static thread_local vec S;   // scratch reused across calls (a fit loop calls this every step)
     S.resize((size_t)n * n);
@@ -486,6 +504,13 @@ int scaled_chol_solve(const vec& M, const vec& rhs, int n, vec& x, double* min_p
     L = S;
     const int fail = (n >= 768) ? chol_upper_blocked(L.data(), n, min_piv2, 64) : chol_upper(L.data(), n, min_piv2);
     if (fail >= 0) return fail;
+    if (cond) {
+        const double* Lp = L.data();
+        *cond = fsnap::lanczos_lambda_min(n, [Lp, n](double* v) {
+            chol_solve(Lp, n, v);
+            return true;
+        });
+    }
     for (int i = 0; i < n; ++i) y[i] = rhs[i] * d[i];
     vec z(y);
     chol_solve(L.data(), n, z.data());
@@ -746,7 +771,7 @@ int solve_impl(int kind, double param, int64_t K64, const double* G, const doubl
         if (Kp >= 384 && (Kp & 127) == 0) Kp += 32;
         static thread_local vec U, dsc, z;
         // the factor this thread's workspace holds: valid for one tagged content of G (see fsnap_solve_diag_tagged)
-        static thread_local struct { const void* owner; unsigned long long gen; int K; double alpha, mp2; } held = {nullptr, 0, 0, 0.0, 0.0};
+        static thread_local struct { const void* owner; unsigned long long gen; int K; double alpha, mp2, piv, lam; } held = {nullptr, 0, 0, 0.0, 0.0, 0.0, 0.0};
         if (owner && held.owner == owner && held.gen == generation && held.K == K && held.alpha == alpha &&
             U.size() == (size_t)Kp * Kp) {
             bool fin = true;
@@ -762,6 +787,7 @@ int solve_impl(int kind, double param, int64_t K64, const double* G, const doubl
                 if (all_finite(beta, K)) {
                     if (rank_out) *rank_out = K;
                     if (rcond_est) *rcond_est = held.mp2;
+                    fsnap_cond_note(held.piv, held.lam, 0, 0);
                     return FSNAP_OK;
                 }
             }
@@ -838,7 +864,24 @@ int solve_impl(int kind, double param, int64_t K64, const double* G, const doubl
             timer.lap("scale/build");
             const bool fact_ok = (chk == 0.0) && fast_chol(U.data(), Kp, &mp2) < 0;
             timer.lap("cholesky");
-            if (fact_ok && mp2 > 1.0e-3) {
+            // LSTSQ stands in for an SVD of the rows (svd.py:54), which knows the conditioning: the smallest pivot does not
+            // (it bounds lambda_min from above only), so the factor is asked -- a few S^-1 applications, fsnap_condest.h.
+            // A factor whose lambda_min is at the rounding level of the statistics is no solution: the general path decides.
+            fsnap::CondEstimate ce;
+            bool cond_ok = true;
+            if (fact_ok && mp2 > 1.0e-3 && kind == FSNAP_SOLVE_LSTSQ) {
+                const double* Up = U.data();
+                ce = fsnap::lanczos_lambda_min(Kp, [Up, Kp](double* v) {
+                    chol_solve(Up, Kp, v);
+                    return true;
+                });
+                cond_ok = ce.lambda_min > 64.0 * K * eps;
+                timer.lap("cond estimate");
+            }
+            if (fact_ok && mp2 > 1.0e-3 && cond_ok) {
+                const double piv = mp2;
+                if (ce.steps && ce.lambda_min < mp2) mp2 = ce.lambda_min;
+                fsnap_cond_note(piv, ce.lambda_min, ce.steps, 0);
                 for (int i = 0; i < K; ++i) z[i] = c[i] * dsc[i];
                 for (int i = K; i < Kp; ++i) z[i] = 0.0;
                 chol_solve(U.data(), Kp, z.data());
@@ -853,6 +896,8 @@ int solve_impl(int kind, double param, int64_t K64, const double* G, const doubl
                         held.K = K;
                         held.alpha = alpha;
                         held.mp2 = mp2;
+                        held.piv = piv;
+                        held.lam = ce.lambda_min;
                     }
                     return FSNAP_OK;
                 }
@@ -895,9 +940,13 @@ int solve_impl(int kind, double param, int64_t K64, const double* G, const doubl
 
     vec x;
     double mp2 = 0.0;
-    const int fail = scaled_chol_solve(R.M, R.rhs, n, x, &mp2);
+    fsnap::CondEstimate ce;
+    const int fail = scaled_chol_solve(R.M, R.rhs, n, x, &mp2, kind == FSNAP_SOLVE_LSTSQ ? &ce : nullptr);
+    const double piv = mp2;
+    if (fail < 0 && ce.steps && ce.lambda_min < mp2) mp2 = ce.lambda_min;     // (see the fast path)
+    fsnap_cond_note(piv, ce.lambda_min, ce.steps, 0);
     if (rcond_est) *rcond_est = mp2;
-    // a Jacobi-scaled SPD matrix with relative pivot below ~n*eps has lost all digits
+    // a Jacobi-scaled SPD matrix with relative pivot -- or smallest eigenvalue -- below ~n*eps has lost all digits
     const double piv_tol = 64.0 * n * eps;
     const bool chol_ok = (fail < 0) && (mp2 > piv_tol);
 

@@ -282,12 +282,15 @@ class _RcclTransport:
 
     kind = "rccl"
 
-    def __init__(self, exchange_id=None):
+    def __init__(self, exchange_id=None, transport=None):
         import os
 
         self.rank = int(os.environ.get("RANK", "0"))
         self.size = int(os.environ.get("WORLD_SIZE", "1"))
         self._exchange_id = exchange_id
+        # None = FSNAP_DIST_TRANSPORT, else RCCL; "p2p" = the one-shot all-reduce over hipIpc windows (csrc/fsnap_p2p.cpp:
+        # one node, also N ranks on ONE GPU).  Only rank 0's choice matters: the transport travels with the id
+        self._wire = transport
         self._joined = False
         self.on_gpu = True
 
@@ -299,10 +302,11 @@ class _RcclTransport:
             return
         from . import _capi, rendezvous
 
+        make_id = lambda: _capi.comm_id(self._wire)        # noqa: E731
         if self._exchange_id is not None:
-            ident = self._exchange_id(_capi.comm_id() if self.rank == 0 else None)
+            ident = self._exchange_id(make_id() if self.rank == 0 else None)
         else:
-            ident = rendezvous.exchange(self.rank, self.size, _capi.comm_id)
+            ident = rendezvous.exchange(self.rank, self.size, make_id)
         ctx.comm_init(self.size, self.rank, ident)
         if self._exchange_id is None:
             rendezvous.done(self.rank)
@@ -344,7 +348,7 @@ class _RcclTransport:
 class ParallelTools:
     """See module docstring.  Attribute names follow fitsnap3lib/parallel_tools.py:157-200."""
 
-    def __init__(self, comm=None, exchange_id=None):
+    def __init__(self, comm=None, exchange_id=None, transport=None):
         self.check_fitsnap_exist = True
         self.create_shared_bool = True
         self.double_size = 8
@@ -366,7 +370,7 @@ class ParallelTools:
             self._size = 1
         else:
             if isinstance(comm, str) and comm.lower() == "rccl":
-                self._transport = _RcclTransport(exchange_id)
+                self._transport = _RcclTransport(exchange_id, transport)
             else:
                 self._transport = _TorchTransport(None if comm in (True, "torch") else comm)
             self.stubs = 0

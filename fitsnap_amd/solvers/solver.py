@@ -89,15 +89,21 @@ def _content_stamp(labels):
 _EPS = float(np.finfo(np.float64).eps)
 
 
+RCOND_MARGIN = 10.0
+"""``rcond`` below = ``fsnap_solve``'s ``rcond_est`` for the LSTSQ kinds: min(smallest pivot of the Jacobi-scaled Cholesky,
+lambda_min of the scaled matrix S estimated FROM THE FACTOR by a few Lanczos steps on S^-1 -- csrc/fsnap_condest.h).  Both
+are estimates from ABOVE; the Lanczos one is within ~1.3 x of lambda_min wherever the statistics resolve it, the pivot alone
+can be off by a factor exponential in K (A = Z (I - triu(1, 1)), K = 26: pivot 0.04, lambda_min 1e-16 -- round 5 decided
+from the pivot and returned answers 1e-6 ... 1 from lstsq on that family).  Every rule divides by this margin first."""
+
+
 def refinement_skip(K, rcond):
     """No refinement step at all: the normal-equation solve is already far inside the parity bar.
 
-    ``rcond`` = smallest pivot of the Jacobi-scaled Cholesky of G = A_w^T A_w (``fsnap_solve``'s ``rcond_est``): an
-    estimate of 1 / kappa(G) = 1 / kappa(A_w)^2 from above (a pivot never undershoots lambda_min of the scaled matrix;
-    the factor K is the margin for how far it can overshoot).  The solve from the statistics is accurate to
-    ~kappa^2 eps; below 1e-10 -- four decades inside the 1e-6 bar of the reference's own checker
+    S has a unit diagonal, so lambda_max <= K and kappa(S) <= K / lambda_min; the solve from the statistics is accurate to
+    ~kappa(S) eps.  Below 1e-10 -- four decades inside the 1e-6 bar of the reference's own checker
     (tests/example_checker.py:54-62) -- a pass over the rows buys nothing a caller can see."""
-    return rcond is not None and rcond > 0.0 and K * _EPS / rcond < 1.0e-10
+    return rcond is not None and rcond > 0.0 and K * _EPS * RCOND_MARGIN / rcond < 1.0e-10
 
 
 def refinement_done(K, step, prev_step, beta_max, rcond):
@@ -105,7 +111,7 @@ def refinement_done(K, step, prev_step, beta_max, rcond):
     stop when what is LEFT is below the accuracy the reference's lstsq itself has, ~kappa(A_w) eps = eps / sqrt(rcond).
 
     Refinement with the row residual contracts the error by rho ~ kappa^2 eps per step; rho is taken as the larger of
-    the prediction K eps / rcond and the contraction just observed (step / prev_step), so what is left after this step is
+    the prediction K eps / lambda_min and the contraction just observed (step / prev_step), so what is left after this step is
     ~ rho / (1 - rho) * step.  On the benchmark problem (kappa ~ 1e4: kappa^2 eps ~ 2e-8) the first correction is ~1e-8 |beta|
     and the second would be ~1e-16 |beta|: one pass over the rows instead of two.  A slowly converging system (rho >= 1/2)
     never stops early; the absolute floor 1e-14 |beta| is the old rule."""
@@ -113,7 +119,8 @@ def refinement_done(K, step, prev_step, beta_max, rcond):
         return True
     if rcond is None or not rcond > 0.0 or not prev_step > 0.0:
         return False
-    rho = max(K * _EPS / rcond, step / prev_step)
+    lam = rcond / RCOND_MARGIN
+    rho = max(K * _EPS / lam, step / prev_step)
     if rho >= 0.5:
         return False
     return rho / (1.0 - rho) * step <= max(4.0 * _EPS / np.sqrt(rcond), 1.0e-14) * beta_max
@@ -544,23 +551,25 @@ class Solver:
             prev = step
         return beta
 
-    ROWSPACE_RCOND = 1.0e-11    # smallest pivot of the Jacobi-scaled Cholesky below which the statistics are not trusted
+    ROWSPACE_RCOND = 1.0e-11    # lambda_min of the Jacobi-scaled statistics (estimate / RCOND_MARGIN) below which they are not trusted
 
     def _needs_row_space(self, K):
-        """After a LSTSQ solve from the statistics: did the K x K system resolve the problem?  No when the scaled
-        Cholesky met a pivot below ``ROWSPACE_RCOND`` (kappa of the equilibrated A_w beyond ~3e5: the refinement with
-        the normal matrix stops converging around 1e7) or when the solve dropped directions that are not simply
-        exactly-zero columns.  Same answer on every rank (the inputs are the all-reduced statistics)."""
+        """After a LSTSQ solve from the statistics: did the K x K system resolve the problem?  No when lambda_min of the
+        scaled matrix -- ``last_rcond`` / ``RCOND_MARGIN``, see there -- is below ``ROWSPACE_RCOND`` (kappa of the
+        equilibrated A_w beyond ~3e5: the refinement with the normal matrix stops converging around 1e7) or when the
+        solve dropped directions that are not simply exactly-zero columns.  Same answer on every rank (the inputs are
+        the all-reduced statistics)."""
         rank, rcond = self.last_rank, getattr(self, "last_rcond", None)
         if rank is None or rcond is None:
             return False
         if rank < 0:            # a probe that came back unresolved: no need to look at the statistics
             return True
+        ill = rcond / RCOND_MARGIN < self.ROWSPACE_RCOND
         if rank < K:
             G = self.last_statistics[0]
             zero_cols = int(np.count_nonzero(np.diag(G) == 0.0))
-            return rank < K - zero_cols or rcond < self.ROWSPACE_RCOND
-        return rcond < self.ROWSPACE_RCOND
+            return rank < K - zero_cols or ill
+        return ill
 
     def _row_space_fit(self, K, rcond):
         """``lstsq(aw, bw, rcond)`` on the rows (``fsnap_lstsq_rows``): CholeskyQR passes on the GPU, dgelsd's K x K end

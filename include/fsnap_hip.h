@@ -42,7 +42,7 @@ typedef struct fsnap_ctx fsnap_ctx;
 #define FSNAP_SOLVE_RIDGE 2      /* (G + alpha I) beta = c, param = alpha (ridge.py:47-57, sklearn Ridge) */
 #define FSNAP_SOLVE_RIDGE_INV 3  /* beta = inv(G + alpha I) c             (regressor.py:10-16 Local_Ridge) */
 /* LSTSQ / RIDGE / RIDGE_INV without the fallback behind the Cholesky factorisations: when no Cholesky factorisation resolves the system the call returns
- * FSNAP_OK at once with *rank = -1 and beta = 0 (and *rcond_est = the smallest scaled pivot met) instead of running the
+ * FSNAP_OK at once with *rank = -1 and beta = 0 (and *rcond_est as described at fsnap_solve) instead of running the
  * cyclic-Jacobi eigendecomposition -- O(K^3) per sweep on one core: 58 s at K = 1595.  For callers that have something
  * better to fall back on: the rows (fsnap_lstsq_rows) or a LAPACK eigensolver. */
 #define FSNAP_SOLVE_LSTSQ_PROBE 4
@@ -283,12 +283,24 @@ int fsnap_residual_rhs(fsnap_ctx* ctx, const double* beta, double* s, double* ss
 
 /* Solve the K x K system given the statistics.  `kind` is one of FSNAP_SOLVE_*;
  * `param` is rcond (LSTSQ) or alpha (RIDGE, RIDGE_INV), ignored for CHOL.
- * beta[K] out; *rank (may be NULL) receives the numerical rank used; *rcond_est (may be
- * NULL) an estimate of 1/cond of the (Jacobi-scaled) matrix that was factorised.
+ * beta[K] out; *rank (may be NULL) receives the numerical rank used; *rcond_est (may be NULL) what the factorisation
+ * knows about the conditioning of the Jacobi-scaled matrix S (unit diagonal, so 1 <= lambda_max <= K): for the LSTSQ
+ * kinds -- which stand in for an SVD of the rows, svd.py:54 -- min(smallest pivot, lambda_min(S) estimated from the factor
+ * by 2 ... 8 Lanczos steps on S^-1, i.e. pairs of triangular sweeps: dpocon's idea, csrc/fsnap_condest.h), an estimate
+ * from ABOVE that is within a factor ~1.3 of lambda_min wherever the statistics still resolve it (lambda_min > ~K eps);
+ * a factor whose estimate falls below 64 K eps counts as unresolved exactly like a failed pivot.  For the other kinds
+ * (sklearn's Cholesky, np.linalg.inv: neither looks at the conditioning) the smallest pivot alone, an upper bound of
+ * lambda_min that can be off by a factor exponential in K.
  * Replaces scipy.linalg.lstsq (svd.py:54), sklearn Ridge's Cholesky solve
  * (ridge.py:47-57) and np.linalg.inv (regressor.py:15). */
 int fsnap_solve(int kind, double param, int64_t K, const double* G, const double* c, double* beta, int* rank,
                 double* rcond_est);
+
+/* What the LAST K x K solve of the calling thread (fsnap_solve, fsnap_solve_device*, fsnap_fit_resident, fsnap_fit_dist) learned
+ * about the conditioning: info[0] = smallest scaled pivot, info[1] = lambda_min estimate from the factor (0 = none taken or
+ * numerically singular), info[2] = applications of S^-1 it took (0 = none: not an LSTSQ kind, or a reused factor),
+ * info[3] = 0 host factor / 1 device factor.  Diagnostic: *rcond_est already carries min(info[0], info[1]). */
+int fsnap_cond_info(double info[4]);
 
 /* LASSO by cyclic coordinate descent on the statistics: minimises (1/2) w^T Q w - q^T w + l1_reg |w|_1 with Q = A_w^T A_w,
  * q = A_w^T b_w, i.e. scikit-learn's Lasso(alpha, fit_intercept=False, max_iter).fit(aw, bw) of the reference
@@ -315,7 +327,11 @@ int fsnap_fit_resident(fsnap_ctx* ctx, int kind, double param, double* beta, int
 
 /* Same as fsnap_solve_device with the right-hand side replaced by rhs (HOST, K doubles; NULL = the c part of the
  * packed buffer): G delta = s of an iterative-refinement step (solver.py has no counterpart: the reference's
- * lstsq works on the rows, see fsnap_residual_rhs) without bringing G to the host. */
+ * lstsq works on the rows, see fsnap_residual_rhs) without bringing G to the host.
+ * Factor reuse (K >= 232, option chol_reuse): when d_packed is the context's OWN statistics buffer (the address
+ * fsnap_fit_resident / fsnap_normal_eq_resident / fsnap_fit_dist handed out) and the last solve of it left its factor on the
+ * device, a call with rhs runs two sweeps instead of a factorisation; every library call that rewrites that buffer
+ * forgets the factor.  A caller-owned device buffer is factorised on every call -- the library cannot see writes to it. */
 int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, const double* d_packed, const double* rhs,
                            double* beta, int* rank, double* rcond_est);
 
@@ -379,7 +395,7 @@ int fsnap_rowspace_chain(int64_t K, int64_t nfac, const double* R, const unsigne
  * w_rmse = sqrt(sum (w r)^2 / n_w), ...).  Predictions (GEMV) and both reduction passes run on the GPU. */
 int fsnap_error_stats(fsnap_ctx* ctx, const double* beta, const int32_t* cat, int ncat, double* stats);
 
-/* ---- multi-GPU: one process per GPU, native RCCL over xGMI ------------------------ */
+/* ---- multi-GPU: one process per GPU; RCCL or one-shot peer-to-peer over xGMI -------- */
 
 /* The reference's data-parallel form of this path (examples/library/transpose_trick/example.py:230-254): every MPI
  * rank accumulates c += aw.T aw, d += aw.T bw over ITS configurations, then comm.Allreduce(c), comm.Allreduce(d)
@@ -398,12 +414,29 @@ int fsnap_error_stats(fsnap_ctx* ctx, const double* beta, const int32_t* cat, in
  * rank returns FSNAP_NUM_NONFINITE from the same call and the failing rank returns its own error. */
 
 /* Rank 0: create the communicator id (ncclGetUniqueId).  The caller distributes the 128 bytes to every rank by
- * whatever it has -- mpi4py comm.bcast on the reference side, a file or a socket in fitsnap_amd/rendezvous.py. */
+ * whatever it has -- mpi4py comm.bcast on the reference side, a file or a socket in fitsnap_amd/rendezvous.py.
+ * With FSNAP_DIST_TRANSPORT=p2p in the environment the id is one of the peer-to-peer transport (next entry). */
 int fsnap_comm_id(char* id);
 
-/* Collective: join the communicator of `nranks` ranks as `rank` (ncclCommInitRank on the context's device). */
+/* Rank 0: the id of a PEER-TO-PEER communicator (csrc/fsnap_p2p.cpp) -- the second transport, for the GPUs of ONE node.
+ * The transport travels with the id: fsnap_comm_init recognises it, so every rank takes the same one.  Every rank
+ * exports a double-buffered window of device memory through a hipIpc handle (exchanged, like the joins, through a POSIX
+ * shared-memory segment named after the id); the all-reduce of a fit is then ONE launch per rank: own statistics ->
+ * own window, a flag pushed into every peer's window, a bounded wait for the peers' flags, the sum of the N windows in
+ * RANK ORDER (bit-identical on every rank).  The host-buffer collectives below go through mailboxes in the same
+ * segment (no launch, no staging).  hipIpc handles open between processes that share a device, so this transport also
+ * runs N ranks on ONE GPU -- what RCCL refuses -- which is how the N > 1 paths are tested on one-GPU boxes.
+ * FSNAP_P2P_SLOT_MB (default 24; larger payloads travel in pieces) / FSNAP_P2P_MAILBOX_MB (default 4) size the window
+ * slots and the mailboxes; needs HSA_ENABLE_IPC_MODE_LEGACY=0 where the host driver only supports dmabuf IPC. */
+int fsnap_comm_id_p2p(char* id);
+
+/* Collective: join the communicator of `nranks` ranks as `rank` (ncclCommInitRank on the context's device, or the
+ * peer-to-peer rendezvous when `id` comes from fsnap_comm_id_p2p). */
 int fsnap_comm_init(fsnap_ctx* ctx, int nranks, int rank, const char* id);
 int fsnap_comm_destroy(fsnap_ctx* ctx);
+
+/* *transport = 0 (no communicator), 1 (RCCL), 2 (peer-to-peer). */
+int fsnap_comm_transport(fsnap_ctx* ctx, int* transport);
 
 /* *nranks / *rank of the context's communicator (1 / 0 without one); either pointer may be NULL. */
 int fsnap_comm_info(fsnap_ctx* ctx, int* nranks, int* rank);

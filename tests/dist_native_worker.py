@@ -1,4 +1,4 @@
-"""Worker of the two-process native-RCCL test (tests/test_gpu_native_comm.py): one process per GPU, launched with
+"""Worker of the two-process native test (tests/test_gpu_native_comm.py; RCCL: one process per GPU, peer-to-peer: the ranks may share one), launched with
 RANK / WORLD_SIZE / LOCAL_RANK / FSNAP_COMM_FILE in the environment; no torch.  Every rank owns the "configurations"
 (blocks of 43 rows) i with i % world == rank of the golden Ta set (the reference's row partition,
 fitsnap3lib/parallel_tools.py:612-651), fits with SVD and RIDGE, runs the error analysis and an ill-conditioned
@@ -79,9 +79,23 @@ def main(outdir):
     ctx.upload_rows(A4[sel], b4[sel])
     ctx.set_weights(w4[sel])
     out["k480_beta"] = ctx.fit_dist(_capi.SOLVE_RIDGE, 1e-8, 480)[0]
-    ctx.set_option("dist_solve", 1)
-    out["k480_beta_root"] = ctx.fit_dist(_capi.SOLVE_RIDGE, 1e-8, 480)[0]
-    ctx.set_option("dist_solve", 0)
+    out["transport"] = np.array(ctx.comm_transport())
+    if ctx.comm_transport() == "rccl":           # (reduce -> solve on rank 0 -> broadcast is an A/B form of the RCCL transport)
+        ctx.set_option("dist_solve", 1)
+        out["k480_beta_root"] = ctx.fit_dist(_capi.SOLVE_RIDGE, 1e-8, 480)[0]
+        ctx.set_option("dist_solve", 0)
+    # K = 1595 (the quadratic SNAP width): triangle payload (10 MB) through the collective, device Cholesky, and the
+    # default solver's refinement with the factor kept on every rank
+    r = np.random.default_rng(1595)
+    A5, b5 = r.standard_normal((4000, 1595)), r.standard_normal(4000)
+    sel = (np.arange(4000) // 100 % world) == rank
+    cfg = Config(pt, {"SOLVER": {"solver": "SVD"}})
+    s = solver_factory.solver("SVD", pt, cfg)
+    s.perform_fit(A5[sel], b5[sel], np.ones(int(sel.sum())), trainall=True)
+    if rank == 0:
+        out["k1595_fit"] = s.fit.copy()
+    out["k1595_rcond"] = np.array(s.last_rcond)
+    out["k1595_steps"] = np.array(s.last_refine_steps)
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
     pt.all_barrier()
     pt.free()

@@ -82,13 +82,15 @@ def test_python_m_fitsnap3_in_a_one_rank_rccl_job_runs_the_collective_path(tmp_p
     _check_outputs(tmp_path, ta_fits)
 
 
-@pytest.mark.skipif(__import__("fitsnap_amd._capi", fromlist=["x"]).device_count() < 2,
-                    reason="needs two GPUs: RCCL does not put two ranks on one device")
-def test_python_m_fitsnap3_on_two_gpus_shards_by_configuration(tmp_path, ta, ta_fits):
+@pytest.mark.parametrize("transport", ["rccl", "p2p"])
+def test_python_m_fitsnap3_with_two_ranks_shards_by_configuration(tmp_path, ta, ta_fits, transport):
+    # RCCL: one GPU per rank.  Peer-to-peer transport: both ranks may share the one GPU of the box
     from test_cli_dist_cpu import write_dump
 
+    if transport == "rccl" and __import__("fitsnap_amd._capi", fromlist=["x"]).device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL does not put two ranks on one device")
     write_dump(tmp_path, ta)
-    procs = [_run_cli(tmp_path, 2, r, {}) for r in range(2)]
+    procs = [_run_cli(tmp_path, 2, r, {}, ("--transport", transport)) for r in range(2)]
     logs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-4000:]
     _check_outputs(tmp_path, ta_fits)

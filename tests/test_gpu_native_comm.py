@@ -273,8 +273,13 @@ def test_bench_launcher_refuses_more_ranks_than_devices():
     assert f"only {n - 1} GPU(s) visible" in out.stderr and f"bench.py: {n}-GPU job failed" in out.stderr
 
 
-@pytest.mark.skipif(_capi.device_count() < 2, reason="needs two GPUs: RCCL does not put two ranks on one device")
-def test_two_process_native_fit_matches_the_reference(tmp_path, ta, ta_fits):
+@pytest.mark.parametrize("transport", ["rccl", "p2p"])
+def test_two_process_native_fit_matches_the_reference(tmp_path, ta, ta_fits, transport):
+    # RCCL needs a device per rank; the peer-to-peer transport (csrc/fsnap_p2p.cpp) also runs both ranks on ONE GPU, which
+    # is what a one-GPU box executes: rows by configuration i % 2, fits against the reference goldens, the triangle
+    # payload at K >= 256, a rank with zero rows, pooled error tables, the row-space solve
+    if transport == "rccl" and _capi.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL does not put two ranks on one device")
     A, b, w = ta
     world = 2
     procs = []
@@ -282,7 +287,7 @@ def test_two_process_native_fit_matches_the_reference(tmp_path, ta, ta_fits):
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world),
                    FSNAP_COMM_FILE=str(tmp_path / "comm_id"), FSNAP_COMM_TOKEN="two-process test", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0", FSNAP_COMM_TIMEOUT="120")
+                   MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0", FSNAP_COMM_TIMEOUT="120", FSNAP_DIST_TRANSPORT=transport)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_native_worker.py"), str(tmp_path)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = [p.communicate(timeout=600)[0] for p in procs]
@@ -315,9 +320,16 @@ def test_two_process_native_fit_matches_the_reference(tmp_path, ta, ta_fits):
     A4, b4, w4 = r.standard_normal((6000, 480)), r.standard_normal(6000), r.uniform(0.5, 2.0, 6000)
     ref4 = orc.ridge_fit(A4, b4, w4, 1e-8)
     for rr in (r0, r1):
+        assert str(rr["transport"]) == transport
         assert maxrel(rr["k480_beta"], ref4) < 1e-6
-        assert np.array_equal(rr["k480_beta_root"], r0["k480_beta_root"]) and maxrel(rr["k480_beta_root"], ref4) < 1e-6
+        if transport == "rccl":
+            assert np.array_equal(rr["k480_beta_root"], r0["k480_beta_root"]) and maxrel(rr["k480_beta_root"], ref4) < 1e-6
     assert np.array_equal(r0["k480_beta"], r1["k480_beta"])                    # deterministic solve of identical sums
+    # K = 1595 through the default solver: the ranks agree on the condition estimate (bit for bit) and hence on the steps
+    r = np.random.default_rng(1595)
+    A5, b5 = r.standard_normal((4000, 1595)), r.standard_normal(4000)
+    assert maxrel(r0["k1595_fit"], orc.svd_fit(A5, b5, np.ones(4000))) < 1e-6
+    assert r0["k1595_rcond"] == r1["k1595_rcond"] and r0["k1595_steps"] == r1["k1595_steps"]
 
 
 def test_process_exits_cleanly_when_rccl_is_loaded_before_torch():

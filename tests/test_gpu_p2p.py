@@ -1,0 +1,74 @@
+"""GPU (-m gpu): the peer-to-peer transport of the exchange step (csrc/fsnap_p2p.cpp) -- the reference's
+comm.Allreduce(c), comm.Allreduce(d) (examples/library/transpose_trick/example.py:245-246) and the small collectives of
+fitsnap3lib/parallel_tools.py:245-249, 426-441, 562-592 -- with SEVERAL ranks on the one GPU of the test box (hipIpc handles
+open between processes that share a device).  The fits through this transport are in tests/test_gpu_native_comm.py and
+tests/test_gpu_cli.py; here: the collectives themselves, bit for bit, and the bounded waits."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from p2p_worker import rank_data
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _launch(tmp_path, world, scenario, **extra):
+    procs = []
+    for rank in range(world):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+        env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", FSNAP_COMM_FILE=str(tmp_path / "comm_id"),
+                   FSNAP_COMM_TOKEN=f"p2p {scenario}", HSA_ENABLE_IPC_MODE_LEGACY="0", FSNAP_COMM_TIMEOUT="60")
+        env.update(extra)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py"), str(tmp_path), scenario],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=300)[0])
+        except subprocess.TimeoutExpired:
+            p.kill()
+            logs.append(p.communicate()[0] + "\n[killed after 300 s]")
+    return procs, logs
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_collectives_between_ranks_that_share_one_gpu(tmp_path, world):
+    procs, logs = _launch(tmp_path, world, "collectives", FSNAP_P2P_SLOT_MB="1", FSNAP_P2P_MAILBOX_MB="1")
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-4000:]
+    res = [dict(np.load(tmp_path / f"rank{r}.npz")) for r in range(world)]
+    for n in (1, 2, 3, 16515, 131072, 300001):
+        # three in-place all-reduces back to back: x -> N x -> N^2 x -> N^3 x, each the sum in RANK ORDER
+        want = rank_data(0, n)
+        for q in range(1, world):
+            want = want + rank_data(q, n)
+        for _ in range(2):
+            acc = want.copy()
+            for q in range(1, world):
+                acc = acc + want
+            want = acc
+        for r in range(world):
+            assert np.array_equal(res[r][f"dev_{n}"], want), (n, r)              # bit-exact: fixed association order
+    ranks = np.arange(world)
+    for r in range(world):
+        assert np.array_equal(res[r]["host_sum"], [np.sum(ranks + 1.0), -np.sum(ranks), 0.5 * world])
+        assert np.array_equal(res[r]["host_max"], [world, 0.0, 0.5]) and np.array_equal(res[r]["host_min"], [1.0, -(world - 1.0), 0.5])
+        big = rank_data(0, 700001)
+        for q in range(1, world):
+            big = big + rank_data(q, 700001)
+        assert np.array_equal(res[r]["host_big"], big)
+        assert bytes(res[r]["gather"]) == b"".join(bytes([q]) * 5 + b"tail" for q in range(world))
+        assert res[r]["gather_big_ok"].all()
+        assert bytes(res[r]["bcast"]) == b"from the last rank"
+
+
+def test_a_dead_peer_ends_the_wait_instead_of_hanging(tmp_path):
+    procs, logs = _launch(tmp_path, 2, "dead_peer", FSNAP_COMM_TIMEOUT="4")
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-4000:]
+    r0 = dict(np.load(tmp_path / "rank0.npz"))
+    assert "did not" in str(r0["error"]) and "rank 0 of 2" in str(r0["error"]), str(r0["error"])
+    assert 3.0 < float(r0["seconds"]) < 30.0
