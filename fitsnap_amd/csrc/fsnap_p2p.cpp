@@ -17,11 +17,11 @@
 // that share ONE device, so the N > 1 code paths run on a one-GPU box (RCCL refuses two ranks on one device).
 //
 // Protocol of all-reduce number g (slot s = g & 1 of a double-buffered window):
-//   1. every workgroup copies its share of the rank's buffer into window slot s, fences at system scope, takes a ticket;
-//      the LAST workgroup stores g into flag[s][me] of EVERY rank's window (a push: polling then stays in local memory);
-//   2. one lane per peer polls flag[s][p] >= g in its own window (bounded: s_sleep + wall clock, a status word in
-//      page-locked memory and NaN results instead of a hang);
-//   3. buffer[i] = slot_0[i] + slot_1[i] + ... + slot_{N-1}[i].
+//   1. workgroup b copies piece b of the rank's buffer into window slot s, fences at system scope and stores g into
+//      flag[s][b][me] of EVERY rank's window (a push: polling then stays in local memory);
+//   2. one lane per peer polls flag[s][b][p] >= g in its own window (bounded: s_sleep + wall clock, a status word in
+//      page-locked memory and NaN results instead of a hang) -- piece b depends on piece b of the peers only;
+//   3. buffer[i] = slot_0[i] + slot_1[i] + ... + slot_{N-1}[i] over piece b.
 // Slot s is written again at g + 2: by then this rank has passed step 2 of g + 1, i.e. every peer has published g + 1,
 // which it does only after its kernel of g (stream order) has finished reading.  No further handshake.
 //
@@ -52,7 +52,8 @@ namespace {
 
 constexpr int P2P_MAX_RANKS = 16;
 constexpr char P2P_MAGIC[8] = {'F', 'S', 'N', 'P', '2', 'P', '0', '1'};
-constexpr size_t P2P_FLAG_BYTES = 4096;       // head of a window: flag[2][P2P_MAX_RANKS] (uint64), padded to a page
+constexpr int P2P_MAX_BLOCKS = 128;
+constexpr size_t P2P_FLAG_BYTES = 2 * (size_t)P2P_MAX_BLOCKS * P2P_MAX_RANKS * 8;       // head of a window: flag[2][workgroup][rank] (uint64)
 
 // ---- shared-memory segment ------------------------------------------------------------------------------------------
 struct ShmRank {
@@ -101,50 +102,43 @@ struct P2P {
     char* peer[P2P_MAX_RANKS] = {};
     bool peer_ipc[P2P_MAX_RANKS] = {};
     uint64_t gen = 0;
-    unsigned* d_ticket = nullptr;
     int* h_status = nullptr;          // page-locked, device-visible: set by a kernel whose wait ran out
 };
 
 // ---- the kernel -----------------------------------------------------------------------------------------------------
 struct P2PArgs {
     double* slot[P2P_MAX_RANKS];              // slot s of every rank's window, in THIS process's address space
-    unsigned long long* flags[P2P_MAX_RANKS]; // flag[s][0 .. P2P_MAX_RANKS) of every rank's window
+    unsigned long long* flags[P2P_MAX_RANKS]; // flag[s][workgroup][rank] of every rank's window
     int nranks, me;
 };
 
-__global__ __launch_bounds__(256) void fsnap_p2p_allreduce_k(double* __restrict__ buf, long long n, P2PArgs a, unsigned long long gen,
-                                                             unsigned* __restrict__ ticket, int* __restrict__ status,
+// Workgroup b of EVERY rank owns the same contiguous piece b of the payload (same n, same grid everywhere), so the only
+// dependency is "piece b of rank p is in p's window": one flag per (workgroup, rank), no grid-wide ticket -- with one the
+// last of 128 workgroups to draw published for all, and the serialised draws cost ~40 us of a 54 us all-reduce at K = 480.
+__global__ __launch_bounds__(256) void fsnap_p2p_allreduce_k(double* __restrict__ buf, long long n, long long piece, P2PArgs a,
+                                                             unsigned long long gen, int* __restrict__ status,
                                                              unsigned long long timeout_ticks) {
-    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nthr = (long long)gridDim.x * blockDim.x;
-    const long long n2 = n >> 1;
+    const long long lo = (long long)blockIdx.x * piece, hi = lo + piece < n ? lo + piece : n;     // piece is even: lo is 16-byte aligned
+    const long long cnt = hi - lo, cnt2 = cnt >> 1;
     // 1. own statistics -> own window (16-byte accesses; an odd last element by thread 0)
     {
-        const double2* __restrict__ src = reinterpret_cast<const double2*>(buf);
-        double2* __restrict__ dst = reinterpret_cast<double2*>(a.slot[a.me]);
-        for (long long i = tid; i < n2; i += nthr) dst[i] = src[i];
-        if (tid == 0 && (n & 1)) a.slot[a.me][n - 1] = buf[n - 1];
+        const double2* __restrict__ src = reinterpret_cast<const double2*>(buf + lo);
+        double2* __restrict__ dst = reinterpret_cast<double2*>(a.slot[a.me] + lo);
+        for (long long i = threadIdx.x; i < cnt2; i += 256) dst[i] = src[i];
+        if (threadIdx.x == 0 && (cnt & 1)) a.slot[a.me][hi - 1] = buf[hi - 1];
     }
+    __shared__ int s_bad;
+    if (threadIdx.x == 0) s_bad = 0;
     __threadfence_system();
     __syncthreads();
-    __shared__ int s_last, s_bad;
-    if (threadIdx.x == 0) {
-        s_bad = 0;
-        const unsigned t = atomicAdd(ticket, 1u);
-        s_last = (t == gridDim.x - 1);
-        if (s_last) *ticket = 0;              // every workgroup of this launch has drawn: ready for the next launch
-    }
-    __syncthreads();
-    if (s_last && (int)threadIdx.x < a.nranks) {
-        __threadfence_system();
-        __hip_atomic_store(a.flags[threadIdx.x] + a.me, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    // 2. wait for every rank's flag in the LOCAL window
+    // 2. publish piece b in every rank's window, then wait for every rank's piece b in the LOCAL window
     if ((int)threadIdx.x < a.nranks) {
-        const unsigned long long* f = a.flags[a.me] + threadIdx.x;
+        __hip_atomic_store(a.flags[threadIdx.x] + (size_t)blockIdx.x * P2P_MAX_RANKS + a.me, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long* f = a.flags[a.me] + (size_t)blockIdx.x * P2P_MAX_RANKS + threadIdx.x;
         const unsigned long long t0 = wall_clock64();
         unsigned spins = 0;
         while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < gen) {
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
             if ((++spins & 255u) == 0 && wall_clock64() - t0 > timeout_ticks) {
                 s_bad = 1;
                 break;
@@ -156,25 +150,25 @@ __global__ __launch_bounds__(256) void fsnap_p2p_allreduce_k(double* __restrict_
     if (s_bad) {
         if (threadIdx.x == 0) *status = 1;
         const double nan = __builtin_nan("");
-        for (long long i = tid; i < n; i += nthr) buf[i] = nan;
+        for (long long i = lo + threadIdx.x; i < hi; i += 256) buf[i] = nan;
         return;
     }
     // 3. sum in rank order (the same order on every rank: bit-identical results)
     {
-        double2* __restrict__ dst = reinterpret_cast<double2*>(buf);
-        for (long long i = tid; i < n2; i += nthr) {
-            double2 acc = reinterpret_cast<const double2*>(a.slot[0])[i];
+        double2* __restrict__ dst = reinterpret_cast<double2*>(buf + lo);
+        for (long long i = threadIdx.x; i < cnt2; i += 256) {
+            double2 acc = reinterpret_cast<const double2*>(a.slot[0] + lo)[i];
             for (int p = 1; p < a.nranks; ++p) {
-                const double2 v = reinterpret_cast<const double2*>(a.slot[p])[i];
+                const double2 v = reinterpret_cast<const double2*>(a.slot[p] + lo)[i];
                 acc.x += v.x;
                 acc.y += v.y;
             }
             dst[i] = acc;
         }
-        if (tid == 0 && (n & 1)) {
-            double acc = a.slot[0][n - 1];
-            for (int p = 1; p < a.nranks; ++p) acc += a.slot[p][n - 1];
-            buf[n - 1] = acc;
+        if (threadIdx.x == 0 && (cnt & 1)) {
+            double acc = a.slot[0][hi - 1];
+            for (int p = 1; p < a.nranks; ++p) acc += a.slot[p][hi - 1];
+            buf[hi - 1] = acc;
         }
     }
 }
@@ -315,8 +309,6 @@ int p2p_init(fsnap_ctx* ctx, int nranks, int rank, const char* id, P2P** out) {
             return bail(ctx->hipfail(e, "hipIpcGetMemHandle (multi-process GPU sharing needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this driver)"));
     }
     if ((e = hipMemset(p->win, 0, P2P_FLAG_BYTES)) != hipSuccess) return bail(ctx->hipfail(e, "hipMemset(p2p flags)"));
-    if ((e = hipMalloc((void**)&p->d_ticket, sizeof(unsigned))) != hipSuccess) return bail(ctx->hipfail(e, "hipMalloc(p2p ticket)"));
-    if ((e = hipMemset(p->d_ticket, 0, sizeof(unsigned))) != hipSuccess) return bail(ctx->hipfail(e, "hipMemset(p2p ticket)"));
     if ((e = hipHostMalloc((void**)&p->h_status, sizeof(int), hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess)
         return bail(ctx->hipfail(e, "hipHostMalloc(p2p status)"));
     *p->h_status = 0;
@@ -399,7 +391,6 @@ void p2p_destroy(fsnap_ctx* ctx, P2P* p, bool broken) {
     for (int q = 0; q < p->nranks; ++q)
         if (p->peer_ipc[q] && p->peer[q]) (void)hipIpcCloseMemHandle(p->peer[q]);
     if (p->win) (void)hipFree(p->win);
-    if (p->d_ticket) (void)hipFree(p->d_ticket);
     if (p->h_status) (void)hipHostFree(p->h_status);
     if (p->shm) munmap(p->shm, p->shm_len);
     delete p;
@@ -419,15 +410,18 @@ int p2p_allreduce_device(fsnap_ctx* ctx, P2P* p, double* d_buf, int64_t n) {
         a.me = p->rank;
         for (int q = 0; q < p->nranks; ++q) {
             a.slot[q] = reinterpret_cast<double*>(p->peer[q] + P2P_FLAG_BYTES + (gen & 1) * p->slot_bytes);
-            a.flags[q] = reinterpret_cast<unsigned long long*>(p->peer[q]) + (gen & 1) * P2P_MAX_RANKS;
+            a.flags[q] = reinterpret_cast<unsigned long long*>(p->peer[q]) + (gen & 1) * (size_t)P2P_MAX_BLOCKS * P2P_MAX_RANKS;
         }
-        // a latency-bound launch: enough workgroups to keep the links busy, few enough to be resident at once beside
-        // whatever else runs (every workgroup polls; a workgroup that cannot start would hold the ticket back)
-        int64_t blocks = (len / 2 + 255) / 256;
+        // a latency-bound launch: ~2 KiB per thread-block pass, at most 128 workgroups -- few enough to be resident at once
+        // beside whatever else runs (every workgroup polls); the same grid on every rank (it follows from len alone)
+        int64_t blocks = (len + 2047) / 2048;
         if (blocks < 1) blocks = 1;
-        if (blocks > 128) blocks = 128;
-        hipLaunchKernelGGL(fsnap_p2p_allreduce_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_buf + off, (long long)len, a,
-                           (unsigned long long)gen, p->d_ticket, p->h_status, (unsigned long long)(tmo * 1.0e8));
+        if (blocks > P2P_MAX_BLOCKS) blocks = P2P_MAX_BLOCKS;
+        int64_t piece = (len + blocks - 1) / blocks;
+        piece += piece & 1;
+        blocks = (len + piece - 1) / piece;
+        hipLaunchKernelGGL(fsnap_p2p_allreduce_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_buf + off, (long long)len,
+                           (long long)piece, a, (unsigned long long)gen, p->h_status, (unsigned long long)(tmo * 1.0e8));
         FSNAP_HIP(hipGetLastError(), "launch fsnap_p2p_allreduce_k");
     }
     return FSNAP_OK;
