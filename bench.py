@@ -572,19 +572,21 @@ def run_svd_solver(ctx, args, head, dev, _capi):
                 ts.append(time.perf_counter() - t0)
             # median of the timed calls: on the driver's boxes ONE call of a series now and then takes 70+ ms inside a stream
             # wait (profiles/r05_lstsq_rows_phases.txt: the same five calls outside bench.py take 5.5 ms each)
-            return float(np.median(ts[8:])) * 1e3
+            # -- the outliers stay visible: mean and maximum of the same calls are reported beside the median
+            t = np.array(ts[8:]) * 1e3
+            return float(np.median(t)), {"ms_mean": float(t.mean()), "ms_max": float(t.max()), "calls": int(len(t))}
 
-        ms_cls = class_fit(A, 8)
+        ms_cls, spread_cls = class_fit(A, 8)
         fit_cls = np.array(sv.fit)
-        out["class_perform_fit"] = {"ms_per_fit": ms_cls, "rows_per_s": m / (ms_cls * 1e-3),
+        out["class_perform_fit"] = {"ms_per_fit": ms_cls, **spread_cls, "rows_per_s": m / (ms_cls * 1e-3),
                                     "refinement_steps": int(sv.last_refine_steps),
                                     "max_rel_diff_vs_steps": float(np.max(np.abs(fit_cls - beta) / np.maximum(np.abs(beta), 1e-300)))}
         if Kc >= 2:
             Ai = A.copy()
             Ai[:, Kc - 1] = Ai[:, 0] * (np.linalg.norm(A[:, Kc - 1]) / max(np.linalg.norm(A[:, 0]), 1e-300)) + 1.0e-9 * A[:, Kc - 1]
-            ms_rs = class_fit(Ai, 5)
+            ms_rs, spread_rs = class_fit(Ai, 5)
             rs = sv.last_row_space
-            out["row_space"] = {"ms_per_fit": ms_rs, "rows_per_s": m / (ms_rs * 1e-3), "used_row_space": rs is not None,
+            out["row_space"] = {"ms_per_fit": ms_rs, **spread_rs, "rows_per_s": m / (ms_rs * 1e-3), "used_row_space": rs is not None,
                                 "info": {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in (rs or {}).items()}
                                 if isinstance(rs, dict) else str(rs)}
         pt.free()

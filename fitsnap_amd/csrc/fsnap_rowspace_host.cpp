@@ -316,6 +316,40 @@ public:
     }
 };
 
+// f(t, team) for t = 0 .. team - 1, for bodies that meet at `bar`: the threads are created FIRST and the barrier is sized to the
+// number that actually started (thread creation fails under a pids cgroup limit / EAGAIN: run_threads' fallback -- the caller
+// runs the missing bodies afterwards -- would leave f(0) waiting at the barrier for threads that do not exist)
+template <class F>
+static void run_team(int nt, SpinBarrier& bar, F&& f) {
+    if (nt <= 1) {
+        bar.resize(1);
+        f(0, 1);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve((size_t)nt - 1);
+    std::atomic<int> team{0};
+    for (int t = 1; t < nt; ++t) {
+        try {
+            th.emplace_back([&f, &team, t] {
+                int n;
+                for (int spins = 0; (n = team.load(std::memory_order_acquire)) == 0; ++spins) {
+                    if (spins < 4000) __builtin_ia32_pause();
+                    else std::this_thread::yield();
+                }
+                f(t, n);
+            });
+        } catch (...) {
+            break;
+        }
+    }
+    const int n = (int)th.size() + 1;
+    bar.resize(n);
+    team.store(n, std::memory_order_release);
+    f(0, n);
+    for (auto& x : th) x.join();
+}
+
 class TriTeam {
     static constexpr int NB = 64;
     const int n;
@@ -524,9 +558,9 @@ double norm2_estimate(int n, const double* T, int steps = 12, int threads = 0) {
     bool stop = false;
     // ONE set of threads for all the steps (a barrier after the partial products, one after the reduction by thread 0)
     SpinBarrier bar(nt);
-    run_threads(nt, [&](int t) {
+    run_team(nt, bar, [&](int t, int team) {
         for (int it = 0; it < steps; ++it) {
-            for (int ch = t; ch < nchunk; ch += nt) {
+            for (int ch = t; ch < nchunk; ch += team) {
                 double* __restrict__ pv = part.data() + (size_t)ch * n;
                 std::fill(pv, pv + n, 0.0);
                 for (int i = ch; i < n; i += nchunk) {            // rows dealt round-robin: row i costs n - i
