@@ -39,8 +39,7 @@ live with HIP events on the kernel's stream around every `--timing-every`-th lau
 included: an event record between two dependent kernels idles the stream for ~5.6 us on this runtime, so the
 instrument samples instead of bracketing every launch), `per_rank` (kernel_ms and allreduce_ms of every rank: HIP
 events around the SYRK kernel and around the collective on each rank's own stream), `n_ranks_seen` (fsnap_comm_info),
-for N > 1 `dist_solve_ab` (the same strong-scaling steps with option dist_solve = 1: reduce to rank 0 -> solve ->
-broadcast beta) and, at N = 1, `cpu_baseline` (the oracle's restatement of the reference's numpy path timed on this
+`transport` (rccl | p2p: `--transport`) and, at N = 1, `cpu_baseline` (the oracle's restatement of the reference's numpy path timed on this
 box's host cores; a reported baseline, not the target).
 """
 from __future__ import annotations
@@ -85,16 +84,11 @@ def parse(argv=None):
     ap.add_argument("--force-dist", action="store_true",
                     help="diagnostics: run the multi-GPU step (RCCL all-reduce, fsnap_fit_dist) in a communicator of ONE "
                          "rank, to measure its fixed overhead against the single-GPU step")
-    ap.add_argument("--dist-solve-ab", type=int, default=-1,
-                    help="1 / 0: time the reduce -> solve on rank 0 -> broadcast variant next to the all-reduce one "
-                         "(default: only when N > 1)")
     ap.add_argument("--pipelined", type=int, default=1,
                     help="1 / 0: also report the throughput with two fits in flight (N = 1 only; an extra object, never `value`)")
     ap.add_argument("--svd-solver", type=int, default=1,
                     help="N = 1: also time the reference's default solver (SVD: probe solve + up to 2 one-pass refinement steps, the "
                          "plugin class, and the row-space path on an ill-conditioned copy); reported as `svd_solver`, never `value`")
-    ap.add_argument("--ab-timeout", type=int, default=30,
-                    help="seconds a collective of the optional dist_solve A/B leg may take before that leg is given up (the scaling numbers measured before it are reported either way)")
     ap.add_argument("--timing-every", type=int, default=4,
                     help="HIP events bracket every N-th kernel launch of the timed region (an event record between two "
                          "dependent kernels idles the stream ~5.6 us; 1 = every launch)")
@@ -102,7 +96,7 @@ def parse(argv=None):
                     help="exchange step of a multi-rank run: native RCCL (default) or the one-shot peer-to-peer all-reduce over hipIpc "
                          "windows (one node; ranks may SHARE a device, which RCCL refuses -- how N > 1 runs on a one-GPU box)")
     ap.add_argument("--job-timeout", type=float, default=1800.0, help="launcher: seconds before a hung job is killed")
-    ap.add_argument("--option", action="append", default=[], help="kernel option key=value (split, nontemporal, nblocks)")
+    ap.add_argument("--option", action="append", default=[], help="library option key=value (include/fsnap_hip.h: nblocks, nsplit, tiled, quad_min_rows, ...)")
     return ap.parse_args(argv)
 
 
@@ -297,11 +291,7 @@ def kernel_name_of(info):
         return f"fsnap_syrk_quad<{info['NB']}>"
     if info["kernel_or_pairs"] == 4:
         return f"fsnap_syrk_wave_p<{info['NB']}>"
-    if info["kernel_or_pairs"] == 3:
-        return f"fsnap_syrk_acc<{info['NB']}>"
-    if info["kernel_or_pairs"] == 2:
-        return f"fsnap_syrk_lds_static<{info['NB']},{info['threads'] // 64}>"
-    return f"fsnap_syrk_wave<{info['NB']},{info['split']}>"
+    return f"fsnap_syrk_acc<{info['NB']}>"
 
 
 def _single_blas_thread():
@@ -373,11 +363,9 @@ def run_mode(ctx, args, mode, rank, world, multi, _capi):
         else:
             ctx.sync()
 
-    def timed(dist_solve):
-        if multi:
-            ctx.set_option("dist_solve", dist_solve)
+    def timed():
         ctx.set_option("timing_every", 0)
-        for _ in range(max(0, args.preheat) if dist_solve == 0 else 20):
+        for _ in range(max(0, args.preheat)):
             step()
         for _ in range(args.warmup):
             step()
@@ -400,7 +388,7 @@ def run_mode(ctx, args, mode, rank, world, multi, _capi):
         comm_ms = float(np.mean(comm_hist[comm_hist >= 0])) if np.any(comm_hist >= 0) else 0.0
         return elapsed, beta, float(np.mean(syrk_hist)), float(np.mean(red_hist)), comm_ms, nh
 
-    elapsed, beta, syrk_ms, red_ms, comm_ms, nh = timed(0)
+    elapsed, beta, syrk_ms, red_ms, comm_ms, nh = timed()
     # per-rank numbers, max-over-ranks wall time
     per_rank = np.zeros((world, 4))
     per_rank[rank] = (elapsed, syrk_ms, comm_ms, float(m))
@@ -412,32 +400,7 @@ def run_mode(ctx, args, mode, rank, world, multi, _capi):
         "rows_per_rank": [int(x) for x in per_rank[:, 3]], "elapsed_per_rank_s": [float(x) for x in per_rank[:, 0]],
         "reduce_ms": red_ms, "sampled": nh, "info": info, "upload_ms": upload_ms, "upload_how": upload_how, "A": A, "b": b, "w": w,
     }
-    out["timed"] = timed
     return out
-
-
-def run_dist_solve_ab(ctx, args, strong, rank, world, _capi):
-    """The strong-scaling steps once more with option dist_solve = 1 (reduce to rank 0 -> solve there -> broadcast beta)
-    against the default (in-place all-reduce, solve on every rank).  Runs LAST and under a short collective deadline:
-    whatever happens here, the scaling numbers measured before it are reported."""
-    try:
-        if os.environ.get("FSNAP_BENCH_FAIL_AB"):            # test hook: this leg fails, the line must still come out
-            raise RuntimeError("failure injected by FSNAP_BENCH_FAIL_AB")
-        ctx.set_option("comm_timeout", max(10, int(args.ab_timeout)))
-        ctx.upload_rows(strong["A"], strong["b"])
-        ctx.set_weights(strong["w"])
-        e1, beta1, _, _, c1, _ = strong["timed"](1)
-        e = np.array([e1])
-        ctx.allreduce_host(e, _capi.REDUCE_MAX)
-        ctx.set_option("dist_solve", 0)
-        ctx.set_option("comm_timeout", 0)
-        return {
-            "allreduce_solve_everywhere_ms_per_step": strong["elapsed"] / args.steps * 1e3,
-            "reduce_solve_on_rank0_bcast_ms_per_step": float(e[0]) / args.steps * 1e3,
-            "same_beta": bool(np.array_equal(strong["beta"], beta1)), "reduce_ms_rank0": c1,
-        }
-    except BaseException as err:  # noqa: BLE001 - optional leg: report, never propagate
-        return {"error": f"rank {rank}: {type(err).__name__}: {err}"}
 
 
 def run_pipelined(args, head, dev, _capi):
@@ -657,12 +620,6 @@ def run_rank(args):
             continue
         results[mode] = run_mode(ctx, args, mode, rank, world, multi, _capi)
     head = results[modes[0]]                               # what `value` reports
-    ab_wanted = args.dist_solve_ab if args.dist_solve_ab >= 0 else (1 if world > 1 else 0)
-    if multi and ctx.comm_transport() == "p2p":
-        ab_wanted = 0                                      # reduce -> solve -> broadcast is an A/B form of the RCCL transport only
-    ab = None
-    if multi and ab_wanted and "strong" in results:
-        ab = run_dist_solve_ab(ctx, args, results["strong"], rank, world, _capi)
 
     pipelined = None
     if rank == 0 and world == 1 and not args.force_dist and args.pipelined:
@@ -775,8 +732,6 @@ def run_rank(args):
                 if mode != head["mode"]:
                     out[f"{mode}_per_rank"] = {"rows": res["rows_per_rank"], "kernel_ms": res["kernel_ms"],
                                                "allreduce_ms": res["allreduce_ms"]}
-        if ab is not None:
-            out["dist_solve_ab"] = ab
         if pipelined is not None:
             out["pipelined"] = pipelined
         if svd_extra is not None:
@@ -795,13 +750,6 @@ def run_rank(args):
                 del Af, bf, wf
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()
-    if ab is not None and "error" in ab:
-        # the optional leg broke the communicator (a peer never reached a collective): the numbers above stand, and the
-        # teardown of a broken communicator is not worth waiting for
-        sys.stdout.flush()
-        sys.stderr.write(f"bench.py: dist_solve A/B failed ({ab['error']}); scaling numbers reported without it\n")
-        sys.stderr.flush()
-        os._exit(0)
     if multi:
         ctx.barrier()
     ctx.close()

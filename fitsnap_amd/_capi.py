@@ -394,7 +394,6 @@ class HipContext:
 
     def set_option(self, key: str, value: int):
         self._check(self._lib.fsnap_set_option(self._h, key.encode(), int(value)))
-        self.__dict__.setdefault("options", {})[key] = int(value)     # what the solver layer may ask about (dist_solve)
 
     # -- rows / weights ----------------------------------------------------------------
     def upload_rows(self, A: np.ndarray, b: np.ndarray):
@@ -690,7 +689,6 @@ class HipContext:
         rc = self._lib.fsnap_fit_dist(self._h, int(kind), float(param), int(K), _ptr(beta), byref(rank), byref(rce), byref(ptr))
         if rc != OK:
             raise_status(rc, (self._lib.fsnap_last_error(self._h) or b"").decode() if rc < 0 else "")
-        # option dist_solve = 1: only rank 0 holds the reduced statistics -- ptr is None on the other ranks
         return beta, rank.value, rce.value, ptr.value
 
     # -- raw device memory ----------------------------------------------------------------

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "_lib")
 LIBNAME = "libfsnap_hip.so"
-SOURCES = ["fsnap_syrk.hip", "fsnap_syrk_quad.hip", "fsnap_rows.hip", "fsnap_chol.hip", "fsnap_trsm.hip", "fsnap_fused.hip", "fsnap_capi.cpp", "fsnap_comm.cpp", "fsnap_p2p.cpp",
+SOURCES = ["fsnap_syrk_quad.hip:0", "fsnap_syrk_quad.hip:1", "fsnap_syrk_quad.hip:2", "fsnap_syrk.hip", "fsnap_rows.hip", "fsnap_chol.hip", "fsnap_trsm.hip", "fsnap_fused.hip", "fsnap_capi.cpp", "fsnap_comm.cpp", "fsnap_p2p.cpp",
            "fsnap_rowspace.cpp", "fsnap_rowspace_host.cpp", "fsnap_solve.cpp"]
 HEADERS = ["fsnap_kernels.h", "fsnap_device_common.h", "fsnap_ctx.h", "fsnap_rowspace_host.h", "fsnap_condest.h", "fsnap_p2p.h", os.path.join("..", "..", "include", "fsnap_hip.h")]
 ARCH = "gfx950"
@@ -36,7 +36,7 @@ def _hipcc() -> str:
 
 def _source_digest() -> str:
     h = hashlib.sha256()
-    for name in SOURCES + HEADERS:
+    for name in sorted({s.split(":")[0] for s in SOURCES}) + HEADERS:
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
@@ -64,9 +64,13 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     for name in HEADERS:
         with open(os.path.join(CSRC, name), "rb") as f:
             hh.update(f.read())
-    for src in SOURCES:
-        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+    for entry in SOURCES:
+        # "file:N" = part N of a translation unit that is compiled in pieces (-DFSNAP_QUAD_PART=N)
+        src, _, part = entry.partition(":")
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + (f"_{part}" if part else "") + ".o")
         cmd = [hipcc, *common]
+        if part:
+            cmd += [f"-DFSNAP_QUAD_PART={part}"]
         if src in ("fsnap_capi.cpp", "fsnap_comm.cpp", "fsnap_p2p.cpp", "fsnap_rowspace.cpp"):
             cmd += ["-x", "hip"]
         if src in ("fsnap_solve.cpp", "fsnap_rowspace_host.cpp"):

@@ -65,9 +65,8 @@ struct Geometry {
     int nblocks, split, threads;
     int64_t cpw;
     int NB;
-    int lds_waves;  // 0 = kernel 1 (wave-triangle); 8 / 16 = kernel 1L (LDS-shared) with that many waves
     bool acc;       // kernel 1A: whole triangle in one wave (accumulation registers), one wave per SIMD
-    bool packed;    // kernel 1P: kernel 1 on packed weights (K <= 80)
+    bool packed;    // kernel 1P (K <= 80)
     bool fused_pack = false;   // kernel 1A packs (w_eff, w_eff b) of its rows into LDS itself: no fsnap_pack_weights_k launch
     bool quad = false;         // kernel 1Q: the triangle dealt to the four waves of a workgroup (144 < K <= 288); cpw = chunks per workgroup
     int cluster = 1;           // kernel 1QC (288 < K <= 512): workgroups per cluster; nblocks = clusters, cpw = chunks per cluster
@@ -76,7 +75,10 @@ struct Geometry {
 // rows below which the tiled kernel keeps 145 ... 288 columns: kernel 1Q writes one partial triangle per workgroup
 // (2 KiB x 55 ... 171 tiles), which short systems do not amortise
 constexpr int64_t QUAD_MIN_ROWS = 8192;
-constexpr int64_t QUAD_MIN_CPG = 24;        // fewest 4-row chunks per workgroup before the grid shrinks
+constexpr int64_t QUAD_MIN_CPG = 24;        // fewest 4-row chunks per workgroup before the grid shrinks (profiles/r05_quad_min_cpg_ab.txt)
+// widest system the accumulator-resident kernel 1A takes (NB = 9 column blocks: the ACE width 142 of examples/Ta_PACE_RIDGE)
+constexpr int64_t ACC_MAX_K = 144;
+constexpr int64_t ACC_MIN_CPW = 12;         // kernel 1A: fewest 4-row chunks per row-wave before its grid shrinks below one workgroup per CU
 // kernel 1QC (289 ... 512 columns on clusters of workgroups) against the tiled kernel, round 5 (profiles/r05_quadc_ab.txt):
 // 500 000 x 368 1.19 against 1.24 ms, 367 900 x 480 1.40 / 1.38 ms (with 1.43 instead of 6.14 GB of HBM reads and a 17 instead of
 // 42 us reduction: the complete fit 1.61 / 1.62 ms), 200 000 x 320 0.41 / 0.37, 100 000 x 512 0.51 / 0.43: a cluster's partial
@@ -86,20 +88,17 @@ constexpr int64_t QUADC_MIN_ROWS = 300000;
 // chunks per workgroup of kernel 1Q (per CLUSTER of kernel 1QC, 288 < K <= 512) for this context's rows, 0 = neither kernel
 // takes them
 int64_t quad_chunks_per_wg(const fsnap_ctx* ctx, int64_t* nblocks_out) {
-    const bool default_kernel = ctx->opt_kernel == 0 || ctx->opt_kernel == 7;
-    if (!ctx->opt_quad || !default_kernel || ctx->opt_tiled) return 0;
-    if (ctx->K <= 144 || ctx->K > 512 || ctx->K <= ctx->opt_acc_max_k) return 0;
+    if (ctx->opt_tiled) return 0;
+    if (ctx->K <= ACC_MAX_K || ctx->K > 512) return 0;
     const int cluster = fsnap::syrk_quad_cluster((int)ctx->K);
     // kernel 1QC exists with fused packing only: pairs brought by a row-space pass, or rows beyond the LDS, stay on the tiled kernel
-    if (cluster > 1 && !ctx->opt_quad_cluster) return 0;
     if (cluster > 1 && (!ctx->opt_fused_pack || ctx->wpack_override)) return 0;
     const int64_t min_rows = ctx->opt_quad_min_rows >= 0 ? ctx->opt_quad_min_rows : (cluster > 1 ? QUADC_MIN_ROWS : QUAD_MIN_ROWS);
     if (ctx->m < min_rows || ctx->m < 4) return 0;
     const int64_t nchunks = (ctx->m + 3) / 4;
     int64_t nblocks = ctx->opt_nblocks > 0 ? ctx->opt_nblocks : (int64_t)ctx->num_cu;
     nblocks /= cluster;                                  // clusters
-    const int64_t min_cpg = ctx->opt_quad_min_cpg > 0 ? ctx->opt_quad_min_cpg : QUAD_MIN_CPG;
-    const int64_t max_blocks = (nchunks + min_cpg - 1) / min_cpg;
+    const int64_t max_blocks = (nchunks + QUAD_MIN_CPG - 1) / QUAD_MIN_CPG;
     if (nblocks > max_blocks) nblocks = max_blocks;
     if (nblocks < 1) nblocks = 1;
     const int64_t cpg = (nchunks + nblocks - 1) / nblocks;
@@ -111,12 +110,9 @@ int64_t quad_chunks_per_wg(const fsnap_ctx* ctx, int64_t* nblocks_out) {
     return cpg;
 }
 
-// widest system the accumulator-resident kernel 1A takes (NB = 9 column blocks: the ACE width 142 of
-// examples/Ta_PACE_RIDGE); option acc_max_k = 128 sends 129 ... 144 columns back to the tiled kernel (A/B)
 inline bool use_tiled(const fsnap_ctx* ctx) {
-    const bool acc_kernel = ctx->opt_kernel == 0 || ctx->opt_kernel == 7;    // the A/B kernels stop at 128 columns
     if (ctx->opt_tiled) return true;
-    if (ctx->K <= (acc_kernel ? ctx->opt_acc_max_k : 128)) return false;
+    if (ctx->K <= ACC_MAX_K) return false;
     return quad_chunks_per_wg(ctx, nullptr) == 0;
 }
 
@@ -124,7 +120,6 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
     const int K = (int)ctx->K;
     const int64_t m = ctx->m;
     g->NB = fsnap::syrk_num_blocks(K);
-    g->lds_waves = 0;
     const int64_t off_limit = (int64_t)0xFFF00000;  // 32-bit buffer offsets, 1 MiB of slack for prefetch overshoot
     g->acc = false;
     g->packed = false;
@@ -143,12 +138,11 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
         g->fused_pack = ctx->opt_fused_pack && !ctx->wpack_override && cpg <= fsnap::syrk_quad_max_cpg();
         return FSNAP_OK;
     }
-    if (g->NB >= 6 && (ctx->opt_kernel == 7 || ctx->opt_kernel == 0)) {
+    if (g->NB >= 6) {
         // kernel 1A: one 4-wave workgroup per CU, every wave streams its own rows and owns the whole triangle
         const int64_t nchunks = (m + 3) / 4;
         int64_t nblocks = ctx->opt_nblocks > 0 ? ctx->opt_nblocks : (int64_t)ctx->num_cu;
-        const int64_t min_cpw = ctx->opt_acc_min_cpw > 0 ? ctx->opt_acc_min_cpw : 12;
-        const int64_t max_blocks = (nchunks + 4 * min_cpw - 1) / (4 * min_cpw);   // >= min_cpw chunks per row-wave (option acc_min_cpw)
+        const int64_t max_blocks = (nchunks + 4 * ACC_MIN_CPW - 1) / (4 * ACC_MIN_CPW);   // >= ACC_MIN_CPW chunks per row-wave
         if (nblocks > max_blocks) nblocks = max_blocks;
         if (nblocks < 1) nblocks = 1;
         int64_t cpw = (nchunks + nblocks * 4 - 1) / (nblocks * 4);
@@ -166,40 +160,13 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
         g->fused_pack = ctx->opt_fused_pack && !ctx->wpack_override && cpw <= fsnap::syrk_acc_max_fused_cpw();
         return FSNAP_OK;
     }
-    if (g->NB >= 6 && ctx->opt_kernel != 1) {
-        // kernel 1L: rows shared through LDS, whole triangle per workgroup
-        const int nw = (ctx->opt_kernel == 4 && g->NB == 8) ? 16 : (ctx->opt_kernel == 5 ? 4 : ctx->opt_kernel == 6 ? 2 : 8);
-        const int64_t nchunks = (m + 3) / 4;
-        int64_t nblocks = ctx->opt_nblocks > 0 ? ctx->opt_nblocks : (int64_t)ctx->num_cu * (nw == 4 ? 3 : nw == 2 ? 4 : 16 / nw);
-        const int64_t max_blocks = (nchunks + 4 * nw - 1) / (4 * nw);   // >= 4 stages per workgroup
-        if (nblocks > max_blocks) nblocks = max_blocks;
-        if (nblocks < 1) nblocks = 1;
-        int64_t cpg = (nchunks + nblocks - 1) / nblocks;
-        cpg = (cpg + nw - 1) / nw * nw;
-        const int64_t max_cpg = off_limit / (ctx->lda * 32) / nw * nw;
-        if (max_cpg < nw) return ctx->fail(FSNAP_E_ARG, "leading dimension %lld too large", (long long)ctx->lda);
-        if (cpg > max_cpg) cpg = max_cpg;
-        nblocks = (nchunks + cpg - 1) / cpg;
-        if (nblocks > 0x7FFFFFF) return ctx->fail(FSNAP_E_ARG, "too many workgroups");
-        g->nblocks = (int)nblocks;
-        g->cpw = cpg;
-        g->split = (ctx->opt_kernel == 3) ? -nw : nw;   // -8 = generic tile-table variant (A/B)
-        g->threads = 64 * nw;
-        g->lds_waves = nw;
-        return FSNAP_OK;
-    }
-    int split = ctx->opt_split ? ctx->opt_split : fsnap::syrk_default_split(K);
-    if (split == 2 && g->NB < 6) split = 1;
-    if (g->NB < 6 && ctx->opt_kernel == 0) {
-        g->packed = true;   // kernel 1P (option kernel = 1 keeps kernel 1 with separate mask / b / w loads for A/B)
-        split = 1;
-    }
-    if (split == 1 && g->NB > 6) split = 2;
-    g->split = split;
-    g->threads = 256 * split;
+    // K <= 80: kernel 1P
+    g->packed = true;
+    g->split = 1;
+    g->threads = 256;
     const int64_t nchunks = (m + 3) / 4;
-    // workgroups resident per CU: waves per SIMD the register budget admits / split
-    int wg_per_cu = fsnap::syrk_waves_per_simd(K, split) / split;
+    // workgroups resident per CU: waves per SIMD the register budget admits
+    int wg_per_cu = fsnap::syrk_waves_per_simd(K, 1);
     if (wg_per_cu < 1) wg_per_cu = 1;
     int64_t nblocks = ctx->opt_nblocks > 0 ? ctx->opt_nblocks : (int64_t)ctx->num_cu * wg_per_cu;
     // keep >= 8 chunks (32 rows) per row-wave so the pipeline prologue amortises
@@ -218,8 +185,7 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
     g->nblocks = (int)nblocks;
     g->cpw = cpw;
     // kernel 1P packs the pairs of its rows itself when they fit its LDS budget (contiguous chunk ranges only)
-    g->fused_pack = g->packed && ctx->opt_fused_pack && !ctx->wpack_override && !ctx->opt_interleave &&
-                    cpw <= fsnap::syrk_wave_p_max_fused_cpw(K, wg_per_cu);
+    g->fused_pack = ctx->opt_fused_pack && !ctx->wpack_override && cpw <= fsnap::syrk_wave_p_max_fused_cpw(K, wg_per_cu);
     return FSNAP_OK;
 }
 
@@ -414,7 +380,6 @@ int ensure_ones(fsnap_ctx* ctx) {
 
 struct TiledGeometry {
     int NSB, npairs, nsplit;
-    int items_per_split = 0;   // kernel 1T2 (0 = kernel 1T)
     int64_t cps;  // chunks per split
 };
 
@@ -464,9 +429,8 @@ double tiled_makespan_units(const std::vector<int>& tiles, int64_t n, int64_t ch
     return makespan;
 }
 
-// geometry of the tiled kernels for m rows of K columns (leading dimension lda); table: kernel 1T2's work items
-// (allow_t2), empty for kernel 1T.  Pure function of the shape and the context's options.
-int tiled_geometry(fsnap_ctx* ctx, int64_t m, int64_t K, int64_t lda, bool allow_t2, TiledGeometry* g, std::vector<int>* table_out) {
+// geometry of the tiled kernel for m rows of K columns (leading dimension lda).  Pure function of the shape and the context's options.
+int tiled_geometry(fsnap_ctx* ctx, int64_t m, int64_t K, int64_t lda, TiledGeometry* g) {
     if (K > 32768) return ctx->fail(FSNAP_E_ARG, "K = %lld too large", (long long)K);
     g->NSB = (int)((K + 63) / 64);
     g->npairs = g->NSB * (g->NSB + 1) / 2;
@@ -477,42 +441,16 @@ int tiled_geometry(fsnap_ctx* ctx, int64_t m, int64_t K, int64_t lda, bool allow
     // work items of one split and their cost in MFMA tiles per chunk
     const int tail = (int)(K & 63);
     const bool half = tail != 0 && tail <= 32;                   // last superblock: second 32-column group empty
-    const bool t2 = allow_t2 && ctx->opt_tiled2 != 0 && g->NSB >= 3;
     std::vector<int> tiles;
-    std::vector<int>& table = *table_out;
-    table.clear();
-    if (t2) {
-        // kernel 1T2: superblock I against consecutive pairs (J, J + 1) right of it (32 tiles, heaviest first), then
-        // the lone last column of the rows with an odd count (16 tiles), then the diagonal (10 tiles)
-        auto tri = [&](int I, int J) { return I * g->NSB - (I * (I - 1)) / 2 + (J - I); };
-        for (int I = 0; I < g->NSB; ++I)
-            for (int J = I + 1; J + 1 < g->NSB; J += 2) {
-                table.insert(table.end(), {0, I, J, tri(I, J)});
-                tiles.push_back((half && J + 1 == g->NSB - 1) ? 24 : 32);
-            }
-        for (int I = 0; I < g->NSB; ++I)
-            if ((g->NSB - 1 - I) & 1) {
-                table.insert(table.end(), {1, I, g->NSB - 1, tri(I, g->NSB - 1)});
-                tiles.push_back(half ? 8 : 16);
-            }
-        for (int I = 0; I < g->NSB; ++I) {
-            table.insert(table.end(), {1, I, I, tri(I, I)});
-            tiles.push_back((half && I == g->NSB - 1) ? 3 : 10);
-        }
-        g->items_per_split = (int)tiles.size();
-    } else {
-        for (int I = 0; I < g->NSB; ++I)                 // kernel 1T's item order: off-diagonal pairs, then the diagonal
-            for (int J = I + 1; J < g->NSB; ++J) tiles.push_back((half && J == g->NSB - 1) ? 8 : 16);
-        for (int I = 0; I < g->NSB; ++I) tiles.push_back((half && I == g->NSB - 1) ? 3 : 10);
-        g->items_per_split = 0;
-    }
+    for (int I = 0; I < g->NSB; ++I)                 // kernel 1T's item order: off-diagonal pairs, then the diagonal
+        for (int J = I + 1; J < g->NSB; ++J) tiles.push_back((half && J == g->NSB - 1) ? 8 : 16);
+    for (int I = 0; I < g->NSB; ++I) tiles.push_back((half && I == g->NSB - 1) ? 3 : 10);
     int64_t nsplit = ctx->opt_nsplit;
     if (nsplit <= 0) {
-        const int64_t groups = ctx->opt_xcd ? 8 : 1;
-        // kernel 1T: two workgroups (8 waves) per CU share the matrix pipe, 66 ns per tile and chunk at ~80 % issue;
-        // kernel 1T2: one workgroup per CU, ~30 ns
-        const int64_t slots = (int64_t)ctx->num_cu * (t2 ? 1 : 2) / groups;
-        const double unit = t2 ? 30.0e-9 : 66.0e-9, ovh = t2 ? 250.0 : 128.0;
+        const int64_t groups = 8;         // contiguous work-item ranges per XCD
+        // two workgroups (8 waves) per CU share the matrix pipe, 66 ns per tile and chunk at ~80 % issue
+        const int64_t slots = (int64_t)ctx->num_cu * 2 / groups;
+        const double unit = 66.0e-9, ovh = 128.0;
         const int64_t part_bytes = (int64_t)g->npairs * 32768;                        // partial triangles of one split
         int64_t n_hi = std::max<int64_t>(1, std::min<int64_t>(1024, nchunks / 128));  // >= 32 chunks per wave
         n_hi = std::min(n_hi, std::max<int64_t>(1, (256ll << 20) / part_bytes));      // <= 256 MiB of partials
@@ -560,28 +498,19 @@ int tiled_geometry(fsnap_ctx* ctx, int64_t m, int64_t K, int64_t lda, bool allow
 int plan_tiled(fsnap_ctx* ctx, TiledGeometry* g) {
     const int64_t m = ctx->m, K = ctx->K;
     if (ctx->tplan_valid && ctx->tplan_key[0] == m && ctx->tplan_key[1] == K && ctx->tplan_key[2] == ctx->lda &&
-        ctx->tplan_key[3] == ctx->opt_nsplit && ctx->tplan_key[4] == ctx->opt_xcd + 4 * ctx->opt_tiled2) {
+        ctx->tplan_key[3] == ctx->opt_nsplit) {
         g->NSB = ctx->tplan[0];
         g->npairs = ctx->tplan[1];
         g->nsplit = ctx->tplan[2];
         g->cps = ctx->tplan_cps;
-        g->items_per_split = ctx->tplan_items;
         return FSNAP_OK;
     }
-    std::vector<int> table;
     int rc;
-    if ((rc = tiled_geometry(ctx, m, K, ctx->lda, true, g, &table))) return rc;
-    if (g->items_per_split > 0) {
-        if (!ctx->titems.ensure(table.size() * sizeof(int))) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(work items) failed");
-        FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");      // a launch may still read the old table
-        FSNAP_HIP(hipMemcpy(ctx->titems.p, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy(work items)");
-    }
-    ctx->tplan_items = g->items_per_split;
+    if ((rc = tiled_geometry(ctx, m, K, ctx->lda, g))) return rc;
     ctx->tplan_key[0] = m;
     ctx->tplan_key[1] = K;
     ctx->tplan_key[2] = ctx->lda;
     ctx->tplan_key[3] = ctx->opt_nsplit;
-    ctx->tplan_key[4] = ctx->opt_xcd + 4 * ctx->opt_tiled2;
     ctx->tplan[0] = g->NSB;
     ctx->tplan[1] = g->npairs;
     ctx->tplan[2] = g->nsplit;
@@ -632,9 +561,6 @@ int launch_normal_eq_tiled(fsnap_ctx* ctx, double* d_packed, bool accumulate) {
     a.nsplit = g.nsplit;
     a.chunks_per_split = g.cps;
     a.nontemporal = false;  // rows are re-read by the other column pairs: keep them cached
-    a.xcd_map = ctx->opt_xcd != 0;
-    a.xcd_order = ctx->opt_xcd == 2 ? 2 : 1;
-    a.ring = ctx->opt_tiled_ring;
     a.part = (double*)ctx->part.p;
     a.cpart = (double*)ctx->cpart.p;
     a.spart = (const double*)ctx->wpack_spart.p;
@@ -651,13 +577,7 @@ int launch_normal_eq_tiled(fsnap_ctx* ctx, double* d_packed, bool accumulate) {
     hipEvent_t* evs;
     if ((rc = fit_events(ctx, &evs))) return rc;
     if (evs) FSNAP_HIP(hipEventRecord(evs[0], ctx->stream), "hipEventRecord");
-    if (g.items_per_split > 0) {
-        a.items = (const int*)ctx->titems.p;
-        a.items_per_split = g.items_per_split;
-        FSNAP_HIP(fsnap::launch_syrk_tiled2(a, ctx->stream), "launch fsnap_syrk_tiled2");
-    } else {
-        FSNAP_HIP(fsnap::launch_syrk_tiled(a, ctx->stream), "launch fsnap_syrk_tiled");
-    }
+    FSNAP_HIP(fsnap::launch_syrk_tiled(a, ctx->stream), "launch fsnap_syrk_tiled");
     if (evs) FSNAP_HIP(hipEventRecord(evs[1], ctx->stream), "hipEventRecord");
     FSNAP_HIP(fsnap::launch_reduce_tiled(a, d_packed, accumulate, ctx->stream), "launch fsnap_reduce_tiled");
     if (evs) FSNAP_HIP(hipEventRecord(evs[2], ctx->stream), "hipEventRecord");
@@ -679,7 +599,7 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
         mask = (const unsigned char*)ctx->ones.p;
     }
     const int NT = g.NB * (g.NB + 1) / 2;
-    const int cs_per_block = g.lds_waves ? 1 : 4 * g.cluster;   // kernel 1L folds c / scalars per workgroup; kernel 1QC: 4 per member
+    const int cs_per_block = 4 * g.cluster;   // c / scalar partials per workgroup (kernel 1QC: 4 per member)
     if (!ctx->part.ensure((size_t)g.nblocks * NT * 256 * sizeof(double)) ||
         !ctx->cpart.ensure((size_t)g.nblocks * cs_per_block * g.NB * 16 * sizeof(double)) ||
         !ctx->spart.ensure((size_t)g.nblocks * cs_per_block * 4 * sizeof(double)))
@@ -695,29 +615,20 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
     a.nblocks = g.nblocks;
     a.split = g.split;
     a.chunks_per_wave = g.cpw;
-    a.nontemporal = ctx->opt_nt != 0;
-    a.ablate = ctx->opt_ablate;
+    a.nontemporal = true;
     a.part = (double*)ctx->part.p;
     a.cpart = (double*)ctx->cpart.p;
     a.spart = (double*)ctx->spart.p;
     int ns = -1;                      // scalar partials: from the SYRK kernel, or (kernel 1A) from the weight packing
     const double* spart_src = a.spart;
-    if ((g.acc || g.packed || g.quad) && g.fused_pack) {
+    if (g.fused_pack) {
         a.fused_pack = true;          // b, w, mask -> pairs in LDS + the b-only scalars per row-wave, inside the SYRK launch
-    } else if (g.acc || g.packed || g.quad) {
+    } else {
         int npk = 0;
         if ((rc = ensure_wpack(ctx, &npk))) return rc;
         a.wpack = ctx->wpack_override ? ctx->wpack_override : (const double*)ctx->wpack.p;
         spart_src = (const double*)ctx->wpack_spart.p;
         ns = npk;
-    }
-    if (g.packed && ctx->opt_interleave) {
-        // kernel 1P, interleaved chunks: one advancing front of addresses over the whole matrix -- every row-wave's
-        // descriptor then spans the matrix, so its last chunk slot (+ the overshoot of the unrolled loop: 8 more
-        // rounds of the grid) must stay within a 32-bit buffer offset
-        const int64_t nchunks = (ctx->m + 3) / 4;
-        const int64_t reach = (nchunks + 9 * (int64_t)g.nblocks * 4) * ctx->lda * 32;
-        a.interleave = reach < (int64_t)0xFFF00000;
     }
     hipEvent_t* evs;
     if ((rc = fit_events(ctx, &evs))) return rc;
@@ -734,21 +645,18 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
         // low byte: flow-control mode (2 bits) and lead (6 bits).  Lead 63 = by cluster size, as measured (HBM reads / algorithmic):
         // clusters of 4 (367 900 x 480) lead 2: 1.01 x, lead 4: 1.5 x; clusters of 2 (500 000 x 368: twice as many clusters share an
         // XCD's L2) lead 0: 1.01 x, lead 1: 1.33 x, lead 2: 1.78 x -- at the same kernel time in every case
-        int flow = ctx->opt_quad_flow & 0xFF;
-        if ((flow >> 2) == 63) flow = (flow & 3) | ((g.cluster == 2 ? 0 : 2) << 2);
+        const int flow = 2 | ((g.cluster == 2 ? 0 : 2) << 2);      // mode 2: publish at the start of a trip, judge at its end
         a.flow_tag = (int)(ctx->quad_flow_tag | (unsigned)flow);
     }
     if (g.quad) FSNAP_HIP(fsnap::launch_syrk_quad(a, ctx->stream), "launch fsnap_syrk_quad");
     else if (g.acc) FSNAP_HIP(fsnap::launch_syrk_acc(a, ctx->stream), "launch fsnap_syrk_acc");
-    else if (g.packed) FSNAP_HIP(fsnap::launch_syrk_wave_p(a, ctx->stream), "launch fsnap_syrk_wave_p");
-    else if (g.lds_waves) FSNAP_HIP(fsnap::launch_syrk_lds(a, ctx->stream), "launch fsnap_syrk_lds");
-    else FSNAP_HIP(fsnap::launch_syrk(a, ctx->stream), "launch fsnap_syrk_wave");
+    else FSNAP_HIP(fsnap::launch_syrk_wave_p(a, ctx->stream), "launch fsnap_syrk_wave_p");
     if (evs) FSNAP_HIP(hipEventRecord(evs[1], ctx->stream), "hipEventRecord");
     // K <= 128 and the context owns the output: the reduction also writes a page-locked host mirror, so the solve
     // needs no D2H copy (the copy's launch latency was 12 us of a 440 us step)
     double* mirror = nullptr;
     // (a system the GPU factorises -- fsnap_solve_device_rhs's rule -- needs no mirror: DEVICE_CHOL_MIN_K columns and more)
-    if (want_mirror && ctx->opt_mirror && !device_factor(ctx, ctx->K)) {
+    if (want_mirror && !device_factor(ctx, ctx->K)) {
         const size_t need = ((size_t)FSNAP_PACKED_LEN(ctx->K) + (size_t)ctx->K) * 8;   // + compact diagonal
         if (ctx->mirror_bytes < need) {
             if (ctx->mirror) (void)hipHostFree(ctx->mirror);
@@ -762,9 +670,9 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
             ctx->mirror_ev = nullptr;
         if (ctx->mirror && ctx->mirror_ev) mirror = ctx->mirror;
     }
-    const bool upper_mirror = mirror && ctx->opt_mirror_upper && ctx->opt_reduce == 0;
+    const bool upper_mirror = mirror != nullptr;      // the mirror's triangle is written once per element, at its upper position
     FSNAP_HIP(fsnap::launch_reduce(a.part, a.cpart, spart_src, g.nblocks, cs_per_block, ns, a.K, d_packed, mirror, accumulate,
-                                   ctx->stream, ctx->opt_reduce, upper_mirror),
+                                   ctx->stream, upper_mirror),
               "launch fsnap_reduce_partials");
     if (evs) FSNAP_HIP(hipEventRecord(evs[2], ctx->stream), "hipEventRecord");
     if (mirror) {
@@ -791,14 +699,11 @@ int wpack_current(fsnap_ctx* ctx) {
 int normal_eq_launch_on(fsnap_ctx* ctx, const double* Q, int64_t ldq, const double* qpack, double* d_packed) {
     const double* const save_A = ctx->dA;
     const int64_t save_lda = ctx->lda;
-    const int save_kernel = ctx->opt_kernel;
     ctx->dA = Q;
     ctx->lda = ldq;
-    ctx->opt_kernel = 0;                 // the default kernels (1A / 1P / tiled) read the per-row pairs
     ctx->wpack_override = qpack;
     const int rc = launch_normal_eq(ctx, d_packed);
     ctx->wpack_override = nullptr;
-    ctx->opt_kernel = save_kernel;
     ctx->dA = save_A;
     ctx->lda = save_lda;
     return rc;
@@ -883,7 +788,7 @@ int fsnap_ctx_destroy(fsnap_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->ownA, &ctx->ownb, &ctx->ownw, &ctx->ownmask, &ctx->ones, &ctx->part, &ctx->cpart,
                       &ctx->spart, &ctx->packed, &ctx->beta, &ctx->preds, &ctx->sse, &ctx->aw, &ctx->bw,
                       &ctx->st_raw, &ctx->st_plan, &ctx->st_frac, &ctx->st_blank, &ctx->dsolve, &ctx->dchol, &ctx->dcat, &ctx->dstat, &ctx->wpack, &ctx->wpack_spart,
-                      &ctx->du, &ctx->dspart, &ctx->dsvec, &ctx->titems};
+                      &ctx->du, &ctx->dspart, &ctx->dsvec};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 2; ++i) {
         if (ctx->rstage[i]) (void)hipHostFree(ctx->rstage[i]);
@@ -925,74 +830,28 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx) {
 
 int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
     if (!ctx || !key) return FSNAP_E_ARG;
-    if (!strcmp(key, "split")) {
-        if (value < 0 || value > 2) return ctx->fail(FSNAP_E_ARG, "split must be 0 (auto), 1 or 2");
-        ctx->opt_split = (int)value;
-    } else if (!strcmp(key, "nontemporal")) {
-        ctx->opt_nt = value != 0;
-    } else if (!strcmp(key, "kernel")) {
-        if (value < 0 || value > 7) return ctx->fail(FSNAP_E_ARG, "kernel must be 0 (auto) or 1..7");
-        ctx->opt_kernel = (int)value;
-    } else if (!strcmp(key, "ablate")) {
-        ctx->opt_ablate = (int)value;
-    } else if (!strcmp(key, "device_solve")) {
+    if (!strcmp(key, "device_solve")) {
         if (value < 0 || value > 2) return ctx->fail(FSNAP_E_ARG, "device_solve must be 0 (auto), 1 (always) or 2 (never)");
         ctx->opt_device_solve = (int)value;
     } else if (!strcmp(key, "tiled")) {
         ctx->opt_tiled = value != 0;
-    } else if (!strcmp(key, "mirror")) {
-        ctx->opt_mirror = value != 0;
-        ctx->mirror_of = nullptr;
-    } else if (!strcmp(key, "xcd")) {
-        if (value < 0 || value > 2) return ctx->fail(FSNAP_E_ARG, "xcd must be 0, 1 (split-major ranges per XCD) or 2 (class-major)");
-        ctx->opt_xcd = (int)value;
-    } else if (!strcmp(key, "tiled2")) {
-        ctx->opt_tiled2 = value != 0;
     } else if (!strcmp(key, "timing_every")) {
         if (value < 0 || value > (1 << 20)) return ctx->fail(FSNAP_E_ARG, "timing_every out of range");
         ctx->opt_timing_every = (int)value;
         ctx->timing_phase = 0;
     } else if (!strcmp(key, "repack")) {
         ctx->opt_repack = value != 0;
-    } else if (!strcmp(key, "tiled_ring")) {
-        if (value < 0 || value > 3) return ctx->fail(FSNAP_E_ARG, "tiled_ring must be 0 ... 3");
-        ctx->opt_tiled_ring = (int)value;
-    } else if (!strcmp(key, "interleave")) {
-        ctx->opt_interleave = value != 0;
     } else if (!strcmp(key, "comm_timeout")) {
         if (value < 0 || value > 86400) return ctx->fail(FSNAP_E_ARG, "comm_timeout must be 0 (FSNAP_COMM_TIMEOUT) ... 86400 seconds");
         ctx->opt_comm_timeout = (int)value;
-    } else if (!strcmp(key, "dist_solve")) {
-        if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "dist_solve must be 0 (solve on every rank) or 1 (rank 0 solves and broadcasts)");
-        ctx->opt_dist_solve = (int)value;
     } else if (!strcmp(key, "chol_reuse")) {
         ctx->opt_chol_reuse = value != 0;
         ctx->chol_factor_of = nullptr;
     } else if (!strcmp(key, "rowspace_reuse_stats")) {
         ctx->opt_rowspace_reuse = value != 0;
-    } else if (!strcmp(key, "chol_form")) {
-        if (value < -1 || value > 5 || value == 3)
-            return ctx->fail(FSNAP_E_ARG, "chol_form must be -1 (default), 0, 1, 2 (single-wave diagonal block), 4 or 5");
-        ctx->opt_chol_form = (int)value;
-    } else if (!strcmp(key, "quad")) {
-        if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "quad must be 0 or 1");
-        ctx->opt_quad = (int)value;
-    } else if (!strcmp(key, "quad_flow")) {
-        if (value < 0 || value > 255 || (value & 3) == 3)
-            return ctx->fail(FSNAP_E_ARG, "quad_flow = mode + 4 * lead: mode 0 (off), 1 (look at the end of a trip) or 2 (at its start), lead 0 ... 63 trips");
-        ctx->opt_quad_flow = (int)value;
-    } else if (!strcmp(key, "quad_cluster")) {
-        if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "quad_cluster must be 0 or 1");
-        ctx->opt_quad_cluster = (int)value;
-    } else if (!strcmp(key, "quad_min_cpg")) {
-        if (value < 0 || value > 4096) return ctx->fail(FSNAP_E_ARG, "quad_min_cpg out of range");
-        ctx->opt_quad_min_cpg = (int)value;
     } else if (!strcmp(key, "quad_min_rows")) {
         if (value < -1) return ctx->fail(FSNAP_E_ARG, "quad_min_rows must be >= -1");
         ctx->opt_quad_min_rows = value;
-    } else if (!strcmp(key, "acc_min_cpw")) {
-        if (value < 0 || value > 4096) return ctx->fail(FSNAP_E_ARG, "acc_min_cpw out of range");
-        ctx->opt_acc_min_cpw = (int)value;
     } else if (!strcmp(key, "reduce_triangle")) {
         if (value < -1 || value > 1) return ctx->fail(FSNAP_E_ARG, "reduce_triangle must be -1 (K >= 256), 0 (never) or 1 (always)");
         ctx->opt_reduce_triangle = (int)value;
@@ -1000,19 +859,10 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
         if (value < 0 || value > 2) return ctx->fail(FSNAP_E_ARG, "staged_upload must be 0 (pageable copy), 1 (probe) or 2 (double buffer)");
         ctx->opt_staged_upload = (int)value;
     } else if (!strcmp(key, "fused_residual")) {
-        if (value < 0 || value > 2) return ctx->fail(FSNAP_E_ARG, "fused_residual must be 0 (two kernels), 1 (one pass) or 2 (one pass, register prefetch)");
+        if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "fused_residual must be 0 (two kernels) or 1 (one pass)");
         ctx->opt_fused_residual = (int)value;
-    } else if (!strcmp(key, "reduce")) {
-        if (value < 0 || value > 1) return ctx->fail(FSNAP_E_ARG, "reduce must be 0 (kernel 2b) or 1 (kernel 2)");
-        ctx->opt_reduce = (int)value;
-    } else if (!strcmp(key, "mirror_upper")) {
-        ctx->opt_mirror_upper = value != 0;
     } else if (!strcmp(key, "fused_pack")) {
         ctx->opt_fused_pack = value != 0;
-    } else if (!strcmp(key, "acc_max_k")) {
-        if (value != 128 && value != 144) return ctx->fail(FSNAP_E_ARG, "acc_max_k must be 128 or 144");
-        ctx->opt_acc_max_k = (int)value;
-        ctx->tplan_valid = false;
     } else if (!strcmp(key, "nsplit")) {
         if (value < 0 || value > (1 << 24)) return ctx->fail(FSNAP_E_ARG, "nsplit out of range");
         ctx->opt_nsplit = (int)value;
@@ -1261,8 +1111,7 @@ int fsnap_assemble_accumulate(fsnap_ctx* ctx, const double* raw, int64_t raw_row
     // geometry of the tiled kernel for a batch of this shape as fsnap_rows_alloc would hold it (lda = K): the fused
     // launch sums in the order of fsnap_assemble + fsnap_normal_eq_accumulate on the tiled kernel
     TiledGeometry g;
-    std::vector<int> unused;
-    if ((rc = tiled_geometry(ctx, nrows, K, K, false, &g, &unused))) return rc;
+    if ((rc = tiled_geometry(ctx, nrows, K, K, &g))) return rc;
     const int npk = fsnap::pack_weights_num_blocks(nrows);
     const size_t recb = fsnap::assemble_row_record_bytes();
     // per-row scratch: b | w | (w_eff, w_eff b) pairs | row records -- 48 bytes per row, nothing of A
@@ -1291,7 +1140,6 @@ int fsnap_assemble_accumulate(fsnap_ctx* ctx, const double* raw, int64_t raw_row
     a.nsplit = g.nsplit;
     a.chunks_per_split = g.cps;
     a.nontemporal = false;
-    a.xcd_map = ctx->opt_xcd != 0;
     a.part = (double*)ctx->fz_part.p;
     a.cpart = (double*)ctx->fz_cpart.p;
     a.spart = (const double*)ctx->fz_spart.p;
@@ -1433,7 +1281,7 @@ int fsnap_mirror_packed(fsnap_ctx* ctx, const double* d_packed, int64_t K) {
     if (!ctx) return FSNAP_E_ARG;
     if (!d_packed || K <= 0) return ctx->fail(FSNAP_E_ARG, "fsnap_mirror_packed: bad argument");
     ctx->mirror_of = nullptr;
-    if (device_factor(ctx, K) || !ctx->opt_mirror) return FSNAP_OK;     // factorised on the GPU: nothing to mirror
+    if (device_factor(ctx, K)) return FSNAP_OK;     // factorised on the GPU: nothing to mirror
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     const size_t need = ((size_t)FSNAP_PACKED_LEN(K) + (size_t)K) * 8;
     if (ctx->mirror_bytes < need) {
@@ -1612,27 +1460,6 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
     FSNAP_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     const double alpha = (kind == FSNAP_SOLVE_RIDGE || kind == FSNAP_SOLVE_RIDGE_INV || kind == FSNAP_SOLVE_RIDGE_PROBE ||
                           kind == FSNAP_SOLVE_RIDGE_INV_PROBE) ? param : 0.0;
-    if (K <= 128 && ctx->opt_device_solve == 1 && !rhs) {
-        ctx->chol_factor_of = nullptr;              // (this path reuses the buffer that holds the scaling of a blocked factorisation)
-        if (!ctx->dsolve.ensure((size_t)(K + 2) * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(solve) failed");
-        double host[130];
-        FSNAP_HIP(fsnap::launch_chol_solve(d_packed, (int)K, alpha, (double*)ctx->dsolve.p, ctx->stream),
-                  "launch fsnap_chol_solve_k");
-        FSNAP_HIP(hipMemcpyAsync(host, ctx->dsolve.p, (size_t)(K + 2) * 8, hipMemcpyDeviceToHost, ctx->stream),
-                  "hipMemcpy(beta)");
-        FSNAP_HIP(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
-        // same acceptance rule as the host fast path: well-conditioned after Jacobi scaling
-        if (host[K + 1] == 0.0 && host[K] > 1.0e-3) {
-            bool fin = true;
-            for (int64_t i = 0; i < K; ++i) fin = fin && (host[i] - host[i] == 0.0);
-            if (fin) {
-                for (int64_t i = 0; i < K; ++i) beta[i] = host[i];
-                if (rank) *rank = (int)K;
-                if (rcond_est) *rcond_est = host[K];
-                return FSNAP_OK;
-            }
-        }
-    }
     // large systems: blocked Cholesky on the GPU (kernels 8a-8e); option device_solve = 2 disables it
     // (threshold and measurements: fsnap::DEVICE_CHOL_MIN_K; below it the host is faster: the panel kernels are latency-bound
     // launches)
@@ -1677,12 +1504,11 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
         // a right-hand side of its own for statistics this context has just factorised (the refinement steps of a fit): the
         // factor, the scaling and the inverses of the diagonal blocks are still in the work buffers -- two sweeps instead of a
         // factorisation (kernel 8f + the backward sweep)
-        const int form_now = ctx->opt_chol_form < 0 ? fsnap::chol_default_form() : ctx->opt_chol_form;
         const bool reuse = rhs && host_out && ctx->opt_chol_reuse && ctx->chol_factor_of == d_packed && ctx->chol_factor_K == K &&
-                           ctx->chol_factor_alpha == alpha && ctx->chol_factor_form == form_now;
+                           ctx->chol_factor_alpha == alpha;
         if (reuse) {
             FSNAP_HIP(fsnap::launch_chol_resolve(d_rhs, n, (double*)ctx->dchol.p, d_dsc, d_z, d_beta, d_status, d_minpiv, host_out,
-                                                 form_now, ctx->stream),
+                                                 ctx->stream),
                       "launch device Cholesky (sweeps)");
             FSNAP_HIP(hipEventRecord(ctx->chol_ev, ctx->stream), "hipEventRecord");
             int wrc;
@@ -1708,7 +1534,7 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
         const bool clear_status = ctx->chol_status_word != (const void*)d_status;
         ctx->chol_status_word = host_out ? (const void*)d_status : nullptr;
         FSNAP_HIP(fsnap::launch_chol_large(d_packed, d_rhs, n, alpha, (double*)ctx->dchol.p, d_dsc, d_z, d_beta, d_status,
-                                           d_minpiv, host_out, clear_status, ctx->opt_chol_form, ctx->stream),
+                                           d_minpiv, host_out, clear_status, ctx->stream),
                   "launch device Cholesky");
         const double* h;
         if (host_out) {
@@ -1755,7 +1581,7 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
                     auto apply_inv = [&](double* v) -> bool {
                         if (hipMemcpyAsync(ctx->dsvec.p, v, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return false;
                         if (fsnap::launch_chol_resolve((const double*)ctx->dsvec.p, n, (double*)ctx->dchol.p, (const double*)ctx->dunit.p, d_z,
-                                                       d_beta, d_status, d_minpiv, host_out, form_now, ctx->stream) != hipSuccess)
+                                                       d_beta, d_status, d_minpiv, host_out, ctx->stream) != hipSuccess)
                             return false;
                         const double* r;
                         if (host_out) {
@@ -1788,7 +1614,6 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
                         ctx->chol_factor_of = d_packed;
                         ctx->chol_factor_K = K;
                         ctx->chol_factor_alpha = alpha;
-                        ctx->chol_factor_form = form_now;
                         ctx->chol_factor_rcond = rc_est;
                         ctx->chol_factor_piv = mp;
                         ctx->chol_factor_lam = ce.lambda_min;
@@ -1904,13 +1729,7 @@ int fsnap_fit_dist(fsnap_ctx* ctx, int kind, double param, int64_t K, double* be
     }
     hipEvent_t* evs = ctx->cur_events;
     int rc;
-    if (ctx->opt_dist_solve == 1 && ctx->comm) {
-        // A/B variant: reduce to rank 0, solve there, broadcast [beta | rank | rcond | status]
-        rc = fsnap::dist_reduce_solve_bcast(ctx, kind, param, K, dp, evs, beta, rank, rcond_est);
-        int nr = 1, me = 0;
-        (void)fsnap_comm_info(ctx, &nr, &me);
-        if (d_packed && me == 0) *d_packed = dp;       // the other ranks hold only their own sums: not handed out
-    } else {
+    {
         if ((rc = fsnap::allreduce_packed(ctx, dp, K))) return rc;       // wide systems: the upper triangle only
         if (evs) {
             FSNAP_HIP(hipEventRecord(evs[3], ctx->stream), "hipEventRecord");
@@ -2000,7 +1819,7 @@ int fsnap_residual_rhs(fsnap_ctx* ctx, const double* beta, double* s, double* ss
     if (fused) {
         FSNAP_HIP(fsnap::launch_residual_rows(ctx->dA, ctx->lda, (const double*)ctx->beta.p, ctx->m, (int)ctx->K, ctx->db, ctx->dw,
                                               mask, (double*)ctx->dspart.p, sse ? (double*)ctx->sse.p : nullptr,
-                                              (double*)ctx->dsvec.p, ctx->stream, ctx->opt_fused_residual == 2),
+                                              (double*)ctx->dsvec.p, ctx->stream),
                   "launch fsnap_residual_rows_k");
     } else {
         FSNAP_HIP(fsnap::launch_gemv_rows(ctx->dA, ctx->lda, (const double*)ctx->beta.p, ctx->m, (int)ctx->K, nullptr, ctx->db,
@@ -2096,7 +1915,7 @@ int fsnap_launch_info(fsnap_ctx* ctx, int64_t* info, int n) {
     if (use_tiled(ctx)) {
         TiledGeometry t;
         if ((rc = plan_tiled(ctx, &t))) return rc;
-        out[0] = (int64_t)(t.items_per_split > 0 ? t.items_per_split : t.npairs) * t.nsplit;
+        out[0] = (int64_t)t.npairs * t.nsplit;
         out[1] = 256;
         out[2] = t.cps / 4;
         out[3] = 4 * t.NSB;
@@ -2111,7 +1930,7 @@ int fsnap_launch_info(fsnap_ctx* ctx, int64_t* info, int n) {
         out[2] = g.cpw;
         out[3] = g.NB;
         out[4] = g.split;
-        out[6] = g.quad ? (g.cluster > 1 ? 6 : 5) : g.acc ? 3 : (g.packed ? 4 : (g.lds_waves ? 2 : 1));
+        out[6] = g.quad ? (g.cluster > 1 ? 6 : 5) : g.acc ? 3 : 4;
         out[7] = g.fused_pack ? 1 : 0;  // kernel id: 1 = wave-triangle, 2 = LDS-shared, 3 = one-wave triangle (1A), 4 = wave-triangle on packed weights (1P), 5 = triangle dealt to the four waves of a workgroup (1Q; chunks per WORKGROUP)
     }
     for (int i = 0; i < n; ++i) info[i] = out[i];

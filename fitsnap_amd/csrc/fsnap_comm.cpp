@@ -34,7 +34,6 @@ struct Rccl {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
-    decltype(&ncclReduce) Reduce = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -72,7 +71,6 @@ static Rccl* rccl() {
     r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
     r.CommAbort = (decltype(r.CommAbort))sym("ncclCommAbort");
     r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
-    r.Reduce = (decltype(r.Reduce))sym("ncclReduce");
     r.Broadcast = (decltype(r.Broadcast))sym("ncclBroadcast");
     r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
@@ -406,78 +404,3 @@ int fsnap_barrier(fsnap_ctx* ctx) {
 }
 
 }  // extern "C"
-
-namespace fsnap {
-
-int dist_reduce_solve_bcast(fsnap_ctx* ctx, int kind, double param, int64_t K, double* dp, hipEvent_t* evs, double* beta,
-                            int* rank, double* rcond_est) {
-    Rccl* r;
-    int rc;
-    if ((rc = need_comm(ctx, &r))) return rc;
-    if (ctx->comm->p2p)
-        return ctx->fail(FSNAP_E_STATE, "option dist_solve = 1 (reduce to rank 0, solve, broadcast) is an A/B form of the RCCL transport; the "
-                                        "peer-to-peer transport has the all-reduce form only");
-    const int64_t n = FSNAP_PACKED_LEN(K);
-    const bool root = ctx->comm->rank == 0;
-    // message: [beta (K) | rank | rcond | status].  Everything that can fail on THIS rank alone is allocated before the
-    // first collective; between the reduce and the broadcast no rank returns -- a rank that left there would keep its
-    // peers in the broadcast until FSNAP_COMM_TIMEOUT.  A local failure is recorded, the broadcast still runs (root:
-    // with its status in the message), and the failing rank reports its own error afterwards.
-    const size_t words = (size_t)K + 3;
-    if (!ctx->commbuf.ensure(words * 8)) return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(collective staging) failed");
-    std::unique_ptr<double[]> msg(new (std::nothrow) double[words]);
-    if (!msg) return ctx->fail(FSNAP_E_NOMEM, "out of host memory");
-    FSNAP_NCCL(r->Reduce(dp, dp, (size_t)n, ncclDouble, ncclSum, 0, ctx->comm->nccl, ctx->stream), "ncclReduce");
-    int local_rc = FSNAP_OK;
-    std::string local_err;
-    auto note = [&](int code, const char* what, hipError_t e) {
-        if (local_rc == FSNAP_OK) {
-            local_rc = ctx->fail(code, "%s: %s", what, hipGetErrorString(e));
-            local_err = ctx->err;
-        }
-    };
-    if (evs) {
-        const hipError_t e = hipEventRecord(evs[3], ctx->stream);
-        if (e != hipSuccess) note(FSNAP_E_HIP, "hipEventRecord", e);
-        else ctx->ring_comm[(ctx->nfit - 1) % fsnap_ctx::RING] = true;
-    }
-    int solve_rc = FSNAP_OK;
-    if (root) {
-        int rk = 0;
-        double rce = 0.0;
-        for (size_t i = 0; i < words; ++i) msg[i] = 0.0;
-        solve_rc = fsnap_mirror_packed(ctx, dp, K);
-        if (solve_rc == FSNAP_OK) solve_rc = fsnap_solve_device_rhs(ctx, kind, param, K, dp, nullptr, msg.get(), &rk, &rce);
-        if (solve_rc != FSNAP_OK && local_rc == FSNAP_OK) local_err = ctx->err;
-        msg[K] = (double)rk;
-        msg[K + 1] = rce;
-        msg[K + 2] = (double)solve_rc;
-        // a failed solve still sends its status: the other ranks are waiting in the broadcast.  If even the copy of the
-        // message fails, the peers receive whatever the staging buffer holds -- made NaN first, which every rank reads
-        // as a failed fit
-        hipError_t e = hipMemcpyAsync(ctx->commbuf.p, msg.get(), words * 8, hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) {
-            note(FSNAP_E_HIP, "hipMemcpy(H2D)", e);
-            (void)hipMemsetAsync(ctx->commbuf.p, 0xFF, words * 8, ctx->stream);
-        }
-    }
-    FSNAP_NCCL(r->Broadcast(ctx->commbuf.p, ctx->commbuf.p, words, ncclDouble, 0, ctx->comm->nccl, ctx->stream), "ncclBroadcast");
-    if (local_rc != FSNAP_OK) {
-        (void)wait_stream(ctx, nullptr, "broadcast of the fit");
-        return ctx->fail(local_rc, "%s", local_err.c_str());
-    }
-    if (!root) FSNAP_HIP(hipMemcpyAsync(msg.get(), ctx->commbuf.p, words * 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy(D2H)");
-    if ((rc = wait_stream(ctx, nullptr, "broadcast of the fit"))) return rc;
-    for (int64_t i = 0; i < K; ++i) beta[i] = msg[i];
-    if (rank) *rank = (int)msg[K];
-    if (rcond_est) *rcond_est = msg[K + 1];
-    if (!(msg[K + 2] == msg[K + 2]))       // NaN message: rank 0 could not even send its status
-        return ctx->fail(FSNAP_NUM_NONFINITE, "fsnap_fit_dist: rank 0 failed before it could send the fit");
-    const int status = (int)msg[K + 2];
-    if (status != FSNAP_OK && !root) ctx->fail(status, "fsnap_fit_dist: the solve on rank 0 returned status %d", status);
-    if (status != FSNAP_OK && root && !local_err.empty()) ctx->fail(status, "%s", local_err.c_str());
-    return status;
-}
-
-}  // namespace fsnap
-

@@ -114,26 +114,15 @@ struct fsnap_ctx {
     bool mirror_upper = false;                    // only the upper triangle of the mirror's G is meaningful (kernel 2b)
     hipEvent_t mirror_ev = nullptr;               // recorded after the reduction that filled the mirror
     // options
-    int opt_split = 0;        // 0 = auto
-    int opt_nt = 1;
-    int opt_tiled_ring = 3;       // kernel 1T: bit 0 diagonal / bit 1 off-diagonal items on the ring form of the pipeline
-    bool opt_interleave = false;  // kernel 1P: row-waves take every NW-th chunk (one address front) instead of contiguous ranges (A/B: no difference measured)
     int opt_nblocks = 0;      // 0 = auto
     int opt_tiled = 0;        // force the general-K tiled kernel also for K <= 128
-    int opt_kernel = 0;       // 0 auto | 1 wave-triangle (kernel 1) | 2 LDS-shared, static per-wave bodies | 3 LDS-shared, generic
     int opt_nsplit = 0;       // row splits of the tiled kernel (0 = auto)
-    int opt_xcd = 1;          // tiled kernel: contiguous work-item ranges per XCD
-    int opt_tiled2 = 0;       // K > 128: 1 = kernel 1T2 (one wave per SIMD, 32-tile items; measured no faster), 0 = kernel 1T
-    int opt_mirror = 1;       // fsnap_normal_eq_resident / fsnap_mirror_packed: a page-locked host mirror of the statistics for every system the HOST factorises (K < DEVICE_CHOL_MIN_K)
     int opt_device_solve = 0; // 0 = auto (K >= DEVICE_CHOL_MIN_K on the GPU, blocked kernels), 1 = every K (K <= 128: fsnap_chol_solve_k), 2 = never
-    int opt_ablate = 0;       // timing-only ablation of kernel 1L (diagnostics; results are wrong)
     // cached launch plan of the tiled kernel (plan_tiled)
     bool tplan_valid = false;
-    int64_t tplan_key[5] = {0, 0, 0, 0, 0};
+    int64_t tplan_key[4] = {0, 0, 0, 0};
     int tplan[3] = {0, 0, 0};
     int64_t tplan_cps = 0;
-    int tplan_items = 0;                          // kernel 1T2: work items per split (table in titems)
-    DevBuf titems;
     // timing flags
     bool t_syrk = false, t_upload = false, t_weight = false, t_predict = false;
 
@@ -148,7 +137,6 @@ struct fsnap_ctx {
     const double* chol_factor_of = nullptr;
     int64_t chol_factor_K = 0;
     double chol_factor_alpha = 0.0;
-    int chol_factor_form = -2;
     double chol_factor_rcond = 0.0;        // what the solve that left the factor reported as *rcond_est (min(pivot, lambda_min estimate))
     double chol_factor_piv = 0.0, chol_factor_lam = 0.0;
     DevBuf dunit;                          // a vector of ones: the "scaling" of a sweep that applies S^-1 itself (condition estimate)
@@ -177,24 +165,13 @@ struct fsnap_ctx {
     int opt_staged_upload = 0;    // fsnap_upload_rows: 0 pageable hipMemcpy (default) | 2 page-locked double buffer | 1 double buffer, probed
     double upload_probe_gbps = 0.0;   // rate at which the host filled the first page-locked slots of the last large upload (GB/s)
     bool upload_staged = false;       // the whole of the last upload went through the double buffer
-    int opt_fused_residual = 1;   // fsnap_residual_rhs, K <= 288: 1 one pass over the rows | 2 one pass, next rows prefetched into a second
-                                  // register set (measured slower: fewer waves per SIMD) | 0 kernels 4 + 7, two passes
-    int opt_reduce = 0;       // reduction of kernel 1 / 1A / 1P partials: 0 = kernel 2b, 1 = kernel 2 (A/B)
-    int opt_mirror_upper = 1; // kernel 2b writes the host mirror's triangle once per element (upper positions)
+    int opt_fused_residual = 1;   // fsnap_residual_rhs, K <= 288: 1 one pass over the rows | 0 kernels 4 + 7, two passes (the form of wider systems)
     int opt_fused_pack = 1;   // kernel 1A forms the per-row pairs of its rows in LDS itself (no packing launch) when they fit
-    int opt_acc_min_cpw = 0;  // kernel 1A: fewest 4-row chunks per row-wave before the grid shrinks (0 = default)
     int opt_rowspace_reuse = 0;  // one-shot, set by the caller right before fsnap_lstsq_rows: the statistics of the fit that just ran (still in the page-locked mirror) are those of the rows as they are now -- the first pass starts from them
     int opt_chol_reuse = 1;   // fsnap_solve_device_rhs with a right-hand side of its own (refinement): 1 = forward + backward sweep with the factor the last solve of the same statistics left on the device, 0 = factorise again (A/B)
-    int opt_chol_form = -1;   // panel loop of the device Cholesky: -1 = default (FSNAP_CHOL_DIAG, else 5: one launch per panel, four-wave diagonal block); 0 | 1 | 2 | 4: the A/B forms (fsnap_chol.hip)
-    int opt_quad_flow = 2 + 4 * 63;  // kernel 1QC (lead 63 = by cluster size: 0 for clusters of 2, 2 for clusters of 4): flow control between the members of a cluster: mode (0 off, 1 look at the end of a trip, 2 at its start) + 4 x lead (trips a member may run ahead)
-    int opt_quad_cluster = 1; // kernel 1QC (288 < K <= 512: kernel 1Q's plan on a cluster of 2 / 4 workgroups of one XCD); 0 = tiled kernel there
-    int opt_quad = 1;         // kernel 1Q (144 < K <= 288: the triangle dealt to the four waves of a workgroup); 0 = tiled kernel there
     int64_t opt_quad_min_rows = -1;   // fewest rows for kernel 1Q (-1 = default)
-    int opt_quad_min_cpg = 0;         // kernel 1Q: fewest 4-row chunks per workgroup before the grid shrinks (0 = default)
-    int opt_acc_max_k = 144;  // widest system on kernel 1A (144 = nine column blocks; 128: 129 ... 144 columns on the tiled kernel)
     int opt_repack = 0;       // 1 = pack (w_eff, w_eff b) on every launch even when b / w / mask are context-owned
     int opt_comm_timeout = 0; // seconds; 0 = FSNAP_COMM_TIMEOUT (default 300): bound of every wait behind a collective of THIS context
-    int opt_dist_solve = 0;   // fsnap_fit_dist: 0 = all-reduce + solve on every rank, 1 = reduce to rank 0 + solve there + broadcast beta
     bool comm_broken = false; // a bounded wait behind a collective ran out: the stream may hold a stuck RCCL kernel
 
     int fail(int code, const char* fmt, ...) {
@@ -228,15 +205,10 @@ double comm_timeout_s(const fsnap_ctx* ctx);  // the context's option comm_timeo
 // before its collective leaves this rank's stream stuck in an RCCL kernel -- and runs out with FSNAP_E_HIP + one line
 // in fsnap_last_error; the communicator is then aborted instead of destroyed when the context goes away.
 int wait_stream(fsnap_ctx* ctx, hipEvent_t ev, const char* what);
-// fsnap_comm.cpp: the reduce-to-root form of a multi-GPU fit (option dist_solve = 1): ncclReduce of the packed statistics to
-// rank 0, fsnap_solve_device there, ncclBroadcast of [beta | rank | rcond | status]; evs[3] (may be null) is recorded
-// behind the reduce
 // fsnap_comm.cpp: in-place sum over the ranks of packed statistics [G | c | scalars]; wide systems as a triangle (option
 // reduce_triangle)
 int allreduce_packed(fsnap_ctx* ctx, double* dp, int64_t K);
 bool allreduce_packed_reserve(fsnap_ctx* ctx, int64_t K);     // its buffer, to be reserved before a caller's first collective
-int dist_reduce_solve_bcast(fsnap_ctx* ctx, int kind, double param, int64_t K, double* dp, hipEvent_t* evs, double* beta,
-                            int* rank, double* rcond_est);
 // fsnap_capi.cpp: statistics of OTHER rows than the resident ones with the resident rows' launch plan -- the passes
 // of the row-space solve run the same SYRK kernels on the orthogonalised copy Q (m x K, leading dimension ldq) with
 // per-row pairs qpack = (1, w_eff b); d_packed receives [Q^T Q | Q^T b_w | ...]

@@ -358,9 +358,9 @@ hipError_t launch_assemble_bw(const double* raw, int64_t raw_ld, int64_t nrows, 
 hipError_t launch_assemble_syrk(const double* raw, int64_t raw_ld, const void* recs, const double* dval, const double* fractions,
                                 const double* blank2J, int ntypes, int ncoeff, int off, const TiledArgs& a, hipStream_t st) {
     const int nitems = (int)((int64_t)a.npairs * a.nsplit);
-    dim3 grid((unsigned)(a.xcd_map ? 8 * ((nitems + 7) / 8) : nitems)), block(256);
+    dim3 grid((unsigned)(8 * ((nitems + 7) / 8))), block(256);
     hipLaunchKernelGGL(fsnap_assemble_syrk_k, grid, block, 0, st, raw, raw_ld, recs, dval, a.wpack, a.m, fractions, blank2J, ntypes,
-                       ncoeff, off, a.K, a.NSB, a.npairs, a.chunks_per_split, nitems, a.xcd_map ? 1 : 0, a.part, a.cpart);
+                       ncoeff, off, a.K, a.NSB, a.npairs, a.chunks_per_split, nitems, 1, a.part, a.cpart);
     return hipGetLastError();
 }
 

@@ -14,17 +14,15 @@ struct SyrkArgs {
     const double* w;            // device, m
     const unsigned char* mask;  // device, m (1 = training row) or nullptr
     int64_t m;
-    int K;                      // <= 128 for the wave-triangle kernel
+    int K;
     int nblocks;                // workgroups (4 row-waves each)
-    int split;                  // sub-waves per row-wave sharing the tile triangle (1 or 2)
+    int split;                  // (1)
     int64_t chunks_per_wave;    // 4-row chunks per wave
     bool nontemporal;           // use nt loads for the A stream
-    int ablate = 0;             // timing-only diagnostic ablation of kernel 1L (0 = off)
     double* part;               // [nblocks][NT][4][64]
     double* cpart;              // [nblocks*4][NB][16]
     double* spart;              // [nblocks*4][4]
     const double* wpack = nullptr;  // kernel 1A: packed (w_eff, w_eff * b) per row (launch_pack_weights)
-    bool interleave = false;        // kernel 1P: row-waves take every NW-th chunk instead of a contiguous range
     int* flow_words = nullptr;      // kernel 1QC: flow-control words, 4 ints per cluster (zero once, never reset)
     int flow_tag = 0;               // kernel 1QC: + 2^20 per launch
     bool fused_pack = false;        // kernels 1A / 1P: the kernel packs (w_eff, w_eff b) of its rows into LDS itself (b, w, mask,
@@ -42,23 +40,15 @@ struct TiledArgs {
     int nsplit;                 // row splits
     int64_t chunks_per_split;   // 4-row chunks per split (each split = 4 waves)
     bool nontemporal;
-    bool xcd_map = true;        // contiguous (split, pair) ranges per XCD (L2 sharing of row slabs)
-    int xcd_order = 1;          // 1: (split, pair) order inside an XCD; 2: class-major (equal-cost items side by side)
-    int ring = 3;               // kernel 1T: bit 0 = diagonal items, bit 1 = off-diagonal items on the ring form of the pipeline
     double* part;               // [nsplit*npairs][16][4][64]
     double* cpart;              // [(nsplit*NSB)*4][4][16]
     const double* spart;        // [ns][4]: partial b-only scalars of fsnap_pack_weights_k
     int ns;
-    const int* items = nullptr; // kernel 1T2: device table [items_per_split][4] = {type, I, J, pair index}
-    int items_per_split = 0;
 };
 
 int syrk_num_blocks(int K);
-int syrk_default_split(int K);
 int syrk_waves_per_simd(int K, int split);
-hipError_t launch_syrk(const SyrkArgs& a, hipStream_t st);
 hipError_t launch_syrk_wave_p(const SyrkArgs& a, hipStream_t st);   // K <= 80, packed weights (a.wpack)
-hipError_t launch_syrk_lds(const SyrkArgs& a, hipStream_t st);
 hipError_t launch_syrk_acc(const SyrkArgs& a, hipStream_t st);
 // kernel 1Q (144 < K <= 288, fsnap_syrk_quad.hip): a.chunks_per_wave = chunks per WORKGROUP; pairs from a.wpack or (a.fused_pack,
 // chunks per workgroup <= syrk_quad_max_cpg()) formed by the kernel
@@ -72,17 +62,15 @@ int64_t syrk_wave_p_max_fused_cpw(int K, int wg_per_cu);   // kernel 1P: same fo
 // mirror: optional page-locked HOST buffer that receives the same packed statistics (zero-copy D2H)
 // accumulate: out += statistics instead of out = statistics
 // ns: number of scalar partials in spart (< 0: nblocks * cs_per_block, like the c partials)
-// variant: 0 = kernel 2b (all loads of a thread in flight), 1 = kernel 2 (A/B); upper_mirror: the mirror receives the
-// triangle at its upper positions only (kernel 2b)
+// upper_mirror: the mirror receives the triangle at its upper positions only
 hipError_t launch_reduce(const double* part, const double* cpart, const double* spart, int nblocks,
                          int cs_per_block, int ns, int K, double* out, double* mirror, bool accumulate, hipStream_t st,
-                         int variant = 0, bool upper_mirror = false);
+                         bool upper_mirror = false);
 int pack_weights_num_blocks(int64_t m);
 // wpack[m][2] = (w_eff, w_eff * b); spart[pack_weights_num_blocks(m)][4] = partial b^T W^2 b, sum(w b), n_train, 0
 hipError_t launch_pack_weights(const double* b, const double* w, const unsigned char* mask, int64_t m, double* wpack,
                                double* spart, hipStream_t st);
 hipError_t launch_syrk_tiled(const TiledArgs& a, hipStream_t st);
-hipError_t launch_syrk_tiled2(const TiledArgs& a, hipStream_t st);
 hipError_t launch_reduce_tiled(const TiledArgs& a, double* out, bool accumulate, hipStream_t st);
 hipError_t launch_weight_rows(const double* A, int64_t lda, const double* b, const double* w,
                               const unsigned char* mask, int64_t m, int K, double* aw, int64_t ldaw, double* bw,
@@ -102,27 +90,21 @@ hipError_t launch_mirror_copy(const double* src, int K, double* mirror, hipStrea
 // packed [G | c | scalars] <-> [upper triangle of G row-major | c | scalars]: the payload of the multi-GPU all-reduce for wide systems
 hipError_t launch_tri_pack(const double* packed, int K, double* tri, hipStream_t st);
 hipError_t launch_tri_unpack(const double* tri, int K, double* packed, hipStream_t st);
-hipError_t launch_chol_solve(const double* packed, int K, double alpha, double* out, hipStream_t st);
 // blocked Cholesky solve for large K: work (chol_large_work_doubles(K) doubles), dsc, z (np = K rounded up to 64),
 // beta (K), status (1 int), minpiv (np / 64) are device scratch / outputs
 // cvec: device right-hand side (NULL = the c part of packed)
 size_t chol_large_work_doubles(int n);
 hipError_t launch_chol_large(const double* packed, const double* cvec, int n, double alpha, double* work, double* dsc, double* z,
-                             double* beta, int* status, double* minpiv, double* host_out, bool clear_status, int form,
-                             hipStream_t st);
-// `form` of the panel loop (option "chol_form"): 5 = one launch per panel + four-wave diagonal block (default), 4 = two launches
-// per panel + four-wave block, 0 | 1 | 2 = two launches per panel + the single-wave block with pivot chain 0 / 1 / 2 (rounds 2-4);
-// one more right-hand side (n doubles, device) for the factor the last launch_chol_large of the same n / form left in `work`
+                             double* beta, int* status, double* minpiv, double* host_out, bool clear_status, hipStream_t st);
+// one more right-hand side (n doubles, device) for the factor the last launch_chol_large of the same n left in `work`
 hipError_t launch_chol_resolve(const double* d_rhs, int n, double* work, const double* dsc, double* z, double* beta, int* status,
-                               const double* minpiv, double* host_out, int form, hipStream_t st);
-// -1 = chol_default_form() (FSNAP_CHOL_DIAG, else 5)
-int chol_default_form();
+                               const double* minpiv, double* host_out, hipStream_t st);
 // factor only (pass factor of the row-space solve, K >= 384): R = chol(D^-1 G D^-1 + shift I) D for the n x n Gram matrix G in
 // device memory, written as the K16 x K16 padded factor + inverse blocks that launch_trsm_rows reads (trsm_factor_doubles(K16)
 // doubles at Rout); status: bit 0 non-finite input, bit 1 failed pivot (retry with a larger shift).  work / dsc / minpiv as
 // for launch_chol_large.
 hipError_t launch_chol_factor(const double* G, int n, double shift, double* work, double* dsc, int* status, double* minpiv,
-                              int K16, double* Rout, int form, hipStream_t st);
+                              int K16, double* Rout, hipStream_t st);
 // out[0 .. n) = row maxima of |G - I|, out[n .. 2 n) = row sums of the squared Jacobi-scaled entries (active columns; NaN row
 // maximum = non-finite input): the steering numbers of a row-space pass, so that G itself can stay in HBM
 hipError_t launch_gram_scan(const double* G, int n, double* out, hipStream_t st);
@@ -136,7 +118,7 @@ int residual_num_blocks(int64_t m, int K);
 // sse_part[residual_num_blocks(m, K)] per-workgroup partial SSE (nullptr: none), out[K]
 hipError_t launch_residual_rows(const double* A, int64_t lda, const double* beta, int64_t m, int K, const double* b,
                                 const double* w, const unsigned char* mask, double* partial, double* sse_part, double* out,
-                                hipStream_t st, bool prefetch = false);
+                                hipStream_t st);
 hipError_t launch_colsum(const double* partial, int nparts, int ncols, double* out, hipStream_t st);
 // w[row] = mask[row] ? wtrain[rank[row]] : 0   (rank = exclusive prefix sum of the mask)
 hipError_t launch_expand_weights(const double* wtrain, const unsigned char* mask, const int* rank, int64_t m, double* w,

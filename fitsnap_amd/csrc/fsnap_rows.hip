@@ -292,9 +292,8 @@ __global__ __launch_bounds__(256) void fsnap_gemvT_rows_k(const double* __restri
 //     r_i = keep_i w_i (b_i - a_i . beta)      lane reduction over the 16 lanes of the row (the bits of kernel 4)
 //     s  += a_i (w_i r_i)                      per-lane column accumulators, folded in a fixed order at the end
 // plus the weighted SSE sum r_i^2.  16 lanes per row, a wave takes 8 rows per step (two groups of four); the latency of a
-// step's loads is covered by the other waves of the SIMD (4 at K = 128, 8 at K = 31).  PF = true prefetches the next step's
-// rows into a second register set instead -- half the waves per SIMD, and slower at every shape measured (10^6 x 128: 0.207
-// against 0.198 ms per call, 4 10^6 x 31: 0.356 / 0.238, 200 000 x 200: 0.119 / 0.094; kept for A/B, option fused_residual = 2).  Rows that do not take part (test
+// step's loads is covered by the other waves of the SIMD (4 at K = 128, 8 at K = 31; prefetching the next step's rows into a
+// second register set instead halves the waves per SIMD and measured slower at every shape, round 4).  Rows that do not take part (test
 // rows, rows past m) are zeroed by selects: NaN / Inf in them reach nothing.  K <= 32 NJ (NJ <= 9: 72 VGPRs of row data
 // per set); wider systems keep the two-kernel form.  HBM-bound: 8K + 17 bytes per row.
 // Per-workgroup partial vectors partial[wg][K] (fold: kernel fsnap_colsum_partials_k), sse_part[wg].
@@ -306,7 +305,7 @@ struct ResidualRows {
     bool keep[2];
 };
 
-template <int NJ, bool PF>
+template <int NJ>
 __global__ __launch_bounds__(256) void fsnap_residual_rows_k(const double* __restrict__ A, int64_t lda,
                                                              const double* __restrict__ beta, int64_t m, int K,
                                                              const double* __restrict__ b, const double* __restrict__ w,
@@ -380,19 +379,7 @@ __global__ __launch_bounds__(256) void fsnap_residual_rows_k(const double* __res
     };
 
     int64_t r0 = wave * 8;
-    if constexpr (PF) {
-        ResidualRows<NJ> R0, R1;
-        if (r0 < m) fetch(r0, R0);
-        for (; r0 < m; r0 += 2 * step) {
-            const bool more = r0 + step < m;
-            if (more) fetch(r0 + step, R1);
-            process(R0);
-            if (more) {
-                if (r0 + 2 * step < m) fetch(r0 + 2 * step, R0);
-                process(R1);
-            }
-        }
-    } else {            // no second register set: more waves per SIMD cover the latency (the default)
+    {                   // one register set: the waves of a SIMD cover each other's load latency
         ResidualRows<NJ> R0;
         for (; r0 < m; r0 += step) {
             fetch(r0, R0);
@@ -778,18 +765,11 @@ int residual_num_blocks(int64_t m, int K) {
 // nullptr), out[K]
 hipError_t launch_residual_rows(const double* A, int64_t lda, const double* beta, int64_t m, int K, const double* b,
                                 const double* w, const unsigned char* mask, double* partial, double* sse_part, double* out,
-                                hipStream_t st, bool prefetch) {
+                                hipStream_t st) {
     const int nb = residual_num_blocks(m, K);
     const int nj = (K + 31) / 32;
-#define FSNAP_LAUNCH(NJ)                                                                                                   \
-    do {                                                                                                                   \
-        if (prefetch)                                                                                                      \
-            hipLaunchKernelGGL((fsnap_residual_rows_k<NJ, true>), dim3((unsigned)nb), dim3(256), 0, st, A, lda, beta, m, K, b, \
-                               w, mask, partial, sse_part);                                                                \
-        else                                                                                                               \
-            hipLaunchKernelGGL((fsnap_residual_rows_k<NJ, false>), dim3((unsigned)nb), dim3(256), 0, st, A, lda, beta, m, K, \
-                               b, w, mask, partial, sse_part);                                                             \
-    } while (0)
+#define FSNAP_LAUNCH(NJ) \
+    hipLaunchKernelGGL((fsnap_residual_rows_k<NJ>), dim3((unsigned)nb), dim3(256), 0, st, A, lda, beta, m, K, b, w, mask, partial, sse_part)
     switch (nj) {
         case 1: FSNAP_LAUNCH(1); break;
         case 2: FSNAP_LAUNCH(2); break;

@@ -349,7 +349,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
             int status = 0;
             for (int attempt = 0; attempt < 10; ++attempt) {
                 FSNAP_HIP(fsnap::launch_chol_factor(dp, K, shift, (double*)ctx->dchol.p, d_dsc, d_status, d_minpiv, K16,
-                                                    (double*)rs->Rdev.p, ctx->opt_chol_form, st), "launch device Cholesky (factor)");
+                                                    (double*)rs->Rdev.p, st), "launch device Cholesky (factor)");
                 FSNAP_HIP(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, st), "hipMemcpy(status)");
                 if ((rc = fsnap::wait_stream(ctx, nullptr, "pass factor"))) return rc;
                 if (status == 0) break;

@@ -18,22 +18,18 @@
 // the vector loads of the last row may over-read (they are select-zeroed).
 //
 // Kernels (details at each definition):
-//   1   fsnap_syrk_wave        fused mask x weight x [A|b]^T [A|b], one wave = whole block
-//                              triangle in registers, no LDS (K <= 80; SPLIT = 2 variant for A/B)
-//   1L  fsnap_syrk_lds_static  same statistics for 80 < K <= 128: rows read ONCE per workgroup, weighted once,
-//                              shared through LDS in MFMA-fragment order; per-wave specialised bodies
-//                              (the default before kernel 1A; option kernel = 2).
-//       fsnap_syrk_lds         generic tile-table variant of 1L (A/B)
-//   1P  fsnap_syrk_wave_p      K <= 80 (default): kernel 1 on packed weights, rows masked by the loads
-//   1T  fsnap_syrk_tiled       general K > 128 (default): 64-column superblock pairs x row splits
-//   1T2 fsnap_syrk_tiled2      general K > 128 (option tiled2 = 1): one wave per SIMD, 64 x 128-column items, 32 AGPR tiles
-//   2   fsnap_reduce_partials / fsnap_reduce_tiled   deterministic fixed-order reduction of the
+//   1A  fsnap_syrk_acc         80 < K <= 144: one wave per SIMD owns the whole tile triangle (32 tiles in the
+//                              accumulation registers, named in inline assembly), streams its own rows, no LDS
+//   1P  fsnap_syrk_wave_p      K <= 80: the triangle (<= 15 tiles) in compiler-allocated registers, five waves per
+//                              SIMD, rows masked by the loads
+//   1T  fsnap_syrk_tiled       general K: 64-column superblock pairs x row splits
+//   2b  fsnap_reduce_partials2 / fsnap_reduce_tiled*   deterministic fixed-order reduction of the
 //                              per-workgroup partial triangles -> packed [G | c | scalars];
 //                              un-permutes the even/odd column interleave, mirrors the triangle
-//   1A  fsnap_syrk_acc         80 < K <= 128, DEFAULT: one wave per SIMD owns the whole tile triangle (32 tiles in
-//                              the accumulation registers, named in inline assembly), streams its own rows, no LDS
+//   (1Q / 1QC, 144 < K <= 512: fsnap_syrk_quad.hip.  Kernels 1, 1L, 1T2 and reduction kernel 2 of rounds 1-4 lost
+//   their A/B runs and are gone; their records are in profiles/ and HISTORY.md.)
 //
-// Common operand trick of kernels 1 / 1L / 1T: v_mfma_f64_16x16x4_f64 takes
+// Common operand trick of all SYRK kernels: v_mfma_f64_16x16x4_f64 takes
 // A[i = lane&15][k = lane>>4] and B[k = lane>>4][j = lane&15]; with k = row inside a 4-row
 // chunk and i/j = column inside a 16-column block, the SAME register (w * a[row][col]) is
 // the A operand of tile (p, .) and the B operand of tile (., p): no transposes, A is read
@@ -63,112 +59,9 @@ __host__ __device__ inline int col_of(int bq, int e, int NB) {
     return 32 * (bq >> 1) + 2 * e + (bq & 1);
 }
 
-template <int NB>
-struct ChunkRegs {
-    double v[NB];   // w * a[row][col_of(bq, lane&15)]  (0 for masked / out-of-range)
-    double wb;      // w * b[row]
-    double cnt;     // 1.0 if the row is a training row (only lanes with (lane&15)==0 use it)
-};
-
-// Raw loads of one 4-row chunk.  All global reads of the SYRK kernel go through buffer
-// descriptors (V#) whose num_records ends at the end of the wave's row range: rows past
-// the range (or past m) read back as zero in hardware, so the tail needs no branches
-// and no address clamps, and the per-chunk address arithmetic is one scalar add
-// (soffset) on loop-invariant per-lane voffsets.  Buffer-load intrinsics also keep the
-// hand-written software pipeline intact: with plain pointer loads InstCombine folds
-// phi(load, load) into load(phi) and moves every prefetch to the top of the next
-// iteration, i.e. un-pipelines the loop.
-template <int NB>
-struct ChunkRaw {
-    u4 pr[NB / 2 > 0 ? NB / 2 : 1];
-    u2 tail;
-    u2 bv, wv;
-    unsigned char mk;
-};
-
-struct WaveBufs {
-    __amdgpu_buffer_rsrc_t A, b, w, mask;
-    unsigned voffA;   // per-lane byte offset inside a chunk: (kr*lda + 2e)*8
-    unsigned voffT;   // tail block: (kr*lda + 16*(NB-1) + e)*8
-    unsigned voffR;   // per-lane row offset kr*8 (b, w); mask uses kr
-    unsigned chunk_bytes;  // 4*lda*8
-};
-
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     // dword3 0x00020000: raw buffer, 32-bit data format (gfx9-family encoding)
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-
-template <int NB, bool NT>
-__device__ __forceinline__ void issue_chunk(ChunkRaw<NB>& r, const WaveBufs& wb, unsigned cl, int kr) {
-    // cl = chunk index local to the wave (wave-uniform)
-    const unsigned soff = cl * wb.chunk_bytes;
-    constexpr int AUX = NT ? 2 : 0;  // 2 = nt (streamed once)
-#pragma unroll
-    for (int j = 0; j < NB / 2; ++j) r.pr[j] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, wb.voffA + 256u * j, soff, AUX);
-    if (NB & 1) r.tail = __builtin_amdgcn_raw_buffer_load_b64(wb.A, wb.voffT, soff, AUX);
-    r.bv = __builtin_amdgcn_raw_buffer_load_b64(wb.b, wb.voffR, cl * 32u, 0);
-    r.wv = __builtin_amdgcn_raw_buffer_load_b64(wb.w, wb.voffR, cl * 32u, 0);
-    r.mk = __builtin_amdgcn_raw_buffer_load_b8(wb.mask, (unsigned)kr, cl * 4u, 0);
-}
-
-template <int NB, bool FULLK>
-__device__ __forceinline__ void finish_chunk(ChunkRegs<NB>& c, const ChunkRaw<NB>& r, int K, int e) {
-    const bool keep = (r.mk != 0);
-    const double wv = __builtin_bit_cast(double, r.wv);
-#pragma unroll
-    for (int j = 0; j < NB / 2; ++j) {
-        const d2 x = __builtin_bit_cast(d2, r.pr[j]);
-        double x0 = wv * x[0];
-        double x1 = wv * x[1];
-        bool k0 = keep, k1 = keep;
-        if (!FULLK) {
-            k0 = k0 && (32 * j + 2 * e < K);
-            k1 = k1 && (32 * j + 2 * e + 1 < K);
-        }
-        c.v[2 * j] = k0 ? x0 : 0.0;
-        c.v[2 * j + 1] = k1 ? x1 : 0.0;
-    }
-    if (NB & 1) {
-        double x = wv * __builtin_bit_cast(double, r.tail);
-        bool kt = keep;
-        if (!FULLK) kt = kt && (16 * (NB - 1) + e < K);
-        c.v[NB - 1] = kt ? x : 0.0;
-    }
-    c.wb = keep ? wv * __builtin_bit_cast(double, r.bv) : 0.0;
-    c.cnt = keep ? 1.0 : 0.0;
-}
-
-// One chunk of matrix work for sub-wave SUB of SPLIT: the tiles t of the packed upper
-// triangle with t % SPLIT == SUB (local accumulator index t / SPLIT).
-template <int NB, int SPLIT, int SUB>
-__device__ __forceinline__ void mfma_chunk(d4 (&acc)[(NB * (NB + 1) / 2 + SPLIT - 1) / SPLIT],
-                                           const ChunkRegs<NB>& c) {
-#pragma unroll
-    for (int p = 0; p < NB; ++p) {
-#pragma unroll
-        for (int q = p; q < NB; ++q) {
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int t = tri_index(p, q, NB);
-            if (t % SPLIT == SUB) {
-                acc[t / SPLIT] = __builtin_amdgcn_mfma_f64_16x16x4f64(c.v[p], c.v[q], acc[t / SPLIT], 0, 0, 0);
-            }
-        }
-    }
-}
-
-template <int NB>
-__device__ __forceinline__ void valu_c_chunk(double (&cacc)[NB], const ChunkRegs<NB>& c) {
-#pragma unroll
-    for (int p = 0; p < NB; ++p) cacc[p] = __builtin_fma(c.v[p], c.wb, cacc[p]);
-}
-
-template <int NB>
-__device__ __forceinline__ void valu_s_chunk(double& bb, double& sbw, double& cnt, const ChunkRegs<NB>& c) {
-    bb = __builtin_fma(c.wb, c.wb, bb);
-    sbw += c.wb;
-    cnt += c.cnt;
 }
 
 __device__ __forceinline__ double xlane_sum_rows(double x) {
@@ -178,171 +71,7 @@ __device__ __forceinline__ double xlane_sum_rows(double x) {
     return x;
 }
 
-// Whole life of one wave: stream its chunk range, keep its share of the triangle in
-// registers, write per-row-wave partials.  SUB == 0 additionally carries c / scalars.
-template <int NB, int SPLIT, int SUB, int DEPTH, bool FULLK, bool NT>
-__device__ __forceinline__ void syrk_wave_body(const double* __restrict__ A, int64_t lda,
-                                               const double* __restrict__ b, const double* __restrict__ w,
-                                               const unsigned char* __restrict__ mask, int64_t m, int K,
-                                               int64_t c0, int64_t c1, int64_t rowwave, double* lds,
-                                               double* __restrict__ part, double* __restrict__ cpart,
-                                               double* __restrict__ spart) {
-    constexpr int NTILE = NB * (NB + 1) / 2;
-    constexpr int NTW = (NTILE + SPLIT - 1) / SPLIT;
-    const int lane = threadIdx.x & 63;
-    const int e = lane & 15;
-    const int kr = lane >> 4;
-
-    d4 acc[NTW];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-    double cacc[NB];
-#pragma unroll
-    for (int p = 0; p < NB; ++p) cacc[p] = 0.0;
-    double bb = 0.0, sbw = 0.0, cnt = 0.0;
-
-    ChunkRaw<NB> r0, r1, r2;
-    ChunkRegs<NB> cr;
-
-    // buffer descriptors covering exactly this wave's rows [row0, row1)
-    const int64_t row0 = c0 << 2;
-    int64_t row1 = c1 << 2;
-    if (row1 > m) row1 = m;
-    const int64_t nrow = row1 > row0 ? row1 - row0 : 0;
-    WaveBufs wb;
-    // +16 B: the 16-byte column over-read of the last row (select-zeroed) stays in range
-    wb.A = make_rsrc(A + row0 * lda, (unsigned)(nrow * lda * 8 + (nrow ? 16 : 0)));
-    wb.b = make_rsrc(b + row0, (unsigned)(nrow * 8));
-    wb.w = make_rsrc(w + row0, (unsigned)(nrow * 8));
-    wb.mask = make_rsrc(mask + row0, (unsigned)nrow);
-    wb.voffA = (unsigned)((kr * lda + 2 * e) * 8);
-    wb.voffT = (unsigned)((kr * lda + 16 * (NB - 1) + e) * 8);
-    wb.voffR = (unsigned)(kr * 8);
-    wb.chunk_bytes = (unsigned)(lda * 32);
-    const unsigned ncl = (unsigned)(c1 > c0 ? c1 - c0 : 0);
-
-    // Software pipeline, DEPTH chunks in flight per wave.  The loop body is branch-free
-    // (one scheduling region: DEPTH x {weight, prefetch, MFMAs}); chunk slots past the
-    // wave's range read zeros through the bounds-checked descriptors, so a wave wastes
-    // at most DEPTH-1 chunks of matrix-pipe time.
-#define FSNAP_STAGE(R, OFF)                                                    \
-    finish_chunk<NB, FULLK>(cr, R, K, e);                                       \
-    issue_chunk<NB, NT>(R, wb, cl + (OFF) + DEPTH, kr);                         \
-    mfma_chunk<NB, SPLIT, SUB>(acc, cr);                                        \
-    if (SUB == 0) valu_c_chunk<NB>(cacc, cr);                                   \
-    if (SUB == SPLIT - 1) valu_s_chunk<NB>(bb, sbw, cnt, cr);
-    if (ncl > 0) {
-        issue_chunk<NB, NT>(r0, wb, 0, kr);
-        issue_chunk<NB, NT>(r1, wb, 1, kr);
-        if (DEPTH == 3) issue_chunk<NB, NT>(r2, wb, 2, kr);
-        for (unsigned cl = 0; cl < ncl; cl += DEPTH) {
-            FSNAP_STAGE(r0, 0)
-            FSNAP_STAGE(r1, 1)
-            if (DEPTH == 3) {
-                FSNAP_STAGE(r2, 2)
-            }
-        }
-    }
-#undef FSNAP_STAGE
-
-    // epilogue 1: fold the four row-waves of the workgroup through LDS (two rounds:
-    // {2,3} -> {0,1}, then 1 -> 0) so that only ONE partial triangle per workgroup goes
-    // to HBM.  Slot layout [slot][u][i][lane] doubles: conflict-free ds_write/read_b64.
-    // All waves of the workgroup execute the same three barriers (wave-uniform paths).
-    {
-        const int rw = (int)(rowwave & 3);
-        double* slot_hi = lds + (size_t)(((rw & 1) * SPLIT + SUB) * NTW) * 256;  // rounds use 2*SPLIT / SPLIT slots
-        if (rw >= 2) {
-#pragma unroll
-            for (int u = 0; u < NTW; ++u)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) slot_hi[(u * 4 + i) * 64 + lane] = acc[u][i];
-        }
-        __syncthreads();
-        if (rw < 2) {
-#pragma unroll
-            for (int u = 0; u < NTW; ++u)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[u][i] += slot_hi[(u * 4 + i) * 64 + lane];
-        }
-        __syncthreads();
-        double* slot_lo = lds + (size_t)(SUB * NTW) * 256;
-        if (rw == 1) {
-#pragma unroll
-            for (int u = 0; u < NTW; ++u)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) slot_lo[(u * 4 + i) * 64 + lane] = acc[u][i];
-        }
-        __syncthreads();
-        if (rw == 0) {
-            // epilogue 2: per-workgroup partial, coalesced 512-B stores
-            double* pw = part + (rowwave >> 2) * (int64_t)(NTILE * 256);
-#pragma unroll
-            for (int u = 0; u < NTW; ++u) {
-                const int t = u * SPLIT + SUB;
-                if (t < NTILE) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        pw[(t * 4 + i) * 64 + lane] = acc[u][i] + slot_lo[(u * 4 + i) * 64 + lane];
-                }
-            }
-        }
-    }
-    if (SUB == 0) {
-        double* cw = cpart + rowwave * (int64_t)(NB * 16);
-#pragma unroll
-        for (int p = 0; p < NB; ++p) {
-            double s = xlane_sum_rows(cacc[p]);
-            if (kr == 0) cw[p * 16 + e] = s;
-        }
-    }
-    if (SUB == SPLIT - 1) {
-        // every lane of a 16-lane row group carries the same bb/sbw/cnt
-        double sb = xlane_sum_rows(bb), ss = xlane_sum_rows(sbw), sc = xlane_sum_rows(cnt);
-        if (lane == 0) {
-            double* sw = spart + rowwave * 4;
-            sw[0] = sb;
-            sw[1] = ss;
-            sw[2] = sc;
-            sw[3] = 0.0;
-        }
-    }
-}
-
 }  // namespace
-
-// ---------------------------------------------------------------------------------
-// Kernel 1: fused mask x weight x SYRK.
-// Workgroup = 4 row-waves x SPLIT sub-waves (256*SPLIT threads): row-wave g =
-// blockIdx.x*4 + (wave & 3) streams chunks [g*cpw, (g+1)*cpw) of 4 rows; its SPLIT
-// sub-waves (wave >> 2) read the same rows (second read is an L1/L2 hit) and own
-// disjoint halves of the block triangle, so that at K = 128 each wave holds 18 tiles
-// (144 accumulator registers) and two waves share each SIMD: one wave's loads and
-// weighting overlap the other's MFMAs.
-// Partial layout (doubles): part[workgroup][NT][4][64] (row-waves folded through LDS) |
-// cpart[rowwave][NB][16] | spart[rowwave][4]
-// ---------------------------------------------------------------------------------
-template <int NB, int SPLIT, int DEPTH, bool FULLK, bool NT>
-__global__ __launch_bounds__(256 * SPLIT, ((NB * (NB + 1) / 2 + SPLIT - 1) / SPLIT > 20) ? 1 : 2) void
-fsnap_syrk_wave(const double* __restrict__ A, int64_t lda, const double* __restrict__ b,
-                const double* __restrict__ w, const unsigned char* __restrict__ mask, int64_t m, int K,
-                int64_t chunks_per_wave, double* __restrict__ part, double* __restrict__ cpart,
-                double* __restrict__ spart) {
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t rowwave = (int64_t)blockIdx.x * 4 + (wv & 3);
-    const int sub = wv >> 2;
-    __shared__ double lds[2 * SPLIT * ((NB * (NB + 1) / 2 + SPLIT - 1) / SPLIT) * 256];
-    const int64_t nchunks = (m + 3) >> 2;
-    int64_t c0 = rowwave * chunks_per_wave;
-    int64_t c1 = c0 + chunks_per_wave;
-    if (c1 > nchunks) c1 = nchunks;
-    if (SPLIT == 1 || sub == 0) {
-        syrk_wave_body<NB, SPLIT, 0, DEPTH, FULLK, NT>(A, lda, b, w, mask, m, K, c0, c1, rowwave, lds, part, cpart, spart);
-    } else {
-        syrk_wave_body<NB, SPLIT, (SPLIT > 1 ? 1 : 0), DEPTH, FULLK, NT>(A, lda, b, w, mask, m, K, c0, c1, rowwave, lds,
-                                                                 part, cpart, spart);
-    }
-}
 
 #ifdef FSNAP_TRACE
 // tools/syrk_trace.hip only: per-workgroup {start, end} (100 MHz wall clock), HW_ID, XCC_ID, and
@@ -829,7 +558,7 @@ constexpr int FSNAP_WAVE_P_PACK_PAD = 16;      // chunk slots the loop may look 
 template <int NB, bool FULLK, bool NT, bool PACK>
 __global__ __launch_bounds__(256, 2) void fsnap_syrk_wave_p(const double* __restrict__ A, int64_t lda,
                                                             const double* __restrict__ wpack, int64_t m, int K,
-                                                            int64_t chunks_per_wave, int interleave,
+                                                            int64_t chunks_per_wave,
                                                             double* __restrict__ part, double* __restrict__ cpart,
                                                             const double* __restrict__ bvec, const double* __restrict__ wvec,
                                                             const unsigned char* __restrict__ mask,
@@ -840,30 +569,19 @@ __global__ __launch_bounds__(256, 2) void fsnap_syrk_wave_p(const double* __rest
     const int rw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t rowwave = (int64_t)blockIdx.x * 4 + rw;
     const int64_t nchunks = (m + 3) >> 2;
-    // Which chunks a row-wave takes.  interleave = 0: a contiguous range of chunks_per_wave chunks.  interleave = 1: chunk
-    // rowwave, rowwave + NW, rowwave + 2 NW, ... (NW = row-waves of the grid): at any moment the chip reads ONE advancing
-    // front of consecutive addresses instead of thousands of separate streams (the stand-alone weighting kernel gained
-    // 5.25 -> 6.4 TB/s when it dropped its looping workgroups).  An A/B switch (option "interleave", off by default): at
-    // 10^6 ... 10^7 x 31 both orders stream at the same rate, 5.3 TB/s on the boxes of round 3.  Needs the whole matrix
-    // within reach of a 32-bit buffer offset.
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    int64_t c0, stride, ncl64;
-    if (interleave) {
-        c0 = rowwave < nchunks ? rowwave : nchunks;
-        stride = nwaves;
-        ncl64 = rowwave < nchunks ? (nchunks - rowwave + nwaves - 1) / nwaves : 0;
-    } else {
-        c0 = rowwave * chunks_per_wave;
+    // a row-wave takes a contiguous range of chunks_per_wave chunks (one advancing front over the whole matrix -- chunk
+    // rowwave, rowwave + NW, ... -- streamed at the same rate in round 3 and is gone)
+    int64_t c0 = rowwave * chunks_per_wave, ncl64;
+    const int64_t stride = 1;
+    {
         int64_t c1 = c0 + chunks_per_wave;
         if (c1 > nchunks) c1 = nchunks;
         if (c0 > c1) c0 = c1;
-        stride = 1;
         ncl64 = c1 - c0;
     }
     const int64_t row0 = c0 << 2;
-    // the descriptors end where the wave's last chunk ends (interleaved: at the end of the matrix): chunk slots past
-    // the wave's range read zeros
-    int64_t row1 = interleave ? m : ((c0 + ncl64) << 2);
+    // the descriptors end where the wave's last chunk ends: chunk slots past the wave's range read zeros
+    int64_t row1 = (c0 + ncl64) << 2;
     if (row1 > m) row1 = m;
     const int64_t nrow = (ncl64 > 0 && row1 > row0) ? row1 - row0 : 0;
     WaveBufsP wb;
@@ -989,113 +707,6 @@ __global__ __launch_bounds__(256, 2) void fsnap_syrk_wave_p(const double* __rest
 }
 
 // ---------------------------------------------------------------------------------
-// Kernel 2: deterministic reduction of the partials into the packed statistics buffer
-//   out = [G (K*K row-major) | c (K) | bTb, sum_bw, n_train].
-// One workgroup (1024 threads) = 16 consecutive partial elements x 64 slices of the
-// partial range: thread (g = tid>>4, l = tid&15) sums partials g, g+64, g+128, ... in a
-// fixed order with 8 independent loads in flight, then a fixed-order 64-way LDS
-// combine.  Element space: [0, NT*256) triangle elements (one partial per workgroup of
-// kernel 1), then NB*16 c elements and 4 scalars (one partial per row-wave).
-// The scatter undoes the even/odd column interleave and mirrors the upper triangle.
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void fsnap_reduce_partials(const double* __restrict__ part,
-                                                              const double* __restrict__ cpart,
-                                                              const double* __restrict__ spart, int nblocks,
-                                                              int cs_per_block, int ns, int NB, int K,
-                                                              double* __restrict__ out, double* __restrict__ mirror,
-                                                              int accumulate) {
-    // One workgroup (1024 threads) = 16 consecutive elements (one 128-B line per partial)
-    // x 64 slices of the partial range; ~585 workgroups at K = 128, every load in flight.
-    __shared__ double red[1024];
-    __shared__ double red2[64];
-    const int NTILE = NB * (NB + 1) / 2;
-    const int nG = NTILE * 256, nC = NB * 16, nS = 4;
-    const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
-    const int idx = blockIdx.x * 16 + l;
-    const double* src = nullptr;
-    int64_t stride = 0;
-    int np = nblocks * cs_per_block;  // c / scalar partials per workgroup of kernel 1 / 1L
-    if (idx < nG) {
-        src = part + idx;
-        stride = nG;
-        np = nblocks;
-    } else if (idx < nG + nC) {
-        src = cpart + (idx - nG);
-        stride = nC;
-    } else if (idx < nG + nC + nS) {
-        src = spart + (idx - nG - nC);
-        stride = nS;
-        if (ns >= 0) np = ns;     // scalar partials come from elsewhere (fsnap_pack_weights_k)
-    }
-    double s = 0.0;
-    if (src) {
-        int p = g;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
-        for (; p + 448 < np; p += 512) {
-            const double x0 = src[(int64_t)p * stride], x1 = src[(int64_t)(p + 64) * stride];
-            const double x2 = src[(int64_t)(p + 128) * stride], x3 = src[(int64_t)(p + 192) * stride];
-            const double x4 = src[(int64_t)(p + 256) * stride], x5 = src[(int64_t)(p + 320) * stride];
-            const double x6 = src[(int64_t)(p + 384) * stride], x7 = src[(int64_t)(p + 448) * stride];
-            a0 += x0; a1 += x1; a2 += x2; a3 += x3; a4 += x4; a5 += x5; a6 += x6; a7 += x7;
-        }
-        for (; p < np; p += 64) a0 += src[(int64_t)p * stride];
-        s = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
-    }
-    red[tid] = s;
-    __syncthreads();
-    // fixed-order 64-way combine: 4 threads per element sum 16 slices each, then 4 -> 1
-    if (tid < 64) {
-        const int el = tid & 15, q = tid >> 4;
-        double t4 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t4 += red[(q * 16 + k) * 16 + el];
-        red2[tid] = t4;
-    }
-    __syncthreads();
-    if (tid < 16 && src) {
-        const double tot = (red2[tid] + red2[16 + tid]) + (red2[32 + tid] + red2[48 + tid]);
-        if (idx < nG) {
-            int t = idx >> 8, rem = idx & 255, i = rem >> 6, ln = rem & 63;
-            // invert tri_index: find p with tri_index(p,p) <= t
-            int p = 0;
-            while (p + 1 < NB && tri_index(p + 1, p + 1, NB) <= t) ++p;
-            int q = p + (t - tri_index(p, p, NB));
-            int ep = (ln >> 4) + 4 * i, eq = ln & 15;
-            int r = col_of(p, ep, NB), c = col_of(q, eq, NB);
-            if (r < K && c < K) {
-                // accumulate: out += statistics of these rows (streaming per-batch accumulation, the reference's
-                // `c += cm; d += dm`, transpose_trick/example.py:236-237); (r, c) and (c, r) hold equal values
-                const double val = accumulate ? out[(int64_t)r * K + c] + tot : tot;
-                out[(int64_t)r * K + c] = val;
-                if (p != q) out[(int64_t)c * K + r] = val;
-                if (mirror) {        // page-locked host copy written by the same kernel (no separate D2H copy)
-                    mirror[(int64_t)r * K + c] = val;
-                    if (p != q) mirror[(int64_t)c * K + r] = val;
-                    // compact copy of the diagonal behind the packed statistics: the host's scaling pass needs it
-                    // first, and 128 entries with a 1 KiB stride are 128 cold cache lines
-                    if (r == c) mirror[(int64_t)K * K + K + 3 + r] = val;
-                }
-            }
-        } else if (idx < nG + nC) {
-            int j = idx - nG;
-            int cidx = col_of(j >> 4, j & 15, NB);
-            if (cidx < K) {
-                const double val = accumulate ? out[(int64_t)K * K + cidx] + tot : tot;
-                out[(int64_t)K * K + cidx] = val;
-                if (mirror) mirror[(int64_t)K * K + cidx] = val;
-            }
-        } else {
-            int j = idx - nG - nC;
-            if (j < 3) {
-                const double val = accumulate ? out[(int64_t)K * K + K + j] + tot : tot;
-                out[(int64_t)K * K + K + j] = val;
-                if (mirror) mirror[(int64_t)K * K + K + j] = val;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------
 // Kernel 2b: the same reduction with every load of a thread in flight at once (default; option reduce = 1 keeps
 // kernel 2 for A/B).  Kernel 2 gives a thread 8-byte loads and, for the 256 partials of a one-workgroup-per-CU launch,
 // runs them as FOUR dependent round trips (its 8-deep loop needs >= 512 partials): 12.3 us for 19 MB that sit in
@@ -1192,505 +803,6 @@ __global__ __launch_bounds__(256) void fsnap_reduce_partials2(const double* __re
         out[(int64_t)K * K + K + idx] = val;
         if (mirror) mirror[(int64_t)K * K + K + idx] = val;
     }
-}
-
-// ---------------------------------------------------------------------------------
-// Kernel 1L: fused mask x weight x SYRK for 80 < K <= 128 with the weighted rows SHARED
-// through LDS (the production kernel for the BASELINE 10^6 x 128 shape).
-// A workgroup of NW waves owns a contiguous row range and the WHOLE block triangle; the
-// NT = NB(NB+1)/2 tiles are dealt to the waves in contiguous runs (at NB = 8, NW = 8:
-// waves 0-3 own 5 tiles, waves 4-7 own 4, so every SIMD carries 9).  Rows move in stages
-// of NW chunks (NW x 4 rows): wave v loads chunk v of the next stage from HBM (16-byte
-// buffer loads, each row read exactly ONCE per launch), applies mask and weight once,
-// accumulates c / scalars for that chunk on the VALU and writes the weighted values to
-// LDS in MFMA-fragment order ([chunk][block][lane], conflict-free ds_write/read_b64).
-// After one barrier per stage every wave reads, per chunk, only the operand blocks of
-// its own tiles and issues its MFMAs.  Versus kernel 1 with SPLIT = 2 this halves the
-// L2/HBM request traffic (measured: the duplicate `nt` reads of the two sub-waves MISS in
-// L2 and the chip fetched 2x the algorithmic bytes), and cuts the fp64 VALU work 8x.
-// LDS: 2 stages x NW chunks x NB blocks x 512 B (64 KiB at NB = 8, NW = 8), so two
-// workgroups share a CU.  Partials: part[wg][NT][4][64] | cpart[wg][NB][16] | spart[wg][4].
-// ---------------------------------------------------------------------------------
-namespace {
-
-// NTM = number of tiles THIS wave owns (compile-time: the kernel dispatches on the wave's
-// class so that the stage loop is one branch-free scheduling region).
-template <int NB, int NW, int NTM, bool FULLK, bool NT>
-__device__ __forceinline__ void syrk_lds_body(double* lds, const WaveBufs& wb, int K, unsigned nstage, int wv, int t0,
-                                              double* __restrict__ pw, double* __restrict__ cw,
-                                              double* __restrict__ sw) {
-    constexpr int NTILE = NB * (NB + 1) / 2;
-    constexpr int STAGE_DOUBLES = NW * NB * 64;
-    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
-
-    int tp[NTM], tq[NTM];
-#pragma unroll
-    for (int u = 0; u < NTM; ++u) {
-        int t = t0 + u;
-        if (t >= NTILE) t = NTILE - 1;
-        int p = 0;
-        while (p + 1 < NB && tri_index(p + 1, p + 1, NB) <= t) ++p;
-        tp[u] = p * 64;                                   // LDS offsets (doubles) of the operand blocks
-        tq[u] = (p + (t - tri_index(p, p, NB))) * 64;
-    }
-    d4 acc[NTM];
-#pragma unroll
-    for (int u = 0; u < NTM; ++u) acc[u] = d4{0.0, 0.0, 0.0, 0.0};
-    double cacc[NB];
-#pragma unroll
-    for (int p = 0; p < NB; ++p) cacc[p] = 0.0;
-    double bb = 0.0, sbw = 0.0, cnt = 0.0;
-
-    ChunkRaw<NB> raw;
-    ChunkRegs<NB> cr;
-    // weight the raw chunk in `raw`, accumulate c / scalars, park it in LDS stage `buf`
-    auto park = [&](int buf) {
-        finish_chunk<NB, FULLK>(cr, raw, K, e);
-        valu_c_chunk<NB>(cacc, cr);
-        valu_s_chunk<NB>(bb, sbw, cnt, cr);
-        double* dst = lds + buf * STAGE_DOUBLES + (wv * NB) * 64 + lane;
-#pragma unroll
-        for (int bq = 0; bq < NB; ++bq) dst[bq * 64] = cr.v[bq];
-    };
-
-    if (nstage > 0) {
-        issue_chunk<NB, NT>(raw, wb, (unsigned)wv, kr);
-        park(0);
-        issue_chunk<NB, NT>(raw, wb, (unsigned)(NW + wv), kr);
-        __syncthreads();
-        for (unsigned s = 0; s < nstage; ++s) {
-            const double* src = lds + (s & 1) * STAGE_DOUBLES + lane;
-#pragma unroll
-            for (int c = 0; c < NW; ++c) {
-#pragma unroll
-                for (int u = 0; u < NTM; ++u) {
-                    const double va = src[c * NB * 64 + tp[u]];
-                    const double vb = src[c * NB * 64 + tq[u]];
-                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(va, vb, acc[u], 0, 0, 0);
-                }
-            }
-            // next stage: weight + park what was prefetched, then prefetch the stage after
-            park((s + 1) & 1);
-            issue_chunk<NB, NT>(raw, wb, (s + 2) * NW + wv, kr);
-            __syncthreads();
-        }
-    }
-
-    // epilogue: tiles are disjoint across waves -> straight to the per-workgroup partial
-#pragma unroll
-    for (int u = 0; u < NTM; ++u) {
-        const int t = t0 + u;
-        if (t < NTILE) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pw[(t * 4 + i) * 64 + lane] = acc[u][i];
-        }
-    }
-    // c / scalars: fold the NW per-wave partials through LDS in a fixed order -> one per workgroup
-    // (the stage buffers are free: every wave is past the last barrier of the stage loop)
-    constexpr int CS = NB * 16 + 4;
-    double* fold = lds + wv * CS;
-#pragma unroll
-    for (int p = 0; p < NB; ++p) {
-        double sm = xlane_sum_rows(cacc[p]);
-        if (kr == 0) fold[p * 16 + e] = sm;
-    }
-    double sb = xlane_sum_rows(bb), ss = xlane_sum_rows(sbw), sc = xlane_sum_rows(cnt);
-    if (lane == 0) {
-        fold[NB * 16 + 0] = sb;
-        fold[NB * 16 + 1] = ss;
-        fold[NB * 16 + 2] = sc;
-        fold[NB * 16 + 3] = 0.0;
-    }
-    __syncthreads();
-    if (wv == 0) {
-        for (int j = lane; j < CS; j += 64) {
-            double tot = 0.0;
-#pragma unroll
-            for (int k = 0; k < NW; ++k) tot += lds[k * CS + j];
-            if (j < NB * 16) cw[j] = tot;
-            else sw[j - NB * 16] = tot;
-        }
-    }
-}
-
-}  // namespace
-
-template <int NB, int NW, bool FULLK, bool NT>
-__global__ __launch_bounds__(64 * NW, 4) void fsnap_syrk_lds(const double* __restrict__ A, int64_t lda,
-                                                             const double* __restrict__ b,
-                                                             const double* __restrict__ w,
-                                                             const unsigned char* __restrict__ mask, int64_t m, int K,
-                                                             int64_t chunks_per_wg, double* __restrict__ part,
-                                                             double* __restrict__ cpart, double* __restrict__ spart) {
-    constexpr int NTILE = NB * (NB + 1) / 2;
-    constexpr int NTW = (NTILE + NW - 1) / NW;        // tiles of a "big" wave
-    constexpr int BIG = NTILE - (NTW - 1) * NW;       // number of waves owning NTW tiles (the rest own NTW - 1)
-    __shared__ double lds[2 * NW * NB * 64];
-
-    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t wg = blockIdx.x;
-
-    // row range of this workgroup and the descriptors that bound it
-    const int64_t nchunks = (m + 3) >> 2;
-    int64_t c0 = wg * chunks_per_wg;
-    int64_t c1 = c0 + chunks_per_wg;
-    if (c1 > nchunks) c1 = nchunks;
-    if (c0 > c1) c0 = c1;
-    const int64_t row0 = c0 << 2;
-    int64_t row1 = c1 << 2;
-    if (row1 > m) row1 = m;
-    const int64_t nrow = row1 > row0 ? row1 - row0 : 0;
-    WaveBufs wb;
-    wb.A = make_rsrc(A + row0 * lda, (unsigned)(nrow * lda * 8 + (nrow ? 16 : 0)));
-    wb.b = make_rsrc(b + row0, (unsigned)(nrow * 8));
-    wb.w = make_rsrc(w + row0, (unsigned)(nrow * 8));
-    wb.mask = make_rsrc(mask + row0, (unsigned)nrow);
-    wb.voffA = (unsigned)((kr * lda + 2 * e) * 8);
-    wb.voffT = (unsigned)((kr * lda + 16 * (NB - 1) + e) * 8);
-    wb.voffR = (unsigned)(kr * 8);
-    wb.chunk_bytes = (unsigned)(lda * 32);
-    const unsigned ncl = (unsigned)(c1 - c0);
-    const unsigned nstage = (ncl + NW - 1) / NW;
-
-    double* pw = part + wg * (int64_t)(NTILE * 256);
-    double* cw = cpart + wg * (int64_t)(NB * 16);
-    double* sw = spart + wg * 4;
-    if (wv < BIG) {
-        syrk_lds_body<NB, NW, NTW, FULLK, NT>(lds, wb, K, nstage, wv, wv * NTW, pw, cw, sw);
-    } else {
-        syrk_lds_body<NB, NW, (NTW > 1 ? NTW - 1 : 1), FULLK, NT>(lds, wb, K, nstage, wv,
-                                                                  BIG * NTW + (wv - BIG) * (NTW - 1), pw, cw, sw);
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// Kernel 1L, statically specialised per wave (the default): same algorithm as
-// fsnap_syrk_lds, but every wave runs a body instantiated for ITS tile list, so the
-// operand offsets are instruction immediates (no per-MFMA address VALU) and an A operand
-// shared by consecutive tiles of a row is read from LDS once (common-subexpression of the
-// identical ds_read).  Measured in-kernel (tools/mfma_f64_peak.hip): the matrix pipe issues
-// one fp64 MFMA per 64 cycles; two ds_read_b64 + wait per MFMA cost ~15 %, one fp64 VALU op
-// per MFMA ~7 % — hence fewer LDS reads and fewer VALU ops per MFMA.
-// ---------------------------------------------------------------------------------
-
-namespace {
-
-template <int NB>
-__host__ __device__ constexpr int tile_p_of(int t) {
-    int p = 0;
-    while (p + 1 < NB && tri_index(p + 1, p + 1, NB) <= t) ++p;
-    return p;
-}
-template <int NB>
-__host__ __device__ constexpr int tile_q_of(int t) {
-    return tile_p_of<NB>(t) + (t - tri_index(tile_p_of<NB>(t), tile_p_of<NB>(t), NB));
-}
-
-template <int NB, int NW>
-struct LdsPlan {
-    static constexpr int NTILE = NB * (NB + 1) / 2;
-    static constexpr int NTW = (NTILE + NW - 1) / NW;
-    static constexpr int BIG = NTILE - (NTW - 1) * NW;
-    static constexpr int ntm(int wv) { return wv < BIG ? NTW : NTW - 1; }
-    static constexpr int t0(int wv) { return wv < BIG ? wv * NTW : BIG * NTW + (wv - BIG) * (NTW - 1); }
-};
-
-template <int P, int Q>
-__device__ __forceinline__ void tile_mfma(d4& acc, const double* src) {
-    const double va = src[P * 64];
-    const double vb = src[Q * 64];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va, vb, acc, 0, 0, 0);
-}
-
-template <int NB, int T0, int NTM, int... U>
-__device__ __forceinline__ void chunk_tiles(d4 (&acc)[NTM], const double* src, std::integer_sequence<int, U...>) {
-    (tile_mfma<tile_p_of<NB>(T0 + U), tile_q_of<NB>(T0 + U)>(acc[U], src), ...);
-}
-
-// split form for operand prefetch: LDS reads of one chunk, then (later) its MFMAs
-template <int NB, int T0, int NTM, int... U>
-__device__ __forceinline__ void chunk_load(double (&va)[NTM], double (&vb)[NTM], const double* src,
-                                           std::integer_sequence<int, U...>) {
-    ((va[U] = src[tile_p_of<NB>(T0 + U) * 64], vb[U] = src[tile_q_of<NB>(T0 + U) * 64]), ...);
-}
-template <int NTM, int... U>
-__device__ __forceinline__ void chunk_mfma(d4 (&acc)[NTM], const double (&va)[NTM], const double (&vb)[NTM],
-                                           std::integer_sequence<int, U...>) {
-    ((acc[U] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[U], vb[U], acc[U], 0, 0, 0)), ...);
-}
-
-template <int NB, int NW, int WV, bool FULLK, bool NT, int ABL>
-__device__ __forceinline__ void syrk_lds_static_body(double* lds, const WaveBufs& wb, int K, unsigned nstage,
-                                                     double* __restrict__ pw, double* __restrict__ cw,
-                                                     double* __restrict__ sw) {
-    using Plan = LdsPlan<NB, NW>;
-    constexpr int NTILE = Plan::NTILE;
-    constexpr int NTM = Plan::ntm(WV) > 0 ? Plan::ntm(WV) : 1;
-    constexpr bool HAS_TILES = Plan::ntm(WV) > 0;
-    constexpr int T0 = Plan::t0(WV);
-    constexpr int STAGE_DOUBLES = NW * NB * 64;
-    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
-
-    d4 acc[NTM];
-#pragma unroll
-    for (int u = 0; u < NTM; ++u) acc[u] = d4{0.0, 0.0, 0.0, 0.0};
-    double cacc[NB];
-#pragma unroll
-    for (int p = 0; p < NB; ++p) cacc[p] = 0.0;
-    double bb = 0.0, sbw = 0.0, cnt = 0.0;
-
-    ChunkRaw<NB> raw;
-    ChunkRegs<NB> cr;
-    // ABL != 0: diagnostic ablations (wrong results, timing only; option "ablate"):
-    //   1 = no HBM loads in the stage loop, 2 = no weighting / c VALU work in park,
-    //   3 = no barriers in the stage loop, 4 = MFMA operands not re-read from LDS
-    auto park = [&](int buf) {
-        if (ABL == 2) {
-#pragma unroll
-            for (int j = 0; j < NB / 2; ++j) {
-                const d2 x = __builtin_bit_cast(d2, raw.pr[j]);
-                cr.v[2 * j] = x[0];
-                cr.v[2 * j + 1] = x[1];
-            }
-        } else {
-            finish_chunk<NB, FULLK>(cr, raw, K, e);
-            valu_c_chunk<NB>(cacc, cr);
-            valu_s_chunk<NB>(bb, sbw, cnt, cr);
-        }
-        double* dst = lds + buf * STAGE_DOUBLES + (WV * NB) * 64 + lane;
-#pragma unroll
-        for (int bq = 0; bq < NB; ++bq) dst[bq * 64] = cr.v[bq];
-    };
-
-    // co-resident workgroups differ in blockIdx / (number of CUs); gridDim / 2 (or / 3) separates the layers
-    const unsigned prio_phase = (ABL == 8) ? (unsigned)(blockIdx.x >= (gridDim.x + 1) / 2) : 0u;
-    if (nstage > 0) {
-        issue_chunk<NB, NT>(raw, wb, (unsigned)WV, kr);
-        park(0);
-        issue_chunk<NB, NT>(raw, wb, (unsigned)(NW + WV), kr);
-        __syncthreads();
-#if defined(FSNAP_TRACE) && FSNAP_TRACE >= 2
-        unsigned long long tr_mfma = 0, tr_park = 0, tr_bar = 0;
-#endif
-        for (unsigned s = 0; s < nstage; ++s) {
-#if defined(FSNAP_TRACE) && FSNAP_TRACE >= 2
-            FSNAP_TRACE_CLK(tr0);
-#endif
-            const double* src = lds + ((ABL == 4) ? 0 : (s & 1)) * STAGE_DOUBLES + lane;
-            // ABL == 6: the younger wave of each SIMD (WV >= NW/2; the SIMD serves its older wave
-            // first) parks the next stage's chunk BEFORE its MFMA phase, i.e. while the older wave
-            // owns the matrix pipe, instead of after it on the stage's critical path
-            constexpr bool EARLY = (ABL == 6) && (WV >= NW / 2);
-            if (EARLY) {
-                park((s + 1) & 1);
-                issue_chunk<NB, NT>(raw, wb, (s + 2) * NW + WV, kr);
-            }
-            // ABL 7 / 8: wave priorities.  The SIMD arbiter serves the highest s_setprio level first and
-            // only then the oldest wave; a wave in its MFMA phase outranks waves that are parking /
-            // issuing loads, so their VALU / LDS / VMEM instructions fill the 60 idle issue cycles
-            // between two MFMAs instead of delaying one.  ABL 8 additionally alternates, stage by
-            // stage, which of the co-resident workgroups wins ties (fair progress, no tail in which
-            // the younger workgroup runs alone).
-            if (ABL == 7) __builtin_amdgcn_s_setprio(2);
-            if (ABL == 8) {
-                if ((s ^ prio_phase) & 1u) __builtin_amdgcn_s_setprio(3);
-                else __builtin_amdgcn_s_setprio(2);
-            }
-            if (ABL == 9 || ABL == 10) {
-                // Interleaved park: the weighting / mask / c work of this wave's next chunk is cut into NB
-                // per-block pieces that are issued BETWEEN the MFMA groups of the stage (a wave issues in
-                // order: VALU / LDS-write instructions placed after the last MFMA of a stage run with the
-                // matrix pipe idle, placed between MFMAs they run in the shadow of the 64-cycle MFMA).
-                const bool keep = (raw.mk != 0);
-                const double wv = __builtin_bit_cast(double, raw.wv);
-                const double wbv = keep ? wv * __builtin_bit_cast(double, raw.bv) : 0.0;
-                double* dst = lds + ((s + 1) & 1) * STAGE_DOUBLES + (WV * NB) * 64 + lane;
-                // ABL == 10: additionally the LDS operands of chunk c + 1 are requested before the MFMAs of chunk c
-                constexpr auto seq = std::make_integer_sequence<int, NTM>{};
-                double oa[2][NTM], ob[2][NTM];
-                if (ABL == 10 && HAS_TILES) chunk_load<NB, T0, NTM>(oa[0], ob[0], src, seq);
-#pragma unroll
-                for (int c = 0; c < NW; ++c) {
-                    if (ABL == 10) {
-                        if (HAS_TILES) {
-                            if (c + 1 < NW) chunk_load<NB, T0, NTM>(oa[(c + 1) & 1], ob[(c + 1) & 1], src + (c + 1) * NB * 64, seq);
-                            chunk_mfma<NTM>(acc, oa[c & 1], ob[c & 1], seq);
-                        }
-                    } else if (HAS_TILES) {
-                        chunk_tiles<NB, T0, NTM>(acc, src + c * NB * 64, seq);
-                    }
-#pragma unroll
-                    for (int j = c * NB / NW; j < (c + 1) * NB / NW; ++j) {
-                        double x;
-                        bool kj = keep;
-                        if ((NB & 1) && j == NB - 1) {
-                            x = __builtin_bit_cast(double, raw.tail);
-                            if (!FULLK) kj = kj && (16 * (NB - 1) + e < K);
-                        } else {
-                            x = __builtin_bit_cast(d2, raw.pr[j >> 1])[j & 1];
-                            if (!FULLK) kj = kj && (32 * (j >> 1) + 2 * e + (j & 1) < K);
-                        }
-                        const double vj = kj ? wv * x : 0.0;
-                        cacc[j] = __builtin_fma(vj, wbv, cacc[j]);
-                        dst[j * 64] = vj;
-                    }
-                    if (c == NW - 1) {
-                        bb = __builtin_fma(wbv, wbv, bb);
-                        sbw += wbv;
-                        cnt += keep ? 1.0 : 0.0;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                issue_chunk<NB, NT>(raw, wb, (s + 2) * NW + WV, kr);
-                __syncthreads();
-                continue;
-            }
-            if (HAS_TILES) {
-                if (ABL == 5) {
-                    // operand prefetch: the LDS reads of chunk c + 1 are issued BEFORE the MFMAs of chunk c
-                    // (double-buffered operand registers; sched_barriers pin the order), so that the matrix
-                    // pipe never waits on lgkmcnt inside a stage
-                    constexpr auto seq = std::make_integer_sequence<int, NTM>{};
-                    double oa[2][NTM], ob[2][NTM];
-                    chunk_load<NB, T0, NTM>(oa[0], ob[0], src, seq);
-#pragma unroll
-                    for (int c = 0; c < NW; ++c) {
-                        if (c + 1 < NW) chunk_load<NB, T0, NTM>(oa[(c + 1) & 1], ob[(c + 1) & 1], src + (c + 1) * NB * 64, seq);
-                        __builtin_amdgcn_sched_barrier(0);
-                        chunk_mfma<NTM>(acc, oa[c & 1], ob[c & 1], seq);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < NW; ++c)
-                        chunk_tiles<NB, T0, NTM>(acc, src + ((ABL == 4) ? 0 : c) * NB * 64, std::make_integer_sequence<int, NTM>{});
-                }
-            }
-#if defined(FSNAP_TRACE) && FSNAP_TRACE >= 2
-            FSNAP_TRACE_CLK(tr1);
-#endif
-            if (ABL == 7 || ABL == 8) __builtin_amdgcn_s_setprio(0);
-            if (!EARLY) {
-                park((s + 1) & 1);
-                if (ABL != 1) issue_chunk<NB, NT>(raw, wb, (s + 2) * NW + WV, kr);
-            }
-#if defined(FSNAP_TRACE) && FSNAP_TRACE >= 2
-            FSNAP_TRACE_CLK(tr2);
-#endif
-            if (ABL != 3) __syncthreads();
-#if defined(FSNAP_TRACE) && FSNAP_TRACE >= 2
-            FSNAP_TRACE_CLK(tr3);
-            tr_mfma += tr1 - tr0;
-            tr_park += tr2 - tr1;
-            tr_bar += tr3 - tr2;
-#endif
-        }
-#if defined(FSNAP_TRACE) && FSNAP_TRACE >= 2
-        if (lane == 0 && blockIdx.x < 4096) {
-            unsigned long long* o = fsnap_trace_wave + ((size_t)blockIdx.x * 16 + WV) * 4;
-            o[0] = tr_mfma;
-            o[1] = tr_park;
-            o[2] = tr_bar;
-            o[3] = nstage;
-        }
-#endif
-    }
-
-    if (HAS_TILES) {
-#pragma unroll
-        for (int u = 0; u < NTM; ++u) {
-            const int t = T0 + u;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pw[(t * 4 + i) * 64 + lane] = acc[u][i];
-        }
-    }
-    constexpr int CS = NB * 16 + 4;
-    double* fold = lds + WV * CS;
-#pragma unroll
-    for (int p = 0; p < NB; ++p) {
-        double sm = xlane_sum_rows(cacc[p]);
-        if (kr == 0) fold[p * 16 + e] = sm;
-    }
-    double sb = xlane_sum_rows(bb), ss = xlane_sum_rows(sbw), sc = xlane_sum_rows(cnt);
-    if (lane == 0) {
-        fold[NB * 16 + 0] = sb;
-        fold[NB * 16 + 1] = ss;
-        fold[NB * 16 + 2] = sc;
-        fold[NB * 16 + 3] = 0.0;
-    }
-    __syncthreads();
-    if (WV == 0) {
-        for (int j = lane; j < CS; j += 64) {
-            double tot = 0.0;
-#pragma unroll
-            for (int k = 0; k < NW; ++k) tot += lds[k * CS + j];
-            if (j < NB * 16) cw[j] = tot;
-            else sw[j - NB * 16] = tot;
-        }
-    }
-}
-
-template <int NB, int NW, bool FULLK, bool NT, int ABL, int... W>
-__device__ __forceinline__ void syrk_lds_dispatch(int wv, double* lds, const WaveBufs& wb, int K, unsigned nstage,
-                                                  double* pw, double* cw, double* sw, std::integer_sequence<int, W...>) {
-    // every wave of the workgroup takes exactly one branch; all bodies execute the same barriers
-    ((wv == W ? (syrk_lds_static_body<NB, NW, W, FULLK, NT, ABL>(lds, wb, K, nstage, pw, cw, sw), 0) : 0), ...);
-}
-
-}  // namespace
-
-template <int NB, int NW, bool FULLK, bool NT, int ABL = 0>
-__global__ __launch_bounds__(64 * NW, (NW == 2 ? 2 : NW == 4 ? 3 : 4)) void fsnap_syrk_lds_static(const double* __restrict__ A, int64_t lda,
-                                                                    const double* __restrict__ b,
-                                                                    const double* __restrict__ w,
-                                                                    const unsigned char* __restrict__ mask, int64_t m,
-                                                                    int K, int64_t chunks_per_wg,
-                                                                    double* __restrict__ part,
-                                                                    double* __restrict__ cpart,
-                                                                    double* __restrict__ spart) {
-    constexpr int NTILE = NB * (NB + 1) / 2;
-    __shared__ double lds[2 * NW * NB * 64];
-#ifdef FSNAP_TRACE
-    const unsigned long long trace_t0 = wall_clock64();
-    const unsigned long long trace_c0 = __builtin_readcyclecounter();
-#endif
-    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t wg = blockIdx.x;
-    const int64_t nchunks = (m + 3) >> 2;
-    int64_t c0 = wg * chunks_per_wg;
-    int64_t c1 = c0 + chunks_per_wg;
-    if (c1 > nchunks) c1 = nchunks;
-    if (c0 > c1) c0 = c1;
-    const int64_t row0 = c0 << 2;
-    int64_t row1 = c1 << 2;
-    if (row1 > m) row1 = m;
-    const int64_t nrow = row1 > row0 ? row1 - row0 : 0;
-    WaveBufs wb;
-    wb.A = make_rsrc(A + row0 * lda, (unsigned)(nrow * lda * 8 + (nrow ? 16 : 0)));
-    wb.b = make_rsrc(b + row0, (unsigned)(nrow * 8));
-    wb.w = make_rsrc(w + row0, (unsigned)(nrow * 8));
-    wb.mask = make_rsrc(mask + row0, (unsigned)nrow);
-    wb.voffA = (unsigned)((kr * lda + 2 * e) * 8);
-    wb.voffT = (unsigned)((kr * lda + 16 * (NB - 1) + e) * 8);
-    wb.voffR = (unsigned)(kr * 8);
-    wb.chunk_bytes = (unsigned)(lda * 32);
-    const unsigned ncl = (unsigned)(c1 - c0);
-    const unsigned nstage = (ncl + NW - 1) / NW;
-    double* pw = part + wg * (int64_t)(NTILE * 256);
-    double* cw = cpart + wg * (int64_t)(NB * 16);
-    double* sw = spart + wg * 4;
-    syrk_lds_dispatch<NB, NW, FULLK, NT, ABL>(wv, lds, wb, K, nstage, pw, cw, sw, std::make_integer_sequence<int, NW>{});
-#ifdef FSNAP_TRACE
-    if (threadIdx.x == 0 && wg < 4096) {
-        fsnap_trace_buf[wg * 8 + 0] = trace_t0;
-        fsnap_trace_buf[wg * 8 + 1] = wall_clock64();
-        fsnap_trace_buf[wg * 8 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
-        fsnap_trace_buf[wg * 8 + 3] = __builtin_amdgcn_s_getreg((3 << 11) | 20);    // HW_REG_XCC_ID[3:0]
-        fsnap_trace_buf[wg * 8 + 4] = __builtin_readcyclecounter() - trace_c0;      // shader-clock cycles of the workgroup's life
-    }
-#endif
 }
 
 // ---------------------------------------------------------------------------------
@@ -1973,53 +1085,17 @@ template <bool NT>
 __global__ __launch_bounds__(256, 2) void fsnap_syrk_tiled(const double* __restrict__ A, int64_t lda,
                                                            const double* __restrict__ wpack, int64_t m, int K,
                                                            int NSB, int npairs, int64_t chunks_per_split,
-                                                           int nitems, int xcd_map, int ring,
+                                                           int nitems,
                                                            double* __restrict__ part, double* __restrict__ cpart) {
     __shared__ double lds[2 * 16 * 256];
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // Work item = (split, pair), pair fastest.  Workgroups are dealt round-robin to the 8 XCDs
-    // (blockIdx % 8); with xcd_map every XCD gets a CONTIGUOUS range of items, so the
+    // (blockIdx % 8); every XCD gets a CONTIGUOUS range of items, so the
     // workgroups that share an L2 sweep the same rows (different column pairs) together and a
     // row slab is fetched from HBM once per XCD instead of once per pair.
     unsigned item = blockIdx.x;
     int I, J, split;
-    if (xcd_map == 2) {
-        // CLASS-major order inside an XCD: the XCD owns a contiguous range of SPLITS; its workgroups run, split after
-        // split, first all full off-diagonal pairs (16 tiles per chunk), then the pairs with the half-empty last superblock
-        // (8), then the diagonal ones (10 / 3).  Items that run side by side then advance through their rows at the same
-        // pace -- with every class of a split resident at once (the (split, pair) order) the fast items run ahead, the
-        // window of rows the group keeps alive outgrows the 4 MB L2 and each pair fetches its rows from HBM again
-        // (367 900 x 480: 6.3 GB per launch for a 1.4 GB matrix, L2 hit rate 45 %).  The price: a split's rows are swept
-        // once per class instead of once.
-        const int nsplit = nitems / npairs;
-        const int xcd = (int)(blockIdx.x & 7u);
-        const int S0 = (int)((int64_t)xcd * nsplit / 8), S1 = (int)((int64_t)(xcd + 1) * nsplit / 8), ns = S1 - S0;
-        int slot = (int)(blockIdx.x >> 3);
-        if (slot >= ns * npairs) return;
-        const bool ragged = (K & 63) != 0 && NSB > 1;      // the last superblock is short: its off-diagonal pairs are a class
-        const int NF = ragged ? NSB - 1 : NSB;             // superblocks whose mutual pairs are full
-        const int n0 = NF * (NF - 1) / 2, n1 = ragged ? NSB - 1 : 0;
-        if (slot < n0 * ns) {                               // class 0: (I, J) row-major in the strict upper triangle of NF
-            split = S0 + slot / n0;
-            int rem = slot % n0;
-            I = 0;
-            while (rem >= NF - 1 - I) {
-                rem -= NF - 1 - I;
-                ++I;
-            }
-            J = I + 1 + rem;
-        } else if (slot < (n0 + n1) * ns) {                 // class 1: (I, NSB - 1)
-            slot -= n0 * ns;
-            split = S0 + slot / n1;
-            I = slot % n1;
-            J = NSB - 1;
-        } else {                                            // class 2: the diagonal
-            slot -= (n0 + n1) * ns;
-            split = S0 + slot / NSB;
-            I = J = slot % NSB;
-        }
-    } else {
-    if (xcd_map) {
+    {
         const unsigned per = ((unsigned)nitems + 7u) >> 3;
         const unsigned slot = blockIdx.x >> 3;
         item = (blockIdx.x & 7u) * per + slot;
@@ -2043,7 +1119,6 @@ __global__ __launch_bounds__(256, 2) void fsnap_syrk_tiled(const double* __restr
     } else {
         I = J = id - noff;
     }
-    }
     const int pair = I * NSB - (I * (I - 1)) / 2 + (J - I);      // slot in the packed upper triangle (partials)
     const int64_t nchunks = (m + 3) >> 2;
     const int64_t cpw = (chunks_per_split + 3) >> 2;
@@ -2060,245 +1135,15 @@ __global__ __launch_bounds__(256, 2) void fsnap_syrk_tiled(const double* __restr
     // 2 = only the first 32-column group does (blocks 2, 3 are empty: their tiles are skipped), 0 = no edge
     const int tail = K & 63;
     const int edge = (J == NSB - 1 && tail != 0) ? (tail <= 32 ? 2 : 4) : 0;
+    // (both kinds of items run the ring form of the load pipeline, see syrk_tiled_body)
     if (I == J) {
-        if (ring & 1) {     // diagonal items on the ring form of the pipeline (see syrk_tiled_body)
-            if (edge == 2) syrk_tiled_body<true, 2, NT, true>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
-            else if (edge == 4) syrk_tiled_body<true, 4, NT, true>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
-            else syrk_tiled_body<true, 0, NT, true>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
-        } else if (edge == 2) syrk_tiled_body<true, 2, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
-        else if (edge == 4) syrk_tiled_body<true, 4, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
-        else syrk_tiled_body<true, 0, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
-    } else if (ring & 2) {
+        if (edge == 2) syrk_tiled_body<true, 2, NT, true>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+        else if (edge == 4) syrk_tiled_body<true, 4, NT, true>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+        else syrk_tiled_body<true, 0, NT, true>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
+    } else {
         if (edge == 2) syrk_tiled_body<false, 2, NT, true>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
         else if (edge == 4) syrk_tiled_body<false, 4, NT, true>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
         else syrk_tiled_body<false, 0, NT, true>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
-    } else {
-        if (edge == 2) syrk_tiled_body<false, 2, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
-        else if (edge == 4) syrk_tiled_body<false, 4, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
-        else syrk_tiled_body<false, 0, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// Kernel 1T2: the tiled kernel with kernel 1A's register plan.  One wave per SIMD (one 4-wave workgroup per CU);
-// an off-diagonal work item is a 64-column superblock I against a PAIR of superblocks (J0, J0 + 1) right of it:
-// 32 tiles in the 256 accumulation registers a[0:255], named by the MFMAs in inline assembly like kernel 1A.
-// Per 4-row chunk a lane loads 4 + 8 doubles and feeds 32 MFMAs (the 16-tile items of kernel 1T: 4 + 4 for 16);
-// the J side goes from the load registers straight into the MFMAs, the I side is multiplied by w^2 one step ahead,
-// block by block, right after the MFMA row that last used the old value.  Four raw sets: rows three chunks ahead.
-// The pairs this shape cannot cover -- the diagonal (I, I), its right neighbour (I, I + 1) for even I, and the lone
-// last column when the number of superblocks is odd -- are work items of the same kernel and run kernel 1T's
-// 16-tile body.  Items come from a table built by the host (heavy items first).
-// Measured (15 213 x 1 595, PMC): matrix pipe busy 75.7 % of the kernel (kernel 1T: 78 %), L2 hit rate 76 % (69 %),
-// HBM-side fetch 0.99 GB (1.82 GB) per launch, kernel time 0.72 ms (0.69 ms): no faster, and slower for few superblocks
-// (K = 256: 0.36 vs 0.25 ms) -- kept as an option for A/B, kernel 1T stays the default.
-// Partials: as kernel 1T (one 16-tile block per 64-column superblock pair and split).
-// ---------------------------------------------------------------------------------
-namespace {
-
-struct RawT2 {
-    u4 pi[2], pj[4];
-    u2 wp;      // w_eff of the lane's row
-};
-
-template <int EDGE, bool NT>
-__device__ __forceinline__ void issue_rows_t2(RawT2& r, const WaveBufsT& wb, unsigned voffI, unsigned voffJ, unsigned cl) {
-    const unsigned soff = cl * wb.chunk_bytes;
-    constexpr int AUX = NT ? 2 : 0;
-    const bool keep = pack_keep_w(r.wp);
-    const unsigned vi = keep ? voffI : FSNAP_OOB_VOFF;
-    const unsigned vj = keep ? voffJ : FSNAP_OOB_VOFF;
-    r.pi[0] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, vi, soff, AUX);
-    r.pi[1] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, vi + 256u, soff, AUX);
-    r.pj[0] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, vj, soff, AUX);
-    r.pj[1] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, vj + 256u, soff, AUX);
-    r.pj[2] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, vj + 512u, soff, AUX);
-    if (EDGE != 2) r.pj[3] = __builtin_amdgcn_raw_buffer_load_b128(wb.A, vj + 768u, soff, AUX);
-}
-
-// B operand block q (0..7) of the 128-column J range: the loaded value itself; with EDGE the second superblock is
-// the last one of the matrix and its columns >= K are zeroed by selects (EDGE == 2: its blocks 6, 7 are empty)
-template <int EDGE>
-__device__ __forceinline__ double vj_block_t2(const RawT2& r, int q, int colJ0, int K, int e) {
-    if (EDGE == 2 && q >= 6) return 0.0;
-    const double x = __builtin_bit_cast(d2, r.pj[q >> 1])[q & 1];
-    if (EDGE != 0 && q >= 4) return (colJ0 + 32 * (q >> 1) + 2 * e + (q & 1) < K) ? x : 0.0;
-    return x;
-}
-
-template <int T, bool SKIP>
-__device__ __forceinline__ void t2_mfma(double a, double b, d4 (&vt)[4]) {
-    if constexpr (!SKIP) acc_mfma<T>(a, b, vt);
-}
-
-template <int P, int EDGE, int... Q>
-__device__ __forceinline__ void t2_row(double vi, const double (&vj)[8], d4 (&vt)[4], std::integer_sequence<int, Q...>) {
-    (t2_mfma<P * 8 + Q, (EDGE == 2 && Q >= 6)>(vi, vj[Q], vt), ...);
-}
-
-// step c: MFMAs of chunk c (A operands VI prepared one step ago, B operands = raw set RC), VI <- w^2 x rows of chunk
-// c + 1 (raw set RN) block by block behind the MFMA rows, rows of chunk c + 3 into the raw set RF consumed one step
-// ago (its packed weights were loaded two steps ago), packed weights of chunk c + 5 into RN's slot.
-template <int EDGE, bool NT>
-__device__ __forceinline__ void t2_step(double (&VI)[4], d4 (&vt)[4], const RawT2& RC, RawT2& RN, RawT2& RF,
-                                        const WaveBufsT& wb, unsigned voffI, unsigned voffJ, unsigned clf, int colJ0,
-                                        int K, int e) {
-    const double wn = __builtin_bit_cast(double, RN.wp);
-    const double w2 = wn * wn;
-    double vj[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) vj[q] = vj_block_t2<EDGE>(RC, q, colJ0, K, e);
-    RN.wp = load_pack_w(wb, clf + 2);       // packed weights TWO steps ahead of the rows they gate (chunk c + 5, used by
-    __builtin_amdgcn_sched_barrier(0);      // the refill in step c + 2) and BEFORE this step's row loads: vmcnt retires
-                                            // in order, the wait for them must not drain the rows issued meanwhile
-    issue_rows_t2<EDGE, NT>(RF, wb, voffI, voffJ, clf);
-    __builtin_amdgcn_sched_barrier(0);
-    constexpr auto cols = std::make_integer_sequence<int, 8>{};
-    t2_row<0, EDGE>(VI[0], vj, vt, cols);
-    VI[0] = w2 * __builtin_bit_cast(d2, RN.pi[0])[0];
-    __builtin_amdgcn_sched_barrier(0);
-    t2_row<1, EDGE>(VI[1], vj, vt, cols);
-    VI[1] = w2 * __builtin_bit_cast(d2, RN.pi[0])[1];
-    __builtin_amdgcn_sched_barrier(0);
-    t2_row<2, EDGE>(VI[2], vj, vt, cols);
-    VI[2] = w2 * __builtin_bit_cast(d2, RN.pi[1])[0];
-    __builtin_amdgcn_sched_barrier(0);
-    t2_row<3, EDGE>(VI[3], vj, vt, cols);
-    VI[3] = w2 * __builtin_bit_cast(d2, RN.pi[1])[1];
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-template <int EDGE, bool NT>
-__device__ __forceinline__ void syrk_tiled2_body(const double* __restrict__ A, int64_t lda,
-                                                 const double* __restrict__ wpack, int64_t m, int K, int I, int J0,
-                                                 int64_t c0, int64_t c1, int rw, double* lds,
-                                                 double* __restrict__ pw0, double* __restrict__ pw1) {
-    const int lane = threadIdx.x & 63, e = lane & 15, kr = lane >> 4;
-    const int64_t row0 = c0 << 2;
-    int64_t row1 = c1 << 2;
-    if (row1 > m) row1 = m;
-    const int64_t nrow = row1 > row0 ? row1 - row0 : 0;
-    WaveBufsT wb;
-    wb.A = make_rsrc(A + row0 * lda, (unsigned)(nrow * lda * 8 + (nrow ? 16 : 0)));
-    wb.wp = make_rsrc(wpack + 2 * row0, (unsigned)(nrow * 16));
-    wb.voffP = (unsigned)(kr * 16);
-    wb.chunk_bytes = (unsigned)(lda * 32);
-    const unsigned voffI = (unsigned)((kr * lda + 64 * I + 2 * e) * 8);
-    const unsigned voffJ = (unsigned)((kr * lda + 64 * J0 + 2 * e) * 8);
-    const unsigned ncl = (unsigned)(c1 > c0 ? c1 - c0 : 0);
-
-    acc_zero_all(std::make_integer_sequence<int, 256>{});
-    d4 vt[4];      // unused (every tile lives in an accumulation register); acc_mfma's signature
-#pragma unroll
-    for (int u = 0; u < 4; ++u) vt[u] = d4{0.0, 0.0, 0.0, 0.0};
-    double VI[4] = {0.0, 0.0, 0.0, 0.0};
-    RawT2 s0, s1, s2, s3;
-    if (ncl > 0) {
-        s0.wp = load_pack_w(wb, 0);
-        s1.wp = load_pack_w(wb, 1);
-        s2.wp = load_pack_w(wb, 2);
-        s3.wp = load_pack_w(wb, 3);
-        issue_rows_t2<EDGE, NT>(s0, wb, voffI, voffJ, 0);
-        issue_rows_t2<EDGE, NT>(s1, wb, voffI, voffJ, 1);
-        issue_rows_t2<EDGE, NT>(s2, wb, voffI, voffJ, 2);
-        {
-            const double w0 = __builtin_bit_cast(double, s0.wp);
-            const double w2 = w0 * w0;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) VI[p] = w2 * __builtin_bit_cast(d2, s0.pi[p >> 1])[p & 1];
-        }
-        s0.wp = load_pack_w(wb, 4);
-        for (unsigned cl = 0; cl < ncl; cl += 4) {
-            t2_step<EDGE, NT>(VI, vt, s0, s1, s3, wb, voffI, voffJ, cl + 3, 64 * J0, K, e);
-            t2_step<EDGE, NT>(VI, vt, s1, s2, s0, wb, voffI, voffJ, cl + 4, 64 * J0, K, e);
-            t2_step<EDGE, NT>(VI, vt, s2, s3, s1, wb, voffI, voffJ, cl + 5, 64 * J0, K, e);
-            t2_step<EDGE, NT>(VI, vt, s3, s0, s2, wb, voffI, voffJ, cl + 6, 64 * J0, K, e);
-        }
-    }
-    // the last MFMAs (16 passes) must have left the pipe before their accumulators are read
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(vt[0]));
-    // fold the four row-waves through LDS in two halves of 16 tiles (4 slots x 16 tiles x 2 KiB = 128 KiB); wave r
-    // then sums a quarter of the tiles over the four slots in a fixed order and stores them
-    auto fold_half = [&](auto half_tag) {
-        constexpr int H = decltype(half_tag)::value;
-        double* slot = lds + (size_t)rw * 16 * 256;
-        {
-            d4 tmp[16];
-            acc_read_range<16 * H>(tmp, vt, std::make_integer_sequence<int, 16>{});
-#pragma unroll
-            for (int u = 0; u < 16; ++u)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) slot[(u * 4 + i) * 64 + lane] = tmp[u][i];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int uu = 0; uu < 4; ++uu) {
-            const int u = rw * 4 + uu;                 // tile 16 H + u = (p, q) with p = 2 H + (u >> 3), q = u & 7
-            const int p = 2 * H + (u >> 3), q = u & 7;
-            double* dst = ((q < 4) ? pw0 : pw1) + (size_t)(p * 4 + (q & 3)) * 256;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int o = (u * 4 + i) * 64 + lane;
-                const double s01 = lds[o] + lds[16 * 256 + o];
-                dst[i * 64 + lane] = (s01 + lds[2 * 16 * 256 + o]) + lds[3 * 16 * 256 + o];
-            }
-        }
-        if (H == 0) __syncthreads();
-    };
-    fold_half(std::integral_constant<int, 0>{});
-    fold_half(std::integral_constant<int, 1>{});
-}
-
-}  // namespace
-
-template <bool NT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void
-fsnap_syrk_tiled2(const double* __restrict__ A, int64_t lda, const double* __restrict__ wpack, int64_t m, int K, int NSB,
-                  int npairs, const int* __restrict__ items, int items_per_split, int64_t chunks_per_split, int nitems,
-                  int xcd_map, double* __restrict__ part, double* __restrict__ cpart) {
-    __shared__ double lds[4 * 16 * 256];
-    // the compiler must count a[0:255] as used (see kernel 1A)
-    asm volatile("" : : : "a0", "a255");
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    unsigned item = blockIdx.x;
-    if (xcd_map) {
-        const unsigned per = ((unsigned)nitems + 7u) >> 3;
-        const unsigned slot = blockIdx.x >> 3;
-        item = (blockIdx.x & 7u) * per + slot;
-        if (slot >= per || item >= (unsigned)nitems) return;
-    }
-    const int local = (int)(item % (unsigned)items_per_split);
-    const int split = (int)(item / (unsigned)items_per_split);
-    const int type = items[4 * local], I = items[4 * local + 1], J = items[4 * local + 2], pair = items[4 * local + 3];
-    const int64_t nchunks = (m + 3) >> 2;
-    const int64_t cpw = (chunks_per_split + 3) >> 2;
-    int64_t s0 = (int64_t)split * chunks_per_split;
-    int64_t s1 = s0 + chunks_per_split;
-    if (s1 > nchunks) s1 = nchunks;
-    int64_t c0 = s0 + (int64_t)wv * cpw;
-    int64_t c1 = c0 + cpw;
-    if (c1 > s1) c1 = s1;
-    if (c0 > s1) c0 = s1;
-    double* pw = part + ((int64_t)split * npairs + pair) * (16 * 256);
-    const int tail = K & 63;
-    if (type == 0) {
-        // superblock I against the superblock pair (J, J + 1), both right of I; J + 1 may be the last superblock
-        const int edge = (J + 1 == NSB - 1 && tail != 0) ? (tail <= 32 ? 2 : 4) : 0;
-        if (edge == 2) syrk_tiled2_body<2, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, pw + 16 * 256);
-        else if (edge == 4) syrk_tiled2_body<4, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, pw + 16 * 256);
-        else syrk_tiled2_body<0, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, pw + 16 * 256);
-    } else {
-        double* cw = cpart + (((int64_t)split * NSB + I) * 4 + wv) * 64;
-        const int edge = (J == NSB - 1 && tail != 0) ? (tail <= 32 ? 2 : 4) : 0;
-        if (I == J) {
-            if (edge == 2) syrk_tiled_body<true, 2, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
-            else if (edge == 4) syrk_tiled_body<true, 4, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
-            else syrk_tiled_body<true, 0, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
-        } else {
-            if (edge == 2) syrk_tiled_body<false, 2, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
-            else if (edge == 4) syrk_tiled_body<false, 4, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
-            else syrk_tiled_body<false, 0, NT>(A, lda, wpack, m, K, I, J, c0, c1, wv, lds, pw, cw);
-        }
     }
 }
 
@@ -2324,6 +1169,7 @@ __device__ __forceinline__ void reduce_tiled_store_g(int64_t idx, double tot, in
         if (!(I == J && p == q)) out[(int64_t)c * K + r] = val;
     }
 }
+
 
 // Few row splits (<= 16, the usual case for wide matrices): one thread per G element sums its partials in order --
 // the same order and therefore the same bits as the sliced kernel below, which for <= 16 partials keeps 15 of its 16
@@ -2417,27 +1263,6 @@ namespace fsnap {
 
 int syrk_num_blocks(int K) { return (K + 15) / 16; }
 
-template <int NB, int SPLIT>
-static hipError_t launch_syrk_nb(const SyrkArgs& a, hipStream_t st) {
-    constexpr int DEPTH = (SPLIT == 2 && NB >= 7) ? 2 : 3;
-    dim3 grid((unsigned)a.nblocks), block(256 * SPLIT);
-    const bool fullk = (a.K == 16 * NB);
-#define FSNAP_LAUNCH(FK, NTL)                                                                              \
-    hipLaunchKernelGGL((fsnap_syrk_wave<NB, SPLIT, DEPTH, FK, NTL>), grid, block, 0, st, a.A, a.lda, a.b, a.w, a.mask, \
-                       a.m, a.K, a.chunks_per_wave, a.part, a.cpart, a.spart)
-    if (fullk) {
-        if (a.nontemporal) FSNAP_LAUNCH(true, true);
-        else FSNAP_LAUNCH(true, false);
-    } else {
-        if (a.nontemporal) FSNAP_LAUNCH(false, true);
-        else FSNAP_LAUNCH(false, false);
-    }
-#undef FSNAP_LAUNCH
-    return hipGetLastError();
-}
-
-int syrk_default_split(int K) { return syrk_num_blocks(K) >= 6 ? 2 : 1; }
-
 // waves per SIMD the register budget of the (NB, SPLIT) instantiation admits
 int syrk_waves_per_simd(int K, int split) {
     const int NB = syrk_num_blocks(K);
@@ -2447,107 +1272,6 @@ int syrk_waves_per_simd(int K, int split) {
     if (wps < 1) wps = 1;
     if (wps > 8) wps = 8;
     return wps;
-}
-
-template <int NB, int NW>
-static hipError_t launch_syrk_lds_nb(const SyrkArgs& a, hipStream_t st) {
-    dim3 grid((unsigned)a.nblocks), block(64 * NW);
-    const bool fullk = (a.K == 16 * NB);
-#define FSNAP_LAUNCH(FK, NTL)                                                                                  \
-    hipLaunchKernelGGL((fsnap_syrk_lds<NB, NW, FK, NTL>), grid, block, 0, st, a.A, a.lda, a.b, a.w, a.mask, a.m, \
-                       a.K, a.chunks_per_wave, a.part, a.cpart, a.spart)
-    if (fullk) {
-        if (a.nontemporal) FSNAP_LAUNCH(true, true);
-        else FSNAP_LAUNCH(true, false);
-    } else {
-        if (a.nontemporal) FSNAP_LAUNCH(false, true);
-        else FSNAP_LAUNCH(false, false);
-    }
-#undef FSNAP_LAUNCH
-    return hipGetLastError();
-}
-
-template <int NB, int NW>
-static hipError_t launch_syrk_lds_static_nb(const SyrkArgs& a, hipStream_t st) {
-    dim3 grid((unsigned)a.nblocks), block(64 * NW);
-    const bool fullk = (a.K == 16 * NB);
-#define FSNAP_ABL(N)                                                                                               \
-    hipLaunchKernelGGL((fsnap_syrk_lds_static<8, 8, true, true, N>), grid, block, 0, st, a.A, a.lda, a.b, a.w, a.mask, \
-                       a.m, a.K, a.chunks_per_wave, a.part, a.cpart, a.spart)
-    if (NB == 8 && fullk && a.ablate == 5) {        // operand-prefetch variant (correct results; A/B)
-        hipLaunchKernelGGL((fsnap_syrk_lds_static<8, NW, true, true, 5>), grid, block, 0, st, a.A, a.lda, a.b, a.w, a.mask,
-                           a.m, a.K, a.chunks_per_wave, a.part, a.cpart, a.spart);
-        return hipGetLastError();
-    }
-#define FSNAP_VARIANT(N)                                                                                           \
-    if (NB == 8 && fullk && a.ablate == N) {                                                                       \
-        hipLaunchKernelGGL((fsnap_syrk_lds_static<8, NW, true, true, N>), grid, block, 0, st, a.A, a.lda, a.b, a.w, \
-                           a.mask, a.m, a.K, a.chunks_per_wave, a.part, a.cpart, a.spart);                         \
-        return hipGetLastError();                                                                                  \
-    }
-    FSNAP_VARIANT(6)   // early park (correct results; A/B)
-    FSNAP_VARIANT(7)   // wave priorities by phase
-    FSNAP_VARIANT(8)   // wave priorities by phase + alternating tie-break between co-resident workgroups
-    FSNAP_VARIANT(9)   // park work interleaved with the MFMA groups
-    FSNAP_VARIANT(10)  // ... plus LDS operand prefetch one chunk ahead
-#undef FSNAP_VARIANT
-    if (NB == 8 && NW == 8 && fullk && a.ablate) {   // timing-only diagnostic variants (option "ablate")
-        switch (a.ablate) {
-            case 1: FSNAP_ABL(1); break;
-            case 2: FSNAP_ABL(2); break;
-            case 3: FSNAP_ABL(3); break;
-            default: FSNAP_ABL(4); break;
-        }
-        return hipGetLastError();
-    }
-#undef FSNAP_ABL
-    if (fullk)
-        hipLaunchKernelGGL((fsnap_syrk_lds_static<NB, NW, true, true>), grid, block, 0, st, a.A, a.lda, a.b, a.w, a.mask,
-                           a.m, a.K, a.chunks_per_wave, a.part, a.cpart, a.spart);
-    else
-        hipLaunchKernelGGL((fsnap_syrk_lds_static<NB, NW, false, true>), grid, block, 0, st, a.A, a.lda, a.b, a.w, a.mask,
-                           a.m, a.K, a.chunks_per_wave, a.part, a.cpart, a.spart);
-    return hipGetLastError();
-}
-
-// a.split = 8: statically specialised kernel 1L (default); a.split = -8: the generic
-// (run-time tile table) variant kept for A/B; a.chunks_per_wave = chunks per workgroup
-hipError_t launch_syrk_lds(const SyrkArgs& a, hipStream_t st) {
-    const int nb = syrk_num_blocks(a.K);
-    if (a.split == 16) {   // one 16-wave workgroup per CU (A/B variant, NB = 8 only)
-        if (nb != 8) return hipErrorInvalidValue;
-        return launch_syrk_lds_static_nb<8, 16>(a, st);
-    }
-    if (a.split == 2) {    // 2-wave workgroups, 18 tiles per wave (two waves per SIMD)
-        switch (nb) {
-            case 6: return launch_syrk_lds_static_nb<6, 2>(a, st);
-            case 7: return launch_syrk_lds_static_nb<7, 2>(a, st);
-            case 8: return launch_syrk_lds_static_nb<8, 2>(a, st);
-            default: return hipErrorInvalidValue;
-        }
-    }
-    if (a.split == 4) {    // four 4-wave workgroups per CU (one wave per SIMD each), 9 tiles per wave
-        switch (nb) {
-            case 6: return launch_syrk_lds_static_nb<6, 4>(a, st);
-            case 7: return launch_syrk_lds_static_nb<7, 4>(a, st);
-            case 8: return launch_syrk_lds_static_nb<8, 4>(a, st);
-            default: return hipErrorInvalidValue;
-        }
-    }
-    if (a.split == 8) {
-        switch (nb) {
-            case 6: return launch_syrk_lds_static_nb<6, 8>(a, st);
-            case 7: return launch_syrk_lds_static_nb<7, 8>(a, st);
-            case 8: return launch_syrk_lds_static_nb<8, 8>(a, st);
-            default: return hipErrorInvalidValue;
-        }
-    }
-    switch (nb) {
-        case 6: return launch_syrk_lds_nb<6, 8>(a, st);
-        case 7: return launch_syrk_lds_nb<7, 8>(a, st);
-        case 8: return launch_syrk_lds_nb<8, 8>(a, st);
-        default: return hipErrorInvalidValue;
-    }
 }
 
 template <int NB>
@@ -2579,14 +1303,14 @@ template <int NB>
 static hipError_t launch_syrk_wave_p_nb(const SyrkArgs& a, hipStream_t st) {
     dim3 grid((unsigned)a.nblocks), block(256);
     const bool fullk = (a.K == 16 * NB);
-    if (a.fused_pack ? (!a.b || !a.w || !a.mask || !a.spart || a.interleave) : !a.wpack) return hipErrorInvalidValue;
+    if (a.fused_pack ? (!a.b || !a.w || !a.mask || !a.spart) : !a.wpack) return hipErrorInvalidValue;
     constexpr size_t fold_bytes = (size_t)2 * (NB * (NB + 1) / 2) * 256 * sizeof(double);
     const size_t pair_bytes = a.fused_pack ? (size_t)4 * (size_t)(a.chunks_per_wave + FSNAP_WAVE_P_PACK_PAD) * 64 : 0;
     const size_t lds = pair_bytes > fold_bytes ? pair_bytes : fold_bytes;
     if (lds > 64 * 1024) return hipErrorInvalidValue;           // (the planner keeps the pairs within the default dynamic limit)
 #define FSNAP_LAUNCH(FK, NTL, PK)                                                                                      \
     hipLaunchKernelGGL((fsnap_syrk_wave_p<NB, FK, NTL, PK>), grid, block, lds, st, a.A, a.lda, a.wpack, a.m, a.K,       \
-                       a.chunks_per_wave, a.interleave ? 1 : 0, a.part, a.cpart, a.b, a.w, a.mask, a.spart)
+                       a.chunks_per_wave, a.part, a.cpart, a.b, a.w, a.mask, a.spart)
 #define FSNAP_LAUNCH_PK(FK, NTL)                       \
     do {                                               \
         if (a.fused_pack) FSNAP_LAUNCH(FK, NTL, true); \
@@ -2641,39 +1365,10 @@ hipError_t launch_syrk_acc(const SyrkArgs& a, hipStream_t st) {
     }
 }
 
-hipError_t launch_syrk(const SyrkArgs& a, hipStream_t st) {
-    const int nb = syrk_num_blocks(a.K);
-    if (a.split == 2) {
-        switch (nb) {
-            case 6: return launch_syrk_nb<6, 2>(a, st);
-            case 7: return launch_syrk_nb<7, 2>(a, st);
-            case 8: return launch_syrk_nb<8, 2>(a, st);
-            default: return hipErrorInvalidValue;
-        }
-    }
-    if (a.split != 1) return hipErrorInvalidValue;
-    switch (nb) {
-        case 1: return launch_syrk_nb<1, 1>(a, st);
-        case 2: return launch_syrk_nb<2, 1>(a, st);
-        case 3: return launch_syrk_nb<3, 1>(a, st);
-        case 4: return launch_syrk_nb<4, 1>(a, st);
-        case 5: return launch_syrk_nb<5, 1>(a, st);
-        case 6: return launch_syrk_nb<6, 1>(a, st);
-        default: return hipErrorInvalidValue;
-    }
-}
-
 hipError_t launch_reduce(const double* part, const double* cpart, const double* spart, int nblocks,
                          int cs_per_block, int ns, int K, double* out, double* mirror, bool accumulate, hipStream_t st,
-                         int variant, bool upper_mirror) {
+                         bool upper_mirror) {
     const int NB = syrk_num_blocks(K);
-    if (variant == 1) {       // kernel 2 (A/B)
-        const int nelem = NB * (NB + 1) / 2 * 256 + NB * 16 + 4;
-        dim3 grid((unsigned)((nelem + 15) / 16)), block(1024);
-        hipLaunchKernelGGL(fsnap_reduce_partials, grid, block, 0, st, part, cpart, spart, nblocks, cs_per_block, ns, NB, K, out,
-                           mirror, accumulate ? 1 : 0);
-        return hipGetLastError();
-    }
     const int ngroups = NB * (NB + 1) / 2 * 8 + (NB * 16 + 31) / 32 + 1;
     hipLaunchKernelGGL(fsnap_reduce_partials2, dim3((unsigned)ngroups), dim3(256), 0, st, part, cpart, spart, nblocks,
                        cs_per_block, ns, NB, K, out, mirror, accumulate ? 1 : 0, upper_mirror ? 1 : 0);
@@ -2682,30 +1377,14 @@ hipError_t launch_reduce(const double* part, const double* cpart, const double* 
 
 hipError_t launch_syrk_tiled(const TiledArgs& a, hipStream_t st) {
     const int nitems = (int)((int64_t)a.npairs * a.nsplit);
-    // xcd_order 2: every XCD owns ceil(nsplit / 8) splits at most, class-major inside (see the kernel)
-    // (it needs a few splits per XCD: with fewer than 16 splits it would leave XCDs idle)
-    const int xmode = a.xcd_map ? ((a.xcd_order == 2 && a.nsplit >= 16) ? 2 : 1) : 0;
-    const int64_t per_xcd = xmode == 2 ? (int64_t)((a.nsplit + 7) / 8) * a.npairs : (nitems + 7) / 8;
-    dim3 grid((unsigned)(xmode ? 8 * per_xcd : nitems)), block(256);
+    const int64_t per_xcd = (nitems + 7) / 8;
+    dim3 grid((unsigned)(8 * per_xcd)), block(256);
     if (a.nontemporal)
         hipLaunchKernelGGL((fsnap_syrk_tiled<true>), grid, block, 0, st, a.A, a.lda, a.wpack, a.m, a.K, a.NSB,
-                           a.npairs, a.chunks_per_split, nitems, xmode, a.ring, a.part, a.cpart);
+                           a.npairs, a.chunks_per_split, nitems, a.part, a.cpart);
     else
         hipLaunchKernelGGL((fsnap_syrk_tiled<false>), grid, block, 0, st, a.A, a.lda, a.wpack, a.m, a.K, a.NSB,
-                           a.npairs, a.chunks_per_split, nitems, xmode, a.ring, a.part, a.cpart);
-    return hipGetLastError();
-}
-
-hipError_t launch_syrk_tiled2(const TiledArgs& a, hipStream_t st) {
-    const int nitems = (int)((int64_t)a.items_per_split * a.nsplit);
-    dim3 grid((unsigned)(a.xcd_map ? 8 * ((nitems + 7) / 8) : nitems)), block(256);
-    if (!a.items) return hipErrorInvalidValue;
-    if (a.nontemporal)
-        hipLaunchKernelGGL((fsnap_syrk_tiled2<true>), grid, block, 0, st, a.A, a.lda, a.wpack, a.m, a.K, a.NSB, a.npairs,
-                           a.items, a.items_per_split, a.chunks_per_split, nitems, (int)a.xcd_map, a.part, a.cpart);
-    else
-        hipLaunchKernelGGL((fsnap_syrk_tiled2<false>), grid, block, 0, st, a.A, a.lda, a.wpack, a.m, a.K, a.NSB, a.npairs,
-                           a.items, a.items_per_split, a.chunks_per_split, nitems, (int)a.xcd_map, a.part, a.cpart);
+                           a.npairs, a.chunks_per_split, nitems, a.part, a.cpart);
     return hipGetLastError();
 }
 

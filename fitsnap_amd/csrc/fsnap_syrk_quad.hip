@@ -715,15 +715,29 @@ fsnap_syrk_quadc(const double* __restrict__ A, int64_t lda, int64_t m, int K, in
 #undef FSNAP_QC_CASE
 }
 
+// The instantiations are compiled in three parts (fitsnap_amd/build.py: -DFSNAP_QUAD_PART=0 | 1 | 2, three objects in parallel:
+// one translation unit with all 23 widths took three minutes, the longest of the build); without the macro (tools that
+// include this file) everything is in one unit.
+#ifndef FSNAP_QUAD_PART
+#define FSNAP_QUAD_PART_ALL 1
+#define FSNAP_QUAD_PART 0
+#endif
+
 namespace fsnap {
 
+hipError_t launch_syrk_quad_part1(const SyrkArgs& a, hipStream_t st);     // NB = 19 ... 25
+hipError_t launch_syrk_quad_part2(const SyrkArgs& a, hipStream_t st);     // NB = 26 ... 32
+
 // chunks per workgroup up to which the workgroup's per-row pairs fit the LDS next to the look-ahead pad
-int64_t syrk_quad_max_cpg() { return QUAD_LDS_DOUBLES / 8 - QUAD_PACK_PAD; }
+static int64_t quad_max_cpg() { return QUAD_LDS_DOUBLES / 8 - QUAD_PACK_PAD; }
+
+#if FSNAP_QUAD_PART == 0
+int64_t syrk_quad_max_cpg() { return quad_max_cpg(); }
 
 template <int NB>
 static hipError_t launch_syrk_quad_nb(const SyrkArgs& a, hipStream_t st) {
     dim3 grid((unsigned)a.nblocks), block(256);
-    if (a.fused_pack ? (!a.b || !a.w || !a.mask || !a.spart || a.chunks_per_wave > syrk_quad_max_cpg()) : !a.wpack)
+    if (a.fused_pack ? (!a.b || !a.w || !a.mask || !a.spart || a.chunks_per_wave > quad_max_cpg()) : !a.wpack)
         return hipErrorInvalidValue;
 #define FSNAP_LAUNCH(FK, PK)                                                                                                   \
     hipLaunchKernelGGL((fsnap_syrk_quad<NB, FK, PK>), grid, block, 0, st, a.A, a.lda, a.wpack, a.m, a.K, a.chunks_per_wave, a.part, \
@@ -738,34 +752,23 @@ static hipError_t launch_syrk_quad_nb(const SyrkArgs& a, hipStream_t st) {
 #undef FSNAP_LAUNCH
     return hipGetLastError();
 }
+#endif
 
 // kernel 1QC (NB = 19 ... 32): a.nblocks CLUSTERS of quad_cluster(NB) workgroups, a.chunks_per_wave = chunks per cluster,
 // a.flow_words (4 ints per cluster, zero-initialised once, never reset) and a.flow_tag (+ 2^20 per launch)
 template <int NB>
 static hipError_t launch_syrk_quadc_nb(const SyrkArgs& a, hipStream_t st) {
     constexpr int C = quad_cluster(NB);
-    if (!a.b || !a.w || !a.mask || !a.spart || !a.flow_words || a.chunks_per_wave > syrk_quad_max_cpg()) return hipErrorInvalidValue;
+    if (!a.b || !a.w || !a.mask || !a.spart || !a.flow_words || a.chunks_per_wave > quad_max_cpg()) return hipErrorInvalidValue;
     const unsigned per_xcd = (unsigned)((a.nblocks + 7) / 8) * C;
     hipLaunchKernelGGL((fsnap_syrk_quadc<NB>), dim3(8 * per_xcd), dim3(256), 0, st, a.A, a.lda, a.m, a.K, a.chunks_per_wave,
                        (int)a.nblocks, a.part, a.cpart, a.b, a.w, a.mask, a.spart, a.flow_words, a.flow_tag);
     return hipGetLastError();
 }
 
-int syrk_quad_cluster(int K) { return quad_cluster((K + 15) / 16); }
-
-// kernel 1Q: a.nblocks workgroups, a.chunks_per_wave = 4-row chunks per WORKGROUP (its four waves sweep the same rows);
-// a.fused_pack: the kernel forms the per-row pairs itself (b, w, mask, spart), otherwise it reads a.wpack
-hipError_t launch_syrk_quad(const SyrkArgs& a, hipStream_t st) {
+#if FSNAP_QUAD_PART == 1 || defined(FSNAP_QUAD_PART_ALL)
+hipError_t launch_syrk_quad_part1(const SyrkArgs& a, hipStream_t st) {
     switch ((a.K + 15) / 16) {
-        case 10: return launch_syrk_quad_nb<10>(a, st);
-        case 11: return launch_syrk_quad_nb<11>(a, st);
-        case 12: return launch_syrk_quad_nb<12>(a, st);
-        case 13: return launch_syrk_quad_nb<13>(a, st);
-        case 14: return launch_syrk_quad_nb<14>(a, st);
-        case 15: return launch_syrk_quad_nb<15>(a, st);
-        case 16: return launch_syrk_quad_nb<16>(a, st);
-        case 17: return launch_syrk_quad_nb<17>(a, st);
-        case 18: return launch_syrk_quad_nb<18>(a, st);
         case 19: return launch_syrk_quadc_nb<19>(a, st);
         case 20: return launch_syrk_quadc_nb<20>(a, st);
         case 21: return launch_syrk_quadc_nb<21>(a, st);
@@ -773,6 +776,14 @@ hipError_t launch_syrk_quad(const SyrkArgs& a, hipStream_t st) {
         case 23: return launch_syrk_quadc_nb<23>(a, st);
         case 24: return launch_syrk_quadc_nb<24>(a, st);
         case 25: return launch_syrk_quadc_nb<25>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+#endif
+
+#if FSNAP_QUAD_PART == 2 || defined(FSNAP_QUAD_PART_ALL)
+hipError_t launch_syrk_quad_part2(const SyrkArgs& a, hipStream_t st) {
+    switch ((a.K + 15) / 16) {
         case 26: return launch_syrk_quadc_nb<26>(a, st);
         case 27: return launch_syrk_quadc_nb<27>(a, st);
         case 28: return launch_syrk_quadc_nb<28>(a, st);
@@ -783,5 +794,28 @@ hipError_t launch_syrk_quad(const SyrkArgs& a, hipStream_t st) {
         default: return hipErrorInvalidValue;
     }
 }
+#endif
+
+#if FSNAP_QUAD_PART == 0
+int syrk_quad_cluster(int K) { return quad_cluster((K + 15) / 16); }
+
+// kernel 1Q: a.nblocks workgroups, a.chunks_per_wave = 4-row chunks per WORKGROUP (its four waves sweep the same rows);
+// a.fused_pack: the kernel forms the per-row pairs itself (b, w, mask, spart), otherwise it reads a.wpack
+hipError_t launch_syrk_quad(const SyrkArgs& a, hipStream_t st) {
+    const int nb = (a.K + 15) / 16;
+    switch (nb) {
+        case 10: return launch_syrk_quad_nb<10>(a, st);
+        case 11: return launch_syrk_quad_nb<11>(a, st);
+        case 12: return launch_syrk_quad_nb<12>(a, st);
+        case 13: return launch_syrk_quad_nb<13>(a, st);
+        case 14: return launch_syrk_quad_nb<14>(a, st);
+        case 15: return launch_syrk_quad_nb<15>(a, st);
+        case 16: return launch_syrk_quad_nb<16>(a, st);
+        case 17: return launch_syrk_quad_nb<17>(a, st);
+        case 18: return launch_syrk_quad_nb<18>(a, st);
+        default: return nb >= 19 && nb <= 25 ? launch_syrk_quad_part1(a, st) : nb >= 26 && nb <= 32 ? launch_syrk_quad_part2(a, st) : hipErrorInvalidValue;
+    }
+}
+#endif
 
 }  // namespace fsnap

@@ -481,12 +481,6 @@ class Solver:
             ctx.drop_rows()                 # rows of an EARLIER fit must not stand in for this rank's empty share
             self._resident_key = None
         if pt.multi:
-            if getattr(ctx, "options", {}).get("dist_solve"):
-                # the reduce-to-root form leaves the statistics on rank 0 only; everything behind a fit here (refinement,
-                # last_statistics, the row-space switch) needs them on every rank -- refuse on ALL ranks alike, before
-                # the collective, instead of diverging on the ranks that would hold a NULL pointer
-                raise RuntimeError("option dist_solve = 1 is a benchmark A/B of fsnap_fit_dist; the solver classes need the "
-                                   "all-reduce form (dist_solve = 0)")
             beta, rank, rcond, ptr = ctx.fit_dist(kind, param, K)       # collective
         else:
             beta, rank, rcond, ptr = ctx.fit_resident(kind, param)      # kernel + reduction + K x K solve, one library call

@@ -73,64 +73,41 @@ int fsnap_ctx_set_stream(fsnap_ctx* ctx, void* hip_stream);
 /* Go back to the context's own non-blocking stream. */
 int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
 
-/* Tuning knobs (all optional; 0 = auto): "kernel" (1 wave-triangle, 2 LDS-shared rows with
- * per-wave specialised bodies, 3 LDS-shared generic variant), "split" (1|2, sub-waves per row-wave of kernel 1),
- * "nontemporal" (0|1), "interleave" (0|1, default 0; 1: the K <= 80 kernel deals the 4-row chunks round-robin to its waves -- one
- * advancing front of addresses -- instead of one contiguous range per wave: an A/B switch, no difference measured), "nblocks" (workgroups of the SYRK kernel), "tiled" (1 = force the
- * general-K tiled kernel also for K <= 128), "nsplit" (row splits of the tiled kernel), "mirror" (0|1, see fsnap_normal_eq_resident), "xcd" (0|1: tiled kernel deals contiguous work-item ranges to each XCD), "tiled2" (0|1: K > 128 on the one-wave-per-SIMD kernel with 64 x 128-column work items, default 0),
- * "tiled_ring" (0 ... 3, default 3: bit 0 / bit 1 put the diagonal / off-diagonal work items of the tiled kernel on the ring form of its
- * load pipeline; 0 = the three-set form of round 2, for A/B runs -- same bits either way),
- * "device_solve" (fsnap_solve_device: 0 = auto: K >= 232 is factorised on the GPU by the blocked kernels; 1 = every K on the GPU; 2 = never),
- * "chol_form" (panel loop of that GPU factorisation: -1 = default -- the FSNAP_CHOL_DIAG environment variable, else 5; 5 = ONE launch
- * per 64-row panel, every wave substituting the row tails it needs itself, diagonal block on four waves; 4 = two launches per panel,
- * four-wave diagonal block; 0 | 1 | 2 = two launches per panel, single-wave diagonal block with pivot chain 0 / 1 / 2 (rounds 2-4); A/B),
- * "repack" (1 = recompute the packed per-row weights (mask * w, mask * w * b) and the b-only scalars on EVERY fit even
- * when b, w and the mask are context-owned and unchanged; default 0 = once per fsnap_set_weights / fsnap_upload_rows),
- * "timing_every" (N: HIP events bracket every N-th SYRK launch only -- an event record between two dependent kernels idles
- * the stream for ~5.6 us; 0 = no events, default 1 = every launch; the first launch after the option is set is a sampled one; fsnap_timing /
- * fsnap_timing_history see the sampled ones),
- * "dist_solve" (fsnap_fit_dist: 0 = in-place all-reduce + solve on every rank, the default; 1 = reduce to rank 0, solve there,
- * broadcast [beta | rank | rcond | status] -- for A/B runs of the scaling benchmark; the reduced statistics then exist on
- * rank 0 only and *d_packed comes back NULL on the other ranks),
- * "comm_timeout" (seconds, 0 = the FSNAP_COMM_TIMEOUT environment default: bound of every wait behind a collective of this
- * context and of fsnap_comm_init -- a phase that may fail without taking the job with it sets a short one),
- * "fused_pack" (0|1, default 1: the 80 < K <= 144 kernel forms the per-row pairs (mask * w, mask * w * b) of its rows in LDS inside
- * the SYRK launch -- no packing launch, nothing of them in HBM -- whenever a workgroup's rows fit; 0 = separate packing kernel, A/B),
- * "acc_min_cpw" (tuning aid: fewest 4-row chunks per row-wave of the 80 < K <= 144 kernel before its grid shrinks below one workgroup
- * per CU; 0 = default 12 -- 6 ... 9 measured within noise of it on 13 035 x 142 and 15 213 x 128),
- * "quad" (0|1, default 1: 145 ... 288 columns go to kernel 1Q -- the tile triangle dealt to the four waves of a workgroup, which sweep
- * the same rows, fsnap_syrk_quad.hip -- when the system has at least "quad_min_rows" rows (-1 = default 8192) and a workgroup's per-row
- * pairs fit the LDS (up to ~2.6 M rows; beyond, the pairs are packed into HBM first); 0 = the tiled kernel there, A/B;
- * "quad_min_cpg": fewest 4-row chunks per workgroup of that kernel before its grid shrinks, 0 = default 24, tuning aid),
- * "quad_cluster" (0|1, default 1: 289 ... 512 columns go to kernel 1QC -- kernel 1Q's plan on a cluster of 2 (up to 368 columns) or 4
- * workgroups placed on one XCD, which sweep the same rows behind a bounded flow-control counter so that HBM sees every row once --
- * when the rows' pairs fit the LDS (fused packing, up to ~650 000 rows on 256 CUs) and the system has at least 300 000 rows
- * ("quad_min_rows" overrides; shorter systems are faster on the tiled kernel); 0 = the tiled kernel there, A/B;
- * "quad_flow" = mode + 4 x lead: that kernel's flow control between the workgroups of a cluster -- mode 0 off (1.8 x the
- * algorithmic HBM reads at 367 900 x 480, 2 % faster), 1 = every member publishes its trip count and looks at its peers at the end
- * of a trip, 2 (default) = at the start of the trip, judged at its end; lead = trips a member may run ahead (default 63 = by cluster
- * size: 0 for clusters of two, 2 for clusters of four)),
- * "acc_max_k" (144 | 128: widest system on the accumulator-resident kernel; 128 sends 129 ... 144 columns to the tiled kernel, A/B),
- * "reduce" (0 = reduction kernel 2b with every load of a thread in flight, the default; 1 = its predecessor, A/B),
- * "mirror_upper" (0|1, default 1: the reduction writes the host mirror's triangle once per element, at its upper position),
- * "fused_residual" (fsnap_residual_rhs for K <= 288: 1 = one pass over the rows, the default; 2 = one pass with the next rows
- * prefetched into a second register set -- measured slower, fewer waves per SIMD; 0 = the two-kernel form, two passes),
- * "chol_reuse" (0|1, default 1: fsnap_solve_device_rhs with a right-hand side of its own -- the refinement steps of a fit -- runs
- * a forward and a backward sweep with the factor that the last solve of the same statistics, order and shift left on the device
- * (kernel 8f + 8e: 0.2 instead of 0.54 ms at K = 1595); 0 = factorise again, A/B.  Every launch that rewrites statistics, an
- * all-reduce or an upload into device memory forgets the factor),
- * "rowspace_reuse_stats" (one-shot, cleared by the next fsnap_lstsq_rows: 1 = the caller states that the fit from the statistics
- * which just ran -- fsnap_fit_resident on this context -- saw the rows, weights and mask as they are now; a single-rank
- * fsnap_lstsq_rows on a system the host factorises then starts its first pass from that fit's statistics, still in the page-locked
- * mirror, instead of computing them again: 0.35 ms of a 10^6 x 128 call),
- * "reduce_triangle" (fsnap_fit_dist / fsnap_lstsq_rows: -1 = systems of >= 256 columns all-reduce [upper triangle | c | scalars],
- * K (K + 1) / 2 + K + 3 doubles, between a pack and an unpack kernel, the default; 0 = always the full K^2 + K + 3; 1 = always
- * the triangle -- every rank of a job must use the same setting),
- * "staged_upload" (fsnap_upload_rows: 0 = the runtime's pageable copy, the default -- it pins the caller's pages and reads them
- * in place, 27 ms for 1.03 GB where pinning is cheap; 2 = a page-locked double buffer filled by FSNAP_UPLOAD_THREADS (default 4)
- * host threads while the DMA drains the other slot -- 104 ms on the same box, whose CPU quota holds the host copies at
- * ~10 GB/s: an option for hosts with free cores and slow pinning; 1 = double buffer, handing the rest to the pageable copy when
- * the host fills its first two 16 MiB slots at less than 20 GB/s).
+/* Options (all optional; defaults in brackets).  Every key steers a path a default configuration can take -- the A/B forms
+ * of rounds 1-5 that lost their measurements (kernels 1 / 1L / 1T2, Cholesky forms 0-4, reduce-to-root fits, ...) are gone,
+ * their records are in profiles/ and HISTORY.md:
+ * "nblocks" [0 = auto] workgroups of the SYRK kernels 1A / 1P / 1Q (clusters of 1QC);
+ * "nsplit" [0 = a scheduling model] row splits of the tiled kernel 1T;
+ * "tiled" [0] 1 = the general-K tiled kernel 1T at every width (what short systems of 145 ... 512 columns, K > 512 and the
+ *   row-space passes at K > 144 run on by default);
+ * "quad_min_rows" [-1 = 8 192 rows for 145 ... 288 columns (kernel 1Q), 300 000 for 289 ... 512 (kernel 1QC)] fewest rows for
+ *   the accumulator-resident kernels at those widths; shorter systems take the tiled kernel;
+ * "fused_pack" [1] kernels 1A / 1P / 1Q / 1QC form the per-row pairs (mask * w, mask * w * b) of their rows in LDS inside the
+ *   SYRK launch whenever a workgroup's rows fit; 0 = always the separate packing kernel (the form of larger shards and of the
+ *   row-space passes);
+ * "repack" [0] 1 = recompute the per-row pairs and the b-only scalars on EVERY fit even when b, w and the mask are
+ *   context-owned and unchanged (what a step of bench.py does);
+ * "timing_every" [1] HIP events bracket every N-th SYRK launch only -- an event record between two dependent kernels idles
+ *   the stream for ~5.6 us; 0 = no events; the first launch after the option is set is a sampled one (fsnap_timing /
+ *   fsnap_timing_history see the sampled ones);
+ * "device_solve" [0 = K >= 232 is factorised on the GPU by the blocked kernels] 1 = from 129 columns on, 2 = never (host);
+ * "chol_reuse" [1] fsnap_solve_device_rhs with a right-hand side of its own -- the refinement steps of a fit, the sweeps of the
+ *   condition estimate -- runs a forward and a backward sweep with the factor the last solve of the context's own statistics
+ *   left on the device (0.2 instead of 0.54 ms at K = 1595); 0 = factorise again;
+ * "fused_residual" [1] fsnap_residual_rhs for K <= 288 in one pass over the rows; 0 = the two-kernel form of wider systems;
+ * "rowspace_reuse_stats" [0; one-shot, cleared by the next fsnap_lstsq_rows] 1 = the caller states that the fit from the
+ *   statistics which just ran -- fsnap_fit_resident on this context -- saw the rows, weights and mask as they are now; a
+ *   single-rank fsnap_lstsq_rows on a system the host factorises then starts its first pass from that fit's statistics, still
+ *   in the page-locked mirror, instead of computing them again: 0.35 ms of a 10^6 x 128 call;
+ * "reduce_triangle" [-1 = systems of >= 256 columns all-reduce [upper triangle | c | scalars], K (K + 1) / 2 + K + 3 doubles,
+ *   between a pack and an unpack kernel] 0 = always the full K^2 + K + 3, 1 = always the triangle -- every rank of a job must
+ *   use the same setting;
+ * "comm_timeout" [0 = the FSNAP_COMM_TIMEOUT environment default] seconds: bound of every wait behind a collective of this
+ *   context and of fsnap_comm_init;
+ * "staged_upload" [0 = the runtime's pageable copy: it pins the caller's pages and reads them in place, 27 ms for 1.03 GB
+ *   where pinning is cheap] fsnap_upload_rows: 2 = a page-locked double buffer filled by FSNAP_UPLOAD_THREADS (default 4)
+ *   host threads while the DMA drains the other slot -- for hosts with free cores and slow pinning; 1 = double buffer, handing
+ *   the rest to the pageable copy when the host fills its first two 16 MiB slots at less than 20 GB/s.
  * Unknown key -> FSNAP_E_ARG. */
 int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value);
 
@@ -243,7 +220,7 @@ int fsnap_assemble_accumulate(fsnap_ctx* ctx, const double* raw, int64_t raw_row
 /* Same as fsnap_normal_eq_async into a context-owned device buffer whose address is
  * returned in *d_packed (valid until the next call on this context); asynchronous.
  * For K <= 128 the reduction kernel also writes the statistics into a page-locked host mirror
- * (option "mirror", default 1), which fsnap_solve_device uses instead of a D2H copy when it is
+ * which fsnap_solve_device uses instead of a D2H copy when it is
  * handed this same pointer: read-only for the caller -- to modify the buffer (e.g. all-reduce it)
  * use fsnap_normal_eq_async with a buffer of your own. */
 int fsnap_normal_eq_resident(fsnap_ctx* ctx, double** d_packed);
@@ -466,8 +443,7 @@ int fsnap_barrier(fsnap_ctx* ctx);
  * the host layer keeps the reference's "fit on rank 0" contract).  K must be given because a rank may own no rows
  * (it then contributes zeros).  Without a communicator: FSNAP_E_STATE (a single-GPU fit is fsnap_fit_resident; there is
  * no silent fallback that would fit one rank's shard).  *d_packed (may be NULL) receives the address of the reduced
- * statistics (context-owned device memory, valid until the next fit).  Option "dist_solve" = 1 selects the
- * reduce -> solve on rank 0 -> broadcast form. */
+ * statistics (context-owned device memory, valid until the next fit). */
 int fsnap_fit_dist(fsnap_ctx* ctx, int kind, double param, int64_t K, double* beta, int* rank, double* rcond_est,
                    double** d_packed);
 
@@ -497,7 +473,7 @@ int fsnap_timing(fsnap_ctx* ctx, double* ms, int n);
 int fsnap_timing_history(fsnap_ctx* ctx, double* syrk_ms, double* reduce_ms, int n);
 
 /* For the same n event-bracketed fits: allreduce_ms[i] = time between the end of this rank's partial reduction and the end
- * of the collective of fsnap_fit_dist on this rank's stream (ncclAllReduce, or ncclReduce with dist_solve = 1) -- it
+ * of the collective of fsnap_fit_dist on this rank's stream (ncclAllReduce, or the peer-to-peer kernel) -- it
  * includes waiting for the slowest peer -- or -1 for a fit without a collective.  Synchronises the context's stream. */
 int fsnap_timing_history_comm(fsnap_ctx* ctx, double* allreduce_ms, int n);
 

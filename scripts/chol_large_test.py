@@ -34,11 +34,6 @@ def main():
     ctx.set_weights(np.ones(8))
     alpha = 1e-8
     args = sys.argv[1:]
-    if "--form" in args:                      # panel loop of the device Cholesky (option "chol_form": 0 | 1 | 2 | 4 | 5)
-        i = args.index("--form")
-        ctx.set_option("chol_form", int(args[i + 1]))
-        print(f"chol_form {args[i + 1]}", flush=True)
-        del args[i:i + 2]
     sizes = [int(x) for x in args] or [256, 384, 512, 640, 768, 1024, 1280, 1595, 2048]
     for K in sizes:
         G, c = problem(K, K)

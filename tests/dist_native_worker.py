@@ -68,8 +68,7 @@ def main(outdir):
         s.perform_fit(A[:0], b[:0], w[:0], trainall=True)
     out["zero_G"] = s.last_statistics[0]
     out["zero_rows_resident"] = np.array(pt.hip().m)
-    # K = 480 through the C ABI: all-reduce in HBM, blocked Cholesky on the GPU of every rank; then the
-    # reduce -> solve on rank 0 -> broadcast variant of the same fit
+    # K = 480 through the C ABI: all-reduce in HBM, blocked Cholesky on the GPU of every rank
     from fitsnap_amd import _capi
 
     r = np.random.default_rng(480)
@@ -80,10 +79,6 @@ def main(outdir):
     ctx.set_weights(w4[sel])
     out["k480_beta"] = ctx.fit_dist(_capi.SOLVE_RIDGE, 1e-8, 480)[0]
     out["transport"] = np.array(ctx.comm_transport())
-    if ctx.comm_transport() == "rccl":           # (reduce -> solve on rank 0 -> broadcast is an A/B form of the RCCL transport)
-        ctx.set_option("dist_solve", 1)
-        out["k480_beta_root"] = ctx.fit_dist(_capi.SOLVE_RIDGE, 1e-8, 480)[0]
-        ctx.set_option("dist_solve", 0)
     # K = 1595 (the quadratic SNAP width): triangle payload (10 MB) through the collective, device Cholesky, and the
     # default solver's refinement with the factor kept on every rank
     r = np.random.default_rng(1595)

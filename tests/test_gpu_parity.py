@@ -116,13 +116,13 @@ def test_cluster_quad_kernel_statistics_all_column_block_shapes(qctx, K):
     info = qctx.launch_info()
     assert info["kernel_or_pairs"] == 6 and info["NB"] == (K + 15) // 16
     stats_close(G, c, s, *orc.normal_eq(A, b, w, t))
-    # the tiled kernel (option quad_cluster = 0) on the same rows: same statistics to rounding
-    qctx.set_option("quad_cluster", 0)
+    # the tiled kernel (what shorter systems of these widths run on) on the same rows: same statistics to rounding
+    qctx.set_option("tiled", 1)
     try:
         G2, c2, s2 = run_stats(qctx, A, b, w, t)
         assert qctx.launch_info()["kernel_or_pairs"] != 6
     finally:
-        qctx.set_option("quad_cluster", 1)
+        qctx.set_option("tiled", 0)
     stats_close(G2, c2, s2, G, c, s)
 
 
@@ -191,12 +191,12 @@ def test_quad_kernel_agrees_with_the_tiled_kernel_and_the_oracle(ctx, K):
     stats_close(*got, *ref)
     again = ctx.normal_eq()
     assert all(np.array_equal(x, y) for x, y in zip(got, again))           # run-to-run bit-identical
-    ctx.set_option("quad", 0)
+    ctx.set_option("tiled", 1)
     try:
         tiled = ctx.normal_eq()
         assert ctx.launch_info()["split"] == 0                              # the tiled kernel
     finally:
-        ctx.set_option("quad", 1)
+        ctx.set_option("tiled", 0)
     stats_close(*tiled, *ref)
     # streaming accumulation (fsnap_normal_eq_accumulate) through kernel 1Q: two batches add up to the whole
     import torch
@@ -259,20 +259,6 @@ def test_statistics_tiny_and_ragged_row_counts(ctx, m):
     stats_close(G, c, s, *orc.normal_eq(A, b, w), tol=1e-11)
 
 
-@pytest.mark.parametrize("split", [1, 2])
-def test_split_variants_agree(ctx, split):
-    A, b, w = orc.synth_problem(20000, 96)           # NB = 6: both layouts exist
-    ctx.set_option("kernel", 1)
-    ctx.set_option("split", split)
-    try:
-        G, c, s = run_stats(ctx, A, b, w)
-        assert ctx.launch_info()["split"] == split
-    finally:
-        ctx.set_option("split", 0)
-        ctx.set_option("kernel", 0)
-    stats_close(G, c, s, *orc.normal_eq(A, b, w))
-
-
 def test_masked_rows_may_hold_garbage(ctx):
     # test rows are excluded by fancy indexing in the reference (svd.py:44-46): NaN/Inf in
     # them must not reach G
@@ -328,25 +314,6 @@ def test_run_to_run_bit_identical(ctx, ta):
     assert np.array_equal(G1, G2) and np.array_equal(c1, c2) and np.array_equal(s1, s2)
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3, 5, 6, 7])
-@pytest.mark.parametrize("K", [81, 96, 110, 112, 128])
-def test_kernel_variants_agree(ctx, kernel, K):
-    # kernel 1 = wave-triangle (two sub-waves), 2 / 3 = LDS-shared rows (static / generic bodies), 5 / 6 = LDS-shared
-    # rows with 4- / 2-wave workgroups, 7 = whole triangle in one wave (accumulation registers; the default)
-    rng = np.random.default_rng(1000 + K)
-    m = 30011
-    A = rng.standard_normal((m, K)) * (10.0 ** rng.uniform(-2, 2, size=K))
-    b = rng.standard_normal(m)
-    w = rng.choice([100.0, 1.0, 1e-8], size=m, p=[0.03, 0.83, 0.14])
-    t = rng.random(m) < 0.15
-    ctx.set_option("kernel", kernel)
-    try:
-        G, c, s = run_stats(ctx, A, b, w, t)
-    finally:
-        ctx.set_option("kernel", 0)
-    stats_close(G, c, s, *orc.normal_eq(A, b, w, t))
-
-
 @pytest.mark.parametrize("m", [1, 3, 4, 13, 47, 48, 49, 191, 193, 1000, 12289])
 @pytest.mark.parametrize("K", [97, 128, 142])
 def test_one_wave_triangle_kernel_tiny_and_ragged_row_counts(ctx, m, K):
@@ -361,40 +328,23 @@ def test_one_wave_triangle_kernel_tiny_and_ragged_row_counts(ctx, m, K):
     stats_close(G, c, s, *orc.normal_eq(A, b, w, t), tol=1e-11)
 
 
-@pytest.mark.parametrize("xcd", [0, 1])
-def test_tiled_kernel_item_mapping_variants_agree(ctx, xcd):
-    rng = np.random.default_rng(31)
-    A = rng.standard_normal((20011, 300))
-    b = rng.standard_normal(20011)
-    w = rng.uniform(0.5, 2.0, 20011)
-    ctx.set_option("xcd", xcd)
-    try:
-        G, c, s = run_stats(ctx, A, b, w)
-    finally:
-        ctx.set_option("xcd", 1)
-    stats_close(G, c, s, *orc.normal_eq(A, b, w), tol=2e-12)
-
-
-@pytest.mark.parametrize("tiled2", [1, 0])
 @pytest.mark.parametrize("K,m", [(129, 5003), (142, 13035), (192, 4001), (200, 3000), (257, 2049), (300, 4100), (448, 3000),
                                  (480, 6000), (1000, 3000), (1595, 2500)])
-def test_general_k_tiled_kernel(ctx, K, m, tiled2):
-    # K > 128: ACE (142), EME (480) and quadratic SNAP (1595) widths -> tiled kernels: 1T2 (one wave per SIMD, superblock
-    # against superblock PAIRS, 32 AGPR tiles; even / odd superblock counts, full / partly filled / half-empty last
-    # superblock) and its predecessor 1T (option tiled2 = 0)
+def test_general_k_tiled_kernel(ctx, K, m):
+    # K > 128: ACE (142), EME (480) and quadratic SNAP (1595) widths on the tiled kernel 1T (even / odd superblock counts,
+    # full / partly filled / half-empty last superblock); option tiled = 1 keeps it covered at the widths kernels 1A / 1Q /
+    # 1QC take by default
     rng = np.random.default_rng(2000 + K)
     A = rng.standard_normal((m, K)) * (10.0 ** rng.uniform(-2, 2, size=K))
     b = rng.standard_normal(m)
     w = rng.choice([100.0, 1.0, 1e-8], size=m, p=[0.03, 0.83, 0.14])
     t = rng.random(m) < 0.1
-    ctx.set_option("tiled2", tiled2)
-    ctx.set_option("acc_max_k", 128)          # 129 ... 144 columns are kernel 1A's by default: keep the tiled kernel covered there
+    ctx.set_option("tiled", 1)
     try:
         G, c, s = run_stats(ctx, A, b, w, t)
         assert ctx.launch_info()["split"] == 0
     finally:
-        ctx.set_option("tiled2", 0)
-        ctx.set_option("acc_max_k", 144)
+        ctx.set_option("tiled", 0)
     stats_close(G, c, s, *orc.normal_eq(A, b, w, t), tol=2e-12)
 
 
@@ -413,12 +363,12 @@ def test_tiled_kernel_masked_rows_may_hold_garbage(ctx, K):
     A2[t] = np.nan
     b2[t] = np.inf
     w2[t] = -np.inf
-    ctx.set_option("acc_max_k", 128)
+    ctx.set_option("tiled", 1)
     try:
         G, c, s = run_stats(ctx, A2, b2, w2, t)
         assert ctx.launch_info()["split"] == 0
     finally:
-        ctx.set_option("acc_max_k", 144)
+        ctx.set_option("tiled", 0)
     stats_close(G, c, s, *orc.normal_eq(A, b, w, t), tol=2e-12)
     assert np.isfinite(G).all() and np.isfinite(c).all() and np.isfinite(s).all()
 
@@ -446,43 +396,6 @@ def test_ridge_fit_k142_ace_shape():
     assert np.max(np.abs(s.fit - ref)) / np.max(np.abs(ref)) < 1e-6
     assert maxrel(s.fit, ref) < 1e-6                                          # element-wise, like every other RIDGE / SVD test
     pt.free()
-
-
-@pytest.mark.parametrize("K,m", [(31, 20011), (16, 7001), (55, 33000), (80, 12345)])
-def test_narrow_kernel_chunk_orders_agree_with_the_oracle(K, m):
-    # kernel 1P deals the 4-row chunks to its waves in contiguous ranges (default) or round-robin (option interleave):
-    # different summation orders of the same rows, both within rounding of the oracle; masked rows stay out either way
-    rng = np.random.default_rng(900 + K)
-    A, b, w = orc.synth_problem(m, K)
-    t = rng.random(m) < 0.25
-    ref = orc.normal_eq(A, b, w, t)
-    c = _capi.HipContext(0)
-    out = []
-    for il in (0, 1):
-        c.set_option("interleave", il)
-        G, cc, s = run_stats(c, A, b, w, t)
-        stats_close(G, cc, s, *ref)
-        out.append(G)
-    assert np.max(np.abs(out[0] - out[1])) <= 1e-12 * np.max(np.abs(out[0]))
-    c.close()
-
-
-@pytest.mark.parametrize("K,m", [(142, 13035), (300, 9001), (480, 30000)])
-def test_tiled_kernel_pipeline_forms_give_the_same_bits(K, m):
-    # option tiled_ring: the load pipeline of the tiled kernel in its three-set form (0) and in ring form for the diagonal
-    # (1) / all (3) work items -- the arithmetic and its order are the same, so are the bits
-    A, b, w = orc.synth_problem(m, K)
-    t = np.random.default_rng(K).random(m) < 0.2
-    c = _capi.HipContext(0)
-    c.set_option("acc_max_k", 128)
-    got = []
-    for ring in (0, 1, 3):
-        c.set_option("tiled_ring", ring)
-        got.append(run_stats(c, A, b, w, t))
-    for G, cc, s in got[1:]:
-        assert np.array_equal(G, got[0][0]) and np.array_equal(cc, got[0][1]) and np.array_equal(s, got[0][2])
-    stats_close(*got[2], *orc.normal_eq(A, b, w, t))
-    c.close()
 
 
 def test_one_context_alternates_between_device_and_host_factorisation():
@@ -535,19 +448,17 @@ def test_large_k_device_cholesky_matches_host_solve(ctx, K, m):
 
 
 @pytest.mark.parametrize("K,m", [(232, 2500), (257, 3001), (480, 6000), (1000, 5000), (1595, 7000)])
-@pytest.mark.parametrize("form", [5, 4, 2])
-def test_device_cholesky_factor_is_reused_for_further_right_hand_sides(ctx, K, m, form):
+def test_device_cholesky_factor_is_reused_for_further_right_hand_sides(ctx, K, m):
     # the refinement steps of a fit solve G delta = s with the G that was just factorised on the GPU: fsnap_solve_device_rhs
     # then runs a forward (kernel 8f) and a backward sweep with the factor left on the device (option "chol_reuse", default 1)
-    # instead of factorising again -- same answers as the full path and as a dense solve, for RIDGE and LSTSQ, in every panel-loop
-    # form; new statistics, a different shift or another buffer forget the factor
+    # instead of factorising again -- same answers as the full path and as a dense solve, for RIDGE and LSTSQ; new statistics, a
+    # different shift or another buffer forget the factor
     rng = np.random.default_rng(9000 + K)
     A = rng.standard_normal((m, K)) * (10.0 ** rng.uniform(-1, 1, size=K))
     b = rng.standard_normal(m)
     w = rng.uniform(0.5, 2.0, m)
     ctx.upload_rows(A, b)
     ctx.set_weights(w)
-    ctx.set_option("chol_form", form)
     ctx.set_option("device_solve", 1)
     try:
         ptr = ctx.normal_eq_resident()
@@ -592,66 +503,7 @@ def test_device_cholesky_factor_is_reused_for_further_right_hand_sides(ctx, K, m
         assert np.abs(x - ref).max() <= 1e-8 * np.abs(ref).max()
     finally:
         ctx.set_option("device_solve", 0)
-        ctx.set_option("chol_form", -1)
         ctx.set_option("chol_reuse", 1)
-
-
-@pytest.mark.parametrize("env", [{"FSNAP_CHOL_FUSED": "1"}, {"FSNAP_CHOL_DIAG": "0"}, {"FSNAP_CHOL_DIAG": "1"}, {"FSNAP_CHOL_DIAG": "2"},
-                                 {"FSNAP_CHOL_DIAG": "4"}, {"FSNAP_CHOL_DIAG": "5"}])
-def test_device_cholesky_ab_forms_solve_the_same_systems(env):
-    # the forms of the blocked device Cholesky (option "chol_form"; here through the environment default, read once per
-    # process): 5 = one launch per panel + four-wave diagonal block (the default), 4 = two launches per panel + four-wave
-    # block, 0 / 1 / 2 = the single-wave block of rounds 2-4 with its three pivot chains, and the flag-synchronised
-    # one-launch kernel of round 4
-    import os
-    import re
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "chol_large_test.py"), "257", "480", "1595"],
-                         env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    rows = re.findall(r"K=\s*(\d+)\s+gpu\s+[\d.]+ ms \(rel ([\d.e+-]+), min pivot ([\d.e+-]+)\).*rhs-variant rel ([\d.e+-]+)", out.stdout)
-    assert [int(r[0]) for r in rows] == [257, 480, 1595], out.stdout
-    for _, rel, piv, rel2 in rows:
-        assert float(rel) < 1e-11 and float(rel2) < 1e-11 and float(piv) > 1e-3      # solved on the GPU (min pivot reported), accurately
-
-
-@pytest.mark.parametrize("K", [232, 300, 383])
-def test_device_cholesky_forms_agree_near_the_pivot_threshold(ctx, K):
-    # option "chol_form": the panel loops of the device Cholesky (5 = one launch per panel + four-wave diagonal block, the
-    # default; 4 = two launches per panel + four-wave block; 0 / 2 = the single-wave block with the pivot read back from the
-    # MFMA / formed on a side chain) on systems whose smallest scaled pivot sits on either side of the 1e-3 acceptance
-    # threshold: the forms must report the same pivot (to rounding), take the same accept / fall-back decision, and agree on
-    # beta.  (In forms 2 / 4 / 5 the diagonal of U is d * (1 / sqrt(d)) from the side chain, not sqrt of the stored pivot.)
-    rng = np.random.default_rng(7000 + K)
-    m = 3 * K
-    base = rng.standard_normal((m, K))
-    for eps_col in (6e-2, 2e-2):                                  # pivot of the near-dependent column ~ eps_col^2
-        A = base.copy()
-        A[:, K - 1] = A[:, 0] + eps_col * A[:, K - 1]
-        b = rng.standard_normal(m)
-        ctx.upload_rows(A, b)
-        ctx.set_weights(np.ones(m))
-        ptr = ctx.normal_eq_resident()
-        got = {}
-        ctx.set_option("device_solve", 1)
-        try:
-            for form in (5, 4, 2, 0):
-                ctx.set_option("chol_form", form)
-                got[form] = ctx.solve_device(_capi.SOLVE_CHOL, 0.0, K, ptr)
-        finally:
-            ctx.set_option("chol_form", -1)
-            ctx.set_option("device_solve", 0)
-        beta0, rank0, rcond0 = got[0]
-        assert rank0 == K
-        for form in (5, 4, 2):
-            beta, rank, rcond = got[form]
-            assert rank == rank0 and rcond == pytest.approx(rcond0, rel=1e-9)
-            assert np.max(np.abs(beta - beta0)) <= 1e-9 * np.max(np.abs(beta0))
-        # one case on each side of the threshold, whatever path produced the accepted answer
-        assert (rcond0 > 1e-3) == (eps_col == 6e-2)
 
 
 @pytest.mark.parametrize("K", [40, 128, 200])
@@ -1045,27 +897,6 @@ def test_full_size_svd_and_ridge_variants_match_the_reference_solvers(big, maske
 # ---------------------------------------------------------------------------------------
 # K x K solve on the device (fsnap_solve_device) vs the host solver
 # ---------------------------------------------------------------------------------------
-@pytest.mark.parametrize("K", [1, 2, 5, 31, 63, 64, 65, 100, 127, 128])
-def test_device_solve_matches_host_solve(ctx, K):
-    A, b, w = orc.synth_problem(3000 + 11 * K, K)
-    ctx.upload_rows(A, b)
-    ctx.set_weights(w)
-    ptr = ctx.normal_eq_resident()
-    G, c, s = ctx.download_packed(ptr, K)
-    ctx.set_option("device_solve", 1)
-    try:
-        for kind, param in ((_capi.SOLVE_RIDGE, 1e-8), (_capi.SOLVE_RIDGE, 1e-2), (_capi.SOLVE_CHOL, 0.0), (_capi.SOLVE_LSTSQ, 1e-13)):
-            bd, rank_d, _ = ctx.solve_device(kind, param, K, ptr)
-            bh, rank_h, _ = _capi.solve(kind, param, G, c)
-            assert rank_d == rank_h == K
-            assert maxrel(bd, bh) < 1e-9
-        ref = orc.ridge_fit(A, b, w, 1e-8)
-        bd, _, _ = ctx.solve_device(_capi.SOLVE_RIDGE, 1e-8, K, ptr)
-        assert maxrel(bd, ref) < 1e-6
-    finally:
-        ctx.set_option("device_solve", 0)
-
-
 def test_device_solve_falls_back_for_hard_systems(ctx, ta, ta_fits):
     import torch
     A, b, w = ta
@@ -1144,24 +975,6 @@ def test_anl_solver_matches_reference(ta, ta_fits, tmp_path, monkeypatch):
     assert np.max(np.abs(s.cov - ref) / (dscale[:, None] * dscale[None, :])) < 1e-5
     assert (tmp_path / "covariance.npy").exists() and (tmp_path / "mean.npy").exists()
     pt.free()
-
-
-@pytest.mark.parametrize("opts", [{"kernel": 4}, {"kernel": 2, "ablate": 5}, {"kernel": 4, "ablate": 5}, {"kernel": 2, "ablate": 6},
-                                  {"kernel": 2, "ablate": 8}, {"kernel": 2, "ablate": 9}, {"kernel": 5, "ablate": 10},
-                                  {"kernel": 6, "ablate": 10}])
-def test_lds_kernel_ab_variants_are_correct(ctx, opts):
-    # A/B variants of kernel 1L at K = 128: 16-wave workgroups, operand prefetch, early park, wave priorities,
-    # interleaved park (`ablate` 5..10 keep results correct; 1..4 are timing-only ablations)
-    A, b, w = orc.synth_problem(70001, 128)
-    t = orc.synth_testing_mask(len(b))
-    for k, v in opts.items():
-        ctx.set_option(k, v)
-    try:
-        G, c, s = run_stats(ctx, A, b, w, t)
-    finally:
-        for k in opts:
-            ctx.set_option(k, 0)
-    stats_close(G, c, s, *orc.normal_eq(A, b, w, t))
 
 
 def test_error_analysis_per_group_rows_match_reference(ta, ta_fits):
@@ -1255,7 +1068,7 @@ def test_residual_rhs_general_k(ctx, K):
                                  (256, 4099), (257, 3001), (275, 9001), (288, 5003)])
 def test_one_pass_residual_rhs(ctx, K, m):
     # fsnap_residual_rhs for K <= 288: kernels 4 + 7 fused, every row read once (option fused_residual: 1 = the default
-    # form, 2 = with the next rows prefetched into a second register set, 0 = the two-kernel form).  All three against the
+    # form, 0 = the two-kernel form that wider systems take).  Both against the
     # oracle's s = aw^T (bw - aw beta) and SSE on the training rows; NaN / Inf in A, b, w of test rows reach nothing in the
     # fused forms (the reference drops those rows by fancy indexing, svd.py:44-46).
     rng = np.random.default_rng(6000 + K)
@@ -1271,7 +1084,7 @@ def test_one_pass_residual_rhs(ctx, K, m):
     w2[t] = -np.inf
     got = {}
     try:
-        for mode in (1, 2, 0):
+        for mode in (1, 0):
             ctx.set_option("fused_residual", mode)
             dirty = mode != 0                      # the two-kernel form multiplies masked rows by u = 0: finite rows only
             ctx.upload_rows(A2 if dirty else A, b2 if dirty else b)
@@ -1283,7 +1096,7 @@ def test_one_pass_residual_rhs(ctx, K, m):
             got[mode] = s
     finally:
         ctx.set_option("fused_residual", 1)
-    assert np.max(np.abs(got[1] - got[0]) / scale) < 1e-14 and np.array_equal(got[1], got[2])
+    assert np.max(np.abs(got[1] - got[0]) / scale) < 1e-14
 
 
 def test_refinement_recovers_lstsq_accuracy(ta, ta_fits):
