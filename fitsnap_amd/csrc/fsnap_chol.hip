@@ -144,13 +144,8 @@ struct __attribute__((aligned(16))) Diag4Lds {
     double slot[64][16];       // multipliers of pivot p: -U[j][i] for i > j, 0 elsewhere
     double inv[64];            // 1/sqrt(d_p); 0.0 = not published yet
     double dummy[64];          // where the lanes that have nothing to publish store
-    double gw[16][64];         // rank-4 form: per pivot group (block, q) the A operand of the group's row transformation ...
-    double gu[16][64];         // ... and of its rank-4 update, lane for lane
-    int gflag[16];             // group published
     double tile[3][4][64];     // U_01, U_02, U_12 handed from wave b to the waves right of it (accumulator layout, lane for lane)
     int tflag[4];              // [0] U_01, [1] U_02, [2] U_12 published
-    double dtile[4][4][64];    // redundant form: the diagonal tile of block step a as its owner holds it BEFORE the first pivot (accumulator layout)
-    int dflag[4];              // ... published
     double T[4][16][17];       // per-wave transpose scratch of the inverses
 };
 
@@ -162,8 +157,6 @@ __device__ __forceinline__ int diag4_tile_index(int a, int b) { return a == 0 ? 
 __device__ __forceinline__ void diag4_lds_reset(Diag4Lds& L, int tid) {
     if (tid < 64) L.inv[tid] = 0.0;
     if (tid < 4) L.tflag[tid] = 0;
-    if (tid < 4) L.dflag[tid] = 0;
-    if (tid < 16) L.gflag[tid] = 0;
 }
 
 // the sixteen multipliers and 1/sqrt(d) of pivot p, as published by the owner: one look (marker first, then payload)
@@ -311,6 +304,11 @@ __device__ __forceinline__ void chol_diag4_wave(d4 (&Tl)[4], Diag4Lds& L, double
     }
     CHOL_STAMP(W, 4);
     // ---- the own block step: owner ------------------------------------------------------------------------------
+    // (Round 6 tried the tile on the VALU instead, one COLUMN per lane -- sixteen registers per lane, pivot j = one multiply,
+    // the update of row i = a v_readlane pair for U[j][i] + one FMA, the chain multiply -> readlane -> FMA -> readlane -> 1 / sqrt:
+    // bit-for-bit as accurate and NOT faster, 5 100-5 400 cycles per owner phase against 5 000-5 300 for the form below
+    // (tools/chol_pipeline_check -DFSNAP_CHOL_TRACE, profiles/r06_chol_valu_diag.txt): the 120 broadcast + FMA pairs of a
+    // 16 x 16 tile cost ~18 cycles each in issue slots and SGPR wait states, and a wave issues them in order with the chain.)
     d4& D = Tl[W];
     double pmin = 1.0e300, psum = 0.0;
     double dcur = readlane_f64(D[0], 0);

@@ -1,6 +1,6 @@
-// tools/chol_pipeline_check.hip -- the whole blocked device Cholesky solve (fsnap::launch_chol_large, every form) on one
-// system, checked against a host Cholesky solve in long double; A/B builds of kernel 8b4's switches:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include [-DFSNAP_D4_NEWTON=3 -DFSNAP_D4_SLEEP=0 ...] tools/chol_pipeline_check.hip -o ...
+// tools/chol_pipeline_check.hip -- the whole blocked device Cholesky solve (fsnap::launch_chol_large) on one system, checked
+// against a host Cholesky solve in long double; with -DFSNAP_CHOL_TRACE=1 the cycle stamps of the last panel launch:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include [-DFSNAP_CHOL_TRACE=1] tools/chol_pipeline_check.hip -o tools/bin/chol_pipeline_check
 #include "../fitsnap_amd/csrc/fsnap_chol.hip"
 
 #include <chrono>
@@ -70,16 +70,16 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&minpiv, (np / 64 + 1) * 8));
     CK(hipMalloc(&status, 64));
     CK(hipMemcpy(dp, packed.data(), packed.size() * 8, hipMemcpyHostToDevice));
-    printf("switches: NEWTON %d SLEEP %d DEFER %d HALF %d, n = %d\n", FSNAP_D4_NEWTON, FSNAP_D4_SLEEP, FSNAP_D4_DEFER, FSNAP_D4_HALF, n);
-    const int forms[] = {5, 4, 2};
-    for (int form : forms) {
+    printf("n = %d\n", n);
+    {
+        const int form = 5;
         std::vector<double> got(n);
         double best = 1e9;
         int st = 0;
         for (int it = 0; it < 12; ++it) {
             CK(hipDeviceSynchronize());
             const auto t0 = std::chrono::steady_clock::now();
-            CK(fsnap::launch_chol_large(dp, nullptr, n, 0.0, work, dsc, z, beta, status, minpiv, nullptr, true, form, 0));
+            CK(fsnap::launch_chol_large(dp, nullptr, n, 0.0, work, dsc, z, beta, status, minpiv, nullptr, true, 0));
             CK(hipDeviceSynchronize());
             const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
             if (it >= 2 && us < best) best = us;
