@@ -302,12 +302,16 @@ int p2p_init(fsnap_ctx* ctx, int nranks, int rank, const char* id, P2P** out) {
         p->win = nullptr;
         e = hipErrorUnknown;
     }
+    const bool fine = e == hipSuccess;
     if (e != hipSuccess) {
         (void)hipGetLastError();
         if ((e = hipMalloc((void**)&p->win, win_bytes)) != hipSuccess) return bail(ctx->hipfail(e, "hipMalloc(p2p window)"));
         if ((e = hipIpcGetMemHandle(&handle, p->win)) != hipSuccess)
             return bail(ctx->hipfail(e, "hipIpcGetMemHandle (multi-process GPU sharing needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this driver)"));
     }
+    if (getenv("FSNAP_P2P_DEBUG"))
+        fprintf(stderr, "[fsnap p2p] rank %d of %d on device %d: window of %zu bytes, %s device memory\n", rank, nranks, ctx->device, win_bytes,
+                fine ? "fine-grained" : "coarse-grained (hipMalloc)");
     if ((e = hipMemset(p->win, 0, P2P_FLAG_BYTES)) != hipSuccess) return bail(ctx->hipfail(e, "hipMemset(p2p flags)"));
     if ((e = hipHostMalloc((void**)&p->h_status, sizeof(int), hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess)
         return bail(ctx->hipfail(e, "hipHostMalloc(p2p status)"));
