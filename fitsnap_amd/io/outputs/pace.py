@@ -41,7 +41,13 @@ def to_potential_mod_string(config):
     ``.yace`` file and the elements."""
     stem = config.sections["OUTFILE"].potential_name.split("/")[-1]
     elements = "".join(f" {t}" for t in config.sections["ACE"].types)
-    return potential_mod_text(config, "pace product", f"{stem}.yace" + elements)
+    text = potential_mod_text(config, "pace product", f"{stem}.yace" + elements)
+    # the file the pair_coeff line names is NOT written by this build (it needs the coupling coefficients of the ACE basis,
+    # fitsnap3lib/lib/sym_ACE, out of scope): say so where a user will look, right behind the header
+    head, sep, rest = text.partition("\n\n")
+    note = (f"# NOTE: {stem}.yace is not produced by this fit stage (ACE basis generation is outside it): build it from\n"
+            f"# {stem}.acecoeff with the reference's writer (fitsnap3lib/io/outputs/pace.py: write_potential) before using this file.\n")
+    return head + "\n" + note + sep + rest
 
 
 def parse_acecoeff(path):
