@@ -47,7 +47,7 @@ def to_potential_mod_string(config):
     head, sep, rest = text.partition("\n\n")
     note = (f"# NOTE: {stem}.yace is not produced by this fit stage (ACE basis generation is outside it): build it from\n"
             f"# {stem}.acecoeff with the reference's writer (fitsnap3lib/io/outputs/pace.py: write_potential) before using this file.\n")
-    return head + "\n" + note + sep + rest
+    return head + "\n" + note + "\n" + rest
 
 
 def parse_acecoeff(path):
