@@ -155,6 +155,10 @@ int nccl_fail(fsnap_ctx* ctx, Rccl* r, ncclResult_t e, const char* what) {
 
 int need_comm(fsnap_ctx* ctx, Rccl** r) {
     if (!ctx->comm || !(ctx->comm->nccl || ctx->comm->p2p)) return ctx->fail(FSNAP_E_STATE, "no communicator: call fsnap_comm_init first");
+    // a bounded wait behind a collective ran out earlier: the ranks are no longer in step (the peer-to-peer transport counts
+    // its collectives), and whatever is entered now can only run into the same deadline again
+    if (ctx->comm_broken && ctx->comm->p2p)
+        return ctx->fail(FSNAP_E_STATE, "the communicator is broken (an earlier collective timed out): destroy the context");
     *r = ctx->comm->p2p ? nullptr : fsnap::rccl();
     return FSNAP_OK;
 }
