@@ -32,6 +32,7 @@ extern "C" int fsnap_solve_diag_upper(int kind, double param, int64_t K, const d
 extern "C" int fsnap_solve_diag(int kind, double param, int64_t K, const double* G, const double* c, const double* diag,
                                 double* beta, int* rank, double* rcond_est);
 extern "C" void fsnap_cond_note(double min_pivot, double lambda_min, int steps, int where);
+extern "C" double fsnap_gen_eig_max(const double* M, const double* N, int k);
 
 #include "fsnap_ctx.h"
 #include "fsnap_condest.h"
@@ -1466,6 +1467,8 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
     if (device_factor(ctx, K)) {
         const int n = (int)K, np = (n + 63) / 64 * 64, npanel = np / 64;
         const size_t head = (size_t)n + npanel + 1;            // [beta | min pivots | status]
+        constexpr int NPR = fsnap::CHOL_PROBES;
+        const size_t head_all = head + (size_t)NPR * NPR;      // ... | Z^T Z of the probes (condition estimate, LSTSQ kinds)
         if (!ctx->dchol.ensure(fsnap::chol_large_work_doubles(n) * 8) || !ctx->dsolve.ensure((head + 2 * (size_t)np) * 8))
             return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(device Cholesky) failed");
         double* dv = (double*)ctx->dsolve.p;
@@ -1477,12 +1480,12 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
         // results come back through page-locked, GPU-visible host memory written by the last launch of the chain (the
         // host polls an event: no D2H copy, whose launch latency was ~10 us); the plain staging buffer + copy remain
         // as the fallback when that allocation fails
-        if (ctx->chol_host_bytes < head * 8) {
+        if (ctx->chol_host_bytes < head_all * 8) {
             if (ctx->chol_host) (void)hipHostFree(ctx->chol_host);
             ctx->chol_host = nullptr;
             ctx->chol_host_bytes = 0;
-            if (hipHostMalloc((void**)&ctx->chol_host, head * 8, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
-                ctx->chol_host_bytes = head * 8;
+            if (hipHostMalloc((void**)&ctx->chol_host, head_all * 8, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
+                ctx->chol_host_bytes = head_all * 8;
         }
         if (ctx->chol_host && !ctx->chol_ev && hipEventCreateWithFlags(&ctx->chol_ev, hipEventDisableTiming) != hipSuccess)
             ctx->chol_ev = nullptr;
@@ -1504,6 +1507,7 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
         // a right-hand side of its own for statistics this context has just factorised (the refinement steps of a fit): the
         // factor, the scaling and the inverses of the diagonal blocks are still in the work buffers -- two sweeps instead of a
         // factorisation (kernel 8f + the backward sweep)
+        const bool lstsq = kind == FSNAP_SOLVE_LSTSQ || kind == FSNAP_SOLVE_LSTSQ_PROBE;
         const bool reuse = rhs && host_out && ctx->opt_chol_reuse && ctx->chol_factor_of == d_packed && ctx->chol_factor_K == K &&
                            ctx->chol_factor_alpha == alpha;
         if (reuse) {
@@ -1534,7 +1538,7 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
         const bool clear_status = ctx->chol_status_word != (const void*)d_status;
         ctx->chol_status_word = host_out ? (const void*)d_status : nullptr;
         FSNAP_HIP(fsnap::launch_chol_large(d_packed, d_rhs, n, alpha, (double*)ctx->dchol.p, d_dsc, d_z, d_beta, d_status,
-                                           d_minpiv, host_out, clear_status, ctx->stream),
+                                           d_minpiv, host_out, clear_status, (lstsq && host_out) ? host_out + head : nullptr, ctx->stream),
                   "launch device Cholesky");
         const double* h;
         if (host_out) {
@@ -1561,46 +1565,27 @@ int fsnap_solve_device_rhs(fsnap_ctx* ctx, int kind, double param, int64_t K, co
             if (fin) {
                 for (int i = 0; i < n; ++i) beta[i] = h[i];
                 // LSTSQ stands in for an SVD of the rows, which knows the conditioning; the smallest pivot bounds lambda_min of
-                // the scaled matrix from above only.  Ask the factor (fsnap_condest.h): each Lanczos step is one forward +
-                // backward sweep with the factor that is on the device anyway (kernels 8f + 8e with a unit "scaling", so that
-                // the sweeps apply S^-1 itself), 2 ... 5 steps.  Same bits on every rank: deterministic kernels on
-                // bit-identical statistics.
+                // the scaled matrix from above only.  The factorisation carried 31 probe vectors in its right-hand-side strip:
+                // Z^T Z = B^T S^-1 B came back with the results, its largest generalised eigenvalue against B^T B is a lower
+                // bound of 1 / lambda_min that holds at least ~0.4 x 31 / K of it (fsnap_chol_probe_gram_k) -- so the estimate
+                // 1 / theta is scaled by 120 / K: what the host layer divides by its margin of 10 is then below lambda_min.
+                // No sweep with the factor (round 6's first form ran 2 ... 5 Lanczos steps of 0.06 ... 0.40 ms each here).
+                // Same bits on every rank: deterministic kernels on bit-identical statistics.
                 fsnap::CondEstimate ce;
-                const bool lstsq = kind == FSNAP_SOLVE_LSTSQ || kind == FSNAP_SOLVE_LSTSQ_PROBE;
-                if (lstsq) {
-                    if (ctx->dunit_n < (size_t)np) {
-                        if (!ctx->dunit.ensure((size_t)np * 8) || !ctx->dsvec.ensure((size_t)n * 8))
-                            return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(unit vector) failed");
-                        std::vector<double> one((size_t)np, 1.0);
-                        FSNAP_HIP(hipMemcpy(ctx->dunit.p, one.data(), (size_t)np * 8, hipMemcpyHostToDevice), "hipMemcpy(unit vector)");
-                        ctx->dunit_n = (size_t)np;
-                    } else if (!ctx->dsvec.ensure((size_t)n * 8)) {
-                        return ctx->fail(FSNAP_E_NOMEM, "hipMalloc(rhs) failed");
-                    }
-                    int apply_rc = FSNAP_OK;
-                    auto apply_inv = [&](double* v) -> bool {
-                        if (hipMemcpyAsync(ctx->dsvec.p, v, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return false;
-                        if (fsnap::launch_chol_resolve((const double*)ctx->dsvec.p, n, (double*)ctx->dchol.p, (const double*)ctx->dunit.p, d_z,
-                                                       d_beta, d_status, d_minpiv, host_out, ctx->stream) != hipSuccess)
-                            return false;
-                        const double* r;
-                        if (host_out) {
-                            if (hipEventRecord(ctx->chol_ev, ctx->stream) != hipSuccess) return false;
-                            if ((apply_rc = fsnap::wait_stream(ctx, ctx->chol_ev, "condition estimate"))) return false;
-                            r = host_out;
-                        } else {
-                            if (hipMemcpyAsync(ctx->pinned, dv, head * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
-                            if ((apply_rc = fsnap::wait_stream(ctx, nullptr, "condition estimate"))) return false;
-                            r = ctx->pinned;
+                if (lstsq && host_out) {
+                    if (ctx->probe_n != n) {
+                        ctx->probe_gram.assign((size_t)NPR * NPR, 0.0);
+                        std::vector<double> row(NPR);
+                        for (int r = 0; r < n; ++r) {
+                            for (int p = 0; p < NPR; ++p) row[p] = fsnap::chol_probe(r, p + 1);
+                            for (int p = 0; p < NPR; ++p)
+                                for (int q = 0; q < NPR; ++q) ctx->probe_gram[(size_t)p * NPR + q] += row[p] * row[q];
                         }
-                        int st2;
-                        memcpy(&st2, r + n + npanel, sizeof(int));
-                        if (st2 != 0) return false;
-                        for (int i = 0; i < n; ++i) v[i] = r[i];
-                        return true;
-                    };
-                    ce = fsnap::lanczos_lambda_min(n, apply_inv, 2, 5);
-                    if (apply_rc) return apply_rc;
+                        ctx->probe_n = n;
+                    }
+                    const double theta = fsnap_gen_eig_max(host_out + head, ctx->probe_gram.data(), NPR);
+                    ce.steps = 1;
+                    ce.lambda_min = theta > 0.0 ? (1.0 / theta) * (n > 120 ? 120.0 / n : 1.0) : 0.0;
                 }
                 const double rc_est = (ce.steps && ce.lambda_min < mp) ? ce.lambda_min : mp;
                 fsnap_cond_note(mp, ce.lambda_min, ce.steps, 1);

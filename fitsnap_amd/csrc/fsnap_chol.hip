@@ -34,6 +34,21 @@
 constexpr int CHOL_NB = 64;
 constexpr int CHOL_XS = 32;   // width of the right-hand-side strip (one block column of kernel 8d)
 
+// probe p (1 .. 31) of the condition estimate at a row: see fsnap_chol_probe_gram_k
+namespace fsnap {
+__host__ __device__ inline double chol_probe_value(int row, int p) {
+    unsigned x = (unsigned)row * 0x9E3779B1u + (unsigned)p * 0x85EBCA77u + 0x27D4EB2Fu;
+    x ^= x >> 15;
+    x *= 0x2C1B3C6Du;
+    x ^= x >> 12;
+    x *= 0x297A2D39u;
+    x ^= x >> 15;
+    const double mag = 0.25 + 0.75 * ((double)(x & 0xFFFFu) / 65536.0);       // exact in fp64: the host forms B^T B from the same values
+    return (x & 0x10000u) ? -mag : mag;
+}
+}  // namespace fsnap
+
+
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -460,7 +475,10 @@ __global__ __launch_bounds__(256) void fsnap_chol_prepare_diag4_k(const double* 
     }
     double v;
     if (j >= np) {
-        v = (j == np && i < n && oki && finite_c) ? ci * di : 0.0;
+        // strip: column 0 the scaled right-hand side; columns 1 .. 31 the PROBE vectors of the condition estimate (fixed
+        // pseudo-random values in +-[0.25, 1]): the factorisation carries them along for nothing, and what comes out --
+        // Z = U^-T B -- gives B^T S^-1 B = Z^T Z without a single extra sweep (fsnap_chol_probe_gram_k)
+        v = (i < n && oki && finite_c) ? (j == np ? ci * di : fsnap::chol_probe_value(i, j - np)) : 0.0;
     } else if (i < n && j < n) {
         bool okj = true;
         const double dj = scale_of(j, okj);
@@ -1080,9 +1098,93 @@ __global__ __launch_bounds__(256) void fsnap_chol_extract_factor_k(const double*
 }
 
 // ---------------------------------------------------------------------------------
+// Condition estimate of the device factor without a sweep (round 6).  The right-hand-side strip of the factorisation is 32
+// columns wide and only its first column is the right-hand side: columns 1 .. 31 carry fixed pseudo-random probe vectors B
+// (fsnap_chol_prepare_diag4_k), the panel loop transforms them with everything else, and at the end the strip holds
+// Z = U^-T B.  Z^T Z = B^T S^-1 B is the Rayleigh-Ritz matrix of S^-1 on the 31-dimensional random subspace span(B): its
+// largest generalised eigenvalue theta (against B^T B; host, 31 x 31) never exceeds 1 / lambda_min(S) and captures at least
+// ~0.4 x 31 / K of it (the share of ANY fixed direction in a random 31-subspace of K dimensions: Beta(31 / 2, (K - 31) / 2),
+// mean 31 / K, three standard deviations below it ~0.4 of that).  So 1 / theta is an estimate of lambda_min from ABOVE that is
+// at most ~K / 12 too large -- the caller scales it by that (fsnap_solve_device_rhs) -- at the price of ONE small launch, where
+// the Lanczos sweeps with the device factor that this replaces cost 0.06 / 0.10 / 0.40 ms EACH at K = 256 / 480 / 1 595 and a
+// well-conditioned 15 213 x 1 595 SVD fit went from 1.3 to 3.5 ms.
+// The strip rows of the LAST panel are never substituted by the panel loop (there is no launch behind the last panel): this
+// kernel runs their forward substitution itself, like fsnap_chol_backsolve_k does for the right-hand side.
+// out[(i - 1) * 31 + (j - 1)] = sum_r Z[r][i] Z[r][j], i, j = 1 .. 31; fixed summation order.
+// ---------------------------------------------------------------------------------
+constexpr int CHOL_NPROBE = CHOL_XS - 1;
+
+__global__ __launch_bounds__(1024) void fsnap_chol_probe_gram_k(const double* __restrict__ Uf, const double* __restrict__ Sraw, int ld,
+                                                               int np, double* __restrict__ out, const int* __restrict__ status) {
+    __shared__ double U11[CHOL_NB * (CHOL_NB + 1)];
+    __shared__ double Zl[CHOL_NB][CHOL_XS];
+    if (*status) return;                       // the factorisation failed: there is no factor to ask (the host does not look)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r0 = np - CHOL_NB;
+    for (int t = tid; t < CHOL_NB * CHOL_NB; t += 1024) U11[(t >> 6) * (CHOL_NB + 1) + (t & 63)] = Uf[(size_t)(r0 + (t >> 6)) * ld + r0 + (t & 63)];
+    if (tid < CHOL_NB) Zl[tid][0] = 0.0;               // (column 0 is the right-hand side: not a probe, never summed)
+    __syncthreads();
+    // y = U11^-T s for the last panel's raw strip rows: one wave per column (wave wv: columns wv + 1 and wv + 17), 64 steps,
+    // multipliers broadcast with v_readlane
+    for (int c = wv + 1; c < CHOL_XS; c += 16) {
+        double v = Sraw[(size_t)(r0 + lane) * ld + np + c];
+        const double invd = 1.0 / U11[lane * (CHOL_NB + 1) + lane];
+#pragma unroll 8
+        for (int k = 0; k < CHOL_NB; ++k) {
+            const double yk = readlane_f64(v, k) * readlane_f64(invd, k);
+            if (lane == k) v = yk;
+            if (lane > k) v = __builtin_fma(-U11[k * (CHOL_NB + 1) + lane], yk, v);
+        }
+        Zl[lane][c] = v;
+    }
+    __syncthreads();
+    // Gram of the strip, 128 rows at a time through LDS: the 32 strip values of a row are 256 contiguous bytes, so a tile is four
+    // coalesced doubles per thread -- all loads of a tile in flight at once, the next tile's on their way while this one is
+    // summed (961 threads walking the rows with two strided loads each paid one HBM round trip per four rows: 0.3 ms at K = 1 595)
+    __shared__ double Zt[128][CHOL_XS + 1];
+    const int i = tid / CHOL_NPROBE + 1, j = tid % CHOL_NPROBE + 1;
+    const bool mine = tid < CHOL_NPROBE * CHOL_NPROBE;
+    const int tr = tid >> 3, tc = (tid & 7) * 4;            // this thread's four values of a tile: row tr, columns tc .. tc + 3
+    double acc = 0.0;
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+    auto fetch = [&](int base) {
+        const int r = base + tr;
+        if (r < r0) {
+            const double* src = Uf + (size_t)r * ld + np + tc;
+            q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3];
+        } else if (r < np) {
+            q0 = Zl[r - r0][tc]; q1 = Zl[r - r0][tc + 1]; q2 = Zl[r - r0][tc + 2]; q3 = Zl[r - r0][tc + 3];
+        } else {
+            q0 = q1 = q2 = q3 = 0.0;
+        }
+    };
+    fetch(0);
+    for (int base = 0; base < np; base += 128) {
+        __syncthreads();                                    // the previous tile has been summed by everybody
+        Zt[tr][tc] = q0; Zt[tr][tc + 1] = q1; Zt[tr][tc + 2] = q2; Zt[tr][tc + 3] = q3;
+        __syncthreads();
+        if (base + 128 < np) fetch(base + 128);
+        if (mine) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 8
+            for (int r = 0; r < 128; r += 4) {
+                a0 = __builtin_fma(Zt[r][i], Zt[r][j], a0);
+                a1 = __builtin_fma(Zt[r + 1][i], Zt[r + 1][j], a1);
+                a2 = __builtin_fma(Zt[r + 2][i], Zt[r + 2][j], a2);
+                a3 = __builtin_fma(Zt[r + 3][i], Zt[r + 3][j], a3);
+            }
+            acc += (a0 + a1) + (a2 + a3);
+        }
+    }
+    if (mine) out[tid] = acc;
+}
+
+// ---------------------------------------------------------------------------------
 // host-side launchers (C++ linkage, used by fsnap_capi.cpp)
 // ---------------------------------------------------------------------------------
 namespace fsnap {
+
+double chol_probe(int row, int p) { return chol_probe_value(row, p); }
 
 size_t chol_large_work_doubles(int n) {
     const size_t np = (size_t)(n + CHOL_NB - 1) / CHOL_NB * CHOL_NB;
@@ -1120,7 +1222,8 @@ static void launch_chol_panels(double* S, double* Uf, int ld, int np, double* Ya
 }
 
 hipError_t launch_chol_large(const double* packed, const double* cvec, int n, double alpha, double* work, double* dsc, double* z,
-                             double* beta, int* status, double* minpiv, double* host_out, bool clear_status, hipStream_t st) {
+                             double* beta, int* status, double* minpiv, double* host_out, bool clear_status, double* probe_out,
+                             hipStream_t st) {
     if (!cvec) cvec = packed + (size_t)n * n;
     const int np = (n + CHOL_NB - 1) / CHOL_NB * CHOL_NB, npanel = np / CHOL_NB, ld = np + CHOL_XS;
     double* S = work;
@@ -1141,6 +1244,10 @@ hipError_t launch_chol_large(const double* packed, const double* cvec, int n, do
                            S, Uf, Yall, status, minpiv, npanel, flag);
     }
     launch_chol_panels(S, Uf, ld, np, Yall, status, minpiv, st);
+    // the probes' Rayleigh-Ritz matrix (condition estimate), before the back substitution's last launch hands the results over
+    if (probe_out)
+        hipLaunchKernelGGL(fsnap_chol_probe_gram_k, dim3(1), dim3(1024), 0, st, (const double*)Uf, (const double*)S, ld, np, probe_out,
+                           (const int*)status);
     static bool bs_attr_set = false;
     if (!bs_attr_set) {
         e = hipFuncSetAttribute((const void*)fsnap_chol_backsolve_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHOL_BS_LDS);

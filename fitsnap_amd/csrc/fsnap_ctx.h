@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "../../include/fsnap_hip.h"
 
@@ -139,8 +140,8 @@ struct fsnap_ctx {
     double chol_factor_alpha = 0.0;
     double chol_factor_rcond = 0.0;        // what the solve that left the factor reported as *rcond_est (min(pivot, lambda_min estimate))
     double chol_factor_piv = 0.0, chol_factor_lam = 0.0;
-    DevBuf dunit;                          // a vector of ones: the "scaling" of a sweep that applies S^-1 itself (condition estimate)
-    size_t dunit_n = 0;
+    std::vector<double> probe_gram;        // B^T B of the probe vectors the device factorisation carries (condition estimate), for probe_n rows
+    int probe_n = 0;
     // small host -> device uploads (weights, masks): which way is faster on THIS box is measured on the first calls (see staged_h2d)
     int h2d_method = -1;                   // -1 undecided, 0 = the runtime's pageable copy (waited for), 1 = page-locked staging
     int h2d_probes = 0;

@@ -95,7 +95,12 @@ hipError_t launch_tri_unpack(const double* tri, int K, double* packed, hipStream
 // cvec: device right-hand side (NULL = the c part of packed)
 size_t chol_large_work_doubles(int n);
 hipError_t launch_chol_large(const double* packed, const double* cvec, int n, double alpha, double* work, double* dsc, double* z,
-                             double* beta, int* status, double* minpiv, double* host_out, bool clear_status, hipStream_t st);
+                             double* beta, int* status, double* minpiv, double* host_out, bool clear_status, double* probe_out,
+                             hipStream_t st);
+// probe_out (may be NULL): receives the CHOL_PROBES x CHOL_PROBES matrix Z^T Z of the probe vectors the strip carries (condition
+// estimate, see fsnap_chol_probe_gram_k); the probe at (row, p), p = 1 .. CHOL_PROBES, is chol_probe(row, p)
+constexpr int CHOL_PROBES = 31;
+double chol_probe(int row, int p);
 // one more right-hand side (n doubles, device) for the factor the last launch_chol_large of the same n left in `work`
 hipError_t launch_chol_resolve(const double* d_rhs, int n, double* work, const double* dsc, double* z, double* beta, int* status,
                                const double* minpiv, double* host_out, hipStream_t st);

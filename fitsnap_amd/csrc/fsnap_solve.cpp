@@ -707,6 +707,50 @@ extern "C" __attribute__((visibility("hidden"))) int fsnap_host_chol_upper(doubl
     return fast_chol(a, n, min_piv);
 }
 
+// Largest theta with M x = theta N x for symmetric k x k matrices (row-major), N positive definite: Cholesky of N, the
+// congruence C = U^-T M U^-1, Lanczos on C.  The Rayleigh-Ritz step of the device factor's condition estimate (k = 31:
+// fsnap_chol_probe_gram_k, fsnap_solve_device_rhs).  Returns -1.0 when N is not positive definite or a value is not finite.
+extern "C" __attribute__((visibility("hidden"))) double fsnap_gen_eig_max(const double* M, const double* N, int k) {
+    if (k <= 0 || !all_finite(M, (size_t)k * k) || !all_finite(N, (size_t)k * k)) return -1.0;
+    vec U(N, N + (size_t)k * k), C((size_t)k * k);
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < i; ++j) U[(size_t)i * k + j] = 0.0;
+    double mp = 0.0;
+    if (chol_upper(U.data(), k, &mp) >= 0) return -1.0;
+    // T = U^-T M: forward substitution down every column of M; then C^T = U^-T T^T the same way (C is symmetric)
+    vec T(M, M + (size_t)k * k);
+    auto forward_columns = [&](vec& X) {
+        for (int i = 0; i < k; ++i) {
+            const double inv = 1.0 / U[(size_t)i * k + i];
+            for (int c = 0; c < k; ++c) {
+                double sacc = X[(size_t)i * k + c];
+                for (int l = 0; l < i; ++l) sacc -= U[(size_t)l * k + i] * X[(size_t)l * k + c];
+                X[(size_t)i * k + c] = sacc * inv;
+            }
+        }
+    };
+    forward_columns(T);
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) C[(size_t)i * k + j] = T[(size_t)j * k + i];
+    forward_columns(C);
+    for (int i = 0; i < k; ++i)
+        for (int j = i + 1; j < k; ++j) C[(size_t)i * k + j] = C[(size_t)j * k + i] = 0.5 * (C[(size_t)i * k + j] + C[(size_t)j * k + i]);
+    // largest eigenvalue of the k x k matrix C: Lanczos with full re-orthogonalisation (a dozen matrix-vector products of k^2
+    // flops; the cyclic Jacobi sweeps this replaced took 0.25 ms at k = 31 -- more than the launch they follow)
+    const double* Cp = C.data();
+    vec tmp((size_t)k);
+    const fsnap::CondEstimate top = fsnap::lanczos_lambda_min(k, [Cp, k, &tmp](double* x) {
+        for (int i = 0; i < k; ++i) {
+            double acc = 0.0;
+            for (int j = 0; j < k; ++j) acc += Cp[(size_t)i * k + j] * x[j];
+            tmp[i] = acc;
+        }
+        for (int i = 0; i < k; ++i) x[i] = tmp[i];
+        return true;
+    }, 4, 16);
+    return top.lambda_min > 0.0 && std::isfinite(top.lambda_min) ? 1.0 / top.lambda_min : -1.0;
+}
+
 extern "C" int fsnap_solve(int kind, double param, int64_t K64, const double* G, const double* c, double* beta,
                            int* rank_out, double* rcond_est) {
     return fsnap_solve_diag(kind, param, K64, G, c, nullptr, beta, rank_out, rcond_est);

@@ -264,7 +264,9 @@ int fsnap_residual_rhs(fsnap_ctx* ctx, const double* beta, double* s, double* ss
  * knows about the conditioning of the Jacobi-scaled matrix S (unit diagonal, so 1 <= lambda_max <= K): for the LSTSQ
  * kinds -- which stand in for an SVD of the rows, svd.py:54 -- min(smallest pivot, lambda_min(S) estimated from the factor
  * by 2 ... 8 Lanczos steps on S^-1, i.e. pairs of triangular sweeps: dpocon's idea, csrc/fsnap_condest.h), an estimate
- * from ABOVE that is within a factor ~1.3 of lambda_min wherever the statistics still resolve it (lambda_min > ~K eps);
+ * from ABOVE that is within a factor ~1.3 of lambda_min wherever the statistics still resolve it (lambda_min > ~K eps)
+ * -- for a factor on the DEVICE (fsnap_solve_device*, K >= 232): the Rayleigh-Ritz value of S^-1 on 31 probe vectors that the
+ * factorisation carries in its right-hand-side strip, scaled by 120 / K, within ~[lambda_min / 5, 10 lambda_min], no sweep --;
  * a factor whose estimate falls below 64 K eps counts as unresolved exactly like a failed pivot.  For the other kinds
  * (sklearn's Cholesky, np.linalg.inv: neither looks at the conditioning) the smallest pivot alone, an upper bound of
  * lambda_min that can be off by a factor exponential in K.

@@ -79,7 +79,7 @@ int main(int argc, char** argv) {
         for (int it = 0; it < 12; ++it) {
             CK(hipDeviceSynchronize());
             const auto t0 = std::chrono::steady_clock::now();
-            CK(fsnap::launch_chol_large(dp, nullptr, n, 0.0, work, dsc, z, beta, status, minpiv, nullptr, true, 0));
+            CK(fsnap::launch_chol_large(dp, nullptr, n, 0.0, work, dsc, z, beta, status, minpiv, nullptr, true, nullptr, 0));
             CK(hipDeviceSynchronize());
             const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
             if (it >= 2 && us < best) best = us;
