@@ -1109,24 +1109,26 @@ __global__ __launch_bounds__(256) void fsnap_chol_extract_factor_k(const double*
 // the Lanczos sweeps with the device factor that this replaces cost 0.06 / 0.10 / 0.40 ms EACH at K = 256 / 480 / 1 595 and a
 // well-conditioned 15 213 x 1 595 SVD fit went from 1.3 to 3.5 ms.
 // The strip rows of the LAST panel are never substituted by the panel loop (there is no launch behind the last panel): this
-// kernel runs their forward substitution itself, like fsnap_chol_backsolve_k does for the right-hand side.
+// kernel runs their forward substitution itself, like fsnap_chol_backsolve_k does for the right-hand side; then Z^T Z on the
+// matrix pipe (a 4-row chunk of the strip = one register per 16-column half, three MFMAs), eight waves over the rows.
 // out[(i - 1) * 31 + (j - 1)] = sum_r Z[r][i] Z[r][j], i, j = 1 .. 31; fixed summation order.
 // ---------------------------------------------------------------------------------
 constexpr int CHOL_NPROBE = CHOL_XS - 1;
 
-__global__ __launch_bounds__(1024) void fsnap_chol_probe_gram_k(const double* __restrict__ Uf, const double* __restrict__ Sraw, int ld,
-                                                               int np, double* __restrict__ out, const int* __restrict__ status) {
+__global__ __launch_bounds__(512) void fsnap_chol_probe_gram_k(const double* __restrict__ Uf, const double* __restrict__ Sraw, int ld,
+                                                              int np, double* __restrict__ out, const int* __restrict__ status) {
     __shared__ double U11[CHOL_NB * (CHOL_NB + 1)];
     __shared__ double Zl[CHOL_NB][CHOL_XS];
+    __shared__ double red[8][3][4][64];                // the waves' partial tiles (0,0), (0,1), (1,1) in the accumulator layout
     if (*status) return;                       // the factorisation failed: there is no factor to ask (the host does not look)
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, e = lane & 15, kr = lane >> 4;
     const int r0 = np - CHOL_NB;
-    for (int t = tid; t < CHOL_NB * CHOL_NB; t += 1024) U11[(t >> 6) * (CHOL_NB + 1) + (t & 63)] = Uf[(size_t)(r0 + (t >> 6)) * ld + r0 + (t & 63)];
-    if (tid < CHOL_NB) Zl[tid][0] = 0.0;               // (column 0 is the right-hand side: not a probe, never summed)
+    for (int t = tid; t < CHOL_NB * CHOL_NB; t += 512) U11[(t >> 6) * (CHOL_NB + 1) + (t & 63)] = Uf[(size_t)(r0 + (t >> 6)) * ld + r0 + (t & 63)];
     __syncthreads();
-    // y = U11^-T s for the last panel's raw strip rows: one wave per column (wave wv: columns wv + 1 and wv + 17), 64 steps,
+    // y = U11^-T s for the last panel's raw strip rows (all 32 columns: column 0 is the right-hand side, whose products land in
+    // row / column 0 of the Gram matrix and are not handed out): one wave per column (wave wv: columns wv, wv + 8, ...), 64 steps,
     // multipliers broadcast with v_readlane
-    for (int c = wv + 1; c < CHOL_XS; c += 16) {
+    for (int c = wv; c < CHOL_XS; c += 8) {
         double v = Sraw[(size_t)(r0 + lane) * ld + np + c];
         const double invd = 1.0 / U11[lane * (CHOL_NB + 1) + lane];
 #pragma unroll 8
@@ -1138,45 +1140,52 @@ __global__ __launch_bounds__(1024) void fsnap_chol_probe_gram_k(const double* __
         Zl[lane][c] = v;
     }
     __syncthreads();
-    // Gram of the strip, 128 rows at a time through LDS: the 32 strip values of a row are 256 contiguous bytes, so a tile is four
-    // coalesced doubles per thread -- all loads of a tile in flight at once, the next tile's on their way while this one is
-    // summed (961 threads walking the rows with two strided loads each paid one HBM round trip per four rows: 0.3 ms at K = 1 595)
-    __shared__ double Zt[128][CHOL_XS + 1];
-    const int i = tid / CHOL_NPROBE + 1, j = tid % CHOL_NPROBE + 1;
-    const bool mine = tid < CHOL_NPROBE * CHOL_NPROBE;
-    const int tr = tid >> 3, tc = (tid & 7) * 4;            // this thread's four values of a tile: row tr, columns tc .. tc + 3
-    double acc = 0.0;
-    double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
-    auto fetch = [&](int base) {
-        const int r = base + tr;
-        if (r < r0) {
-            const double* src = Uf + (size_t)r * ld + np + tc;
-            q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3];
-        } else if (r < np) {
-            q0 = Zl[r - r0][tc]; q1 = Zl[r - r0][tc + 1]; q2 = Zl[r - r0][tc + 2]; q3 = Zl[r - r0][tc + 3];
-        } else {
-            q0 = q1 = q2 = q3 = 0.0;
-        }
-    };
-    fetch(0);
-    for (int base = 0; base < np; base += 128) {
-        __syncthreads();                                    // the previous tile has been summed by everybody
-        Zt[tr][tc] = q0; Zt[tr][tc + 1] = q1; Zt[tr][tc + 2] = q2; Zt[tr][tc + 3] = q3;
-        __syncthreads();
-        if (base + 128 < np) fetch(base + 128);
-        if (mine) {
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll 8
-            for (int r = 0; r < 128; r += 4) {
-                a0 = __builtin_fma(Zt[r][i], Zt[r][j], a0);
-                a1 = __builtin_fma(Zt[r + 1][i], Zt[r + 1][j], a1);
-                a2 = __builtin_fma(Zt[r + 2][i], Zt[r + 2][j], a2);
-                a3 = __builtin_fma(Zt[r + 3][i], Zt[r + 3][j], a3);
+    // Z^T Z on the matrix pipe: a 4-row chunk of the strip is one register per 16-column half -- A operand (column e, row kr) and B
+    // operand (row kr, column e) at once, kernel 1's operand trick --, three MFMAs per chunk for the tiles (0,0), (0,1), (1,1);
+    // wave wv takes the chunks wv, wv + 8, ...; eight loads in flight per lane
+    d4 t00 = {0.0, 0.0, 0.0, 0.0}, t01 = t00, t11 = t00;
+    const int nchunk = np / 4;
+    for (int c0 = wv; c0 < nchunk; c0 += 8 * 4) {
+        double h0[4], h1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = 4 * (c0 + 8 * u) + kr;
+            if (row < r0) {
+                h0[u] = Uf[(size_t)row * ld + np + e];
+                h1[u] = Uf[(size_t)row * ld + np + 16 + e];
+            } else if (row < np) {
+                h0[u] = Zl[row - r0][e];
+                h1[u] = Zl[row - r0][16 + e];
+            } else {
+                h0[u] = h1[u] = 0.0;
             }
-            acc += (a0 + a1) + (a2 + a3);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(h0[u], h0[u], t00, 0, 0, 0);
+            t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(h0[u], h1[u], t01, 0, 0, 0);
+            t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(h1[u], h1[u], t11, 0, 0, 0);
         }
     }
-    if (mine) out[tid] = acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[wv][0][r][lane] = t00[r];
+        red[wv][1][r][lane] = t01[r];
+        red[wv][2][r][lane] = t11[r];
+    }
+    __syncthreads();
+    // fixed-order sum over the eight waves; element (tile, r, lane) = entry (16 a + 4 r + kr, 16 b + e) of the 32 x 32 Gram matrix
+    for (int t = tid; t < 3 * 256; t += 512) {
+        const int tile = t >> 8, r = (t >> 6) & 3, ln = t & 63;
+        double acc = red[0][tile][r][ln];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) acc += red[w][tile][r][ln];
+        const int i = (tile == 2 ? 16 : 0) + 4 * r + (ln >> 4), j = (tile == 0 ? 0 : 16) + (ln & 15);
+        if (i >= 1 && j >= 1) {
+            out[(i - 1) * CHOL_NPROBE + (j - 1)] = acc;
+            if (tile == 1) out[(j - 1) * CHOL_NPROBE + (i - 1)] = acc;      // the (1,0) tile is the transpose of (0,1)
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -1246,7 +1255,7 @@ hipError_t launch_chol_large(const double* packed, const double* cvec, int n, do
     launch_chol_panels(S, Uf, ld, np, Yall, status, minpiv, st);
     // the probes' Rayleigh-Ritz matrix (condition estimate), before the back substitution's last launch hands the results over
     if (probe_out)
-        hipLaunchKernelGGL(fsnap_chol_probe_gram_k, dim3(1), dim3(1024), 0, st, (const double*)Uf, (const double*)S, ld, np, probe_out,
+        hipLaunchKernelGGL(fsnap_chol_probe_gram_k, dim3(1), dim3(512), 0, st, (const double*)Uf, (const double*)S, ld, np, probe_out,
                            (const int*)status);
     static bool bs_attr_set = false;
     if (!bs_attr_set) {
