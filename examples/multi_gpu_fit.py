@@ -1,14 +1,15 @@
 """Data-parallel fit over several MI355X, one process per GPU, native RCCL behind the C ABI (no torch in the processes):
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
-        examples/multi_gpu_fit.py [--rows-per-gpu 1000000] [--cols 128] [--solver RIDGE|SVD]
+        examples/multi_gpu_fit.py [--rows-per-gpu 1000000] [--cols 128] [--solver RIDGE|SVD] [--transport rccl|p2p]
 
 (the launcher is only used to start the processes and set RANK / LOCAL_RANK / WORLD_SIZE.)  The reference's form of this
 algorithm is examples/library/transpose_trick/example.py:230-254: every MPI rank accumulates aw.T aw and aw.T bw over ITS
 configurations, then comm.Allreduce(c), comm.Allreduce(d) and one solve.  Here every rank keeps the rows of its
 configurations in the HBM of its GPU; ``solver.perform_fit`` is collective: fused statistics kernel, ONE in-place
-ncclAllReduce of K^2 + K + 3 doubles on the kernels' stream, K x K solve; ``solver.fit`` ends up on rank 0, like the
-reference.  ``error_analysis`` pools per-group error sums (a fixed-size table per rank), no row ever moves."""
+all-reduce of K^2 + K + 3 doubles on the kernels' stream (``ncclAllReduce``, or with ``--transport p2p`` one launch of the
+peer-to-peer transport over hipIpc windows, which also puts several ranks on ONE GPU), K x K solve; ``solver.fit`` ends up on
+rank 0, like the reference.  ``error_analysis`` pools per-group error sums (a fixed-size table per rank), no row ever moves."""
 import argparse
 import os
 import sys
@@ -24,13 +25,14 @@ def main():
     ap.add_argument("--rows-per-gpu", type=int, default=1_000_000)
     ap.add_argument("--cols", type=int, default=128)
     ap.add_argument("--solver", default="RIDGE", choices=["RIDGE", "SVD"])
+    ap.add_argument("--transport", default=None, choices=["rccl", "p2p"])
     args = ap.parse_args()
     from fitsnap_amd.config import Config
     from fitsnap_amd.parallel_tools import ParallelTools
     from fitsnap_amd.solvers import solver_factory
     from fitsnap_amd.synthetic import synth_problem
 
-    pt = ParallelTools(comm="rccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    pt = ParallelTools(comm="rccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None, transport=args.transport)
     rank, world = pt.get_rank(), pt.get_size()
     m, K = args.rows_per_gpu, args.cols
     # this rank's "configurations": a disjoint block of the synthetic rows (a real run fills pt.shared_arrays from LAMMPS)
