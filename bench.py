@@ -634,7 +634,10 @@ def run_rank(args):
     wk = None
     if rank == 0:
         try:
-            m1 = head["rows_this_rank"]
+            # the rows RESIDENT now are those of the mode that ran last (strong and weak hold different shards of a
+            # multi-rank job: sizing the output by the first mode's rows overran it -- a GPU memory fault on rank 0 of every
+            # `--scaling both` run with N > 1, found when round 6 first ran two ranks)
+            m1 = results[modes[-1]]["rows_this_rank"]
             d_aw = ctx.dev_alloc(m1 * Kc * 8)
             d_bw = ctx.dev_alloc(m1 * 8)
             wms = []

@@ -74,6 +74,24 @@ def main(outdir, scenario):
             out[f"doubles_{K}"] = np.array(n)
             ctx.dev_free(d)
             ctx.barrier()
+    elif scenario.startswith("reupload"):
+        # a job that fits one set of rows, then a LARGER one on the same contexts (bench.py: strong then weak scaling): every
+        # buffer of the context is re-allocated between two series of collectives
+        from fitsnap_amd.synthetic import synth_problem
+
+        K = 128
+        for m in (120000, 260000):
+            A, b, w = synth_problem(m, K, row_offset=rank * 16 * 65536)
+            ctx.upload_rows(A, b)
+            ctx.set_weights(w)
+            for _ in range(25):
+                beta = ctx.fit_dist(_capi.SOLVE_RIDGE, 1e-8, K)[0]
+            ctx.barrier()
+            out[f"beta_{m}"] = beta
+            t = np.zeros((world, 2))
+            t[rank] = (m, rank)
+            ctx.allreduce_host(t.reshape(-1))
+            out[f"table_{m}"] = t
     elif scenario == "dead_peer":
         # rank 1 leaves before the collective: rank 0's all-reduce must come back with an error inside the bound
         # (FSNAP_COMM_TIMEOUT = 4 in the environment), not hang -- the wait INSIDE the kernel is bounded too

@@ -220,6 +220,28 @@ def test_bench_runs_the_multi_gpu_step_without_torch(tmp_path):
     assert rec["transport"] == "rccl"
 
 
+def test_bench_two_ranks_both_scalings_on_the_peer_to_peer_transport():
+    # `bench.py --gpus 2` as the driver runs it (both scalings in one job), with the two ranks on the peer-to-peer transport so
+    # that they can share the one GPU of the box.  First executed in round 6 -- and it crashed: rank 0's weighting-kernel leg
+    # sized its output by the FIRST mode's shard while the rows of the LAST mode were resident (a GPU memory fault in every
+    # N > 1 run with --scaling both, whatever the transport).
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    env["FSNAP_COMM_TIMEOUT"] = "120"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "p2p", "--rows", "262144",
+                          "--steps", "5", "--warmup", "2", "--preheat", "10"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["n_ranks_seen"] == 2 and rec["transport"] == "p2p" and rec["ranks_per_device"] == 2
+    assert rec["scaling"] == "strong" and rec["strong_value"] == rec["value"] > 0 and rec["weak_value"] > 0
+    assert len(rec["per_rank"]["kernel_ms"]) == 2 and all(t > 0 for t in rec["per_rank"]["allreduce_ms"])
+    assert rec["per_rank"]["rows"] == [131072, 131072]
+    assert rec["weighting_kernel"]["ms"] > 0 and rec["cpu_baseline"]["value"] > 0 and rec["torch_imported"] is False
+
+
 def test_bench_single_gpu_line_carries_the_contract_fields_and_the_pipelined_leg():
     # plain `python bench.py` on one GPU: ONE JSON line with the driver's fields, roofline + cpu_baseline objects, and the
     # two-fits-in-flight leg as an extra object (same coefficients, never `value`)

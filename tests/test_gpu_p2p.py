@@ -72,3 +72,13 @@ def test_a_dead_peer_ends_the_wait_instead_of_hanging(tmp_path):
     r0 = dict(np.load(tmp_path / "rank0.npz"))
     assert "did not" in str(r0["error"]) and "rank 0 of 2" in str(r0["error"]), str(r0["error"])
     assert 3.0 < float(r0["seconds"]) < 30.0
+
+
+def test_larger_rows_on_the_same_contexts_between_two_series_of_fits(tmp_path):
+    # strong then weak scaling in one job: every buffer of a context is re-allocated between two series of collective fits
+    procs, logs = _launch(tmp_path, 2, "reupload")
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-4000:]
+    r0, r1 = (dict(np.load(tmp_path / f"rank{r}.npz")) for r in range(2))
+    for m in (120000, 260000):
+        assert np.array_equal(r0[f"beta_{m}"], r1[f"beta_{m}"])                 # same bits on both ranks
+        assert np.array_equal(r0[f"table_{m}"], [[m, 0.0], [m, 1.0]]) and np.array_equal(r0[f"table_{m}"], r1[f"table_{m}"])
