@@ -82,3 +82,12 @@ def test_larger_rows_on_the_same_contexts_between_two_series_of_fits(tmp_path):
     for m in (120000, 260000):
         assert np.array_equal(r0[f"beta_{m}"], r1[f"beta_{m}"])                 # same bits on both ranks
         assert np.array_equal(r0[f"table_{m}"], [[m, 0.0], [m, 1.0]]) and np.array_equal(r0[f"table_{m}"], r1[f"table_{m}"])
+
+
+def test_every_linear_solver_class_with_two_ranks_matches_one_process():
+    # SVD, RIDGE (sklearn and local), ARD, ANL, LASSO on the golden Ta rows dealt to two ranks by configuration i % 2 (the
+    # reference's partition, parallel_tools.py:612-651) against the same fits in one process: scripts/multi_rank_solvers.py
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "multi_rank_solvers.py")], capture_output=True, text=True,
+                         timeout=900, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert "worst" in out.stdout and out.stdout.count("two ranks vs one process") == 6
