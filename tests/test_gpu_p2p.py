@@ -91,3 +91,12 @@ def test_every_linear_solver_class_with_two_ranks_matches_one_process():
                          timeout=900, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     assert "worst" in out.stdout and out.stdout.count("two ranks vs one process") == 6
+
+
+def test_flows_that_only_a_multi_rank_job_exercises():
+    # scripts/multi_rank_flows.py: the collective row-space solve of a 24 000 x 480 system with kappa 1e9 (device pass factors,
+    # factor chain) against numpy's lstsq on all rows; a re-weighting loop on resident rows (perform_fit + error_analysis per
+    # candidate) and ParallelTools.free() in mid-job against the same flow in one process
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "multi_rank_flows.py")], capture_output=True, text=True,
+                         timeout=1200, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout + out.stderr)[-3000:]
