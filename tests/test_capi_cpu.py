@@ -190,3 +190,14 @@ def test_host_solve_padding_is_transparent(K):
         ref = d * np.linalg.solve((G + alpha * np.eye(K)) * d[:, None] * d[None, :], c * d)
         assert rank == K
         assert np.linalg.norm(beta - ref) / np.linalg.norm(ref) < 1e-8, (K, kind)
+
+
+def test_peer_to_peer_communicator_ids_carry_their_transport(monkeypatch):
+    # fsnap_comm_id_p2p needs no GPU: 128 bytes, a magic prefix that fsnap_comm_init recognises (the transport travels with the
+    # id), a random token behind it; FSNAP_DIST_TRANSPORT=p2p makes the plain fsnap_comm_id return one too
+    a, b = _capi.comm_id("p2p"), _capi.comm_id("p2p")
+    assert len(a) == len(b) == _capi.COMM_ID_BYTES and a[:8] == b[:8] == b"FSNP2P01" and a[8:32] != b[8:32]
+    monkeypatch.setenv("FSNAP_DIST_TRANSPORT", "p2p")
+    assert _capi.comm_id()[:8] == b"FSNP2P01"
+    with pytest.raises(ValueError):
+        _capi.comm_id("mpi")
