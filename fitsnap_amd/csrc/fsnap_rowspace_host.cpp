@@ -1004,7 +1004,6 @@ int FactorSolver::deflate_width(double rc, std::vector<double>& X, double norm_b
     HostProf hp5_("deflate: iteration + rest");
     double G[DB * DB], P[DB * DB], Q[DB * DB], sig[DB];
     vec uc((size_t)MAXCUT * n), vc((size_t)MAXCUT * n);
-    double sc[MAXCUT];
     vec un((size_t)n);
     int k = 0;
     bool conv = false;
@@ -1035,7 +1034,6 @@ int FactorSolver::deflate_width(double rc, std::vector<double>& X, double norm_b
         for (int c = 0; c < k; ++c) {
             double* u = uc.data() + (size_t)c * n;
             double* v = vc.data() + (size_t)c * n;
-            sc[c] = 1.0 / sig[c];
             for (int i = 0; i < n; ++i) {
                 double tu = 0.0, tv = 0.0;
                 for (int b = 0; b < DB; ++b) {

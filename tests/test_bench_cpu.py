@@ -25,7 +25,7 @@ def test_committed_traffic_record_belongs_to_the_committed_kernel_sources():
     assert recs[0]["rows"] == 1000000 and recs[0]["K"] == 128          # the headline shape comes first
     for rec in recs:
         assert rec["source_sha256"] == bench.kernel_source_digest(rec["kernel"]), \
-            "the kernel's source file / fsnap_device_common.h changed after the PMC passes: re-run scripts/pmc_record_r04.sh"
+            "the kernel's source file / fsnap_device_common.h changed after the PMC passes: re-run scripts/pmc_record_all.sh"
         info = {"workgroups": rec["workgroups"], "threads": rec["threads"], "chunks_per_wave": rec["chunks_per_wave"]}
         traffic, source = bench.recorded_traffic(rec["rows"], rec["K"], info, rec["kernel"])
         assert traffic == rec["hbm_bytes_per_launch"] and "FETCH_SIZE" in source
