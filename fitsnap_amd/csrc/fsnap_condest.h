@@ -55,12 +55,16 @@ inline double tridiag_lambda_max(const double* a, const double* b, int n) {
 // apply_inv(x): x <- S^-1 x in place (n doubles); returns false when the operator failed (non-finite result, device
 // error): the estimate is then 0 (numerically singular) and the caller takes its general path.
 // Stops after >= min_steps steps once a step raises the Ritz value by less than 25 %, at max_steps, or when the Krylov
-// space closes (an invariant subspace: the Ritz value is exact).
+// space closes (an invariant subspace: the Ritz value is exact).  `growth`: the stopping ratio (1.25 = the 25 % above);
+// `theta_trace` (max_steps doubles, optional): the largest Ritz value after every step taken, zeros behind the last one.
 template <class ApplyInv>
-CondEstimate lanczos_lambda_min(int n, ApplyInv&& apply_inv, int min_steps = 2, int max_steps = 8) {
+CondEstimate lanczos_lambda_min(int n, ApplyInv&& apply_inv, int min_steps = 2, int max_steps = 8, double growth = 1.25,
+                                double* theta_trace = nullptr) {
     CondEstimate out;
     if (n <= 0) return out;
     if (max_steps > 16) max_steps = 16;
+    if (theta_trace)
+        for (int j = 0; j < max_steps; ++j) theta_trace[j] = 0.0;
     std::vector<double> V((size_t)(max_steps + 1) * n), w(n);
     double al[16], be[16];
     // fixed start vector: a 64-bit LCG mapped to (-1, 1), never near zero in every component at once
@@ -90,7 +94,8 @@ CondEstimate lanczos_lambda_min(int n, ApplyInv&& apply_inv, int min_steps = 2, 
         out.steps = j + 1;
         theta = tridiag_lambda_max(al, be, j + 1);
         if (!(theta > 0.0) || !std::isfinite(theta)) return CondEstimate{0.0, j + 1};
-        if (j + 1 >= min_steps && theta <= 1.25 * theta_prev) break;
+        if (theta_trace) theta_trace[j] = theta;
+        if (j + 1 >= min_steps && theta <= growth * theta_prev) break;
         if (j + 1 == max_steps) break;
         theta_prev = theta;
         // next Lanczos vector: full re-orthogonalisation (twice), the Krylov space is at most 16 vectors

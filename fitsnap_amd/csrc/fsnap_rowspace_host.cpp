@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/fsnap_hip.h"
+#include "fsnap_condest.h"
 #include "fsnap_rowspace_host.h"
 
 extern "C" int fsnap_host_chol_upper(double* a, int n, double* min_piv);   // fsnap_solve.cpp
@@ -124,6 +125,17 @@ static void run_tasks(int nt, std::vector<std::function<void()>>& tasks) {
     run_threads(nt, [&](int t) {
         for (int i = t; i < n; i += nt) tasks[i]();
     });
+}
+
+// sum of squares with eight independent partial sums in a fixed order (one dependent chain costs 4 cycles per entry)
+static double sum_squares(const double* p, size_t n) {
+    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8)
+        for (int j = 0; j < 8; ++j) t[j] += p[i + j] * p[i + j];
+    double r = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    for (; i < n; ++i) r += p[i] * p[i];
+    return r;
 }
 
 bool finite_all(const double* p, size_t n) {
@@ -509,57 +521,62 @@ double inverse_norm1_estimate(int n, const double* T, bool transposed, int threa
     return std::fmax(est, 2.0 * alt / (3.0 * n));
 }
 
-// ||T^-1||_2 = 1 / sigma_min(T) by inverse iteration on T^T T (two triangular solves per step), started from a fixed
-// pseudo-random vector; the Rayleigh quotients increase towards the largest eigenvalue of (T^T T)^-1, so the result is a
-// LOWER estimate -- a few per cent low after a dozen steps unless the start vector is nearly orthogonal to the whole
-// cluster of smallest singular directions.  Cost: 2 * steps * n^2 / 2 flops.
-double inverse_norm2_estimate(int n, const double* T, int steps = 14, int snap_steps = 0, double* snap = nullptr, int threads = 1) {
+// ||T^-1||_2 = 1 / sigma_min(T) from the Lanczos process on (T^T T)^-1 (two triangular solves per step, fsnap_condest.h: fixed
+// start vector, full re-orthogonalisation): the largest Ritz value increases towards 1 / sigma_min^2, so the result is a
+// LOWER estimate -- after j steps at least what j steps of inverse iteration from the same start return, and within a few
+// per cent once a step adds less than 10 %.  4 ... 10 steps; until round 6 this was 14 steps of plain inverse iteration,
+// 28 sequential solves of K^2 / 2 that were the long pole of the chain's estimators (16 of 32 ms at K = 1595).
+// `snap`: what the first `snap_steps` steps alone return (the quick look of certified()).
+double inverse_norm2_estimate(int n, const double* T, int snap_steps = 0, double* snap = nullptr, int threads = 1) {
     if (snap) *snap = 0.0;
     if (n == 0) return 0.0;
     TriTeam team(n, threads);
-    vec v((size_t)n);
-    unsigned long long state = 0x9E3779B97F4A7C15ull;
-    double nv = 0.0;
-    for (int i = 0; i < n; ++i) {
-        state = state * 6364136223846793005ull + 1442695040888963407ull;
-        v[i] = ((double)(state >> 11) / 9007199254740992.0) - 0.5;
-        nv += v[i] * v[i];
+    constexpr int MAX_STEPS = 10;
+    double trace[MAX_STEPS];
+    const fsnap::CondEstimate ce = fsnap::lanczos_lambda_min(
+        n,
+        [&](double* v) {
+            team.solve_upper_transposed(T, v);     // w = T^-T v
+            team.solve_upper(T, v);                // v = T^-1 w = (T^T T)^-1 v_old
+            double chk = 0.0;
+            for (int i = 0; i < n; ++i) chk += v[i] * 0.0;
+            return chk == 0.0;
+        },
+        4, MAX_STEPS, 1.10, trace);
+    const double inf = std::numeric_limits<double>::infinity();
+    if (!(ce.lambda_min > 0.0)) {               // a singular or non-finite factor: ||T^-1|| is unbounded
+        if (snap) *snap = inf;
+        return inf;
     }
-    nv = std::sqrt(nv);
-    for (double& x : v) x /= nv;
-    double est = 0.0;
-    for (int it = 0; it < steps; ++it) {
-        team.solve_upper_transposed(T, v.data());     // w = T^-T v
-        team.solve_upper(T, v.data());                // v = T^-1 w = (T^T T)^-1 v_old
-        double nn = 0.0;
-        for (double x : v) nn += x * x;
-        nn = std::sqrt(nn);
-        if (!(nn > 0.0) || !std::isfinite(nn)) {
-            if (snap && it < snap_steps) *snap = std::numeric_limits<double>::infinity();
-            return std::numeric_limits<double>::infinity();
-        }
-        est = std::sqrt(nn);                          // ||(T^T T)^-1 v|| -> 1 / sigma_min^2 for unit v
-        if (snap && it + 1 == snap_steps) *snap = est;     // what `snap_steps` steps alone would have returned
-        for (double& x : v) x /= nn;
+    if (snap && snap_steps > 0) {
+        const int j = std::min(snap_steps, ce.steps) - 1;
+        *snap = trace[j] > 0.0 ? std::sqrt(trace[j]) : 0.0;
     }
-    return est;
+    return std::sqrt(1.0 / ce.lambda_min);
 }
 
-// ||T||_2 by power iteration on T^T T (upper triangular T, row-major): a lower estimate, close after a dozen steps.
-// One pass over T per step (w_i = t_i . v and v' += w_i t_i use the same row); the rows are cut into a FIXED number of chunks
-// with a partial v' each, summed in chunk order -- the value does not depend on how many threads ran the chunks.
-double norm2_estimate(int n, const double* T, int steps = 12, int threads = 0) {
+// ||T||_2 from the Lanczos process on T^T T (upper triangular T, row-major; uniform start vector, full re-orthogonalisation):
+// a LOWER estimate, after j steps at least what j steps of power iteration return; 3 ... `steps` steps, stopping once a step
+// adds less than 2 % (until round 6: 12 steps of power iteration, the long pole of the chain's estimators once the inverse
+// iteration had gone).  One pass over T per step (w_i = t_i . v and v' += w_i t_i use the same row); the rows are cut into a
+// FIXED number of chunks with a partial v' each, summed in chunk order -- the value does not depend on how many threads ran
+// the chunks.
+double norm2_estimate(int n, const double* T, int steps = 8, int threads = 0) {
     if (n == 0) return 0.0;
+    if (steps > 16) steps = 16;
     // (one set of threads for all steps; `threads` > 0: the caller's share when other estimators run beside this one)
     const int nchunk = n >= 384 ? 16 : 1;
     const int nt = std::min(std::min(threads_for(n, 0.5 * (double)n * n * steps), threads > 0 ? threads : 64), nchunk);
-    vec v((size_t)n, 1.0 / std::sqrt((double)n)), part((size_t)nchunk * n);
-    double est = 0.0, bad = 0.0;
-    bool stop = false;
-    // ONE set of threads for all the steps (a barrier after the partial products, one after the reduction by thread 0)
+    vec V((size_t)(steps + 1) * n), part((size_t)nchunk * n), w((size_t)n);
+    std::fill(V.begin(), V.begin() + n, 1.0 / std::sqrt((double)n));
+    double al[16], be[16];
+    double theta = 0.0, theta_prev = 0.0, bad = 0.0;
+    bool stop = false, broken = false;
+    // ONE set of threads for all the steps (a barrier after the partial products, one after the serial part by thread 0)
     SpinBarrier bar(nt);
     run_team(nt, bar, [&](int t, int team) {
         for (int it = 0; it < steps; ++it) {
+            const double* __restrict__ v = V.data() + (size_t)it * n;
             for (int ch = t; ch < nchunk; ch += team) {
                 double* __restrict__ pv = part.data() + (size_t)ch * n;
                 std::fill(pv, pv + n, 0.0);
@@ -572,27 +589,208 @@ double norm2_estimate(int n, const double* T, int steps = 12, int threads = 0) {
             }
             bar.wait();
             if (t == 0) {
-                double nn = 0.0;
+                double a = 0.0;
                 for (int k = 0; k < n; ++k) {
                     double t2 = 0.0;
                     for (int ch = 0; ch < nchunk; ++ch) t2 += part[(size_t)ch * n + k];
-                    v[k] = t2;
-                    nn += t2 * t2;
+                    w[k] = t2;
+                    a += t2 * v[k];
                 }
-                nn = std::sqrt(nn);
-                if (!(nn > 0.0) || !std::isfinite(nn)) {
-                    bad = nn;
-                    stop = true;
+                if (!(a > 0.0) || !std::isfinite(a)) {          // T^T T is positive semi-definite: zero = a zero factor
+                    bad = a;
+                    broken = stop = true;
                 } else {
-                    est = std::sqrt(nn);                  // ||T^T T v|| -> sigma_max^2 for unit v
-                    for (double& x : v) x /= nn;
+                    al[it] = a;
+                    theta = fsnap::tridiag_lambda_max(al, be, it + 1);
+                    if ((it + 1 >= 3 && theta <= 1.02 * theta_prev) || it + 1 == steps) stop = true;
+                    theta_prev = theta;
+                    if (!stop) {
+                        for (int pass = 0; pass < 2; ++pass)
+                            for (int p = 0; p <= it; ++p) {
+                                const double* vp = V.data() + (size_t)p * n;
+                                double d = 0.0;
+                                for (int k = 0; k < n; ++k) d += vp[k] * w[k];
+                                for (int k = 0; k < n; ++k) w[k] -= d * vp[k];
+                            }
+                        double b2 = 0.0;
+                        for (int k = 0; k < n; ++k) b2 += w[k] * w[k];
+                        const double bn = std::sqrt(b2);
+                        if (!(bn > 1.0e-14 * theta)) {
+                            stop = true;                          // invariant subspace: theta is an eigenvalue
+                        } else {
+                            be[it] = bn;
+                            double* vn = V.data() + (size_t)(it + 1) * n;
+                            for (int k = 0; k < n; ++k) vn[k] = w[k] / bn;
+                        }
+                    }
                 }
             }
             bar.wait();
             if (stop) return;
         }
     });
-    return stop ? bad : est;
+    return broken ? bad : std::sqrt(theta);
+}
+
+
+// ---- 64 x 64 tiles of the O(n^3) phases (product of the factors, explicit inverse) ---------------------------------------
+// Round 5 formed both by rows with axpys of whole rows: every multiply-add streamed 8 bytes of the other matrix through L2
+// (20 / 16 ms at K = 1595 on twelve threads, ~7 GF/s a thread).  By tiles the operands of 2 x 64^3 flops are 3 x 32 KB, and a
+// 4 x 8 register block does 8 multiply-adds per 6 loads from L1.  Every output element is accumulated in ONE fixed order
+// (tiles of the inner dimension ascending, inside a tile k ascending): the bits do not depend on the thread count.
+constexpr int TB = 64;
+typedef double v4 __attribute__((vector_size(32)));
+typedef double v4u __attribute__((vector_size(32), aligned(8)));
+
+// C[mb x nb] += s * A[mb x kb] B[kb x nb]  (row-major pieces of larger arrays; s = +1 / -1)
+template <bool SUB>
+static void tile_gemm(double* __restrict__ C, size_t ldc, const double* __restrict__ A, size_t lda, const double* __restrict__ B, size_t ldb,
+                      int mb, int nb, int kb) {
+    int i = 0;
+    for (; i + 4 <= mb; i += 4) {
+        const double *a0 = A + (size_t)i * lda, *a1 = a0 + lda, *a2 = a1 + lda, *a3 = a2 + lda;
+        int j = 0;
+        for (; j + 8 <= nb; j += 8) {
+            v4 c00 = {0, 0, 0, 0}, c01 = c00, c10 = c00, c11 = c00, c20 = c00, c21 = c00, c30 = c00, c31 = c00;
+            const double* b = B + j;
+            for (int k = 0; k < kb; ++k, b += ldb) {
+                const v4 b0 = *(const v4u*)b, b1 = *(const v4u*)(b + 4);
+                const v4 x0 = {a0[k], a0[k], a0[k], a0[k]}, x1 = {a1[k], a1[k], a1[k], a1[k]};
+                const v4 x2 = {a2[k], a2[k], a2[k], a2[k]}, x3 = {a3[k], a3[k], a3[k], a3[k]};
+                c00 += x0 * b0; c01 += x0 * b1;
+                c10 += x1 * b0; c11 += x1 * b1;
+                c20 += x2 * b0; c21 += x2 * b1;
+                c30 += x3 * b0; c31 += x3 * b1;
+            }
+            double* c = C + (size_t)i * ldc + j;
+            if (SUB) {
+                *(v4u*)c -= c00; *(v4u*)(c + 4) -= c01; c += ldc;
+                *(v4u*)c -= c10; *(v4u*)(c + 4) -= c11; c += ldc;
+                *(v4u*)c -= c20; *(v4u*)(c + 4) -= c21; c += ldc;
+                *(v4u*)c -= c30; *(v4u*)(c + 4) -= c31;
+            } else {
+                *(v4u*)c += c00; *(v4u*)(c + 4) += c01; c += ldc;
+                *(v4u*)c += c10; *(v4u*)(c + 4) += c11; c += ldc;
+                *(v4u*)c += c20; *(v4u*)(c + 4) += c21; c += ldc;
+                *(v4u*)c += c30; *(v4u*)(c + 4) += c31;
+            }
+        }
+        for (; j < nb; ++j) {                            // ragged columns
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+            for (int k = 0; k < kb; ++k) {
+                const double bv = B[(size_t)k * ldb + j];
+                t0 += a0[k] * bv; t1 += a1[k] * bv; t2 += a2[k] * bv; t3 += a3[k] * bv;
+            }
+            double* c = C + (size_t)i * ldc + j;
+            if (SUB) { c[0] -= t0; c[ldc] -= t1; c[2 * ldc] -= t2; c[3 * ldc] -= t3; }
+            else { c[0] += t0; c[ldc] += t1; c[2 * ldc] += t2; c[3 * ldc] += t3; }
+        }
+    }
+    for (; i < mb; ++i) {                                // ragged rows
+        const double* a = A + (size_t)i * lda;
+        double* c = C + (size_t)i * ldc;
+        for (int j = 0; j < nb; ++j) {
+            double t = 0.0;
+            for (int k = 0; k < kb; ++k) t += a[k] * B[(size_t)k * ldb + j];
+            if (SUB) c[j] -= t; else c[j] += t;
+        }
+    }
+}
+
+// tasks of unequal cost, heaviest first, dealt to the threads in a snake (0 .. nt-1, nt-1 .. 0, ...): a static split that
+// stays within a task of even
+template <class F>
+static void run_weighted(int nt, std::vector<std::pair<double, int>>& cost_and_id, F&& f) {
+    std::stable_sort(cost_and_id.begin(), cost_and_id.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
+    const int n = (int)cost_and_id.size();
+    if (nt > n) nt = n < 1 ? 1 : n;
+    run_threads(nt, [&](int t) {
+        for (int r = 0; r * nt < n; ++r) {
+            const int i = r * nt + ((r & 1) ? nt - 1 - t : t);
+            if (i < n) f(cost_and_id[i].second);
+        }
+    });
+}
+
+// C = A B for upper triangular n x n matrices (full row-major storage, zeros below the diagonal; C is overwritten, strictly
+// lower part zero): tile (I, J) = sum_{I <= Kb <= J} A_{I Kb} B_{Kb J}
+static void upper_product(int n, const double* A, const double* B, double* C) {
+    const int nb = (n + TB - 1) / TB;
+    const int nt = threads_for(n, (double)n * n * n / 3.0);
+    std::vector<std::pair<double, int>> tiles;
+    for (int I = 0; I < nb; ++I)
+        for (int J = 0; J < nb; ++J) tiles.emplace_back(J >= I ? (double)(J - I + 1) : 0.01, I * nb + J);
+    run_weighted(nt, tiles, [&](int id) {
+        const int I = id / nb, J = id % nb;
+        const int i0 = I * TB, j0 = J * TB, mi = std::min(TB, n - i0), nj = std::min(TB, n - j0);
+        for (int i = 0; i < mi; ++i) std::fill(C + (size_t)(i0 + i) * n + j0, C + (size_t)(i0 + i) * n + j0 + nj, 0.0);
+        if (J < I) return;
+        double Bt[TB * TB];                                   // the B tile, contiguous: its 64 rows lie 8 n bytes apart (a page each)
+        for (int Kb = I; Kb <= J; ++Kb) {
+            const int k0 = Kb * TB, kk = std::min(TB, n - k0);
+            for (int k = 0; k < kk; ++k) memcpy(Bt + (size_t)k * TB, B + (size_t)(k0 + k) * n + j0, (size_t)nj * sizeof(double));
+            tile_gemm<false>(C + (size_t)i0 * n + j0, (size_t)n, A + (size_t)i0 * n + k0, (size_t)n, Bt, (size_t)TB, mi, nj, kk);
+        }
+    });
+}
+
+// X = T^-1 for an upper triangular n x n matrix (full row-major storage; X must be zero on entry, its strictly lower part stays
+// zero).  Diagonal tiles by back substitution (rows from the bottom, axpys of <= 64 entries); column strips of 32: for I = J-1 .. 0
+// T_{II} X_{I, strip} = -(sum_{I < Kb <= J} T_{I Kb} X_{Kb, strip}), the sum by tiles, the solve by back substitution.
+static void upper_inverse(int n, const double* T, double* X) {
+    const int nb = (n + TB - 1) / TB;
+    const int nt = threads_for(n, (double)n * n * n / 3.0);
+    run_threads(std::min(nt, nb), [&](int t) {
+        const int team = std::min(nt, nb);
+        for (int I = t; I < nb; I += team) {
+            const int c0 = I * TB, c1 = std::min(n, c0 + TB);
+            for (int i = c1 - 1; i >= c0; --i) {
+                double* __restrict__ xi = X + (size_t)i * n;
+                const double* ti = T + (size_t)i * n;
+                xi[i] = 1.0;
+                for (int k = i + 1; k < c1; ++k) {
+                    const double f = ti[k];
+                    if (f == 0.0) continue;
+                    const double* __restrict__ xk = X + (size_t)k * n;
+                    for (int c = k; c < c1; ++c) xi[c] -= f * xk[c];
+                }
+                const double inv = 1.0 / ti[i];
+                for (int c = i; c < c1; ++c) xi[c] *= inv;
+            }
+        }
+    });
+    constexpr int SW = 32;                               // strip width: two strips per tile column, twice the tasks to balance
+    std::vector<std::pair<double, int>> strips;
+    for (int c0 = TB; c0 < n; c0 += SW) strips.emplace_back((double)(c0 / TB) * (c0 / TB), c0);
+    run_weighted(nt, strips, [&](int c0) {
+        const int J = c0 / TB, w = std::min(SW, n - c0);
+        double S[TB * SW];
+        for (int I = J - 1; I >= 0; --I) {
+            const int i0 = I * TB;
+            std::fill(S, S + TB * SW, 0.0);
+            for (int Kb = I + 1; Kb <= J; ++Kb) {
+                const int k0 = Kb * TB, kk = std::min(TB, n - k0);
+                tile_gemm<false>(S, SW, T + (size_t)i0 * n + k0, (size_t)n, X + (size_t)k0 * n + c0, (size_t)n, TB, w, kk);
+            }
+            // X_{I, strip} = -T_II^-1 S by back substitution inside the tile (NOT -X_II S: the product with the explicit inverse of
+            // a diagonal tile that holds a rounding-level pivot leaves a residual T X - I of the size of that inverse, and the
+            // deflation's certificate reads the rounding-level content of X)
+            for (int i = TB - 1; i >= 0; --i) {
+                const double* ti = T + (size_t)(i0 + i) * n + i0;
+                double* __restrict__ si = S + (size_t)i * SW;
+                for (int k = i + 1; k < TB; ++k) {
+                    const double f = ti[k];
+                    if (f == 0.0) continue;
+                    const double* __restrict__ sk = S + (size_t)k * SW;
+                    for (int c = 0; c < SW; ++c) si[c] += f * sk[c];
+                }
+                const double inv = -1.0 / ti[i];
+                double* __restrict__ xi = X + (size_t)(i0 + i) * n + c0;
+                for (int c = 0; c < SW; ++c) si[c] *= inv;                 // row i of S now holds x_i: the rows above add T_ik x_k
+                for (int c = 0; c < w; ++c) xi[c] = si[c];
+            }
+        }
+    });
 }
 
 }  // namespace
@@ -608,12 +806,13 @@ void FactorChain::start(int K_, const double* G) {
 
 // Everything condition_bound() and certified() need to know about the factors, gathered once: per factor ONE sweep for the exact
 // norm pairs of R and of E = R - I, and -- unless the factor is near the identity (the later passes: Neumann bound, no iteration) --
-// Hager's estimator for R^-1 and R^-T and inverse iteration on R^T R (14 steps, with the value after 3 steps kept: the quick look
-// of certified() uses that one).  The sweeps and the three estimators of every factor are independent tasks on the host threads
-// (~50 triangular solves of 10 MB each per factor at K = 1595: 115 ms on one core).
+// Hager's estimator for R^-1 and R^-T, the Lanczos process on (R^T R)^-1 (4 ... 10 steps, with the value after 3 steps kept: the
+// quick look of certified() uses that one) and on R^T R.  The sweeps and the four estimators of every factor are independent tasks
+// on the host threads (round 5: 14 steps of inverse iteration + 12 of power iteration, ~50 triangular solves of 10 MB each per
+// factor at K = 1595 -- 115 ms on one core, 16 ms on the team; round 6: ~25 and 9 ms).
 struct ChainLook {
     double n1 = 0.0, ninf = 0.0, enorm = 0.0, rmax = 0.0, dmax = 0.0;      // ||R||_1, ||R||_inf, sqrt(||E||_1 ||E||_inf), max |r_ij|, max 1 / |r_ii|
-    double h1 = 0.0, hinf = 0.0, inv2_3 = 0.0, inv2_14 = 0.0, norm2 = 0.0;      // (norm2: power iteration, a lower estimate of ||R||_2)
+    double h1 = 0.0, hinf = 0.0, inv2_3 = 0.0, inv2_full = 0.0, norm2 = 0.0;      // (inv2_full, inv2_3: Lanczos on (R^T R)^-1, converged / after 3 steps; norm2: Lanczos on R^T R -- lower estimates)
     bool near_identity = false;
 };
 
@@ -622,57 +821,100 @@ static std::vector<ChainLook> chain_looks(int K, const std::vector<const double*
     std::vector<ChainLook> L(R.size());
     const int nt = threads_for(K, 30.0 * (double)K * K);          // (the estimators of one factor: ~50 substitutions of K^2 / 2)
     std::vector<std::function<void()>> tasks;
+    // the sweeps: rows dealt round-robin to a FIXED number of parts per factor (row i costs K - i), partial column sums added in
+    // part order -- the values do not depend on the thread count.  Off the diagonal |e_ij| = |r_ij|: the sums of E = R - I follow
+    // from those of R and the diagonal.
+    constexpr int NPART = 8;
+    struct SweepPart {
+        vec colsum;
+        double ninf = 0.0, einf = 0.0, rmax = 0.0, dmax = 0.0;
+    };
+    std::vector<SweepPart> parts(R.size() * NPART);
     for (size_t f = 0; f < R.size(); ++f)
-        tasks.emplace_back([&, f] {
-            const double* Rk = R[f];
-            ChainLook& l = L[f];
-            vec colsum((size_t)K, 0.0), dcolsum((size_t)K, 0.0);
-            double ninf = 0.0, einfn = 0.0, rmax = 0.0, dmax = 0.0;
-            for (int i = 0; i < K; ++i) {
-                const double* ri = Rk + (size_t)i * K;
-                double rs = 0.0, es = 0.0;
-                for (int c = i; c < K; ++c) {
-                    const double a = std::fabs(ri[c]), e = std::fabs(ri[c] - (c == i ? 1.0 : 0.0));
-                    rs += a;
-                    es += e;
-                    colsum[c] += a;
-                    dcolsum[c] += e;
-                    rmax = std::fmax(rmax, a);
+        for (int pt = 0; pt < NPART; ++pt)
+            tasks.emplace_back([&, f, pt] {
+                const double* Rk = R[f];
+                SweepPart& sp = parts[f * NPART + pt];
+                sp.colsum.assign((size_t)K, 0.0);
+                double* __restrict__ cs = sp.colsum.data();
+                double ninf = 0.0, einf = 0.0, rmax = 0.0, dmax = 0.0;
+                for (int i = pt; i < K; i += NPART) {
+                    const double* __restrict__ ri = Rk + (size_t)i * K;
+                    double rs = 0.0, rm = 0.0;
+                    for (int c = i + 1; c < K; ++c) {
+                        const double a = std::fabs(ri[c]);
+                        rs += a;
+                        cs[c] += a;
+                        rm = a > rm ? a : rm;
+                    }
+                    const double d = std::fabs(ri[i]);
+                    cs[i] += d;
+                    rmax = std::fmax(rmax, std::fmax(rm, d));
+                    ninf = std::fmax(ninf, rs + d);
+                    einf = std::fmax(einf, rs + std::fabs(ri[i] - 1.0));
+                    dmax = std::fmax(dmax, d > 0.0 ? 1.0 / d : std::numeric_limits<double>::infinity());
                 }
-                ninf = std::fmax(ninf, rs);
-                einfn = std::fmax(einfn, es);
-                const double d = std::fabs(ri[i]);
-                dmax = std::fmax(dmax, d > 0.0 ? 1.0 / d : std::numeric_limits<double>::infinity());
-            }
-            double n1 = 0.0, e1n = 0.0;
-            for (int c = 0; c < K; ++c) {
-                n1 = std::fmax(n1, colsum[c]);
-                e1n = std::fmax(e1n, dcolsum[c]);
-            }
-            // (the entries below the diagonal of a factor are zero: the full-matrix maximum of the earlier code is this one)
-            l.n1 = n1;
-            l.ninf = ninf;
-            l.enorm = std::sqrt(e1n * einfn);           // >= ||R - I||_2
-            l.rmax = rmax;
-            l.dmax = dmax;
-            l.near_identity = l.enorm < 0.5;
-        });
+                sp.ninf = ninf;
+                sp.einf = einf;
+                sp.rmax = rmax;
+                sp.dmax = dmax;
+            });
     run_tasks(nt, tasks);
     tasks.clear();
+    for (size_t f = 0; f < R.size(); ++f) {
+        ChainLook& l = L[f];
+        const double* Rk = R[f];
+        double n1 = 0.0, e1n = 0.0, ninf = 0.0, einf = 0.0, rmax = 0.0, dmax = 0.0;
+        for (int c = 0; c < K; ++c) {
+            double t = 0.0;
+            for (int pt = 0; pt < NPART; ++pt) t += parts[f * NPART + pt].colsum[c];
+            const double rcc = Rk[(size_t)c * K + c];
+            n1 = std::fmax(n1, t);
+            e1n = std::fmax(e1n, std::fmax(t - std::fabs(rcc), 0.0) + std::fabs(rcc - 1.0));
+        }
+        for (int pt = 0; pt < NPART; ++pt) {
+            const SweepPart& sp = parts[f * NPART + pt];
+            ninf = std::fmax(ninf, sp.ninf);
+            einf = std::fmax(einf, sp.einf);
+            rmax = std::fmax(rmax, sp.rmax);
+            dmax = std::fmax(dmax, sp.dmax);
+        }
+        // (the entries below the diagonal of a factor are zero: the full-matrix maximum of the earlier code is this one)
+        l.n1 = n1;
+        l.ninf = ninf;
+        l.enorm = std::sqrt(e1n * einf);           // >= ||R - I||_2
+        l.rmax = rmax;
+        l.dmax = dmax;
+        l.near_identity = l.enorm < 0.5;
+    }
     int nest = 0;
     for (size_t f = 0; f < R.size(); ++f) nest += L[f].near_identity ? 0 : 3;
-    // the estimators run side by side, each with a team for its substitutions; the inverse iteration is the long one (28 solves
-    // against <= 11): it gets the largest share.  The power iteration for ||R||_2 (only the sharper bound behind the quick look
-    // uses it) runs beside them instead of after them: 12 passes over the factor that were 12 ms of a 45 ms fit at K = 1595.
+    // the estimators run side by side, each with a team for its substitutions; the Lanczos process on the inverse is the long one
+    // (8 ... 20 solves against <= 11): it gets the largest share.  The one for ||R||_2 (only the sharper bound behind the quick look
+    // uses it) runs beside them instead of after them.
     const int nfac = nest / 3;
-    const int long_task = nfac > 0 ? std::max(1, (3 * nt) / (8 * nfac)) : 1, power_task = nfac > 0 ? std::max(1, nt / (4 * nfac)) : 1,
-              per_task = nfac > 0 ? std::max(1, (3 * nt) / (16 * nfac)) : 1;
+    // shares of a factor's threads: a third each for the two Lanczos processes (<= 20 solves / <= 8 passes of twice a solve's
+    // work), a sixth for each of Hager's (<= 11 solves)
+    const int long_task = nfac > 0 ? std::max(1, nt / (3 * nfac)) : 1, power_task = long_task,
+              per_task = nfac > 0 ? std::max(1, nt / (6 * nfac)) : 1;
     for (size_t f = 0; f < R.size(); ++f) {
         if (L[f].near_identity) continue;
-        tasks.emplace_back([&, f] { L[f].inv2_14 = inverse_norm2_estimate(K, R[f], 14, 3, &L[f].inv2_3, long_task); });
-        tasks.emplace_back([&, f] { L[f].norm2 = norm2_estimate(K, R[f], 12, power_task); });
-        tasks.emplace_back([&, f] { L[f].h1 = inverse_norm1_estimate(K, R[f], false, per_task); });
-        tasks.emplace_back([&, f] { L[f].hinf = inverse_norm1_estimate(K, R[f], true, per_task); });
+        tasks.emplace_back([&, f] {
+            HostProf hp("  estimator: Lanczos on (R^T R)^-1");
+            L[f].inv2_full = inverse_norm2_estimate(K, R[f], 3, &L[f].inv2_3, long_task);
+        });
+        tasks.emplace_back([&, f] {
+            HostProf hp("  estimator: Lanczos on R^T R");
+            L[f].norm2 = norm2_estimate(K, R[f], 8, power_task);
+        });
+        tasks.emplace_back([&, f] {
+            HostProf hp("  estimator: Hager ||R^-1||_1");
+            L[f].h1 = inverse_norm1_estimate(K, R[f], false, per_task);
+        });
+        tasks.emplace_back([&, f] {
+            HostProf hp("  estimator: Hager ||R^-1||_inf");
+            L[f].hinf = inverse_norm1_estimate(K, R[f], true, per_task);
+        });
     }
     run_tasks(nt, tasks);
     return L;
@@ -684,7 +926,7 @@ static double chain_bound_from(int K, const std::vector<const double*>& R, const
     double nrm = 1.0, inv = 1.0;
     for (size_t f = 0; f < R.size(); ++f) {
         const ChainLook& l = L[f];
-        // sqrt(||R||_1 ||R||_inf) is a true bound but overshoots a graded factor by one or two orders; power iteration
+        // sqrt(||R||_1 ||R||_inf) is a true bound but overshoots a graded factor by one or two orders; the Lanczos value
         // approaches ||R||_2 from below: x 1.25, and never below the largest entry
         if (l.near_identity) nrm *= std::fmin(std::sqrt(l.n1 * l.ninf), 1.0 + l.enorm);          // ||I + E||_2 <= 1 + ||E||_2
         else nrm *= std::fmin(std::sqrt(l.n1 * l.ninf), std::fmax(1.25 * l.norm2, l.rmax));
@@ -692,9 +934,9 @@ static double chain_bound_from(int K, const std::vector<const double*>& R, const
             inv *= 1.0 / (1.0 - l.enorm);                      // Neumann series: the factors of the later passes
         } else {
             // the sharper of two upper estimates of ||R^-1||_2: the 1- / inf-norm pair (Hager / Higham's estimator x 3) and
-            // inverse iteration on R^T R (x 2: it approaches 1 / sigma_min from below)
+            // the Lanczos value of (R^T R)^-1 (x 2: it approaches 1 / sigma_min from below)
             const double by_norm1 = 3.0 * std::sqrt(l.h1 * l.hinf);
-            const double by_iteration = 2.0 * l.inv2_14;
+            const double by_iteration = 2.0 * l.inv2_full;
             // never below what either estimator has actually SEEN (each is a lower bound of its own norm):
             // ||B||_2 >= ||B||_1 / sqrt(n)
             const double floor2 = std::fmax(l.h1, l.hinf) / std::sqrt((double)K);
@@ -715,7 +957,7 @@ bool FactorChain::certified(double rcond, double* norm_out, double* inv_norm_out
     const double rc = rcond > 0.0 ? rcond : 0.0;
     const std::vector<ChainLook> L = chain_looks(K, R);
     // A quick look first: ||R||_2 <= sqrt(||R||_1 ||R||_inf) (exact) and, for ||R^-1||_2, the largest of three lower
-    // estimates (three steps of inverse iteration, Hager's 1- / inf-norm pair, the inverse's diagonal), times 10 -- inverse
+    // estimates (three Lanczos steps on the inverse, Hager's 1- / inf-norm pair, the inverse's diagonal), times 10 -- inverse
     // iteration approaches ||R^-1||_2 from BELOW, and on a steeply graded factor three steps from a flat start can sit far below
     // it; the exact lower bound max_i 1 / |r_ii| and Hager's estimates (dlacon's iteration is exact on graded triangular factors
     // in all but contrived cases) keep the quick look honest.  When even that leaves FOUR orders of margin the sharper
@@ -754,27 +996,20 @@ void FactorChain::solve(const double* z, double* beta) const {
 
 void FactorChain::product(double* Rhat) const {
     HostProf hp_("product");
-    std::fill(Rhat, Rhat + (size_t)K * K, 0.0);
-    if (R.empty()) return;
-    memcpy(Rhat, R[0], (size_t)K * K * sizeof(double));
-    const int nt = threads_for(K, (double)K * K * K / 3.0);
-    vec next(R.size() > 1 ? (size_t)K * K : 0);
-    for (size_t k = 1; k < R.size(); ++k) {
-        const double* Rp = R[k];
-        // row a of Rp R_hat = sum_{b >= a} Rp[a][b] R_hat[b][b:]: rows are independent (dealt round-robin: row a costs (K - a)^2 / 2)
-        run_threads(nt, [&](int t) {
-            for (int a = t; a < K; a += nt) {
-                double* __restrict__ out = next.data() + (size_t)a * K;
-                std::fill(out, out + K, 0.0);
-                for (int b = a; b < K; ++b) {
-                    const double f = Rp[(size_t)a * K + b];
-                    if (f == 0.0) continue;
-                    const double* __restrict__ r = Rhat + (size_t)b * K;
-                    for (int c = b; c < K; ++c) out[c] += f * r[c];
-                }
-            }
-        });
-        memcpy(Rhat, next.data(), (size_t)K * K * sizeof(double));
+    if (R.empty()) {
+        std::fill(Rhat, Rhat + (size_t)K * K, 0.0);
+        return;
+    }
+    if (R.size() == 1) memcpy(Rhat, R[0], (size_t)K * K * sizeof(double));
+    // R[k] ... R[1] R[0], 64 x 64 tiles on the host threads; the products alternate between Rhat and a second array so that the
+    // last one lands in Rhat (upper_product writes every tile of its output, the zeros below the diagonal included)
+    const size_t nprod = R.size() - 1;
+    vec other(nprod > 1 ? (size_t)K * K : 0);
+    const double* cur = R[0];
+    for (size_t k = 1; k <= nprod; ++k) {
+        double* out = ((nprod - k) & 1) ? other.data() : Rhat;
+        upper_product(K, R[k], cur, out);
+        cur = out;
     }
     for (int j = 0; j < K; ++j)
         if (!active[j]) {
@@ -1124,7 +1359,7 @@ int FactorSolver::deflate_width(double rc, std::vector<double>& X, double norm_b
     deflated = true;
     ncut = k;
     rank = n - k;
-    smax = lower;                // a lower estimate of sigma_max (power iteration) ...
+    smax = lower;                // a lower estimate of sigma_max (Lanczos) ...
     smin = 1.0 / inv_norm;       // ... and a lower bound of the smallest kept singular value
     return 1;
 }
@@ -1158,13 +1393,27 @@ void FactorSolver::prepare(int K_, const double* Rhat, double rcond) {
         n = (int)act.size();
         rank = 0;
         T.assign((size_t)n * n, 0.0);
-        for (int a = 0; a < n; ++a)
-            for (int b = a; b < n; ++b) T[(size_t)a * n + b] = Rhat[(size_t)act[a] * K + act[b]];
         if (n == 0) return;
         // Frobenius bounds: sigma_max <= ||T||_F, sigma_min >= 1 / ||T^-1||_F.  If even these cannot put a singular
         // value below rcond * sigma_max, dgelsd would not truncate either and its solution is T^-1 z.
+        // (rows gathered and squared by the host threads; the sum of squares of row a is one number whatever the split, the
+        // rows are added in order)
+        vec rowsq((size_t)n);
+        {
+            const int ntg = threads_for(n, 2.0 * (double)n * n);
+            run_threads(ntg, [&](int t) {
+                for (int a = t; a < n; a += ntg) {
+                    double* ta = T.data() + (size_t)a * n;
+                    const double* ra = Rhat + (size_t)act[a] * K;
+                    if (n == K) memcpy(ta + a, ra + a, (size_t)(n - a) * sizeof(double));
+                    else
+                        for (int b = a; b < n; ++b) ta[b] = ra[act[b]];
+                    rowsq[a] = sum_squares(ta + a, (size_t)(n - a));
+                }
+            });
+        }
         double fro = 0.0;
-        for (double v : T) fro += v * v;
+        for (double v : rowsq) fro += v;
         fro = std::sqrt(fro);
         double inv2 = 0.0, fro2 = fro, inv_norm = 0.0;
         bool ok = true;
@@ -1175,32 +1424,13 @@ void FactorSolver::prepare(int K_, const double* Rhat, double rcond) {
         vec X((size_t)n * n, 0.0);
         {
             HostProf hp2_("prepare: inverse + norms");
-            // columns are independent (X e_c = T^-1 e_c): blocks of 64 columns dealt round-robin to the threads, every element
-            // accumulated in the same order whatever the split
-            const int nt = threads_for(n, (double)n * n * n / 3.0), nblk = (n + 63) / 64;
-            run_threads(nt, [&](int t) {
-                for (int blk = t; blk < nblk; blk += nt) {
-                    const int c0 = blk * 64, c1 = std::min(n, c0 + 64);
-                    for (int i = c1 - 1; i >= 0; --i) {
-                        double* __restrict__ xi = X.data() + (size_t)i * n;
-                        const double* ti = T.data() + (size_t)i * n;
-                        if (i >= c0) xi[i] = 1.0;
-                        for (int k = i + 1; k < c1; ++k) {
-                            const double f = ti[k];
-                            if (f == 0.0) continue;
-                            const double* __restrict__ xk = X.data() + (size_t)k * n;
-                            for (int c = std::max(k, c0); c < c1; ++c) xi[c] -= f * xk[c];
-                        }
-                        const double inv = 1.0 / ti[i];
-                        for (int c = std::max(i, c0); c < c1; ++c) xi[c] *= inv;
-                    }
-                }
-            });
+            const int nt = threads_for(n, (double)n * n * n / 3.0);
+            upper_inverse(n, T.data(), X.data());                       // 64 x 64 tiles, column strips on the host threads
             double bt = fro, bx = 0.0;
             std::vector<std::function<void()>> tasks;
             tasks.emplace_back([&] {
                 double t2 = 0.0;
-                for (double v : X) t2 += v * v;
+                for (int i = 0; i < n; ++i) t2 += sum_squares(X.data() + (size_t)i * n + i, (size_t)(n - i));      // (X is upper triangular)
                 inv2 = t2;
             });
             tasks.emplace_back([&] { bt = one_inf_norm(n, T.data()); });

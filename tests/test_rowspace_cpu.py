@@ -381,3 +381,42 @@ def test_large_k_host_phases_do_not_depend_on_the_thread_count(tmp_path):
     assert outs[0] == outs[1] == outs[2]
     lines = outs[0].strip().splitlines()
     assert len(lines) == 3 and lines[0].startswith("448 1.0") and lines[1].startswith("443 0.0") and lines[2].startswith("434 0.0")
+
+
+def _upper_factor(A):
+    R = np.linalg.qr(A, mode="r")
+    return R * np.sign(np.diag(R))[:, None]
+
+
+def _bound_families():
+    rng = np.random.default_rng(11)
+    for K in (64, 400):
+        U, _ = np.linalg.qr(rng.standard_normal((2 * K, K)))
+        V, _ = np.linalg.qr(rng.standard_normal((K, K)))
+        for lk in (2.0, 6.0, 9.0, 10.5):
+            yield f"graded-{K}-{lk}", _upper_factor((U * np.logspace(0, -lk, K)) @ V.T)
+            one = np.ones(K)
+            one[-1] = 10.0 ** -lk
+            yield f"one-small-{K}-{lk}", _upper_factor((U * one) @ V.T)
+            half = np.ones(K)
+            half[K // 2:] = 10.0 ** -lk
+            yield f"half-small-{K}-{lk}", _upper_factor((U * half) @ V.T)
+    for theta, n in ((1.2, 64), (1.2, 90), (1.0, 64)):                 # Kahan's matrices: pivots say nothing about sigma_min
+        yield f"kahan-{theta}-{n}", np.diag(np.sin(theta) ** np.arange(n)) @ (np.eye(n) - np.cos(theta) * np.triu(np.ones((n, n)), 1))
+    for n in (18, 26, 40):                                              # the hidden family of the round-5 verdict, as a factor
+        Z, _ = np.linalg.qr(rng.standard_normal((4000, n)))
+        yield f"hidden-{n}", _upper_factor(Z @ (np.eye(n) - np.triu(np.ones((n, n)), 1)))
+
+
+def test_condition_bound_of_a_factor_is_above_the_truth_and_sharp_where_it_decides():
+    # The bound is built from LOWER estimates (Lanczos on R^T R and on its inverse -- round 6; 12 + 14 steps of power / inverse
+    # iteration before --, Hager's 1-norm pair) times explicit margins: it must never fall below cond_2, and where the quick look
+    # (margins of 10 per estimate) does not settle the question it must sit within the 2 x 1.25 of its margins
+    rng = np.random.default_rng(3)
+    for name, R in _bound_families():
+        s = np.linalg.svd(R, compute_uv=False)
+        cond = s[0] / s[-1]
+        _, _, info = _capi.rowspace_chain([R], rng.standard_normal(len(R)), 1.0e-13)
+        ratio = info["cond_bound"] / cond
+        assert ratio >= 1.0, (name, ratio)
+        assert ratio <= (5.0 if cond >= 1.0e9 else 2000.0), (name, ratio)
