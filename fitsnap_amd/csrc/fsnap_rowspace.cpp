@@ -148,7 +148,7 @@ int fsnap_rowspace_chain(int64_t K64, int64_t nfac, const double* R, const unsig
         chain.solve(z, beta);
         for (int j = 0; j < K; ++j) rk += chain.active[j] ? 1 : 0;
     } else {
-        vec Rhat((size_t)K * K);
+        fsnap_rs::Scratch Rhat((size_t)K * K);
         chain.product(Rhat.data());
         FactorSolver fs;
         fs.prepare(K, Rhat.data(), rcond);
@@ -415,13 +415,14 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
     if (!finite_all(z.data(), z.size())) return ctx->fail(FSNAP_NUM_NONFINITE, "row-space solve: non-finite Q^T b");
 
     FactorSolver fs;
+    fsnap_rs::Scratch Rprod;
     bool use_chain = false;
     double chain_norm = 0.0, chain_inv = 0.0;
     if (chained) {
         use_chain = chain.certified(rcond, &chain_norm, &chain_inv, nullptr);         // no singular value can be cut
         if (!use_chain) {
-            Rhat.assign((size_t)K * K, 0.0);
-            chain.product(Rhat.data());
+            Rprod.reset((size_t)K * K);                         // (product() writes every entry)
+            chain.product(Rprod.data());
         }
     }
     if (!use_chain) {
@@ -430,7 +431,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
             fs.external_user = ctx->dense_pinv_user;
             fs.token = ++ctx->dense_pinv_token;
         }
-        fs.prepare(K, Rhat.data(), rcond);
+        fs.prepare(K, Rprod.size() ? Rprod.data() : Rhat.data(), rcond);
     }
     mark("condition bound / prepare");
     auto apply = [&](const double* rhs, double* out) {

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -35,6 +36,73 @@ struct HostProf {
 };
 
 using vec = std::vector<double>;
+
+// ---- Scratch: per-thread pool of large blocks ----------------------------------------------------------------------------------
+namespace {
+struct ScratchPool {
+    static constexpr int SLOTS = 4;
+    static constexpr size_t MAX_KEEP = (size_t)8 << 20;          // doubles: blocks above 64 MB are not kept
+    double* p[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    size_t cap[SLOTS] = {0, 0, 0, 0};
+    ~ScratchPool() {
+        for (int i = 0; i < SLOTS; ++i) free(p[i]);
+    }
+};
+thread_local ScratchPool g_scratch;
+}  // namespace
+
+void Scratch::reset(size_t n) {
+    if (n <= cap_ && p_) {
+        n_ = n;
+        return;
+    }
+    release();
+    if (n == 0) return;
+    ScratchPool& pool = g_scratch;
+    int best = -1;
+    for (int i = 0; i < ScratchPool::SLOTS; ++i)
+        if (pool.p[i] && pool.cap[i] >= n && (best < 0 || pool.cap[i] < pool.cap[best])) best = i;
+    if (best >= 0) {
+        p_ = pool.p[best];
+        cap_ = pool.cap[best];
+        pool.p[best] = nullptr;
+        pool.cap[best] = 0;
+    } else {
+        const size_t bytes = ((n * sizeof(double) + 63) / 64) * 64;
+        p_ = static_cast<double*>(aligned_alloc(64, bytes));
+        if (!p_) throw std::bad_alloc();
+        cap_ = bytes / sizeof(double);
+    }
+    n_ = n;
+}
+
+void Scratch::release() {
+    if (!p_) return;
+    ScratchPool& pool = g_scratch;
+    int slot = -1;
+    if (cap_ <= ScratchPool::MAX_KEEP) {
+        for (int i = 0; i < ScratchPool::SLOTS && slot < 0; ++i)
+            if (!pool.p[i]) slot = i;
+        if (slot < 0) {                                 // full: replace the smallest block if this one is larger
+            int smallest = 0;
+            for (int i = 1; i < ScratchPool::SLOTS; ++i)
+                if (pool.cap[i] < pool.cap[smallest]) smallest = i;
+            if (pool.cap[smallest] < cap_) {
+                free(pool.p[smallest]);
+                pool.p[smallest] = nullptr;
+                slot = smallest;
+            }
+        }
+    }
+    if (slot >= 0) {
+        pool.p[slot] = p_;
+        pool.cap[slot] = cap_;
+    } else {
+        free(p_);
+    }
+    p_ = nullptr;
+    n_ = cap_ = 0;
+}
 static const double EPS = std::numeric_limits<double>::epsilon();
 
 // ---- host threads for the O(n^3) / many-solve phases of large systems ---------------------------------------------------------
@@ -734,8 +802,8 @@ static void upper_product(int n, const double* A, const double* B, double* C) {
     });
 }
 
-// X = T^-1 for an upper triangular n x n matrix (full row-major storage; X must be zero on entry, its strictly lower part stays
-// zero).  Diagonal tiles by back substitution (rows from the bottom, axpys of <= 64 entries); column strips of 32: for I = J-1 .. 0
+// X = T^-1 for an upper triangular n x n matrix (full row-major storage; X need not be initialised: every entry is written, the
+// strictly lower part with zeros).  Diagonal tiles by back substitution (rows from the bottom, axpys of <= 64 entries); column strips of 32: for I = J-1 .. 0
 // T_{II} X_{I, strip} = -(sum_{I < Kb <= J} T_{I Kb} X_{Kb, strip}), the sum by tiles, the solve by back substitution.
 static void upper_inverse(int n, const double* T, double* X) {
     const int nb = (n + TB - 1) / TB;
@@ -744,6 +812,7 @@ static void upper_inverse(int n, const double* T, double* X) {
         const int team = std::min(nt, nb);
         for (int I = t; I < nb; I += team) {
             const int c0 = I * TB, c1 = std::min(n, c0 + TB);
+            for (int i = c0; i < c1; ++i) std::fill(X + (size_t)i * n, X + (size_t)i * n + c1, 0.0);      // left of and inside the diagonal tile
             for (int i = c1 - 1; i >= c0; --i) {
                 double* __restrict__ xi = X + (size_t)i * n;
                 const double* ti = T + (size_t)i * n;
@@ -1004,7 +1073,7 @@ void FactorChain::product(double* Rhat) const {
     // R[k] ... R[1] R[0], 64 x 64 tiles on the host threads; the products alternate between Rhat and a second array so that the
     // last one lands in Rhat (upper_product writes every tile of its output, the zeros below the diagonal included)
     const size_t nprod = R.size() - 1;
-    vec other(nprod > 1 ? (size_t)K * K : 0);
+    Scratch other(nprod > 1 ? (size_t)K * K : 0);              // (every tile of an output is written: no zeroing)
     const double* cur = R[0];
     for (size_t k = 1; k <= nprod; ++k) {
         double* out = ((nprod - k) & 1) ? other.data() : Rhat;
@@ -1037,6 +1106,43 @@ double one_inf_norm(int n, const double* B) {
     return std::sqrt(n1 * ninf);
 }
 
+// ... and ||B||_F^2 beside it, on the host threads: the rows in 8 FIXED parts (partial column sums added in part order, the squares
+// row by row): the values do not depend on the thread count
+void full_norms(int n, const double* B, double* fro2_out, double* one_inf_out) {
+    constexpr int NPART = 8;
+    vec col((size_t)NPART * n, 0.0), rowsq((size_t)n, 0.0);
+    double ninf_part[NPART] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int nt = std::min(threads_for(n, 2.0 * (double)n * n), NPART);
+    run_threads(nt, [&](int t) {
+        for (int pt = t; pt < NPART; pt += nt) {
+            double* __restrict__ cs = col.data() + (size_t)pt * n;
+            double ninf = 0.0;
+            for (int i = pt; i < n; i += NPART) {
+                const double* __restrict__ bi = B + (size_t)i * n;
+                double rs = 0.0;
+                for (int c = 0; c < n; ++c) {
+                    const double a = std::fabs(bi[c]);
+                    rs += a;
+                    cs[c] += a;
+                }
+                ninf = std::fmax(ninf, rs);
+                rowsq[i] = sum_squares(bi, (size_t)n);
+            }
+            ninf_part[pt] = ninf;
+        }
+    });
+    double n1 = 0.0, ninf = 0.0, f2 = 0.0;
+    for (int c = 0; c < n; ++c) {
+        double tcol = 0.0;
+        for (int pt = 0; pt < NPART; ++pt) tcol += col[(size_t)pt * n + c];
+        n1 = std::fmax(n1, tcol);
+    }
+    for (int pt = 0; pt < NPART; ++pt) ninf = std::fmax(ninf, ninf_part[pt]);
+    for (int i = 0; i < n; ++i) f2 += rowsq[i];
+    *fro2_out = f2;
+    *one_inf_out = std::sqrt(n1 * ninf);
+}
+
 inline double dot_n(const double* x, const double* y, int n) {
     double t = 0.0;
     for (int k = 0; k < n; ++k) t += x[k] * y[k];
@@ -1065,49 +1171,87 @@ namespace {
 constexpr int BCW = 4;
 inline size_t bix(int n, int i, int c) { return ((size_t)(c / BCW) * n + (size_t)i) * BCW + (size_t)(c % BCW); }
 
-// W <- T^-1 W / W <- T^-T W for an n x DB block.  The right-hand sides are independent: the column groups are dealt to the host threads.
+// W <- T^-1 W / W <- T^-T W for an n x DB block, blocks of 64 unknowns at a time on a team of host threads: the diagonal block's
+// substitution by column groups (independent right-hand sides), then the update of all other rows with that block, the rows (or
+// row ranges) dealt to the threads -- every element of T is read ONCE per solve for all DB columns.  (Round 5 dealt whole column
+// groups to the threads: at DB = 16 four threads, each streaming all of T; two of these solves per step of the subspace iteration
+// were 2 x 1.5 ms at n = 1595.)  The arithmetic of an element does not depend on the team's size.
 template <int DB>
 void solve_upper_block(int n, const double* T, double* W) {
-    constexpr int CW = BCW, NG = DB / CW;
-    static_assert(DB % CW == 0, "block width");
-    const int nt = std::min(threads_for(n, 0.5 * (double)n * n * DB), NG);
-    run_threads(nt, [&](int t) {
-        for (int g = t; g < NG; g += nt) {
-            double* Wg = W + (size_t)g * n * CW;
-            for (int i = n - 1; i >= 0; --i) {
-                const double* ti = T + (size_t)i * n;
-                double acc[CW];
-                for (int c = 0; c < CW; ++c) acc[c] = Wg[(size_t)i * CW + c];
-                for (int k = i + 1; k < n; ++k) {
-                    const double f = ti[k];
-                    const double* wk = Wg + (size_t)k * CW;
-                    for (int c = 0; c < CW; ++c) acc[c] -= f * wk[c];
+    constexpr int CW = BCW, NG = DB / CW, NB = 64;
+    static_assert(DB % CW == 0 && CW == 4, "block width");
+    const int nt = threads_for(n, 0.5 * (double)n * n * DB);
+    SpinBarrier bar(nt);
+    run_team(nt, bar, [&](int t, int team) {
+        for (int b1 = n; b1 > 0; b1 -= NB) {
+            const int b0 = std::max(0, b1 - NB);
+            for (int g = t; g < NG; g += team) {
+                double* Wg = W + (size_t)g * n * CW;
+                for (int i = b1 - 1; i >= b0; --i) {
+                    const double* ti = T + (size_t)i * n;
+                    v4 acc = *(const v4u*)(Wg + (size_t)i * CW);
+                    for (int k = i + 1; k < b1; ++k) {
+                        const v4 f = {ti[k], ti[k], ti[k], ti[k]};
+                        acc -= f * *(const v4u*)(Wg + (size_t)k * CW);
+                    }
+                    const double inv = 1.0 / ti[i];
+                    const v4 iv = {inv, inv, inv, inv};
+                    *(v4u*)(Wg + (size_t)i * CW) = acc * iv;
                 }
-                const double inv = 1.0 / ti[i];
-                for (int c = 0; c < CW; ++c) Wg[(size_t)i * CW + c] = acc[c] * inv;
             }
+            bar.wait();
+            for (int i = t; i < b0; i += team) {
+                const double* __restrict__ ti = T + (size_t)i * n;
+                v4 s[NG];
+                for (int g = 0; g < NG; ++g) s[g] = v4{0, 0, 0, 0};
+                for (int k = b0; k < b1; ++k) {
+                    const v4 f = {ti[k], ti[k], ti[k], ti[k]};
+                    for (int g = 0; g < NG; ++g) s[g] += f * *(const v4u*)(W + ((size_t)g * n + k) * CW);
+                }
+                for (int g = 0; g < NG; ++g) *(v4u*)(W + ((size_t)g * n + i) * CW) -= s[g];
+            }
+            bar.wait();
         }
     });
 }
 
 template <int DB>
 void solve_upper_transposed_block(int n, const double* T, double* W) {
-    constexpr int CW = BCW, NG = DB / CW;
-    const int nt = std::min(threads_for(n, 0.5 * (double)n * n * DB), NG);
-    run_threads(nt, [&](int t) {
-        for (int g = t; g < NG; g += nt) {
-            double* Wg = W + (size_t)g * n * CW;
-            for (int i = 0; i < n; ++i) {
-                const double* ti = T + (size_t)i * n;
-                const double inv = 1.0 / ti[i];
-                double zi[CW];
-                for (int c = 0; c < CW; ++c) Wg[(size_t)i * CW + c] = zi[c] = Wg[(size_t)i * CW + c] * inv;
-                for (int k = i + 1; k < n; ++k) {
-                    const double f = ti[k];
-                    double* wk = Wg + (size_t)k * CW;
-                    for (int c = 0; c < CW; ++c) wk[c] -= f * zi[c];
+    constexpr int CW = BCW, NG = DB / CW, NB = 64;
+    const int nt = threads_for(n, 0.5 * (double)n * n * DB);
+    SpinBarrier bar(nt);
+    run_team(nt, bar, [&](int t, int team) {
+        for (int b0 = 0; b0 < n; b0 += NB) {
+            const int b1 = std::min(n, b0 + NB);
+            for (int g = t; g < NG; g += team) {
+                double* Wg = W + (size_t)g * n * CW;
+                for (int i = b0; i < b1; ++i) {
+                    const double* ti = T + (size_t)i * n;
+                    const double inv = 1.0 / ti[i];
+                    const v4 iv = {inv, inv, inv, inv};
+                    const v4 zi = *(const v4u*)(Wg + (size_t)i * CW) * iv;
+                    *(v4u*)(Wg + (size_t)i * CW) = zi;
+                    for (int k = i + 1; k < b1; ++k) {
+                        const v4 f = {ti[k], ti[k], ti[k], ti[k]};
+                        *(v4u*)(Wg + (size_t)k * CW) -= f * zi;
+                    }
                 }
             }
+            bar.wait();
+            // rows k >= b1 of every group: W_k -= T[i][k] W_i for the block's i in ascending order -- a contiguous range of k per thread
+            const int rest = n - b1, chunk = (rest + team - 1) / team;
+            const int c0 = std::min(n, b1 + t * chunk), c1 = std::min(n, c0 + chunk);
+            if (c1 > c0)
+                for (int i = b0; i < b1; ++i) {                       // (the thread's rows of W -- chunk x DB doubles -- stay in L1)
+                    const double* __restrict__ ti = T + (size_t)i * n;
+                    v4 wi[NG];
+                    for (int g = 0; g < NG; ++g) wi[g] = *(const v4u*)(W + ((size_t)g * n + i) * CW);
+                    for (int k = c0; k < c1; ++k) {
+                        const v4 f = {ti[k], ti[k], ti[k], ti[k]};
+                        for (int g = 0; g < NG; ++g) *(v4u*)(W + ((size_t)g * n + k) * CW) -= f * wi[g];
+                    }
+                }
+            bar.wait();
         }
     });
 }
@@ -1214,7 +1358,7 @@ void small_svd(const double* G, double* P, double* sig, double* Q) {
 // convergence, a certificate that does not close -- returns 0 and the Jacobi SVD decides.  n = 128, one dropped direction: ~0.25 ms
 // against 1.8 ms of Jacobi sweeps.
 template <int DB, int MAXCUT>
-int FactorSolver::deflate_width(double rc, std::vector<double>& X, double norm_bound, double lower) {
+int FactorSolver::deflate_width(double rc, Scratch& X, double norm_bound, double lower) {
     constexpr int MAXIT = 10;
     if (n < 4 * DB) return 0;                                       // small systems: the Jacobi SVD costs little
     const double cut = rc * lower;
@@ -1343,16 +1487,7 @@ int FactorSolver::deflate_width(double rc, std::vector<double>& X, double norm_b
         });
     }
     double fr = 0.0, oi = 0.0;
-    {
-        std::vector<std::function<void()>> tasks;
-        tasks.emplace_back([&] {
-            double t2 = 0.0;
-            for (double x : X) t2 += x * x;
-            fr = t2;
-        });
-        tasks.emplace_back([&] { oi = one_inf_norm(n, X.data()); });
-        run_tasks(threads_for(n, 2.0 * (double)n * n), tasks);
-    }
+    full_norms(n, X.data(), &fr, &oi);
     if (!std::isfinite(fr)) return 0;
     const double inv_norm = std::fmin(std::sqrt(fr), oi);
     if (!(norm_bound * inv_norm * rc < 0.1)) return 0;
@@ -1368,7 +1503,7 @@ int FactorSolver::deflate_width(double rc, std::vector<double>& X, double norm_b
 // 1 ... 4 dropped directions with 8 vectors; when there are more, once again with 16 (up to 10) and with 32 vectors (up to 24; X is
 // only touched after the iteration has converged, and the first Rayleigh-Ritz step already tells that a width is too narrow).
 // false = the SVD decides.
-bool FactorSolver::deflate(double rc, std::vector<double>& X, double norm_bound) {
+bool FactorSolver::deflate(double rc, Scratch& X, double norm_bound) {
     HostProf hp_("deflate");
     if (const char* e = getenv("FSNAP_ROWSPACE_DEFLATE"))           // A/B switch: 0 = always the Jacobi SVD
         if (e[0] == '0') return false;
@@ -1392,7 +1527,7 @@ void FactorSolver::prepare(int K_, const double* Rhat, double rcond) {
             if (Rhat[(size_t)j * K + j] != 0.0) act.push_back(j);
         n = (int)act.size();
         rank = 0;
-        T.assign((size_t)n * n, 0.0);
+        T.reset((size_t)n * n);
         if (n == 0) return;
         // Frobenius bounds: sigma_max <= ||T||_F, sigma_min >= 1 / ||T^-1||_F.  If even these cannot put a singular
         // value below rcond * sigma_max, dgelsd would not truncate either and its solution is T^-1 z.
@@ -1405,6 +1540,7 @@ void FactorSolver::prepare(int K_, const double* Rhat, double rcond) {
                 for (int a = t; a < n; a += ntg) {
                     double* ta = T.data() + (size_t)a * n;
                     const double* ra = Rhat + (size_t)act[a] * K;
+                    std::fill(ta, ta + a, 0.0);                          // (a Scratch block: nothing is zero by itself)
                     if (n == K) memcpy(ta + a, ra + a, (size_t)(n - a) * sizeof(double));
                     else
                         for (int b = a; b < n; ++b) ta[b] = ra[act[b]];
@@ -1421,7 +1557,7 @@ void FactorSolver::prepare(int K_, const double* Rhat, double rcond) {
         ncut = 0;
         // X = T^-1 by back substitution, row by row from the bottom: X_i = (e_i - sum_{k>i} T_ik X_k) / T_ii -- every
         // update is an axpy of contiguous rows (the column-by-column form walked X with stride n: 0.4 ms at n = 128)
-        vec X((size_t)n * n, 0.0);
+        Scratch X((size_t)n * n);                                  // (upper_inverse writes all of it)
         {
             HostProf hp2_("prepare: inverse + norms");
             const int nt = threads_for(n, (double)n * n * n / 3.0);

@@ -2,9 +2,44 @@
 // with its GPU orchestration (fsnap_rowspace.cpp).  Internal; the public entry points are in include/fsnap_hip.h.
 #pragma once
 #include <algorithm>
+#include <cstddef>
 #include <vector>
 
 namespace fsnap_rs {
+
+// n doubles whose CONTENTS ARE UNDEFINED, from a small per-thread pool of blocks that stay mapped between calls.  The K x K
+// arrays of the large-K paths were fresh zero-filled vectors per call: 3 - 4 ms each of page faults + memset at K = 1595 (four of
+// them in a fit with dependent columns: 14 of 67 ms); the users below overwrite or zero what they need on their threads.
+class Scratch {
+    double* p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;
+
+public:
+    Scratch() = default;
+    explicit Scratch(size_t n) { reset(n); }
+    ~Scratch() { release(); }
+    Scratch(const Scratch&) = delete;
+    Scratch& operator=(const Scratch&) = delete;
+    Scratch(Scratch&& o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; }
+    Scratch& operator=(Scratch&& o) noexcept {
+        if (this != &o) {
+            release();
+            p_ = o.p_; n_ = o.n_; cap_ = o.cap_;
+            o.p_ = nullptr; o.n_ = o.cap_ = 0;
+        }
+        return *this;
+    }
+    void reset(size_t n);        // (throws std::bad_alloc like a vector)
+    void release();
+    double* data() { return p_; }
+    const double* data() const { return p_; }
+    size_t size() const { return n_; }
+    double* begin() { return p_; }
+    double* end() { return p_ + n_; }
+    const double* begin() const { return p_; }
+    const double* end() const { return p_ + n_; }
+};
+
 
 bool finite_all(const double* p, size_t n);
 // max |G_ij - delta_ij| over the columns with a non-zero diagonal entry
@@ -56,7 +91,7 @@ struct FactorSolver {
                                // substitution between two projections (deflate), no SVD
     int ncut = 0;
     std::vector<double> Uc, Vc;   // the dropped triplets' left / right singular vectors (ncut x n each, orthonormal rows)
-    std::vector<double> T;     // n x n active block of R_hat (row-major, upper)
+    Scratch T;                 // n x n active block of R_hat (row-major, upper; zero below the diagonal)
     std::vector<double> W, J, s2;   // SVD form: rows of W = sigma_i v_i^T (n x n), J = U^T (n x n), s2 = sigma_i^2
     std::vector<char> keep;
     double smax = 0.0, smin = 0.0;
@@ -71,9 +106,9 @@ struct FactorSolver {
     mutable bool use_external = false;
     void prepare(int K_, const double* Rhat, double rcond);
     void jacobi_svd(double rcond);
-    bool deflate(double rcond, std::vector<double>& X, double norm_bound);   // X = T^-1 on entry (overwritten)
+    bool deflate(double rcond, Scratch& X, double norm_bound);   // X = T^-1 on entry (overwritten)
     template <int DB, int MAXCUT>
-    int deflate_width(double rcond, std::vector<double>& X, double norm_bound, double lower);   // 1 done, 0 no, -1 more than MAXCUT
+    int deflate_width(double rcond, Scratch& X, double norm_bound, double lower);   // 1 done, 0 no, -1 more than MAXCUT
     void apply(const double* z, double* beta) const;   // beta (K entries, zeros in inactive columns) = pinv(R_hat) z
 };
 
