@@ -439,6 +439,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
         else fs.apply(rhs, out);
     };
     apply(z.data(), beta);
+    mark("solve");
     // one refinement step with the residual of the original rows
     double rel_step = 0.0;
     {
@@ -454,6 +455,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
             FSNAP_HIP(hipMemcpyAsync(hvec + K, rs->dz.p, (size_t)K * 8, hipMemcpyDeviceToHost, st), "hipMemcpy(dz)");
             if ((rc = fsnap::wait_stream(ctx, nullptr, "row-space refinement"))) return rc;
             memcpy(dzh.data(), hvec + K, (size_t)K * 8);
+            mark("refinement: residual pass");
         }
         if (nranks > 1 && (rc = fsnap_allreduce_host(ctx, dzh.data(), K, 0))) return rc;
         if (finite_all(dzh.data(), dzh.size())) {
@@ -468,7 +470,7 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
             for (int j = 0; j < K; ++j) beta[j] += dbeta[j];
         }
     }
-    mark("solve + refinement step");
+    mark("refinement: solve");
     int nact = 0;
     if (use_chain)
         for (int j = 0; j < K; ++j) nact += chain.active[j] ? 1 : 0;

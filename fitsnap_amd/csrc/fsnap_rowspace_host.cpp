@@ -35,6 +35,24 @@ struct HostProf {
     }
 };
 
+// ... and a sum over the repetitions of a phase inside a loop (printed when it goes out of scope)
+struct HostProfSum {
+    const char* what;
+    double ms = 0.0;
+    int calls = 0;
+    explicit HostProfSum(const char* w) : what(w) {}
+    template <class F>
+    void time(F&& f) {
+        const auto t0 = std::chrono::steady_clock::now();
+        f();
+        ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        ++calls;
+    }
+    ~HostProfSum() {
+        if (calls && getenv("FSNAP_ROWSPACE_TIMING")) fprintf(stderr, "[fsnap_rowspace_host]     %-28s %8.3f ms in %d calls\n", what, ms, calls);
+    }
+};
+
 using vec = std::vector<double>;
 
 // ---- Scratch: per-thread pool of large blocks ----------------------------------------------------------------------------------
@@ -206,6 +224,17 @@ static double sum_squares(const double* p, size_t n) {
     return r;
 }
 
+// (eight partial sums in a fixed order: one dependent chain costs 4 cycles per entry)
+static inline double dot_n(const double* x, const double* y, int n) {
+    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int k = 0;
+    for (; k + 8 <= n; k += 8)
+        for (int j = 0; j < 8; ++j) t[j] += x[k + j] * y[k + j];
+    double r = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    for (; k < n; ++k) r += x[k] * y[k];
+    return r;
+}
+
 bool finite_all(const double* p, size_t n) {
     // x * 0 is 0 for finite x and NaN for NaN / Inf; eight independent sums (one dependent chain costs 4 cycles per entry:
     // 10 ms for the 1595 x 1595 statistics)
@@ -350,9 +379,7 @@ namespace {
 void solve_upper(int n, const double* T, double* x) {
     for (int i = n - 1; i >= 0; --i) {
         const double* ti = T + (size_t)i * n;
-        double s = x[i];
-        for (int k = i + 1; k < n; ++k) s -= ti[k] * x[k];
-        x[i] = s / ti[i];
+        x[i] = (x[i] - dot_n(ti + i + 1, x + i + 1, n - i - 1)) / ti[i];      // (dot_n: eight partial sums, not one chain of n - i)
     }
 }
 
@@ -447,16 +474,11 @@ class TriTeam {
             if (t == 0)
                 for (int i = b1 - 1; i >= b0; --i) {
                     const double* ti = T + (size_t)i * n;
-                    double s = x[i];
-                    for (int k = i + 1; k < b1; ++k) s -= ti[k] * x[k];
-                    x[i] = s / ti[i];
+                    x[i] = (x[i] - dot_n(ti + i + 1, x + i + 1, b1 - i - 1)) / ti[i];
                 }
             bar.wait();
             for (int i = t; i < b0; i += nt) {
-                const double* ti = T + (size_t)i * n;
-                double s = 0.0;
-                for (int k = b0; k < b1; ++k) s += ti[k] * x[k];
-                x[i] -= s;
+                x[i] -= dot_n(T + (size_t)i * n + b0, x + b0, b1 - b0);
             }
             bar.wait();
         }
@@ -505,7 +527,16 @@ class TriTeam {
         x = x_;
         job_gen.fetch_add(1, std::memory_order_release);
     }
-    static int team_size(int n, int want) { return n < 1024 ? 1 : std::max(1, std::min(want, 8)); }      // (a solve at n = 480 is 30 us of work)
+    // (a solve at n = 480 is 30 us of work; beyond FSNAP_TRI_TEAM threads the two barriers per 64 unknowns cost more than the rows
+    // they share out, now that the dot products run on eight partial sums)
+    static int team_size(int n, int want) {
+        static const int cap = [] {
+            const char* e = getenv("FSNAP_TRI_TEAM");
+            const int v = e && *e ? atoi(e) : 4;
+            return v < 1 ? 1 : (v > 16 ? 16 : v);
+        }();
+        return n < 1024 ? 1 : std::max(1, std::min(want, cap));
+    }
 
 public:
     // `want` threads (the caller included); small systems keep the single-thread substitutions
@@ -650,8 +681,7 @@ double norm2_estimate(int n, const double* T, int steps = 8, int threads = 0) {
                 std::fill(pv, pv + n, 0.0);
                 for (int i = ch; i < n; i += nchunk) {            // rows dealt round-robin: row i costs n - i
                     const double* __restrict__ ti = T + (size_t)i * n;
-                    double acc = 0.0;
-                    for (int k = i; k < n; ++k) acc += ti[k] * v[k];
+                    const double acc = dot_n(ti + i, v + i, n - i);
                     for (int k = i; k < n; ++k) pv[k] += ti[k] * acc;
                 }
             }
@@ -676,8 +706,7 @@ double norm2_estimate(int n, const double* T, int steps = 8, int threads = 0) {
                         for (int pass = 0; pass < 2; ++pass)
                             for (int p = 0; p <= it; ++p) {
                                 const double* vp = V.data() + (size_t)p * n;
-                                double d = 0.0;
-                                for (int k = 0; k < n; ++k) d += vp[k] * w[k];
+                                const double d = dot_n(vp, w.data(), n);
                                 for (int k = 0; k < n; ++k) w[k] -= d * vp[k];
                             }
                         double b2 = 0.0;
@@ -1143,11 +1172,6 @@ void full_norms(int n, const double* B, double* fro2_out, double* one_inf_out) {
     *one_inf_out = std::sqrt(n1 * ninf);
 }
 
-inline double dot_n(const double* x, const double* y, int n) {
-    double t = 0.0;
-    for (int k = 0; k < n; ++k) t += x[k] * y[k];
-    return t;
-}
 
 // x <- x - sum_j (q_j . x) q_j for the orthonormal rows q_j of Q (nq x n), twice ("twice is enough")
 inline void project_out(int n, int nq, const double* Q, double* x) {
@@ -1171,117 +1195,96 @@ namespace {
 constexpr int BCW = 4;
 inline size_t bix(int n, int i, int c) { return ((size_t)(c / BCW) * n + (size_t)i) * BCW + (size_t)(c % BCW); }
 
-// W <- T^-1 W / W <- T^-T W for an n x DB block, blocks of 64 unknowns at a time on a team of host threads: the diagonal block's
-// substitution by column groups (independent right-hand sides), then the update of all other rows with that block, the rows (or
-// row ranges) dealt to the threads -- every element of T is read ONCE per solve for all DB columns.  (Round 5 dealt whole column
-// groups to the threads: at DB = 16 four threads, each streaming all of T; two of these solves per step of the subspace iteration
-// were 2 x 1.5 ms at n = 1595.)  The arithmetic of an element does not depend on the team's size.
+// W <- T^-1 W / W <- T^-T W for an n x DB block.  The right-hand sides are independent: the column groups are dealt to the host threads.
+// (Round 6 also built the cooperative form -- blocks of 64 / 128 unknowns on a team, T read once for all columns --: 1.4 ms per solve
+// at n = 1595 with 2 ... 12 threads against 2.0 with one; the barriers and the row-strided pieces of T cost what the team gains.)
 template <int DB>
 void solve_upper_block(int n, const double* T, double* W) {
-    constexpr int CW = BCW, NG = DB / CW, NB = 64;
-    static_assert(DB % CW == 0 && CW == 4, "block width");
-    const int nt = threads_for(n, 0.5 * (double)n * n * DB);
-    SpinBarrier bar(nt);
-    run_team(nt, bar, [&](int t, int team) {
-        for (int b1 = n; b1 > 0; b1 -= NB) {
-            const int b0 = std::max(0, b1 - NB);
-            for (int g = t; g < NG; g += team) {
-                double* Wg = W + (size_t)g * n * CW;
-                for (int i = b1 - 1; i >= b0; --i) {
-                    const double* ti = T + (size_t)i * n;
-                    v4 acc = *(const v4u*)(Wg + (size_t)i * CW);
-                    for (int k = i + 1; k < b1; ++k) {
-                        const v4 f = {ti[k], ti[k], ti[k], ti[k]};
-                        acc -= f * *(const v4u*)(Wg + (size_t)k * CW);
-                    }
-                    const double inv = 1.0 / ti[i];
-                    const v4 iv = {inv, inv, inv, inv};
-                    *(v4u*)(Wg + (size_t)i * CW) = acc * iv;
-                }
-            }
-            bar.wait();
-            for (int i = t; i < b0; i += team) {
+    constexpr int CW = BCW, NG = DB / CW;
+    static_assert(DB % CW == 0, "block width");
+    const int nt = std::min(threads_for(n, 0.5 * (double)n * n * DB), NG);
+    run_threads(nt, [&](int t) {
+        for (int g = t; g < NG; g += nt) {
+            double* Wg = W + (size_t)g * n * CW;
+            for (int i = n - 1; i >= 0; --i) {
                 const double* __restrict__ ti = T + (size_t)i * n;
-                v4 s[NG];
-                for (int g = 0; g < NG; ++g) s[g] = v4{0, 0, 0, 0};
-                for (int k = b0; k < b1; ++k) {
-                    const v4 f = {ti[k], ti[k], ti[k], ti[k]};
-                    for (int g = 0; g < NG; ++g) s[g] += f * *(const v4u*)(W + ((size_t)g * n + k) * CW);
+                // four partial sums over k (one chain of dependent multiply-adds is 4 cycles per entry of T: 1.5 ms per solve at
+                // n = 1595), added in a fixed order
+                v4 s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;
+                int k = i + 1;
+                for (; k + 4 <= n; k += 4) {
+                    const double* wk = Wg + (size_t)k * CW;
+                    s0 += v4{ti[k], ti[k], ti[k], ti[k]} * *(const v4u*)wk;
+                    s1 += v4{ti[k + 1], ti[k + 1], ti[k + 1], ti[k + 1]} * *(const v4u*)(wk + CW);
+                    s2 += v4{ti[k + 2], ti[k + 2], ti[k + 2], ti[k + 2]} * *(const v4u*)(wk + 2 * CW);
+                    s3 += v4{ti[k + 3], ti[k + 3], ti[k + 3], ti[k + 3]} * *(const v4u*)(wk + 3 * CW);
                 }
-                for (int g = 0; g < NG; ++g) *(v4u*)(W + ((size_t)g * n + i) * CW) -= s[g];
+                for (; k < n; ++k) s0 += v4{ti[k], ti[k], ti[k], ti[k]} * *(const v4u*)(Wg + (size_t)k * CW);
+                const double inv = 1.0 / ti[i];
+                const v4 acc = *(const v4u*)(Wg + (size_t)i * CW) - ((s0 + s1) + (s2 + s3));
+                *(v4u*)(Wg + (size_t)i * CW) = acc * v4{inv, inv, inv, inv};
             }
-            bar.wait();
         }
     });
 }
 
 template <int DB>
 void solve_upper_transposed_block(int n, const double* T, double* W) {
-    constexpr int CW = BCW, NG = DB / CW, NB = 64;
-    const int nt = threads_for(n, 0.5 * (double)n * n * DB);
-    SpinBarrier bar(nt);
-    run_team(nt, bar, [&](int t, int team) {
-        for (int b0 = 0; b0 < n; b0 += NB) {
-            const int b1 = std::min(n, b0 + NB);
-            for (int g = t; g < NG; g += team) {
-                double* Wg = W + (size_t)g * n * CW;
-                for (int i = b0; i < b1; ++i) {
-                    const double* ti = T + (size_t)i * n;
-                    const double inv = 1.0 / ti[i];
-                    const v4 iv = {inv, inv, inv, inv};
-                    const v4 zi = *(const v4u*)(Wg + (size_t)i * CW) * iv;
-                    *(v4u*)(Wg + (size_t)i * CW) = zi;
-                    for (int k = i + 1; k < b1; ++k) {
-                        const v4 f = {ti[k], ti[k], ti[k], ti[k]};
-                        *(v4u*)(Wg + (size_t)k * CW) -= f * zi;
-                    }
+    constexpr int CW = BCW, NG = DB / CW;
+    const int nt = std::min(threads_for(n, 0.5 * (double)n * n * DB), NG);
+    run_threads(nt, [&](int t) {
+        for (int g = t; g < NG; g += nt) {
+            double* Wg = W + (size_t)g * n * CW;
+            for (int i = 0; i < n; ++i) {
+                const double* ti = T + (size_t)i * n;
+                const double inv = 1.0 / ti[i];
+                double zi[CW];
+                for (int c = 0; c < CW; ++c) Wg[(size_t)i * CW + c] = zi[c] = Wg[(size_t)i * CW + c] * inv;
+                for (int k = i + 1; k < n; ++k) {
+                    const double f = ti[k];
+                    double* wk = Wg + (size_t)k * CW;
+                    for (int c = 0; c < CW; ++c) wk[c] -= f * zi[c];
                 }
             }
-            bar.wait();
-            // rows k >= b1 of every group: W_k -= T[i][k] W_i for the block's i in ascending order -- a contiguous range of k per thread
-            const int rest = n - b1, chunk = (rest + team - 1) / team;
-            const int c0 = std::min(n, b1 + t * chunk), c1 = std::min(n, c0 + chunk);
-            if (c1 > c0)
-                for (int i = b0; i < b1; ++i) {                       // (the thread's rows of W -- chunk x DB doubles -- stay in L1)
-                    const double* __restrict__ ti = T + (size_t)i * n;
-                    v4 wi[NG];
-                    for (int g = 0; g < NG; ++g) wi[g] = *(const v4u*)(W + ((size_t)g * n + i) * CW);
-                    for (int k = c0; k < c1; ++k) {
-                        const v4 f = {ti[k], ti[k], ti[k], ti[k]};
-                        for (int g = 0; g < NG; ++g) *(v4u*)(W + ((size_t)g * n + k) * CW) -= f * wi[g];
-                    }
-                }
-            bar.wait();
         }
     });
 }
 
-// orthonormal columns by modified Gram-Schmidt, twice; a column that vanishes is replaced by a pseudo-random one
+// orthonormal columns by modified Gram-Schmidt, twice; a column that vanishes is replaced by a pseudo-random one.  On a
+// column-major copy (contiguous dot products and axpys; the panel layout of the block walks a column with stride 4).
 template <int DB>
 void orthonormalise_block(int n, double* W) {
+    vec C((size_t)DB * n);
+    for (int c = 0; c < DB; ++c) {
+        double* col = C.data() + (size_t)c * n;
+        for (int i = 0; i < n; ++i) col[i] = W[bix(n, i, c)];
+    }
     unsigned long long state = 0xD1B54A32D192ED03ull;
     for (int c = 0; c < DB; ++c) {
+        double* __restrict__ col = C.data() + (size_t)c * n;
         for (int attempt = 0; attempt < 3; ++attempt) {
-            double before = 0.0;
-            for (int i = 0; i < n; ++i) before += W[bix(n, i, c)] * W[bix(n, i, c)];
+            const double before = dot_n(col, col, n);
             for (int rep = 0; rep < 2; ++rep)
                 for (int p = 0; p < c; ++p) {
-                    double t = 0.0;
-                    for (int i = 0; i < n; ++i) t += W[bix(n, i, p)] * W[bix(n, i, c)];
-                    for (int i = 0; i < n; ++i) W[bix(n, i, c)] -= t * W[bix(n, i, p)];
+                    const double* __restrict__ prev = C.data() + (size_t)p * n;
+                    const double t = dot_n(prev, col, n);
+                    for (int i = 0; i < n; ++i) col[i] -= t * prev[i];
                 }
-            double nn = 0.0;
-            for (int i = 0; i < n; ++i) nn += W[bix(n, i, c)] * W[bix(n, i, c)];
+            const double nn = dot_n(col, col, n);
             if (nn > 1.0e-24 * before && nn > 0.0 && std::isfinite(nn)) {
                 const double f = 1.0 / std::sqrt(nn);
-                for (int i = 0; i < n; ++i) W[bix(n, i, c)] *= f;
+                for (int i = 0; i < n; ++i) col[i] *= f;
                 break;
             }
             for (int i = 0; i < n; ++i) {          // (numerically) inside the span of the earlier columns: start over
                 state = state * 6364136223846793005ull + 1442695040888963407ull;
-                W[bix(n, i, c)] = ((double)(state >> 11) / 9007199254740992.0) - 0.5;
+                col[i] = ((double)(state >> 11) / 9007199254740992.0) - 0.5;
             }
         }
+    }
+    for (int c = 0; c < DB; ++c) {
+        const double* col = C.data() + (size_t)c * n;
+        for (int i = 0; i < n; ++i) W[bix(n, i, c)] = col[i];
     }
 }
 
@@ -1381,6 +1384,8 @@ int FactorSolver::deflate_width(double rc, Scratch& X, double norm_bound, double
         orthonormalise_block<DB>(n, U.data());
     }
     HostProf hp5_("deflate: iteration + rest");
+    HostProfSum ps_solve("deflate: block solves"), ps_ortho("deflate: orthonormalisations"), ps_ritz("deflate: Rayleigh-Ritz"),
+        ps_check("deflate: subspace check");
     double G[DB * DB], P[DB * DB], Q[DB * DB], sig[DB];
     vec uc((size_t)MAXCUT * n), vc((size_t)MAXCUT * n);
     vec un((size_t)n);
@@ -1389,24 +1394,27 @@ int FactorSolver::deflate_width(double rc, Scratch& X, double norm_bound, double
     double prev_worst = 1.0;
     for (int it = 0; it < MAXIT && !conv; ++it) {
         W = U;
-        solve_upper_block<DB>(n, T.data(), W.data());                   // W = T^-1 U
+        ps_solve.time([&] { solve_upper_block<DB>(n, T.data(), W.data()); });                   // W = T^-1 U
         V = W;
-        orthonormalise_block<DB>(n, V.data());
-        for (int a = 0; a < DB; ++a)
-            for (int b = 0; b < DB; ++b) {
-                double t = 0.0;
-                for (int i = 0; i < n; ++i) t += V[bix(n, i, a)] * W[bix(n, i, b)];
-                G[a * DB + b] = t;                                  // G = V^T T^-1 U
-            }
+        ps_ortho.time([&] { orthonormalise_block<DB>(n, V.data()); });
+        ps_ritz.time([&] {
+            for (int a = 0; a < DB; ++a)
+                for (int b = 0; b < DB; ++b) {
+                    double t = 0.0;
+                    for (int i = 0; i < n; ++i) t += V[bix(n, i, a)] * W[bix(n, i, b)];
+                    G[a * DB + b] = t;                                  // G = V^T T^-1 U
+                }
+        });
         for (double g : G)
             if (!std::isfinite(g)) return 0;
-        small_svd<DB>(G, P, sig, Q);                                    // T^-1 (U Q) ~ (V P) diag(sig): Ritz triplets of the inverse
+        ps_ritz.time([&] { small_svd<DB>(G, P, sig, Q); });             // T^-1 (U Q) ~ (V P) diag(sig): Ritz triplets of the inverse
         k = 0;
         while (k < DB && sig[k] > 0.0 && 1.0 / sig[k] <= cut) ++k;
         if (k > MAXCUT) return -1;                                  // more dropped directions than this width takes on
         if (k == 0 && it >= 2) return 0;                        // nothing certainly below the cut: the SVD decides
         Z = V;
-        solve_upper_transposed_block<DB>(n, T.data(), Z.data());        // Z = T^-T V
+        ps_solve.time([&] { solve_upper_transposed_block<DB>(n, T.data(), Z.data()); });        // Z = T^-T V
+        const auto t_check = std::chrono::steady_clock::now();
         // converged when the dropped Ritz vectors span a singular subspace: T^-T (their v's) lies inside the span of their u's.
         // (Not triplet by triplet: values at the rounding level of T mix freely among themselves from one solve to the next,
         // the SUBSPACE is what the projections of apply() need and what is well determined.)
@@ -1439,9 +1447,11 @@ int FactorSolver::deflate_width(double rc, Scratch& X, double norm_bound, double
         // done at the rounding floor -- or where the iteration stops improving: the floor sits at ~eps x the condition of the KEPT part
         conv = k > 0 && (worst <= 64.0 * EPS || (it >= 1 && worst <= 1.0e-11 && worst > 0.5 * prev_worst));
         prev_worst = worst;
+        ps_check.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_check).count();
+        ++ps_check.calls;
         if (!conv) {
             U = Z;
-            orthonormalise_block<DB>(n, U.data());
+            ps_ortho.time([&] { orthonormalise_block<DB>(n, U.data()); });
         }
     }
     if (!conv) return 0;
@@ -1487,7 +1497,10 @@ int FactorSolver::deflate_width(double rc, Scratch& X, double norm_bound, double
         });
     }
     double fr = 0.0, oi = 0.0;
-    full_norms(n, X.data(), &fr, &oi);
+    {
+        HostProf hp6_("deflate: norms of the rest");
+        full_norms(n, X.data(), &fr, &oi);
+    }
     if (!std::isfinite(fr)) return 0;
     const double inv_norm = std::fmin(std::sqrt(fr), oi);
     if (!(norm_bound * inv_norm * rc < 0.1)) return 0;
