@@ -420,3 +420,34 @@ def test_condition_bound_of_a_factor_is_above_the_truth_and_sharp_where_it_decid
         ratio = info["cond_bound"] / cond
         assert ratio >= 1.0, (name, ratio)
         assert ratio <= (5.0 if cond >= 1.0e9 else 2000.0), (name, ratio)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 31, 63, 64, 65, 67, 127, 129, 131, 197, 259])
+def test_tiled_inverse_and_product_at_ragged_sizes(n):
+    # The explicit inverse (64 x 64 tiles, strips of 32 columns, a 4 x 8 register block with scalar edges) only feeds certificates:
+    # a wrong entry would not change a solution, it would change what the solver BELIEVES about sigma_min.  Pin it through the
+    # numbers it reports -- smin = 1 / min(||X||_F, sqrt(||X||_1 ||X||_inf)) must be a lower bound of sigma_min within sqrt(n) --
+    # at sizes that leave ragged rows (n % 4), ragged columns (n % 8), a ragged strip (n % 32) and a ragged tile (n % 64); and the
+    # product of two factors (same tiles) through a chain that cannot be certified
+    rng = np.random.default_rng(n)
+    R = _upper_factor(rng.standard_normal((2 * n + 3, n)))
+    z = rng.standard_normal(n)
+    beta, rank, info = _capi.rowspace_solve(R, z, 1.0e-13)
+    s = np.linalg.svd(R, compute_uv=False)
+    assert rank == n and info[0] == 0.0                          # back substitution behind the Frobenius certificate
+    assert np.allclose(beta, sl.solve_triangular(R, z), rtol=1e-9, atol=0)
+    X = np.linalg.inv(R)
+    expect = 1.0 / min(np.linalg.norm(X), np.sqrt(np.linalg.norm(X, 1) * np.linalg.norm(X, np.inf)))
+    assert info[2] == pytest.approx(expect, rel=1e-10)
+    assert info[2] <= s[-1] * (1 + 1e-12) and info[2] >= s[-1] / (2.0 * np.sqrt(n) + 1.0)
+    if n >= 31:
+        # two factors whose product has kappa = 1e12: no certificate for the chain, the factors are multiplied out (upper_product)
+        U, _ = np.linalg.qr(rng.standard_normal((2 * n, n)))
+        V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        R1 = _upper_factor((U * np.logspace(0, -12, n)) @ V.T)
+        R2 = np.eye(n) + np.triu(rng.standard_normal((n, n))) / (4.0 * n)
+        beta2, rank2, info2 = _capi.rowspace_chain([R1, R2], z, 1.0e-13)
+        assert not info2["chain"]
+        ref, _, rank_ref, _ = sl.lstsq(R2 @ R1, z, cond=1.0e-13, lapack_driver="gelsd")
+        assert rank2 == rank_ref
+        assert np.linalg.norm(beta2 - ref) <= 1e-3 * np.linalg.norm(ref)
