@@ -62,8 +62,16 @@ struct ScratchPool {
     static constexpr size_t MAX_KEEP = (size_t)8 << 20;          // doubles: blocks above 64 MB are not kept
     double* p[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     size_t cap[SLOTS] = {0, 0, 0, 0};
+    bool alive = true;                                           // false once the thread's pool has been torn down: a Scratch that
+                                                                 // outlives it (an object destroyed late in thread / process exit)
+                                                                 // frees its block instead of parking it
     ~ScratchPool() {
-        for (int i = 0; i < SLOTS; ++i) free(p[i]);
+        alive = false;
+        for (int i = 0; i < SLOTS; ++i) {
+            free(p[i]);
+            p[i] = nullptr;
+            cap[i] = 0;
+        }
     }
 };
 thread_local ScratchPool g_scratch;
@@ -78,7 +86,7 @@ void Scratch::reset(size_t n) {
     if (n == 0) return;
     ScratchPool& pool = g_scratch;
     int best = -1;
-    for (int i = 0; i < ScratchPool::SLOTS; ++i)
+    for (int i = 0; pool.alive && i < ScratchPool::SLOTS; ++i)
         if (pool.p[i] && pool.cap[i] >= n && (best < 0 || pool.cap[i] < pool.cap[best])) best = i;
     if (best >= 0) {
         p_ = pool.p[best];
@@ -98,7 +106,7 @@ void Scratch::release() {
     if (!p_) return;
     ScratchPool& pool = g_scratch;
     int slot = -1;
-    if (cap_ <= ScratchPool::MAX_KEEP) {
+    if (pool.alive && cap_ <= ScratchPool::MAX_KEEP) {
         for (int i = 0; i < ScratchPool::SLOTS && slot < 0; ++i)
             if (!pool.p[i]) slot = i;
         if (slot < 0) {                                 // full: replace the smallest block if this one is larger
