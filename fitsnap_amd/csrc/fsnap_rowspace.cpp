@@ -72,6 +72,28 @@ struct RowSpace {
     }
     // page-locked staging for what crosses PCIe every pass: the K x K statistics down, the factor up (from pageable
     // memory each of these copies went through the runtime's own staging, ~40 us apiece)
+    // the factor of a device-factorised pass goes home on a stream of its own, behind an event, while the pass kernel and the
+    // statistics of Q run (20 MB at K = 1595: 0.4 ms that used to sit between the two on the fit's stream)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t fac_ready = nullptr, fac_copied = nullptr;
+    bool copy_pending = false;
+    bool copy_ensure() {
+        if (copy_stream) return true;
+        if (hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess) {
+            copy_stream = nullptr;
+            return false;
+        }
+        if (hipEventCreateWithFlags(&fac_ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&fac_copied, hipEventDisableTiming) != hipSuccess) {
+            if (fac_ready) (void)hipEventDestroy(fac_ready);
+            if (fac_copied) (void)hipEventDestroy(fac_copied);
+            fac_ready = fac_copied = nullptr;
+            (void)hipStreamDestroy(copy_stream);
+            copy_stream = nullptr;
+            return false;
+        }
+        return true;
+    }
     double* pin = nullptr;
     size_t pin_doubles = 0;
     bool pin_ensure(size_t n) {
@@ -90,6 +112,12 @@ void rowspace_release(fsnap_ctx* ctx) {
     RowSpace* rs = ctx->rowspace;
     DevBuf* bufs[] = {&rs->Q, &rs->qpack, &rs->Rdev, &rs->packed, &rs->rvec, &rs->dz, &rs->dzpart, &rs->beta, &rs->scan};
     for (DevBuf* b : bufs) b->release();
+    if (rs->copy_stream) {
+        (void)hipStreamSynchronize(rs->copy_stream);
+        (void)hipEventDestroy(rs->fac_ready);
+        (void)hipEventDestroy(rs->fac_copied);
+        (void)hipStreamDestroy(rs->copy_stream);
+    }
     if (rs->pin) (void)hipHostFree(rs->pin);
     for (double* p : rs->pinfac)
         if (p) (void)hipHostFree(p);
@@ -347,6 +375,9 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
             // shift: a few times the rounding level of the Gram matrix, x 100 and again when a pivot fails (as factor_pass)
             shift = 4.0 * (K + 100.0) * std::numeric_limits<double>::epsilon() * fro;
             int status = 0;
+            if (rs->copy_pending) {          // the previous pass's factor is still being read out of Rdev by the copy stream
+                FSNAP_HIP(hipStreamWaitEvent(st, rs->fac_copied, 0), "hipStreamWaitEvent");
+            }
             for (int attempt = 0; attempt < 10; ++attempt) {
                 FSNAP_HIP(fsnap::launch_chol_factor(dp, K, shift, (double*)ctx->dchol.p, d_dsc, d_status, d_minpiv, K16,
                                                     (double*)rs->Rdev.p, st), "launch device Cholesky (factor)");
@@ -377,6 +408,25 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
         fsnap::trsm_invert_diagonal_blocks(Rpad, K16);
         FSNAP_HIP(hipMemcpyAsync(rs->Rdev.p, Rpad, rdoubles * 8, hipMemcpyHostToDevice, st), "hipMemcpy(R)");
         }
+        if (device_factor) {
+            // the factor for the K x K end: K x K compact into a page-locked block of its own, where it stays (no second copy).
+            // On the copy stream, behind an event (the factorisation is complete: its status has been read): the download
+            // runs beside the pass kernel and the statistics of Q; the next factorisation and the K x K end wait for it.
+            double* hf = rs->pinfac_get((size_t)pass - 1, (size_t)K * K);
+            if (!hf) return ctx->fail(FSNAP_E_NOMEM, "hipHostMalloc(factor staging) failed");
+            hipStream_t cs = rs->copy_ensure() ? rs->copy_stream : st;
+            if (cs != st) {
+                FSNAP_HIP(hipEventRecord(rs->fac_ready, st), "hipEventRecord");
+                FSNAP_HIP(hipStreamWaitEvent(cs, rs->fac_ready, 0), "hipStreamWaitEvent");
+            }
+            FSNAP_HIP(hipMemcpy2DAsync(hf, (size_t)K * 8, rs->Rdev.p, (size_t)K16 * 8, (size_t)K * 8, (size_t)K, hipMemcpyDeviceToHost, cs),
+                      "hipMemcpy(factor)");
+            if (cs != st) {
+                FSNAP_HIP(hipEventRecord(rs->fac_copied, cs), "hipEventRecord");
+                rs->copy_pending = true;
+            }
+            chain.push_view(hf);
+        }
         if (have_rows) {
             if (pass == 1)
                 FSNAP_HIP(fsnap::launch_trsm_rows(ctx->dA, ctx->lda, (const double*)ctx->wpack.p, dQ, K, ctx->m, K,
@@ -385,21 +435,17 @@ int fsnap_lstsq_rows(fsnap_ctx* ctx, double rcond, int64_t K64, double* beta, in
                 FSNAP_HIP(fsnap::launch_trsm_rows(dQ, K, nullptr, dQ, K, ctx->m, K, (const double*)rs->Rdev.p, K16, st),
                           "launch fsnap_trsm_rows_k");
         }
-        if (device_factor) {
-            // the factor for the K x K end, behind the pass on the same stream: K x K compact into a page-locked block of its
-            // own, where it stays (no second copy)
-            double* hf = rs->pinfac_get((size_t)pass - 1, (size_t)K * K);
-            if (!hf) return ctx->fail(FSNAP_E_NOMEM, "hipHostMalloc(factor staging) failed");
-            FSNAP_HIP(hipMemcpy2DAsync(hf, (size_t)K * 8, rs->Rdev.p, (size_t)K16 * 8, (size_t)K * 8, (size_t)K, hipMemcpyDeviceToHost, st),
-                      "hipMemcpy(factor)");
-            chain.push_view(hf);
-        }
-        if ((rc = fsnap::wait_stream(ctx, nullptr, "row-space pass"))) return rc;      // Rpad is reused by the next pass
+        // (host-factorised widths: Rpad is reused by the next pass; device-factorised: the statistics of Q queue behind the pass)
+        if (!device_factor && (rc = fsnap::wait_stream(ctx, nullptr, "row-space pass"))) return rc;
         passes = pass;
-        mark("factor upload + TRSM pass");
+        mark(device_factor ? "TRSM pass launched" : "factor upload + TRSM pass");
         if ((rc = gather_stats(false))) return rc;
-        mark("statistics of Q");
+        mark(device_factor ? "TRSM pass + statistics of Q" : "statistics of Q");
         memcpy(z.data(), host + (size_t)K * K, (size_t)K * 8);     // z = Q^T (w b)
+    }
+    if (rs->copy_pending) {                  // the factors are read on the host from here on
+        rs->copy_pending = false;
+        if ((rc = fsnap::wait_stream(ctx, rs->fac_copied, "factor download"))) return rc;
     }
     if (!converged) {
         // pass budget used up: judge the last Q as it is (the refinement step below absorbs what is left)
