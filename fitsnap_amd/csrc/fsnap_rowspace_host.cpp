@@ -1481,26 +1481,31 @@ int FactorSolver::deflate_width(double rc, Scratch& X, double norm_bound, double
                 }
             }
         });
-        // X <- (I - Vc^T Vc) X: columns are independent -- blocks of 64 columns (n x 64 doubles stay in L2 over the k vectors)
+        // X <- (I - Vc^T Vc) X: columns are independent -- blocks of 64 columns, COPIED into a contiguous n x 64 panel for the 2 k
+        // passes (the rows of a block lie a page apart in X: twelve strided passes per block were latency-bound, 3.5 of the 4.4 ms
+        // of these projections at n = 1595) and written back once; same arithmetic, element by element
         const int nblk = (n + 63) / 64;
         run_threads(nt, [&](int t) {
             double tb[64];
+            vec panel((size_t)n * 64);
             for (int blk = t; blk < nblk; blk += nt) {
                 const int c0 = blk * 64, cw = std::min(64, n - c0);
+                for (int i = 0; i < n; ++i) memcpy(panel.data() + (size_t)i * 64, X.data() + (size_t)i * n + c0, (size_t)cw * sizeof(double));
                 for (int c = 0; c < k; ++c) {
                     const double* v = Vc.data() + (size_t)c * n;
                     for (int j = 0; j < cw; ++j) tb[j] = 0.0;
                     for (int i = 0; i < n; ++i) {
-                        const double* xi = X.data() + (size_t)i * n + c0;
+                        const double* __restrict__ xi = panel.data() + (size_t)i * 64;
                         const double vi = v[i];
                         for (int j = 0; j < cw; ++j) tb[j] += vi * xi[j];
                     }
                     for (int i = 0; i < n; ++i) {
-                        double* xi = X.data() + (size_t)i * n + c0;
+                        double* __restrict__ xi = panel.data() + (size_t)i * 64;
                         const double vi = v[i];
                         for (int j = 0; j < cw; ++j) xi[j] -= vi * tb[j];
                     }
                 }
+                for (int i = 0; i < n; ++i) memcpy(X.data() + (size_t)i * n + c0, panel.data() + (size_t)i * 64, (size_t)cw * sizeof(double));
             }
         });
     }
