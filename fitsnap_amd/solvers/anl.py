@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from .._hostblas import blas_threads
 from .solver import Solver
 
 
@@ -32,14 +33,16 @@ class ANL(Solver):
             else:
                 print("The Matrix is ill-conditioned for the transpose trick")
         if transposed:
-            invptp = np.linalg.pinv(G.T @ G + cov_nugget * np.diag(np.ones((nbas,))))
+            with blas_threads(nbas):
+                invptp = np.linalg.pinv(G.T @ G + cov_nugget * np.diag(np.ones((nbas,))))
             invptp = invptp * 0.5 + invptp.T * 0.5
             fit = np.dot(invptp, G.T @ c)
             res = c - G @ fit
             sse = float(res @ res)
             npt = float(nbas)                       # the "rows" of the transposed system
         else:
-            invptp = np.linalg.pinv(G + cov_nugget * np.diag(np.ones((nbas,))))       # anl.py:39
+            with blas_threads(nbas):            # (an SVD of K x K: _hostblas.py)
+                invptp = np.linalg.pinv(G + cov_nugget * np.diag(np.ones((nbas,))))       # anl.py:39
             invptp = invptp * 0.5 + invptp.T * 0.5                                     # anl.py:40
             fit = np.dot(invptp, c)
             # res = bw - aw @ fit; bp = res.res / 2  (anl.py:46-47): exact streamed residual on the GPU

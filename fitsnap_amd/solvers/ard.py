@@ -21,6 +21,7 @@ from __future__ import annotations
 import numpy as np
 from scipy.linalg import pinvh
 
+from .._hostblas import blas_threads
 from .solver import Solver
 
 
@@ -85,7 +86,8 @@ class ARD(Solver):
 
         def update_sigma(alpha_, lambda_, keep):
             dk = dsc[keep]
-            scaled = pinvh(np.diag(lambda_[keep] / dk ** 2) + alpha_ * Gh[np.ix_(keep, keep)])
+            with blas_threads(len(dk)):         # (an eigh of <= K x K: the BLAS pool sized by the CPUs it sees takes 20 x longer)
+                scaled = pinvh(np.diag(lambda_[keep] / dk ** 2) + alpha_ * Gh[np.ix_(keep, keep)])
             return scaled / np.outer(dk, dk)
 
         def sse_of(coef_):
