@@ -273,8 +273,11 @@ def make_dense_pinv():
             n = int(n)
             held = cache.get("svd")
             if held is None or held[0] != (token, n):
+                from ._hostblas import blas_threads
+
                 T = np.ctypeslib.as_array(T_p, shape=(n, n))
-                U, sv, Vt = sl.svd(T, full_matrices=False, lapack_driver="gesdd")
+                with blas_threads(n):               # (a BLAS pool sized by the CPUs it SEES is throttled behind a cgroup quota)
+                    U, sv, Vt = sl.svd(T, full_matrices=False, lapack_driver="gesdd")
                 keep = sv > rcond * sv[0] if (n and sv[0] > 0.0) else np.zeros(n, dtype=bool)   # gelsd's cut
                 held = ((token, n), U[:, keep].copy(), sv[keep].copy(), Vt[keep].copy())
                 cache["svd"] = held

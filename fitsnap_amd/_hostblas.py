@@ -4,7 +4,7 @@
 The statistics come from the GPU; what is left on the host is an eigen- or singular-value decomposition of a K x K matrix.
 OpenBLAS / MKL size their pools by the CPUs they SEE: on the MI355X boxes that is 256 logical CPUs behind a cgroup quota of 16,
 and a 128 x 128 ``eigh`` then takes 12 ms instead of 0.6 (six of them were 72 of the 89 ms of an ARD fit at 10^6 x 128,
-``scripts/consumer_fit_survey.py``).  ``blas_threads(K)`` limits the pools for the duration of such a call: one thread per ~256
+``scripts/consumer_fit_survey.py``).  ``blas_threads(K)`` limits the pools for the duration of such a call: one thread per 128
 columns, never more than the CPUs this process may use.  A no-op without ``threadpoolctl`` (a dependency of scikit-learn, which
 the reference's own ARD solver needs)."""
 from __future__ import annotations
@@ -51,6 +51,6 @@ def blas_threads(K):
         if _controller is None:
             from threadpoolctl import ThreadpoolController
             _controller = ThreadpoolController()        # (the libraries are looked up once: ~1 ms)
-        return _controller.limit(limits=max(1, min(cpu_budget(), int(K) // 256 + 1)))
+        return _controller.limit(limits=max(1, min(cpu_budget(), int(K) // 128)))
     except Exception:
         return contextlib.nullcontext()

@@ -27,7 +27,8 @@ class ANL(Solver):
         if config.sections["EXTRAS"].apply_transpose:
             # anl.py:31-36: the regression is run on (aw.T aw, aw.T bw) = (G, c) instead of the rows when
             # cond(aw)^2 = lambda_max(G) / lambda_min(G) < 1 / eps -- all of it K x K host algebra on the statistics
-            ev = np.linalg.eigvalsh(G)
+            with blas_threads(len(c)):
+                ev = np.linalg.eigvalsh(G)
             if abs(ev[-1]) / max(abs(ev[0]), np.finfo(float).tiny) < 1.0 / np.finfo(float).eps:
                 transposed = True
             else:

@@ -24,6 +24,7 @@ from __future__ import annotations
 import numpy as np
 
 from .. import _capi
+from .._hostblas import blas_threads
 
 
 class _TrainWeights:
@@ -442,7 +443,8 @@ class Solver:
             return beta, 0
         M = 0.5 * (G[np.ix_(keep, keep)] + G[np.ix_(keep, keep)].T)
         M[np.diag_indices(n)] += alpha
-        ev, V = np.linalg.eigh(M)
+        with blas_threads(n):
+            ev, V = np.linalg.eigh(M)
         eps = np.finfo(np.float64).eps
         cut = 4.0 * n * eps if ridge else max(float(param) ** 2 if param > 0 else 0.0, 4.0 * n * eps)
         used = ev > cut * np.max(np.abs(ev))

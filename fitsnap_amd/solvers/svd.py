@@ -6,6 +6,7 @@ from sys import float_info as fi
 import numpy as np
 
 from .. import _capi
+from .._hostblas import blas_threads
 from .solver import Solver
 
 
@@ -62,7 +63,8 @@ class SVD(Solver):
             if "EXTRAS" in self.config.sections and self.config.sections["EXTRAS"].apply_transpose:
                 # svd.py:48-53: lstsq on (aw.T aw, aw.T bw) when cond(aw)^2 < 1/eps, i.e. the
                 # 1e-13 cut then applies to the singular values of G itself (= eigenvalues)
-                ev = np.linalg.eigvalsh(G)
+                with blas_threads(len(c)):
+                    ev = np.linalg.eigvalsh(G)
                 cond2 = abs(ev[-1]) / max(abs(ev[0]), np.finfo(float).tiny)
                 if cond2 < 1 / fi.epsilon:
                     rcond = np.sqrt(self.RCOND)

@@ -699,5 +699,5 @@ def test_host_blas_limiter_limits_and_restores():
         assert all(n == 1 for n in inside)
     with blas_threads(1000):
         inside = [p["num_threads"] for p in threadpool_info()]
-        assert all(n <= max(1, min(cpu_budget(), 4)) for n in inside)
+        assert all(n <= max(1, min(cpu_budget(), 1000 // 128)) for n in inside)
     assert [(p["internal_api"], p["num_threads"]) for p in threadpool_info()] == before
