@@ -451,3 +451,37 @@ def test_tiled_inverse_and_product_at_ragged_sizes(n):
         ref, _, rank_ref, _ = sl.lstsq(R2 @ R1, z, cond=1.0e-13, lapack_driver="gelsd")
         assert rank2 == rank_ref
         assert np.linalg.norm(beta2 - ref) <= 1e-3 * np.linalg.norm(ref)
+
+
+_TEAM_PROBE = r"""
+import sys, hashlib, numpy as np
+sys.path.insert(0, sys.argv[1])
+from fitsnap_amd import _capi
+K = 1100
+rng = np.random.default_rng(11)
+U, _ = np.linalg.qr(rng.standard_normal((K + 200, K)))
+V, _ = np.linalg.qr(rng.standard_normal((K, K)))
+R1 = np.linalg.qr((U * np.logspace(0, -8, K)) @ V.T, mode="r")
+R1 = R1 * np.sign(np.diag(R1))[:, None]
+R2 = np.eye(K) + 1e-2 * np.triu(rng.standard_normal((K, K))) / K
+z = rng.standard_normal(K)
+beta, rank, info = _capi.rowspace_chain([R1, R2], z, 1e-13)
+print(rank, info["chain"], repr(info["cond_bound"]), hashlib.sha256(beta.tobytes()).hexdigest())
+"""
+
+
+def test_cooperative_substitutions_do_not_depend_on_the_team(tmp_path):
+    # from 1 024 unknowns on a triangular substitution runs on a team (FSNAP_TRI_TEAM threads, blocks of 64 unknowns, dot products
+    # on eight partial sums in a fixed order): the certified chain's solution and its condition bound carry the same bits with
+    # one, two and five threads per substitution and with two or seven host threads around them
+    import subprocess
+    import sys
+
+    script = tmp_path / "probe.py"
+    script.write_text(_TEAM_PROBE)
+    outs = []
+    for team, nt in (("1", "2"), ("2", "7"), ("5", "7")):
+        env = dict(os.environ, FSNAP_TRI_TEAM=team, FSNAP_HOST_THREADS=nt)
+        outs.append(subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600, check=True).stdout)
+    assert outs[0] == outs[1] == outs[2]
+    assert outs[0].startswith("1100 1.0")
