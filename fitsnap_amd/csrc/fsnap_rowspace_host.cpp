@@ -870,13 +870,18 @@ static void upper_inverse(int n, const double* T, double* X) {
     for (int c0 = TB; c0 < n; c0 += SW) strips.emplace_back((double)(c0 / TB) * (c0 / TB), c0);
     run_weighted(nt, strips, [&](int c0) {
         const int J = c0 / TB, w = std::min(SW, n - c0);
+        const int rows = std::min(n, (J + 1) * TB);
         double S[TB * SW];
+        // the strip of X as a contiguous rows x 32 panel (its rows lie a page apart in X): the diagonal tile's piece first, every
+        // solved tile row is added as it is written
+        vec P((size_t)rows * SW, 0.0);
+        for (int k = J * TB; k < rows; ++k) memcpy(P.data() + (size_t)k * SW, X + (size_t)k * n + c0, (size_t)w * sizeof(double));
         for (int I = J - 1; I >= 0; --I) {
             const int i0 = I * TB;
             std::fill(S, S + TB * SW, 0.0);
             for (int Kb = I + 1; Kb <= J; ++Kb) {
                 const int k0 = Kb * TB, kk = std::min(TB, n - k0);
-                tile_gemm<false>(S, SW, T + (size_t)i0 * n + k0, (size_t)n, X + (size_t)k0 * n + c0, (size_t)n, TB, w, kk);
+                tile_gemm<false>(S, SW, T + (size_t)i0 * n + k0, (size_t)n, P.data() + (size_t)k0 * SW, SW, TB, w, kk);
             }
             // X_{I, strip} = -T_II^-1 S by back substitution inside the tile (NOT -X_II S: the product with the explicit inverse of
             // a diagonal tile that holds a rounding-level pivot leaves a residual T X - I of the size of that inverse, and the
@@ -894,6 +899,7 @@ static void upper_inverse(int n, const double* T, double* X) {
                 double* __restrict__ xi = X + (size_t)(i0 + i) * n + c0;
                 for (int c = 0; c < SW; ++c) si[c] *= inv;                 // row i of S now holds x_i: the rows above add T_ik x_k
                 for (int c = 0; c < w; ++c) xi[c] = si[c];
+                memcpy(P.data() + (size_t)(i0 + i) * SW, si, (size_t)SW * sizeof(double));
             }
         }
     });
@@ -1587,7 +1593,10 @@ void FactorSolver::prepare(int K_, const double* Rhat, double rcond) {
         {
             HostProf hp2_("prepare: inverse + norms");
             const int nt = threads_for(n, (double)n * n * n / 3.0);
-            upper_inverse(n, T.data(), X.data());                       // 64 x 64 tiles, column strips on the host threads
+            {
+                HostProf hpi_("  prepare: inverse alone");
+                upper_inverse(n, T.data(), X.data());                   // 64 x 64 tiles, column strips on the host threads
+            }
             double bt = fro, bx = 0.0;
             std::vector<std::function<void()>> tasks;
             tasks.emplace_back([&] {
