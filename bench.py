@@ -249,7 +249,8 @@ def kernel_source_digest(kernel_name=""):
     """sha256 of the sources of the named SYRK kernel (fsnap_syrk_quad<...> lives in a file of its own): ties a recorded
     PMC traffic number to the code it was measured on."""
     h = hashlib.sha256()
-    main = "fsnap_syrk_quad.hip" if kernel_name.startswith("fsnap_syrk_quad") else "fsnap_syrk.hip"
+    main = ("fsnap_syrk_quad.hip" if kernel_name.startswith("fsnap_syrk_quad") else
+            "fsnap_syrk_short.hip" if kernel_name.startswith("fsnap_syrk_short") else "fsnap_syrk.hip")
     for name in (main, "fsnap_device_common.h"):
         with open(os.path.join(ROOT, "fitsnap_amd", "csrc", name), "rb") as f:
             h.update(f.read())
@@ -285,6 +286,8 @@ def recorded_traffic(m, Kc, info, kernel_name):
 def kernel_name_of(info):
     if info["split"] == 0:
         return "fsnap_syrk_tiled"
+    if info["kernel_or_pairs"] == 7:
+        return f"fsnap_syrk_short<{info['NB']}>"
     if info["kernel_or_pairs"] == 6:
         return f"fsnap_syrk_quadc<{info['NB']}>"
     if info["kernel_or_pairs"] == 5:

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "_lib")
 LIBNAME = "libfsnap_hip.so"
-SOURCES = ["fsnap_syrk_quad.hip:0", "fsnap_syrk_quad.hip:1", "fsnap_syrk_quad.hip:2", "fsnap_syrk.hip", "fsnap_rows.hip", "fsnap_chol.hip", "fsnap_trsm.hip", "fsnap_fused.hip", "fsnap_capi.cpp", "fsnap_comm.cpp", "fsnap_p2p.cpp",
+SOURCES = ["fsnap_syrk_quad.hip:0", "fsnap_syrk_quad.hip:1", "fsnap_syrk_quad.hip:2", "fsnap_syrk.hip", "fsnap_syrk_short.hip", "fsnap_rows.hip", "fsnap_chol.hip", "fsnap_trsm.hip", "fsnap_fused.hip", "fsnap_capi.cpp", "fsnap_comm.cpp", "fsnap_p2p.cpp",
            "fsnap_rowspace.cpp", "fsnap_rowspace_host.cpp", "fsnap_solve.cpp"]
 HEADERS = ["fsnap_kernels.h", "fsnap_device_common.h", "fsnap_ctx.h", "fsnap_rowspace_host.h", "fsnap_condest.h", "fsnap_p2p.h", os.path.join("..", "..", "include", "fsnap_hip.h")]
 ARCH = "gfx950"

@@ -70,6 +70,7 @@ struct Geometry {
     bool packed;    // kernel 1P (K <= 80)
     bool fused_pack = false;   // kernel 1A packs (w_eff, w_eff b) of its rows into LDS itself: no fsnap_pack_weights_k launch
     bool quad = false;         // kernel 1Q: the triangle dealt to the four waves of a workgroup (144 < K <= 288); cpw = chunks per workgroup
+    bool shortk = false;       // kernel 1S (80 < K <= 144, short systems): nblocks = chunks, cpw = ROWS per chunk, two workgroups per chunk
     int cluster = 1;           // kernel 1QC (288 < K <= 512): workgroups per cluster; nblocks = clusters, cpw = chunks per cluster
 };
 
@@ -79,6 +80,11 @@ constexpr int64_t QUAD_MIN_ROWS = 8192;
 constexpr int64_t QUAD_MIN_CPG = 24;        // fewest 4-row chunks per workgroup before the grid shrinks (profiles/r05_quad_min_cpg_ab.txt)
 // widest system the accumulator-resident kernel 1A takes (NB = 9 column blocks: the ACE width 142 of examples/Ta_PACE_RIDGE)
 constexpr int64_t ACC_MAX_K = 144;
+// longest system kernel 1S takes by default, in staging phases (128 rows, 112 at NB = 9) per workgroup with half the CUs' worth of
+// chunks (two workgroups share a chunk): 28 672 ... 32 768 rows on 256 CUs.  Measured (profiles/r06_short_kernel.txt, kernel us,
+// 1S | 1A): 13 035 x 142 19.6 | 31.7, 20 000 x 142 24.6 | 34.4, 28 672 x 142 28.0 | 35.7, 40 000 x 142 36.4 | 37.3, 60 000 x 142 51.8 | 41.5
+constexpr int64_t SHORT_MAX_PHASES = 2;
+constexpr int64_t SHORT_MIN_CHUNK_ROWS = 32;
 constexpr int64_t ACC_MIN_CPW = 12;         // kernel 1A: fewest 4-row chunks per row-wave before its grid shrinks below one workgroup per CU
 // kernel 1QC (289 ... 512 columns on clusters of workgroups) against the tiled kernel, round 5 (profiles/r05_quadc_ab.txt):
 // 500 000 x 368 1.19 against 1.24 ms, 367 900 x 480 1.40 / 1.38 ms (with 1.43 instead of 6.14 GB of HBM reads and a 17 instead of
@@ -138,6 +144,23 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
         // fused packing: the workgroup's per-row pairs must fit the LDS; the row-space passes bring pairs of their own
         g->fused_pack = ctx->opt_fused_pack && !ctx->wpack_override && cpg <= fsnap::syrk_quad_max_cpg();
         return FSNAP_OK;
+    }
+    if (g->NB >= 6 && ctx->opt_short != 0 && (ctx->opt_short == 1 || m <= SHORT_MAX_PHASES * (int64_t)fsnap::syrk_short_phase_rows(K) * (ctx->num_cu / 2)) &&
+        ctx->lda * 8 * (int64_t)128 + 16 <= (int64_t)0xFFFFF000) {
+        // kernel 1S: chunks of rows staged through LDS, the triangle dealt over the 16 waves of the two workgroups of a chunk
+        int64_t want = ctx->opt_nblocks > 0 ? ctx->opt_nblocks : std::max<int64_t>(1, (int64_t)ctx->num_cu / 2);
+        int64_t rpc = ((m + want - 1) / want + 3) / 4 * 4;
+        if (rpc < SHORT_MIN_CHUNK_ROWS) rpc = SHORT_MIN_CHUNK_ROWS;
+        const int64_t nchunk = (m + rpc - 1) / rpc;
+        if (rpc <= 0x7FFFFFF0 && nchunk <= 0x3FFFFFF) {
+            g->nblocks = (int)nchunk;
+            g->cpw = rpc;
+            g->split = 1;
+            g->threads = 512;
+            g->shortk = true;
+            g->fused_pack = ctx->opt_fused_pack && !ctx->wpack_override;
+            return FSNAP_OK;
+        }
     }
     if (g->NB >= 6) {
         // kernel 1A: one 4-wave workgroup per CU, every wave streams its own rows and owns the whole triangle
@@ -600,7 +623,7 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
         mask = (const unsigned char*)ctx->ones.p;
     }
     const int NT = g.NB * (g.NB + 1) / 2;
-    const int cs_per_block = 4 * g.cluster;   // c / scalar partials per workgroup (kernel 1QC: 4 per member)
+    const int cs_per_block = g.shortk ? 1 : 4 * g.cluster;   // c / scalar partials per workgroup (kernel 1QC: 4 per member; kernel 1S: one per chunk)
     if (!ctx->part.ensure((size_t)g.nblocks * NT * 256 * sizeof(double)) ||
         !ctx->cpart.ensure((size_t)g.nblocks * cs_per_block * g.NB * 16 * sizeof(double)) ||
         !ctx->spart.ensure((size_t)g.nblocks * cs_per_block * 4 * sizeof(double)))
@@ -649,7 +672,8 @@ int launch_normal_eq(fsnap_ctx* ctx, double* d_packed, bool want_mirror = false,
         const int flow = 2 | ((g.cluster == 2 ? 0 : 2) << 2);      // mode 2: publish at the start of a trip, judge at its end
         a.flow_tag = (int)(ctx->quad_flow_tag | (unsigned)flow);
     }
-    if (g.quad) FSNAP_HIP(fsnap::launch_syrk_quad(a, ctx->stream), "launch fsnap_syrk_quad");
+    if (g.shortk) FSNAP_HIP(fsnap::launch_syrk_short(a, ctx->stream), "launch fsnap_syrk_short");
+    else if (g.quad) FSNAP_HIP(fsnap::launch_syrk_quad(a, ctx->stream), "launch fsnap_syrk_quad");
     else if (g.acc) FSNAP_HIP(fsnap::launch_syrk_acc(a, ctx->stream), "launch fsnap_syrk_acc");
     else FSNAP_HIP(fsnap::launch_syrk_wave_p(a, ctx->stream), "launch fsnap_syrk_wave_p");
     if (evs) FSNAP_HIP(hipEventRecord(evs[1], ctx->stream), "hipEventRecord");
@@ -836,6 +860,9 @@ int fsnap_set_option(fsnap_ctx* ctx, const char* key, int64_t value) {
         ctx->opt_device_solve = (int)value;
     } else if (!strcmp(key, "tiled")) {
         ctx->opt_tiled = value != 0;
+    } else if (!strcmp(key, "short")) {
+        if (value < -1 || value > 1) return ctx->fail(FSNAP_E_ARG, "short must be -1 (by the row count), 0 (never) or 1 (always)");
+        ctx->opt_short = (int)value;
     } else if (!strcmp(key, "timing_every")) {
         if (value < 0 || value > (1 << 20)) return ctx->fail(FSNAP_E_ARG, "timing_every out of range");
         ctx->opt_timing_every = (int)value;
@@ -1915,7 +1942,7 @@ int fsnap_launch_info(fsnap_ctx* ctx, int64_t* info, int n) {
         out[2] = g.cpw;
         out[3] = g.NB;
         out[4] = g.split;
-        out[6] = g.quad ? (g.cluster > 1 ? 6 : 5) : g.acc ? 3 : 4;
+        out[6] = g.shortk ? 7 : g.quad ? (g.cluster > 1 ? 6 : 5) : g.acc ? 3 : 4;
         out[7] = g.fused_pack ? 1 : 0;  // kernel id: 1 = wave-triangle, 2 = LDS-shared, 3 = one-wave triangle (1A), 4 = wave-triangle on packed weights (1P), 5 = triangle dealt to the four waves of a workgroup (1Q; chunks per WORKGROUP)
     }
     for (int i = 0; i < n; ++i) info[i] = out[i];

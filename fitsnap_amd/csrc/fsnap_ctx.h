@@ -117,6 +117,7 @@ struct fsnap_ctx {
     // options
     int opt_nblocks = 0;      // 0 = auto
     int opt_tiled = 0;        // force the general-K tiled kernel also for K <= 128
+    int opt_short = -1;       // kernel 1S for 81 ... 144 columns: -1 = systems of at most SHORT_MAX_ROWS rows, 0 = never, 1 = always
     int opt_nsplit = 0;       // row splits of the tiled kernel (0 = auto)
     int opt_device_solve = 0; // 0 = auto (K >= DEVICE_CHOL_MIN_K on the GPU, blocked kernels), 1 = every K (K <= 128: fsnap_chol_solve_k), 2 = never
     // cached launch plan of the tiled kernel (plan_tiled)

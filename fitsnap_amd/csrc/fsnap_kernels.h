@@ -58,6 +58,12 @@ int64_t syrk_quad_max_cpg();
 // a.chunks_per_wave = chunks per cluster, fused packing only)
 int syrk_quad_cluster(int K);
 int64_t syrk_acc_max_fused_cpw();
+// kernel 1S (fsnap_syrk_short.hip; 80 < K <= 144, short systems): a.nblocks = CHUNKS of a.chunks_per_wave ROWS (a multiple of 4),
+// two workgroups per chunk; part[chunk][NT][4][64] | cpart[chunk][NB][16] | spart[chunk][4] (one c / scalar partial per chunk);
+// pairs from a.wpack or (a.fused_pack) formed by the kernel, any chunk length (phases of syrk_short_phase_rows() rows)
+hipError_t launch_syrk_short(const SyrkArgs& a, hipStream_t st);
+bool syrk_short_takes(int K);
+int syrk_short_phase_rows(int K);
 int64_t syrk_wave_p_max_fused_cpw(int K, int wg_per_cu);   // kernel 1P: same for its (smaller, shared) LDS budget
 // mirror: optional page-locked HOST buffer that receives the same packed statistics (zero-copy D2H)
 // accumulate: out += statistics instead of out = statistics

@@ -80,6 +80,10 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * "nsplit" [0 = a scheduling model] row splits of the tiled kernel 1T;
  * "tiled" [0] 1 = the general-K tiled kernel 1T at every width (what short systems of 145 ... 512 columns, K > 512 and the
  *   row-space passes at K > 144 run on by default);
+ * "short" [-1 = systems of 81 ... 144 columns with at most two staging phases of rows per pair of CUs (a phase: 128 rows, 112 at
+ *   129 ... 144 columns -- 28 672 ... 32 768 rows on 256 CUs) take kernel 1S, which deals the tile triangle over 16 waves per row chunk
+ *   instead of giving every wave the whole triangle (13 035 x 142, examples/Ta_PACE_RIDGE)] 0 = never (kernel 1A), 1 = at
+ *   every row count (chunks longer than a phase are staged in several);
  * "quad_min_rows" [-1 = 8 192 rows for 145 ... 288 columns (kernel 1Q), 300 000 for 289 ... 512 (kernel 1QC)] fewest rows for
  *   the accumulator-resident kernels at those widths; shorter systems take the tiled kernel;
  * "fused_pack" [1] kernels 1A / 1P / 1Q / 1QC form the per-row pairs (mask * w, mask * w * b) of their rows in LDS inside the
@@ -489,7 +493,8 @@ int fsnap_timing_count(fsnap_ctx* ctx, int64_t* sampled, int64_t* launches);
  * workgroup (kernel 1L) / per wave (tiled), info[3] = NB (16-column blocks), info[4] =
  * split (kernel 1) or waves per workgroup (kernel 1L), info[5] = compute units of the
  * device, info[6] = kernel id (1 wave-triangle, 2 LDS-shared, 3 one-wave triangle 1A, 4 packed
- * wave-triangle 1P, 5 workgroup triangle 1Q -- info[2] is then chunks per WORKGROUP; tiled:
+ * wave-triangle 1P, 5 workgroup triangle 1Q -- info[2] is then chunks per WORKGROUP; 7 short-system
+ * kernel 1S -- info[0] = row chunks (two workgroups each), info[2] = ROWS per chunk; tiled:
  * superblock pairs), info[7] = row splits (tiled kernel) / 1 when the kernel packs the
  * per-row pairs itself. */
 int fsnap_launch_info(fsnap_ctx* ctx, int64_t* info, int n);

@@ -68,9 +68,18 @@ def test_statistics_all_column_block_shapes(ctx, K):
     w = rng.choice([100.0, 1.0, 1e-8], size=m, p=[0.03, 0.83, 0.14])
     t = rng.random(m) < 0.2
     G, c, s = run_stats(ctx, A, b, w, t)
-    if K > 128:
-        assert ctx.launch_info()["kernel_or_pairs"] == 3
-    stats_close(G, c, s, *orc.normal_eq(A, b, w, t))
+    ref = orc.normal_eq(A, b, w, t)
+    stats_close(G, c, s, *ref)
+    if K > 80:
+        # systems this short run on kernel 1S by default (tests/test_gpu_short.py); kernel 1A on the same rows
+        assert ctx.launch_info()["kernel_or_pairs"] == 7
+        ctx.set_option("short", 0)
+        try:
+            G, c, s = run_stats(ctx, A, b, w, t)
+            assert ctx.launch_info()["kernel_or_pairs"] == 3
+        finally:
+            ctx.set_option("short", -1)
+        stats_close(G, c, s, *ref)
 
 
 # ---------------------------------------------------------------------------------------
@@ -323,8 +332,12 @@ def test_one_wave_triangle_kernel_tiny_and_ragged_row_counts(ctx, m, K):
     b = rng.standard_normal(m)
     w = rng.uniform(0.5, 2.0, m)
     t = rng.random(m) < 0.3
-    G, c, s = run_stats(ctx, A, b, w, t)
-    assert ctx.launch_info()["kernel_or_pairs"] == 3
+    ctx.set_option("short", 0)          # (kernel 1S takes systems this short by default: tests/test_gpu_short.py)
+    try:
+        G, c, s = run_stats(ctx, A, b, w, t)
+        assert ctx.launch_info()["kernel_or_pairs"] == 3
+    finally:
+        ctx.set_option("short", -1)
     stats_close(G, c, s, *orc.normal_eq(A, b, w, t), tol=1e-11)
 
 
@@ -1188,8 +1201,12 @@ def test_one_wave_triangle_kernel_masked_rows_may_hold_garbage(ctx, K):
     A2[t] = np.nan
     b2[t] = np.inf
     w2[t] = -np.inf
-    G, c, s = run_stats(ctx, A2, b2, w2, t)
-    assert ctx.launch_info()["kernel_or_pairs"] == 3
+    ctx.set_option("short", 0)          # (kernel 1S takes systems this short by default: tests/test_gpu_short.py has its own)
+    try:
+        G, c, s = run_stats(ctx, A2, b2, w2, t)
+        assert ctx.launch_info()["kernel_or_pairs"] == 3
+    finally:
+        ctx.set_option("short", -1)
     stats_close(G, c, s, *orc.normal_eq(A, b, w, t))
     assert np.isfinite(G).all() and np.isfinite(c).all() and np.isfinite(s).all()
 
@@ -1208,9 +1225,15 @@ def test_one_wave_triangle_kernel_strided_rows(ctx):
     db = torch.from_numpy(b).to(dev)
     ctx.bind_rows(dbig.data_ptr() + 3 * 8, 9001, 100, 131, db.data_ptr())
     ctx.set_weights(w)
-    G, c, s = ctx.normal_eq()
-    assert ctx.launch_info()["kernel_or_pairs"] == 3
-    stats_close(G, c, s, *orc.normal_eq(A, b, w))
+    ref = orc.normal_eq(A, b, w)
+    for short, kernel in ((0, 3), (-1, 7)):         # kernel 1A, then kernel 1S (the default of a system this short)
+        ctx.set_option("short", short)
+        try:
+            G, c, s = ctx.normal_eq()
+            assert ctx.launch_info()["kernel_or_pairs"] == kernel
+        finally:
+            ctx.set_option("short", -1)
+        stats_close(G, c, s, *ref)
 
 
 @pytest.mark.parametrize("K,m", [(96, 30011), (110, 1772), (128, 250003), (142, 13035), (144, 70001),
@@ -1233,7 +1256,8 @@ def test_fused_packing_gives_the_bits_of_the_packing_kernel(K, m):
         c.set_option("fused_pack", fused)
         got.append(run_stats(c, A, b2, w2, t))
         info = c.launch_info()
-        assert info["kernel_or_pairs"] == (3 if K > 80 else 4) and info["fused_pack"] == fused
+        short = 80 < K <= 144 and m <= (112 if K > 128 else 128) * 256          # kernel 1S's default range on 256 CUs
+        assert info["kernel_or_pairs"] == (7 if short else 3 if K > 80 else 4) and info["fused_pack"] == fused
         stats_close(*got[-1], *ref)
     assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
     assert got[0][2][2] == got[1][2][2]
