@@ -146,7 +146,7 @@ int plan_geometry(fsnap_ctx* ctx, Geometry* g) {
         return FSNAP_OK;
     }
     if (g->NB >= 6 && ctx->opt_short != 0 && (ctx->opt_short == 1 || m <= SHORT_MAX_PHASES * (int64_t)fsnap::syrk_short_phase_rows(K) * (ctx->num_cu / 2)) &&
-        ctx->lda * 8 * (int64_t)128 + 16 <= (int64_t)0xFFFFF000) {
+        ctx->lda * 8 * (int64_t)136 + 16 <= (int64_t)0xFFFFF000) {
         // kernel 1S: chunks of rows staged through LDS, the triangle dealt over the 16 waves of the two workgroups of a chunk
         int64_t want = ctx->opt_nblocks > 0 ? ctx->opt_nblocks : std::max<int64_t>(1, (int64_t)ctx->num_cu / 2);
         int64_t rpc = ((m + want - 1) / want + 3) / 4 * 4;

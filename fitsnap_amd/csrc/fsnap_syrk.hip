@@ -757,24 +757,7 @@ __global__ __launch_bounds__(256) void fsnap_reduce_partials2(const double* __re
                 a3 += x[j + 3];
             }
         }
-        // the rest (all of it when there are fewer than 241 partials: the 68 ... 136 workgroups of a short system, the ~126
-        // chunks of kernel 1S) the same way, the slots past the end read as zeros -- one load after the other it was
-        // np / 16 DEPENDENT round trips: 10 us for the 11.5 MB of 126 partials at 142 columns
-        if (p < np) {
-            d2 x[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int q = p + 16 * j;
-                x[j] = q < np ? *reinterpret_cast<const d2*>(s0 + (int64_t)q * stride) : d2{0.0, 0.0};
-            }
-#pragma unroll
-            for (int j = 0; j < 16; j += 4) {
-                a0 += x[j];
-                a1 += x[j + 1];
-                a2 += x[j + 2];
-                a3 += x[j + 3];
-            }
-        }
+        for (; p < np; p += 16) a0 += *reinterpret_cast<const d2*>(s0 + (int64_t)p * stride);
     }
     const d2 sv = (a0 + a1) + (a2 + a3);
     *reinterpret_cast<d2*>(&red[slice][2 * sub]) = sv;

@@ -378,7 +378,7 @@ static hipError_t launch_syrk_short_nb(const SyrkArgs& a, hipStream_t st) {
 hipError_t launch_syrk_short(const SyrkArgs& a, hipStream_t st) {
     if (a.fused_pack ? (!a.b || !a.w || !a.mask || !a.spart) : !a.wpack) return hipErrorInvalidValue;
     if (a.nblocks < 1 || a.chunks_per_wave < 4 || (a.chunks_per_wave & 3) || a.chunks_per_wave > 0x7FFFFFF0) return hipErrorInvalidValue;
-    if (a.lda * 8 * (int64_t)128 + 16 > (int64_t)0xFFFFF000) return hipErrorInvalidValue;      // 32-bit offsets inside a phase
+    if (a.lda * 8 * (int64_t)136 + 16 > (int64_t)0xFFFFF000) return hipErrorInvalidValue;      // 32-bit offsets inside a phase (the staging loop looks at up to 135 row slots)
     switch (syrk_num_blocks(a.K)) {
         case 6: return launch_syrk_short_nb<6>(a, st);
         case 7: return launch_syrk_short_nb<7>(a, st);

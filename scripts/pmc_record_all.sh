@@ -12,11 +12,16 @@ O=$R/gpurun_out/${TAG}_record
 mkdir -p $O
 export TMPDIR=/tmp
 cd $R
-rm -f profiles/pmc_traffic.json            # the headline record comes first; everything is re-taken
+# FSNAP_PMC_SHAPES="13035 142;28672 142": only these shapes, appended to (or replacing their records in) the existing file --
+# after a change of ONE kernel's source file (kernel 1S lives in fsnap_syrk_short.hip with a digest of its own)
+if [ -z "$FSNAP_PMC_SHAPES" ]; then
+  rm -f profiles/pmc_traffic.json          # the headline record comes first; everything is re-taken
+fi
 # rows K [extra bench flags]
 SHAPES=("1000000 128" "1772880 110" "1772880 142" "367900 480" "500000 368" "1000000 256" "15213 1595" "500000 128 --force-dist"
         "250000 128 --force-dist" "125000 128 --force-dist" "15213 31" "1000000 31" "13035 142" "1772880 168" "367900 288" "100000 168"
         "100000 192" "13035 256" "100000 272")
+if [ -n "$FSNAP_PMC_SHAPES" ]; then IFS=';' read -ra SHAPES <<< "$FSNAP_PMC_SHAPES"; fi
 for s in "${SHAPES[@]}"; do
   read -r rows K extra <<< "$s"
   name=${rows}x${K}
