@@ -40,53 +40,88 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
-// macro-tile (P, Q) of wave slot s = 8 g + wave (g = which of the chunk's two workgroups), -1 = none.  The macro-tiles
-// are sorted by their tile count and dealt over the 8 (workgroup, SIMD) bins in a snake: the first eight to the waves
-// 0 ... 3 of the bins 0 ... 7, the rest to the waves 4 ... 7 of the bins 7 ... 0 (waves w and w + 4 share a SIMD), so a
-// SIMD carries at most 6 of the 45 tiles at NB = 9 (5.6 would be even).
+// Work of wave slot s = 8 g + wave (g = which of the chunk's two workgroups): macro-tile (P, Q) and the MASK of its four
+// products the wave owns -- bit 0: a0 b0 = tile (2P, 2Q), bit 1: a0 b1 = (2P, 2Q + 1), bit 2: a1 b0 = (2P + 1, 2Q), bit 3:
+// a1 b1 = (2P + 1, 2Q + 1); an off-diagonal macro-tile is 1111, a diagonal one 1011 (not the mirror a1 b0), with the zero
+// block of an odd NB 0101 / 0001.  P = -1: none.  The items are sorted by their tile count and dealt over the 8 (workgroup,
+// SIMD) bins in a snake: the first eight to the waves 0 ... 3 of the bins 0 ... 7, the rest to the waves 4 ... 7 of the bins
+// 7 ... 0 (waves w and w + 4 share a SIMD).  NB = 9: 15 items, at most 6 of the 45 tiles on a SIMD (5.6 would be even).
+// When that leaves a bin with two diagonal macro-tiles (NB = 8: ten items, 3 + 3 against 4 everywhere else) the diagonal ones
+// are split into 0011 and 1000 -- 14 items, at most 5 of the 36 tiles on a SIMD; make_slots takes whichever deal has the
+// smaller maximum.
 struct SlotTable {
-    int P[16], Q[16];
+    int P[16], Q[16], M[16];
+    int max_load;
 };
-constexpr SlotTable make_slots(int NB) {
+constexpr int popcount4(int m) { return (m & 1) + ((m >> 1) & 1) + ((m >> 2) & 1) + ((m >> 3) & 1); }
+constexpr SlotTable deal_slots(int NB, bool split_diag) {
     SlotTable t{};
     for (int s = 0; s < 16; ++s) {
         t.P[s] = -1;
         t.Q[s] = -1;
+        t.M[s] = 0;
     }
+    t.max_load = 1 << 20;
     const int np = (NB + 1) / 2;
-    int lp[16] = {}, lq[16] = {}, lc[16] = {};
+    int lp[24] = {}, lq[24] = {}, lm[24] = {};
     int n = 0;
+    auto add = [&](int P, int Q, int mask) {        // insertion by tile count, descending
+        int k = n;
+        while (k > 0 && popcount4(lm[k - 1]) < popcount4(mask)) {
+            lp[k] = lp[k - 1];
+            lq[k] = lq[k - 1];
+            lm[k] = lm[k - 1];
+            --k;
+        }
+        lp[k] = P;
+        lq[k] = Q;
+        lm[k] = mask;
+        ++n;
+    };
     for (int P = 0; P < np; ++P)
         for (int Q = P; Q < np; ++Q) {
             const bool qfull = 2 * Q + 1 < NB;
-            const int cost = (P == Q) ? (qfull ? 3 : 1) : (qfull ? 4 : 2);
-            int k = n;
-            while (k > 0 && lc[k - 1] < cost) {
-                lp[k] = lp[k - 1];
-                lq[k] = lq[k - 1];
-                lc[k] = lc[k - 1];
-                --k;
+            if (P != Q) {
+                add(P, Q, qfull ? 15 : 5);
+            } else if (!qfull) {
+                add(P, Q, 1);
+            } else if (split_diag) {
+                add(P, Q, 3);
+                add(P, Q, 8);
+            } else {
+                add(P, Q, 11);
             }
-            lp[k] = P;
-            lq[k] = Q;
-            lc[k] = cost;
-            ++n;
         }
-    for (int i = 0; i < n && i < 16; ++i) {
+    if (n > 16) return t;
+    int load[8] = {};
+    for (int i = 0; i < n; ++i) {
         const int bin = i < 8 ? i : 15 - i;
         const int g = bin & 1, simd = bin >> 1;
         const int slot = g * 8 + (i < 8 ? simd : 4 + simd);
         t.P[slot] = lp[i];
         t.Q[slot] = lq[i];
+        t.M[slot] = lm[i];
+        load[bin] += popcount4(lm[i]);
     }
+    t.max_load = 0;
+    for (int b = 0; b < 8; ++b)
+        if (load[b] > t.max_load) t.max_load = load[b];
     return t;
+}
+constexpr SlotTable make_slots(int NB) {
+    const SlotTable a = deal_slots(NB, false), b = deal_slots(NB, true);
+    return b.max_load < a.max_load ? b : a;
 }
 
 template <int NB>
 struct ShortSlots {
     static_assert(NB >= 1 && NB <= 9, "at most 15 macro-tiles for the 16 wave slots of a chunk");
     static constexpr SlotTable tab = make_slots(NB);
+    static_assert(tab.max_load <= 6, "a SIMD carries at most 6 tiles");
 };
+static_assert(ShortSlots<9>::tab.max_load == 6 && ShortSlots<8>::tab.max_load == 5 && ShortSlots<7>::tab.max_load == 4 &&
+                  ShortSlots<6>::tab.max_load == 4,
+              "the deals DESIGN 3.1b quotes");
 
 }  // namespace
 
@@ -148,7 +183,7 @@ __global__ __launch_bounds__(SHORT_THREADS) void fsnap_syrk_short(const double* 
     // multiply role
     const int slot = g * 8 + wave;
     const int P = ShortSlots<NB>::tab.P[slot], Q = ShortSlots<NB>::tab.Q[slot];
-    const bool qfull = 2 * Q + 1 < NB;              // (only the last group of an odd NB is not: its second block is the zero block)
+    const int MK = __builtin_amdgcn_readfirstlane(ShortSlots<NB>::tab.M[slot]);      // which of the four products are this wave's
     const double* xp = X + kr * LDW + 32 * (P < 0 ? 0 : P) + 2 * e;
     const double* xq = X + kr * LDW + 32 * (Q < 0 ? 0 : Q) + 2 * e;
     // where the unit lands in the staged row
@@ -259,35 +294,38 @@ __global__ __launch_bounds__(SHORT_THREADS) void fsnap_syrk_short(const double* 
         }
         __syncthreads();
         FSNAP_SHORT_STAMP(2);
-        // 4. the wave's macro-tile over the phase's 4-row steps: a = group P, b = group Q; one v_mfma_f64_16x16x4_f64 is 64
-        // cycles of the SIMD's matrix pipe, so only the tiles that exist are multiplied -- four kinds of macro-tile, four
-        // loops over the same accumulators (acc1 = a0 b1, acc2 = a1 b0, acc3 = a1 b1): off-diagonal 4 products, diagonal 3
-        // (not the mirror a1 b0), with the zero block of an odd NB 2 (b1 = 0) / 1
+        // 4. the wave's products over the phase's 4-row steps: a = group P, b = group Q; one v_mfma_f64_16x16x4_f64 is 64
+        // cycles of the SIMD's matrix pipe, so only the tiles that exist are multiplied -- one loop per mask over the same
+        // accumulators (acc0 = a0 b0, acc1 = a0 b1, acc2 = a1 b0, acc3 = a1 b1)
         const int nstep = nr4 >> 2;
-        auto products = [&](auto kind_tag) {
-            constexpr int KIND = decltype(kind_tag)::value;       // 0 off-diagonal, 1 diagonal, 2 / 3 the same with the zero block
+        auto products = [&](auto mask_tag, auto diag_tag) {
+            constexpr int MASK = decltype(mask_tag)::value;
+            constexpr bool DIAG = decltype(diag_tag)::value;
             for (int s0 = 0; s0 < nstep; s0 += 2) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const int off = (s0 + s) * 4 * LDW;
                     const d2 a = *reinterpret_cast<const d2*>(xp + off);
                     d2 b = a;
-                    if constexpr (KIND == 0 || KIND == 2) b = *reinterpret_cast<const d2*>(xq + off);
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc0, 0, 0, 0);
-                    if constexpr (KIND <= 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[1], acc1, 0, 0, 0);
-                    if constexpr (KIND == 0 || KIND == 2) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[0], acc2, 0, 0, 0);
-                    if constexpr (KIND <= 1) acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc3, 0, 0, 0);
+                    if constexpr (!DIAG) b = *reinterpret_cast<const d2*>(xq + off);
+                    if constexpr (MASK & 1) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc0, 0, 0, 0);
+                    if constexpr (MASK & 2) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[1], acc1, 0, 0, 0);
+                    if constexpr (MASK & 4) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[0], acc2, 0, 0, 0);
+                    if constexpr (MASK & 8) acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc3, 0, 0, 0);
                 }
             }
         };
-        if (P >= 0) {
-            if (qfull) {
-                if (P != Q) products(std::integral_constant<int, 0>{});
-                else products(std::integral_constant<int, 1>{});
-            } else {
-                if (P != Q) products(std::integral_constant<int, 2>{});
-                else products(std::integral_constant<int, 3>{});
-            }
+        using std::integral_constant;
+        using std::false_type;
+        using std::true_type;
+        switch (P >= 0 ? MK : 0) {
+            case 15: products(integral_constant<int, 15>{}, false_type{}); break;
+            case 5: products(integral_constant<int, 5>{}, false_type{}); break;
+            case 11: products(integral_constant<int, 11>{}, true_type{}); break;
+            case 3: products(integral_constant<int, 3>{}, true_type{}); break;
+            case 8: products(integral_constant<int, 8>{}, true_type{}); break;
+            case 1: products(integral_constant<int, 1>{}, true_type{}); break;
+            default: break;
         }
         __syncthreads();        // the next phase (or the c fold) overwrites X and PK
         FSNAP_SHORT_STAMP(3);
@@ -299,22 +337,14 @@ __global__ __launch_bounds__(SHORT_THREADS) void fsnap_syrk_short(const double* 
         auto store = [&](int p, int q, const d4& v) {
             double* t = pw + tri_index(p, q, NB) * 256 + lane;
 #pragma unroll
+            // (plain stores: nontemporal ones take 1 us off this launch -- 12.7 -> 11.7 us back to back, nothing dirty in L2 at
+            // the kernel's end -- and put 1.5 ... 2.4 us on kernel 2b, which then reads the partial tiles from memory)
             for (int i = 0; i < 4; ++i) t[i * 64] = v[i];
         };
-        if (P != Q) {
-            store(2 * P, 2 * Q, acc0);
-            store(2 * P + 1, 2 * Q, acc2);
-            if (qfull) {
-                store(2 * P, 2 * Q + 1, acc1);
-                store(2 * P + 1, 2 * Q + 1, acc3);
-            }
-        } else {
-            store(2 * P, 2 * P, acc0);
-            if (qfull) {
-                store(2 * P, 2 * P + 1, acc1);
-                store(2 * P + 1, 2 * P + 1, acc3);
-            }
-        }
+        if (MK & 1) store(2 * P, 2 * Q, acc0);
+        if (MK & 2) store(2 * P, 2 * Q + 1, acc1);
+        if (MK & 4) store(2 * P + 1, 2 * Q, acc2);
+        if (MK & 8) store(2 * P + 1, 2 * Q + 1, acc3);
     }
     FSNAP_SHORT_STAMP(4);
     if (g != 0) return;
