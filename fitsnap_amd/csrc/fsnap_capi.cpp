@@ -81,9 +81,10 @@ constexpr int64_t QUAD_MIN_CPG = 24;        // fewest 4-row chunks per workgroup
 // widest system the accumulator-resident kernel 1A takes (NB = 9 column blocks: the ACE width 142 of examples/Ta_PACE_RIDGE)
 constexpr int64_t ACC_MAX_K = 144;
 // longest system kernel 1S takes by default, in staging phases (128 rows, 112 at NB = 9) per workgroup with half the CUs' worth of
-// chunks (two workgroups share a chunk): 28 672 ... 32 768 rows on 256 CUs.  Measured (profiles/r06_short_kernel.txt, kernel us,
-// 1S | 1A): 13 035 x 142 19.6 | 31.7, 20 000 x 142 24.6 | 34.4, 28 672 x 142 28.0 | 35.7, 40 000 x 142 36.4 | 37.3, 60 000 x 142 51.8 | 41.5
-constexpr int64_t SHORT_MAX_PHASES = 2;
+// chunks (two workgroups share a chunk): 43 008 ... 49 152 rows on 256 CUs.  Measured (profiles/r06_short_kernel.txt, kernel us,
+// 1S | 1A): 13 035 x 142 18.3 | 32.1, 20 000 x 142 22.9 | 35.1, 28 672 x 142 25.2 | 36.7, 40 000 x 142 32.0 | 37.0 (x 128: 27.7 | 32.3,
+// x 96: 23.3 | 22.8), 60 000 x 142 43.5 | 41.3, 125 000 x 128 62.4 | 55.2
+constexpr int64_t SHORT_MAX_PHASES = 3;
 constexpr int64_t SHORT_MIN_CHUNK_ROWS = 32;
 constexpr int64_t ACC_MIN_CPW = 12;         // kernel 1A: fewest 4-row chunks per row-wave before its grid shrinks below one workgroup per CU
 // kernel 1QC (289 ... 512 columns on clusters of workgroups) against the tiled kernel, round 5 (profiles/r05_quadc_ab.txt):

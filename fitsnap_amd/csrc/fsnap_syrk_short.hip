@@ -138,7 +138,10 @@ __device__ unsigned long long fsnap_short_trace[1024 * 8];
 
 // grid: 16 x ceil(nchunk / 8) workgroups; workgroup bid serves chunk (bid & 7) + 8 (bid >> 4) as member g = (bid >> 3) & 1:
 // consecutive workgroup ids go round the 8 XCDs, so both members of a chunk share an L2
-template <int NB>
+// WPACK: the per-row pairs come from `wpack` (fsnap_pack_weights_k's array, or the pairs of a row-space pass) instead of being
+// formed from b, w and the mask -- a compile-time switch: a run-time one put a join (and a wait for the loads in flight) between
+// the loads of the next phase and the products of this one
+template <int NB, bool WPACK>
 __global__ __launch_bounds__(SHORT_THREADS) void fsnap_syrk_short(const double* __restrict__ A, int64_t lda,
                                                                    const double* __restrict__ wpack,
                                                                    const double* __restrict__ bvec,
@@ -202,41 +205,44 @@ __global__ __launch_bounds__(SHORT_THREADS) void fsnap_syrk_short(const double* 
     d2 cacc = {0.0, 0.0};
     double bb = 0.0, sb = 0.0, cnt = 0.0;
 
+    // The loads of a phase: its per-row pairs (w_eff, w_eff b) FIRST (vmcnt retires in order: behind the rows they would be
+    // seen only when every row has arrived), the three of a row side by side, not behind the mask's branch; then every row
+    // of the phase (16 bytes past the last row may be read: fsnap_hip.h's padding rule).  Every thread loads -- the ones
+    // without a row of their own row 0 of the phase, the non-stagers out of range -- so that the code up to the barrier is one
+    // straight line and the compiler's wait for the pairs is vmcnt(ITER), not vmcnt(0).  The row step is the instruction's
+    // scalar offset; rows past nr are out of the descriptor's range and read zeros (the first 16 bytes behind it excepted --
+    // those meet a (0, 0) pair).
+    // The loads of phase p + 1 go out BEFORE the products of phase p (the rows wait in the 64 registers of `raw`), so a
+    // chunk of several phases pays the HBM round trip once: stage | load next, multiply | stage | ...
+    unsigned char mk = 0;
+    double wr = 0.0, br = 0.0;
+    d2 pv = {0.0, 0.0};
+    u4 raw[ITER];
+    auto issue_loads = [&](int64_t ph0) {
+        const int nr = (int)(row1 - ph0 < SHORT_RP ? row1 - ph0 : SHORT_RP);
+        const int64_t row = ph0 + (tid < nr ? tid : 0);
+        if constexpr (WPACK) {
+            pv = *reinterpret_cast<const d2*>(wpack + 2 * row);
+        } else {
+            mk = mask[row];
+            wr = wvec[row];
+            br = bvec[row];
+        }
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc(A + ph0 * lda, (unsigned)((int64_t)nr * lda * 8 + 16));
+        const unsigned voff = stager ? (unsigned)(((int64_t)rg * lda + 2 * u) * 8) : 0xFFFFF000u;
+        const unsigned rstep = (unsigned)(lda * 8 * RG);
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) raw[it] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff, (unsigned)it * rstep, 0);
+    };
+    issue_loads(row0);
+
     for (int64_t ph0 = row0; ph0 < row1; ph0 += SHORT_RP) {
         const int nr = (int)(row1 - ph0 < SHORT_RP ? row1 - ph0 : SHORT_RP);
         const int nr4 = (nr + 7) & ~7;         // whole pairs of 4-row steps: the rows behind the last one are staged as zeros
-        // 1. the loads of the per-row pairs (w_eff, w_eff b) go out FIRST (vmcnt retires in order: behind the rows they would be
-        // seen only when every row has arrived), the three of a row side by side, not behind the mask's branch
-        // (every thread loads -- the ones without a row of their own row 0 of the phase, the non-stagers out of range -- so that
-        // the code up to the barrier is one straight line and the compiler's wait for the pairs is vmcnt(ITER), not vmcnt(0))
-        unsigned char mk = 0;
-        double wr = 0.0, br = 0.0;
-        d2 pv = {0.0, 0.0};
-        {
-            const int64_t row = ph0 + (tid < nr ? tid : 0);
-            if (wpack) {
-                pv = *reinterpret_cast<const d2*>(wpack + 2 * row);
-            } else {
-                mk = mask[row];
-                wr = wvec[row];
-                br = bvec[row];
-            }
-        }
-        // 2. every row of the phase on its way (16 bytes past the last row may be read: fsnap_hip.h's padding rule).  The row
-        // step is the instruction's scalar offset; rows past nr are out of the descriptor's range and read zeros (the first
-        // 16 bytes behind it excepted -- those meet a (0, 0) pair).
-        const __amdgpu_buffer_rsrc_t ra = make_rsrc(A + ph0 * lda, (unsigned)((int64_t)nr * lda * 8 + 16));
-        u4 raw[ITER];
-        {
-            const unsigned voff = stager ? (unsigned)(((int64_t)rg * lda + 2 * u) * 8) : 0xFFFFF000u;
-            const unsigned rstep = (unsigned)(lda * 8 * RG);
-#pragma unroll
-            for (int it = 0; it < ITER; ++it) raw[it] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff, (unsigned)it * rstep, 0);
-        }
         // the pairs into LDS while the rows are still in flight
         if (tid < SHORT_RP) {
             d2 pr = {0.0, 0.0};
-            if (wpack) {
+            if constexpr (WPACK) {
                 if (tid < nr) pr = pv;
             } else {
                 const bool keep = tid < nr && mk != 0;
@@ -278,10 +284,14 @@ __global__ __launch_bounds__(SHORT_THREADS) void fsnap_syrk_short(const double* 
                         x[0] = (keep && col0) ? pr[0] * a[0] : 0.0;
                         x[1] = (keep && col1) ? pr[0] * a[1] : 0.0;
                         if ((it + 1) * RG <= SHORT_RP || row < SHORT_RP) {
-                            // two 8-byte stores, xdx apart (1; 2 in the last block of an odd NB): no branch, same LDS cycles as one 16-byte store
                             double* xr = X + row * LDW + xcol;
-                            xr[0] = x[0];
-                            xr[xdx] = x[1];
+                            if constexpr (NB & 1) {
+                                // two 8-byte stores, xdx apart (1; 2 in the last block of an odd NB): no branch
+                                xr[0] = x[0];
+                                xr[xdx] = x[1];
+                            } else {
+                                *reinterpret_cast<d2*>(xr) = x;      // (8-byte stores 16 bytes apart meet two to a bank)
+                            }
                         }
                         if (g == 0) {
                             cacc[0] = __builtin_fma(x[0], pr[1], cacc[0]);
@@ -294,6 +304,7 @@ __global__ __launch_bounds__(SHORT_THREADS) void fsnap_syrk_short(const double* 
         }
         __syncthreads();
         FSNAP_SHORT_STAMP(2);
+        if (ph0 + SHORT_RP < row1) issue_loads(ph0 + SHORT_RP);       // the next phase's rows travel while this one is multiplied
         // 4. the wave's products over the phase's 4-row steps: a = group P, b = group Q; one v_mfma_f64_16x16x4_f64 is 64
         // cycles of the SIMD's matrix pipe, so only the tiles that exist are multiplied -- one loop per mask over the same
         // accumulators (acc0 = a0 b0, acc1 = a0 b1, acc2 = a1 b0, acc3 = a1 b1)
@@ -352,7 +363,7 @@ __global__ __launch_bounds__(SHORT_THREADS) void fsnap_syrk_short(const double* 
     // c: the RG row groups in a fixed order; column 2u + h of the matrix is element (p, e) of kernel 1A's interleave
     constexpr int LDC = 16 * NB;
     if (stager) *reinterpret_cast<d2*>(X + rg * LDC + 2 * u) = cacc;
-    if (!wpack && tid < 128) {                     // waves 0 and 1 in full (the threads past SHORT_RP bring zeros)
+    if (!WPACK && tid < 128) {                     // waves 0 and 1 in full (the threads past SHORT_RP bring zeros)
 #pragma unroll
         for (int sh = 1; sh < 64; sh <<= 1) {       // fixed butterfly: deterministic
             bb += __shfl_xor(bb, sh, 64);
@@ -380,7 +391,7 @@ __global__ __launch_bounds__(SHORT_THREADS) void fsnap_syrk_short(const double* 
         }
         cpart[(int64_t)chunk * (NB * 16) + p * 16 + el] = s;
     }
-    if (!wpack && tid == 0) {
+    if (!WPACK && tid == 0) {
         double* so = spart + (int64_t)chunk * 4;
         so[0] = bb + PK[0];
         so[1] = sb + PK[1];
@@ -398,8 +409,12 @@ template <int NB>
 static hipError_t launch_syrk_short_nb(const SyrkArgs& a, hipStream_t st) {
     const int nchunk = a.nblocks;
     dim3 grid((unsigned)(16 * ((nchunk + 7) / 8))), block(SHORT_THREADS);
-    hipLaunchKernelGGL((fsnap_syrk_short<NB>), grid, block, 0, st, a.A, a.lda, a.fused_pack ? nullptr : a.wpack, a.b, a.w, a.mask,
-                       a.m, a.K, (int)a.chunks_per_wave, nchunk, a.part, a.cpart, a.spart);
+    if (a.fused_pack)
+        hipLaunchKernelGGL((fsnap_syrk_short<NB, false>), grid, block, 0, st, a.A, a.lda, nullptr, a.b, a.w, a.mask, a.m, a.K,
+                           (int)a.chunks_per_wave, nchunk, a.part, a.cpart, a.spart);
+    else
+        hipLaunchKernelGGL((fsnap_syrk_short<NB, true>), grid, block, 0, st, a.A, a.lda, a.wpack, a.b, a.w, a.mask, a.m, a.K,
+                           (int)a.chunks_per_wave, nchunk, a.part, a.cpart, a.spart);
     return hipGetLastError();
 }
 

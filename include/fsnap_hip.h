@@ -80,8 +80,8 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  * "nsplit" [0 = a scheduling model] row splits of the tiled kernel 1T;
  * "tiled" [0] 1 = the general-K tiled kernel 1T at every width (what short systems of 145 ... 512 columns, K > 512 and the
  *   row-space passes at K > 144 run on by default);
- * "short" [-1 = systems of 81 ... 144 columns with at most two staging phases of rows per pair of CUs (a phase: 128 rows, 112 at
- *   129 ... 144 columns -- 28 672 ... 32 768 rows on 256 CUs) take kernel 1S, which deals the tile triangle over 16 waves per row chunk
+ * "short" [-1 = systems of 81 ... 144 columns with at most three staging phases of rows per pair of CUs (a phase: 128 rows, 112 at
+ *   129 ... 144 columns -- 43 008 ... 49 152 rows on 256 CUs) take kernel 1S, which deals the tile triangle over 16 waves per row chunk
  *   instead of giving every wave the whole triangle (13 035 x 142, examples/Ta_PACE_RIDGE)] 0 = never (kernel 1A), 1 = at
  *   every row count (chunks longer than a phase are staged in several);
  * "quad_min_rows" [-1 = 8 192 rows for 145 ... 288 columns (kernel 1Q), 300 000 for 289 ... 512 (kernel 1QC)] fewest rows for

@@ -10,14 +10,16 @@ import json,sys
 d=json.loads('''$out'''); r=d['roofline']
 print('$rows x $K', ' '.join('$*'.split()), '| fit', round(d['ms_per_step']*1e3,1), 'us kernel', round(r['kernel_ms_avg']*1e3,1), 'us reduce', round(r['reduce_kernel_ms_avg']*1e3,1), 'us', r['kernel'], 'wg', d['config']['launch']['workgroups'], 'rows/chunk', d['config']['launch']['chunks_per_wave'])"
 }
-for shape in "13035 142" "13035 128" "13035 110" "13035 96" "8000 142" "4000 142" "14336 142" "16384 128"; do
+[ "$1" = "long" ] || for shape in "13035 142" "13035 128" "13035 110" "13035 96" "8000 142" "4000 142" "14336 142" "16384 128"; do
   run $shape
   run $shape --option short=0
 done
-# past the default range: two and more phases per workgroup against kernel 1A
-for rows in 20000 28672 40000 60000; do
-  run $rows 142 --option short=1
-  run $rows 142
-  run $rows 128 --option short=1
-  run $rows 128
+# longer systems: several phases per workgroup (the next phase's rows are loaded while this one is multiplied) against kernel 1A
+if [ "$1" = "long" ]; then
+for rows in 20000 28672 40000 60000 100000 125000 250000; do
+  for K in 142 128 110 96; do
+    run $rows $K --option short=1
+    run $rows $K --option short=0
+  done
 done
+fi

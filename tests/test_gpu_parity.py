@@ -1256,7 +1256,7 @@ def test_fused_packing_gives_the_bits_of_the_packing_kernel(K, m):
         c.set_option("fused_pack", fused)
         got.append(run_stats(c, A, b2, w2, t))
         info = c.launch_info()
-        short = 80 < K <= 144 and m <= (112 if K > 128 else 128) * 256          # kernel 1S's default range on 256 CUs
+        short = 80 < K <= 144 and m <= (112 if K > 128 else 128) * 384          # kernel 1S's default range on 256 CUs
         assert info["kernel_or_pairs"] == (7 if short else 3 if K > 80 else 4) and info["fused_pack"] == fused
         stats_close(*got[-1], *ref)
     assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])

@@ -42,10 +42,10 @@ def test_short_kernel_statistics_all_column_block_shapes(ctx, K):
     stats_close(G, c, s, *orc.normal_eq(A, b, w, t))
 
 
-@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 15, 16, 17, 31, 33, 111, 112, 113, 127, 128, 129, 1000, 14336, 14337, 28672])
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 15, 16, 17, 31, 33, 111, 112, 113, 127, 128, 129, 1000, 14336, 14337, 28672, 28673, 43008])
 @pytest.mark.parametrize("K", [96, 110, 142])
 def test_short_kernel_tiny_and_ragged_row_counts(ctx, m, K):
-    # one chunk of a few rows, chunks that end inside a 16-row group of steps, a full phase, the first system of two phases, the
+    # one chunk of a few rows, chunks that end inside an 8-row pair of steps, a full phase, the first systems of two and three phases, the
     # longest default system at 142 columns
     A, b, w, t = problem(m, K, 7000 + 13 * m + K)
     G, c, s = run_stats(ctx, A, b, w, t)
