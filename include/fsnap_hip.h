@@ -76,7 +76,7 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
 /* Options (all optional; defaults in brackets).  Every key steers a path a default configuration can take -- the A/B forms
  * of rounds 1-5 that lost their measurements (kernels 1 / 1L / 1T2, Cholesky forms 0-4, reduce-to-root fits, ...) are gone,
  * their records are in profiles/ and HISTORY.md:
- * "nblocks" [0 = auto] workgroups of the SYRK kernels 1A / 1P / 1Q (clusters of 1QC);
+ * "nblocks" [0 = auto] workgroups of the SYRK kernels 1A / 1P / 1Q (clusters of 1QC, row chunks of 1S);
  * "nsplit" [0 = a scheduling model] row splits of the tiled kernel 1T;
  * "tiled" [0] 1 = the general-K tiled kernel 1T at every width (what short systems of 145 ... 512 columns, K > 512 and the
  *   row-space passes at K > 144 run on by default);
@@ -86,7 +86,7 @@ int fsnap_ctx_use_own_stream(fsnap_ctx* ctx);
  *   every row count (chunks longer than a phase are staged in several);
  * "quad_min_rows" [-1 = 8 192 rows for 145 ... 288 columns (kernel 1Q), 300 000 for 289 ... 512 (kernel 1QC)] fewest rows for
  *   the accumulator-resident kernels at those widths; shorter systems take the tiled kernel;
- * "fused_pack" [1] kernels 1A / 1P / 1Q / 1QC form the per-row pairs (mask * w, mask * w * b) of their rows in LDS inside the
+ * "fused_pack" [1] kernels 1A / 1S / 1P / 1Q / 1QC form the per-row pairs (mask * w, mask * w * b) of their rows in LDS inside the
  *   SYRK launch whenever a workgroup's rows fit; 0 = always the separate packing kernel (the form of larger shards and of the
  *   row-space passes);
  * "repack" [0] 1 = recompute the per-row pairs and the b-only scalars on EVERY fit even when b, w and the mask are
