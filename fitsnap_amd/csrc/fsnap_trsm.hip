@@ -38,6 +38,18 @@ __device__ __forceinline__ void trsm_static_for(F&& f) {
     trsm_static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
+#ifdef FSNAP_TRSM_TRACE
+// tools/trsm_trace.hip only: wall-clock stamps (100 MHz) per row tile of kernel 13C: 0 entry, 1 + 5 P panel P loaded / weighted
+// and its left-looking updates done, 2 + 5 P + J block J of panel P done, 15 exit
+__device__ unsigned long long fsnap_trsm_trace[8192 * 16];
+#define FSNAP_TRSM_STAMP(i)                                                                                  \
+    do {                                                                                                     \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) fsnap_trsm_trace[blockIdx.x * 16 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define FSNAP_TRSM_STAMP(i)
+#endif
+
 // Kernel 13C (round 5; K <= 128): kernel 13A's pass with TWO waves per SIMD.  Kernel 13A keeps a wave's whole 64 x K tile in
 // the accumulation registers -- one wave per SIMD, and of the 48 us a tile takes only 12 are matrix pipe and 13 the VALU
 // substitution: the rest are LDS hand-overs, the staging of R and the tile load with nothing else on the SIMD to run
@@ -65,6 +77,7 @@ __global__ __launch_bounds__(64, 2) void fsnap_trsm_acc2_k(const double* __restr
     __shared__ double Wl[64];                     // first pass: the row weights of the tile
     const int lane = threadIdx.x, e = lane & 15, g = lane >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * 64;
+    FSNAP_TRSM_STAMP(0);
     if constexpr (FIRST) {
         Wl[lane] = (row0 + lane < m) ? wpack[2 * (row0 + lane)] : 0.0;
         trsm_wave_sync();
@@ -130,21 +143,28 @@ __global__ __launch_bounds__(64, 2) void fsnap_trsm_acc2_k(const double* __restr
                         qb[t] = (d2u){0.0, 0.0};
                     }
                 }
+                // every B operand of the block row requested before the first product: taken one k-step at a time (4 loads, 16
+                // products, 4 loads, ...) the loop waited for an L2 round trip per k-step (tools/trsm_trace.hip: 30 -> 26 us of a
+                // tile's 92 in this loop at K = 128; the pass 0.604 -> 0.595 ms in place, 0.740 -> 0.702 ms first pass)
+                double bf[4][NBP];
+#pragma unroll
+                for (int sk = 0; sk < 4; ++sk)
+#pragma unroll
+                    for (int jb = 0; jb < NBP; ++jb) bf[sk][jb] = R[(size_t)(kb * 16 + 4 * g + sk) * K16 + (4 * P + jb) * 16 + e];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int sk = 0; sk < 4; ++sk) {
-                    double bf[NBP];
-#pragma unroll
-                    for (int jb = 0; jb < NBP; ++jb) bf[jb] = R[(size_t)(kb * 16 + 4 * g + sk) * K16 + (4 * P + jb) * 16 + e];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const double af = -((sk < 2) ? qa[t][sk & 1] : qb[t][sk & 1]);
 #pragma unroll
                         for (int jb = 0; jb < NBP; ++jb)
-                            acc[jb][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf[jb], acc[jb][t], 0, 0, 0);
+                            acc[jb][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf[sk][jb], acc[jb][t], 0, 0, 0);
                     }
                 }
             }
         }
+        FSNAP_TRSM_STAMP(1 + 5 * P);
         // right-looking inside the panel
         trsm_static_for<NBP>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
@@ -206,10 +226,12 @@ __global__ __launch_bounds__(64, 2) void fsnap_trsm_acc2_k(const double* __restr
                             acc[L][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t][sk], bfu[L - J - 1][sk], acc[L][t], 0, 0, 0);
             }
             trsm_wave_sync();    // X and Rd are reused by the next block
+            FSNAP_TRSM_STAMP(2 + 5 * P + J);
         });
         // the panel's stores must have landed before the next panel reads them back as operands (same wave, same addresses)
         if constexpr (P + 1 < NP) __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
     });
+    FSNAP_TRSM_STAMP(15);
 }
 
 // Kernel 13B (K > 128, the default there): the pass in PANELS of 128 columns with a 16 TR x 128 row tile per wave in the
