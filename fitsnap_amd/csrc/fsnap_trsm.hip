@@ -106,8 +106,10 @@ __global__ __launch_bounds__(64, 2) void fsnap_trsm_acc2_k(const double* __restr
                         const int col = (4 * P + jb) * 16 + e;
                         const u2 raw = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + (unsigned)((4 * P + jb) * 128), 0, 0);
                         const double x = __builtin_bit_cast(double, raw);
-                        // (a column >= K of the last block lies in the NEXT row when lda == K: selected away, not masked by the descriptor)
-                        acc[jb][t][v] = (col < K) ? x : 0.0;
+                        // (a column >= K of the LAST block lies in the NEXT row when lda == K: selected away, not masked by the
+                        // descriptor; every other block is inside the K columns by the definition of NB)
+                        if (4 * P + jb == NB - 1) acc[jb][t][v] = (col < K) ? x : 0.0;      // (compile-time after unrolling)
+                        else acc[jb][t][v] = x;
                     }
                 }
         }
@@ -132,15 +134,25 @@ __global__ __launch_bounds__(64, 2) void fsnap_trsm_acc2_k(const double* __restr
                 // A operand (Q)[i = e][k]: k-step s of lane group g takes column 4 g + s of the block (kernel 13's pairing:
                 // four adjacent doubles of the lane's row, two 16-byte loads); B operand R[16 kb + 4 g + s][column]
                 d2u qa[4], qb[4];
+                if (row0 + 64 <= m) {              // (a tile inside the matrix: no row guards -- wave-uniform)
+                    const double* p0 = Q + (row0 + e) * ldq + kb * 16 + 4 * g;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int64_t r = row0 + t * 16 + e;
-                    const double* p = Q + (r < m ? r : 0) * ldq + kb * 16 + 4 * g;
-                    qa[t] = *reinterpret_cast<const d2u*>(p);
-                    qb[t] = *reinterpret_cast<const d2u*>(p + 2);
-                    if (r >= m) {
-                        qa[t] = (d2u){0.0, 0.0};
-                        qb[t] = (d2u){0.0, 0.0};
+                    for (int t = 0; t < 4; ++t) {
+                        const double* p = p0 + (int64_t)(t * 16) * ldq;
+                        qa[t] = *reinterpret_cast<const d2u*>(p);
+                        qb[t] = *reinterpret_cast<const d2u*>(p + 2);
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int64_t r = row0 + t * 16 + e;
+                        const double* p = Q + (r < m ? r : 0) * ldq + kb * 16 + 4 * g;
+                        qa[t] = *reinterpret_cast<const d2u*>(p);
+                        qb[t] = *reinterpret_cast<const d2u*>(p + 2);
+                        if (r >= m) {
+                            qa[t] = (d2u){0.0, 0.0};
+                            qb[t] = (d2u){0.0, 0.0};
+                        }
                     }
                 }
                 // every B operand of the block row requested before the first product: taken one k-step at a time (4 loads, 16
@@ -183,8 +195,10 @@ __global__ __launch_bounds__(64, 2) void fsnap_trsm_acc2_k(const double* __restr
 #pragma unroll
             for (int v = 0; v < 4; ++v) Rd[g + 4 * v][e] = R[(size_t)(JG * 16 + g + 4 * v) * K16 + JG * 16 + e];
             trsm_wave_sync();
-            if (lane < 16) Rinv[lane] = 1.0 / Rd[lane][lane];
+            if (lane < 16) Rinv[lane] = 1.0 / Rd[lane][lane];      // (the reciprocals the host left on the diagonal of the block's
+                                                                   // inverse, loaded instead: one more L2 round trip per block, 3 % slower)
             trsm_wave_sync();
+            const bool fast = row0 + 64 <= m && (JG < NB - 1 || JG * 16 + 16 <= K);      // wave-uniform
             {
                 double x[16];
 #pragma unroll
@@ -200,16 +214,29 @@ __global__ __launch_bounds__(64, 2) void fsnap_trsm_acc2_k(const double* __restr
                 for (int j = 0; j < 16; ++j) X[lane][j] = x[j];
             }
             trsm_wave_sync();
-            // the solved block: out to Q in the accumulator layout, and as the A operand of the updates inside the panel
+            // the solved block: out to Q in the accumulator layout (16 lanes = 128 contiguous bytes of a row; the lane's own row
+            // straight from the registers -- eight 16-byte stores to 64 different rows per instruction -- measured 16 % slower),
+            // and as the A operand of the updates inside the panel
             {
                 const int col = JG * 16 + e;
+                // (a tile inside the matrix and a block inside its K columns -- every tile but the last, every block but maybe
+                // the last: one wave-uniform branch -- stores without the 16 row / column guards and their exec-mask branches:
+                // the pass 0.595 -> 0.55 ms in place, 0.70 -> 0.56 ms first pass at 10^6 x 128)
+                if (fast) {
+                    double* qb0 = Q + (row0 + g) * ldq + col;
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                    for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int64_t r = row0 + t * 16 + g + 4 * v;
-                        if (r < m && col < K) Q[r * ldq + col] = X[t * 16 + g + 4 * v][e];
-                    }
+                        for (int v = 0; v < 4; ++v) qb0[(int64_t)(t * 16 + 4 * v) * ldq] = X[t * 16 + g + 4 * v][e];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int64_t r = row0 + t * 16 + g + 4 * v;
+                            if (r < m && col < K) Q[r * ldq + col] = X[t * 16 + g + 4 * v][e];
+                        }
+                }
             }
             if constexpr (J + 1 < NBP) {
                 double af[4][4];
