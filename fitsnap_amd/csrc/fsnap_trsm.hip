@@ -195,14 +195,19 @@ __global__ __launch_bounds__(64, 2) void fsnap_trsm_acc2_k(const double* __restr
 #pragma unroll
             for (int v = 0; v < 4; ++v) Rd[g + 4 * v][e] = R[(size_t)(JG * 16 + g + 4 * v) * K16 + JG * 16 + e];
             trsm_wave_sync();
+            if constexpr (P == 0 && J == 1) FSNAP_TRSM_STAMP(11);
             if (lane < 16) Rinv[lane] = 1.0 / Rd[lane][lane];      // (the reciprocals the host left on the diagonal of the block's
                                                                    // inverse, loaded instead: one more L2 round trip per block, 3 % slower)
             trsm_wave_sync();
+            if constexpr (P == 0 && J == 1) FSNAP_TRSM_STAMP(12);
             const bool fast = row0 + 64 <= m && (JG < NB - 1 || JG * 16 + 16 <= K);      // wave-uniform
             {
                 double x[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) x[j] = X[lane][j];
+                // (R_JJ and the reciprocals from uniform addresses -- scalar loads, SGPR operands, no LDS read in the chain of the 16
+                // steps -- made this block's substitution 3.3 -> 2.4 us and the pass 7 % SLOWER: the scalar loads' waits drain the LDS
+                // queue and R does not fit the scalar cache; profiles/r06_trsm_trace.txt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const double q = x[i] * Rinv[i];
@@ -214,6 +219,7 @@ __global__ __launch_bounds__(64, 2) void fsnap_trsm_acc2_k(const double* __restr
                 for (int j = 0; j < 16; ++j) X[lane][j] = x[j];
             }
             trsm_wave_sync();
+            if constexpr (P == 0 && J == 1) FSNAP_TRSM_STAMP(13);
             // the solved block: out to Q in the accumulator layout (16 lanes = 128 contiguous bytes of a row; the lane's own row
             // straight from the registers -- eight 16-byte stores to 64 different rows per instruction -- measured 16 % slower),
             // and as the A operand of the updates inside the panel
@@ -244,6 +250,7 @@ __global__ __launch_bounds__(64, 2) void fsnap_trsm_acc2_k(const double* __restr
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int sk = 0; sk < 4; ++sk) af[t][sk] = -X[t * 16 + e][4 * sk + g];
+                if constexpr (P == 0 && J == 1) FSNAP_TRSM_STAMP(14);
 #pragma unroll
                 for (int L = J + 1; L < NBP; ++L)
 #pragma unroll
@@ -651,6 +658,8 @@ hipError_t launch_trsm_rows(const double* src, int64_t lds, const double* wpack,
     // K <= 128: kernel 13C (64-column panels, two waves per SIMD) for every pass.  tools/trsm_check, 10^6 rows, round 5 (kernel 13A,
     // one wave per SIMD with the whole 64 x K tile -- gone since -- / 13C, ms): in-place passes K = 128 0.737 / 0.590, 110 0.642 / 0.535,
     // 96 0.517 / 0.383, 64 0.249 / 0.201, 31 0.135 / 0.108; first pass 128 0.765 / 0.709, 110 0.690 / 0.701, 96 0.546 / 0.479
+    // Round 6 (unguarded loads / stores of tiles inside the matrix, B operands of a left-looking block row at once): in place 128
+    // 0.524, 110 0.52 ... 0.53, 96 0.385; first pass 128 0.54 ... 0.55, 96 0.38 ... 0.40 (profiles/r06_trsm_trace.txt)
     if (K16 <= 128) {
         const dim3 grid((unsigned)nb), block(64);
 #define FSNAP_TRSM_ACC2(NBV)                                                                                                 \

@@ -79,5 +79,17 @@ int main(int argc, char** argv) {
         else printf("  -> block %d of panel %d done                  %7.2f us (max %.2f)\n", (i - 2) % 5, (i - 2) / 5, av, mx);
     }
     printf("  entry -> exit of a tile, average %.2f us\n", total);
+    if (NB >= 3) {
+        // inside block 1 of panel 0: stamps 2 (block 0 done) -> 11 (block and R_JJ in LDS) -> 12 (reciprocals) -> 13 (substitution,
+        // solved block back in LDS) -> 14 (stores issued, A operands read) -> 3 (updates done)
+        const int seq[6] = {2, 11, 12, 13, 14, 3};
+        const char* nm[5] = {"block + R_JJ into LDS (waits for R_JJ from L2)", "reciprocals of the diagonal", "substitution + block back to LDS",
+                             "stores issued, A operands read", "updates (32 MFMAs)"};
+        for (int k = 0; k < 5; ++k) {
+            double av = 0;
+            for (int t = 0; t < ntile; ++t) av += (double)(tr[t * 16 + seq[k + 1]] - tr[t * 16 + seq[k]]) * 0.01;
+            printf("     block 1 of panel 0: %-50s %6.2f us\n", nm[k], av / ntile);
+        }
+    }
     return 0;
 }
