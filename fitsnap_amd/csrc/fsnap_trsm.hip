@@ -10,7 +10,7 @@
 //
 // Every pass: Q_J = S_J R_JJ^-1 by TRUE substitution (not a multiplication by an inverse: the backward error has to stay
 // ~eps |R|, that is what makes A_w = Q R_hat hold), the updates S_L -= Q_J R_JL on the fp64 matrix pipe; m K^2 flop per pass
-// (K = 128: as much as the SYRK).  Kernel 13C (K <= 128) and kernel 13B (K > 128) below; kernel 13 (left-looking, round 2)
+// (K = 128: as much as the SYRK).  Kernel 13C (K <= 128; 129 ... 144 columns from 32 768 rows on) and kernel 13B (K > 128) below; kernel 13 (left-looking, round 2)
 // and kernel 13A (one wave per SIMD with the whole 64 x K tile, rounds 3-4) are gone -- profiles/r04_trsm_13a_vs_13b.txt,
 // r05_bench_kernel_stats.csv hold their numbers.
 #include <cstdlib>
@@ -50,7 +50,7 @@ __device__ unsigned long long fsnap_trsm_trace[8192 * 16];
 #define FSNAP_TRSM_STAMP(i)
 #endif
 
-// Kernel 13C (round 5; K <= 128): kernel 13A's pass with TWO waves per SIMD.  Kernel 13A keeps a wave's whole 64 x K tile in
+// Kernel 13C (round 5; K <= 128, round 6: K <= 144): kernel 13A's pass with TWO waves per SIMD.  Kernel 13A keeps a wave's whole 64 x K tile in
 // the accumulation registers -- one wave per SIMD, and of the 48 us a tile takes only 12 are matrix pipe and 13 the VALU
 // substitution: the rest are LDS hand-overs, the staging of R and the tile load with nothing else on the SIMD to run
 // (profiles/r04_trsm_13a_vs_13b.txt).  Here a wave holds a 64 x 64 PANEL of its rows (128 accumulation registers), so two
@@ -660,7 +660,10 @@ hipError_t launch_trsm_rows(const double* src, int64_t lds, const double* wpack,
     // 96 0.517 / 0.383, 64 0.249 / 0.201, 31 0.135 / 0.108; first pass 128 0.765 / 0.709, 110 0.690 / 0.701, 96 0.546 / 0.479
     // Round 6 (unguarded loads / stores of tiles inside the matrix, B operands of a left-looking block row at once): in place 128
     // 0.524, 110 0.52 ... 0.53, 96 0.385; first pass 128 0.54 ... 0.55, 96 0.38 ... 0.40 (profiles/r06_trsm_trace.txt)
-    if (K16 <= 128) {
+    // Nine blocks (129 ... 144 columns: the ACE width 142 of examples/Ta_PACE_RIDGE) since round 6, from 32 768 rows on: 10^6 x 142
+    // 1.31 -> 0.86 ms in place, 1.45 -> 0.92 ms first pass, 10^6 x 144 1.31 -> 0.70 ms (rows of 142 doubles straddle the 128-byte
+    // lines); a short system has too few 64-row tiles for one wave each (13 035 x 142: 0.047 against kernel 13B's 0.032 ms)
+    if (K16 <= 128 || (K16 == 144 && m >= 64 * 512)) {
         const dim3 grid((unsigned)nb), block(64);
 #define FSNAP_TRSM_ACC2(NBV)                                                                                                 \
     case NBV:                                                                                                                \
@@ -669,7 +672,7 @@ hipError_t launch_trsm_rows(const double* src, int64_t lds, const double* wpack,
         break;
         switch (K16 / 16) {
             FSNAP_TRSM_ACC2(1) FSNAP_TRSM_ACC2(2) FSNAP_TRSM_ACC2(3) FSNAP_TRSM_ACC2(4)
-            FSNAP_TRSM_ACC2(5) FSNAP_TRSM_ACC2(6) FSNAP_TRSM_ACC2(7) FSNAP_TRSM_ACC2(8)
+            FSNAP_TRSM_ACC2(5) FSNAP_TRSM_ACC2(6) FSNAP_TRSM_ACC2(7) FSNAP_TRSM_ACC2(8) FSNAP_TRSM_ACC2(9)
             default: return hipErrorInvalidValue;
         }
 #undef FSNAP_TRSM_ACC2

@@ -171,3 +171,24 @@ def test_short_kernel_row_space_solve_of_an_ill_conditioned_short_system(ctx):
     assert rank == K
     ref = orc.svd_fit(A, b, w)
     assert maxrel(beta, ref) < max(1e-6, 50 * 1e9 * 2.2e-16)
+
+
+def test_row_space_solve_at_the_ace_width_on_the_two_wave_pass_kernel(ctx):
+    # 129 ... 144 columns from 32 768 rows on: the row-space passes run on kernel 13C with nine column blocks (three 64-column
+    # panels, the last one a single block) instead of kernel 13B -- first pass (weighted rows of A) and in-place passes; the
+    # statistics of Q on kernel 1S (pairs from HBM, three phases per workgroup)
+    m, K = 40000, 142
+    rng = np.random.default_rng(23)
+    U, _ = np.linalg.qr(rng.standard_normal((m, K)))
+    V, _ = np.linalg.qr(rng.standard_normal((K, K)))
+    sv = np.logspace(0, -8, K)
+    A = (U * sv) @ V.T
+    b = A @ rng.standard_normal(K) + 1e-6 * rng.standard_normal(m)
+    w = rng.uniform(0.5, 2.0, m)
+    w[rng.random(m) < 0.05] = 0.0                     # zero-weight rows become zero rows of Q
+    ctx.upload_rows(A, b)
+    ctx.set_weights(w)
+    beta, rank, info = ctx.lstsq_rows(1e-13)
+    assert rank == K and info["passes"] >= 2
+    kappa = np.linalg.cond(w[:, None] * A)            # (the weights stretch the 1e9 of the unweighted rows)
+    assert maxrel(beta, orc.svd_fit(A, b, w)) < max(1e-6, 50 * kappa * 2.2e-16)
